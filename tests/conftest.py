@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    import numpy as np
+    here = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(here, "cases.json")) as f:
+        cases = json.load(f)
+    arr = np.load(os.path.join(here, "cases.npz"))
+    return cases, arr

@@ -1,0 +1,177 @@
+"""Pins the CPU oracle (oracle/sigkern_oracle.py).
+
+The reference holds no golden vectors; its only check is notebooks/signature_kernel.ipynb, three
+identities against esig signature features on unseeded data (cells 6-29).  These tests re-run those
+identities at the notebook's own shapes with an independent truncated-signature routine standing in
+for esig, then pin the order-1 recursion by brute force, then check the committed fixtures are what
+the oracle produces."""
+import numpy as np
+import pytest
+
+from oracle import sigkern_oracle as O
+
+
+def _relerr(a, b):
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-300)
+
+
+@pytest.fixture(scope="module")
+def notebook_data():
+    rng = np.random.default_rng(4)
+    M, N, L, d, T = 5, 100, 50, 3, 100         # notebook cells 4 and 15
+    X = rng.standard_normal((N, L, d))
+    Z = rng.standard_normal((M * (M + 1) // 2, T, d))
+    sigs = np.stack([O.truncated_signature(x, M) for x in X])       # cell 6 (esig.tosig.stream2sig)
+    tens = O.rank1_tensor_features(Z, M)                            # cell 18
+    kern = O.SignatureKernelOracle(L * d, d, M, base="linear", order=M, normalization=False)  # cell 11
+    return X.reshape(N, -1), Z, sigs, tens, kern
+
+
+def test_notebook_identity_seq_vs_seq(notebook_data):
+    X, Z, sigs, tens, kern = notebook_data
+    K = kern.compute_K_symm(X)                                      # cell 11
+    K_sig = sigs @ sigs.T                                           # cell 8
+    # the notebook reports Fro-norm 1.1e-8 on entries of size ~1e7 (cell 13)
+    assert _relerr(K, K_sig) < 1e-12
+
+
+def test_notebook_identity_levels(notebook_data):
+    X, Z, sigs, tens, kern = notebook_data
+    Kl = kern.K(X, return_levels=True)
+    for m, sl in enumerate(O.signature_level_slices(3, 5)):
+        assert _relerr(Kl[m], sigs[:, sl] @ sigs[:, sl].T) < 1e-12
+
+
+def test_notebook_identity_tens_vs_seq(notebook_data):
+    X, Z, sigs, tens, kern = notebook_data
+    assert _relerr(kern.compute_K_tens_vs_seq(Z, X), tens @ sigs.T) < 1e-12   # cells 19-23
+
+
+def test_notebook_identity_tens_vs_tens(notebook_data):
+    X, Z, sigs, tens, kern = notebook_data
+    assert _relerr(kern.compute_K_tens(Z), tens @ tens.T) < 1e-12             # cells 25-29
+
+
+def test_baseline_config1_identity():
+    """BASELINE.json configs[0]: N=64, L=32, d=3, num_levels=4, order=num_levels."""
+    rng = np.random.default_rng(0)
+    N, L, d, M = 64, 32, 3, 4
+    X = rng.standard_normal((N, L, d))
+    sigs = np.stack([O.truncated_signature(x, M) for x in X])
+    kern = O.SignatureKernelOracle(L * d, d, M, base="linear", order=M, normalization=False)
+    assert _relerr(kern.K(X.reshape(N, -1)), sigs @ sigs.T) < 1e-12
+
+
+def test_first_order_is_strictly_increasing_tuple_sum():
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((3, 6, 2))
+    Y = rng.standard_normal((2, 5, 2))
+    kern = O.SignatureKernelOracle(12, 2, 3, base="linear", order=1, normalization=False)
+    Kl = kern.K(X.reshape(3, -1), Y.reshape(2, -1), return_levels=True)
+    dx, dy = np.diff(X, axis=1), np.diff(Y, axis=1)
+    for i in range(3):
+        for j in range(2):
+            np.testing.assert_allclose(Kl[:, i, j], O.brute_force_first_order(dx[i] @ dy[j].T, 3), rtol=1e-12, atol=1e-13)
+
+
+def test_higher_order_interpolates_between_first_order_and_signature():
+    rng = np.random.default_rng(2)
+    N, L, d, M = 5, 8, 2, 4
+    X = rng.standard_normal((N, L, d)).reshape(N, -1)
+    K = {o: O.SignatureKernelOracle(L * d, d, M, base="linear", order=o, normalization=False).K(X, return_levels=True)
+         for o in (1, 2, 3, 4)}
+    # levels <= order are exact signature levels; levels 0,1 agree for every order
+    for o in (1, 2, 3):
+        np.testing.assert_allclose(K[o][:o + 1], K[4][:o + 1], rtol=1e-11, atol=1e-12)
+        assert _relerr(K[o][o + 1], K[4][o + 1]) > 1e-6
+    # order clamp: order<=0 or >=M means M (kernels.py:57)
+    assert O.SignatureKernelOracle(L * d, d, M, order=-1).order == M
+    assert O.SignatureKernelOracle(L * d, d, M, order=7).order == M
+
+
+def test_tens_vs_seq_higher_order_identity():
+    rng = np.random.default_rng(3)
+    N, L, d, M, T = 6, 9, 3, 4, 5
+    X = rng.standard_normal((N, L, d))
+    Z = rng.standard_normal((M * (M + 1) // 2, T, d))
+    sigs = np.stack([O.truncated_signature(x, M) for x in X])
+    tens = O.rank1_tensor_features(Z, M)
+    kern = O.SignatureKernelOracle(L * d, d, M, base="linear", order=M, normalization=False)
+    assert _relerr(kern.K_tens_vs_seq(Z, X.reshape(N, -1)), tens @ sigs.T) < 1e-12
+
+
+def test_normalisation_quirks():
+    """jitter goes on the diagonal before normalising; Kzz is never normalised."""
+    rng = np.random.default_rng(5)
+    N, L, d, M = 7, 6, 2, 3
+    X = rng.standard_normal((N, L, d)).reshape(N, -1)
+    kern = O.SignatureKernelOracle(L * d, d, M, base="rbf", normalization=True)
+    Kl = kern.K(X, return_levels=True)
+    np.testing.assert_allclose(np.diagonal(Kl, axis1=1, axis2=2), 1.0, rtol=1e-14)
+    off = Kl[0][~np.eye(N, dtype=bool)]
+    np.testing.assert_allclose(off, 1.0 / (1.0 + 1e-6), rtol=1e-14)          # level 0 off-diagonal
+    np.testing.assert_allclose(kern.K(X, X, return_levels=True)[0], 1.0 / (1.0 + 1e-6), rtol=1e-14)
+    np.testing.assert_allclose(kern.Kdiag(X), np.full(N, M + 1.0))
+    Z = rng.standard_normal((M * (M + 1) // 2, 4, d))
+    kern_nn = O.SignatureKernelOracle(L * d, d, M, base="rbf", normalization=False)
+    np.testing.assert_allclose(kern.K_tens(Z), kern_nn.K_tens(Z))
+
+
+def test_symmetric_equals_cross_without_normalisation():
+    rng = np.random.default_rng(6)
+    N, L, d, M = 6, 7, 3, 4
+    X = rng.standard_normal((N, L, d)).reshape(N, -1)
+    for base in O.BASE_KERNELS:
+        kern = O.SignatureKernelOracle(L * d, d, M, base=base, normalization=False)
+        np.testing.assert_allclose(kern.K(X), kern.K(X, X), rtol=1e-12, atol=1e-12)
+        Kd = kern.Kdiag(X, return_levels=True)
+        np.testing.assert_allclose(Kd, np.diagonal(kern.K(X, return_levels=True), axis1=1, axis2=2), rtol=1e-10, atol=1e-12)
+
+
+def test_constructor_validation():
+    with pytest.raises(ValueError):
+        O.SignatureKernelOracle(10, 3, 2)
+    with pytest.raises(ValueError):
+        O.SignatureKernelOracle(9, 3, 2, num_lags=-1)
+    with pytest.raises(ValueError):
+        O.SignatureKernelOracle(9, 3, 2, num_lags=1.5)
+
+
+def test_lags_shapes_and_zero_lag_limit():
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((3, 9, 2))
+    out = O.add_lags_to_sequences(X, np.array([0.125, 0.25]))
+    assert out.shape == (3, 9, 3, 2)
+    np.testing.assert_allclose(out[:, :, 0], X)
+    # a lag of exactly one grid step (1/(L-1)) reproduces the sequence shifted by one, first value held
+    np.testing.assert_allclose(out[:, 1:, 1], X[:, :-1], atol=1e-12)
+    np.testing.assert_allclose(out[:, 0, 1], X[:, 0], atol=1e-12)
+
+
+def test_committed_fixtures_match_oracle(golden):
+    """The committed vectors are exactly what tests/golden/make_golden.py produces from the oracle."""
+    cases, arr = golden
+    names = {c["name"] for c in cases}
+    assert {"nb_K", "nb_Kzx", "nb_Kzz", "c1_o1_n1", "c1_o4_n0"} <= names
+    for c in cases:
+        if c["method"] not in ("K", "K_tens", "K_tens_vs_seq"):
+            continue
+        kern = O.SignatureKernelOracle(**{k: (np.asarray(v) if isinstance(v, list) else v) for k, v in c["kern"].items()})
+        n = c["name"]
+        if c["method"] == "K":
+            out = kern.K(arr[n + "/X"], arr[n + "/X2"] if "X2" in c["has"] else None, **c["call"])
+        elif c["method"] == "K_tens":
+            out = kern.K_tens(arr[n + "/Z"], **c["call"])
+        else:
+            out = kern.K_tens_vs_seq(arr[n + "/Z"], arr[n + "/X"], **c["call"])
+        np.testing.assert_allclose(out, arr[n + "/out0"], rtol=1e-12, atol=1e-12, err_msg=n)
+
+
+def test_fixture_notebook_cases_satisfy_signature_identity(golden):
+    cases, arr = golden
+    X = arr["nb_K/X"].reshape(40, 50, 3)
+    sigs = np.stack([O.truncated_signature(x, 5) for x in X])
+    tens = O.rank1_tensor_features(arr["nb_Kzx/Z"], 5)
+    assert _relerr(arr["nb_K/out0"], sigs @ sigs.T) < 1e-12
+    assert _relerr(arr["nb_Kzx/out0"], tens @ sigs.T) < 1e-12
+    assert _relerr(arr["nb_Kzz/out0"], tens @ tens.T) < 1e-12
