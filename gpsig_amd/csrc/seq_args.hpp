@@ -1,0 +1,129 @@
+// seq_args.hpp -- launch arguments of the seq-gram kernel, task list construction and the pair
+// epilogue.  HIP-free: shared by the gfx950 kernel, the host API and the CPU lock-step emulator
+// used by the test-suite.
+#pragma once
+
+#include <stdint.h>
+#include <vector>
+
+#include "seq_core.hpp"
+
+namespace gpsig {
+
+struct SeqTask {
+    int32_t y0;   // first y-side sequence of the block
+    int32_t x0;   // first x-side sequence of the run
+    int32_t nx;   // run length
+};
+
+enum : int { PRED_ALL = 0, PRED_CIRCULANT = 1, PRED_DIAG = 2 };
+
+struct SeqGramArgs {
+    const void* xrec;       // x-side records: N1 x rec_stride elements
+    const void* yrec;       // y-side records: N2 x rec_stride_y elements
+    const SeqTask* tasks;
+    int64_t N1, N2;
+    int64_t xrec_stride, yrec_stride;  // elements between consecutive sequences' records
+    int32_t R1, R2;         // record rows per sequence on each side
+    int32_t RS;             // elements between consecutive record rows (D + pad)
+    int32_t M;
+    int32_t nslot;          // LDS ring depth
+    int32_t slot_elems;     // elements per ring slot (>= R1*RS, multiple of 128 so a slot is whole 1 KiB DMA pieces for fp64)
+    int32_t kind;           // base kernel (point modes)
+    double p0, p1;
+    // epilogue:  v_m = (K_m + [i==j] * jitter_diag) * ax[m][i] * by[m][j],  m = 0..M  (K_0 = 1)
+    void* out;
+    int64_t si, sj, sm;     // element strides of the x index, y index, level index in `out`
+    const void* ax;         // (N1, M+1) sequence-major, or NULL (== 1)
+    const void* by;         // (N2, M+1) sequence-major, or NULL (== 1)
+    double jitter_diag;
+    int32_t sum_levels;     // 1: out[i*si + j*sj] = sum_m v_m ; 0: out[m*sm + i*si + j*sj] = v_m
+    int32_t pred;           // PRED_*
+    int32_t mirror;         // also store at (j, i)
+    int32_t use_glds;       // stage x records with global_load_lds (LDS DMA) instead of load + ds_write
+};
+
+
+// Pair epilogue (gpsig/kernels.py:430-433 / :463-469 normalisation, :471 sigma*variances, :473-476
+// level sum), applied to the finished pair held by lane state L.  `store(offset, value)` writes one
+// element of `out`.
+template <typename T, class Lane, class Store>
+GPSIG_HD void seq_emit(const Lane& L, const SeqGramArgs& A, int64_t i, int64_t j, int M, Store store) {
+    bool emit = true;
+    if (A.pred == PRED_CIRCULANT) {
+        const int64_t N = A.N1, H = N / 2;
+        int64_t dlt = j - i;
+        if (dlt < 0) dlt += N;
+        emit = dlt < H || (dlt == H && ((N & 1) || i < j));
+    } else if (A.pred == PRED_DIAG) {
+        emit = (i == j);
+    }
+    if (!emit) return;
+    const T* ax = A.ax ? static_cast<const T*>(A.ax) + i * (M + 1) : nullptr;
+    const T* by = A.by ? static_cast<const T*>(A.by) + j * (M + 1) : nullptr;
+    const T dj = (i == j) ? T(A.jitter_diag) : T(0);
+    int64_t o1 = i * A.si + j * A.sj, o2 = j * A.si + i * A.sj;
+    const bool mir = A.mirror && i != j;
+    T acc = T(0);
+    for (int m = 0; m <= M; ++m) {
+        T v = (m == 0 ? T(1) : L.level_value(m, M)) + dj;
+        if (ax) v *= ax[m];
+        if (by) v *= by[m];
+        if (A.sum_levels) {
+            acc += v;
+        } else {
+            store(o1, v);
+            if (mir) store(o2, v);
+            o1 += A.sm;
+            o2 += A.sm;
+        }
+    }
+    if (A.sum_levels) {
+        store(o1, acc);
+        if (mir) store(o2, acc);
+    }
+}
+
+// ---- host-side planning ----------------------------------------------------------------------
+struct SeqPlan {
+    int ypb;     // y sequences per task block = 64 / G
+    int nslot;   // LDS ring depth: the slot refilled when lane 0 starts x number k must no longer be read
+                 // by lane G-1, which is still G-1 steps behind:  (nslot - 2) * R1 >= G - 1
+};
+inline int seq_ring_depth(int G, int R1) { return 2 + (G - 1 + R1 - 1) / R1; }
+
+// Task list.  pred == PRED_ALL: every (x, y) pair of an N1 x N2 cross Gram.  PRED_CIRCULANT (N1 == N2,
+// same sequences): each unordered pair once -- y block [y0, y0+ypb) against the x window
+// [y0 - N/2, y0 + ypb) taken modulo N, so every block has the same amount of work.  PRED_DIAG: the
+// block-diagonal only.  Runs are cut into pieces of at most `max_run` x's; shard (index, count)
+// keeps every count-th task (tasks are independent).
+inline std::vector<SeqTask> seq_build_tasks(int64_t N1, int64_t N2, int ypb, int pred, int max_run,
+                                            int shard_index, int shard_count) {
+    std::vector<SeqTask> t;
+    int64_t counter = 0;
+    auto push = [&](int64_t y0, int64_t x0, int64_t nx) {
+        for (int64_t o = 0; o < nx; o += max_run) {
+            int64_t n = nx - o < max_run ? nx - o : max_run;
+            int64_t xs = x0 + o;
+            if (pred == PRED_CIRCULANT) xs %= N1;
+            if ((counter++ % shard_count) == shard_index) t.push_back(SeqTask{int32_t(y0), int32_t(xs), int32_t(n)});
+        }
+    };
+    for (int64_t y0 = 0; y0 < N2; y0 += ypb) {
+        if (pred == PRED_ALL) {
+            push(y0, 0, N1);
+        } else if (pred == PRED_DIAG) {
+            int64_t hi = y0 + ypb < N1 ? y0 + ypb : N1;
+            if (y0 < hi) push(y0, y0, hi - y0);
+        } else {
+            const int64_t N = N1, H = N / 2;
+            int64_t nx = H + ypb;
+            if (nx > N) nx = N;
+            int64_t x0 = ((y0 - H) % N + N) % N;
+            push(y0, x0, nx);
+        }
+    }
+    return t;
+}
+
+}  // namespace gpsig

@@ -1,0 +1,232 @@
+// seq_core.hpp -- per-lane arithmetic of the sequence-vs-sequence signature-kernel recursion.
+//
+// Shared, verbatim, by the gfx950 kernel (seq_gram_kernel.hpp) and by the host-side lock-step wave
+// emulator that the CPU test-suite runs (tests/emu/).  Nothing here touches memory spaces or lanes:
+// cross-lane inputs arrive in NbrIn, the x-side row arrives as a register array.
+//
+// What it computes (first-order algorithm, gpsig/signature_algs.py:8-35).  For one pair (x, y) with
+// increment lattice dM[a][b] (signature_algs.py:26) the reference evaluates, level by level over the
+// whole lattice,  R_1 = dM,  R_m = dM * excumsum_b(excumsum_a(R_{m-1})),  K_m = sum R_m.
+// Here the same numbers come from ONE sweep over lattice rows a that carries, per level m, the
+// inclusive 2-D prefix  Q_m[a][b] = sum_{a'<=a, b'<=b} R_m[a'][b']  of the previous row only:
+//     s_m[a][b] = s_m[a][b-1] + dM[a][b] * Q_{m-1}[a-1][b-1]      (row prefix of R_m;  Q_0 == 1)
+//     Q_m[a][b] = Q_m[a-1][b] + s_m[a][b]
+//     K_m       = Q_m[last][last]
+// i.e. two fp64 instructions per lattice cell and level (one FMA, one add) instead of the
+// reference's five full-lattice passes, with O(M * L2) state instead of O(L1 * L2).
+//
+// Lane mapping.  A pair occupies G consecutive lanes; lane `lam` owns C consecutive lattice columns
+// (record rows C*lam .. C*lam+C-1 of the y side).  Row prefixes cross lanes through a carry that is
+// handed to the next lane ONE STEP LATER (lane lam works on lattice row t-lam at step t), so no
+// log-step scan is needed: each step a lane reads its left neighbour's end-of-chunk row prefix
+// (`cin`) and its left neighbour's last-column Q from before that neighbour's latest update (`din`).
+#pragma once
+
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define GPSIG_HD __host__ __device__ __forceinline__
+#else
+#define GPSIG_HD inline
+#endif
+
+namespace gpsig {
+
+// values equal enum gpsig_base_kernel in include/gpsig_hip.h
+enum : int { BASE_LINEAR = 0, BASE_RBF = 1, BASE_COSINE = 2, BASE_POLY = 3, BASE_MIX = 4,
+             BASE_MATERN12 = 5, BASE_MATERN32 = 6, BASE_MATERN52 = 7 };
+
+// how dM is produced
+enum : int {
+    MODE_INC = 0,      // dM[a][b] = <xrow_a, yrow_b>      (linear base kernel: rows are increments, or points if difference=False)
+    MODE_PT_DIFF = 1,  // dM = double increment of kappa(x_a, y_b) over point rows (signature_algs.py:26)
+    MODE_PT_NODIFF = 2 // dM[a][b] = kappa(x_a, y_b)        (difference=False, non-linear base kernel)
+};
+
+// Static kernel on R^d from the inner product and the two squared norms (gpsig/kernels.py:765-781, 799-993).
+template <typename T>
+GPSIG_HD T base_eval(int kind, T inner, T xs, T ys, T p0, T p1) {
+    switch (kind) {
+        case BASE_LINEAR: return inner;                                            // :799-806
+        case BASE_COSINE: return inner / (sqrt(xs) * sqrt(ys));                     // :820-828
+        case BASE_POLY: return pow(inner + p0, p1);                                 // :844-848
+        default: break;
+    }
+    const T dist = fma(T(-2), inner, xs + ys);                                      // _square_dist :765-776
+    if (kind == BASE_RBF) return exp(-dist / 2);                                    // :862-864
+    if (kind == BASE_MIX) return p0 * exp(-dist / 2) + (T(1) - p0) * inner;         // :881-892
+    const T r = sqrt(fmax(dist, T(1e-40)));                                         // _euclid_dist :779-781
+    if (kind == BASE_MATERN12) return exp(-r);                                      // :955-958
+    if (kind == BASE_MATERN32) {                                                    // :974-977
+        const T c = T(1.7320508075688772935);
+        return (T(1) + c * r) * exp(-c * r);
+    }
+    const T c = T(2.2360679774997896964);                                           // :991-993
+    return (T(1) + c * r + T(5.0 / 3.0) * (r * r)) * exp(-c * r);
+}
+
+template <typename T, int C, int D, int MMAX, int MODE>
+struct SeqLane {
+    static constexpr int NQ = MMAX > 1 ? MMAX - 1 : 1;
+    T y[C][D];      // y-side record rows owned by this lane (increments, or points)
+    T q[NQ][C];     // Q_m for levels m = 1 .. M-1 (index m-1), current as of the last processed row
+    T qold[NQ];     // Q_m[.., last column of the chunk] from BEFORE the last processed row
+    T s[MMAX];      // end-of-chunk row prefix of R_m for the last processed row (the carry handed right)
+    T ktop;         // running K_M (only the row totals of the top level are needed)
+    // point modes only
+    T y2[C];        // |y|^2 per owned column
+    T kprev[C];     // kappa(previous x point, owned y columns)
+    T kleft;        // kappa(previous x point, last column of the left neighbour)
+
+    GPSIG_HD void reset() {
+#pragma unroll
+        for (int m = 0; m < NQ; ++m) {
+#pragma unroll
+            for (int r = 0; r < C; ++r) q[m][r] = T(0);
+            qold[m] = T(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m) s[m] = T(0);
+        ktop = T(0);
+    }
+    GPSIG_HD void init() {
+        reset();
+#pragma unroll
+        for (int r = 0; r < C; ++r) { kprev[r] = T(0); y2[r] = T(0); }
+        kleft = T(0);
+    }
+    // K_m for m = 1..M as seen by the LAST lane of the pair's group
+    GPSIG_HD T level_value(int m, int M) const {
+        T v = ktop;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+            if (k == m - 1 && m < M) v = q[k][C - 1];
+        return v;
+    }
+};
+
+// Cross-lane inputs are fetched through a policy object `Nbr` with three members, each returning the
+// LEFT neighbour's copy of one of this lane's own state words as of the end of the previous step:
+//     T cin(int m)      left neighbour's s[m]
+//     T din(int m)      left neighbour's qold[m]
+//     T kleft()         left neighbour's kprev[C-1]      (MODE_PT_DIFF)
+// (zero for the first lane of a pair group).  On the GPU they are DPP row/wave shifts issued right
+// where the value is consumed -- legal because s[m] / qold[m] / kprev are only overwritten later in
+// the same step -- which keeps the 2M+1 shifted words out of the live register set.  The CPU
+// emulator serves them from a snapshot (NbrSnapshot) taken before any lane of the wave has stepped.
+template <typename T, int MMAX>
+struct NbrSnapshot {
+    static constexpr int NQ = MMAX > 1 ? MMAX - 1 : 1;
+    T s[MMAX];
+    T qold[NQ];
+    T klast;
+    GPSIG_HD T cin(int m) const { return s[m]; }
+    GPSIG_HD T din(int m) const { return qold[m]; }
+    GPSIG_HD T kleft() const { return klast; }
+};
+
+namespace detail {
+template <int MI, typename T, int C, int D, int MMAX, int MODE, class Nbr>
+GPSIG_HD void seq_level(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&dm)[C], int M) {
+    if (MI < M) {                       // wave-uniform (compile-time when M is)
+        T sm = nbr.cin(MI);
+        if (MI == M - 1) {              // top level: accumulate the row total only
+            if constexpr (MI == 0) {
+#pragma unroll
+                for (int r = 0; r < C; ++r) sm += dm[r];
+            } else {
+                sm = fma(dm[0], nbr.din(MI - 1), sm);
+#pragma unroll
+                for (int r = 1; r < C; ++r) sm = fma(dm[r], L.q[MI - 1][r - 1], sm);
+            }
+            L.ktop += sm;
+        } else if constexpr (MI < MMAX - 1) {
+            const T last = L.q[MI][C - 1];
+            if constexpr (MI == 0) {
+#pragma unroll
+                for (int r = 0; r < C; ++r) { sm += dm[r]; L.q[0][r] += sm; }
+            } else {
+                sm = fma(dm[0], nbr.din(MI - 1), sm);
+                L.q[MI][0] += sm;
+#pragma unroll
+                for (int r = 1; r < C; ++r) { sm = fma(dm[r], L.q[MI - 1][r - 1], sm); L.q[MI][r] += sm; }
+            }
+            L.qold[MI] = last;
+        }
+        L.s[MI] = sm;
+    }
+    if constexpr (MI > 0) seq_level<MI - 1>(L, nbr, dm, M);   // descending: level m+1 reads Q_m before level m updates it
+}
+}  // namespace detail
+
+// One lattice row for one lane, given dM for the lane's C columns.
+template <typename T, int C, int D, int MMAX, int MODE, class Nbr>
+GPSIG_HD void seq_recursion(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&dm)[C], int M) {
+    detail::seq_level<MMAX - 1>(L, nbr, dm, M);
+}
+
+// Full step.  xr: the x-side record row for this step.  dummy: this step is not a lattice row of the
+// current pair (pair boundary / lane outside its active window): contributes nothing.
+// [rlo, rhi): owned columns that are real lattice columns (point modes; MODE_INC relies on zero rows).
+template <typename T, int C, int D, int MMAX, int MODE, class Nbr>
+GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&xr)[D], int M,
+                       bool dummy, int rlo, int rhi, int kind, T p0, T p1) {
+    T dm[C];
+    if constexpr (MODE == MODE_INC) {
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            T acc = xr[0] * L.y[r][0];
+#pragma unroll
+            for (int f = 1; f < D; ++f) acc = fma(xr[f], L.y[r][f], acc);
+            dm[r] = acc;
+        }
+    } else {
+        T xs = xr[0] * xr[0];
+#pragma unroll
+        for (int f = 1; f < D; ++f) xs = fma(xr[f], xr[f], xs);
+        T knew[C];
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            T acc = xr[0] * L.y[r][0];
+#pragma unroll
+            for (int f = 1; f < D; ++f) acc = fma(xr[f], L.y[r][f], acc);
+            knew[r] = base_eval<T>(kind, acc, xs, L.y2[r], p0, p1);
+        }
+        if constexpr (MODE == MODE_PT_DIFF) {
+            const T kleft_new = nbr.kleft();
+            dm[0] = (knew[0] - kleft_new) - (L.kprev[0] - L.kleft);
+#pragma unroll
+            for (int r = 1; r < C; ++r) dm[r] = (knew[r] - knew[r - 1]) - (L.kprev[r] - L.kprev[r - 1]);
+#pragma unroll
+            for (int r = 0; r < C; ++r) L.kprev[r] = knew[r];
+            L.kleft = kleft_new;
+        } else {
+#pragma unroll
+            for (int r = 0; r < C; ++r) dm[r] = knew[r];
+        }
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+            if (dummy || r < rlo || r >= rhi) dm[r] = T(0);
+    }
+    seq_recursion(L, nbr, dm, M);
+}
+
+// Per-lane position in the stream of x-side record rows.  Lane `lam` of a group starts `lam` steps late.
+struct LaneCtl {
+    int n;     // steps since this lane became active (negative: not yet)
+    int a;     // record row within the current x            (0 .. R1-1)
+    int p;     // index of the current x within the task      (0 .. nx; == nx: flush step)
+    int slot;  // LDS ring slot of the current x
+    GPSIG_HD void init(int lam) { n = -lam; a = 0; p = 0; slot = 0; }
+    GPSIG_HD bool active(int nx) const { return n >= 0 && p < nx; }
+    // the step at which the lane sits on row 0 of x number p>=1 (or on the flush step) emits pair p-1
+    GPSIG_HD bool boundary() const { return n >= 0 && a == 0; }
+    GPSIG_HD void advance(int R1, int nslot) {
+        if (n >= 0) {
+            if (++a == R1) { a = 0; ++p; if (++slot == nslot) slot = 0; }
+        }
+        ++n;
+    }
+};
+
+}  // namespace gpsig

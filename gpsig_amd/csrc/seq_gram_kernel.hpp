@@ -1,0 +1,174 @@
+// seq_gram_kernel.hpp -- gfx950 kernel for the sequence-vs-sequence signature-kernel Gram
+// (SignatureKernel._K_seq / _K_seq_diag + the normalise / weight / level-sum epilogue of
+// SignatureKernel.K, gpsig/kernels.py:188-237 and :430-476).
+//
+// One 64-lane workgroup (= one wavefront) per task.  A task is a block of 64/G y-side sequences held
+// in registers (each pair group of G lanes owns one y; lane lam owns C consecutive lattice columns)
+// against a run of x-side sequences streamed through a small LDS ring.  Lanes of a group run the
+// lattice-row recursion of seq_core.hpp skewed by one step per lane, so the only cross-lane traffic
+// is one DPP shift (row_shr:1 / wave_shr:1) of M carries + (M-1) diagonal terms per step, and pairs
+// follow each other without draining the pipeline.  Levels are normalised, weighted and summed in
+// registers at each pair boundary; one 8-byte store (two with the mirror) leaves the chip per pair.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "seq_args.hpp"
+#include "seq_core.hpp"
+
+namespace gpsig {
+
+template <int G>
+__device__ __forceinline__ int dpp_shr1_i32(int v) {
+    // lane l receives lane l-1's value; the first lane of each group of G receives 0
+    if constexpr (G == 16) return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    else return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);                      // wave_shr:1
+}
+template <int G>
+__device__ __forceinline__ double shr1(double v) {
+    int lo = dpp_shr1_i32<G>(__double2loint(v)), hi = dpp_shr1_i32<G>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <int G>
+__device__ __forceinline__ float shr1(float v) {
+    return __int_as_float(dpp_shr1_i32<G>(__float_as_int(v)));
+}
+
+// EXACT: num_levels == MMAX is a compile-time constant (no level branches in the step);
+// otherwise any num_levels <= MMAX is accepted at run time.
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT>
+__global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
+    static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
+    static_assert((D * sizeof(T)) % 16 == 0, "record rows are read with 16-byte LDS loads");
+    using Lane = SeqLane<T, C, D, MMAX, MODE>;
+    constexpr int VEC = 16 / sizeof(T);                  // elements per 16-byte piece
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* const zero_row = reinterpret_cast<T*>(smem_raw);   // RS elements of zeros (rows of inactive lanes)
+    T* const ring = zero_row + A.RS;                       // nslot slots of slot_elems
+
+    const int lane = threadIdx.x;
+    const int lam = lane & (G - 1);
+    const int grp = lane / G;
+    const SeqTask tk = A.tasks[blockIdx.x];
+    const int M = EXACT ? MMAX : A.M;
+    const int R1 = A.R1, RS = A.RS, nslot = A.nslot, nx = tk.nx;
+    const T* const xrec = static_cast<const T*>(A.xrec);
+    const T* const yrec = static_cast<const T*>(A.yrec);
+
+    if (lane < RS) zero_row[lane] = T(0);
+
+    // ---- y side: this lane's C record rows of sequence j -------------------------------------
+    const int64_t j = int64_t(tk.y0) + grp;
+    const bool jvalid = j < A.N2;
+    Lane L;
+    L.init();
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+        const int row = C * lam + r;
+        const bool ok = jvalid && row < A.R2;
+        const T* src = yrec + (ok ? j * A.yrec_stride + int64_t(row) * RS : 0);
+        T ys = T(0);
+#pragma unroll
+        for (int f = 0; f < D; f += VEC) {
+            vecT v = ok ? *reinterpret_cast<const vecT*>(src + f) : vecT(T(0));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { L.y[r][f + e] = v[e]; ys = fma(v[e], v[e], ys); }
+        }
+        L.y2[r] = ys;
+    }
+    // real lattice columns among the owned ones (point modes; see seq_core.hpp)
+    const int rlo = (lam == 0) ? 1 : 0;
+    int rhi = A.R2 - C * lam;
+    rhi = rhi < 0 ? 0 : (rhi > C ? C : rhi);
+
+    // ---- x side staging ------------------------------------------------------------------------
+    auto stage = [&](int p, int slot) {   // copy the record of x number p of the run into ring slot `slot`
+        int64_t i = int64_t(tk.x0) + p;
+        if (i >= A.N1) i -= A.N1;                         // circulant runs wrap around
+        const T* src = xrec + i * A.xrec_stride;
+        T* dst = ring + int64_t(slot) * A.slot_elems;
+        const int pieces = A.slot_elems / VEC;            // multiple of 64
+        if (A.use_glds) {
+            for (int c = 0; c < pieces; c += 64)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + int64_t(c + lane) * VEC),
+                    (__attribute__((address_space(3))) void*)(dst + int64_t(c) * VEC), 16, 0, 0);
+        } else {
+            for (int c = lane; c < pieces; c += 64)
+                reinterpret_cast<vecT*>(dst)[c] = reinterpret_cast<const vecT*>(src)[c];
+        }
+    };
+    stage(0, 0);
+
+    LaneCtl ctl;
+    ctl.init(lam);
+    const T p0 = T(A.p0), p1 = T(A.p1);
+
+    // left-neighbour reads: one DPP shift per 32-bit half, issued where the value is consumed
+    struct DevNbr {
+        const Lane& L;
+        __device__ __forceinline__ T cin(int m) const { return shr1<G>(L.s[m]); }
+        __device__ __forceinline__ T din(int m) const { return shr1<G>(L.qold[m]); }
+        __device__ __forceinline__ T kleft() const { return shr1<G>(L.kprev[C - 1]); }
+    };
+
+    // Lane 0 of each group starts x number k at step k*R1: its record must be resident by then, and the
+    // next one is requested at that moment.  The ring depth chosen by the host (seq_ring_depth)
+    // guarantees the slot being refilled is no longer read by the slowest lane: (nslot-2)*R1 >= G-1.
+    // After the last x, G more steps let lane lam emit its last pair at step nx*R1 + lam.
+    const int nsteps = nx * R1 + G;
+    int a_u = 0, k_u = 0, slot_next = 1 % nslot;          // wave-uniform position of lane 0
+    for (int t = 0; t < nsteps; ++t) {
+        if (a_u == 0 && k_u < nx) {
+            if (A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (k_u + 1 < nx) {
+                stage(k_u + 1, slot_next);
+                if (++slot_next == nslot) slot_next = 0;
+            }
+        }
+        if (++a_u == R1) { a_u = 0; ++k_u; }
+
+        // pair boundary: the pair that just finished is complete in the last lane of the group
+        if (ctl.boundary()) {
+            if (lam == G - 1 && ctl.p >= 1 && ctl.p <= nx && jvalid) {
+                int64_t i = int64_t(tk.x0) + (ctl.p - 1);
+                if (i >= A.N1) i -= A.N1;
+                T* const out = static_cast<T*>(A.out);
+                seq_emit<T>(L, A, i, j, M, [&](int64_t off, T v) { out[off] = v; });
+            }
+            L.reset();
+        }
+
+        // this lane's x-side record row (16-byte LDS reads; rows are RS = D + pad apart, conflict-free)
+        const bool act = ctl.active(nx);
+        const T* rowp = act ? ring + int64_t(ctl.slot) * A.slot_elems + ctl.a * RS : zero_row;
+        T xr[D];
+#pragma unroll
+        for (int f = 0; f < D; f += VEC) {
+            vecT v = *reinterpret_cast<const vecT*>(rowp + f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) xr[f + e] = v[e];
+        }
+        const bool dummy = !act || ctl.a == 0;
+
+        seq_step(L, DevNbr{L}, xr, M, dummy, rlo, rhi, A.kind, p0, p1);
+        ctl.advance(R1, nslot);
+    }
+}
+
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT>
+hipError_t seq_gram_launch(const SeqGramArgs& A, int ntasks, size_t lds_bytes, hipStream_t stream) {
+    if (ntasks <= 0) return hipSuccess;
+    auto kern = seq_gram_kernel<T, G, C, D, MMAX, MODE, EXACT>;
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(ntasks), dim3(64), lds_bytes, stream, A);
+    return hipGetLastError();
+}
+
+}  // namespace gpsig

@@ -1,0 +1,133 @@
+/* gpsig_hip.h -- C ABI of libgpsig_hip.so: the MI355X (gfx950) signature-kernel evaluation path.
+ *
+ * The reference (tgcsaba/GPSig) is pure Python on TensorFlow 1.15 / GPflow 1.5.1 and has no native
+ * boundary of its own; the entry points below are what a GPflow-side binding for this path would
+ * call instead of building the TF graph.  Each one names the reference method it replaces
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - All arrays are row-major and contiguous.  Sequences are passed exactly as the reference's
+ *     numpy-facing wrappers take them: X is (N, L*d) viewed as (N, L, d) (gpsig/kernels.py:417-418),
+ *     Z is (lt, T, d) or (lt, T, 2, d) with lt = M(M+1)/2 (gpsig/inducing_variables.py:28-46).
+ *   - "levels" outputs have a leading axis of num_levels+1 (level 0 == 1, gpsig/signature_algs.py:20).
+ *   - Data pointers are host or device pointers according to gpsig_set_pointer_mode(); the
+ *     hyper-parameter arrays inside gpsig_params are always HOST pointers.
+ *   - Every function returns GPSIG_OK (0) or a negative error code; gpsig_last_error() gives text.
+ *   - Caller owns all inputs and outputs.  Scratch memory is owned by the ctx.  One ctx per
+ *     (device, stream); calls on different ctxs may run concurrently; a ctx is not re-entrant.
+ *   - In device-pointer mode calls are asynchronous on the ctx stream; in host-pointer mode they
+ *     return after the result has been copied back.
+ *   - There is no CPU fallback anywhere behind this ABI.
+ */
+#ifndef GPSIG_HIP_H
+#define GPSIG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPSIG_ABI_VERSION 1
+
+enum gpsig_status {
+    GPSIG_OK = 0,
+    GPSIG_ERR_INVALID = -1,      /* bad argument (the Python shim raises ValueError) */
+    GPSIG_ERR_UNSUPPORTED = -2,  /* valid in the reference, not built here yet (NotImplementedError) */
+    GPSIG_ERR_HIP = -3,          /* HIP runtime failure (RuntimeError) */
+    GPSIG_ERR_NOMEM = -4
+};
+
+/* static (state-space) kernels, gpsig/kernels.py:786-993 */
+enum gpsig_base_kernel {
+    GPSIG_BASE_LINEAR = 0,    /* SignatureLinear    _lin       :799-806 */
+    GPSIG_BASE_RBF = 1,       /* SignatureRBF/Gauss _rbf       :862-864 */
+    GPSIG_BASE_COSINE = 2,    /* SignatureCosine    _cos       :820-828 */
+    GPSIG_BASE_POLY = 3,      /* SignaturePoly      _poly      :844-848  base_params = {gamma, degree} */
+    GPSIG_BASE_MIX = 4,       /* SignatureMix       _mix       :881-892  base_params = {mixing} */
+    GPSIG_BASE_MATERN12 = 5,  /* SignatureMatern12/Laplace/Exponential :955-958 */
+    GPSIG_BASE_MATERN32 = 6,  /* SignatureMatern32  :974-977 */
+    GPSIG_BASE_MATERN52 = 7   /* SignatureMatern52  :991-993 */
+};
+
+enum gpsig_dtype { GPSIG_F64 = 0, GPSIG_F32 = 1 };
+enum gpsig_pointer_mode { GPSIG_PTR_HOST = 0, GPSIG_PTR_DEVICE = 1 };
+
+typedef struct gpsig_ctx gpsig_ctx;
+
+/* Constructor state of gpsig.kernels.SignatureKernel (gpsig/kernels.py:18-88), constrained values. */
+typedef struct gpsig_params {
+    int32_t base_kernel;     /* enum gpsig_base_kernel */
+    int32_t dtype;           /* enum gpsig_dtype: element type of every data pointer */
+    int32_t num_features;    /* d: state-space dimension of ONE lag copy (kernels.py:54) */
+    int32_t num_levels;      /* M (kernels.py:55) */
+    int32_t order;           /* 1..M, already clamped as kernels.py:57 does */
+    int32_t difference;      /* kernels.py:63 */
+    int32_t normalization;   /* kernels.py:62 */
+    int32_t num_lags;        /* kernels.py:70-82 */
+    double sigma;            /* kernels.py:66 */
+    double jitter;           /* gpflow.settings.jitter, 1e-6 (kernels.py:431,463,578) */
+    double base_params[4];
+    const double* variances;     /* host, M+1 entries (kernels.py:65) */
+    const double* lengthscales;  /* host, d entries, or NULL = no scaling (kernels.py:84-88) */
+    const double* lags;          /* host, num_lags entries (kernels.py:79), NULL if num_lags == 0 */
+    const double* gamma;         /* host, num_lags+1 entries (kernels.py:80-82), NULL if num_lags == 0 */
+} gpsig_params;
+
+/* ---- context ----------------------------------------------------------------------------- */
+int gpsig_abi_version(void);
+/* stream: a hipStream_t cast to void*, or NULL for the default stream */
+int gpsig_ctx_create(int device, void* stream, gpsig_ctx** out);
+void gpsig_ctx_destroy(gpsig_ctx* ctx);
+const char* gpsig_last_error(gpsig_ctx* ctx); /* ctx may be NULL: error of the last failed create */
+int gpsig_set_pointer_mode(gpsig_ctx* ctx, int mode);
+int gpsig_sync(gpsig_ctx* ctx);
+/* Restrict the following K / Kzx calls to shard `index` of `count` (independent pair blocks, no
+ * exchange).  Entries outside the shard are left untouched in the output.  (0, 1) = everything. */
+int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
+/* HIP-event timing of the dominant kernel (the pair recursion) launched by the calls since the last
+ * reset, measured on the ctx stream: total milliseconds and number of launches. */
+int gpsig_timing_reset(gpsig_ctx* ctx);
+int gpsig_timing_get(gpsig_ctx* ctx, double* kernel_ms, int64_t* launches, int64_t* pairs);
+
+/* ---- unnormalised level tensors (the signature_algs.py layer) ----------------------------- */
+/* SignatureKernel._K_seq (kernels.py:208-237) -> signature_kern_first_order / _higher_order
+ * (signature_algs.py:8-74) on the base-kernel tensor of (X, X2).  X2 == NULL: symmetric.
+ * Inputs are used as given (no lengthscale division).  out: (M+1, N1, N2). */
+int gpsig_seq_gram_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2,
+                          int64_t N1, int64_t N2, int32_t L1, int32_t L2, void* out);
+/* SignatureKernel._K_seq_diag (kernels.py:188-205).  out: (M+1, N). */
+int gpsig_seq_diag_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L, void* out);
+/* SignatureKernel._K_tens (kernels.py:263-283) -> tensor_kern (signature_algs.py:76-99).  out: (M+1, T, T). */
+int gpsig_tens_gram_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, void* out);
+/* SignatureKernel._K_tens_vs_seq (kernels.py:313-340) -> signature_kern_tens_vs_seq_first_order /
+ * _higher_order (signature_algs.py:101-160).  out: (M+1, T, N). */
+int gpsig_tens_vs_seq_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X,
+                             int64_t T, int64_t N, int32_t L, int32_t increments, void* out);
+
+/* ---- end-to-end kernel evaluations (scaling, lags, normalisation, sigma*variances, level sum) */
+/* SignatureKernel.K (kernels.py:401-476).  out: (N1, N2), or (M+1, N1, N2) if return_levels. */
+int gpsig_kernel_K(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2,
+                   int64_t N1, int64_t N2, int32_t L1, int32_t L2, int32_t return_levels, void* out);
+/* SignatureKernel.Kdiag (kernels.py:479-510).  out: (N,) or (M+1, N). */
+int gpsig_kernel_Kdiag(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L,
+                       int32_t return_levels, void* out);
+/* SignatureKernel.K_tens (kernels.py:513-536).  out: (T, T) or (M+1, T, T). */
+int gpsig_kernel_K_tens(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, int64_t T, int32_t increments,
+                        int32_t return_levels, void* out);
+/* SignatureKernel.K_tens_vs_seq (kernels.py:539-588).  out: (T, N) or (M+1, T, N). */
+int gpsig_kernel_K_tens_vs_seq(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X,
+                               int64_t T, int64_t N, int32_t L, int32_t increments, int32_t return_levels, void* out);
+/* SignatureKernel.K_tens_n_seq_covs (kernels.py:591-671).  Kxx is (N,) / (M+1, N) unless full_X_cov. */
+int gpsig_kernel_K_tens_n_seq_covs(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X,
+                                   int64_t T, int64_t N, int32_t L, int32_t increments, int32_t full_X_cov,
+                                   int32_t return_levels, void* Kzz, void* Kzx, void* Kxx);
+/* SignatureKernel.K_seq_n_seq_covs (kernels.py:674-761): X = inducing sequences, X2 = data. */
+int gpsig_kernel_K_seq_n_seq_covs(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2,
+                                  int64_t N1, int64_t N2, int32_t L1, int32_t L2, int32_t full_X2_cov,
+                                  int32_t return_levels, void* Kxx, void* Kxx2, void* Kx2x2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSIG_HIP_H */

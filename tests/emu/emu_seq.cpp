@@ -1,0 +1,160 @@
+// CPU lock-step emulator of the gfx950 seq-gram kernel -- TEST INFRASTRUCTURE ONLY.
+//
+// It runs the very same per-lane code (gpsig_amd/csrc/seq_core.hpp: seq_step, LaneCtl; seq_args.hpp:
+// seq_emit, seq_build_tasks, seq_ring_depth) for the 64 lanes of a wavefront in lock step, with the
+// DPP shifts replaced by a snapshot of the left neighbour's registers and the LDS ring replaced by a
+// plain array that is refilled at exactly the steps the kernel refills it.  The CPU test-suite uses it
+// to check the skewed-lane recursion, pair hand-over, ring-slot reuse, task coverage and the epilogue
+// against the oracle without a GPU.  The product never links or loads this file.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "seq_args.hpp"
+#include "seq_core.hpp"
+
+using namespace gpsig;
+
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT>
+static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
+    using Lane = SeqLane<T, C, D, MMAX, MODE>;
+    const int M = EXACT ? MMAX : A.M;
+    const int R1 = A.R1, RS = A.RS, nslot = A.nslot, nx = tk.nx;
+    const T* xrec = static_cast<const T*>(A.xrec);
+    const T* yrec = static_cast<const T*>(A.yrec);
+    std::vector<T> zero_row(RS, T(0));
+    std::vector<T> ring(size_t(nslot) * A.slot_elems, T(0) / T(0));   // NaN-poisoned: stale reads must not matter
+    Lane L[64];
+    LaneCtl ctl[64];
+    int64_t jj[64]; bool jvalid[64]; int rlo[64], rhi[64];
+    for (int lane = 0; lane < 64; ++lane) {
+        const int lam = lane & (G - 1), grp = lane / G;
+        jj[lane] = int64_t(tk.y0) + grp;
+        jvalid[lane] = jj[lane] < A.N2;
+        L[lane].init();
+        for (int r = 0; r < C; ++r) {
+            const int row = C * lam + r;
+            const bool ok = jvalid[lane] && row < A.R2;
+            T ys = 0;
+            for (int f = 0; f < D; ++f) {
+                T v = ok ? yrec[jj[lane] * A.yrec_stride + int64_t(row) * RS + f] : T(0);
+                L[lane].y[r][f] = v;
+                ys = std::fma(v, v, ys);
+            }
+            L[lane].y2[r] = ys;
+        }
+        rlo[lane] = lam == 0 ? 1 : 0;
+        int h = A.R2 - C * lam;
+        rhi[lane] = h < 0 ? 0 : (h > C ? C : h);
+        ctl[lane].init(lam);
+    }
+    auto stage = [&](int p, int slot) {
+        int64_t i = int64_t(tk.x0) + p;
+        if (i >= A.N1) i -= A.N1;
+        std::memcpy(ring.data() + size_t(slot) * A.slot_elems, xrec + i * A.xrec_stride, sizeof(T) * A.slot_elems);
+    };
+    stage(0, 0);
+    const int nsteps = nx * R1 + G;
+    int a_u = 0, k_u = 0, slot_next = 1 % nslot;
+    T* out = static_cast<T*>(A.out);
+    for (int t = 0; t < nsteps; ++t) {
+        if (a_u == 0 && k_u < nx) {
+            if (k_u + 1 < nx) { stage(k_u + 1, slot_next); if (++slot_next == nslot) slot_next = 0; }
+        }
+        if (++a_u == R1) { a_u = 0; ++k_u; }
+        // snapshot of every lane's hand-over registers before anyone steps
+        NbrSnapshot<T, MMAX> snap[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            const int lam = lane & (G - 1);
+            NbrSnapshot<T, MMAX>& S = snap[lane];
+            for (int m = 0; m < MMAX; ++m) S.s[m] = lam ? L[lane - 1].s[m] : T(0);
+            for (int m = 0; m < NbrSnapshot<T, MMAX>::NQ; ++m) S.qold[m] = lam ? L[lane - 1].qold[m] : T(0);
+            S.klast = lam ? L[lane - 1].kprev[C - 1] : T(0);
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int lam = lane & (G - 1);
+            if (ctl[lane].boundary()) {
+                if (lam == G - 1 && ctl[lane].p >= 1 && ctl[lane].p <= nx && jvalid[lane]) {
+                    int64_t i = int64_t(tk.x0) + (ctl[lane].p - 1);
+                    if (i >= A.N1) i -= A.N1;
+                    seq_emit<T>(L[lane], A, i, jj[lane], M, [&](int64_t off, T v) { out[off] = v; });
+                }
+                L[lane].reset();
+            }
+            const bool act = ctl[lane].active(nx);
+            const T* rowp = act ? ring.data() + size_t(ctl[lane].slot) * A.slot_elems + ctl[lane].a * RS : zero_row.data();
+            T xr[D];
+            for (int f = 0; f < D; ++f) xr[f] = rowp[f];
+            const bool dummy = !act || ctl[lane].a == 0;
+            seq_step(L[lane], snap[lane], xr, M, dummy, rlo[lane], rhi[lane], A.kind, T(A.p0), T(A.p1));
+            ctl[lane].advance(R1, nslot);
+        }
+    }
+}
+
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT>
+static void emu_run(const SeqGramArgs& A, int ntasks) {
+    for (int b = 0; b < ntasks; ++b) emu_task<T, G, C, D, MMAX, MODE, EXACT>(A, A.tasks[b]);
+}
+
+#define TRY(G_, C_, D_, MM_, EX_)                                                                         \
+    if (G == G_ && C == C_ && D == D_ && MMAX == MM_ && exact == int(EX_)) {                              \
+        if (mode == MODE_INC) emu_run<double, G_, C_, D_, MM_, MODE_INC, EX_>(*A, ntasks);                 \
+        else if (mode == MODE_PT_DIFF) emu_run<double, G_, C_, D_, MM_, MODE_PT_DIFF, EX_>(*A, ntasks);    \
+        else emu_run<double, G_, C_, D_, MM_, MODE_PT_NODIFF, EX_>(*A, ntasks);                            \
+        return 0;                                                                                         \
+    }
+
+extern "C" {
+
+int emu_seq_gram(int G, int C, int D, int MMAX, int mode, int exact, const SeqGramArgs* A, int ntasks) {
+    TRY(16, 4, 8, 5, true)
+    TRY(16, 4, 8, 4, true)
+    TRY(16, 2, 4, 4, true)
+    TRY(16, 2, 4, 5, true)
+    TRY(16, 1, 2, 3, true)
+    TRY(16, 1, 4, 8, false)
+    TRY(16, 2, 4, 8, false)
+    TRY(16, 4, 4, 8, false)
+    TRY(16, 8, 2, 8, false)
+    TRY(64, 1, 4, 8, false)
+    TRY(64, 2, 2, 4, true)
+    return -1;
+}
+
+int emu_ring_depth(int G, int R1) { return seq_ring_depth(G, R1); }
+
+// returns the number of tasks; writes at most cap of them
+int emu_build_tasks(int64_t N1, int64_t N2, int ypb, int pred, int max_run, int shard_index, int shard_count,
+                    SeqTask* out, int cap) {
+    std::vector<SeqTask> t = seq_build_tasks(N1, N2, ypb, pred, max_run, shard_index, shard_count);
+    for (size_t k = 0; k < t.size() && int(k) < cap; ++k) out[k] = t[k];
+    return int(t.size());
+}
+
+}  // extern "C"
+
+#include "seq_configs.hpp"
+
+// The emulator's own (small) config table, searched with the product's selection function.
+static const SeqConfig EMU_TABLE[] = {
+    {16, 4, 8, 5, true}, {16, 4, 8, 4, true}, {16, 2, 4, 4, true}, {16, 2, 4, 5, true}, {16, 1, 2, 3, true},
+    {16, 1, 4, 8, false}, {16, 2, 4, 8, false}, {16, 4, 4, 8, false}, {16, 8, 2, 8, false},
+    {64, 1, 4, 8, false}, {64, 2, 2, 4, true},
+};
+
+extern "C" {
+int emu_select(int Ry, int d, int M, int allow_exact, int* cfg /*G,C,D,MMAX,exact*/) {
+    const int n = int(sizeof(EMU_TABLE) / sizeof(EMU_TABLE[0]));
+    int k = seq_select(EMU_TABLE, n, Ry, d, M, allow_exact != 0);
+    if (k < 0) return -1;
+    cfg[0] = EMU_TABLE[k].G; cfg[1] = EMU_TABLE[k].C; cfg[2] = EMU_TABLE[k].D; cfg[3] = EMU_TABLE[k].MMAX;
+    cfg[4] = EMU_TABLE[k].exact;
+    return k;
+}
+int emu_geometry(int base_kind, int difference, int L, int D, int elem_bytes, int* out /*mode,rows,RS,rec_elems*/) {
+    SeqGeom g = seq_geometry(base_kind, difference, L, D, elem_bytes);
+    out[0] = g.mode; out[1] = g.rows; out[2] = g.RS; out[3] = g.rec_elems;
+    return 0;
+}
+}

@@ -24,31 +24,31 @@ def notebook_data():
     sigs = np.stack([O.truncated_signature(x, M) for x in X])       # cell 6 (esig.tosig.stream2sig)
     tens = O.rank1_tensor_features(Z, M)                            # cell 18
     kern = O.SignatureKernelOracle(L * d, d, M, base="linear", order=M, normalization=False)  # cell 11
-    return X.reshape(N, -1), Z, sigs, tens, kern
+    Kl = kern.K(X.reshape(N, -1), return_levels=True)               # cell 11, levels kept apart
+    return X.reshape(N, -1), Z, sigs, tens, kern, Kl
 
 
 def test_notebook_identity_seq_vs_seq(notebook_data):
-    X, Z, sigs, tens, kern = notebook_data
-    K = kern.compute_K_symm(X)                                      # cell 11
+    X, Z, sigs, tens, kern, Kl = notebook_data
+    K = Kl.sum(axis=0)                                              # cell 11 (variances = 1)
     K_sig = sigs @ sigs.T                                           # cell 8
     # the notebook reports Fro-norm 1.1e-8 on entries of size ~1e7 (cell 13)
     assert _relerr(K, K_sig) < 1e-12
 
 
 def test_notebook_identity_levels(notebook_data):
-    X, Z, sigs, tens, kern = notebook_data
-    Kl = kern.K(X, return_levels=True)
+    X, Z, sigs, tens, kern, Kl = notebook_data
     for m, sl in enumerate(O.signature_level_slices(3, 5)):
         assert _relerr(Kl[m], sigs[:, sl] @ sigs[:, sl].T) < 1e-12
 
 
 def test_notebook_identity_tens_vs_seq(notebook_data):
-    X, Z, sigs, tens, kern = notebook_data
+    X, Z, sigs, tens, kern, Kl = notebook_data
     assert _relerr(kern.compute_K_tens_vs_seq(Z, X), tens @ sigs.T) < 1e-12   # cells 19-23
 
 
 def test_notebook_identity_tens_vs_tens(notebook_data):
-    X, Z, sigs, tens, kern = notebook_data
+    X, Z, sigs, tens, kern, Kl = notebook_data
     assert _relerr(kern.compute_K_tens(Z), tens @ tens.T) < 1e-12             # cells 25-29
 
 
