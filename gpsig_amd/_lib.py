@@ -1,0 +1,157 @@
+"""ctypes binding of libgpsig_hip.so (include/gpsig_hip.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` / ``make -C gpsig_amd/csrc``.
+There is no CPU fallback: if the library or a HIP device is missing, importing works but the first
+kernel evaluation raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgpsig_hip.so")
+
+GPSIG_OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4
+PTR_HOST, PTR_DEVICE = 0, 1
+F64, F32 = 0, 1
+BASE = {"linear": 0, "rbf": 1, "cosine": 2, "poly": 3, "mix": 4, "matern12": 5, "matern32": 6, "matern52": 7}
+
+
+class Params(C.Structure):
+    """struct gpsig_params (include/gpsig_hip.h)."""
+    _fields_ = [
+        ("base_kernel", C.c_int32), ("dtype", C.c_int32), ("num_features", C.c_int32), ("num_levels", C.c_int32),
+        ("order", C.c_int32), ("difference", C.c_int32), ("normalization", C.c_int32), ("num_lags", C.c_int32),
+        ("sigma", C.c_double), ("jitter", C.c_double), ("base_params", C.c_double * 4),
+        ("variances", C.POINTER(C.c_double)), ("lengthscales", C.POINTER(C.c_double)),
+        ("lags", C.POINTER(C.c_double)), ("gamma", C.POINTER(C.c_double)),
+    ]
+
+
+_P = C.POINTER(Params)
+_vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
+
+# name -> argtypes after (ctx, params); every symbol include/gpsig_hip.h declares must appear here or in _PLAIN
+_KERNEL_FUNCS = {
+    "gpsig_seq_gram_levels": [_vp, _vp, _i64, _i64, _i32, _i32, _vp],
+    "gpsig_seq_diag_levels": [_vp, _i64, _i32, _vp],
+    "gpsig_tens_gram_levels": [_vp, _i64, _i32, _vp],
+    "gpsig_tens_vs_seq_levels": [_vp, _vp, _i64, _i64, _i32, _i32, _vp],
+    "gpsig_kernel_K": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "gpsig_kernel_Kdiag": [_vp, _i64, _i32, _i32, _vp],
+    "gpsig_kernel_K_tens": [_vp, _i64, _i32, _i32, _vp],
+    "gpsig_kernel_K_tens_vs_seq": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "gpsig_kernel_K_tens_n_seq_covs": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "gpsig_kernel_K_seq_n_seq_covs": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+}
+_PLAIN = {
+    "gpsig_abi_version": ([], C.c_int),
+    "gpsig_ctx_create": ([C.c_int, _vp, C.POINTER(_vp)], C.c_int),
+    "gpsig_ctx_destroy": ([_vp], None),
+    "gpsig_last_error": ([_vp], C.c_char_p),
+    "gpsig_set_pointer_mode": ([_vp, C.c_int], C.c_int),
+    "gpsig_sync": ([_vp], C.c_int),
+    "gpsig_set_shard": ([_vp, C.c_int, C.c_int], C.c_int),
+    "gpsig_set_option": ([_vp, C.c_char_p, C.c_int], C.c_int),
+    "gpsig_timing_reset": ([_vp], C.c_int),
+    "gpsig_timing_get": ([_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)], C.c_int),
+}
+ALL_SYMBOLS = sorted(list(_KERNEL_FUNCS) + list(_PLAIN))
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C gpsig_amd/csrc).  gpsig_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (args, res) in _PLAIN.items():
+            f = getattr(lib, name)
+            f.argtypes, f.restype = args, res
+        for name, args in _KERNEL_FUNCS.items():
+            f = getattr(lib, name)
+            f.argtypes, f.restype = [_vp, _P] + args, C.c_int
+        if lib.gpsig_abi_version() != 1:
+            raise RuntimeError("libgpsig_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+class GpsigError(RuntimeError):
+    pass
+
+
+def raise_for(rc, msg):
+    if rc == GPSIG_OK:
+        return
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == ERR_NOMEM:
+        raise MemoryError(msg)
+    raise GpsigError(msg)
+
+
+class Context:
+    """One gpsig_ctx: a (device, stream) pair plus its scratch memory."""
+
+    def __init__(self, device=0, stream=0):
+        lib = load()
+        h = _vp()
+        rc = lib.gpsig_ctx_create(int(device), _vp(stream) if stream else None, C.byref(h))
+        if rc != GPSIG_OK:
+            raise_for(rc, (lib.gpsig_last_error(None) or b"gpsig_ctx_create failed").decode())
+        self._h, self._lib, self.device, self.stream = h, lib, int(device), int(stream or 0)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpsig_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != GPSIG_OK:
+            raise_for(rc, (self._lib.gpsig_last_error(self._h) or b"").decode())
+
+    def call(self, name, params, *args):
+        self.check(getattr(self._lib, name)(self._h, C.byref(params), *args))
+
+    def set_pointer_mode(self, mode):
+        self.check(self._lib.gpsig_set_pointer_mode(self._h, mode))
+
+    def set_shard(self, index, count):
+        self.check(self._lib.gpsig_set_shard(self._h, int(index), int(count)))
+
+    def set_option(self, name, value):
+        self.check(self._lib.gpsig_set_option(self._h, name.encode(), int(value)))
+
+    def sync(self):
+        self.check(self._lib.gpsig_sync(self._h))
+
+    def timing_reset(self):
+        self.check(self._lib.gpsig_timing_reset(self._h))
+
+    def timing_get(self):
+        ms, n, pairs = C.c_double(), _i64(), _i64()
+        self.check(self._lib.gpsig_timing_get(self._h, C.byref(ms), C.byref(n), C.byref(pairs)))
+        return ms.value, n.value, pairs.value
+
+
+_contexts = {}
+
+
+def context(device=0, stream=0):
+    key = (int(device), int(stream or 0))
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = _contexts[key] = Context(*key)
+    return ctx

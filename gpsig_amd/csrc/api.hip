@@ -1,0 +1,923 @@
+// api.hip -- implementation of the C ABI declared in include/gpsig_hip.h.
+//
+// Host-side orchestration only: input preparation, kernel-shape selection, task lists, scratch
+// memory, HIP-event timing.  All arithmetic happens in the kernels of seq_gram_kernel.hpp and
+// aux_kernels.hpp.  There is deliberately no CPU fallback: without a HIP device every entry point
+// fails with GPSIG_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpsig_hip.h"
+#include "aux_kernels.hpp"
+#include "seq_args.hpp"
+#include "seq_configs.hpp"
+
+namespace gpsig {
+typedef hipError_t (*SeqLaunchFn)(const SeqGramArgs&, int, size_t, hipStream_t);
+SeqLaunchFn seq_lookup_inc_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_inc_g16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_inc_g64(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptd_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptd_g16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptd_g64(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptn_g16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptn_g64(int, int, int, int, bool);
+typedef hipError_t (*TvsLaunchFn)(const TvsArgs&, hipStream_t);
+TvsLaunchFn tvs_lookup(int M, int TT, bool incr);
+}  // namespace gpsig
+
+using namespace gpsig;
+
+namespace {
+
+#define X_CFG(G_, C_, D_, MM_, EX_) {G_, C_, D_, MM_, EX_},
+const SeqConfig SEQ_TABLE[] = {GPSIG_SEQ_CONFIGS_ALL(X_CFG)};
+const SeqConfig SEQ_TABLE_GENERIC[] = {GPSIG_SEQ_CONFIGS_GENERIC(X_CFG)};
+#undef X_CFG
+constexpr int N_SEQ_TABLE = int(sizeof(SEQ_TABLE) / sizeof(SEQ_TABLE[0]));
+constexpr int N_SEQ_TABLE_GENERIC = int(sizeof(SEQ_TABLE_GENERIC) / sizeof(SEQ_TABLE_GENERIC[0]));
+
+SeqLaunchFn seq_launcher(int mode, const SeqConfig& c) {
+    SeqLaunchFn f = nullptr;
+    if (mode == MODE_INC) {
+        if ((f = seq_lookup_inc_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+        if ((f = seq_lookup_inc_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+        return seq_lookup_inc_g64(c.G, c.C, c.D, c.MMAX, c.exact);
+    }
+    if (mode == MODE_PT_DIFF) {
+        if ((f = seq_lookup_ptd_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+        if ((f = seq_lookup_ptd_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+        return seq_lookup_ptd_g64(c.G, c.C, c.D, c.MMAX, c.exact);
+    }
+    if ((f = seq_lookup_ptn_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+    return seq_lookup_ptn_g64(c.G, c.C, c.D, c.MMAX, c.exact);
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+enum BufId {
+    B_IN0, B_IN1, B_IN2,          // host-mode input staging
+    B_OUT0, B_OUT1, B_OUT2,       // host-mode output staging
+    B_REC0, B_REC1,               // seq-gram records
+    B_DLEV0, B_DLEV1,             // diagonal levels
+    B_FAC0, B_FAC1,               // per-sequence factors
+    B_TASKS, B_W, B_XT, B_ZT, B_ZS, B_TMP0, B_TMP1,
+    B_COUNT
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct gpsig_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int ptr_mode = GPSIG_PTR_HOST;
+    int shard_i = 0, shard_n = 1;
+    int use_glds = 0;
+    int allow_exact = 1;
+    int max_run = 0;
+    std::string err;
+    DevBuf buf[B_COUNT];
+    std::vector<SeqTask> host_tasks;
+    // timing of the pair-recursion launches
+    std::vector<hipEvent_t> ev;     // pairs (start, stop)
+    size_t ev_used = 0;
+    int64_t t_launches = 0, t_pairs = 0;
+};
+
+namespace {
+
+int fail(gpsig_ctx* c, int code, const char* fmt, ...) {
+    char tmp[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof(tmp), fmt, ap);
+    va_end(ap);
+    if (c) c->err = tmp; else g_create_error = tmp;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e__ = (expr);                                                                                \
+        if (e__ != hipSuccess) return fail((c), GPSIG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+#define CHK(expr)                    \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != GPSIG_OK) return rc__; \
+    } while (0)
+
+int ensure(gpsig_ctx* c, int id, size_t bytes, void** out) {
+    DevBuf& b = c->buf[id];
+    if (bytes > b.cap) {
+        if (b.p) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // nothing in flight may still use the old block
+            HIPCHK(c, hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) return fail(c, GPSIG_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        b.cap = want;
+    }
+    *out = b.p;
+    return GPSIG_OK;
+}
+
+// input pointer as the caller gave it -> device pointer
+int in_dev(gpsig_ctx* c, int id, const void* user, size_t bytes, const void** dev) {
+    if (!user && bytes) return fail(c, GPSIG_ERR_INVALID, "null input pointer");
+    if (c->ptr_mode == GPSIG_PTR_DEVICE && user) { *dev = user; return GPSIG_OK; }
+    void* p;
+    CHK(ensure(c, id, bytes ? bytes : 8, &p));
+    if (bytes && c->ptr_mode == GPSIG_PTR_HOST) HIPCHK(c, hipMemcpyAsync(p, user, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev = p;
+    return GPSIG_OK;
+}
+int out_dev(gpsig_ctx* c, int id, void* user, size_t bytes, void** dev) {
+    if (!user && bytes) return fail(c, GPSIG_ERR_INVALID, "null output pointer");
+    if (c->ptr_mode == GPSIG_PTR_DEVICE && user) { *dev = user; return GPSIG_OK; }
+    return ensure(c, id, bytes ? bytes : 8, dev);
+}
+int out_done(gpsig_ctx* c, void* user, const void* dev, size_t bytes) {
+    if (c->ptr_mode == GPSIG_PTR_DEVICE || !user) return GPSIG_OK;
+    if (bytes) HIPCHK(c, hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    return GPSIG_OK;
+}
+int finish(gpsig_ctx* c) {
+    if (c->ptr_mode == GPSIG_PTR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GPSIG_OK;
+}
+
+int grid_for(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 256 * 16) g = 256 * 16;
+    return int(g);
+}
+
+int check_params(gpsig_ctx* c, const gpsig_params* p) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (!p) return fail(c, GPSIG_ERR_INVALID, "params is NULL");
+    if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "only float64 is built in this round (dtype=%d)", p->dtype);
+    if (p->num_levels < 1) return fail(c, GPSIG_ERR_INVALID, "num_levels must be >= 1");
+    if (p->num_features < 1 || p->num_features > MAX_FEATURES)
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "num_features=%d outside [1, %d]", p->num_features, MAX_FEATURES);
+    if (p->num_lags < 0 || p->num_lags > MAX_LAGS) return fail(c, GPSIG_ERR_UNSUPPORTED, "num_lags=%d outside [0, %d]", p->num_lags, MAX_LAGS);
+    if (p->base_kernel < GPSIG_BASE_LINEAR || p->base_kernel > GPSIG_BASE_MATERN52) return fail(c, GPSIG_ERR_INVALID, "unknown base kernel %d", p->base_kernel);
+    if (p->order < 1 || p->order > p->num_levels) return fail(c, GPSIG_ERR_INVALID, "order=%d outside [1, num_levels]", p->order);
+    if (p->order != 1 && p->num_levels > 1)
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "higher-order recursion (order=%d) is not built on the GPU yet; order=1 only", p->order);
+    if (!p->variances) return fail(c, GPSIG_ERR_INVALID, "variances is NULL");
+    if (p->num_lags > 0 && (!p->lags || !p->gamma)) return fail(c, GPSIG_ERR_INVALID, "num_lags > 0 needs lags and gamma");
+    return GPSIG_OK;
+}
+
+ScaleParams scale_of(const gpsig_params* p, bool apply_scaling) {
+    ScaleParams s;
+    memset(&s, 0, sizeof(s));
+    s.d_in = p->num_features;
+    s.num_lags = apply_scaling ? p->num_lags : 0;
+    s.has_ls = apply_scaling && p->lengthscales != nullptr;
+    for (int f = 0; f < p->num_features; ++f) s.ls[f] = s.has_ls ? p->lengthscales[f] : 1.0;
+    for (int l = 0; l < s.num_lags; ++l) s.lags[l] = p->lags[l];
+    for (int l = 0; l <= s.num_lags; ++l) s.gamma[l] = s.num_lags > 0 ? p->gamma[l] : 1.0;
+    s.jitter = 1e-6;   // settings.jitter inside lin_interp (gpsig/lags.py:22)
+    return s;
+}
+
+void base_p(const gpsig_params* p, double* p0, double* p1) {
+    *p0 = p->base_params[0];
+    *p1 = p->base_params[1];
+}
+
+// weights sigma * variances[m] on the device
+int upload_weights(gpsig_ctx* c, const gpsig_params* p, const double** w) {
+    const int M1 = p->num_levels + 1;
+    std::vector<double> h(M1);
+    for (int m = 0; m < M1; ++m) h[m] = p->sigma * p->variances[m];
+    void* d;
+    CHK(ensure(c, B_W, sizeof(double) * M1, &d));
+    HIPCHK(c, hipMemcpyAsync(d, h.data(), sizeof(double) * M1, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // h goes out of scope
+    *w = static_cast<const double*>(d);
+    return GPSIG_OK;
+}
+
+// ---- seq-gram planning -----------------------------------------------------------------------------
+struct SeqPlanned {
+    SeqConfig cfg;
+    SeqLaunchFn fn;
+    int mode, d_eff;
+};
+
+int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
+    SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, 8);
+    const SeqConfig* tab = g0.mode == MODE_PT_NODIFF ? SEQ_TABLE_GENERIC : SEQ_TABLE;
+    const int ntab = g0.mode == MODE_PT_NODIFF ? N_SEQ_TABLE_GENERIC : N_SEQ_TABLE;
+    int k = seq_select(tab, ntab, g0.rows, d_eff, p->num_levels, c->allow_exact != 0);
+    if (k < 0)
+        return fail(c, GPSIG_ERR_UNSUPPORTED,
+                    "no seq-gram kernel shape for %d record rows on the register-resident side, d=%d, num_levels=%d "
+                    "(built: rows <= 512, d*(num_lags+1) <= 16 (<= 8 beyond 256 rows), num_levels <= 8)",
+                    g0.rows, d_eff, p->num_levels);
+    out->cfg = tab[k];
+    out->mode = g0.mode;
+    out->d_eff = d_eff;
+    out->fn = seq_launcher(g0.mode, tab[k]);
+    if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "seq-gram kernel shape missing from this build");
+    return GPSIG_OK;
+}
+
+// records of N sequences (device, user layout (N, L, d)) into buffer `id`
+int make_records(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const SeqPlanned& pl, const void* Xdev, int64_t N,
+                 int L, int id, const void** rec, SeqGeom* geom) {
+    *geom = seq_geometry(p->base_kernel, p->difference, L, pl.cfg.D, 8);
+    const size_t bytes = size_t(N) * geom->rec_elems * sizeof(double);
+    void* d;
+    CHK(ensure(c, id, bytes ? bytes : 8, &d));
+    if (N > 0) {
+        HIPCHK(c, hipMemsetAsync(d, 0, bytes, c->stream));
+        ScaleParams s = scale_of(p, apply_scaling);
+        const int64_t total = N * geom->rows * s.d_eff();
+        hipLaunchKernelGGL(prep_seq_records_kernel<double>, dim3(grid_for(total)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(Xdev), N, L, s, geom->mode, p->difference, geom->rows, geom->RS,
+                           int64_t(geom->rec_elems), static_cast<double*>(d));
+        HIPCHK(c, hipGetLastError());
+    }
+    *rec = d;
+    return GPSIG_OK;
+}
+
+int timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
+    if (c->ev_used + 2 > c->ev.size()) {
+        hipEvent_t a, b;
+        HIPCHK(c, hipEventCreate(&a));
+        HIPCHK(c, hipEventCreate(&b));
+        c->ev.push_back(a);
+        c->ev.push_back(b);
+    }
+    *e0 = c->ev[c->ev_used];
+    *e1 = c->ev[c->ev_used + 1];
+    c->ev_used += 2;
+    HIPCHK(c, hipEventRecord(*e0, c->stream));
+    return GPSIG_OK;
+}
+
+struct SeqRun {
+    const void* xrec; const void* yrec;
+    SeqGeom gx, gy;
+    int64_t N1, N2;
+    void* out; int64_t si, sj, sm;
+    const void* ax; const void* by;
+    double jitter_diag;
+    int sum_levels, pred, mirror;
+    bool timed;
+};
+
+int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const SeqRun& r) {
+    if (r.N1 <= 0 || r.N2 <= 0) return GPSIG_OK;
+    if (r.N1 > 0x7fffffff || r.N2 > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 sequences");
+    const int ypb = 64 / pl.cfg.G;
+    // aim for ~64k independent tasks (about 20 per resident wave slot) so the tail is a few per cent
+    const int64_t nblocks = (r.N2 + ypb - 1) / ypb;
+    const int64_t xtot = r.pred == PRED_ALL ? r.N1 : (r.pred == PRED_DIAG ? ypb : r.N1 / 2 + ypb);
+    int64_t max_run = (xtot * nblocks + 65535) / 65536;
+    if (max_run < 8) max_run = 8;
+    if (max_run > 256) max_run = 256;
+    if (c->max_run > 0) max_run = c->max_run;
+    c->host_tasks = seq_build_tasks(r.N1, r.N2, ypb, r.pred, int(max_run), c->shard_i, c->shard_n);
+    const int ntasks = int(c->host_tasks.size());
+    if (ntasks == 0) return GPSIG_OK;
+    void* dt;
+    CHK(ensure(c, B_TASKS, sizeof(SeqTask) * size_t(ntasks), &dt));
+    HIPCHK(c, hipMemcpyAsync(dt, c->host_tasks.data(), sizeof(SeqTask) * size_t(ntasks), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // host_tasks is pageable and reused by the next launch
+
+    SeqGramArgs A;
+    memset(&A, 0, sizeof(A));
+    A.xrec = r.xrec; A.yrec = r.yrec; A.tasks = static_cast<const SeqTask*>(dt);
+    A.N1 = r.N1; A.N2 = r.N2;
+    A.xrec_stride = r.gx.rec_elems; A.yrec_stride = r.gy.rec_elems;
+    A.R1 = r.gx.rows; A.R2 = r.gy.rows; A.RS = r.gx.RS; A.M = p->num_levels;
+    A.nslot = seq_ring_depth(pl.cfg.G, r.gx.rows);
+    A.slot_elems = r.gx.rec_elems;
+    A.kind = p->base_kernel;
+    base_p(p, &A.p0, &A.p1);
+    A.out = r.out; A.si = r.si; A.sj = r.sj; A.sm = r.sm;
+    A.ax = r.ax; A.by = r.by; A.jitter_diag = r.jitter_diag;
+    A.sum_levels = r.sum_levels; A.pred = r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds;
+    const size_t lds = sizeof(double) * (size_t(A.RS) + size_t(A.nslot) * A.slot_elems);
+    if (lds > 160 * 1024) return fail(c, GPSIG_ERR_UNSUPPORTED, "x-side records of %d rows do not fit the LDS ring (%zu bytes)", A.R1, lds);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (r.timed) CHK(timing_begin(c, &e0, &e1));
+    HIPCHK(c, pl.fn(A, ntasks, lds, c->stream));
+    if (r.timed) {
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        c->t_launches += 1;
+        int64_t pairs = 0;
+        for (const SeqTask& t : c->host_tasks) pairs += int64_t(t.nx) * ypb;
+        c->t_pairs += pairs;
+    }
+    return GPSIG_OK;
+}
+
+// diag levels of N sequences, sequence-major (N, M+1), into buffer `id`
+int diag_levels(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const void* rec, const SeqGeom& g, int64_t N,
+                int id, const void** dlev) {
+    const int M1 = p->num_levels + 1;
+    void* d;
+    CHK(ensure(c, id, sizeof(double) * size_t(N) * M1 + 8, &d));
+    SeqRun r;
+    memset(&r, 0, sizeof(r));
+    r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
+    r.out = d; r.si = M1; r.sj = 0; r.sm = 1;
+    r.sum_levels = 0; r.pred = PRED_DIAG; r.mirror = 0; r.timed = false;
+    // the diag pass must cover every sequence on every shard: factors are needed for all rows/columns
+    const int si = c->shard_i, sn = c->shard_n;
+    c->shard_i = 0; c->shard_n = 1;
+    int rc = launch_seq(c, p, pl, r);
+    c->shard_i = si; c->shard_n = sn;
+    CHK(rc);
+    *dlev = d;
+    return GPSIG_OK;
+}
+
+int make_factors(gpsig_ctx* c, const void* dlev, int64_t N, int M1, const double* w, double jitter, int id, const void** fac,
+                 int squared = 0) {
+    void* d;
+    CHK(ensure(c, id, sizeof(double) * size_t(N) * M1 + 8, &d));
+    if (N > 0) {
+        hipLaunchKernelGGL(factors_kernel<double>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(dlev), N, M1, w, jitter, squared, static_cast<double*>(d));
+        HIPCHK(c, hipGetLastError());
+    }
+    *fac = d;
+    return GPSIG_OK;
+}
+
+// Per-sequence factors w[m] / sqrt(diag_m + jitter) (or squared) of one side, with that side's own kernel shape:
+// the diagonal pass keeps the sequence itself in registers, whatever the main pass does with it.
+int side_factors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* X, int64_t N, int L, const double* w,
+                 int squared, int id_dlev, int id_fac, const void** fac) {
+    const int d_eff = p->num_features * ((apply_scaling ? p->num_lags : 0) + 1);
+    SeqPlanned pl;
+    CHK(plan_seq(c, p, d_eff, L, &pl));
+    const void* rec;
+    SeqGeom g;
+    CHK(make_records(c, p, apply_scaling, pl, X, N, L, B_REC0, &rec, &g));
+    const void* dl;
+    CHK(diag_levels(c, p, pl, rec, g, N, id_dlev, &dl));
+    return make_factors(c, dl, N, p->num_levels + 1, w, p->jitter, id_fac, fac, squared);
+}
+
+// Core of K / _K_seq on device pointers.  raw: no scaling, no normalisation, no weights (levels out).
+// x_squared: X-side factor 1/(diag+jitter) instead of 1/sqrt(diag+jitter) (K_seq_n_seq_covs quirk, kernels.py:713+:750).
+int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, const void* X2, int64_t N1, int64_t N2,
+                 int L1, int L2, int return_levels, void* out, bool timed, int x_squared = 0) {
+    if (L1 < 1 || L2 < 1) return fail(c, GPSIG_ERR_INVALID, "sequence length must be >= 1");
+    const bool sym = X2 == nullptr;
+    const int M1 = p->num_levels + 1;
+    const int d_eff = p->num_features * ((raw ? 0 : p->num_lags) + 1);
+    // register-resident ("y") side: X2 by default; the shorter one if the lengths differ
+    bool swap = false;
+    if (!sym && L1 < L2) swap = true;
+    SeqPlanned pl;
+    int rc = plan_seq(c, p, d_eff, sym ? L1 : (swap ? L1 : L2), &pl);
+    if (rc != GPSIG_OK && !sym) {       // maybe the other side fits
+        swap = !swap;
+        int rc2 = plan_seq(c, p, d_eff, swap ? L1 : L2, &pl);
+        if (rc2 != GPSIG_OK) return rc2;
+    } else if (rc != GPSIG_OK) {
+        return rc;
+    }
+    const void *fa = nullptr, *fb = nullptr;
+    double jitter_diag = 0.0;
+    if (!raw) {
+        const double* w;
+        CHK(upload_weights(c, p, &w));
+        if (p->normalization) {
+            CHK(side_factors(c, p, true, X, N1, L1, w, x_squared, B_DLEV0, B_FAC0, &fa));
+            if (sym) CHK(make_factors(c, c->buf[B_DLEV0].p, N1, M1, nullptr, p->jitter, B_FAC1, &fb));
+            else CHK(side_factors(c, p, true, X2, N2, L2, nullptr, 0, B_DLEV1, B_FAC1, &fb));
+            if (sym) jitter_diag = p->jitter;        // kernels.py:431 (symmetric) vs :463-464 (cross: diagonals only)
+        } else {
+            CHK(make_factors(c, nullptr, N1, M1, w, 0.0, B_FAC0, &fa));
+        }
+    }
+    const void *rec1, *rec2;
+    SeqGeom g1, g2;
+    CHK(make_records(c, p, !raw, pl, X, N1, L1, B_REC0, &rec1, &g1));
+    if (sym) { rec2 = rec1; g2 = g1; }
+    else CHK(make_records(c, p, !raw, pl, X2, N2, L2, B_REC1, &rec2, &g2));
+    SeqRun r;
+    memset(&r, 0, sizeof(r));
+    const int64_t Ncols = sym ? N1 : N2;
+    r.out = out; r.sm = N1 * Ncols;
+    r.sum_levels = return_levels ? 0 : 1;
+    if (raw) r.sum_levels = 0;
+    r.jitter_diag = jitter_diag;
+    r.pred = sym ? PRED_CIRCULANT : PRED_ALL;
+    r.mirror = sym ? 1 : 0;
+    r.timed = timed;
+    if (!swap) {   // x = X (rows of the output), y = X2 (columns)
+        r.xrec = rec1; r.yrec = rec2; r.gx = g1; r.gy = g2; r.N1 = N1; r.N2 = Ncols;
+        r.si = Ncols; r.sj = 1; r.ax = fa; r.by = fb;
+    } else {       // x = X2 (columns), y = X (rows)
+        r.xrec = rec2; r.yrec = rec1; r.gx = g2; r.gy = g1; r.N1 = N2; r.N2 = N1;
+        r.si = 1; r.sj = N2; r.ax = fb; r.by = fa;
+    }
+    return launch_seq(c, p, pl, r);
+}
+
+size_t seq_out_elems(const gpsig_params* p, int64_t N1, int64_t N2, int levels) {
+    return size_t(N1) * size_t(N2) * (levels ? size_t(p->num_levels + 1) : 1);
+}
+
+// ---- tensors ---------------------------------------------------------------------------------------
+int prep_tensors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* Zdev, int64_t Tn, int E,
+                 const void** ZT, const void** ZS) {
+    const int lt = p->num_levels * (p->num_levels + 1) / 2;
+    ScaleParams s = scale_of(p, apply_scaling);
+    const int d_eff = s.d_eff();
+    void *zt, *zs;
+    CHK(ensure(c, B_ZT, sizeof(double) * size_t(Tn) * d_eff * lt * E + 8, &zt));
+    CHK(ensure(c, B_ZS, sizeof(double) * size_t(Tn) * lt * E + 8, &zs));
+    if (Tn > 0) {
+        hipLaunchKernelGGL(prep_tensors_kernel<double>, dim3(grid_for(Tn * lt * E)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(Zdev), lt, Tn, E, s, static_cast<double*>(zt), static_cast<double*>(zs));
+        HIPCHK(c, hipGetLastError());
+    }
+    *ZT = zt; *ZS = zs;
+    return GPSIG_OK;
+}
+
+int tens_gram_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Z, int64_t Tn, int increments,
+                     int return_levels, void* out) {
+    const int E = increments ? 2 : 1;
+    const void *ZT, *ZS;
+    CHK(prep_tensors(c, p, !raw, Z, Tn, E, &ZT, &ZS));
+    TensGramArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ZT = ZT; A.ZS = ZS; A.Tn = Tn; A.M = p->num_levels; A.d_eff = p->num_features * ((raw ? 0 : p->num_lags) + 1);
+    A.E = E; A.kind = p->base_kernel;
+    base_p(p, &A.p0, &A.p1);
+    A.w = nullptr;
+    if (!raw) CHK(upload_weights(c, p, &A.w));
+    A.out = out;
+    A.sum_levels = (raw || return_levels) ? 0 : 1;
+    if (Tn > 0) {
+        hipLaunchKernelGGL(tens_gram_kernel<double>, dim3(grid_for(Tn * Tn)), dim3(256), 0, c->stream, A);
+        HIPCHK(c, hipGetLastError());
+    }
+    return GPSIG_OK;
+}
+
+// Kzx on device pointers.  fx: per-sequence factors (N, M+1) or NULL.
+int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* ZT, const void* ZS, const void* X,
+                       int64_t Tn, int64_t N, int L, int increments, const void* fx, const double* w, int return_levels,
+                       void* out) {
+    const int M = p->num_levels;
+    const int64_t Npad = (N + 63) / 64 * 64;
+    ScaleParams sx = scale_of(p, !raw);
+    const int d_eff = sx.d_eff();
+    void* xt;
+    CHK(ensure(c, B_XT, sizeof(double) * size_t(L) * d_eff * Npad + 8, &xt));
+    if (N > 0) {
+        hipLaunchKernelGGL(prep_seq_timemajor_kernel<double>, dim3(grid_for(int64_t(L) * d_eff * Npad)), dim3(256), 0,
+                           c->stream, static_cast<const double*>(X), N, Npad, L, sx, static_cast<double*>(xt));
+        HIPCHK(c, hipGetLastError());
+    }
+    const int lt = M * (M + 1) / 2;
+    const int E = increments ? 2 : 1;
+    int TT = (lt * (2 + E) * 2 <= 100) ? 2 : 1;
+    TvsLaunchFn fn = tvs_lookup(M, TT, increments != 0);
+    if (!fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "tensor-vs-sequence kernel is built for num_levels <= 8 (got %d)", M);
+    TvsArgs A;
+    memset(&A, 0, sizeof(A));
+    A.XT = xt; A.ZT = ZT; A.ZS = ZS; A.N = N; A.Npad = Npad; A.Tn = Tn;
+    A.L = L; A.d_eff = d_eff; A.kind = p->base_kernel; A.difference = p->difference;
+    base_p(p, &A.p0, &A.p1);
+    A.fx = fx; A.w = w; A.out = out; A.sum_levels = (raw || return_levels) ? 0 : 1;
+    if (N > 0 && Tn > 0) {
+        hipEvent_t e0, e1;
+        CHK(timing_begin(c, &e0, &e1));
+        HIPCHK(c, fn(A, c->stream));
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        c->t_launches += 1;
+        c->t_pairs += Tn * N;
+    }
+    return GPSIG_OK;
+}
+
+// per-sequence 1/sqrt(diag + jitter) factors (N, M+1) of sequences X, into B_FAC1
+int seq_diag_factors(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int L, const void** fac) {
+    return side_factors(c, p, true, X, N, L, nullptr, 0, B_DLEV0, B_FAC1, fac);
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int gpsig_abi_version(void) { return GPSIG_ABI_VERSION; }
+
+int gpsig_ctx_create(int device, void* stream, gpsig_ctx** out) {
+    if (!out) return GPSIG_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, GPSIG_ERR_HIP, "no HIP device available (%s); libgpsig_hip has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, GPSIG_ERR_INVALID, "device %d out of range [0, %d)", device, count);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, GPSIG_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, GPSIG_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, GPSIG_ERR_UNSUPPORTED, "device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+    gpsig_ctx* c = new gpsig_ctx();
+    c->device = device;
+    c->stream = static_cast<hipStream_t>(stream);
+    const char* g = getenv("GPSIG_GLDS");
+    c->use_glds = g ? atoi(g) : 0;
+    const char* ex = getenv("GPSIG_NO_EXACT");
+    c->allow_exact = (ex && atoi(ex)) ? 0 : 1;
+    *out = c;
+    return GPSIG_OK;
+}
+
+void gpsig_ctx_destroy(gpsig_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf& b : c->buf)
+        if (b.p) (void)hipFree(b.p);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    delete c;
+}
+
+const char* gpsig_last_error(gpsig_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int gpsig_set_pointer_mode(gpsig_ctx* c, int mode) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (mode != GPSIG_PTR_HOST && mode != GPSIG_PTR_DEVICE) return fail(c, GPSIG_ERR_INVALID, "unknown pointer mode %d", mode);
+    c->ptr_mode = mode;
+    return GPSIG_OK;
+}
+
+int gpsig_sync(gpsig_ctx* c) {
+    if (!c) return GPSIG_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GPSIG_OK;
+}
+
+int gpsig_set_shard(gpsig_ctx* c, int index, int count) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (count < 1 || index < 0 || index >= count) return fail(c, GPSIG_ERR_INVALID, "bad shard (%d of %d)", index, count);
+    c->shard_i = index;
+    c->shard_n = count;
+    return GPSIG_OK;
+}
+
+int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
+    if (!c || !name) return GPSIG_ERR_INVALID;
+    if (!strcmp(name, "glds")) c->use_glds = value ? 1 : 0;
+    else if (!strcmp(name, "exact")) c->allow_exact = value ? 1 : 0;
+    else if (!strcmp(name, "max_run")) c->max_run = value > 0 ? value : 0;
+    else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);
+    return GPSIG_OK;
+}
+
+int gpsig_timing_reset(gpsig_ctx* c) {
+    if (!c) return GPSIG_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->ev_used = 0;
+    c->t_launches = 0;
+    c->t_pairs = 0;
+    return GPSIG_OK;
+}
+
+int gpsig_timing_get(gpsig_ctx* c, double* kernel_ms, int64_t* launches, int64_t* pairs) {
+    if (!c) return GPSIG_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]));
+        tot += ms;
+    }
+    if (kernel_ms) *kernel_ms = tot;
+    if (launches) *launches = c->t_launches;
+    if (pairs) *pairs = c->t_pairs;
+    return GPSIG_OK;
+}
+
+#define ENTER(c, p)                         \
+    CHK(check_params((c), (p)));            \
+    HIPCHK((c), hipSetDevice((c)->device));
+
+int gpsig_seq_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
+                          int32_t L1, int32_t L2, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1);
+    gpsig_params q = *p;
+    q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
+    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    const void *dX, *dX2 = nullptr;
+    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N1) * L1 * d, &dX));
+    if (X2) CHK(in_dev(c, B_IN1, X2, sizeof(double) * size_t(N2) * L2 * d, &dX2));
+    const int64_t Nc = X2 ? N2 : N1;
+    const size_t ob = sizeof(double) * seq_out_elems(p, N1, Nc, 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    CHK(seq_K_device(c, &q, true, dX, dX2, N1, Nc, L1, X2 ? L2 : L1, 1, dout, true));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_seq_diag_levels(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1);
+    gpsig_params q = *p;
+    q.num_features = d; q.num_lags = 0;
+    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    const int M1 = p->num_levels + 1;
+    const void* dX;
+    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * d, &dX));
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, sizeof(double) * size_t(N) * M1, &dout));
+    SeqPlanned pl;
+    CHK(plan_seq(c, &q, d, L, &pl));
+    const void* rec;
+    SeqGeom g;
+    CHK(make_records(c, &q, false, pl, dX, N, L, B_REC0, &rec, &g));
+    SeqRun r;
+    memset(&r, 0, sizeof(r));
+    r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
+    r.out = dout; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
+    CHK(launch_seq(c, &q, pl, r));
+    CHK(out_done(c, out, dout, sizeof(double) * size_t(N) * M1));
+    return finish(c);
+}
+
+int gpsig_tens_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    const void* dZ;
+    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
+    const size_t ob = sizeof(double) * size_t(T) * T * (p->num_levels + 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    gpsig_params q = *p;
+    q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
+    CHK(tens_gram_device(c, &q, true, dZ, T, increments, 1, dout));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_tens_vs_seq_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
+                             int32_t L, int32_t increments, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    const void *dZ, *dX;
+    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
+    CHK(in_dev(c, B_IN1, X, sizeof(double) * size_t(N) * L * d, &dX));
+    const size_t ob = sizeof(double) * size_t(T) * N * (p->num_levels + 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    gpsig_params q = *p;
+    q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
+    const void *ZT, *ZS;
+    CHK(prep_tensors(c, &q, false, dZ, T, E, &ZT, &ZS));
+    CHK(tens_vs_seq_device(c, &q, true, ZT, ZS, dX, T, N, L, increments, nullptr, nullptr, 1, dout));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_kernel_K(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2, int32_t L1,
+                   int32_t L2, int32_t return_levels, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features;
+    const void *dX, *dX2 = nullptr;
+    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N1) * L1 * d, &dX));
+    if (X2) CHK(in_dev(c, B_IN1, X2, sizeof(double) * size_t(N2) * L2 * d, &dX2));
+    const int64_t Nc = X2 ? N2 : N1;
+    const size_t ob = sizeof(double) * seq_out_elems(p, N1, Nc, return_levels);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    CHK(seq_K_device(c, p, false, dX, dX2, N1, Nc, L1, X2 ? L2 : L1, return_levels, dout, true));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_kernel_Kdiag(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int32_t return_levels, void* out) {
+    ENTER(c, p);
+    const int M1 = p->num_levels + 1;
+    const size_t ob = sizeof(double) * size_t(N) * (return_levels ? M1 : 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    const double* w;
+    CHK(upload_weights(c, p, &w));
+    void* tmp;
+    CHK(ensure(c, B_TMP0, sizeof(double) * size_t(N) * M1 + 8, &tmp));
+    if (p->normalization) {
+        // kernels.py:486-490: sigma * variances, no data touched
+        if (N > 0) {
+            hipLaunchKernelGGL(fill_kernel<double>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream, static_cast<double*>(tmp), N * M1, 1.0);
+            HIPCHK(c, hipGetLastError());
+        }
+    } else {
+        const void* dX;
+        CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
+        const int d_eff = p->num_features * (p->num_lags + 1);
+        SeqPlanned pl;
+        CHK(plan_seq(c, p, d_eff, L, &pl));
+        const void* rec;
+        SeqGeom g;
+        CHK(make_records(c, p, true, pl, dX, N, L, B_REC0, &rec, &g));
+        SeqRun r;
+        memset(&r, 0, sizeof(r));
+        r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
+        r.out = tmp; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
+        CHK(launch_seq(c, p, pl, r));
+    }
+    if (N > 0) {
+        hipLaunchKernelGGL(weight_levels_kernel<double>, dim3(grid_for(N)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(tmp), N, M1, w, return_levels ? 0 : 1, static_cast<double*>(dout));
+        HIPCHK(c, hipGetLastError());
+    }
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_kernel_K_tens(gpsig_ctx* c, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, int32_t return_levels, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    const void* dZ;
+    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
+    const size_t ob = sizeof(double) * size_t(T) * T * (return_levels ? p->num_levels + 1 : 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    CHK(tens_gram_device(c, p, false, dZ, T, increments, return_levels, dout));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_kernel_K_tens_vs_seq(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
+                               int32_t L, int32_t increments, int32_t return_levels, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    const void *dZ, *dX;
+    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
+    CHK(in_dev(c, B_IN1, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
+    const size_t ob = sizeof(double) * size_t(T) * N * (return_levels ? p->num_levels + 1 : 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    const void* fx = nullptr;
+    if (p->normalization) CHK(seq_diag_factors(c, p, dX, N, L, &fx));     // kernels.py:572-581
+    const double* w;
+    CHK(upload_weights(c, p, &w));
+    const void *ZT, *ZS;
+    CHK(prep_tensors(c, p, true, dZ, T, E, &ZT, &ZS));
+    CHK(tens_vs_seq_device(c, p, false, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dout));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_kernel_K_tens_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
+                                   int32_t L, int32_t increments, int32_t full_X_cov, int32_t return_levels, void* Kzz,
+                                   void* Kzx, void* Kxx) {
+    ENTER(c, p);
+    const int M1 = p->num_levels + 1;
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    const size_t lv = return_levels ? size_t(M1) : 1;
+    const void *dZ, *dX;
+    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
+    CHK(in_dev(c, B_IN1, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
+    const size_t bzz = sizeof(double) * size_t(T) * T * lv, bzx = sizeof(double) * size_t(T) * N * lv;
+    const size_t bxx = sizeof(double) * (full_X_cov ? size_t(N) * N : size_t(N)) * lv;
+    void *dzz, *dzx, *dxx;
+    CHK(out_dev(c, B_OUT0, Kzz, bzz, &dzz));
+    CHK(out_dev(c, B_OUT1, Kzx, bzx, &dzx));
+    CHK(out_dev(c, B_OUT2, Kxx, bxx, &dxx));
+    const double* w;
+    CHK(upload_weights(c, p, &w));
+    // Kzz: never normalised (kernels.py:623, :641/:665)
+    CHK(tens_gram_device(c, p, false, dZ, T, increments, return_levels, dzz));
+    // Kzx: divided by sqrt(diag_x + jitter) when normalising (kernels.py:638 / :660) -- with full_X_cov the
+    // diagonal of (Kxx + jitter*I) is the same number
+    const void* fx = nullptr;
+    if (p->normalization) CHK(seq_diag_factors(c, p, dX, N, L, &fx));
+    const void *ZT, *ZS;
+    CHK(prep_tensors(c, p, true, dZ, T, E, &ZT, &ZS));
+    CHK(tens_vs_seq_device(c, p, false, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dzx));
+    if (full_X_cov) {
+        CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, return_levels, dxx, true));   // kernels.py:630-640
+    } else {
+        void* tmp;
+        CHK(ensure(c, B_TMP0, sizeof(double) * size_t(N) * M1 + 8, &tmp));
+        if (p->normalization) {   // kernels.py:661
+            if (N > 0) {
+                hipLaunchKernelGGL(fill_kernel<double>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream, static_cast<double*>(tmp), N * M1, 1.0);
+                HIPCHK(c, hipGetLastError());
+            }
+        } else {                  // kernels.py:653, :663
+            const int d_eff = p->num_features * (p->num_lags + 1);
+            SeqPlanned pl;
+            CHK(plan_seq(c, p, d_eff, L, &pl));
+            const void* rec;
+            SeqGeom g;
+            CHK(make_records(c, p, true, pl, dX, N, L, B_REC0, &rec, &g));
+            SeqRun r;
+            memset(&r, 0, sizeof(r));
+            r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
+            r.out = tmp; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
+            CHK(launch_seq(c, p, pl, r));
+        }
+        if (N > 0) {
+            hipLaunchKernelGGL(weight_levels_kernel<double>, dim3(grid_for(N)), dim3(256), 0, c->stream,
+                               static_cast<const double*>(tmp), N, M1, w, return_levels ? 0 : 1, static_cast<double*>(dxx));
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    CHK(out_done(c, Kzz, dzz, bzz));
+    CHK(out_done(c, Kzx, dzx, bzx));
+    CHK(out_done(c, Kxx, dxx, bxx));
+    return finish(c);
+}
+
+int gpsig_kernel_K_seq_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
+                                  int32_t L1, int32_t L2, int32_t full_X2_cov, int32_t return_levels, void* Kxx, void* Kxx2,
+                                  void* Kx2x2) {
+    ENTER(c, p);
+    const int M1 = p->num_levels + 1, d = p->num_features;
+    const size_t lv = return_levels ? size_t(M1) : 1;
+    const void *dX, *dX2;
+    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N1) * L1 * d, &dX));
+    CHK(in_dev(c, B_IN1, X2, sizeof(double) * size_t(N2) * L2 * d, &dX2));
+    const size_t b11 = sizeof(double) * size_t(N1) * N1 * lv, b12 = sizeof(double) * size_t(N1) * N2 * lv;
+    const size_t b22 = sizeof(double) * (full_X2_cov ? size_t(N2) * N2 : size_t(N2)) * lv;
+    void *d11, *d12, *d22;
+    CHK(out_dev(c, B_OUT0, Kxx, b11, &d11));
+    CHK(out_dev(c, B_OUT1, Kxx2, b12, &d12));
+    CHK(out_dev(c, B_OUT2, Kx2x2, b22, &d22));
+    // Kxx (kernels.py:704, :709-712, :730/:755) == K(X)
+    CHK(seq_K_device(c, p, false, dX, nullptr, N1, N1, L1, L1, return_levels, d11, true));
+    // Kxx2 (kernels.py:705, :713, :727 / :750).  Reference quirk, reproduced: in the diagonal-only branch the
+    // X-side factor is applied twice (:713 then :750), i.e. 1/(diag_x + jitter) instead of 1/sqrt(.).
+    CHK(seq_K_device(c, p, false, dX, dX2, N1, N2, L1, L2, return_levels, d12, true, (p->normalization && !full_X2_cov) ? 1 : 0));
+    if (full_X2_cov) {
+        // kernels.py:719-732; :723-728 reference undefined names -- the evident intent (mirror of :709-712) == K(X2)
+        CHK(seq_K_device(c, p, false, dX2, nullptr, N2, N2, L2, L2, return_levels, d22, true));
+    } else {
+        const double* w;
+        CHK(upload_weights(c, p, &w));
+        void* tmp;
+        CHK(ensure(c, B_TMP0, sizeof(double) * size_t(N2) * M1 + 8, &tmp));
+        if (p->normalization) {   // kernels.py:751
+            if (N2 > 0) {
+                hipLaunchKernelGGL(fill_kernel<double>, dim3(grid_for(N2 * M1)), dim3(256), 0, c->stream, static_cast<double*>(tmp), N2 * M1, 1.0);
+                HIPCHK(c, hipGetLastError());
+            }
+        } else {                  // kernels.py:743, :753
+            SeqPlanned pl;
+            CHK(plan_seq(c, p, d * (p->num_lags + 1), L2, &pl));
+            const void* rec;
+            SeqGeom g;
+            CHK(make_records(c, p, true, pl, dX2, N2, L2, B_REC0, &rec, &g));
+            SeqRun r;
+            memset(&r, 0, sizeof(r));
+            r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N2; r.N2 = N2;
+            r.out = tmp; r.si = 1; r.sj = 0; r.sm = N2; r.pred = PRED_DIAG; r.timed = true;
+            CHK(launch_seq(c, p, pl, r));
+        }
+        if (N2 > 0) {
+            hipLaunchKernelGGL(weight_levels_kernel<double>, dim3(grid_for(N2)), dim3(256), 0, c->stream,
+                               static_cast<const double*>(tmp), N2, M1, w, return_levels ? 0 : 1, static_cast<double*>(d22));
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    CHK(out_done(c, Kxx, d11, b11));
+    CHK(out_done(c, Kxx2, d12, b12));
+    CHK(out_done(c, Kx2x2, d22, b22));
+    return finish(c);
+}
+
+}  // extern "C"

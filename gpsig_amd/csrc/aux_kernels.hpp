@@ -1,0 +1,320 @@
+// aux_kernels.hpp -- the small kernels around the pair recursion: input preparation (lengthscale
+// division, lags, increments, record layout), per-sequence normalisation factors, and the
+// inducing-tensor kernels (tensor-vs-sequence scans, tensor-vs-tensor products).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "seq_core.hpp"
+
+namespace gpsig {
+
+constexpr int MAX_FEATURES = 32;  // d (one lag copy)
+constexpr int MAX_LAGS = 8;
+
+// Scaling state of SignatureKernel (gpsig/kernels.py:343-398), by value in kernel arguments.
+struct ScaleParams {
+    int d_in;        // num_features
+    int num_lags;    // p
+    int has_ls;
+    double inv_unused;
+    double ls[MAX_FEATURES];
+    double lags[MAX_LAGS];
+    double gamma[MAX_LAGS + 1];
+    double jitter;
+    __host__ __device__ int d_eff() const { return d_in * (num_lags + 1); }
+};
+
+// x~[n][t][fe]: observation t of sequence n after add_lags_to_sequences (gpsig/lags.py:41-63), division by
+// the lengthscales (kernels.py:357-358) and the lag weights gamma (kernels.py:360-361).  fe = lag * d_in + f.
+template <typename T>
+__device__ __forceinline__ T scaled_point(const T* __restrict__ Xn, int L, int t, int fe, const ScaleParams& P) {
+    const int lag = fe / P.d_in, f = fe - lag * P.d_in;
+    T v;
+    if (lag == 0) {
+        v = Xn[int64_t(t) * P.d_in + f];
+    } else {
+        // lin_interp (gpsig/lags.py:7-38): left = the last grid time not later than the query (+jitter)
+        const T denom = T(L - 1);
+        const T tq = fmax(T(t) / denom - T(P.lags[lag - 1]), T(0));     // lags.py:56-57
+        int left = 0;
+        for (int i = L - 1; i >= 0; --i)
+            if (!(T(i) / denom - tq > T(P.jitter))) { left = i; break; }  // lags.py:20-22
+        const int right = left + 1 < L ? left + 1 : L - 1;              // lags.py:23 (never out of range for lags > 0)
+        const T xl = Xn[int64_t(left) * P.d_in + f], xr = Xn[int64_t(right) * P.d_in + f];
+        const T tl = T(left) / denom, tr = T(right) / denom;
+        v = xl + (tq - tl) * (xr - xl) / (tr - tl);                     // lags.py:33
+    }
+    if (P.has_ls) v = v / T(P.ls[f]);
+    if (P.num_lags > 0) v = v * T(P.gamma[lag]);
+    return v;
+}
+
+// Records for the seq-gram kernel (layout: seq_configs.hpp / SeqGeom).  One thread per (n, row, fe).
+// `out` must have been zero-filled (padding columns and the record tail stay zero).
+template <typename T>
+__global__ void prep_seq_records_kernel(const T* __restrict__ X, int64_t N, int L, ScaleParams P, int mode,
+                                        int difference, int rows, int RS, int64_t rec_elems, T* __restrict__ out) {
+    const int d_eff = P.d_eff();
+    const int64_t total = N * rows * d_eff;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int fe = int(idx % d_eff);
+        const int row = int((idx / d_eff) % rows);
+        const int64_t n = idx / (int64_t(d_eff) * rows);
+        const T* Xn = X + n * int64_t(L) * P.d_in;
+        T v = T(0);
+        if (mode == MODE_PT_DIFF) {
+            v = scaled_point<T>(Xn, L, row, fe, P);
+        } else if (row >= 1) {   // leading zero row
+            if (mode == MODE_INC && difference) v = scaled_point<T>(Xn, L, row, fe, P) - scaled_point<T>(Xn, L, row - 1, fe, P);
+            else v = scaled_point<T>(Xn, L, row - 1, fe, P);
+        }
+        out[n * rec_elems + int64_t(row) * RS + fe] = v;
+    }
+}
+
+// Time-major scaled observations for the tensor-vs-sequence kernel: XT[(t * d_eff + fe) * Npad + n].
+template <typename T>
+__global__ void prep_seq_timemajor_kernel(const T* __restrict__ X, int64_t N, int64_t Npad, int L, ScaleParams P,
+                                          T* __restrict__ out) {
+    const int d_eff = P.d_eff();
+    const int64_t total = int64_t(L) * d_eff * Npad;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t n = idx % Npad;
+        const int fe = int((idx / Npad) % d_eff);
+        const int t = int(idx / (Npad * d_eff));
+        out[idx] = n < N ? scaled_point<T>(X + n * int64_t(L) * P.d_in, L, t, fe, P) : T(0);
+    }
+}
+
+// Scaled inducing tensors (kernels.py:367-398).  In: Z (lt, T, E, d_eff) with E = 2 for increments else 1.
+// Out: ZT[((t * d_eff + fe) * lt + k) * E + e]  and  ZS[(t * lt + k) * E + e] = |z|^2.
+template <typename T>
+__global__ void prep_tensors_kernel(const T* __restrict__ Z, int lt, int64_t Tn, int E, ScaleParams P,
+                                    T* __restrict__ ZT, T* __restrict__ ZS) {
+    const int d_eff = P.d_eff();
+    const int64_t total = Tn * lt * E;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int e = int(idx % E);
+        const int k = int((idx / E) % lt);
+        const int64_t t = idx / (int64_t(E) * lt);
+        T ss = T(0);
+        for (int fe = 0; fe < d_eff; ++fe) {
+            const int lag = fe / P.d_in, f = fe - lag * P.d_in;
+            T v = Z[((int64_t(k) * Tn + t) * E + e) * d_eff + fe];
+            if (P.has_ls) {                                   // kernels.py:374-379 / :391-395: no lag weights without lengthscales
+                v = v / T(P.ls[f]);
+                if (P.num_lags > 0) v = v * T(P.gamma[lag]);
+            }
+            ZT[((t * d_eff + fe) * lt + k) * E + e] = v;
+            ss = fma(v, v, ss);
+        }
+        ZS[(t * lt + k) * E + e] = ss;
+    }
+}
+
+// fac[n][m] = w[m] / sqrt(dlev[n][m] + jitter)   (normalise)   or   w[m]   (dlev == nullptr);
+// squared == 1: w[m] / (dlev[n][m] + jitter)  -- the double division of kernels.py:713 + :750
+template <typename T>
+__global__ void factors_kernel(const T* __restrict__ dlev, int64_t N, int M1, const double* __restrict__ w, double jitter,
+                               int squared, T* __restrict__ fac) {
+    const int64_t total = N * M1;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int m = int(idx % M1);
+        const T wm = w ? T(w[m]) : T(1);
+        if (!dlev) fac[idx] = wm;
+        else if (squared) { const T s = sqrt(dlev[idx] + T(jitter)); fac[idx] = wm / s / s; }
+        else fac[idx] = wm / sqrt(dlev[idx] + T(jitter));
+    }
+}
+
+// out[idx] = sum_m in[m * stride + idx] * w[m]   or   out[m * stride + idx] = in[...] * w[m]
+template <typename T>
+__global__ void weight_levels_kernel(const T* __restrict__ in, int64_t stride, int M1, const double* __restrict__ w,
+                                     int sum_levels, T* __restrict__ out) {
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < stride; idx += int64_t(gridDim.x) * blockDim.x) {
+        T acc = T(0);
+        for (int m = 0; m < M1; ++m) {
+            const T v = in[m * stride + idx] * T(w[m]);
+            if (sum_levels) acc += v; else out[m * stride + idx] = v;
+        }
+        if (sum_levels) out[idx] = acc;
+    }
+}
+
+template <typename T>
+__global__ void fill_kernel(T* __restrict__ p, int64_t n, T v) {
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < n; idx += int64_t(gridDim.x) * blockDim.x) p[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inducing tensors vs sequences: SignatureKernel._K_tens_vs_seq + signature_kern_tens_vs_seq_first_order
+// (gpsig/kernels.py:313-340, gpsig/signature_algs.py:101-127) + the epilogue of K_tens_vs_seq
+// (kernels.py:572-588).  One lane per sequence, TT tensors per wave; the time axis is swept once with
+// the lt = M(M+1)/2 running sums of the level chains in registers:
+//     level i uses components k0 .. k0+i-1 (k0 = i(i-1)/2):
+//     u[k0+j] += dM[k0+j](tau) * u[k0+j-1]   (j = i-1 .. 1, using u from before this time step)
+//     u[k0]   += dM[k0](tau)                  ;  K_i = u[k0+i-1] after the last step
+// which is the exclusive-cumsum chain of signature_algs.py:120-125.  No cross-lane traffic; the
+// sequences are read time-major (coalesced over lanes), the tensor components are wave-uniform.
+struct TvsArgs {
+    const void* XT;     // (L, d_eff, Npad) scaled observations
+    const void* ZT;     // (T, d_eff, lt, E) scaled tensor components
+    const void* ZS;     // (T, lt, E) squared norms
+    int64_t N, Npad, Tn;
+    int32_t L, d_eff, kind, difference;
+    double p0, p1;
+    const void* fx;     // (N, M+1) per-sequence factors (1/sqrt(diag+jitter)) or NULL
+    const double* w;    // (M+1) level weights sigma*variances, or NULL (raw levels)
+    void* out;          // (T, N) or (M+1, T, N)
+    int32_t sum_levels;
+};
+
+template <typename T, int M, int TT, bool INCR>
+__global__ __launch_bounds__(64) void tens_vs_seq_kernel(const TvsArgs A) {
+    constexpr int LT = M * (M + 1) / 2;
+    constexpr int E = INCR ? 2 : 1;
+    const int lane = threadIdx.x;
+    const int64_t n = blockIdx.x * int64_t(64) + lane;
+    const int64_t t0 = blockIdx.y * int64_t(TT);
+    const T* __restrict__ XT = static_cast<const T*>(A.XT);
+    const T* __restrict__ ZT = static_cast<const T*>(A.ZT);
+    const T* __restrict__ ZS = static_cast<const T*>(A.ZS);
+    const int d = A.d_eff;
+    const T p0 = T(A.p0), p1 = T(A.p1);
+
+    T u[TT][LT], kprev[TT][LT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int k = 0; k < LT; ++k) { u[tt][k] = T(0); kprev[tt][k] = T(0); }
+
+    for (int tau = 0; tau < A.L; ++tau) {
+        T ip[TT][LT][E];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int k = 0; k < LT; ++k)
+#pragma unroll
+                for (int e = 0; e < E; ++e) ip[tt][k][e] = T(0);
+        T xs = T(0);
+        for (int f = 0; f < d; ++f) {
+            const T x = XT[(int64_t(tau) * d + f) * A.Npad + n];
+            xs = fma(x, x, xs);
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const int64_t t = (t0 + tt < A.Tn) ? t0 + tt : A.Tn - 1;
+                const T* __restrict__ z = ZT + (t * d + f) * (LT * E);     // wave-uniform
+#pragma unroll
+                for (int k = 0; k < LT; ++k)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) ip[tt][k][e] = fma(z[k * E + e], x, ip[tt][k][e]);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int64_t t = (t0 + tt < A.Tn) ? t0 + tt : A.Tn - 1;
+            const T* __restrict__ zs = ZS + t * (LT * E);
+            T dm[LT];
+#pragma unroll
+            for (int k = 0; k < LT; ++k) {
+                T kv;
+                if constexpr (INCR) {   // kernels.py:329-330: kappa(z[.,1], x) - kappa(z[.,0], x)
+                    kv = base_eval<T>(A.kind, ip[tt][k][1], zs[k * 2 + 1], xs, p0, p1) -
+                         base_eval<T>(A.kind, ip[tt][k][0], zs[k * 2], xs, p0, p1);
+                } else {
+                    kv = base_eval<T>(A.kind, ip[tt][k][0], zs[k], xs, p0, p1);
+                }
+                if (A.difference) { dm[k] = kv - kprev[tt][k]; kprev[tt][k] = kv; }   // signature_algs.py:114
+                else dm[k] = kv;
+            }
+            if (!(A.difference && tau == 0)) {
+#pragma unroll
+                for (int i = M; i >= 1; --i) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int k0 = i * (i - 1) / 2;
+#pragma unroll
+                    for (int j = i - 1; j >= 1; --j) u[tt][k0 + j] = fma(dm[k0 + j], u[tt][k0 + j - 1], u[tt][k0 + j]);
+                    u[tt][k0] += dm[k0];
+                }
+            }
+        }
+    }
+
+    if (n >= A.N) return;
+    const T* fx = A.fx ? static_cast<const T*>(A.fx) + n * (M + 1) : nullptr;
+    T* out = static_cast<T*>(A.out);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+        const int64_t t = t0 + tt;
+        if (t >= A.Tn) break;
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i <= M; ++i) {
+            T v = i == 0 ? T(1) : u[tt][i * (i - 1) / 2 + i - 1];
+            if (fx) v *= fx[i];
+            if (A.w) v *= T(A.w[i]);
+            if (A.sum_levels) acc += v;
+            else out[(int64_t(i) * A.Tn + t) * A.N + n] = v;
+        }
+        if (A.sum_levels) out[t * A.N + n] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inducing tensors vs inducing tensors: SignatureKernel._K_tens + tensor_kern (kernels.py:263-283,
+// signature_algs.py:76-99) + sigma*variances weighting (kernels.py:531-536).  One thread per (t, t').
+struct TensGramArgs {
+    const void* ZT;   // (T, d_eff, lt, E)
+    const void* ZS;   // (T, lt, E)
+    int64_t Tn;
+    int32_t M, d_eff, E, kind;
+    double p0, p1;
+    const double* w;  // (M+1) or NULL
+    void* out;        // (T, T) or (M+1, T, T)
+    int32_t sum_levels;
+};
+
+template <typename T>
+__global__ void tens_gram_kernel(const TensGramArgs A) {
+    const int64_t total = A.Tn * A.Tn;
+    const T* __restrict__ ZT = static_cast<const T*>(A.ZT);
+    const T* __restrict__ ZS = static_cast<const T*>(A.ZS);
+    T* out = static_cast<T*>(A.out);
+    const int lt = A.M * (A.M + 1) / 2, E = A.E, d = A.d_eff;
+    const T p0 = T(A.p0), p1 = T(A.p1);
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t t1 = idx / A.Tn, t2 = idx % A.Tn;
+        T acc = T(0);
+        int k = 0;
+        for (int i = 0; i <= A.M; ++i) {
+            T R = T(1);
+            for (int j = 0; j < i; ++j, ++k) {
+                T mk;
+                if (E == 1) {
+                    T ip = T(0);
+                    for (int f = 0; f < d; ++f) ip = fma(ZT[(t1 * d + f) * lt + k], ZT[(t2 * d + f) * lt + k], ip);
+                    mk = base_eval<T>(A.kind, ip, ZS[t1 * lt + k], ZS[t2 * lt + k], p0, p1);
+                } else {   // kernels.py:275-277
+                    T kv[2][2];
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) {
+                            T ip = T(0);
+                            for (int f = 0; f < d; ++f)
+                                ip = fma(ZT[((t1 * d + f) * lt + k) * 2 + a], ZT[((t2 * d + f) * lt + k) * 2 + b], ip);
+                            kv[a][b] = base_eval<T>(A.kind, ip, ZS[(t1 * lt + k) * 2 + a], ZS[(t2 * lt + k) * 2 + b], p0, p1);
+                        }
+                    mk = kv[1][1] + kv[0][0] - kv[1][0] - kv[0][1];
+                }
+                R = (j == 0) ? mk : mk * R;                       // signature_algs.py:92-96
+            }
+            T v = R;
+            if (A.w) v *= T(A.w[i]);
+            if (A.sum_levels) acc += v; else out[int64_t(i) * total + idx] = v;
+        }
+        if (A.sum_levels) out[idx] = acc;
+    }
+}
+
+}  // namespace gpsig

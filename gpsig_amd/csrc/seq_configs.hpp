@@ -21,13 +21,16 @@ struct SeqConfig {
     X(16, 2, 4, 4, true)  X(16, 2, 4, 5, true)  \
     X(16, 4, 4, 4, true)  X(16, 4, 4, 5, true)  \
     X(16, 4, 8, 4, true)  X(16, 4, 8, 5, true)
-#define GPSIG_SEQ_CONFIGS_GENERIC(X) \
+#define GPSIG_SEQ_CONFIGS_G16(X) \
     X(16, 1, 4, 8, false) X(16, 2, 4, 8, false) X(16, 4, 4, 8, false) X(16, 8, 4, 8, false) \
     X(16, 1, 8, 8, false) X(16, 2, 8, 8, false) X(16, 4, 8, 8, false) X(16, 8, 8, 8, false) \
-    X(16, 1, 16, 8, false) X(16, 2, 16, 8, false) X(16, 4, 16, 8, false)                    \
+    X(16, 1, 16, 8, false) X(16, 2, 16, 8, false) X(16, 4, 16, 8, false)
+#define GPSIG_SEQ_CONFIGS_G64(X) \
     X(64, 1, 4, 8, false) X(64, 2, 4, 8, false) X(64, 4, 4, 8, false) X(64, 8, 4, 8, false) \
     X(64, 1, 8, 8, false) X(64, 2, 8, 8, false) X(64, 4, 8, 8, false) X(64, 8, 8, 8, false) \
     X(64, 1, 16, 8, false) X(64, 2, 16, 8, false) X(64, 4, 16, 8, false)
+#define GPSIG_SEQ_CONFIGS_GENERIC(X) GPSIG_SEQ_CONFIGS_G16(X) GPSIG_SEQ_CONFIGS_G64(X)
+#define GPSIG_SEQ_CONFIGS_ALL(X) GPSIG_SEQ_CONFIGS_EXACT(X) GPSIG_SEQ_CONFIGS_GENERIC(X)
 
 // Pick the cheapest config that fits: y-side record rows Ry <= G*C, d <= D, levels M (== MMAX if exact,
 // <= MMAX otherwise).  Cost = lanes*columns*D actually paid per pair (G*C*D); ties go to the exact

@@ -25,6 +25,7 @@
 #include <cmath>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define GPSIG_HD __host__ __device__ __forceinline__
 #else
 #define GPSIG_HD inline

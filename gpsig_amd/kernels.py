@@ -1,0 +1,438 @@
+"""Signature kernels on MI355X: the call surface of ``gpsig.kernels`` (reference: gpsig/kernels.py).
+
+Same class names, constructor arguments, validation errors and array conventions as the reference's
+``SignatureKernel`` family; the work is done by the HIP library behind ``include/gpsig_hip.h``.
+TensorFlow / GPflow are not involved: hyper-parameters are plain NumPy attributes holding the
+constrained values (``variances`` (M+1,), ``sigma`` scalar, ``lengthscales`` (d,) or None, ...), and
+every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CUDA-out (device
+pointers, asynchronous on the current stream).
+
+Not built yet (raise NotImplementedError, never a silent fallback): ``order > 1`` on the GPU,
+``low_rank=True``, ``SignatureSpectral``, float32.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+try:  # torch is only plumbing: device memory and streams
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+JITTER = 1e-6   # gpflow.settings.jitter
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+class _Launch:
+    """Marshals one C-ABI call: pointer mode, contiguity, output allocation."""
+
+    def __init__(self, *arrays):
+        tens = [a for a in arrays if a is not None and _is_torch(a) and a.is_cuda]
+        self.device_mode = len(tens) > 0
+        if self.device_mode:
+            if any(a is not None and not (_is_torch(a) and a.is_cuda) for a in arrays):
+                raise ValueError("mixing CUDA tensors with host arrays in one call")
+            self.dev = tens[0].device
+            stream = torch.cuda.current_stream(self.dev).cuda_stream
+            self.ctx = _lib.context(self.dev.index or 0, stream)
+            self.ctx.set_pointer_mode(_lib.PTR_DEVICE)
+        else:
+            self.ctx = _lib.context(0, 0)
+            self.ctx.set_pointer_mode(_lib.PTR_HOST)
+        self.keep = []
+
+    def inp(self, a):
+        if a is None:
+            return None
+        if self.device_mode:
+            t = a.detach().to(torch.float64).contiguous()
+            self.keep.append(t)
+            return C.c_void_p(t.data_ptr())
+        t = np.ascontiguousarray(a.detach().cpu().numpy() if _is_torch(a) else a, dtype=np.float64)
+        self.keep.append(t)
+        return C.c_void_p(t.ctypes.data)
+
+    def out(self, shape):
+        if self.device_mode:
+            t = torch.empty(tuple(int(s) for s in shape), dtype=torch.float64, device=self.dev)
+            return t, C.c_void_p(t.data_ptr())
+        t = np.empty(tuple(int(s) for s in shape), dtype=np.float64)
+        return t, C.c_void_p(t.ctypes.data)
+
+
+def _shape(a):
+    return tuple(a.shape)
+
+
+class SignatureKernel:
+    """Reference: ``gpsig.kernels.SignatureKernel`` (gpsig/kernels.py:15-761).
+
+    # Args (as the reference, kernels.py:18-51)
+    :input_dim:      total size of one input row = len_examples * num_features
+    :num_features:   state-space dimension of the sequences
+    :num_levels:     truncation level M of the signature
+    :active_dims:    columns of the input that feed the kernel (GPflow ``Kernel._slice``); default all
+    :variances:      (M+1,) level variances
+    :lengthscales:   (num_features,) or None for no scaling
+    :order:          1..M; <=0 or >=M means M (kernels.py:57)
+    :normalization:  normalise each level (kernels.py:430-433, :455-469)
+    :difference:     difference the base-kernel tensor (signature_algs.py:25-26)
+    :num_lags:       None or a non-negative int (kernels.py:70-82)
+    :low_rank, num_components, rank_bound, sparsity: validated as the reference does; low_rank=True is not built
+    """
+    _base = None
+
+    def __init__(self, input_dim, num_features, num_levels, active_dims=None, variances=1, lengthscales=1, order=1,
+                 normalization=True, difference=True, num_lags=None, low_rank=False, num_components=50, rank_bound=None,
+                 sparsity='sqrt', name=None):
+        self.input_dim = int(input_dim)
+        self.active_dims = self._validate_active_dims(input_dim, active_dims)
+        self.name = name
+        self.num_features = num_features
+        self.num_levels = num_levels
+        self.len_examples = self._validate_number_of_features(input_dim, num_features)
+        self.order = num_levels if (order <= 0 or order >= num_levels) else order                 # kernels.py:57
+        if self.order != 1 and low_rank:
+            raise NotImplementedError('Higher-order algorithms not compatible with low-rank mode (yet).')   # :59-60
+        self.normalization = normalization
+        self.difference = difference
+        self.variances = self._validate_signature_param("variances", variances, num_levels + 1)   # :65
+        self.sigma = 1.0                                                                          # :66
+        self.low_rank, self.num_components, self.rank_bound, self.sparsity = self._validate_low_rank_params(
+            low_rank, num_components, rank_bound, sparsity)
+        if num_lags is None:
+            self.num_lags = 0
+        else:
+            if not isinstance(num_lags, int) or num_lags < 0:
+                raise ValueError('The variable num_lags most be a nonnegative integer or None.')  # :74-75
+            self.num_lags = int(num_lags)
+            if num_lags > 0:
+                self.lags = 0.1 * np.asarray(range(1, num_lags + 1), dtype=np.float64)           # :79
+                gamma = 1. / np.asarray(range(1, self.num_lags + 2), dtype=np.float64)           # :80
+                self.gamma = gamma / np.sum(gamma)                                               # :81
+        if lengthscales is not None:
+            self.lengthscales = self._validate_signature_param("lengthscales", lengthscales, self.num_features)  # :84-86
+        else:
+            self.lengthscales = None
+        self._base_params = (0.0, 0.0)
+
+    # ---- validators (kernels.py:94-133) ------------------------------------------------------
+    @staticmethod
+    def _validate_active_dims(input_dim, active_dims):
+        if active_dims is None:
+            return slice(int(input_dim))
+        if isinstance(active_dims, slice):
+            return active_dims
+        return np.asarray(active_dims, dtype=np.int64)
+
+    def _validate_number_of_features(self, input_dim, num_features):
+        if input_dim % num_features == 0:
+            return int(input_dim / num_features)
+        raise ValueError("The arguments num_features and input_dim are not consistent.")
+
+    def _validate_low_rank_params(self, low_rank, num_components, rank_bound, sparsity):
+        if low_rank is not None and low_rank == True:  # noqa: E712  (as the reference)
+            if not type(low_rank) == bool:
+                raise ValueError("Unknown low-rank argument: %s. It should be True of False." % low_rank)
+            if sparsity not in ['log', 'sqrt', 'lin']:
+                raise ValueError("Unknown sparsity argument %s. Possible values are 'sqrt', 'log', 'lin'" % sparsity)
+            if rank_bound is not None and rank_bound <= 0:
+                raise ValueError("The rank-bound in the low-rank algorithm must be either None or a positiv integer.")
+            if num_components is None or num_components <= 0:
+                raise ValueError("The number of components in the kernel approximation must be a positive integer.")
+            if rank_bound is None:
+                rank_bound = num_components
+        else:
+            low_rank = False
+        return low_rank, num_components, rank_bound, sparsity
+
+    def _validate_signature_param(self, name, value, length):
+        value = value * np.ones(length, dtype=np.float64)
+        correct_shape = () if length == 1 else (length,)
+        if np.asarray(value).squeeze().shape != correct_shape:
+            raise ValueError("shape of parameter {} is not what is expected ({})".format(name, length))
+        return value
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _params(self, keep):
+        if self._base is None:
+            raise NotImplementedError("SignatureKernel is abstract: use SignatureLinear, SignatureRBF, ...")
+        if self.low_rank:
+            raise NotImplementedError("low_rank=True (Nystrom + randomised Hadamard sketch) is not built on the GPU yet")
+        p = _lib.Params()
+        p.base_kernel = _lib.BASE[self._base]
+        p.dtype = _lib.F64
+        p.num_features, p.num_levels, p.order = int(self.num_features), int(self.num_levels), int(self.order)
+        p.difference, p.normalization, p.num_lags = int(bool(self.difference)), int(bool(self.normalization)), int(self.num_lags)
+        p.sigma, p.jitter = float(self.sigma), JITTER
+        bp = self._current_base_params()
+        for k in range(4):
+            p.base_params[k] = float(bp[k]) if k < len(bp) else 0.0
+
+        def host(v):
+            a = np.ascontiguousarray(v, dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_double))
+        p.variances = host(np.asarray(self.variances).reshape(-1))
+        p.lengthscales = host(np.asarray(self.lengthscales).reshape(-1)) if self.lengthscales is not None else None
+        if self.num_lags > 0:
+            p.lags, p.gamma = host(self.lags), host(self.gamma)
+        return p
+
+    def _current_base_params(self):
+        return self._base_params
+
+    def _slice(self, X, X2=None):
+        """GPflow ``Kernel._slice``: keep the active columns."""
+        def one(A):
+            if A is None:
+                return None
+            if isinstance(self.active_dims, slice):
+                return A[..., self.active_dims]
+            idx = torch.as_tensor(self.active_dims, device=A.device) if _is_torch(A) else self.active_dims
+            return A[..., idx]
+        return one(X), one(X2)
+
+    def _seq_dims(self, X):
+        n, width = _shape(X)[0], int(np.prod(_shape(X)[1:]))
+        if width % self.num_features != 0:
+            raise ValueError("input width %d is not a multiple of num_features=%d" % (width, self.num_features))
+        return n, width // self.num_features
+
+    def _tens_dims(self, Z, increments):
+        lt = self.num_levels * (self.num_levels + 1) // 2
+        shp = _shape(Z)
+        d_eff = self.num_features * (self.num_lags + 1)
+        want = (lt, shp[1], 2, d_eff) if increments else (lt, shp[1], d_eff)
+        if len(shp) != len(want) or shp != want:
+            raise ValueError("inducing tensors have shape %s, expected %s" % (shp, want))
+        return shp[1]
+
+    # ---- kernel evaluations ----------------------------------------------------------------------
+    def K(self, X, X2=None, presliced=False, return_levels=False, presliced_X=False, presliced_X2=False):
+        """Reference: kernels.py:401-476.  (N1, N2) or (M+1, N1, N2)."""
+        if presliced:
+            presliced_X = presliced_X2 = True
+        if not presliced_X:
+            X, _ = self._slice(X, None)
+        if not presliced_X2 and X2 is not None:
+            X2, _ = self._slice(X2, None)
+        L_ = _Launch(X, X2)
+        n1, l1 = self._seq_dims(X)
+        n2, l2 = self._seq_dims(X2) if X2 is not None else (n1, l1)
+        p = self._params(L_.keep)
+        out, optr = L_.out((self.num_levels + 1, n1, n2) if return_levels else (n1, n2))
+        L_.ctx.call("gpsig_kernel_K", p, L_.inp(X), L_.inp(X2), n1, n2, l1, l2, int(bool(return_levels)), optr)
+        return out
+
+    def Kdiag(self, X, presliced=False, return_levels=False):
+        """Reference: kernels.py:479-510.  (N,) or (M+1, N)."""
+        if not presliced:
+            X, _ = self._slice(X, None)
+        L_ = _Launch(X)
+        n, l = self._seq_dims(X)
+        p = self._params(L_.keep)
+        out, optr = L_.out((self.num_levels + 1, n) if return_levels else (n,))
+        L_.ctx.call("gpsig_kernel_Kdiag", p, L_.inp(X), n, l, int(bool(return_levels)), optr)
+        return out
+
+    def K_tens(self, Z, return_levels=False, increments=False):
+        """Reference: kernels.py:513-536.  (T, T) or (M+1, T, T); never normalised."""
+        L_ = _Launch(Z)
+        t = self._tens_dims(Z, increments)
+        p = self._params(L_.keep)
+        out, optr = L_.out((self.num_levels + 1, t, t) if return_levels else (t, t))
+        L_.ctx.call("gpsig_kernel_K_tens", p, L_.inp(Z), t, int(bool(increments)), int(bool(return_levels)), optr)
+        return out
+
+    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False, presliced=False):
+        """Reference: kernels.py:539-588.  (T, N) or (M+1, T, N); normalised on the sequence axis only."""
+        if not presliced:
+            X, _ = self._slice(X, None)
+        L_ = _Launch(Z, X)
+        t = self._tens_dims(Z, increments)
+        n, l = self._seq_dims(X)
+        p = self._params(L_.keep)
+        out, optr = L_.out((self.num_levels + 1, t, n) if return_levels else (t, n))
+        L_.ctx.call("gpsig_kernel_K_tens_vs_seq", p, L_.inp(Z), L_.inp(X), t, n, l, int(bool(increments)),
+                    int(bool(return_levels)), optr)
+        return out
+
+    def K_tens_n_seq_covs(self, Z, X, full_X_cov=False, return_levels=False, increments=False, presliced=False):
+        """Reference: kernels.py:591-671.  Returns (Kzz, Kzx, Kxx); Kxx is the diagonal unless full_X_cov."""
+        if not presliced:
+            X, _ = self._slice(X, None)
+        L_ = _Launch(Z, X)
+        t = self._tens_dims(Z, increments)
+        n, l = self._seq_dims(X)
+        p = self._params(L_.keep)
+        lv = (self.num_levels + 1,) if return_levels else ()
+        Kzz, pzz = L_.out(lv + (t, t))
+        Kzx, pzx = L_.out(lv + (t, n))
+        Kxx, pxx = L_.out(lv + ((n, n) if full_X_cov else (n,)))
+        L_.ctx.call("gpsig_kernel_K_tens_n_seq_covs", p, L_.inp(Z), L_.inp(X), t, n, l, int(bool(increments)),
+                    int(bool(full_X_cov)), int(bool(return_levels)), pzz, pzx, pxx)
+        return Kzz, Kzx, Kxx
+
+    def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False, presliced=False):
+        """Reference: kernels.py:674-761 (X = inducing sequences, X2 = data).  Returns (Kxx, Kxx2, Kx2x2).
+        The double division of Kxx2 by the X-side diagonal in the diagonal-only branch (:713 + :750) is
+        reproduced; the undefined names of :723-728 are read as the evident mirror of :709-712."""
+        if not presliced:
+            X2, _ = self._slice(X2, None)
+        L_ = _Launch(X, X2)
+        n1, l1 = self._seq_dims(X)
+        n2, l2 = self._seq_dims(X2)
+        p = self._params(L_.keep)
+        lv = (self.num_levels + 1,) if return_levels else ()
+        Kxx, p11 = L_.out(lv + (n1, n1))
+        Kxx2, p12 = L_.out(lv + (n1, n2))
+        Kx2x2, p22 = L_.out(lv + ((n2, n2) if full_X2_cov else (n2,)))
+        L_.ctx.call("gpsig_kernel_K_seq_n_seq_covs", p, L_.inp(X), L_.inp(X2), n1, n2, l1, l2, int(bool(full_X2_cov)),
+                    int(bool(return_levels)), p11, p12, p22)
+        return Kxx, Kxx2, Kx2x2
+
+    # ---- the signature_algs.py layer: unnormalised level tensors -----------------------------------
+    def _K_seq(self, X, X2=None):
+        """Reference: kernels.py:208-237 on already scaled (N, L, d') sequences -> (M+1, N1, N2)."""
+        L_ = _Launch(X, X2)
+        n1, l1 = _shape(X)[0], _shape(X)[1]
+        n2, l2 = (_shape(X2)[0], _shape(X2)[1]) if X2 is not None else (n1, l1)
+        p = self._params(L_.keep)
+        out, optr = L_.out((self.num_levels + 1, n1, n2))
+        L_.ctx.call("gpsig_seq_gram_levels", p, L_.inp(X), L_.inp(X2), n1, n2, l1, l2, optr)
+        return out
+
+    def _K_seq_diag(self, X):
+        """Reference: kernels.py:188-205 -> (M+1, N)."""
+        L_ = _Launch(X)
+        n, l = _shape(X)[0], _shape(X)[1]
+        p = self._params(L_.keep)
+        out, optr = L_.out((self.num_levels + 1, n))
+        L_.ctx.call("gpsig_seq_diag_levels", p, L_.inp(X), n, l, optr)
+        return out
+
+    def _K_tens(self, Z, increments=False):
+        """Reference: kernels.py:263-283 on already scaled tensors -> (M+1, T, T)."""
+        L_ = _Launch(Z)
+        t = _shape(Z)[1]
+        p = self._params(L_.keep)
+        out, optr = L_.out((self.num_levels + 1, t, t))
+        L_.ctx.call("gpsig_tens_gram_levels", p, L_.inp(Z), t, int(bool(increments)), optr)
+        return out
+
+    def _K_tens_vs_seq(self, Z, X, increments=False):
+        """Reference: kernels.py:313-340 on already scaled inputs -> (M+1, T, N)."""
+        L_ = _Launch(Z, X)
+        t, n, l = _shape(Z)[1], _shape(X)[0], _shape(X)[1]
+        p = self._params(L_.keep)
+        out, optr = L_.out((self.num_levels + 1, t, n))
+        L_.ctx.call("gpsig_tens_vs_seq_levels", p, L_.inp(Z), L_.inp(X), t, n, l, int(bool(increments)), optr)
+        return out
+
+    # ---- numpy-facing wrappers (kernels.py:141-186; GPflow autoflow in the reference) --------------------
+    def compute_K(self, X, Y):
+        return self.K(X, Y)
+
+    def compute_K_symm(self, X):
+        return self.K(X)
+
+    def compute_K_level_diags(self, X):
+        return self.Kdiag(X, return_levels=True)
+
+    def compute_K_levels(self, X, X2):
+        return self.K(X, X2, return_levels=True)
+
+    def compute_Kdiag(self, X):
+        return self.Kdiag(X)
+
+    def compute_K_tens(self, Z):
+        return self.K_tens(Z, return_levels=False)
+
+    def compute_K_tens_vs_seq(self, Z, X):
+        return self.K_tens_vs_seq(Z, X, return_levels=False)
+
+    def compute_K_incr_tens(self, Z):
+        return self.K_tens(Z, increments=True, return_levels=False)
+
+    def compute_K_incr_tens_vs_seq(self, Z, X):
+        return self.K_tens_vs_seq(Z, X, increments=True, return_levels=False)
+
+
+class SignatureLinear(SignatureKernel):
+    """Identity state-space embedding (kernels.py:786-806)."""
+    _base = "linear"
+
+
+class SignatureCosine(SignatureKernel):
+    """Cosine similarity as state-space kernel (kernels.py:808-828)."""
+    _base = "cosine"
+
+
+class SignaturePoly(SignatureKernel):
+    """Polynomial state-space kernel (x.y + gamma)^degree (kernels.py:831-848)."""
+    _base = "poly"
+
+    def __init__(self, input_dim, num_features, num_levels, gamma=1, degree=3, **kwargs):
+        SignatureKernel.__init__(self, input_dim, num_features, num_levels, **kwargs)
+        if self.num_lags > 0:
+            # the reference stores the offset in self.gamma, overwriting the lag weights of kernels.py:82 (:837)
+            raise NotImplementedError("SignaturePoly with num_lags > 0: the reference overwrites the lag weights (kernels.py:82 vs :837)")
+        self.gamma = float(gamma)
+        self.degree = float(degree)
+
+    def _current_base_params(self):
+        return (float(self.gamma), float(self.degree))
+
+
+class SignatureRBF(SignatureKernel):
+    """Gaussian state-space kernel exp(-|x-y|^2/2) on the scaled inputs (kernels.py:850-864)."""
+    _base = "rbf"
+
+
+SignatureGauss = SignatureRBF
+
+
+class SignatureMix(SignatureKernel):
+    """mixing * RBF + (1 - mixing) * linear (kernels.py:870-892)."""
+    _base = "mix"
+
+    def __init__(self, input_dim, num_features, num_levels, **kwargs):
+        SignatureKernel.__init__(self, input_dim, num_features, num_levels, **kwargs)
+        self.mixing = 0.5
+
+    def _current_base_params(self):
+        return (float(self.mixing), 0.0)
+
+
+class SignatureSpectral(SignatureKernel):
+    """Spectral-mixture state-space kernels (kernels.py:894-942) are not built on the GPU."""
+
+    def __init__(self, input_dim, num_features, num_levels, family='gauss', Q=5, **kwargs):
+        if family not in ('exp', 'exponential', 'gauss', 'gaussian', 'rbf', 'mixed', 'mix'):
+            raise ValueError("Unrecognized spectral family name.")
+        raise NotImplementedError("SignatureSpectral is not built on the GPU yet")
+
+
+class SignatureMatern12(SignatureKernel):
+    """exp(-r) (kernels.py:944-958)."""
+    _base = "matern12"
+
+
+SignatureLaplace = SignatureMatern12
+SignatureExponential = SignatureMatern12
+
+
+class SignatureMatern32(SignatureKernel):
+    """(1 + sqrt(3) r) exp(-sqrt(3) r) (kernels.py:964-977)."""
+    _base = "matern32"
+
+
+class SignatureMatern52(SignatureKernel):
+    """(1 + sqrt(5) r + 5/3 r^2) exp(-sqrt(5) r) (kernels.py:981-993)."""
+    _base = "matern52"

@@ -1,0 +1,105 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, refuses to run without a device (no CPU fallback), and the Python surface validates its
+arguments like the reference does.  No GPU compute here."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gpsig_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "gpsig_hip.h")).read()
+    declared = set(re.findall(r"\b(gpsig_[a-z_A-Z0-9]+)\s*\(", header)) - {"gpsig_ctx"}
+    assert declared == set(lib.ALL_SYMBOLS), "include/gpsig_hip.h and gpsig_amd/_lib.py disagree"
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (gpsig_\w+)", nm))
+    assert declared <= exported, declared - exported
+    assert lib.load().gpsig_abi_version() == 1
+
+
+def test_params_struct_matches_header_layout(lib):
+    import ctypes as C
+    # 8 int32, 2 double, 4 double, 4 pointers
+    assert C.sizeof(lib.Params) == 8 * 4 + 2 * 8 + 4 * 8 + 4 * 8
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from gpsig_amd import kernels
+    k = kernels.SignatureLinear(12, 3, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        k.compute_K_symm(np.zeros((2, 12)))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gpsig_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+                assert "emu_" not in src, f"{f} mentions the emulator"
+
+
+def test_constructor_validation_matches_reference():
+    from gpsig_amd import kernels as K
+    with pytest.raises(ValueError, match="not consistent"):
+        K.SignatureLinear(10, 3, 2)                                   # kernels.py:98-101
+    with pytest.raises(ValueError, match="num_lags"):
+        K.SignatureLinear(9, 3, 2, num_lags=-1)                       # kernels.py:74-75
+    with pytest.raises(ValueError, match="num_lags"):
+        K.SignatureLinear(9, 3, 2, num_lags=1.5)
+    with pytest.raises(ValueError, match="shape of parameter variances"):
+        K.SignatureLinear(9, 3, 2, variances=np.ones((3, 1)))         # kernels.py:129-132
+    with pytest.raises(ValueError, match="shape of parameter lengthscales"):
+        K.SignatureLinear(9, 3, 2, lengthscales=np.ones((3, 1)))
+    with pytest.raises(ValueError):
+        K.SignatureLinear(9, 3, 2, variances=np.ones(5))              # numpy broadcast error, as in the reference (:129)
+    with pytest.raises(ValueError, match="sparsity"):
+        K.SignatureLinear(9, 3, 2, low_rank=True, sparsity="cube")    # kernels.py:112-113
+    with pytest.raises(ValueError, match="rank-bound"):
+        K.SignatureLinear(9, 3, 2, low_rank=True, rank_bound=0)       # kernels.py:114-115
+    with pytest.raises(ValueError, match="number of components"):
+        K.SignatureLinear(9, 3, 2, low_rank=True, num_components=0)   # kernels.py:116-117
+    with pytest.raises(NotImplementedError):
+        K.SignatureLinear(9, 3, 3, order=2, low_rank=True)            # kernels.py:59-60
+    with pytest.raises(ValueError, match="spectral family"):
+        K.SignatureSpectral(9, 3, 2, family="nope")                   # kernels.py:909-910
+    k = K.SignatureRBF(9, 3, 4, order=-1)
+    assert k.order == 4 and K.SignatureRBF(9, 3, 4, order=9).order == 4 and K.SignatureRBF(9, 3, 4).order == 1  # :57
+    assert k.variances.shape == (5,) and k.lengthscales.shape == (3,) and k.sigma == 1.0
+    assert K.SignatureRBF(9, 3, 4, lengthscales=None).lengthscales is None
+    k = K.SignatureRBF(9, 3, 2, num_lags=2)
+    np.testing.assert_allclose(k.lags, [0.1, 0.2])                    # kernels.py:79
+    np.testing.assert_allclose(k.gamma, np.array([1, 1 / 2, 1 / 3]) / (1 + 1 / 2 + 1 / 3))   # :80-81
+    assert K.SignatureGauss is K.SignatureRBF and K.SignatureLaplace is K.SignatureMatern12 is K.SignatureExponential
+
+
+def test_inducing_classes_validate_like_reference():
+    from gpsig_amd import inducing_variables as IV
+    M = 3
+    Z = np.zeros((6, 5, 2))
+    f = IV.InducingTensors(Z, M)
+    assert len(f) == 5 and f.len_tensors == 6 and not f.increments
+    with pytest.raises(AssertionError):
+        IV.InducingTensors(np.zeros((5, 5, 2)), M)                    # inducing_variables.py:40
+    with pytest.raises(AssertionError):
+        IV.InducingTensors(Z, M, increments=True)                     # :42-43
+    f = IV.InducingTensors(np.zeros((6, 5, 2, 2)), M, increments=True, learn_weights=True)
+    assert f.W.shape == (M, 5, 5)                                     # :26
+    s = IV.InducingSequences(np.zeros((4, 7, 2)), M, learn_weights=True)
+    assert len(s) == 4 and s.len_inducing == 7 and s.W.shape == (M, 4, 4)
