@@ -79,19 +79,22 @@ struct SeqLane {
     T kprev[C];     // kappa(previous x point, owned y columns)
     T kleft;        // kappa(previous x point, last column of the left neighbour)
 
+    // Pair boundary.  Only the accumulators are cleared: s[] and qold[] are hand-over words that the RIGHT
+    // neighbour still has to read during this very step (it is one lattice row behind), and both are
+    // rewritten by this lane's own step before anyone reads them again.
     GPSIG_HD void reset() {
 #pragma unroll
-        for (int m = 0; m < NQ; ++m) {
+        for (int m = 0; m < NQ; ++m)
 #pragma unroll
             for (int r = 0; r < C; ++r) q[m][r] = T(0);
-            qold[m] = T(0);
-        }
-#pragma unroll
-        for (int m = 0; m < MMAX; ++m) s[m] = T(0);
         ktop = T(0);
     }
     GPSIG_HD void init() {
         reset();
+#pragma unroll
+        for (int m = 0; m < NQ; ++m) qold[m] = T(0);
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m) s[m] = T(0);
 #pragma unroll
         for (int r = 0; r < C; ++r) { kprev[r] = T(0); y2[r] = T(0); }
         kleft = T(0);

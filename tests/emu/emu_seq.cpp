@@ -62,15 +62,10 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
             if (k_u + 1 < nx) { stage(k_u + 1, slot_next); if (++slot_next == nslot) slot_next = 0; }
         }
         if (++a_u == R1) { a_u = 0; ++k_u; }
-        // snapshot of every lane's hand-over registers before anyone steps
-        NbrSnapshot<T, MMAX> snap[64];
-        for (int lane = 0; lane < 64; ++lane) {
-            const int lam = lane & (G - 1);
-            NbrSnapshot<T, MMAX>& S = snap[lane];
-            for (int m = 0; m < MMAX; ++m) S.s[m] = lam ? L[lane - 1].s[m] : T(0);
-            for (int m = 0; m < NbrSnapshot<T, MMAX>::NQ; ++m) S.qold[m] = lam ? L[lane - 1].qold[m] : T(0);
-            S.klast = lam ? L[lane - 1].kprev[C - 1] : T(0);
-        }
+        // Order of events inside one step of the real wave: (1) the pair-boundary block (emit + reset) runs for
+        // the lanes that sit on a boundary, (2) every lane reads its left neighbour's hand-over registers (DPP
+        // shifts issued inside seq_step, before those registers are rewritten), (3) arithmetic.  The snapshot
+        // therefore has to be taken AFTER the boundary blocks of all lanes.
         for (int lane = 0; lane < 64; ++lane) {
             const int lam = lane & (G - 1);
             if (ctl[lane].boundary()) {
@@ -81,6 +76,16 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
                 }
                 L[lane].reset();
             }
+        }
+        NbrSnapshot<T, MMAX> snap[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            const int lam = lane & (G - 1);
+            NbrSnapshot<T, MMAX>& S = snap[lane];
+            for (int m = 0; m < MMAX; ++m) S.s[m] = lam ? L[lane - 1].s[m] : T(0);
+            for (int m = 0; m < NbrSnapshot<T, MMAX>::NQ; ++m) S.qold[m] = lam ? L[lane - 1].qold[m] : T(0);
+            S.klast = lam ? L[lane - 1].kprev[C - 1] : T(0);
+        }
+        for (int lane = 0; lane < 64; ++lane) {
             const bool act = ctl[lane].active(nx);
             const T* rowp = act ? ring.data() + size_t(ctl[lane].slot) * A.slot_elems + ctl[lane].a * RS : zero_row.data();
             T xr[D];
