@@ -285,6 +285,7 @@ struct SeqRun {
     double jitter_diag;
     int sum_levels, pred, mirror;
     bool timed;
+    int64_t y_begin, y_end;   // y-block range (0, 0) = all
 };
 
 int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const SeqRun& r) {
@@ -298,7 +299,8 @@ int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const 
     if (max_run < 8) max_run = 8;
     if (max_run > 256) max_run = 256;
     if (c->max_run > 0) max_run = c->max_run;
-    c->host_tasks = seq_build_tasks(r.N1, r.N2, ypb, r.pred, int(max_run), c->shard_i, c->shard_n);
+    c->host_tasks = seq_build_tasks(r.N1, r.N2, ypb, r.pred, int(max_run), c->shard_i, c->shard_n, r.y_begin,
+                                    r.y_end > 0 ? r.y_end : -1);
     const int ntasks = int(c->host_tasks.size());
     if (ntasks == 0) return GPSIG_OK;
     void* dt;
@@ -386,7 +388,8 @@ int side_factors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const 
 // Core of K / _K_seq on device pointers.  raw: no scaling, no normalisation, no weights (levels out).
 // x_squared: X-side factor 1/(diag+jitter) instead of 1/sqrt(diag+jitter) (K_seq_n_seq_covs quirk, kernels.py:713+:750).
 int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, const void* X2, int64_t N1, int64_t N2,
-                 int L1, int L2, int return_levels, void* out, bool timed, int x_squared = 0) {
+                 int L1, int L2, int return_levels, void* out, bool timed, int x_squared = 0, int64_t row_begin = 0,
+                 int64_t row_end = 0) {
     if (L1 < 1 || L2 < 1) return fail(c, GPSIG_ERR_INVALID, "sequence length must be >= 1");
     const bool sym = X2 == nullptr;
     const int M1 = p->num_levels + 1;
@@ -432,6 +435,14 @@ int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, c
     r.pred = sym ? PRED_CIRCULANT : PRED_ALL;
     r.mirror = sym ? 1 : 0;
     r.timed = timed;
+    if (row_end > 0) {   // owned-row block of the symmetric Gram: row = y index, no mirror, block-local row offset
+        r.xrec = rec1; r.yrec = rec1; r.gx = g1; r.gy = g1; r.N1 = N1;
+        r.N2 = row_end;          // y indices >= row_end belong to the next block: never loaded, never emitted
+        r.si = 1; r.sj = N1; r.ax = fa; r.by = fb; r.mirror = 0;
+        r.y_begin = row_begin; r.y_end = row_end;
+        r.out = static_cast<double*>(out) - row_begin * N1;
+        return launch_seq(c, p, pl, r);
+    }
     if (!swap) {   // x = X (rows of the output), y = X2 (columns)
         r.xrec = rec1; r.yrec = rec2; r.gx = g1; r.gy = g2; r.N1 = N1; r.N2 = Ncols;
         r.si = Ncols; r.sj = 1; r.ax = fa; r.by = fb;
@@ -724,6 +735,41 @@ int gpsig_kernel_K(gpsig_ctx* c, const gpsig_params* p, const void* X, const voi
     CHK(out_dev(c, B_OUT0, out, ob, &dout));
     CHK(seq_K_device(c, p, false, dX, dX2, N1, Nc, L1, X2 ? L2 : L1, return_levels, dout, true));
     CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_kernel_K_symm_rows(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int64_t row_begin,
+                             int64_t row_end, void* out_rows) {
+    ENTER(c, p);
+    if (row_begin < 0 || row_end > N || row_begin > row_end || ((row_begin % 4) != 0 && row_begin != row_end))
+        return fail(c, GPSIG_ERR_INVALID, "bad row range [%lld, %lld) of %lld (row_begin must be a multiple of 4)",
+                    (long long)row_begin, (long long)row_end, (long long)N);
+    const void* dX;
+    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
+    const size_t ob = sizeof(double) * size_t(row_end - row_begin) * N;
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out_rows, ob, &dout));
+    if (row_end > row_begin) CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, 0, dout, true, 0, row_begin, row_end));
+    CHK(out_done(c, out_rows, dout, ob));
+    return finish(c);
+}
+
+int gpsig_symmetrize_owned_rows(gpsig_ctx* c, int32_t dtype, const void* half, int64_t N, void* out) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "only float64 is built in this round");
+    if (half == out) return fail(c, GPSIG_ERR_INVALID, "symmetrize needs distinct buffers");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t b = sizeof(double) * size_t(N) * N;
+    const void* dh;
+    CHK(in_dev(c, B_IN0, half, b, &dh));
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, b, &dout));
+    if (N > 0) {
+        hipLaunchKernelGGL(symmetrize_owned_rows_kernel<double>, dim3(grid_for(N * N)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(dh), N, static_cast<double*>(dout));
+        HIPCHK(c, hipGetLastError());
+    }
+    CHK(out_done(c, out, dout, b));
     return finish(c);
 }
 

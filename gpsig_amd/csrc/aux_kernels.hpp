@@ -143,6 +143,20 @@ __global__ void weight_levels_kernel(const T* __restrict__ in, int64_t stride, i
     }
 }
 
+// Full symmetric matrix from stacked owned-row blocks (see gpsig_kernel_K_symm_rows): the ownership rule is the
+// emission predicate of the seq-gram kernel (PRED_CIRCULANT in seq_args.hpp) with i = column, j = row.
+template <typename T>
+__global__ void symmetrize_owned_rows_kernel(const T* __restrict__ half, int64_t N, T* __restrict__ out) {
+    const int64_t total = N * N, H = N / 2;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t r = idx / N, c = idx - r * N;
+        int64_t dlt = r - c;
+        if (dlt < 0) dlt += N;
+        const bool owned = dlt < H || (dlt == H && ((N & 1) || c < r));
+        out[idx] = owned ? half[idx] : half[c * N + r];
+    }
+}
+
 template <typename T>
 __global__ void fill_kernel(T* __restrict__ p, int64_t n, T v) {
     for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < n; idx += int64_t(gridDim.x) * blockDim.x) p[idx] = v;

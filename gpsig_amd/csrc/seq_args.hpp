@@ -97,8 +97,9 @@ inline int seq_ring_depth(int G, int R1) { return 2 + (G - 1 + R1 - 1) / R1; }
 // [y0 - N/2, y0 + ypb) taken modulo N, so every block has the same amount of work.  PRED_DIAG: the
 // block-diagonal only.  Runs are cut into pieces of at most `max_run` x's; shard (index, count)
 // keeps every count-th task (tasks are independent).
+// [y_begin, y_end): restrict to the y blocks of that range (y_begin a multiple of ypb); (0, -1) = all.
 inline std::vector<SeqTask> seq_build_tasks(int64_t N1, int64_t N2, int ypb, int pred, int max_run,
-                                            int shard_index, int shard_count) {
+                                            int shard_index, int shard_count, int64_t y_begin = 0, int64_t y_end = -1) {
     std::vector<SeqTask> t;
     int64_t counter = 0;
     auto push = [&](int64_t y0, int64_t x0, int64_t nx) {
@@ -109,7 +110,8 @@ inline std::vector<SeqTask> seq_build_tasks(int64_t N1, int64_t N2, int ypb, int
             if ((counter++ % shard_count) == shard_index) t.push_back(SeqTask{int32_t(y0), int32_t(xs), int32_t(n)});
         }
     };
-    for (int64_t y0 = 0; y0 < N2; y0 += ypb) {
+    if (y_end < 0 || y_end > N2) y_end = N2;
+    for (int64_t y0 = y_begin; y0 < y_end; y0 += ypb) {
         if (pred == PRED_ALL) {
             push(y0, 0, N1);
         } else if (pred == PRED_DIAG) {

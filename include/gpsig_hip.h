@@ -114,6 +114,16 @@ int gpsig_tens_vs_seq_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* 
 /* SignatureKernel.K (kernels.py:401-476).  out: (N1, N2), or (M+1, N1, N2) if return_levels. */
 int gpsig_kernel_K(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2,
                    int64_t N1, int64_t N2, int32_t L1, int32_t L2, int32_t return_levels, void* out);
+/* Row-block form of the symmetric K(X) for multi-GPU runs (no reference analogue: the reference is single
+ * device).  Every unordered pair {i, j} of the N sequences is owned by exactly one row: row j owns the
+ * columns i with (j - i) mod N in [0, N/2] (ties at N/2, N even, go to the smaller index as column).  A rank
+ * computes the owned entries of rows [row_begin, row_end) -- row_begin a multiple of 4 -- into `out_rows`,
+ * a (row_end - row_begin, N) block; entries it does not own are left untouched.  The blocks of all ranks,
+ * stacked, are turned into the full symmetric matrix by gpsig_symmetrize_owned_rows. */
+int gpsig_kernel_K_symm_rows(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L,
+                             int64_t row_begin, int64_t row_end, void* out_rows);
+/* out[r][c] = half[r][c] if row r owns column c, else half[c][r].  half, out: (N, N), distinct buffers. */
+int gpsig_symmetrize_owned_rows(gpsig_ctx* ctx, int32_t dtype, const void* half, int64_t N, void* out);
 /* SignatureKernel.Kdiag (kernels.py:479-510).  out: (N,) or (M+1, N). */
 int gpsig_kernel_Kdiag(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L,
                        int32_t return_levels, void* out);

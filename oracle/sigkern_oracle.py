@@ -39,6 +39,8 @@ JITTER = 1e-6  # gpflow.settings.jitter == settings.numerics.jitter_level (GPflo
 # ---------------------------------------------------------------------------
 def _excumsum(A, axis):
     """tf.cumsum(A, exclusive=True, axis=axis)."""
+    if A.shape[axis] == 0:
+        return A.copy()
     out = np.cumsum(A, axis=axis)
     out = np.roll(out, 1, axis=axis)
     idx = [slice(None)] * A.ndim

@@ -131,8 +131,8 @@ int emu_ring_depth(int G, int R1) { return seq_ring_depth(G, R1); }
 
 // returns the number of tasks; writes at most cap of them
 int emu_build_tasks(int64_t N1, int64_t N2, int ypb, int pred, int max_run, int shard_index, int shard_count,
-                    SeqTask* out, int cap) {
-    std::vector<SeqTask> t = seq_build_tasks(N1, N2, ypb, pred, max_run, shard_index, shard_count);
+                    int64_t y_begin, int64_t y_end, SeqTask* out, int cap) {
+    std::vector<SeqTask> t = seq_build_tasks(N1, N2, ypb, pred, max_run, shard_index, shard_count, y_begin, y_end);
     for (size_t k = 0; k < t.size() && int(k) < cap; ++k) out[k] = t[k];
     return int(t.size());
 }

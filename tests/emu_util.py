@@ -49,7 +49,7 @@ def lib():
         _lib = C.CDLL(so)
         _lib.emu_seq_gram.argtypes = [C.c_int] * 6 + [C.POINTER(SeqGramArgs), C.c_int]
         _lib.emu_build_tasks.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                         C.POINTER(SeqTask), C.c_int]
+                                         C.c_int64, C.c_int64, C.POINTER(SeqTask), C.c_int]
     return _lib
 
 
@@ -82,16 +82,16 @@ def build_records(Xs, geom, difference, D):
     return rec
 
 
-def tasks_for(N1, N2, ypb, pred, max_run=64, shard=(0, 1)):
-    n = lib().emu_build_tasks(N1, N2, ypb, pred, max_run, shard[0], shard[1], None, 0)
+def tasks_for(N1, N2, ypb, pred, max_run=64, shard=(0, 1), yrange=(0, -1)):
+    n = lib().emu_build_tasks(N1, N2, ypb, pred, max_run, shard[0], shard[1], yrange[0], yrange[1], None, 0)
     arr = (SeqTask * max(n, 1))()
-    lib().emu_build_tasks(N1, N2, ypb, pred, max_run, shard[0], shard[1], arr, n)
+    lib().emu_build_tasks(N1, N2, ypb, pred, max_run, shard[0], shard[1], yrange[0], yrange[1], arr, n)
     return arr, n
 
 
 def run(cfg, geom_x, geom_y, xrec, yrec, N1, N2, M, kind, p0, p1, out, si, sj, sm, ax, by, jitter_diag, sum_levels,
-        pred, mirror, max_run=64, shard=(0, 1)):
-    tasks, nt = tasks_for(N1, N2, 64 // cfg["G"], pred, max_run, shard)
+        pred, mirror, max_run=64, shard=(0, 1), yrange=(0, -1), out_offset=0):
+    tasks, nt = tasks_for(N1, N2, 64 // cfg["G"], pred, max_run, shard, yrange)
     A = SeqGramArgs()
     A.xrec, A.yrec, A.tasks = xrec.ctypes.data, yrec.ctypes.data, C.addressof(tasks)
     A.N1, A.N2 = N1, N2
@@ -100,7 +100,7 @@ def run(cfg, geom_x, geom_y, xrec, yrec, N1, N2, M, kind, p0, p1, out, si, sj, s
     A.nslot = lib().emu_ring_depth(cfg["G"], geom_x["rows"])
     A.slot_elems = geom_x["rec_elems"]
     A.kind, A.p0, A.p1 = kind, p0, p1
-    A.out, A.si, A.sj, A.sm = out.ctypes.data, si, sj, sm
+    A.out, A.si, A.sj, A.sm = out.ctypes.data + 8 * out_offset, si, sj, sm
     A.ax = ax.ctypes.data if ax is not None else None
     A.by = by.ctypes.data if by is not None else None
     A.jitter_diag, A.sum_levels, A.pred, A.mirror, A.use_glds = jitter_diag, int(sum_levels), pred, int(mirror), 0
@@ -163,4 +163,26 @@ def kernel_K(X1s, X2s, base, M, variances, sigma, normalization, difference=True
     out = np.full((M + 1, N1, N2) if return_levels else (N1, N2), np.nan)
     run(cfg, gx, gy, xrec, yrec, N1, N2, M, BASE_IDS[base], *base_params, out, N2, 1, N1 * N2, ax, by,
         jitter if (sym and normalization) else 0.0, not return_levels, PRED_CIRCULANT if sym else PRED_ALL, sym)
+    return out
+
+
+def kernel_K_owned_rows(Xs, base, M, variances, sigma, normalization, row_begin, row_end, jitter=1e-6):
+    """Emulator counterpart of gpsig_kernel_K_symm_rows: the owned entries of rows [row_begin, row_end) of the
+    symmetric, normalised, weighted, level-summed Gram; everything else is left at zero."""
+    N, L, d = Xs.shape
+    w = sigma * np.asarray(variances, dtype=np.float64)
+    if normalization:
+        dl, _ = seq_levels(Xs, None, base, M, diag_only=True)
+        ax = np.ascontiguousarray((w[:, None] / np.sqrt(dl + jitter)).T)
+        by = np.ascontiguousarray((1.0 / np.sqrt(dl + jitter)).T)
+    else:
+        ax, by = np.ascontiguousarray(np.tile(w[None, :], (N, 1))), None
+    gy = geometry(base, True, L, 4)
+    cfg = select(gy["rows"], d, M)
+    g = geometry(base, True, L, cfg["D"])
+    rec = build_records(Xs, g, True, cfg["D"])
+    out = np.zeros((row_end - row_begin, N))
+    # as the C API does: x index = column (si = 1), y index = row (sj = N), y indices >= row_end are invalid (N2 = row_end)
+    run(cfg, g, g, rec, rec, N, row_end, M, BASE_IDS[base], 0.0, 0.0, out, 1, N, 0, ax, by,
+        jitter if normalization else 0.0, True, PRED_CIRCULANT, False, yrange=(row_begin, row_end), out_offset=-row_begin * N)
     return out
