@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 N_BASE, L, D, M = 4096, 64, 8, 5
 B_PAIR = (L + L) * D * 8 + 8                      # pair-stream bytes: both L x d streams + one fp64 result
 F_PAIR = 2 * L * L * D + (L - 1) * (L - 1) * 4 * M   # reference op count per pair
+F_EXEC = (L - 1) * (L - 1) * (2 * D + 3 * M - 1)      # fp64 flops the row-sweep kernel executes per evaluated pair
 HBM_PEAK_GBS = 8000.0                             # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
@@ -166,7 +167,9 @@ def main():
                          "traffic": traffic,
                          "kernel": "seq_gram_kernel (pair recursion)", "kernel_ms_per_launch": per_launch_ms,
                          "algorithmic_bytes_per_pair": B_PAIR, "pairs_per_launch": entries_rank,
-                         "alu_frac_fp64_vector": (entries_rank * F_PAIR / (per_launch_ms * 1e-3) / 1e12) / FP64_VECTOR_PEAK_TFLOPS,
+                         "alu_frac_fp64_vector": ((float(n_total) * (n_total + 1) / 2 / n_gpus) * F_EXEC / (per_launch_ms * 1e-3) / 1e12)
+                                                 / FP64_VECTOR_PEAK_TFLOPS,
+                         "reference_flops_frac_fp64_vector": (entries_rank * F_PAIR / (per_launch_ms * 1e-3) / 1e12) / FP64_VECTOR_PEAK_TFLOPS,
                          "frac_on_unique_pairs": achieved / HBM_PEAK_GBS * (n_total + 1) / (2.0 * n_total)},
         }
         if cpu is not None:

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpsig_hip.so")
+LIB_PATH = os.environ.get("GPSIG_LIB") or os.path.join(_HERE, "lib", "libgpsig_hip.so")   # GPSIG_LIB: A/B builds
 
 GPSIG_OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4
 PTR_HOST, PTR_DEVICE = 0, 1

@@ -314,7 +314,8 @@ int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const 
     A.N1 = r.N1; A.N2 = r.N2;
     A.xrec_stride = r.gx.rec_elems; A.yrec_stride = r.gy.rec_elems;
     A.R1 = r.gx.rows; A.R2 = r.gy.rows; A.RS = r.gx.RS; A.M = p->num_levels;
-    A.nslot = seq_ring_depth(pl.cfg.G, r.gx.rows);
+    A.nslot = seq_ring(pl.cfg.G, r.gx.rows).nslot;
+    A.issue_at = seq_ring(pl.cfg.G, r.gx.rows).issue_at;
     A.slot_elems = r.gx.rec_elems;
     A.kind = p->base_kernel;
     base_p(p, &A.p0, &A.p1);

@@ -28,6 +28,7 @@ struct SeqGramArgs {
     int32_t RS;             // elements between consecutive record rows (D + pad)
     int32_t M;
     int32_t nslot;          // LDS ring depth
+    int32_t issue_at;       // step within an x at which the next x's record is requested (seq_ring)
     int32_t slot_elems;     // elements per ring slot (>= R1*RS, multiple of 128 so a slot is whole 1 KiB DMA pieces for fp64)
     int32_t kind;           // base kernel (point modes)
     double p0, p1;
@@ -85,12 +86,19 @@ GPSIG_HD void seq_emit(const Lane& L, const SeqGramArgs& A, int64_t i, int64_t j
 }
 
 // ---- host-side planning ----------------------------------------------------------------------
-struct SeqPlan {
-    int ypb;     // y sequences per task block = 64 / G
-    int nslot;   // LDS ring depth: the slot refilled when lane 0 starts x number k must no longer be read
-                 // by lane G-1, which is still G-1 steps behind:  (nslot - 2) * R1 >= G - 1
+// LDS ring of x-side records.  Lane lam of a pair group starts x number k at step k*R1 + lam, so while lane 0
+// is already on x_k the slowest lane (G-1) still reads x_{k-1} for G-1 more steps.  The record of x_{k+1} is
+// requested at step k*R1 + issue_at.  With issue_at = G the slot of x_{k-1} is free by then, so two slots
+// suffice as long as the copy has R1 - G steps to land (R1 >= 2G); shorter records are requested at the
+// start of x_k instead and the ring is deepened until (nslot - 2) * R1 >= G - 1.
+struct SeqRing {
+    int nslot, issue_at;
 };
-inline int seq_ring_depth(int G, int R1) { return 2 + (G - 1 + R1 - 1) / R1; }
+inline SeqRing seq_ring(int G, int R1) {
+    if (R1 >= 2 * G) return SeqRing{2, G};
+    return SeqRing{2 + (G - 1 + R1 - 1) / R1, 0};
+}
+inline int seq_ring_depth(int G, int R1) { return seq_ring(G, R1).nslot; }
 
 // Task list.  pred == PRED_ALL: every (x, y) pair of an N1 x N2 cross Gram.  PRED_CIRCULANT (N1 == N2,
 // same sequences): each unordered pair once -- y block [y0, y0+ypb) against the x window

@@ -115,19 +115,37 @@ __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
         __device__ __forceinline__ T kleft() const { return shr1<G>(L.kprev[C - 1]); }
     };
 
-    // Lane 0 of each group starts x number k at step k*R1: its record must be resident by then, and the
-    // next one is requested at that moment.  The ring depth chosen by the host (seq_ring_depth)
-    // guarantees the slot being refilled is no longer read by the slowest lane: (nslot-2)*R1 >= G-1.
-    // After the last x, G more steps let lane lam emit its last pair at step nx*R1 + lam.
+    // Lane 0 of each group starts x number k at step k*R1: its record must be resident by then.  The next
+    // record is requested issue_at steps later, into a slot the slowest lane no longer reads (seq_ring in
+    // seq_args.hpp).  After the last x, G more steps let lane lam emit its last pair at step nx*R1 + lam.
     const int nsteps = nx * R1 + G;
     int a_u = 0, k_u = 0, slot_next = 1 % nslot;          // wave-uniform position of lane 0
-    for (int t = 0; t < nsteps; ++t) {
-        if (a_u == 0 && k_u < nx) {
-            if (A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (k_u + 1 < nx) {
-                stage(k_u + 1, slot_next);
-                if (++slot_next == nslot) slot_next = 0;
-            }
+    // x-side record row of a lane for the step described by `cc` (16-byte LDS reads; rows are RS = D + pad apart,
+    // so the 16 lanes of a pair group hit 16 different bank groups)
+    auto load_row = [&](const LaneCtl& cc, T (&dst)[D]) {
+        const T* rowp = cc.active(nx) ? ring + int64_t(cc.slot) * A.slot_elems + cc.a * RS : zero_row;
+#pragma unroll
+        for (int f = 0; f < D; f += VEC) {
+            vecT v = *reinterpret_cast<const vecT*>(rowp + f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dst[f + e] = v[e];
+        }
+    };
+    // Requesting the next step's row before this step's arithmetic costs 2*D more live registers; on gfx950 the
+    // flagship shape then drops from 3 to 2 waves per SIMD and runs 7 % slower (profiles/r01_ab_variants.txt),
+    // so it is off by default.
+#ifndef GPSIG_PREFETCH_ROWS
+#define GPSIG_PREFETCH_ROWS 0
+#endif
+    constexpr bool PF = GPSIG_PREFETCH_ROWS != 0;
+    if (A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    T xr_next[D];
+    if (PF) load_row(ctl, xr_next);
+
+    auto one_step = [&]() {
+        if (a_u == A.issue_at && k_u + 1 < nx) {
+            stage(k_u + 1, slot_next);
+            if (++slot_next == nslot) slot_next = 0;
         }
         if (++a_u == R1) { a_u = 0; ++k_u; }
 
@@ -142,20 +160,28 @@ __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
             L.reset();
         }
 
-        // this lane's x-side record row (16-byte LDS reads; rows are RS = D + pad apart, conflict-free)
-        const bool act = ctl.active(nx);
-        const T* rowp = act ? ring + int64_t(ctl.slot) * A.slot_elems + ctl.a * RS : zero_row;
         T xr[D];
+        if (PF) {
 #pragma unroll
-        for (int f = 0; f < D; f += VEC) {
-            vecT v = *reinterpret_cast<const vecT*>(rowp + f);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) xr[f + e] = v[e];
+            for (int f = 0; f < D; ++f) xr[f] = xr_next[f];
+        } else {
+            load_row(ctl, xr);
         }
-        const bool dummy = !act || ctl.a == 0;
+        const bool dummy = !ctl.active(nx) || ctl.a == 0;
+
+        // software pipeline: the row for the NEXT step is requested from LDS before this step's arithmetic.
+        // If lane 0 opens a new x at the next step, its record (requested issue_at steps into this x) must have landed.
+        ctl.advance(R1, nslot);
+        if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PF) load_row(ctl, xr_next);
 
         seq_step(L, DevNbr{L}, xr, M, dummy, rlo, rhi, A.kind, p0, p1);
-        ctl.advance(R1, nslot);
+    };
+    // two steps per trip: the loop-carried hand-over words (s, qold) alternate registers instead of being copied
+    // back every step.  An odd step count is rounded up; the extra step finds every lane past its last pair.
+    for (int t = 0; t < nsteps; t += 2) {
+        one_step();
+        one_step();
     }
 }
 

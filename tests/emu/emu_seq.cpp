@@ -58,9 +58,7 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
     int a_u = 0, k_u = 0, slot_next = 1 % nslot;
     T* out = static_cast<T*>(A.out);
     for (int t = 0; t < nsteps; ++t) {
-        if (a_u == 0 && k_u < nx) {
-            if (k_u + 1 < nx) { stage(k_u + 1, slot_next); if (++slot_next == nslot) slot_next = 0; }
-        }
+        if (a_u == A.issue_at && k_u + 1 < nx) { stage(k_u + 1, slot_next); if (++slot_next == nslot) slot_next = 0; }
         if (++a_u == R1) { a_u = 0; ++k_u; }
         // Order of events inside one step of the real wave: (1) the pair-boundary block (emit + reset) runs for
         // the lanes that sit on a boundary, (2) every lane reads its left neighbour's hand-over registers (DPP
@@ -128,6 +126,7 @@ int emu_seq_gram(int G, int C, int D, int MMAX, int mode, int exact, const SeqGr
 }
 
 int emu_ring_depth(int G, int R1) { return seq_ring_depth(G, R1); }
+int emu_ring_issue_at(int G, int R1) { return seq_ring(G, R1).issue_at; }
 
 // returns the number of tasks; writes at most cap of them
 int emu_build_tasks(int64_t N1, int64_t N2, int ypb, int pred, int max_run, int shard_index, int shard_count,

@@ -27,7 +27,7 @@ class SeqGramArgs(C.Structure):
         ("xrec", C.c_void_p), ("yrec", C.c_void_p), ("tasks", C.c_void_p),
         ("N1", C.c_int64), ("N2", C.c_int64), ("xrec_stride", C.c_int64), ("yrec_stride", C.c_int64),
         ("R1", C.c_int32), ("R2", C.c_int32), ("RS", C.c_int32), ("M", C.c_int32), ("nslot", C.c_int32),
-        ("slot_elems", C.c_int32), ("kind", C.c_int32),
+        ("issue_at", C.c_int32), ("slot_elems", C.c_int32), ("kind", C.c_int32),
         ("p0", C.c_double), ("p1", C.c_double),
         ("out", C.c_void_p), ("si", C.c_int64), ("sj", C.c_int64), ("sm", C.c_int64),
         ("ax", C.c_void_p), ("by", C.c_void_p), ("jitter_diag", C.c_double),
@@ -98,6 +98,7 @@ def run(cfg, geom_x, geom_y, xrec, yrec, N1, N2, M, kind, p0, p1, out, si, sj, s
     A.xrec_stride, A.yrec_stride = geom_x["rec_elems"], geom_y["rec_elems"]
     A.R1, A.R2, A.RS, A.M = geom_x["rows"], geom_y["rows"], geom_x["RS"], M
     A.nslot = lib().emu_ring_depth(cfg["G"], geom_x["rows"])
+    A.issue_at = lib().emu_ring_issue_at(cfg["G"], geom_x["rows"])
     A.slot_elems = geom_x["rec_elems"]
     A.kind, A.p0, A.p1 = kind, p0, p1
     A.out, A.si, A.sj, A.sm = out.ctypes.data + 8 * out_offset, si, sj, sm
