@@ -28,6 +28,12 @@ SeqLaunchFn seq_lookup_ptd_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptd_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptn_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptn_g64(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ho_inc_d4(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_inc_d8(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_inc_d16(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_ptd_d4(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_ptd_d8(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_ptd_d16(int, int, int, int, int);
 typedef hipError_t (*TvsLaunchFn)(const TvsArgs&, hipStream_t);
 TvsLaunchFn tvs_lookup(int M, int TT, bool incr);
 }  // namespace gpsig
@@ -40,6 +46,10 @@ namespace {
 const SeqConfig SEQ_TABLE[] = {GPSIG_SEQ_CONFIGS_ALL(X_CFG)};
 const SeqConfig SEQ_TABLE_GENERIC[] = {GPSIG_SEQ_CONFIGS_GENERIC(X_CFG)};
 #undef X_CFG
+#define X_HO(G_, C_, D_, MM_, OM_) {G_, C_, D_, MM_, OM_},
+const SeqHOConfig SEQ_HO_TABLE[] = {GPSIG_SEQ_HO_ALL(X_HO)};
+#undef X_HO
+constexpr int N_SEQ_HO_TABLE = int(sizeof(SEQ_HO_TABLE) / sizeof(SEQ_HO_TABLE[0]));
 constexpr int N_SEQ_TABLE = int(sizeof(SEQ_TABLE) / sizeof(SEQ_TABLE[0]));
 constexpr int N_SEQ_TABLE_GENERIC = int(sizeof(SEQ_TABLE_GENERIC) / sizeof(SEQ_TABLE_GENERIC[0]));
 
@@ -57,6 +67,20 @@ SeqLaunchFn seq_launcher(int mode, const SeqConfig& c) {
     }
     if ((f = seq_lookup_ptn_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
     return seq_lookup_ptn_g64(c.G, c.C, c.D, c.MMAX, c.exact);
+}
+
+SeqLaunchFn seq_launcher_ho(int mode, const SeqHOConfig& c) {
+    if (mode == MODE_INC) {
+        if (c.D == 4) return seq_lookup_ho_inc_d4(c.G, c.C, c.D, c.MMAX, c.OMAX);
+        if (c.D == 8) return seq_lookup_ho_inc_d8(c.G, c.C, c.D, c.MMAX, c.OMAX);
+        return seq_lookup_ho_inc_d16(c.G, c.C, c.D, c.MMAX, c.OMAX);
+    }
+    if (mode == MODE_PT_DIFF) {
+        if (c.D == 4) return seq_lookup_ho_ptd_d4(c.G, c.C, c.D, c.MMAX, c.OMAX);
+        if (c.D == 8) return seq_lookup_ho_ptd_d8(c.G, c.C, c.D, c.MMAX, c.OMAX);
+        return seq_lookup_ho_ptd_d16(c.G, c.C, c.D, c.MMAX, c.OMAX);
+    }
+    return nullptr;
 }
 
 struct DevBuf {
@@ -178,8 +202,6 @@ int check_params(gpsig_ctx* c, const gpsig_params* p) {
     if (p->num_lags < 0 || p->num_lags > MAX_LAGS) return fail(c, GPSIG_ERR_UNSUPPORTED, "num_lags=%d outside [0, %d]", p->num_lags, MAX_LAGS);
     if (p->base_kernel < GPSIG_BASE_LINEAR || p->base_kernel > GPSIG_BASE_MATERN52) return fail(c, GPSIG_ERR_INVALID, "unknown base kernel %d", p->base_kernel);
     if (p->order < 1 || p->order > p->num_levels) return fail(c, GPSIG_ERR_INVALID, "order=%d outside [1, num_levels]", p->order);
-    if (p->order != 1 && p->num_levels > 1)
-        return fail(c, GPSIG_ERR_UNSUPPORTED, "higher-order recursion (order=%d) is not built on the GPU yet; order=1 only", p->order);
     if (!p->variances) return fail(c, GPSIG_ERR_INVALID, "variances is NULL");
     if (p->num_lags > 0 && (!p->lags || !p->gamma)) return fail(c, GPSIG_ERR_INVALID, "num_lags > 0 needs lags and gamma");
     return GPSIG_OK;
@@ -225,6 +247,23 @@ struct SeqPlanned {
 
 int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, 8);
+    if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
+        if (g0.mode == MODE_PT_NODIFF)
+            return fail(c, GPSIG_ERR_UNSUPPORTED, "order > 1 with difference=False and a non-linear base kernel is not built");
+        int k = seq_select_ho(SEQ_HO_TABLE, N_SEQ_HO_TABLE, g0.rows, d_eff, p->num_levels, p->order);
+        if (k < 0)
+            return fail(c, GPSIG_ERR_UNSUPPORTED,
+                        "no higher-order seq-gram kernel shape for %d record rows, d=%d, num_levels=%d, order=%d (built: order <= 8 up "
+                        "to 64 rows, <= 4 up to 128 rows, 2 up to 512 rows; num_levels <= 6 (8 up to 64 rows); d <= 16)",
+                        g0.rows, d_eff, p->num_levels, p->order);
+        const SeqHOConfig& h = SEQ_HO_TABLE[k];
+        out->cfg = SeqConfig{h.G, h.C, h.D, h.MMAX, false};
+        out->mode = g0.mode;
+        out->d_eff = d_eff;
+        out->fn = seq_launcher_ho(g0.mode, h);
+        if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "higher-order kernel shape missing from this build");
+        return GPSIG_OK;
+    }
     const SeqConfig* tab = g0.mode == MODE_PT_NODIFF ? SEQ_TABLE_GENERIC : SEQ_TABLE;
     const int ntab = g0.mode == MODE_PT_NODIFF ? N_SEQ_TABLE_GENERIC : N_SEQ_TABLE;
     int k = seq_select(tab, ntab, g0.rows, d_eff, p->num_levels, c->allow_exact != 0);
@@ -313,7 +352,7 @@ int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const 
     A.xrec = r.xrec; A.yrec = r.yrec; A.tasks = static_cast<const SeqTask*>(dt);
     A.N1 = r.N1; A.N2 = r.N2;
     A.xrec_stride = r.gx.rec_elems; A.yrec_stride = r.gy.rec_elems;
-    A.R1 = r.gx.rows; A.R2 = r.gy.rows; A.RS = r.gx.RS; A.M = p->num_levels;
+    A.R1 = r.gx.rows; A.R2 = r.gy.rows; A.RS = r.gx.RS; A.M = p->num_levels; A.order = p->order;
     A.nslot = seq_ring(pl.cfg.G, r.gx.rows).nslot;
     A.issue_at = seq_ring(pl.cfg.G, r.gx.rows).issue_at;
     A.slot_elems = r.gx.rec_elems;
@@ -520,7 +559,7 @@ int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void
     TvsArgs A;
     memset(&A, 0, sizeof(A));
     A.XT = xt; A.ZT = ZT; A.ZS = ZS; A.N = N; A.Npad = Npad; A.Tn = Tn;
-    A.L = L; A.d_eff = d_eff; A.kind = p->base_kernel; A.difference = p->difference;
+    A.L = L; A.d_eff = d_eff; A.kind = p->base_kernel; A.difference = p->difference; A.order = p->order;
     base_p(p, &A.p0, &A.p1);
     A.fx = fx; A.w = w; A.out = out; A.sum_levels = (raw || return_levels) ? 0 : 1;
     if (N > 0 && Tn > 0) {

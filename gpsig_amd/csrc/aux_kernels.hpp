@@ -177,7 +177,7 @@ struct TvsArgs {
     const void* ZT;     // (T, d_eff, lt, E) scaled tensor components
     const void* ZS;     // (T, lt, E) squared norms
     int64_t N, Npad, Tn;
-    int32_t L, d_eff, kind, difference;
+    int32_t L, d_eff, kind, difference, order;
     double p0, p1;
     const void* fx;     // (N, M+1) per-sequence factors (1/sqrt(diag+jitter)) or NULL
     const double* w;    // (M+1) level weights sigma*variances, or NULL (raw levels)
@@ -244,13 +244,38 @@ __global__ __launch_bounds__(64) void tens_vs_seq_kernel(const TvsArgs A) {
                 else dm[k] = kv;
             }
             if (!(A.difference && tau == 0)) {
+                if (A.order <= 1) {
 #pragma unroll
-                for (int i = M; i >= 1; --i) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int k0 = i * (i - 1) / 2;
+                    for (int i = M; i >= 1; --i) {
+                        const int k0 = i * (i - 1) / 2;
 #pragma unroll
-                    for (int j = i - 1; j >= 1; --j) u[tt][k0 + j] = fma(dm[k0 + j], u[tt][k0 + j - 1], u[tt][k0 + j]);
-                    u[tt][k0] += dm[k0];
+                        for (int j = i - 1; j >= 1; --j) u[tt][k0 + j] = fma(dm[k0 + j], u[tt][k0 + j - 1], u[tt][k0 + j]);
+                        u[tt][k0] += dm[k0];
+                    }
+                } else {
+                    // higher-order chains (signature_algs.py:147-158): position j of level i keeps min(j+1, order) terms
+                    // R[l] of this time step; R'[0] = dM * excumsum(sum R), R'[l] = dM * R[l-1] / (l+1).
+#pragma unroll
+                    for (int i = 1; i <= M; ++i) {
+                        const int k0 = i * (i - 1) / 2;
+                        T Rp[M], Rc[M];
+                        Rp[0] = dm[k0];
+                        T totp = dm[k0];
+#pragma unroll
+                        for (int j = 1; j < i; ++j) {
+                            const int dj = (j + 1 < A.order) ? j + 1 : A.order;
+                            Rc[0] = dm[k0 + j] * u[tt][k0 + j - 1];                       // running sum up to the previous step
+                            T totc = Rc[0];
+#pragma unroll
+                            for (int l = 1; l <= j; ++l)
+                                if (l < dj) { Rc[l] = (dm[k0 + j] * (T(1) / T(l + 1))) * Rp[l - 1]; totc += Rc[l]; }
+                            u[tt][k0 + j - 1] += totp;
+#pragma unroll
+                            for (int l = 0; l <= j; ++l) Rp[l] = Rc[l];
+                            totp = totc;
+                        }
+                        u[tt][k0 + i - 1] += totp;
+                    }
                 }
             }
         }

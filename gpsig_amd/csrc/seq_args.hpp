@@ -27,6 +27,7 @@ struct SeqGramArgs {
     int32_t R1, R2;         // record rows per sequence on each side
     int32_t RS;             // elements between consecutive record rows (D + pad)
     int32_t M;
+    int32_t order;          // 1, or the reference's `order` for the higher-order kernels
     int32_t nslot;          // LDS ring depth
     int32_t issue_at;       // step within an x at which the next x's record is requested (seq_ring)
     int32_t slot_elems;     // elements per ring slot (>= R1*RS, multiple of 128 so a slot is whole 1 KiB DMA pieces for fp64)

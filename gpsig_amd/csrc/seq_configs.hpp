@@ -32,6 +32,31 @@ struct SeqConfig {
 #define GPSIG_SEQ_CONFIGS_GENERIC(X) GPSIG_SEQ_CONFIGS_G16(X) GPSIG_SEQ_CONFIGS_G64(X)
 #define GPSIG_SEQ_CONFIGS_ALL(X) GPSIG_SEQ_CONFIGS_EXACT(X) GPSIG_SEQ_CONFIGS_GENERIC(X)
 
+// Higher-order kernels (run-time num_levels <= MMAX, run-time order <= OMAX), MODE_INC and MODE_PT_DIFF.
+// X(G, C, D, MMAX, OMAX).  State and temporaries grow with C * OMAX^2, so wide lanes come with small orders.
+#define GPSIG_SEQ_HO_SHAPES(X, D_) \
+    X(16, 4, D_, 6, 2) X(16, 2, D_, 6, 4) X(64, 1, D_, 8, 8) X(64, 2, D_, 6, 4) X(64, 4, D_, 6, 2) X(64, 8, D_, 6, 2)
+#define GPSIG_SEQ_HO_D4(X) GPSIG_SEQ_HO_SHAPES(X, 4)
+#define GPSIG_SEQ_HO_D8(X) GPSIG_SEQ_HO_SHAPES(X, 8)
+#define GPSIG_SEQ_HO_D16(X) GPSIG_SEQ_HO_SHAPES(X, 16)
+#define GPSIG_SEQ_HO_ALL(X) GPSIG_SEQ_HO_D4(X) GPSIG_SEQ_HO_D8(X) GPSIG_SEQ_HO_D16(X)
+
+struct SeqHOConfig {
+    int G, C, D, MMAX, OMAX;
+};
+// cheapest higher-order shape that fits (rows, d, num_levels, order); -1 if none
+inline int seq_select_ho(const SeqHOConfig* tab, int n, int Ry, int d, int M, int order) {
+    int best = -1;
+    long best_cost = 0;
+    for (int k = 0; k < n; ++k) {
+        const SeqHOConfig& c = tab[k];
+        if (c.MMAX < M || c.OMAX < order || c.D < d || long(c.G) * c.C < Ry) continue;
+        const long cost = (long(c.G) * c.C * (c.D + 4L * c.OMAX * c.OMAX)) * 2 + (c.G == 16 ? 0 : 1);
+        if (best < 0 || cost < best_cost) { best = k; best_cost = cost; }
+    }
+    return best;
+}
+
 // Pick the cheapest config that fits: y-side record rows Ry <= G*C, d <= D, levels M (== MMAX if exact,
 // <= MMAX otherwise).  Cost = lanes*columns*D actually paid per pair (G*C*D); ties go to the exact
 // variant, then to the smaller group (more pairs per wave).  Returns -1 if nothing fits.

@@ -78,6 +78,7 @@ struct SeqLane {
     T y2[C];        // |y|^2 per owned column
     T kprev[C];     // kappa(previous x point, owned y columns)
     T kleft;        // kappa(previous x point, last column of the left neighbour)
+    static constexpr bool HIGHER_ORDER = false;
 
     // Pair boundary.  Only the accumulators are cleared: s[] and qold[] are hand-over words that the RIGHT
     // neighbour still has to read during this very step (it is one lattice row behind), and both are
@@ -114,6 +115,7 @@ struct SeqLane {
 //     T cin(int m)      left neighbour's s[m]
 //     T din(int m)      left neighbour's qold[m]
 //     T kleft()         left neighbour's kprev[C-1]      (MODE_PT_DIFF)
+//     T win(int m, int r)  left neighbour's w[m][r]      (higher-order lanes)
 // (zero for the first lane of a pair group).  On the GPU they are DPP row/wave shifts issued right
 // where the value is consumed -- legal because s[m] / qold[m] / kprev are only overwritten later in
 // the same step -- which keeps the 2M+1 shifted words out of the live register set.  The CPU
@@ -124,9 +126,11 @@ struct NbrSnapshot {
     T s[MMAX];
     T qold[NQ];
     T klast;
+    T w[NQ][8];    // higher-order lanes only
     GPSIG_HD T cin(int m) const { return s[m]; }
     GPSIG_HD T din(int m) const { return qold[m]; }
     GPSIG_HD T kleft() const { return klast; }
+    GPSIG_HD T win(int m, int r) const { return w[m][r]; }
 };
 
 namespace detail {
@@ -169,13 +173,175 @@ GPSIG_HD void seq_recursion(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, con
     detail::seq_level<MMAX - 1>(L, nbr, dm, M);
 }
 
-// Full step.  xr: the x-side record row for this step.  dummy: this step is not a lattice row of the
+// Full first-order step.  xr: the x-side record row for this step.  dummy: this step is not a lattice row of the
 // current pair (pair boundary / lane outside its active window): contributes nothing.
 // [rlo, rhi): owned columns that are real lattice columns (point modes; MODE_INC relies on zero rows).
 template <typename T, int C, int D, int MMAX, int MODE, class Nbr>
-GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&xr)[D], int M,
-                       bool dummy, int rlo, int rhi, int kind, T p0, T p1) {
-    T dm[C];
+GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&xr)[D], int M, int /*order*/,
+                       bool dummy, int rlo, int rhi, int kind, T p0, T p1);
+
+// =====================================================================================================
+// Higher-order algorithm (gpsig/signature_algs.py:37-74), same lane mapping and skew.
+//
+// The reference keeps, per level, a d x d grid (d = min(level, order)) of full lattices R[r][s] indexed by how
+// often the last x index (r+1 times) and the last y index (s+1 times) have been repeated:
+//     R_m[0][0] = dM * excumsum_ab( sum_{r,s} R_{m-1}[r][s] )                       (:64)
+//     R_m[0][s] = dM/(s+1) * excumsum_a( sum_r R_{m-1}[r][s-1] )                    (:66)
+//     R_m[r][0] = dM/(r+1) * excumsum_b( sum_s R_{m-1}[r-1][s] )                    (:67)
+//     R_m[r][s] = dM/((r+1)(s+1)) * R_{m-1}[r-1][s-1]                               (:69)
+//     K_m = sum_{a,b} sum_{r,s} R_m[r][s]                                           (:71)
+// In the row sweep that becomes, per level m < M and per owned column:  QT_m (inclusive 2-D prefix of the grid
+// total, as in the first-order case), PC_{m,s} (column prefix, i.e. running sum over rows, of sum_r R_m[r][s]),
+// and per row the running row prefixes of sum_s R_m[r][s], whose chunk-end values `w` join `s` and `qold` as
+// hand-over words to the right neighbour.  Levels are processed in ascending order inside a step because level m
+// needs level m-1's values of the SAME lattice row; level m-1's prefixes are advanced past the row only after
+// level m has read their previous-row values.
+template <typename T, int C, int D, int MMAX, int OMAX, int MODE>
+struct SeqLaneHO {
+    static constexpr int NQ = MMAX > 1 ? MMAX - 1 : 1;
+    static constexpr int NO = OMAX > 1 ? OMAX - 1 : 1;
+    static constexpr bool HIGHER_ORDER = true;
+    T y[C][D];
+    T q[NQ][C];        // QT_m
+    T qold[NQ];        // QT_m[last owned column] before the last processed row    (hand-over)
+    T s[MMAX];         // chunk-end row prefix of the level total                   (hand-over)
+    T pc[NQ][NO][C];   // PC_{m,s}
+    T w[NQ][NO];       // chunk-end row prefix of sum_s R_m[r][s] for r < order-1   (hand-over)
+    T ktop;
+    T y2[C], kprev[C], kleft;
+
+    GPSIG_HD void reset() {
+#pragma unroll
+        for (int m = 0; m < NQ; ++m)
+#pragma unroll
+            for (int r = 0; r < C; ++r) {
+                q[m][r] = T(0);
+#pragma unroll
+                for (int o = 0; o < NO; ++o) pc[m][o][r] = T(0);
+            }
+        ktop = T(0);
+    }
+    GPSIG_HD void init() {
+        reset();
+#pragma unroll
+        for (int m = 0; m < NQ; ++m) {
+            qold[m] = T(0);
+#pragma unroll
+            for (int o = 0; o < NO; ++o) w[m][o] = T(0);
+        }
+#pragma unroll
+        for (int m = 0; m < MMAX; ++m) s[m] = T(0);
+#pragma unroll
+        for (int r = 0; r < C; ++r) { kprev[r] = T(0); y2[r] = T(0); }
+        kleft = T(0);
+    }
+    GPSIG_HD T level_value(int m, int M) const {
+        T v = ktop;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+            if (k == m - 1 && m < M) v = q[k][C - 1];
+        return v;
+    }
+};
+
+namespace detail {
+// level LV (1-based, compile time) of the higher-order step; Rp = level LV-1's grid values of this lattice row
+template <int LV, typename T, int C, int D, int MMAX, int OMAX, int MODE, class Nbr>
+GPSIG_HD void seq_ho_level(SeqLaneHO<T, C, D, MMAX, OMAX, MODE>& L, const Nbr& nbr, const T (&dm)[C], int M, int order,
+                           T (&Rp)[OMAX][OMAX][C]) {
+    if (LV <= M) {
+        constexpr int DC = LV < OMAX ? LV : OMAX;                // static bounds of this / the previous level's grid
+        constexpr int DP = (LV - 1) < OMAX ? (LV - 1) : OMAX;
+        const int dcur = LV < order ? LV : order;                // signature_algs.py:62
+        const int dprev = (LV - 1) < order ? (LV - 1) : order;
+        T Rc[OMAX][OMAX][C];
+        if constexpr (LV == 1) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) Rc[0][0][c] = dm[c];                                        // :58-60
+        } else {
+            constexpr int MI = LV - 2;                           // state index of level LV-1
+            T tot[C], cs[DP > 0 ? DP : 1][C], rs[DP > 0 ? DP : 1][C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                tot[c] = T(0);
+#pragma unroll
+                for (int a = 0; a < DP; ++a) { cs[a][c] = T(0); rs[a][c] = T(0); }
+#pragma unroll
+                for (int r = 0; r < DP; ++r)
+#pragma unroll
+                    for (int sx = 0; sx < DP; ++sx)
+                        if (r < dprev && sx < dprev) { tot[c] += Rp[r][sx][c]; cs[sx][c] += Rp[r][sx][c]; rs[r][c] += Rp[r][sx][c]; }
+            }
+            T wrun[DC > 1 ? DC - 1 : 1];
+#pragma unroll
+            for (int r = 0; r < DC - 1; ++r) wrun[r] = (r < dcur - 1) ? nbr.win(MI, r) : T(0);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const T qd = (c == 0) ? nbr.din(MI) : L.q[MI][c == 0 ? 0 : c - 1];
+                Rc[0][0][c] = dm[c] * qd;                                                             // :64
+#pragma unroll
+                for (int sx = 1; sx < DC; ++sx)
+                    if (sx < dcur) Rc[0][sx][c] = (dm[c] * (T(1) / T(sx + 1))) * L.pc[MI][sx - 1][c];  // :66
+#pragma unroll
+                for (int r = 1; r < DC; ++r)
+                    if (r < dcur) Rc[r][0][c] = (dm[c] * (T(1) / T(r + 1))) * wrun[r - 1];             // :67
+#pragma unroll
+                for (int r = 1; r < DC; ++r)
+#pragma unroll
+                    for (int sx = 1; sx < DC; ++sx)
+                        if (r < dcur && sx < dcur)
+                            Rc[r][sx][c] = (dm[c] * (T(1) / (T(r + 1) * T(sx + 1)))) * Rp[r - 1][sx - 1][c];   // :69
+#pragma unroll
+                for (int r = 0; r < DC - 1; ++r)
+                    if (r < dcur - 1) wrun[r] += rs[r][c];
+            }
+            // level LV-1's prefixes move past this lattice row now that their previous-row values have been used
+            T srun = nbr.cin(MI);
+            const T last = L.q[MI][C - 1];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                srun += tot[c];
+                L.q[MI][c] += srun;
+#pragma unroll
+                for (int sx = 0; sx < DC - 1; ++sx)
+                    if (sx < dcur - 1) L.pc[MI][sx][c] += cs[sx][c];
+            }
+            L.qold[MI] = last;
+            L.s[MI] = srun;
+#pragma unroll
+            for (int r = 0; r < DC - 1; ++r)
+                if (r < dcur - 1) L.w[MI][r] = wrun[r];
+        }
+        if (LV == M) {              // top level: only the lattice total is needed (signature_algs.py:71)
+            T srun = nbr.cin(LV - 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int r = 0; r < DC; ++r)
+#pragma unroll
+                    for (int sx = 0; sx < DC; ++sx)
+                        if (r < dcur && sx < dcur) srun += Rc[r][sx][c];
+            L.s[LV - 1] = srun;
+            L.ktop += srun;
+        }
+        if constexpr (LV < MMAX) {
+            T Rn[OMAX][OMAX][C];
+#pragma unroll
+            for (int r = 0; r < DC; ++r)
+#pragma unroll
+                for (int sx = 0; sx < DC; ++sx)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) Rn[r][sx][c] = Rc[r][sx][c];
+            seq_ho_level<LV + 1>(L, nbr, dm, M, order, Rn);
+        }
+    }
+}
+}  // namespace detail
+
+// dM for the lane's C columns from the x-side row (shared by both algorithms)
+template <typename T, int C, int D, int MODE, class Lane, class Nbr>
+GPSIG_HD void seq_increments(Lane& L, const Nbr& nbr, const T (&xr)[D], bool dummy, int rlo, int rhi, int kind, T p0, T p1,
+                             T (&dm)[C]) {
     if constexpr (MODE == MODE_INC) {
 #pragma unroll
         for (int r = 0; r < C; ++r) {
@@ -212,6 +378,23 @@ GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T 
         for (int r = 0; r < C; ++r)
             if (dummy || r < rlo || r >= rhi) dm[r] = T(0);
     }
+}
+
+// Higher-order step (order = the reference's `order`, 2 <= order <= OMAX; order 1 also works and equals seq_step).
+template <typename T, int C, int D, int MMAX, int OMAX, int MODE, class Nbr>
+GPSIG_HD void seq_step(SeqLaneHO<T, C, D, MMAX, OMAX, MODE>& L, const Nbr& nbr, const T (&xr)[D], int M, int order,
+                       bool dummy, int rlo, int rhi, int kind, T p0, T p1) {
+    T dm[C];
+    seq_increments<T, C, D, MODE>(L, nbr, xr, dummy, rlo, rhi, kind, p0, p1, dm);
+    T R0[OMAX][OMAX][C];
+    detail::seq_ho_level<1>(L, nbr, dm, M, order, R0);
+}
+
+template <typename T, int C, int D, int MMAX, int MODE, class Nbr>
+GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&xr)[D], int M, int /*order*/,
+                       bool dummy, int rlo, int rhi, int kind, T p0, T p1) {
+    T dm[C];
+    seq_increments<T, C, D, MODE>(L, nbr, xr, dummy, rlo, rhi, kind, p0, p1, dm);
     seq_recursion(L, nbr, dm, M);
 }
 

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "seq_args.hpp"
 #include "seq_core.hpp"
 
@@ -37,11 +39,13 @@ __device__ __forceinline__ float shr1(float v) {
 
 // EXACT: num_levels == MMAX is a compile-time constant (no level branches in the step);
 // otherwise any num_levels <= MMAX is accepted at run time.
-template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT>
+// OMAX == 0: first-order algorithm (signature_algs.py:8-35).  OMAX >= 2: higher-order algorithm
+// (signature_algs.py:37-74) for any run-time order <= OMAX.
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0>
 __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
     static_assert((D * sizeof(T)) % 16 == 0, "record rows are read with 16-byte LDS loads");
-    using Lane = SeqLane<T, C, D, MMAX, MODE>;
+    using Lane = typename std::conditional<OMAX == 0, SeqLane<T, C, D, MMAX, MODE>, SeqLaneHO<T, C, D, MMAX, (OMAX > 0 ? OMAX : 1), MODE>>::type;
     constexpr int VEC = 16 / sizeof(T);                  // elements per 16-byte piece
     typedef T vecT __attribute__((ext_vector_type(VEC)));
 
@@ -113,6 +117,9 @@ __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
         __device__ __forceinline__ T cin(int m) const { return shr1<G>(L.s[m]); }
         __device__ __forceinline__ T din(int m) const { return shr1<G>(L.qold[m]); }
         __device__ __forceinline__ T kleft() const { return shr1<G>(L.kprev[C - 1]); }
+        __device__ __forceinline__ T win(int m, int r) const {
+            if constexpr (Lane::HIGHER_ORDER) return shr1<G>(L.w[m][r]); else return T(0);
+        }
     };
 
     // Lane 0 of each group starts x number k at step k*R1: its record must be resident by then.  The next
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
         if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (PF) load_row(ctl, xr_next);
 
-        seq_step(L, DevNbr{L}, xr, M, dummy, rlo, rhi, A.kind, p0, p1);
+        seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, A.kind, p0, p1);
     };
     // two steps per trip: the loop-carried hand-over words (s, qold) alternate registers instead of being copied
     // back every step.  An odd step count is rounded up; the extra step finds every lane past its last pair.
@@ -185,10 +192,10 @@ __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
     }
 }
 
-template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT>
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0>
 hipError_t seq_gram_launch(const SeqGramArgs& A, int ntasks, size_t lds_bytes, hipStream_t stream) {
     if (ntasks <= 0) return hipSuccess;
-    auto kern = seq_gram_kernel<T, G, C, D, MMAX, MODE, EXACT>;
+    auto kern = seq_gram_kernel<T, G, C, D, MMAX, MODE, EXACT, OMAX>;
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
         if (e != hipSuccess) return e;

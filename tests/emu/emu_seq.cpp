@@ -8,6 +8,7 @@
 // against the oracle without a GPU.  The product never links or loads this file.
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "seq_args.hpp"
@@ -15,9 +16,9 @@
 
 using namespace gpsig;
 
-template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT>
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0>
 static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
-    using Lane = SeqLane<T, C, D, MMAX, MODE>;
+    using Lane = typename std::conditional<OMAX == 0, SeqLane<T, C, D, MMAX, MODE>, SeqLaneHO<T, C, D, MMAX, (OMAX > 0 ? OMAX : 1), MODE>>::type;
     const int M = EXACT ? MMAX : A.M;
     const int R1 = A.R1, RS = A.RS, nslot = A.nslot, nx = tk.nx;
     const T* xrec = static_cast<const T*>(A.xrec);
@@ -82,6 +83,10 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
             for (int m = 0; m < MMAX; ++m) S.s[m] = lam ? L[lane - 1].s[m] : T(0);
             for (int m = 0; m < NbrSnapshot<T, MMAX>::NQ; ++m) S.qold[m] = lam ? L[lane - 1].qold[m] : T(0);
             S.klast = lam ? L[lane - 1].kprev[C - 1] : T(0);
+            if constexpr (Lane::HIGHER_ORDER) {
+                for (int m = 0; m < Lane::NQ; ++m)
+                    for (int r = 0; r < Lane::NO; ++r) S.w[m][r] = lam ? L[lane - 1].w[m][r] : T(0);
+            }
         }
         for (int lane = 0; lane < 64; ++lane) {
             const bool act = ctl[lane].active(nx);
@@ -89,15 +94,15 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
             T xr[D];
             for (int f = 0; f < D; ++f) xr[f] = rowp[f];
             const bool dummy = !act || ctl[lane].a == 0;
-            seq_step(L[lane], snap[lane], xr, M, dummy, rlo[lane], rhi[lane], A.kind, T(A.p0), T(A.p1));
+            seq_step(L[lane], snap[lane], xr, M, A.order, dummy, rlo[lane], rhi[lane], A.kind, T(A.p0), T(A.p1));
             ctl[lane].advance(R1, nslot);
         }
     }
 }
 
-template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT>
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0>
 static void emu_run(const SeqGramArgs& A, int ntasks) {
-    for (int b = 0; b < ntasks; ++b) emu_task<T, G, C, D, MMAX, MODE, EXACT>(A, A.tasks[b]);
+    for (int b = 0; b < ntasks; ++b) emu_task<T, G, C, D, MMAX, MODE, EXACT, OMAX>(A, A.tasks[b]);
 }
 
 #define TRY(G_, C_, D_, MM_, EX_)                                                                         \
@@ -108,7 +113,23 @@ static void emu_run(const SeqGramArgs& A, int ntasks) {
         return 0;                                                                                         \
     }
 
+#define TRY_HO(G_, C_, D_, MM_, OM_)                                                                             \
+    if (G == G_ && C == C_ && D == D_ && MMAX == MM_ && OMAX == OM_) {                                           \
+        if (mode == MODE_INC) emu_run<double, G_, C_, D_, MM_, MODE_INC, false, OM_>(*A, ntasks);                \
+        else if (mode == MODE_PT_DIFF) emu_run<double, G_, C_, D_, MM_, MODE_PT_DIFF, false, OM_>(*A, ntasks);   \
+        else return -2;                                                                                         \
+        return 0;                                                                                               \
+    }
+
 extern "C" {
+
+// higher-order kernels: emulator table {G, C, D, MMAX, OMAX}
+int emu_seq_gram_ho(int G, int C, int D, int MMAX, int OMAX, int mode, const SeqGramArgs* A, int ntasks) {
+    TRY_HO(64, 1, 4, 6, 6)
+    TRY_HO(64, 2, 4, 5, 3)
+    TRY_HO(16, 2, 4, 4, 4)
+    return -1;
+}
 
 int emu_seq_gram(int G, int C, int D, int MMAX, int mode, int exact, const SeqGramArgs* A, int ntasks) {
     TRY(16, 4, 8, 5, true)

@@ -26,7 +26,7 @@ class SeqGramArgs(C.Structure):
     _fields_ = [
         ("xrec", C.c_void_p), ("yrec", C.c_void_p), ("tasks", C.c_void_p),
         ("N1", C.c_int64), ("N2", C.c_int64), ("xrec_stride", C.c_int64), ("yrec_stride", C.c_int64),
-        ("R1", C.c_int32), ("R2", C.c_int32), ("RS", C.c_int32), ("M", C.c_int32), ("nslot", C.c_int32),
+        ("R1", C.c_int32), ("R2", C.c_int32), ("RS", C.c_int32), ("M", C.c_int32), ("order", C.c_int32), ("nslot", C.c_int32),
         ("issue_at", C.c_int32), ("slot_elems", C.c_int32), ("kind", C.c_int32),
         ("p0", C.c_double), ("p1", C.c_double),
         ("out", C.c_void_p), ("si", C.c_int64), ("sj", C.c_int64), ("sm", C.c_int64),
@@ -48,6 +48,7 @@ def lib():
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, "-o", so, srcs[0]])
         _lib = C.CDLL(so)
         _lib.emu_seq_gram.argtypes = [C.c_int] * 6 + [C.POINTER(SeqGramArgs), C.c_int]
+        _lib.emu_seq_gram_ho.argtypes = [C.c_int] * 6 + [C.POINTER(SeqGramArgs), C.c_int]
         _lib.emu_build_tasks.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int64, C.c_int64, C.POINTER(SeqTask), C.c_int]
     return _lib
@@ -90,13 +91,13 @@ def tasks_for(N1, N2, ypb, pred, max_run=64, shard=(0, 1), yrange=(0, -1)):
 
 
 def run(cfg, geom_x, geom_y, xrec, yrec, N1, N2, M, kind, p0, p1, out, si, sj, sm, ax, by, jitter_diag, sum_levels,
-        pred, mirror, max_run=64, shard=(0, 1), yrange=(0, -1), out_offset=0):
+        pred, mirror, max_run=64, shard=(0, 1), yrange=(0, -1), out_offset=0, order=1):
     tasks, nt = tasks_for(N1, N2, 64 // cfg["G"], pred, max_run, shard, yrange)
     A = SeqGramArgs()
     A.xrec, A.yrec, A.tasks = xrec.ctypes.data, yrec.ctypes.data, C.addressof(tasks)
     A.N1, A.N2 = N1, N2
     A.xrec_stride, A.yrec_stride = geom_x["rec_elems"], geom_y["rec_elems"]
-    A.R1, A.R2, A.RS, A.M = geom_x["rows"], geom_y["rows"], geom_x["RS"], M
+    A.R1, A.R2, A.RS, A.M, A.order = geom_x["rows"], geom_y["rows"], geom_x["RS"], M, order
     A.nslot = lib().emu_ring_depth(cfg["G"], geom_x["rows"])
     A.issue_at = lib().emu_ring_issue_at(cfg["G"], geom_x["rows"])
     A.slot_elems = geom_x["rec_elems"]
@@ -105,7 +106,10 @@ def run(cfg, geom_x, geom_y, xrec, yrec, N1, N2, M, kind, p0, p1, out, si, sj, s
     A.ax = ax.ctypes.data if ax is not None else None
     A.by = by.ctypes.data if by is not None else None
     A.jitter_diag, A.sum_levels, A.pred, A.mirror, A.use_glds = jitter_diag, int(sum_levels), pred, int(mirror), 0
-    rc = lib().emu_seq_gram(cfg["G"], cfg["C"], cfg["D"], cfg["MMAX"], geom_x["mode"], cfg["exact"], C.byref(A), nt)
+    if cfg.get("OMAX"):
+        rc = lib().emu_seq_gram_ho(cfg["G"], cfg["C"], cfg["D"], cfg["MMAX"], cfg["OMAX"], geom_x["mode"], C.byref(A), nt)
+    else:
+        rc = lib().emu_seq_gram(cfg["G"], cfg["C"], cfg["D"], cfg["MMAX"], geom_x["mode"], cfg["exact"], C.byref(A), nt)
     if rc != 0:
         raise RuntimeError("emulator has no such config")
     return nt
@@ -186,4 +190,29 @@ def kernel_K_owned_rows(Xs, base, M, variances, sigma, normalization, row_begin,
     # as the C API does: x index = column (si = 1), y index = row (sj = N), y indices >= row_end are invalid (N2 = row_end)
     run(cfg, g, g, rec, rec, N, row_end, M, BASE_IDS[base], 0.0, 0.0, out, 1, N, 0, ax, by,
         jitter if normalization else 0.0, True, PRED_CIRCULANT, False, yrange=(row_begin, row_end), out_offset=-row_begin * N)
+    return out
+
+
+HO_TABLE = [dict(G=64, C=1, D=4, MMAX=6, OMAX=6), dict(G=64, C=2, D=4, MMAX=5, OMAX=3), dict(G=16, C=2, D=4, MMAX=4, OMAX=4)]
+
+
+def seq_levels_ho(X1s, X2s, base, M, order, cfg, difference=True, base_params=(0.0, 0.0), diag_only=False):
+    """Unnormalised levels through the emulated HIGHER-ORDER kernel (signature_algs.py:37-74) with config `cfg`."""
+    sym = X2s is None
+    Y = X1s if sym else X2s
+    N1, L1, d = X1s.shape
+    N2, L2, _ = Y.shape
+    gx = geometry(base, difference, L1, cfg["D"])
+    gy = geometry(base, difference, L2, cfg["D"])
+    assert gy["rows"] <= cfg["G"] * cfg["C"] and d <= cfg["D"] and M <= cfg["MMAX"] and order <= cfg["OMAX"]
+    xrec = build_records(X1s, gx, difference, cfg["D"])
+    yrec = xrec if sym else build_records(Y, gy, difference, cfg["D"])
+    kind = BASE_IDS[base]
+    if diag_only:
+        out = np.full((M + 1, N1), np.nan)
+        run(cfg, gx, gy, xrec, yrec, N1, N2, M, kind, *base_params, out, 1, 0, N1, None, None, 0.0, False, PRED_DIAG, False, order=order)
+    else:
+        out = np.full((M + 1, N1, N2), np.nan)
+        run(cfg, gx, gy, xrec, yrec, N1, N2, M, kind, *base_params, out, N2, 1, N1 * N2, None, None, 0.0, False,
+            PRED_CIRCULANT if sym else PRED_ALL, sym, order=order)
     return out

@@ -161,3 +161,32 @@ def test_golden_fixture_cases_through_emulator(golden):
         np.testing.assert_allclose(got, arr[n + "/out0"], rtol=tol, atol=1e-12, err_msg=n)
         done += 1
     assert done >= 30
+
+
+# ------------------------------------------------------------------------------------------------
+# higher-order algorithm (signature_algs.py:37-74) through the emulated kernel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", E.HO_TABLE, ids=lambda c: f"G{c['G']}C{c['C']}o{c['OMAX']}")
+@pytest.mark.parametrize("N,L,d,M,order", [(5, 9, 3, 4, 2), (5, 9, 3, 4, 3), (4, 12, 2, 4, 4), (3, 20, 2, 5, 2),
+                                           (3, 9, 2, 2, 2), (3, 9, 2, 1, 1), (4, 8, 2, 4, 1), (3, 30, 3, 6, 6)])
+def test_higher_order_levels(cfg, N, L, d, M, order):
+    if M > cfg["MMAX"] or order > cfg["OMAX"] or L > cfg["G"] * cfg["C"]:
+        pytest.skip("outside this emulator shape")
+    rng = np.random.default_rng(N + L + M + order)
+    X, Y = rng.standard_normal((N, L, d)), rng.standard_normal((3, max(L - 2, 2), d))
+    for base in ("linear", "rbf"):
+        k = O.SignatureKernelOracle(L * d, d, M, base=base, normalization=False, lengthscales=None, order=order)
+        assert rel(E.seq_levels_ho(X, None, base, M, order, cfg), k._K_seq(X)) < 1e-12
+        assert rel(E.seq_levels_ho(X, Y, base, M, order, cfg), k._K_seq(X, Y)) < 1e-12
+        assert rel(E.seq_levels_ho(X, None, base, M, order, cfg, diag_only=True), k._K_seq_diag(X)) < 1e-12
+
+
+def test_full_order_kernel_is_the_signature_inner_product():
+    """notebooks/signature_kernel.ipynb cells 6-13 (order = num_levels vs signature features), through the emulator."""
+    rng = np.random.default_rng(77)
+    N, L, d, M = 6, 14, 3, 4
+    X = rng.standard_normal((N, L, d))
+    sigs = np.stack([O.truncated_signature(x, M) for x in X])
+    got = E.seq_levels_ho(X, None, "linear", M, M, E.HO_TABLE[0])
+    for m, sl in enumerate(O.signature_level_slices(d, M)):
+        assert rel(got[m], sigs[:, sl] @ sigs[:, sl].T) < 1e-12
