@@ -107,7 +107,7 @@ struct gpsig_ctx {
     hipStream_t stream = nullptr;
     int ptr_mode = GPSIG_PTR_HOST;
     int shard_i = 0, shard_n = 1;
-    int use_glds = 0;
+    int use_glds = 1;
     int allow_exact = 1;
     int max_run = 0;
     std::string err;
@@ -605,7 +605,7 @@ int gpsig_ctx_create(int device, void* stream, gpsig_ctx** out) {
     c->device = device;
     c->stream = static_cast<hipStream_t>(stream);
     const char* g = getenv("GPSIG_GLDS");
-    c->use_glds = g ? atoi(g) : 0;
+    c->use_glds = g ? atoi(g) : 1;     // LDS-DMA staging is the default (bit-identical to load + ds_write, slightly faster)
     const char* ex = getenv("GPSIG_NO_EXACT");
     c->allow_exact = (ex && atoi(ex)) ? 0 : 1;
     *out = c;

@@ -398,21 +398,27 @@ GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T 
     seq_recursion(L, nbr, dm, M);
 }
 
-// Per-lane position in the stream of x-side record rows.  Lane `lam` of a group starts `lam` steps late.
+// Per-lane position in the stream of x-side record rows.  Lane `lam` of a group starts `lam` steps late; all
+// counters simply run from -lam so that the lane's first real step is the one where they reach zero.  The ring
+// offset is advanced incrementally (no multiplies in the step loop).
 struct LaneCtl {
-    int n;     // steps since this lane became active (negative: not yet)
-    int a;     // record row within the current x            (0 .. R1-1)
-    int p;     // index of the current x within the task      (0 .. nx; == nx: flush step)
-    int slot;  // LDS ring slot of the current x
-    GPSIG_HD void init(int lam) { n = -lam; a = 0; p = 0; slot = 0; }
-    GPSIG_HD bool active(int nx) const { return n >= 0 && p < nx; }
-    // the step at which the lane sits on row 0 of x number p>=1 (or on the flush step) emits pair p-1
-    GPSIG_HD bool boundary() const { return n >= 0 && a == 0; }
-    GPSIG_HD void advance(int R1, int nslot) {
-        if (n >= 0) {
-            if (++a == R1) { a = 0; ++p; if (++slot == nslot) slot = 0; }
+    int n;      // steps since this lane became active (negative: not yet)
+    int a;      // record row within the current x (0 .. R1-1); negative before the lane's first step
+    int p;      // index of the current x within the task (== nx on the flush step)
+    int off;    // element offset of the current row inside the LDS ring
+    int sbase;  // element offset of the current x's ring slot
+    GPSIG_HD void init(int lam, int RS) { n = -lam; a = -lam; p = 0; off = -lam * RS; sbase = 0; }
+    GPSIG_HD bool active(int total_rows) const { return unsigned(n) < unsigned(total_rows); }   // total_rows = nx * R1
+    // the step at which the lane sits on row 0 of x number p >= 1 (or on the flush step) emits pair p-1
+    GPSIG_HD bool boundary() const { return a == 0; }
+    GPSIG_HD void advance(int R1, int RS, int slot_elems, int ring_elems) {
+        ++n; ++a; off += RS;
+        if (a == R1) {
+            a = 0; ++p;
+            sbase += slot_elems;
+            if (sbase == ring_elems) sbase = 0;
+            off = sbase;
         }
-        ++n;
     }
 };
 

@@ -42,7 +42,7 @@ __device__ __forceinline__ float shr1(float v) {
 // OMAX == 0: first-order algorithm (signature_algs.py:8-35).  OMAX >= 2: higher-order algorithm
 // (signature_algs.py:37-74) for any run-time order <= OMAX.
 template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0>
-__global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
+__global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1) void seq_gram_kernel(const SeqGramArgs A) {
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
     static_assert((D * sizeof(T)) % 16 == 0, "record rows are read with 16-byte LDS loads");
     using Lane = typename std::conditional<OMAX == 0, SeqLane<T, C, D, MMAX, MODE>, SeqLaneHO<T, C, D, MMAX, (OMAX > 0 ? OMAX : 1), MODE>>::type;
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
     stage(0, 0);
 
     LaneCtl ctl;
-    ctl.init(lam);
+    ctl.init(lam, RS);
+    const int total_rows = nx * R1, ring_elems = nslot * A.slot_elems;
     const T p0 = T(A.p0), p1 = T(A.p1);
 
     // left-neighbour reads: one DPP shift per 32-bit half, issued where the value is consumed
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
     // x-side record row of a lane for the step described by `cc` (16-byte LDS reads; rows are RS = D + pad apart,
     // so the 16 lanes of a pair group hit 16 different bank groups)
     auto load_row = [&](const LaneCtl& cc, T (&dst)[D]) {
-        const T* rowp = cc.active(nx) ? ring + int64_t(cc.slot) * A.slot_elems + cc.a * RS : zero_row;
+        const T* rowp = cc.active(total_rows) ? ring + cc.off : zero_row;
 #pragma unroll
         for (int f = 0; f < D; f += VEC) {
             vecT v = *reinterpret_cast<const vecT*>(rowp + f);
@@ -174,11 +175,11 @@ __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
         } else {
             load_row(ctl, xr);
         }
-        const bool dummy = !ctl.active(nx) || ctl.a == 0;
+        const bool dummy = !ctl.active(total_rows) || ctl.a == 0;
 
         // software pipeline: the row for the NEXT step is requested from LDS before this step's arithmetic.
         // If lane 0 opens a new x at the next step, its record (requested issue_at steps into this x) must have landed.
-        ctl.advance(R1, nslot);
+        ctl.advance(R1, RS, A.slot_elems, ring_elems);
         if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (PF) load_row(ctl, xr_next);
 
@@ -186,9 +187,15 @@ __global__ __launch_bounds__(64) void seq_gram_kernel(const SeqGramArgs A) {
     };
     // two steps per trip: the loop-carried hand-over words (s, qold) alternate registers instead of being copied
     // back every step.  An odd step count is rounded up; the extra step finds every lane past its last pair.
-    for (int t = 0; t < nsteps; t += 2) {
-        one_step();
-        one_step();
+    // (only where it pays: the point-kernel and higher-order bodies are large enough to lose a wave per SIMD to
+    // the doubled live ranges)
+    if constexpr (MODE == MODE_INC && OMAX == 0) {
+        for (int t = 0; t < nsteps; t += 2) {
+            one_step();
+            one_step();
+        }
+    } else {
+        for (int t = 0; t < nsteps; ++t) one_step();
     }
 }
 

@@ -47,7 +47,7 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
         rlo[lane] = lam == 0 ? 1 : 0;
         int h = A.R2 - C * lam;
         rhi[lane] = h < 0 ? 0 : (h > C ? C : h);
-        ctl[lane].init(lam);
+        ctl[lane].init(lam, RS);
     }
     auto stage = [&](int p, int slot) {
         int64_t i = int64_t(tk.x0) + p;
@@ -56,6 +56,7 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
     };
     stage(0, 0);
     const int nsteps = nx * R1 + G;
+    const int total_rows = nx * R1, ring_elems = nslot * A.slot_elems;
     int a_u = 0, k_u = 0, slot_next = 1 % nslot;
     T* out = static_cast<T*>(A.out);
     for (int t = 0; t < nsteps; ++t) {
@@ -89,13 +90,13 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
             }
         }
         for (int lane = 0; lane < 64; ++lane) {
-            const bool act = ctl[lane].active(nx);
-            const T* rowp = act ? ring.data() + size_t(ctl[lane].slot) * A.slot_elems + ctl[lane].a * RS : zero_row.data();
+            const bool act = ctl[lane].active(total_rows);
+            const T* rowp = act ? ring.data() + ctl[lane].off : zero_row.data();
             T xr[D];
             for (int f = 0; f < D; ++f) xr[f] = rowp[f];
             const bool dummy = !act || ctl[lane].a == 0;
             seq_step(L[lane], snap[lane], xr, M, A.order, dummy, rlo[lane], rhi[lane], A.kind, T(A.p0), T(A.p1));
-            ctl[lane].advance(R1, nslot);
+            ctl[lane].advance(R1, RS, A.slot_elems, ring_elems);
         }
     }
 }

@@ -298,17 +298,17 @@ def test_lds_dma_staging_and_generic_kernels_agree_bitwise(K):
     ctx = _lib.context(0, 0)
     base = kern.K(X)
     try:
-        ctx.set_option("glds", 1)
+        ctx.set_option("glds", 0)
         np.testing.assert_array_equal(kern.K(X), base)
         ctx.set_option("exact", 0)
         np.testing.assert_array_equal(kern.K(X), base)
-        ctx.set_option("glds", 0)
+        ctx.set_option("glds", 1)
         np.testing.assert_array_equal(kern.K(X), base)
         ctx.set_option("exact", 1)
         ctx.set_option("max_run", 3)
         np.testing.assert_array_equal(kern.K(X), base)
     finally:
-        ctx.set_option("glds", 0); ctx.set_option("exact", 1); ctx.set_option("max_run", 0)
+        ctx.set_option("glds", 1); ctx.set_option("exact", 1); ctx.set_option("max_run", 0)
 
 
 def test_shards_partition_the_gram(K):
