@@ -36,6 +36,8 @@ SeqLaunchFn seq_lookup_ho_ptd_d8(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_ptd_d16(int, int, int, int, int);
 typedef hipError_t (*TvsLaunchFn)(const TvsArgs&, hipStream_t);
 TvsLaunchFn tvs_lookup(int M, int TT, bool incr);
+typedef hipError_t (*TvsLaneTLaunchFn)(const TvsLaneTArgs&, hipStream_t);
+bool tvs_lanet_plan(int M, int d, bool incr, TvsLaneTLaunchFn* fns, int* ngroups);
 }  // namespace gpsig
 
 using namespace gpsig;
@@ -94,7 +96,7 @@ enum BufId {
     B_REC0, B_REC1,               // seq-gram records
     B_DLEV0, B_DLEV1,             // diagonal levels
     B_FAC0, B_FAC1,               // per-sequence factors
-    B_TASKS, B_W, B_XT, B_ZT, B_ZS, B_TMP0, B_TMP1,
+    B_TASKS, B_W, B_XT, B_ZT, B_ZS, B_ZL, B_ZN, B_TMP0, B_TMP1,
     B_COUNT
 };
 
@@ -110,6 +112,7 @@ struct gpsig_ctx {
     int use_glds = 1;
     int allow_exact = 1;
     int max_run = 0;
+    int tens_lanes = -1;   // -1 auto, 0 sequence lanes, 1 tensor lanes
     std::string err;
     DevBuf buf[B_COUNT];
     std::vector<SeqTask> host_tasks;
@@ -536,11 +539,51 @@ int tens_gram_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* 
     return GPSIG_OK;
 }
 
-// Kzx on device pointers.  fx: per-sequence factors (N, M+1) or NULL.
-int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* ZT, const void* ZS, const void* X,
-                       int64_t Tn, int64_t N, int L, int increments, const void* fx, const double* w, int return_levels,
-                       void* out) {
+// fx: per-sequence factors (N, M+1) or NULL.
+int tens_vs_seq_lanet_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Zdev, const void* X, int64_t Tn,
+                             int64_t N, int L, int increments, const void* fx, const double* w, int return_levels, void* out,
+                             const TvsLaneTLaunchFn* fns, int ngroups) {
+    const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
+    ScaleParams s = scale_of(p, !raw);
+    const int d_eff = s.d_eff();
+    const int64_t Tpad = (Tn + 63) / 64 * 64;
+    void *zl, *zn, *xs;
+    CHK(ensure(c, B_ZL, sizeof(double) * size_t(lt) * E * d_eff * Tpad + 8, &zl));
+    CHK(ensure(c, B_ZN, sizeof(double) * size_t(lt) * E * Tpad + 8, &zn));
+    CHK(ensure(c, B_XT, sizeof(double) * size_t(N) * L * d_eff + 8, &xs));
+    hipLaunchKernelGGL(prep_tensors_lanet_kernel<double>, dim3(grid_for(Tpad * lt * E)), dim3(256), 0, c->stream,
+                       static_cast<const double*>(Zdev), lt, Tn, Tpad, E, s, static_cast<double*>(zl), static_cast<double*>(zn));
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(prep_seq_scaled_kernel<double>, dim3(grid_for(N * int64_t(L) * d_eff)), dim3(256), 0, c->stream,
+                       static_cast<const double*>(X), N, L, s, static_cast<double*>(xs));
+    HIPCHK(c, hipGetLastError());
+    TvsLaneTArgs A;
+    memset(&A, 0, sizeof(A));
+    A.XS = xs; A.ZL = zl; A.ZN = zn; A.N = N; A.Tn = Tn; A.Tpad = Tpad;
+    A.L = L; A.d_eff = d_eff; A.kind = p->base_kernel; A.difference = p->difference; A.order = p->order; A.M = M;
+    base_p(p, &A.p0, &A.p1);
+    A.fx = fx; A.w = w; A.out = out; A.sum_levels = (raw || return_levels) ? 0 : 1;
+    hipEvent_t e0, e1;
+    CHK(timing_begin(c, &e0, &e1));
+    for (int g = 0; g < ngroups; ++g) HIPCHK(c, fns[g](A, c->stream));
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    c->t_launches += 1;
+    c->t_pairs += Tn * N;
+    return GPSIG_OK;
+}
+
+// Kzx on device pointers.  Zdev: the caller's (lt, T, E, d') tensor array; ZT/ZS: its sequence-lane preparation.
+int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Zdev, const void* ZT, const void* ZS,
+                       const void* X, int64_t Tn, int64_t N, int L, int increments, const void* fx, const double* w,
+                       int return_levels, void* out) {
     const int M = p->num_levels;
+    if (N > 0 && Tn > 0 && N <= 65535 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1) &&
+        size_t(L) * scale_of(p, !raw).d_eff() * sizeof(double) <= 48 * 1024) {
+        TvsLaneTLaunchFn fns[8];
+        int ng = 0;
+        if (tvs_lanet_plan(M, scale_of(p, !raw).d_eff(), increments != 0, fns, &ng))
+            return tens_vs_seq_lanet_device(c, p, raw, Zdev, X, Tn, N, L, increments, fx, w, return_levels, out, fns, ng);
+    }
     const int64_t Npad = (N + 63) / 64 * 64;
     ScaleParams sx = scale_of(p, !raw);
     const int d_eff = sx.d_eff();
@@ -650,6 +693,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     if (!strcmp(name, "glds")) c->use_glds = value ? 1 : 0;
     else if (!strcmp(name, "exact")) c->allow_exact = value ? 1 : 0;
     else if (!strcmp(name, "max_run")) c->max_run = value > 0 ? value : 0;
+    else if (!strcmp(name, "tensor_lanes")) c->tens_lanes = value;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);
     return GPSIG_OK;
 }
@@ -757,7 +801,7 @@ int gpsig_tens_vs_seq_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z,
     q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
     const void *ZT, *ZS;
     CHK(prep_tensors(c, &q, false, dZ, T, E, &ZT, &ZS));
-    CHK(tens_vs_seq_device(c, &q, true, ZT, ZS, dX, T, N, L, increments, nullptr, nullptr, 1, dout));
+    CHK(tens_vs_seq_device(c, &q, true, dZ, ZT, ZS, dX, T, N, L, increments, nullptr, nullptr, 1, dout));
     CHK(out_done(c, out, dout, ob));
     return finish(c);
 }
@@ -882,7 +926,7 @@ int gpsig_kernel_K_tens_vs_seq(gpsig_ctx* c, const gpsig_params* p, const void* 
     CHK(upload_weights(c, p, &w));
     const void *ZT, *ZS;
     CHK(prep_tensors(c, p, true, dZ, T, E, &ZT, &ZS));
-    CHK(tens_vs_seq_device(c, p, false, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dout));
+    CHK(tens_vs_seq_device(c, p, false, dZ, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dout));
     CHK(out_done(c, out, dout, ob));
     return finish(c);
 }
@@ -913,7 +957,7 @@ int gpsig_kernel_K_tens_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const vo
     if (p->normalization) CHK(seq_diag_factors(c, p, dX, N, L, &fx));
     const void *ZT, *ZS;
     CHK(prep_tensors(c, p, true, dZ, T, E, &ZT, &ZS));
-    CHK(tens_vs_seq_device(c, p, false, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dzx));
+    CHK(tens_vs_seq_device(c, p, false, dZ, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dzx));
     if (full_X_cov) {
         CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, return_levels, dxx, true));   // kernels.py:630-640
     } else {

@@ -231,17 +231,19 @@ __global__ __launch_bounds__(64) void tens_vs_seq_kernel(const TvsArgs A) {
             const int64_t t = (t0 + tt < A.Tn) ? t0 + tt : A.Tn - 1;
             const T* __restrict__ zs = ZS + t * (LT * E);
             T dm[LT];
+            {
+                T kvv[LT * E], zz[LT * E];
 #pragma unroll
-            for (int k = 0; k < LT; ++k) {
-                T kv;
-                if constexpr (INCR) {   // kernels.py:329-330: kappa(z[.,1], x) - kappa(z[.,0], x)
-                    kv = base_eval<T>(A.kind, ip[tt][k][1], zs[k * 2 + 1], xs, p0, p1) -
-                         base_eval<T>(A.kind, ip[tt][k][0], zs[k * 2], xs, p0, p1);
-                } else {
-                    kv = base_eval<T>(A.kind, ip[tt][k][0], zs[k], xs, p0, p1);
+                for (int k = 0; k < LT; ++k)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) { kvv[k * E + e] = ip[tt][k][e]; zz[k * E + e] = zs[k * E + e]; }
+                base_eval_n<T, LT * E>(A.kind, kvv, zz, xs, p0, p1);
+#pragma unroll
+                for (int k = 0; k < LT; ++k) {
+                    const T kv = INCR ? kvv[k * E + E - 1] - kvv[k * E] : kvv[k * E];   // kernels.py:329-330
+                    if (A.difference) { dm[k] = kv - kprev[tt][k]; kprev[tt][k] = kv; }   // signature_algs.py:114
+                    else dm[k] = kv;
                 }
-                if (A.difference) { dm[k] = kv - kprev[tt][k]; kprev[tt][k] = kv; }   // signature_algs.py:114
-                else dm[k] = kv;
             }
             if (!(A.difference && tau == 0)) {
                 if (A.order <= 1) {
@@ -298,6 +300,178 @@ __global__ __launch_bounds__(64) void tens_vs_seq_kernel(const TvsArgs A) {
             else out[(int64_t(i) * A.Tn + t) * A.N + n] = v;
         }
         if (A.sum_levels) out[t * A.N + n] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tensor-lane variant of the tensor-vs-sequence kernel: one lane per inducing TENSOR, one wavefront per
+// (block of 64 tensors, sequence).  The sequence's observation x(tau) is then wave-uniform (scalar loads of
+// the caller's own (N, L, d) layout after scaling, no transposed copy) and the tensor components of the level
+// being swept sit in registers, so the inner product is D fp64 FMAs with a scalar operand and no LDS or
+// per-lane memory traffic inside the time loop.  Levels are swept one after the other (a level's chain only
+// involves its own components, signature_algs.py:118-125).  Used when there are at least 32 tensors.
+struct TvsLaneTArgs {
+    const void* XS;     // (N, L, d_eff) scaled observations, sequence-major
+    const void* ZL;     // (lt, E, d_eff, Tpad) scaled tensor components, tensor index fastest
+    const void* ZN;     // (lt, E, Tpad) squared norms
+    int64_t N, Tn, Tpad;
+    int32_t L, d_eff, kind, difference, order, M;
+    double p0, p1;
+    const void* fx;     // (N, M+1) per-sequence factors or NULL
+    const double* w;    // (M+1) level weights or NULL
+    void* out;          // (T, N) or (M+1, T, N)
+    int32_t sum_levels;
+};
+
+// One kernel instance sweeps the levels LO..HI together (their components all in registers: the host splits the
+// levels into groups that fit, tvl_plan in tens_inst.hip); the first group also writes level 0, later groups add
+// to the level sum written by the earlier ones (same stream, so ordered).
+template <typename T, int LO, int HI, int D, bool INCR>
+__global__ __launch_bounds__(64) void tens_vs_seq_lanet_kernel(const TvsLaneTArgs A) {
+    constexpr int E = INCR ? 2 : 1;
+    constexpr int K0 = LO * (LO - 1) / 2;                         // first component of level LO
+    constexpr int NC = HI * (HI + 1) / 2 - K0;                    // components of levels LO..HI
+    extern __shared__ __attribute__((aligned(16))) unsigned char tvl_smem[];
+    T* const xbuf = reinterpret_cast<T*>(tvl_smem);               // the whole scaled sequence: L * d values
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x * int64_t(64) + lane;            // < Tpad by construction
+    const int64_t n = blockIdx.y;
+    const int d = A.d_eff, M = A.M;
+    {   // one coalesced pass over the sequence; every later read is a same-address (broadcast) LDS read
+        const T* __restrict__ XG = static_cast<const T*>(A.XS) + n * int64_t(A.L) * d;
+        for (int idx = lane; idx < A.L * d; idx += 64) xbuf[idx] = XG[idx];
+    }
+    const T* __restrict__ ZL = static_cast<const T*>(A.ZL);
+    const T* __restrict__ ZN = static_cast<const T*>(A.ZN);
+    const T p0 = T(A.p0), p1 = T(A.p1);
+    const T* fx = A.fx ? static_cast<const T*>(A.fx) + n * (M + 1) : nullptr;
+    T* out = static_cast<T*>(A.out);
+
+    T z[NC][E][D], zz[NC * E];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            zz[c * E + e] = ZN[(int64_t(K0 + c) * E + e) * A.Tpad + t];
+#pragma unroll
+            for (int f = 0; f < D; ++f) z[c][e][f] = (f < d) ? ZL[((int64_t(K0 + c) * E + e) * d + f) * A.Tpad + t] : T(0);
+        }
+    T u[NC], kprev[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { u[c] = T(0); kprev[c] = T(0); }
+
+    for (int tau = 0; tau < A.L; ++tau) {
+        T x[D];
+        T xs = T(0);
+#pragma unroll
+        for (int f = 0; f < D; ++f) { x[f] = (f < d) ? xbuf[tau * d + f] : T(0); xs = fma(x[f], x[f], xs); }
+        T kvv[NC * E];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                T ip = z[c][e][0] * x[0];
+#pragma unroll
+                for (int f = 1; f < D; ++f) ip = fma(z[c][e][f], x[f], ip);
+                kvv[c * E + e] = ip;
+            }
+        base_eval_n<T, NC * E>(A.kind, kvv, zz, xs, p0, p1);
+        T dm[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const T k1 = INCR ? kvv[c * E + E - 1] - kvv[c * E] : kvv[c * E];               // kernels.py:329-330
+            if (A.difference) { dm[c] = k1 - kprev[c]; kprev[c] = k1; } else dm[c] = k1;     // signature_algs.py:114
+        }
+        if (A.difference && tau == 0) continue;
+#pragma unroll
+        for (int i = LO; i <= HI; ++i) {
+            constexpr int dummy0 = 0; (void)dummy0;
+            const int c0 = i * (i - 1) / 2 - K0;
+            if (A.order <= 1) {
+#pragma unroll
+                for (int j = i - 1; j >= 1; --j) u[c0 + j] = fma(dm[c0 + j], u[c0 + j - 1], u[c0 + j]);   // signature_algs.py:122-124
+                u[c0] += dm[c0];
+            } else {                                                                         // signature_algs.py:147-158
+                T Rp[HI], Rc[HI];
+                Rp[0] = dm[c0];
+                T totp = dm[c0];
+#pragma unroll
+                for (int j = 1; j < i; ++j) {
+                    const int dj = (j + 1 < A.order) ? j + 1 : A.order;
+                    Rc[0] = dm[c0 + j] * u[c0 + j - 1];
+                    T totc = Rc[0];
+#pragma unroll
+                    for (int l = 1; l <= j; ++l)
+                        if (l < dj) { Rc[l] = (dm[c0 + j] * (T(1) / T(l + 1))) * Rp[l - 1]; totc += Rc[l]; }
+                    u[c0 + j - 1] += totp;
+#pragma unroll
+                    for (int l = 0; l <= j; ++l) Rp[l] = Rc[l];
+                    totp = totc;
+                }
+                u[c0 + i - 1] += totp;
+            }
+        }
+    }
+
+    if (t >= A.Tn) return;
+    T acc = T(0);
+    if (LO == 1) {                                                 // level 0 (signature_algs.py:116)
+        T v0 = T(1);
+        if (fx) v0 *= fx[0];
+        if (A.w) v0 *= T(A.w[0]);
+        if (A.sum_levels) acc = v0; else out[(int64_t(0) * A.Tn + t) * A.N + n] = v0;
+    } else if (A.sum_levels) {
+        acc = out[t * A.N + n];
+    }
+#pragma unroll
+    for (int i = LO; i <= HI; ++i) {
+        T v = u[i * (i - 1) / 2 - K0 + i - 1];
+        if (fx) v *= fx[i];
+        if (A.w) v *= T(A.w[i]);
+        if (A.sum_levels) acc += v; else out[(int64_t(i) * A.Tn + t) * A.N + n] = v;
+    }
+    if (A.sum_levels) out[t * A.N + n] = acc;
+}
+
+// Scaled inducing tensors in the tensor-lane layout.  In: Z (lt, T, E, d_eff).
+// Out: ZL[((k * E + e) * d_eff + fe) * Tpad + t], ZN[(k * E + e) * Tpad + t] = |z|^2  (zero for t >= T).
+template <typename T>
+__global__ void prep_tensors_lanet_kernel(const T* __restrict__ Z, int lt, int64_t Tn, int64_t Tpad, int E, ScaleParams P,
+                                          T* __restrict__ ZL, T* __restrict__ ZN) {
+    const int d_eff = P.d_eff();
+    const int64_t total = Tpad * lt * E;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t t = idx % Tpad;
+        const int e = int((idx / Tpad) % E);
+        const int k = int(idx / (Tpad * E));
+        T ss = T(0);
+        for (int fe = 0; fe < d_eff; ++fe) {
+            const int lag = fe / P.d_in, f = fe - lag * P.d_in;
+            T v = T(0);
+            if (t < Tn) {
+                v = Z[((int64_t(k) * Tn + t) * E + e) * d_eff + fe];
+                if (P.has_ls) {
+                    v = v / T(P.ls[f]);
+                    if (P.num_lags > 0) v = v * T(P.gamma[lag]);
+                }
+            }
+            ZL[((int64_t(k) * E + e) * d_eff + fe) * Tpad + t] = v;
+            ss = fma(v, v, ss);
+        }
+        ZN[(int64_t(k) * E + e) * Tpad + t] = ss;
+    }
+}
+
+// Scaled observations in the caller's own layout: XS[(n * L + t) * d_eff + fe].
+template <typename T>
+__global__ void prep_seq_scaled_kernel(const T* __restrict__ X, int64_t N, int L, ScaleParams P, T* __restrict__ out) {
+    const int d_eff = P.d_eff();
+    const int64_t total = N * int64_t(L) * d_eff;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int fe = int(idx % d_eff);
+        const int t = int((idx / d_eff) % L);
+        const int64_t n = idx / (int64_t(d_eff) * L);
+        out[idx] = scaled_point<T>(X + n * int64_t(L) * P.d_in, L, t, fe, P);
     }
 }
 

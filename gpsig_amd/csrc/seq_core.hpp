@@ -66,6 +66,56 @@ GPSIG_HD T base_eval(int kind, T inner, T xs, T ys, T p0, T p1) {
     return (T(1) + c * r + T(5.0 / 3.0) * (r * r)) * exp(-c * r);
 }
 
+// The same for NV inner products at once, in place: v[i] (inner product) -> kappa.  a2[i] is the squared norm
+// on the per-value side, b2 the squared norm of the shared point.  The switch on the kernel family sits OUTSIDE
+// the unrolled loops: one wave-uniform branch per call instead of one per value.
+template <typename T, int NV>
+GPSIG_HD void base_eval_n(int kind, T (&v)[NV], const T (&a2)[NV], T b2, T p0, T p1, int nvalid = NV) {
+    switch (kind) {
+        case BASE_LINEAR: return;
+        case BASE_COSINE: {
+            const T sb = sqrt(b2);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = v[i] / (sb * sqrt(a2[i]));
+            return;
+        }
+        case BASE_POLY:
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = pow(v[i] + p0, p1);
+            return;
+        case BASE_RBF:
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = exp(-fma(T(-2), v[i], b2 + a2[i]) / 2);
+            return;
+        case BASE_MIX:
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = p0 * exp(-fma(T(-2), v[i], b2 + a2[i]) / 2) + (T(1) - p0) * v[i];
+            return;
+        case BASE_MATERN12:
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = exp(-sqrt(fmax(fma(T(-2), v[i], b2 + a2[i]), T(1e-40))));
+            return;
+        case BASE_MATERN32: {
+            const T c = T(1.7320508075688772935);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (i < nvalid) {
+                const T r = sqrt(fmax(fma(T(-2), v[i], b2 + a2[i]), T(1e-40)));
+                v[i] = (T(1) + c * r) * exp(-c * r);
+            }
+            return;
+        }
+        default: {
+            const T c = T(2.2360679774997896964);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) if (i < nvalid) {
+                const T r = sqrt(fmax(fma(T(-2), v[i], b2 + a2[i]), T(1e-40)));
+                v[i] = (T(1) + c * r + T(5.0 / 3.0) * (r * r)) * exp(-c * r);
+            }
+            return;
+        }
+    }
+}
+
 template <typename T, int C, int D, int MMAX, int MODE>
 struct SeqLane {
     static constexpr int NQ = MMAX > 1 ? MMAX - 1 : 1;
@@ -360,8 +410,9 @@ GPSIG_HD void seq_increments(Lane& L, const Nbr& nbr, const T (&xr)[D], bool dum
             T acc = xr[0] * L.y[r][0];
 #pragma unroll
             for (int f = 1; f < D; ++f) acc = fma(xr[f], L.y[r][f], acc);
-            knew[r] = base_eval<T>(kind, acc, xs, L.y2[r], p0, p1);
+            knew[r] = acc;
         }
+        base_eval_n<T, C>(kind, knew, L.y2, xs, p0, p1);
         if constexpr (MODE == MODE_PT_DIFF) {
             const T kleft_new = nbr.kleft();
             dm[0] = (knew[0] - kleft_new) - (L.kprev[0] - L.kleft);

@@ -88,7 +88,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
 /* Tuning / debugging knobs; unknown names return GPSIG_ERR_INVALID.
  *   "glds"        1: stage x-side records with LDS-DMA (global_load_lds), 0: load + ds_write
  *   "exact"       1: allow the kernels specialised on num_levels, 0: generic kernels only
- *   "max_run"     >0: x-side run length per task, 0: automatic */
+ *   "max_run"     >0: x-side run length per task, 0: automatic
+ *   "tensor_lanes" tensor-vs-sequence kernel: 1 one lane per tensor, 0 one lane per sequence, -1 automatic */
 int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
 /* HIP-event timing of the dominant kernel (the pair recursion) launched by the calls since the last
  * reset, measured on the ctx stream: total milliseconds and number of launches. */

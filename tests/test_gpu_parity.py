@@ -414,3 +414,29 @@ def test_owned_row_blocks_reassemble_the_symmetric_gram(K):
     # ShardedGram with world == 1 is kern.K
     g = parallel.ShardedGram(kern, n, torch.device("cuda", 0))
     assert torch.equal(g(X), full)
+
+
+@pytest.mark.parametrize("T", [5, 40, 130])
+def test_tensor_vs_sequence_lane_mappings_agree(K, T):
+    """Kzx has two kernels: one lane per sequence (few tensors) and one lane per tensor (>= 32 tensors).  Both must
+    match the oracle, for every base kernel family, increments, higher order, levels and lags."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(T)
+    N, L, d, M = 37, 23, 3, 4
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+    ctx = _lib.context(0, 0)
+    try:
+        for base in ("linear", "rbf", "matern32"):
+            for incr in (False, True):
+                for order, lags in ((1, None), (3, None), (1, 1)):
+                    dd = d * ((lags or 0) + 1)
+                    Z = rng.standard_normal((M * (M + 1) // 2, T, 2, dd) if incr else (M * (M + 1) // 2, T, dd))
+                    kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, order=order, num_lags=lags,
+                              lengthscales=0.5 + rng.random(d))
+                    want = make_oracle(kw).K_tens_vs_seq(Z, X, increments=incr, return_levels=True)
+                    for mode in (0, 1):
+                        ctx.set_option("tensor_lanes", mode)
+                        got = make_kernel(K, kw).K_tens_vs_seq(Z, X, increments=incr, return_levels=True)
+                        assert relerr(got, want) <= TOL, (base, incr, order, lags, mode)
+    finally:
+        ctx.set_option("tensor_lanes", -1)
