@@ -35,7 +35,13 @@ SeqLaunchFn seq_lookup_ho_ptd_d4(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_ptd_d8(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_ptd_d16(int, int, int, int, int);
 typedef hipError_t (*TvsLaunchFn)(const TvsArgs&, hipStream_t);
-TvsLaunchFn tvs_lookup(int M, int TT, bool incr);
+TvsLaunchFn tvs_lookup(int M, int TT, bool incr, bool f32);
+SeqLaunchFn seq_lookup_f32_inc_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_inc_g16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_inc_g64(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptd_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptd_g16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptd_g64(int, int, int, int, bool);
 typedef hipError_t (*TvsLaneTLaunchFn)(const TvsLaneTArgs&, hipStream_t);
 bool tvs_lanet_plan(int M, int d, bool incr, TvsLaneTLaunchFn* fns, int* ngroups);
 }  // namespace gpsig
@@ -52,11 +58,28 @@ const SeqConfig SEQ_TABLE_GENERIC[] = {GPSIG_SEQ_CONFIGS_GENERIC(X_CFG)};
 const SeqHOConfig SEQ_HO_TABLE[] = {GPSIG_SEQ_HO_ALL(X_HO)};
 #undef X_HO
 constexpr int N_SEQ_HO_TABLE = int(sizeof(SEQ_HO_TABLE) / sizeof(SEQ_HO_TABLE[0]));
+#define X_CFG2(G_, C_, D_, MM_, EX_) {G_, C_, D_, MM_, EX_},
+const SeqConfig SEQ_TABLE_F32[] = {GPSIG_SEQ_CONFIGS_F32_ALL(X_CFG2)};
+#undef X_CFG2
+constexpr int N_SEQ_TABLE_F32 = int(sizeof(SEQ_TABLE_F32) / sizeof(SEQ_TABLE_F32[0]));
 constexpr int N_SEQ_TABLE = int(sizeof(SEQ_TABLE) / sizeof(SEQ_TABLE[0]));
 constexpr int N_SEQ_TABLE_GENERIC = int(sizeof(SEQ_TABLE_GENERIC) / sizeof(SEQ_TABLE_GENERIC[0]));
 
-SeqLaunchFn seq_launcher(int mode, const SeqConfig& c) {
+SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32) {
     SeqLaunchFn f = nullptr;
+    if (f32) {
+        if (mode == MODE_INC) {
+            if ((f = seq_lookup_f32_inc_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if ((f = seq_lookup_f32_inc_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            return seq_lookup_f32_inc_g64(c.G, c.C, c.D, c.MMAX, c.exact);
+        }
+        if (mode == MODE_PT_DIFF) {
+            if ((f = seq_lookup_f32_ptd_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if ((f = seq_lookup_f32_ptd_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            return seq_lookup_f32_ptd_g64(c.G, c.C, c.D, c.MMAX, c.exact);
+        }
+        return nullptr;
+    }
     if (mode == MODE_INC) {
         if ((f = seq_lookup_inc_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
         if ((f = seq_lookup_inc_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
@@ -71,7 +94,8 @@ SeqLaunchFn seq_launcher(int mode, const SeqConfig& c) {
     return seq_lookup_ptn_g64(c.G, c.C, c.D, c.MMAX, c.exact);
 }
 
-SeqLaunchFn seq_launcher_ho(int mode, const SeqHOConfig& c) {
+SeqLaunchFn seq_launcher_ho(int mode, const SeqHOConfig& c, bool f32) {
+    if (f32) return nullptr;   // higher-order kernels are built for float64 only
     if (mode == MODE_INC) {
         if (c.D == 4) return seq_lookup_ho_inc_d4(c.G, c.C, c.D, c.MMAX, c.OMAX);
         if (c.D == 8) return seq_lookup_ho_inc_d8(c.G, c.C, c.D, c.MMAX, c.OMAX);
@@ -198,7 +222,7 @@ int grid_for(int64_t n, int block = 256) {
 int check_params(gpsig_ctx* c, const gpsig_params* p) {
     if (!c) return GPSIG_ERR_INVALID;
     if (!p) return fail(c, GPSIG_ERR_INVALID, "params is NULL");
-    if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "only float64 is built in this round (dtype=%d)", p->dtype);
+    if (p->dtype != GPSIG_F64 && p->dtype != GPSIG_F32) return fail(c, GPSIG_ERR_INVALID, "unknown dtype %d", p->dtype);
     if (p->num_levels < 1) return fail(c, GPSIG_ERR_INVALID, "num_levels must be >= 1");
     if (p->num_features < 1 || p->num_features > MAX_FEATURES)
         return fail(c, GPSIG_ERR_UNSUPPORTED, "num_features=%d outside [1, %d]", p->num_features, MAX_FEATURES);
@@ -241,6 +265,12 @@ int upload_weights(gpsig_ctx* c, const gpsig_params* p, const double** w) {
     return GPSIG_OK;
 }
 
+#define ENTER(c, p)                         \
+    CHK(check_params((c), (p)));            \
+    HIPCHK((c), hipSetDevice((c)->device));
+
+template <typename TT>
+struct Impl {
 // ---- seq-gram planning -----------------------------------------------------------------------------
 struct SeqPlanned {
     SeqConfig cfg;
@@ -248,8 +278,8 @@ struct SeqPlanned {
     int mode, d_eff;
 };
 
-int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
-    SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, 8);
+static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
+    SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
     if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
         if (g0.mode == MODE_PT_NODIFF)
             return fail(c, GPSIG_ERR_UNSUPPORTED, "order > 1 with difference=False and a non-linear base kernel is not built");
@@ -263,12 +293,15 @@ int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned*
         out->cfg = SeqConfig{h.G, h.C, h.D, h.MMAX, false};
         out->mode = g0.mode;
         out->d_eff = d_eff;
-        out->fn = seq_launcher_ho(g0.mode, h);
+        out->fn = seq_launcher_ho(g0.mode, h, sizeof(TT) == 4);
         if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "higher-order kernel shape missing from this build");
         return GPSIG_OK;
     }
-    const SeqConfig* tab = g0.mode == MODE_PT_NODIFF ? SEQ_TABLE_GENERIC : SEQ_TABLE;
-    const int ntab = g0.mode == MODE_PT_NODIFF ? N_SEQ_TABLE_GENERIC : N_SEQ_TABLE;
+    const bool f32 = sizeof(TT) == 4;
+    if (f32 && g0.mode == MODE_PT_NODIFF)
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "float32 with difference=False and a non-linear base kernel is not built");
+    const SeqConfig* tab = f32 ? SEQ_TABLE_F32 : (g0.mode == MODE_PT_NODIFF ? SEQ_TABLE_GENERIC : SEQ_TABLE);
+    const int ntab = f32 ? N_SEQ_TABLE_F32 : (g0.mode == MODE_PT_NODIFF ? N_SEQ_TABLE_GENERIC : N_SEQ_TABLE);
     int k = seq_select(tab, ntab, g0.rows, d_eff, p->num_levels, c->allow_exact != 0);
     if (k < 0)
         return fail(c, GPSIG_ERR_UNSUPPORTED,
@@ -278,32 +311,32 @@ int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned*
     out->cfg = tab[k];
     out->mode = g0.mode;
     out->d_eff = d_eff;
-    out->fn = seq_launcher(g0.mode, tab[k]);
+    out->fn = seq_launcher(g0.mode, tab[k], sizeof(TT) == 4);
     if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "seq-gram kernel shape missing from this build");
     return GPSIG_OK;
 }
 
 // records of N sequences (device, user layout (N, L, d)) into buffer `id`
-int make_records(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const SeqPlanned& pl, const void* Xdev, int64_t N,
+static int make_records(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const SeqPlanned& pl, const void* Xdev, int64_t N,
                  int L, int id, const void** rec, SeqGeom* geom) {
-    *geom = seq_geometry(p->base_kernel, p->difference, L, pl.cfg.D, 8);
-    const size_t bytes = size_t(N) * geom->rec_elems * sizeof(double);
+    *geom = seq_geometry(p->base_kernel, p->difference, L, pl.cfg.D, int(sizeof(TT)));
+    const size_t bytes = size_t(N) * geom->rec_elems * sizeof(TT);
     void* d;
     CHK(ensure(c, id, bytes ? bytes : 8, &d));
     if (N > 0) {
         HIPCHK(c, hipMemsetAsync(d, 0, bytes, c->stream));
         ScaleParams s = scale_of(p, apply_scaling);
         const int64_t total = N * geom->rows * s.d_eff();
-        hipLaunchKernelGGL(prep_seq_records_kernel<double>, dim3(grid_for(total)), dim3(256), 0, c->stream,
-                           static_cast<const double*>(Xdev), N, L, s, geom->mode, p->difference, geom->rows, geom->RS,
-                           int64_t(geom->rec_elems), static_cast<double*>(d));
+        hipLaunchKernelGGL(prep_seq_records_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, c->stream,
+                           static_cast<const TT*>(Xdev), N, L, s, geom->mode, p->difference, geom->rows, geom->RS,
+                           int64_t(geom->rec_elems), static_cast<TT*>(d));
         HIPCHK(c, hipGetLastError());
     }
     *rec = d;
     return GPSIG_OK;
 }
 
-int timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
+static int timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
     if (c->ev_used + 2 > c->ev.size()) {
         hipEvent_t a, b;
         HIPCHK(c, hipEventCreate(&a));
@@ -330,7 +363,7 @@ struct SeqRun {
     int64_t y_begin, y_end;   // y-block range (0, 0) = all
 };
 
-int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const SeqRun& r) {
+static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const SeqRun& r) {
     if (r.N1 <= 0 || r.N2 <= 0) return GPSIG_OK;
     if (r.N1 > 0x7fffffff || r.N2 > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 sequences");
     const int ypb = 64 / pl.cfg.G;
@@ -364,7 +397,7 @@ int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const 
     A.out = r.out; A.si = r.si; A.sj = r.sj; A.sm = r.sm;
     A.ax = r.ax; A.by = r.by; A.jitter_diag = r.jitter_diag;
     A.sum_levels = r.sum_levels; A.pred = r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds;
-    const size_t lds = sizeof(double) * (size_t(A.RS) + size_t(A.nslot) * A.slot_elems);
+    const size_t lds = sizeof(TT) * (size_t(A.RS) + size_t(A.nslot) * A.slot_elems);
     if (lds > 160 * 1024) return fail(c, GPSIG_ERR_UNSUPPORTED, "x-side records of %d rows do not fit the LDS ring (%zu bytes)", A.R1, lds);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (r.timed) CHK(timing_begin(c, &e0, &e1));
@@ -380,11 +413,11 @@ int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const 
 }
 
 // diag levels of N sequences, sequence-major (N, M+1), into buffer `id`
-int diag_levels(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const void* rec, const SeqGeom& g, int64_t N,
+static int diag_levels(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const void* rec, const SeqGeom& g, int64_t N,
                 int id, const void** dlev) {
     const int M1 = p->num_levels + 1;
     void* d;
-    CHK(ensure(c, id, sizeof(double) * size_t(N) * M1 + 8, &d));
+    CHK(ensure(c, id, sizeof(TT) * size_t(N) * M1 + 8, &d));
     SeqRun r;
     memset(&r, 0, sizeof(r));
     r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
@@ -400,13 +433,13 @@ int diag_levels(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const
     return GPSIG_OK;
 }
 
-int make_factors(gpsig_ctx* c, const void* dlev, int64_t N, int M1, const double* w, double jitter, int id, const void** fac,
+static int make_factors(gpsig_ctx* c, const void* dlev, int64_t N, int M1, const double* w, double jitter, int id, const void** fac,
                  int squared = 0) {
     void* d;
-    CHK(ensure(c, id, sizeof(double) * size_t(N) * M1 + 8, &d));
+    CHK(ensure(c, id, sizeof(TT) * size_t(N) * M1 + 8, &d));
     if (N > 0) {
-        hipLaunchKernelGGL(factors_kernel<double>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream,
-                           static_cast<const double*>(dlev), N, M1, w, jitter, squared, static_cast<double*>(d));
+        hipLaunchKernelGGL(factors_kernel<TT>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream,
+                           static_cast<const TT*>(dlev), N, M1, w, jitter, squared, static_cast<TT*>(d));
         HIPCHK(c, hipGetLastError());
     }
     *fac = d;
@@ -415,7 +448,7 @@ int make_factors(gpsig_ctx* c, const void* dlev, int64_t N, int M1, const double
 
 // Per-sequence factors w[m] / sqrt(diag_m + jitter) (or squared) of one side, with that side's own kernel shape:
 // the diagonal pass keeps the sequence itself in registers, whatever the main pass does with it.
-int side_factors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* X, int64_t N, int L, const double* w,
+static int side_factors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* X, int64_t N, int L, const double* w,
                  int squared, int id_dlev, int id_fac, const void** fac) {
     const int d_eff = p->num_features * ((apply_scaling ? p->num_lags : 0) + 1);
     SeqPlanned pl;
@@ -430,7 +463,7 @@ int side_factors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const 
 
 // Core of K / _K_seq on device pointers.  raw: no scaling, no normalisation, no weights (levels out).
 // x_squared: X-side factor 1/(diag+jitter) instead of 1/sqrt(diag+jitter) (K_seq_n_seq_covs quirk, kernels.py:713+:750).
-int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, const void* X2, int64_t N1, int64_t N2,
+static int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, const void* X2, int64_t N1, int64_t N2,
                  int L1, int L2, int return_levels, void* out, bool timed, int x_squared = 0, int64_t row_begin = 0,
                  int64_t row_end = 0) {
     if (L1 < 1 || L2 < 1) return fail(c, GPSIG_ERR_INVALID, "sequence length must be >= 1");
@@ -483,7 +516,7 @@ int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, c
         r.N2 = row_end;          // y indices >= row_end belong to the next block: never loaded, never emitted
         r.si = 1; r.sj = N1; r.ax = fa; r.by = fb; r.mirror = 0;
         r.y_begin = row_begin; r.y_end = row_end;
-        r.out = static_cast<double*>(out) - row_begin * N1;
+        r.out = static_cast<TT*>(out) - row_begin * N1;
         return launch_seq(c, p, pl, r);
     }
     if (!swap) {   // x = X (rows of the output), y = X2 (columns)
@@ -496,29 +529,29 @@ int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, c
     return launch_seq(c, p, pl, r);
 }
 
-size_t seq_out_elems(const gpsig_params* p, int64_t N1, int64_t N2, int levels) {
+static size_t seq_out_elems(const gpsig_params* p, int64_t N1, int64_t N2, int levels) {
     return size_t(N1) * size_t(N2) * (levels ? size_t(p->num_levels + 1) : 1);
 }
 
 // ---- tensors ---------------------------------------------------------------------------------------
-int prep_tensors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* Zdev, int64_t Tn, int E,
+static int prep_tensors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* Zdev, int64_t Tn, int E,
                  const void** ZT, const void** ZS) {
     const int lt = p->num_levels * (p->num_levels + 1) / 2;
     ScaleParams s = scale_of(p, apply_scaling);
     const int d_eff = s.d_eff();
     void *zt, *zs;
-    CHK(ensure(c, B_ZT, sizeof(double) * size_t(Tn) * d_eff * lt * E + 8, &zt));
-    CHK(ensure(c, B_ZS, sizeof(double) * size_t(Tn) * lt * E + 8, &zs));
+    CHK(ensure(c, B_ZT, sizeof(TT) * size_t(Tn) * d_eff * lt * E + 8, &zt));
+    CHK(ensure(c, B_ZS, sizeof(TT) * size_t(Tn) * lt * E + 8, &zs));
     if (Tn > 0) {
-        hipLaunchKernelGGL(prep_tensors_kernel<double>, dim3(grid_for(Tn * lt * E)), dim3(256), 0, c->stream,
-                           static_cast<const double*>(Zdev), lt, Tn, E, s, static_cast<double*>(zt), static_cast<double*>(zs));
+        hipLaunchKernelGGL(prep_tensors_kernel<TT>, dim3(grid_for(Tn * lt * E)), dim3(256), 0, c->stream,
+                           static_cast<const TT*>(Zdev), lt, Tn, E, s, static_cast<TT*>(zt), static_cast<TT*>(zs));
         HIPCHK(c, hipGetLastError());
     }
     *ZT = zt; *ZS = zs;
     return GPSIG_OK;
 }
 
-int tens_gram_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Z, int64_t Tn, int increments,
+static int tens_gram_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Z, int64_t Tn, int increments,
                      int return_levels, void* out) {
     const int E = increments ? 2 : 1;
     const void *ZT, *ZS;
@@ -533,14 +566,14 @@ int tens_gram_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* 
     A.out = out;
     A.sum_levels = (raw || return_levels) ? 0 : 1;
     if (Tn > 0) {
-        hipLaunchKernelGGL(tens_gram_kernel<double>, dim3(grid_for(Tn * Tn)), dim3(256), 0, c->stream, A);
+        hipLaunchKernelGGL(tens_gram_kernel<TT>, dim3(grid_for(Tn * Tn)), dim3(256), 0, c->stream, A);
         HIPCHK(c, hipGetLastError());
     }
     return GPSIG_OK;
 }
 
 // fx: per-sequence factors (N, M+1) or NULL.
-int tens_vs_seq_lanet_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Zdev, const void* X, int64_t Tn,
+static int tens_vs_seq_lanet_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Zdev, const void* X, int64_t Tn,
                              int64_t N, int L, int increments, const void* fx, const double* w, int return_levels, void* out,
                              const TvsLaneTLaunchFn* fns, int ngroups) {
     const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
@@ -548,14 +581,14 @@ int tens_vs_seq_lanet_device(gpsig_ctx* c, const gpsig_params* p, bool raw, cons
     const int d_eff = s.d_eff();
     const int64_t Tpad = (Tn + 63) / 64 * 64;
     void *zl, *zn, *xs;
-    CHK(ensure(c, B_ZL, sizeof(double) * size_t(lt) * E * d_eff * Tpad + 8, &zl));
-    CHK(ensure(c, B_ZN, sizeof(double) * size_t(lt) * E * Tpad + 8, &zn));
-    CHK(ensure(c, B_XT, sizeof(double) * size_t(N) * L * d_eff + 8, &xs));
-    hipLaunchKernelGGL(prep_tensors_lanet_kernel<double>, dim3(grid_for(Tpad * lt * E)), dim3(256), 0, c->stream,
-                       static_cast<const double*>(Zdev), lt, Tn, Tpad, E, s, static_cast<double*>(zl), static_cast<double*>(zn));
+    CHK(ensure(c, B_ZL, sizeof(TT) * size_t(lt) * E * d_eff * Tpad + 8, &zl));
+    CHK(ensure(c, B_ZN, sizeof(TT) * size_t(lt) * E * Tpad + 8, &zn));
+    CHK(ensure(c, B_XT, sizeof(TT) * size_t(N) * L * d_eff + 8, &xs));
+    hipLaunchKernelGGL(prep_tensors_lanet_kernel<TT>, dim3(grid_for(Tpad * lt * E)), dim3(256), 0, c->stream,
+                       static_cast<const TT*>(Zdev), lt, Tn, Tpad, E, s, static_cast<TT*>(zl), static_cast<TT*>(zn));
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(prep_seq_scaled_kernel<double>, dim3(grid_for(N * int64_t(L) * d_eff)), dim3(256), 0, c->stream,
-                       static_cast<const double*>(X), N, L, s, static_cast<double*>(xs));
+    hipLaunchKernelGGL(prep_seq_scaled_kernel<TT>, dim3(grid_for(N * int64_t(L) * d_eff)), dim3(256), 0, c->stream,
+                       static_cast<const TT*>(X), N, L, s, static_cast<TT*>(xs));
     HIPCHK(c, hipGetLastError());
     TvsLaneTArgs A;
     memset(&A, 0, sizeof(A));
@@ -573,31 +606,31 @@ int tens_vs_seq_lanet_device(gpsig_ctx* c, const gpsig_params* p, bool raw, cons
 }
 
 // Kzx on device pointers.  Zdev: the caller's (lt, T, E, d') tensor array; ZT/ZS: its sequence-lane preparation.
-int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Zdev, const void* ZT, const void* ZS,
+static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Zdev, const void* ZT, const void* ZS,
                        const void* X, int64_t Tn, int64_t N, int L, int increments, const void* fx, const double* w,
                        int return_levels, void* out) {
     const int M = p->num_levels;
     if (N > 0 && Tn > 0 && N <= 65535 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1) &&
-        size_t(L) * scale_of(p, !raw).d_eff() * sizeof(double) <= 48 * 1024) {
+        size_t(L) * scale_of(p, !raw).d_eff() * sizeof(TT) <= 48 * 1024) {
         TvsLaneTLaunchFn fns[8];
         int ng = 0;
-        if (tvs_lanet_plan(M, scale_of(p, !raw).d_eff(), increments != 0, fns, &ng))
+        if (sizeof(TT) == 8 && tvs_lanet_plan(M, scale_of(p, !raw).d_eff(), increments != 0, fns, &ng))
             return tens_vs_seq_lanet_device(c, p, raw, Zdev, X, Tn, N, L, increments, fx, w, return_levels, out, fns, ng);
     }
     const int64_t Npad = (N + 63) / 64 * 64;
     ScaleParams sx = scale_of(p, !raw);
     const int d_eff = sx.d_eff();
     void* xt;
-    CHK(ensure(c, B_XT, sizeof(double) * size_t(L) * d_eff * Npad + 8, &xt));
+    CHK(ensure(c, B_XT, sizeof(TT) * size_t(L) * d_eff * Npad + 8, &xt));
     if (N > 0) {
-        hipLaunchKernelGGL(prep_seq_timemajor_kernel<double>, dim3(grid_for(int64_t(L) * d_eff * Npad)), dim3(256), 0,
-                           c->stream, static_cast<const double*>(X), N, Npad, L, sx, static_cast<double*>(xt));
+        hipLaunchKernelGGL(prep_seq_timemajor_kernel<TT>, dim3(grid_for(int64_t(L) * d_eff * Npad)), dim3(256), 0,
+                           c->stream, static_cast<const TT*>(X), N, Npad, L, sx, static_cast<TT*>(xt));
         HIPCHK(c, hipGetLastError());
     }
     const int lt = M * (M + 1) / 2;
     const int E = increments ? 2 : 1;
-    int TT = (lt * (2 + E) * 2 <= 100) ? 2 : 1;
-    TvsLaunchFn fn = tvs_lookup(M, TT, increments != 0);
+    int NTT = (lt * (2 + E) * 2 <= 100) ? 2 : 1;
+    TvsLaunchFn fn = tvs_lookup(M, NTT, increments != 0, sizeof(TT) == 4);
     if (!fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "tensor-vs-sequence kernel is built for num_levels <= 8 (got %d)", M);
     TvsArgs A;
     memset(&A, 0, sizeof(A));
@@ -617,9 +650,334 @@ int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void
 }
 
 // per-sequence 1/sqrt(diag + jitter) factors (N, M+1) of sequences X, into B_FAC1
-int seq_diag_factors(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int L, const void** fac) {
+static int seq_diag_factors(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int L, const void** fac) {
     return side_factors(c, p, true, X, N, L, nullptr, 0, B_DLEV0, B_FAC1, fac);
 }
+
+static int e_seq_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
+                          int32_t L1, int32_t L2, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1);
+    gpsig_params q = *p;
+    q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
+    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    const void *dX, *dX2 = nullptr;
+    CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N1) * L1 * d, &dX));
+    if (X2) CHK(in_dev(c, B_IN1, X2, sizeof(TT) * size_t(N2) * L2 * d, &dX2));
+    const int64_t Nc = X2 ? N2 : N1;
+    const size_t ob = sizeof(TT) * seq_out_elems(p, N1, Nc, 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    CHK(seq_K_device(c, &q, true, dX, dX2, N1, Nc, L1, X2 ? L2 : L1, 1, dout, true));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+static int e_seq_diag_levels(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1);
+    gpsig_params q = *p;
+    q.num_features = d; q.num_lags = 0;
+    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    const int M1 = p->num_levels + 1;
+    const void* dX;
+    CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N) * L * d, &dX));
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, sizeof(TT) * size_t(N) * M1, &dout));
+    SeqPlanned pl;
+    CHK(plan_seq(c, &q, d, L, &pl));
+    const void* rec;
+    SeqGeom g;
+    CHK(make_records(c, &q, false, pl, dX, N, L, B_REC0, &rec, &g));
+    SeqRun r;
+    memset(&r, 0, sizeof(r));
+    r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
+    r.out = dout; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
+    CHK(launch_seq(c, &q, pl, r));
+    CHK(out_done(c, out, dout, sizeof(TT) * size_t(N) * M1));
+    return finish(c);
+}
+
+static int e_tens_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    const void* dZ;
+    CHK(in_dev(c, B_IN0, Z, sizeof(TT) * size_t(lt) * T * E * d, &dZ));
+    const size_t ob = sizeof(TT) * size_t(T) * T * (p->num_levels + 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    gpsig_params q = *p;
+    q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
+    CHK(tens_gram_device(c, &q, true, dZ, T, increments, 1, dout));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+static int e_tens_vs_seq_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
+                             int32_t L, int32_t increments, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    const void *dZ, *dX;
+    CHK(in_dev(c, B_IN0, Z, sizeof(TT) * size_t(lt) * T * E * d, &dZ));
+    CHK(in_dev(c, B_IN1, X, sizeof(TT) * size_t(N) * L * d, &dX));
+    const size_t ob = sizeof(TT) * size_t(T) * N * (p->num_levels + 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    gpsig_params q = *p;
+    q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
+    const void *ZT, *ZS;
+    CHK(prep_tensors(c, &q, false, dZ, T, E, &ZT, &ZS));
+    CHK(tens_vs_seq_device(c, &q, true, dZ, ZT, ZS, dX, T, N, L, increments, nullptr, nullptr, 1, dout));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+static int e_kernel_K(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2, int32_t L1,
+                   int32_t L2, int32_t return_levels, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features;
+    const void *dX, *dX2 = nullptr;
+    CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N1) * L1 * d, &dX));
+    if (X2) CHK(in_dev(c, B_IN1, X2, sizeof(TT) * size_t(N2) * L2 * d, &dX2));
+    const int64_t Nc = X2 ? N2 : N1;
+    const size_t ob = sizeof(TT) * seq_out_elems(p, N1, Nc, return_levels);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    CHK(seq_K_device(c, p, false, dX, dX2, N1, Nc, L1, X2 ? L2 : L1, return_levels, dout, true));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+static int e_kernel_K_symm_rows(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int64_t row_begin,
+                             int64_t row_end, void* out_rows) {
+    ENTER(c, p);
+    if (row_begin < 0 || row_end > N || row_begin > row_end || ((row_begin % 4) != 0 && row_begin != row_end))
+        return fail(c, GPSIG_ERR_INVALID, "bad row range [%lld, %lld) of %lld (row_begin must be a multiple of 4)",
+                    (long long)row_begin, (long long)row_end, (long long)N);
+    const void* dX;
+    CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N) * L * p->num_features, &dX));
+    const size_t ob = sizeof(TT) * size_t(row_end - row_begin) * N;
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out_rows, ob, &dout));
+    if (row_end > row_begin) CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, 0, dout, true, 0, row_begin, row_end));
+    CHK(out_done(c, out_rows, dout, ob));
+    return finish(c);
+}
+
+static int e_symmetrize_owned_rows(gpsig_ctx* c, int32_t dtype, const void* half, int64_t N, void* out) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (half == out) return fail(c, GPSIG_ERR_INVALID, "symmetrize needs distinct buffers");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t b = sizeof(TT) * size_t(N) * N;
+    const void* dh;
+    CHK(in_dev(c, B_IN0, half, b, &dh));
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, b, &dout));
+    if (N > 0) {
+        hipLaunchKernelGGL(symmetrize_owned_rows_kernel<TT>, dim3(grid_for(N * N)), dim3(256), 0, c->stream,
+                           static_cast<const TT*>(dh), N, static_cast<TT*>(dout));
+        HIPCHK(c, hipGetLastError());
+    }
+    CHK(out_done(c, out, dout, b));
+    return finish(c);
+}
+
+static int e_kernel_Kdiag(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int32_t return_levels, void* out) {
+    ENTER(c, p);
+    const int M1 = p->num_levels + 1;
+    const size_t ob = sizeof(TT) * size_t(N) * (return_levels ? M1 : 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    const double* w;
+    CHK(upload_weights(c, p, &w));
+    void* tmp;
+    CHK(ensure(c, B_TMP0, sizeof(TT) * size_t(N) * M1 + 8, &tmp));
+    if (p->normalization) {
+        // kernels.py:486-490: sigma * variances, no data touched
+        if (N > 0) {
+            hipLaunchKernelGGL(fill_kernel<TT>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream, static_cast<TT*>(tmp), N * M1, TT(1));
+            HIPCHK(c, hipGetLastError());
+        }
+    } else {
+        const void* dX;
+        CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N) * L * p->num_features, &dX));
+        const int d_eff = p->num_features * (p->num_lags + 1);
+        SeqPlanned pl;
+        CHK(plan_seq(c, p, d_eff, L, &pl));
+        const void* rec;
+        SeqGeom g;
+        CHK(make_records(c, p, true, pl, dX, N, L, B_REC0, &rec, &g));
+        SeqRun r;
+        memset(&r, 0, sizeof(r));
+        r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
+        r.out = tmp; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
+        CHK(launch_seq(c, p, pl, r));
+    }
+    if (N > 0) {
+        hipLaunchKernelGGL(weight_levels_kernel<TT>, dim3(grid_for(N)), dim3(256), 0, c->stream,
+                           static_cast<const TT*>(tmp), N, M1, w, return_levels ? 0 : 1, static_cast<TT*>(dout));
+        HIPCHK(c, hipGetLastError());
+    }
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+static int e_kernel_K_tens(gpsig_ctx* c, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, int32_t return_levels, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    const void* dZ;
+    CHK(in_dev(c, B_IN0, Z, sizeof(TT) * size_t(lt) * T * E * d, &dZ));
+    const size_t ob = sizeof(TT) * size_t(T) * T * (return_levels ? p->num_levels + 1 : 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    CHK(tens_gram_device(c, p, false, dZ, T, increments, return_levels, dout));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+static int e_kernel_K_tens_vs_seq(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
+                               int32_t L, int32_t increments, int32_t return_levels, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    const void *dZ, *dX;
+    CHK(in_dev(c, B_IN0, Z, sizeof(TT) * size_t(lt) * T * E * d, &dZ));
+    CHK(in_dev(c, B_IN1, X, sizeof(TT) * size_t(N) * L * p->num_features, &dX));
+    const size_t ob = sizeof(TT) * size_t(T) * N * (return_levels ? p->num_levels + 1 : 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    const void* fx = nullptr;
+    if (p->normalization) CHK(seq_diag_factors(c, p, dX, N, L, &fx));     // kernels.py:572-581
+    const double* w;
+    CHK(upload_weights(c, p, &w));
+    const void *ZT, *ZS;
+    CHK(prep_tensors(c, p, true, dZ, T, E, &ZT, &ZS));
+    CHK(tens_vs_seq_device(c, p, false, dZ, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dout));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+static int e_kernel_K_tens_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
+                                   int32_t L, int32_t increments, int32_t full_X_cov, int32_t return_levels, void* Kzz,
+                                   void* Kzx, void* Kxx) {
+    ENTER(c, p);
+    const int M1 = p->num_levels + 1;
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    const size_t lv = return_levels ? size_t(M1) : 1;
+    const void *dZ, *dX;
+    CHK(in_dev(c, B_IN0, Z, sizeof(TT) * size_t(lt) * T * E * d, &dZ));
+    CHK(in_dev(c, B_IN1, X, sizeof(TT) * size_t(N) * L * p->num_features, &dX));
+    const size_t bzz = sizeof(TT) * size_t(T) * T * lv, bzx = sizeof(TT) * size_t(T) * N * lv;
+    const size_t bxx = sizeof(TT) * (full_X_cov ? size_t(N) * N : size_t(N)) * lv;
+    void *dzz, *dzx, *dxx;
+    CHK(out_dev(c, B_OUT0, Kzz, bzz, &dzz));
+    CHK(out_dev(c, B_OUT1, Kzx, bzx, &dzx));
+    CHK(out_dev(c, B_OUT2, Kxx, bxx, &dxx));
+    const double* w;
+    CHK(upload_weights(c, p, &w));
+    // Kzz: never normalised (kernels.py:623, :641/:665)
+    CHK(tens_gram_device(c, p, false, dZ, T, increments, return_levels, dzz));
+    // Kzx: divided by sqrt(diag_x + jitter) when normalising (kernels.py:638 / :660) -- with full_X_cov the
+    // diagonal of (Kxx + jitter*I) is the same number
+    const void* fx = nullptr;
+    if (p->normalization) CHK(seq_diag_factors(c, p, dX, N, L, &fx));
+    const void *ZT, *ZS;
+    CHK(prep_tensors(c, p, true, dZ, T, E, &ZT, &ZS));
+    CHK(tens_vs_seq_device(c, p, false, dZ, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dzx));
+    if (full_X_cov) {
+        CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, return_levels, dxx, true));   // kernels.py:630-640
+    } else {
+        void* tmp;
+        CHK(ensure(c, B_TMP0, sizeof(TT) * size_t(N) * M1 + 8, &tmp));
+        if (p->normalization) {   // kernels.py:661
+            if (N > 0) {
+                hipLaunchKernelGGL(fill_kernel<TT>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream, static_cast<TT*>(tmp), N * M1, TT(1));
+                HIPCHK(c, hipGetLastError());
+            }
+        } else {                  // kernels.py:653, :663
+            const int d_eff = p->num_features * (p->num_lags + 1);
+            SeqPlanned pl;
+            CHK(plan_seq(c, p, d_eff, L, &pl));
+            const void* rec;
+            SeqGeom g;
+            CHK(make_records(c, p, true, pl, dX, N, L, B_REC0, &rec, &g));
+            SeqRun r;
+            memset(&r, 0, sizeof(r));
+            r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
+            r.out = tmp; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
+            CHK(launch_seq(c, p, pl, r));
+        }
+        if (N > 0) {
+            hipLaunchKernelGGL(weight_levels_kernel<TT>, dim3(grid_for(N)), dim3(256), 0, c->stream,
+                               static_cast<const TT*>(tmp), N, M1, w, return_levels ? 0 : 1, static_cast<TT*>(dxx));
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    CHK(out_done(c, Kzz, dzz, bzz));
+    CHK(out_done(c, Kzx, dzx, bzx));
+    CHK(out_done(c, Kxx, dxx, bxx));
+    return finish(c);
+}
+
+static int e_kernel_K_seq_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
+                                  int32_t L1, int32_t L2, int32_t full_X2_cov, int32_t return_levels, void* Kxx, void* Kxx2,
+                                  void* Kx2x2) {
+    ENTER(c, p);
+    const int M1 = p->num_levels + 1, d = p->num_features;
+    const size_t lv = return_levels ? size_t(M1) : 1;
+    const void *dX, *dX2;
+    CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N1) * L1 * d, &dX));
+    CHK(in_dev(c, B_IN1, X2, sizeof(TT) * size_t(N2) * L2 * d, &dX2));
+    const size_t b11 = sizeof(TT) * size_t(N1) * N1 * lv, b12 = sizeof(TT) * size_t(N1) * N2 * lv;
+    const size_t b22 = sizeof(TT) * (full_X2_cov ? size_t(N2) * N2 : size_t(N2)) * lv;
+    void *d11, *d12, *d22;
+    CHK(out_dev(c, B_OUT0, Kxx, b11, &d11));
+    CHK(out_dev(c, B_OUT1, Kxx2, b12, &d12));
+    CHK(out_dev(c, B_OUT2, Kx2x2, b22, &d22));
+    // Kxx (kernels.py:704, :709-712, :730/:755) == K(X)
+    CHK(seq_K_device(c, p, false, dX, nullptr, N1, N1, L1, L1, return_levels, d11, true));
+    // Kxx2 (kernels.py:705, :713, :727 / :750).  Reference quirk, reproduced: in the diagonal-only branch the
+    // X-side factor is applied twice (:713 then :750), i.e. 1/(diag_x + jitter) instead of 1/sqrt(.).
+    CHK(seq_K_device(c, p, false, dX, dX2, N1, N2, L1, L2, return_levels, d12, true, (p->normalization && !full_X2_cov) ? 1 : 0));
+    if (full_X2_cov) {
+        // kernels.py:719-732; :723-728 reference undefined names -- the evident intent (mirror of :709-712) == K(X2)
+        CHK(seq_K_device(c, p, false, dX2, nullptr, N2, N2, L2, L2, return_levels, d22, true));
+    } else {
+        const double* w;
+        CHK(upload_weights(c, p, &w));
+        void* tmp;
+        CHK(ensure(c, B_TMP0, sizeof(TT) * size_t(N2) * M1 + 8, &tmp));
+        if (p->normalization) {   // kernels.py:751
+            if (N2 > 0) {
+                hipLaunchKernelGGL(fill_kernel<TT>, dim3(grid_for(N2 * M1)), dim3(256), 0, c->stream, static_cast<TT*>(tmp), N2 * M1, TT(1));
+                HIPCHK(c, hipGetLastError());
+            }
+        } else {                  // kernels.py:743, :753
+            SeqPlanned pl;
+            CHK(plan_seq(c, p, d * (p->num_lags + 1), L2, &pl));
+            const void* rec;
+            SeqGeom g;
+            CHK(make_records(c, p, true, pl, dX2, N2, L2, B_REC0, &rec, &g));
+            SeqRun r;
+            memset(&r, 0, sizeof(r));
+            r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N2; r.N2 = N2;
+            r.out = tmp; r.si = 1; r.sj = 0; r.sm = N2; r.pred = PRED_DIAG; r.timed = true;
+            CHK(launch_seq(c, p, pl, r));
+        }
+        if (N2 > 0) {
+            hipLaunchKernelGGL(weight_levels_kernel<TT>, dim3(grid_for(N2)), dim3(256), 0, c->stream,
+                               static_cast<const TT*>(tmp), N2, M1, w, return_levels ? 0 : 1, static_cast<TT*>(d22));
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    CHK(out_done(c, Kxx, d11, b11));
+    CHK(out_done(c, Kxx2, d12, b12));
+    CHK(out_done(c, Kx2x2, d22, b22));
+    return finish(c);
+}
+
+};
 
 }  // namespace
 
@@ -722,332 +1080,85 @@ int gpsig_timing_get(gpsig_ctx* c, double* kernel_ms, int64_t* launches, int64_t
     return GPSIG_OK;
 }
 
-#define ENTER(c, p)                         \
-    CHK(check_params((c), (p)));            \
-    HIPCHK((c), hipSetDevice((c)->device));
+
+
+
+
+
+
+
+
+
+
+
 
 int gpsig_seq_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
                           int32_t L1, int32_t L2, void* out) {
-    ENTER(c, p);
-    const int d = p->num_features * (p->num_lags + 1);
-    gpsig_params q = *p;
-    q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
-    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
-    const void *dX, *dX2 = nullptr;
-    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N1) * L1 * d, &dX));
-    if (X2) CHK(in_dev(c, B_IN1, X2, sizeof(double) * size_t(N2) * L2 * d, &dX2));
-    const int64_t Nc = X2 ? N2 : N1;
-    const size_t ob = sizeof(double) * seq_out_elems(p, N1, Nc, 1);
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out, ob, &dout));
-    CHK(seq_K_device(c, &q, true, dX, dX2, N1, Nc, L1, X2 ? L2 : L1, 1, dout, true));
-    CHK(out_done(c, out, dout, ob));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_seq_gram_levels(c, p, X, X2, N1, N2, L1, L2, out) : Impl<double>::e_seq_gram_levels(c, p, X, X2, N1, N2, L1, L2, out);
 }
 
 int gpsig_seq_diag_levels(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, void* out) {
-    ENTER(c, p);
-    const int d = p->num_features * (p->num_lags + 1);
-    gpsig_params q = *p;
-    q.num_features = d; q.num_lags = 0;
-    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
-    const int M1 = p->num_levels + 1;
-    const void* dX;
-    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * d, &dX));
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out, sizeof(double) * size_t(N) * M1, &dout));
-    SeqPlanned pl;
-    CHK(plan_seq(c, &q, d, L, &pl));
-    const void* rec;
-    SeqGeom g;
-    CHK(make_records(c, &q, false, pl, dX, N, L, B_REC0, &rec, &g));
-    SeqRun r;
-    memset(&r, 0, sizeof(r));
-    r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
-    r.out = dout; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
-    CHK(launch_seq(c, &q, pl, r));
-    CHK(out_done(c, out, dout, sizeof(double) * size_t(N) * M1));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_seq_diag_levels(c, p, X, N, L, out) : Impl<double>::e_seq_diag_levels(c, p, X, N, L, out);
 }
 
 int gpsig_tens_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, void* out) {
-    ENTER(c, p);
-    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
-    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
-    const void* dZ;
-    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
-    const size_t ob = sizeof(double) * size_t(T) * T * (p->num_levels + 1);
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out, ob, &dout));
-    gpsig_params q = *p;
-    q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
-    CHK(tens_gram_device(c, &q, true, dZ, T, increments, 1, dout));
-    CHK(out_done(c, out, dout, ob));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_tens_gram_levels(c, p, Z, T, increments, out) : Impl<double>::e_tens_gram_levels(c, p, Z, T, increments, out);
 }
 
 int gpsig_tens_vs_seq_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
                              int32_t L, int32_t increments, void* out) {
-    ENTER(c, p);
-    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
-    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
-    const void *dZ, *dX;
-    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
-    CHK(in_dev(c, B_IN1, X, sizeof(double) * size_t(N) * L * d, &dX));
-    const size_t ob = sizeof(double) * size_t(T) * N * (p->num_levels + 1);
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out, ob, &dout));
-    gpsig_params q = *p;
-    q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
-    const void *ZT, *ZS;
-    CHK(prep_tensors(c, &q, false, dZ, T, E, &ZT, &ZS));
-    CHK(tens_vs_seq_device(c, &q, true, dZ, ZT, ZS, dX, T, N, L, increments, nullptr, nullptr, 1, dout));
-    CHK(out_done(c, out, dout, ob));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_tens_vs_seq_levels(c, p, Z, X, T, N, L, increments, out) : Impl<double>::e_tens_vs_seq_levels(c, p, Z, X, T, N, L, increments, out);
 }
 
 int gpsig_kernel_K(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2, int32_t L1,
                    int32_t L2, int32_t return_levels, void* out) {
-    ENTER(c, p);
-    const int d = p->num_features;
-    const void *dX, *dX2 = nullptr;
-    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N1) * L1 * d, &dX));
-    if (X2) CHK(in_dev(c, B_IN1, X2, sizeof(double) * size_t(N2) * L2 * d, &dX2));
-    const int64_t Nc = X2 ? N2 : N1;
-    const size_t ob = sizeof(double) * seq_out_elems(p, N1, Nc, return_levels);
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out, ob, &dout));
-    CHK(seq_K_device(c, p, false, dX, dX2, N1, Nc, L1, X2 ? L2 : L1, return_levels, dout, true));
-    CHK(out_done(c, out, dout, ob));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K(c, p, X, X2, N1, N2, L1, L2, return_levels, out) : Impl<double>::e_kernel_K(c, p, X, X2, N1, N2, L1, L2, return_levels, out);
 }
 
 int gpsig_kernel_K_symm_rows(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int64_t row_begin,
                              int64_t row_end, void* out_rows) {
-    ENTER(c, p);
-    if (row_begin < 0 || row_end > N || row_begin > row_end || ((row_begin % 4) != 0 && row_begin != row_end))
-        return fail(c, GPSIG_ERR_INVALID, "bad row range [%lld, %lld) of %lld (row_begin must be a multiple of 4)",
-                    (long long)row_begin, (long long)row_end, (long long)N);
-    const void* dX;
-    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
-    const size_t ob = sizeof(double) * size_t(row_end - row_begin) * N;
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out_rows, ob, &dout));
-    if (row_end > row_begin) CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, 0, dout, true, 0, row_begin, row_end));
-    CHK(out_done(c, out_rows, dout, ob));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K_symm_rows(c, p, X, N, L, row_begin, row_end, out_rows) : Impl<double>::e_kernel_K_symm_rows(c, p, X, N, L, row_begin, row_end, out_rows);
 }
 
 int gpsig_symmetrize_owned_rows(gpsig_ctx* c, int32_t dtype, const void* half, int64_t N, void* out) {
     if (!c) return GPSIG_ERR_INVALID;
-    if (dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "only float64 is built in this round");
-    if (half == out) return fail(c, GPSIG_ERR_INVALID, "symmetrize needs distinct buffers");
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t b = sizeof(double) * size_t(N) * N;
-    const void* dh;
-    CHK(in_dev(c, B_IN0, half, b, &dh));
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out, b, &dout));
-    if (N > 0) {
-        hipLaunchKernelGGL(symmetrize_owned_rows_kernel<double>, dim3(grid_for(N * N)), dim3(256), 0, c->stream,
-                           static_cast<const double*>(dh), N, static_cast<double*>(dout));
-        HIPCHK(c, hipGetLastError());
-    }
-    CHK(out_done(c, out, dout, b));
-    return finish(c);
+    return dtype == GPSIG_F32 ? Impl<float>::e_symmetrize_owned_rows(c, dtype, half, N, out) : Impl<double>::e_symmetrize_owned_rows(c, dtype, half, N, out);
 }
 
 int gpsig_kernel_Kdiag(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int32_t return_levels, void* out) {
-    ENTER(c, p);
-    const int M1 = p->num_levels + 1;
-    const size_t ob = sizeof(double) * size_t(N) * (return_levels ? M1 : 1);
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out, ob, &dout));
-    const double* w;
-    CHK(upload_weights(c, p, &w));
-    void* tmp;
-    CHK(ensure(c, B_TMP0, sizeof(double) * size_t(N) * M1 + 8, &tmp));
-    if (p->normalization) {
-        // kernels.py:486-490: sigma * variances, no data touched
-        if (N > 0) {
-            hipLaunchKernelGGL(fill_kernel<double>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream, static_cast<double*>(tmp), N * M1, 1.0);
-            HIPCHK(c, hipGetLastError());
-        }
-    } else {
-        const void* dX;
-        CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
-        const int d_eff = p->num_features * (p->num_lags + 1);
-        SeqPlanned pl;
-        CHK(plan_seq(c, p, d_eff, L, &pl));
-        const void* rec;
-        SeqGeom g;
-        CHK(make_records(c, p, true, pl, dX, N, L, B_REC0, &rec, &g));
-        SeqRun r;
-        memset(&r, 0, sizeof(r));
-        r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
-        r.out = tmp; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
-        CHK(launch_seq(c, p, pl, r));
-    }
-    if (N > 0) {
-        hipLaunchKernelGGL(weight_levels_kernel<double>, dim3(grid_for(N)), dim3(256), 0, c->stream,
-                           static_cast<const double*>(tmp), N, M1, w, return_levels ? 0 : 1, static_cast<double*>(dout));
-        HIPCHK(c, hipGetLastError());
-    }
-    CHK(out_done(c, out, dout, ob));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_Kdiag(c, p, X, N, L, return_levels, out) : Impl<double>::e_kernel_Kdiag(c, p, X, N, L, return_levels, out);
 }
 
 int gpsig_kernel_K_tens(gpsig_ctx* c, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, int32_t return_levels, void* out) {
-    ENTER(c, p);
-    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
-    const void* dZ;
-    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
-    const size_t ob = sizeof(double) * size_t(T) * T * (return_levels ? p->num_levels + 1 : 1);
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out, ob, &dout));
-    CHK(tens_gram_device(c, p, false, dZ, T, increments, return_levels, dout));
-    CHK(out_done(c, out, dout, ob));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K_tens(c, p, Z, T, increments, return_levels, out) : Impl<double>::e_kernel_K_tens(c, p, Z, T, increments, return_levels, out);
 }
 
 int gpsig_kernel_K_tens_vs_seq(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
                                int32_t L, int32_t increments, int32_t return_levels, void* out) {
-    ENTER(c, p);
-    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
-    const void *dZ, *dX;
-    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
-    CHK(in_dev(c, B_IN1, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
-    const size_t ob = sizeof(double) * size_t(T) * N * (return_levels ? p->num_levels + 1 : 1);
-    void* dout;
-    CHK(out_dev(c, B_OUT0, out, ob, &dout));
-    const void* fx = nullptr;
-    if (p->normalization) CHK(seq_diag_factors(c, p, dX, N, L, &fx));     // kernels.py:572-581
-    const double* w;
-    CHK(upload_weights(c, p, &w));
-    const void *ZT, *ZS;
-    CHK(prep_tensors(c, p, true, dZ, T, E, &ZT, &ZS));
-    CHK(tens_vs_seq_device(c, p, false, dZ, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dout));
-    CHK(out_done(c, out, dout, ob));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K_tens_vs_seq(c, p, Z, X, T, N, L, increments, return_levels, out) : Impl<double>::e_kernel_K_tens_vs_seq(c, p, Z, X, T, N, L, increments, return_levels, out);
 }
 
 int gpsig_kernel_K_tens_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
                                    int32_t L, int32_t increments, int32_t full_X_cov, int32_t return_levels, void* Kzz,
                                    void* Kzx, void* Kxx) {
-    ENTER(c, p);
-    const int M1 = p->num_levels + 1;
-    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
-    const size_t lv = return_levels ? size_t(M1) : 1;
-    const void *dZ, *dX;
-    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d, &dZ));
-    CHK(in_dev(c, B_IN1, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
-    const size_t bzz = sizeof(double) * size_t(T) * T * lv, bzx = sizeof(double) * size_t(T) * N * lv;
-    const size_t bxx = sizeof(double) * (full_X_cov ? size_t(N) * N : size_t(N)) * lv;
-    void *dzz, *dzx, *dxx;
-    CHK(out_dev(c, B_OUT0, Kzz, bzz, &dzz));
-    CHK(out_dev(c, B_OUT1, Kzx, bzx, &dzx));
-    CHK(out_dev(c, B_OUT2, Kxx, bxx, &dxx));
-    const double* w;
-    CHK(upload_weights(c, p, &w));
-    // Kzz: never normalised (kernels.py:623, :641/:665)
-    CHK(tens_gram_device(c, p, false, dZ, T, increments, return_levels, dzz));
-    // Kzx: divided by sqrt(diag_x + jitter) when normalising (kernels.py:638 / :660) -- with full_X_cov the
-    // diagonal of (Kxx + jitter*I) is the same number
-    const void* fx = nullptr;
-    if (p->normalization) CHK(seq_diag_factors(c, p, dX, N, L, &fx));
-    const void *ZT, *ZS;
-    CHK(prep_tensors(c, p, true, dZ, T, E, &ZT, &ZS));
-    CHK(tens_vs_seq_device(c, p, false, dZ, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dzx));
-    if (full_X_cov) {
-        CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, return_levels, dxx, true));   // kernels.py:630-640
-    } else {
-        void* tmp;
-        CHK(ensure(c, B_TMP0, sizeof(double) * size_t(N) * M1 + 8, &tmp));
-        if (p->normalization) {   // kernels.py:661
-            if (N > 0) {
-                hipLaunchKernelGGL(fill_kernel<double>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream, static_cast<double*>(tmp), N * M1, 1.0);
-                HIPCHK(c, hipGetLastError());
-            }
-        } else {                  // kernels.py:653, :663
-            const int d_eff = p->num_features * (p->num_lags + 1);
-            SeqPlanned pl;
-            CHK(plan_seq(c, p, d_eff, L, &pl));
-            const void* rec;
-            SeqGeom g;
-            CHK(make_records(c, p, true, pl, dX, N, L, B_REC0, &rec, &g));
-            SeqRun r;
-            memset(&r, 0, sizeof(r));
-            r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
-            r.out = tmp; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
-            CHK(launch_seq(c, p, pl, r));
-        }
-        if (N > 0) {
-            hipLaunchKernelGGL(weight_levels_kernel<double>, dim3(grid_for(N)), dim3(256), 0, c->stream,
-                               static_cast<const double*>(tmp), N, M1, w, return_levels ? 0 : 1, static_cast<double*>(dxx));
-            HIPCHK(c, hipGetLastError());
-        }
-    }
-    CHK(out_done(c, Kzz, dzz, bzz));
-    CHK(out_done(c, Kzx, dzx, bzx));
-    CHK(out_done(c, Kxx, dxx, bxx));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K_tens_n_seq_covs(c, p, Z, X, T, N, L, increments, full_X_cov, return_levels, Kzz, Kzx, Kxx) : Impl<double>::e_kernel_K_tens_n_seq_covs(c, p, Z, X, T, N, L, increments, full_X_cov, return_levels, Kzz, Kzx, Kxx);
 }
 
 int gpsig_kernel_K_seq_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
                                   int32_t L1, int32_t L2, int32_t full_X2_cov, int32_t return_levels, void* Kxx, void* Kxx2,
                                   void* Kx2x2) {
-    ENTER(c, p);
-    const int M1 = p->num_levels + 1, d = p->num_features;
-    const size_t lv = return_levels ? size_t(M1) : 1;
-    const void *dX, *dX2;
-    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N1) * L1 * d, &dX));
-    CHK(in_dev(c, B_IN1, X2, sizeof(double) * size_t(N2) * L2 * d, &dX2));
-    const size_t b11 = sizeof(double) * size_t(N1) * N1 * lv, b12 = sizeof(double) * size_t(N1) * N2 * lv;
-    const size_t b22 = sizeof(double) * (full_X2_cov ? size_t(N2) * N2 : size_t(N2)) * lv;
-    void *d11, *d12, *d22;
-    CHK(out_dev(c, B_OUT0, Kxx, b11, &d11));
-    CHK(out_dev(c, B_OUT1, Kxx2, b12, &d12));
-    CHK(out_dev(c, B_OUT2, Kx2x2, b22, &d22));
-    // Kxx (kernels.py:704, :709-712, :730/:755) == K(X)
-    CHK(seq_K_device(c, p, false, dX, nullptr, N1, N1, L1, L1, return_levels, d11, true));
-    // Kxx2 (kernels.py:705, :713, :727 / :750).  Reference quirk, reproduced: in the diagonal-only branch the
-    // X-side factor is applied twice (:713 then :750), i.e. 1/(diag_x + jitter) instead of 1/sqrt(.).
-    CHK(seq_K_device(c, p, false, dX, dX2, N1, N2, L1, L2, return_levels, d12, true, (p->normalization && !full_X2_cov) ? 1 : 0));
-    if (full_X2_cov) {
-        // kernels.py:719-732; :723-728 reference undefined names -- the evident intent (mirror of :709-712) == K(X2)
-        CHK(seq_K_device(c, p, false, dX2, nullptr, N2, N2, L2, L2, return_levels, d22, true));
-    } else {
-        const double* w;
-        CHK(upload_weights(c, p, &w));
-        void* tmp;
-        CHK(ensure(c, B_TMP0, sizeof(double) * size_t(N2) * M1 + 8, &tmp));
-        if (p->normalization) {   // kernels.py:751
-            if (N2 > 0) {
-                hipLaunchKernelGGL(fill_kernel<double>, dim3(grid_for(N2 * M1)), dim3(256), 0, c->stream, static_cast<double*>(tmp), N2 * M1, 1.0);
-                HIPCHK(c, hipGetLastError());
-            }
-        } else {                  // kernels.py:743, :753
-            SeqPlanned pl;
-            CHK(plan_seq(c, p, d * (p->num_lags + 1), L2, &pl));
-            const void* rec;
-            SeqGeom g;
-            CHK(make_records(c, p, true, pl, dX2, N2, L2, B_REC0, &rec, &g));
-            SeqRun r;
-            memset(&r, 0, sizeof(r));
-            r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N2; r.N2 = N2;
-            r.out = tmp; r.si = 1; r.sj = 0; r.sm = N2; r.pred = PRED_DIAG; r.timed = true;
-            CHK(launch_seq(c, p, pl, r));
-        }
-        if (N2 > 0) {
-            hipLaunchKernelGGL(weight_levels_kernel<double>, dim3(grid_for(N2)), dim3(256), 0, c->stream,
-                               static_cast<const double*>(tmp), N2, M1, w, return_levels ? 0 : 1, static_cast<double*>(d22));
-            HIPCHK(c, hipGetLastError());
-        }
-    }
-    CHK(out_done(c, Kxx, d11, b11));
-    CHK(out_done(c, Kxx2, d12, b12));
-    CHK(out_done(c, Kx2x2, d22, b22));
-    return finish(c);
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K_seq_n_seq_covs(c, p, X, X2, N1, N2, L1, L2, full_X2_cov, return_levels, Kxx, Kxx2, Kx2x2) : Impl<double>::e_kernel_K_seq_n_seq_covs(c, p, X, X2, N1, N2, L1, L2, full_X2_cov, return_levels, Kxx, Kxx2, Kx2x2);
 }
 
 }  // extern "C"

@@ -8,7 +8,7 @@ every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CU
 pointers, asynchronous on the current stream).
 
 Not built yet (raise NotImplementedError, never a silent fallback): ``order > 1`` on the GPU,
-``low_rank=True``, ``SignatureSpectral``, float32.
+``low_rank=True``, ``SignatureSpectral``; float32 inputs are computed in float32 (order 1 only).
 """
 import ctypes as C
 
@@ -45,23 +45,29 @@ class _Launch:
             self.ctx = _lib.context(0, 0)
             self.ctx.set_pointer_mode(_lib.PTR_HOST)
         self.keep = []
+        # the arithmetic type follows the data (the reference has one global settings.float_type): float32 in,
+        # float32 kernels and float32 out; anything else is computed in float64
+        given = [a for a in arrays if a is not None]
+        self.f32 = len(given) > 0 and all(str(a.dtype).endswith("float32") for a in given)
+        self.np_dtype = np.float32 if self.f32 else np.float64
+        self.dtype_id = _lib.F32 if self.f32 else _lib.F64
 
     def inp(self, a):
         if a is None:
             return None
         if self.device_mode:
-            t = a.detach().to(torch.float64).contiguous()
+            t = a.detach().to(torch.float32 if self.f32 else torch.float64).contiguous()
             self.keep.append(t)
             return C.c_void_p(t.data_ptr())
-        t = np.ascontiguousarray(a.detach().cpu().numpy() if _is_torch(a) else a, dtype=np.float64)
+        t = np.ascontiguousarray(a.detach().cpu().numpy() if _is_torch(a) else a, dtype=self.np_dtype)
         self.keep.append(t)
         return C.c_void_p(t.ctypes.data)
 
     def out(self, shape):
         if self.device_mode:
-            t = torch.empty(tuple(int(s) for s in shape), dtype=torch.float64, device=self.dev)
+            t = torch.empty(tuple(int(s) for s in shape), dtype=torch.float32 if self.f32 else torch.float64, device=self.dev)
             return t, C.c_void_p(t.data_ptr())
-        t = np.empty(tuple(int(s) for s in shape), dtype=np.float64)
+        t = np.empty(tuple(int(s) for s in shape), dtype=self.np_dtype)
         return t, C.c_void_p(t.ctypes.data)
 
 
@@ -159,14 +165,14 @@ class SignatureKernel:
         return value
 
     # ---- plumbing ------------------------------------------------------------------------------
-    def _params(self, keep):
+    def _params(self, keep, dtype_id=_lib.F64):
         if self._base is None:
             raise NotImplementedError("SignatureKernel is abstract: use SignatureLinear, SignatureRBF, ...")
         if self.low_rank:
             raise NotImplementedError("low_rank=True (Nystrom + randomised Hadamard sketch) is not built on the GPU yet")
         p = _lib.Params()
         p.base_kernel = _lib.BASE[self._base]
-        p.dtype = _lib.F64
+        p.dtype = dtype_id
         p.num_features, p.num_levels, p.order = int(self.num_features), int(self.num_levels), int(self.order)
         p.difference, p.normalization, p.num_lags = int(bool(self.difference)), int(bool(self.normalization)), int(self.num_lags)
         p.sigma, p.jitter = float(self.sigma), JITTER
@@ -225,7 +231,7 @@ class SignatureKernel:
         L_ = _Launch(X, X2)
         n1, l1 = self._seq_dims(X)
         n2, l2 = self._seq_dims(X2) if X2 is not None else (n1, l1)
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         out, optr = L_.out((self.num_levels + 1, n1, n2) if return_levels else (n1, n2))
         L_.ctx.call("gpsig_kernel_K", p, L_.inp(X), L_.inp(X2), n1, n2, l1, l2, int(bool(return_levels)), optr)
         return out
@@ -236,7 +242,7 @@ class SignatureKernel:
             X, _ = self._slice(X, None)
         L_ = _Launch(X)
         n, l = self._seq_dims(X)
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         out, optr = L_.out((self.num_levels + 1, n) if return_levels else (n,))
         L_.ctx.call("gpsig_kernel_Kdiag", p, L_.inp(X), n, l, int(bool(return_levels)), optr)
         return out
@@ -245,7 +251,7 @@ class SignatureKernel:
         """Reference: kernels.py:513-536.  (T, T) or (M+1, T, T); never normalised."""
         L_ = _Launch(Z)
         t = self._tens_dims(Z, increments)
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         out, optr = L_.out((self.num_levels + 1, t, t) if return_levels else (t, t))
         L_.ctx.call("gpsig_kernel_K_tens", p, L_.inp(Z), t, int(bool(increments)), int(bool(return_levels)), optr)
         return out
@@ -257,7 +263,7 @@ class SignatureKernel:
         L_ = _Launch(Z, X)
         t = self._tens_dims(Z, increments)
         n, l = self._seq_dims(X)
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         out, optr = L_.out((self.num_levels + 1, t, n) if return_levels else (t, n))
         L_.ctx.call("gpsig_kernel_K_tens_vs_seq", p, L_.inp(Z), L_.inp(X), t, n, l, int(bool(increments)),
                     int(bool(return_levels)), optr)
@@ -270,7 +276,7 @@ class SignatureKernel:
         L_ = _Launch(Z, X)
         t = self._tens_dims(Z, increments)
         n, l = self._seq_dims(X)
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         lv = (self.num_levels + 1,) if return_levels else ()
         Kzz, pzz = L_.out(lv + (t, t))
         Kzx, pzx = L_.out(lv + (t, n))
@@ -288,7 +294,7 @@ class SignatureKernel:
         L_ = _Launch(X, X2)
         n1, l1 = self._seq_dims(X)
         n2, l2 = self._seq_dims(X2)
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         lv = (self.num_levels + 1,) if return_levels else ()
         Kxx, p11 = L_.out(lv + (n1, n1))
         Kxx2, p12 = L_.out(lv + (n1, n2))
@@ -303,7 +309,7 @@ class SignatureKernel:
         L_ = _Launch(X, X2)
         n1, l1 = _shape(X)[0], _shape(X)[1]
         n2, l2 = (_shape(X2)[0], _shape(X2)[1]) if X2 is not None else (n1, l1)
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         out, optr = L_.out((self.num_levels + 1, n1, n2))
         L_.ctx.call("gpsig_seq_gram_levels", p, L_.inp(X), L_.inp(X2), n1, n2, l1, l2, optr)
         return out
@@ -312,7 +318,7 @@ class SignatureKernel:
         """Reference: kernels.py:188-205 -> (M+1, N)."""
         L_ = _Launch(X)
         n, l = _shape(X)[0], _shape(X)[1]
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         out, optr = L_.out((self.num_levels + 1, n))
         L_.ctx.call("gpsig_seq_diag_levels", p, L_.inp(X), n, l, optr)
         return out
@@ -321,7 +327,7 @@ class SignatureKernel:
         """Reference: kernels.py:263-283 on already scaled tensors -> (M+1, T, T)."""
         L_ = _Launch(Z)
         t = _shape(Z)[1]
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         out, optr = L_.out((self.num_levels + 1, t, t))
         L_.ctx.call("gpsig_tens_gram_levels", p, L_.inp(Z), t, int(bool(increments)), optr)
         return out
@@ -330,7 +336,7 @@ class SignatureKernel:
         """Reference: kernels.py:313-340 on already scaled inputs -> (M+1, T, N)."""
         L_ = _Launch(Z, X)
         t, n, l = _shape(Z)[1], _shape(X)[0], _shape(X)[1]
-        p = self._params(L_.keep)
+        p = self._params(L_.keep, L_.dtype_id)
         out, optr = L_.out((self.num_levels + 1, t, n))
         L_.ctx.call("gpsig_tens_vs_seq_levels", p, L_.inp(Z), L_.inp(X), t, n, l, int(bool(increments)), optr)
         return out

@@ -440,3 +440,53 @@ def test_tensor_vs_sequence_lane_mappings_agree(K, T):
                         assert relerr(got, want) <= TOL, (base, incr, order, lags, mode)
     finally:
         ctx.set_option("tensor_lanes", -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# float32 (BASELINE.json configs[4]: RBF, fp32).  Tolerance, stated by SURVEY.md 8(d): 1e-4 on normalised entries
+# (float32 rounding of O(1e-7) per operation through an L1 x L2 x M recursion; the fp64 oracle is the reference).
+# ------------------------------------------------------------------------------------------------
+TOL32 = 1e-4
+
+
+def relerr32(got, want):
+    """float32 bound: max |K - K_ref| <= 1e-4 * max |K_ref| (matrix-relative: tensor-vs-sequence entries are signed sums that
+    pass through zero, so an entry-relative bound has no meaning in float32)."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    return float(np.abs(got - want).max() / np.abs(want).max())
+
+
+@pytest.mark.parametrize("base", ["linear", "rbf", "matern32"])
+def test_float32_matches_the_float64_oracle(K, base):
+    rng = np.random.default_rng(32)
+    N, L, d, M = 40, 30, 5, 4
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+    Y = np.cumsum(0.3 * rng.standard_normal((11, L, d)), axis=1).reshape(11, -1)
+    Z = rng.standard_normal((M * (M + 1) // 2, 9, d))
+    kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, lengthscales=0.7 + rng.random(d))
+    kx, ko = make_kernel(K, kw), make_oracle(kw)
+    X32, Y32, Z32 = X.astype(np.float32), Y.astype(np.float32), Z.astype(np.float32)
+    got = kx.K(X32)
+    assert got.dtype == np.float32
+    assert relerr32(got, ko.K(X32.astype(np.float64))) <= TOL32
+    assert relerr32(kx.K(X32, Y32), ko.K(X32.astype(np.float64), Y32.astype(np.float64))) <= TOL32
+    assert relerr32(kx.K_tens_vs_seq(Z32, X32), ko.K_tens_vs_seq(Z32.astype(np.float64), X32.astype(np.float64))) <= TOL32
+    assert relerr32(kx.K_tens(Z32), ko.K_tens(Z32.astype(np.float64))) <= TOL32
+    assert relerr32(kx.Kdiag(X32), ko.Kdiag(X32.astype(np.float64))) <= TOL32
+    # mixed precision inputs are computed in float64
+    assert kx.K(X32, Y).dtype == np.float64
+
+
+def test_float32_config5_shape_reduced_n(K):
+    """BASELINE.json configs[4] shape: L=128, d=16, num_levels=6, fp32, RBF, at N=48."""
+    import torch
+    rng = np.random.default_rng(5)
+    N, L, d, M = 48, 128, 16, 6
+    X = np.cumsum(0.1 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1).astype(np.float32)
+    kw = dict(input_dim=L * d, num_features=d, num_levels=M, base="rbf", lengthscales=np.sqrt(d) * np.ones(d))
+    got = make_kernel(K, kw).K(torch.as_tensor(X, device="cuda:0"))
+    assert got.dtype == torch.float32
+    want = O.K_symm_tiled(make_oracle(kw), X.astype(np.float64), tile=16)
+    assert relerr(got.cpu().numpy(), want) <= TOL32
+    assert torch.equal(got, got.T)
