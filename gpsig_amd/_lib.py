@@ -26,7 +26,21 @@ class Params(C.Structure):
     ]
 
 
+class SketchC(C.Structure):
+    """struct gpsig_sketch."""
+    _fields_ = [("k1", C.c_int32), ("k2", C.c_int32), ("r", C.c_int32), ("nnz", C.c_int32),
+                ("colptr", C.POINTER(C.c_int32)), ("i1", C.POINTER(C.c_int32)), ("i2", C.POINTER(C.c_int32)),
+                ("val", C.POINTER(C.c_double))]
+
+
+class LowRankC(C.Structure):
+    """struct gpsig_lowrank."""
+    _fields_ = [("num_components", C.c_int32), ("rank_bound", C.c_int32), ("num_sketches", C.c_int32),
+                ("landmarks", C.POINTER(C.c_double)), ("whitening", C.POINTER(C.c_double)), ("sketches", C.POINTER(SketchC))]
+
+
 _P = C.POINTER(Params)
+_LR = C.POINTER(LowRankC)
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
 
 # name -> argtypes after (ctx, params); every symbol include/gpsig_hip.h declares must appear here or in _PLAIN
@@ -42,6 +56,12 @@ _KERNEL_FUNCS = {
     "gpsig_kernel_K_tens_vs_seq": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "gpsig_kernel_K_tens_n_seq_covs": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "gpsig_kernel_K_seq_n_seq_covs": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "gpsig_lr_gather_points": [_vp, _i64, _i32, C.POINTER(_i64), _i64, C.POINTER(C.c_double)],
+    "gpsig_base_kernel_matrix": [C.POINTER(C.c_double), C.POINTER(C.c_double), _i64, _i64, _i32, C.POINTER(C.c_double)],
+    "gpsig_lr_seq_features": [_LR, _vp, _i64, _i32, _vp],
+    "gpsig_lr_tens_features": [_LR, _vp, _i64, _i32, _vp],
+    "gpsig_lr_kernel": [_LR, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "gpsig_lr_kernel_diag": [_LR, _vp, _i64, _i32, _vp],
 }
 _PLAIN = {
     "gpsig_abi_version": ([], C.c_int),

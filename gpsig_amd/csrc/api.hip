@@ -15,6 +15,7 @@
 
 #include "../../include/gpsig_hip.h"
 #include "aux_kernels.hpp"
+#include "lowrank_kernels.hpp"
 #include "seq_args.hpp"
 #include "seq_configs.hpp"
 
@@ -121,6 +122,7 @@ enum BufId {
     B_DLEV0, B_DLEV1,             // diagonal levels
     B_FAC0, B_FAC1,               // per-sequence factors
     B_TASKS, B_W, B_XT, B_ZT, B_ZS, B_ZL, B_ZN, B_TMP0, B_TMP1,
+    B_LR0, B_LR1, B_LR2, B_LR3, B_LR4, B_LR5, B_LR6, B_LR7, B_LR8,
     B_COUNT
 };
 
@@ -268,6 +270,92 @@ int upload_weights(gpsig_ctx* c, const gpsig_params* p, const double** w) {
 #define ENTER(c, p)                         \
     CHK(check_params((c), (p)));            \
     HIPCHK((c), hipSetDevice((c)->device));
+
+
+// ---- low-rank mode (float64) ---------------------------------------------------------------------------
+struct LrDev {                 // device copies of a gpsig_lowrank
+    const double* S; const double* Wh;
+    int c, r, nsk;
+    std::vector<const int32_t*> colptr, i1, i2;
+    std::vector<const double*> val;
+    std::vector<int> k1, k2;
+};
+
+int lr_check(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr) {
+    if (!lr) return fail(c, GPSIG_ERR_INVALID, "lowrank descriptor is NULL");
+    if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "low-rank mode is built for float64 only");
+    if (p->order != 1 && p->num_levels > 1) return fail(c, GPSIG_ERR_UNSUPPORTED, "Low-rank mode not implemented for order higher than 1.");
+    if (lr->num_components < 1 || lr->rank_bound < 1) return fail(c, GPSIG_ERR_INVALID, "num_components and rank_bound must be positive");
+    if (lr->num_sketches != p->num_levels - 1) return fail(c, GPSIG_ERR_INVALID, "need one sketch per level 2..num_levels");
+    if (!lr->landmarks || !lr->whitening || (lr->num_sketches > 0 && !lr->sketches)) return fail(c, GPSIG_ERR_INVALID, "NULL low-rank array");
+    int k2 = lr->num_components;
+    for (int i = 0; i < lr->num_sketches; ++i) {
+        const gpsig_sketch& sk = lr->sketches[i];
+        if (sk.k1 != lr->num_components || sk.k2 != k2 || sk.r != lr->rank_bound)
+            return fail(c, GPSIG_ERR_INVALID, "sketch %d has shape (%d, %d) -> %d, expected (%d, %d) -> %d", i, sk.k1, sk.k2, sk.r,
+                        lr->num_components, k2, lr->rank_bound);
+        k2 = lr->rank_bound;
+    }
+    return GPSIG_OK;
+}
+
+// upload landmarks, whitening and sketches into one scratch block
+int lr_upload(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, int d_eff, LrDev* D) {
+    const int cc = lr->num_components;
+    size_t bytes = sizeof(double) * (size_t(cc) * d_eff + size_t(cc) * cc);
+    for (int i = 0; i < lr->num_sketches; ++i)
+        bytes += sizeof(int32_t) * (size_t(lr->sketches[i].r) + 1 + 2 * size_t(lr->sketches[i].nnz)) + sizeof(double) * size_t(lr->sketches[i].nnz) + 64;
+    std::vector<unsigned char> h(bytes + 64);
+    void* dbase;
+    CHK(ensure(c, B_LR0, h.size(), &dbase));
+    size_t o = 0;
+    auto put = [&](const void* src, size_t n) -> size_t {
+        o = (o + 7) / 8 * 8;
+        memcpy(h.data() + o, src, n);
+        size_t at = o;
+        o += n;
+        return at;
+    };
+    D->c = cc; D->r = lr->rank_bound; D->nsk = lr->num_sketches;
+    unsigned char* db = static_cast<unsigned char*>(dbase);
+    D->S = reinterpret_cast<const double*>(db + put(lr->landmarks, sizeof(double) * size_t(cc) * d_eff));
+    D->Wh = reinterpret_cast<const double*>(db + put(lr->whitening, sizeof(double) * size_t(cc) * cc));
+    for (int i = 0; i < lr->num_sketches; ++i) {
+        const gpsig_sketch& sk = lr->sketches[i];
+        D->colptr.push_back(reinterpret_cast<const int32_t*>(db + put(sk.colptr, sizeof(int32_t) * (size_t(sk.r) + 1))));
+        D->i1.push_back(reinterpret_cast<const int32_t*>(db + put(sk.i1, sizeof(int32_t) * size_t(sk.nnz))));
+        D->i2.push_back(reinterpret_cast<const int32_t*>(db + put(sk.i2, sizeof(int32_t) * size_t(sk.nnz))));
+        D->val.push_back(reinterpret_cast<const double*>(db + put(sk.val, sizeof(double) * size_t(sk.nnz))));
+        D->k1.push_back(sk.k1); D->k2.push_back(sk.k2);
+    }
+    HIPCHK(c, hipMemcpyAsync(dbase, h.data(), o, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)p;
+    return GPSIG_OK;
+}
+
+int lr_gemm(gpsig_ctx* c, const double* A, const double* B, int64_t N1, int64_t N2, int K, int64_t lda, int64_t ldb, double* C_,
+            int64_t ldc) {
+    if (N1 <= 0 || N2 <= 0) return GPSIG_OK;
+    dim3 grid((unsigned)((N2 + 63) / 64), (unsigned)((N1 + 63) / 64));
+    hipLaunchKernelGGL(gemm_abt_f64_mfma_kernel, grid, dim3(256), 0, c->stream, A, B, N1, N2, K, lda, ldb, C_, ldc);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+
+int lr_level_offsets(gpsig_ctx* c, int M, int cc, int r, const int32_t** dev_off, int* F) {
+    std::vector<int32_t> off(M + 2);
+    off[0] = 0; off[1] = 1;
+    if (M >= 1) off[2] = 1 + cc;
+    for (int m = 2; m <= M; ++m) off[m + 1] = off[m] + r;
+    *F = off[M + 1];
+    void* d;
+    CHK(ensure(c, B_LR1, sizeof(int32_t) * off.size(), &d));
+    HIPCHK(c, hipMemcpyAsync(d, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *dev_off = static_cast<const int32_t*>(d);
+    return GPSIG_OK;
+}
 
 template <typename TT>
 struct Impl {
@@ -1159,6 +1247,310 @@ int gpsig_kernel_K_seq_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const voi
                                   void* Kx2x2) {
     if (!c || !p) return GPSIG_ERR_INVALID;
     return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K_seq_n_seq_covs(c, p, X, X2, N1, N2, L1, L2, full_X2_cov, return_levels, Kxx, Kxx2, Kx2x2) : Impl<double>::e_kernel_K_seq_n_seq_covs(c, p, X, X2, N1, N2, L1, L2, full_X2_cov, return_levels, Kxx, Kxx2, Kx2x2);
+}
+
+
+int gpsig_lr_gather_points(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, const int64_t* idx, int64_t R,
+                           double* out_host) {
+    ENTER(c, p);
+    if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "low-rank mode is built for float64 only");
+    if (!idx || !out_host || R < 0) return fail(c, GPSIG_ERR_INVALID, "bad landmark request");
+    for (int64_t k = 0; k < R; ++k)
+        if (idx[k] < 0 || idx[k] >= N * L) return fail(c, GPSIG_ERR_INVALID, "landmark index out of range");
+    ScaleParams s = scale_of(p, true);
+    const int d_eff = s.d_eff();
+    const void* dX;
+    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
+    void *didx, *dout;
+    CHK(ensure(c, B_LR2, sizeof(int64_t) * size_t(R) + 8, &didx));
+    CHK(ensure(c, B_LR3, sizeof(double) * size_t(R) * d_eff + 8, &dout));
+    if (R > 0) {
+        HIPCHK(c, hipMemcpyAsync(didx, idx, sizeof(int64_t) * size_t(R), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(lr_gather_points_kernel<double>, dim3(grid_for(R * d_eff)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(dX), L, s, static_cast<const int64_t*>(didx), R, static_cast<double*>(dout));
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(out_host, dout, sizeof(double) * size_t(R) * d_eff, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GPSIG_OK;
+}
+
+int gpsig_base_kernel_matrix(gpsig_ctx* c, const gpsig_params* p, const double* A_host, const double* B_host, int64_t na, int64_t nb,
+                             int32_t d, double* out_host) {
+    ENTER(c, p);
+    if (!A_host || !B_host || !out_host || na < 0 || nb < 0 || d < 1) return fail(c, GPSIG_ERR_INVALID, "bad base-kernel-matrix request");
+    void *da, *db, *dout;
+    CHK(ensure(c, B_LR2, sizeof(double) * size_t(na) * d + 8, &da));
+    CHK(ensure(c, B_LR3, sizeof(double) * size_t(nb) * d + 8, &db));
+    CHK(ensure(c, B_LR4, sizeof(double) * size_t(na) * nb + 8, &dout));
+    if (na > 0 && nb > 0) {
+        HIPCHK(c, hipMemcpyAsync(da, A_host, sizeof(double) * size_t(na) * d, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(db, B_host, sizeof(double) * size_t(nb) * d, hipMemcpyHostToDevice, c->stream));
+        double p0, p1;
+        base_p(p, &p0, &p1);
+        hipLaunchKernelGGL(base_kernel_matrix_kernel<double>, dim3(grid_for(na * nb)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(da), static_cast<const double*>(db), na, nb, int(d), int(p->base_kernel), p0, p1,
+                           static_cast<double*>(dout));
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(out_host, dout, sizeof(double) * size_t(na) * nb, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GPSIG_OK;
+}
+
+int gpsig_lr_seq_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, const void* X, int64_t N, int32_t L, void* Phi) {
+    ENTER(c, p);
+    CHK(lr_check(c, p, lr));
+    const int M = p->num_levels;
+    ScaleParams s = scale_of(p, true);
+    const int d_eff = s.d_eff();
+    LrDev D;
+    CHK(lr_upload(c, p, lr, d_eff, &D));
+    const int cc = D.c, r = D.r;
+    const int F = 1 + cc + (M - 1) * r;
+    const int l = p->difference ? L - 1 : L;
+    const void* dX;
+    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
+    void* dPhi;
+    CHK(out_dev(c, B_OUT0, Phi, sizeof(double) * size_t(N) * F, &dPhi));
+    double* phi = static_cast<double*>(dPhi);
+    double p0, p1;
+    base_p(p, &p0, &p1);
+    void *kxs, *feat, *U, *Pa, *Pb;
+    const int wmax = cc > r ? cc : r;
+    CHK(ensure(c, B_LR2, sizeof(double) * size_t(N) * L * cc + 8, &kxs));
+    CHK(ensure(c, B_LR3, sizeof(double) * size_t(N) * L * cc + 8, &feat));
+    CHK(ensure(c, B_LR4, sizeof(double) * size_t(N) * (l > 0 ? l : 1) * cc + 8, &U));
+    CHK(ensure(c, B_LR5, sizeof(double) * size_t(N) * (l > 0 ? l : 1) * wmax + 8, &Pa));
+    CHK(ensure(c, B_LR6, sizeof(double) * size_t(N) * (l > 0 ? l : 1) * wmax + 8, &Pb));
+    if (N <= 0) return finish(c);
+    // Nystrom features (low_rank_calculations.py:59-60): kappa(X, S) then the whitening GEMM on the matrix cores
+    hipLaunchKernelGGL(lr_seq_cross_kernel<double>, dim3(grid_for(N * L * cc)), dim3(256), 0, c->stream, static_cast<const double*>(dX),
+                       N, int(L), s, D.S, cc, int(p->base_kernel), p0, p1, static_cast<double*>(kxs));
+    HIPCHK(c, hipGetLastError());
+    // feat = kxs (NL, c) * Wh (c, c) = kxs * (Wh^T)^T : pass B = Wh^T, i.e. read Wh column-wise -> upload is row-major Wh, so
+    // B[j][k] must be Wh[k][j]: use the transposed copy made below
+    void* wht;
+    CHK(ensure(c, B_LR7, sizeof(double) * size_t(cc) * cc + 8, &wht));
+    {
+        std::vector<double> t(size_t(cc) * cc);
+        for (int a = 0; a < cc; ++a)
+            for (int b = 0; b < cc; ++b) t[size_t(b) * cc + a] = lr->whitening[size_t(a) * cc + b];
+        HIPCHK(c, hipMemcpyAsync(wht, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    CHK(lr_gemm(c, static_cast<const double*>(kxs), static_cast<const double*>(wht), N * L, cc, cc, cc, cc, static_cast<double*>(feat), cc));
+    // level 0 and level 1 (signature_algs.py:177-182)
+    hipLaunchKernelGGL(fill_kernel<double>, dim3(grid_for(N * F)), dim3(256), 0, c->stream, phi, N * F, 0.0);
+    HIPCHK(c, hipGetLastError());
+    {
+        // Phi[:, 0] = 1
+        std::vector<double> ones(1, 1.0);
+        (void)ones;
+    }
+    if (l > 0) {
+        hipLaunchKernelGGL(lr_time_diff_kernel<double>, dim3(grid_for(N * l * cc)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(feat), N, int(L), cc, int(p->difference), static_cast<double*>(U));
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(lr_timesum_kernel<double>, dim3(grid_for(N * cc)), dim3(256), 0, c->stream, static_cast<const double*>(U), N, l,
+                           cc, phi, int64_t(F), 1);
+        HIPCHK(c, hipGetLastError());
+        // P = U; for level i: P = excumsum_t(P); P = sketch(U, P); Phi_i = sum_t P     (signature_algs.py:184-191)
+        HIPCHK(c, hipMemcpyAsync(Pa, U, sizeof(double) * size_t(N) * l * cc, hipMemcpyDeviceToDevice, c->stream));
+        double *cur = static_cast<double*>(Pa), *nxt = static_cast<double*>(Pb);
+        int kw = cc;
+        for (int i = 2; i <= M; ++i) {
+            hipLaunchKernelGGL(lr_excumsum_kernel<double>, dim3(grid_for(N * kw)), dim3(256), 0, c->stream, cur, N, l, kw, phi, int64_t(F), 0, 0);
+            HIPCHK(c, hipGetLastError());
+            hipLaunchKernelGGL(lr_sketch_kernel<double>, dim3(grid_for(N * l * r)), dim3(256), 0, c->stream, static_cast<const double*>(U),
+                               int64_t(cc), static_cast<const double*>(cur), int64_t(kw), N * l, r, D.colptr[i - 2], D.i1[i - 2], D.i2[i - 2],
+                               D.val[i - 2], nxt, int64_t(r));
+            HIPCHK(c, hipGetLastError());
+            hipLaunchKernelGGL(lr_timesum_kernel<double>, dim3(grid_for(N * r)), dim3(256), 0, c->stream, static_cast<const double*>(nxt), N, l,
+                               r, phi, int64_t(F), 1 + cc + (i - 2) * r);
+            HIPCHK(c, hipGetLastError());
+            double* t = cur; cur = nxt; nxt = t;
+            kw = r;
+        }
+    }
+    hipLaunchKernelGGL(fill_strided_kernel<double>, dim3(grid_for(N)), dim3(256), 0, c->stream, phi, N, int64_t(F), 1.0);
+    HIPCHK(c, hipGetLastError());
+    CHK(out_done(c, Phi, dPhi, sizeof(double) * size_t(N) * F));
+    return finish(c);
+}
+
+int gpsig_lr_tens_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, const void* Z, int64_t T, int32_t increments,
+                           void* Phi) {
+    ENTER(c, p);
+    CHK(lr_check(c, p, lr));
+    const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
+    ScaleParams s = scale_of(p, true);
+    const int d_eff = s.d_eff();
+    LrDev D;
+    CHK(lr_upload(c, p, lr, d_eff, &D));
+    const int cc = D.c, r = D.r;
+    const int F = 1 + cc + (M - 1) * r;
+    const void* dZ;
+    CHK(in_dev(c, B_IN0, Z, sizeof(double) * size_t(lt) * T * E * d_eff, &dZ));
+    void* dPhi;
+    CHK(out_dev(c, B_OUT0, Phi, sizeof(double) * size_t(T) * F, &dPhi));
+    double* phi = static_cast<double*>(dPhi);
+    if (T <= 0) return finish(c);
+    double p0, p1;
+    base_p(p, &p0, &p1);
+    const int64_t rows = int64_t(lt) * T * E;
+    void *kxs, *feat, *U, *Ra, *Rb, *wht;
+    const int wmax = cc > r ? cc : r;
+    CHK(ensure(c, B_LR2, sizeof(double) * size_t(rows) * cc + 8, &kxs));
+    CHK(ensure(c, B_LR3, sizeof(double) * size_t(rows) * cc + 8, &feat));
+    CHK(ensure(c, B_LR4, sizeof(double) * size_t(lt) * T * cc + 8, &U));
+    CHK(ensure(c, B_LR5, sizeof(double) * size_t(T) * wmax + 8, &Ra));
+    CHK(ensure(c, B_LR6, sizeof(double) * size_t(T) * wmax + 8, &Rb));
+    CHK(ensure(c, B_LR7, sizeof(double) * size_t(cc) * cc + 8, &wht));
+    {
+        std::vector<double> t(size_t(cc) * cc);
+        for (int a = 0; a < cc; ++a)
+            for (int b = 0; b < cc; ++b) t[size_t(b) * cc + a] = lr->whitening[size_t(a) * cc + b];
+        HIPCHK(c, hipMemcpyAsync(wht, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    hipLaunchKernelGGL(lr_tens_cross_kernel<double>, dim3(grid_for(rows * cc)), dim3(256), 0, c->stream, static_cast<const double*>(dZ), rows,
+                       s, D.S, cc, int(p->base_kernel), p0, p1, static_cast<double*>(kxs));
+    HIPCHK(c, hipGetLastError());
+    CHK(lr_gemm(c, static_cast<const double*>(kxs), static_cast<const double*>(wht), rows, cc, cc, cc, cc, static_cast<double*>(feat), cc));
+    // increments: F(z[.,1]) - F(z[.,0]) (kernels.py:304); rows are ((k*T + t)*E + e): a "time difference" over e with L = E
+    if (increments) {
+        hipLaunchKernelGGL(lr_time_diff_kernel<double>, dim3(grid_for(int64_t(lt) * T * cc)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(feat), int64_t(lt) * T, 2, cc, 1, static_cast<double*>(U));
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipMemcpyAsync(U, feat, sizeof(double) * size_t(lt) * T * cc, hipMemcpyDeviceToDevice, c->stream));
+    }
+    hipLaunchKernelGGL(fill_kernel<double>, dim3(grid_for(T * F)), dim3(256), 0, c->stream, phi, T * F, 0.0);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(fill_strided_kernel<double>, dim3(grid_for(T)), dim3(256), 0, c->stream, phi, T, int64_t(F), 1.0);
+    HIPCHK(c, hipGetLastError());
+    // tensor_kern_lr_feature (signature_algs.py:211-221): R = U[k]; R = sketch_{j-1}(U[k'], R)
+    const double* Ud = static_cast<const double*>(U);
+    int k = 0;
+    for (int i = 1; i <= M; ++i) {
+        const double* R = Ud + size_t(k) * T * cc;
+        int kw = cc;
+        ++k;
+        double *cur = static_cast<double*>(Ra), *nxt = static_cast<double*>(Rb);
+        for (int j = 1; j < i; ++j) {
+            hipLaunchKernelGGL(lr_sketch_kernel<double>, dim3(grid_for(T * r)), dim3(256), 0, c->stream, Ud + size_t(k) * T * cc, int64_t(cc), R,
+                               int64_t(kw), T, r, D.colptr[j - 1], D.i1[j - 1], D.i2[j - 1], D.val[j - 1], cur, int64_t(r));
+            HIPCHK(c, hipGetLastError());
+            R = cur;
+            kw = r;
+            double* t = cur; cur = nxt; nxt = t;
+            ++k;
+        }
+        const int off = i == 1 ? 1 : 1 + cc + (i - 2) * r;
+        hipLaunchKernelGGL(copy_block_kernel<double>, dim3(grid_for(T * kw)), dim3(256), 0, c->stream, R, T, kw, int64_t(kw), phi, int64_t(F), off);
+        HIPCHK(c, hipGetLastError());
+    }
+    CHK(out_done(c, Phi, dPhi, sizeof(double) * size_t(T) * F));
+    return finish(c);
+}
+
+int gpsig_lr_kernel(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, const void* PhiA, const void* PhiB, int64_t N1, int64_t N2,
+                    int32_t normalize_a, int32_t normalize_b, int32_t return_levels, void* out) {
+    ENTER(c, p);
+    if (!lr) return fail(c, GPSIG_ERR_INVALID, "lowrank descriptor is NULL");
+    if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "low-rank mode is built for float64 only");
+    const int M = p->num_levels, M1 = M + 1, cc = lr->num_components, r = lr->rank_bound;
+    const bool sym = PhiB == nullptr;
+    if (sym) N2 = N1;
+    const int32_t* off;
+    int F;
+    CHK(lr_level_offsets(c, M, cc, r, &off, &F));
+    const void *dA, *dB;
+    CHK(in_dev(c, B_IN0, PhiA, sizeof(double) * size_t(N1) * F, &dA));
+    if (sym) dB = dA; else CHK(in_dev(c, B_IN1, PhiB, sizeof(double) * size_t(N2) * F, &dB));
+    const size_t ob = sizeof(double) * size_t(N1) * N2 * (return_levels ? M1 : 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    const double* w;
+    CHK(upload_weights(c, p, &w));
+    void *fa, *fb, *sa, *sb;
+    CHK(ensure(c, B_LR2, sizeof(double) * size_t(N1) * M1 + 8, &fa));
+    CHK(ensure(c, B_LR3, sizeof(double) * size_t(N2) * M1 + 8, &fb));
+    CHK(ensure(c, B_LR4, sizeof(double) * size_t(N1) * F + 8, &sa));
+    CHK(ensure(c, B_LR5, sizeof(double) * size_t(N2) * F + 8, &sb));
+    if (N1 <= 0 || N2 <= 0) return finish(c);
+    // per-row level factors: A side carries sigma*variances, both sides 1/sqrt(|Phi_m|^2 + jitter) when normalising
+    hipLaunchKernelGGL(lr_level_factors_kernel<double>, dim3(grid_for(N1 * M1)), dim3(256), 0, c->stream, static_cast<const double*>(dA), N1,
+                       int64_t(F), M1, off, w, p->jitter, int(normalize_a != 0), static_cast<double*>(fa));
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(lr_level_factors_kernel<double>, dim3(grid_for(N2 * M1)), dim3(256), 0, c->stream, static_cast<const double*>(dB), N2,
+                       int64_t(F), M1, off, static_cast<const double*>(nullptr), p->jitter, int((sym ? normalize_a : normalize_b) != 0),
+                       static_cast<double*>(fb));
+    HIPCHK(c, hipGetLastError());
+    const bool jit_diag = sym && normalize_a;         // kernels.py:431
+    if (!return_levels) {
+        hipLaunchKernelGGL(lr_scale_factors_kernel<double>, dim3(grid_for(N1 * F)), dim3(256), 0, c->stream, static_cast<const double*>(dA), N1,
+                           int64_t(F), M1, off, static_cast<const double*>(fa), -1, static_cast<double*>(sa), int64_t(F));
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(lr_scale_factors_kernel<double>, dim3(grid_for(N2 * F)), dim3(256), 0, c->stream, static_cast<const double*>(dB), N2,
+                           int64_t(F), M1, off, static_cast<const double*>(fb), -1, static_cast<double*>(sb), int64_t(F));
+        HIPCHK(c, hipGetLastError());
+        CHK(lr_gemm(c, static_cast<const double*>(sa), static_cast<const double*>(sb), N1, N2, F, F, F, static_cast<double*>(dout), N2));
+        if (jit_diag) {
+            hipLaunchKernelGGL(lr_add_jitter_diag_kernel<double>, dim3(grid_for(N1)), dim3(256), 0, c->stream, static_cast<double*>(dout), N1, M1,
+                               static_cast<const double*>(fa), static_cast<const double*>(fb), p->jitter, -1);
+            HIPCHK(c, hipGetLastError());
+        }
+    } else {
+        std::vector<int32_t> hoff(M1 + 1);
+        hoff[0] = 0; hoff[1] = 1;
+        if (M >= 1) hoff[2] = 1 + cc;
+        for (int m = 2; m <= M; ++m) hoff[m + 1] = hoff[m] + r;
+        for (int m = 0; m <= M; ++m) {
+            const int wdt = hoff[m + 1] - hoff[m];
+            hipLaunchKernelGGL(lr_scale_factors_kernel<double>, dim3(grid_for(N1 * wdt)), dim3(256), 0, c->stream, static_cast<const double*>(dA),
+                               N1, int64_t(F), M1, off, static_cast<const double*>(fa), m, static_cast<double*>(sa), int64_t(wdt));
+            HIPCHK(c, hipGetLastError());
+            hipLaunchKernelGGL(lr_scale_factors_kernel<double>, dim3(grid_for(N2 * wdt)), dim3(256), 0, c->stream, static_cast<const double*>(dB),
+                               N2, int64_t(F), M1, off, static_cast<const double*>(fb), m, static_cast<double*>(sb), int64_t(wdt));
+            HIPCHK(c, hipGetLastError());
+            double* om = static_cast<double*>(dout) + size_t(m) * N1 * N2;
+            CHK(lr_gemm(c, static_cast<const double*>(sa), static_cast<const double*>(sb), N1, N2, wdt, wdt, wdt, om, N2));
+            if (jit_diag) {
+                hipLaunchKernelGGL(lr_add_jitter_diag_kernel<double>, dim3(grid_for(N1)), dim3(256), 0, c->stream, om, N1, M1,
+                                   static_cast<const double*>(fa), static_cast<const double*>(fb), p->jitter, m);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
+    }
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_lr_kernel_diag(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, const void* Phi, int64_t N, int32_t return_levels,
+                         void* out) {
+    ENTER(c, p);
+    if (!lr) return fail(c, GPSIG_ERR_INVALID, "lowrank descriptor is NULL");
+    if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "low-rank mode is built for float64 only");
+    const int M = p->num_levels, M1 = M + 1;
+    const int32_t* off;
+    int F;
+    CHK(lr_level_offsets(c, M, lr->num_components, lr->rank_bound, &off, &F));
+    const void* dP;
+    CHK(in_dev(c, B_IN0, Phi, sizeof(double) * size_t(N) * F, &dP));
+    const size_t ob = sizeof(double) * size_t(N) * (return_levels ? M1 : 1);
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    const double* w;
+    CHK(upload_weights(c, p, &w));
+    if (N > 0) {
+        hipLaunchKernelGGL(lr_level_diag_kernel<double>, dim3(grid_for(N * M1)), dim3(256), 0, c->stream, static_cast<const double*>(dP), N,
+                           int64_t(F), M1, off, w, int(return_levels != 0), static_cast<double*>(dout));
+        HIPCHK(c, hipGetLastError());
+    }
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
 }
 
 }  // extern "C"

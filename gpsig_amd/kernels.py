@@ -8,13 +8,14 @@ every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CU
 pointers, asynchronous on the current stream).
 
 Not built yet (raise NotImplementedError, never a silent fallback): ``order > 1`` on the GPU,
-``low_rank=True``, ``SignatureSpectral``; float32 inputs are computed in float32 (order 1 only).
+``SignatureSpectral``; ``low_rank=True`` inside ``K_tens_n_seq_covs`` / ``K_seq_n_seq_covs``; float32 inputs are
+computed in float32 (order 1, exact mode only).
 """
 import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _lib, low_rank as _lr
 
 try:  # torch is only plumbing: device memory and streams
     import torch
@@ -75,6 +76,34 @@ def _shape(a):
     return tuple(a.shape)
 
 
+class LowRankState:
+    """The random objects of one low-rank evaluation (reference: drawn inside the TF graph, kernels.py:443-449,
+    low_rank_calculations.py:47-57): landmarks (c, d') -- scaled points --, whitening (c, c), one sketch per level >= 2."""
+
+    def __init__(self, landmarks, whitening, sketches, rank_bound):
+        self.landmarks = np.ascontiguousarray(landmarks, dtype=np.float64)
+        self.whitening = np.ascontiguousarray(whitening, dtype=np.float64)
+        self.sketches = list(sketches)
+        self.rank_bound = int(rank_bound)
+        self.num_components = self.landmarks.shape[0]
+
+    def as_c(self, keep):
+        arr = (_lib.SketchC * max(len(self.sketches), 1))()
+        for k, sk in enumerate(self.sketches):
+            arr[k].k1, arr[k].k2, arr[k].r, arr[k].nnz = sk.k1, sk.k2, sk.r, int(sk.val.shape[0])
+            arr[k].colptr = sk.colptr.ctypes.data_as(C.POINTER(C.c_int32))
+            arr[k].i1 = sk.i1.ctypes.data_as(C.POINTER(C.c_int32))
+            arr[k].i2 = sk.i2.ctypes.data_as(C.POINTER(C.c_int32))
+            arr[k].val = sk.val.ctypes.data_as(C.POINTER(C.c_double))
+        lr = _lib.LowRankC()
+        lr.num_components, lr.rank_bound, lr.num_sketches = self.num_components, self.rank_bound, len(self.sketches)
+        lr.landmarks = self.landmarks.ctypes.data_as(C.POINTER(C.c_double))
+        lr.whitening = self.whitening.ctypes.data_as(C.POINTER(C.c_double))
+        lr.sketches = arr
+        keep.extend([arr, lr, self])
+        return lr
+
+
 class SignatureKernel:
     """Reference: ``gpsig.kernels.SignatureKernel`` (gpsig/kernels.py:15-761).
 
@@ -126,6 +155,7 @@ class SignatureKernel:
         else:
             self.lengthscales = None
         self._base_params = (0.0, 0.0)
+        self.rng = np.random.default_rng()   # low-rank mode: source of landmarks and projections (the reference uses TF's global RNG)
 
     # ---- validators (kernels.py:94-133) ------------------------------------------------------
     @staticmethod
@@ -168,8 +198,6 @@ class SignatureKernel:
     def _params(self, keep, dtype_id=_lib.F64):
         if self._base is None:
             raise NotImplementedError("SignatureKernel is abstract: use SignatureLinear, SignatureRBF, ...")
-        if self.low_rank:
-            raise NotImplementedError("low_rank=True (Nystrom + randomised Hadamard sketch) is not built on the GPU yet")
         p = _lib.Params()
         p.base_kernel = _lib.BASE[self._base]
         p.dtype = dtype_id
@@ -220,14 +248,17 @@ class SignatureKernel:
         return shp[1]
 
     # ---- kernel evaluations ----------------------------------------------------------------------
-    def K(self, X, X2=None, presliced=False, return_levels=False, presliced_X=False, presliced_X2=False):
-        """Reference: kernels.py:401-476.  (N1, N2) or (M+1, N1, N2)."""
+    def K(self, X, X2=None, presliced=False, return_levels=False, presliced_X=False, presliced_X2=False, lr_state=None):
+        """Reference: kernels.py:401-476.  (N1, N2) or (M+1, N1, N2).  lr_state: low-rank mode only, the random
+        objects to use (default: drawn afresh, as the reference does)."""
         if presliced:
             presliced_X = presliced_X2 = True
         if not presliced_X:
             X, _ = self._slice(X, None)
         if not presliced_X2 and X2 is not None:
             X2, _ = self._slice(X2, None)
+        if self.low_rank:
+            return self._K_lr(X, X2, return_levels, lr_state)
         L_ = _Launch(X, X2)
         n1, l1 = self._seq_dims(X)
         n2, l2 = self._seq_dims(X2) if X2 is not None else (n1, l1)
@@ -236,10 +267,19 @@ class SignatureKernel:
         L_.ctx.call("gpsig_kernel_K", p, L_.inp(X), L_.inp(X2), n1, n2, l1, l2, int(bool(return_levels)), optr)
         return out
 
-    def Kdiag(self, X, presliced=False, return_levels=False):
+    def Kdiag(self, X, presliced=False, return_levels=False, lr_state=None):
         """Reference: kernels.py:479-510.  (N,) or (M+1, N)."""
         if not presliced:
             X, _ = self._slice(X, None)
+        if self.low_rank and not self.normalization:
+            st = lr_state or self.draw_low_rank(X=X)
+            L_ = _Launch(X)
+            p = self._params(L_.keep)
+            lr = st.as_c(L_.keep)
+            Phi, pp, n = self._lr_features(L_, p, lr, X)
+            out, optr = L_.out((self.num_levels + 1, n) if return_levels else (n,))
+            L_.ctx.call("gpsig_lr_kernel_diag", p, lr, pp, n, int(bool(return_levels)), optr)
+            return out
         L_ = _Launch(X)
         n, l = self._seq_dims(X)
         p = self._params(L_.keep, L_.dtype_id)
@@ -247,8 +287,17 @@ class SignatureKernel:
         L_.ctx.call("gpsig_kernel_Kdiag", p, L_.inp(X), n, l, int(bool(return_levels)), optr)
         return out
 
-    def K_tens(self, Z, return_levels=False, increments=False):
+    def K_tens(self, Z, return_levels=False, increments=False, lr_state=None):
         """Reference: kernels.py:513-536.  (T, T) or (M+1, T, T); never normalised."""
+        if self.low_rank:
+            st = lr_state or self.draw_low_rank(Z=Z, increments=increments)
+            L_ = _Launch(Z)
+            p = self._params(L_.keep)
+            lr = st.as_c(L_.keep)
+            Phi, pp, t = self._lr_features(L_, p, lr, Z, tensors=True, increments=increments)
+            out, optr = L_.out((self.num_levels + 1, t, t) if return_levels else (t, t))
+            L_.ctx.call("gpsig_lr_kernel", p, lr, pp, None, t, t, 0, 0, int(bool(return_levels)), optr)
+            return out
         L_ = _Launch(Z)
         t = self._tens_dims(Z, increments)
         p = self._params(L_.keep, L_.dtype_id)
@@ -256,10 +305,20 @@ class SignatureKernel:
         L_.ctx.call("gpsig_kernel_K_tens", p, L_.inp(Z), t, int(bool(increments)), int(bool(return_levels)), optr)
         return out
 
-    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False, presliced=False):
+    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False, presliced=False, lr_state=None):
         """Reference: kernels.py:539-588.  (T, N) or (M+1, T, N); normalised on the sequence axis only."""
         if not presliced:
             X, _ = self._slice(X, None)
+        if self.low_rank:
+            st = lr_state or self.draw_low_rank(X=X, Z=Z, increments=increments)
+            L_ = _Launch(Z, X)
+            p = self._params(L_.keep)
+            lr = st.as_c(L_.keep)
+            PZ, pz, t = self._lr_features(L_, p, lr, Z, tensors=True, increments=increments)
+            PX, px, n = self._lr_features(L_, p, lr, X)
+            out, optr = L_.out((self.num_levels + 1, t, n) if return_levels else (t, n))
+            L_.ctx.call("gpsig_lr_kernel", p, lr, pz, px, t, n, 0, int(bool(self.normalization)), int(bool(return_levels)), optr)
+            return out
         L_ = _Launch(Z, X)
         t = self._tens_dims(Z, increments)
         n, l = self._seq_dims(X)
@@ -273,6 +332,18 @@ class SignatureKernel:
         """Reference: kernels.py:591-671.  Returns (Kzz, Kzx, Kxx); Kxx is the diagonal unless full_X_cov."""
         if not presliced:
             X, _ = self._slice(X, None)
+        if self.low_rank:
+            # one shared draw of landmarks / projections for all three matrices (kernels.py:613-621)
+            st = self.draw_low_rank(X=X, Z=Z, increments=increments)
+            Kzz = self.K_tens(Z, return_levels=return_levels, increments=increments, lr_state=st)
+            Kzx = self.K_tens_vs_seq(Z, X, return_levels=return_levels, increments=increments, presliced=True, lr_state=st)
+            if full_X_cov:
+                Kxx = self.K(X, presliced=True, return_levels=return_levels, lr_state=st)
+                if self.normalization:
+                    pass   # Kzx is already divided by sqrt(diag + jitter) of the same factors (kernels.py:638 == :581)
+            else:
+                Kxx = self.Kdiag(X, presliced=True, return_levels=return_levels, lr_state=st)
+            return Kzz, Kzx, Kxx
         L_ = _Launch(Z, X)
         t = self._tens_dims(Z, increments)
         n, l = self._seq_dims(X)
@@ -291,6 +362,8 @@ class SignatureKernel:
         reproduced; the undefined names of :723-728 are read as the evident mirror of :709-712."""
         if not presliced:
             X2, _ = self._slice(X2, None)
+        if self.low_rank:
+            raise NotImplementedError("K_seq_n_seq_covs in low-rank mode is not built")
         L_ = _Launch(X, X2)
         n1, l1 = self._seq_dims(X)
         n2, l2 = self._seq_dims(X2)
@@ -302,6 +375,91 @@ class SignatureKernel:
         L_.ctx.call("gpsig_kernel_K_seq_n_seq_covs", p, L_.inp(X), L_.inp(X2), n1, n2, l1, l2, int(bool(full_X2_cov)),
                     int(bool(return_levels)), p11, p12, p22)
         return Kxx, Kxx2, Kx2x2
+
+    # ---- low-rank mode (kernels.py:239-311 and the low_rank branches of K / Kdiag / K_tens / K_tens_vs_seq) -----
+    def _scaled_tensor_points(self, Z, increments):
+        """kernels.py:367-398 on the host (inducing tensors are small): flat scaled components (rows, d')."""
+        Z = np.asarray(Z.detach().cpu().numpy() if _is_torch(Z) else Z, dtype=np.float64)
+        d_eff = self.num_features * (self.num_lags + 1)
+        Zf = Z.reshape(-1, self.num_lags + 1, self.num_features).copy()
+        if self.lengthscales is not None:
+            Zf = Zf / np.asarray(self.lengthscales)[None, None, :]
+            if self.num_lags > 0:
+                Zf = Zf * np.asarray(self.gamma)[None, :, None]
+        return Zf.reshape(-1, d_eff)
+
+    def draw_low_rank(self, X=None, X2=None, Z=None, increments=False):
+        """Draw the landmarks (uniformly, without replacement, from the scaled points of every given argument:
+        kernels.py:444-446, :562-563), whiten their Gram (low_rank_calculations.py:50-57) and draw one projection
+        per level (low_rank_calculations.py:76-193).  Returns a LowRankState that can be passed to K(..., lr_state=)."""
+        cands = []
+        L_ = _Launch(X, X2)
+        p = self._params(L_.keep, _lib.F64)
+        total = 0
+        seqs = []
+        for A in (X, X2):
+            if A is not None:
+                n, l = self._seq_dims(A)
+                seqs.append((A, n, l, total))
+                total += n * l
+        ztot = 0
+        if Z is not None:
+            zp = self._scaled_tensor_points(Z, increments)
+            ztot = zp.shape[0]
+        c = int(self.num_components)
+        if c > total + ztot:
+            raise ValueError("num_components exceeds the number of available points")
+        pick = np.sort(self.rng.permutation(total + ztot)[:c])
+        d_eff = self.num_features * (self.num_lags + 1)
+        parts = []
+        if Z is not None:
+            parts.append(zp[pick[pick < ztot]])
+        for A, n, l, off in seqs:
+            sel = pick[(pick >= ztot + off) & (pick < ztot + off + n * l)] - ztot - off
+            out = np.empty((sel.shape[0], d_eff))
+            if sel.shape[0]:
+                idx = np.ascontiguousarray(sel, dtype=np.int64)
+                L_.ctx.call("gpsig_lr_gather_points", p, L_.inp(A), n, l, idx.ctypes.data_as(C.POINTER(C.c_int64)), idx.shape[0],
+                            out.ctypes.data_as(C.POINTER(C.c_double)))
+            parts.append(out)
+        S = np.ascontiguousarray(np.concatenate(parts, axis=0))
+        W = np.empty((c, c))
+        L_.ctx.call("gpsig_base_kernel_matrix", p, S.ctypes.data_as(C.POINTER(C.c_double)), S.ctypes.data_as(C.POINTER(C.c_double)), c, c,
+                    d_eff, W.ctypes.data_as(C.POINTER(C.c_double)))
+        W = W + np.diag(JITTER * self.rng.random(c))                              # low_rank_calculations.py:52
+        ev, U = np.linalg.eigh(W)                                                 # :55
+        Wh = U / np.sqrt(ev + JITTER)[None, :]                                    # :56-57, :60
+        sk = _lr.draw_level_sketches(self.rng, self.num_levels, c, int(self.rank_bound), self.sparsity)
+        return LowRankState(S, Wh, sk, self.rank_bound)
+
+    def _lr_features(self, L_, p, lr, A, tensors=False, increments=False):
+        F = 1 + lr.num_components + (self.num_levels - 1) * lr.rank_bound
+        if tensors:
+            t = self._tens_dims(A, increments)
+            Phi, pp = L_.out((t, F))
+            L_.ctx.call("gpsig_lr_tens_features", p, lr, L_.inp(A), t, int(bool(increments)), pp)
+            return Phi, pp, t
+        n, l = self._seq_dims(A)
+        Phi, pp = L_.out((n, F))
+        L_.ctx.call("gpsig_lr_seq_features", p, lr, L_.inp(A), n, l, pp)
+        return Phi, pp, n
+
+    def _K_lr(self, X, X2, return_levels, lr_state):
+        st = lr_state or self.draw_low_rank(X=X, X2=X2)
+        L_ = _Launch(X, X2)
+        if L_.f32:
+            raise NotImplementedError("low-rank mode is built for float64 only")
+        p = self._params(L_.keep)
+        lr = st.as_c(L_.keep)
+        PA, pa, n1 = self._lr_features(L_, p, lr, X)
+        if X2 is None:
+            PB, pb, n2 = None, None, n1
+        else:
+            PB, pb, n2 = self._lr_features(L_, p, lr, X2)
+        out, optr = L_.out((self.num_levels + 1, n1, n2) if return_levels else (n1, n2))
+        nrm = int(bool(self.normalization))
+        L_.ctx.call("gpsig_lr_kernel", p, lr, pa, pb, n1, n2, nrm, nrm, int(bool(return_levels)), optr)
+        return out
 
     # ---- the signature_algs.py layer: unnormalised level tensors -----------------------------------
     def _K_seq(self, X, X2=None):

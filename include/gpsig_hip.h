@@ -143,6 +143,51 @@ int gpsig_kernel_K_seq_n_seq_covs(gpsig_ctx* ctx, const gpsig_params* p, const v
                                   int64_t N1, int64_t N2, int32_t L1, int32_t L2, int32_t full_X2_cov,
                                   int32_t return_levels, void* Kxx, void* Kxx2, void* Kx2x2);
 
+/* ---- low-rank mode (low_rank=True): gpsig/low_rank_calculations.py, gpsig/signature_algs.py:162-222,
+ * gpsig/kernels.py:239-311, :424-426, :442-458, :499-501, :525-527, :560-574.  float64 only.
+ *
+ * The reference draws landmarks and random projections with TensorFlow's RNG inside the graph; here they are
+ * drawn by the caller and passed in (all HOST pointers), which makes the device code deterministic:
+ *   landmarks  (c, d') scaled points, whitening (c, c) = U / sqrt(S + jitter) of the landmark Gram
+ *              (low_rank_calculations.py:50-60);
+ *   sketches   one per level 2..M: the projection of low_rank_calculations.py:104-193 stored by output column,
+ *              out[j] = sum_{e in [colptr[j], colptr[j+1])} val[e] * A[i1[e]] * B[i2[e]].
+ * Factor matrices Phi are (rows, F), F = 1 + c + (M-1) r, level blocks [1 | c | r | ... | r]. */
+typedef struct gpsig_sketch {
+    int32_t k1, k2, r, nnz;
+    const int32_t* colptr;   /* r + 1 */
+    const int32_t* i1;       /* nnz, < k1 */
+    const int32_t* i2;       /* nnz, < k2 */
+    const double* val;       /* nnz */
+} gpsig_sketch;
+typedef struct gpsig_lowrank {
+    int32_t num_components;  /* c */
+    int32_t rank_bound;      /* r */
+    int32_t num_sketches;    /* M - 1 */
+    const double* landmarks;
+    const double* whitening;
+    const gpsig_sketch* sketches;
+} gpsig_lowrank;
+/* scaled / lagged observations number idx[0..R) (flat index n*L + t) of X -> out (R, d') on the HOST (landmark candidates) */
+int gpsig_lr_gather_points(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L, const int64_t* idx,
+                           int64_t R, double* out_host);
+/* kappa(A, B) of already scaled points, all on the HOST: A (na, d'), B (nb, d') -> out (na, nb) */
+int gpsig_base_kernel_matrix(gpsig_ctx* ctx, const gpsig_params* p, const double* A_host, const double* B_host, int64_t na,
+                             int64_t nb, int32_t d, double* out_host);
+/* SignatureKernel._K_seq_lr_feat (kernels.py:239-261): Nystrom_map + signature_kern_first_order_lr_feature.  Phi: (N, F). */
+int gpsig_lr_seq_features(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowrank* lr, const void* X, int64_t N, int32_t L, void* Phi);
+/* SignatureKernel._K_tens_lr_feat (kernels.py:285-311): Nystrom_map + tensor_kern_lr_feature.  Phi: (T, F). */
+int gpsig_lr_tens_features(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowrank* lr, const void* Z, int64_t T,
+                           int32_t increments, void* Phi);
+/* Kernel matrix from factors: level Grams PhiA_m PhiB_m^T (fp64 MFMA), optional per-side level normalisation
+ * 1/sqrt(|Phi_m|^2 + jitter) (kernels.py:457-469, :574-581), sigma*variances, level sum.  PhiB == NULL: symmetric, with
+ * the jitter of kernels.py:431 on the diagonal when normalising.  out: (N1, N2) or (M+1, N1, N2). */
+int gpsig_lr_kernel(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowrank* lr, const void* PhiA, const void* PhiB, int64_t N1,
+                    int64_t N2, int32_t normalize_a, int32_t normalize_b, int32_t return_levels, void* out);
+/* diagonal sum_j Phi_m[n][j]^2 * sigma * variances[m] (kernels.py:499-510).  out: (N,) or (M+1, N). */
+int gpsig_lr_kernel_diag(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowrank* lr, const void* Phi, int64_t N,
+                         int32_t return_levels, void* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -599,6 +599,127 @@ def inducing_sequences_Kuu_Kuf_Kff(kern, Z, X, W=None, jitter=0.0, full_f_cov=Fa
 
 
 # ---------------------------------------------------------------------------
+# Low-rank algorithms: gpsig/low_rank_calculations.py, gpsig/signature_algs.py:162-222, gpsig/kernels.py:239-311.
+# The reference draws landmarks and projections with TensorFlow's RNG inside the graph (not reproducible), so these
+# restatements take the random objects as ARGUMENTS: `landmarks` (c, d') and `sketches` (one per level >= 2, anything
+# with an .apply(A, B) -> (..., r) method; the tests pass the very objects the product uses, gpsig_amd.low_rank.Sketch,
+# whose apply() is a plain NumPy sum).  Parity with the reference is therefore statistical only;
+# parity between the HIP path and this restatement, given the same random objects, is exact.
+# Q6 (reference bugs NOT reproduced): signature_algs.py:191 appends reduce_sum(U) instead of reduce_sum(P);
+# kernels.py:425,448-449 pass the unscaled X to the low-rank feature map while Kdiag (:500) passes the scaled one.
+# ---------------------------------------------------------------------------
+def nystrom_whitening(kern_fn, landmarks, jitter_diag):
+    """low_rank_calculations.py:50-57: W = k(S,S) + diag(jitter_diag); eig; S += jitter; returns U / sqrt(S) (c, c)."""
+    W = kern_fn(landmarks, landmarks) + np.diag(jitter_diag)                      # :51-52
+    S, U = np.linalg.eigh(W)                                                     # :55
+    S = S + JITTER                                                               # :56
+    return U / np.sqrt(S)[None, :]                                               # :57, :60
+
+
+def nystrom_map(X, kern_fn, landmarks, whitening):
+    """low_rank_calculations.py:59-61: k(X, S) @ U / D.  X: (P, d') -> (P, c)."""
+    return kern_fn(X, landmarks) @ whitening
+
+
+def signature_kern_first_order_lr_feature(U, num_levels, sketches, difference=True):
+    """signature_algs.py:162-192 with the evident fix of :191.  U: (N, L, c) -> list of (N, .) factors."""
+    Phi = [np.ones((U.shape[0], 1), dtype=U.dtype)]                              # :177
+    if difference:
+        U = U[:, 1:, :] - U[:, :-1, :]                                           # :180
+    Phi.append(U.sum(axis=1))                                                    # :182
+    P = U                                                                        # :184
+    for i in range(2, num_levels + 1):                                           # :185
+        P = _excumsum(P, 1)                                                      # :186
+        P = sketches[i - 2].apply(U, P)                                          # :188/:190  lr_hadamard_prod_rand(U, P, ...)
+        Phi.append(P.sum(axis=1))                                                # :191 (Q6: the reference sums U here)
+    return Phi
+
+
+def tensor_kern_lr_feature(U, num_levels, sketches):
+    """signature_algs.py:194-222.  U: (lt, T, c) -> list of (T, .) factors."""
+    Phi = [np.ones((U.shape[1], 1), dtype=U.dtype)]                              # :209
+    k = 0
+    for i in range(1, num_levels + 1):                                           # :212
+        R = U[k]; k += 1                                                         # :213-214
+        for j in range(1, i):                                                    # :215
+            R = sketches[j - 1].apply(U[k], R); k += 1                           # :217/:219  lr_hadamard_prod_rand(U[k], R, ...)
+        Phi.append(R)                                                            # :221
+    return Phi
+
+
+class LowRankOracle:
+    """The low_rank=True branches of SignatureKernel (kernels.py:424-426, 442-458, 499-501, 525-527, 560-574, 612-628)
+    on top of a SignatureKernelOracle `k` (which supplies scaling, base kernel, weights)."""
+
+    def __init__(self, k, landmarks, jitter_diag, sketches):
+        self.k, self.S, self.sk = k, np.asarray(landmarks, dtype=np.float64), sketches
+        self.Wh = nystrom_whitening(k._base_kern, self.S, jitter_diag)
+
+    def seq_features(self, X):
+        k = self.k
+        Xs = k._apply_scaling_and_lags_to_sequences(k._seq3(X))                  # (Q6: scaled, as Kdiag :497-500 does)
+        N, L, dd = Xs.shape
+        F = nystrom_map(Xs.reshape(N * L, dd), k._base_kern, self.S, self.Wh).reshape(N, L, -1)    # kernels.py:252-254
+        return signature_kern_first_order_lr_feature(F, k.num_levels, self.sk, difference=k.difference)   # :257
+
+    def tens_features(self, Z, increments=False):
+        k = self.k
+        Zs = k._scale_Z(Z, increments)
+        lt, T, dd = Zs.shape[0], Zs.shape[1], Zs.shape[-1]
+        if increments:                                                           # kernels.py:300-304
+            F = nystrom_map(Zs.reshape(lt * T * 2, dd), k._base_kern, self.S, self.Wh).reshape(lt, T, 2, -1)
+            F = F[:, :, 1, :] - F[:, :, 0, :]
+        else:                                                                    # :306-308
+            F = nystrom_map(Zs.reshape(lt * T, dd), k._base_kern, self.S, self.Wh).reshape(lt, T, -1)
+        return tensor_kern_lr_feature(F, k.num_levels, self.sk)                  # :310
+
+    def _finish(self, Kl, return_levels):
+        Kl = Kl * self.k._weights()[:, None, None]
+        return Kl if return_levels else Kl.sum(axis=0)
+
+    def K(self, X, X2=None, return_levels=False):
+        """kernels.py:423-476, low-rank branch."""
+        P1 = self.seq_features(X)
+        if X2 is None:
+            Kl = np.stack([P @ P.T for P in P1], axis=0)                          # :426
+            if self.k.normalization:
+                Kl = Kl + JITTER * np.eye(Kl.shape[1])[None]                      # :431
+                dsq = np.sqrt(np.diagonal(Kl, axis1=1, axis2=2))
+                Kl = Kl / (dsq[:, :, None] * dsq[:, None, :])                     # :432-433
+        else:
+            P2 = self.seq_features(X2)
+            Kl = np.stack([a @ b.T for a, b in zip(P1, P2)], axis=0)              # :451
+            if self.k.normalization:
+                d1 = np.sqrt(np.stack([np.sum(np.square(P), axis=-1) for P in P1], axis=0) + JITTER)   # :457, :463
+                d2 = np.sqrt(np.stack([np.sum(np.square(P), axis=-1) for P in P2], axis=0) + JITTER)
+                Kl = Kl / (d1[:, :, None] * d2[:, None, :])                       # :469
+        return self._finish(Kl, return_levels)
+
+    def Kdiag(self, X, return_levels=False):
+        """kernels.py:479-510."""
+        k = self.k
+        N = np.asarray(X).shape[0]
+        if k.normalization:
+            return np.tile(k._weights()[:, None], [1, N]) if return_levels else np.full((N,), k.sigma * np.sum(k.variances))
+        Kd = np.stack([np.sum(np.square(P), axis=-1) for P in self.seq_features(X)], axis=0) * k._weights()[:, None]   # :501-505
+        return Kd if return_levels else Kd.sum(axis=0)
+
+    def K_tens(self, Z, return_levels=False, increments=False):
+        """kernels.py:525-536."""
+        Kl = np.stack([P @ P.T for P in self.tens_features(Z, increments)], axis=0)
+        return self._finish(Kl, return_levels)
+
+    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False):
+        """kernels.py:560-588."""
+        PZ, PX = self.tens_features(Z, increments), self.seq_features(X)
+        Kl = np.stack([a @ b.T for a, b in zip(PZ, PX)], axis=0)                  # :568
+        if self.k.normalization:
+            dx = np.sqrt(np.stack([np.sum(np.square(P), axis=-1) for P in PX], axis=0) + JITTER)       # :574-580
+            Kl = Kl / dx[:, None, :]                                              # :581
+        return self._finish(Kl, return_levels)
+
+
+# ---------------------------------------------------------------------------
 # Independent validators (NOT restatements of the reference): they stand in for esig, which the
 # reference's notebook uses and this image lacks.
 # ---------------------------------------------------------------------------

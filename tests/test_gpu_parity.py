@@ -347,7 +347,7 @@ def test_unsupported_shapes_fail_loudly(K):
     with pytest.raises(NotImplementedError, match="no seq-gram kernel shape"):
         K.SignatureLinear(20 * 5, 20, 3).K(np.zeros((2, 100)))             # d = 20 > 16
     with pytest.raises(NotImplementedError):
-        K.SignatureLinear(12, 3, 3, low_rank=True).K(np.zeros((2, 12)))
+        K.SignatureRBF(12, 3, 3, low_rank=True, num_components=4).K(np.zeros((4, 12), dtype=np.float32))   # low-rank is float64 only
     with pytest.raises(ValueError):
         K.SignatureLinear(12, 3, 3).K_tens(np.zeros((5, 4, 3)))            # lt must be 6
 
@@ -490,3 +490,76 @@ def test_float32_config5_shape_reduced_n(K):
     want = O.K_symm_tiled(make_oracle(kw), X.astype(np.float64), tile=16)
     assert relerr(got.cpu().numpy(), want) <= TOL32
     assert torch.equal(got, got.T)
+
+
+# ------------------------------------------------------------------------------------------------
+# low-rank mode (gpsig/low_rank_calculations.py, signature_algs.py:162-222): the reference's randomness is TF's and
+# cannot be reproduced, so (i) given the SAME landmarks and projections the HIP path must equal the restatement of
+# the intended maths exactly, (ii) in the exact limit it must reproduce the exact kernel, (iii) statistically the
+# approximation error must shrink as num_components / rank_bound grow.
+# ------------------------------------------------------------------------------------------------
+def _lr_pair(K, base, L, d, M, **kw):
+    kx = make_kernel(K, dict(input_dim=L * d, num_features=d, num_levels=M, base=base, low_rank=True, **kw))
+    okw = {k: v for k, v in kw.items() if k not in ("num_components", "rank_bound", "sparsity")}
+    return kx, make_oracle(dict(input_dim=L * d, num_features=d, num_levels=M, base=base, **okw))
+
+
+@pytest.mark.parametrize("sparsity", ["sqrt", "log", "lin"])
+@pytest.mark.parametrize("base", ["rbf", "linear"])
+def test_low_rank_equals_restatement_given_the_same_randomness(K, sparsity, base):
+    rng = np.random.default_rng(41)
+    N, L, d, M, T = 23, 12, 3, 4, 7
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+    Y = np.cumsum(0.3 * rng.standard_normal((9, L, d)), axis=1).reshape(9, -1)
+    for norm in (True, False):
+        for incr in (False, True):
+            Z = rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d))
+            kx, ko = _lr_pair(K, base, L, d, M, normalization=norm, num_components=11, rank_bound=9, sparsity=sparsity,
+                              lengthscales=0.6 + rng.random(d), variances=0.5 + rng.random(M + 1))
+            kx.rng = np.random.default_rng(7)
+            st = kx.draw_low_rank(X=X, X2=Y, Z=Z, increments=incr)
+            lo = O.LowRankOracle(ko, st.landmarks, np.zeros(st.num_components), st.sketches)
+            lo.Wh = st.whitening                       # the same whitening (the product adds the reference's random jitter)
+            assert relerr(kx.K(X, lr_state=st), lo.K(X)) <= 1e-9
+            assert relerr(kx.K(X, Y, lr_state=st, return_levels=True), lo.K(X, Y, return_levels=True)) <= 1e-9
+            assert relerr(kx.K_tens(Z, increments=incr, lr_state=st), lo.K_tens(Z, increments=incr)) <= 1e-9
+            assert relerr(kx.K_tens_vs_seq(Z, X, increments=incr, lr_state=st, return_levels=True),
+                          lo.K_tens_vs_seq(Z, X, increments=incr, return_levels=True)) <= 1e-9
+            assert relerr(kx.Kdiag(X, lr_state=st), lo.Kdiag(X)) <= 1e-9
+
+
+def test_low_rank_exact_limit_and_convergence(K):
+    rng = np.random.default_rng(43)
+    N, L, d = 8, 5, 2
+    X = np.cumsum(0.5 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+    # every point a landmark + every coordinate pair kept ('lin', rank_bound = c^2 at level 2): the exact kernel
+    c = N * L
+    kx, ko = _lr_pair(K, "rbf", L, d, 2, normalization=False, num_components=c, rank_bound=c * c, sparsity="lin", lengthscales=None)
+    kx.rng = np.random.default_rng(1)
+    exact = ko.K(X)
+    assert np.abs(kx.K(X) - exact).max() <= 1e-4 * np.abs(exact).max()      # only the Nystrom jitter (1e-6) separates them
+    # statistically: mean error over draws shrinks as the rank grows
+    N, L, d, M = 30, 10, 2, 3
+    X = np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+    ko = make_oracle(dict(input_dim=L * d, num_features=d, num_levels=M, base="rbf"))
+    exact = ko.K(X)
+    errs = []
+    for c_, r_ in ((10, 10), (40, 40), (120, 160)):
+        kx = make_kernel(K, dict(input_dim=L * d, num_features=d, num_levels=M, base="rbf", low_rank=True, num_components=c_,
+                                 rank_bound=r_, sparsity="sqrt"))
+        kx.rng = np.random.default_rng(3)
+        errs.append(np.mean([np.linalg.norm(kx.K(X) - exact) / np.linalg.norm(exact) for _ in range(6)]))
+    assert errs[0] > errs[1] > errs[2] and errs[2] < 0.5 * errs[0], errs
+
+
+def test_low_rank_validation(K):
+    with pytest.raises(NotImplementedError):
+        K.SignatureRBF(12, 3, 3, low_rank=True, order=2)                  # kernels.py:59-60
+    kx = K.SignatureRBF(12, 3, 3, low_rank=True, num_components=1000)
+    with pytest.raises(ValueError, match="num_components"):
+        kx.K(np.zeros((2, 12)))
+    # the three SVGP matrices share one draw
+    rng = np.random.default_rng(5)
+    kx = K.SignatureRBF(12, 3, 3, low_rank=True, num_components=8, rank_bound=8)
+    Kzz, Kzx, Kxx = kx.K_tens_n_seq_covs(rng.standard_normal((6, 4, 3)), rng.standard_normal((10, 12)))
+    assert Kzz.shape == (4, 4) and Kzx.shape == (4, 10) and Kxx.shape == (10,)
