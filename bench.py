@@ -100,11 +100,17 @@ def main():
     import torch.distributed as dist
     from gpsig_amd import _lib, kernels, parallel
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("GPSIG_BENCH_BACKEND", "nccl")       # "gloo": functional check of the N > 1 path on a box with one GPU
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_total = N_BASE if n_gpus == 1 else int(round(N_BASE * math.sqrt(n_gpus) / 64.0)) * 64
     rng = np.random.default_rng(0)
@@ -177,6 +183,9 @@ def main():
         chk = out[:8, :8].diagonal().cpu().numpy() if out is not None else None
         if chk is not None:
             assert np.allclose(chk, M + 1.0, atol=1e-9), chk
+        if os.environ.get("GPSIG_BENCH_VERIFY") and n_gpus > 1:      # the gathered Gram against the single-context one
+            ref = kern.K(X)
+            res["verify_max_abs_diff_vs_single_rank"] = float((out - ref).abs().max().item())
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -59,12 +59,26 @@ class ShardedGram:
         b0, b1 = self.bounds[self.rank], self.bounds[self.rank + 1]
         self.ctx.set_pointer_mode(_lib.PTR_DEVICE)
         self.ctx.call("gpsig_kernel_K_symm_rows", p, C.c_void_p(X.data_ptr()), n, L, b0, b1, C.c_void_p(self.rows.data_ptr()))
-        if self.rank == 0:
+        if dist.get_backend() != "nccl":            # CPU collectives (tests on a box with fewer GPUs than ranks): stage through the host
+            torch.cuda.synchronize(self.dev)
+            host = self.rows.cpu()
+            if self.rank == 0:
+                parts = [torch.empty_like(host) for _ in range(self.world)]
+                dist.gather(host, gather_list=parts, dst=0)
+                for dst_t, src_t in zip(self.parts, parts):
+                    dst_t.copy_(src_t)
+            else:
+                dist.gather(host, dst=0)
+                return None
+        elif self.rank == 0:
             dist.gather(self.rows, gather_list=self.parts, dst=0)
+        else:
+            dist.gather(self.rows, dst=0)
+            return None
+        if self.rank == 0:
             self.ctx.check(self.ctx._lib.gpsig_symmetrize_owned_rows(self.ctx._h, _lib.F64, C.c_void_p(self.half.data_ptr()), n,
                                                                        C.c_void_p(self.out.data_ptr())))
             return self.out
-        dist.gather(self.rows, dst=0)
         return None
 
 
