@@ -1,0 +1,131 @@
+"""Sparse variational GP prediction on top of the signature covariances: the call surface of ``gpsig.models.SVGP``'s
+``_build_predict`` (reference: gpsig/models.py:62-73) and the prior KL of ``_build_likelihood`` (:46-51).
+
+The three covariances come from ``inducing_variables.Kuu_Kuf_Kff`` (HIP kernels); the dense linear algebra --
+Cholesky of Kzz, the triangular solves, the matmuls of GPflow 1.5.1's ``conditionals.base_conditional`` and
+``kullback_leiblers.gauss_kl`` (pinned by requirements.txt:8, not vendored; restated from their published
+algorithm) -- runs on the device through torch.linalg, i.e. rocSOLVER (potrf, trsm) and rocBLAS / hipBLASLt.
+Training (GPflow actions, TF optimisers, likelihood expectations) is out of scope.
+"""
+import numpy as np
+
+from . import inducing_variables as iv
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+JITTER = 1e-6   # gpflow.settings.jitter (models.py:65)
+
+
+def _dev(a, device):
+    if torch.is_tensor(a):
+        return a.to(device=device, dtype=torch.float64)
+    return torch.as_tensor(np.asarray(a, dtype=np.float64), device=device)
+
+
+def base_conditional(Kmn, Kmm, Knn, f, *, full_cov=False, q_sqrt=None, white=False):
+    """GPflow 1.5.1 ``conditionals.base_conditional``.  Kmn (M, N), Kmm (M, M), Knn (N,) or (N, N), f (M, R),
+    q_sqrt None, (M, R) [diagonal] or (R, M, M) [lower triangular].  Returns fmean (N, R), fvar (N, R) or (R, N, N)."""
+    R = f.shape[1]
+    Lm = torch.linalg.cholesky(Kmm)                                           # rocSOLVER potrf
+    A = torch.linalg.solve_triangular(Lm, Kmn, upper=False)                   # trsm: Lm^-1 Kmn
+    if full_cov:
+        fvar = (Knn - A.T @ A).unsqueeze(0).repeat(R, 1, 1)
+    else:
+        fvar = (Knn - (A * A).sum(0)).unsqueeze(0).repeat(R, 1)
+    if not white:
+        A = torch.linalg.solve_triangular(Lm.T, A, upper=True)                # Lm^-T A
+    fmean = A.T @ f
+    if q_sqrt is not None:
+        if q_sqrt.dim() == 2:
+            LTA = A.unsqueeze(0) * q_sqrt.T.unsqueeze(2)                      # (R, M, N)
+        elif q_sqrt.dim() == 3:
+            LTA = torch.tril(q_sqrt).transpose(1, 2) @ A.unsqueeze(0)
+        else:
+            raise ValueError("Bad dimension for q_sqrt: %s" % str(q_sqrt.dim()))
+        fvar = fvar + (LTA.transpose(1, 2) @ LTA if full_cov else (LTA * LTA).sum(1))
+    if not full_cov:
+        fvar = fvar.T
+    return fmean, fvar
+
+
+def gauss_kl(q_mu, q_sqrt, K=None):
+    """GPflow 1.5.1 ``kullback_leiblers.gauss_kl``: KL[N(q_mu, q_sqrt q_sqrt^T) || N(0, K)] summed over the R latent
+    functions (K None: the prior is white).  q_mu (M, R); q_sqrt (M, R) diagonal or (R, M, M) lower triangular."""
+    white = K is None
+    diag = q_sqrt.dim() == 2
+    M, R = q_mu.shape
+    if white:
+        alpha = q_mu
+    else:
+        Lp = torch.linalg.cholesky(K)
+        alpha = torch.linalg.solve_triangular(Lp, q_mu, upper=False)
+    if diag:
+        Lq_diag = q_sqrt
+    else:
+        Lq = torch.tril(q_sqrt)
+        Lq_diag = torch.diagonal(Lq, dim1=1, dim2=2)
+    two_kl = (alpha * alpha).sum() - R * M - torch.log(Lq_diag * Lq_diag).sum()
+    if white:
+        two_kl = two_kl + ((q_sqrt * q_sqrt).sum() if diag else (Lq * Lq).sum())
+    else:
+        if diag:
+            Lp_inv = torch.linalg.solve_triangular(Lp, torch.eye(M, dtype=K.dtype, device=K.device), upper=False)
+            K_inv_diag = (Lp_inv * Lp_inv).sum(0)
+            two_kl = two_kl + (K_inv_diag.unsqueeze(1) * q_sqrt * q_sqrt).sum()
+        else:
+            LpiLq = torch.linalg.solve_triangular(Lp.unsqueeze(0).expand(R, M, M), Lq, upper=False)
+            two_kl = two_kl + (LpiLq * LpiLq).sum()
+        two_kl = two_kl + R * torch.log(torch.diagonal(Lp) ** 2).sum()
+    return 0.5 * two_kl
+
+
+class SVGP:
+    """Prediction half of ``gpsig.models.SVGP`` (gpsig/models.py:13-73): variational parameters + feature + kernel.
+
+    :kern:     a gpsig_amd.kernels.SignatureKernel
+    :feat:     InducingTensors or InducingSequences (models.py:19-20)
+    :q_mu:     (num_inducing, num_latent); :q_sqrt: (num_latent, M, M) lower-triangular or (M, num_latent) if q_diag
+    :whiten:   models.py:35 (default True)
+    """
+
+    def __init__(self, kern, feat, num_latent=1, q_diag=False, whiten=True, q_mu=None, q_sqrt=None, mean_function=None, device="cuda:0"):
+        if not isinstance(feat, (iv.InducingTensors, iv.InducingSequences)):
+            raise ValueError('feat must be of type either InducingTensors or InducingSequences')     # models.py:19-20
+        self.kern, self.feature, self.q_diag, self.whiten = kern, feat, q_diag, whiten
+        self.mean_function = mean_function
+        self.device = torch.device(device)
+        m = len(feat)
+        self.num_latent = num_latent if q_mu is None else np.asarray(q_mu).shape[1]
+        # GPflow's _init_variational_parameters: zero mean, identity square root
+        self.q_mu = np.zeros((m, self.num_latent)) if q_mu is None else q_mu
+        if q_sqrt is None:
+            q_sqrt = np.ones((m, self.num_latent)) if q_diag else np.tile(np.eye(m)[None], [self.num_latent, 1, 1])
+        self.q_sqrt = q_sqrt
+
+    def _covs(self, X_new, full_cov):
+        Kzz, Kzx, Kxx = iv.Kuu_Kuf_Kff(self.feature, self.kern, X_new, jitter=JITTER, full_f_cov=full_cov)   # models.py:65
+        return _dev(Kzz, self.device), _dev(Kzx, self.device), _dev(Kxx, self.device)
+
+    def predict_f(self, X_new, full_cov=False, return_Kzz=False):
+        """models.py:62-73.  Returns (f_mean (N, R), f_var (N, R) or (R, N, N)) as torch tensors on the device."""
+        Kzz, Kzx, Kxx = self._covs(X_new, full_cov)
+        q_mu, q_sqrt = _dev(self.q_mu, self.device), _dev(self.q_sqrt, self.device)
+        if not self.q_diag:
+            q_sqrt = torch.tril(q_sqrt)                                                             # models.py:66
+        f_mean, f_var = base_conditional(Kzx, Kzz, Kxx, q_mu, full_cov=full_cov, q_sqrt=q_sqrt, white=self.whiten)
+        if self.mean_function is not None:
+            f_mean = f_mean + _dev(self.mean_function(X_new), self.device)                           # models.py:67
+        return (f_mean, f_var, Kzz) if return_Kzz else (f_mean, f_var)
+
+    def prior_kl(self):
+        """The KL term of models.py:46-51."""
+        q_mu, q_sqrt = _dev(self.q_mu, self.device), _dev(self.q_sqrt, self.device)
+        if not self.q_diag:
+            q_sqrt = torch.tril(q_sqrt)
+        if self.whiten:
+            return gauss_kl(q_mu, q_sqrt)
+        Kzz = _dev(iv.Kuu(self.feature, self.kern, jitter=JITTER), self.device)
+        return gauss_kl(q_mu, q_sqrt, K=Kzz)

@@ -175,3 +175,30 @@ def test_fixture_notebook_cases_satisfy_signature_identity(golden):
     assert _relerr(arr["nb_K/out0"], sigs @ sigs.T) < 1e-12
     assert _relerr(arr["nb_Kzx/out0"], tens @ sigs.T) < 1e-12
     assert _relerr(arr["nb_Kzz/out0"], tens @ tens.T) < 1e-12
+
+
+def test_svgp_algebra_restatement_properties():
+    """oracle/svgp_oracle.py (GPflow 1.5.1 base_conditional / gauss_kl restated): closed-form sanity checks."""
+    from oracle import svgp_oracle as SO
+    rng = np.random.default_rng(8)
+    M_, N_, R = 6, 9, 2
+    A = rng.standard_normal((M_ + N_, M_ + N_ + 3))
+    Kfull = A @ A.T + 1e-3 * np.eye(M_ + N_)
+    Kmm, Kmn, Knn = Kfull[:M_, :M_], Kfull[:M_, M_:], Kfull[M_:, M_:]
+    Lm = np.linalg.cholesky(Kmm)
+    # KL of the prior against itself is zero, in both parametrisations
+    assert abs(SO.gauss_kl(np.zeros((M_, R)), np.tile(np.eye(M_)[None], [R, 1, 1]))) < 1e-12
+    assert abs(SO.gauss_kl(np.zeros((M_, R)), np.tile(Lm[None], [R, 1, 1]), K=Kmm)) < 1e-10
+    assert abs(SO.gauss_kl(np.zeros((M_, R)), np.ones((M_, R)))) < 1e-12
+    # q = prior (non-whitened: q_sqrt = chol Kmm) gives back the prior marginals
+    f = np.zeros((M_, R))
+    mean, var = SO.base_conditional(Kmn, Kmm, np.diag(Knn), f, q_sqrt=np.tile(Lm[None], [R, 1, 1]), white=False)
+    np.testing.assert_allclose(mean, 0, atol=1e-12)
+    np.testing.assert_allclose(var, np.tile(np.diag(Knn)[:, None], [1, R]), rtol=1e-9)
+    mean, var = SO.base_conditional(Kmn, Kmm, Knn, f, full_cov=True, q_sqrt=np.tile(np.eye(M_)[None], [R, 1, 1]), white=True)
+    np.testing.assert_allclose(var[0], Knn, rtol=1e-8, atol=1e-10)
+    # exact GP posterior mean with a delta posterior at u = Kmm alpha
+    u = rng.standard_normal((M_, R))
+    mean, var = SO.base_conditional(Kmn, Kmm, np.diag(Knn), u, q_sqrt=None, white=False)
+    np.testing.assert_allclose(mean, Kmn.T @ np.linalg.solve(Kmm, u), rtol=1e-8)
+    np.testing.assert_allclose(var[:, 0], np.diag(Knn - Kmn.T @ np.linalg.solve(Kmm, Kmn)), rtol=1e-7, atol=1e-9)
