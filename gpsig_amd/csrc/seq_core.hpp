@@ -19,7 +19,7 @@
 // (record rows C*lam .. C*lam+C-1 of the y side).  Row prefixes cross lanes through a carry that is
 // handed to the next lane ONE STEP LATER (lane lam works on lattice row t-lam at step t), so no
 // log-step scan is needed: each step a lane reads its left neighbour's end-of-chunk row prefix
-// (`cin`) and its left neighbour's last-column Q from before that neighbour's latest update (`din`).
+// (`cin`); the neighbour's last-column Q it also needs is tracked locally as a ghost column (SeqLane::qg).
 #pragma once
 
 #include <cmath>
@@ -121,7 +121,9 @@ struct SeqLane {
     static constexpr int NQ = MMAX > 1 ? MMAX - 1 : 1;
     T y[C][D];      // y-side record rows owned by this lane (increments, or points)
     T q[NQ][C];     // Q_m for levels m = 1 .. M-1 (index m-1), current as of the last processed row
-    T qold[NQ];     // Q_m[.., last column of the chunk] from BEFORE the last processed row
+    T qg[NQ];       // ghost column: Q_m of the LEFT neighbour's last column, as of the last processed row.  It is advanced
+                    // with the carry received from that neighbour (qg += cin), which is bit for bit the neighbour's own update,
+                    // so the diagonal term Q_{m-1}[a-1][b-1] of a lane's first column costs one add instead of a hand-over
     T s[MMAX];      // end-of-chunk row prefix of R_m for the last processed row (the carry handed right)
     T ktop;         // running K_M (only the row totals of the top level are needed)
     // point modes only
@@ -130,20 +132,20 @@ struct SeqLane {
     T kleft;        // kappa(previous x point, last column of the left neighbour)
     static constexpr bool HIGHER_ORDER = false;
 
-    // Pair boundary.  Only the accumulators are cleared: s[] and qold[] are hand-over words that the RIGHT
-    // neighbour still has to read during this very step (it is one lattice row behind), and both are
-    // rewritten by this lane's own step before anyone reads them again.
+    // Pair boundary.  Only the accumulators are cleared: s[] holds the hand-over words that the RIGHT neighbour
+    // still has to read during this very step (it is one lattice row behind); they are rewritten by this lane's
+    // own step before anyone reads them again.
     GPSIG_HD void reset() {
 #pragma unroll
-        for (int m = 0; m < NQ; ++m)
+        for (int m = 0; m < NQ; ++m) {
 #pragma unroll
             for (int r = 0; r < C; ++r) q[m][r] = T(0);
+            qg[m] = T(0);
+        }
         ktop = T(0);
     }
     GPSIG_HD void init() {
         reset();
-#pragma unroll
-        for (int m = 0; m < NQ; ++m) qold[m] = T(0);
 #pragma unroll
         for (int m = 0; m < MMAX; ++m) s[m] = T(0);
 #pragma unroll
@@ -163,22 +165,19 @@ struct SeqLane {
 // Cross-lane inputs are fetched through a policy object `Nbr` with three members, each returning the
 // LEFT neighbour's copy of one of this lane's own state words as of the end of the previous step:
 //     T cin(int m)      left neighbour's s[m]
-//     T din(int m)      left neighbour's qold[m]
 //     T kleft()         left neighbour's kprev[C-1]      (MODE_PT_DIFF)
 //     T win(int m, int r)  left neighbour's w[m][r]      (higher-order lanes)
 // (zero for the first lane of a pair group).  On the GPU they are DPP row/wave shifts issued right
-// where the value is consumed -- legal because s[m] / qold[m] / kprev are only overwritten later in
+// where the value is consumed -- legal because s[m] / kprev are only overwritten later in
 // the same step -- which keeps the 2M+1 shifted words out of the live register set.  The CPU
 // emulator serves them from a snapshot (NbrSnapshot) taken before any lane of the wave has stepped.
 template <typename T, int MMAX>
 struct NbrSnapshot {
     static constexpr int NQ = MMAX > 1 ? MMAX - 1 : 1;
     T s[MMAX];
-    T qold[NQ];
     T klast;
     T w[NQ][8];    // higher-order lanes only
     GPSIG_HD T cin(int m) const { return s[m]; }
-    GPSIG_HD T din(int m) const { return qold[m]; }
     GPSIG_HD T kleft() const { return klast; }
     GPSIG_HD T win(int m, int r) const { return w[m][r]; }
 };
@@ -187,29 +186,29 @@ namespace detail {
 template <int MI, typename T, int C, int D, int MMAX, int MODE, class Nbr>
 GPSIG_HD void seq_level(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&dm)[C], int M) {
     if (MI < M) {                       // wave-uniform (compile-time when M is)
-        T sm = nbr.cin(MI);
+        const T cin = nbr.cin(MI);      // left neighbour's end-of-chunk row prefix of R_m for this lattice row
+        T sm = cin;
         if (MI == M - 1) {              // top level: accumulate the row total only
             if constexpr (MI == 0) {
 #pragma unroll
                 for (int r = 0; r < C; ++r) sm += dm[r];
             } else {
-                sm = fma(dm[0], nbr.din(MI - 1), sm);
+                sm = fma(dm[0], L.qg[MI - 1], sm);
 #pragma unroll
                 for (int r = 1; r < C; ++r) sm = fma(dm[r], L.q[MI - 1][r - 1], sm);
             }
             L.ktop += sm;
         } else if constexpr (MI < MMAX - 1) {
-            const T last = L.q[MI][C - 1];
             if constexpr (MI == 0) {
 #pragma unroll
                 for (int r = 0; r < C; ++r) { sm += dm[r]; L.q[0][r] += sm; }
             } else {
-                sm = fma(dm[0], nbr.din(MI - 1), sm);
+                sm = fma(dm[0], L.qg[MI - 1], sm);
                 L.q[MI][0] += sm;
 #pragma unroll
                 for (int r = 1; r < C; ++r) { sm = fma(dm[r], L.q[MI - 1][r - 1], sm); L.q[MI][r] += sm; }
             }
-            L.qold[MI] = last;
+            L.qg[MI] += cin;            // the ghost column moves past this row (read by level MI+2 ... already done: descending order)
         }
         L.s[MI] = sm;
     }
@@ -242,7 +241,7 @@ GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T 
 //     K_m = sum_{a,b} sum_{r,s} R_m[r][s]                                           (:71)
 // In the row sweep that becomes, per level m < M and per owned column:  QT_m (inclusive 2-D prefix of the grid
 // total, as in the first-order case), PC_{m,s} (column prefix, i.e. running sum over rows, of sum_r R_m[r][s]),
-// and per row the running row prefixes of sum_s R_m[r][s], whose chunk-end values `w` join `s` and `qold` as
+// and per row the running row prefixes of sum_s R_m[r][s], whose chunk-end values `w` join `s` as
 // hand-over words to the right neighbour.  Levels are processed in ascending order inside a step because level m
 // needs level m-1's values of the SAME lattice row; level m-1's prefixes are advanced past the row only after
 // level m has read their previous-row values.
@@ -253,7 +252,7 @@ struct SeqLaneHO {
     static constexpr bool HIGHER_ORDER = true;
     T y[C][D];
     T q[NQ][C];        // QT_m
-    T qold[NQ];        // QT_m[last owned column] before the last processed row    (hand-over)
+    T qg[NQ];          // ghost column of QT_m (see SeqLane::qg)
     T s[MMAX];         // chunk-end row prefix of the level total                   (hand-over)
     T pc[NQ][NO][C];   // PC_{m,s}
     T w[NQ][NO];       // chunk-end row prefix of sum_s R_m[r][s] for r < order-1   (hand-over)
@@ -269,13 +268,14 @@ struct SeqLaneHO {
 #pragma unroll
                 for (int o = 0; o < NO; ++o) pc[m][o][r] = T(0);
             }
+#pragma unroll
+        for (int m = 0; m < NQ; ++m) qg[m] = T(0);
         ktop = T(0);
     }
     GPSIG_HD void init() {
         reset();
 #pragma unroll
         for (int m = 0; m < NQ; ++m) {
-            qold[m] = T(0);
 #pragma unroll
             for (int o = 0; o < NO; ++o) w[m][o] = T(0);
         }
@@ -327,7 +327,7 @@ GPSIG_HD void seq_ho_level(SeqLaneHO<T, C, D, MMAX, OMAX, MODE>& L, const Nbr& n
             for (int r = 0; r < DC - 1; ++r) wrun[r] = (r < dcur - 1) ? nbr.win(MI, r) : T(0);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const T qd = (c == 0) ? nbr.din(MI) : L.q[MI][c == 0 ? 0 : c - 1];
+                const T qd = (c == 0) ? L.qg[MI] : L.q[MI][c == 0 ? 0 : c - 1];
                 Rc[0][0][c] = dm[c] * qd;                                                             // :64
 #pragma unroll
                 for (int sx = 1; sx < DC; ++sx)
@@ -346,8 +346,9 @@ GPSIG_HD void seq_ho_level(SeqLaneHO<T, C, D, MMAX, OMAX, MODE>& L, const Nbr& n
                     if (r < dcur - 1) wrun[r] += rs[r][c];
             }
             // level LV-1's prefixes move past this lattice row now that their previous-row values have been used
-            T srun = nbr.cin(MI);
-            const T last = L.q[MI][C - 1];
+            const T cin = nbr.cin(MI);
+            T srun = cin;
+            L.qg[MI] += cin;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 srun += tot[c];
@@ -356,7 +357,6 @@ GPSIG_HD void seq_ho_level(SeqLaneHO<T, C, D, MMAX, OMAX, MODE>& L, const Nbr& n
                 for (int sx = 0; sx < DC - 1; ++sx)
                     if (sx < dcur - 1) L.pc[MI][sx][c] += cs[sx][c];
             }
-            L.qold[MI] = last;
             L.s[MI] = srun;
 #pragma unroll
             for (int r = 0; r < DC - 1; ++r)
@@ -449,28 +449,33 @@ GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T 
     seq_recursion(L, nbr, dm, M);
 }
 
-// Per-lane position in the stream of x-side record rows.  Lane `lam` of a group starts `lam` steps late; all
-// counters simply run from -lam so that the lane's first real step is the one where they reach zero.  The ring
-// offset is advanced incrementally (no multiplies in the step loop).
+// Per-lane position in the stream of x-side record rows, event driven: between events a step costs one add on the
+// row offset and one decrement.  Events (each `period` = R1 steps apart once the lane has started): the lane's start,
+// every pair boundary (row 0 of the next x: the pair that just ended is emitted, accumulators are cleared), and the
+// flush step after the last x, after which the lane idles on the zero row.  Offsets are in elements from the start of
+// the LDS block: [zero row: RS elements][ring: nslot slots of slot_elems].
 struct LaneCtl {
-    int n;      // steps since this lane became active (negative: not yet)
-    int a;      // record row within the current x (0 .. R1-1); negative before the lane's first step
-    int p;      // index of the current x within the task (== nx on the flush step)
-    int off;    // element offset of the current row inside the LDS ring
-    int sbase;  // element offset of the current x's ring slot
-    GPSIG_HD void init(int lam, int RS) { n = -lam; a = -lam; p = 0; off = -lam * RS; sbase = 0; }
-    GPSIG_HD bool active(int total_rows) const { return unsigned(n) < unsigned(total_rows); }   // total_rows = nx * R1
-    // the step at which the lane sits on row 0 of x number p >= 1 (or on the flush step) emits pair p-1
-    GPSIG_HD bool boundary() const { return a == 0; }
-    GPSIG_HD void advance(int R1, int RS, int slot_elems, int ring_elems) {
-        ++n; ++a; off += RS;
-        if (a == R1) {
-            a = 0; ++p;
-            sbase += slot_elems;
-            if (sbase == ring_elems) sbase = 0;
-            off = sbase;
-        }
+    int left;     // steps until the next event (0: the event is due at this step)
+    int rowoff;   // element offset of this step's record row
+    int stride;   // RS while sweeping an x, 0 while idle
+    int p;        // index of the current x within the task; == nx from the flush step on
+    int sbase;    // element offset of the current x's ring slot
+    bool row0;    // this step is row 0 of an x / the flush step (pair boundary) -- or the lane is idle
+
+    GPSIG_HD void init(int lam, int RS) { left = lam; rowoff = 0; stride = 0; p = -1; sbase = RS; row0 = true; }
+    // Call at the start of every step.  Returns true on a pair boundary (p >= 1 then names the pair p-1 that ended).
+    GPSIG_HD bool begin_step(int nx, int R1, int RS, int slot_elems, int ring_elems) {
+        row0 = (stride == 0);
+        if (left != 0) return false;
+        ++p;
+        if (p > nx) { left = 0x3fffffff; return false; }          // idle for good
+        if (p >= 1) { sbase += slot_elems; if (sbase == RS + ring_elems) sbase = RS; }
+        row0 = true;
+        if (p < nx) { rowoff = sbase; stride = RS; left = R1; }    // row 0 of x number p
+        else { rowoff = 0; stride = 0; left = 1; }                 // flush step: zero row; one more event retires the lane
+        return true;
     }
+    GPSIG_HD void end_step() { rowoff += stride; --left; }
 };
 
 }  // namespace gpsig

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
     typedef T vecT __attribute__((ext_vector_type(VEC)));
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* const zero_row = reinterpret_cast<T*>(smem_raw);   // RS elements of zeros (rows of inactive lanes)
+    T* const zero_row = reinterpret_cast<T*>(smem_raw);   // RS elements of zeros (rows of idle lanes); LaneCtl offsets start here
     T* const ring = zero_row + A.RS;                       // nslot slots of slot_elems
 
     const int lane = threadIdx.x;
@@ -109,14 +109,13 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
 
     LaneCtl ctl;
     ctl.init(lam, RS);
-    const int total_rows = nx * R1, ring_elems = nslot * A.slot_elems;
+    const int ring_elems = nslot * A.slot_elems;
     const T p0 = T(A.p0), p1 = T(A.p1);
 
     // left-neighbour reads: one DPP shift per 32-bit half, issued where the value is consumed
     struct DevNbr {
         const Lane& L;
         __device__ __forceinline__ T cin(int m) const { return shr1<G>(L.s[m]); }
-        __device__ __forceinline__ T din(int m) const { return shr1<G>(L.qold[m]); }
         __device__ __forceinline__ T kleft() const { return shr1<G>(L.kprev[C - 1]); }
         __device__ __forceinline__ T win(int m, int r) const {
             if constexpr (Lane::HIGHER_ORDER) return shr1<G>(L.w[m][r]); else return T(0);
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
     // x-side record row of a lane for the step described by `cc` (16-byte LDS reads; rows are RS = D + pad apart,
     // so the 16 lanes of a pair group hit 16 different bank groups)
     auto load_row = [&](const LaneCtl& cc, T (&dst)[D]) {
-        const T* rowp = cc.active(total_rows) ? ring + cc.off : zero_row;
+        const T* rowp = zero_row + cc.rowoff;
 #pragma unroll
         for (int f = 0; f < D; f += VEC) {
             vecT v = *reinterpret_cast<const vecT*>(rowp + f);
@@ -139,16 +138,9 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
             for (int e = 0; e < VEC; ++e) dst[f + e] = v[e];
         }
     };
-    // Requesting the next step's row before this step's arithmetic costs 2*D more live registers; on gfx950 the
-    // flagship shape then drops from 3 to 2 waves per SIMD and runs 7 % slower (profiles/r01_ab_variants.txt),
-    // so it is off by default.
-#ifndef GPSIG_PREFETCH_ROWS
-#define GPSIG_PREFETCH_ROWS 0
-#endif
-    constexpr bool PF = GPSIG_PREFETCH_ROWS != 0;
+    // (Requesting the next step's row one step ahead was tried: 2*D more live registers cost the flagship shape a wave
+    // per SIMD and 7 % of its speed -- profiles/r01_ab_variants.txt.)
     if (A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    T xr_next[D];
-    if (PF) load_row(ctl, xr_next);
 
     auto one_step = [&]() {
         if (a_u == A.issue_at && k_u + 1 < nx) {
@@ -158,8 +150,8 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
         if (++a_u == R1) { a_u = 0; ++k_u; }
 
         // pair boundary: the pair that just finished is complete in the last lane of the group
-        if (ctl.boundary()) {
-            if (lam == G - 1 && ctl.p >= 1 && ctl.p <= nx && jvalid) {
+        if (ctl.begin_step(nx, R1, RS, A.slot_elems, ring_elems)) {
+            if (lam == G - 1 && ctl.p >= 1 && jvalid) {
                 int64_t i = int64_t(tk.x0) + (ctl.p - 1);
                 if (i >= A.N1) i -= A.N1;
                 T* const out = static_cast<T*>(A.out);
@@ -169,21 +161,14 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
         }
 
         T xr[D];
-        if (PF) {
-#pragma unroll
-            for (int f = 0; f < D; ++f) xr[f] = xr_next[f];
-        } else {
-            load_row(ctl, xr);
-        }
-        const bool dummy = !ctl.active(total_rows) || ctl.a == 0;
+        load_row(ctl, xr);
+        const bool dummy = ctl.row0;
 
-        // software pipeline: the row for the NEXT step is requested from LDS before this step's arithmetic.
-        // If lane 0 opens a new x at the next step, its record (requested issue_at steps into this x) must have landed.
-        ctl.advance(R1, RS, A.slot_elems, ring_elems);
+        // if lane 0 opens a new x at the next step, its record (requested issue_at steps into this x) must have landed
         if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (PF) load_row(ctl, xr_next);
 
         seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, A.kind, p0, p1);
+        ctl.end_step();
     };
     // two steps per trip: the loop-carried hand-over words (s, qold) alternate registers instead of being copied
     // back every step.  An odd step count is rounded up; the extra step finds every lane past its last pair.

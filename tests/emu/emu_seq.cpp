@@ -23,8 +23,10 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
     const int R1 = A.R1, RS = A.RS, nslot = A.nslot, nx = tk.nx;
     const T* xrec = static_cast<const T*>(A.xrec);
     const T* yrec = static_cast<const T*>(A.yrec);
-    std::vector<T> zero_row(RS, T(0));
-    std::vector<T> ring(size_t(nslot) * A.slot_elems, T(0) / T(0));   // NaN-poisoned: stale reads must not matter
+    // [zero row][ring]; the ring is NaN-poisoned: reads of slots that were never filled must not matter
+    std::vector<T> lds(size_t(RS) + size_t(nslot) * A.slot_elems, T(0) / T(0));
+    for (int k = 0; k < RS; ++k) lds[k] = T(0);
+    T* const ring_base = lds.data() + RS;
     Lane L[64];
     LaneCtl ctl[64];
     int64_t jj[64]; bool jvalid[64]; int rlo[64], rhi[64];
@@ -52,11 +54,11 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
     auto stage = [&](int p, int slot) {
         int64_t i = int64_t(tk.x0) + p;
         if (i >= A.N1) i -= A.N1;
-        std::memcpy(ring.data() + size_t(slot) * A.slot_elems, xrec + i * A.xrec_stride, sizeof(T) * A.slot_elems);
+        std::memcpy(ring_base + size_t(slot) * A.slot_elems, xrec + i * A.xrec_stride, sizeof(T) * A.slot_elems);
     };
     stage(0, 0);
     const int nsteps = nx * R1 + G;
-    const int total_rows = nx * R1, ring_elems = nslot * A.slot_elems;
+    const int ring_elems = nslot * A.slot_elems;
     int a_u = 0, k_u = 0, slot_next = 1 % nslot;
     T* out = static_cast<T*>(A.out);
     for (int t = 0; t < nsteps; ++t) {
@@ -68,8 +70,8 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
         // therefore has to be taken AFTER the boundary blocks of all lanes.
         for (int lane = 0; lane < 64; ++lane) {
             const int lam = lane & (G - 1);
-            if (ctl[lane].boundary()) {
-                if (lam == G - 1 && ctl[lane].p >= 1 && ctl[lane].p <= nx && jvalid[lane]) {
+            if (ctl[lane].begin_step(nx, R1, RS, A.slot_elems, ring_elems)) {
+                if (lam == G - 1 && ctl[lane].p >= 1 && jvalid[lane]) {
                     int64_t i = int64_t(tk.x0) + (ctl[lane].p - 1);
                     if (i >= A.N1) i -= A.N1;
                     seq_emit<T>(L[lane], A, i, jj[lane], M, [&](int64_t off, T v) { out[off] = v; });
@@ -82,7 +84,6 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
             const int lam = lane & (G - 1);
             NbrSnapshot<T, MMAX>& S = snap[lane];
             for (int m = 0; m < MMAX; ++m) S.s[m] = lam ? L[lane - 1].s[m] : T(0);
-            for (int m = 0; m < NbrSnapshot<T, MMAX>::NQ; ++m) S.qold[m] = lam ? L[lane - 1].qold[m] : T(0);
             S.klast = lam ? L[lane - 1].kprev[C - 1] : T(0);
             if constexpr (Lane::HIGHER_ORDER) {
                 for (int m = 0; m < Lane::NQ; ++m)
@@ -90,13 +91,12 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
             }
         }
         for (int lane = 0; lane < 64; ++lane) {
-            const bool act = ctl[lane].active(total_rows);
-            const T* rowp = act ? ring.data() + ctl[lane].off : zero_row.data();
+            const T* rowp = lds.data() + ctl[lane].rowoff;
             T xr[D];
             for (int f = 0; f < D; ++f) xr[f] = rowp[f];
-            const bool dummy = !act || ctl[lane].a == 0;
+            const bool dummy = ctl[lane].row0;
             seq_step(L[lane], snap[lane], xr, M, A.order, dummy, rlo[lane], rhi[lane], A.kind, T(A.p0), T(A.p1));
-            ctl[lane].advance(R1, RS, A.slot_elems, ring_elems);
+            ctl[lane].end_step();
         }
     }
 }
