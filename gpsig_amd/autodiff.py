@@ -1,0 +1,430 @@
+"""Differentiable signature kernels: the training-time counterpart of ``gpsig_amd.kernels``.
+
+The reference is trained by TensorFlow's autodiff straight through ``SignatureKernel.K*`` (gpsig/training.py:149-164,
+gpsig/models.py:40-59).  Here the same role is split in two:
+
+* the heavy part -- the level recursions ``_K_seq``, ``_K_seq_diag``, ``_K_tens``, ``_K_tens_vs_seq`` (gpsig/kernels.py:188-340)
+  and their reverse-mode derivatives -- runs in the HIP library (forward: the fused kernels of ``gpsig_*_levels``; backward:
+  ``gpsig_*_levels_grad``), wrapped as ``torch.autograd.Function``s;
+* the light, elementwise part -- lengthscale / lag scaling (kernels.py:343-398), level normalisation, ``sigma * variances``
+  and the level sum (kernels.py:401-671) -- is written with torch ops on the GPU so that autograd chains it.
+
+``SignatureKernelModule`` holds the hyper-parameters as unconstrained ``torch.nn.Parameter``s with GPflow 1.5.1's transforms
+(``transforms.positive`` = softplus + 1e-6 for variances, sigma, lengthscales, gamma, the base-kernel parameter;
+``transforms.Logistic`` for lags; kernels.py:65-88) so that an optimiser step means what it means in the reference.
+First-order algorithm (order = 1), float64, exact (non low-rank) mode.  No CPU fallback: tensors must live on the GPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .kernels import JITTER, SignatureKernel
+
+_POS_LOWER = 1e-6   # gpflow.transforms.positive = Log1pe(lower=1e-6)
+
+
+def positive(raw):
+    """gpflow.transforms.Log1pe.forward: softplus(x) + 1e-6."""
+    return torch.nn.functional.softplus(raw) + _POS_LOWER
+
+
+def positive_inverse(value):
+    """gpflow.transforms.Log1pe.backward."""
+    y = np.asarray(value, dtype=np.float64) - _POS_LOWER
+    return np.where(y > 35.0, y, np.log(np.expm1(np.maximum(y, 1e-300))))
+
+
+def logistic_inverse(value):
+    v = np.asarray(value, dtype=np.float64)
+    return np.log(v) - np.log1p(-v)
+
+
+class _Spec:
+    """What a level primitive needs besides its tensors."""
+
+    def __init__(self, base, num_levels, difference, p1=0.0):
+        self.base, self.num_levels, self.difference, self.p1 = base, int(num_levels), bool(difference), float(p1)
+
+    def params(self, d_cols, p0, keep):
+        p = _lib.Params()
+        p.base_kernel = _lib.BASE[self.base]
+        p.dtype = _lib.F64
+        p.num_features, p.num_levels, p.order = int(d_cols), self.num_levels, 1
+        p.difference, p.normalization, p.num_lags = int(self.difference), 0, 0
+        p.sigma, p.jitter = 1.0, JITTER
+        p.base_params[0], p.base_params[1] = float(p0), self.p1
+        ones = np.ones(self.num_levels + 1)
+        keep.append(ones)
+        p.variances = ones.ctypes.data_as(C.POINTER(C.c_double))
+        p.lengthscales = None
+        return p
+
+
+def _ctx_for(t):
+    if not t.is_cuda:
+        raise RuntimeError("gpsig_amd.autodiff needs CUDA (ROCm) tensors: there is no CPU path")
+    ctx = _lib.context(t.device.index or 0, torch.cuda.current_stream(t.device).cuda_stream)
+    ctx.set_pointer_mode(_lib.PTR_DEVICE)
+    return ctx
+
+
+def _c(t):
+    return t.detach().to(torch.float64).contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _p0_value(p0):
+    return float(p0.detach().cpu()) if p0 is not None else 0.0
+
+
+class _SeqGramLevels(torch.autograd.Function):
+    """_K_seq (kernels.py:208-237): scaled sequences (N1, L1, d) [, (N2, L2, d)] -> (M+1, N1, N2)."""
+
+    @staticmethod
+    def forward(ctx, Xs, X2s, p0, spec):
+        X, X2 = _c(Xs), (None if X2s is None else _c(X2s))
+        n1, l1, d = X.shape
+        n2, l2 = (n1, l1) if X2 is None else X2.shape[:2]
+        keep = []
+        p = spec.params(d, _p0_value(p0), keep)
+        out = torch.empty((spec.num_levels + 1, n1, n2), dtype=torch.float64, device=X.device)
+        _ctx_for(X).call("gpsig_seq_gram_levels", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(out))
+        ctx.spec, ctx.has_x2, ctx.has_p0 = spec, X2 is not None, p0 is not None
+        ctx.save_for_backward(X, X2 if X2 is not None else X.new_empty(0), p0 if p0 is not None else X.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        X, X2, p0 = ctx.saved_tensors
+        X2 = X2 if ctx.has_x2 else None
+        n1, l1, d = X.shape
+        n2, l2 = (n1, l1) if X2 is None else X2.shape[:2]
+        keep = []
+        p = ctx.spec.params(d, _p0_value(p0) if ctx.has_p0 else 0.0, keep)
+        G = _c(G)
+        gX = torch.empty_like(X)
+        gX2 = None if X2 is None else torch.empty_like(X2)
+        gb = torch.zeros(2, dtype=torch.float64, device=X.device)
+        _ctx_for(X).call("gpsig_seq_gram_levels_grad", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(G), _ptr(gX),
+                         None if gX2 is None else _ptr(gX2), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
+        gp0 = gb[0].to(p0.device).reshape(p0.shape) if ctx.has_p0 else None
+        return gX, gX2, gp0, None
+
+
+class _SeqDiagLevels(torch.autograd.Function):
+    """_K_seq_diag (kernels.py:188-205): (N, L, d) -> (M+1, N)."""
+
+    @staticmethod
+    def forward(ctx, Xs, p0, spec):
+        X = _c(Xs)
+        n, l, d = X.shape
+        keep = []
+        p = spec.params(d, _p0_value(p0), keep)
+        out = torch.empty((spec.num_levels + 1, n), dtype=torch.float64, device=X.device)
+        _ctx_for(X).call("gpsig_seq_diag_levels", p, _ptr(X), n, l, _ptr(out))
+        ctx.spec, ctx.has_p0 = spec, p0 is not None
+        ctx.save_for_backward(X, p0 if p0 is not None else X.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        X, p0 = ctx.saved_tensors
+        n, l, d = X.shape
+        keep = []
+        p = ctx.spec.params(d, _p0_value(p0) if ctx.has_p0 else 0.0, keep)
+        G = _c(G)
+        gX = torch.empty_like(X)
+        gb = torch.zeros(2, dtype=torch.float64, device=X.device)
+        _ctx_for(X).call("gpsig_seq_diag_levels_grad", p, _ptr(X), n, l, _ptr(G), _ptr(gX), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
+        gp0 = gb[0].to(p0.device).reshape(p0.shape) if ctx.has_p0 else None
+        return gX, gp0, None
+
+
+class _TensGramLevels(torch.autograd.Function):
+    """_K_tens (kernels.py:263-283): scaled inducing tensors (lt, T, [2,] d) -> (M+1, T, T)."""
+
+    @staticmethod
+    def forward(ctx, Zs, p0, spec, increments):
+        Z = _c(Zs)
+        t, d = Z.shape[1], Z.shape[-1]
+        keep = []
+        p = spec.params(d, _p0_value(p0), keep)
+        out = torch.empty((spec.num_levels + 1, t, t), dtype=torch.float64, device=Z.device)
+        _ctx_for(Z).call("gpsig_tens_gram_levels", p, _ptr(Z), t, int(bool(increments)), _ptr(out))
+        ctx.spec, ctx.has_p0, ctx.increments = spec, p0 is not None, bool(increments)
+        ctx.save_for_backward(Z, p0 if p0 is not None else Z.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        Z, p0 = ctx.saved_tensors
+        t, d = Z.shape[1], Z.shape[-1]
+        keep = []
+        p = ctx.spec.params(d, _p0_value(p0) if ctx.has_p0 else 0.0, keep)
+        G = _c(G)
+        gZ = torch.empty_like(Z)
+        gb = torch.zeros(2, dtype=torch.float64, device=Z.device)
+        _ctx_for(Z).call("gpsig_tens_gram_levels_grad", p, _ptr(Z), t, int(ctx.increments), _ptr(G), _ptr(gZ),
+                         C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
+        gp0 = gb[0].to(p0.device).reshape(p0.shape) if ctx.has_p0 else None
+        return gZ, gp0, None, None
+
+
+class _TensVsSeqLevels(torch.autograd.Function):
+    """_K_tens_vs_seq (kernels.py:313-340): (lt, T, [2,] d), (N, L, d) -> (M+1, T, N)."""
+
+    @staticmethod
+    def forward(ctx, Zs, Xs, p0, spec, increments):
+        Z, X = _c(Zs), _c(Xs)
+        t, d = Z.shape[1], Z.shape[-1]
+        n, l = X.shape[:2]
+        keep = []
+        p = spec.params(d, _p0_value(p0), keep)
+        out = torch.empty((spec.num_levels + 1, t, n), dtype=torch.float64, device=Z.device)
+        _ctx_for(Z).call("gpsig_tens_vs_seq_levels", p, _ptr(Z), _ptr(X), t, n, l, int(bool(increments)), _ptr(out))
+        ctx.spec, ctx.has_p0, ctx.increments = spec, p0 is not None, bool(increments)
+        ctx.save_for_backward(Z, X, p0 if p0 is not None else Z.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        Z, X, p0 = ctx.saved_tensors
+        t, d = Z.shape[1], Z.shape[-1]
+        n, l = X.shape[:2]
+        keep = []
+        p = ctx.spec.params(d, _p0_value(p0) if ctx.has_p0 else 0.0, keep)
+        G = _c(G)
+        gZ, gX = torch.empty_like(Z), torch.empty_like(X)
+        gb = torch.zeros(2, dtype=torch.float64, device=Z.device)
+        _ctx_for(Z).call("gpsig_tens_vs_seq_levels_grad", p, _ptr(Z), _ptr(X), t, n, l, int(ctx.increments), _ptr(G), _ptr(gZ), _ptr(gX),
+                         C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
+        gp0 = gb[0].to(p0.device).reshape(p0.shape) if ctx.has_p0 else None
+        return gZ, gX, gp0, None, None
+
+
+# ---- scaling (gpsig/kernels.py:343-398, gpsig/lags.py) in torch ------------------------------------------------------
+def _lin_interp(time, X, time_query):
+    """gpsig/lags.py:7-38 (3-D branch :32-33).  X (N, L, d), time (L,), time_query (L, p) -> (N, L, p, d)."""
+    dist = time[:, None, None] - time_query[None, :, :]                                             # :20
+    masked = torch.where(dist > JITTER, torch.full_like(dist, -math.inf), dist)                     # :22
+    left = torch.argmax(masked, dim=0)
+    right = torch.clamp(left + 1, max=X.shape[1] - 1)                                               # :23
+    Xl, Xr = X[:, left, :], X[:, right, :]                                                          # :25-26
+    tl, tr = time[left], time[right]                                                                # :28-29
+    return Xl + (time_query[None, ..., None] - tl[None, ..., None]) * (Xr - Xl) / (tr[None, ..., None] - tl[None, ..., None])  # :33
+
+
+def _add_lags(X, lags):
+    """gpsig/lags.py:41-63.  (N, L, d) -> (N, L, p+1, d)."""
+    L = X.shape[1]
+    time = torch.arange(L, dtype=X.dtype, device=X.device) / (L - 1)                                # :56
+    time_lags = torch.clamp(time[:, None] - lags[None, :], min=0.)                                  # :57
+    return torch.cat((X[:, :, None, :], _lin_interp(time, X, time_lags)), dim=2)                    # :59-61
+
+
+class SignatureKernelModule(torch.nn.Module):
+    """Trainable view of a ``gpsig_amd.kernels.SignatureKernel`` (order 1, exact mode).
+
+    ``kern`` supplies the structure (base kernel, levels, normalisation, lags, ...) and the initial hyper-parameter values;
+    ``write_back()`` copies the trained values into it so that the fused inference path (``kern.K`` etc.) uses them."""
+
+    def __init__(self, kern: SignatureKernel, device="cuda"):
+        super().__init__()
+        if kern._base is None:
+            raise NotImplementedError("SignatureKernel is abstract: use SignatureLinear, SignatureRBF, ...")
+        if kern.order != 1 and kern.num_levels > 1:
+            raise NotImplementedError("gradients are built for the first-order algorithm (order=1) only")
+        if kern.low_rank:
+            raise NotImplementedError("gradients are built for the exact (non low-rank) mode only")
+        self.kern = kern
+        dev = torch.device(device)
+        par = lambda v: torch.nn.Parameter(torch.as_tensor(np.asarray(v, dtype=np.float64), device=dev))
+        self.raw_variances = par(positive_inverse(kern.variances))
+        self.raw_sigma = par(positive_inverse(kern.sigma))
+        self.raw_lengthscales = par(positive_inverse(kern.lengthscales)) if kern.lengthscales is not None else None
+        if kern.num_lags > 0:
+            self.raw_lags = par(logistic_inverse(kern.lags))
+            self.raw_gamma = par(positive_inverse(kern.gamma))
+        bp = kern._current_base_params()
+        self._has_p0 = kern._base in ("poly", "mix")
+        self.raw_p0 = par(positive_inverse(bp[0])) if self._has_p0 else None
+        self._spec = _Spec(kern._base, kern.num_levels, kern.difference, p1=float(bp[1]) if len(bp) > 1 else 0.0)
+
+    # constrained values
+    @property
+    def variances(self): return positive(self.raw_variances)
+    @property
+    def sigma(self): return positive(self.raw_sigma)
+    @property
+    def lengthscales(self): return None if self.raw_lengthscales is None else positive(self.raw_lengthscales)
+    @property
+    def lags(self): return torch.sigmoid(self.raw_lags)
+    @property
+    def gamma(self): return positive(self.raw_gamma)
+    @property
+    def p0(self): return positive(self.raw_p0) if self._has_p0 else None
+
+    def write_back(self):
+        k = self.kern
+        k.variances = self.variances.detach().cpu().numpy()
+        k.sigma = float(self.sigma.detach().cpu())
+        if self.raw_lengthscales is not None:
+            k.lengthscales = self.lengthscales.detach().cpu().numpy()
+        if k.num_lags > 0:
+            k.lags, k.gamma = self.lags.detach().cpu().numpy(), self.gamma.detach().cpu().numpy()
+        if self._has_p0:
+            k._set_base_p0(float(self.p0.detach().cpu()))
+        return k
+
+    # ---- scaling -------------------------------------------------------------------------------------------------
+    def _seq3(self, X):
+        X, _ = self.kern._slice(X, None)
+        return X.reshape(X.shape[0], -1, self.kern.num_features)                                    # kernels.py:417-418
+
+    def scale_sequences(self, X):
+        """kernels.py:343-364.  (N, L, d) -> (N, L, d * (num_lags + 1))."""
+        k = self.kern
+        N, L, _ = X.shape
+        if k.num_lags > 0:
+            X = _add_lags(X, self.lags)                                                             # :353
+        X = X.reshape(N, L, k.num_lags + 1, k.num_features)                                         # :355
+        if self.raw_lengthscales is not None:
+            X = X / self.lengthscales[None, None, None, :]                                          # :358
+        if k.num_lags > 0:
+            X = X * self.gamma[None, None, :, None]                                                 # :361
+        return X.reshape(N, L, -1)
+
+    def scale_tensors(self, Z):
+        """kernels.py:367-398 (both layouts: (lt, T, d') and (lt, T, 2, d'))."""
+        k = self.kern
+        if self.raw_lengthscales is None:
+            return Z                                                                                # :374 / :391
+        shape = Z.shape
+        Z = Z.reshape(*shape[:-1], k.num_lags + 1, k.num_features) / self.lengthscales
+        if k.num_lags > 0:
+            Z = Z * self.gamma[:, None]
+        return Z.reshape(shape)
+
+    # ---- level primitives ------------------------------------------------------------------------------------------
+    def _seq_levels(self, Xs, X2s=None): return _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
+    def _diag_levels(self, Xs): return _SeqDiagLevels.apply(Xs, self.p0, self._spec)
+    def _tens_levels(self, Zs, increments): return _TensGramLevels.apply(Zs, self.p0, self._spec, increments)
+    def _tvs_levels(self, Zs, Xs, increments): return _TensVsSeqLevels.apply(Zs, Xs, self.p0, self._spec, increments)
+
+    def _w(self):
+        return self.sigma * self.variances                                                          # kernels.py:471
+
+    # ---- kernel evaluations ----------------------------------------------------------------------------------------
+    def K(self, X, X2=None, return_levels=False):
+        """kernels.py:401-476."""
+        Xs = self.scale_sequences(self._seq3(X))
+        N = Xs.shape[0]
+        if X2 is None:
+            K = self._seq_levels(Xs)
+            if self.kern.normalization:
+                K = K + JITTER * torch.eye(N, dtype=K.dtype, device=K.device)[None]                 # :431
+                dsq = torch.sqrt(torch.diagonal(K, dim1=1, dim2=2))                                 # :432
+                K = K / (dsq[:, :, None] * dsq[:, None, :])                                         # :433
+        else:
+            X2s = self.scale_sequences(self._seq3(X2))
+            K = self._seq_levels(Xs, X2s)
+            if self.kern.normalization:
+                d1 = torch.sqrt(self._diag_levels(Xs) + JITTER)                                     # :460-466
+                d2 = torch.sqrt(self._diag_levels(X2s) + JITTER)
+                K = K / (d1[:, :, None] * d2[:, None, :])                                           # :469
+        K = K * self._w()[:, None, None]
+        return K if return_levels else K.sum(dim=0)
+
+    def Kdiag(self, X, return_levels=False):
+        """kernels.py:479-510."""
+        N = X.shape[0]
+        if self.kern.normalization:
+            Kd = self._w()[:, None].expand(-1, N)                                                   # :486-490
+        else:
+            Kd = self._diag_levels(self.scale_sequences(self._seq3(X))) * self._w()[:, None]
+        return Kd if return_levels else Kd.sum(dim=0)
+
+    def K_tens(self, Z, return_levels=False, increments=False):
+        """kernels.py:513-536."""
+        K = self._tens_levels(self.scale_tensors(Z), increments) * self._w()[:, None, None]
+        return K if return_levels else K.sum(dim=0)
+
+    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False):
+        """kernels.py:539-588."""
+        Xs = self.scale_sequences(self._seq3(X))
+        K = self._tvs_levels(self.scale_tensors(Z), Xs, increments)
+        if self.kern.normalization:
+            K = K / torch.sqrt(self._diag_levels(Xs) + JITTER)[:, None, :]                          # :576-581
+        K = K * self._w()[:, None, None]
+        return K if return_levels else K.sum(dim=0)
+
+    def K_tens_n_seq_covs(self, Z, X, full_X_cov=False, return_levels=False, increments=False):
+        """kernels.py:591-671: Kzz, Kzx and Kxx (full or diagonal) from one scaling of the inputs."""
+        Xs = self.scale_sequences(self._seq3(X))
+        N = Xs.shape[0]
+        Zs = self.scale_tensors(Z)
+        Kzz = self._tens_levels(Zs, increments)                                                     # :623
+        Kzx = self._tvs_levels(Zs, Xs, increments)                                                  # :624
+        w = self._w()
+        if full_X_cov:
+            Kxx = self._seq_levels(Xs)                                                              # :630
+            if self.kern.normalization:
+                Kxx = Kxx + JITTER * torch.eye(N, dtype=Kxx.dtype, device=Kxx.device)[None]         # :633
+                dsq = torch.sqrt(torch.diagonal(Kxx, dim1=1, dim2=2))
+                Kxx = Kxx / (dsq[:, :, None] * dsq[:, None, :])                                     # :637
+                Kzx = Kzx / dsq[:, None, :]                                                         # :638
+            Kxx = Kxx * w[:, None, None]
+        else:
+            Kxx = self._diag_levels(Xs)                                                             # :653
+            if self.kern.normalization:
+                Kzx = Kzx / torch.sqrt(Kxx + JITTER)[:, None, :]                                    # :656-660
+                Kxx = w[:, None].expand(-1, N)                                                      # :661
+            else:
+                Kxx = Kxx * w[:, None]
+        Kzz = Kzz * w[:, None, None]
+        Kzx = Kzx * w[:, None, None]
+        if return_levels:
+            return Kzz, Kzx, Kxx
+        return Kzz.sum(dim=0), Kzx.sum(dim=0), Kxx.sum(dim=0)
+
+    def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False):
+        """kernels.py:674-761 (``X`` = inducing sequences, ``X2`` = data), including the double division of :713 + :750."""
+        Xs = self.scale_sequences(self._seq3(X))
+        X2s = self.scale_sequences(self._seq3(X2))
+        N, N2 = Xs.shape[0], X2s.shape[0]
+        w = self._w()
+        Kxx = self._seq_levels(Xs)
+        Kxx2 = self._seq_levels(Xs, X2s)
+        norm = self.kern.normalization
+        if norm:
+            Kxx = Kxx + JITTER * torch.eye(N, dtype=Kxx.dtype, device=Kxx.device)[None]             # :709
+            dsq = torch.sqrt(torch.diagonal(Kxx, dim1=1, dim2=2))
+            Kxx = Kxx / (dsq[:, :, None] * dsq[:, None, :])
+            Kxx2 = Kxx2 / dsq[:, :, None]                                                           # :713
+        if full_X2_cov:
+            Kx2x2 = self._seq_levels(X2s)
+            if norm:
+                Kx2x2 = Kx2x2 + JITTER * torch.eye(N2, dtype=Kxx.dtype, device=Kxx.device)[None]
+                d2 = torch.sqrt(torch.diagonal(Kx2x2, dim1=1, dim2=2))
+                Kxx2 = Kxx2 / d2[:, None, :]
+                Kx2x2 = Kx2x2 / (d2[:, :, None] * d2[:, None, :])
+            Kx2x2 = Kx2x2 * w[:, None, None]
+        else:
+            Kx2x2 = self._diag_levels(X2s)
+            if norm:
+                d2 = torch.sqrt(Kx2x2 + JITTER)
+                Kxx2 = Kxx2 / (dsq[:, :, None] * d2[:, None, :])                                    # :750 (second division by dsq: reference quirk)
+                Kx2x2 = w[:, None].expand(-1, N2)
+            else:
+                Kx2x2 = Kx2x2 * w[:, None]
+        Kxx = Kxx * w[:, None, None]
+        Kxx2 = Kxx2 * w[:, None, None]
+        if return_levels:
+            return Kxx, Kxx2, Kx2x2
+        return Kxx.sum(dim=0), Kxx2.sum(dim=0), Kx2x2.sum(dim=0)

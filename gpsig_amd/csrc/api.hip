@@ -110,116 +110,11 @@ SeqLaunchFn seq_launcher_ho(int mode, const SeqHOConfig& c, bool f32) {
     return nullptr;
 }
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-};
-
-enum BufId {
-    B_IN0, B_IN1, B_IN2,          // host-mode input staging
-    B_OUT0, B_OUT1, B_OUT2,       // host-mode output staging
-    B_REC0, B_REC1,               // seq-gram records
-    B_DLEV0, B_DLEV1,             // diagonal levels
-    B_FAC0, B_FAC1,               // per-sequence factors
-    B_TASKS, B_W, B_XT, B_ZT, B_ZS, B_ZL, B_ZN, B_TMP0, B_TMP1,
-    B_LR0, B_LR1, B_LR2, B_LR3, B_LR4, B_LR5, B_LR6, B_LR7, B_LR8,
-    B_COUNT
-};
-
-thread_local std::string g_create_error;
-
 }  // namespace
 
-struct gpsig_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    int ptr_mode = GPSIG_PTR_HOST;
-    int shard_i = 0, shard_n = 1;
-    int use_glds = 1;
-    int allow_exact = 1;
-    int max_run = 0;
-    int tens_lanes = -1;   // -1 auto, 0 sequence lanes, 1 tensor lanes
-    std::string err;
-    DevBuf buf[B_COUNT];
-    std::vector<SeqTask> host_tasks;
-    // timing of the pair-recursion launches
-    std::vector<hipEvent_t> ev;     // pairs (start, stop)
-    size_t ev_used = 0;
-    int64_t t_launches = 0, t_pairs = 0;
-};
+#include "ctx.hpp"
 
 namespace {
-
-int fail(gpsig_ctx* c, int code, const char* fmt, ...) {
-    char tmp[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(tmp, sizeof(tmp), fmt, ap);
-    va_end(ap);
-    if (c) c->err = tmp; else g_create_error = tmp;
-    return code;
-}
-
-#define HIPCHK(c, expr)                                                                                         \
-    do {                                                                                                        \
-        hipError_t e__ = (expr);                                                                                \
-        if (e__ != hipSuccess) return fail((c), GPSIG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
-    } while (0)
-#define CHK(expr)                    \
-    do {                             \
-        int rc__ = (expr);           \
-        if (rc__ != GPSIG_OK) return rc__; \
-    } while (0)
-
-int ensure(gpsig_ctx* c, int id, size_t bytes, void** out) {
-    DevBuf& b = c->buf[id];
-    if (bytes > b.cap) {
-        if (b.p) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));   // nothing in flight may still use the old block
-            HIPCHK(c, hipFree(b.p));
-            b.p = nullptr;
-            b.cap = 0;
-        }
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&b.p, want);
-        if (e != hipSuccess) return fail(c, GPSIG_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
-        b.cap = want;
-    }
-    *out = b.p;
-    return GPSIG_OK;
-}
-
-// input pointer as the caller gave it -> device pointer
-int in_dev(gpsig_ctx* c, int id, const void* user, size_t bytes, const void** dev) {
-    if (!user && bytes) return fail(c, GPSIG_ERR_INVALID, "null input pointer");
-    if (c->ptr_mode == GPSIG_PTR_DEVICE && user) { *dev = user; return GPSIG_OK; }
-    void* p;
-    CHK(ensure(c, id, bytes ? bytes : 8, &p));
-    if (bytes && c->ptr_mode == GPSIG_PTR_HOST) HIPCHK(c, hipMemcpyAsync(p, user, bytes, hipMemcpyHostToDevice, c->stream));
-    *dev = p;
-    return GPSIG_OK;
-}
-int out_dev(gpsig_ctx* c, int id, void* user, size_t bytes, void** dev) {
-    if (!user && bytes) return fail(c, GPSIG_ERR_INVALID, "null output pointer");
-    if (c->ptr_mode == GPSIG_PTR_DEVICE && user) { *dev = user; return GPSIG_OK; }
-    return ensure(c, id, bytes ? bytes : 8, dev);
-}
-int out_done(gpsig_ctx* c, void* user, const void* dev, size_t bytes) {
-    if (c->ptr_mode == GPSIG_PTR_DEVICE || !user) return GPSIG_OK;
-    if (bytes) HIPCHK(c, hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, c->stream));
-    return GPSIG_OK;
-}
-int finish(gpsig_ctx* c) {
-    if (c->ptr_mode == GPSIG_PTR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
-    return GPSIG_OK;
-}
-
-int grid_for(int64_t n, int block = 256) {
-    int64_t g = (n + block - 1) / block;
-    if (g < 1) g = 1;
-    if (g > 256 * 16) g = 256 * 16;
-    return int(g);
-}
 
 int check_params(gpsig_ctx* c, const gpsig_params* p) {
     if (!c) return GPSIG_ERR_INVALID;
@@ -1140,6 +1035,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "exact")) c->allow_exact = value ? 1 : 0;
     else if (!strcmp(name, "max_run")) c->max_run = value > 0 ? value : 0;
     else if (!strcmp(name, "tensor_lanes")) c->tens_lanes = value;
+    else if (!strcmp(name, "grad_scratch_mb")) c->grad_scratch_mb = value > 0 ? value : 4096;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);
     return GPSIG_OK;
 }

@@ -1,0 +1,312 @@
+// grad_api.hip -- C-ABI entry points of the gradient path (include/gpsig_hip.h, "gradients").
+//
+// Reverse-mode derivatives of the four level primitives (_K_seq, _K_seq_diag, _K_tens, _K_tens_vs_seq of
+// gpsig/kernels.py:188-340) with respect to their (already scaled) inputs; first-order algorithm, float64.  The
+// reference differentiates these through TensorFlow (training.py:149-164); there is no reference gradient code
+// to cite, the formulas are in grad_core.hpp.  Host side only: staging, chunking by the scratch budget, launches.
+#include "ctx.hpp"
+#include "grad_kernels.hpp"
+
+using namespace gpsig;
+
+namespace {
+
+int grad_check(gpsig_ctx* c, const gpsig_params* p, int* d, int* DP) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (!p) return fail(c, GPSIG_ERR_INVALID, "params is NULL");
+    if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for float64 only");
+    if (p->num_levels < 1) return fail(c, GPSIG_ERR_INVALID, "num_levels must be >= 1");
+    if (p->num_levels > GRAD_MAX_LEVELS) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for num_levels <= %d", GRAD_MAX_LEVELS);
+    if (p->order != 1 && p->num_levels > 1) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for the first-order algorithm (order=1) only");
+    if (p->base_kernel < GPSIG_BASE_LINEAR || p->base_kernel > GPSIG_BASE_MATERN52) return fail(c, GPSIG_ERR_INVALID, "unknown base kernel %d", p->base_kernel);
+    if (p->num_features < 1 || p->num_lags < 0) return fail(c, GPSIG_ERR_INVALID, "bad num_features / num_lags");
+    *d = p->num_features * (p->num_lags + 1);      // raw entry points: columns are taken as they come
+    if (*d > 32) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 32 feature columns (got %d)", *d);
+    *DP = *d <= 4 ? 4 : (*d <= 8 ? 8 : (*d <= 16 ? 16 : 32));
+    HIPCHK(c, hipSetDevice(c->device));
+    return GPSIG_OK;
+}
+
+int lattice_mode(const gpsig_params* p) {
+    if (!p->difference) return MODE_PT_NODIFF;
+    return p->base_kernel == GPSIG_BASE_LINEAR ? MODE_INC : MODE_PT_DIFF;
+}
+
+size_t scratch_budget(const gpsig_ctx* c) { return size_t(c->grad_scratch_mb > 0 ? c->grad_scratch_mb : 4096) << 20; }
+
+int to_timemajor(gpsig_ctx* c, const double* X, double* XT, int64_t N, int L, int d, int DP, int64_t stride) {
+    hipLaunchKernelGGL(grad_to_timemajor_kernel, dim3(grid_for(int64_t(L) * DP * stride)), dim3(256), 0, c->stream, X, XT, int(N), L, d, DP, stride);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+int from_timemajor(gpsig_ctx* c, const double* gXT, double* gX, int64_t N, int L, int d, int DP, int64_t stride) {
+    if (N * L * d == 0) return GPSIG_OK;
+    hipLaunchKernelGGL(grad_from_timemajor_kernel, dim3(grid_for(N * L * d)), dim3(256), 0, c->stream, gXT, gX, int(N), L, d, DP, stride, 0);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+
+template <typename A>
+int launch_seq(gpsig_ctx* c, int DP, dim3 grid, const A& a) {
+    switch (DP) {
+        case 4: hipLaunchKernelGGL(seq_pair_grad_kernel<4>, grid, dim3(64), 0, c->stream, a); break;
+        case 8: hipLaunchKernelGGL(seq_pair_grad_kernel<8>, grid, dim3(64), 0, c->stream, a); break;
+        case 16: hipLaunchKernelGGL(seq_pair_grad_kernel<16>, grid, dim3(64), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(seq_pair_grad_kernel<32>, grid, dim3(64), 0, c->stream, a); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+int launch_tvs(gpsig_ctx* c, int DP, dim3 grid, const TvsGradArgs& a) {
+    switch (DP) {
+        case 4: hipLaunchKernelGGL(tvs_pair_grad_kernel<4>, grid, dim3(64), 0, c->stream, a); break;
+        case 8: hipLaunchKernelGGL(tvs_pair_grad_kernel<8>, grid, dim3(64), 0, c->stream, a); break;
+        case 16: hipLaunchKernelGGL(tvs_pair_grad_kernel<16>, grid, dim3(64), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(tvs_pair_grad_kernel<32>, grid, dim3(64), 0, c->stream, a); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+int launch_tens(gpsig_ctx* c, int DP, dim3 grid, const TensGradArgs& a) {
+    switch (DP) {
+        case 4: hipLaunchKernelGGL(tens_pair_grad_kernel<4>, grid, dim3(64), 0, c->stream, a); break;
+        case 8: hipLaunchKernelGGL(tens_pair_grad_kernel<8>, grid, dim3(64), 0, c->stream, a); break;
+        case 16: hipLaunchKernelGGL(tens_pair_grad_kernel<16>, grid, dim3(64), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(tens_pair_grad_kernel<32>, grid, dim3(64), 0, c->stream, a); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+
+int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
+
+// gbase: 2 doubles on the device, zeroed
+int gbase_begin(gpsig_ctx* c, double** dev) {
+    void* p;
+    CHK(ensure(c, B_GR7, 2 * sizeof(double), &p));
+    HIPCHK(c, hipMemsetAsync(p, 0, 2 * sizeof(double), c->stream));
+    *dev = static_cast<double*>(p);
+    return GPSIG_OK;
+}
+int gbase_end(gpsig_ctx* c, const double* dev, double* user) {
+    if (!user) return GPSIG_OK;
+    HIPCHK(c, hipMemcpyAsync(user, dev, 2 * sizeof(double), c->ptr_mode == GPSIG_PTR_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+    return GPSIG_OK;
+}
+
+// shared body of the Gram and the diagonal gradient
+int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
+             const void* G, void* gX, void* gY, double* g_base) {
+    int d, DP;
+    CHK(grad_check(c, p, &d, &DP));
+    if (N1 < 0 || N2 < 0 || L1 < 1 || L2 < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
+    if (N1 > 0x7fffffff || N2 > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 sequences");
+    const bool sym = !diag && Y == nullptr;
+    if (sym) { N2 = N1; L2 = L1; }
+    const int M = p->num_levels, M1 = M + 1;
+    const int mode = lattice_mode(p);
+    const size_t xb = sizeof(double) * size_t(N1) * L1 * d, yb = sizeof(double) * size_t(N2) * L2 * d;
+    const size_t gb = sizeof(double) * size_t(M1) * N1 * (diag ? 1 : N2);
+    const void *dX, *dY = nullptr, *dG;
+    CHK(in_dev(c, B_IN0, X, xb, &dX));
+    if (!diag && !sym) CHK(in_dev(c, B_IN1, Y, yb, &dY));
+    CHK(in_dev(c, B_IN2, G, gb, &dG));
+    void *dgX, *dgY = nullptr;
+    CHK(out_dev(c, B_OUT0, gX, xb, &dgX));
+    if (!diag && !sym) CHK(out_dev(c, B_OUT1, gY, yb, &dgY));
+    double* dgb;
+    CHK(gbase_begin(c, &dgb));
+    if (N1 == 0 || N2 == 0) {
+        if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
+        if (dgY && yb) HIPCHK(c, hipMemsetAsync(dgY, 0, yb, c->stream));
+    } else {
+        const int64_t s1 = pad64(N1), s2 = pad64(N2);
+        void *xT, *yT = nullptr, *gxT, *gyT = nullptr;
+        const size_t xtb = sizeof(double) * size_t(L1) * DP * s1, ytb = sizeof(double) * size_t(L2) * DP * s2;
+        CHK(ensure(c, B_GR0, xtb, &xT));
+        CHK(ensure(c, B_GR2, xtb, &gxT));
+        CHK(to_timemajor(c, static_cast<const double*>(dX), static_cast<double*>(xT), N1, L1, d, DP, s1));
+        HIPCHK(c, hipMemsetAsync(gxT, 0, xtb, c->stream));
+        if (!diag && !sym) {
+            CHK(ensure(c, B_GR1, ytb, &yT));
+            CHK(ensure(c, B_GR3, ytb, &gyT));
+            CHK(to_timemajor(c, static_cast<const double*>(dY), static_cast<double*>(yT), N2, L2, d, DP, s2));
+            HIPCHK(c, hipMemsetAsync(gyT, 0, ytb, c->stream));
+        }
+        const int dr = mode == MODE_PT_NODIFF ? 0 : 1;
+        const int R1 = L1 - dr, R2 = L2 - dr;
+        const size_t per_j = sizeof(double) * size_t(M) * size_t(R1 > 0 ? R1 : 0) * size_t(R2 > 0 ? R2 : 0) * size_t(s1);
+        int64_t chunk = diag ? 1 : int64_t(scratch_budget(c) / (per_j ? per_j : 1));
+        if (chunk < 1) chunk = 1;
+        if (chunk > N2) chunk = N2;
+        if (chunk > 65535) chunk = 65535;
+        void* scr;
+        CHK(ensure(c, B_GR4, per_j * size_t(chunk) + 64, &scr));
+        SeqGradArgs A;
+        memset(&A, 0, sizeof(A));
+        A.xT = static_cast<const double*>(xT);
+        A.yT = (diag || sym) ? A.xT : static_cast<const double*>(yT);
+        A.gxT = static_cast<double*>(gxT);
+        A.gyT = (diag || sym) ? A.gxT : static_cast<double*>(gyT);
+        A.xstride = s1;
+        A.ystride = (diag || sym) ? s1 : s2;
+        A.N1 = int(N1); A.N2 = int(N2); A.L1 = L1; A.L2 = L2;
+        A.M = M; A.kind = p->base_kernel; A.mode = mode;
+        A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
+        A.diag = diag ? 1 : 0;
+        A.G = static_cast<const double*>(dG);
+        A.gm = diag ? N1 : N1 * N2; A.gi = diag ? 1 : N2; A.gj = diag ? 0 : 1;
+        A.scratch = static_cast<double*>(scr);
+        A.levels = nullptr;
+        A.gbase = dgb;
+        const unsigned gx_ = unsigned(s1 / 64);
+        if (diag) {
+            A.j0 = 0; A.nj = 1; A.pairs = s1;
+            CHK(launch_seq(c, DP, dim3(gx_, 1), A));
+        } else {
+            for (int64_t j0 = 0; j0 < N2; j0 += chunk) {
+                const int64_t nj = (N2 - j0 < chunk) ? N2 - j0 : chunk;
+                A.j0 = int(j0); A.nj = int(nj); A.pairs = s1 * nj;
+                CHK(launch_seq(c, DP, dim3(gx_, unsigned(nj)), A));
+            }
+        }
+        CHK(from_timemajor(c, static_cast<const double*>(gxT), static_cast<double*>(dgX), N1, L1, d, DP, s1));
+        if (!diag && !sym) CHK(from_timemajor(c, static_cast<const double*>(gyT), static_cast<double*>(dgY), N2, L2, d, DP, s2));
+    }
+    CHK(out_done(c, gX, dgX, xb));
+    if (!diag && !sym) CHK(out_done(c, gY, dgY, yb));
+    CHK(gbase_end(c, dgb, g_base));
+    return finish(c);
+}
+
+int pad_rows(gpsig_ctx* c, const double* Z, double* ZP, int64_t rows, int d, int DP) {
+    if (rows == 0) return GPSIG_OK;
+    hipLaunchKernelGGL(grad_pad_rows_kernel, dim3(grid_for(rows * DP)), dim3(256), 0, c->stream, Z, ZP, rows, d, DP);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+int unpad_rows(gpsig_ctx* c, const double* ZP, double* Z, int64_t rows, int d, int DP) {
+    if (rows == 0) return GPSIG_OK;
+    hipLaunchKernelGGL(grad_unpad_rows_kernel, dim3(grid_for(rows * d)), dim3(256), 0, c->stream, ZP, Z, rows, d, DP, 0);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpsig_seq_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2, int32_t L1,
+                               int32_t L2, const void* G, void* gX, void* gX2, double* g_base) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (X2 && !gX2) return fail(c, GPSIG_ERR_INVALID, "gX2 is NULL");
+    return seq_grad(c, p, X, X2, N1, N2, L1, L2, false, G, gX, gX2, g_base);
+}
+
+int gpsig_seq_diag_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, const void* G, void* gX,
+                               double* g_base) {
+    if (!c) return GPSIG_ERR_INVALID;
+    return seq_grad(c, p, X, nullptr, N, N, L, L, true, G, gX, nullptr, g_base);
+}
+
+int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, const void* G, void* gZ,
+                                double* g_base) {
+    int d, DP;
+    CHK(grad_check(c, p, &d, &DP));
+    if (T < 0 || T > 65535) return fail(c, GPSIG_ERR_INVALID, "bad number of tensors");
+    const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
+    const int64_t rows = int64_t(lt) * T * E;
+    const size_t zb = sizeof(double) * size_t(rows) * d, gb = sizeof(double) * size_t(M + 1) * T * T;
+    const void *dZ, *dG;
+    CHK(in_dev(c, B_IN0, Z, zb, &dZ));
+    CHK(in_dev(c, B_IN2, G, gb, &dG));
+    void* dgZ;
+    CHK(out_dev(c, B_OUT0, gZ, zb, &dgZ));
+    double* dgb;
+    CHK(gbase_begin(c, &dgb));
+    if (T > 0) {
+        void *zp, *gzp;
+        CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
+        CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
+        CHK(pad_rows(c, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
+        HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
+        TensGradArgs A;
+        memset(&A, 0, sizeof(A));
+        A.z = static_cast<const double*>(zp); A.gz = static_cast<double*>(gzp);
+        A.T = int(T); A.M = M; A.kind = p->base_kernel; A.incr = increments ? 1 : 0;
+        A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
+        A.G = static_cast<const double*>(dG); A.gm = T * T; A.gt = T; A.gn = 1;
+        A.gbase = dgb;
+        CHK(launch_tens(c, DP, dim3(unsigned((T + 63) / 64), unsigned(T)), A));
+        CHK(unpad_rows(c, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
+    }
+    CHK(out_done(c, gZ, dgZ, zb));
+    CHK(gbase_end(c, dgb, g_base));
+    return finish(c);
+}
+
+int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N, int32_t L,
+                                  int32_t increments, const void* G, void* gZ, void* gX, double* g_base) {
+    int d, DP;
+    CHK(grad_check(c, p, &d, &DP));
+    if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
+    if (N > 0x7fffffff || T > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 items");
+    const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
+    const int64_t rows = int64_t(lt) * T * E;
+    const size_t zb = sizeof(double) * size_t(rows) * d, xb = sizeof(double) * size_t(N) * L * d, gb = sizeof(double) * size_t(M + 1) * T * N;
+    const void *dZ, *dX, *dG;
+    CHK(in_dev(c, B_IN0, Z, zb, &dZ));
+    CHK(in_dev(c, B_IN1, X, xb, &dX));
+    CHK(in_dev(c, B_IN2, G, gb, &dG));
+    void *dgZ, *dgX;
+    CHK(out_dev(c, B_OUT0, gZ, zb, &dgZ));
+    CHK(out_dev(c, B_OUT1, gX, xb, &dgX));
+    double* dgb;
+    CHK(gbase_begin(c, &dgb));
+    if (T == 0 || N == 0) {
+        if (zb) HIPCHK(c, hipMemsetAsync(dgZ, 0, zb, c->stream));
+        if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
+    } else {
+        const int64_t s = pad64(N);
+        void *zp, *gzp, *xT, *gxT, *scr;
+        const size_t xtb = sizeof(double) * size_t(L) * DP * s;
+        CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
+        CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
+        CHK(ensure(c, B_GR2, xtb, &xT));
+        CHK(ensure(c, B_GR3, xtb, &gxT));
+        CHK(pad_rows(c, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
+        CHK(to_timemajor(c, static_cast<const double*>(dX), static_cast<double*>(xT), N, L, d, DP, s));
+        HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
+        HIPCHK(c, hipMemsetAsync(gxT, 0, xtb, c->stream));
+        const int R = p->difference ? L - 1 : L;
+        const size_t per_t = sizeof(double) * size_t(lt + M * (M - 1) / 2) * size_t(R > 0 ? R : 0) * size_t(s);
+        int64_t chunk = int64_t(scratch_budget(c) / (per_t ? per_t : 1));
+        if (chunk < 1) chunk = 1;
+        if (chunk > T) chunk = T;
+        if (chunk > 65535) chunk = 65535;
+        CHK(ensure(c, B_GR4, per_t * size_t(chunk) + 64, &scr));
+        TvsGradArgs A;
+        memset(&A, 0, sizeof(A));
+        A.z = static_cast<const double*>(zp); A.gz = static_cast<double*>(gzp);
+        A.xT = static_cast<const double*>(xT); A.gxT = static_cast<double*>(gxT);
+        A.xstride = s;
+        A.T = int(T); A.N = int(N); A.L = L; A.M = M; A.kind = p->base_kernel; A.incr = increments ? 1 : 0; A.diff = p->difference ? 1 : 0;
+        A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
+        A.G = static_cast<const double*>(dG); A.gm = T * N; A.gt = N; A.gn = 1;
+        A.scratch = static_cast<double*>(scr);
+        A.gbase = dgb;
+        for (int64_t t0 = 0; t0 < T; t0 += chunk) {
+            const int64_t nt = (T - t0 < chunk) ? T - t0 : chunk;
+            A.t0 = int(t0); A.nt = int(nt); A.pairs = s * nt;
+            CHK(launch_tvs(c, DP, dim3(unsigned(s / 64), unsigned(nt)), A));
+        }
+        CHK(unpad_rows(c, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
+        CHK(from_timemajor(c, static_cast<const double*>(gxT), static_cast<double*>(dgX), N, L, d, DP, s));
+    }
+    CHK(out_done(c, gZ, dgZ, zb));
+    CHK(out_done(c, gX, dgX, xb));
+    CHK(gbase_end(c, dgb, g_base));
+    return finish(c);
+}
+
+}  // extern "C"

@@ -7,9 +7,9 @@ constrained values (``variances`` (M+1,), ``sigma`` scalar, ``lengthscales`` (d,
 every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CUDA-out (device
 pointers, asynchronous on the current stream).
 
-Not built yet (raise NotImplementedError, never a silent fallback): ``order > 1`` on the GPU,
-``SignatureSpectral``; ``low_rank=True`` inside ``K_tens_n_seq_covs`` / ``K_seq_n_seq_covs``; float32 inputs are
-computed in float32 (order 1, exact mode only).
+float32 inputs are computed in float32 (order 1, exact mode only).  Not built yet (raise NotImplementedError, never a
+silent fallback): ``SignatureSpectral``; ``low_rank=True`` inside ``K_seq_n_seq_covs`` and in float32; ``order > 1`` in
+float32 or with ``difference=False`` and a non-linear base kernel.  Training (gradients): ``gpsig_amd.autodiff``.
 """
 import ctypes as C
 
@@ -553,6 +553,9 @@ class SignaturePoly(SignatureKernel):
     def _current_base_params(self):
         return (float(self.gamma), float(self.degree))
 
+    def _set_base_p0(self, value):
+        self.gamma = float(value)
+
 
 class SignatureRBF(SignatureKernel):
     """Gaussian state-space kernel exp(-|x-y|^2/2) on the scaled inputs (kernels.py:850-864)."""
@@ -572,6 +575,9 @@ class SignatureMix(SignatureKernel):
 
     def _current_base_params(self):
         return (float(self.mixing), 0.0)
+
+    def _set_base_p0(self, value):
+        self.mixing = float(value)
 
 
 class SignatureSpectral(SignatureKernel):

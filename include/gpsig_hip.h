@@ -188,6 +188,26 @@ int gpsig_lr_kernel(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowrank* 
 int gpsig_lr_kernel_diag(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowrank* lr, const void* Phi, int64_t N,
                          int32_t return_levels, void* out);
 
+/* ---- gradients (reverse mode) of the level primitives ------------------------------------------------------------
+ * The reference has no gradient code: it trains through TensorFlow's autodiff of the graph these primitives stand
+ * for (gpsig/training.py:149-164, gpsig/models.py:40-59).  Each function below takes the upstream gradient G of the
+ * (M+1, ...) level array its forward counterpart returns and produces the gradients with respect to the inputs of
+ * that primitive, i.e. what tf.gradients would return for _K_seq / _K_seq_diag / _K_tens / _K_tens_vs_seq
+ * (gpsig/kernels.py:188-340) with order = 1.  As for the forward primitives, inputs are taken as they come (already
+ * scaled, d = num_features * (num_lags + 1) columns); float64 only.  Outputs are overwritten.  g_base: 2 doubles in the
+ * context's pointer mode or NULL; [0] receives the gradient with respect to base_params[0] (gamma of SignaturePoly,
+ * kernels.py:844-848; mixing of SignatureMix, :881-892).  Option "grad_scratch_mb" bounds the lattice scratch. */
+/* X2 == NULL: symmetric Gram, gX receives both roles of every sequence. */
+int gpsig_seq_gram_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
+                               int32_t L1, int32_t L2, const void* G /* (M+1, N1, N2) */, void* gX, void* gX2, double* g_base);
+int gpsig_seq_diag_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L,
+                               const void* G /* (M+1, N) */, void* gX, double* g_base);
+int gpsig_tens_gram_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, int64_t T, int32_t increments,
+                                const void* G /* (M+1, T, T) */, void* gZ, double* g_base);
+int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
+                                  int32_t L, int32_t increments, const void* G /* (M+1, T, N) */, void* gZ, void* gX,
+                                  double* g_base);
+
 #ifdef __cplusplus
 }
 #endif

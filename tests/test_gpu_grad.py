@@ -1,0 +1,236 @@
+"""GPU parity of the gradient path (through the C ABI) against torch.autograd of the differentiable oracle.
+
+The reference has no gradient code and no gradient tests: it trains by TensorFlow autodiff of the graph that
+oracle/sigkern_oracle_torch.py restates (pinned on CPU by tests/test_grad_core.py).  Tolerance: float64, 1e-6 relative
+to the largest gradient entry (north_star's tolerance for the kernel entries); observed ~1e-13.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sigkern_oracle_torch as OT
+
+pytestmark = pytest.mark.gpu
+
+BASES = ["linear", "rbf", "cosine", "poly", "mix", "matern12", "matern32", "matern52"]
+_P = C.POINTER(C.c_double)
+
+
+def _bp(base):
+    return (1.0, 3.0) if base == "poly" else ((0.4, 0.0) if base == "mix" else (0.0, 0.0))
+
+
+def _t_kern(base, d, M, **kw):
+    p0, p1 = _bp(base)
+    return OT.SignatureKernelTorchOracle(d, M, base, p0=torch.tensor(p0, dtype=torch.float64, requires_grad=True), p1=p1, **kw)
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def _host_ctx():
+    from gpsig_amd import _lib
+    ctx = _lib.context(0, 0)
+    ctx.set_pointer_mode(_lib.PTR_HOST)
+    return ctx
+
+
+def _params(base, d, M, difference, keep):
+    from gpsig_amd.autodiff import _Spec
+    p0, p1 = _bp(base)
+    return _Spec(base, M, difference, p1).params(d, p0, keep)
+
+
+def _vp(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+@pytest.mark.parametrize("base", BASES)
+@pytest.mark.parametrize("difference", [True, False])
+def test_seq_level_gradients(base, difference):
+    rng = np.random.default_rng(21)
+    ctx = _host_ctx()
+    tol = 1e-6
+    for (M, N1, N2, L1, L2, d, kind) in [(4, 70, 5, 9, 7, 3, "cross"), (3, 9, 9, 6, 6, 2, "sym"), (5, 130, 130, 8, 8, 5, "diag"), (2, 3, 4, 5, 3, 11, "cross")]:
+        X = rng.standard_normal((N1, L1, d)) * 0.5
+        Y = rng.standard_normal((N2, L2, d)) * 0.5 if kind == "cross" else None
+        G = rng.standard_normal((M + 1, N1) if kind == "diag" else (M + 1, N1, N2 if kind == "cross" else N1))
+        kt = _t_kern(base, d, M, difference=difference)
+        tX = torch.tensor(X, requires_grad=True)
+        tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+        lev = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
+        (lev * torch.tensor(G)).sum().backward()
+        keep = []
+        p = _params(base, d, M, difference, keep)
+        gX, gY, gb = np.empty_like(X), (None if Y is None else np.empty_like(Y)), np.zeros(2)
+        if kind == "diag":
+            ctx.call("gpsig_seq_diag_levels_grad", p, _vp(X), N1, L1, _vp(G), _vp(gX), gb.ctypes.data_as(_P))
+        else:
+            ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2 if Y is not None else N1, L1, L2 if Y is not None else L1,
+                     _vp(G), _vp(gX), _vp(gY), gb.ctypes.data_as(_P))
+        assert rel(gX, tX.grad) < tol, (kind, rel(gX, tX.grad))
+        if Y is not None:
+            assert rel(gY, tY.grad) < tol
+        if base in ("poly", "mix"):
+            assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
+
+
+def test_seq_level_gradients_are_chunk_invariant():
+    rng = np.random.default_rng(22)
+    ctx = _host_ctx()
+    M, N1, N2, L1, L2, d = 4, 100, 37, 12, 10, 4
+    X, Y = rng.standard_normal((N1, L1, d)) * 0.4, rng.standard_normal((N2, L2, d)) * 0.4
+    G = rng.standard_normal((M + 1, N1, N2))
+    keep = []
+    p = _params("rbf", d, M, True, keep)
+    res = []
+    for mb in (4096, 1):
+        ctx.set_option("grad_scratch_mb", mb)
+        gX, gY = np.empty_like(X), np.empty_like(Y)
+        ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2, L1, L2, _vp(G), _vp(gX), _vp(gY), None)
+        res.append((gX, gY))
+    ctx.set_option("grad_scratch_mb", 4096)
+    assert rel(res[1][0], res[0][0]) < 1e-12 and rel(res[1][1], res[0][1]) < 1e-12
+    kt = _t_kern("rbf", d, M)
+    tX, tY = torch.tensor(X, requires_grad=True), torch.tensor(Y, requires_grad=True)
+    (kt.K_seq_levels(tX, tY) * torch.tensor(G)).sum().backward()
+    assert rel(res[0][0], tX.grad) < 1e-9 and rel(res[0][1], tY.grad) < 1e-9
+
+
+@pytest.mark.parametrize("base", BASES)
+@pytest.mark.parametrize("difference", [True, False])
+@pytest.mark.parametrize("increments", [False, True])
+def test_tensor_level_gradients(base, difference, increments):
+    rng = np.random.default_rng(23)
+    ctx = _host_ctx()
+    M, T, N, L, d = 4, 5, 70, 9, 3
+    lt = M * (M + 1) // 2
+    Z = rng.standard_normal((lt, T, 2, d) if increments else (lt, T, d)) * 0.5
+    X = rng.standard_normal((N, L, d)) * 0.5
+    G = rng.standard_normal((M + 1, T, N))
+    kt = _t_kern(base, d, M, difference=difference)
+    tZ, tX = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+    (kt.K_tens_vs_seq_levels(tZ, tX, increments) * torch.tensor(G)).sum().backward()
+    keep = []
+    p = _params(base, d, M, difference, keep)
+    gZ, gX, gb = np.empty_like(Z), np.empty_like(X), np.zeros(2)
+    ctx.set_option("grad_scratch_mb", 1)     # several launches
+    ctx.call("gpsig_tens_vs_seq_levels_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(G), _vp(gZ), _vp(gX), gb.ctypes.data_as(_P))
+    ctx.set_option("grad_scratch_mb", 4096)
+    assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9
+    if base in ("poly", "mix"):
+        assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
+    G2 = rng.standard_normal((M + 1, T, T))
+    kt = _t_kern(base, d, M)
+    tZ = torch.tensor(Z, requires_grad=True)
+    (kt.K_tens_levels(tZ, increments) * torch.tensor(G2)).sum().backward()
+    gZ, gb = np.empty_like(Z), np.zeros(2)
+    ctx.call("gpsig_tens_gram_levels_grad", p, _vp(Z), T, int(increments), _vp(G2), _vp(gZ), gb.ctypes.data_as(_P))
+    assert rel(gZ, tZ.grad) < 1e-9
+    if base in ("poly", "mix"):
+        assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
+
+
+def _module_and_oracle(base, d, M, L, num_lags=0, normalization=True, difference=True, lengthscales=True):
+    from gpsig_amd import kernels, autodiff
+    cls = {"linear": kernels.SignatureLinear, "rbf": kernels.SignatureRBF, "poly": kernels.SignaturePoly, "mix": kernels.SignatureMix,
+           "matern32": kernels.SignatureMatern32, "cosine": kernels.SignatureCosine}[base]
+    rng = np.random.default_rng(31)
+    kern = cls(L * d, d, M, normalization=normalization, difference=difference, num_lags=num_lags or None,
+               lengthscales=(rng.uniform(0.8, 1.6, d) if lengthscales else None), variances=rng.uniform(0.5, 1.5, M + 1))
+    kern.sigma = 1.3
+    mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
+    leaf = lambda t: None if t is None else t.detach().cpu().clone().requires_grad_(True)
+    orc = OT.SignatureKernelTorchOracle(d, M, base, variances=leaf(mod.variances), sigma=leaf(mod.sigma), lengthscales=leaf(mod.lengthscales),
+                                        normalization=normalization, difference=difference, num_lags=num_lags,
+                                        lags=leaf(mod.lags) if num_lags else None, gamma=leaf(mod.gamma) if num_lags else None,
+                                        p0=leaf(mod.p0), p1=kern._current_base_params()[1])
+    return mod, orc
+
+
+def _constrained_grads(mod, loss):
+    """d loss / d constrained hyper-parameters of the module"""
+    names = ["variances", "sigma", "lengthscales", "p0"] + (["lags", "gamma"] if mod.kern.num_lags > 0 else [])
+    vals = {n: getattr(mod, n) for n in names}
+    vals = {n: v for n, v in vals.items() if v is not None}
+    return vals
+
+
+@pytest.mark.parametrize("base,num_lags,normalization,difference",
+                         [("rbf", 0, True, True), ("linear", 1, True, True), ("poly", 0, False, True), ("mix", 0, True, False),
+                          ("matern32", 2, True, True), ("cosine", 0, True, True), ("linear", 0, False, False)])
+def test_module_gradients_match_oracle_autograd(base, num_lags, normalization, difference):
+    d, M, L, N, N2, T = 3, 3, 8, 7, 5, 4
+    mod, orc = _module_and_oracle(base, d, M, L, num_lags, normalization, difference, lengthscales=(base != "cosine"))
+    rng = np.random.default_rng(32)
+    X, X2 = rng.standard_normal((N, L * d)) * 0.5, rng.standard_normal((N2, L * d)) * 0.5
+    de = d * (num_lags + 1)
+    lt = M * (M + 1) // 2
+    for increments in (False, True):
+        Z = rng.standard_normal((lt, T, 2, de) if increments else (lt, T, de)) * 0.5
+        W1, W2, W3 = rng.standard_normal((T, T)), rng.standard_normal((T, N)), rng.standard_normal(N)
+        Wk, Wc = rng.standard_normal((N, N)), rng.standard_normal((N, N2))
+        dev = torch.device("cuda:0")
+        cu = lambda a: torch.tensor(a, device=dev)
+        Zg = torch.tensor(Z, device=dev, requires_grad=True)
+        Xg = torch.tensor(X, device=dev, requires_grad=True)
+        Kzz, Kzx, Kxx = mod.K_tens_n_seq_covs(Zg, Xg, increments=increments)
+        loss = (Kzz * cu(W1)).sum() + (Kzx * cu(W2)).sum() + (Kxx * cu(W3)).sum() + (mod.K(Xg) * cu(Wk)).sum() + (mod.K(Xg, cu(X2)) * cu(Wc)).sum()
+        mod.zero_grad()
+        loss.backward()
+        Zc = torch.tensor(Z, requires_grad=True)
+        Xc = torch.tensor(X, requires_grad=True)
+        for t in (orc.variances, orc.sigma, orc.lengthscales, orc.lags, orc.gamma, orc.p0):
+            if t is not None and t.grad is not None:
+                t.grad = None
+        oKzz, oKzx, oKxx = orc.K_tens_n_seq_covs(Zc, Xc, increments=increments)
+        oloss = (oKzz * torch.tensor(W1)).sum() + (oKzx * torch.tensor(W2)).sum() + (oKxx * torch.tensor(W3)).sum() + \
+                (orc.K(Xc) * torch.tensor(Wk)).sum() + (orc.K(Xc, torch.tensor(X2)) * torch.tensor(Wc)).sum()
+        oloss.backward()
+        assert abs(loss.item() - oloss.item()) < 1e-9 * max(1.0, abs(oloss.item()))
+        assert rel(Zg.grad, Zc.grad) < 1e-8
+        assert rel(Xg.grad, Xc.grad) < 1e-8
+        # hyper-parameters: compare in the unconstrained space through the same transforms
+        pairs = [(mod.raw_variances, orc.variances, "pos"), (mod.raw_sigma, orc.sigma, "pos")]
+        if mod.raw_lengthscales is not None:
+            pairs.append((mod.raw_lengthscales, orc.lengthscales, "pos"))
+        if num_lags:
+            pairs += [(mod.raw_lags, orc.lags, "logistic"), (mod.raw_gamma, orc.gamma, "pos")]
+        if mod.raw_p0 is not None:
+            pairs.append((mod.raw_p0, orc.p0, "pos"))
+        for raw, con, kind in pairs:
+            r = raw.detach().cpu()
+            jac = torch.sigmoid(r) if kind == "pos" else torch.sigmoid(r) * (1 - torch.sigmoid(r))
+            want = con.grad * jac
+            assert rel(raw.grad, want) < 1e-8, (kind, raw.grad, want)
+
+
+def test_hyperparameters_can_be_trained():
+    """A few Adam steps on a kernel-alignment loss decrease it, and write_back() moves the values into the inference path."""
+    from gpsig_amd import kernels, autodiff
+    rng = np.random.default_rng(33)
+    N, L, d, M = 24, 10, 2, 3
+    lab = np.repeat([0, 1], N // 2)
+    X = np.cumsum(rng.standard_normal((N, L, d)) * 0.3, axis=1) + lab[:, None, None] * np.linspace(0, 1, L)[None, :, None]
+    target = torch.tensor((lab[:, None] == lab[None, :]).astype(np.float64), device="cuda:0")
+    kern = kernels.SignatureRBF(L * d, d, M, lengthscales=3.0)
+    mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
+    Xg = torch.tensor(X.reshape(N, -1), device="cuda:0")
+    opt = torch.optim.Adam(mod.parameters(), lr=0.05)
+    losses = []
+    for _ in range(15):
+        opt.zero_grad()
+        K = mod.K(Xg)
+        loss = ((K / (M + 1) - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    mod.write_back()
+    K_inf = kern.K(Xg)
+    assert rel(K_inf, mod.K(Xg)) < 1e-9

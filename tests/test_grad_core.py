@@ -1,0 +1,150 @@
+"""CPU checks of the gradient path's building blocks.
+
+1. The differentiable oracle (oracle/sigkern_oracle_torch.py) is pinned: its values equal the NumPy oracle's, and
+   its autograd gradients equal central finite differences of the NumPy oracle.
+2. The per-pair adjoint code the gfx950 gradient kernels run (gpsig_amd/csrc/grad_core.hpp, compiled for the host by
+   tests/emu/emu_grad.cpp) reproduces torch.autograd of that oracle for every base kernel and layout.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sigkern_oracle as O
+from oracle import sigkern_oracle_torch as OT
+from tests import emu_grad_util as EG
+
+BASES = ["linear", "rbf", "cosine", "poly", "mix", "matern12", "matern32", "matern52"]
+
+
+def _bp(base):
+    return (1.0, 3.0) if base == "poly" else ((0.4, 0.0) if base == "mix" else (0.0, 0.0))
+
+
+def _np_kern(base, d, M, **kw):
+    p0, p1 = _bp(base)
+    bp = {"gamma": p0, "degree": p1} if base == "poly" else ({"mixing": p0} if base == "mix" else None)
+    return O.SignatureKernelOracle(d * 1, d, M, base=base, base_params=bp, **kw)
+
+
+def _t_kern(base, d, M, **kw):
+    p0, p1 = _bp(base)
+    return OT.SignatureKernelTorchOracle(d, M, base, p0=torch.tensor(p0, dtype=torch.float64, requires_grad=True), p1=p1, **kw)
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-300))
+
+
+@pytest.mark.parametrize("base", BASES)
+@pytest.mark.parametrize("normalization", [True, False])
+def test_torch_oracle_values_equal_numpy_oracle(base, normalization):
+    rng = np.random.default_rng(3)
+    N, N2, L, d, M, T = 4, 3, 6, 3, 3, 4
+    X, X2 = rng.standard_normal((N, L * d)) * 0.6, rng.standard_normal((N2, L * d)) * 0.6
+    ls = rng.uniform(0.7, 1.5, d)
+    var = rng.uniform(0.5, 1.5, M + 1)
+    kn = _np_kern(base, d, M, normalization=normalization, lengthscales=ls, variances=var)
+    kn.input_dim = L * d
+    kt = _t_kern(base, d, M, normalization=normalization, lengthscales=ls, variances=var)
+    tX, tX2 = torch.tensor(X), torch.tensor(X2)
+    tol = 1e-6 if base == "matern12" else 1e-11
+    assert rel(kt.K(tX).detach(), kn.K(X)) < tol
+    assert rel(kt.K(tX, tX2).detach(), kn.K(X, X2)) < tol
+    assert rel(kt.Kdiag(tX).detach(), kn.Kdiag(X)) < tol
+    for incr in (False, True):
+        Z = rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d))
+        tZ = torch.tensor(Z)
+        assert rel(kt.K_tens(tZ, increments=incr).detach(), kn.K_tens(Z, increments=incr)) < tol
+        assert rel(kt.K_tens_vs_seq(tZ, tX, increments=incr).detach(), kn.K_tens_vs_seq(Z, X, increments=incr)) < tol
+        a = kt.K_tens_n_seq_covs(tZ, tX, increments=incr)
+        b = kn.K_tens_n_seq_covs(Z, X, increments=incr)
+        for u, v in zip(a, b):
+            assert rel(u.detach(), v) < tol
+
+
+def test_torch_oracle_with_lags_equals_numpy_oracle():
+    rng = np.random.default_rng(4)
+    N, L, d, M = 3, 7, 2, 3
+    X = rng.standard_normal((N, L * d))
+    kn = O.SignatureKernelOracle(L * d, d, M, base="rbf", num_lags=2, lengthscales=1.3)
+    kt = OT.SignatureKernelTorchOracle(d, M, "rbf", lengthscales=kn.lengthscales, num_lags=2, lags=kn.lags, gamma=kn.gamma)
+    assert rel(kt.K(torch.tensor(X)).detach(), kn.K(X)) < 1e-11
+
+
+def test_torch_oracle_gradient_equals_finite_differences_of_numpy_oracle():
+    rng = np.random.default_rng(5)
+    N, L, d, M = 3, 5, 2, 3
+    X = rng.standard_normal((N, L * d)) * 0.7
+    W = rng.standard_normal((N, N))
+    ls0, var0 = np.array([0.9, 1.4]), rng.uniform(0.5, 1.5, M + 1)
+
+    def loss_np(ls, var):
+        k = O.SignatureKernelOracle(L * d, d, M, base="rbf", lengthscales=ls, variances=var)
+        return float((k.K(X) * W).sum())
+    ls = torch.tensor(ls0, requires_grad=True)
+    var = torch.tensor(var0, requires_grad=True)
+    kt = OT.SignatureKernelTorchOracle(d, M, "rbf", lengthscales=ls, variances=var)
+    (kt.K(torch.tensor(X)) * torch.tensor(W)).sum().backward()
+    h = 1e-6
+    for i in range(d):
+        e = np.zeros(d); e[i] = h
+        fd = (loss_np(ls0 + e, var0) - loss_np(ls0 - e, var0)) / (2 * h)
+        assert abs(fd - ls.grad[i].item()) < 1e-6 * max(1.0, abs(fd))
+    for i in range(M + 1):
+        e = np.zeros(M + 1); e[i] = h
+        fd = (loss_np(ls0, var0 + e) - loss_np(ls0, var0 - e)) / (2 * h)
+        assert abs(fd - var.grad[i].item()) < 1e-6 * max(1.0, abs(fd))
+
+
+@pytest.mark.parametrize("base", BASES)
+@pytest.mark.parametrize("difference", [True, False])
+def test_seq_pair_adjoint_equals_autograd(base, difference):
+    rng = np.random.default_rng(11)
+    p0, p1 = _bp(base)
+    tol = 1e-6 if base == "matern12" else 1e-12
+    for (M, N1, N2, L1, L2, d, kind) in [(4, 3, 2, 6, 5, 3, "cross"), (3, 3, 3, 5, 5, 2, "sym"), (5, 4, 4, 7, 7, 5, "diag"), (1, 2, 3, 4, 2, 9, "cross")]:
+        X = rng.standard_normal((N1, L1, d)) * 0.5
+        Y = rng.standard_normal((N2, L2, d)) * 0.5 if kind == "cross" else None
+        G = rng.standard_normal((M + 1, N1) if kind == "diag" else (M + 1, N1, N2 if kind == "cross" else N1))
+        kt = _t_kern(base, d, M, difference=difference)
+        tX = torch.tensor(X, requires_grad=True)
+        tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+        lev = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
+        (lev * torch.tensor(G)).sum().backward()
+        levels, gX, gY, gp0 = EG.seq_grad(X, Y, G, M, base, difference, p0, p1, diag=(kind == "diag"))
+        assert rel(levels, lev.detach()) < tol
+        assert rel(gX, tX.grad) < tol
+        if Y is not None:
+            assert rel(gY, tY.grad) < tol
+        if base in ("poly", "mix"):
+            assert abs(gp0 - kt.p0.grad.item()) < 1e-11 * max(1.0, abs(gp0))
+
+
+@pytest.mark.parametrize("base", BASES)
+@pytest.mark.parametrize("difference", [True, False])
+@pytest.mark.parametrize("increments", [False, True])
+def test_tensor_adjoints_equal_autograd(base, difference, increments):
+    rng = np.random.default_rng(12)
+    p0, p1 = _bp(base)
+    M, T, N, L, d = 4, 3, 4, 6, 3
+    lt = M * (M + 1) // 2
+    Z = rng.standard_normal((lt, T, 2, d) if increments else (lt, T, d)) * 0.5
+    X = rng.standard_normal((N, L, d)) * 0.5
+    G = rng.standard_normal((M + 1, T, N))
+    kt = _t_kern(base, d, M, difference=difference)
+    tZ, tX = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+    lev = kt.K_tens_vs_seq_levels(tZ, tX, increments)
+    (lev * torch.tensor(G)).sum().backward()
+    levels, gZ, gX, gp0 = EG.tvs_grad(Z, X, G, M, base, difference, increments, p0, p1)
+    assert rel(levels, lev.detach()) < 1e-12 and rel(gZ, tZ.grad) < 1e-12 and rel(gX, tX.grad) < 1e-12
+    if base in ("poly", "mix"):
+        assert abs(gp0 - kt.p0.grad.item()) < 1e-11 * max(1.0, abs(gp0))
+    # tensor vs tensor
+    G2 = rng.standard_normal((M + 1, T, T))
+    kt = _t_kern(base, d, M)
+    tZ = torch.tensor(Z, requires_grad=True)
+    (kt.K_tens_levels(tZ, increments) * torch.tensor(G2)).sum().backward()
+    gZ, gp0 = EG.tens_grad(Z, G2, M, base, increments, p0, p1)
+    assert rel(gZ, tZ.grad) < 1e-12
+    if base in ("poly", "mix"):
+        assert abs(gp0 - kt.p0.grad.item()) < 1e-10 * max(1.0, abs(gp0))
