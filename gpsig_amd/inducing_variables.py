@@ -52,6 +52,11 @@ class InducingSequences(SignatureInducing):
         self.len_inducing = Z.shape[1]
 
 
+def _is_kernel(kern):
+    # a SignatureKernel, or its trainable view gpsig_amd.autodiff.SignatureKernelModule (same methods, torch tensors)
+    return isinstance(kern, SignatureKernel) or isinstance(getattr(kern, "kern", None), SignatureKernel)
+
+
 def _mm(A, B):
     return torch.matmul(A, B) if _is_torch(A) or _is_torch(B) else np.matmul(A, B)
 
@@ -82,7 +87,7 @@ def _eye_like(n, ref):
 
 def Kuu(feat, kern, *, jitter=0.0):
     """Reference: inducing_variables.py:78-87 (tensors), :101-110 (sequences)."""
-    assert isinstance(kern, SignatureKernel)
+    assert _is_kernel(kern)
     if isinstance(feat, InducingTensors):
         if feat.learn_weights:
             Kzz = _mix_square(feat.W, kern.K_tens(feat.Z, return_levels=True, increments=feat.increments))
@@ -100,7 +105,7 @@ def Kuu(feat, kern, *, jitter=0.0):
 
 def Kuf(feat, kern, X_new):
     """Reference: inducing_variables.py:68-76 (tensors), :112-120 (sequences)."""
-    assert isinstance(kern, SignatureKernel)
+    assert _is_kernel(kern)
     if isinstance(feat, InducingTensors):
         if feat.learn_weights:
             return _mix_left(feat.W, kern.K_tens_vs_seq(feat.Z, X_new, return_levels=True, increments=feat.increments))
@@ -115,7 +120,7 @@ def Kuf(feat, kern, X_new):
 def Kuu_Kuf_Kff(feat, kern, X_new, *, jitter=0.0, full_f_cov=False):
     """Reference: inducing_variables.py:51-66 (tensors), :122-137 (sequences): the three matrices SVGP needs in
     one call.  (``tf.shape(X)`` at :63/:134 is an undefined name in the reference; X_new is what is meant.)"""
-    assert isinstance(kern, SignatureKernel)
+    assert _is_kernel(kern)
     if isinstance(feat, InducingTensors):
         if feat.learn_weights:
             Kzz, Kzx, Kxx = kern.K_tens_n_seq_covs(feat.Z, X_new, full_X_cov=full_f_cov, return_levels=True,

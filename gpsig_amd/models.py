@@ -5,7 +5,10 @@ The three covariances come from ``inducing_variables.Kuu_Kuf_Kff`` (HIP kernels)
 Cholesky of Kzz, the triangular solves, the matmuls of GPflow 1.5.1's ``conditionals.base_conditional`` and
 ``kullback_leiblers.gauss_kl`` (pinned by requirements.txt:8, not vendored; restated from their published
 algorithm) -- runs on the device through torch.linalg, i.e. rocSOLVER (potrf, trsm) and rocBLAS / hipBLASLt.
-Training (GPflow actions, TF optimisers, likelihood expectations) is out of scope.
+``SVGPModule`` is the trainable model: the ELBO of ``_build_likelihood`` (models.py:40-59) on top of
+``gpsig_amd.autodiff.SignatureKernelModule`` (HIP forward and backward kernels) and ``gpsig_amd.likelihoods``;
+``fit`` is a plain Adam loop (the reference drives TF optimisers through GPflow actions, gpsig/training.py --
+control plane, not rebuilt).
 """
 import numpy as np
 
@@ -129,3 +132,100 @@ class SVGP:
             return gauss_kl(q_mu, q_sqrt)
         Kzz = _dev(iv.Kuu(self.feature, self.kern, jitter=JITTER), self.device)
         return gauss_kl(q_mu, q_sqrt, K=Kzz)
+
+
+class SVGPModule(torch.nn.Module if torch is not None else object):
+    """Trainable ``gpsig.models.SVGP`` (gpsig/models.py:13-73): kernel hyper-parameters, inducing tensors / sequences,
+    optional level weights and the variational parameters are ``torch.nn.Parameter``s on the GPU.
+
+    :kern:        a ``gpsig_amd.kernels.SignatureKernel`` (wrapped) or a ``gpsig_amd.autodiff.SignatureKernelModule``
+    :feat:        ``InducingTensors`` / ``InducingSequences`` holding the initial Z (and ``learn_weights``)
+    :likelihood:  an object of ``gpsig_amd.likelihoods``
+    :num_data:    size of the full data set, for minibatch scaling of the data-fit term (models.py:57-58)
+    """
+
+    def __init__(self, kern, feat, likelihood, num_latent=1, q_diag=False, whiten=True, num_data=None, mean_function=None, device="cuda:0"):
+        super().__init__()
+        from .autodiff import SignatureKernelModule
+        if not isinstance(feat, (iv.InducingTensors, iv.InducingSequences)):
+            raise ValueError('feat must be of type either InducingTensors or InducingSequences')     # models.py:19-20
+        dev = torch.device(device)
+        self.kernel = kern if isinstance(kern, SignatureKernelModule) else SignatureKernelModule(kern, device=dev)
+        self.likelihood = likelihood
+        self.q_diag, self.whiten, self.num_data, self.mean_function = q_diag, whiten, num_data, mean_function
+        self._feat_cls = type(feat)
+        self._increments = bool(getattr(feat, "increments", False))
+        self._learn_weights = bool(feat.learn_weights)
+        self._num_levels = self.kernel.kern.num_levels
+        self.Z = torch.nn.Parameter(_dev(feat.Z, dev))
+        if self._learn_weights:
+            self.W = torch.nn.Parameter(_dev(feat.W, dev))
+        m = len(feat)
+        self.num_latent = num_latent
+        # gpflow.models.SVGP._init_variational_parameters
+        self.q_mu = torch.nn.Parameter(torch.zeros((m, num_latent), dtype=torch.float64, device=dev))
+        if q_diag:
+            self.q_sqrt = torch.nn.Parameter(torch.ones((m, num_latent), dtype=torch.float64, device=dev))
+        else:
+            self.q_sqrt = torch.nn.Parameter(torch.eye(m, dtype=torch.float64, device=dev)[None].repeat(num_latent, 1, 1))
+
+    def feature(self):
+        """The feature object the dispatch functions of ``inducing_variables`` expect, viewing the current parameters."""
+        if self._feat_cls is iv.InducingTensors:
+            f = iv.InducingTensors(self.Z, self._num_levels, increments=self._increments)
+        else:
+            f = iv.InducingSequences(self.Z, self._num_levels)
+        f.learn_weights = self._learn_weights
+        if self._learn_weights:
+            f.W = self.W
+        return f
+
+    def _q_sqrt(self):
+        return self.q_sqrt if self.q_diag else torch.tril(self.q_sqrt)                               # models.py:48/:66
+
+    def predict_f(self, X_new, full_cov=False, return_Kzz=False):
+        """models.py:62-73."""
+        Kzz, Kzx, Kxx = iv.Kuu_Kuf_Kff(self.feature(), self.kernel, X_new, jitter=JITTER, full_f_cov=full_cov)   # :65
+        f_mean, f_var = base_conditional(Kzx, Kzz, Kxx, self.q_mu, full_cov=full_cov, q_sqrt=self._q_sqrt(), white=self.whiten)
+        if self.mean_function is not None:
+            f_mean = f_mean + self.mean_function(X_new)
+        return (f_mean, f_var, Kzz) if return_Kzz else (f_mean, f_var)
+
+    def elbo(self, X, Y):
+        """models.py:40-59: sum of variational expectations, scaled to the full data set, minus the prior KL."""
+        if self.whiten:
+            f_mean, f_var = self.predict_f(X)
+            KL = gauss_kl(self.q_mu, self._q_sqrt())                                                 # :47-48
+        else:
+            f_mean, f_var, Kzz = self.predict_f(X, return_Kzz=True)
+            KL = gauss_kl(self.q_mu, self._q_sqrt(), K=Kzz)                                          # :50-51
+        var_exp = self.likelihood.variational_expectations(f_mean, f_var, Y)                         # :54
+        scale = float(self.num_data or X.shape[0]) / float(X.shape[0])                               # :57
+        return var_exp.sum() * scale - KL
+
+    def predict_y(self, X_new):
+        f_mean, f_var = self.predict_f(X_new)
+        return self.likelihood.predict_mean_and_var(f_mean, f_var)
+
+    def fit(self, X, Y, iterations=100, lr=1e-2, minibatch_size=None, seed=0, callback=None):
+        """Maximise the ELBO with Adam.  Returns the ELBO trace."""
+        opt = torch.optim.Adam(self.parameters(), lr=lr)
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        n = X.shape[0]
+        if self.num_data is None:
+            self.num_data = n
+        trace = []
+        for it in range(iterations):
+            if minibatch_size is not None and minibatch_size < n:
+                idx = torch.randperm(n, generator=gen)[:minibatch_size].to(X.device)
+                xb, yb = X[idx], Y[idx]
+            else:
+                xb, yb = X, Y
+            opt.zero_grad()
+            loss = -self.elbo(xb, yb)
+            loss.backward()
+            opt.step()
+            trace.append(-loss.item())
+            if callback is not None:
+                callback(it, trace[-1])
+        return trace

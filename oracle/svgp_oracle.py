@@ -45,3 +45,47 @@ def gauss_kl(q_mu, q_sqrt, K=None):
                 two_kl += np.sum(solve_triangular(Lp, Lq[r], lower=True) ** 2)
         two_kl += R * np.sum(np.log(np.diag(Lp) ** 2))
     return 0.5 * two_kl
+
+
+# ---- likelihoods (GPflow 1.5.1 gpflow/likelihoods.py, restated; 20-point Gauss-Hermite as GPflow's default) ----------
+def _gh(n=20):
+    return np.polynomial.hermite.hermgauss(n)
+
+
+def gaussian_variational_expectations(Fmu, Fvar, Y, variance):
+    return -0.5 * np.log(2 * np.pi) - 0.5 * np.log(variance) - 0.5 * ((Y - Fmu) ** 2 + Fvar) / variance
+
+
+def _inv_probit(x):
+    from scipy.special import erf
+    return 0.5 * (1.0 + erf(x / np.sqrt(2.0))) * (1 - 2e-3) + 1e-3
+
+
+def bernoulli_variational_expectations(Fmu, Fvar, Y):
+    x, w = _gh()
+    out = np.zeros_like(Fmu)
+    for xi, wi in zip(x, w):
+        p = _inv_probit(Fmu + np.sqrt(2.0 * Fvar) * xi)
+        out += wi / np.sqrt(np.pi) * np.log(np.where(Y == 1, p, 1 - p))
+    return out
+
+
+def multiclass_variational_expectations(Fmu, Fvar, Y, num_classes, epsilon=1e-3):
+    from scipy.special import erf
+    x, w = _gh()
+    N = Fmu.shape[0]
+    p = np.zeros((N, 1))
+    y = Y.reshape(-1).astype(int)
+    for n in range(N):
+        acc = 0.0
+        for xi, wi in zip(x, w):
+            X = Fmu[n, y[n]] + xi * np.sqrt(max(2.0 * Fvar[n, y[n]], 1e-10))
+            prod = 1.0
+            for k in range(num_classes):
+                if k == y[n]:
+                    continue
+                cdf = 0.5 * (1.0 + erf((X - Fmu[n, k]) / np.sqrt(max(Fvar[n, k], 1e-10)) / np.sqrt(2.0)))
+                prod *= cdf * (1 - 2e-4) + 1e-4
+            acc += wi / np.sqrt(np.pi) * prod
+        p[n, 0] = acc
+    return p * np.log(1.0 - epsilon) + (1.0 - p) * np.log(epsilon / (num_classes - 1.0))
