@@ -43,6 +43,7 @@ struct gpsig_ctx {
     int max_run = 0;
     int tens_lanes = -1;   // -1 auto, 0 sequence lanes, 1 tensor lanes
     int grad_scratch_mb = 4096;   // lattice scratch of one gradient launch
+    int grad_impl = 0;            // 0: fastest built variant, 1: storage-based reference variant
     std::string err;
     DevBuf buf[B_COUNT];
     std::vector<gpsig::SeqTask> host_tasks;

@@ -6,6 +6,14 @@
 // to cite, the formulas are in grad_core.hpp.  Host side only: staging, chunking by the scratch budget, launches.
 #include "ctx.hpp"
 #include "grad_kernels.hpp"
+#include "grad_wave_kernel.hpp"
+
+namespace gpsig {
+typedef hipError_t (*WaveLaunchFn)(const WaveGradArgs&, int, hipStream_t);
+WaveLaunchFn wave_lookup_inc(int G, int C, int DP, int LQ);
+WaveLaunchFn wave_lookup_ptd(int G, int C, int DP, int LQ);
+WaveLaunchFn wave_lookup_ptn(int G, int C, int DP, int LQ);
+}  // namespace gpsig
 
 using namespace gpsig;
 
@@ -67,6 +75,16 @@ int launch_tvs(gpsig_ctx* c, int DP, dim3 grid, const TvsGradArgs& a) {
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
 }
+// scratch-free tensor-vs-sequence gradient; built where the per-lane accumulators (M * E * DP doubles) fit the register file
+bool tvs_fused_available(int DP, int M, int E) { return M <= 4 && DP <= 8; }
+int launch_tvs_fused(gpsig_ctx* c, int DP, int E, dim3 grid, const TvsGradArgs& a) {
+    if (DP == 4 && E == 1) hipLaunchKernelGGL((tvs_pair_grad_fused_kernel<4, 4, 1>), grid, dim3(64), 0, c->stream, a);
+    else if (DP == 4) hipLaunchKernelGGL((tvs_pair_grad_fused_kernel<4, 4, 2>), grid, dim3(64), 0, c->stream, a);
+    else if (E == 1) hipLaunchKernelGGL((tvs_pair_grad_fused_kernel<8, 4, 1>), grid, dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL((tvs_pair_grad_fused_kernel<8, 4, 2>), grid, dim3(64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
 int launch_tens(gpsig_ctx* c, int DP, dim3 grid, const TensGradArgs& a) {
     switch (DP) {
         case 4: hipLaunchKernelGGL(tens_pair_grad_kernel<4>, grid, dim3(64), 0, c->stream, a); break;
@@ -94,6 +112,91 @@ int gbase_end(gpsig_ctx* c, const double* dev, double* user) {
     return GPSIG_OK;
 }
 
+
+// ---- wavefront-parallel path (grad_wave_kernel.hpp) ------------------------------------------------------------------------
+WaveLaunchFn wave_plan(int mode, int R2, int DP, int M, int* G, int* C) {
+    if (DP > 16 || M - 1 > 7) return nullptr;
+    static const int shapes[][2] = {{16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8}};
+    for (auto& sh : shapes) {
+        if (sh[0] * sh[1] < R2) continue;
+        WaveLaunchFn f = mode == MODE_INC ? wave_lookup_inc(sh[0], sh[1], DP, M - 1)
+                                          : (mode == MODE_PT_DIFF ? wave_lookup_ptd(sh[0], sh[1], DP, M - 1) : wave_lookup_ptn(sh[0], sh[1], DP, M - 1));
+        if (f) { *G = sh[0]; *C = sh[1]; return f; }
+    }
+    return nullptr;
+}
+
+template <int SIDE>
+int launch_contract(gpsig_ctx* c, int DP, dim3 grid, int block, size_t lds, const LamContractArgs& a) {
+    switch (DP) {
+        case 4: hipLaunchKernelGGL((lam_contract_kernel<4, SIDE>), grid, dim3(block), lds, c->stream, a); break;
+        case 8: hipLaunchKernelGGL((lam_contract_kernel<8, SIDE>), grid, dim3(block), lds, c->stream, a); break;
+        default: hipLaunchKernelGGL((lam_contract_kernel<16, SIDE>), grid, dim3(block), lds, c->stream, a); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+
+int seq_grad_wave(gpsig_ctx* c, const gpsig_params* p, WaveLaunchFn fn, int G, int C, int DP, int mode, const double* X, const double* Y, int64_t N1,
+                  int64_t N2, int L1, int L2, int d, bool diag, bool sym, const double* Gup, double* gX, double* gY, double* gbase) {
+    const int M = p->num_levels, dr = mode == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = L1 - dr, R2 = L2 - dr, TF = R1 + G - 1, PW = 64 / G;
+    HIPCHK(c, hipMemsetAsync(gX, 0, sizeof(double) * size_t(N1) * L1 * d, c->stream));
+    if (!diag && !sym) HIPCHK(c, hipMemsetAsync(gY, 0, sizeof(double) * size_t(N2) * L2 * d, c->stream));
+    if (R1 <= 0 || R2 <= 0) return GPSIG_OK;                 // empty lattice: the levels do not depend on the data
+    const size_t per_pair = sizeof(double) * size_t(R1) * R2;
+    const int64_t row_pairs = diag ? 1 : N2;
+    int64_t ni_max = int64_t(scratch_budget(c) / (per_pair * size_t(row_pairs)));
+    if (ni_max < 1) ni_max = 1;
+    if (ni_max > N1) ni_max = N1;
+    if (ni_max > 65535) ni_max = 65535;
+    void *lam, *scr;
+    CHK(ensure(c, B_GR5, per_pair * size_t(row_pairs) * size_t(ni_max) + 64, &lam));
+    const int64_t max_pairs = ni_max * row_pairs;
+    int64_t ngroups = max_pairs < 8192 ? max_pairs : 8192;
+    ngroups = (ngroups + PW - 1) / PW * PW;
+    const size_t slot = sizeof(double) * size_t(M > 1 ? M - 1 : 1) * TF * G * C;
+    CHK(ensure(c, B_GR6, slot * size_t(ngroups) + 64, &scr));
+    WaveGradArgs A;
+    memset(&A, 0, sizeof(A));
+    A.X = X; A.Y = Y; A.N1 = int(N1); A.N2 = int(N2); A.L1 = L1; A.L2 = L2; A.d = d;
+    A.M = M; A.kind = p->base_kernel; A.mode = mode; A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
+    A.diag = diag ? 1 : 0;
+    A.G = Gup; A.gm = diag ? N1 : N1 * N2; A.gi = diag ? 1 : N2; A.gj = diag ? 0 : 1;
+    A.scratch = static_cast<double*>(scr); A.lam = static_cast<double*>(lam);
+    LamContractArgs K;
+    memset(&K, 0, sizeof(K));
+    K.X = X; K.Y = Y; K.L1 = L1; K.L2 = L2; K.d = d; K.kind = p->base_kernel; K.mode = mode; K.p0 = A.p0; K.p1 = A.p1;
+    K.lam = A.lam; K.diag = A.diag; K.j0 = 0; K.nj = diag ? 1 : N2;
+    for (int64_t i0 = 0; i0 < N1; i0 += ni_max) {
+        const int64_t ni = (N1 - i0 < ni_max) ? N1 - i0 : ni_max;
+        A.pair0 = i0 * row_pairs; A.npairs = ni * row_pairs;
+        int64_t ng = A.npairs < ngroups ? A.npairs : ngroups;
+        ng = (ng + PW - 1) / PW * PW;
+        A.ngroups = int(ng);
+        hipError_t e = fn(A, int(ng / PW), c->stream);
+        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_wave_kernel launch failed: %s", hipGetErrorString(e));
+        K.i0 = i0; K.ni = ni;
+        auto slices = [](int64_t targets, int64_t partners) {
+            int64_t s = (2048 + targets - 1) / targets;
+            if (s > partners) s = partners;
+            if (s > 1024) s = 1024;
+            return s < 1 ? int64_t(1) : s;
+        };
+        // x side: targets i0..i0+ni, partners = all j
+        K.gT = gX; K.gbase = gbase;
+        K.nslices = int(diag ? 1 : slices(ni, N2));
+        int blk = L1 >= 256 ? 256 : int((L1 + 63) / 64 * 64);
+        CHK(launch_contract<0>(c, DP, dim3(unsigned(ni), unsigned(K.nslices)), blk, sizeof(double) * size_t(L2) * DP, K));
+        // y side: targets = all j (diag: the same i's), partners = i0..i0+ni
+        K.gT = gY; K.gbase = nullptr;
+        K.nslices = int(diag ? 1 : slices(N2, ni));
+        blk = L2 >= 256 ? 256 : int((L2 + 63) / 64 * 64);
+        CHK(launch_contract<1>(c, DP, dim3(unsigned(diag ? ni : N2), unsigned(K.nslices)), blk, sizeof(double) * size_t(L1) * DP, K));
+    }
+    return GPSIG_OK;
+}
+
 // shared body of the Gram and the diagonal gradient
 int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
              const void* G, void* gX, void* gY, double* g_base) {
@@ -116,9 +219,15 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     if (!diag && !sym) CHK(out_dev(c, B_OUT1, gY, yb, &dgY));
     double* dgb;
     CHK(gbase_begin(c, &dgb));
+    WaveLaunchFn wfn = nullptr;
+    int wG = 0, wC = 0;
+    if (c->grad_impl == 0 && N1 > 0 && N2 > 0) wfn = wave_plan(mode, L2 - (mode == MODE_PT_NODIFF ? 0 : 1), DP, M, &wG, &wC);
     if (N1 == 0 || N2 == 0) {
         if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
         if (dgY && yb) HIPCHK(c, hipMemsetAsync(dgY, 0, yb, c->stream));
+    } else if (wfn) {
+        CHK(seq_grad_wave(c, p, wfn, wG, wC, DP, mode, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, d,
+                          diag, sym, static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), dgb));
     } else {
         const int64_t s1 = pad64(N1), s2 = pad64(N2);
         void *xT, *yT = nullptr, *gxT, *gyT = nullptr;
@@ -268,7 +377,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
     } else {
         const int64_t s = pad64(N);
-        void *zp, *gzp, *xT, *gxT, *scr;
+        void *zp, *gzp, *xT, *gxT, *scr = nullptr;
         const size_t xtb = sizeof(double) * size_t(L) * DP * s;
         CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
         CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
@@ -279,12 +388,13 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
         HIPCHK(c, hipMemsetAsync(gxT, 0, xtb, c->stream));
         const int R = p->difference ? L - 1 : L;
+        const bool fused = c->grad_impl == 0 && tvs_fused_available(DP, M, E);
         const size_t per_t = sizeof(double) * size_t(lt + M * (M - 1) / 2) * size_t(R > 0 ? R : 0) * size_t(s);
         int64_t chunk = int64_t(scratch_budget(c) / (per_t ? per_t : 1));
         if (chunk < 1) chunk = 1;
         if (chunk > T) chunk = T;
         if (chunk > 65535) chunk = 65535;
-        CHK(ensure(c, B_GR4, per_t * size_t(chunk) + 64, &scr));
+        if (!fused) CHK(ensure(c, B_GR4, per_t * size_t(chunk) + 64, &scr));
         TvsGradArgs A;
         memset(&A, 0, sizeof(A));
         A.z = static_cast<const double*>(zp); A.gz = static_cast<double*>(gzp);
@@ -293,12 +403,17 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         A.T = int(T); A.N = int(N); A.L = L; A.M = M; A.kind = p->base_kernel; A.incr = increments ? 1 : 0; A.diff = p->difference ? 1 : 0;
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         A.G = static_cast<const double*>(dG); A.gm = T * N; A.gt = N; A.gn = 1;
-        A.scratch = static_cast<double*>(scr);
         A.gbase = dgb;
-        for (int64_t t0 = 0; t0 < T; t0 += chunk) {
-            const int64_t nt = (T - t0 < chunk) ? T - t0 : chunk;
-            A.t0 = int(t0); A.nt = int(nt); A.pairs = s * nt;
-            CHK(launch_tvs(c, DP, dim3(unsigned(s / 64), unsigned(nt)), A));
+        if (fused) {
+            if (T > 65535) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 65535 inducing tensors");
+            CHK(launch_tvs_fused(c, DP, E, dim3(unsigned(s / 64), unsigned(T)), A));
+        } else {
+            A.scratch = static_cast<double*>(scr);
+            for (int64_t t0 = 0; t0 < T; t0 += chunk) {
+                const int64_t nt = (T - t0 < chunk) ? T - t0 : chunk;
+                A.t0 = int(t0); A.nt = int(nt); A.pairs = s * nt;
+                CHK(launch_tvs(c, DP, dim3(unsigned(s / 64), unsigned(nt)), A));
+            }
         }
         CHK(unpad_rows(c, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
         CHK(from_timemajor(c, static_cast<const double*>(gxT), static_cast<double*>(dgX), N, L, d, DP, s));

@@ -76,6 +76,15 @@ __global__ void __launch_bounds__(64) tvs_pair_grad_kernel(const TvsGradArgs A) 
     P.contract();
 }
 
+// scratch-free variant: grid (ceil(N / 64), T); block 64
+template <int DP, int MMAX, int E>
+__global__ void __launch_bounds__(64) tvs_pair_grad_fused_kernel(const TvsGradArgs A) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    const int t = blockIdx.y;
+    TvsPairGradFused<DP, MMAX, E> P(A, t, n < A.N ? n : 0, n < A.N);
+    P.run();
+}
+
 // grid (ceil(T / 64), T); block 64: lanes = t2, blockIdx.y = t
 template <int DP>
 __global__ void __launch_bounds__(64) tens_pair_grad_kernel(const TensGradArgs A) {

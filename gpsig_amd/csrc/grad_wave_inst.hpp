@@ -1,0 +1,27 @@
+// grad_wave_inst.hpp -- instantiation list of seq_grad_wave_kernel for one lattice mode (included by grad_wave_inst_*.hip)
+#pragma once
+#include "grad_wave_kernel.hpp"
+
+namespace gpsig {
+typedef hipError_t (*WaveLaunchFn)(const WaveGradArgs&, int, hipStream_t);
+
+template <int G, int C, int DP, int LQ, int MODE>
+hipError_t wave_launch(const WaveGradArgs& a, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL((seq_grad_wave_kernel<G, C, DP, LQ, MODE>), dim3(nblocks), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// (G, C, DP): lanes per pair, columns per lane, padded feature count.  C * DP bounded by the register file.
+#define GPSIG_WAVE_SHAPES(X) \
+    X(16, 2, 4) X(16, 2, 8) X(16, 2, 16) X(16, 4, 4) X(16, 4, 8) X(16, 4, 16) \
+    X(64, 2, 4) X(64, 2, 8) X(64, 2, 16) X(64, 4, 16) X(64, 8, 4) X(64, 8, 8)
+
+template <int MODE>
+WaveLaunchFn wave_lookup_mode(int G, int C, int DP, int LQ) {
+#define X_W(G_, C_, D_)                                                              \
+    if (G == G_ && C == C_ && DP == D_) return LQ <= 4 ? wave_launch<G_, C_, D_, 4, MODE> : wave_launch<G_, C_, D_, 7, MODE>;
+    GPSIG_WAVE_SHAPES(X_W)
+#undef X_W
+    return nullptr;
+}
+}  // namespace gpsig

@@ -1,0 +1,247 @@
+// grad_wave_kernel.hpp -- gfx950 kernels of the wavefront-parallel sequence-pair gradient.
+//
+//   seq_grad_wave_kernel   the two lattice sweeps of grad_wave_core.hpp: 64/G pairs per wavefront, one DPP shift per
+//                          handed-over word and step (row_shr/row_shl for G = 16, wave_shr/wave_shl for G = 64), forward
+//                          Q's through an HBM scratch slot per pair group, Lam[a][b] out.
+//   lam_contract_kernel    Lam -> gradients of the observations: Gam = adjoint of the double increment
+//                          (signature_algs.py:26), times the base kernel's derivatives (grad_core.hpp: base_eval_grad).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "grad_wave_core.hpp"
+
+namespace gpsig {
+
+template <int G>
+__device__ __forceinline__ double wave_from_left(double v) {      // lane l <- lane l-1, 0 into the first lane of each group
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (G == 16) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true);     // row_shr:1
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);     // wave_shr:1
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    }
+    return __hiloint2double(hi, lo);
+}
+template <int G>
+__device__ __forceinline__ double wave_from_right(double v) {     // lane l <- lane l+1, 0 into the last lane of each group
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (G == 16) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x101, 0xf, 0xf, true);     // row_shl:1
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x101, 0xf, 0xf, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);     // wave_shl:1
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+template <int DP>
+__device__ __forceinline__ void wave_load_point(const double* __restrict__ S, int64_t seq, int L, int d, int r, double (&v)[DP]) {
+    const double* p = S + (seq * L + r) * d;
+    const bool ok = r >= 0 && r < L;
+#pragma unroll
+    for (int f = 0; f < DP; ++f) v[f] = (ok && f < d) ? p[f] : 0.0;
+}
+
+// grid: ngroups / (64 / G) workgroups of one wavefront
+template <int G, int C, int DP, int LQ, int MODE>
+__global__ void __launch_bounds__(64) seq_grad_wave_kernel(const WaveGradArgs A) {
+    constexpr int PW = 64 / G;
+    const int lane = threadIdx.x, lam = lane % G;
+    const int grp = blockIdx.x * PW + lane / G;
+    const int dr = MODE == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = A.L1 - dr, R2 = A.L2 - dr, M = A.M;
+    const int TF = R1 + G - 1;
+    double* scr = A.scratch + size_t(grp) * size_t(M - 1) * TF * G * C;
+    auto slot = [&](int m, int tf, int l, int c) -> double& { return scr[((size_t(m) * TF + tf) * G + l) * C + c]; };
+    const int64_t rounds = (A.npairs + A.ngroups - 1) / A.ngroups;
+
+    WaveDm<C, DP, MODE> dmg;
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t pp = rd * A.ngroups + grp;
+        const bool have = pp < A.npairs;
+        const int64_t pg = A.pair0 + (have ? pp : 0);
+        const int64_t i = A.diag ? pg : pg / A.N2, j = A.diag ? pg : pg % A.N2;
+        {
+            double ypts[C + 1][DP];
+#pragma unroll
+            for (int c = 0; c <= C; ++c) wave_load_point<DP>(A.Y, j, A.L2, A.d, C * lam + c, ypts[c]);
+            int nv = R2 - C * lam;
+            dmg.set_y(ypts, nv < 0 ? 0 : (nv > C ? C : nv));
+        }
+        double clev[LQ + 2];
+#pragma unroll
+        for (int p = 0; p < LQ + 2; ++p) clev[p] = (have && p >= 1 && p <= M) ? A.G[p * A.gm + i * A.gi + j * A.gj] : 0.0;
+
+        // ---- forward sweep
+        {
+            WaveFwd<C, LQ> fw;
+            fw.reset();
+            if (MODE != MODE_PT_NODIFF) {
+                double x0[DP];
+                wave_load_point<DP>(A.X, i, A.L1, A.d, 0, x0);
+                dmg.prime(x0, A.kind, A.p0, A.p1);
+            }
+            for (int t = 0; t < TF; ++t) {
+                double cin[LQ + 2];
+                cin[0] = 0.0;
+#pragma unroll
+                for (int m = 1; m < LQ + 2; ++m) cin[m] = wave_from_left<G>(fw.sout[m]);
+                const int a = t - lam;
+                if (a >= 0 && a < R1) {
+                    double xn[DP], dm[C];
+                    wave_load_point<DP>(A.X, i, A.L1, A.d, a + dr, xn);
+                    dmg.row(xn, true, A.kind, A.p0, A.p1, dm);
+                    fw.step(dm, cin, M);
+#pragma unroll
+                    for (int m = 0; m < LQ; ++m)
+                        if (m < M - 1) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) slot(m, t, lam, c) = fw.q[m][c];
+                        }
+                }
+            }
+        }
+        __threadfence();        // the backward sweep reads what other lanes of this wavefront stored
+
+        // ---- backward sweep
+        {
+            WaveBwd<C, LQ> bw;
+            bw.reset();
+            if (MODE != MODE_PT_NODIFF) {
+                double xl[DP];
+                wave_load_point<DP>(A.X, i, A.L1, A.d, R1, xl);
+                dmg.prime(xl, A.kind, A.p0, A.p1);
+            }
+            double* lamrow = A.lam + size_t(have ? pp : 0) * R1 * R2;
+            for (int u = 0; u < TF; ++u) {
+                double sin[LQ];
+#pragma unroll
+                for (int p = 0; p < LQ; ++p) sin[p] = wave_from_right<G>(bw.svout[p]);
+                const int a = R1 - 1 - (u - (G - 1 - lam));
+                if (a >= 0 && a < R1) {
+                    double xn[DP], dm[C], qfd[LQ][C], lv[C];
+                    wave_load_point<DP>(A.X, i, A.L1, A.d, a, xn);
+                    dmg.row(xn, false, A.kind, A.p0, A.p1, dm);
+                    const int tf = a - 1 + lam;          // forward step at which this lane stored row a-1
+#pragma unroll
+                    for (int m = 0; m < LQ; ++m)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            double v = 0.0;
+                            if (m < M - 1 && a > 0) {
+                                if (c > 0) v = slot(m, tf, lam, c - 1);
+                                else if (lam > 0) v = slot(m, tf - 1, lam - 1, C - 1);
+                            }
+                            qfd[m][c] = v;
+                        }
+                    bw.step(dm, clev, qfd, sin, M, lv);
+                    if (have) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            if (c < dmg.nvalid) lamrow[size_t(a) * R2 + C * lam + c] = lv[c];
+                    }
+                }
+            }
+        }
+        __threadfence();        // the slot is rewritten by the next pair
+    }
+}
+
+// One launch contracts Lam of a block of pairs into the gradient of ONE side.
+//   SIDE 0: target = x.  grid (target sequences, partner slices), threads = target points p; inner loops: partner sequences, partner points q.
+//   SIDE 1: target = y.  Same with the roles (and the indices of Lam) exchanged.
+// Lam of pair (i, j) sits at lam + ((i - i0) * nj + (j - j0)) * R1 * R2 (diag: pair i at (i - i0) * R1 * R2).
+struct LamContractArgs {
+    const double* X; const double* Y;      // (N, L, d) row-major scaled observations
+    int L1, L2, d, kind, mode;
+    double p0, p1;
+    const double* lam;
+    int64_t i0, ni, j0, nj;                // block of pairs covered by lam (diag: j == i, nj ignored)
+    int diag;
+    double* gT;                            // gradient of the target side, user layout (N, L, d), accumulated with atomics
+    double* gbase;                         // optional; only SIDE 0 adds to it
+    int nslices;                           // partner sequences are dealt round-robin to gridDim.y slices
+};
+
+template <int DP, int SIDE>
+__global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs A) {
+    extern __shared__ double part[];       // one partner sequence: Lp x DP
+    const int dr = A.mode == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = A.L1 - dr, R2 = A.L2 - dr;
+    const int Lt = SIDE == 0 ? A.L1 : A.L2, Lp = SIDE == 0 ? A.L2 : A.L1;
+    const int64_t tseq = (SIDE == 0 ? A.i0 : A.j0) + blockIdx.x;          // target sequence
+    const double* T = SIDE == 0 ? A.X : A.Y;
+    const double* P = SIDE == 0 ? A.Y : A.X;
+    const int64_t np = A.diag ? 1 : (SIDE == 0 ? A.nj : A.ni);
+    const bool nodiff = A.mode == MODE_PT_NODIFF;
+    double gp0 = 0.0;
+    for (int tp0 = 0; tp0 < Lt; tp0 += blockDim.x) {                      // target points in tiles of blockDim.x
+        const int tp = tp0 + threadIdx.x;
+        const bool tv = tp < Lt;
+        double xt[DP], acc[DP], accs = 0.0, ts = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) {
+            xt[f] = (tv && f < A.d) ? T[(tseq * Lt + tp) * A.d + f] : 0.0;
+            acc[f] = 0.0;
+            ts = fma(xt[f], xt[f], ts);
+        }
+        for (int64_t k = blockIdx.y; k < np; k += A.nslices) {
+            const int64_t pseq = A.diag ? tseq : (SIDE == 0 ? A.j0 : A.i0) + k;
+            __syncthreads();
+            for (int e = threadIdx.x; e < Lp * DP; e += blockDim.x) {
+                const int q = e / DP, f = e % DP;
+                part[e] = f < A.d ? P[(pseq * Lp + q) * A.d + f] : 0.0;
+            }
+            __syncthreads();
+            const int64_t pi = A.diag ? (tseq - A.i0) : (SIDE == 0 ? (tseq - A.i0) * A.nj + k : k * A.nj + (tseq - A.j0));
+            const double* lm = A.lam + pi * int64_t(R1) * R2;
+            if (tv) {
+                // Gam[p][q] = Lam[p-1][q-1] - Lam[p-1][q] - Lam[p][q-1] + Lam[p][q]  (zero outside the lattice); nodiff: Gam = Lam
+                // SIDE 0: p = tp fixed, q runs; SIDE 1: q = tp fixed, p runs.
+                double lo_prev = 0.0, hi_prev = 0.0;      // Lam at (fixed-1, run-1), (fixed, run-1)
+                for (int r = 0; r < Lp; ++r) {
+                    double gam;
+                    if (nodiff) {
+                        gam = SIDE == 0 ? lm[int64_t(tp) * R2 + r] : lm[int64_t(r) * R2 + tp];
+                    } else {
+                        // along the running index r (cell index r-1 | r), across the fixed index (cell index tp-1 | tp)
+                        const int Rr = SIDE == 0 ? R2 : R1, Rf = SIDE == 0 ? R1 : R2;
+                        double lo = 0.0, hi = 0.0;                   // Lam at (fixed-1, r), (fixed, r)
+                        if (r < Rr) {
+                            if (tp > 0) lo = SIDE == 0 ? lm[int64_t(tp - 1) * R2 + r] : lm[int64_t(r) * R2 + tp - 1];
+                            if (tp < Rf) hi = SIDE == 0 ? lm[int64_t(tp) * R2 + r] : lm[int64_t(r) * R2 + tp];
+                        }
+                        gam = (lo_prev - lo) - (hi_prev - hi);
+                        lo_prev = lo;
+                        hi_prev = hi;
+                    }
+                    const double* yq = part + r * DP;
+                    double in = 0.0, ps = 0.0;
+#pragma unroll
+                    for (int f = 0; f < DP; ++f) { in = fma(xt[f], yq[f], in); ps = fma(yq[f], yq[f], ps); }
+                    // derivative with respect to the target point; base_eval_grad's first argument is x
+                    const BaseGrad g = SIDE == 0 ? base_eval_grad(A.kind, in, ts, ps, A.p0, A.p1) : base_eval_grad(A.kind, in, ps, ts, A.p0, A.p1);
+                    const double w = gam * (g.cy - g.cd);
+                    accs = fma(gam, (SIDE == 0 ? g.cx : g.cx2) + g.cd, accs);
+                    if (SIDE == 0) gp0 = fma(gam, g.dp0, gp0);
+#pragma unroll
+                    for (int f = 0; f < DP; ++f) acc[f] = fma(w, yq[f], acc[f]);
+                }
+            }
+        }
+        if (tv) {
+#pragma unroll
+            for (int f = 0; f < DP; ++f)
+                if (f < A.d) atomicAdd(&A.gT[(tseq * Lt + tp) * A.d + f], fma(accs, xt[f], acc[f]));
+        }
+    }
+    if (SIDE == 0 && A.gbase) {
+        grad_add(&A.gbase[0], gp0, true, true);          // one atomic per wavefront
+    }
+}
+
+}  // namespace gpsig

@@ -3,9 +3,12 @@
 // of atomics, so the adjoint recursions can be checked against torch.autograd on a machine without a GPU.
 #include <cstdint>
 #include <cstring>
+#include <array>
+#include <algorithm>
 #include <vector>
 
 #include "grad_core.hpp"
+#include "grad_wave_core.hpp"
 
 using namespace gpsig;
 
@@ -63,6 +66,13 @@ void tvs_run(TvsGradArgs& A, double* levels_out) {
                 for (int m = 0; m <= A.M; ++m) levels_out[(size_t(m) * A.T + t) * A.N + n] = lev[m];
         }
 }
+template <int DP, int E>
+void tvs_run_fused(TvsGradArgs& A, double* levels_out) {
+    A.levels = levels_out;
+    A.pairs = int64_t(A.T) * A.N; A.level_t = A.N; A.level_n = 1;
+    for (int t = 0; t < A.T; ++t)
+        for (int n = 0; n < A.N; ++n) TvsPairGradFused<DP, 4, E>(A, t, n, true).run();
+}
 template <int DP>
 void tens_run(TensGradArgs& A) {
     for (int t = 0; t < A.T; ++t)
@@ -108,7 +118,7 @@ int emu_seq_grad(const double* X, const double* Y, int N1, int N2, int L1, int L
 
 // Z (lt, T, [2,] d), X (N, L, d), G (M+1, T, N)
 int emu_tvs_grad(const double* Z, const double* X, int T, int N, int L, int d, int M, int kind, int incr, int diff, double p0, double p1,
-                 const double* G, double* gZ, double* gX, double* levels_out, double* gbase) {
+                 const double* G, double* gZ, double* gX, double* levels_out, double* gbase, int fused) {
     const int DP = pad_of(d), lt = M * (M + 1) / 2, E = incr ? 2 : 1;
     const int64_t rows = int64_t(lt) * T * E;
     std::vector<double> zp = pad_rows(Z, rows, d, DP), gzp(zp.size(), 0.0), xT = timemajor(X, N, L, d, DP), gxT(xT.size(), 0.0);
@@ -122,7 +132,13 @@ int emu_tvs_grad(const double* Z, const double* X, int T, int N, int L, int d, i
     A.G = G; A.gm = int64_t(T) * N; A.gt = N; A.gn = 1;
     A.scratch = scr.data();
     A.gbase = gb;
-    switch (DP) {
+    if (fused) {
+        if (M > 4 || DP > 8) return -2;
+        if (DP == 4 && E == 1) tvs_run_fused<4, 1>(A, levels_out);
+        else if (DP == 4) tvs_run_fused<4, 2>(A, levels_out);
+        else if (E == 1) tvs_run_fused<8, 1>(A, levels_out);
+        else tvs_run_fused<8, 2>(A, levels_out);
+    } else switch (DP) {
         case 4: tvs_run<4>(A, levels_out); break;
         case 8: tvs_run<8>(A, levels_out); break;
         case 16: tvs_run<16>(A, levels_out); break;
@@ -159,3 +175,141 @@ int emu_tens_grad(const double* Z, int T, int d, int M, int kind, int incr, doub
 }
 
 }  // extern "C"
+
+namespace {
+// lock-step emulation of one pair group of the wave kernel: G lanes, C columns each
+template <int G, int C, int DP, int LQ, int MODE>
+void wave_pair(const double* X, const double* Y, int i, int j, int L1, int L2, int d, int M, int kind, double p0, double p1,
+               const double* clev_in /* M+1 */, std::vector<double>& lam_out) {
+    const int dr = MODE == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = L1 - dr, R2 = L2 - dr, TF = R1 + G - 1;
+    auto load = [&](const double* S, int seq, int L, int r, double (&v)[DP]) {
+        for (int f = 0; f < DP; ++f) v[f] = (r >= 0 && r < L && f < d) ? S[(size_t(seq) * L + r) * d + f] : 0.0;
+    };
+    std::vector<WaveDm<C, DP, MODE>> dm(G);
+    std::vector<double> scr(size_t(M > 1 ? M - 1 : 1) * TF * G * C, 0.0);
+    auto slot = [&](int m, int tf, int l, int c) -> double& { return scr[((size_t(m) * TF + tf) * G + l) * C + c]; };
+    double clev[LQ + 2];
+    for (int p = 0; p < LQ + 2; ++p) clev[p] = (p >= 1 && p <= M) ? clev_in[p] : 0.0;
+    for (int l = 0; l < G; ++l) {
+        double ypts[C + 1][DP];
+        for (int c = 0; c <= C; ++c) load(Y, j, L2, C * l + c, ypts[c]);
+        int nv = R2 - C * l;
+        dm[l].set_y(ypts, nv < 0 ? 0 : (nv > C ? C : nv));
+    }
+    lam_out.assign(size_t(R1) * R2, 0.0);
+    {   // forward
+        std::vector<WaveFwd<C, LQ>> fw(G);
+        for (int l = 0; l < G; ++l) {
+            fw[l].reset();
+            if (MODE != MODE_PT_NODIFF) { double x0[DP]; load(X, i, L1, 0, x0); dm[l].prime(x0, kind, p0, p1); }
+        }
+        for (int t = 0; t < TF; ++t) {
+            std::vector<std::array<double, LQ + 2>> snap(G);
+            for (int l = 0; l < G; ++l)
+                for (int m = 0; m < LQ + 2; ++m) snap[l][m] = l > 0 ? fw[l - 1].sout[m] : 0.0;
+            for (int l = 0; l < G; ++l) {
+                const int a = t - l;
+                if (a < 0 || a >= R1) continue;
+                double cin[LQ + 2], xn[DP], dmv[C];
+                for (int m = 0; m < LQ + 2; ++m) cin[m] = snap[l][m];
+                cin[0] = 0.0;
+                load(X, i, L1, a + dr, xn);
+                dm[l].row(xn, true, kind, p0, p1, dmv);
+                fw[l].step(dmv, cin, M);
+                for (int m = 0; m < LQ; ++m)
+                    if (m < M - 1)
+                        for (int c = 0; c < C; ++c) slot(m, t, l, c) = fw[l].q[m][c];
+            }
+        }
+    }
+    {   // backward
+        std::vector<WaveBwd<C, LQ>> bw(G);
+        for (int l = 0; l < G; ++l) {
+            bw[l].reset();
+            if (MODE != MODE_PT_NODIFF) { double xl[DP]; load(X, i, L1, R1, xl); dm[l].prime(xl, kind, p0, p1); }
+        }
+        for (int u = 0; u < TF; ++u) {
+            std::vector<std::array<double, LQ>> snap(G);
+            for (int l = 0; l < G; ++l)
+                for (int p = 0; p < LQ; ++p) snap[l][p] = l < G - 1 ? bw[l + 1].svout[p] : 0.0;
+            for (int l = 0; l < G; ++l) {
+                const int a = R1 - 1 - (u - (G - 1 - l));
+                if (a < 0 || a >= R1) continue;
+                double sin[LQ], xn[DP], dmv[C], qfd[LQ][C], lv[C];
+                for (int p = 0; p < LQ; ++p) sin[p] = snap[l][p];
+                load(X, i, L1, a, xn);
+                dm[l].row(xn, false, kind, p0, p1, dmv);
+                const int tf = a - 1 + l;
+                for (int m = 0; m < LQ; ++m)
+                    for (int c = 0; c < C; ++c) {
+                        double v = 0.0;
+                        if (m < M - 1 && a > 0) {
+                            if (c > 0) v = slot(m, tf, l, c - 1);
+                            else if (l > 0) v = slot(m, tf - 1, l - 1, C - 1);
+                        }
+                        qfd[m][c] = v;
+                    }
+                bw[l].step(dmv, clev, qfd, sin, M, lv);
+                for (int c = 0; c < C; ++c)
+                    if (c < dm[l].nvalid) lam_out[size_t(a) * R2 + C * l + c] = lv[c];
+            }
+        }
+    }
+}
+
+template <int G, int C, int DP, int LQ>
+void wave_pair_mode(int mode, const double* X, const double* Y, int i, int j, int L1, int L2, int d, int M, int kind, double p0, double p1,
+                    const double* clev, std::vector<double>& lam) {
+    if (mode == MODE_INC) wave_pair<G, C, DP, LQ, MODE_INC>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, lam);
+    else if (mode == MODE_PT_DIFF) wave_pair<G, C, DP, LQ, MODE_PT_DIFF>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, lam);
+    else wave_pair<G, C, DP, LQ, MODE_PT_NODIFF>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, lam);
+}
+}  // namespace
+
+extern "C" {
+// The wave formulation (grad_wave_core.hpp) for the lattice sweeps, followed by the per-pair contraction of grad_core.hpp.
+// Same contract as emu_seq_grad.  (Gg, Cc) in {(16,2), (16,4), (64,2)}; returns -2 for anything else or if the lattice does not fit.
+int emu_seq_grad_wave(const double* X, const double* Y, int N1, int N2, int L1, int L2, int d, int M, int kind, int mode, double p0, double p1,
+                      int diag, const double* G, double* gX, double* gY, double* gbase, int Gg, int Cc) {
+    const int DP = pad_of(d);
+    const bool sym = !diag && !Y;
+    if (diag || sym) { N2 = N1; L2 = L1; Y = X; }
+    const int dr = mode == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = L1 - dr, R2 = L2 - dr;
+    if (DP != 4 && DP != 8) return -2;
+    if (R2 > Gg * Cc || M > 8) return -2;
+    std::vector<double> xT = timemajor(X, N1, L1, d, DP), yT, gxT(xT.size(), 0.0), gyT;
+    const bool two = !diag && !sym;
+    if (two) { yT = timemajor(Y, N2, L2, d, DP); gyT.assign(yT.size(), 0.0); }
+    double gb[2] = {0, 0};
+    SeqGradArgs A;
+    memset(&A, 0, sizeof(A));
+    A.xT = xT.data(); A.yT = two ? yT.data() : xT.data();
+    A.gxT = gxT.data(); A.gyT = two ? gyT.data() : gxT.data();
+    A.xstride = N1; A.ystride = N2;
+    A.N1 = N1; A.N2 = N2; A.L1 = L1; A.L2 = L2; A.M = M; A.kind = kind; A.mode = mode; A.p0 = p0; A.p1 = p1;
+    A.diag = diag; A.pairs = 1; A.gbase = gb;
+    std::vector<double> lam, clev(M + 1);
+    for (int i = 0; i < N1; ++i)
+        for (int j = diag ? i : 0; j < (diag ? i + 1 : N2); ++j) {
+            for (int m = 0; m <= M; ++m) clev[m] = diag ? G[size_t(m) * N1 + i] : G[(size_t(m) * N1 + i) * N2 + j];
+#define WP(GG, CC, DD, LL) wave_pair_mode<GG, CC, DD, LL>(mode, X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev.data(), lam)
+            const bool small = M <= 5;
+            if (Gg == 16 && Cc == 2) { if (DP == 4) { if (small) WP(16, 2, 4, 4); else WP(16, 2, 4, 7); } else { if (small) WP(16, 2, 8, 4); else WP(16, 2, 8, 7); } }
+            else if (Gg == 16 && Cc == 4) { if (DP == 4) { if (small) WP(16, 4, 4, 4); else WP(16, 4, 4, 7); } else { if (small) WP(16, 4, 8, 4); else WP(16, 4, 8, 7); } }
+            else if (Gg == 64 && Cc == 2) { if (DP == 4) { if (small) WP(64, 2, 4, 4); else WP(64, 2, 4, 7); } else { if (small) WP(64, 2, 8, 4); else WP(64, 2, 8, 7); } }
+            else return -2;
+#undef WP
+            std::vector<double> scr(size_t(M) * (R1 > 0 ? R1 : 0) * (R2 > 0 ? R2 : 0) + 8, 0.0);
+            std::copy(lam.begin(), lam.end(), scr.begin());           // slot 0 = Lam
+            A.scratch = scr.data();
+            auto run = [&](auto P) { P.contract(); };
+            if (DP == 4) run(SeqPairGrad<4>(A, i, j, 0, true)); else run(SeqPairGrad<8>(A, i, j, 0, true));
+        }
+    from_timemajor(gxT, gX, N1, L1, d, DP);
+    if (two) from_timemajor(gyT, gY, N2, L2, d, DP);
+    if (gbase) { gbase[0] = gb[0]; gbase[1] = gb[1]; }
+    return 0;
+}
+}

@@ -18,7 +18,8 @@ def lib():
     global _lib
     if _lib is None:
         so = os.path.join(EMU_DIR, "libemu_grad.so")
-        srcs = [os.path.join(EMU_DIR, "emu_grad.cpp"), os.path.join(CSRC, "grad_core.hpp"), os.path.join(CSRC, "seq_core.hpp")]
+        srcs = [os.path.join(EMU_DIR, "emu_grad.cpp"), os.path.join(CSRC, "grad_core.hpp"), os.path.join(CSRC, "grad_wave_core.hpp"),
+                os.path.join(CSRC, "seq_core.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + CSRC, "-o", so, srcs[0]])
         _lib = C.CDLL(so)
@@ -46,12 +47,14 @@ def seq_grad(X, Y, G, M, base, difference, p0=0.0, p1=0.0, diag=False):
     return lev, gX, gY, gb[0]
 
 
-def tvs_grad(Z, X, G, M, base, difference, increments, p0=0.0, p1=0.0):
+def tvs_grad(Z, X, G, M, base, difference, increments, p0=0.0, p1=0.0, fused=False):
     Z, X, G = (np.ascontiguousarray(a, np.float64) for a in (Z, X, G))
     T, (N, L, d) = Z.shape[1], X.shape
     gZ, gX, lev, gb = np.zeros_like(Z), np.zeros_like(X), np.zeros_like(G), np.zeros(2)
-    lib().emu_tvs_grad(_ptr(Z), _ptr(X), T, N, L, d, M, BASE_IDS[base], int(increments), int(difference), C.c_double(p0), C.c_double(p1),
-                       _ptr(G), _ptr(gZ), _ptr(gX), _ptr(lev), _ptr(gb))
+    rc = lib().emu_tvs_grad(_ptr(Z), _ptr(X), T, N, L, d, M, BASE_IDS[base], int(increments), int(difference), C.c_double(p0), C.c_double(p1),
+                            _ptr(G), _ptr(gZ), _ptr(gX), _ptr(lev), _ptr(gb), int(fused))
+    if rc != 0:
+        raise NotImplementedError("no such emulator variant")
     return lev, gZ, gX, gb[0]
 
 
@@ -61,3 +64,18 @@ def tens_grad(Z, G, M, base, increments, p0=0.0, p1=0.0):
     gZ, gb = np.zeros_like(Z), np.zeros(2)
     lib().emu_tens_grad(_ptr(Z), T, d, M, BASE_IDS[base], int(increments), C.c_double(p0), C.c_double(p1), _ptr(G), _ptr(gZ), _ptr(gb))
     return gZ, gb[0]
+
+
+def seq_grad_wave(X, Y, G, M, base, difference, p0=0.0, p1=0.0, diag=False, group=16, cols=4):
+    """The wave formulation (skewed forward sweep, oppositely skewed backward sweep).  -> gX, gY, g_p0"""
+    X = np.ascontiguousarray(X, np.float64)
+    Y = None if Y is None else np.ascontiguousarray(Y, np.float64)
+    G = np.ascontiguousarray(G, np.float64)
+    N1, L1, d = X.shape
+    N2, L2 = (N1, L1) if Y is None else Y.shape[:2]
+    gX, gY, gb = np.zeros_like(X), (None if Y is None else np.zeros_like(Y)), np.zeros(2)
+    rc = lib().emu_seq_grad_wave(_ptr(X), _ptr(Y), N1, N2, L1, L2, d, M, BASE_IDS[base], lattice_mode(base, difference), C.c_double(p0), C.c_double(p1),
+                                 int(diag), _ptr(G), _ptr(gX), _ptr(gY), _ptr(gb), int(group), int(cols))
+    if rc != 0:
+        raise NotImplementedError("wave emulator: unsupported shape")
+    return gX, gY, gb[0]

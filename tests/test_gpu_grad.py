@@ -344,3 +344,32 @@ def test_svgp_fit_learns_a_toy_classification():
     fm, fv = sv.predict_f(X)
     fm2, fv2 = model.predict_f(Xg)
     assert rel(fm, fm2) < 1e-8 and rel(fv, fv2) < 1e-8
+
+
+@pytest.mark.parametrize("base,difference", [("linear", True), ("rbf", True), ("rbf", False), ("matern52", True), ("linear", False)])
+def test_wave_and_storage_gradient_kernels_agree(base, difference):
+    """The wavefront-parallel path (default) against the one-pair-per-thread storage path, over the kernel shapes the planner
+    can pick: 16 or 64 lanes per pair, 2..8 columns per lane, padded feature counts 4 / 8 / 16, more than 5 levels."""
+    rng = np.random.default_rng(50)
+    ctx = _host_ctx()
+    for (M, N1, N2, L1, L2, d, kind) in [(4, 9, 7, 20, 31, 3, "cross"), (5, 6, 6, 64, 64, 8, "sym"), (3, 70, 70, 50, 50, 6, "diag"), (7, 3, 4, 12, 100, 2, "cross"),
+                                           (2, 2, 3, 40, 200, 12, "cross"), (3, 2, 2, 33, 400, 5, "cross"), (4, 5, 4, 1 + int(difference), 9, 3, "cross")]:
+        X = rng.standard_normal((N1, L1, d)) * 0.3
+        Y = rng.standard_normal((N2, L2, d)) * 0.3 if kind == "cross" else None
+        G = rng.standard_normal((M + 1, N1) if kind == "diag" else (M + 1, N1, N2 if kind == "cross" else N1))
+        keep = []
+        p = _params(base, d, M, difference, keep)
+        res = []
+        for impl in (0, 1):
+            ctx.set_option("grad_impl", impl)
+            gX, gY = np.empty_like(X), (None if Y is None else np.empty_like(Y))
+            if kind == "diag":
+                ctx.call("gpsig_seq_diag_levels_grad", p, _vp(X), N1, L1, _vp(G), _vp(gX), None)
+            else:
+                ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2 if Y is not None else N1, L1, L2 if Y is not None else L1,
+                         _vp(G), _vp(gX), _vp(gY), None)
+            res.append((gX, gY))
+        ctx.set_option("grad_impl", 0)
+        assert rel(res[0][0], res[1][0]) < 1e-9, (kind, L2, rel(res[0][0], res[1][0]))
+        if Y is not None:
+            assert rel(res[0][1], res[1][1]) < 1e-9, (kind, L2, rel(res[0][1], res[1][1]))

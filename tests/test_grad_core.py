@@ -135,10 +135,12 @@ def test_tensor_adjoints_equal_autograd(base, difference, increments):
     tZ, tX = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
     lev = kt.K_tens_vs_seq_levels(tZ, tX, increments)
     (lev * torch.tensor(G)).sum().backward()
-    levels, gZ, gX, gp0 = EG.tvs_grad(Z, X, G, M, base, difference, increments, p0, p1)
-    assert rel(levels, lev.detach()) < 1e-12 and rel(gZ, tZ.grad) < 1e-12 and rel(gX, tX.grad) < 1e-12
-    if base in ("poly", "mix"):
-        assert abs(gp0 - kt.p0.grad.item()) < 1e-11 * max(1.0, abs(gp0))
+    for fused in (False, True):       # storage-based and scratch-free (undo) formulations
+        levels, gZ, gX, gp0 = EG.tvs_grad(Z, X, G, M, base, difference, increments, p0, p1, fused=fused)
+        tol = 1e-10 if fused else 1e-12
+        assert rel(levels, lev.detach()) < 1e-12 and rel(gZ, tZ.grad) < tol and rel(gX, tX.grad) < tol, (fused, rel(gZ, tZ.grad), rel(gX, tX.grad))
+        if base in ("poly", "mix"):
+            assert abs(gp0 - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gp0))
     # tensor vs tensor
     G2 = rng.standard_normal((M + 1, T, T))
     kt = _t_kern(base, d, M)
@@ -148,3 +150,30 @@ def test_tensor_adjoints_equal_autograd(base, difference, increments):
     assert rel(gZ, tZ.grad) < 1e-12
     if base in ("poly", "mix"):
         assert abs(gp0 - kt.p0.grad.item()) < 1e-10 * max(1.0, abs(gp0))
+
+
+@pytest.mark.parametrize("base", ["linear", "rbf", "poly", "matern32"])
+@pytest.mark.parametrize("difference", [True, False])
+@pytest.mark.parametrize("group,cols", [(16, 2), (16, 4), (64, 2)])
+def test_wave_formulation_equals_autograd(base, difference, group, cols):
+    """grad_wave_core.hpp: the two skewed sweeps with handed-over prefixes / suffixes, lock-step on the CPU."""
+    rng = np.random.default_rng(13)
+    p0, p1 = _bp(base)
+    cap = group * cols
+    shapes = [(4, 2, 3, 6, 5, 3, "cross"), (3, 2, 2, 9, 9, 2, "sym"), (5, 3, 3, 7, 7, 5, "diag"), (1, 2, 2, 3, 4, 7, "cross"), (7, 2, 2, 6, 6, 2, "cross"),
+              (3, 1, 2, 5, min(cap, 40) + (1 if difference else 0), 2, "cross"), (2, 2, 1, 30, 3, 3, "cross")]
+    for (M, N1, N2, L1, L2, d, kind) in shapes:
+        X = rng.standard_normal((N1, L1, d)) * 0.5
+        Y = rng.standard_normal((N2, L2, d)) * 0.5 if kind == "cross" else None
+        G = rng.standard_normal((M + 1, N1) if kind == "diag" else (M + 1, N1, N2 if kind == "cross" else N1))
+        kt = _t_kern(base, d, M, difference=difference)
+        tX = torch.tensor(X, requires_grad=True)
+        tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+        lev = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
+        (lev * torch.tensor(G)).sum().backward()
+        gX, gY, gp0 = EG.seq_grad_wave(X, Y, G, M, base, difference, p0, p1, diag=(kind == "diag"), group=group, cols=cols)
+        assert rel(gX, tX.grad) < 1e-11, (M, kind, rel(gX, tX.grad))
+        if Y is not None:
+            assert rel(gY, tY.grad) < 1e-11
+        if base == "poly":
+            assert abs(gp0 - kt.p0.grad.item()) < 1e-10 * max(1.0, abs(gp0))
