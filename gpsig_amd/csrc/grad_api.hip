@@ -85,6 +85,27 @@ int launch_tvs_fused(gpsig_ctx* c, int DP, int E, dim3 grid, const TvsGradArgs& 
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
 }
+// tensor-lane variant (operands in LDS, wavefront reduction of the observations' gradient)
+bool tvs_lanet_available(int DP, int M, int E, int L) {
+    const size_t lds = sizeof(double) * (size_t(4) * E * 64 * (DP + 2) + size_t(L) * DP + 64 * (DP + 2));
+    return M <= 4 && DP <= 8 && lds <= 64 * 1024;
+}
+int launch_tvs_lanet(gpsig_ctx* c, int DP, int E, dim3 grid, const TvsLaneTGradArgs& a) {
+    const size_t lds = sizeof(double) * (size_t(4) * E * 64 * (DP + 2) + size_t(a.L) * DP + 64 * (DP + 2));
+#define LANET(DP_, E_)                                                                                                                        \
+    do {                                                                                                                                     \
+        if (a.kind == BASE_LINEAR) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, BASE_LINEAR>), grid, dim3(64), lds, c->stream, a);  \
+        else if (a.kind == BASE_RBF) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, BASE_RBF>), grid, dim3(64), lds, c->stream, a);   \
+        else hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, -1>), grid, dim3(64), lds, c->stream, a);                                 \
+    } while (0)
+    if (DP == 4 && E == 1) LANET(4, 1);
+    else if (DP == 4) LANET(4, 2);
+    else if (E == 1) LANET(8, 1);
+    else LANET(8, 2);
+#undef LANET
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
 int launch_tens(gpsig_ctx* c, int DP, dim3 grid, const TensGradArgs& a) {
     switch (DP) {
         case 4: hipLaunchKernelGGL(tens_pair_grad_kernel<4>, grid, dim3(64), 0, c->stream, a); break;
@@ -375,6 +396,29 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     if (T == 0 || N == 0) {
         if (zb) HIPCHK(c, hipMemsetAsync(dgZ, 0, zb, c->stream));
         if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
+    } else if (c->grad_impl == 0 && tvs_lanet_available(DP, M, E, L)) {
+        void *zp, *gzp;
+        CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
+        CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
+        CHK(pad_rows(c, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
+        HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
+        HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
+        TvsLaneTGradArgs A;
+        memset(&A, 0, sizeof(A));
+        A.z = static_cast<const double*>(zp); A.gz = static_cast<double*>(gzp);
+        A.X = static_cast<const double*>(dX); A.gX = static_cast<double*>(dgX);
+        A.T = int(T); A.N = int(N); A.L = L; A.d = d; A.M = M; A.kind = p->base_kernel; A.diff = p->difference ? 1 : 0;
+        A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
+        A.G = static_cast<const double*>(dG); A.gm = T * N; A.gt = N; A.gn = 1;
+        A.gbase = dgb;
+        const int64_t tb = (T + 63) / 64;
+        int64_t runs = (2048 + tb - 1) / tb;
+        if (runs > N) runs = N;
+        if (runs > 65535) runs = 65535;
+        A.nrun = int((N + runs - 1) / runs);
+        runs = (N + A.nrun - 1) / A.nrun;
+        CHK(launch_tvs_lanet(c, DP, E, dim3(unsigned(tb), unsigned(runs)), A));
+        CHK(unpad_rows(c, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
     } else {
         const int64_t s = pad64(N);
         void *zp, *gzp, *xT, *gxT, *scr = nullptr;
@@ -388,7 +432,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
         HIPCHK(c, hipMemsetAsync(gxT, 0, xtb, c->stream));
         const int R = p->difference ? L - 1 : L;
-        const bool fused = c->grad_impl == 0 && tvs_fused_available(DP, M, E);
+        const bool fused = c->grad_impl != 1 && tvs_fused_available(DP, M, E);     // grad_impl 2: one pair per thread, scratch-free
         const size_t per_t = sizeof(double) * size_t(lt + M * (M - 1) / 2) * size_t(R > 0 ? R : 0) * size_t(s);
         int64_t chunk = int64_t(scratch_budget(c) / (per_t ? per_t : 1));
         if (chunk < 1) chunk = 1;

@@ -605,204 +605,231 @@ struct TvsPairGrad {
 // undoing the forward recursion (u_j[tau] = u_j[tau+1] - m[tau] * u_{j-1}[tau], lowest chain first), the base kernel is
 // evaluated once per (component, time point) and pass, and the contraction with its derivatives happens in the same
 // backward sweep.  MMAX bounds the chain length (registers), E = 2 for increments.
+//
+// tvs_level_grad handles ONE level of ONE (tensor, sequence) pair.  Where the data comes from and where the gradient of
+// the observations goes is the caller's business (IO): the one-pair-per-thread kernel reads a time-major array and adds
+// with atomics, the tensor-lane kernel reads both operands from LDS and reduces over the wavefront first.
+//   IO::z(k, e, f): feature f of component k, point e     IO::load_x(tt, v)     IO::emit_gx(tt, gx)
+//   IO::fence(): called once per time step and before each contraction; an IO whose z() reads LDS makes it an optimisation
+//   barrier so that the compiler re-reads the components instead of keeping all of them in registers.
+template <int E>
+struct TvsEv {                // kz_k(x) = sum_e sign_e kappa(z_k^e, x) and what its derivatives need
+    double k;
+    double wz[E];             // sign * (cy - cd): multiplies z in d/dx and x in d/dz
+    double vx[E];             // sign * (cx2 + cd): multiplies x in d/dx
+    double vz[E];             // sign * (cx + cd): multiplies z in d/dz
+    double dp0;               // d kz / d base_params[0]
+};
+
+// KIND >= 0 fixes the base kernel at compile time (the derivative coefficients that are identically zero, or equal to
+// the kernel value, then cost no registers); KIND < 0 takes it from the argument.
+template <int DP, int E, int KIND, class IO>
+GPSIG_HD TvsEv<E> tvs_eval(const IO& io, int k, const double (&x)[DP], double xs, bool with_grad, int kind_rt, double p0, double p1) {
+    const int kind = KIND >= 0 ? KIND : kind_rt;
+    TvsEv<E> r;
+    r.k = 0.0;
+    r.dp0 = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double sgn = (E == 2 && e == 0) ? -1.0 : 1.0;
+        double in = 0.0, zs = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) {
+            const double zf = io.z(k, e, f);
+            in = fma(zf, x[f], in);
+            zs = fma(zf, zf, zs);
+        }
+        if (with_grad) {
+            const BaseGrad g = base_eval_grad(kind, in, zs, xs, p0, p1);
+            r.k += sgn * g.k;
+            r.wz[e] = sgn * (g.cy - g.cd);
+            r.vx[e] = sgn * (g.cx2 + g.cd);
+            r.vz[e] = sgn * (g.cx + g.cd);
+            r.dp0 += sgn * g.dp0;
+        } else {
+            r.k += sgn * base_eval<double>(kind, in, zs, xs, p0, p1);
+            r.wz[e] = r.vx[e] = r.vz[e] = 0.0;
+        }
+    }
+    return r;
+}
+
+template <int DP, int MMAX, int E, class IO>
+GPSIG_HD void tvs_contract(IO& io, int i, int k0, int tt, const double (&x)[DP], const double (&gk)[MMAX], const TvsEv<E> (&ev)[MMAX],
+                           double (&gzacc)[MMAX][E][DP], double& gp0) {
+    double gx[DP];
+    io.fence();
+#pragma unroll
+    for (int f = 0; f < DP; ++f) gx[f] = 0.0;
+#pragma unroll
+    for (int j = 0; j < MMAX; ++j)
+        if (j < i) {
+            gp0 = fma(gk[j], ev[j].dp0, gp0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double a = gk[j] * ev[j].wz[e], bx = gk[j] * ev[j].vx[e], bz = gk[j] * ev[j].vz[e];
+#pragma unroll
+                for (int f = 0; f < DP; ++f) {
+                    const double zf = io.z(k0 + j, e, f);
+                    gx[f] = fma(a, zf, fma(bx, x[f], gx[f]));
+                    gzacc[j][e][f] = fma(a, x[f], fma(bz, zf, gzacc[j][e][f]));
+                }
+            }
+        }
+    io.emit_gx(tt, gx);
+}
+
+// i: level (chain length), k0: its first component, R: number of increments (or of points when diff is false),
+// c: upstream gradient of this level.  Returns the level's value (the forward result, free of charge).
+template <int DP, int MMAX, int E, int KIND = -1, class IO>
+GPSIG_HD double tvs_level_grad(IO& io, int i, int k0, int R, bool diff, int kind, double p0, double p1, double c,
+                               double (&gzacc)[MMAX][E][DP], double& gp0) {
+    // ---- forward: chains u_1 .. u_i (exclusive prefixes; after the sweep u_j = sum_tau R_j[tau])
+    double u[MMAX + 1];
+#pragma unroll
+    for (int j = 0; j <= MMAX; ++j) u[j] = 0.0;
+    double x[DP], kprev[MMAX];
+    auto sq = [](const double (&v)[DP]) {
+        double s = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) s = fma(v[f], v[f], s);
+        return s;
+    };
+    if (diff) {
+        io.load_x(0, x);
+        const double xs = sq(x);
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j) kprev[j] = j < i ? tvs_eval<DP, E, KIND>(io, k0 + j, x, xs, false, kind, p0, p1).k : 0.0;
+    }
+    for (int tau = 0; tau < R; ++tau) {
+        io.fence();
+        io.load_x(diff ? tau + 1 : tau, x);
+        const double xs = sq(x);
+        double carry = 1.0;
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j)
+            if (j < i) {
+                const double kv = tvs_eval<DP, E, KIND>(io, k0 + j, x, xs, false, kind, p0, p1).k;
+                const double m = diff ? kv - kprev[j] : kv;
+                kprev[j] = kv;
+                const double r = m * carry;
+                carry = u[j + 1];
+                u[j + 1] += r;
+            }
+    }
+    double ki = 0.0;
+#pragma unroll
+    for (int j = 1; j <= MMAX; ++j)
+        if (j == i) ki = u[j];
+    // ---- backward: undo the chains, build w, contract
+    double w[MMAX + 1], gprev[MMAX];
+    TvsEv<E> evn[MMAX];      // evaluations at the later time point (tau + 1)
+#pragma unroll
+    for (int j = 0; j <= MMAX; ++j) w[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < MMAX; ++j) gprev[j] = 0.0;
+    double xn[DP];           // x at the later time point
+    if (diff) {
+        io.load_x(R, xn);
+        const double xs = sq(xn);
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j)
+            if (j < i) evn[j] = tvs_eval<DP, E, KIND>(io, k0 + j, xn, xs, true, kind, p0, p1);
+    }
+    for (int tau = R - 1; tau >= 0; --tau) {
+        io.fence();
+        io.load_x(tau, x);
+        const double xs = sq(x);
+        TvsEv<E> evc[MMAX];
+        double m[MMAX], gm[MMAX], ulow[MMAX];
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j)
+            if (j < i) {
+                evc[j] = tvs_eval<DP, E, KIND>(io, k0 + j, x, xs, true, kind, p0, p1);
+                m[j] = diff ? evn[j].k - evc[j].k : evc[j].k;
+            }
+        // undo: u_{j+1}[tau] = u_{j+1}[tau+1] - m[j] * u_j[tau]   (u_0 == 1), lowest chain first
+        double below = 1.0;
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j)
+            if (j < i) {
+                ulow[j] = below;                 // u_j[tau]: what R_{j+1}[tau] was multiplied with
+                u[j + 1] = fma(-m[j], below, u[j + 1]);
+                below = u[j + 1];
+            }
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j)
+            if (j < i) gm[j] = ulow[j] * (j == i - 1 ? c : w[j + 1]);           // dL/dm_{k0+j}[tau] = u_j[tau] * w_{j+1}[tau]
+#pragma unroll
+        for (int j = 1; j < MMAX; ++j)
+            if (j < i) w[j] = fma(m[j], (j == i - 1 ? c : w[j + 1]), w[j]);     // w_j[tau-1] += m_{k0+j}[tau] * w_{j+1}[tau]
+        if (diff) {
+            double gk[MMAX];
+#pragma unroll
+            for (int j = 0; j < MMAX; ++j) gk[j] = j < i ? gm[j] - gprev[j] : 0.0;   // dL/d kz(x_{tau+1})
+            tvs_contract<DP, MMAX, E>(io, i, k0, tau + 1, xn, gk, evn, gzacc, gp0);
+#pragma unroll
+            for (int j = 0; j < MMAX; ++j)
+                if (j < i) { gprev[j] = gm[j]; evn[j] = evc[j]; }
+#pragma unroll
+            for (int f = 0; f < DP; ++f) xn[f] = x[f];
+        } else {
+            tvs_contract<DP, MMAX, E>(io, i, k0, tau, x, gm, evc, gzacc, gp0);
+        }
+    }
+    if (diff) {          // time point 0
+        double gk[MMAX];
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j) gk[j] = j < i ? -gprev[j] : 0.0;
+        tvs_contract<DP, MMAX, E>(io, i, k0, 0, xn, gk, evn, gzacc, gp0);
+    }
+    return ki;
+}
+
+// one (tensor, sequence) pair per thread: operands from global memory, atomics for the observations
 template <int DP, int MMAX, int E>
 struct TvsPairGradFused {
     const TvsGradArgs& A;
     int t, n;
     bool valid;
-    int R;
 
-    GPSIG_HD TvsPairGradFused(const TvsGradArgs& a, int t_, int n_, bool valid_) : A(a), t(t_), n(n_), valid(valid_) {
-        R = A.diff ? A.L - 1 : A.L;
-    }
+    GPSIG_HD TvsPairGradFused(const TvsGradArgs& a, int t_, int n_, bool valid_) : A(a), t(t_), n(n_), valid(valid_) {}
+    GPSIG_HD double z(int k, int e, int f) const { return A.z[((int64_t(k) * A.T + t) * E + e) * DP + f]; }
+    GPSIG_HD void fence() const {}
     GPSIG_HD void load_x(int tt, double (&v)[DP]) const {
 #pragma unroll
         for (int f = 0; f < DP; ++f) v[f] = A.xT[(int64_t(tt) * DP + f) * A.xstride + n];
     }
-    GPSIG_HD const double* zptr(int k, int which) const { return A.z + ((int64_t(k) * A.T + t) * E + which) * DP; }
-    GPSIG_HD double* gzptr(int k, int which) const { return A.gz + ((int64_t(k) * A.T + t) * E + which) * DP; }
-
-    struct Ev {               // kappa(z_k^e, x) and what its derivatives need, e = 0..E-1
-        double k;             // kz_k(x) (signed sum over e)
-        double wz[E];         // sign * (cy - cd): multiplies z in d/dx and x in d/dz
-        double vx[E];         // sign * (cx2 + cd): multiplies x in d/dx
-        double vz[E];         // sign * (cx + cd): multiplies z in d/dz
-        double dp0;           // signed d kz / d base_params[0]
-    };
-    GPSIG_HD Ev eval(int k, const double (&x)[DP], double xs, bool with_grad) const {
-        Ev r;
-        r.k = 0.0;
-        r.dp0 = 0.0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const double sgn = (E == 2 && e == 0) ? -1.0 : 1.0;
-            const double* z = zptr(k, e);
-            double in = 0.0, zs = 0.0;
-#pragma unroll
-            for (int f = 0; f < DP; ++f) { in = fma(z[f], x[f], in); zs = fma(z[f], z[f], zs); }
-            if (with_grad) {
-                const BaseGrad g = base_eval_grad(A.kind, in, zs, xs, A.p0, A.p1);
-                r.k += sgn * g.k;
-                r.wz[e] = sgn * (g.cy - g.cd);
-                r.vx[e] = sgn * (g.cx2 + g.cd);
-                r.vz[e] = sgn * (g.cx + g.cd);
-                r.dp0 += sgn * g.dp0;
-            } else {
-                r.k += sgn * base_eval<double>(A.kind, in, zs, xs, A.p0, A.p1);
-                r.wz[e] = r.vx[e] = r.vz[e] = 0.0;
-            }
-        }
-        return r;
-    }
-    static GPSIG_HD double sq(const double (&x)[DP]) {
-        double s = 0.0;
-#pragma unroll
-        for (int f = 0; f < DP; ++f) s = fma(x[f], x[f], s);
-        return s;
-    }
-
-    // contraction of gk[j] = dL/d kz_{k0+j}(x) at one time point: observations (atomic, coalesced over the wavefront's
-    // sequences) and per-lane accumulators for the components
-    GPSIG_HD void contract(int i, int tt, const double (&x)[DP], const double (&gk)[MMAX], const Ev (&ev)[MMAX], int k0,
-                           double (&gzacc)[MMAX][E][DP], double& gp0) const {
-        double gx[DP];
-#pragma unroll
-        for (int f = 0; f < DP; ++f) gx[f] = 0.0;
-#pragma unroll
-        for (int j = 0; j < MMAX; ++j)
-            if (j < i) {
-                gp0 = fma(gk[j], ev[j].dp0, gp0);
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const double* z = zptr(k0 + j, e);
-                    const double a = gk[j] * ev[j].wz[e], bx = gk[j] * ev[j].vx[e], bz = gk[j] * ev[j].vz[e];
-#pragma unroll
-                    for (int f = 0; f < DP; ++f) {
-                        gx[f] = fma(a, z[f], fma(bx, x[f], gx[f]));
-                        gzacc[j][e][f] = fma(a, x[f], fma(bz, z[f], gzacc[j][e][f]));
-                    }
-                }
-            }
+    GPSIG_HD void emit_gx(int tt, const double (&gx)[DP]) const {
 #ifdef GPSIG_EXPERIMENT_NO_GX
-        if (gx[0] == 123.456) A.gxT[0] = gx[1] + gx[2] + gx[3];
+        if (gx[0] == 123.456) A.gxT[0] = gx[1];
 #else
 #pragma unroll
         for (int f = 0; f < DP; ++f) grad_add(&A.gxT[(int64_t(tt) * DP + f) * A.xstride + n], gx[f], false, valid);
 #endif
     }
-
-    GPSIG_HD void run() const {
+    GPSIG_HD void run() {
+        const int R = A.diff ? A.L - 1 : A.L;
         int k0 = 0;
         double gp0 = 0.0;
         if (A.levels && valid) A.levels[A.pairs_index(t, n, 0)] = 1.0;
         for (int i = 1; i <= A.M; ++i) {
-            // ---- forward: chains u_1 .. u_i (exclusive prefixes; after the sweep u_j = sum_tau R_j[tau])
-            double u[MMAX + 1];
+            double gzacc[MMAX][E][DP];
 #pragma unroll
-            for (int j = 0; j <= MMAX; ++j) u[j] = 0.0;
-            double x[DP], kprev[MMAX];
-            if (A.diff) {
-                load_x(0, x);
-                const double xs = sq(x);
-#pragma unroll
-                for (int j = 0; j < MMAX; ++j) kprev[j] = j < i ? eval(k0 + j, x, xs, false).k : 0.0;
-            }
-            for (int tau = 0; tau < R; ++tau) {
-                load_x(A.diff ? tau + 1 : tau, x);
-                const double xs = sq(x);
-                double carry = 1.0;
-#pragma unroll
-                for (int j = 0; j < MMAX; ++j)
-                    if (j < i) {
-                        const double kv = eval(k0 + j, x, xs, false).k;
-                        const double m = A.diff ? kv - kprev[j] : kv;
-                        kprev[j] = kv;
-                        const double r = m * carry;
-                        carry = u[j + 1];
-                        u[j + 1] += r;
-                    }
-            }
-            if (A.levels && valid) {
-                double ki = 0.0;
-#pragma unroll
-                for (int j = 1; j <= MMAX; ++j)
-                    if (j == i) ki = u[j];
-                A.levels[A.pairs_index(t, n, i)] = ki;
-            }
-            // ---- backward: undo the chains, build w, contract
-            const double c = valid ? A.G[i * A.gm + t * A.gt + n * A.gn] : 0.0;
-            double w[MMAX + 1], gprev[MMAX], gzacc[MMAX][E][DP];
-            Ev evn[MMAX];      // evaluations at the later time point (tau + 1)
-#pragma unroll
-            for (int j = 0; j <= MMAX; ++j) w[j] = 0.0;
-#pragma unroll
-            for (int j = 0; j < MMAX; ++j) {
-                gprev[j] = 0.0;
+            for (int j = 0; j < MMAX; ++j)
 #pragma unroll
                 for (int e = 0; e < E; ++e)
 #pragma unroll
                     for (int f = 0; f < DP; ++f) gzacc[j][e][f] = 0.0;
-            }
-            double xn[DP];     // x at the later time point
-            if (A.diff) {
-                load_x(R, xn);
-                const double xs = sq(xn);
-#pragma unroll
-                for (int j = 0; j < MMAX; ++j)
-                    if (j < i) evn[j] = eval(k0 + j, xn, xs, true);
-            }
-            for (int tau = R - 1; tau >= 0; --tau) {
-                load_x(tau, x);
-                const double xs = sq(x);
-                Ev evc[MMAX];
-                double m[MMAX], gm[MMAX], ulow[MMAX];
-#pragma unroll
-                for (int j = 0; j < MMAX; ++j)
-                    if (j < i) {
-                        evc[j] = eval(k0 + j, x, xs, true);
-                        m[j] = A.diff ? evn[j].k - evc[j].k : evc[j].k;
-                    }
-                // undo: u_{j+1}[tau] = u_{j+1}[tau+1] - m[j] * u_j[tau]   (u_0 == 1), lowest chain first
-                double below = 1.0;
-#pragma unroll
-                for (int j = 0; j < MMAX; ++j)
-                    if (j < i) {
-                        ulow[j] = below;                 // u_j[tau]: what R_{j+1}[tau] was multiplied with
-                        u[j + 1] = fma(-m[j], below, u[j + 1]);
-                        below = u[j + 1];
-                    }
-#pragma unroll
-                for (int j = 0; j < MMAX; ++j)
-                    if (j < i) gm[j] = ulow[j] * (j == i - 1 ? c : w[j + 1]);           // dL/dm_{k0+j}[tau] = u_j[tau] * w_{j+1}[tau]
-#pragma unroll
-                for (int j = 1; j < MMAX; ++j)
-                    if (j < i) w[j] = fma(m[j], (j == i - 1 ? c : w[j + 1]), w[j]);     // w_j[tau-1] += m_{k0+j}[tau] * w_{j+1}[tau]
-                if (A.diff) {
-                    double gk[MMAX];
-#pragma unroll
-                    for (int j = 0; j < MMAX; ++j) gk[j] = j < i ? gm[j] - gprev[j] : 0.0;   // dL/d kz(x_{tau+1})
-                    contract(i, tau + 1, xn, gk, evn, k0, gzacc, gp0);
-#pragma unroll
-                    for (int j = 0; j < MMAX; ++j)
-                        if (j < i) { gprev[j] = gm[j]; evn[j] = evc[j]; }
-#pragma unroll
-                    for (int f = 0; f < DP; ++f) xn[f] = x[f];
-                } else {
-                    contract(i, tau, x, gm, evc, k0, gzacc, gp0);
-                }
-            }
-            if (A.diff && R >= 0) {          // time point 0
-                double gk[MMAX];
-#pragma unroll
-                for (int j = 0; j < MMAX; ++j) gk[j] = j < i ? -gprev[j] : 0.0;
-                contract(i, 0, xn, gk, evn, k0, gzacc, gp0);
-            }
+            const double c = valid ? A.G[i * A.gm + t * A.gt + n * A.gn] : 0.0;
+            const double ki = tvs_level_grad<DP, MMAX, E>(*this, i, k0, R, A.diff != 0, A.kind, A.p0, A.p1, c, gzacc, gp0);
+            if (A.levels && valid) A.levels[A.pairs_index(t, n, i)] = ki;
 #pragma unroll
             for (int j = 0; j < MMAX; ++j)
                 if (j < i) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
-                        double* gzp = gzptr(k0 + j, e);
+                        double* gzp = A.gz + ((int64_t(k0 + j) * A.T + t) * E + e) * DP;
 #pragma unroll
                         for (int f = 0; f < DP; ++f) grad_add(&gzp[f], gzacc[j][e][f], true, valid);
                     }

@@ -85,6 +85,112 @@ __global__ void __launch_bounds__(64) tvs_pair_grad_fused_kernel(const TvsGradAr
     P.run();
 }
 
+
+// Tensor-lane variant of the tensor-vs-sequence gradient: lane = inducing tensor (64 per wavefront), the sequences of a run
+// are streamed one after the other through LDS (broadcast reads), the level's components of the 64 tensors sit in LDS
+// as well, the per-lane accumulators of d/dz live in registers for the whole run, and the gradient of an observation is
+// summed over the 64 tensors through an LDS transpose before ONE 8*DP-byte atomic per (level, sequence, time point).
+struct TvsLaneTGradArgs {
+    const double* z;        // scaled components padded to DP: (lt, T, E, DP)
+    const double* X;        // scaled sequences, user layout (N, L, d)
+    double* gz;             // (lt, T, E, DP), accumulated
+    double* gX;             // (N, L, d), accumulated
+    int T, N, L, d, M, kind, diff;
+    double p0, p1;
+    const double* G; int64_t gm, gt, gn;
+    int nrun;               // sequences per workgroup
+    double* gbase;
+};
+
+template <int DP, int MMAX, int E>
+struct TvsLaneTIO {
+    static constexpr int ZP = DP + 2;      // row stride: 16 consecutive lanes hit 16 different 16-byte bank groups
+    const double* zs; const double* xs; double* red;
+    const TvsLaneTGradArgs& A;
+    int lane, n;
+    bool valid;                // this lane holds a tensor
+    mutable int zoff;          // lane * ZP, laundered by fence()
+    __device__ __forceinline__ void fence() const { asm volatile("" : "+v"(zoff)); }
+    __device__ __forceinline__ double z(int k, int e, int f) const { return zs[(k * E + e) * 64 * ZP + zoff + f]; }
+    __device__ __forceinline__ void load_x(int tt, double (&v)[DP]) const {
+#pragma unroll
+        for (int f = 0; f < DP; ++f) v[f] = xs[tt * DP + f];
+    }
+    __device__ __forceinline__ void emit_gx(int tt, const double (&gx)[DP]) const {
+#pragma unroll
+        for (int f = 0; f < DP; ++f) red[lane * ZP + f] = valid ? gx[f] : 0.0;
+        __syncthreads();
+        const int f = lane % DP, part = lane / DP;
+        double sacc = 0.0;
+#pragma unroll
+        for (int r = 0; r < DP; ++r) sacc += red[(part * DP + r) * ZP + f];
+#pragma unroll
+        for (int o = DP; o < 64; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
+        if (lane < DP && lane < A.d) atomicAdd(&A.gX[(int64_t(n) * A.L + tt) * A.d + lane], sacc);
+        __syncthreads();
+    }
+};
+
+// grid (ceil(T / 64), runs); block 64; dynamic LDS: (MMAX * E * 64 * (DP + 2) + L * DP + 64 * (DP + 2)) doubles
+template <int DP, int MMAX, int E, int KIND>
+__global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradArgs A) {
+    extern __shared__ double tvs_sm[];
+    constexpr int ZP = DP + 2;
+    double* zs = tvs_sm;
+    double* xs = zs + MMAX * E * 64 * ZP;
+    double* red = xs + A.L * DP;
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x * 64 + lane;
+    const bool valid = t < A.T;
+    const int n0 = blockIdx.y * A.nrun, n1 = (n0 + A.nrun < A.N) ? n0 + A.nrun : A.N;
+    const int R = A.diff ? A.L - 1 : A.L;
+    TvsLaneTIO<DP, MMAX, E> io{zs, xs, red, A, lane, 0, valid, lane * ZP};
+    int k0 = 0;
+    double gp0 = 0.0;
+    for (int i = 1; i <= A.M; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j)
+            if (j < i) {
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int f = 0; f < DP; ++f)
+                        zs[((j * E + e) * 64 + lane) * ZP + f] = valid ? A.z[((int64_t(k0 + j) * A.T + t) * E + e) * DP + f] : 0.0;
+            }
+        double gzacc[MMAX][E][DP];
+#pragma unroll
+        for (int j = 0; j < MMAX; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int f = 0; f < DP; ++f) gzacc[j][e][f] = 0.0;
+        for (int n = n0; n < n1; ++n) {
+            __syncthreads();
+            for (int e = lane; e < A.L * DP; e += 64) {
+                const int q = e / DP, f = e % DP;
+                xs[e] = f < A.d ? A.X[(int64_t(n) * A.L + q) * A.d + f] : 0.0;
+            }
+            __syncthreads();
+            io.n = n;
+            const double c = valid ? A.G[i * A.gm + t * A.gt + n * A.gn] : 0.0;
+            tvs_level_grad<DP, MMAX, E, KIND>(io, i, 0, R, A.diff != 0, A.kind, A.p0, A.p1, c, gzacc, gp0);
+        }
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < MMAX; ++j)
+                if (j < i) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+#pragma unroll
+                        for (int f = 0; f < DP; ++f) atomicAdd(&A.gz[((int64_t(k0 + j) * A.T + t) * E + e) * DP + f], gzacc[j][e][f]);
+                }
+        }
+        k0 += i;
+    }
+    if (A.gbase) grad_add(&A.gbase[0], gp0, true, valid);
+}
+
 // grid (ceil(T / 64), T); block 64: lanes = t2, blockIdx.y = t
 template <int DP>
 __global__ void __launch_bounds__(64) tens_pair_grad_kernel(const TensGradArgs A) {

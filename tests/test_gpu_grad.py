@@ -118,13 +118,16 @@ def test_tensor_level_gradients(base, difference, increments):
     (kt.K_tens_vs_seq_levels(tZ, tX, increments) * torch.tensor(G)).sum().backward()
     keep = []
     p = _params(base, d, M, difference, keep)
-    gZ, gX, gb = np.empty_like(Z), np.empty_like(X), np.zeros(2)
-    ctx.set_option("grad_scratch_mb", 1)     # several launches
-    ctx.call("gpsig_tens_vs_seq_levels_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(G), _vp(gZ), _vp(gX), gb.ctypes.data_as(_P))
-    ctx.set_option("grad_scratch_mb", 4096)
-    assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9
-    if base in ("poly", "mix"):
-        assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
+    for impl in (0, 1, 2):     # tensor lanes (default) / one pair per thread with a stored lattice / one pair per thread, scratch-free
+        gZ, gX, gb = np.empty_like(Z), np.empty_like(X), np.zeros(2)
+        ctx.set_option("grad_impl", impl)
+        ctx.set_option("grad_scratch_mb", 1)     # several launches
+        ctx.call("gpsig_tens_vs_seq_levels_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(G), _vp(gZ), _vp(gX), gb.ctypes.data_as(_P))
+        ctx.set_option("grad_scratch_mb", 4096)
+        ctx.set_option("grad_impl", 0)
+        assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9, (impl, rel(gZ, tZ.grad), rel(gX, tX.grad))
+        if base in ("poly", "mix"):
+            assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
     G2 = rng.standard_normal((M + 1, T, T))
     kt = _t_kern(base, d, M)
     tZ = torch.tensor(Z, requires_grad=True)
