@@ -86,22 +86,26 @@ int launch_tvs_fused(gpsig_ctx* c, int DP, int E, dim3 grid, const TvsGradArgs& 
     return GPSIG_OK;
 }
 // tensor-lane variant (operands in LDS, wavefront reduction of the observations' gradient)
-bool tvs_lanet_available(int DP, int M, int E, int L) {
-    const size_t lds = sizeof(double) * (size_t(4) * E * 64 * (DP + 2) + size_t(L) * DP + 64 * (DP + 2));
-    return M <= 4 && DP <= 8 && lds <= 64 * 1024;
+size_t tvs_lanet_lds(int DP, int E, int L, bool zreg) {
+    return sizeof(double) * ((zreg ? 0 : size_t(4) * E * 64 * (DP + 2)) + size_t(L) * DP + size_t(L) + 2 * 64 * (DP + 2));
+}
+bool tvs_lanet_zreg(const gpsig_ctx* c, int DP, int E) { return E == 1 && (c->tvs_zreg < 0 ? true : c->tvs_zreg != 0); }
+bool tvs_lanet_available(const gpsig_ctx* c, int DP, int M, int E, int L) {
+    return M <= 4 && DP <= 8 && tvs_lanet_lds(DP, E, L, tvs_lanet_zreg(c, DP, E)) <= 64 * 1024;
 }
 int launch_tvs_lanet(gpsig_ctx* c, int DP, int E, dim3 grid, const TvsLaneTGradArgs& a) {
-    const size_t lds = sizeof(double) * (size_t(4) * E * 64 * (DP + 2) + size_t(a.L) * DP + 64 * (DP + 2));
-#define LANET(DP_, E_)                                                                                                                        \
-    do {                                                                                                                                     \
-        if (a.kind == BASE_LINEAR) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, BASE_LINEAR>), grid, dim3(64), lds, c->stream, a);  \
-        else if (a.kind == BASE_RBF) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, BASE_RBF>), grid, dim3(64), lds, c->stream, a);   \
-        else hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, -1>), grid, dim3(64), lds, c->stream, a);                                 \
+    const bool zreg = tvs_lanet_zreg(c, DP, E);
+    const size_t lds = tvs_lanet_lds(DP, E, a.L, zreg);
+#define LANET(DP_, E_, Z_)                                                                                                                          \
+    do {                                                                                                                                           \
+        if (a.kind == BASE_LINEAR) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, BASE_LINEAR, Z_>), grid, dim3(64), lds, c->stream, a);   \
+        else if (a.kind == BASE_RBF) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, BASE_RBF, Z_>), grid, dim3(64), lds, c->stream, a);    \
+        else hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, -1, Z_>), grid, dim3(64), lds, c->stream, a);                                  \
     } while (0)
-    if (DP == 4 && E == 1) LANET(4, 1);
-    else if (DP == 4) LANET(4, 2);
-    else if (E == 1) LANET(8, 1);
-    else LANET(8, 2);
+    if (DP == 4 && E == 1) { if (zreg) LANET(4, 1, true); else LANET(4, 1, false); }
+    else if (DP == 4) LANET(4, 2, false);
+    else if (E == 1) { if (zreg) LANET(8, 1, true); else LANET(8, 1, false); }
+    else LANET(8, 2, false);
 #undef LANET
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
@@ -322,6 +326,21 @@ int unpad_rows(gpsig_ctx* c, const double* ZP, double* Z, int64_t rows, int d, i
     return GPSIG_OK;
 }
 
+int pad_z(gpsig_ctx* c, bool collapse, const double* Z, double* ZP, int64_t rows, int d, int DP) {
+    if (!collapse) return pad_rows(c, Z, ZP, rows, d, DP);
+    if (rows == 0) return GPSIG_OK;
+    hipLaunchKernelGGL(grad_pad_diff_rows_kernel, dim3(grid_for(rows * DP)), dim3(256), 0, c->stream, Z, ZP, rows, d, DP);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+int unpad_z(gpsig_ctx* c, bool collapse, const double* ZP, double* Z, int64_t rows, int d, int DP) {
+    if (!collapse) return unpad_rows(c, ZP, Z, rows, d, DP);
+    if (rows == 0) return GPSIG_OK;
+    hipLaunchKernelGGL(grad_unpad_pm_rows_kernel, dim3(grid_for(rows * d)), dim3(256), 0, c->stream, ZP, Z, rows, d, DP);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -381,9 +400,11 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     CHK(grad_check(c, p, &d, &DP));
     if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
     if (N > 0x7fffffff || T > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 items");
-    const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
-    const int64_t rows = int64_t(lt) * T * E;
-    const size_t zb = sizeof(double) * size_t(rows) * d, xb = sizeof(double) * size_t(N) * L * d, gb = sizeof(double) * size_t(M + 1) * T * N;
+    const int M = p->num_levels, lt = M * (M + 1) / 2;
+    const bool collapse = increments && p->base_kernel == GPSIG_BASE_LINEAR;      // <z1, x> - <z0, x> = <z1 - z0, x>
+    const int E = (increments && !collapse) ? 2 : 1;
+    const int64_t rows = int64_t(lt) * T * E;                                      // padded rows the kernels see
+    const size_t zb = sizeof(double) * size_t(lt) * T * (increments ? 2 : 1) * d, xb = sizeof(double) * size_t(N) * L * d, gb = sizeof(double) * size_t(M + 1) * T * N;
     const void *dZ, *dX, *dG;
     CHK(in_dev(c, B_IN0, Z, zb, &dZ));
     CHK(in_dev(c, B_IN1, X, xb, &dX));
@@ -396,11 +417,11 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     if (T == 0 || N == 0) {
         if (zb) HIPCHK(c, hipMemsetAsync(dgZ, 0, zb, c->stream));
         if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
-    } else if (c->grad_impl == 0 && tvs_lanet_available(DP, M, E, L)) {
+    } else if (c->grad_impl == 0 && tvs_lanet_available(c, DP, M, E, L)) {
         void *zp, *gzp;
         CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
         CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
-        CHK(pad_rows(c, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
+        CHK(pad_z(c, collapse, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
         HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
         HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
         TvsLaneTGradArgs A;
@@ -418,7 +439,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         A.nrun = int((N + runs - 1) / runs);
         runs = (N + A.nrun - 1) / A.nrun;
         CHK(launch_tvs_lanet(c, DP, E, dim3(unsigned(tb), unsigned(runs)), A));
-        CHK(unpad_rows(c, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
+        CHK(unpad_z(c, collapse, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
     } else {
         const int64_t s = pad64(N);
         void *zp, *gzp, *xT, *gxT, *scr = nullptr;
@@ -427,7 +448,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
         CHK(ensure(c, B_GR2, xtb, &xT));
         CHK(ensure(c, B_GR3, xtb, &gxT));
-        CHK(pad_rows(c, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
+        CHK(pad_z(c, collapse, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
         CHK(to_timemajor(c, static_cast<const double*>(dX), static_cast<double*>(xT), N, L, d, DP, s));
         HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
         HIPCHK(c, hipMemsetAsync(gxT, 0, xtb, c->stream));
@@ -444,7 +465,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         A.z = static_cast<const double*>(zp); A.gz = static_cast<double*>(gzp);
         A.xT = static_cast<const double*>(xT); A.gxT = static_cast<double*>(gxT);
         A.xstride = s;
-        A.T = int(T); A.N = int(N); A.L = L; A.M = M; A.kind = p->base_kernel; A.incr = increments ? 1 : 0; A.diff = p->difference ? 1 : 0;
+        A.T = int(T); A.N = int(N); A.L = L; A.M = M; A.kind = p->base_kernel; A.incr = E == 2 ? 1 : 0; A.diff = p->difference ? 1 : 0;
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         A.G = static_cast<const double*>(dG); A.gm = T * N; A.gt = N; A.gn = 1;
         A.gbase = dgb;
@@ -459,7 +480,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
                 CHK(launch_tvs(c, DP, dim3(unsigned(s / 64), unsigned(nt)), A));
             }
         }
-        CHK(unpad_rows(c, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
+        CHK(unpad_z(c, collapse, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
         CHK(from_timemajor(c, static_cast<const double*>(gxT), static_cast<double*>(dgX), N, L, d, DP, s));
     }
     CHK(out_done(c, gZ, dgZ, zb));

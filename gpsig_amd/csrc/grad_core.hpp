@@ -609,7 +609,8 @@ struct TvsPairGrad {
 // tvs_level_grad handles ONE level of ONE (tensor, sequence) pair.  Where the data comes from and where the gradient of
 // the observations goes is the caller's business (IO): the one-pair-per-thread kernel reads a time-major array and adds
 // with atomics, the tensor-lane kernel reads both operands from LDS and reduces over the wavefront first.
-//   IO::z(k, e, f): feature f of component k, point e     IO::load_x(tt, v)     IO::emit_gx(tt, gx)
+//   IO::z(k, e, f): feature f of component k, point e;  IO::zsq(k, e): its squared norm
+//   IO::load_x(tt, v) -> |x_tt|^2     IO::emit_gx(tt, gx)
 //   IO::fence(): called once per time step and before each contraction; an IO whose z() reads LDS makes it an optimisation
 //   barrier so that the compiler re-reads the components instead of keeping all of them in registers.
 template <int E>
@@ -632,13 +633,10 @@ GPSIG_HD TvsEv<E> tvs_eval(const IO& io, int k, const double (&x)[DP], double xs
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const double sgn = (E == 2 && e == 0) ? -1.0 : 1.0;
-        double in = 0.0, zs = 0.0;
+        double in = 0.0;
 #pragma unroll
-        for (int f = 0; f < DP; ++f) {
-            const double zf = io.z(k, e, f);
-            in = fma(zf, x[f], in);
-            zs = fma(zf, zf, zs);
-        }
+        for (int f = 0; f < DP; ++f) in = fma(io.z(k, e, f), x[f], in);
+        const double zs = io.zsq(k, e);
         if (with_grad) {
             const BaseGrad g = base_eval_grad(kind, in, zs, xs, p0, p1);
             r.k += sgn * g.k;
@@ -689,22 +687,14 @@ GPSIG_HD double tvs_level_grad(IO& io, int i, int k0, int R, bool diff, int kind
 #pragma unroll
     for (int j = 0; j <= MMAX; ++j) u[j] = 0.0;
     double x[DP], kprev[MMAX];
-    auto sq = [](const double (&v)[DP]) {
-        double s = 0.0;
-#pragma unroll
-        for (int f = 0; f < DP; ++f) s = fma(v[f], v[f], s);
-        return s;
-    };
     if (diff) {
-        io.load_x(0, x);
-        const double xs = sq(x);
+        const double xs = io.load_x(0, x);
 #pragma unroll
         for (int j = 0; j < MMAX; ++j) kprev[j] = j < i ? tvs_eval<DP, E, KIND>(io, k0 + j, x, xs, false, kind, p0, p1).k : 0.0;
     }
     for (int tau = 0; tau < R; ++tau) {
         io.fence();
-        io.load_x(diff ? tau + 1 : tau, x);
-        const double xs = sq(x);
+        const double xs = io.load_x(diff ? tau + 1 : tau, x);
         double carry = 1.0;
 #pragma unroll
         for (int j = 0; j < MMAX; ++j)
@@ -730,16 +720,14 @@ GPSIG_HD double tvs_level_grad(IO& io, int i, int k0, int R, bool diff, int kind
     for (int j = 0; j < MMAX; ++j) gprev[j] = 0.0;
     double xn[DP];           // x at the later time point
     if (diff) {
-        io.load_x(R, xn);
-        const double xs = sq(xn);
+        const double xs = io.load_x(R, xn);
 #pragma unroll
         for (int j = 0; j < MMAX; ++j)
             if (j < i) evn[j] = tvs_eval<DP, E, KIND>(io, k0 + j, xn, xs, true, kind, p0, p1);
     }
     for (int tau = R - 1; tau >= 0; --tau) {
         io.fence();
-        io.load_x(tau, x);
-        const double xs = sq(x);
+        const double xs = io.load_x(tau, x);
         TvsEv<E> evc[MMAX];
         double m[MMAX], gm[MMAX], ulow[MMAX];
 #pragma unroll
@@ -796,9 +784,20 @@ struct TvsPairGradFused {
     GPSIG_HD TvsPairGradFused(const TvsGradArgs& a, int t_, int n_, bool valid_) : A(a), t(t_), n(n_), valid(valid_) {}
     GPSIG_HD double z(int k, int e, int f) const { return A.z[((int64_t(k) * A.T + t) * E + e) * DP + f]; }
     GPSIG_HD void fence() const {}
-    GPSIG_HD void load_x(int tt, double (&v)[DP]) const {
+    GPSIG_HD double zsq(int k, int e) const {
+        double s = 0.0;
 #pragma unroll
-        for (int f = 0; f < DP; ++f) v[f] = A.xT[(int64_t(tt) * DP + f) * A.xstride + n];
+        for (int f = 0; f < DP; ++f) s = fma(z(k, e, f), z(k, e, f), s);
+        return s;
+    }
+    GPSIG_HD double load_x(int tt, double (&v)[DP]) const {
+        double s = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) {
+            v[f] = A.xT[(int64_t(tt) * DP + f) * A.xstride + n];
+            s = fma(v[f], v[f], s);
+        }
+        return s;
     }
     GPSIG_HD void emit_gx(int tt, const double (&gx)[DP]) const {
 #ifdef GPSIG_EXPERIMENT_NO_GX

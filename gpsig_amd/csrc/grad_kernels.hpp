@@ -51,6 +51,27 @@ __global__ void grad_unpad_rows_kernel(const double* __restrict__ ZP, double* __
     }
 }
 
+// Linear base kernel with increments (kernels.py:328-330): kappa(z1, x) - kappa(z0, x) = <z1 - z0, x>, so the pair of points
+// collapses to its difference on the way in, and the gradient fans out as (-g, +g) on the way out.
+__global__ void grad_pad_diff_rows_kernel(const double* __restrict__ Z, double* __restrict__ ZP, int64_t rows, int d, int DP) {
+    const int64_t total = rows * DP;      // rows = lt * T (each holding two points in Z)
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int f = int(e % DP);
+        const int64_t r = e / DP;
+        ZP[e] = f < d ? Z[(2 * r + 1) * d + f] - Z[(2 * r) * d + f] : 0.0;
+    }
+}
+__global__ void grad_unpad_pm_rows_kernel(const double* __restrict__ ZP, double* __restrict__ Z, int64_t rows, int d, int DP) {
+    const int64_t total = rows * d;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int f = int(e % d);
+        const int64_t r = e / d;
+        const double g = ZP[r * DP + f];
+        Z[(2 * r) * d + f] = -g;
+        Z[(2 * r + 1) * d + f] = g;
+    }
+}
+
 // grid (ceil(N1 / 64), nj or 1); block 64
 template <int DP>
 __global__ void __launch_bounds__(64) seq_pair_grad_kernel(const SeqGradArgs A) {
@@ -102,61 +123,86 @@ struct TvsLaneTGradArgs {
     double* gbase;
 };
 
-template <int DP, int MMAX, int E>
+// ZREG: the level's components live in registers (affordable when E == 1) instead of LDS
+template <int DP, int MMAX, int E, bool ZREG>
 struct TvsLaneTIO {
     static constexpr int ZP = DP + 2;      // row stride: 16 consecutive lanes hit 16 different 16-byte bank groups
-    const double* zs; const double* xs; double* red;
+    const double* zs; const double* xs; const double* xsq; double* red;
     const TvsLaneTGradArgs& A;
     int lane, n;
     bool valid;                // this lane holds a tensor
-    mutable int zoff;          // lane * ZP, laundered by fence()
-    __device__ __forceinline__ void fence() const { asm volatile("" : "+v"(zoff)); }
-    __device__ __forceinline__ double z(int k, int e, int f) const { return zs[(k * E + e) * 64 * ZP + zoff + f]; }
-    __device__ __forceinline__ void load_x(int tt, double (&v)[DP]) const {
+    double zr[ZREG ? MMAX : 1][E][DP];
+    double zn[ZREG ? MMAX : 1][E];   // squared norms of the level's components (kept only next to register-resident components)
+    int flip;                  // which of the two reduction buffers the next emit uses
+    __device__ __forceinline__ void fence() const {}
+    __device__ __forceinline__ double z(int k, int e, int f) const {
+        if constexpr (ZREG) return zr[k][e][f];
+        else return zs[((k * E + e) * 64 + lane) * ZP + f];
+    }
+    __device__ __forceinline__ double zsq(int k, int e) const {
+        if constexpr (ZREG) return zn[k][e];
+        else {
+            double s = 0.0;
+#pragma unroll
+            for (int f = 0; f < DP; ++f) s = fma(z(k, e, f), z(k, e, f), s);
+            return s;
+        }
+    }
+    __device__ __forceinline__ double load_x(int tt, double (&v)[DP]) const {
 #pragma unroll
         for (int f = 0; f < DP; ++f) v[f] = xs[tt * DP + f];
+        return xsq[tt];
     }
-    __device__ __forceinline__ void emit_gx(int tt, const double (&gx)[DP]) const {
+    // sum of gx over the 64 tensors of the wavefront -> one atomic of DP doubles.  Two buffers: one barrier per call.
+    __device__ __forceinline__ void emit_gx(int tt, const double (&gx)[DP]) {
+        double* rb = red + flip * 64 * ZP;
+        flip ^= 1;
 #pragma unroll
-        for (int f = 0; f < DP; ++f) red[lane * ZP + f] = valid ? gx[f] : 0.0;
+        for (int f = 0; f < DP; ++f) rb[lane * ZP + f] = valid ? gx[f] : 0.0;
         __syncthreads();
         const int f = lane % DP, part = lane / DP;
         double sacc = 0.0;
 #pragma unroll
-        for (int r = 0; r < DP; ++r) sacc += red[(part * DP + r) * ZP + f];
+        for (int r = 0; r < DP; ++r) sacc += rb[(part * DP + r) * ZP + f];
 #pragma unroll
         for (int o = DP; o < 64; o <<= 1) sacc += __shfl_xor(sacc, o, 64);
         if (lane < DP && lane < A.d) atomicAdd(&A.gX[(int64_t(n) * A.L + tt) * A.d + lane], sacc);
-        __syncthreads();
     }
 };
 
-// grid (ceil(T / 64), runs); block 64; dynamic LDS: (MMAX * E * 64 * (DP + 2) + L * DP + 64 * (DP + 2)) doubles
-template <int DP, int MMAX, int E, int KIND>
+// grid (ceil(T / 64), runs); block 64; dynamic LDS: ((ZREG ? 0 : MMAX * E * 64 * (DP + 2)) + L * DP + L + 2 * 64 * (DP + 2)) doubles
+template <int DP, int MMAX, int E, int KIND, bool ZREG>
 __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradArgs A) {
     extern __shared__ double tvs_sm[];
     constexpr int ZP = DP + 2;
     double* zs = tvs_sm;
-    double* xs = zs + MMAX * E * 64 * ZP;
-    double* red = xs + A.L * DP;
+    double* xs = zs + (ZREG ? 0 : MMAX * E * 64 * ZP);
+    double* xsq = xs + A.L * DP;
+    double* red = xsq + A.L;
     const int lane = threadIdx.x;
     const int t = blockIdx.x * 64 + lane;
     const bool valid = t < A.T;
     const int n0 = blockIdx.y * A.nrun, n1 = (n0 + A.nrun < A.N) ? n0 + A.nrun : A.N;
     const int R = A.diff ? A.L - 1 : A.L;
-    TvsLaneTIO<DP, MMAX, E> io{zs, xs, red, A, lane, 0, valid, lane * ZP};
+    TvsLaneTIO<DP, MMAX, E, ZREG> io{zs, xs, xsq, red, A, lane, 0, valid, {}, {}, 0};
     int k0 = 0;
     double gp0 = 0.0;
     for (int i = 1; i <= A.M; ++i) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < MMAX; ++j)
-            if (j < i) {
 #pragma unroll
-                for (int e = 0; e < E; ++e)
+            for (int e = 0; e < E; ++e) {
+                double nrm = 0.0;
 #pragma unroll
-                    for (int f = 0; f < DP; ++f)
-                        zs[((j * E + e) * 64 + lane) * ZP + f] = valid ? A.z[((int64_t(k0 + j) * A.T + t) * E + e) * DP + f] : 0.0;
+                for (int f = 0; f < DP; ++f) {
+                    // lanes without a tensor get a harmless finite point
+                    const double v = (j < i && valid) ? A.z[((int64_t(k0 + j) * A.T + t) * E + e) * DP + f] : 1.0;
+                    if constexpr (ZREG) io.zr[j][e][f] = v;
+                    else if (j < i) zs[((j * E + e) * 64 + lane) * ZP + f] = v;
+                    nrm = fma(v, v, nrm);
+                }
+                if constexpr (ZREG) io.zn[j][e] = nrm;
             }
         double gzacc[MMAX][E][DP];
 #pragma unroll
@@ -170,6 +216,13 @@ __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradAr
             for (int e = lane; e < A.L * DP; e += 64) {
                 const int q = e / DP, f = e % DP;
                 xs[e] = f < A.d ? A.X[(int64_t(n) * A.L + q) * A.d + f] : 0.0;
+            }
+            __syncthreads();
+            for (int q = lane; q < A.L; q += 64) {
+                double sq = 0.0;
+#pragma unroll
+                for (int f = 0; f < DP; ++f) sq = fma(xs[q * DP + f], xs[q * DP + f], sq);
+                xsq[q] = sq;
             }
             __syncthreads();
             io.n = n;

@@ -8,6 +8,9 @@ import numpy as np, torch
 from gpsig_amd import kernels, models, likelihoods as LK, inducing_variables as iv, autodiff
 
 dev = torch.device("cuda:0")
+if os.environ.get("GPSIG_TVS_ZREG"):
+    from gpsig_amd import _lib
+    _c = _lib.context(0, torch.cuda.current_stream(torch.device("cuda:0")).cuda_stream); _c.set_option("tvs_zreg", int(os.environ["GPSIG_TVS_ZREG"]))
 rng = np.random.default_rng(0)
 
 
