@@ -43,7 +43,8 @@ struct gpsig_ctx {
     int max_run = 0;
     int tens_lanes = -1;   // -1 auto, 0 sequence lanes, 1 tensor lanes
     int grad_scratch_mb = 4096;   // lattice scratch of one gradient launch
-    int grad_impl = 0;            // 0: fastest built variant, 1: storage-based reference variant, 2: one pair per thread, scratch-free
+    int grad_impl = 0;            // 0: planner's choice, 1: one pair per thread + stored lattice, 2: one pair per thread scratch-free (tensor-vs-seq),
+                                  // 3: wavefront kernel + stored lattice, 4: scratch-free wavefront kernel wherever it is built
     int tvs_zreg = -1;            // tensor-lane gradient: components in registers (1) or LDS (0); -1 = planner's choice
     std::string err;
     DevBuf buf[B_COUNT];

@@ -13,6 +13,10 @@ typedef hipError_t (*WaveLaunchFn)(const WaveGradArgs&, int, hipStream_t);
 WaveLaunchFn wave_lookup_inc(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptd(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptn(int G, int C, int DP, int LQ);
+typedef hipError_t (*Wave2LaunchFn)(const Wave2Args&, int, size_t, hipStream_t);
+Wave2LaunchFn wave2_lookup_inc(int G, int C, int DP, int LQ);
+Wave2LaunchFn wave2_lookup_ptd(int G, int C, int DP, int LQ);
+Wave2LaunchFn wave2_lookup_ptn(int G, int C, int DP, int LQ);
 }  // namespace gpsig
 
 using namespace gpsig;
@@ -222,6 +226,59 @@ int seq_grad_wave(gpsig_ctx* c, const gpsig_params* p, WaveLaunchFn fn, int G, i
     return GPSIG_OK;
 }
 
+
+// ---- scratch-free wavefront path (seq_grad_wave2_kernel): one launch per register-resident side ------------------------------
+Wave2LaunchFn wave2_plan(int mode, int Rreg, int DP, int M, bool forced, int* G, int* C) {
+    if (DP > 16 || M - 1 > 7) return nullptr;
+    // Point kernels carry the derivative coefficients of a whole row on top of the recursion state and currently run faster
+    // through the stored-lattice kernel + contraction; the scratch-free kernel is the default for the linear kernel only.
+    if (mode != MODE_INC && !forced) return nullptr;
+    static const int shapes[][2] = {{16, 2}, {16, 4}, {64, 2}, {64, 8}};
+    for (auto& sh : shapes) {
+        if (sh[0] * sh[1] < Rreg) continue;
+        if (sh[1] * DP > 32) continue;                     // larger per-lane tiles spill
+        if (mode != MODE_INC && sh[1] * DP > 16) continue; // point kernels carry the derivative coefficients as well
+        Wave2LaunchFn f = mode == MODE_INC ? wave2_lookup_inc(sh[0], sh[1], DP, M - 1)
+                                           : (mode == MODE_PT_DIFF ? wave2_lookup_ptd(sh[0], sh[1], DP, M - 1) : wave2_lookup_ptn(sh[0], sh[1], DP, M - 1));
+        if (f) { *G = sh[0]; *C = sh[1]; return f; }
+    }
+    return nullptr;
+}
+
+// gradient of the register-resident side R (NR sequences) against the streamed side S; pairs (s, r) for all s (diag: s == r)
+int wave2_side(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, int mode, const double* S, const double* R, double* gR, int64_t NS, int64_t NR,
+               int LS, int LR, int d, bool diag, const double* Gup, int64_t gm, int64_t gs, int64_t gr, bool gsym, double gscale, double* gbase,
+               double gbase_scale) {
+    const int M = p->num_levels, dr = mode == MODE_PT_NODIFF ? 0 : 1, PW = 64 / G;
+    const int R1 = LS - dr;
+    // tasks: one register-side sequence x a run of streamed sequences
+    int64_t run = diag ? 1 : (NS * NR + 16383) / 16384;
+    if (run < 1) run = 1;
+    if (run > NS) run = NS;
+    std::vector<SeqTask>& T = c->host_tasks;
+    T.clear();
+    for (int64_t r = 0; r < NR; ++r) {
+        if (diag) { T.push_back(SeqTask{int32_t(r), int32_t(r), 1}); continue; }
+        for (int64_t x0 = 0; x0 < NS; x0 += run) T.push_back(SeqTask{int32_t(r), int32_t(x0), int32_t(NS - x0 < run ? NS - x0 : run)});
+    }
+    void* dt;
+    CHK(ensure(c, B_TASKS, sizeof(SeqTask) * T.size() + 64, &dt));
+    HIPCHK(c, hipMemcpyAsync(dt, T.data(), sizeof(SeqTask) * T.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));         // host_tasks is reused by the next call
+    Wave2Args A;
+    memset(&A, 0, sizeof(A));
+    A.S = S; A.R = R; A.gR = gR; A.NS = int(NS); A.NR = int(NR); A.LS = LS; A.LR = LR; A.d = d;
+    A.M = M; A.kind = p->base_kernel; A.mode = mode; A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
+    A.tasks = static_cast<const SeqTask*>(dt); A.ntasks = int(T.size());
+    A.G = Gup; A.gm = gm; A.gs = gs; A.gr = gr; A.gsym = gsym ? 1 : 0; A.gscale = gscale;
+    A.gbase = gbase; A.gbase_scale = gbase_scale;
+    const int nblocks = int((T.size() + PW - 1) / PW);
+    const size_t lds = sizeof(double) * size_t(PW) * size_t(R1 > 0 ? R1 : 1) * size_t(M - 1 <= 4 ? 4 : 7);
+    hipError_t e = fn(A, nblocks, lds, c->stream);
+    if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_wave2_kernel launch failed: %s", hipGetErrorString(e));
+    return GPSIG_OK;
+}
+
 // shared body of the Gram and the diagonal gradient
 int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
              const void* G, void* gX, void* gY, double* g_base) {
@@ -245,11 +302,34 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     double* dgb;
     CHK(gbase_begin(c, &dgb));
     WaveLaunchFn wfn = nullptr;
-    int wG = 0, wC = 0;
-    if (c->grad_impl == 0 && N1 > 0 && N2 > 0) wfn = wave_plan(mode, L2 - (mode == MODE_PT_NODIFF ? 0 : 1), DP, M, &wG, &wC);
+    Wave2LaunchFn w2x = nullptr, w2y = nullptr;            // scratch-free kernels with x resp. y as the register-resident side
+    int wG = 0, wC = 0, w2xG = 0, w2xC = 0, w2yG = 0, w2yC = 0;
+    const int drr = mode == MODE_PT_NODIFF ? 0 : 1;
+    if ((c->grad_impl == 0 || c->grad_impl == 3 || c->grad_impl == 4) && N1 > 0 && N2 > 0) wfn = wave_plan(mode, L2 - drr, DP, M, &wG, &wC);
+    if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0 && L1 - drr > 0 && L2 - drr > 0) {
+        w2x = wave2_plan(mode, L1 - drr, DP, M, c->grad_impl == 4, &w2xG, &w2xC);
+        w2y = (diag || sym) ? w2x : wave2_plan(mode, L2 - drr, DP, M, c->grad_impl == 4, &w2yG, &w2yC);
+        if (!w2x || !w2y) w2x = w2y = nullptr;
+    }
     if (N1 == 0 || N2 == 0) {
         if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
         if (dgY && yb) HIPCHK(c, hipMemsetAsync(dgY, 0, yb, c->stream));
+    } else if (w2x) {
+        const double* Xd = static_cast<const double*>(dX);
+        const double* Gd = static_cast<const double*>(dG);
+        HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
+        if (diag) {
+            // both roles of the pair (x_i, x_i) have the same derivative: twice the register-side gradient
+            CHK(wave2_side(c, p, w2x, w2xG, mode, Xd, Xd, static_cast<double*>(dgX), N1, N1, L1, L1, d, true, Gd, N1, 1, 0, false, 2.0, dgb, 0.5));
+        } else if (sym) {
+            // k(x_s, x_r) = k(x_r, x_s): the gradient of x_r collects G[s][r] + G[r][s] over all s
+            CHK(wave2_side(c, p, w2x, w2xG, mode, Xd, Xd, static_cast<double*>(dgX), N1, N1, L1, L1, d, false, Gd, N1 * N1, N1, 1, true, 1.0, dgb, 0.5));
+        } else {
+            const double* Yd = static_cast<const double*>(dY);
+            HIPCHK(c, hipMemsetAsync(dgY, 0, yb, c->stream));
+            CHK(wave2_side(c, p, w2y, w2yG, mode, Xd, Yd, static_cast<double*>(dgY), N1, N2, L1, L2, d, false, Gd, N1 * N2, N2, 1, false, 1.0, dgb, 1.0));
+            CHK(wave2_side(c, p, w2x, w2xG, mode, Yd, Xd, static_cast<double*>(dgX), N2, N1, L2, L1, d, false, Gd, N1 * N2, 1, N2, false, 1.0, nullptr, 0.0));
+        }
     } else if (wfn) {
         CHK(seq_grad_wave(c, p, wfn, wG, wC, DP, mode, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, d,
                           diag, sym, static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), dgb));

@@ -215,4 +215,317 @@ struct WaveGradArgs {
     int ngroups;                           // groups in flight = scratch slots
 };
 
+// =====================================================================================================================
+// Scratch-free formulation.  The backward sweep does not read the forward Q's back from memory, it UNDOES the forward
+// recursion row by row: Q_m[a-1][b] = Q_m[a][b] - s_m[a][b], with the row prefix s_m[a][b] written as
+// (row total) - (row suffix).  The row totals rowtot_m[a] = sum_b R_m[a][b] are the only thing the forward sweep has to
+// leave behind (M-1 doubles per lattice row, in LDS); the suffixes arrive from the right neighbour exactly like the
+// suffix sums of dM * U do.  Only the gradient of the REGISTER-RESIDENT side (y) is produced -- per-lane accumulators, no
+// cross-lane traffic; the other side comes from a second launch with the roles exchanged (or, for a symmetric Gram, from
+// the symmetry k(x, y) = k(y, x): upstream G + G^T).
+// =====================================================================================================================
+template <int C, int LQ>
+struct WaveUndo {
+    double qf[LQ][C], qfg[LQ];                  // Q_m[a][b_c] and the ghost column Q_m[a][b_0 - 1]; undone row by row
+    double qb[LQ][C], qbg[LQ];                  // as WaveBwd
+    double svout[LQ], sufout[LQ];
+
+    GPSIG_HD void init(const WaveFwd<C, LQ>& fw) {
+#pragma unroll
+        for (int m = 0; m < LQ; ++m) {
+            qfg[m] = fw.qg[m];
+            qbg[m] = svout[m] = sufout[m] = 0.0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { qf[m][c] = fw.q[m][c]; qb[m][c] = 0.0; }
+        }
+    }
+    // rowtot[m-1] = sum_b R_m[a][b]; sufin[m-1] / svin[p-1]: the right neighbour's sufout / svout of ITS previous step.
+    // first_row: a == 0 (Q[-1][.] == 0 exactly); first_lane: b_0 == 0 (Q[.][-1] == 0 exactly).
+    GPSIG_HD void step(const double (&dm)[C], const double (&clev)[LQ + 2], const double (&rowtot)[LQ], const double (&sufin)[LQ],
+                       const double (&svin)[LQ], int M, bool first_row, bool first_lane, double (&lam)[C]) {
+        double D[LQ + 1][C];                    // D[m][c] = Q_m[a-1][b_c - 1];  D[0] == 1
+#pragma unroll
+        for (int c = 0; c < C; ++c) D[0][c] = 1.0;
+#pragma unroll
+        for (int m = 1; m <= LQ; ++m) {
+            if (m < M) {
+                double v = sufin[m - 1] - rowtot[m - 1];
+#pragma unroll
+                for (int c = C - 1; c >= 0; --c) {
+                    qf[m - 1][c] += v;                              // Q_m[a-1][b_c] = Q_m[a][b_c] - (rowtot - suffix beyond b_c)
+                    v = fma(dm[c], D[m - 1][c], v);                 // + R_m[a][b_c]
+                }
+                qfg[m - 1] += v;
+                sufout[m - 1] = v + rowtot[m - 1];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                double d = c == 0 ? qfg[m - 1] : qf[m - 1][c > 0 ? c - 1 : 0];
+                if (first_row || (first_lane && c == 0) || m >= M) d = 0.0;
+                D[m][c] = d;
+            }
+        }
+        double U[LQ + 2][C];
+#pragma unroll
+        for (int p = 1; p <= LQ + 1; ++p)
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int pi = p - 1 < LQ ? p - 1 : LQ - 1;
+                if (p < M) U[p][c] = clev[p] + (c < C - 1 ? qb[pi][c < C - 1 ? c + 1 : c] : qbg[pi]);
+                else U[p][c] = p == M ? clev[p] : 0.0;
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            double l = U[1][c];
+#pragma unroll
+            for (int p = 2; p <= LQ + 1; ++p)
+                if (p <= M) l = fma(D[p - 1][c], U[p][c], l);
+            lam[c] = l;
+        }
+#pragma unroll
+        for (int p = 1; p <= LQ; ++p)
+            if (p < M) {
+                double sv = svin[p - 1];
+#pragma unroll
+                for (int c = C - 1; c >= 0; --c) {
+                    sv = fma(dm[c], U[p + 1][c], sv);
+                    qb[p - 1][c] += sv;
+                }
+                svout[p - 1] = sv;
+                qbg[p - 1] += svin[p - 1];
+            }
+    }
+};
+
+// Backward-sweep dM generator that also accumulates the gradient of the lane's own y points.
+//   g[c][f], c = 0..C: gradient with respect to feature f of point y_{b_0 + c}   (MODE_PT_NODIFF: c < C)
+// MODE_INC works on increments (dM = <dx_a, dy_b>): g is first accumulated per increment column and folded to points by fold().
+template <int C, int DP, int MODE>
+struct WaveGy {
+    double y[C + 1][DP], ys[C + 1];     // the lane's points (MODE_INC: y[c], c < C, holds the increment y_{b+1} - y_b)
+    double g[C + 1][DP];
+    double xk[DP];                       // the x point row kept from the previous step
+    double rd[C];                        // MODE_PT_DIFF: kappa(x_{a+1}, y_{b+1}) - kappa(x_{a+1}, y_b)
+    double wy[C + 1], wx[C + 1];         // MODE_PT_DIFF: d kappa(x_{a+1}, y_c)/dy = wx * x + wy * y   (coefficients of the kept row)
+    double lamk[C];                      // Lam of the row processed in the previous step
+    double gp0;
+    int nvalid;
+
+    // once per run of x sequences: the lane's points and zeroed accumulators
+    GPSIG_HD void set_y(const double (&ypts)[C + 1][DP], int nvalid_) {
+        nvalid = nvalid_;
+        gp0 = 0.0;
+#pragma unroll
+        for (int c = 0; c <= C; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int f = 0; f < DP; ++f) {
+                if (MODE == MODE_INC) { if (c < C) y[c][f] = ypts[c + 1][f] - ypts[c][f]; else y[c][f] = 0.0; }
+                else y[c][f] = ypts[c][f];
+                s = fma(ypts[c][f], ypts[c][f], s);
+                g[c][f] = 0.0;
+            }
+            ys[c] = s;
+        }
+    }
+    // gradient of point c (0 .. nvalid, or .. nvalid-1 without differences), feature f, after a run
+    GPSIG_HD double point_grad(int c, int f) const {
+        if (MODE != MODE_INC) return g[c][f];
+        return (c > 0 ? g[c > 0 ? c - 1 : 0][f] : 0.0) - (c < nvalid ? g[c < C ? c : C - 1][f] : 0.0);
+    }
+    // kappa and d kappa/dy coefficients of one x row against the lane's points
+    GPSIG_HD void eval_row(const double (&x)[DP], int kind, double p0, double p1, double (&k)[C + 1], double (&cwy)[C + 1], double (&cwx)[C + 1],
+                           double (&dp)[C + 1], int npts) const {
+        double xs = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) xs = fma(x[f], x[f], xs);
+#pragma unroll
+        for (int c = 0; c <= C; ++c) {
+            if (c < npts) {
+                double in = 0.0;
+#pragma unroll
+                for (int f = 0; f < DP; ++f) in = fma(x[f], y[c][f], in);
+                const BaseGrad bg = base_eval_grad(kind, in, xs, ys[c], p0, p1);
+                k[c] = bg.k;
+                cwx[c] = bg.cy - bg.cd;          // d kappa/dy = (cy - cd) x + (cx2 + cd) y
+                cwy[c] = bg.cx2 + bg.cd;
+                dp[c] = bg.dp0;
+            } else {
+                k[c] = cwx[c] = cwy[c] = dp[c] = 0.0;
+            }
+        }
+    }
+    // ---- forward sweep (dM only, no derivatives): same storage as the backward sweep uses
+    GPSIG_HD void prime_fwd(const double (&x0)[DP], int kind, double p0, double p1) {
+#pragma unroll
+        for (int f = 0; f < DP; ++f) xk[f] = x0[f];
+        if (MODE == MODE_PT_DIFF) {
+            double k[C + 1];
+            kappa_row(x0, kind, p0, p1, k, nvalid + 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) rd[c] = k[c + 1] - k[c];
+        }
+    }
+    GPSIG_HD void kappa_row(const double (&x)[DP], int kind, double p0, double p1, double (&k)[C + 1], int npts) const {
+        double xs = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) xs = fma(x[f], x[f], xs);
+#pragma unroll
+        for (int c = 0; c <= C; ++c) {
+            double in = 0.0;
+#pragma unroll
+            for (int f = 0; f < DP; ++f) in = fma(x[f], y[c][f], in);
+            k[c] = c < npts ? base_eval<double>(kind, in, xs, ys[c], p0, p1) : 0.0;
+        }
+    }
+    // xnew: x_{a+1} (difference modes) or x_a
+    GPSIG_HD void row_fwd(const double (&xnew)[DP], int kind, double p0, double p1, double (&dm)[C]) {
+        if (MODE == MODE_INC) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int f = 0; f < DP; ++f) acc = fma(xnew[f] - xk[f], y[c][f], acc);
+                dm[c] = acc;
+            }
+#pragma unroll
+            for (int f = 0; f < DP; ++f) xk[f] = xnew[f];
+        } else if (MODE == MODE_PT_DIFF) {
+            double k[C + 1];
+            kappa_row(xnew, kind, p0, p1, k, nvalid + 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double nd = k[c + 1] - k[c];
+                dm[c] = nd - rd[c];
+                rd[c] = nd;
+            }
+        } else {
+            double k[C + 1];
+            kappa_row(xnew, kind, p0, p1, k, nvalid);
+#pragma unroll
+            for (int c = 0; c < C; ++c) dm[c] = k[c];
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (c >= nvalid) dm[c] = 0.0;
+    }
+
+    // before the backward sweep: x_{R1} (difference modes)
+    GPSIG_HD void prime(const double (&x)[DP], int kind, double p0, double p1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) lamk[c] = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) xk[f] = x[f];
+        if (MODE == MODE_PT_DIFF) {
+            double k[C + 1], a1[C + 1], a2[C + 1], dp[C + 1];
+            eval_row(x, kind, p0, p1, k, a1, a2, dp, nvalid + 1);
+#pragma unroll
+            for (int c = 0; c < C; ++c) rd[c] = k[c + 1] - k[c];
+#pragma unroll
+            for (int c = 0; c <= C; ++c) { wy[c] = a1[c]; wx[c] = a2[c]; dpk[c] = dp[c]; }
+        }
+    }
+    double dpk[C + 1];                   // d kappa(x_kept, y_c) / d base_params[0]
+
+    // dM of lattice row a from x_a (backward order); keeps what the contraction of this row needs
+    double xcur[DP], kwy[C + 1], kwx[C + 1], kdp[C + 1], dxa[DP];
+    GPSIG_HD void row(const double (&xa)[DP], int kind, double p0, double p1, double (&dm)[C]) {
+        if (MODE == MODE_INC) {
+#pragma unroll
+            for (int f = 0; f < DP; ++f) dxa[f] = xk[f] - xa[f];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int f = 0; f < DP; ++f) acc = fma(dxa[f], y[c][f], acc);
+                dm[c] = acc;
+            }
+        } else if (MODE == MODE_PT_DIFF) {
+            double k[C + 1], a1[C + 1], a2[C + 1], dp[C + 1];
+            eval_row(xa, kind, p0, p1, k, a1, a2, dp, nvalid + 1);
+#pragma unroll
+            for (int c = 0; c <= C; ++c) { kwy[c] = a1[c]; kwx[c] = a2[c]; kdp[c] = dp[c]; }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double nd = k[c + 1] - k[c];
+                dm[c] = rd[c] - nd;
+                rd[c] = nd;
+            }
+        } else {
+            double k[C + 1], a1[C + 1], a2[C + 1], dp[C + 1];
+            eval_row(xa, kind, p0, p1, k, a1, a2, dp, nvalid);
+#pragma unroll
+            for (int c = 0; c <= C; ++c) { kwy[c] = a1[c]; kwx[c] = a2[c]; kdp[c] = dp[c]; }
+#pragma unroll
+            for (int c = 0; c < C; ++c) dm[c] = k[c];
+        }
+#pragma unroll
+        for (int f = 0; f < DP; ++f) xcur[f] = xa[f];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            if (c >= nvalid) dm[c] = 0.0;
+    }
+    // after Lam of row a is known
+    GPSIG_HD void contract(const double (&lam_in)[C]) {
+        double lam[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) lam[c] = c < nvalid ? lam_in[c] : 0.0;
+        if (MODE == MODE_INC) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int f = 0; f < DP; ++f) g[c][f] = fma(lam[c], dxa[f], g[c][f]);
+        } else if (MODE == MODE_PT_DIFF) {
+            // adjoint of rd of the KEPT row (x_{a+1}): grd[c] = Lam[a][c] - Lam[a+1][c]; point c receives grd[c-1] - grd[c]
+            double h[C + 1];
+#pragma unroll
+            for (int c = 0; c <= C; ++c) {
+                const double left = c > 0 ? lam[c - 1] - lamk[c - 1] : 0.0;
+                const double right = c < C ? lam[c] - lamk[c] : 0.0;
+                h[c] = left - right;
+                gp0 = fma(h[c], dpk[c], gp0);
+            }
+#pragma unroll
+            for (int c = 0; c <= C; ++c) {
+                const double a = h[c] * wx[c], b = h[c] * wy[c];
+#pragma unroll
+                for (int f = 0; f < DP; ++f) g[c][f] = fma(a, xk[f], fma(b, y[c][f], g[c][f]));
+            }
+#pragma unroll
+            for (int c = 0; c <= C; ++c) { wy[c] = kwy[c]; wx[c] = kwx[c]; dpk[c] = kdp[c]; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double a = lam[c] * kwx[c], b = lam[c] * kwy[c];
+                gp0 = fma(lam[c], kdp[c], gp0);
+#pragma unroll
+                for (int f = 0; f < DP; ++f) g[c][f] = fma(a, xcur[f], fma(b, y[c][f], g[c][f]));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) lamk[c] = lam[c];
+#pragma unroll
+        for (int f = 0; f < DP; ++f) xk[f] = xcur[f];
+    }
+    // after the last row (a == 0) of a pair: the kept row is x_0 (MODE_PT_DIFF only)
+    GPSIG_HD void finish_pair() {
+        if (MODE == MODE_PT_DIFF) {
+            double h[C + 1];
+#pragma unroll
+            for (int c = 0; c <= C; ++c) {
+                const double left = c > 0 ? -lamk[c - 1] : 0.0;
+                const double right = c < C ? -lamk[c] : 0.0;
+                h[c] = left - right;
+                gp0 = fma(h[c], dpk[c], gp0);
+            }
+#pragma unroll
+            for (int c = 0; c <= C; ++c) {
+                const double a = h[c] * wx[c], b = h[c] * wy[c];
+#pragma unroll
+                for (int f = 0; f < DP; ++f) g[c][f] = fma(a, xk[f], fma(b, y[c][f], g[c][f]));
+            }
+        }
+    }
+};
+
 }  // namespace gpsig

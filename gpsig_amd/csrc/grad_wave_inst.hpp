@@ -16,6 +16,21 @@ hipError_t wave_launch(const WaveGradArgs& a, int nblocks, hipStream_t s) {
     X(16, 2, 4) X(16, 2, 8) X(16, 2, 16) X(16, 4, 4) X(16, 4, 8) X(16, 4, 16) \
     X(64, 2, 4) X(64, 2, 8) X(64, 2, 16) X(64, 4, 16) X(64, 8, 4) X(64, 8, 8)
 
+typedef hipError_t (*Wave2LaunchFn)(const Wave2Args&, int, size_t, hipStream_t);
+template <int G, int C, int DP, int LQ, int MODE>
+hipError_t wave2_launch(const Wave2Args& a, int nblocks, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((seq_grad_wave2_kernel<G, C, DP, LQ, MODE>), dim3(nblocks), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+template <int MODE>
+Wave2LaunchFn wave2_lookup_mode(int G, int C, int DP, int LQ) {
+#define X_W2(G_, C_, D_)                                                             \
+    if (G == G_ && C == C_ && DP == D_) return LQ <= 4 ? wave2_launch<G_, C_, D_, 4, MODE> : wave2_launch<G_, C_, D_, 7, MODE>;
+    GPSIG_WAVE_SHAPES(X_W2)
+#undef X_W2
+    return nullptr;
+}
+
 template <int MODE>
 WaveLaunchFn wave_lookup_mode(int G, int C, int DP, int LQ) {
 #define X_W(G_, C_, D_)                                                              \

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "grad_wave_core.hpp"
+#include "seq_args.hpp"
 
 namespace gpsig {
 
@@ -242,6 +243,141 @@ __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs
     if (SIDE == 0 && A.gbase) {
         grad_add(&A.gbase[0], gp0, true, true);          // one atomic per wavefront
     }
+}
+
+}  // namespace gpsig
+
+namespace gpsig {
+
+// ---- scratch-free kernel (WaveUndo / WaveGy) ------------------------------------------------------------------------------
+// A task = one register-side sequence against a run of streamed sequences; 64/G tasks per wavefront in lock step.
+struct Wave2Args {
+    const double* S; const double* R;      // streamed side / register-resident side, user layout (N, L, d)
+    double* gR;                            // gradient of the register-resident side, (NR, LR, d), accumulated with atomics
+    int NS, NR, LS, LR, d;
+    int M, kind, mode;
+    double p0, p1;
+    const SeqTask* tasks;                  // y0 = register-side sequence, x0 / nx = run of streamed sequences
+    int ntasks;
+    const double* G; int64_t gm, gs, gr;   // upstream: G[m * gm + s * gs + r * gr]
+    int gsym;                              // add the transposed term G[m * gm + r * gs + s * gr] (symmetric Gram)
+    double gscale;                         // 1, or 2 for the diagonal (both roles of the same sequence)
+    double* gbase; double gbase_scale;     // optional: d/d base_params[0], scaled (0.5 where both orders of a pair are swept)
+};
+
+// dynamic LDS: (64 / G) * (LS rows) * LQ doubles
+template <int G, int C, int DP, int LQ, int MODE>
+__global__ void __launch_bounds__(64) seq_grad_wave2_kernel(const Wave2Args A) {
+    extern __shared__ double w2_sm[];
+    constexpr int PW = 64 / G;
+    const int lane = threadIdx.x, lam = lane % G, gw = lane / G;
+    const int dr = MODE == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = A.LS - dr, R2 = A.LR - dr, M = A.M;
+    const int TF = R1 + G - 1;
+    double* rt = w2_sm + size_t(gw) * (R1 > 0 ? R1 : 1) * LQ;         // rowtot[a][m-1]
+    const int tid = blockIdx.x * PW + gw;
+    const bool has_task = tid < A.ntasks;
+    const SeqTask tk = has_task ? A.tasks[tid] : SeqTask{0, 0, 0};
+    // the longest run in this wavefront
+    int nmax = tk.nx;
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
+    const int64_t r = tk.y0;
+    const int last_lane = R2 > 0 ? (R2 - 1) / C : 0;
+
+    WaveGy<C, DP, MODE> gy;
+    {
+        double ypts[C + 1][DP];
+#pragma unroll
+        for (int c = 0; c <= C; ++c) wave_load_point<DP>(A.R, r, A.LR, A.d, C * lam + c, ypts[c]);
+        int nv = R2 - C * lam;
+        gy.set_y(ypts, nv < 0 ? 0 : (nv > C ? C : nv));
+    }
+    for (int it = 0; it < nmax; ++it) {
+        const bool have = has_task && it < tk.nx;
+        const int64_t s = tk.x0 + (have ? it : 0);
+        double clev[LQ + 2];
+#pragma unroll
+        for (int p = 0; p < LQ + 2; ++p) {
+            double v = 0.0;
+            if (have && p >= 1 && p <= M) {
+                v = A.G[p * A.gm + s * A.gs + r * A.gr];
+                if (A.gsym) v += A.G[p * A.gm + r * A.gs + s * A.gr];
+                v *= A.gscale;
+            }
+            clev[p] = v;
+        }
+        WaveFwd<C, LQ> fw;
+        fw.reset();
+        double xn[DP];
+        if (MODE != MODE_PT_NODIFF) {
+            wave_load_point<DP>(A.S, s, A.LS, A.d, 0, xn);
+            gy.prime_fwd(xn, A.kind, A.p0, A.p1);
+        }
+        wave_load_point<DP>(A.S, s, A.LS, A.d, 0 - lam + dr, xn);          // row of step 0
+        for (int t = 0; t < TF; ++t) {
+            double cin[LQ + 2], xnext[DP];
+            cin[0] = 0.0;
+#pragma unroll
+            for (int m = 1; m < LQ + 2; ++m) cin[m] = wave_from_left<G>(fw.sout[m]);
+            const int a = t - lam;
+            wave_load_point<DP>(A.S, s, A.LS, A.d, a + 1 + dr, xnext);     // prefetch the row of step t+1
+            if (a >= 0 && a < R1) {
+                double dm[C];
+                gy.row_fwd(xn, A.kind, A.p0, A.p1, dm);
+                fw.step(dm, cin, M);
+                if (lam == last_lane) {
+#pragma unroll
+                    for (int m = 1; m <= LQ; ++m) rt[a * LQ + m - 1] = m < M ? fw.sout[m] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < DP; ++f) xn[f] = xnext[f];
+        }
+        __syncthreads();
+        WaveUndo<C, LQ> bw;
+        bw.init(fw);
+        {
+            double xl[DP];
+            wave_load_point<DP>(A.S, s, A.LS, A.d, R1, xl);
+            gy.prime(xl, A.kind, A.p0, A.p1);
+        }
+        wave_load_point<DP>(A.S, s, A.LS, A.d, R1 - 1 + (G - 1 - lam), xn);  // row of step 0 (out of range -> zeros)
+        for (int u = 0; u < TF; ++u) {
+            double sufin[LQ], svin[LQ], xnext[DP];
+#pragma unroll
+            for (int p = 0; p < LQ; ++p) {
+                sufin[p] = wave_from_right<G>(bw.sufout[p]);
+                svin[p] = wave_from_right<G>(bw.svout[p]);
+            }
+            const int a = R1 - 1 - (u - (G - 1 - lam));
+            wave_load_point<DP>(A.S, s, A.LS, A.d, a - 1, xnext);
+            if (a >= 0 && a < R1) {
+                double dm[C], rtv[LQ], lv[C];
+#pragma unroll
+                for (int p = 0; p < LQ; ++p) rtv[p] = rt[a * LQ + p];
+                gy.row(xn, A.kind, A.p0, A.p1, dm);
+                bw.step(dm, clev, rtv, sufin, svin, M, a == 0, lam == 0, lv);
+                gy.contract(lv);
+                if (a == 0) gy.finish_pair();
+            }
+#pragma unroll
+            for (int f = 0; f < DP; ++f) xn[f] = xnext[f];
+        }
+        __syncthreads();
+    }
+    if (has_task) {
+        const int npts = MODE == MODE_PT_NODIFF ? gy.nvalid : (gy.nvalid > 0 ? gy.nvalid + 1 : 0);
+#pragma unroll
+        for (int c = 0; c <= C; ++c)
+            if (c < npts) {
+                const int q = C * lam + c;
+#pragma unroll
+                for (int f = 0; f < DP; ++f)
+                    if (f < A.d) atomicAdd(&A.gR[(r * A.LR + q) * A.d + f], gy.point_grad(c, f));
+            }
+    }
+    if (A.gbase) grad_add(&A.gbase[0], gy.gp0 * A.gbase_scale, true, has_task);
 }
 
 }  // namespace gpsig

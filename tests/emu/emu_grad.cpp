@@ -313,3 +313,137 @@ int emu_seq_grad_wave(const double* X, const double* Y, int N1, int N2, int L1, 
     return 0;
 }
 }
+
+namespace {
+// lock-step emulation of the scratch-free wave formulation: gradient of the register-resident side only.
+// gy: (L2, d) accumulated.
+template <int G, int C, int DP, int LQ, int MODE>
+double wave2_pair(const double* X, const double* Y, int i, int j, int L1, int L2, int d, int M, int kind, double p0, double p1,
+                  const double* clev_in, double* gy) {
+    const int dr = MODE == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = L1 - dr, R2 = L2 - dr, TF = R1 + G - 1;
+    auto load = [&](const double* S, int seq, int L, int r, double (&v)[DP]) {
+        for (int f = 0; f < DP; ++f) v[f] = (r >= 0 && r < L && f < d) ? S[(size_t(seq) * L + r) * d + f] : 0.0;
+    };
+    std::vector<WaveDm<C, DP, MODE>> dm(G);
+    std::vector<WaveGy<C, DP, MODE>> gyl(G);
+    std::vector<WaveFwd<C, LQ>> fw(G);
+    std::vector<double> rowtot(size_t(R1 > 0 ? R1 : 1) * LQ, 0.0);
+    double clev[LQ + 2];
+    for (int p = 0; p < LQ + 2; ++p) clev[p] = (p >= 1 && p <= M) ? clev_in[p] : 0.0;
+    const int last_lane = R2 > 0 ? (R2 - 1) / C : 0;
+    for (int l = 0; l < G; ++l) {
+        double ypts[C + 1][DP];
+        for (int c = 0; c <= C; ++c) load(Y, j, L2, C * l + c, ypts[c]);
+        int nv = R2 - C * l;
+        nv = nv < 0 ? 0 : (nv > C ? C : nv);
+        dm[l].set_y(ypts, nv);
+        gyl[l].set_y(ypts, nv);
+        fw[l].reset();
+        if (MODE != MODE_PT_NODIFF) { double x0[DP]; load(X, i, L1, 0, x0); dm[l].prime(x0, kind, p0, p1); }
+    }
+    for (int t = 0; t < TF; ++t) {
+        std::vector<std::array<double, LQ + 2>> snap(G);
+        for (int l = 0; l < G; ++l)
+            for (int m = 0; m < LQ + 2; ++m) snap[l][m] = l > 0 ? fw[l - 1].sout[m] : 0.0;
+        for (int l = 0; l < G; ++l) {
+            const int a = t - l;
+            if (a < 0 || a >= R1) continue;
+            double cin[LQ + 2], xn[DP], dmv[C];
+            for (int m = 0; m < LQ + 2; ++m) cin[m] = snap[l][m];
+            cin[0] = 0.0;
+            load(X, i, L1, a + dr, xn);
+            dm[l].row(xn, true, kind, p0, p1, dmv);
+            fw[l].step(dmv, cin, M);
+            if (l == last_lane)
+                for (int m = 1; m <= LQ; ++m) rowtot[size_t(a) * LQ + m - 1] = m < M ? fw[l].sout[m] : 0.0;
+        }
+    }
+    std::vector<WaveUndo<C, LQ>> bw(G);
+    for (int l = 0; l < G; ++l) {
+        bw[l].init(fw[l]);
+        double xl[DP];
+        load(X, i, L1, R1, xl);            // difference modes: x_{R1}; no-difference: row R1 does not exist (zeros), unused
+        gyl[l].prime(xl, kind, p0, p1);
+    }
+    for (int u = 0; u < TF; ++u) {
+        std::vector<std::array<double, 2 * LQ>> snap(G);
+        for (int l = 0; l < G; ++l)
+            for (int p = 0; p < LQ; ++p) {
+                snap[l][p] = l < G - 1 ? bw[l + 1].sufout[p] : 0.0;
+                snap[l][LQ + p] = l < G - 1 ? bw[l + 1].svout[p] : 0.0;
+            }
+        for (int l = 0; l < G; ++l) {
+            const int a = R1 - 1 - (u - (G - 1 - l));
+            if (a < 0 || a >= R1) continue;
+            double sufin[LQ], svin[LQ], rt[LQ], xn[DP], dmv[C], lv[C];
+            for (int p = 0; p < LQ; ++p) { sufin[p] = snap[l][p]; svin[p] = snap[l][LQ + p]; rt[p] = rowtot[size_t(a) * LQ + p]; }
+            load(X, i, L1, a, xn);
+            gyl[l].row(xn, kind, p0, p1, dmv);
+            bw[l].step(dmv, clev, rt, sufin, svin, M, a == 0, l == 0, lv);
+            gyl[l].contract(lv);
+            if (a == 0) gyl[l].finish_pair();
+        }
+    }
+    double gp0 = 0.0;
+    for (int l = 0; l < G; ++l) {
+        gp0 += gyl[l].gp0;
+        const int npts = MODE == MODE_PT_NODIFF ? gyl[l].nvalid : (gyl[l].nvalid > 0 ? gyl[l].nvalid + 1 : 0);
+        for (int c = 0; c < npts; ++c) {
+            const int q = C * l + c;
+            for (int f = 0; f < d; ++f) {
+                double v;
+                if (MODE == MODE_INC) v = (c > 0 ? gyl[l].g[c - 1][f] : 0.0) - (c < gyl[l].nvalid ? gyl[l].g[c][f] : 0.0);
+                else v = gyl[l].g[c][f];
+                gy[size_t(q) * d + f] += v;
+            }
+        }
+    }
+    return gp0;
+}
+
+template <int G, int C, int DP, int LQ>
+double wave2_pair_mode(int mode, const double* X, const double* Y, int i, int j, int L1, int L2, int d, int M, int kind, double p0, double p1,
+                       const double* clev, double* gy) {
+    if (mode == MODE_INC) return wave2_pair<G, C, DP, LQ, MODE_INC>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, gy);
+    if (mode == MODE_PT_DIFF) return wave2_pair<G, C, DP, LQ, MODE_PT_DIFF>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, gy);
+    return wave2_pair<G, C, DP, LQ, MODE_PT_NODIFF>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, gy);
+}
+}  // namespace
+
+extern "C" {
+// Scratch-free wave formulation: every pair is swept twice, once per role, each sweep yielding the gradient of its
+// register-resident side.  Same contract as emu_seq_grad.
+int emu_seq_grad_wave2(const double* X, const double* Y, int N1, int N2, int L1, int L2, int d, int M, int kind, int mode, double p0, double p1,
+                       int diag, const double* G, double* gX, double* gY, double* gbase, int Gg, int Cc) {
+    const int DP = pad_of(d);
+    const bool sym = !diag && !Y;
+    if (diag || sym) { N2 = N1; L2 = L1; Y = X; gY = gX; }
+    const int dr = mode == MODE_PT_NODIFF ? 0 : 1;
+    if (DP != 4 && DP != 8) return -2;
+    if (L1 - dr > Gg * Cc || L2 - dr > Gg * Cc || M > 8) return -2;
+    std::fill(gX, gX + size_t(N1) * L1 * d, 0.0);
+    if (gY != gX) std::fill(gY, gY + size_t(N2) * L2 * d, 0.0);
+    std::vector<double> clev(M + 1);
+    double gp0 = 0.0;
+    for (int i = 0; i < N1; ++i)
+        for (int j = diag ? i : 0; j < (diag ? i + 1 : N2); ++j) {
+            for (int m = 0; m <= M; ++m) clev[m] = diag ? G[size_t(m) * N1 + i] : G[(size_t(m) * N1 + i) * N2 + j];
+#define WP2(GG, CC, DD, LL, XX, YY, II, JJ, LA, LB, OUT) wave2_pair_mode<GG, CC, DD, LL>(mode, XX, YY, II, JJ, LA, LB, d, M, kind, p0, p1, clev.data(), OUT)
+#define BOTH(GG, CC, DD, LL)                                                                  \
+    do {                                                                                      \
+        gp0 += WP2(GG, CC, DD, LL, X, Y, i, j, L1, L2, gY + size_t(j) * L2 * d);              \
+        WP2(GG, CC, DD, LL, Y, X, j, i, L2, L1, gX + size_t(i) * L1 * d);                     \
+    } while (0)
+            const bool small = M <= 5;
+            if (Gg == 16 && Cc == 2) { if (DP == 4) { if (small) BOTH(16, 2, 4, 4); else BOTH(16, 2, 4, 7); } else { if (small) BOTH(16, 2, 8, 4); else BOTH(16, 2, 8, 7); } }
+            else if (Gg == 16 && Cc == 4) { if (DP == 4) { if (small) BOTH(16, 4, 4, 4); else BOTH(16, 4, 4, 7); } else { if (small) BOTH(16, 4, 8, 4); else BOTH(16, 4, 8, 7); } }
+            else if (Gg == 64 && Cc == 2) { if (DP == 4) { if (small) BOTH(64, 2, 4, 4); else BOTH(64, 2, 4, 7); } else { if (small) BOTH(64, 2, 8, 4); else BOTH(64, 2, 8, 7); } }
+            else return -2;
+#undef BOTH
+#undef WP2
+        }
+    if (gbase) { gbase[0] = gp0; gbase[1] = 0.0; }
+    return 0;
+}
+}

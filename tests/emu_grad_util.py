@@ -66,7 +66,7 @@ def tens_grad(Z, G, M, base, increments, p0=0.0, p1=0.0):
     return gZ, gb[0]
 
 
-def seq_grad_wave(X, Y, G, M, base, difference, p0=0.0, p1=0.0, diag=False, group=16, cols=4):
+def seq_grad_wave(X, Y, G, M, base, difference, p0=0.0, p1=0.0, diag=False, group=16, cols=4, scratch_free=False):
     """The wave formulation (skewed forward sweep, oppositely skewed backward sweep).  -> gX, gY, g_p0"""
     X = np.ascontiguousarray(X, np.float64)
     Y = None if Y is None else np.ascontiguousarray(Y, np.float64)
@@ -74,8 +74,9 @@ def seq_grad_wave(X, Y, G, M, base, difference, p0=0.0, p1=0.0, diag=False, grou
     N1, L1, d = X.shape
     N2, L2 = (N1, L1) if Y is None else Y.shape[:2]
     gX, gY, gb = np.zeros_like(X), (None if Y is None else np.zeros_like(Y)), np.zeros(2)
-    rc = lib().emu_seq_grad_wave(_ptr(X), _ptr(Y), N1, N2, L1, L2, d, M, BASE_IDS[base], lattice_mode(base, difference), C.c_double(p0), C.c_double(p1),
-                                 int(diag), _ptr(G), _ptr(gX), _ptr(gY), _ptr(gb), int(group), int(cols))
+    fn = lib().emu_seq_grad_wave2 if scratch_free else lib().emu_seq_grad_wave
+    rc = fn(_ptr(X), _ptr(Y), N1, N2, L1, L2, d, M, BASE_IDS[base], lattice_mode(base, difference), C.c_double(p0), C.c_double(p1),
+            int(diag), _ptr(G), _ptr(gX), _ptr(gY), _ptr(gb), int(group), int(cols))
     if rc != 0:
         raise NotImplementedError("wave emulator: unsupported shape")
     return gX, gY, gb[0]

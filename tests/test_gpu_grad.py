@@ -363,7 +363,7 @@ def test_wave_and_storage_gradient_kernels_agree(base, difference):
         keep = []
         p = _params(base, d, M, difference, keep)
         res = []
-        for impl in (0, 1):
+        for impl in (1, 0, 3, 4):   # one pair per thread (stored lattice) / planner's choice / wavefront + stored lattice / wavefront scratch-free
             ctx.set_option("grad_impl", impl)
             gX, gY = np.empty_like(X), (None if Y is None else np.empty_like(Y))
             if kind == "diag":
@@ -373,6 +373,7 @@ def test_wave_and_storage_gradient_kernels_agree(base, difference):
                          _vp(G), _vp(gX), _vp(gY), None)
             res.append((gX, gY))
         ctx.set_option("grad_impl", 0)
-        assert rel(res[0][0], res[1][0]) < 1e-9, (kind, L2, rel(res[0][0], res[1][0]))
-        if Y is not None:
-            assert rel(res[0][1], res[1][1]) < 1e-9, (kind, L2, rel(res[0][1], res[1][1]))
+        for k in (1, 2, 3):
+            assert rel(res[k][0], res[0][0]) < 1e-9, (kind, L2, k, rel(res[k][0], res[0][0]))
+            if Y is not None:
+                assert rel(res[k][1], res[0][1]) < 1e-9, (kind, L2, k, rel(res[k][1], res[0][1]))
