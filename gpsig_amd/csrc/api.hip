@@ -289,7 +289,7 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
     if (k < 0)
         return fail(c, GPSIG_ERR_UNSUPPORTED,
                     "no seq-gram kernel shape for %d record rows on the register-resident side, d=%d, num_levels=%d "
-                    "(built: rows <= 512, d*(num_lags+1) <= 16 (<= 8 beyond 256 rows), num_levels <= 8)",
+                    "(built: rows <= 512 for d*(num_lags+1) <= 8, <= 256 up to 16, <= 128 up to 32; num_levels <= 8)",
                     g0.rows, d_eff, p->num_levels);
     out->cfg = tab[k];
     out->mode = g0.mode;

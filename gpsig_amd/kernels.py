@@ -394,6 +394,8 @@ class SignatureKernel:
         per level (low_rank_calculations.py:76-193).  Returns a LowRankState that can be passed to K(..., lr_state=)."""
         cands = []
         L_ = _Launch(X, X2)
+        if L_.f32:
+            raise NotImplementedError("low-rank mode is built for float64 only")
         p = self._params(L_.keep, _lib.F64)
         total = 0
         seqs = []

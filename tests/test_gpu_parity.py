@@ -341,11 +341,32 @@ def test_shards_partition_the_gram(K):
         ctx.set_option("max_run", 0)
 
 
+@pytest.mark.parametrize("base", ["linear", "rbf", "matern32"])
+def test_wide_state_spaces(K, base):
+    """d * (num_lags + 1) up to 32 (the reference's benchmarks run with num_lags = 1 on data sets with more than 8 channels)."""
+    rng = np.random.default_rng(77)
+    for (N, N2, L, d, M, lags, f32) in [(9, 5, 20, 20, 4, 0, False), (7, 6, 100, 12, 3, 1, False), (6, 4, 30, 32, 5, 0, False), (8, 8, 40, 17, 4, 0, True)]:
+        X, X2 = rng.standard_normal((N, L * d)) * 0.4, rng.standard_normal((N2, L * d)) * 0.4
+        cls = {"linear": K.SignatureLinear, "rbf": K.SignatureRBF, "matern32": K.SignatureMatern32}[base]
+        kw = dict(num_lags=lags or None, lengthscales=rng.uniform(0.8, 1.5, d))
+        k = cls(L * d, d, M, **kw)
+        ko = O.SignatureKernelOracle(L * d, d, M, base=base, **kw)
+        dt = np.float32 if f32 else np.float64
+        tol = 1e-4 if f32 else 1e-6
+        for got, want in ((k.K(X.astype(dt)), ko.K(X)), (k.K(X.astype(dt), X2.astype(dt)), ko.K(X, X2)), (k.Kdiag(X.astype(dt)), ko.Kdiag(X))):
+            assert np.abs(np.asarray(got, dtype=np.float64) - want).max() <= tol * np.abs(want).max(), (base, d, lags, f32)
+        Z = rng.standard_normal((M * (M + 1) // 2, 5, d * (lags + 1))) * 0.4
+        got, want = k.K_tens_vs_seq(Z.astype(dt), X.astype(dt)), ko.K_tens_vs_seq(Z, X)
+        assert np.abs(np.asarray(got, dtype=np.float64) - want).max() <= tol * np.abs(want).max()
+
+
 def test_unsupported_shapes_fail_loudly(K):
     with pytest.raises(NotImplementedError, match="no seq-gram kernel shape"):
         K.SignatureLinear(2 * 600, 2, 3).K(np.zeros((2, 1200)))            # 600 rows on the register side
     with pytest.raises(NotImplementedError, match="no seq-gram kernel shape"):
-        K.SignatureLinear(20 * 5, 20, 3).K(np.zeros((2, 100)))             # d = 20 > 16
+        K.SignatureLinear(20 * 200, 20, 3).K(np.zeros((2, 4000)))          # d = 20 needs the 32-wide shapes: up to 128 rows
+    with pytest.raises(NotImplementedError):
+        K.SignatureLinear(40 * 5, 40, 3).K(np.zeros((2, 200)))             # d = 40 > 32
     with pytest.raises(NotImplementedError):
         K.SignatureRBF(12, 3, 3, low_rank=True, num_components=4).K(np.zeros((4, 12), dtype=np.float32))   # low-rank is float64 only
     with pytest.raises(ValueError):
