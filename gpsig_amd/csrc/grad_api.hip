@@ -90,26 +90,28 @@ int launch_tvs_fused(gpsig_ctx* c, int DP, int E, dim3 grid, const TvsGradArgs& 
     return GPSIG_OK;
 }
 // tensor-lane variant (operands in LDS, wavefront reduction of the observations' gradient)
-size_t tvs_lanet_lds(int DP, int E, int L, bool zreg) {
-    return sizeof(double) * ((zreg ? 0 : size_t(4) * E * 64 * (DP + 2)) + size_t(L) * DP + size_t(L) + 2 * 64 * (DP + 2));
+// E here is what a LANE holds: incremental tensors are split over lane pairs (one point each), so every launch is E == 1
+size_t tvs_lanet_lds(int DP, int L, bool zreg) {
+    return sizeof(double) * ((zreg ? 0 : size_t(4) * 64 * (DP + 2)) + size_t(L) * DP + size_t(L) + 2 * 64 * (DP + 2));
 }
-bool tvs_lanet_zreg(const gpsig_ctx* c, int DP, int E) { return E == 1 && (c->tvs_zreg < 0 ? true : c->tvs_zreg != 0); }
-bool tvs_lanet_available(const gpsig_ctx* c, int DP, int M, int E, int L) {
-    return M <= 4 && DP <= 8 && tvs_lanet_lds(DP, E, L, tvs_lanet_zreg(c, DP, E)) <= 64 * 1024;
-}
-int launch_tvs_lanet(gpsig_ctx* c, int DP, int E, dim3 grid, const TvsLaneTGradArgs& a) {
-    const bool zreg = tvs_lanet_zreg(c, DP, E);
-    const size_t lds = tvs_lanet_lds(DP, E, a.L, zreg);
-#define LANET(DP_, E_, Z_)                                                                                                                          \
-    do {                                                                                                                                           \
-        if (a.kind == BASE_LINEAR) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, BASE_LINEAR, Z_>), grid, dim3(64), lds, c->stream, a);   \
-        else if (a.kind == BASE_RBF) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, BASE_RBF, Z_>), grid, dim3(64), lds, c->stream, a);    \
-        else hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, E_, -1, Z_>), grid, dim3(64), lds, c->stream, a);                                  \
+bool tvs_lanet_zreg(const gpsig_ctx* c) { return c->tvs_zreg < 0 ? true : c->tvs_zreg != 0; }
+bool tvs_lanet_available(const gpsig_ctx* c, int DP, int M, int L) { return M <= 4 && DP <= 8 && tvs_lanet_lds(DP, L, tvs_lanet_zreg(c)) <= 64 * 1024; }
+int launch_tvs_lanet(gpsig_ctx* c, int DP, bool paired, dim3 grid, const TvsLaneTGradArgs& a) {
+    const bool zreg = tvs_lanet_zreg(c);
+    const size_t lds = tvs_lanet_lds(DP, a.L, zreg);
+#define LANET(DP_, Z_, P_)                                                                                                                           \
+    do {                                                                                                                                            \
+        if (a.kind == BASE_LINEAR) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, 1, BASE_LINEAR, Z_, P_>), grid, dim3(64), lds, c->stream, a); \
+        else if (a.kind == BASE_RBF) hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, 1, BASE_RBF, Z_, P_>), grid, dim3(64), lds, c->stream, a);  \
+        else hipLaunchKernelGGL((tvs_grad_lanet_kernel<DP_, 4, 1, -1, Z_, P_>), grid, dim3(64), lds, c->stream, a);                                \
     } while (0)
-    if (DP == 4 && E == 1) { if (zreg) LANET(4, 1, true); else LANET(4, 1, false); }
-    else if (DP == 4) LANET(4, 2, false);
-    else if (E == 1) { if (zreg) LANET(8, 1, true); else LANET(8, 1, false); }
-    else LANET(8, 2, false);
+#define LANET2(DP_)                                              \
+    do {                                                         \
+        if (zreg) { if (paired) LANET(DP_, true, true); else LANET(DP_, true, false); }   \
+        else { if (paired) LANET(DP_, false, true); else LANET(DP_, false, false); }      \
+    } while (0)
+    if (DP == 4) LANET2(4); else LANET2(8);
+#undef LANET2
 #undef LANET
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
@@ -497,7 +499,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     if (T == 0 || N == 0) {
         if (zb) HIPCHK(c, hipMemsetAsync(dgZ, 0, zb, c->stream));
         if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
-    } else if (c->grad_impl == 0 && tvs_lanet_available(c, DP, M, E, L)) {
+    } else if (c->grad_impl == 0 && tvs_lanet_available(c, DP, M, L)) {
         void *zp, *gzp;
         CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
         CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
@@ -512,13 +514,14 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         A.G = static_cast<const double*>(dG); A.gm = T * N; A.gt = N; A.gn = 1;
         A.gbase = dgb;
-        const int64_t tb = (T + 63) / 64;
+        const int tpw = E == 2 ? 32 : 64;              // tensors per wavefront
+        const int64_t tb = (T + tpw - 1) / tpw;
         int64_t runs = (2048 + tb - 1) / tb;
         if (runs > N) runs = N;
         if (runs > 65535) runs = 65535;
         A.nrun = int((N + runs - 1) / runs);
         runs = (N + A.nrun - 1) / A.nrun;
-        CHK(launch_tvs_lanet(c, DP, E, dim3(unsigned(tb), unsigned(runs)), A));
+        CHK(launch_tvs_lanet(c, DP, E == 2, dim3(unsigned(tb), unsigned(runs)), A));
         CHK(unpad_z(c, collapse, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
     } else {
         const int64_t s = pad64(N);

@@ -611,6 +611,8 @@ struct TvsPairGrad {
 // with atomics, the tensor-lane kernel reads both operands from LDS and reduces over the wavefront first.
 //   IO::z(k, e, f): feature f of component k, point e;  IO::zsq(k, e): its squared norm
 //   IO::load_x(tt, v) -> |x_tt|^2     IO::emit_gx(tt, gx)
+//   IO::sign() / IO::combine(k): +1 / identity, except where the two points of an incremental tensor sit in two adjacent
+//   lanes (E == 1 per lane): then sign() is -1 for the first point and combine() adds the partner lane's value.
 //   IO::fence(): called once per time step and before each contraction; an IO whose z() reads LDS makes it an optimisation
 //   barrier so that the compiler re-reads the components instead of keeping all of them in registers.
 template <int E>
@@ -632,7 +634,7 @@ GPSIG_HD TvsEv<E> tvs_eval(const IO& io, int k, const double (&x)[DP], double xs
     r.dp0 = 0.0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const double sgn = (E == 2 && e == 0) ? -1.0 : 1.0;
+        const double sgn = E == 2 ? (e == 0 ? -1.0 : 1.0) : io.sign();
         double in = 0.0;
 #pragma unroll
         for (int f = 0; f < DP; ++f) in = fma(io.z(k, e, f), x[f], in);
@@ -649,6 +651,7 @@ GPSIG_HD TvsEv<E> tvs_eval(const IO& io, int k, const double (&x)[DP], double xs
             r.wz[e] = r.vx[e] = r.vz[e] = 0.0;
         }
     }
+    r.k = io.combine(r.k);
     return r;
 }
 
@@ -784,6 +787,8 @@ struct TvsPairGradFused {
     GPSIG_HD TvsPairGradFused(const TvsGradArgs& a, int t_, int n_, bool valid_) : A(a), t(t_), n(n_), valid(valid_) {}
     GPSIG_HD double z(int k, int e, int f) const { return A.z[((int64_t(k) * A.T + t) * E + e) * DP + f]; }
     GPSIG_HD void fence() const {}
+    GPSIG_HD double sign() const { return 1.0; }
+    GPSIG_HD double combine(double k) const { return k; }
     GPSIG_HD double zsq(int k, int e) const {
         double s = 0.0;
 #pragma unroll

@@ -124,7 +124,7 @@ struct TvsLaneTGradArgs {
 };
 
 // ZREG: the level's components live in registers (affordable when E == 1) instead of LDS
-template <int DP, int MMAX, int E, bool ZREG>
+template <int DP, int MMAX, int E, bool ZREG, bool PAIRED = false>
 struct TvsLaneTIO {
     static constexpr int ZP = DP + 2;      // row stride: 16 consecutive lanes hit 16 different 16-byte bank groups
     const double* zs; const double* xs; const double* xsq; double* red;
@@ -135,6 +135,17 @@ struct TvsLaneTIO {
     double zn[ZREG ? MMAX : 1][E];   // squared norms of the level's components (kept only next to register-resident components)
     int flip;                  // which of the two reduction buffers the next emit uses
     __device__ __forceinline__ void fence() const {}
+    // PAIRED: lanes 2t and 2t+1 hold the two points of incremental tensor t (kernels.py:328-330: kappa(z1, x) - kappa(z0, x))
+    __device__ __forceinline__ double sign() const { return (PAIRED && (lane & 1) == 0) ? -1.0 : 1.0; }
+    __device__ __forceinline__ double combine(double k) const {
+        if constexpr (!PAIRED) return k;
+        else {
+            int lo = __double2loint(k), hi = __double2hiint(k);
+            lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
+            hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true);
+            return k + __hiloint2double(hi, lo);
+        }
+    }
     __device__ __forceinline__ double z(int k, int e, int f) const {
         if constexpr (ZREG) return zr[k][e][f];
         else return zs[((k * E + e) * 64 + lane) * ZP + f];
@@ -171,7 +182,8 @@ struct TvsLaneTIO {
 };
 
 // grid (ceil(T / 64), runs); block 64; dynamic LDS: ((ZREG ? 0 : MMAX * E * 64 * (DP + 2)) + L * DP + L + 2 * 64 * (DP + 2)) doubles
-template <int DP, int MMAX, int E, int KIND, bool ZREG>
+// PAIRED (E == 1 in the template, two points per tensor in the data): 32 tensors per wavefront, lane 2t + e holds point e
+template <int DP, int MMAX, int E, int KIND, bool ZREG, bool PAIRED = false>
 __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradArgs A) {
     extern __shared__ double tvs_sm[];
     constexpr int ZP = DP + 2;
@@ -180,11 +192,13 @@ __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradAr
     double* xsq = xs + A.L * DP;
     double* red = xsq + A.L;
     const int lane = threadIdx.x;
-    const int t = blockIdx.x * 64 + lane;
+    const int t = PAIRED ? blockIdx.x * 32 + lane / 2 : blockIdx.x * 64 + lane;
+    constexpr int EZ = PAIRED ? 2 : E;               // points per tensor in A.z / A.gz
+    const int pe = PAIRED ? (lane & 1) : 0;          // which of them this lane holds
     const bool valid = t < A.T;
     const int n0 = blockIdx.y * A.nrun, n1 = (n0 + A.nrun < A.N) ? n0 + A.nrun : A.N;
     const int R = A.diff ? A.L - 1 : A.L;
-    TvsLaneTIO<DP, MMAX, E, ZREG> io{zs, xs, xsq, red, A, lane, 0, valid, {}, {}, 0};
+    TvsLaneTIO<DP, MMAX, E, ZREG, PAIRED> io{zs, xs, xsq, red, A, lane, 0, valid, {}, {}, 0};
     int k0 = 0;
     double gp0 = 0.0;
     for (int i = 1; i <= A.M; ++i) {
@@ -197,7 +211,7 @@ __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradAr
 #pragma unroll
                 for (int f = 0; f < DP; ++f) {
                     // lanes without a tensor get a harmless finite point
-                    const double v = (j < i && valid) ? A.z[((int64_t(k0 + j) * A.T + t) * E + e) * DP + f] : 1.0;
+                    const double v = (j < i && valid) ? A.z[((int64_t(k0 + j) * A.T + t) * EZ + (PAIRED ? pe : e)) * DP + f] : 1.0;
                     if constexpr (ZREG) io.zr[j][e][f] = v;
                     else if (j < i) zs[((j * E + e) * 64 + lane) * ZP + f] = v;
                     nrm = fma(v, v, nrm);
@@ -236,7 +250,7 @@ __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradAr
 #pragma unroll
                     for (int e = 0; e < E; ++e)
 #pragma unroll
-                        for (int f = 0; f < DP; ++f) atomicAdd(&A.gz[((int64_t(k0 + j) * A.T + t) * E + e) * DP + f], gzacc[j][e][f]);
+                        for (int f = 0; f < DP; ++f) atomicAdd(&A.gz[((int64_t(k0 + j) * A.T + t) * EZ + (PAIRED ? pe : e)) * DP + f], gzacc[j][e][f]);
                 }
         }
         k0 += i;
