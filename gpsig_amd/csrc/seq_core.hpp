@@ -44,6 +44,17 @@ enum : int {
     MODE_PT_NODIFF = 2 // dM[a][b] = kappa(x_a, y_b)        (difference=False, non-linear base kernel)
 };
 
+// exp of a non-positive argument.  float32 on the device: v_exp_f32(x * log2 e), about 1e-6 relative over the range a
+// kernel value can matter in (the float32 tolerance is 1e-4); float64 and the host: the library exp.
+GPSIG_HD double kexp(double x) { return exp(x); }
+GPSIG_HD float kexp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __expf(x);
+#else
+    return expf(x);
+#endif
+}
+
 // Static kernel on R^d from the inner product and the two squared norms (gpsig/kernels.py:765-781, 799-993).
 template <typename T>
 GPSIG_HD T base_eval(int kind, T inner, T xs, T ys, T p0, T p1) {
@@ -54,16 +65,16 @@ GPSIG_HD T base_eval(int kind, T inner, T xs, T ys, T p0, T p1) {
         default: break;
     }
     const T dist = fma(T(-2), inner, xs + ys);                                      // _square_dist :765-776
-    if (kind == BASE_RBF) return exp(-dist / 2);                                    // :862-864
-    if (kind == BASE_MIX) return p0 * exp(-dist / 2) + (T(1) - p0) * inner;         // :881-892
+    if (kind == BASE_RBF) return kexp(-dist / 2);                                    // :862-864
+    if (kind == BASE_MIX) return p0 * kexp(-dist / 2) + (T(1) - p0) * inner;         // :881-892
     const T r = sqrt(fmax(dist, T(1e-40)));                                         // _euclid_dist :779-781
-    if (kind == BASE_MATERN12) return exp(-r);                                      // :955-958
+    if (kind == BASE_MATERN12) return kexp(-r);                                      // :955-958
     if (kind == BASE_MATERN32) {                                                    // :974-977
         const T c = T(1.7320508075688772935);
-        return (T(1) + c * r) * exp(-c * r);
+        return (T(1) + c * r) * kexp(-c * r);
     }
     const T c = T(2.2360679774997896964);                                           // :991-993
-    return (T(1) + c * r + T(5.0 / 3.0) * (r * r)) * exp(-c * r);
+    return (T(1) + c * r + T(5.0 / 3.0) * (r * r)) * kexp(-c * r);
 }
 
 // The same for NV inner products at once, in place: v[i] (inner product) -> kappa.  a2[i] is the squared norm
@@ -85,22 +96,22 @@ GPSIG_HD void base_eval_n(int kind, T (&v)[NV], const T (&a2)[NV], T b2, T p0, T
             return;
         case BASE_RBF:
 #pragma unroll
-            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = exp(-fma(T(-2), v[i], b2 + a2[i]) / 2);
+            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = kexp(-fma(T(-2), v[i], b2 + a2[i]) / 2);
             return;
         case BASE_MIX:
 #pragma unroll
-            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = p0 * exp(-fma(T(-2), v[i], b2 + a2[i]) / 2) + (T(1) - p0) * v[i];
+            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = p0 * kexp(-fma(T(-2), v[i], b2 + a2[i]) / 2) + (T(1) - p0) * v[i];
             return;
         case BASE_MATERN12:
 #pragma unroll
-            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = exp(-sqrt(fmax(fma(T(-2), v[i], b2 + a2[i]), T(1e-40))));
+            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = kexp(-sqrt(fmax(fma(T(-2), v[i], b2 + a2[i]), T(1e-40))));
             return;
         case BASE_MATERN32: {
             const T c = T(1.7320508075688772935);
 #pragma unroll
             for (int i = 0; i < NV; ++i) if (i < nvalid) {
                 const T r = sqrt(fmax(fma(T(-2), v[i], b2 + a2[i]), T(1e-40)));
-                v[i] = (T(1) + c * r) * exp(-c * r);
+                v[i] = (T(1) + c * r) * kexp(-c * r);
             }
             return;
         }
@@ -109,7 +120,7 @@ GPSIG_HD void base_eval_n(int kind, T (&v)[NV], const T (&a2)[NV], T b2, T p0, T
 #pragma unroll
             for (int i = 0; i < NV; ++i) if (i < nvalid) {
                 const T r = sqrt(fmax(fma(T(-2), v[i], b2 + a2[i]), T(1e-40)));
-                v[i] = (T(1) + c * r + T(5.0 / 3.0) * (r * r)) * exp(-c * r);
+                v[i] = (T(1) + c * r + T(5.0 / 3.0) * (r * r)) * kexp(-c * r);
             }
             return;
         }
