@@ -356,14 +356,14 @@ class SignatureKernel:
                     int(bool(full_X_cov)), int(bool(return_levels)), pzz, pzx, pxx)
         return Kzz, Kzx, Kxx
 
-    def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False, presliced=False):
+    def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False, presliced=False, lr_state=None):
         """Reference: kernels.py:674-761 (X = inducing sequences, X2 = data).  Returns (Kxx, Kxx2, Kx2x2).
         The double division of Kxx2 by the X-side diagonal in the diagonal-only branch (:713 + :750) is
         reproduced; the undefined names of :723-728 are read as the evident mirror of :709-712."""
         if not presliced:
             X2, _ = self._slice(X2, None)
         if self.low_rank:
-            raise NotImplementedError("K_seq_n_seq_covs in low-rank mode is not built")
+            return self._K_seq_n_seq_covs_lr(X, X2, full_X2_cov, return_levels, lr_state)
         L_ = _Launch(X, X2)
         n1, l1 = self._seq_dims(X)
         n2, l2 = self._seq_dims(X2)
@@ -462,6 +462,63 @@ class SignatureKernel:
         nrm = int(bool(self.normalization))
         L_.ctx.call("gpsig_lr_kernel", p, lr, pa, pb, n1, n2, nrm, nrm, int(bool(return_levels)), optr)
         return out
+
+    def _K_seq_n_seq_covs_lr(self, X, X2, full_X2_cov, return_levels, lr_state):
+        """kernels.py:696-761, low-rank branch: level Grams of the factor matrices (HIP: features + fp64-MFMA GEMMs), then the
+        normalisation / weighting of :706-761 as elementwise torch ops on the device."""
+        st = lr_state or self.draw_low_rank(X=X, X2=X2)
+        L_ = _Launch(X, X2)
+        if L_.f32:
+            raise NotImplementedError("low-rank mode is built for float64 only")
+        p = self._params(L_.keep)
+        ones = np.ones(self.num_levels + 1)
+        L_.keep.append(ones)
+        p.sigma, p.variances = 1.0, ones.ctypes.data_as(C.POINTER(C.c_double))      # raw level Grams; weights are applied below
+        lr = st.as_c(L_.keep)
+        P1, pp1, n1 = self._lr_features(L_, p, lr, X)
+        P2, pp2, n2 = self._lr_features(L_, p, lr, X2)
+        M1 = self.num_levels + 1
+        Kxx, o11 = L_.out((M1, n1, n1))
+        Kxx2, o12 = L_.out((M1, n1, n2))
+        L_.ctx.call("gpsig_lr_kernel", p, lr, pp1, None, n1, n1, 0, 0, 1, o11)                     # :702
+        L_.ctx.call("gpsig_lr_kernel", p, lr, pp1, pp2, n1, n2, 0, 0, 1, o12)                      # :703
+        if full_X2_cov:
+            K22, o22 = L_.out((M1, n2, n2))
+            L_.ctx.call("gpsig_lr_kernel", p, lr, pp2, None, n2, n2, 0, 0, 1, o22)                 # :718
+        else:
+            K22, o22 = L_.out((M1, n2))
+            L_.ctx.call("gpsig_lr_kernel_diag", p, lr, pp2, n2, 1, o22)                            # :740
+        if not L_.device_mode:
+            L_.ctx.sync()
+        dev = L_.dev if L_.device_mode else torch.device("cuda", 0)
+        t = lambda a: a if _is_torch(a) else torch.as_tensor(a, device=dev)
+        Kxx, Kxx2, K22 = t(Kxx), t(Kxx2), t(K22)
+        w = torch.as_tensor(float(self.sigma) * np.asarray(self.variances, dtype=np.float64), device=dev)
+        if self.normalization:
+            Kxx = Kxx + JITTER * torch.eye(n1, dtype=Kxx.dtype, device=dev)[None]                   # :709
+            dsq = torch.sqrt(torch.diagonal(Kxx, dim1=1, dim2=2))
+            Kxx = Kxx / (dsq[:, :, None] * dsq[:, None, :])
+            Kxx2 = Kxx2 / dsq[:, :, None]                                                           # :713
+        if full_X2_cov:
+            if self.normalization:                                                                  # :723-728 (intent; undefined names there)
+                K22 = K22 + JITTER * torch.eye(n2, dtype=K22.dtype, device=dev)[None]
+                d2 = torch.sqrt(torch.diagonal(K22, dim1=1, dim2=2))
+                Kxx2 = Kxx2 / d2[:, None, :]
+                K22 = K22 / (d2[:, :, None] * d2[:, None, :])
+            K22 = K22 * w[:, None, None]
+        else:
+            if self.normalization:
+                d2 = torch.sqrt(K22 + JITTER)                                                       # :746-748
+                Kxx2 = Kxx2 / (dsq[:, :, None] * d2[:, None, :])                                    # :750 (second division by dsq: reference quirk)
+                K22 = w[:, None].expand(-1, n2).clone()                                             # :751
+            else:
+                K22 = K22 * w[:, None]
+        Kxx, Kxx2 = Kxx * w[:, None, None], Kxx2 * w[:, None, None]
+        if not return_levels:
+            Kxx, Kxx2, K22 = Kxx.sum(0), Kxx2.sum(0), K22.sum(0)
+        if not L_.device_mode:
+            return Kxx.cpu().numpy(), Kxx2.cpu().numpy(), K22.cpu().numpy()
+        return Kxx, Kxx2, K22
 
     # ---- the signature_algs.py layer: unnormalised level tensors -----------------------------------
     def _K_seq(self, X, X2=None):

@@ -719,6 +719,42 @@ class LowRankOracle:
         return self._finish(Kl, return_levels)
 
 
+    def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False):
+        """kernels.py:674-761, low-rank branch (:696-703, :718, :740); normalisation as in the exact branch, including the
+        double division of :713 + :750 and the intent of the undefined names at :723-728."""
+        k = self.k
+        P1, P2 = self.seq_features(X), self.seq_features(X2)
+        N, N2 = P1[0].shape[0], P2[0].shape[0]
+        w = k._weights()
+        Kxx = np.stack([P @ P.T for P in P1], axis=0)                             # :702
+        Kxx2 = np.stack([a @ b.T for a, b in zip(P1, P2)], axis=0)                # :703
+        if k.normalization:
+            Kxx = Kxx + JITTER * np.eye(N)[None]                                  # :709
+            dsq = np.sqrt(np.diagonal(Kxx, axis1=1, axis2=2))
+            Kxx = Kxx / (dsq[:, :, None] * dsq[:, None, :])
+            Kxx2 = Kxx2 / dsq[:, :, None]                                         # :713
+        if full_X2_cov:
+            K22 = np.stack([P @ P.T for P in P2], axis=0)                         # :718
+            if k.normalization:
+                K22 = K22 + JITTER * np.eye(N2)[None]
+                d2 = np.sqrt(np.diagonal(K22, axis1=1, axis2=2))
+                Kxx2 = Kxx2 / d2[:, None, :]
+                K22 = K22 / (d2[:, :, None] * d2[:, None, :])
+            K22 = K22 * w[:, None, None]
+        else:
+            K22 = np.stack([np.sum(np.square(P), axis=-1) for P in P2], axis=0)   # :740
+            if k.normalization:
+                d2 = np.sqrt(K22 + JITTER)
+                Kxx2 = Kxx2 / (dsq[:, :, None] * d2[:, None, :])                  # :750
+                K22 = np.tile(w[:, None], [1, N2])
+            else:
+                K22 = K22 * w[:, None]
+        Kxx, Kxx2 = Kxx * w[:, None, None], Kxx2 * w[:, None, None]
+        if return_levels:
+            return Kxx, Kxx2, K22
+        return Kxx.sum(axis=0), Kxx2.sum(axis=0), K22.sum(axis=0)
+
+
 # ---------------------------------------------------------------------------
 # Independent validators (NOT restatements of the reference): they stand in for esig, which the
 # reference's notebook uses and this image lacks.

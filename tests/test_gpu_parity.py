@@ -547,6 +547,13 @@ def test_low_rank_equals_restatement_given_the_same_randomness(K, sparsity, base
             assert relerr(kx.K_tens_vs_seq(Z, X, increments=incr, lr_state=st, return_levels=True),
                           lo.K_tens_vs_seq(Z, X, increments=incr, return_levels=True)) <= 1e-9
             assert relerr(kx.Kdiag(X, lr_state=st), lo.Kdiag(X)) <= 1e-9
+            if not incr:     # inducing sequences (kernels.py:674-761, low-rank branch): all three covariances, both layouts of Kx2x2
+                for full in (False, True):
+                    for lev in (False, True):
+                        got = kx.K_seq_n_seq_covs(Y.reshape(9, L, d), X, full_X2_cov=full, return_levels=lev, lr_state=st)
+                        want = lo.K_seq_n_seq_covs(Y, X, full_X2_cov=full, return_levels=lev)
+                        for g, w in zip(got, want):
+                            assert relerr(g, w) <= 1e-9, (full, lev)
 
 
 def test_low_rank_exact_limit_and_convergence(K):
