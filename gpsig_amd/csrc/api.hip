@@ -35,6 +35,15 @@ SeqLaunchFn seq_lookup_ho_inc_d16(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_ptd_d4(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_ptd_d8(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_ptd_d16(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_inc_d4(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_inc_d8(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_inc_d16(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_ptd_d4(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_ptd_d8(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_ptd_d16(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_ptn_d4(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_ptn_d8(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_ptn_d16(int, int, int, int, int);
 typedef hipError_t (*TvsLaunchFn)(const TvsArgs&, hipStream_t);
 TvsLaunchFn tvs_lookup(int M, int TT, bool incr, bool f32);
 SeqLaunchFn seq_lookup_f32_inc_exact(int, int, int, int, bool);
@@ -96,18 +105,21 @@ SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32) {
 }
 
 SeqLaunchFn seq_launcher_ho(int mode, const SeqHOConfig& c, bool f32) {
-    if (f32) return nullptr;   // higher-order kernels are built for float64 only
-    if (mode == MODE_INC) {
-        if (c.D == 4) return seq_lookup_ho_inc_d4(c.G, c.C, c.D, c.MMAX, c.OMAX);
-        if (c.D == 8) return seq_lookup_ho_inc_d8(c.G, c.C, c.D, c.MMAX, c.OMAX);
-        return seq_lookup_ho_inc_d16(c.G, c.C, c.D, c.MMAX, c.OMAX);
+#define HO_PICK(V)                                                                \
+    do {                                                                          \
+        if (c.D == 4) return seq_lookup_ho_##V##_d4(c.G, c.C, c.D, c.MMAX, c.OMAX);   \
+        if (c.D == 8) return seq_lookup_ho_##V##_d8(c.G, c.C, c.D, c.MMAX, c.OMAX);   \
+        return seq_lookup_ho_##V##_d16(c.G, c.C, c.D, c.MMAX, c.OMAX);            \
+    } while (0)
+    if (f32) {
+        if (mode == MODE_INC) HO_PICK(f32_inc);
+        if (mode == MODE_PT_DIFF) HO_PICK(f32_ptd);
+        return nullptr;            // float32 without differences: not built
     }
-    if (mode == MODE_PT_DIFF) {
-        if (c.D == 4) return seq_lookup_ho_ptd_d4(c.G, c.C, c.D, c.MMAX, c.OMAX);
-        if (c.D == 8) return seq_lookup_ho_ptd_d8(c.G, c.C, c.D, c.MMAX, c.OMAX);
-        return seq_lookup_ho_ptd_d16(c.G, c.C, c.D, c.MMAX, c.OMAX);
-    }
-    return nullptr;
+    if (mode == MODE_INC) HO_PICK(inc);
+    if (mode == MODE_PT_DIFF) HO_PICK(ptd);
+    HO_PICK(ptn);
+#undef HO_PICK
 }
 
 }  // namespace
@@ -264,8 +276,8 @@ struct SeqPlanned {
 static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
     if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
-        if (g0.mode == MODE_PT_NODIFF)
-            return fail(c, GPSIG_ERR_UNSUPPORTED, "order > 1 with difference=False and a non-linear base kernel is not built");
+        if (g0.mode == MODE_PT_NODIFF && sizeof(TT) == 4)
+            return fail(c, GPSIG_ERR_UNSUPPORTED, "float32 with difference=False and a non-linear base kernel is not built");
         int k = seq_select_ho(SEQ_HO_TABLE, N_SEQ_HO_TABLE, g0.rows, d_eff, p->num_levels, p->order);
         if (k < 0)
             return fail(c, GPSIG_ERR_UNSUPPORTED,

@@ -7,9 +7,9 @@ constrained values (``variances`` (M+1,), ``sigma`` scalar, ``lengthscales`` (d,
 every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CUDA-out (device
 pointers, asynchronous on the current stream).
 
-float32 inputs are computed in float32 (order 1, exact mode only).  Not built yet (raise NotImplementedError, never a
-silent fallback): ``SignatureSpectral``; ``low_rank=True`` inside ``K_seq_n_seq_covs`` and in float32; ``order > 1`` in
-float32 or with ``difference=False`` and a non-linear base kernel.  Training (gradients): ``gpsig_amd.autodiff``.
+float32 inputs are computed in float32 (exact mode only).  Not built yet (raise NotImplementedError, never a silent
+fallback): ``SignatureSpectral``; ``low_rank=True`` in float32; float32 with ``difference=False`` and a non-linear base
+kernel.  Training (gradients): ``gpsig_amd.autodiff``.
 """
 import ctypes as C
 

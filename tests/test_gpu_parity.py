@@ -147,6 +147,19 @@ def test_higher_order_shapes(K, L, M, order):
         assert relerr(kx.K(X), ko.K(X)) <= TOL
         assert relerr(kx.K(X, Y, return_levels=True), ko.K(X, Y, return_levels=True)) <= TOL
         assert relerr(kx.K_tens_vs_seq(Z, X, increments=True), ko.K_tens_vs_seq(Z, X, increments=True)) <= TOL
+    # without differences (a non-linear base kernel then feeds kappa itself into the recursion), and in float32
+    kw = dict(input_dim=L * d, num_features=d, num_levels=M, base="rbf", order=order, difference=False)
+    kx, ko = make_kernel(K, kw), make_oracle(kw)
+    Xs, Ys = 0.3 * X, 0.3 * Y
+    assert relerr(kx.K(Xs), ko.K(Xs)) <= TOL
+    assert relerr(kx.K(Xs, Ys, return_levels=True), ko.K(Xs, Ys, return_levels=True)) <= TOL
+    for base in ("linear", "rbf"):
+        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, order=order)
+        kx, ko = make_kernel(K, kw), make_oracle(kw)
+        got = kx.K(X.astype(np.float32), Y.astype(np.float32))
+        assert got.dtype == np.float32
+        assert relerr32(got, ko.K(X.astype(np.float32).astype(np.float64), Y.astype(np.float32).astype(np.float64))) <= TOL32
+        assert relerr32(kx.K(X.astype(np.float32)), ko.K(X.astype(np.float32).astype(np.float64))) <= TOL32
 
 
 # ------------------------------------------------------------------------------------------------
