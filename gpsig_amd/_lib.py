@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("GPSIG_LIB") or os.path.join(_HERE, "lib", "libgpsig_h
 GPSIG_OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = 0, -1, -2, -3, -4
 PTR_HOST, PTR_DEVICE = 0, 1
 F64, F32 = 0, 1
-BASE = {"linear": 0, "rbf": 1, "cosine": 2, "poly": 3, "mix": 4, "matern12": 5, "matern32": 6, "matern52": 7}
+BASE = {"linear": 0, "rbf": 1, "cosine": 2, "poly": 3, "mix": 4, "matern12": 5, "matern32": 6, "matern52": 7, "spectral": 8}
 
 
 class Params(C.Structure):
@@ -23,6 +23,7 @@ class Params(C.Structure):
         ("sigma", C.c_double), ("jitter", C.c_double), ("base_params", C.c_double * 4),
         ("variances", C.POINTER(C.c_double)), ("lengthscales", C.POINTER(C.c_double)),
         ("lags", C.POINTER(C.c_double)), ("gamma", C.POINTER(C.c_double)),
+        ("base_table", C.POINTER(C.c_double)), ("base_table_len", C.c_int64),
     ]
 
 

@@ -136,7 +136,16 @@ int check_params(gpsig_ctx* c, const gpsig_params* p) {
     if (p->num_features < 1 || p->num_features > MAX_FEATURES)
         return fail(c, GPSIG_ERR_UNSUPPORTED, "num_features=%d outside [1, %d]", p->num_features, MAX_FEATURES);
     if (p->num_lags < 0 || p->num_lags > MAX_LAGS) return fail(c, GPSIG_ERR_UNSUPPORTED, "num_lags=%d outside [0, %d]", p->num_lags, MAX_LAGS);
-    if (p->base_kernel < GPSIG_BASE_LINEAR || p->base_kernel > GPSIG_BASE_MATERN52) return fail(c, GPSIG_ERR_INVALID, "unknown base kernel %d", p->base_kernel);
+    if (p->base_kernel < GPSIG_BASE_LINEAR || p->base_kernel > GPSIG_BASE_SPECTRAL) return fail(c, GPSIG_ERR_INVALID, "unknown base kernel %d", p->base_kernel);
+    if (p->base_kernel == GPSIG_BASE_SPECTRAL) {
+        const int Q = int(p->base_params[0]), fam = int(p->base_params[1]);
+        if (Q < 1 || Q > 64 || fam < 0 || fam > 2) return fail(c, GPSIG_ERR_INVALID, "spectral kernel: bad number of components / family");
+        if (!p->base_table || p->base_table_len != int64_t(Q) * (1 + 2 * p->num_features))
+            return fail(c, GPSIG_ERR_INVALID, "spectral kernel: base_table must hold alpha[Q], omega[Q][d], gamma[Q][d]");
+        if (p->lengthscales || p->num_lags != 0)
+            return fail(c, GPSIG_ERR_INVALID, "spectral kernel: lengthscales must be NULL and num_lags 0 (kernels.py:907, :82 vs :913)");
+        if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for float64 only");
+    }
     if (p->order < 1 || p->order > p->num_levels) return fail(c, GPSIG_ERR_INVALID, "order=%d outside [1, num_levels]", p->order);
     if (!p->variances) return fail(c, GPSIG_ERR_INVALID, "variances is NULL");
     if (p->num_lags > 0 && (!p->lags || !p->gamma)) return fail(c, GPSIG_ERR_INVALID, "num_lags > 0 needs lags and gamma");
@@ -154,6 +163,27 @@ ScaleParams scale_of(const gpsig_params* p, bool apply_scaling) {
     for (int l = 0; l <= s.num_lags; ++l) s.gamma[l] = s.num_lags > 0 ? p->gamma[l] : 1.0;
     s.jitter = 1e-6;   // settings.jitter inside lin_interp (gpsig/lags.py:22)
     return s;
+}
+
+// BASE_SPECTRAL: alpha[Q], omega[Q][SPECTRAL_STRIDE], gamma[Q][SPECTRAL_STRIDE] on the device (zero padded); NULL otherwise
+int spectral_table(gpsig_ctx* c, const gpsig_params* p, const double** dev) {
+    *dev = nullptr;
+    if (p->base_kernel != GPSIG_BASE_SPECTRAL) return GPSIG_OK;
+    const int Q = int(p->base_params[0]), d = p->num_features;
+    std::vector<double> h(size_t(Q) * (1 + 2 * SPECTRAL_STRIDE), 0.0);
+    for (int q = 0; q < Q; ++q) {
+        h[q] = p->base_table[q];
+        for (int f = 0; f < d; ++f) {
+            h[Q + size_t(q) * SPECTRAL_STRIDE + f] = p->base_table[Q + size_t(q) * d + f];
+            h[Q + size_t(Q) * SPECTRAL_STRIDE + size_t(q) * SPECTRAL_STRIDE + f] = p->base_table[Q + size_t(Q) * d + size_t(q) * d + f];
+        }
+    }
+    void* dp;
+    CHK(ensure(c, B_SPEC, sizeof(double) * h.size(), &dp));
+    HIPCHK(c, hipMemcpyAsync(dp, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *dev = static_cast<const double*>(dp);
+    return GPSIG_OK;
 }
 
 void base_p(const gpsig_params* p, double* p0, double* p1) {
@@ -191,6 +221,7 @@ struct LrDev {                 // device copies of a gpsig_lowrank
 int lr_check(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr) {
     if (!lr) return fail(c, GPSIG_ERR_INVALID, "lowrank descriptor is NULL");
     if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "low-rank mode is built for float64 only");
+    if (p->base_kernel == GPSIG_BASE_SPECTRAL) return fail(c, GPSIG_ERR_UNSUPPORTED, "low-rank mode is not built for the spectral base kernel");
     if (p->order != 1 && p->num_levels > 1) return fail(c, GPSIG_ERR_UNSUPPORTED, "Low-rank mode not implemented for order higher than 1.");
     if (lr->num_components < 1 || lr->rank_bound < 1) return fail(c, GPSIG_ERR_INVALID, "num_components and rank_bound must be positive");
     if (lr->num_sketches != p->num_levels - 1) return fail(c, GPSIG_ERR_INVALID, "need one sketch per level 2..num_levels");
@@ -389,6 +420,7 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     A.slot_elems = r.gx.rec_elems;
     A.kind = p->base_kernel;
     base_p(p, &A.p0, &A.p1);
+    CHK(spectral_table(c, p, &A.spec));
     A.out = r.out; A.si = r.si; A.sj = r.sj; A.sm = r.sm;
     A.ax = r.ax; A.by = r.by; A.jitter_diag = r.jitter_diag;
     A.sum_levels = r.sum_levels; A.pred = r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds;
@@ -556,6 +588,7 @@ static int tens_gram_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const
     A.ZT = ZT; A.ZS = ZS; A.Tn = Tn; A.M = p->num_levels; A.d_eff = p->num_features * ((raw ? 0 : p->num_lags) + 1);
     A.E = E; A.kind = p->base_kernel;
     base_p(p, &A.p0, &A.p1);
+    CHK(spectral_table(c, p, &A.spec));
     A.w = nullptr;
     if (!raw) CHK(upload_weights(c, p, &A.w));
     A.out = out;
@@ -605,7 +638,7 @@ static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, con
                        const void* X, int64_t Tn, int64_t N, int L, int increments, const void* fx, const double* w,
                        int return_levels, void* out) {
     const int M = p->num_levels;
-    if (N > 0 && Tn > 0 && N <= 65535 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1) &&
+    if (N > 0 && Tn > 0 && N <= 65535 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1) && p->base_kernel != GPSIG_BASE_SPECTRAL &&
         size_t(L) * scale_of(p, !raw).d_eff() * sizeof(TT) <= 48 * 1024) {
         TvsLaneTLaunchFn fns[8];
         int ng = 0;
@@ -632,6 +665,7 @@ static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, con
     A.XT = xt; A.ZT = ZT; A.ZS = ZS; A.N = N; A.Npad = Npad; A.Tn = Tn;
     A.L = L; A.d_eff = d_eff; A.kind = p->base_kernel; A.difference = p->difference; A.order = p->order;
     base_p(p, &A.p0, &A.p1);
+    CHK(spectral_table(c, p, &A.spec));
     A.fx = fx; A.w = w; A.out = out; A.sum_levels = (raw || return_levels) ? 0 : 1;
     if (N > 0 && Tn > 0) {
         hipEvent_t e0, e1;

@@ -183,6 +183,7 @@ struct TvsArgs {
     const double* w;    // (M+1) level weights sigma*variances, or NULL (raw levels)
     void* out;          // (T, N) or (M+1, T, N)
     int32_t sum_levels;
+    const double* spec; // BASE_SPECTRAL table (seq_core.hpp: spectral_eval); p0 = Q, p1 = family
 };
 
 template <typename T, int M, int TT, bool INCR>
@@ -213,6 +214,25 @@ __global__ __launch_bounds__(64) void tens_vs_seq_kernel(const TvsArgs A) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) ip[tt][k][e] = T(0);
         T xs = T(0);
+        const bool spectral = A.kind == BASE_SPECTRAL;
+        if (spectral) {
+            // not a function of inner products: every (component, point) takes its own pass over the features
+            const T* __restrict__ xcol = XT + int64_t(tau) * d * A.Npad + n;
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                const int64_t t = (t0 + tt < A.Tn) ? t0 + tt : A.Tn - 1;
+                for (int ke = 0; ke < LT * E; ++ke) {
+                    const T* __restrict__ z = ZT + t * d * (LT * E) + ke;
+                    const T v = spectral_eval<T>(A.spec, int(A.p0), int(A.p1), d, [&](int f) { return xcol[int64_t(f) * A.Npad]; },
+                                                 [&](int f) { return z[int64_t(f) * (LT * E)]; });
+#pragma unroll
+                    for (int k = 0; k < LT; ++k)
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            if (k * E + e == ke) ip[tt][k][e] = v;
+                }
+            }
+        } else
         for (int f = 0; f < d; ++f) {
             const T x = XT[(int64_t(tau) * d + f) * A.Npad + n];
             xs = fma(x, x, xs);
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(64) void tens_vs_seq_kernel(const TvsArgs A) {
                 for (int k = 0; k < LT; ++k)
 #pragma unroll
                     for (int e = 0; e < E; ++e) { kvv[k * E + e] = ip[tt][k][e]; zz[k * E + e] = zs[k * E + e]; }
-                base_eval_n<T, LT * E>(A.kind, kvv, zz, xs, p0, p1);
+                if (!spectral) base_eval_n<T, LT * E>(A.kind, kvv, zz, xs, p0, p1);
 #pragma unroll
                 for (int k = 0; k < LT; ++k) {
                     const T kv = INCR ? kvv[k * E + E - 1] - kvv[k * E] : kvv[k * E];   // kernels.py:329-330
@@ -487,6 +507,7 @@ struct TensGramArgs {
     const double* w;  // (M+1) or NULL
     void* out;        // (T, T) or (M+1, T, T)
     int32_t sum_levels;
+    const double* spec;   // BASE_SPECTRAL table
 };
 
 template <typename T>
@@ -506,13 +527,23 @@ __global__ void tens_gram_kernel(const TensGramArgs A) {
             for (int j = 0; j < i; ++j, ++k) {
                 T mk;
                 if (E == 1) {
-                    T ip = T(0);
-                    for (int f = 0; f < d; ++f) ip = fma(ZT[(t1 * d + f) * lt + k], ZT[(t2 * d + f) * lt + k], ip);
-                    mk = base_eval<T>(A.kind, ip, ZS[t1 * lt + k], ZS[t2 * lt + k], p0, p1);
+                    if (A.kind == BASE_SPECTRAL) {
+                        mk = spectral_eval<T>(A.spec, int(A.p0), int(A.p1), d, [&](int f) { return ZT[(t1 * d + f) * lt + k]; },
+                                              [&](int f) { return ZT[(t2 * d + f) * lt + k]; });
+                    } else {
+                        T ip = T(0);
+                        for (int f = 0; f < d; ++f) ip = fma(ZT[(t1 * d + f) * lt + k], ZT[(t2 * d + f) * lt + k], ip);
+                        mk = base_eval<T>(A.kind, ip, ZS[t1 * lt + k], ZS[t2 * lt + k], p0, p1);
+                    }
                 } else {   // kernels.py:275-277
                     T kv[2][2];
                     for (int a = 0; a < 2; ++a)
                         for (int b = 0; b < 2; ++b) {
+                            if (A.kind == BASE_SPECTRAL) {
+                                kv[a][b] = spectral_eval<T>(A.spec, int(A.p0), int(A.p1), d, [&](int f) { return ZT[((t1 * d + f) * lt + k) * 2 + a]; },
+                                                            [&](int f) { return ZT[((t2 * d + f) * lt + k) * 2 + b]; });
+                                continue;
+                            }
                             T ip = T(0);
                             for (int f = 0; f < d; ++f)
                                 ip = fma(ZT[((t1 * d + f) * lt + k) * 2 + a], ZT[((t2 * d + f) * lt + k) * 2 + b], ip);

@@ -43,6 +43,7 @@ struct SeqGramArgs {
     int32_t pred;           // PRED_*
     int32_t mirror;         // also store at (j, i)
     int32_t use_glds;       // stage x records with global_load_lds (LDS DMA) instead of load + ds_write
+    const double* spec;     // BASE_SPECTRAL: alpha[Q], omega[Q][D], gamma[Q][D] (Q = p0, family = p1, D = the kernel's padded width)
 };
 
 

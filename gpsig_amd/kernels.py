@@ -8,7 +8,7 @@ every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CU
 pointers, asynchronous on the current stream).
 
 float32 inputs are computed in float32 (exact mode only).  Not built yet (raise NotImplementedError, never a silent
-fallback): ``SignatureSpectral``; ``low_rank=True`` in float32; float32 with ``difference=False`` and a non-linear base
+fallback): ``SignatureSpectral`` in float32 / low-rank mode / with gradients; ``low_rank=True`` in float32; float32 with ``difference=False`` and a non-linear base
 kernel.  Training (gradients): ``gpsig_amd.autodiff``.
 """
 import ctypes as C
@@ -640,12 +640,45 @@ class SignatureMix(SignatureKernel):
 
 
 class SignatureSpectral(SignatureKernel):
-    """Spectral-mixture state-space kernels (kernels.py:894-942) are not built on the GPU."""
+    """Spectral-mixture state-space kernels (kernels.py:894-942):
+    kappa(x, y) = sum_q alpha_q * E_q(x - y) * cos(2 pi <omega_q, x - y>), E_q Gaussian ('gauss' / 'rbf'), exponential ('exp')
+    or, for 'mixed', Gaussian for the first floor(Q/2) components and exponential for the rest (the reference's 'mixed' branch
+    references an undefined name and has a sign slip, :932-936; the evident intent is built).  As in the reference there is
+    no lengthscale scaling (:907) -- gamma (Q, num_features) plays that role."""
+    _base = "spectral"
+    _FAMILIES = {'exp': 1, 'exponential': 1, 'gauss': 0, 'gaussian': 0, 'rbf': 0, 'mixed': 2, 'mix': 2}
 
     def __init__(self, input_dim, num_features, num_levels, family='gauss', Q=5, **kwargs):
-        if family not in ('exp', 'exponential', 'gauss', 'gaussian', 'rbf', 'mixed', 'mix'):
-            raise ValueError("Unrecognized spectral family name.")
-        raise NotImplementedError("SignatureSpectral is not built on the GPU yet")
+        kwargs.pop("lengthscales", None)
+        SignatureKernel.__init__(self, input_dim, num_features, num_levels, lengthscales=None, **kwargs)     # :907
+        if family not in self._FAMILIES:
+            raise ValueError("Unrecognized spectral family name.")                                           # :916
+        if self.num_lags > 0:
+            # the reference stores its (Q, d) scale matrix in self.gamma, overwriting the lag weights of kernels.py:82 (:913)
+            raise NotImplementedError("SignatureSpectral with num_lags > 0: the reference overwrites the lag weights (kernels.py:82 vs :913)")
+        if self.low_rank:
+            raise NotImplementedError("SignatureSpectral in low-rank mode is not built")
+        self.family = {0: 'rbf', 1: 'exp', 2: 'mixed'}[self._FAMILIES[family]]                               # :909-914
+        self.Q = int(Q)
+        self.alpha = np.exp(np.random.randn(self.Q))                                                         # :919
+        self.omega = np.exp(np.random.randn(self.Q, self.num_features))                                      # :920
+        self.gamma = np.exp(np.random.randn(self.Q, self.num_features))                                      # :921
+
+    def _current_base_params(self):
+        return (float(self.Q), float(self._FAMILIES[self.family]))
+
+    def _params(self, keep, dtype_id=_lib.F64):
+        p = SignatureKernel._params(self, keep, dtype_id)
+        tab = np.ascontiguousarray(np.concatenate([np.asarray(self.alpha, dtype=np.float64).reshape(-1),
+                                                   np.asarray(self.omega, dtype=np.float64).reshape(-1),
+                                                   np.asarray(self.gamma, dtype=np.float64).reshape(-1)]))
+        if tab.shape[0] != self.Q * (1 + 2 * self.num_features):
+            raise ValueError("alpha, omega, gamma must have shapes (Q,), (Q, num_features), (Q, num_features)")
+        keep.append(tab)
+        p.base_table = tab.ctypes.data_as(C.POINTER(C.c_double))
+        p.base_table_len = tab.shape[0]
+        p.lags, p.gamma = None, None
+        return p
 
 
 class SignatureMatern12(SignatureKernel):

@@ -47,7 +47,10 @@ enum gpsig_base_kernel {
     GPSIG_BASE_MIX = 4,       /* SignatureMix       _mix       :881-892  base_params = {mixing} */
     GPSIG_BASE_MATERN12 = 5,  /* SignatureMatern12/Laplace/Exponential :955-958 */
     GPSIG_BASE_MATERN32 = 6,  /* SignatureMatern32  :974-977 */
-    GPSIG_BASE_MATERN52 = 7   /* SignatureMatern52  :991-993 */
+    GPSIG_BASE_MATERN52 = 7,  /* SignatureMatern52  :991-993 */
+    GPSIG_BASE_SPECTRAL = 8   /* SignatureSpectral  _spectral  :921-942  base_params = {Q, family (0 rbf, 1 exp, 2 mixed)};
+                                 base_table = alpha[Q], omega[Q][d], gamma[Q][d]; needs lengthscales == NULL, num_lags == 0
+                                 (as the reference: :907, and its gamma clashes with the lag weights of :82) */
 };
 
 enum gpsig_dtype { GPSIG_F64 = 0, GPSIG_F32 = 1 };
@@ -72,6 +75,8 @@ typedef struct gpsig_params {
     const double* lengthscales;  /* host, d entries, or NULL = no scaling (kernels.py:84-88) */
     const double* lags;          /* host, num_lags entries (kernels.py:79), NULL if num_lags == 0 */
     const double* gamma;         /* host, num_lags+1 entries (kernels.py:80-82), NULL if num_lags == 0 */
+    const double* base_table;    /* host, extra parameters of the base kernel (GPSIG_BASE_SPECTRAL), else NULL */
+    int64_t base_table_len;      /* number of doubles in base_table */
 } gpsig_params;
 
 /* ---- context ----------------------------------------------------------------------------- */

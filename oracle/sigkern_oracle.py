@@ -262,9 +262,27 @@ def base_matern52(X, X2=None, **_):
     return (1.0 + np.sqrt(5.) * r + 5. / 3. * np.square(r)) * np.exp(-np.sqrt(5.) * r)
 
 
+def base_spectral(X, X2=None, alpha=None, omega=None, gamma=None, family="rbf", **_):
+    """gpsig/kernels.py:921-942.  X (P, d), X2 (P2, d) or batched (N, L, d) [the reference's tile() works on 2-D inputs only;
+    batching is the evident extension].  'mixed': Q6 -- the reference uses an undefined Q and flips a sign (:932-936); the
+    intent (first floor(Q/2) components Gaussian, the rest exponential) is implemented."""
+    X2 = X if X2 is None else X2
+    diff = X[..., :, None, :] - X2[..., None, :, :]                                                   # (..., P, P2, d)
+    Q = alpha.shape[0]
+    out = 0.0
+    for q in range(Q):
+        sq = np.sum(np.square(diff * gamma[q]), axis=-1)
+        if family == "rbf" or (family == "mixed" and q < Q // 2):
+            env = np.exp(-sq / 2)                                                                     # :926
+        else:
+            env = np.exp(-np.sqrt(sq) / 2)                                                            # :924
+        out = out + alpha[q] * env * np.cos(2. * np.pi * np.sum(diff * omega[q], axis=-1))            # :937, :942
+    return out
+
+
 BASE_KERNELS = {
     "linear": base_lin, "cosine": base_cos, "poly": base_poly, "rbf": base_rbf, "mix": base_mix,
-    "matern12": base_matern12, "matern32": base_matern32, "matern52": base_matern52,
+    "matern12": base_matern12, "matern32": base_matern32, "matern52": base_matern52, "spectral": base_spectral,
 }
 
 

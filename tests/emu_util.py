@@ -32,6 +32,7 @@ class SeqGramArgs(C.Structure):
         ("out", C.c_void_p), ("si", C.c_int64), ("sj", C.c_int64), ("sm", C.c_int64),
         ("ax", C.c_void_p), ("by", C.c_void_p), ("jitter_diag", C.c_double),
         ("sum_levels", C.c_int32), ("pred", C.c_int32), ("mirror", C.c_int32), ("use_glds", C.c_int32),
+        ("spec", C.c_void_p),
     ]
 
 

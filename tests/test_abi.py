@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_params_struct_matches_header_layout(lib):
     import ctypes as C
     # 8 int32, 2 double, 4 double, 4 pointers
-    assert C.sizeof(lib.Params) == 8 * 4 + 2 * 8 + 4 * 8 + 4 * 8
+    assert C.sizeof(lib.Params) == 8 * 4 + 2 * 8 + 4 * 8 + 4 * 8 + 2 * 8
 
 
 def test_no_cpu_fallback(lib):

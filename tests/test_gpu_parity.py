@@ -31,7 +31,7 @@ def K():
     return kernels
 
 
-CLASS = {"linear": "SignatureLinear", "rbf": "SignatureRBF", "cosine": "SignatureCosine", "poly": "SignaturePoly",
+CLASS = {"spectral": "SignatureSpectral", "linear": "SignatureLinear", "rbf": "SignatureRBF", "cosine": "SignatureCosine", "poly": "SignaturePoly",
          "mix": "SignatureMix", "matern12": "SignatureMatern12", "matern32": "SignatureMatern32", "matern52": "SignatureMatern52"}
 
 
@@ -371,6 +371,34 @@ def test_wide_state_spaces(K, base):
         Z = rng.standard_normal((M * (M + 1) // 2, 5, d * (lags + 1))) * 0.4
         got, want = k.K_tens_vs_seq(Z.astype(dt), X.astype(dt)), ko.K_tens_vs_seq(Z, X)
         assert np.abs(np.asarray(got, dtype=np.float64) - want).max() <= tol * np.abs(want).max()
+
+
+@pytest.mark.parametrize("family", ["gauss", "exp", "mixed"])
+def test_spectral_base_kernel(K, family):
+    """SignatureSpectral (kernels.py:894-942): every evaluation of the exact mode against the oracle, orders 1 and 2."""
+    rng = np.random.default_rng(88)
+    N, N2, L, d, M, T, Q = 9, 6, 14, 3, 4, 5, 5
+    X, X2 = 0.5 * rng.standard_normal((N, L * d)), 0.5 * rng.standard_normal((N2, L * d))
+    for order, norm, diff in ((1, True, True), (2, False, True), (1, True, False)):
+        k = K.SignatureSpectral(L * d, d, M, family=family, Q=Q, order=order, normalization=norm, difference=diff, variances=rng.uniform(0.5, 1.5, M + 1))
+        k.alpha, k.omega, k.gamma = rng.uniform(0.3, 1.2, Q), 0.3 * rng.standard_normal((Q, d)), rng.uniform(0.4, 1.3, (Q, d))
+        fam = {"gauss": "rbf", "exp": "exp", "mixed": "mixed"}[family]
+        ko = O.SignatureKernelOracle(L * d, d, M, base="spectral", order=order, normalization=norm, difference=diff, lengthscales=None,
+                                     variances=k.variances, base_params=dict(alpha=k.alpha, omega=k.omega, gamma=k.gamma, family=fam))
+        assert relerr(k.K(X), ko.K(X)) <= TOL
+        assert relerr(k.K(X, X2, return_levels=True), ko.K(X, X2, return_levels=True)) <= TOL
+        assert relerr(k.Kdiag(X), ko.Kdiag(X)) <= TOL
+        for incr in (False, True):
+            Z = 0.5 * rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d))
+            assert relerr(k.K_tens(Z, increments=incr), ko.K_tens(Z, increments=incr)) <= TOL
+            assert relerr(k.K_tens_vs_seq(Z, X, increments=incr, return_levels=True), ko.K_tens_vs_seq(Z, X, increments=incr, return_levels=True)) <= TOL
+            got, want = k.K_tens_n_seq_covs(Z, X, increments=incr), ko.K_tens_n_seq_covs(Z, X, increments=incr)
+            for g, w in zip(got, want):
+                assert relerr(g, w) <= TOL
+    with pytest.raises(ValueError):
+        K.SignatureSpectral(L * d, d, M, family="nope")
+    with pytest.raises(NotImplementedError):
+        k.K(X.astype(np.float32))
 
 
 def test_unsupported_shapes_fail_loudly(K):

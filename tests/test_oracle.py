@@ -122,7 +122,9 @@ def test_symmetric_equals_cross_without_normalisation():
     N, L, d, M = 6, 7, 3, 4
     X = rng.standard_normal((N, L, d)).reshape(N, -1)
     for base in O.BASE_KERNELS:
-        kern = O.SignatureKernelOracle(L * d, d, M, base=base, normalization=False)
+        bp = dict(alpha=rng.uniform(0.5, 1, 3), omega=0.3 * rng.standard_normal((3, d)), gamma=rng.uniform(0.5, 1.5, (3, d)), family="mixed") \
+            if base == "spectral" else None
+        kern = O.SignatureKernelOracle(L * d, d, M, base=base, normalization=False, base_params=bp)
         np.testing.assert_allclose(kern.K(X), kern.K(X, X), rtol=1e-12, atol=1e-12)
         Kd = kern.Kdiag(X, return_levels=True)
         np.testing.assert_allclose(Kd, np.diagonal(kern.K(X, return_levels=True), axis1=1, axis2=2), rtol=1e-10, atol=1e-12)
@@ -202,3 +204,20 @@ def test_svgp_algebra_restatement_properties():
     mean, var = SO.base_conditional(Kmn, Kmm, np.diag(Knn), u, q_sqrt=None, white=False)
     np.testing.assert_allclose(mean, Kmn.T @ np.linalg.solve(Kmm, u), rtol=1e-8)
     np.testing.assert_allclose(var[:, 0], np.diag(Knn - Kmn.T @ np.linalg.solve(Kmm, Kmn)), rtol=1e-7, atol=1e-9)
+
+
+def test_spectral_base_kernel_reduces_to_rbf_and_matern12():
+    """kernels.py:921-942: with one component, omega = 0 and alpha = 1 the spectral kernel is the Gaussian kernel of the
+    gamma-scaled points ('rbf' family) resp. exp(-r/2) ('exp' family); 'mixed' splits the components floor(Q/2) : rest."""
+    rng = np.random.default_rng(9)
+    X, Y = rng.standard_normal((7, 3)), rng.standard_normal((5, 3))
+    g = rng.uniform(0.5, 1.5, (1, 3))
+    one, zero = np.ones(1), np.zeros((1, 3))
+    assert np.allclose(O.base_spectral(X, Y, one, zero, g, "rbf"), O.base_rbf(X * g, Y * g), rtol=1e-13)
+    assert np.allclose(O.base_spectral(X, Y, one, zero, g, "exp"), np.exp(-O._euclid_dist(X * g, Y * g) / 2), rtol=1e-13)
+    a, om, ga = rng.uniform(0.5, 1, 3), rng.standard_normal((3, 3)), rng.uniform(0.5, 1.5, (3, 3))
+    mixed = O.base_spectral(X, Y, a, om, ga, "mixed")
+    want = O.base_spectral(X, Y, a[:1], om[:1], ga[:1], "rbf") + O.base_spectral(X, Y, a[1:], om[1:], ga[1:], "exp")
+    assert np.allclose(mixed, want, rtol=1e-13)
+    # symmetric in its arguments, unit-free diagonal sum_q alpha_q
+    assert np.allclose(np.diag(O.base_spectral(X, None, a, om, ga, "mixed")), a.sum())
