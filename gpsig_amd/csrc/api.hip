@@ -1232,8 +1232,10 @@ int gpsig_base_kernel_matrix(gpsig_ctx* c, const gpsig_params* p, const double* 
         HIPCHK(c, hipMemcpyAsync(db, B_host, sizeof(double) * size_t(nb) * d, hipMemcpyHostToDevice, c->stream));
         double p0, p1;
         base_p(p, &p0, &p1);
+        const double* spec;
+        CHK(spectral_table(c, p, &spec));
         hipLaunchKernelGGL(base_kernel_matrix_kernel<double>, dim3(grid_for(na * nb)), dim3(256), 0, c->stream,
-                           static_cast<const double*>(da), static_cast<const double*>(db), na, nb, int(d), int(p->base_kernel), p0, p1,
+                           static_cast<const double*>(da), static_cast<const double*>(db), na, nb, int(d), int(p->base_kernel), p0, p1, spec,
                            static_cast<double*>(dout));
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(out_host, dout, sizeof(double) * size_t(na) * nb, hipMemcpyDeviceToHost, c->stream));

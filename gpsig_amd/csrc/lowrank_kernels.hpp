@@ -32,10 +32,14 @@ __global__ void lr_gather_points_kernel(const T* __restrict__ X, int L, ScalePar
 // Base-kernel matrix of already scaled points: out[a][b] = kappa(A[a], B[b]); A (na, d), B (nb, d).
 template <typename T>
 __global__ void base_kernel_matrix_kernel(const T* __restrict__ A, const T* __restrict__ B, int64_t na, int64_t nb, int d, int kind,
-                                          T p0, T p1, T* __restrict__ out) {
+                                          T p0, T p1, const double* __restrict__ spec, T* __restrict__ out) {
     const int64_t total = na * nb;
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
         const int64_t a = i / nb, b = i % nb;
+        if (kind == BASE_SPECTRAL) {
+            out[i] = spectral_eval<T>(spec, int(p0), int(p1), d, [&](int f) { return A[a * d + f]; }, [&](int f) { return B[b * d + f]; });
+            continue;
+        }
         T ip = T(0), as = T(0), bs = T(0);
         for (int f = 0; f < d; ++f) {
             const T x = A[a * d + f], y = B[b * d + f];

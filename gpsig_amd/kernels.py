@@ -565,6 +565,26 @@ class SignatureKernel:
     def compute_K_symm(self, X):
         return self.K(X)
 
+    def compute_base_kern_symm(self, X):
+        """Reference: kernels.py:150-157.  The static kernel on every pair of (scaled, lagged) observations of X, (N, N, L, L)."""
+        X, _ = self._slice(X, None)
+        L_ = _Launch(X)
+        if L_.f32:
+            raise NotImplementedError("compute_base_kern_symm is built for float64 only")
+        n, l = self._seq_dims(X)
+        p = self._params(L_.keep, _lib.F64)
+        d_eff = self.num_features * (self.num_lags + 1)
+        pts = np.empty((n * l, d_eff))
+        if n * l:
+            idx = np.arange(n * l, dtype=np.int64)
+            L_.ctx.call("gpsig_lr_gather_points", p, L_.inp(X), n, l, idx.ctypes.data_as(C.POINTER(C.c_int64)), n * l,
+                        pts.ctypes.data_as(C.POINTER(C.c_double)))                                     # :152-154 (scaling, lags)
+        W = np.empty((n * l, n * l))
+        L_.ctx.call("gpsig_base_kernel_matrix", p, pts.ctypes.data_as(C.POINTER(C.c_double)), pts.ctypes.data_as(C.POINTER(C.c_double)),
+                    n * l, n * l, d_eff, W.ctypes.data_as(C.POINTER(C.c_double)))                        # :155
+        out = W.reshape(n, l, n, l).transpose(0, 2, 1, 3)                                               # :156-157
+        return torch.as_tensor(np.ascontiguousarray(out), device=L_.dev) if L_.device_mode else out
+
     def compute_K_level_diags(self, X):
         return self.Kdiag(X, return_levels=True)
 

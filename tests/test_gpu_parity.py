@@ -373,6 +373,18 @@ def test_wide_state_spaces(K, base):
         assert np.abs(np.asarray(got, dtype=np.float64) - want).max() <= tol * np.abs(want).max()
 
 
+def test_compute_base_kern_symm(K):
+    """kernels.py:150-157: the static kernel between all observations, (N, N, L, L), after scaling and lags."""
+    rng = np.random.default_rng(90)
+    N, L, d, M = 5, 9, 3, 3
+    X = rng.standard_normal((N, L * d))
+    for base, kw in (("rbf", dict(lengthscales=rng.uniform(0.7, 1.4, d))), ("matern32", dict(num_lags=1)), ("linear", {})):
+        kx, ko = make_kernel(K, dict(input_dim=L * d, num_features=d, num_levels=M, base=base, **kw)), \
+            make_oracle(dict(input_dim=L * d, num_features=d, num_levels=M, base=base, **kw))
+        got, want = kx.compute_base_kern_symm(X), ko.compute_base_kern_symm(X)
+        assert got.shape == (N, N, L, L) and relerr(got, want) <= TOL
+
+
 @pytest.mark.parametrize("family", ["gauss", "exp", "mixed"])
 def test_spectral_base_kernel(K, family):
     """SignatureSpectral (kernels.py:894-942): every evaluation of the exact mode against the oracle, orders 1 and 2."""
