@@ -6,6 +6,6 @@
 
 Everything is computed by hand-written HIP kernels for gfx950 behind the C ABI of include/gpsig_hip.h;
 there is no CPU fallback."""
-from . import _lib, inducing_variables, kernels  # noqa: F401
+from . import _lib, inducing_variables, kernels, utils  # noqa: F401
 
-__all__ = ["kernels", "inducing_variables"]
+__all__ = ["kernels", "inducing_variables", "utils"]   # training side: gpsig_amd.autodiff, gpsig_amd.models, gpsig_amd.likelihoods
