@@ -613,8 +613,6 @@ struct TvsPairGrad {
 //   IO::load_x(tt, v) -> |x_tt|^2     IO::emit_gx(tt, gx)
 //   IO::sign() / IO::combine(k): +1 / identity, except where the two points of an incremental tensor sit in two adjacent
 //   lanes (E == 1 per lane): then sign() is -1 for the first point and combine() adds the partner lane's value.
-//   IO::fence(): called once per time step and before each contraction; an IO whose z() reads LDS makes it an optimisation
-//   barrier so that the compiler re-reads the components instead of keeping all of them in registers.
 template <int E>
 struct TvsEv {                // kz_k(x) = sum_e sign_e kappa(z_k^e, x) and what its derivatives need
     double k;
@@ -659,7 +657,6 @@ template <int DP, int MMAX, int E, class IO>
 GPSIG_HD void tvs_contract(IO& io, int i, int k0, int tt, const double (&x)[DP], const double (&gk)[MMAX], const TvsEv<E> (&ev)[MMAX],
                            double (&gzacc)[MMAX][E][DP], double& gp0) {
     double gx[DP];
-    io.fence();
 #pragma unroll
     for (int f = 0; f < DP; ++f) gx[f] = 0.0;
 #pragma unroll
@@ -696,8 +693,7 @@ GPSIG_HD double tvs_level_grad(IO& io, int i, int k0, int R, bool diff, int kind
         for (int j = 0; j < MMAX; ++j) kprev[j] = j < i ? tvs_eval<DP, E, KIND>(io, k0 + j, x, xs, false, kind, p0, p1).k : 0.0;
     }
     for (int tau = 0; tau < R; ++tau) {
-        io.fence();
-        const double xs = io.load_x(diff ? tau + 1 : tau, x);
+            const double xs = io.load_x(diff ? tau + 1 : tau, x);
         double carry = 1.0;
 #pragma unroll
         for (int j = 0; j < MMAX; ++j)
@@ -729,8 +725,7 @@ GPSIG_HD double tvs_level_grad(IO& io, int i, int k0, int R, bool diff, int kind
             if (j < i) evn[j] = tvs_eval<DP, E, KIND>(io, k0 + j, xn, xs, true, kind, p0, p1);
     }
     for (int tau = R - 1; tau >= 0; --tau) {
-        io.fence();
-        const double xs = io.load_x(tau, x);
+            const double xs = io.load_x(tau, x);
         TvsEv<E> evc[MMAX];
         double m[MMAX], gm[MMAX], ulow[MMAX];
 #pragma unroll
@@ -786,7 +781,6 @@ struct TvsPairGradFused {
 
     GPSIG_HD TvsPairGradFused(const TvsGradArgs& a, int t_, int n_, bool valid_) : A(a), t(t_), n(n_), valid(valid_) {}
     GPSIG_HD double z(int k, int e, int f) const { return A.z[((int64_t(k) * A.T + t) * E + e) * DP + f]; }
-    GPSIG_HD void fence() const {}
     GPSIG_HD double sign() const { return 1.0; }
     GPSIG_HD double combine(double k) const { return k; }
     GPSIG_HD double zsq(int k, int e) const {
@@ -805,12 +799,8 @@ struct TvsPairGradFused {
         return s;
     }
     GPSIG_HD void emit_gx(int tt, const double (&gx)[DP]) const {
-#ifdef GPSIG_EXPERIMENT_NO_GX
-        if (gx[0] == 123.456) A.gxT[0] = gx[1];
-#else
 #pragma unroll
         for (int f = 0; f < DP; ++f) grad_add(&A.gxT[(int64_t(tt) * DP + f) * A.xstride + n], gx[f], false, valid);
-#endif
     }
     GPSIG_HD void run() {
         const int R = A.diff ? A.L - 1 : A.L;

@@ -134,7 +134,6 @@ struct TvsLaneTIO {
     double zr[ZREG ? MMAX : 1][E][DP];
     double zn[ZREG ? MMAX : 1][E];   // squared norms of the level's components (kept only next to register-resident components)
     int flip;                  // which of the two reduction buffers the next emit uses
-    __device__ __forceinline__ void fence() const {}
     // PAIRED: lanes 2t and 2t+1 hold the two points of incremental tensor t (kernels.py:328-330: kappa(z1, x) - kappa(z0, x))
     __device__ __forceinline__ double sign() const { return (PAIRED && (lane & 1) == 0) ? -1.0 : 1.0; }
     __device__ __forceinline__ double combine(double k) const {
