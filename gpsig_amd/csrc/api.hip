@@ -473,19 +473,129 @@ static int make_factors(gpsig_ctx* c, const void* dlev, int64_t N, int M1, const
     return GPSIG_OK;
 }
 
+// ---- any-shape fallback (seq_levels_generic_kernel): float64, first-order algorithm --------------------------------------
+static bool generic_ok(const gpsig_params* p) { return sizeof(TT) == 8 && (p->order == 1 || p->num_levels == 1); }
+
+// raw levels of the pairs (i, j) (or (i, i) when diag) into out[m * sm + i * si + j * sj]
+static int generic_levels(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* X, const void* Y, int64_t N1, int64_t N2,
+                          int L1, int L2, bool diag, double* out, int64_t sm, int64_t si, int64_t sj) {
+    if (N1 == 0 || N2 == 0) return GPSIG_OK;
+    ScaleParams sp = scale_of(p, apply_scaling);
+    const int d_eff = sp.d_eff(), M = p->num_levels;
+    const int64_t s1 = (N1 + 63) / 64 * 64, s2 = (N2 + 63) / 64 * 64;
+    void *xt, *yt = nullptr;
+    CHK(ensure(c, B_GR0, sizeof(double) * size_t(L1) * d_eff * s1 + 8, &xt));
+    hipLaunchKernelGGL(prep_seq_timemajor_kernel<double>, dim3(grid_for(int64_t(L1) * d_eff * s1)), dim3(256), 0, c->stream,
+                       static_cast<const double*>(X), N1, s1, L1, sp, static_cast<double*>(xt));
+    HIPCHK(c, hipGetLastError());
+    const bool same = diag || Y == nullptr || Y == X;
+    if (!same) {
+        CHK(ensure(c, B_GR1, sizeof(double) * size_t(L2) * d_eff * s2 + 8, &yt));
+        hipLaunchKernelGGL(prep_seq_timemajor_kernel<double>, dim3(grid_for(int64_t(L2) * d_eff * s2)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(Y), N2, s2, L2, sp, static_cast<double*>(yt));
+        HIPCHK(c, hipGetLastError());
+    }
+    const SeqGeom g = seq_geometry(p->base_kernel, p->difference, L2, 4, 8);
+    // the linear kernel without differences is a point kernel here (kappa = <x, y>)
+    const int mode = (g.mode == MODE_INC && !p->difference) ? MODE_PT_NODIFF : g.mode;
+    const int dr = mode == MODE_PT_NODIFF ? 0 : 1;
+    const int R2 = L2 - dr;
+    const size_t per_j = sizeof(double) * size_t(M > 1 ? M - 1 : 1) * size_t(R2 > 0 ? R2 : 1) * size_t(s1);
+    int64_t chunk = diag ? 1 : int64_t((size_t(c->grad_scratch_mb > 0 ? c->grad_scratch_mb : 4096) << 20) / per_j);
+    if (chunk < 1) chunk = 1;
+    if (chunk > N2) chunk = N2;
+    if (chunk > 65535) chunk = 65535;
+    void* scr;
+    CHK(ensure(c, B_GR4, per_j * size_t(chunk) + 64, &scr));
+    GenericSeqArgs A;
+    memset(&A, 0, sizeof(A));
+    A.XT = static_cast<const double*>(xt); A.YT = same ? A.XT : static_cast<const double*>(yt);
+    A.xstride = s1; A.ystride = same ? s1 : s2;
+    A.N1 = N1; A.N2 = N2; A.L1 = L1; A.L2 = L2; A.d = d_eff; A.M = M; A.kind = p->base_kernel; A.mode = mode; A.diag = diag ? 1 : 0;
+    base_p(p, &A.p0, &A.p1);
+    CHK(spectral_table(c, p, &A.spec));
+    A.scratch = static_cast<double*>(scr);
+    A.out = out; A.sm = sm; A.si = si; A.sj = sj;
+    for (int64_t j0 = 0; j0 < (diag ? 1 : N2); j0 += chunk) {
+        const int64_t nj = diag ? 1 : ((N2 - j0 < chunk) ? N2 - j0 : chunk);
+        A.j0 = j0; A.pairs = s1 * nj;
+        hipLaunchKernelGGL(seq_levels_generic_kernel, dim3(unsigned(s1 / 64), unsigned(nj)), dim3(64), 0, c->stream, A);
+        HIPCHK(c, hipGetLastError());
+    }
+    return GPSIG_OK;
+}
+
+// K / _K_seq for shapes the wavefront kernel is not built for
+static int seq_K_generic(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, const void* X2, int64_t N1, int64_t N2, int L1, int L2,
+                         int return_levels, void* out, int x_squared) {
+    const bool sym = X2 == nullptr;
+    const int M1 = p->num_levels + 1;
+    const int64_t Nc = sym ? N1 : N2;
+    const void *fa = nullptr, *fb = nullptr;
+    double jitter_diag = 0.0;
+    if (!raw) {
+        const double* w;
+        CHK(upload_weights(c, p, &w));
+        if (p->normalization) {
+            CHK(side_factors(c, p, true, X, N1, L1, w, x_squared, B_DLEV0, B_FAC0, &fa));
+            if (sym) CHK(make_factors(c, c->buf[B_DLEV0].p, N1, M1, nullptr, p->jitter, B_FAC1, &fb));
+            else CHK(side_factors(c, p, true, X2, N2, L2, nullptr, 0, B_DLEV1, B_FAC1, &fb));
+            if (sym) jitter_diag = p->jitter;
+        } else {
+            CHK(make_factors(c, nullptr, N1, M1, w, 0.0, B_FAC0, &fa));
+        }
+    }
+    if (raw) return generic_levels(c, p, false, X, sym ? X : X2, N1, Nc, L1, sym ? L1 : L2, false, static_cast<double*>(out), N1 * Nc, Nc, 1);
+    void* lev;
+    CHK(ensure(c, B_GR5, sizeof(double) * size_t(M1) * N1 * Nc + 8, &lev));
+    CHK(generic_levels(c, p, true, X, sym ? X : X2, N1, Nc, L1, sym ? L1 : L2, false, static_cast<double*>(lev), N1 * Nc, Nc, 1));
+    if (N1 > 0 && Nc > 0) {
+        hipLaunchKernelGGL(levels_epilogue_kernel, dim3(grid_for(N1 * Nc)), dim3(256), 0, c->stream, static_cast<const double*>(lev), N1, Nc, M1,
+                           static_cast<const double*>(fa), static_cast<const double*>(fb), jitter_diag, return_levels ? 0 : 1,
+                           static_cast<double*>(out));
+        HIPCHK(c, hipGetLastError());
+    }
+    return GPSIG_OK;
+}
+
 // Per-sequence factors w[m] / sqrt(diag_m + jitter) (or squared) of one side, with that side's own kernel shape:
 // the diagonal pass keeps the sequence itself in registers, whatever the main pass does with it.
 static int side_factors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* X, int64_t N, int L, const double* w,
                  int squared, int id_dlev, int id_fac, const void** fac) {
     const int d_eff = p->num_features * ((apply_scaling ? p->num_lags : 0) + 1);
     SeqPlanned pl;
-    CHK(plan_seq(c, p, d_eff, L, &pl));
+    const int rc = plan_seq(c, p, d_eff, L, &pl);
+    if (rc == GPSIG_ERR_UNSUPPORTED && generic_ok(p)) {
+        void* dl;
+        CHK(ensure(c, id_dlev, sizeof(double) * size_t(N) * (p->num_levels + 1) + 8, &dl));
+        CHK(generic_levels(c, p, apply_scaling, X, X, N, N, L, L, true, static_cast<double*>(dl), 1, p->num_levels + 1, 0));
+        return make_factors(c, dl, N, p->num_levels + 1, w, p->jitter, id_fac, fac, squared);
+    }
+    CHK(rc);
     const void* rec;
     SeqGeom g;
     CHK(make_records(c, p, apply_scaling, pl, X, N, L, B_REC0, &rec, &g));
     const void* dl;
     CHK(diag_levels(c, p, pl, rec, g, N, id_dlev, &dl));
     return make_factors(c, dl, N, p->num_levels + 1, w, p->jitter, id_fac, fac, squared);
+}
+
+// diagonal levels of N sequences into out (M+1, N): the wavefront kernel where it is built for the shape, else the fallback
+static int diag_levels_mn(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* X, int64_t N, int L, void* out) {
+    const int d_eff = p->num_features * ((apply_scaling ? p->num_lags : 0) + 1);
+    SeqPlanned pl;
+    const int rc = plan_seq(c, p, d_eff, L, &pl);
+    if (rc == GPSIG_ERR_UNSUPPORTED && generic_ok(p))
+        return generic_levels(c, p, apply_scaling, X, X, N, N, L, L, true, static_cast<double*>(out), N, 1, 0);
+    CHK(rc);
+    const void* rec;
+    SeqGeom g;
+    CHK(make_records(c, p, apply_scaling, pl, X, N, L, B_REC0, &rec, &g));
+    SeqRun r;
+    memset(&r, 0, sizeof(r));
+    r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
+    r.out = out; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
+    return launch_seq(c, p, pl, r);
 }
 
 // Core of K / _K_seq on device pointers.  raw: no scaling, no normalisation, no weights (levels out).
@@ -504,11 +614,13 @@ static int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const voi
     int rc = plan_seq(c, p, d_eff, sym ? L1 : (swap ? L1 : L2), &pl);
     if (rc != GPSIG_OK && !sym) {       // maybe the other side fits
         swap = !swap;
-        int rc2 = plan_seq(c, p, d_eff, swap ? L1 : L2, &pl);
-        if (rc2 != GPSIG_OK) return rc2;
-    } else if (rc != GPSIG_OK) {
-        return rc;
+        rc = plan_seq(c, p, d_eff, swap ? L1 : L2, &pl);
     }
+    if (rc == GPSIG_ERR_UNSUPPORTED && generic_ok(p) && row_end == 0) {     // any-shape fallback, orders of magnitude slower per pair
+        if (timed) { c->t_launches += 0; }
+        return seq_K_generic(c, p, raw, X, X2, N1, N2, L1, L2, return_levels, out, x_squared);
+    }
+    if (rc != GPSIG_OK) return rc;
     const void *fa = nullptr, *fb = nullptr;
     double jitter_diag = 0.0;
     if (!raw) {
@@ -713,16 +825,7 @@ static int e_seq_diag_levels(gpsig_ctx* c, const gpsig_params* p, const void* X,
     CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N) * L * d, &dX));
     void* dout;
     CHK(out_dev(c, B_OUT0, out, sizeof(TT) * size_t(N) * M1, &dout));
-    SeqPlanned pl;
-    CHK(plan_seq(c, &q, d, L, &pl));
-    const void* rec;
-    SeqGeom g;
-    CHK(make_records(c, &q, false, pl, dX, N, L, B_REC0, &rec, &g));
-    SeqRun r;
-    memset(&r, 0, sizeof(r));
-    r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
-    r.out = dout; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
-    CHK(launch_seq(c, &q, pl, r));
+    CHK(diag_levels_mn(c, &q, false, dX, N, L, dout));
     CHK(out_done(c, out, dout, sizeof(TT) * size_t(N) * M1));
     return finish(c);
 }
@@ -832,17 +935,7 @@ static int e_kernel_Kdiag(gpsig_ctx* c, const gpsig_params* p, const void* X, in
     } else {
         const void* dX;
         CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N) * L * p->num_features, &dX));
-        const int d_eff = p->num_features * (p->num_lags + 1);
-        SeqPlanned pl;
-        CHK(plan_seq(c, p, d_eff, L, &pl));
-        const void* rec;
-        SeqGeom g;
-        CHK(make_records(c, p, true, pl, dX, N, L, B_REC0, &rec, &g));
-        SeqRun r;
-        memset(&r, 0, sizeof(r));
-        r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
-        r.out = tmp; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
-        CHK(launch_seq(c, p, pl, r));
+        CHK(diag_levels_mn(c, p, true, dX, N, L, tmp));
     }
     if (N > 0) {
         hipLaunchKernelGGL(weight_levels_kernel<TT>, dim3(grid_for(N)), dim3(256), 0, c->stream,
@@ -925,17 +1018,7 @@ static int e_kernel_K_tens_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const
                 HIPCHK(c, hipGetLastError());
             }
         } else {                  // kernels.py:653, :663
-            const int d_eff = p->num_features * (p->num_lags + 1);
-            SeqPlanned pl;
-            CHK(plan_seq(c, p, d_eff, L, &pl));
-            const void* rec;
-            SeqGeom g;
-            CHK(make_records(c, p, true, pl, dX, N, L, B_REC0, &rec, &g));
-            SeqRun r;
-            memset(&r, 0, sizeof(r));
-            r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N; r.N2 = N;
-            r.out = tmp; r.si = 1; r.sj = 0; r.sm = N; r.pred = PRED_DIAG; r.timed = true;
-            CHK(launch_seq(c, p, pl, r));
+            CHK(diag_levels_mn(c, p, true, dX, N, L, tmp));
         }
         if (N > 0) {
             hipLaunchKernelGGL(weight_levels_kernel<TT>, dim3(grid_for(N)), dim3(256), 0, c->stream,
@@ -983,16 +1066,7 @@ static int e_kernel_K_seq_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const 
                 HIPCHK(c, hipGetLastError());
             }
         } else {                  // kernels.py:743, :753
-            SeqPlanned pl;
-            CHK(plan_seq(c, p, d * (p->num_lags + 1), L2, &pl));
-            const void* rec;
-            SeqGeom g;
-            CHK(make_records(c, p, true, pl, dX2, N2, L2, B_REC0, &rec, &g));
-            SeqRun r;
-            memset(&r, 0, sizeof(r));
-            r.xrec = rec; r.yrec = rec; r.gx = g; r.gy = g; r.N1 = N2; r.N2 = N2;
-            r.out = tmp; r.si = 1; r.sj = 0; r.sm = N2; r.pred = PRED_DIAG; r.timed = true;
-            CHK(launch_seq(c, p, pl, r));
+            CHK(diag_levels_mn(c, p, true, dX2, N2, L2, tmp));
         }
         if (N2 > 0) {
             hipLaunchKernelGGL(weight_levels_kernel<TT>, dim3(grid_for(N2)), dim3(256), 0, c->stream,

@@ -561,4 +561,122 @@ __global__ void tens_gram_kernel(const TensGramArgs A) {
     }
 }
 
+// ---- any-shape fallback of the sequence-vs-sequence recursion (first-order algorithm, signature_algs.py:8-35) -------------
+// One pair per thread, 64 consecutive x sequences against one y sequence per wavefront (or the pairs (i, i) for the
+// diagonal).  The previous lattice row of Q_1..Q_{M-1} sits in an HBM scratch array laid out [level][column][pair], so a
+// wavefront's accesses are contiguous; nothing has to fit registers or LDS, hence no limit on either length or on the
+// number of features.  Orders of magnitude slower per pair than seq_gram_kernel: used only for shapes that kernel is not
+// built for (register-side sequences beyond its column capacity, more than 32 state-space dimensions after lags).
+struct GenericSeqArgs {
+    const double* XT; const double* YT;    // time-major scaled points [(t * d + f) * stride + n]
+    int64_t xstride, ystride;
+    int64_t N1, N2;
+    int32_t L1, L2, d, M, kind, mode, diag;
+    double p0, p1;
+    const double* spec;
+    int64_t j0;                            // this launch covers y sequences j0 .. j0 + gridDim.y - 1
+    double* scratch;                       // (M-1) * R2 * pairs doubles
+    int64_t pairs;
+    double* out;                           // levels: out[m * sm + i * si + j * sj]
+    int64_t sm, si, sj;
+};
+
+__device__ __forceinline__ double generic_kappa(const GenericSeqArgs& A, int64_t i, int ta, int64_t j, int tb) {
+    const double* x = A.XT + int64_t(ta) * A.d * A.xstride + i;
+    const double* y = A.YT + int64_t(tb) * A.d * A.ystride + j;
+    if (A.kind == BASE_SPECTRAL)
+        return spectral_eval<double>(A.spec, int(A.p0), int(A.p1), A.d, [&](int f) { return x[int64_t(f) * A.xstride]; },
+                                     [&](int f) { return y[int64_t(f) * A.ystride]; });
+    double in = 0.0, xs = 0.0, ys = 0.0;
+    for (int f = 0; f < A.d; ++f) {
+        const double xv = x[int64_t(f) * A.xstride], yv = y[int64_t(f) * A.ystride];
+        in = fma(xv, yv, in); xs = fma(xv, xv, xs); ys = fma(yv, yv, ys);
+    }
+    return base_eval<double>(A.kind, in, xs, ys, A.p0, A.p1);
+}
+
+// grid (ceil(N1 / 64), number of y sequences of this launch or 1 for the diagonal); block 64
+static __global__ void __launch_bounds__(64) seq_levels_generic_kernel(const GenericSeqArgs A) {
+    constexpr int MM = 8;
+    const int64_t i = int64_t(blockIdx.x) * 64 + threadIdx.x;
+    const bool valid = i < A.N1;
+    const int64_t ii = valid ? i : 0;
+    const int64_t j = A.diag ? ii : A.j0 + blockIdx.y;
+    const int64_t pidx = (int64_t(blockIdx.y) * gridDim.x + blockIdx.x) * 64 + threadIdx.x;
+    const int dr = A.mode == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = A.L1 - dr, R2 = A.L2 - dr, M = A.M;
+    auto qrow = [&](int m, int b) -> double& { return A.scratch[(int64_t(m - 1) * R2 + b) * A.pairs + pidx]; };
+    double ktop = 0.0, qlast[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) qlast[m] = 0.0;
+    for (int a = 0; a < R1; ++a) {
+        double s[MM + 1], qd[MM];
+#pragma unroll
+        for (int m = 0; m <= MM; ++m) s[m] = 0.0;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) qd[m] = 0.0;
+        double klo = 0.0, khi = 0.0;            // kappa(x_a, y_b), kappa(x_{a+1}, y_b)
+        if (A.mode == MODE_PT_DIFF) { klo = generic_kappa(A, ii, a, j, 0); khi = generic_kappa(A, ii, a + 1, j, 0); }
+        for (int b = 0; b < R2; ++b) {
+            double dm;
+            if (A.mode == MODE_INC) {
+                dm = 0.0;
+                for (int f = 0; f < A.d; ++f) {
+                    const double* x = A.XT + (int64_t(a) * A.d + f) * A.xstride + ii;
+                    const double* y = A.YT + (int64_t(b) * A.d + f) * A.ystride + j;
+                    dm = fma(x[int64_t(A.d) * A.xstride] - x[0], y[int64_t(A.d) * A.ystride] - y[0], dm);
+                }
+            } else if (A.mode == MODE_PT_DIFF) {
+                const double nlo = generic_kappa(A, ii, a, j, b + 1), nhi = generic_kappa(A, ii, a + 1, j, b + 1);
+                dm = (nhi - khi) - (nlo - klo);                  // signature_algs.py:26
+                klo = nlo; khi = nhi;
+            } else {
+                dm = generic_kappa(A, ii, a, j, b);
+            }
+            double qup[MM];
+#pragma unroll
+            for (int m = 1; m < MM; ++m) qup[m] = (m < M && a > 0) ? qrow(m, b) : 0.0;
+            s[1] += dm;
+#pragma unroll
+            for (int m = 2; m <= MM; ++m)
+                if (m <= M) s[m] = fma(dm, qd[m - 1], s[m]);
+#pragma unroll
+            for (int m = 1; m < MM; ++m)
+                if (m < M) {
+                    const double q = qup[m] + s[m];
+                    qrow(m, b) = q;
+                    qd[m] = qup[m];
+                    qlast[m] = q;
+                }
+        }
+#pragma unroll
+        for (int m = 1; m <= MM; ++m)
+            if (m == M) ktop += s[m];
+    }
+    if (!valid) return;
+    double* o = A.out + i * A.si + (A.diag ? 0 : j * A.sj);
+    o[0] = 1.0;
+#pragma unroll
+    for (int m = 1; m < MM; ++m)
+        if (m < M) o[m * A.sm] = (R1 > 0 && R2 > 0) ? qlast[m] : 0.0;
+    o[int64_t(M) * A.sm] = ktop;
+}
+
+// levels (M1, N1, N2) -> out[i][j] = sum_m (lev + jitter_diag * [i == j]) * ax[i][m] * by[j][m]   (or per level)
+static __global__ void levels_epilogue_kernel(const double* __restrict__ lev, int64_t N1, int64_t N2, int M1, const double* __restrict__ ax,
+                                       const double* __restrict__ by, double jitter_diag, int sum_levels, double* __restrict__ out) {
+    const int64_t total = N1 * N2;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t i = idx / N2, j = idx % N2;
+        double acc = 0.0;
+        for (int m = 0; m < M1; ++m) {
+            double v = lev[m * total + idx] + (i == j ? jitter_diag : 0.0);
+            if (ax) v *= ax[i * M1 + m];
+            if (by) v *= by[j * M1 + m];
+            if (sum_levels) acc += v; else out[m * total + idx] = v;
+        }
+        if (sum_levels) out[idx] = acc;
+    }
+}
+
 }  // namespace gpsig

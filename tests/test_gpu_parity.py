@@ -413,13 +413,33 @@ def test_spectral_base_kernel(K, family):
         k.K(X.astype(np.float32))
 
 
+def test_any_shape_fallback(K):
+    """Shapes the wavefront kernel is not built for -- both sides longer than its column capacity, more than 32 state-space
+    dimensions after lags -- go through the one-pair-per-thread fallback (float64, order 1) and must match the oracle too."""
+    rng = np.random.default_rng(91)
+    cases = [("linear", 5, 4, 600, 2, 3, None, True), ("rbf", 4, 3, 530, 2, 3, None, True), ("matern32", 3, 3, 300, 12, 3, None, True),
+             ("rbf", 4, 4, 40, 20, 4, 1, True), ("linear", 4, 3, 140, 20, 3, None, False), ("mix", 3, 3, 30, 24, 3, 1, True)]
+    for base, N, N2, L, d, M, lags, norm in cases:
+        X = np.cumsum(0.05 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+        X2 = np.cumsum(0.05 * rng.standard_normal((N2, L, d)), axis=1).reshape(N2, -1)
+        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, num_lags=lags, normalization=norm, lengthscales=0.8 + 0.4 * rng.random(d))
+        kx, ko = make_kernel(K, kw), make_oracle(kw)
+        assert relerr(kx.K(X), ko.K(X)) <= TOL, (base, L, d)
+        assert relerr(kx.K(X, X2, return_levels=True), ko.K(X, X2, return_levels=True)) <= TOL
+        assert relerr(kx.Kdiag(X), ko.Kdiag(X)) <= TOL
+        Z = 0.3 * rng.standard_normal((M * (M + 1) // 2, 4, d * ((lags or 0) + 1)))
+        got, want = kx.K_tens_n_seq_covs(Z, X), ko.K_tens_n_seq_covs(Z, X)
+        for g, w in zip(got, want):
+            assert relerr(g, w) <= TOL
+
+
 def test_unsupported_shapes_fail_loudly(K):
-    with pytest.raises(NotImplementedError, match="no seq-gram kernel shape"):
-        K.SignatureLinear(2 * 600, 2, 3).K(np.zeros((2, 1200)))            # 600 rows on the register side
-    with pytest.raises(NotImplementedError, match="no seq-gram kernel shape"):
-        K.SignatureLinear(20 * 200, 20, 3).K(np.zeros((2, 4000)))          # d = 20 needs the 32-wide shapes: up to 128 rows
+    with pytest.raises(NotImplementedError, match="no higher-order seq-gram kernel shape"):
+        K.SignatureLinear(2 * 600, 2, 3, order=2).K(np.zeros((2, 1200)))   # 600 rows on the register side, order 2: no fallback
     with pytest.raises(NotImplementedError):
-        K.SignatureLinear(40 * 5, 40, 3).K(np.zeros((2, 200)))             # d = 40 > 32
+        K.SignatureLinear(2 * 600, 2, 3).K(np.zeros((2, 1200), dtype=np.float32))   # the fallback is float64 only
+    with pytest.raises(NotImplementedError):
+        K.SignatureLinear(40 * 5, 40, 3).K(np.zeros((2, 200)))             # more than 32 features per lag copy
     with pytest.raises(NotImplementedError):
         K.SignatureRBF(12, 3, 3, low_rank=True, num_components=4).K(np.zeros((4, 12), dtype=np.float32))   # low-rank is float64 only
     with pytest.raises(ValueError):
