@@ -305,6 +305,8 @@ struct SeqPlanned {
 };
 
 static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
+    if (p->base_kernel == GPSIG_BASE_SPECTRAL)      // takes the points, not inner products: one-pair-per-thread kernel only
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for the first-order algorithm (order=1) only");
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
     if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
         if (g0.mode == MODE_PT_NODIFF && sizeof(TT) == 4)
@@ -420,7 +422,6 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     A.slot_elems = r.gx.rec_elems;
     A.kind = p->base_kernel;
     base_p(p, &A.p0, &A.p1);
-    CHK(spectral_table(c, p, &A.spec));
     A.out = r.out; A.si = r.si; A.sj = r.sj; A.sm = r.sm;
     A.ax = r.ax; A.by = r.by; A.jitter_diag = r.jitter_diag;
     A.sum_levels = r.sum_levels; A.pred = r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds;

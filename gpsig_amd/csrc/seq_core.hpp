@@ -59,7 +59,9 @@ GPSIG_HD float kexp(float x) {
 //     kappa(x, y) = sum_q alpha_q * E_q * cos(2 pi <omega_q, x - y>),   E_q = exp(-|gamma_q (x - y)|^2 / 2)   ('rbf' family)
 //                                                                        or  exp(-|gamma_q (x - y)| / 2)     ('exp' family)
 // 'mixed' (:932-936 reference undefined names and a sign error there; the evident intent is taken): the first floor(Q/2)
-// components Gaussian, the rest exponential.  It is not a function of (<x,y>, |x|^2, |y|^2), so it takes the points.
+// components Gaussian, the rest exponential.  It is not a function of (<x,y>, |x|^2, |y|^2), so it takes the points; the
+// wavefront kernel (seq_step below) does not carry it -- sequence-vs-sequence evaluations with this kernel go through the
+// one-pair-per-thread kernel of aux_kernels.hpp.
 // Table layout (doubles): alpha[Q], omega[Q][SPECTRAL_STRIDE], gamma[Q][SPECTRAL_STRIDE], zero beyond the d features.
 enum : int { SPECTRAL_RBF = 0, SPECTRAL_EXP = 1, SPECTRAL_MIXED = 2, SPECTRAL_STRIDE = 32 };
 template <typename T, class FX, class FY>
@@ -266,7 +268,7 @@ GPSIG_HD void seq_recursion(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, con
 // [rlo, rhi): owned columns that are real lattice columns (point modes; MODE_INC relies on zero rows).
 template <typename T, int C, int D, int MMAX, int MODE, class Nbr>
 GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&xr)[D], int M, int /*order*/,
-                       bool dummy, int rlo, int rhi, int kind, T p0, T p1, const double* spec = nullptr);
+                       bool dummy, int rlo, int rhi, int kind, T p0, T p1);
 
 // =====================================================================================================
 // Higher-order algorithm (gpsig/signature_algs.py:37-74), same lane mapping and skew.
@@ -430,7 +432,7 @@ GPSIG_HD void seq_ho_level(SeqLaneHO<T, C, D, MMAX, OMAX, MODE>& L, const Nbr& n
 // dM for the lane's C columns from the x-side row (shared by both algorithms)
 template <typename T, int C, int D, int MODE, class Lane, class Nbr>
 GPSIG_HD void seq_increments(Lane& L, const Nbr& nbr, const T (&xr)[D], bool dummy, int rlo, int rhi, int kind, T p0, T p1,
-                             const double* spec, T (&dm)[C]) {
+                             T (&dm)[C]) {
     if constexpr (MODE == MODE_INC) {
 #pragma unroll
         for (int r = 0; r < C; ++r) {
@@ -444,38 +446,14 @@ GPSIG_HD void seq_increments(Lane& L, const Nbr& nbr, const T (&xr)[D], bool dum
 #pragma unroll
         for (int f = 1; f < D; ++f) xs = fma(xr[f], xr[f], xs);
         T knew[C];
-        if (kind == BASE_SPECTRAL) {
-            // p0 = number of components, p1 = family; rows, points and the table are zero beyond the d features
 #pragma unroll
-            for (int r = 0; r < C; ++r) {
-                T acc = T(0);
-                for (int q = 0; q < int(p0); ++q) {
-                    const double* om = spec + int(p0) + q * SPECTRAL_STRIDE;
-                    const double* ga = om + int(p0) * SPECTRAL_STRIDE;
-                    T w1 = T(0), w2 = T(0);
+        for (int r = 0; r < C; ++r) {
+            T acc = xr[0] * L.y[r][0];
 #pragma unroll
-                    for (int f = 0; f < D; ++f) {
-                        const T diff = xr[f] - L.y[r][f];
-                        const T gd = T(ga[f]) * diff;
-                        w1 = fma(gd, gd, w1);
-                        w2 = fma(T(om[f]), diff, w2);
-                    }
-                    const bool gauss = int(p1) == SPECTRAL_RBF || (int(p1) == SPECTRAL_MIXED && q < int(p0) / 2);
-                    const T env = gauss ? kexp(-w1 / 2) : kexp(-sqrt(w1) / 2);
-                    acc = fma(T(spec[q]) * env, cos(T(6.283185307179586476925) * w2), acc);
-                }
-                knew[r] = acc;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < C; ++r) {
-                T acc = xr[0] * L.y[r][0];
-#pragma unroll
-                for (int f = 1; f < D; ++f) acc = fma(xr[f], L.y[r][f], acc);
-                knew[r] = acc;
-            }
-            base_eval_n<T, C>(kind, knew, L.y2, xs, p0, p1);
+            for (int f = 1; f < D; ++f) acc = fma(xr[f], L.y[r][f], acc);
+            knew[r] = acc;
         }
+        base_eval_n<T, C>(kind, knew, L.y2, xs, p0, p1);
         if constexpr (MODE == MODE_PT_DIFF) {
             const T kleft_new = nbr.kleft();
             dm[0] = (knew[0] - kleft_new) - (L.kprev[0] - L.kleft);
@@ -497,18 +475,18 @@ GPSIG_HD void seq_increments(Lane& L, const Nbr& nbr, const T (&xr)[D], bool dum
 // Higher-order step (order = the reference's `order`, 2 <= order <= OMAX; order 1 also works and equals seq_step).
 template <typename T, int C, int D, int MMAX, int OMAX, int MODE, class Nbr>
 GPSIG_HD void seq_step(SeqLaneHO<T, C, D, MMAX, OMAX, MODE>& L, const Nbr& nbr, const T (&xr)[D], int M, int order,
-                       bool dummy, int rlo, int rhi, int kind, T p0, T p1, const double* spec = nullptr) {
+                       bool dummy, int rlo, int rhi, int kind, T p0, T p1) {
     T dm[C];
-    seq_increments<T, C, D, MODE>(L, nbr, xr, dummy, rlo, rhi, kind, p0, p1, spec, dm);
+    seq_increments<T, C, D, MODE>(L, nbr, xr, dummy, rlo, rhi, kind, p0, p1, dm);
     T R0[OMAX][OMAX][C];
     detail::seq_ho_level<1>(L, nbr, dm, M, order, R0);
 }
 
 template <typename T, int C, int D, int MMAX, int MODE, class Nbr>
 GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&xr)[D], int M, int /*order*/,
-                       bool dummy, int rlo, int rhi, int kind, T p0, T p1, const double* spec) {
+                       bool dummy, int rlo, int rhi, int kind, T p0, T p1) {
     T dm[C];
-    seq_increments<T, C, D, MODE>(L, nbr, xr, dummy, rlo, rhi, kind, p0, p1, spec, dm);
+    seq_increments<T, C, D, MODE>(L, nbr, xr, dummy, rlo, rhi, kind, p0, p1, dm);
     seq_recursion(L, nbr, dm, M);
 }
 

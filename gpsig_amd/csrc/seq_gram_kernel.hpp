@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
         // if lane 0 opens a new x at the next step, its record (requested issue_at steps into this x) must have landed
         if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-        seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, A.kind, p0, p1, A.spec);
+        seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, A.kind, p0, p1);
         ctl.end_step();
     };
     // two steps per trip: the loop-carried hand-over words (s, qold) alternate registers instead of being copied

@@ -95,7 +95,7 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
             T xr[D];
             for (int f = 0; f < D; ++f) xr[f] = rowp[f];
             const bool dummy = ctl[lane].row0;
-            seq_step(L[lane], snap[lane], xr, M, A.order, dummy, rlo[lane], rhi[lane], A.kind, T(A.p0), T(A.p1), A.spec);
+            seq_step(L[lane], snap[lane], xr, M, A.order, dummy, rlo[lane], rhi[lane], A.kind, T(A.p0), T(A.p1));
             ctl[lane].end_step();
         }
     }
