@@ -52,6 +52,11 @@ SeqLaunchFn seq_lookup_f32_inc_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_ptd_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_ptd_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_ptd_g64(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptn_g16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptn_g64(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ho_f32_ptn_d4(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_ptn_d8(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_ptn_d16(int, int, int, int, int);
 typedef hipError_t (*TvsLaneTLaunchFn)(const TvsLaneTArgs&, hipStream_t);
 bool tvs_lanet_plan(int M, int d, bool incr, TvsLaneTLaunchFn* fns, int* ngroups);
 }  // namespace gpsig
@@ -88,7 +93,9 @@ SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32) {
             if ((f = seq_lookup_f32_ptd_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
             return seq_lookup_f32_ptd_g64(c.G, c.C, c.D, c.MMAX, c.exact);
         }
-        return nullptr;
+        if (c.exact) return nullptr;
+        if ((f = seq_lookup_f32_ptn_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+        return seq_lookup_f32_ptn_g64(c.G, c.C, c.D, c.MMAX, c.exact);
     }
     if (mode == MODE_INC) {
         if ((f = seq_lookup_inc_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
@@ -114,7 +121,7 @@ SeqLaunchFn seq_launcher_ho(int mode, const SeqHOConfig& c, bool f32) {
     if (f32) {
         if (mode == MODE_INC) HO_PICK(f32_inc);
         if (mode == MODE_PT_DIFF) HO_PICK(f32_ptd);
-        return nullptr;            // float32 without differences: not built
+        HO_PICK(f32_ptn);
     }
     if (mode == MODE_INC) HO_PICK(inc);
     if (mode == MODE_PT_DIFF) HO_PICK(ptd);
@@ -309,8 +316,6 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
         return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for the first-order algorithm (order=1) only");
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
     if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
-        if (g0.mode == MODE_PT_NODIFF && sizeof(TT) == 4)
-            return fail(c, GPSIG_ERR_UNSUPPORTED, "float32 with difference=False and a non-linear base kernel is not built");
         int k = seq_select_ho(SEQ_HO_TABLE, N_SEQ_HO_TABLE, g0.rows, d_eff, p->num_levels, p->order);
         if (k < 0)
             return fail(c, GPSIG_ERR_UNSUPPORTED,
@@ -326,11 +331,9 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
         return GPSIG_OK;
     }
     const bool f32 = sizeof(TT) == 4;
-    if (f32 && g0.mode == MODE_PT_NODIFF)
-        return fail(c, GPSIG_ERR_UNSUPPORTED, "float32 with difference=False and a non-linear base kernel is not built");
     const SeqConfig* tab = f32 ? SEQ_TABLE_F32 : (g0.mode == MODE_PT_NODIFF ? SEQ_TABLE_GENERIC : SEQ_TABLE);
     const int ntab = f32 ? N_SEQ_TABLE_F32 : (g0.mode == MODE_PT_NODIFF ? N_SEQ_TABLE_GENERIC : N_SEQ_TABLE);
-    int k = seq_select(tab, ntab, g0.rows, d_eff, p->num_levels, c->allow_exact != 0);
+    int k = seq_select(tab, ntab, g0.rows, d_eff, p->num_levels, c->allow_exact != 0 && g0.mode != MODE_PT_NODIFF);
     if (k < 0)
         return fail(c, GPSIG_ERR_UNSUPPORTED,
                     "no seq-gram kernel shape for %d record rows on the register-resident side, d=%d, num_levels=%d "

@@ -8,8 +8,7 @@ every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CU
 pointers, asynchronous on the current stream).
 
 float32 inputs are computed in float32 (exact mode only).  Not built yet (raise NotImplementedError, never a silent
-fallback): ``SignatureSpectral`` in float32 / low-rank mode / with gradients; ``low_rank=True`` in float32; float32 with ``difference=False`` and a non-linear base
-kernel.  Training (gradients): ``gpsig_amd.autodiff``.
+fallback): ``SignatureSpectral`` in float32 / low-rank mode / with gradients; ``low_rank=True`` in float32.  Training (gradients): ``gpsig_amd.autodiff``.
 """
 import ctypes as C
 

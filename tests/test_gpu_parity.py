@@ -572,6 +572,12 @@ def test_float32_matches_the_float64_oracle(K, base):
     assert relerr32(kx.Kdiag(X32), ko.Kdiag(X32.astype(np.float64))) <= TOL32
     # mixed precision inputs are computed in float64
     assert kx.K(X32, Y).dtype == np.float64
+    # without differences (kappa itself feeds the recursion): smaller inputs keep the levels in float32 range
+    kw = dict(kw, difference=False)
+    kx, ko = make_kernel(K, kw), make_oracle(kw)
+    Xs, Ys = 0.3 * X32, 0.3 * Y32
+    assert relerr32(kx.K(Xs), ko.K(Xs.astype(np.float64))) <= TOL32
+    assert relerr32(kx.K(Xs, Ys), ko.K(Xs.astype(np.float64), Ys.astype(np.float64))) <= TOL32
 
 
 def test_float32_config5_shape_reduced_n(K):
