@@ -116,6 +116,16 @@ int launch_tvs_lanet(gpsig_ctx* c, int DP, bool paired, dim3 grid, const TvsLane
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
 }
+// row-owned variant (registers bound it to num_levels <= 4, DP <= 8)
+bool tens_row_available(int DP, int M) { return M <= 4 && DP <= 8; }
+int launch_tens_row(gpsig_ctx* c, int DP, int E, dim3 grid, const TensGradArgs& a) {
+    if (DP == 4 && E == 1) hipLaunchKernelGGL((tens_row_grad_kernel<4, 4, 1>), grid, dim3(64), 0, c->stream, a);
+    else if (DP == 4) hipLaunchKernelGGL((tens_row_grad_kernel<4, 4, 2>), grid, dim3(64), 0, c->stream, a);
+    else if (E == 1) hipLaunchKernelGGL((tens_row_grad_kernel<8, 4, 1>), grid, dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL((tens_row_grad_kernel<8, 4, 2>), grid, dim3(64), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
 int launch_tens(gpsig_ctx* c, int DP, dim3 grid, const TensGradArgs& a) {
     switch (DP) {
         case 4: hipLaunchKernelGGL(tens_pair_grad_kernel<4>, grid, dim3(64), 0, c->stream, a); break;
@@ -468,7 +478,14 @@ int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void*
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         A.G = static_cast<const double*>(dG); A.gm = T * T; A.gt = T; A.gn = 1;
         A.gbase = dgb;
-        CHK(launch_tens(c, DP, dim3(unsigned((T + 63) / 64), unsigned(T)), A));
+        if (c->grad_impl == 0 && tens_row_available(DP, M)) {
+            const int64_t tb = (T + 63) / 64;
+            int64_t slices = (1024 + tb - 1) / tb;
+            if (slices > T) slices = T;
+            CHK(launch_tens_row(c, DP, E, dim3(unsigned(tb), unsigned(slices)), A));
+        } else {
+            CHK(launch_tens(c, DP, dim3(unsigned((T + 63) / 64), unsigned(T)), A));
+        }
         CHK(unpad_rows(c, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
     }
     CHK(out_done(c, gZ, dgZ, zb));

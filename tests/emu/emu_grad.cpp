@@ -152,7 +152,8 @@ int emu_tvs_grad(const double* Z, const double* X, int T, int N, int L, int d, i
 }
 
 // Z (lt, T, [2,] d), G (M+1, T, T)
-int emu_tens_grad(const double* Z, int T, int d, int M, int kind, int incr, double p0, double p1, const double* G, double* gZ, double* gbase) {
+int emu_tens_grad(const double* Z, int T, int d, int M, int kind, int incr, double p0, double p1, const double* G, double* gZ, double* gbase,
+                  int row_owned) {
     const int DP = pad_of(d), lt = M * (M + 1) / 2, E = incr ? 2 : 1;
     const int64_t rows = int64_t(lt) * T * E;
     std::vector<double> zp = pad_rows(Z, rows, d, DP), gzp(zp.size(), 0.0);
@@ -162,7 +163,16 @@ int emu_tens_grad(const double* Z, int T, int d, int M, int kind, int incr, doub
     A.z = zp.data(); A.gz = gzp.data(); A.T = T; A.M = M; A.kind = kind; A.incr = incr; A.p0 = p0; A.p1 = p1;
     A.G = G; A.gm = int64_t(T) * T; A.gt = T; A.gn = 1;
     A.gbase = gb;
-    switch (DP) {
+    if (row_owned) {
+        if (M > 4 || DP > 8) return -2;
+        for (int sl = 0; sl < 3; ++sl)
+            for (int t = 0; t < T; ++t) {
+                if (DP == 4 && E == 1) TensRowGrad<4, 4, 1>(A, t, true).run(sl, 3);
+                else if (DP == 4) TensRowGrad<4, 4, 2>(A, t, true).run(sl, 3);
+                else if (E == 1) TensRowGrad<8, 4, 1>(A, t, true).run(sl, 3);
+                else TensRowGrad<8, 4, 2>(A, t, true).run(sl, 3);
+            }
+    } else switch (DP) {
         case 4: tens_run<4>(A); break;
         case 8: tens_run<8>(A); break;
         case 16: tens_run<16>(A); break;

@@ -58,11 +58,12 @@ def tvs_grad(Z, X, G, M, base, difference, increments, p0=0.0, p1=0.0, fused=Fal
     return lev, gZ, gX, gb[0]
 
 
-def tens_grad(Z, G, M, base, increments, p0=0.0, p1=0.0):
+def tens_grad(Z, G, M, base, increments, p0=0.0, p1=0.0, row_owned=False):
     Z, G = np.ascontiguousarray(Z, np.float64), np.ascontiguousarray(G, np.float64)
     T, d = Z.shape[1], Z.shape[-1]
     gZ, gb = np.zeros_like(Z), np.zeros(2)
-    lib().emu_tens_grad(_ptr(Z), T, d, M, BASE_IDS[base], int(increments), C.c_double(p0), C.c_double(p1), _ptr(G), _ptr(gZ), _ptr(gb))
+    if lib().emu_tens_grad(_ptr(Z), T, d, M, BASE_IDS[base], int(increments), C.c_double(p0), C.c_double(p1), _ptr(G), _ptr(gZ), _ptr(gb), int(row_owned)):
+        raise NotImplementedError("no such emulator variant")
     return gZ, gb[0]
 
 

@@ -146,10 +146,11 @@ def test_tensor_adjoints_equal_autograd(base, difference, increments):
     kt = _t_kern(base, d, M)
     tZ = torch.tensor(Z, requires_grad=True)
     (kt.K_tens_levels(tZ, increments) * torch.tensor(G2)).sum().backward()
-    gZ, gp0 = EG.tens_grad(Z, G2, M, base, increments, p0, p1)
-    assert rel(gZ, tZ.grad) < 1e-12
-    if base in ("poly", "mix"):
-        assert abs(gp0 - kt.p0.grad.item()) < 1e-10 * max(1.0, abs(gp0))
+    for row_owned in (False, True):       # one (t, t') entry per thread / one tensor per thread using the symmetry of Kzz
+        gZ, gp0 = EG.tens_grad(Z, G2, M, base, increments, p0, p1, row_owned=row_owned)
+        assert rel(gZ, tZ.grad) < 1e-12, row_owned
+        if base in ("poly", "mix"):
+            assert abs(gp0 - kt.p0.grad.item()) < 1e-10 * max(1.0, abs(gp0))
 
 
 @pytest.mark.parametrize("base", ["linear", "rbf", "poly", "matern32"])

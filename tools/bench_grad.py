@@ -39,6 +39,22 @@ if "a" in which:
             opt.zero_grad(); loss = -model.elbo(X[idx], Y[idx]); loss.backward(); opt.step()
         dt = timeit(step, n=50, warm=5)
         print(f"(a) SVGP training step (LIBRAS shape, minibatch {mb}, {T} inducing tensors, kernel trainable={trainable}): {dt*1e3:.2f} ms = {1/dt:.1f} it/s")
+if "d" in which:
+    # benchmarks/run_gpsig_benchmarks.py:32: num_levels=4, 500 inducing tensors with increments, num_lags=1, minibatch 50; a mid-sized data set
+    N, L, d, M, T, C, mb = 400, 200, 3, 4, 500, 5, 50
+    Xn = np.cumsum(rng.standard_normal((N, L, d)) * 0.1, axis=1)
+    X = torch.tensor(Xn.reshape(N, -1), device=dev)
+    Y = torch.tensor(rng.integers(0, C, (N, 1)).astype(np.float64), device=dev)
+    from gpsig_amd import utils
+    Z = utils.suggest_initial_inducing_tensors(Xn, M, T, increments=True, num_lags=1, rng=rng)
+    kern = kernels.SignatureRBF(L * d, d, M, lengthscales=1.0, num_lags=1)
+    model = models.SVGPModule(kern, iv.InducingTensors(Z, M, increments=True), LK.MultiClass(C), num_latent=C, num_data=N, device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    idx = torch.arange(mb, device=dev)
+    def step():
+        opt.zero_grad(); loss = -model.elbo(X[idx], Y[idx]); loss.backward(); opt.step()
+    dt = timeit(step, n=20, warm=3)
+    print(f"(d) SVGP training step (benchmark settings: 500 inducing tensors, increments, num_lags=1, minibatch {mb}, L={L}, d={d}): {dt*1e3:.2f} ms = {1/dt:.1f} it/s")
 if "b" in which:
     T, N, L, d, M = 512, 16384, 50, 6, 4
     X = torch.tensor(np.cumsum(0.2 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1), device=dev)
