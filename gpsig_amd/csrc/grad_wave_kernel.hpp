@@ -86,16 +86,18 @@ __global__ void __launch_bounds__(64) seq_grad_wave_kernel(const WaveGradArgs A)
                 wave_load_point<DP>(A.X, i, A.L1, A.d, 0, x0);
                 dmg.prime(x0, A.kind, A.p0, A.p1);
             }
+            double xcur[DP];                                  // the point row of the coming step, loaded one step ahead
+            wave_load_point<DP>(A.X, i, A.L1, A.d, 0 - lam + dr, xcur);
             for (int t = 0; t < TF; ++t) {
-                double cin[LQ + 2];
+                double cin[LQ + 2], xnext[DP];
                 cin[0] = 0.0;
 #pragma unroll
                 for (int m = 1; m < LQ + 2; ++m) cin[m] = wave_from_left<G>(fw.sout[m]);
                 const int a = t - lam;
+                wave_load_point<DP>(A.X, i, A.L1, A.d, a + 1 + dr, xnext);
                 if (a >= 0 && a < R1) {
-                    double xn[DP], dm[C];
-                    wave_load_point<DP>(A.X, i, A.L1, A.d, a + dr, xn);
-                    dmg.row(xn, true, A.kind, A.p0, A.p1, dm);
+                    double dm[C];
+                    dmg.row(xcur, true, A.kind, A.p0, A.p1, dm);
                     fw.step(dm, cin, M);
 #pragma unroll
                     for (int m = 0; m < LQ; ++m)
@@ -104,6 +106,8 @@ __global__ void __launch_bounds__(64) seq_grad_wave_kernel(const WaveGradArgs A)
                             for (int c = 0; c < C; ++c) slot(m, t, lam, c) = fw.q[m][c];
                         }
                 }
+#pragma unroll
+                for (int f = 0; f < DP; ++f) xcur[f] = xnext[f];
             }
         }
         __threadfence();        // the backward sweep reads what other lanes of this wavefront stored
@@ -118,18 +122,19 @@ __global__ void __launch_bounds__(64) seq_grad_wave_kernel(const WaveGradArgs A)
                 dmg.prime(xl, A.kind, A.p0, A.p1);
             }
             double* lamrow = A.lam + size_t(have ? pp : 0) * R1 * R2;
+            double xcur[DP];
+            wave_load_point<DP>(A.X, i, A.L1, A.d, R1 - 1 + (G - 1 - lam), xcur);     // row of step 0 (beyond the sequence: zeros)
             for (int u = 0; u < TF; ++u) {
-                double sin[LQ];
+                double sin[LQ], xnext[DP];
 #pragma unroll
                 for (int p = 0; p < LQ; ++p) sin[p] = wave_from_right<G>(bw.svout[p]);
                 const int a = R1 - 1 - (u - (G - 1 - lam));
+                wave_load_point<DP>(A.X, i, A.L1, A.d, a - 1, xnext);
                 if (a >= 0 && a < R1) {
-                    double xn[DP], dm[C], qfd[LQ][C], lv[C];
-                    wave_load_point<DP>(A.X, i, A.L1, A.d, a, xn);
-                    dmg.row(xn, false, A.kind, A.p0, A.p1, dm);
+                    double dm[C], qfd[LQ][C], lv[C];
                     const int tf = a - 1 + lam;          // forward step at which this lane stored row a-1
 #pragma unroll
-                    for (int m = 0; m < LQ; ++m)
+                    for (int m = 0; m < LQ; ++m)         // issued before the kernel evaluations that hide their latency
 #pragma unroll
                         for (int c = 0; c < C; ++c) {
                             double v = 0.0;
@@ -139,6 +144,7 @@ __global__ void __launch_bounds__(64) seq_grad_wave_kernel(const WaveGradArgs A)
                             }
                             qfd[m][c] = v;
                         }
+                    dmg.row(xcur, false, A.kind, A.p0, A.p1, dm);
                     bw.step(dm, clev, qfd, sin, M, lv);
                     if (have) {
 #pragma unroll
@@ -146,6 +152,8 @@ __global__ void __launch_bounds__(64) seq_grad_wave_kernel(const WaveGradArgs A)
                             if (c < dmg.nvalid) lamrow[size_t(a) * R2 + C * lam + c] = lv[c];
                     }
                 }
+#pragma unroll
+                for (int f = 0; f < DP; ++f) xcur[f] = xnext[f];
             }
         }
         __threadfence();        // the slot is rewritten by the next pair
