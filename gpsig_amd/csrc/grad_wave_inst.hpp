@@ -14,7 +14,7 @@ hipError_t wave_launch(const WaveGradArgs& a, int nblocks, hipStream_t s) {
 // (G, C, DP): lanes per pair, columns per lane, padded feature count.  C * DP bounded by the register file.
 #define GPSIG_WAVE_SHAPES(X) \
     X(16, 2, 4) X(16, 2, 8) X(16, 2, 16) X(16, 4, 4) X(16, 4, 8) X(16, 4, 16) \
-    X(64, 2, 4) X(64, 2, 8) X(64, 2, 16) X(64, 4, 16) X(64, 8, 4) X(64, 8, 8)
+    X(64, 2, 4) X(64, 2, 8) X(64, 2, 16) X(64, 4, 4) X(64, 4, 8) X(64, 4, 16) X(64, 8, 4) X(64, 8, 8)
 
 typedef hipError_t (*Wave2LaunchFn)(const Wave2Args&, int, size_t, hipStream_t);
 template <int G, int C, int DP, int LQ, int MODE>

@@ -122,30 +122,36 @@ __global__ void __launch_bounds__(64) seq_grad_wave_kernel(const WaveGradArgs A)
                 dmg.prime(xl, A.kind, A.p0, A.p1);
             }
             double* lamrow = A.lam + size_t(have ? pp : 0) * R1 * R2;
-            double xcur[DP];
+            double xcur[DP], qcur[LQ][C];
             wave_load_point<DP>(A.X, i, A.L1, A.d, R1 - 1 + (G - 1 - lam), xcur);     // row of step 0 (beyond the sequence: zeros)
+            // forward values Q_m[a-1][b_c - 1] of lattice row a: written at forward step a - 1 + lam (own columns) and one
+            // step earlier by the left neighbour (first column); fetched one backward step ahead of their use
+            auto fetch_q = [&](int a, double (&q)[LQ][C]) {
+                const int tf = a - 1 + lam;
+#pragma unroll
+                for (int m = 0; m < LQ; ++m)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        double v = 0.0;
+                        if (m < M - 1 && a > 0 && a < R1) {
+                            if (c > 0) v = slot(m, tf, lam, c - 1);
+                            else if (lam > 0) v = slot(m, tf - 1, lam - 1, C - 1);
+                        }
+                        q[m][c] = v;
+                    }
+            };
+            fetch_q(R1 - 1 + (G - 1 - lam), qcur);
             for (int u = 0; u < TF; ++u) {
-                double sin[LQ], xnext[DP];
+                double sin[LQ], xnext[DP], qnext[LQ][C];
 #pragma unroll
                 for (int p = 0; p < LQ; ++p) sin[p] = wave_from_right<G>(bw.svout[p]);
                 const int a = R1 - 1 - (u - (G - 1 - lam));
                 wave_load_point<DP>(A.X, i, A.L1, A.d, a - 1, xnext);
+                fetch_q(a - 1, qnext);
                 if (a >= 0 && a < R1) {
-                    double dm[C], qfd[LQ][C], lv[C];
-                    const int tf = a - 1 + lam;          // forward step at which this lane stored row a-1
-#pragma unroll
-                    for (int m = 0; m < LQ; ++m)         // issued before the kernel evaluations that hide their latency
-#pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            double v = 0.0;
-                            if (m < M - 1 && a > 0) {
-                                if (c > 0) v = slot(m, tf, lam, c - 1);
-                                else if (lam > 0) v = slot(m, tf - 1, lam - 1, C - 1);
-                            }
-                            qfd[m][c] = v;
-                        }
+                    double dm[C], lv[C];
                     dmg.row(xcur, false, A.kind, A.p0, A.p1, dm);
-                    bw.step(dm, clev, qfd, sin, M, lv);
+                    bw.step(dm, clev, qcur, sin, M, lv);
                     if (have) {
 #pragma unroll
                         for (int c = 0; c < C; ++c)
@@ -154,6 +160,10 @@ __global__ void __launch_bounds__(64) seq_grad_wave_kernel(const WaveGradArgs A)
                 }
 #pragma unroll
                 for (int f = 0; f < DP; ++f) xcur[f] = xnext[f];
+#pragma unroll
+                for (int m = 0; m < LQ; ++m)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) qcur[m][c] = qnext[m][c];
             }
         }
         __threadfence();        // the slot is rewritten by the next pair
