@@ -377,3 +377,44 @@ def test_wave_and_storage_gradient_kernels_agree(base, difference):
             assert rel(res[k][0], res[0][0]) < 1e-9, (kind, L2, k, rel(res[k][0], res[0][0]))
             if Y is not None:
                 assert rel(res[k][1], res[0][1]) < 1e-9, (kind, L2, k, rel(res[k][1], res[0][1]))
+
+
+def test_inducing_sequences_model(K=None):
+    """InducingSequences (inducing_variables.py:89-137): the differentiable K_seq_n_seq_covs equals the fused evaluation path
+    (which is pinned to the oracle in test_gpu_parity.py), its gradient passes a finite-difference check, and the SVGP built on
+    it trains."""
+    from gpsig_amd import kernels, models, autodiff, likelihoods as LK, inducing_variables as iv
+    rng = np.random.default_rng(60)
+    N, L, d, M, T, Lz = 30, 10, 2, 3, 6, 4
+    X, Y = _toy(N, L, d, seed=61)
+    Zs = 0.4 * rng.standard_normal((T, Lz, d))
+    kern = kernels.SignatureRBF(L * d, d, M, lengthscales=rng.uniform(0.8, 1.4, d), variances=rng.uniform(0.6, 1.4, M + 1))
+    mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
+    dev = torch.device("cuda:0")
+    Zg = torch.tensor(Zs, device=dev, requires_grad=True)
+    Xg = torch.tensor(X, device=dev)
+    for full in (False, True):
+        got = mod.K_seq_n_seq_covs(Zg, Xg, full_X2_cov=full)
+        want = kern.K_seq_n_seq_covs(Zs, X, full_X2_cov=full)
+        for g, w in zip(got, want):
+            assert rel(g, w) < 1e-9
+    W1, W2 = torch.tensor(rng.standard_normal((T, T)), device=dev), torch.tensor(rng.standard_normal((T, N)), device=dev)
+
+    def loss_of(Zt):
+        a, b, c = mod.K_seq_n_seq_covs(Zt, Xg)
+        return (a * W1).sum() + (b * W2).sum() + c.sum()
+    loss_of(Zg).backward()
+    h = 1e-6
+    for idx in [(0, 0, 0), (2, 3, 1), (5, 1, 0)]:
+        Zp, Zm = Zs.copy(), Zs.copy()
+        Zp[idx] += h
+        Zm[idx] -= h
+        with torch.no_grad():
+            fd = (loss_of(torch.tensor(Zp, device=dev)) - loss_of(torch.tensor(Zm, device=dev))).item() / (2 * h)
+        assert abs(fd - Zg.grad[idx].item()) < 1e-5 * max(1.0, abs(fd)), (idx, fd, Zg.grad[idx].item())
+    # Training: with normalisation the reference divides Kzx by the inducing-side diagonal twice (kernels.py:713 + :750,
+    # reproduced), which makes Kzx inconsistent with Kzz and the predictive variance negative -- so train without it.
+    kern2 = kernels.SignatureRBF(L * d, d, M, lengthscales=1.0, normalization=False, variances=0.3)
+    model = models.SVGPModule(kern2, iv.InducingSequences(Zs, M, learn_weights=True), LK.Bernoulli(), device="cuda:0")
+    trace = model.fit(Xg, torch.tensor(Y, device=dev), iterations=25, lr=0.02)
+    assert np.all(np.isfinite(trace)) and trace[-1] > trace[0]

@@ -21,7 +21,7 @@ def timeit(fn, n=5, warm=2):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 
 
-which = sys.argv[1:] or ["a", "b", "c"]
+which = sys.argv[1:] or ["a", "d", "b", "c"]
 if "a" in which:
     # notebooks/ts_classification.ipynb: LIBRAS, N_train=144 (here synthetic of that shape), L=45, d=3 (+ time? no), M=4, 200 inducing tensors
     # with increments, minibatch 50, 15 classes, SignatureRBF
