@@ -57,6 +57,12 @@ SeqLaunchFn seq_lookup_f32_ptn_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ho_f32_ptn_d4(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_f32_ptn_d8(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_f32_ptn_d16(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_inc_d32(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_ptd_d32(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_ptn_d32(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_inc_d32(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_ptd_d32(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_f32_ptn_d32(int, int, int, int, int);
 typedef hipError_t (*TvsLaneTLaunchFn)(const TvsLaneTArgs&, hipStream_t);
 bool tvs_lanet_plan(int M, int d, bool incr, TvsLaneTLaunchFn* fns, int* ngroups);
 }  // namespace gpsig
@@ -116,7 +122,8 @@ SeqLaunchFn seq_launcher_ho(int mode, const SeqHOConfig& c, bool f32) {
     do {                                                                          \
         if (c.D == 4) return seq_lookup_ho_##V##_d4(c.G, c.C, c.D, c.MMAX, c.OMAX);   \
         if (c.D == 8) return seq_lookup_ho_##V##_d8(c.G, c.C, c.D, c.MMAX, c.OMAX);   \
-        return seq_lookup_ho_##V##_d16(c.G, c.C, c.D, c.MMAX, c.OMAX);            \
+        if (c.D == 16) return seq_lookup_ho_##V##_d16(c.G, c.C, c.D, c.MMAX, c.OMAX); \
+        return seq_lookup_ho_##V##_d32(c.G, c.C, c.D, c.MMAX, c.OMAX);            \
     } while (0)
     if (f32) {
         if (mode == MODE_INC) HO_PICK(f32_inc);
@@ -313,14 +320,14 @@ struct SeqPlanned {
 
 static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
     if (p->base_kernel == GPSIG_BASE_SPECTRAL)      // takes the points, not inner products: one-pair-per-thread kernel only
-        return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for the first-order algorithm (order=1) only");
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for float64 only");
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
     if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
         int k = seq_select_ho(SEQ_HO_TABLE, N_SEQ_HO_TABLE, g0.rows, d_eff, p->num_levels, p->order);
         if (k < 0)
             return fail(c, GPSIG_ERR_UNSUPPORTED,
                         "no higher-order seq-gram kernel shape for %d record rows, d=%d, num_levels=%d, order=%d (built: order <= 8 up "
-                        "to 64 rows, <= 4 up to 128 rows, 2 up to 512 rows; num_levels <= 6 (8 up to 64 rows); d <= 16)",
+                        "to 64 rows, <= 4 up to 128 rows, 2 up to 512 rows; num_levels <= 6 (8 up to 64 rows); d <= 16, or d <= 32 with at most 128 rows)",
                         g0.rows, d_eff, p->num_levels, p->order);
         const SeqHOConfig& h = SEQ_HO_TABLE[k];
         out->cfg = SeqConfig{h.G, h.C, h.D, h.MMAX, false};
@@ -478,7 +485,7 @@ static int make_factors(gpsig_ctx* c, const void* dlev, int64_t N, int M1, const
 }
 
 // ---- any-shape fallback (seq_levels_generic_kernel): float64, first-order algorithm --------------------------------------
-static bool generic_ok(const gpsig_params* p) { return sizeof(TT) == 8 && (p->order == 1 || p->num_levels == 1); }
+static bool generic_ok(const gpsig_params* p) { return sizeof(TT) == 8 && p->num_levels <= 8 && p->order <= 8; }
 
 // raw levels of the pairs (i, j) (or (i, i) when diag) into out[m * sm + i * si + j * sj]
 static int generic_levels(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* X, const void* Y, int64_t N1, int64_t N2,
@@ -504,7 +511,8 @@ static int generic_levels(gpsig_ctx* c, const gpsig_params* p, bool apply_scalin
     const int mode = (g.mode == MODE_INC && !p->difference) ? MODE_PT_NODIFF : g.mode;
     const int dr = mode == MODE_PT_NODIFF ? 0 : 1;
     const int R2 = L2 - dr;
-    const size_t per_j = sizeof(double) * size_t(M > 1 ? M - 1 : 1) * size_t(R2 > 0 ? R2 : 1) * size_t(s1);
+    const bool ho = p->order > 1 && M > 1;
+    const size_t per_j = sizeof(double) * size_t(M > 1 ? M - 1 : 1) * (ho ? 9 : 1) * size_t(R2 > 0 ? R2 : 1) * size_t(s1);
     int64_t chunk = diag ? 1 : int64_t((size_t(c->grad_scratch_mb > 0 ? c->grad_scratch_mb : 4096) << 20) / per_j);
     if (chunk < 1) chunk = 1;
     if (chunk > N2) chunk = N2;
@@ -523,7 +531,8 @@ static int generic_levels(gpsig_ctx* c, const gpsig_params* p, bool apply_scalin
     for (int64_t j0 = 0; j0 < (diag ? 1 : N2); j0 += chunk) {
         const int64_t nj = diag ? 1 : ((N2 - j0 < chunk) ? N2 - j0 : chunk);
         A.j0 = j0; A.pairs = s1 * nj;
-        hipLaunchKernelGGL(seq_levels_generic_kernel, dim3(unsigned(s1 / 64), unsigned(nj)), dim3(64), 0, c->stream, A);
+        if (ho) hipLaunchKernelGGL(seq_levels_generic_ho_kernel, dim3(unsigned(s1 / 64), unsigned(nj)), dim3(64), 0, c->stream, A, int(p->order));
+        else hipLaunchKernelGGL(seq_levels_generic_kernel, dim3(unsigned(s1 / 64), unsigned(nj)), dim3(64), 0, c->stream, A);
         HIPCHK(c, hipGetLastError());
     }
     return GPSIG_OK;

@@ -662,6 +662,112 @@ static __global__ void __launch_bounds__(64) seq_levels_generic_kernel(const Gen
     o[int64_t(M) * A.sm] = ktop;
 }
 
+// Higher-order algorithm (signature_algs.py:37-74) in the same any-shape, one-pair-per-thread form.  Per lattice cell and
+// level m the reference's d x d grid (d = min(m, order)) is
+//     R_m[0][0]     = dM * (exclusive 2-D prefix of the grid total of level m-1)                       (:64)
+//     R_m[0][j-1]   = dM / j * (exclusive prefix over rows a of the column sum  sum_r R_{m-1}[r][j-2])   (:66)
+//     R_m[j-1][0]   = dM / j * (exclusive prefix over columns b of the row sum  sum_s R_{m-1}[j-2][s])   (:67)
+//     R_m[j-1][k-1] = dM / (j k) * R_{m-1}[j-2][k-2]   at the same cell                                    (:69)
+// and K_m = sum over cells and grid entries (:71).  Scratch per pair and lattice column: for each level m < M the inclusive
+// 2-D prefix Q_m of the previous row and the OM column prefixes; the row prefixes run in (private) registers along a row.
+static __global__ void __launch_bounds__(64) seq_levels_generic_ho_kernel(const GenericSeqArgs A, int order) {
+    constexpr int MM = 8, OM = 8;
+    const int64_t i = int64_t(blockIdx.x) * 64 + threadIdx.x;
+    const bool valid = i < A.N1;
+    const int64_t ii = valid ? i : 0;
+    const int64_t j = A.diag ? ii : A.j0 + blockIdx.y;
+    const int64_t pidx = (int64_t(blockIdx.y) * gridDim.x + blockIdx.x) * 64 + threadIdx.x;
+    const int dr = A.mode == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = A.L1 - dr, R2 = A.L2 - dr, M = A.M;
+    // scratch slot (level m in 1..M-1, q in 0..OM, column b): q == 0 -> Q_m, q == 1 + s -> column prefix of grid column s
+    auto slot = [&](int m, int q, int b) -> double& { return A.scratch[((int64_t(m - 1) * (OM + 1) + q) * R2 + b) * A.pairs + pidx]; };
+    double K[MM + 1];
+    for (int m = 0; m <= MM; ++m) K[m] = 0.0;
+    for (int a = 0; a < R1; ++a) {
+        double sq[MM], qd[MM], RE[MM][OM];       // row prefix of the grid total, Q_m[a-1][b-1], row prefixes of the row sums
+        for (int m = 0; m < MM; ++m) {
+            sq[m] = qd[m] = 0.0;
+            for (int r = 0; r < OM; ++r) RE[m][r] = 0.0;
+        }
+        double klo = 0.0, khi = 0.0;
+        if (A.mode == MODE_PT_DIFF) { klo = generic_kappa(A, ii, a, j, 0); khi = generic_kappa(A, ii, a + 1, j, 0); }
+        for (int b = 0; b < R2; ++b) {
+            double dm;
+            if (A.mode == MODE_INC) {
+                dm = 0.0;
+                for (int f = 0; f < A.d; ++f) {
+                    const double* x = A.XT + (int64_t(a) * A.d + f) * A.xstride + ii;
+                    const double* y = A.YT + (int64_t(b) * A.d + f) * A.ystride + j;
+                    dm = fma(x[int64_t(A.d) * A.xstride] - x[0], y[int64_t(A.d) * A.ystride] - y[0], dm);
+                }
+            } else if (A.mode == MODE_PT_DIFF) {
+                const double nlo = generic_kappa(A, ii, a, j, b + 1), nhi = generic_kappa(A, ii, a + 1, j, b + 1);
+                dm = (nhi - khi) - (nlo - klo);
+                klo = nlo; khi = nhi;
+            } else {
+                dm = generic_kappa(A, ii, a, j, b);
+            }
+            double Rp[OM][OM], Rc[OM][OM];        // grids of level m-1 and m at this cell
+            Rp[0][0] = dm;                        // level 1 (:58-60)
+            int dp = 1;
+            K[1] += dm;
+            for (int m = 2; m <= M + 1; ++m) {
+                const int lv = m - 1;             // level whose grid is in Rp
+                // state of level lv before this cell: exclusive prefixes
+                double qup = 0.0, CE[OM];
+                for (int s2 = 0; s2 < OM; ++s2) CE[s2] = 0.0;
+                if (lv < M) {
+                    if (a > 0) {
+                        qup = slot(lv, 0, b);
+                        for (int s2 = 0; s2 < dp; ++s2) CE[s2] = slot(lv, 1 + s2, b);
+                    }
+                }
+                if (m <= M) {
+                    const int dc = m < order ? m : order;
+                    Rc[0][0] = dm * qd[lv - 1];                                               // Q_lv[a-1][b-1]
+                    for (int jj = 2; jj <= dc; ++jj) {
+                        Rc[0][jj - 1] = dm / jj * CE[jj - 2];
+                        Rc[jj - 1][0] = dm / jj * RE[lv - 1][jj - 2];
+                        for (int kk = 2; kk <= dc; ++kk) Rc[jj - 1][kk - 1] = dm / (double(jj) * kk) * Rp[jj - 2][kk - 2];
+                    }
+                    double tot = 0.0;
+                    for (int r = 0; r < dc; ++r)
+                        for (int s2 = 0; s2 < dc; ++s2) tot += Rc[r][s2];
+                    K[m] += tot;
+                }
+                // fold this cell of level lv into its prefixes (level lv + 1 has consumed the exclusive values)
+                if (lv < M) {
+                    double tot = 0.0;
+                    for (int r = 0; r < dp; ++r) {
+                        double rs = 0.0;
+                        for (int s2 = 0; s2 < dp; ++s2) rs += Rp[r][s2];
+                        RE[lv - 1][r] += rs;
+                        tot += rs;
+                    }
+                    for (int s2 = 0; s2 < dp; ++s2) {
+                        double cs = 0.0;
+                        for (int r = 0; r < dp; ++r) cs += Rp[r][s2];
+                        slot(lv, 1 + s2, b) = CE[s2] + cs;
+                    }
+                    sq[lv - 1] += tot;
+                    slot(lv, 0, b) = qup + sq[lv - 1];
+                    qd[lv - 1] = qup;
+                }
+                if (m <= M) {
+                    const int dc = m < order ? m : order;
+                    for (int r = 0; r < dc; ++r)
+                        for (int s2 = 0; s2 < dc; ++s2) Rp[r][s2] = Rc[r][s2];
+                    dp = dc;
+                }
+            }
+        }
+    }
+    if (!valid) return;
+    double* o = A.out + i * A.si + (A.diag ? 0 : j * A.sj);
+    o[0] = 1.0;
+    for (int m = 1; m <= M; ++m) o[m * A.sm] = K[m];
+}
+
 // levels (M1, N1, N2) -> out[i][j] = sum_m (lev + jitter_diag * [i == j]) * ax[i][m] * by[j][m]   (or per level)
 static __global__ void levels_epilogue_kernel(const double* __restrict__ lev, int64_t N1, int64_t N2, int M1, const double* __restrict__ ax,
                                        const double* __restrict__ by, double jitter_diag, int sum_levels, double* __restrict__ out) {

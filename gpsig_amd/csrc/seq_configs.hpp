@@ -47,7 +47,9 @@ struct SeqConfig {
 #define GPSIG_SEQ_HO_D4(X) GPSIG_SEQ_HO_SHAPES(X, 4)
 #define GPSIG_SEQ_HO_D8(X) GPSIG_SEQ_HO_SHAPES(X, 8)
 #define GPSIG_SEQ_HO_D16(X) GPSIG_SEQ_HO_SHAPES(X, 16)
-#define GPSIG_SEQ_HO_ALL(X) GPSIG_SEQ_HO_D4(X) GPSIG_SEQ_HO_D8(X) GPSIG_SEQ_HO_D16(X)
+// 32-wide state spaces: only the narrow lanes fit the register file
+#define GPSIG_SEQ_HO_D32(X) X(16, 2, 32, 6, 2) X(64, 1, 32, 8, 8) X(64, 2, 32, 6, 4)
+#define GPSIG_SEQ_HO_ALL(X) GPSIG_SEQ_HO_D4(X) GPSIG_SEQ_HO_D8(X) GPSIG_SEQ_HO_D16(X) GPSIG_SEQ_HO_D32(X)
 
 struct SeqHOConfig {
     int G, C, D, MMAX, OMAX;

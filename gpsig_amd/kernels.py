@@ -7,8 +7,8 @@ constrained values (``variances`` (M+1,), ``sigma`` scalar, ``lengthscales`` (d,
 every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CUDA-out (device
 pointers, asynchronous on the current stream).
 
-float32 inputs are computed in float32 (exact mode only).  Not built yet (raise NotImplementedError, never a silent
-fallback): ``SignatureSpectral`` in float32 / low-rank mode / with gradients; ``low_rank=True`` in float32.  Training (gradients): ``gpsig_amd.autodiff``.
+float32 inputs are computed in float32 where the float32 kernels are built, else by the float64 kernels and rounded.
+Not built (raise NotImplementedError, never a silent CPU fallback): ``SignatureSpectral`` in low-rank mode / with gradients.  Training (gradients): ``gpsig_amd.autodiff``.
 """
 import ctypes as C
 
@@ -73,6 +73,30 @@ class _Launch:
 
 def _shape(a):
     return tuple(a.shape)
+
+
+def _is_f32(a):
+    return a is not None and hasattr(a, "dtype") and str(a.dtype).endswith("float32")
+
+
+def _f32_upcast(method):
+    """float32 evaluations the float32 kernels are not built for (shapes beyond the wavefront kernels, the spectral kernel,
+    low-rank mode) are computed by the float64 kernels on the GPU and rounded to float32 -- never less accurate than asked for."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        try:
+            return method(self, *args, **kwargs)
+        except NotImplementedError:
+            arrays = [a for a in args if hasattr(a, "dtype") and hasattr(a, "shape")]
+            if not arrays or not all(_is_f32(a) for a in arrays):
+                raise
+            up = lambda a: (a.double() if _is_torch(a) else np.asarray(a, dtype=np.float64)) if _is_f32(a) else a   # noqa: E731
+            out = method(self, *[up(a) for a in args], **kwargs)
+            down = lambda o: o.float() if _is_torch(o) else np.asarray(o, dtype=np.float32)                          # noqa: E731
+            return tuple(down(o) for o in out) if isinstance(out, tuple) else down(out)
+    return wrapper
 
 
 class LowRankState:
@@ -247,6 +271,7 @@ class SignatureKernel:
         return shp[1]
 
     # ---- kernel evaluations ----------------------------------------------------------------------
+    @_f32_upcast
     def K(self, X, X2=None, presliced=False, return_levels=False, presliced_X=False, presliced_X2=False, lr_state=None):
         """Reference: kernels.py:401-476.  (N1, N2) or (M+1, N1, N2).  lr_state: low-rank mode only, the random
         objects to use (default: drawn afresh, as the reference does)."""
@@ -266,6 +291,7 @@ class SignatureKernel:
         L_.ctx.call("gpsig_kernel_K", p, L_.inp(X), L_.inp(X2), n1, n2, l1, l2, int(bool(return_levels)), optr)
         return out
 
+    @_f32_upcast
     def Kdiag(self, X, presliced=False, return_levels=False, lr_state=None):
         """Reference: kernels.py:479-510.  (N,) or (M+1, N)."""
         if not presliced:
@@ -286,6 +312,7 @@ class SignatureKernel:
         L_.ctx.call("gpsig_kernel_Kdiag", p, L_.inp(X), n, l, int(bool(return_levels)), optr)
         return out
 
+    @_f32_upcast
     def K_tens(self, Z, return_levels=False, increments=False, lr_state=None):
         """Reference: kernels.py:513-536.  (T, T) or (M+1, T, T); never normalised."""
         if self.low_rank:
@@ -304,6 +331,7 @@ class SignatureKernel:
         L_.ctx.call("gpsig_kernel_K_tens", p, L_.inp(Z), t, int(bool(increments)), int(bool(return_levels)), optr)
         return out
 
+    @_f32_upcast
     def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False, presliced=False, lr_state=None):
         """Reference: kernels.py:539-588.  (T, N) or (M+1, T, N); normalised on the sequence axis only."""
         if not presliced:
@@ -327,6 +355,7 @@ class SignatureKernel:
                     int(bool(return_levels)), optr)
         return out
 
+    @_f32_upcast
     def K_tens_n_seq_covs(self, Z, X, full_X_cov=False, return_levels=False, increments=False, presliced=False):
         """Reference: kernels.py:591-671.  Returns (Kzz, Kzx, Kxx); Kxx is the diagonal unless full_X_cov."""
         if not presliced:
@@ -355,6 +384,7 @@ class SignatureKernel:
                     int(bool(full_X_cov)), int(bool(return_levels)), pzz, pzx, pxx)
         return Kzz, Kzx, Kxx
 
+    @_f32_upcast
     def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False, presliced=False, lr_state=None):
         """Reference: kernels.py:674-761 (X = inducing sequences, X2 = data).  Returns (Kxx, Kxx2, Kx2x2).
         The double division of Kxx2 by the X-side diagonal in the diagonal-only branch (:713 + :750) is

@@ -409,24 +409,30 @@ def test_spectral_base_kernel(K, family):
                 assert relerr(g, w) <= TOL
     with pytest.raises(ValueError):
         K.SignatureSpectral(L * d, d, M, family="nope")
-    with pytest.raises(NotImplementedError):
-        k.K(X.astype(np.float32))
-    with pytest.raises(NotImplementedError):
-        K.SignatureSpectral(L * d, d, M, family=family, order=2).K(X)       # sequence-vs-sequence: first-order algorithm only
+    got32 = k.K(X.astype(np.float32))                    # no float32 spectral kernel: float64 kernels, rounded
+    assert got32.dtype == np.float32 and relerr32(got32, ko.K(X.astype(np.float32).astype(np.float64))) <= TOL32
+    k2 = K.SignatureSpectral(L * d, d, M, family=family, Q=Q, order=2, normalization=False)       # higher order: through the fallback too
+    k2.alpha, k2.omega, k2.gamma = k.alpha, k.omega, k.gamma
+    ko2 = O.SignatureKernelOracle(L * d, d, M, base="spectral", order=2, normalization=False, lengthscales=None,
+                                  base_params=dict(alpha=k.alpha, omega=k.omega, gamma=k.gamma, family=fam))
+    assert relerr(k2.K(X, X2), ko2.K(X, X2)) <= TOL
 
 
 def test_any_shape_fallback(K):
     """Shapes the wavefront kernel is not built for -- both sides longer than its column capacity, more than 32 state-space
     dimensions after lags -- go through the one-pair-per-thread fallback (float64, order 1) and must match the oracle too."""
     rng = np.random.default_rng(91)
-    cases = [("linear", 5, 4, 600, 2, 3, None, True), ("rbf", 4, 3, 530, 2, 3, None, True), ("matern32", 3, 3, 300, 12, 3, None, True),
-             ("rbf", 4, 4, 40, 20, 4, 1, True), ("linear", 4, 3, 140, 20, 3, None, False), ("mix", 3, 3, 30, 24, 3, 1, True)]
-    for base, N, N2, L, d, M, lags, norm in cases:
+    cases = [("linear", 5, 4, 600, 2, 3, None, True, 1), ("rbf", 4, 3, 530, 2, 3, None, True, 1), ("matern32", 3, 3, 300, 12, 3, None, True, 1),
+             ("rbf", 4, 4, 40, 20, 4, 1, True, 1), ("linear", 4, 3, 140, 20, 3, None, False, 1), ("mix", 3, 3, 30, 24, 3, 1, True, 1),
+             ("linear", 4, 3, 140, 3, 4, None, False, 4), ("rbf", 3, 3, 70, 2, 6, None, True, 6), ("matern52", 3, 2, 20, 24, 3, 1, True, 2),
+             ("linear", 3, 3, 540, 2, 3, None, True, 2)]
+    for base, N, N2, L, d, M, lags, norm, order in cases:
         X = np.cumsum(0.05 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
         X2 = np.cumsum(0.05 * rng.standard_normal((N2, L, d)), axis=1).reshape(N2, -1)
-        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, num_lags=lags, normalization=norm, lengthscales=0.8 + 0.4 * rng.random(d))
+        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, num_lags=lags, normalization=norm, lengthscales=0.8 + 0.4 * rng.random(d),
+                  order=order)
         kx, ko = make_kernel(K, kw), make_oracle(kw)
-        assert relerr(kx.K(X), ko.K(X)) <= TOL, (base, L, d)
+        assert relerr(kx.K(X), ko.K(X)) <= TOL, (base, L, d, order)
         assert relerr(kx.K(X, X2, return_levels=True), ko.K(X, X2, return_levels=True)) <= TOL
         assert relerr(kx.Kdiag(X), ko.Kdiag(X)) <= TOL
         Z = 0.3 * rng.standard_normal((M * (M + 1) // 2, 4, d * ((lags or 0) + 1)))
@@ -436,14 +442,10 @@ def test_any_shape_fallback(K):
 
 
 def test_unsupported_shapes_fail_loudly(K):
-    with pytest.raises(NotImplementedError, match="no higher-order seq-gram kernel shape"):
-        K.SignatureLinear(2 * 600, 2, 3, order=2).K(np.zeros((2, 1200)))   # 600 rows on the register side, order 2: no fallback
-    with pytest.raises(NotImplementedError):
-        K.SignatureLinear(2 * 600, 2, 3).K(np.zeros((2, 1200), dtype=np.float32))   # the fallback is float64 only
+    assert K.SignatureLinear(2 * 600, 2, 3, order=2).K(np.zeros((2, 1200), dtype=np.float32)).dtype == np.float32   # float64 fallback, rounded
     with pytest.raises(NotImplementedError):
         K.SignatureLinear(40 * 5, 40, 3).K(np.zeros((2, 200)))             # more than 32 features per lag copy
-    with pytest.raises(NotImplementedError):
-        K.SignatureRBF(12, 3, 3, low_rank=True, num_components=4).K(np.zeros((4, 12), dtype=np.float32))   # low-rank is float64 only
+    assert K.SignatureRBF(12, 3, 3, low_rank=True, num_components=4).K(np.zeros((4, 12), dtype=np.float32)).dtype == np.float32   # via float64
     with pytest.raises(ValueError):
         K.SignatureLinear(12, 3, 3).K_tens(np.zeros((5, 4, 3)))            # lt must be 6
 

@@ -1,0 +1,91 @@
+"""Randomised parity sweep of the evaluation path against the CPU oracle (run on a GPU box):
+    python tools/fuzz_parity.py [cases] [seed]
+Draws kernel families, orders, flags, dtypes and ragged shapes at random and reports every case whose relative error exceeds
+the tolerance (float64 1e-6, float32 1e-4 on the matrix scale)."""
+import os, sys, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gpsig_amd import kernels as K
+from oracle import sigkern_oracle as O
+
+CLASS = {"linear": K.SignatureLinear, "rbf": K.SignatureRBF, "cosine": K.SignatureCosine, "poly": K.SignaturePoly, "mix": K.SignatureMix,
+         "matern12": K.SignatureMatern12, "matern32": K.SignatureMatern32, "matern52": K.SignatureMatern52}
+
+
+def relerr(got, want, f32):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want)
+    if f32:
+        return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-300))
+    return float(np.max(np.abs(got - want) / (np.abs(want) + 1e-6 * np.abs(want).max() + 1e-300)))
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    for it in range(cases):
+        base = rng.choice(list(CLASS))
+        M = int(rng.integers(1, 7))
+        order = int(rng.choice([1, 1, 1, 2, 3, M]))
+        d = int(rng.choice([1, 2, 3, 5, 8, 11, 16, 20]))
+        lags = int(rng.choice([0, 0, 0, 1, 2])) if base != "poly" else 0
+        L1, L2 = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 130])), int(rng.choice([1, 2, 5, 17, 32, 65, 90]))
+        N1, N2 = int(rng.integers(1, 40)), int(rng.integers(1, 20))
+        norm, diff = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) > 0)
+        f32 = bool(rng.integers(0, 5) == 0)
+        if (L1 == 1 or L2 == 1) and diff:
+            L1, L2 = max(L1, 2), max(L2, 2)
+        if lags and min(L1, L2) < 3:
+            lags = 0
+        kw = dict(num_levels=M, order=order, normalization=norm, difference=diff, num_lags=lags or None,
+                  lengthscales=rng.uniform(0.7, 1.6, d), variances=rng.uniform(0.5, 1.5, M + 1))
+        desc = dict(base=base, M=M, order=order, d=d, lags=lags, L1=L1, L2=L2, N1=N1, N2=N2, norm=norm, diff=diff, f32=f32)
+        try:
+            scale = 0.3 / np.sqrt(d)
+            X = np.cumsum(scale * rng.standard_normal((N1, L1, d)), axis=1).reshape(N1, -1)
+            X2 = np.cumsum(scale * rng.standard_normal((N2, L2, d)), axis=1).reshape(N2, -1)
+            if base == "cosine":
+                X, X2 = X + 1.0, X2 + 1.0
+            dt = np.float32 if f32 else np.float64
+            lt = M * (M + 1) // 2
+            incr = bool(rng.integers(0, 2))
+            T = int(rng.integers(1, 9))
+            de = d * (lags + 1)
+            Z = 0.5 * rng.standard_normal((lt, T, 2, de) if incr else (lt, T, de)) + (1.0 if base == "cosine" else 0.0)
+            kx1 = CLASS[base](L1 * d, d, **kw)
+            ko1 = O.SignatureKernelOracle(L1 * d, d, base=base, **kw, base_params=({"gamma": 1.0, "degree": 3.0} if base == "poly" else None))
+            ko1.input_dim = L1 * d
+            Xq, X2q, Zq = X.astype(dt), X2.astype(dt), Z.astype(dt)
+            Xo, X2o, Zo = Xq.astype(np.float64), X2q.astype(np.float64), Zq.astype(np.float64)
+            tol = 1e-4 if f32 else 1e-6
+            checks = [("K", lambda: kx1.K(Xq), lambda: ko1.K(Xo)), ("Kdiag", lambda: kx1.Kdiag(Xq), lambda: ko1.Kdiag(Xo)),
+                      ("Kzx", lambda: kx1.K_tens_vs_seq(Zq, Xq, increments=incr), lambda: ko1.K_tens_vs_seq(Zo, Xo, increments=incr)),
+                      ("Kzz", lambda: kx1.K_tens(Zq, increments=incr), lambda: ko1.K_tens(Zo, increments=incr)),
+                      ("Kx", lambda: kx1.K(Xq, X2q, presliced=True), lambda: ko1.K(Xo, X2o) if L1 == L2 else _cross(ko1, Xo, X2o, d))]
+            for name, g, w in checks:
+                try:
+                    got = g()
+                except NotImplementedError as e:
+                    print(f"[{it}] {name}: NotImplementedError ({str(e)[:90]}) {desc}")
+                    continue
+                err = relerr(got, w(), f32)
+                if not (err <= tol):
+                    bad += 1
+                    print(f"[{it}] {name}: rel.err {err:.3e} > {tol}  {desc} incr={incr} T={T}")
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.savez(f"gpurun_out/fuzz_fail_{it}_{name}.npz", X=Xo, X2=X2o, Z=Zo, got=np.asarray(got, dtype=np.float64), want=w(),
+                             ls=kw["lengthscales"], var=kw["variances"], desc=str(desc), incr=incr)
+        except Exception:
+            bad += 1
+            print(f"[{it}] EXCEPTION {desc}")
+            traceback.print_exc()
+    print(f"fuzz: {cases} cases, {bad} failures")
+
+
+def _cross(ko, X, X2, d):
+    # the oracle class reshapes by num_features, so ragged lengths just work
+    return ko.K(X, X2)
+
+
+if __name__ == "__main__":
+    main()
