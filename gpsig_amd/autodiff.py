@@ -283,8 +283,9 @@ class SignatureKernelModule(torch.nn.Module):
         return k
 
     # ---- scaling -------------------------------------------------------------------------------------------------
-    def _seq3(self, X):
-        X, _ = self.kern._slice(X, None)
+    def _seq3(self, X, presliced=False):
+        if not presliced:
+            X, _ = self.kern._slice(X, None)                                                        # GPflow Kernel._slice (kernels.py:411-415)
         return X.reshape(X.shape[0], -1, self.kern.num_features)                                    # kernels.py:417-418
 
     def scale_sequences(self, X):
@@ -321,9 +322,9 @@ class SignatureKernelModule(torch.nn.Module):
         return self.sigma * self.variances                                                          # kernels.py:471
 
     # ---- kernel evaluations ----------------------------------------------------------------------------------------
-    def K(self, X, X2=None, return_levels=False):
+    def K(self, X, X2=None, presliced=False, return_levels=False, presliced_X=False, presliced_X2=False):
         """kernels.py:401-476."""
-        Xs = self.scale_sequences(self._seq3(X))
+        Xs = self.scale_sequences(self._seq3(X, presliced or presliced_X))
         N = Xs.shape[0]
         if X2 is None:
             K = self._seq_levels(Xs)
@@ -332,7 +333,7 @@ class SignatureKernelModule(torch.nn.Module):
                 dsq = torch.sqrt(torch.diagonal(K, dim1=1, dim2=2))                                 # :432
                 K = K / (dsq[:, :, None] * dsq[:, None, :])                                         # :433
         else:
-            X2s = self.scale_sequences(self._seq3(X2))
+            X2s = self.scale_sequences(self._seq3(X2, presliced or presliced_X2))
             K = self._seq_levels(Xs, X2s)
             if self.kern.normalization:
                 d1 = torch.sqrt(self._diag_levels(Xs) + JITTER)                                     # :460-466
@@ -341,13 +342,13 @@ class SignatureKernelModule(torch.nn.Module):
         K = K * self._w()[:, None, None]
         return K if return_levels else K.sum(dim=0)
 
-    def Kdiag(self, X, return_levels=False):
+    def Kdiag(self, X, presliced=False, return_levels=False):
         """kernels.py:479-510."""
         N = X.shape[0]
         if self.kern.normalization:
             Kd = self._w()[:, None].expand(-1, N)                                                   # :486-490
         else:
-            Kd = self._diag_levels(self.scale_sequences(self._seq3(X))) * self._w()[:, None]
+            Kd = self._diag_levels(self.scale_sequences(self._seq3(X, presliced))) * self._w()[:, None]
         return Kd if return_levels else Kd.sum(dim=0)
 
     def K_tens(self, Z, return_levels=False, increments=False):
@@ -355,18 +356,18 @@ class SignatureKernelModule(torch.nn.Module):
         K = self._tens_levels(self.scale_tensors(Z), increments) * self._w()[:, None, None]
         return K if return_levels else K.sum(dim=0)
 
-    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False):
+    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False, presliced=False):
         """kernels.py:539-588."""
-        Xs = self.scale_sequences(self._seq3(X))
+        Xs = self.scale_sequences(self._seq3(X, presliced))
         K = self._tvs_levels(self.scale_tensors(Z), Xs, increments)
         if self.kern.normalization:
             K = K / torch.sqrt(self._diag_levels(Xs) + JITTER)[:, None, :]                          # :576-581
         K = K * self._w()[:, None, None]
         return K if return_levels else K.sum(dim=0)
 
-    def K_tens_n_seq_covs(self, Z, X, full_X_cov=False, return_levels=False, increments=False):
+    def K_tens_n_seq_covs(self, Z, X, full_X_cov=False, return_levels=False, increments=False, presliced=False):
         """kernels.py:591-671: Kzz, Kzx and Kxx (full or diagonal) from one scaling of the inputs."""
-        Xs = self.scale_sequences(self._seq3(X))
+        Xs = self.scale_sequences(self._seq3(X, presliced))
         N = Xs.shape[0]
         Zs = self.scale_tensors(Z)
         Kzz = self._tens_levels(Zs, increments)                                                     # :623
@@ -393,10 +394,11 @@ class SignatureKernelModule(torch.nn.Module):
             return Kzz, Kzx, Kxx
         return Kzz.sum(dim=0), Kzx.sum(dim=0), Kxx.sum(dim=0)
 
-    def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False):
-        """kernels.py:674-761 (``X`` = inducing sequences, ``X2`` = data), including the double division of :713 + :750."""
-        Xs = self.scale_sequences(self._seq3(X))
-        X2s = self.scale_sequences(self._seq3(X2))
+    def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False, presliced=False):
+        """kernels.py:674-761 (``X`` = inducing sequences, never sliced: :679-680; ``X2`` = data), including the double division
+        of :713 + :750."""
+        Xs = self.scale_sequences(self._seq3(X, True))
+        X2s = self.scale_sequences(self._seq3(X2, presliced))
         N, N2 = Xs.shape[0], X2s.shape[0]
         w = self._w()
         Kxx = self._seq_levels(Xs)
