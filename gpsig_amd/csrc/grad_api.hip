@@ -116,13 +116,15 @@ int launch_tvs_lanet(gpsig_ctx* c, int DP, bool paired, dim3 grid, const TvsLane
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
 }
-// row-owned variant (registers bound it to num_levels <= 4, DP <= 8)
-bool tens_row_available(int DP, int M) { return M <= 4 && DP <= 8; }
+// row-owned variant: every shape
 int launch_tens_row(gpsig_ctx* c, int DP, int E, dim3 grid, const TensGradArgs& a) {
-    if (DP == 4 && E == 1) hipLaunchKernelGGL((tens_row_grad_kernel<4, 4, 1>), grid, dim3(64), 0, c->stream, a);
-    else if (DP == 4) hipLaunchKernelGGL((tens_row_grad_kernel<4, 4, 2>), grid, dim3(64), 0, c->stream, a);
-    else if (E == 1) hipLaunchKernelGGL((tens_row_grad_kernel<8, 4, 1>), grid, dim3(64), 0, c->stream, a);
-    else hipLaunchKernelGGL((tens_row_grad_kernel<8, 4, 2>), grid, dim3(64), 0, c->stream, a);
+#define TROW(DP_)                                                                                                     \
+    do {                                                                                                             \
+        if (E == 1) hipLaunchKernelGGL((tens_row_grad_kernel<DP_, 1>), grid, dim3(64), 0, c->stream, a);             \
+        else hipLaunchKernelGGL((tens_row_grad_kernel<DP_, 2>), grid, dim3(64), 0, c->stream, a);                    \
+    } while (0)
+    if (DP == 4) TROW(4); else if (DP == 8) TROW(8); else if (DP == 16) TROW(16); else TROW(32);
+#undef TROW
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
 }
@@ -478,7 +480,7 @@ int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void*
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         A.G = static_cast<const double*>(dG); A.gm = T * T; A.gt = T; A.gn = 1;
         A.gbase = dgb;
-        if (c->grad_impl == 0 && tens_row_available(DP, M)) {
+        if (c->grad_impl == 0) {
             const int64_t tb = (T + 63) / 64;
             int64_t slices = (1024 + tb - 1) / tb;
             if (slices > T) slices = T;

@@ -914,9 +914,11 @@ struct TensPairGrad {
 
 // Row-owned variant: thread = inducing tensor t (and a slice of the partners t2).  Kzz's level products are symmetric under
 // t <-> t2, so  d/dz_t sum G[t][t2] F(t, t2) = sum_t2 (G[t][t2] + G[t2][t]) d_1 F(t, t2):  only derivatives with respect to the
-// FIRST argument are needed, they accumulate in registers level by level, and each thread ends with i * E * DP atomics
-// instead of one wavefront reduction per (component, point, feature, partner).
-template <int DP, int MMAX, int E>
+// FIRST argument are needed and they accumulate in registers, one component at a time (the other components' kernel values
+// are re-evaluated per component -- i times more kernel evaluations on a T x T problem, in exchange for E * DP accumulators
+// instead of i * E * DP), so each thread ends with lt * E * DP atomics instead of one wavefront reduction per
+// (component, point, feature, partner).
+template <int DP, int E>
 struct TensRowGrad {
     const TensGradArgs& A;
     int t;
@@ -924,83 +926,70 @@ struct TensRowGrad {
 
     GPSIG_HD TensRowGrad(const TensGradArgs& a, int t_, bool valid_) : A(a), t(t_), valid(valid_) {}
     GPSIG_HD const double* zptr(int k, int tt, int e) const { return A.z + ((int64_t(k) * A.T + tt) * E + e) * DP; }
+    // Mz_k(t, t2): kappa for E == 1, the double increment of kernels.py:277 for E == 2
+    GPSIG_HD double mz(int k, int t2) const {
+        double mv = 0.0;
+#pragma unroll
+        for (int a = 0; a < E; ++a)
+#pragma unroll
+            for (int b = 0; b < E; ++b) {
+                const double* za = zptr(k, t, a);
+                const double* zb = zptr(k, t2, b);
+                double in = 0.0, as = 0.0, bs = 0.0;
+#pragma unroll
+                for (int f = 0; f < DP; ++f) { in = fma(za[f], zb[f], in); as = fma(za[f], za[f], as); bs = fma(zb[f], zb[f], bs); }
+                mv += (a == b ? 1.0 : -1.0) * base_eval<double>(A.kind, in, as, bs, A.p0, A.p1);
+            }
+        return mv;
+    }
     // slices: partners t2 = slice, slice + nslices, ...
     GPSIG_HD void run(int slice, int nslices) const {
         int k0 = 0;
         double gp0 = 0.0;
         for (int i = 1; i <= A.M; ++i) {
-            double za[MMAX][E][DP], zas[MMAX][E], acc[MMAX][E][DP];
-#pragma unroll
-            for (int j = 0; j < MMAX; ++j)
+            for (int j = 0; j < i; ++j) {
+                double za[E][DP], zas[E], acc[E][DP];
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     double s = 0.0;
 #pragma unroll
                     for (int f = 0; f < DP; ++f) {
-                        const double v = j < i ? zptr(k0 + j, t, e)[f] : 0.0;
-                        za[j][e][f] = v;
-                        acc[j][e][f] = 0.0;
-                        s = fma(v, v, s);
+                        za[e][f] = zptr(k0 + j, t, e)[f];
+                        acc[e][f] = 0.0;
+                        s = fma(za[e][f], za[e][f], s);
                     }
-                    zas[j][e] = s;
+                    zas[e] = s;
                 }
-            for (int t2 = slice; t2 < A.T; t2 += nslices) {
-                const double g12 = valid ? A.G[i * A.gm + t * A.gt + t2 * A.gn] : 0.0;
-                const double c = g12 + (valid ? A.G[i * A.gm + t2 * A.gt + t * A.gn] : 0.0);
-                // m[j] = Mz_{k0+j}(t, t2) and, per (point of t, point of t2), the derivative coefficients with respect to z_t
-                double m[MMAX];
-                BaseGrad bg[MMAX][E][E];
+                for (int t2 = slice; t2 < A.T; t2 += nslices) {
+                    const double g12 = valid ? A.G[i * A.gm + t * A.gt + t2 * A.gn] : 0.0;
+                    const double c = g12 + (valid ? A.G[i * A.gm + t2 * A.gt + t * A.gn] : 0.0);
+                    double others = 1.0;
+                    for (int q = 0; q < i; ++q)
+                        if (q != j) others *= mz(k0 + q, t2);
 #pragma unroll
-                for (int j = 0; j < MMAX; ++j) {
-                    m[j] = 1.0;
-                    if (j < i) {
-                        double mv = 0.0;
+                    for (int a = 0; a < E; ++a)
 #pragma unroll
-                        for (int a = 0; a < E; ++a)
+                        for (int b = 0; b < E; ++b) {
+                            const double* zb = zptr(k0 + j, t2, b);
+                            double in = 0.0, bs = 0.0;
 #pragma unroll
-                            for (int b = 0; b < E; ++b) {
-                                const double* zb = zptr(k0 + j, t2, b);
-                                double in = 0.0, bs = 0.0;
+                            for (int f = 0; f < DP; ++f) { in = fma(za[a][f], zb[f], in); bs = fma(zb[f], zb[f], bs); }
+                            const BaseGrad g = base_eval_grad(A.kind, in, zas[a], bs, A.p0, A.p1);
+                            const double sg = (a == b ? 1.0 : -1.0);
+                            gp0 = fma(g12 * others * sg, g.dp0, gp0);
+                            const double w = c * others * sg;
+                            const double wy = w * (g.cy - g.cd), wx = w * (g.cx + g.cd);     // d kappa/dx = (cy - cd) y + (cx + cd) x
 #pragma unroll
-                                for (int f = 0; f < DP; ++f) { in = fma(za[j][a][f], zb[f], in); bs = fma(zb[f], zb[f], bs); }
-                                bg[j][a][b] = base_eval_grad(A.kind, in, zas[j][a], bs, A.p0, A.p1);
-                                mv += (a == b ? 1.0 : -1.0) * bg[j][a][b].k;        // kernels.py:277 (E == 1: the single term)
-                            }
-                        m[j] = mv;
-                    }
+                            for (int f = 0; f < DP; ++f) acc[a][f] = fma(wy, zb[f], fma(wx, za[a][f], acc[a][f]));
+                        }
                 }
 #pragma unroll
-                for (int j = 0; j < MMAX; ++j)
-                    if (j < i) {
-                        double others = 1.0;
+                for (int e = 0; e < E; ++e) {
+                    double* gz = A.gz + ((int64_t(k0 + j) * A.T + t) * E + e) * DP;
 #pragma unroll
-                        for (int q = 0; q < MMAX; ++q)
-                            if (q != j) others *= m[q];
-#pragma unroll
-                        for (int a = 0; a < E; ++a)
-#pragma unroll
-                            for (int b = 0; b < E; ++b) {
-                                const double sg = (a == b ? 1.0 : -1.0);
-                                const BaseGrad& g = bg[j][a][b];
-                                gp0 = fma(g12 * others * sg, g.dp0, gp0);
-                                const double w = c * others * sg;
-                                const double* zb = zptr(k0 + j, t2, b);
-                                const double wy = w * (g.cy - g.cd), wx = w * (g.cx + g.cd);     // d kappa/dx = (cy - cd) y + (cx + cd) x
-#pragma unroll
-                                for (int f = 0; f < DP; ++f) acc[j][a][f] = fma(wy, zb[f], fma(wx, za[j][a][f], acc[j][a][f]));
-                            }
-                    }
+                    for (int f = 0; f < DP; ++f) grad_add(&gz[f], acc[e][f], false, valid);
+                }
             }
-#pragma unroll
-            for (int j = 0; j < MMAX; ++j)
-                if (j < i) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        double* gz = A.gz + ((int64_t(k0 + j) * A.T + t) * E + e) * DP;
-#pragma unroll
-                        for (int f = 0; f < DP; ++f) grad_add(&gz[f], acc[j][e][f], false, valid);
-                    }
-                }
             k0 += i;
         }
         if (A.gbase) grad_add(&A.gbase[0], gp0, true, valid);

@@ -258,11 +258,11 @@ __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradAr
 }
 
 // row-owned tensor-vs-tensor gradient: grid (ceil(T / 64), slices); block 64: lanes = t
-template <int DP, int MMAX, int E>
+template <int DP, int E>
 __global__ void __launch_bounds__(64) tens_row_grad_kernel(const TensGradArgs A) {
     const int t = blockIdx.x * 64 + threadIdx.x;
     const bool valid = t < A.T;
-    TensRowGrad<DP, MMAX, E>(A, valid ? t : 0, valid).run(blockIdx.y, gridDim.y);
+    TensRowGrad<DP, E>(A, valid ? t : 0, valid).run(blockIdx.y, gridDim.y);
 }
 
 // grid (ceil(T / 64), T); block 64: lanes = t2, blockIdx.y = t

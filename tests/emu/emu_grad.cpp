@@ -164,13 +164,16 @@ int emu_tens_grad(const double* Z, int T, int d, int M, int kind, int incr, doub
     A.G = G; A.gm = int64_t(T) * T; A.gt = T; A.gn = 1;
     A.gbase = gb;
     if (row_owned) {
-        if (M > 4 || DP > 8) return -2;
         for (int sl = 0; sl < 3; ++sl)
             for (int t = 0; t < T; ++t) {
-                if (DP == 4 && E == 1) TensRowGrad<4, 4, 1>(A, t, true).run(sl, 3);
-                else if (DP == 4) TensRowGrad<4, 4, 2>(A, t, true).run(sl, 3);
-                else if (E == 1) TensRowGrad<8, 4, 1>(A, t, true).run(sl, 3);
-                else TensRowGrad<8, 4, 2>(A, t, true).run(sl, 3);
+                if (DP == 4 && E == 1) TensRowGrad<4, 1>(A, t, true).run(sl, 3);
+                else if (DP == 4) TensRowGrad<4, 2>(A, t, true).run(sl, 3);
+                else if (DP == 8 && E == 1) TensRowGrad<8, 1>(A, t, true).run(sl, 3);
+                else if (DP == 8) TensRowGrad<8, 2>(A, t, true).run(sl, 3);
+                else if (DP == 16 && E == 1) TensRowGrad<16, 1>(A, t, true).run(sl, 3);
+                else if (DP == 16) TensRowGrad<16, 2>(A, t, true).run(sl, 3);
+                else if (E == 1) TensRowGrad<32, 1>(A, t, true).run(sl, 3);
+                else TensRowGrad<32, 2>(A, t, true).run(sl, 3);
             }
     } else switch (DP) {
         case 4: tens_run<4>(A); break;

@@ -8,7 +8,7 @@ base = sys.argv[1] if len(sys.argv) > 1 else "linear"
 X = torch.as_tensor(np.random.default_rng(0).standard_normal((N, L * D)), device="cuda:0")
 kern = (kernels.SignatureLinear if base == "linear" else kernels.SignatureRBF)(L * D, D, M, lengthscales=1.0 if base == "linear" else D ** 0.5)
 ctx = _lib.context(0, torch.cuda.current_stream().cuda_stream)
-for opts in ([("glds", 0)], [("glds", 1)], [("glds", 1), ("max_run", 64)], [("glds", 1), ("max_run", 16)]):
+for opts in ([("glds", 0)], [("glds", 1)], [("glds", 1), ("max_run", 256)], [("glds", 1), ("max_run", 128)], [("glds", 1), ("max_run", 64)], [("glds", 1), ("max_run", 32)], [("glds", 1), ("max_run", 16)]):
     for k, v in (("glds", 0), ("max_run", 0)): ctx.set_option(k, v)
     for k, v in opts: ctx.set_option(k, v)
     kern.K(X); torch.cuda.synchronize()
