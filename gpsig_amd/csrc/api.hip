@@ -212,8 +212,12 @@ int upload_weights(gpsig_ctx* c, const gpsig_params* p, const double** w) {
     for (int m = 0; m < M1; ++m) h[m] = p->sigma * p->variances[m];
     void* d;
     CHK(ensure(c, B_W, sizeof(double) * M1, &d));
-    HIPCHK(c, hipMemcpyAsync(d, h.data(), sizeof(double) * M1, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // h goes out of scope
+    if (c->last_weights != h) {          // unchanged hyper-parameters: the device copy is still right
+        c->last_weights.clear();
+        HIPCHK(c, hipMemcpyAsync(d, h.data(), sizeof(double) * M1, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // h goes out of scope
+        c->last_weights = h;
+    }
     *w = static_cast<const double*>(d);
     return GPSIG_OK;
 }
@@ -412,14 +416,28 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     if (max_run < 8) max_run = 8;
     if (max_run > 256) max_run = 256;
     if (c->max_run > 0) max_run = c->max_run;
-    c->host_tasks = seq_build_tasks(r.N1, r.N2, ypb, r.pred, int(max_run), c->shard_i, c->shard_n, r.y_begin,
-                                    r.y_end > 0 ? r.y_end : -1);
-    const int ntasks = int(c->host_tasks.size());
+    // the task list is a function of these integers only: reuse the device copy while they stay the same
+    const int64_t key[10] = {r.N1, r.N2, ypb, r.pred, max_run, c->shard_i, c->shard_n, r.y_begin, r.y_end > 0 ? r.y_end : -1, 1};
+    TaskCache& tc = r.pred == PRED_DIAG ? c->tc_diag : c->tc_main;
+    const int tbuf = r.pred == PRED_DIAG ? B_TASKS_DIAG : B_TASKS;
+    void* dt = nullptr;
+    int ntasks;
+    if (tc.match(key) && c->buf[tbuf].p) {
+        dt = c->buf[tbuf].p;
+        ntasks = tc.ntasks;
+    } else {
+        tc.valid = false;
+        c->host_tasks = seq_build_tasks(r.N1, r.N2, ypb, r.pred, int(max_run), c->shard_i, c->shard_n, r.y_begin,
+                                        r.y_end > 0 ? r.y_end : -1);
+        ntasks = int(c->host_tasks.size());
+        if (ntasks > 0) {
+            CHK(ensure(c, tbuf, sizeof(SeqTask) * size_t(ntasks), &dt));
+            HIPCHK(c, hipMemcpyAsync(dt, c->host_tasks.data(), sizeof(SeqTask) * size_t(ntasks), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // host_tasks is pageable and reused by the next launch
+        }
+        tc.set(key, ntasks);
+    }
     if (ntasks == 0) return GPSIG_OK;
-    void* dt;
-    CHK(ensure(c, B_TASKS, sizeof(SeqTask) * size_t(ntasks), &dt));
-    HIPCHK(c, hipMemcpyAsync(dt, c->host_tasks.data(), sizeof(SeqTask) * size_t(ntasks), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // host_tasks is pageable and reused by the next launch
 
     SeqGramArgs A;
     memset(&A, 0, sizeof(A));

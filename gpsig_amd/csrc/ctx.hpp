@@ -29,10 +29,25 @@ enum BufId {
     B_LR0, B_LR1, B_LR2, B_LR3, B_LR4, B_LR5, B_LR6, B_LR7, B_LR8,
     B_GR0, B_GR1, B_GR2, B_GR3, B_GR4, B_GR5, B_GR6, B_GR7,   // gradient path scratch
     B_SPEC,                                                    // spectral base-kernel table
+    B_TASKS_DIAG, B_TASKS_W2A, B_TASKS_W2B,                    // task lists that stay valid across calls (see TaskCache)
     B_COUNT
 };
 
 inline thread_local std::string g_create_error;
+
+// A task list depends only on a handful of integers; the device copy is reused while they do not change (no host rebuild, no
+// upload, no host-device synchronisation per call).
+struct TaskCache {
+    int64_t key[10] = {0};
+    int ntasks = 0;
+    bool valid = false;
+    bool match(const int64_t (&k)[10]) const {
+        if (!valid) return false;
+        for (int i = 0; i < 10; ++i) if (key[i] != k[i]) return false;
+        return true;
+    }
+    void set(const int64_t (&k)[10], int n) { for (int i = 0; i < 10; ++i) key[i] = k[i]; ntasks = n; valid = true; }
+};
 
 struct gpsig_ctx {
     int device = 0;
@@ -50,6 +65,9 @@ struct gpsig_ctx {
     std::string err;
     DevBuf buf[B_COUNT];
     std::vector<gpsig::SeqTask> host_tasks;
+    TaskCache tc_main, tc_diag, tc_w2a, tc_w2b;
+    int w2_flip = 0;
+    std::vector<double> last_weights;      // what B_W currently holds
     // timing of the pair-recursion launches
     std::vector<hipEvent_t> ev;     // pairs (start, stop)
     size_t ev_used = 0;

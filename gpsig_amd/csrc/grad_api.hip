@@ -269,24 +269,40 @@ int wave2_side(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, int
     int64_t run = diag ? 1 : (NS * NR + 16383) / 16384;
     if (run < 1) run = 1;
     if (run > NS) run = NS;
-    std::vector<SeqTask>& T = c->host_tasks;
-    T.clear();
-    for (int64_t r = 0; r < NR; ++r) {
-        if (diag) { T.push_back(SeqTask{int32_t(r), int32_t(r), 1}); continue; }
-        for (int64_t x0 = 0; x0 < NS; x0 += run) T.push_back(SeqTask{int32_t(r), int32_t(x0), int32_t(NS - x0 < run ? NS - x0 : run)});
-    }
+    // two cached task lists: a cross Gram alternates between its two sides
+    const int64_t key[10] = {NS, NR, run, diag ? 1 : 0, 0, 0, 0, 0, 0, 2};
+    TaskCache* tc = c->tc_w2a.match(key) ? &c->tc_w2a : (c->tc_w2b.match(key) ? &c->tc_w2b : nullptr);
+    int tbuf = tc == &c->tc_w2a ? B_TASKS_W2A : B_TASKS_W2B;
     void* dt;
-    CHK(ensure(c, B_TASKS, sizeof(SeqTask) * T.size() + 64, &dt));
-    HIPCHK(c, hipMemcpyAsync(dt, T.data(), sizeof(SeqTask) * T.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));         // host_tasks is reused by the next call
+    size_t ntasks;
+    if (tc && c->buf[tbuf].p) {
+        dt = c->buf[tbuf].p;
+        ntasks = size_t(tc->ntasks);
+    } else {
+        c->w2_flip ^= 1;
+        tc = c->w2_flip ? &c->tc_w2a : &c->tc_w2b;
+        tbuf = c->w2_flip ? B_TASKS_W2A : B_TASKS_W2B;
+        tc->valid = false;
+        std::vector<SeqTask>& T = c->host_tasks;
+        T.clear();
+        for (int64_t r = 0; r < NR; ++r) {
+            if (diag) { T.push_back(SeqTask{int32_t(r), int32_t(r), 1}); continue; }
+            for (int64_t x0 = 0; x0 < NS; x0 += run) T.push_back(SeqTask{int32_t(r), int32_t(x0), int32_t(NS - x0 < run ? NS - x0 : run)});
+        }
+        ntasks = T.size();
+        CHK(ensure(c, tbuf, sizeof(SeqTask) * ntasks + 64, &dt));
+        HIPCHK(c, hipMemcpyAsync(dt, T.data(), sizeof(SeqTask) * ntasks, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));         // host_tasks is reused by the next call
+        tc->set(key, int(ntasks));
+    }
     Wave2Args A;
     memset(&A, 0, sizeof(A));
     A.S = S; A.R = R; A.gR = gR; A.NS = int(NS); A.NR = int(NR); A.LS = LS; A.LR = LR; A.d = d;
     A.M = M; A.kind = p->base_kernel; A.mode = mode; A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
-    A.tasks = static_cast<const SeqTask*>(dt); A.ntasks = int(T.size());
+    A.tasks = static_cast<const SeqTask*>(dt); A.ntasks = int(ntasks);
     A.G = Gup; A.gm = gm; A.gs = gs; A.gr = gr; A.gsym = gsym ? 1 : 0; A.gscale = gscale;
     A.gbase = gbase; A.gbase_scale = gbase_scale;
-    const int nblocks = int((T.size() + PW - 1) / PW);
+    const int nblocks = int((ntasks + PW - 1) / PW);
     const size_t lds = sizeof(double) * size_t(PW) * size_t(R1 > 0 ? R1 : 1) * size_t(M - 1 <= 4 ? 4 : 7);
     hipError_t e = fn(A, nblocks, lds, c->stream);
     if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_wave2_kernel launch failed: %s", hipGetErrorString(e));
