@@ -17,6 +17,8 @@ typedef hipError_t (*Wave2LaunchFn)(const Wave2Args&, int, size_t, hipStream_t);
 Wave2LaunchFn wave2_lookup_inc(int G, int C, int DP, int LQ);
 Wave2LaunchFn wave2_lookup_ptd(int G, int C, int DP, int LQ);
 Wave2LaunchFn wave2_lookup_ptn(int G, int C, int DP, int LQ);
+Wave2LaunchFn lam_undo_lookup_ptd(int G, int C, int DP, int LQ);
+Wave2LaunchFn lam_undo_lookup_ptn(int G, int C, int DP, int LQ);
 }  // namespace gpsig
 
 using namespace gpsig;
@@ -169,6 +171,9 @@ WaveLaunchFn wave_plan(int mode, int R2, int DP, int M, int* G, int* C) {
     return nullptr;
 }
 
+// workgroups of lam_contract_kernel: the partner loop waits on its Lam loads, so the launch is sized for several wavefronts per SIMD
+constexpr int64_t CONTRACT_BLOCKS = 16384;
+
 template <int SIDE>
 int launch_contract(gpsig_ctx* c, int DP, dim3 grid, int block, size_t lds, const LamContractArgs& a) {
     switch (DP) {
@@ -221,7 +226,7 @@ int seq_grad_wave(gpsig_ctx* c, const gpsig_params* p, WaveLaunchFn fn, int G, i
         if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_wave_kernel launch failed: %s", hipGetErrorString(e));
         K.i0 = i0; K.ni = ni;
         auto slices = [](int64_t targets, int64_t partners) {
-            int64_t s = (2048 + targets - 1) / targets;
+            int64_t s = (CONTRACT_BLOCKS + targets - 1) / targets;
             if (s > partners) s = partners;
             if (s > 1024) s = 1024;
             return s < 1 ? int64_t(1) : s;
@@ -230,12 +235,12 @@ int seq_grad_wave(gpsig_ctx* c, const gpsig_params* p, WaveLaunchFn fn, int G, i
         K.gT = gX; K.gbase = gbase;
         K.nslices = int(diag ? 1 : slices(ni, N2));
         int blk = L1 >= 256 ? 256 : int((L1 + 63) / 64 * 64);
-        CHK(launch_contract<0>(c, DP, dim3(unsigned(ni), unsigned(K.nslices)), blk, sizeof(double) * size_t(L2) * DP, K));
+        CHK(launch_contract<0>(c, DP, dim3(unsigned(ni), unsigned(K.nslices)), blk, sizeof(double) * size_t(L2) * (DP + 1), K));
         // y side: targets = all j (diag: the same i's), partners = i0..i0+ni
         K.gT = gY; K.gbase = nullptr;
         K.nslices = int(diag ? 1 : slices(N2, ni));
         blk = L2 >= 256 ? 256 : int((L2 + 63) / 64 * 64);
-        CHK(launch_contract<1>(c, DP, dim3(unsigned(diag ? ni : N2), unsigned(K.nslices)), blk, sizeof(double) * size_t(L1) * DP, K));
+        CHK(launch_contract<1>(c, DP, dim3(unsigned(diag ? ni : N2), unsigned(K.nslices)), blk, sizeof(double) * size_t(L1) * (DP + 1), K));
     }
     return GPSIG_OK;
 }
@@ -259,17 +264,16 @@ Wave2LaunchFn wave2_plan(int mode, int Rreg, int DP, int M, bool forced, int* G,
     return nullptr;
 }
 
-// gradient of the register-resident side R (NR sequences) against the streamed side S; pairs (s, r) for all s (diag: s == r)
-int wave2_side(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, int mode, const double* S, const double* R, double* gR, int64_t NS, int64_t NR,
-               int LS, int LR, int d, bool diag, const double* Gup, int64_t gm, int64_t gs, int64_t gr, bool gsym, double gscale, double* gbase,
-               double gbase_scale) {
-    const int M = p->num_levels, dr = mode == MODE_PT_NODIFF ? 0 : 1, PW = 64 / G;
-    const int R1 = LS - dr;
-    // tasks: one register-side sequence x a run of streamed sequences
+// dynamic LDS of the scratch-free kernels: the row totals of 64 / G streamed sequences
+size_t wave2_lds(int G, int R1, int M) { return sizeof(double) * size_t(64 / G) * size_t(R1 > 0 ? R1 : 1) * size_t(M - 1 <= 4 ? 4 : 7); }
+constexpr size_t WAVE2_LDS_MAX = 64 * 1024;
+
+// tasks of the scratch-free kernels: one register-side sequence (0 .. NR) x a run of streamed sequences (0 .. NS); diag: (r, r).
+// Two cached lists: a cross Gram alternates between its two sides.
+int wave2_tasks(gpsig_ctx* c, int64_t NS, int64_t NR, bool diag, const SeqTask** tasks, size_t* ntasks_out) {
     int64_t run = diag ? 1 : (NS * NR + 16383) / 16384;
     if (run < 1) run = 1;
     if (run > NS) run = NS;
-    // two cached task lists: a cross Gram alternates between its two sides
     const int64_t key[10] = {NS, NR, run, diag ? 1 : 0, 0, 0, 0, 0, 0, 2};
     TaskCache* tc = c->tc_w2a.match(key) ? &c->tc_w2a : (c->tc_w2b.match(key) ? &c->tc_w2b : nullptr);
     int tbuf = tc == &c->tc_w2a ? B_TASKS_W2A : B_TASKS_W2B;
@@ -295,17 +299,107 @@ int wave2_side(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, int
         HIPCHK(c, hipStreamSynchronize(c->stream));         // host_tasks is reused by the next call
         tc->set(key, int(ntasks));
     }
+    *tasks = static_cast<const SeqTask*>(dt);
+    *ntasks_out = ntasks;
+    return GPSIG_OK;
+}
+
+// gradient of the register-resident side R (NR sequences) against the streamed side S; pairs (s, r) for all s (diag: s == r)
+int wave2_side(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, int mode, const double* S, const double* R, double* gR, int64_t NS, int64_t NR,
+               int LS, int LR, int d, bool diag, const double* Gup, int64_t gm, int64_t gs, int64_t gr, bool gsym, double gscale, double* gbase,
+               double gbase_scale) {
+    const int M = p->num_levels, dr = mode == MODE_PT_NODIFF ? 0 : 1, PW = 64 / G;
+    const int R1 = LS - dr;
+    const SeqTask* dt;
+    size_t ntasks;
+    CHK(wave2_tasks(c, NS, NR, diag, &dt, &ntasks));
     Wave2Args A;
     memset(&A, 0, sizeof(A));
     A.S = S; A.R = R; A.gR = gR; A.NS = int(NS); A.NR = int(NR); A.LS = LS; A.LR = LR; A.d = d;
     A.M = M; A.kind = p->base_kernel; A.mode = mode; A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
-    A.tasks = static_cast<const SeqTask*>(dt); A.ntasks = int(ntasks);
+    A.tasks = dt; A.ntasks = int(ntasks);
     A.G = Gup; A.gm = gm; A.gs = gs; A.gr = gr; A.gsym = gsym ? 1 : 0; A.gscale = gscale;
     A.gbase = gbase; A.gbase_scale = gbase_scale;
     const int nblocks = int((ntasks + PW - 1) / PW);
-    const size_t lds = sizeof(double) * size_t(PW) * size_t(R1 > 0 ? R1 : 1) * size_t(M - 1 <= 4 ? 4 : 7);
-    hipError_t e = fn(A, nblocks, lds, c->stream);
+    hipError_t e = fn(A, nblocks, wave2_lds(G, R1, M), c->stream);
     if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_wave2_kernel launch failed: %s", hipGetErrorString(e));
+    return GPSIG_OK;
+}
+
+// ---- point kernels: scratch-free sweeps that store Lam (seq_lam_undo_kernel) + lam_contract_kernel for both sides -------------
+Wave2LaunchFn lam_undo_plan(int mode, int R1, int R2, int DP, int M, int* G, int* C) {
+    // the linear kernel on increments runs faster through seq_grad_wave2_kernel (44 ms against 66 ms for a 1024 x 1024 Gram)
+    if (mode == MODE_INC || DP > 16 || M - 1 > 7) return nullptr;
+    static const int shapes[][2] = {{16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8}};
+    for (auto& sh : shapes) {
+        if (sh[0] * sh[1] < R2) continue;
+        if (wave2_lds(sh[0], R1, M) > WAVE2_LDS_MAX) continue;
+        Wave2LaunchFn f = mode == MODE_PT_DIFF ? lam_undo_lookup_ptd(sh[0], sh[1], DP, M - 1) : lam_undo_lookup_ptn(sh[0], sh[1], DP, M - 1);
+        if (f) { *G = sh[0]; *C = sh[1]; return f; }
+    }
+    return nullptr;
+}
+
+// Blocks of pairs (i0 .. i0+ni) x (j0 .. j0+nj) sized to the scratch budget for Lam.  Symmetric Gram: block rows i0 .. i0+ni
+// take the columns j >= i0 only; a pair beyond the block's own square appears once and carries G[i][j] + G[j][i].
+int seq_grad_undo(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, int DP, int mode, const double* X, const double* Y, int64_t N1,
+                  int64_t N2, int L1, int L2, int d, bool diag, bool sym, const double* Gup, double* gX, double* gY, double* gbase) {
+    const int M = p->num_levels, dr = mode == MODE_PT_NODIFF ? 0 : 1, PW = 64 / G;
+    const int R1 = L1 - dr, R2 = L2 - dr;
+    HIPCHK(c, hipMemsetAsync(gX, 0, sizeof(double) * size_t(N1) * L1 * d, c->stream));
+    if (!diag && !sym) HIPCHK(c, hipMemsetAsync(gY, 0, sizeof(double) * size_t(N2) * L2 * d, c->stream));
+    if (R1 <= 0 || R2 <= 0) return GPSIG_OK;                 // empty lattice: the levels do not depend on the data
+    const size_t per_pair = sizeof(double) * size_t(R1) * R2;
+    Wave2Args A;
+    memset(&A, 0, sizeof(A));
+    A.S = X; A.R = Y; A.NS = int(N1); A.NR = int(N2); A.LS = L1; A.LR = L2; A.d = d;
+    A.M = M; A.kind = p->base_kernel; A.mode = mode; A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
+    A.G = Gup; A.gm = diag ? N1 : N1 * N2; A.gs = diag ? 1 : N2; A.gr = diag ? 0 : 1; A.gscale = 1.0;
+    A.diag = diag ? 1 : 0;
+    LamContractArgs K;
+    memset(&K, 0, sizeof(K));
+    K.X = X; K.Y = Y; K.L1 = L1; K.L2 = L2; K.d = d; K.kind = p->base_kernel; K.mode = mode; K.p0 = A.p0; K.p1 = A.p1;
+    K.diag = A.diag;
+    {
+        // the largest block: never more than the budget unless a single row of pairs exceeds it
+        const size_t row = per_pair * size_t(diag ? 1 : N2), all = row * size_t(N1), cap = scratch_budget(c) > row ? scratch_budget(c) : row;
+        void* lam;
+        CHK(ensure(c, B_GR5, (all < cap ? all : cap) + 64, &lam));
+    }
+    for (int64_t i0 = 0; i0 < N1;) {
+        const int64_t j0 = (diag || sym) ? i0 : 0;
+        const int64_t nj = diag ? 1 : N2 - j0;
+        int64_t ni = int64_t(scratch_budget(c) / (per_pair * size_t(nj)));
+        if (ni < 1) ni = 1;
+        if (ni > N1 - i0) ni = N1 - i0;
+        if (ni > 65535) ni = 65535;
+        void* lam;
+        CHK(ensure(c, B_GR5, per_pair * size_t(nj) * size_t(ni) + 64, &lam));
+        const SeqTask* dt;
+        size_t ntasks;
+        CHK(wave2_tasks(c, ni, diag ? ni : nj, diag, &dt, &ntasks));
+        A.tasks = dt; A.ntasks = int(ntasks);
+        A.lam = static_cast<double*>(lam); A.i0 = i0; A.j0 = j0; A.nj = nj;
+        A.gsym = sym ? 1 : 0; A.gsym_from = i0 + ni;
+        hipError_t e = fn(A, int((ntasks + PW - 1) / PW), wave2_lds(G, R1, M), c->stream);
+        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_lam_undo_kernel launch failed: %s", hipGetErrorString(e));
+        K.lam = A.lam; K.i0 = i0; K.ni = ni; K.j0 = j0; K.nj = nj;
+        auto slices = [](int64_t targets, int64_t partners) {
+            int64_t s = (CONTRACT_BLOCKS + targets - 1) / targets;
+            if (s > partners) s = partners;
+            if (s > 1024) s = 1024;
+            return s < 1 ? int64_t(1) : s;
+        };
+        K.gT = gX; K.gbase = gbase;
+        K.nslices = int(diag ? 1 : slices(ni, nj));
+        int blk = L1 >= 256 ? 256 : int((L1 + 63) / 64 * 64);
+        CHK(launch_contract<0>(c, DP, dim3(unsigned(ni), unsigned(K.nslices)), blk, sizeof(double) * size_t(L2) * (DP + 1), K));
+        K.gT = (diag || sym) ? gX : gY; K.gbase = nullptr;
+        K.nslices = int(diag ? 1 : slices(nj, ni));
+        blk = L2 >= 256 ? 256 : int((L2 + 63) / 64 * 64);
+        CHK(launch_contract<1>(c, DP, dim3(unsigned(diag ? ni : nj), unsigned(K.nslices)), blk, sizeof(double) * size_t(L1) * (DP + 1), K));
+        i0 += ni;
+    }
     return GPSIG_OK;
 }
 
@@ -341,6 +435,10 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
         w2y = (diag || sym) ? w2x : wave2_plan(mode, L2 - drr, DP, M, c->grad_impl == 4, &w2yG, &w2yC);
         if (!w2x || !w2y) w2x = w2y = nullptr;
     }
+    if (w2x && (wave2_lds(w2xG, L2 - drr, M) > WAVE2_LDS_MAX || (!diag && !sym && wave2_lds(w2yG, L1 - drr, M) > WAVE2_LDS_MAX))) w2x = w2y = nullptr;
+    Wave2LaunchFn lfn = nullptr;                           // point kernels: scratch-free sweeps with Lam out
+    int lG = 0, lC = 0;
+    if ((c->grad_impl == 0 || c->grad_impl == 5) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, L1 - drr, L2 - drr, DP, M, &lG, &lC);
     if (N1 == 0 || N2 == 0) {
         if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
         if (dgY && yb) HIPCHK(c, hipMemsetAsync(dgY, 0, yb, c->stream));
@@ -360,6 +458,9 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
             CHK(wave2_side(c, p, w2y, w2yG, mode, Xd, Yd, static_cast<double*>(dgY), N1, N2, L1, L2, d, false, Gd, N1 * N2, N2, 1, false, 1.0, dgb, 1.0));
             CHK(wave2_side(c, p, w2x, w2xG, mode, Yd, Xd, static_cast<double*>(dgX), N2, N1, L2, L1, d, false, Gd, N1 * N2, 1, N2, false, 1.0, nullptr, 0.0));
         }
+    } else if (lfn) {
+        CHK(seq_grad_undo(c, p, lfn, lG, DP, mode, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, d,
+                          diag, sym, static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), dgb));
     } else if (wfn) {
         CHK(seq_grad_wave(c, p, wfn, wG, wC, DP, mode, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, d,
                           diag, sym, static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), dgb));

@@ -31,6 +31,20 @@ Wave2LaunchFn wave2_lookup_mode(int G, int C, int DP, int LQ) {
     return nullptr;
 }
 
+template <int G, int C, int DP, int LQ, int MODE>
+hipError_t lam_undo_launch(const Wave2Args& a, int nblocks, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((seq_lam_undo_kernel<G, C, DP, LQ, MODE>), dim3(nblocks), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+template <int MODE>
+Wave2LaunchFn lam_undo_lookup_mode(int G, int C, int DP, int LQ) {
+#define X_LU(G_, C_, D_)                                                             \
+    if (G == G_ && C == C_ && DP == D_) return LQ <= 4 ? lam_undo_launch<G_, C_, D_, 4, MODE> : lam_undo_launch<G_, C_, D_, 7, MODE>;
+    GPSIG_WAVE_SHAPES(X_LU)
+#undef X_LU
+    return nullptr;
+}
+
 template <int MODE>
 WaveLaunchFn wave_lookup_mode(int G, int C, int DP, int LQ) {
 #define X_W(G_, C_, D_)                                                              \

@@ -188,7 +188,7 @@ struct LamContractArgs {
 
 template <int DP, int SIDE>
 __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs A) {
-    extern __shared__ double part[];       // one partner sequence: Lp x DP
+    extern __shared__ double part[];       // one partner sequence: Lp x DP, then its Lp squared norms
     const int dr = A.mode == MODE_PT_NODIFF ? 0 : 1;
     const int R1 = A.L1 - dr, R2 = A.L2 - dr;
     const int Lt = SIDE == 0 ? A.L1 : A.L2, Lp = SIDE == 0 ? A.L2 : A.L1;
@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs
     const double* P = SIDE == 0 ? A.Y : A.X;
     const int64_t np = A.diag ? 1 : (SIDE == 0 ? A.nj : A.ni);
     const bool nodiff = A.mode == MODE_PT_NODIFF;
+    double* pnorm = part + Lp * DP;
     double gp0 = 0.0;
     for (int tp0 = 0; tp0 < Lt; tp0 += blockDim.x) {                      // target points in tiles of blockDim.x
         const int tp = tp0 + threadIdx.x;
@@ -214,6 +215,13 @@ __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs
             for (int e = threadIdx.x; e < Lp * DP; e += blockDim.x) {
                 const int q = e / DP, f = e % DP;
                 part[e] = f < A.d ? P[(pseq * Lp + q) * A.d + f] : 0.0;
+            }
+            __syncthreads();
+            for (int q = threadIdx.x; q < Lp; q += blockDim.x) {
+                double ps = 0.0;
+#pragma unroll
+                for (int f = 0; f < DP; ++f) ps = fma(part[q * DP + f], part[q * DP + f], ps);
+                pnorm[q] = ps;
             }
             __syncthreads();
             const int64_t pi = A.diag ? (tseq - A.i0) : (SIDE == 0 ? (tseq - A.i0) * A.nj + k : k * A.nj + (tseq - A.j0));
@@ -239,9 +247,10 @@ __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs
                         hi_prev = hi;
                     }
                     const double* yq = part + r * DP;
-                    double in = 0.0, ps = 0.0;
+                    double in = 0.0;
+                    const double ps = pnorm[r];
 #pragma unroll
-                    for (int f = 0; f < DP; ++f) { in = fma(xt[f], yq[f], in); ps = fma(yq[f], yq[f], ps); }
+                    for (int f = 0; f < DP; ++f) in = fma(xt[f], yq[f], in);
                     // derivative with respect to the target point; base_eval_grad's first argument is x
                     const BaseGrad g = SIDE == 0 ? base_eval_grad(A.kind, in, ts, ps, A.p0, A.p1) : base_eval_grad(A.kind, in, ps, ts, A.p0, A.p1);
                     const double w = gam * (g.cy - g.cd);
@@ -281,6 +290,11 @@ struct Wave2Args {
     int gsym;                              // add the transposed term G[m * gm + r * gs + s * gr] (symmetric Gram)
     double gscale;                         // 1, or 2 for the diagonal (both roles of the same sequence)
     double* gbase; double gbase_scale;     // optional: d/d base_params[0], scaled (0.5 where both orders of a pair are swept)
+    // seq_lam_undo_kernel only: tasks index a block of pairs, streamed i0 .. i0+ni against register-side j0 .. j0+nj
+    double* lam;                           // Lam of pair (i, j) at ((i - i0) * nj + (j - j0)) * R1 * R2 (diag: (i - i0) * R1 * R2)
+    int64_t i0, j0, nj;
+    int diag;
+    int64_t gsym_from;                     // gsym: the transposed term is added for register-side sequences >= gsym_from only
 };
 
 // dynamic LDS: (64 / G) * (LS rows) * LQ doubles
@@ -396,6 +410,114 @@ __global__ void __launch_bounds__(64) seq_grad_wave2_kernel(const Wave2Args A) {
             }
     }
     if (A.gbase) grad_add(&A.gbase[0], gy.gp0 * A.gbase_scale, true, has_task);
+}
+
+// ---- scratch-free forward state, Lam out (WaveUndo / WaveDm): the point kernels ------------------------------------------------
+// The sweeps of seq_grad_wave2_kernel with the kernel derivative left out: the backward sweep stores Lam of every pair, and
+// lam_contract_kernel turns it into the gradient of both sides.  Per lane this keeps the points of C + 1 columns and the
+// recursion state only, so the 16-lane shapes that hold 4 pairs per wavefront fit for every base kernel.
+template <int G, int C, int DP, int LQ, int MODE>
+__global__ void __launch_bounds__(64) seq_lam_undo_kernel(const Wave2Args A) {
+    extern __shared__ double w2_sm[];
+    constexpr int PW = 64 / G;
+    const int lane = threadIdx.x, ln = lane % G, gw = lane / G;
+    const int dr = MODE == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = A.LS - dr, R2 = A.LR - dr, M = A.M;
+    const int TF = R1 + G - 1;
+    double* rt = w2_sm + size_t(gw) * (R1 > 0 ? R1 : 1) * LQ;         // rowtot[a][m-1]
+    const int tid = blockIdx.x * PW + gw;
+    const bool has_task = tid < A.ntasks;
+    const SeqTask tk = has_task ? A.tasks[tid] : SeqTask{0, 0, 0};
+    int nmax = tk.nx;
+#pragma unroll
+    for (int o = G; o < 64; o <<= 1) { const int v = __shfl_xor(nmax, o, 64); nmax = v > nmax ? v : nmax; }
+    const int64_t r = A.j0 + tk.y0;
+    const int last_lane = R2 > 0 ? (R2 - 1) / C : 0;
+
+    WaveDm<C, DP, MODE> dmg;
+    {
+        double ypts[C + 1][DP];
+#pragma unroll
+        for (int c = 0; c <= C; ++c) wave_load_point<DP>(A.R, r, A.LR, A.d, C * ln + c, ypts[c]);
+        int nv = R2 - C * ln;
+        dmg.set_y(ypts, nv < 0 ? 0 : (nv > C ? C : nv));
+    }
+    for (int it = 0; it < nmax; ++it) {
+        const bool have = has_task && it < tk.nx;
+        const int64_t sl = tk.x0 + (have ? it : 0), s = A.i0 + sl;
+        double clev[LQ + 2];
+#pragma unroll
+        for (int p = 0; p < LQ + 2; ++p) {
+            double v = 0.0;
+            if (have && p >= 1 && p <= M) {
+                v = A.G[p * A.gm + s * A.gs + r * A.gr];
+                if (A.gsym && r >= A.gsym_from) v += A.G[p * A.gm + r * A.gs + s * A.gr];
+            }
+            clev[p] = v;
+        }
+        WaveFwd<C, LQ> fw;
+        fw.reset();
+        double xn[DP];
+        if (MODE != MODE_PT_NODIFF) {
+            wave_load_point<DP>(A.S, s, A.LS, A.d, 0, xn);
+            dmg.prime(xn, A.kind, A.p0, A.p1);
+        }
+        wave_load_point<DP>(A.S, s, A.LS, A.d, 0 - ln + dr, xn);           // row of step 0
+        for (int t = 0; t < TF; ++t) {
+            double cin[LQ + 2], xnext[DP];
+            cin[0] = 0.0;
+#pragma unroll
+            for (int m = 1; m < LQ + 2; ++m) cin[m] = wave_from_left<G>(fw.sout[m]);
+            const int a = t - ln;
+            wave_load_point<DP>(A.S, s, A.LS, A.d, a + 1 + dr, xnext);     // prefetch the row of step t+1
+            if (a >= 0 && a < R1) {
+                double dm[C];
+                dmg.row(xn, true, A.kind, A.p0, A.p1, dm);
+                fw.step(dm, cin, M);
+                if (ln == last_lane) {
+#pragma unroll
+                    for (int m = 1; m <= LQ; ++m) rt[a * LQ + m - 1] = m < M ? fw.sout[m] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < DP; ++f) xn[f] = xnext[f];
+        }
+        __syncthreads();
+        WaveUndo<C, LQ> bw;
+        bw.init(fw);
+        if (MODE != MODE_PT_NODIFF) {
+            double xl[DP];
+            wave_load_point<DP>(A.S, s, A.LS, A.d, R1, xl);
+            dmg.prime(xl, A.kind, A.p0, A.p1);
+        }
+        double* lamrow = A.lam + size_t(A.diag ? sl : sl * A.nj + tk.y0) * R1 * R2;
+        wave_load_point<DP>(A.S, s, A.LS, A.d, R1 - 1 + (G - 1 - ln), xn);   // row of step 0 (out of range -> zeros)
+        for (int u = 0; u < TF; ++u) {
+            double sufin[LQ], svin[LQ], xnext[DP];
+#pragma unroll
+            for (int p = 0; p < LQ; ++p) {
+                sufin[p] = wave_from_right<G>(bw.sufout[p]);
+                svin[p] = wave_from_right<G>(bw.svout[p]);
+            }
+            const int a = R1 - 1 - (u - (G - 1 - ln));
+            wave_load_point<DP>(A.S, s, A.LS, A.d, a - 1, xnext);
+            if (a >= 0 && a < R1) {
+                double dm[C], rtv[LQ], lv[C];
+#pragma unroll
+                for (int p = 0; p < LQ; ++p) rtv[p] = rt[a * LQ + p];
+                dmg.row(xn, false, A.kind, A.p0, A.p1, dm);
+                bw.step(dm, clev, rtv, sufin, svin, M, a == 0, ln == 0, lv);
+                if (have) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (c < dmg.nvalid) lamrow[size_t(a) * R2 + C * ln + c] = lv[c];
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < DP; ++f) xn[f] = xnext[f];
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace gpsig

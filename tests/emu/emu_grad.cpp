@@ -271,9 +271,83 @@ void wave_pair(const double* X, const double* Y, int i, int j, int L1, int L2, i
     }
 }
 
+// Lam of one pair through the scratch-free formulation: forward sweep keeping the row totals, backward sweep undoing the
+// forward recursion (WaveUndo) with the plain dM generator (WaveDm) -- the sweeps of seq_lam_undo_kernel.
+template <int G, int C, int DP, int LQ, int MODE>
+void wave_pair_undo(const double* X, const double* Y, int i, int j, int L1, int L2, int d, int M, int kind, double p0, double p1,
+                    const double* clev_in, std::vector<double>& lam_out) {
+    const int dr = MODE == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = L1 - dr, R2 = L2 - dr, TF = R1 + G - 1;
+    auto load = [&](const double* S, int seq, int L, int r, double (&v)[DP]) {
+        for (int f = 0; f < DP; ++f) v[f] = (r >= 0 && r < L && f < d) ? S[(size_t(seq) * L + r) * d + f] : 0.0;
+    };
+    std::vector<WaveDm<C, DP, MODE>> dm(G);
+    std::vector<WaveFwd<C, LQ>> fw(G);
+    std::vector<double> rowtot(size_t(R1 > 0 ? R1 : 1) * LQ, 0.0);
+    double clev[LQ + 2];
+    for (int p = 0; p < LQ + 2; ++p) clev[p] = (p >= 1 && p <= M) ? clev_in[p] : 0.0;
+    const int last_lane = R2 > 0 ? (R2 - 1) / C : 0;
+    lam_out.assign(size_t(R1) * R2, 0.0);
+    for (int l = 0; l < G; ++l) {
+        double ypts[C + 1][DP];
+        for (int c = 0; c <= C; ++c) load(Y, j, L2, C * l + c, ypts[c]);
+        int nv = R2 - C * l;
+        dm[l].set_y(ypts, nv < 0 ? 0 : (nv > C ? C : nv));
+        fw[l].reset();
+        if (MODE != MODE_PT_NODIFF) { double x0[DP]; load(X, i, L1, 0, x0); dm[l].prime(x0, kind, p0, p1); }
+    }
+    for (int t = 0; t < TF; ++t) {
+        std::vector<std::array<double, LQ + 2>> snap(G);
+        for (int l = 0; l < G; ++l)
+            for (int m = 0; m < LQ + 2; ++m) snap[l][m] = l > 0 ? fw[l - 1].sout[m] : 0.0;
+        for (int l = 0; l < G; ++l) {
+            const int a = t - l;
+            if (a < 0 || a >= R1) continue;
+            double cin[LQ + 2], xn[DP], dmv[C];
+            for (int m = 0; m < LQ + 2; ++m) cin[m] = snap[l][m];
+            cin[0] = 0.0;
+            load(X, i, L1, a + dr, xn);
+            dm[l].row(xn, true, kind, p0, p1, dmv);
+            fw[l].step(dmv, cin, M);
+            if (l == last_lane)
+                for (int m = 1; m <= LQ; ++m) rowtot[size_t(a) * LQ + m - 1] = m < M ? fw[l].sout[m] : 0.0;
+        }
+    }
+    std::vector<WaveUndo<C, LQ>> bw(G);
+    for (int l = 0; l < G; ++l) {
+        bw[l].init(fw[l]);
+        if (MODE != MODE_PT_NODIFF) { double xl[DP]; load(X, i, L1, R1, xl); dm[l].prime(xl, kind, p0, p1); }
+    }
+    for (int u = 0; u < TF; ++u) {
+        std::vector<std::array<double, 2 * LQ>> snap(G);
+        for (int l = 0; l < G; ++l)
+            for (int p = 0; p < LQ; ++p) {
+                snap[l][p] = l < G - 1 ? bw[l + 1].sufout[p] : 0.0;
+                snap[l][LQ + p] = l < G - 1 ? bw[l + 1].svout[p] : 0.0;
+            }
+        for (int l = 0; l < G; ++l) {
+            const int a = R1 - 1 - (u - (G - 1 - l));
+            if (a < 0 || a >= R1) continue;
+            double sufin[LQ], svin[LQ], rt[LQ], xn[DP], dmv[C], lv[C];
+            for (int p = 0; p < LQ; ++p) { sufin[p] = snap[l][p]; svin[p] = snap[l][LQ + p]; rt[p] = rowtot[size_t(a) * LQ + p]; }
+            load(X, i, L1, a, xn);
+            dm[l].row(xn, false, kind, p0, p1, dmv);
+            bw[l].step(dmv, clev, rt, sufin, svin, M, a == 0, l == 0, lv);
+            for (int c = 0; c < C; ++c)
+                if (c < dm[l].nvalid) lam_out[size_t(a) * R2 + C * l + c] = lv[c];
+        }
+    }
+}
+
 template <int G, int C, int DP, int LQ>
 void wave_pair_mode(int mode, const double* X, const double* Y, int i, int j, int L1, int L2, int d, int M, int kind, double p0, double p1,
-                    const double* clev, std::vector<double>& lam) {
+                    const double* clev, std::vector<double>& lam, bool undo) {
+    if (undo) {
+        if (mode == MODE_INC) wave_pair_undo<G, C, DP, LQ, MODE_INC>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, lam);
+        else if (mode == MODE_PT_DIFF) wave_pair_undo<G, C, DP, LQ, MODE_PT_DIFF>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, lam);
+        else wave_pair_undo<G, C, DP, LQ, MODE_PT_NODIFF>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, lam);
+        return;
+    }
     if (mode == MODE_INC) wave_pair<G, C, DP, LQ, MODE_INC>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, lam);
     else if (mode == MODE_PT_DIFF) wave_pair<G, C, DP, LQ, MODE_PT_DIFF>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, lam);
     else wave_pair<G, C, DP, LQ, MODE_PT_NODIFF>(X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev, lam);
@@ -283,8 +357,9 @@ void wave_pair_mode(int mode, const double* X, const double* Y, int i, int j, in
 extern "C" {
 // The wave formulation (grad_wave_core.hpp) for the lattice sweeps, followed by the per-pair contraction of grad_core.hpp.
 // Same contract as emu_seq_grad.  (Gg, Cc) in {(16,2), (16,4), (64,2)}; returns -2 for anything else or if the lattice does not fit.
+// undo: Lam from the scratch-free sweeps (wave_pair_undo) instead of the stored forward lattice.
 int emu_seq_grad_wave(const double* X, const double* Y, int N1, int N2, int L1, int L2, int d, int M, int kind, int mode, double p0, double p1,
-                      int diag, const double* G, double* gX, double* gY, double* gbase, int Gg, int Cc) {
+                      int diag, const double* G, double* gX, double* gY, double* gbase, int Gg, int Cc, int undo) {
     const int DP = pad_of(d);
     const bool sym = !diag && !Y;
     if (diag || sym) { N2 = N1; L2 = L1; Y = X; }
@@ -307,7 +382,7 @@ int emu_seq_grad_wave(const double* X, const double* Y, int N1, int N2, int L1, 
     for (int i = 0; i < N1; ++i)
         for (int j = diag ? i : 0; j < (diag ? i + 1 : N2); ++j) {
             for (int m = 0; m <= M; ++m) clev[m] = diag ? G[size_t(m) * N1 + i] : G[(size_t(m) * N1 + i) * N2 + j];
-#define WP(GG, CC, DD, LL) wave_pair_mode<GG, CC, DD, LL>(mode, X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev.data(), lam)
+#define WP(GG, CC, DD, LL) wave_pair_mode<GG, CC, DD, LL>(mode, X, Y, i, j, L1, L2, d, M, kind, p0, p1, clev.data(), lam, undo != 0)
             const bool small = M <= 5;
             if (Gg == 16 && Cc == 2) { if (DP == 4) { if (small) WP(16, 2, 4, 4); else WP(16, 2, 4, 7); } else { if (small) WP(16, 2, 8, 4); else WP(16, 2, 8, 7); } }
             else if (Gg == 16 && Cc == 4) { if (DP == 4) { if (small) WP(16, 4, 4, 4); else WP(16, 4, 4, 7); } else { if (small) WP(16, 4, 8, 4); else WP(16, 4, 8, 7); } }

@@ -68,16 +68,21 @@ def tens_grad(Z, G, M, base, increments, p0=0.0, p1=0.0, row_owned=False):
 
 
 def seq_grad_wave(X, Y, G, M, base, difference, p0=0.0, p1=0.0, diag=False, group=16, cols=4, scratch_free=False):
-    """The wave formulation (skewed forward sweep, oppositely skewed backward sweep).  -> gX, gY, g_p0"""
+    """The wave formulation (skewed forward sweep, oppositely skewed backward sweep).  -> gX, gY, g_p0
+    scratch_free: False = forward lattice kept, True = forward recursion undone with the gradient of the register side formed
+    in the sweep, "lam" = forward recursion undone with Lam out and the per-pair contraction."""
     X = np.ascontiguousarray(X, np.float64)
     Y = None if Y is None else np.ascontiguousarray(Y, np.float64)
     G = np.ascontiguousarray(G, np.float64)
     N1, L1, d = X.shape
     N2, L2 = (N1, L1) if Y is None else Y.shape[:2]
     gX, gY, gb = np.zeros_like(X), (None if Y is None else np.zeros_like(Y)), np.zeros(2)
-    fn = lib().emu_seq_grad_wave2 if scratch_free else lib().emu_seq_grad_wave
-    rc = fn(_ptr(X), _ptr(Y), N1, N2, L1, L2, d, M, BASE_IDS[base], lattice_mode(base, difference), C.c_double(p0), C.c_double(p1),
+    args = (_ptr(X), _ptr(Y), N1, N2, L1, L2, d, M, BASE_IDS[base], lattice_mode(base, difference), C.c_double(p0), C.c_double(p1),
             int(diag), _ptr(G), _ptr(gX), _ptr(gY), _ptr(gb), int(group), int(cols))
+    if scratch_free is True:
+        rc = lib().emu_seq_grad_wave2(*args)
+    else:
+        rc = lib().emu_seq_grad_wave(*args, int(scratch_free == "lam"))
     if rc != 0:
         raise NotImplementedError("wave emulator: unsupported shape")
     return gX, gY, gb[0]

@@ -80,6 +80,39 @@ def test_seq_level_gradients(base, difference):
             assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
 
 
+@pytest.mark.parametrize("base,difference", [("rbf", True), ("poly", True), ("matern32", False)])
+def test_point_kernel_gradients_in_blocks(base, difference):
+    """seq_lam_undo_kernel + lam_contract_kernel over several blocks of pairs: a symmetric Gram visits the pairs beyond a
+    block's own square once, with G[i][j] + G[j][i]; the base-kernel parameter gradient is summed over the blocks."""
+    rng = np.random.default_rng(24)
+    ctx = _host_ctx()
+    for (M, N, L, d, kind) in [(4, 41, 20, 3, "sym"), (3, 500, 18, 2, "diag"), (4, 30, 20, 3, "cross")]:
+        X = rng.standard_normal((N, L, d)) * 0.4
+        Y = rng.standard_normal((N + 3, L - 2, d)) * 0.4 if kind == "cross" else None
+        G = rng.standard_normal((M + 1, N) if kind == "diag" else (M + 1, N, N + 3 if kind == "cross" else N))
+        kt = _t_kern(base, d, M, difference=difference)
+        tX = torch.tensor(X, requires_grad=True)
+        tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+        lev = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
+        (lev * torch.tensor(G)).sum().backward()
+        keep = []
+        p = _params(base, d, M, difference, keep)
+        for mb in (1, 4096):
+            ctx.set_option("grad_scratch_mb", mb)
+            gX, gY, gb = np.empty_like(X), (None if Y is None else np.empty_like(Y)), np.zeros(2)
+            if kind == "diag":
+                ctx.call("gpsig_seq_diag_levels_grad", p, _vp(X), N, L, _vp(G), _vp(gX), gb.ctypes.data_as(_P))
+            else:
+                ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N, N + 3 if Y is not None else N, L, L - 2 if Y is not None else L,
+                         _vp(G), _vp(gX), _vp(gY), gb.ctypes.data_as(_P))
+            ctx.set_option("grad_scratch_mb", 4096)
+            assert rel(gX, tX.grad) < 1e-9, (kind, mb, rel(gX, tX.grad))
+            if Y is not None:
+                assert rel(gY, tY.grad) < 1e-9, (kind, mb)
+            if base == "poly":
+                assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0])), (kind, mb)
+
+
 def test_seq_level_gradients_are_chunk_invariant():
     rng = np.random.default_rng(22)
     ctx = _host_ctx()
@@ -363,7 +396,7 @@ def test_wave_and_storage_gradient_kernels_agree(base, difference):
         keep = []
         p = _params(base, d, M, difference, keep)
         res = []
-        for impl in (1, 0, 3, 4):   # one pair per thread (stored lattice) / planner's choice / wavefront + stored lattice / wavefront scratch-free
+        for impl in (1, 0, 3, 4):   # one pair per thread (stored lattice) / planner's choice (point kernels: scratch-free sweeps with Lam out) / wavefront + stored lattice / wavefront scratch-free with the gradient formed in the sweep
             ctx.set_option("grad_impl", impl)
             gX, gY = np.empty_like(X), (None if Y is None else np.empty_like(Y))
             if kind == "diag":

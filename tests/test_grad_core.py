@@ -156,10 +156,11 @@ def test_tensor_adjoints_equal_autograd(base, difference, increments):
 @pytest.mark.parametrize("base", ["linear", "rbf", "poly", "matern32"])
 @pytest.mark.parametrize("difference", [True, False])
 @pytest.mark.parametrize("group,cols", [(16, 2), (16, 4), (64, 2)])
-@pytest.mark.parametrize("scratch_free", [False, True])
+@pytest.mark.parametrize("scratch_free", [False, True, "lam"])
 def test_wave_formulation_equals_autograd(base, difference, group, cols, scratch_free):
     """grad_wave_core.hpp: the two skewed sweeps with handed-over prefixes / suffixes, lock-step on the CPU; with the forward
-    lattice kept (scratch) and with the forward recursion undone on the way back (scratch-free)."""
+    lattice kept (scratch), with the forward recursion undone on the way back and the gradient formed in the sweep
+    (scratch-free), and with the forward recursion undone and Lam handed to the per-pair contraction ("lam")."""
     rng = np.random.default_rng(13)
     p0, p1 = _bp(base)
     cap = group * cols
@@ -174,7 +175,7 @@ def test_wave_formulation_equals_autograd(base, difference, group, cols, scratch
         tY = None if Y is None else torch.tensor(Y, requires_grad=True)
         lev = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
         (lev * torch.tensor(G)).sum().backward()
-        if scratch_free and max(L1, L2) - (1 if difference else 0) > group * cols:
+        if scratch_free is True and max(L1, L2) - (1 if difference else 0) > group * cols:
             continue          # both sides take the register role in turn
         gX, gY, gp0 = EG.seq_grad_wave(X, Y, G, M, base, difference, p0, p1, diag=(kind == "diag"), group=group, cols=cols, scratch_free=scratch_free)
         tol = 1e-9 if scratch_free else 1e-11

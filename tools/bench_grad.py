@@ -8,9 +8,10 @@ import numpy as np, torch
 from gpsig_amd import kernels, models, likelihoods as LK, inducing_variables as iv, autodiff
 
 dev = torch.device("cuda:0")
-if os.environ.get("GPSIG_TVS_ZREG"):
-    from gpsig_amd import _lib
-    _c = _lib.context(0, torch.cuda.current_stream(torch.device("cuda:0")).cuda_stream); _c.set_option("tvs_zreg", int(os.environ["GPSIG_TVS_ZREG"]))
+for _env, _opt in (("GPSIG_TVS_ZREG", "tvs_zreg"), ("GPSIG_GRAD_IMPL", "grad_impl")):
+    if os.environ.get(_env):
+        from gpsig_amd import _lib
+        _lib.context(0, torch.cuda.current_stream(dev).cuda_stream).set_option(_opt, int(os.environ[_env]))
 rng = np.random.default_rng(0)
 
 
