@@ -154,6 +154,7 @@ int check_params(gpsig_ctx* c, const gpsig_params* p) {
     if (p->base_kernel == GPSIG_BASE_SPECTRAL) {
         const int Q = int(p->base_params[0]), fam = int(p->base_params[1]);
         if (Q < 1 || Q > 64 || fam < 0 || fam > 2) return fail(c, GPSIG_ERR_INVALID, "spectral kernel: bad number of components / family");
+        if (p->num_features > SPECTRAL_STRIDE) return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for at most %d features", int(SPECTRAL_STRIDE));
         if (!p->base_table || p->base_table_len != int64_t(Q) * (1 + 2 * p->num_features))
             return fail(c, GPSIG_ERR_INVALID, "spectral kernel: base_table must hold alpha[Q], omega[Q][d], gamma[Q][d]");
         if (p->lengthscales || p->num_lags != 0)

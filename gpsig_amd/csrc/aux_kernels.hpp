@@ -10,7 +10,7 @@
 
 namespace gpsig {
 
-constexpr int MAX_FEATURES = 32;  // d (one lag copy)
+constexpr int MAX_FEATURES = 64;  // d (one lag copy); more than 32 columns after lags run through the any-shape kernels
 constexpr int MAX_LAGS = 8;
 
 // Scaling state of SignatureKernel (gpsig/kernels.py:343-398), by value in kernel arguments.

@@ -35,8 +35,8 @@ int grad_check(gpsig_ctx* c, const gpsig_params* p, int* d, int* DP) {
     if (p->base_kernel < GPSIG_BASE_LINEAR || p->base_kernel > GPSIG_BASE_MATERN52) return fail(c, GPSIG_ERR_INVALID, "unknown base kernel %d", p->base_kernel);
     if (p->num_features < 1 || p->num_lags < 0) return fail(c, GPSIG_ERR_INVALID, "bad num_features / num_lags");
     *d = p->num_features * (p->num_lags + 1);      // raw entry points: columns are taken as they come
-    if (*d > 32) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 32 feature columns (got %d)", *d);
-    *DP = *d <= 4 ? 4 : (*d <= 8 ? 8 : (*d <= 16 ? 16 : 32));
+    if (*d > 64) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns (got %d)", *d);
+    *DP = *d <= 4 ? 4 : (*d <= 8 ? 8 : (*d <= 16 ? 16 : (*d <= 32 ? 32 : 64)));
     HIPCHK(c, hipSetDevice(c->device));
     return GPSIG_OK;
 }
@@ -66,7 +66,8 @@ int launch_seq(gpsig_ctx* c, int DP, dim3 grid, const A& a) {
         case 4: hipLaunchKernelGGL(seq_pair_grad_kernel<4>, grid, dim3(64), 0, c->stream, a); break;
         case 8: hipLaunchKernelGGL(seq_pair_grad_kernel<8>, grid, dim3(64), 0, c->stream, a); break;
         case 16: hipLaunchKernelGGL(seq_pair_grad_kernel<16>, grid, dim3(64), 0, c->stream, a); break;
-        default: hipLaunchKernelGGL(seq_pair_grad_kernel<32>, grid, dim3(64), 0, c->stream, a); break;
+        case 32: hipLaunchKernelGGL(seq_pair_grad_kernel<32>, grid, dim3(64), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(seq_pair_grad_kernel<64>, grid, dim3(64), 0, c->stream, a); break;
     }
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
@@ -76,7 +77,8 @@ int launch_tvs(gpsig_ctx* c, int DP, dim3 grid, const TvsGradArgs& a) {
         case 4: hipLaunchKernelGGL(tvs_pair_grad_kernel<4>, grid, dim3(64), 0, c->stream, a); break;
         case 8: hipLaunchKernelGGL(tvs_pair_grad_kernel<8>, grid, dim3(64), 0, c->stream, a); break;
         case 16: hipLaunchKernelGGL(tvs_pair_grad_kernel<16>, grid, dim3(64), 0, c->stream, a); break;
-        default: hipLaunchKernelGGL(tvs_pair_grad_kernel<32>, grid, dim3(64), 0, c->stream, a); break;
+        case 32: hipLaunchKernelGGL(tvs_pair_grad_kernel<32>, grid, dim3(64), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(tvs_pair_grad_kernel<64>, grid, dim3(64), 0, c->stream, a); break;
     }
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
@@ -125,7 +127,7 @@ int launch_tens_row(gpsig_ctx* c, int DP, int E, dim3 grid, const TensGradArgs& 
         if (E == 1) hipLaunchKernelGGL((tens_row_grad_kernel<DP_, 1>), grid, dim3(64), 0, c->stream, a);             \
         else hipLaunchKernelGGL((tens_row_grad_kernel<DP_, 2>), grid, dim3(64), 0, c->stream, a);                    \
     } while (0)
-    if (DP == 4) TROW(4); else if (DP == 8) TROW(8); else if (DP == 16) TROW(16); else TROW(32);
+    if (DP == 4) TROW(4); else if (DP == 8) TROW(8); else if (DP == 16) TROW(16); else if (DP == 32) TROW(32); else TROW(64);
 #undef TROW
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
@@ -135,7 +137,8 @@ int launch_tens(gpsig_ctx* c, int DP, dim3 grid, const TensGradArgs& a) {
         case 4: hipLaunchKernelGGL(tens_pair_grad_kernel<4>, grid, dim3(64), 0, c->stream, a); break;
         case 8: hipLaunchKernelGGL(tens_pair_grad_kernel<8>, grid, dim3(64), 0, c->stream, a); break;
         case 16: hipLaunchKernelGGL(tens_pair_grad_kernel<16>, grid, dim3(64), 0, c->stream, a); break;
-        default: hipLaunchKernelGGL(tens_pair_grad_kernel<32>, grid, dim3(64), 0, c->stream, a); break;
+        case 32: hipLaunchKernelGGL(tens_pair_grad_kernel<32>, grid, dim3(64), 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(tens_pair_grad_kernel<64>, grid, dim3(64), 0, c->stream, a); break;
     }
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;

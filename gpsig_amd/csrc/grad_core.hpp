@@ -653,9 +653,11 @@ GPSIG_HD TvsEv<E> tvs_eval(const IO& io, int k, const double (&x)[DP], double xs
     return r;
 }
 
-template <int DP, int MMAX, int E, class IO>
-GPSIG_HD void tvs_contract(IO& io, int i, int k0, int tt, const double (&x)[DP], const double (&gk)[MMAX], const TvsEv<E> (&ev)[MMAX],
+// KIND as in tvs_eval: the linear kernel has d kz/dx = wz z, d kz/dz = wz x; the RBF kernel d kz/dx = wz (z - x) = -d kz/dz.
+template <int DP, int MMAX, int E, int IC = 0, int KIND = -1, class IO>
+GPSIG_HD void tvs_contract(IO& io, int i_rt, int k0, int tt, const double (&x)[DP], const double (&gk)[MMAX], const TvsEv<E> (&ev)[MMAX],
                            double (&gzacc)[MMAX][E][DP], double& gp0) {
+    const int i = IC > 0 ? IC : i_rt;
     double gx[DP];
 #pragma unroll
     for (int f = 0; f < DP; ++f) gx[f] = 0.0;
@@ -665,12 +667,29 @@ GPSIG_HD void tvs_contract(IO& io, int i, int k0, int tt, const double (&x)[DP],
             gp0 = fma(gk[j], ev[j].dp0, gp0);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const double a = gk[j] * ev[j].wz[e], bx = gk[j] * ev[j].vx[e], bz = gk[j] * ev[j].vz[e];
+                const double a = gk[j] * ev[j].wz[e];
+                if constexpr (KIND == BASE_LINEAR) {
 #pragma unroll
-                for (int f = 0; f < DP; ++f) {
-                    const double zf = io.z(k0 + j, e, f);
-                    gx[f] = fma(a, zf, fma(bx, x[f], gx[f]));
-                    gzacc[j][e][f] = fma(a, x[f], fma(bz, zf, gzacc[j][e][f]));
+                    for (int f = 0; f < DP; ++f) {
+                        gx[f] = fma(a, io.z(k0 + j, e, f), gx[f]);
+                        gzacc[j][e][f] = fma(a, x[f], gzacc[j][e][f]);
+                    }
+                } else if constexpr (KIND == BASE_RBF) {
+                    const double na = -a;
+#pragma unroll
+                    for (int f = 0; f < DP; ++f) {
+                        const double dzx = io.z(k0 + j, e, f) - x[f];
+                        gx[f] = fma(a, dzx, gx[f]);
+                        gzacc[j][e][f] = fma(na, dzx, gzacc[j][e][f]);
+                    }
+                } else {
+                    const double bx = gk[j] * ev[j].vx[e], bz = gk[j] * ev[j].vz[e];
+#pragma unroll
+                    for (int f = 0; f < DP; ++f) {
+                        const double zf = io.z(k0 + j, e, f);
+                        gx[f] = fma(a, zf, fma(bx, x[f], gx[f]));
+                        gzacc[j][e][f] = fma(a, x[f], fma(bz, zf, gzacc[j][e][f]));
+                    }
                 }
             }
         }
@@ -679,9 +698,11 @@ GPSIG_HD void tvs_contract(IO& io, int i, int k0, int tt, const double (&x)[DP],
 
 // i: level (chain length), k0: its first component, R: number of increments (or of points when diff is false),
 // c: upstream gradient of this level.  Returns the level's value (the forward result, free of charge).
-template <int DP, int MMAX, int E, int KIND = -1, class IO>
-GPSIG_HD double tvs_level_grad(IO& io, int i, int k0, int R, bool diff, int kind, double p0, double p1, double c,
+// IC > 0 fixes the chain length at compile time (the loops over the chains then carry no predication).
+template <int DP, int MMAX, int E, int KIND = -1, int IC = 0, class IO>
+GPSIG_HD double tvs_level_grad(IO& io, int i_rt, int k0, int R, bool diff, int kind, double p0, double p1, double c,
                                double (&gzacc)[MMAX][E][DP], double& gp0) {
+    const int i = IC > 0 ? IC : i_rt;
     // ---- forward: chains u_1 .. u_i (exclusive prefixes; after the sweep u_j = sum_tau R_j[tau])
     double u[MMAX + 1];
 #pragma unroll
@@ -753,21 +774,21 @@ GPSIG_HD double tvs_level_grad(IO& io, int i, int k0, int R, bool diff, int kind
             double gk[MMAX];
 #pragma unroll
             for (int j = 0; j < MMAX; ++j) gk[j] = j < i ? gm[j] - gprev[j] : 0.0;   // dL/d kz(x_{tau+1})
-            tvs_contract<DP, MMAX, E>(io, i, k0, tau + 1, xn, gk, evn, gzacc, gp0);
+            tvs_contract<DP, MMAX, E, IC, KIND>(io, i, k0, tau + 1, xn, gk, evn, gzacc, gp0);
 #pragma unroll
             for (int j = 0; j < MMAX; ++j)
                 if (j < i) { gprev[j] = gm[j]; evn[j] = evc[j]; }
 #pragma unroll
             for (int f = 0; f < DP; ++f) xn[f] = x[f];
         } else {
-            tvs_contract<DP, MMAX, E>(io, i, k0, tau, x, gm, evc, gzacc, gp0);
+            tvs_contract<DP, MMAX, E, IC, KIND>(io, i, k0, tau, x, gm, evc, gzacc, gp0);
         }
     }
     if (diff) {          // time point 0
         double gk[MMAX];
 #pragma unroll
         for (int j = 0; j < MMAX; ++j) gk[j] = j < i ? -gprev[j] : 0.0;
-        tvs_contract<DP, MMAX, E>(io, i, k0, 0, xn, gk, evn, gzacc, gp0);
+        tvs_contract<DP, MMAX, E, IC, KIND>(io, i, k0, 0, xn, gk, evn, gzacc, gp0);
     }
     return ki;
 }

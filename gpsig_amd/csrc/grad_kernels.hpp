@@ -240,7 +240,12 @@ __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradAr
             __syncthreads();
             io.n = n;
             const double c = valid ? A.G[i * A.gm + t * A.gt + n * A.gn] : 0.0;
-            tvs_level_grad<DP, MMAX, E, KIND>(io, i, 0, R, A.diff != 0, A.kind, A.p0, A.p1, c, gzacc, gp0);
+            switch (i) {
+                case 1: tvs_level_grad<DP, MMAX, E, KIND, 1>(io, i, 0, R, A.diff != 0, A.kind, A.p0, A.p1, c, gzacc, gp0); break;
+                case 2: tvs_level_grad<DP, MMAX, E, KIND, 2>(io, i, 0, R, A.diff != 0, A.kind, A.p0, A.p1, c, gzacc, gp0); break;
+                case 3: tvs_level_grad<DP, MMAX, E, KIND, 3>(io, i, 0, R, A.diff != 0, A.kind, A.p0, A.p1, c, gzacc, gp0); break;
+                default: tvs_level_grad<DP, MMAX, E, KIND, MMAX>(io, i, 0, R, A.diff != 0, A.kind, A.p0, A.p1, c, gzacc, gp0); break;
+            }
         }
         if (valid) {
 #pragma unroll

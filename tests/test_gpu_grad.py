@@ -113,6 +113,45 @@ def test_point_kernel_gradients_in_blocks(base, difference):
                 assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0])), (kind, mb)
 
 
+def test_gradients_with_wide_state_space():
+    """More than 32 feature columns (e.g. d = 11 with two lags): the one-pair-per-thread kernels at a padded width of 64."""
+    rng = np.random.default_rng(26)
+    ctx = _host_ctx()
+    M, d = 3, 40
+    for base, difference in (("rbf", True), ("linear", True), ("matern32", False)):
+        X, Y = rng.standard_normal((5, 7, d)) * 0.2, rng.standard_normal((4, 6, d)) * 0.2
+        G = rng.standard_normal((M + 1, 5, 4))
+        kt = _t_kern(base, d, M, difference=difference)
+        tX, tY = torch.tensor(X, requires_grad=True), torch.tensor(Y, requires_grad=True)
+        (kt.K_seq_levels(tX, tY) * torch.tensor(G)).sum().backward()
+        keep = []
+        p = _params(base, d, M, difference, keep)
+        gX, gY = np.empty_like(X), np.empty_like(Y)
+        ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), 5, 4, 7, 6, _vp(G), _vp(gX), _vp(gY), None)
+        assert rel(gX, tX.grad) < 1e-9 and rel(gY, tY.grad) < 1e-9, (base, rel(gX, tX.grad))
+        # inducing tensors against sequences, and against each other
+        T, lt = 6, M * (M + 1) // 2
+        Z = rng.standard_normal((lt, T, 2, d)) * 0.2
+        Gt = rng.standard_normal((M + 1, T, 5))
+        tZ, tX = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+        (kt.K_tens_vs_seq_levels(tZ, tX, True) * torch.tensor(Gt)).sum().backward()
+        gZ, gX = np.empty_like(Z), np.empty_like(X)
+        ctx.call("gpsig_tens_vs_seq_levels_grad", p, _vp(Z), _vp(X), T, 5, 7, 1, _vp(Gt), _vp(gZ), _vp(gX), None)
+        assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9, (base, rel(gZ, tZ.grad))
+        Gz = rng.standard_normal((M + 1, T, T))
+        tZ = torch.tensor(Z, requires_grad=True)
+        (kt.K_tens_levels(tZ, True) * torch.tensor(Gz)).sum().backward()
+        gZ = np.empty_like(Z)
+        ctx.call("gpsig_tens_gram_levels_grad", p, _vp(Z), T, 1, _vp(Gz), _vp(gZ), None)
+        assert rel(gZ, tZ.grad) < 1e-9, (base, rel(gZ, tZ.grad))
+    keep = []
+    p = _params("rbf", 65, M, True, keep)
+    X = rng.standard_normal((2, 4, 65))
+    G = rng.standard_normal((M + 1, 2, 2))
+    with pytest.raises(NotImplementedError, match="at most 64 feature columns"):
+        ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), None, 2, 2, 4, 4, _vp(G), _vp(np.empty_like(X)), None, None)
+
+
 def test_seq_level_gradients_are_chunk_invariant():
     rng = np.random.default_rng(22)
     ctx = _host_ctx()

@@ -425,7 +425,8 @@ def test_any_shape_fallback(K):
     cases = [("linear", 5, 4, 600, 2, 3, None, True, 1), ("rbf", 4, 3, 530, 2, 3, None, True, 1), ("matern32", 3, 3, 300, 12, 3, None, True, 1),
              ("rbf", 4, 4, 40, 20, 4, 1, True, 1), ("linear", 4, 3, 140, 20, 3, None, False, 1), ("mix", 3, 3, 30, 24, 3, 1, True, 1),
              ("linear", 4, 3, 140, 3, 4, None, False, 4), ("rbf", 3, 3, 70, 2, 6, None, True, 6), ("matern52", 3, 2, 20, 24, 3, 1, True, 2),
-             ("linear", 3, 3, 540, 2, 3, None, True, 2)]
+             ("linear", 3, 3, 540, 2, 3, None, True, 2), ("rbf", 4, 3, 12, 40, 3, None, True, 1), ("linear", 3, 3, 9, 64, 3, None, True, 2),
+             ("matern32", 3, 2, 10, 33, 2, 1, True, 1)]
     for base, N, N2, L, d, M, lags, norm, order in cases:
         X = np.cumsum(0.05 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
         X2 = np.cumsum(0.05 * rng.standard_normal((N2, L, d)), axis=1).reshape(N2, -1)
@@ -444,7 +445,7 @@ def test_any_shape_fallback(K):
 def test_unsupported_shapes_fail_loudly(K):
     assert K.SignatureLinear(2 * 600, 2, 3, order=2).K(np.zeros((2, 1200), dtype=np.float32)).dtype == np.float32   # float64 fallback, rounded
     with pytest.raises(NotImplementedError):
-        K.SignatureLinear(40 * 5, 40, 3).K(np.zeros((2, 200)))             # more than 32 features per lag copy
+        K.SignatureLinear(70 * 5, 70, 3).K(np.zeros((2, 350)))             # more than 64 features per lag copy
     assert K.SignatureRBF(12, 3, 3, low_rank=True, num_components=4).K(np.zeros((4, 12), dtype=np.float32)).dtype == np.float32   # via float64
     with pytest.raises(ValueError):
         K.SignatureLinear(12, 3, 3).K_tens(np.zeros((5, 4, 3)))            # lt must be 6
