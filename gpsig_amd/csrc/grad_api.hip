@@ -15,8 +15,6 @@ WaveLaunchFn wave_lookup_ptd(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptn(int G, int C, int DP, int LQ);
 typedef hipError_t (*Wave2LaunchFn)(const Wave2Args&, int, size_t, hipStream_t);
 Wave2LaunchFn wave2_lookup_inc(int G, int C, int DP, int LQ);
-Wave2LaunchFn wave2_lookup_ptd(int G, int C, int DP, int LQ);
-Wave2LaunchFn wave2_lookup_ptn(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptd(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn(int G, int C, int DP, int LQ);
 }  // namespace gpsig
@@ -250,25 +248,22 @@ int seq_grad_wave(gpsig_ctx* c, const gpsig_params* p, WaveLaunchFn fn, int G, i
 
 
 // ---- scratch-free wavefront path (seq_grad_wave2_kernel): one launch per register-resident side ------------------------------
-Wave2LaunchFn wave2_plan(int mode, int Rreg, int DP, int M, bool forced, int* G, int* C) {
-    if (DP > 16 || M - 1 > 7) return nullptr;
-    // Point kernels carry the derivative coefficients of a whole row on top of the recursion state and currently run faster
-    // through the stored-lattice kernel + contraction; the scratch-free kernel is the default for the linear kernel only.
-    if (mode != MODE_INC && !forced) return nullptr;
+Wave2LaunchFn wave2_plan(int mode, int Rreg, int DP, int M, int* G, int* C) {
+    // The linear kernel on increments only: the point kernels would carry the derivative coefficients of a whole row on top
+    // of the recursion state; they run through seq_lam_undo_kernel + lam_contract_kernel.
+    if (mode != MODE_INC || DP > 16 || M - 1 > 7) return nullptr;
     static const int shapes[][2] = {{16, 2}, {16, 4}, {64, 2}, {64, 8}};
     for (auto& sh : shapes) {
         if (sh[0] * sh[1] < Rreg) continue;
         if (sh[1] * DP > 32) continue;                     // larger per-lane tiles spill
-        if (mode != MODE_INC && sh[1] * DP > 16) continue; // point kernels carry the derivative coefficients as well
-        Wave2LaunchFn f = mode == MODE_INC ? wave2_lookup_inc(sh[0], sh[1], DP, M - 1)
-                                           : (mode == MODE_PT_DIFF ? wave2_lookup_ptd(sh[0], sh[1], DP, M - 1) : wave2_lookup_ptn(sh[0], sh[1], DP, M - 1));
+        Wave2LaunchFn f = wave2_lookup_inc(sh[0], sh[1], DP, M - 1);
         if (f) { *G = sh[0]; *C = sh[1]; return f; }
     }
     return nullptr;
 }
 
 // dynamic LDS of the scratch-free kernels: the row totals of 64 / G streamed sequences
-size_t wave2_lds(int G, int R1, int M) { return sizeof(double) * size_t(64 / G) * size_t(R1 > 0 ? R1 : 1) * size_t(M - 1 <= 4 ? 4 : 7); }
+size_t wave2_lds(int G, int R1, int M) { return sizeof(double) * size_t(64 / G) * size_t(R1 > 0 ? R1 : 1) * size_t(M - 1 == 3 ? 3 : (M - 1 <= 4 ? 4 : 7)); }
 constexpr size_t WAVE2_LDS_MAX = 64 * 1024;
 
 // tasks of the scratch-free kernels: one register-side sequence (0 .. NR) x a run of streamed sequences (0 .. NS); diag: (r, r).
@@ -434,14 +429,14 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     const int drr = mode == MODE_PT_NODIFF ? 0 : 1;
     if ((c->grad_impl == 0 || c->grad_impl == 3 || c->grad_impl == 4) && N1 > 0 && N2 > 0) wfn = wave_plan(mode, L2 - drr, DP, M, &wG, &wC);
     if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0 && L1 - drr > 0 && L2 - drr > 0) {
-        w2x = wave2_plan(mode, L1 - drr, DP, M, c->grad_impl == 4, &w2xG, &w2xC);
-        w2y = (diag || sym) ? w2x : wave2_plan(mode, L2 - drr, DP, M, c->grad_impl == 4, &w2yG, &w2yC);
+        w2x = wave2_plan(mode, L1 - drr, DP, M, &w2xG, &w2xC);
+        w2y = (diag || sym) ? w2x : wave2_plan(mode, L2 - drr, DP, M, &w2yG, &w2yC);
         if (!w2x || !w2y) w2x = w2y = nullptr;
     }
     if (w2x && (wave2_lds(w2xG, L2 - drr, M) > WAVE2_LDS_MAX || (!diag && !sym && wave2_lds(w2yG, L1 - drr, M) > WAVE2_LDS_MAX))) w2x = w2y = nullptr;
     Wave2LaunchFn lfn = nullptr;                           // point kernels: scratch-free sweeps with Lam out
     int lG = 0, lC = 0;
-    if ((c->grad_impl == 0 || c->grad_impl == 5) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, L1 - drr, L2 - drr, DP, M, &lG, &lC);
+    if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, L1 - drr, L2 - drr, DP, M, &lG, &lC);
     if (N1 == 0 || N2 == 0) {
         if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
         if (dgY && yb) HIPCHK(c, hipMemsetAsync(dgY, 0, yb, c->stream));

@@ -2,5 +2,4 @@
 #include "grad_wave_inst.hpp"
 namespace gpsig {
 WaveLaunchFn wave_lookup_inc(int G, int C, int DP, int LQ) { return wave_lookup_mode<MODE_INC>(G, C, DP, LQ); }
-Wave2LaunchFn wave2_lookup_inc(int G, int C, int DP, int LQ) { return wave2_lookup_mode<MODE_INC>(G, C, DP, LQ); }
 }

@@ -2,6 +2,4 @@
 #include "grad_wave_inst.hpp"
 namespace gpsig {
 WaveLaunchFn wave_lookup_ptd(int G, int C, int DP, int LQ) { return wave_lookup_mode<MODE_PT_DIFF>(G, C, DP, LQ); }
-Wave2LaunchFn wave2_lookup_ptd(int G, int C, int DP, int LQ) { return wave2_lookup_mode<MODE_PT_DIFF>(G, C, DP, LQ); }
-Wave2LaunchFn lam_undo_lookup_ptd(int G, int C, int DP, int LQ) { return lam_undo_lookup_mode<MODE_PT_DIFF>(G, C, DP, LQ); }
 }

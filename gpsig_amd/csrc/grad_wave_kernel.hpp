@@ -297,14 +297,14 @@ struct Wave2Args {
     int64_t gsym_from;                     // gsym: the transposed term is added for register-side sequences >= gsym_from only
 };
 
-// dynamic LDS: (64 / G) * (LS rows) * LQ doubles
-template <int G, int C, int DP, int LQ, int MODE>
+// dynamic LDS: (64 / G) * (LS rows) * LQ doubles.  MX: num_levels == LQ + 1 at compile time (no level predicates in the sweeps).
+template <int G, int C, int DP, int LQ, int MODE, bool MX = false>
 __global__ void __launch_bounds__(64) seq_grad_wave2_kernel(const Wave2Args A) {
     extern __shared__ double w2_sm[];
     constexpr int PW = 64 / G;
     const int lane = threadIdx.x, lam = lane % G, gw = lane / G;
     const int dr = MODE == MODE_PT_NODIFF ? 0 : 1;
-    const int R1 = A.LS - dr, R2 = A.LR - dr, M = A.M;
+    const int R1 = A.LS - dr, R2 = A.LR - dr, M = MX ? LQ + 1 : A.M;
     const int TF = R1 + G - 1;
     double* rt = w2_sm + size_t(gw) * (R1 > 0 ? R1 : 1) * LQ;         // rowtot[a][m-1]
     const int tid = blockIdx.x * PW + gw;
@@ -416,13 +416,13 @@ __global__ void __launch_bounds__(64) seq_grad_wave2_kernel(const Wave2Args A) {
 // The sweeps of seq_grad_wave2_kernel with the kernel derivative left out: the backward sweep stores Lam of every pair, and
 // lam_contract_kernel turns it into the gradient of both sides.  Per lane this keeps the points of C + 1 columns and the
 // recursion state only, so the 16-lane shapes that hold 4 pairs per wavefront fit for every base kernel.
-template <int G, int C, int DP, int LQ, int MODE>
+template <int G, int C, int DP, int LQ, int MODE, bool MX = false>
 __global__ void __launch_bounds__(64) seq_lam_undo_kernel(const Wave2Args A) {
     extern __shared__ double w2_sm[];
     constexpr int PW = 64 / G;
     const int lane = threadIdx.x, ln = lane % G, gw = lane / G;
     const int dr = MODE == MODE_PT_NODIFF ? 0 : 1;
-    const int R1 = A.LS - dr, R2 = A.LR - dr, M = A.M;
+    const int R1 = A.LS - dr, R2 = A.LR - dr, M = MX ? LQ + 1 : A.M;
     const int TF = R1 + G - 1;
     double* rt = w2_sm + size_t(gw) * (R1 > 0 ? R1 : 1) * LQ;         // rowtot[a][m-1]
     const int tid = blockIdx.x * PW + gw;

@@ -97,8 +97,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "tensor_lanes" tensor-vs-sequence kernel: 1 one lane per tensor, 0 one lane per sequence, -1 automatic
  *   "grad_scratch_mb" lattice scratch of one gradient / fallback launch in MiB (default 4096)
  *   "grad_impl"   gradient kernels: 0 planner's choice, 1 one pair per thread with the lattice in HBM scratch, 2 one pair per
- *                 thread scratch-free (tensor vs sequence), 3 wavefront kernel with the lattice in HBM scratch, 4 scratch-free
- *                 wavefront kernel forming the gradient in the sweep wherever it is built, 5 as 0
+ *                 thread scratch-free (tensor vs sequence), 3 wavefront kernel with the lattice in HBM scratch, 4 scratch-free wavefront
+ *                 kernels (what the planner picks wherever they are built)
  *   "tvs_zreg"    tensor-lane gradient: components in registers (1) or LDS (0), -1 automatic */
 int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
 /* HIP-event timing of the dominant kernel (the pair recursion) launched by the calls since the last
