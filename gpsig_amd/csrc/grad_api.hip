@@ -15,8 +15,10 @@ WaveLaunchFn wave_lookup_ptd(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptn(int G, int C, int DP, int LQ);
 typedef hipError_t (*Wave2LaunchFn)(const Wave2Args&, int, size_t, hipStream_t);
 Wave2LaunchFn wave2_lookup_inc(int G, int C, int DP, int LQ);
-Wave2LaunchFn lam_undo_lookup_ptd(int G, int C, int DP, int LQ);
-Wave2LaunchFn lam_undo_lookup_ptn(int G, int C, int DP, int LQ);
+Wave2LaunchFn lam_undo_lookup_ptd_rbf(int G, int C, int DP, int LQ);
+Wave2LaunchFn lam_undo_lookup_ptd_gen(int G, int C, int DP, int LQ);
+Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
+Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
 }  // namespace gpsig
 
 using namespace gpsig;
@@ -177,11 +179,19 @@ constexpr int64_t CONTRACT_BLOCKS = 16384;
 
 template <int SIDE>
 int launch_contract(gpsig_ctx* c, int DP, dim3 grid, int block, size_t lds, const LamContractArgs& a) {
-    switch (DP) {
-        case 4: hipLaunchKernelGGL((lam_contract_kernel<4, SIDE>), grid, dim3(block), lds, c->stream, a); break;
-        case 8: hipLaunchKernelGGL((lam_contract_kernel<8, SIDE>), grid, dim3(block), lds, c->stream, a); break;
-        default: hipLaunchKernelGGL((lam_contract_kernel<16, SIDE>), grid, dim3(block), lds, c->stream, a); break;
-    }
+    const bool nodiff = a.mode == MODE_PT_NODIFF, rbf = a.kind == BASE_RBF;
+#define LC(DP_)                                                                                                                         \
+    do {                                                                                                                                \
+        if (rbf) {                                                                                                                      \
+            if (nodiff) hipLaunchKernelGGL((lam_contract_kernel<DP_, SIDE, BASE_RBF, true>), grid, dim3(block), lds, c->stream, a);     \
+            else hipLaunchKernelGGL((lam_contract_kernel<DP_, SIDE, BASE_RBF, false>), grid, dim3(block), lds, c->stream, a);           \
+        } else {                                                                                                                        \
+            if (nodiff) hipLaunchKernelGGL((lam_contract_kernel<DP_, SIDE, -1, true>), grid, dim3(block), lds, c->stream, a);           \
+            else hipLaunchKernelGGL((lam_contract_kernel<DP_, SIDE, -1, false>), grid, dim3(block), lds, c->stream, a);                 \
+        }                                                                                                                               \
+    } while (0)
+    if (DP == 4) LC(4); else if (DP == 8) LC(8); else LC(16);
+#undef LC
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
 }
@@ -325,14 +335,16 @@ int wave2_side(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, int
 }
 
 // ---- point kernels: scratch-free sweeps that store Lam (seq_lam_undo_kernel) + lam_contract_kernel for both sides -------------
-Wave2LaunchFn lam_undo_plan(int mode, int R1, int R2, int DP, int M, int* G, int* C) {
+Wave2LaunchFn lam_undo_plan(int mode, int kind, int R1, int R2, int DP, int M, int* G, int* C) {
     // the linear kernel on increments runs faster through seq_grad_wave2_kernel (44 ms against 66 ms for a 1024 x 1024 Gram)
     if (mode == MODE_INC || DP > 16 || M - 1 > 7) return nullptr;
     static const int shapes[][2] = {{16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8}};
     for (auto& sh : shapes) {
         if (sh[0] * sh[1] < R2) continue;
         if (wave2_lds(sh[0], R1, M) > WAVE2_LDS_MAX) continue;
-        Wave2LaunchFn f = mode == MODE_PT_DIFF ? lam_undo_lookup_ptd(sh[0], sh[1], DP, M - 1) : lam_undo_lookup_ptn(sh[0], sh[1], DP, M - 1);
+        const bool rbf = kind == BASE_RBF;
+        Wave2LaunchFn f = mode == MODE_PT_DIFF ? (rbf ? lam_undo_lookup_ptd_rbf : lam_undo_lookup_ptd_gen)(sh[0], sh[1], DP, M - 1)
+                                               : (rbf ? lam_undo_lookup_ptn_rbf : lam_undo_lookup_ptn_gen)(sh[0], sh[1], DP, M - 1);
         if (f) { *G = sh[0]; *C = sh[1]; return f; }
     }
     return nullptr;
@@ -436,7 +448,7 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     if (w2x && (wave2_lds(w2xG, L2 - drr, M) > WAVE2_LDS_MAX || (!diag && !sym && wave2_lds(w2yG, L1 - drr, M) > WAVE2_LDS_MAX))) w2x = w2y = nullptr;
     Wave2LaunchFn lfn = nullptr;                           // point kernels: scratch-free sweeps with Lam out
     int lG = 0, lC = 0;
-    if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, L1 - drr, L2 - drr, DP, M, &lG, &lC);
+    if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, p->base_kernel, L1 - drr, L2 - drr, DP, M, &lG, &lC);
     if (N1 == 0 || N2 == 0) {
         if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
         if (dgY && yb) HIPCHK(c, hipMemsetAsync(dgY, 0, yb, c->stream));

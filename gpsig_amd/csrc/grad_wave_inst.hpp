@@ -39,18 +39,22 @@ Wave2LaunchFn wave2_lookup_mode(int G, int C, int DP, int LQ) {
 #endif
 
 #ifdef GPSIG_INST_LAM
-template <int G, int C, int DP, int LQ, int MODE, bool MX>
-hipError_t lam_undo_launch(const Wave2Args& a, int nblocks, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((seq_lam_undo_kernel<G, C, DP, LQ, MODE, MX>), dim3(nblocks), dim3(64), lds, s, a);
-    return hipGetLastError();
-}
-template <int MODE>
-Wave2LaunchFn lam_undo_lookup_mode(int G, int C, int DP, int LQ) {
-#define X_LU(G_, C_, D_) GPSIG_W2_PICK(lam_undo_launch, G_, C_, D_)
-    GPSIG_WAVE_SHAPES(X_LU)
+// KIND is part of every name here: the translation units of the two kernel families instantiate different functions
+template <int KIND>
+struct LamUndoInst {
+    template <int G, int C, int DP, int LQ, int MODE, bool MX>
+    static hipError_t launch(const Wave2Args& a, int nblocks, size_t lds, hipStream_t s) {
+        hipLaunchKernelGGL((seq_lam_undo_kernel<G, C, DP, LQ, MODE, MX, KIND>), dim3(nblocks), dim3(64), lds, s, a);
+        return hipGetLastError();
+    }
+    template <int MODE>
+    static Wave2LaunchFn lookup(int G, int C, int DP, int LQ) {
+#define X_LU(G_, C_, D_) GPSIG_W2_PICK(launch, G_, C_, D_)
+        GPSIG_WAVE_SHAPES(X_LU)
 #undef X_LU
-    return nullptr;
-}
+        return nullptr;
+    }
+};
 #endif
 
 template <int MODE>

@@ -186,17 +186,19 @@ struct LamContractArgs {
     int nslices;                           // partner sequences are dealt round-robin to gridDim.y slices
 };
 
-template <int DP, int SIDE>
+// KIND >= 0 fixes the base kernel at compile time (-1: A.kind); NODIFF: MODE_PT_NODIFF (Gam = Lam).
+template <int DP, int SIDE, int KIND, bool NODIFF>
 __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs A) {
     extern __shared__ double part[];       // one partner sequence: Lp x DP, then its Lp squared norms
-    const int dr = A.mode == MODE_PT_NODIFF ? 0 : 1;
+    constexpr int dr = NODIFF ? 0 : 1;
+    const int kind = KIND >= 0 ? KIND : A.kind;
     const int R1 = A.L1 - dr, R2 = A.L2 - dr;
     const int Lt = SIDE == 0 ? A.L1 : A.L2, Lp = SIDE == 0 ? A.L2 : A.L1;
     const int64_t tseq = (SIDE == 0 ? A.i0 : A.j0) + blockIdx.x;          // target sequence
     const double* T = SIDE == 0 ? A.X : A.Y;
     const double* P = SIDE == 0 ? A.Y : A.X;
     const int64_t np = A.diag ? 1 : (SIDE == 0 ? A.nj : A.ni);
-    const bool nodiff = A.mode == MODE_PT_NODIFF;
+    constexpr bool nodiff = NODIFF;
     double* pnorm = part + Lp * DP;
     double gp0 = 0.0;
     for (int tp0 = 0; tp0 < Lt; tp0 += blockDim.x) {                      // target points in tiles of blockDim.x
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs
 #pragma unroll
                     for (int f = 0; f < DP; ++f) in = fma(xt[f], yq[f], in);
                     // derivative with respect to the target point; base_eval_grad's first argument is x
-                    const BaseGrad g = SIDE == 0 ? base_eval_grad(A.kind, in, ts, ps, A.p0, A.p1) : base_eval_grad(A.kind, in, ps, ts, A.p0, A.p1);
+                    const BaseGrad g = SIDE == 0 ? base_eval_grad(kind, in, ts, ps, A.p0, A.p1) : base_eval_grad(kind, in, ps, ts, A.p0, A.p1);
                     const double w = gam * (g.cy - g.cd);
                     accs = fma(gam, (SIDE == 0 ? g.cx : g.cx2) + g.cd, accs);
                     if (SIDE == 0) gp0 = fma(gam, g.dp0, gp0);
@@ -416,9 +418,12 @@ __global__ void __launch_bounds__(64) seq_grad_wave2_kernel(const Wave2Args A) {
 // The sweeps of seq_grad_wave2_kernel with the kernel derivative left out: the backward sweep stores Lam of every pair, and
 // lam_contract_kernel turns it into the gradient of both sides.  Per lane this keeps the points of C + 1 columns and the
 // recursion state only, so the 16-lane shapes that hold 4 pairs per wavefront fit for every base kernel.
-template <int G, int C, int DP, int LQ, int MODE, bool MX = false>
+// KIND >= 0 fixes the base kernel at compile time: the C + 1 evaluations of a row then interleave instead of queueing behind a
+// switch (1024 x 1024 RBF Gram: 56 -> 34 ms for the sweeps).
+template <int G, int C, int DP, int LQ, int MODE, bool MX = false, int KIND = -1>
 __global__ void __launch_bounds__(64) seq_lam_undo_kernel(const Wave2Args A) {
     extern __shared__ double w2_sm[];
+    const int kind = KIND >= 0 ? KIND : A.kind;
     constexpr int PW = 64 / G;
     const int lane = threadIdx.x, ln = lane % G, gw = lane / G;
     const int dr = MODE == MODE_PT_NODIFF ? 0 : 1;
@@ -460,7 +465,7 @@ __global__ void __launch_bounds__(64) seq_lam_undo_kernel(const Wave2Args A) {
         double xn[DP];
         if (MODE != MODE_PT_NODIFF) {
             wave_load_point<DP>(A.S, s, A.LS, A.d, 0, xn);
-            dmg.prime(xn, A.kind, A.p0, A.p1);
+            dmg.prime(xn, kind, A.p0, A.p1);
         }
         wave_load_point<DP>(A.S, s, A.LS, A.d, 0 - ln + dr, xn);           // row of step 0
         for (int t = 0; t < TF; ++t) {
@@ -472,7 +477,7 @@ __global__ void __launch_bounds__(64) seq_lam_undo_kernel(const Wave2Args A) {
             wave_load_point<DP>(A.S, s, A.LS, A.d, a + 1 + dr, xnext);     // prefetch the row of step t+1
             if (a >= 0 && a < R1) {
                 double dm[C];
-                dmg.row(xn, true, A.kind, A.p0, A.p1, dm);
+                dmg.row(xn, true, kind, A.p0, A.p1, dm);
                 fw.step(dm, cin, M);
                 if (ln == last_lane) {
 #pragma unroll
@@ -488,7 +493,7 @@ __global__ void __launch_bounds__(64) seq_lam_undo_kernel(const Wave2Args A) {
         if (MODE != MODE_PT_NODIFF) {
             double xl[DP];
             wave_load_point<DP>(A.S, s, A.LS, A.d, R1, xl);
-            dmg.prime(xl, A.kind, A.p0, A.p1);
+            dmg.prime(xl, kind, A.p0, A.p1);
         }
         double* lamrow = A.lam + size_t(A.diag ? sl : sl * A.nj + tk.y0) * R1 * R2;
         wave_load_point<DP>(A.S, s, A.LS, A.d, R1 - 1 + (G - 1 - ln), xn);   // row of step 0 (out of range -> zeros)
@@ -505,7 +510,7 @@ __global__ void __launch_bounds__(64) seq_lam_undo_kernel(const Wave2Args A) {
                 double dm[C], rtv[LQ], lv[C];
 #pragma unroll
                 for (int p = 0; p < LQ; ++p) rtv[p] = rt[a * LQ + p];
-                dmg.row(xn, false, A.kind, A.p0, A.p1, dm);
+                dmg.row(xn, false, kind, A.p0, A.p1, dm);
                 bw.step(dm, clev, rtv, sufin, svin, M, a == 0, ln == 0, lv);
                 if (have) {
 #pragma unroll
