@@ -611,7 +611,7 @@ int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void*
             const int64_t tb = (T + 63) / 64;
             int64_t slices = (1024 + tb - 1) / tb;
             if (slices > T) slices = T;
-            CHK(launch_tens_row(c, DP, E, dim3(unsigned(tb), unsigned(slices)), A));
+            CHK(launch_tens_row(c, DP, E, dim3(unsigned(tb), unsigned(slices), unsigned(M * (M + 1) / 2)), A));
         } else {
             CHK(launch_tens(c, DP, dim3(unsigned((T + 63) / 64), unsigned(T)), A));
         }

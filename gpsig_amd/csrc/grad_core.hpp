@@ -963,12 +963,14 @@ struct TensRowGrad {
             }
         return mv;
     }
-    // slices: partners t2 = slice, slice + nslices, ...
-    GPSIG_HD void run(int slice, int nslices) const {
+    // slices: partners t2 = slice, slice + nslices, ...;  comp >= 0: only component comp (the launch spreads the components
+    // over workgroups: the chain of dependent loads per wavefront is what bounds this kernel at a few hundred tensors)
+    GPSIG_HD void run(int slice, int nslices, int comp = -1) const {
         int k0 = 0;
         double gp0 = 0.0;
         for (int i = 1; i <= A.M; ++i) {
             for (int j = 0; j < i; ++j) {
+                if (comp >= 0 && k0 + j != comp) continue;
                 double za[E][DP], zas[E], acc[E][DP];
 #pragma unroll
                 for (int e = 0; e < E; ++e) {

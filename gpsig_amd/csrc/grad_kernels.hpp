@@ -262,12 +262,12 @@ __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradAr
     if (A.gbase) grad_add(&A.gbase[0], gp0, true, valid);
 }
 
-// row-owned tensor-vs-tensor gradient: grid (ceil(T / 64), slices); block 64: lanes = t
+// row-owned tensor-vs-tensor gradient: grid (ceil(T / 64), slices, components); block 64: lanes = t
 template <int DP, int E>
 __global__ void __launch_bounds__(64) tens_row_grad_kernel(const TensGradArgs A) {
     const int t = blockIdx.x * 64 + threadIdx.x;
     const bool valid = t < A.T;
-    TensRowGrad<DP, E>(A, valid ? t : 0, valid).run(blockIdx.y, gridDim.y);
+    TensRowGrad<DP, E>(A, valid ? t : 0, valid).run(blockIdx.y, gridDim.y, gridDim.z > 1 ? int(blockIdx.z) : -1);
 }
 
 // grid (ceil(T / 64), T); block 64: lanes = t2, blockIdx.y = t
