@@ -80,6 +80,10 @@ _PLAIN = {
     "gpsig_symmetrize_owned_rows": ([_vp, _i32, _vp, _i64, _vp], C.c_int),
     "gpsig_timing_reset": ([_vp], C.c_int),
     "gpsig_timing_get": ([_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)], C.c_int),
+    "gpsig_graph_begin": ([_vp], C.c_int),
+    "gpsig_graph_end": ([_vp, C.POINTER(_vp)], C.c_int),
+    "gpsig_graph_launch": ([_vp, _vp], C.c_int),
+    "gpsig_graph_destroy": ([_vp], None),
 }
 ALL_SYMBOLS = sorted(list(_KERNEL_FUNCS) + list(_PLAIN))
 
@@ -164,6 +168,15 @@ class Context:
     def sync(self):
         self.check(self._lib.gpsig_sync(self._h))
 
+    def graph(self):
+        """HIP-graph capture of the calls made in the with-block (include/gpsig_hip.h: gpsig_graph_begin):
+
+            with ctx.graph() as g:
+                ctx.call("gpsig_kernel_K", params, ...)      # recorded, not executed
+            g.launch()                                        # replays them with one launch
+        """
+        return Graph(self)
+
     def timing_reset(self):
         self.check(self._lib.gpsig_timing_reset(self._h))
 
@@ -171,6 +184,36 @@ class Context:
         ms, n, pairs = C.c_double(), _i64(), _i64()
         self.check(self._lib.gpsig_timing_get(self._h, C.byref(ms), C.byref(n), C.byref(pairs)))
         return ms.value, n.value, pairs.value
+
+
+class Graph:
+    def __init__(self, ctx):
+        self.ctx, self._g = ctx, None
+
+    def __enter__(self):
+        self.ctx.check(self.ctx._lib.gpsig_graph_begin(self.ctx._h))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        g = _vp()
+        rc = self.ctx._lib.gpsig_graph_end(self.ctx._h, C.byref(g))
+        if exc_type is None:
+            self.ctx.check(rc)
+            self._g = g
+        return False
+
+    def launch(self):
+        if self._g is None:
+            raise ValueError("the graph was not recorded")
+        self.ctx.check(self.ctx._lib.gpsig_graph_launch(self.ctx._h, self._g))
+
+    def __del__(self):
+        if getattr(self, "_g", None) is not None:
+            try:
+                self.ctx._lib.gpsig_graph_destroy(self._g)
+            except Exception:
+                pass
+            self._g = None
 
 
 _contexts = {}

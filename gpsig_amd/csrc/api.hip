@@ -138,6 +138,8 @@ SeqLaunchFn seq_launcher_ho(int mode, const SeqHOConfig& c, bool f32) {
 
 }  // namespace
 
+#include <new>
+
 #include "ctx.hpp"
 
 namespace {
@@ -185,6 +187,7 @@ int spectral_table(gpsig_ctx* c, const gpsig_params* p, const double** dev) {
     *dev = nullptr;
     if (p->base_kernel != GPSIG_BASE_SPECTRAL) return GPSIG_OK;
     const int Q = int(p->base_params[0]), d = p->num_features;
+    CHK(no_capture(c, "the spectral kernel's table is uploaded per call"));
     std::vector<double> h(size_t(Q) * (1 + 2 * SPECTRAL_STRIDE), 0.0);
     for (int q = 0; q < Q; ++q) {
         h[q] = p->base_table[q];
@@ -196,7 +199,7 @@ int spectral_table(gpsig_ctx* c, const gpsig_params* p, const double** dev) {
     void* dp;
     CHK(ensure(c, B_SPEC, sizeof(double) * h.size(), &dp));
     HIPCHK(c, hipMemcpyAsync(dp, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(host_sync(c));
     *dev = static_cast<const double*>(dp);
     return GPSIG_OK;
 }
@@ -214,9 +217,11 @@ int upload_weights(gpsig_ctx* c, const gpsig_params* p, const double** w) {
     void* d;
     CHK(ensure(c, B_W, sizeof(double) * M1, &d));
     if (c->last_weights != h) {          // unchanged hyper-parameters: the device copy is still right
+        CHK(no_capture(c, "the level weights changed"));
+        ++c->alloc_gen;                  // a recorded graph was made for the old weights
         c->last_weights.clear();
         HIPCHK(c, hipMemcpyAsync(d, h.data(), sizeof(double) * M1, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));   // h goes out of scope
+        CHK(host_sync(c));   // h goes out of scope
         c->last_weights = h;
     }
     *w = static_cast<const double*>(d);
@@ -286,7 +291,7 @@ int lr_upload(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, int 
         D->k1.push_back(sk.k1); D->k2.push_back(sk.k2);
     }
     HIPCHK(c, hipMemcpyAsync(dbase, h.data(), o, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(host_sync(c));
     (void)p;
     return GPSIG_OK;
 }
@@ -309,7 +314,7 @@ int lr_level_offsets(gpsig_ctx* c, int M, int cc, int r, const int32_t** dev_off
     void* d;
     CHK(ensure(c, B_LR1, sizeof(int32_t) * off.size(), &d));
     HIPCHK(c, hipMemcpyAsync(d, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(host_sync(c));
     *dev_off = static_cast<const int32_t*>(d);
     return GPSIG_OK;
 }
@@ -367,7 +372,7 @@ static int make_records(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling,
     void* d;
     CHK(ensure(c, id, bytes ? bytes : 8, &d));
     if (N > 0) {
-        HIPCHK(c, hipMemsetAsync(d, 0, bytes, c->stream));
+        CHK(zero_async(c, d, bytes));
         ScaleParams s = scale_of(p, apply_scaling);
         const int64_t total = N * geom->rows * s.d_eff();
         hipLaunchKernelGGL(prep_seq_records_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, c->stream,
@@ -379,7 +384,12 @@ static int make_records(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling,
     return GPSIG_OK;
 }
 
-static int timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
+// Timing covers the launches since gpsig_timing_reset, up to TIMING_MAX_EVENTS of them (a long-running caller that never
+// reads the timing must not accumulate events); *on says whether this launch is timed.  Never inside a graph capture.
+static constexpr size_t TIMING_MAX_EVENTS = 8192;
+static int timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1, bool* on) {
+    *on = false;
+    if (c->capturing || c->ev_used + 2 > TIMING_MAX_EVENTS) return GPSIG_OK;
     if (c->ev_used + 2 > c->ev.size()) {
         hipEvent_t a, b;
         HIPCHK(c, hipEventCreate(&a));
@@ -391,6 +401,7 @@ static int timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
     *e1 = c->ev[c->ev_used + 1];
     c->ev_used += 2;
     HIPCHK(c, hipEventRecord(*e0, c->stream));
+    *on = true;
     return GPSIG_OK;
 }
 
@@ -413,36 +424,29 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     // aim for ~64k independent tasks (about 20 per resident wave slot) so the tail is a few per cent
     const int64_t nblocks = (r.N2 + ypb - 1) / ypb;
     const int64_t xtot = r.pred == PRED_ALL ? r.N1 : (r.pred == PRED_DIAG ? ypb : r.N1 / 2 + ypb);
+    // ... unless the whole problem is smaller than that: then short runs, so that a small evaluation is spread over the chip
+    // instead of a few wavefronts sweeping eight pairs in a row
     int64_t max_run = (xtot * nblocks + 65535) / 65536;
-    if (max_run < 8) max_run = 8;
+    const int64_t run_floor = xtot * nblocks >= 8 * 4096 ? 8 : (xtot * nblocks / 4096 > 1 ? xtot * nblocks / 4096 : 1);
+    if (max_run < run_floor) max_run = run_floor;
     if (max_run > 256) max_run = 256;
     if (c->max_run > 0) max_run = c->max_run;
     // the task list is a function of these integers only: reuse the device copy while they stay the same
     const int64_t key[10] = {r.N1, r.N2, ypb, r.pred, max_run, c->shard_i, c->shard_n, r.y_begin, r.y_end > 0 ? r.y_end : -1, 1};
-    TaskCache& tc = r.pred == PRED_DIAG ? c->tc_diag : c->tc_main;
-    const int tbuf = r.pred == PRED_DIAG ? B_TASKS_DIAG : B_TASKS;
-    void* dt = nullptr;
-    int ntasks;
-    if (tc.match(key) && c->buf[tbuf].p) {
-        dt = c->buf[tbuf].p;
-        ntasks = tc.ntasks;
-    } else {
-        tc.valid = false;
-        c->host_tasks = seq_build_tasks(r.N1, r.N2, ypb, r.pred, int(max_run), c->shard_i, c->shard_n, r.y_begin,
-                                        r.y_end > 0 ? r.y_end : -1);
-        ntasks = int(c->host_tasks.size());
-        if (ntasks > 0) {
-            CHK(ensure(c, tbuf, sizeof(SeqTask) * size_t(ntasks), &dt));
-            HIPCHK(c, hipMemcpyAsync(dt, c->host_tasks.data(), sizeof(SeqTask) * size_t(ntasks), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));   // host_tasks is pageable and reused by the next launch
-        }
-        tc.set(key, ntasks);
-    }
+    const SeqTask* dt = nullptr;
+    int ntasks = 0;
+    int64_t npairs = 0;
+    CHK(task_list(c, key, [&](std::vector<SeqTask>& T) {
+        T = seq_build_tasks(r.N1, r.N2, ypb, r.pred, int(max_run), c->shard_i, c->shard_n, r.y_begin, r.y_end > 0 ? r.y_end : -1);
+        int64_t pairs = 0;
+        for (const SeqTask& t : T) pairs += int64_t(t.nx) * ypb;
+        return pairs;
+    }, &dt, &ntasks, &npairs));
     if (ntasks == 0) return GPSIG_OK;
 
     SeqGramArgs A;
     memset(&A, 0, sizeof(A));
-    A.xrec = r.xrec; A.yrec = r.yrec; A.tasks = static_cast<const SeqTask*>(dt);
+    A.xrec = r.xrec; A.yrec = r.yrec; A.tasks = dt;
     A.N1 = r.N1; A.N2 = r.N2;
     A.xrec_stride = r.gx.rec_elems; A.yrec_stride = r.gy.rec_elems;
     A.R1 = r.gx.rows; A.R2 = r.gy.rows; A.RS = r.gx.RS; A.M = p->num_levels; A.order = p->order;
@@ -457,14 +461,13 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     const size_t lds = sizeof(TT) * (size_t(A.RS) + size_t(A.nslot) * A.slot_elems);
     if (lds > 160 * 1024) return fail(c, GPSIG_ERR_UNSUPPORTED, "x-side records of %d rows do not fit the LDS ring (%zu bytes)", A.R1, lds);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (r.timed) CHK(timing_begin(c, &e0, &e1));
+    bool timed = false;
+    if (r.timed) CHK(timing_begin(c, &e0, &e1, &timed));
     HIPCHK(c, pl.fn(A, ntasks, lds, c->stream));
-    if (r.timed) {
+    if (timed) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
         c->t_launches += 1;
-        int64_t pairs = 0;
-        for (const SeqTask& t : c->host_tasks) pairs += int64_t(t.nx) * ypb;
-        c->t_pairs += pairs;
+        c->t_pairs += npairs;
     }
     return GPSIG_OK;
 }
@@ -769,11 +772,14 @@ static int tens_vs_seq_lanet_device(gpsig_ctx* c, const gpsig_params* p, bool ra
     base_p(p, &A.p0, &A.p1);
     A.fx = fx; A.w = w; A.out = out; A.sum_levels = (raw || return_levels) ? 0 : 1;
     hipEvent_t e0, e1;
-    CHK(timing_begin(c, &e0, &e1));
+    bool timed;
+    CHK(timing_begin(c, &e0, &e1, &timed));
     for (int g = 0; g < ngroups; ++g) HIPCHK(c, fns[g](A, c->stream));
-    HIPCHK(c, hipEventRecord(e1, c->stream));
-    c->t_launches += 1;
-    c->t_pairs += Tn * N;
+    if (timed) {
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        c->t_launches += 1;
+        c->t_pairs += Tn * N;
+    }
     return GPSIG_OK;
 }
 
@@ -813,11 +819,14 @@ static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, con
     A.fx = fx; A.w = w; A.out = out; A.sum_levels = (raw || return_levels) ? 0 : 1;
     if (N > 0 && Tn > 0) {
         hipEvent_t e0, e1;
-        CHK(timing_begin(c, &e0, &e1));
+        bool timed;
+        CHK(timing_begin(c, &e0, &e1, &timed));
         HIPCHK(c, fn(A, c->stream));
-        HIPCHK(c, hipEventRecord(e1, c->stream));
-        c->t_launches += 1;
-        c->t_pairs += Tn * N;
+        if (timed) {
+            HIPCHK(c, hipEventRecord(e1, c->stream));
+            c->t_launches += 1;
+            c->t_pairs += Tn * N;
+        }
     }
     return GPSIG_OK;
 }
@@ -1154,6 +1163,8 @@ void gpsig_ctx_destroy(gpsig_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf& b : c->buf)
         if (b.p) (void)hipFree(b.p);
+    for (TaskSlot& t : c->task_slots)
+        if (t.buf.p) (void)hipFree(t.buf.p);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
 }
@@ -1169,7 +1180,7 @@ int gpsig_set_pointer_mode(gpsig_ctx* c, int mode) {
 
 int gpsig_sync(gpsig_ctx* c) {
     if (!c) return GPSIG_ERR_INVALID;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(host_sync(c));
     return GPSIG_OK;
 }
 
@@ -1194,9 +1205,66 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     return GPSIG_OK;
 }
 
+int gpsig_graph_begin(gpsig_ctx* c) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (c->capturing) return fail(c, GPSIG_ERR_INVALID, "a graph capture is already open on this context");
+    if (c->ptr_mode != GPSIG_PTR_DEVICE) return fail(c, GPSIG_ERR_INVALID, "graph capture needs device-pointer mode (gpsig_set_pointer_mode)");
+    if (c->stream == nullptr) return fail(c, GPSIG_ERR_INVALID, "the default stream cannot be captured: create the context on a stream of its own");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    c->capturing = true;
+    c->capture_failed = false;
+    return GPSIG_OK;
+}
+
+int gpsig_graph_end(gpsig_ctx* c, gpsig_graph** out) {
+    if (!c || !out) return GPSIG_ERR_INVALID;
+    *out = nullptr;
+    if (!c->capturing) return fail(c, GPSIG_ERR_INVALID, "no graph capture is open on this context");
+    c->capturing = false;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (c->capture_failed) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        // c->err still holds what the failing call reported
+        return GPSIG_ERR_INVALID;
+    }
+    if (e != hipSuccess || !g) return fail(c, GPSIG_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    gpsig_graph* G = new (std::nothrow) gpsig_graph();
+    if (!G) { (void)hipGraphDestroy(g); return fail(c, GPSIG_ERR_NOMEM, "out of host memory"); }
+    G->graph = g; G->ctx = c; G->alloc_gen = c->alloc_gen;
+    const hipError_t ei = hipGraphInstantiate(&G->exec, g, nullptr, nullptr, 0);
+    if (ei != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        delete G;
+        return fail(c, GPSIG_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+    }
+    *out = G;
+    return GPSIG_OK;
+}
+
+int gpsig_graph_launch(gpsig_ctx* c, gpsig_graph* G) {
+    if (!c || !G) return GPSIG_ERR_INVALID;
+    if (G->ctx != c) return fail(c, GPSIG_ERR_INVALID, "the graph was recorded on another context");
+    if (c->capturing) return fail(c, GPSIG_ERR_INVALID, "a graph capture is open on this context");
+    if (G->alloc_gen != c->alloc_gen)
+        return fail(c, GPSIG_ERR_INVALID, "scratch buffers moved since the graph was recorded (a later call needed more memory, other task lists or other level weights): record it again");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipGraphLaunch(G->exec, c->stream));
+    return GPSIG_OK;
+}
+
+void gpsig_graph_destroy(gpsig_graph* G) {
+    if (!G) return;
+    if (G->exec) (void)hipGraphExecDestroy(G->exec);
+    if (G->graph) (void)hipGraphDestroy(G->graph);
+    delete G;
+}
+
 int gpsig_timing_reset(gpsig_ctx* c) {
     if (!c) return GPSIG_ERR_INVALID;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(host_sync(c));
     c->ev_used = 0;
     c->t_launches = 0;
     c->t_pairs = 0;
@@ -1205,7 +1273,7 @@ int gpsig_timing_reset(gpsig_ctx* c) {
 
 int gpsig_timing_get(gpsig_ctx* c, double* kernel_ms, int64_t* launches, int64_t* pairs) {
     if (!c) return GPSIG_ERR_INVALID;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(host_sync(c));
     double tot = 0.0;
     for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
         float ms = 0.f;
@@ -1321,7 +1389,7 @@ int gpsig_lr_gather_points(gpsig_ctx* c, const gpsig_params* p, const void* X, i
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(out_host, dout, sizeof(double) * size_t(R) * d_eff, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(host_sync(c));
     return GPSIG_OK;
 }
 
@@ -1346,7 +1414,7 @@ int gpsig_base_kernel_matrix(gpsig_ctx* c, const gpsig_params* p, const double* 
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(out_host, dout, sizeof(double) * size_t(na) * nb, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(host_sync(c));
     return GPSIG_OK;
 }
 
@@ -1389,7 +1457,7 @@ int gpsig_lr_seq_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowra
         for (int a = 0; a < cc; ++a)
             for (int b = 0; b < cc; ++b) t[size_t(b) * cc + a] = lr->whitening[size_t(a) * cc + b];
         HIPCHK(c, hipMemcpyAsync(wht, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        CHK(host_sync(c));
     }
     CHK(lr_gemm(c, static_cast<const double*>(kxs), static_cast<const double*>(wht), N * L, cc, cc, cc, cc, static_cast<double*>(feat), cc));
     // level 0 and level 1 (signature_algs.py:177-182)
@@ -1464,7 +1532,7 @@ int gpsig_lr_tens_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowr
         for (int a = 0; a < cc; ++a)
             for (int b = 0; b < cc; ++b) t[size_t(b) * cc + a] = lr->whitening[size_t(a) * cc + b];
         HIPCHK(c, hipMemcpyAsync(wht, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        CHK(host_sync(c));
     }
     hipLaunchKernelGGL(lr_tens_cross_kernel<double>, dim3(grid_for(rows * cc)), dim3(256), 0, c->stream, static_cast<const double*>(dZ), rows,
                        s, D.S, cc, int(p->base_kernel), p0, p1, static_cast<double*>(kxs));

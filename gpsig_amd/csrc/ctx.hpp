@@ -29,7 +29,6 @@ enum BufId {
     B_LR0, B_LR1, B_LR2, B_LR3, B_LR4, B_LR5, B_LR6, B_LR7, B_LR8,
     B_GR0, B_GR1, B_GR2, B_GR3, B_GR4, B_GR5, B_GR6, B_GR7,   // gradient path scratch
     B_SPEC,                                                    // spectral base-kernel table
-    B_TASKS_DIAG, B_TASKS_W2A, B_TASKS_W2B,                    // task lists that stay valid across calls (see TaskCache)
     B_COUNT
 };
 
@@ -49,6 +48,14 @@ struct TaskCache {
     void set(const int64_t (&k)[10], int n) { for (int i = 0; i < 10; ++i) key[i] = k[i]; ntasks = n; valid = true; }
 };
 
+struct TaskSlot {
+    TaskCache tc;
+    DevBuf buf;
+    uint64_t stamp = 0;
+    int64_t aux = 0;             // what the builder returned (the number of pairs the list covers)
+};
+constexpr size_t TASK_SLOTS = 16;
+
 struct gpsig_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -65,13 +72,23 @@ struct gpsig_ctx {
     std::string err;
     DevBuf buf[B_COUNT];
     std::vector<gpsig::SeqTask> host_tasks;
-    TaskCache tc_main, tc_diag, tc_w2a, tc_w2b;
-    int w2_flip = 0;
+    std::vector<TaskSlot> task_slots;      // device-resident task lists, least recently used one replaced (task_list())
+    uint64_t task_clock = 0;
     std::vector<double> last_weights;      // what B_W currently holds
     // timing of the pair-recursion launches
     std::vector<hipEvent_t> ev;     // pairs (start, stop)
     size_t ev_used = 0;
     int64_t t_launches = 0, t_pairs = 0;
+    // HIP-graph capture (gpsig_graph_begin .. gpsig_graph_end): launches only -- nothing may allocate, upload or synchronise
+    bool capturing = false, capture_failed = false;
+    uint64_t alloc_gen = 0;         // bumped whenever a scratch buffer moves; a graph replays only against the generation it saw
+};
+
+struct gpsig_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t alloc_gen = 0;
+    gpsig_ctx* ctx = nullptr;
 };
 
 inline int fail(gpsig_ctx* c, int code, const char* fmt, ...) {
@@ -95,11 +112,54 @@ inline int fail(gpsig_ctx* c, int code, const char* fmt, ...) {
         if (rc__ != GPSIG_OK) return rc__; \
     } while (0)
 
+// what a call needs the host for; inside a graph capture that is an error (the call was not run with these shapes and
+// hyper-parameters before the capture began)
+inline int no_capture(gpsig_ctx* c, const char* what) {
+    if (!c->capturing) return GPSIG_OK;
+    c->capture_failed = true;
+    return fail(c, GPSIG_ERR_INVALID, "graph capture: %s -- run the same calls once before gpsig_graph_begin", what);
+}
+
+// Zero fill on the ctx stream.  Inside a graph capture a kernel does it: memset nodes were seen to run out of order with the
+// kernel nodes around them when a recorded graph is replayed (ROCm 7.2), which left zeroed records behind a finished prep kernel.
+#ifdef __HIPCC__
+static __global__ void zero_fill_kernel(unsigned long long* p, size_t n8, unsigned char* tail, int ntail) {
+    const size_t stride = size_t(gridDim.x) * blockDim.x;
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n8; i += stride) p[i] = 0ull;
+    if (blockIdx.x == 0 && int(threadIdx.x) < ntail) tail[threadIdx.x] = 0;
+}
+#endif
+inline int zero_async(gpsig_ctx* c, void* p, size_t bytes) {
+    if (!bytes) return GPSIG_OK;
+#ifdef __HIPCC__
+    if (c->capturing && (reinterpret_cast<uintptr_t>(p) & 7) == 0) {
+        const size_t n8 = bytes / 8;
+        size_t g = (n8 + 255) / 256;
+        if (g < 1) g = 1;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(unsigned(g)), dim3(256), 0, c->stream, static_cast<unsigned long long*>(p), n8,
+                           static_cast<unsigned char*>(p) + n8 * 8, int(bytes - n8 * 8));
+        HIPCHK(c, hipGetLastError());
+        return GPSIG_OK;
+    }
+#endif
+    HIPCHK(c, hipMemsetAsync(p, 0, bytes, c->stream));
+    return GPSIG_OK;
+}
+
+inline int host_sync(gpsig_ctx* c) {
+    CHK(no_capture(c, "the call has to wait for the stream"));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GPSIG_OK;
+}
+
 inline int ensure(gpsig_ctx* c, int id, size_t bytes, void** out) {
     DevBuf& b = c->buf[id];
     if (bytes > b.cap) {
+        CHK(no_capture(c, "a scratch buffer has to grow"));
+        ++c->alloc_gen;
         if (b.p) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));   // nothing in flight may still use the old block
+            CHK(host_sync(c));   // nothing in flight may still use the old block
             HIPCHK(c, hipFree(b.p));
             b.p = nullptr;
             b.cap = 0;
@@ -110,6 +170,53 @@ inline int ensure(gpsig_ctx* c, int id, size_t bytes, void** out) {
         b.cap = want;
     }
     *out = b.p;
+    return GPSIG_OK;
+}
+
+// Device copy of the task list identified by `key` (its defining integers, key[9] = which builder).  On a miss `build` fills
+// c->host_tasks (returning a number kept with the list) and the list is uploaded into the least recently used slot.  *tasks is null for an empty list.
+template <typename Build>
+inline int task_list(gpsig_ctx* c, const int64_t (&key)[10], Build build, const gpsig::SeqTask** tasks, int* ntasks, int64_t* aux = nullptr) {
+    TaskSlot* slot = nullptr;
+    for (TaskSlot& s : c->task_slots)
+        if (s.tc.match(key)) { slot = &s; break; }
+    if (!slot) {
+        CHK(no_capture(c, "a task list has to be built and uploaded"));
+        if (c->task_slots.size() < TASK_SLOTS) {
+            if (c->task_slots.capacity() < TASK_SLOTS) c->task_slots.reserve(TASK_SLOTS);
+            c->task_slots.emplace_back();
+            slot = &c->task_slots.back();
+        } else {
+            slot = &c->task_slots[0];
+            for (TaskSlot& s : c->task_slots)
+                if (s.stamp < slot->stamp) slot = &s;
+        }
+        slot->tc.valid = false;
+        ++c->alloc_gen;                          // a recorded graph may still point at what this slot held
+        slot->aux = build(c->host_tasks);
+        const size_t n = c->host_tasks.size(), bytes = sizeof(gpsig::SeqTask) * n + 64;
+        if (bytes > slot->buf.cap) {
+            if (slot->buf.p) {
+                CHK(host_sync(c));
+                HIPCHK(c, hipFree(slot->buf.p));
+                slot->buf.p = nullptr;
+                slot->buf.cap = 0;
+            }
+            const size_t want = bytes + bytes / 8 + 256;
+            hipError_t e = hipMalloc(&slot->buf.p, want);
+            if (e != hipSuccess) return fail(c, GPSIG_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+            slot->buf.cap = want;
+        }
+        if (n) {
+            HIPCHK(c, hipMemcpyAsync(slot->buf.p, c->host_tasks.data(), sizeof(gpsig::SeqTask) * n, hipMemcpyHostToDevice, c->stream));
+            CHK(host_sync(c));                   // host_tasks is pageable and reused by the next call
+        }
+        slot->tc.set(key, int(n));
+    }
+    slot->stamp = ++c->task_clock;
+    *ntasks = slot->tc.ntasks;
+    if (aux) *aux = slot->aux;
+    *tasks = *ntasks ? static_cast<const gpsig::SeqTask*>(slot->buf.p) : nullptr;
     return GPSIG_OK;
 }
 
@@ -134,7 +241,7 @@ inline int out_done(gpsig_ctx* c, void* user, const void* dev, size_t bytes) {
     return GPSIG_OK;
 }
 inline int finish(gpsig_ctx* c) {
-    if (c->ptr_mode == GPSIG_PTR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ptr_mode == GPSIG_PTR_HOST) CHK(host_sync(c));
     return GPSIG_OK;
 }
 

@@ -150,7 +150,7 @@ int64_t pad64(int64_t n) { return (n + 63) / 64 * 64; }
 int gbase_begin(gpsig_ctx* c, double** dev) {
     void* p;
     CHK(ensure(c, B_GR7, 2 * sizeof(double), &p));
-    HIPCHK(c, hipMemsetAsync(p, 0, 2 * sizeof(double), c->stream));
+    CHK(zero_async(c, p, 2 * sizeof(double)));
     *dev = static_cast<double*>(p);
     return GPSIG_OK;
 }
@@ -200,8 +200,8 @@ int seq_grad_wave(gpsig_ctx* c, const gpsig_params* p, WaveLaunchFn fn, int G, i
                   int64_t N2, int L1, int L2, int d, bool diag, bool sym, const double* Gup, double* gX, double* gY, double* gbase) {
     const int M = p->num_levels, dr = mode == MODE_PT_NODIFF ? 0 : 1;
     const int R1 = L1 - dr, R2 = L2 - dr, TF = R1 + G - 1, PW = 64 / G;
-    HIPCHK(c, hipMemsetAsync(gX, 0, sizeof(double) * size_t(N1) * L1 * d, c->stream));
-    if (!diag && !sym) HIPCHK(c, hipMemsetAsync(gY, 0, sizeof(double) * size_t(N2) * L2 * d, c->stream));
+    CHK(zero_async(c, gX, sizeof(double) * size_t(N1) * L1 * d));
+    if (!diag && !sym) CHK(zero_async(c, gY, sizeof(double) * size_t(N2) * L2 * d));
     if (R1 <= 0 || R2 <= 0) return GPSIG_OK;                 // empty lattice: the levels do not depend on the data
     const size_t per_pair = sizeof(double) * size_t(R1) * R2;
     const int64_t row_pairs = diag ? 1 : N2;
@@ -277,38 +277,21 @@ size_t wave2_lds(int G, int R1, int M) { return sizeof(double) * size_t(64 / G) 
 constexpr size_t WAVE2_LDS_MAX = 64 * 1024;
 
 // tasks of the scratch-free kernels: one register-side sequence (0 .. NR) x a run of streamed sequences (0 .. NS); diag: (r, r).
-// Two cached lists: a cross Gram alternates between its two sides.
 int wave2_tasks(gpsig_ctx* c, int64_t NS, int64_t NR, bool diag, const SeqTask** tasks, size_t* ntasks_out) {
     int64_t run = diag ? 1 : (NS * NR + 16383) / 16384;
     if (run < 1) run = 1;
     if (run > NS) run = NS;
     const int64_t key[10] = {NS, NR, run, diag ? 1 : 0, 0, 0, 0, 0, 0, 2};
-    TaskCache* tc = c->tc_w2a.match(key) ? &c->tc_w2a : (c->tc_w2b.match(key) ? &c->tc_w2b : nullptr);
-    int tbuf = tc == &c->tc_w2a ? B_TASKS_W2A : B_TASKS_W2B;
-    void* dt;
-    size_t ntasks;
-    if (tc && c->buf[tbuf].p) {
-        dt = c->buf[tbuf].p;
-        ntasks = size_t(tc->ntasks);
-    } else {
-        c->w2_flip ^= 1;
-        tc = c->w2_flip ? &c->tc_w2a : &c->tc_w2b;
-        tbuf = c->w2_flip ? B_TASKS_W2A : B_TASKS_W2B;
-        tc->valid = false;
-        std::vector<SeqTask>& T = c->host_tasks;
+    int n = 0;
+    CHK(task_list(c, key, [&](std::vector<SeqTask>& T) {
         T.clear();
         for (int64_t r = 0; r < NR; ++r) {
             if (diag) { T.push_back(SeqTask{int32_t(r), int32_t(r), 1}); continue; }
             for (int64_t x0 = 0; x0 < NS; x0 += run) T.push_back(SeqTask{int32_t(r), int32_t(x0), int32_t(NS - x0 < run ? NS - x0 : run)});
         }
-        ntasks = T.size();
-        CHK(ensure(c, tbuf, sizeof(SeqTask) * ntasks + 64, &dt));
-        HIPCHK(c, hipMemcpyAsync(dt, T.data(), sizeof(SeqTask) * ntasks, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));         // host_tasks is reused by the next call
-        tc->set(key, int(ntasks));
-    }
-    *tasks = static_cast<const SeqTask*>(dt);
-    *ntasks_out = ntasks;
+        return int64_t(0);
+    }, tasks, &n));
+    *ntasks_out = size_t(n);
     return GPSIG_OK;
 }
 
@@ -356,8 +339,8 @@ int seq_grad_undo(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, 
                   int64_t N2, int L1, int L2, int d, bool diag, bool sym, const double* Gup, double* gX, double* gY, double* gbase) {
     const int M = p->num_levels, dr = mode == MODE_PT_NODIFF ? 0 : 1, PW = 64 / G;
     const int R1 = L1 - dr, R2 = L2 - dr;
-    HIPCHK(c, hipMemsetAsync(gX, 0, sizeof(double) * size_t(N1) * L1 * d, c->stream));
-    if (!diag && !sym) HIPCHK(c, hipMemsetAsync(gY, 0, sizeof(double) * size_t(N2) * L2 * d, c->stream));
+    CHK(zero_async(c, gX, sizeof(double) * size_t(N1) * L1 * d));
+    if (!diag && !sym) CHK(zero_async(c, gY, sizeof(double) * size_t(N2) * L2 * d));
     if (R1 <= 0 || R2 <= 0) return GPSIG_OK;                 // empty lattice: the levels do not depend on the data
     const size_t per_pair = sizeof(double) * size_t(R1) * R2;
     Wave2Args A;
@@ -450,12 +433,12 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     int lG = 0, lC = 0;
     if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, p->base_kernel, L1 - drr, L2 - drr, DP, M, &lG, &lC);
     if (N1 == 0 || N2 == 0) {
-        if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
-        if (dgY && yb) HIPCHK(c, hipMemsetAsync(dgY, 0, yb, c->stream));
+        if (xb) CHK(zero_async(c, dgX, xb));
+        if (dgY && yb) CHK(zero_async(c, dgY, yb));
     } else if (w2x) {
         const double* Xd = static_cast<const double*>(dX);
         const double* Gd = static_cast<const double*>(dG);
-        HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
+        CHK(zero_async(c, dgX, xb));
         if (diag) {
             // both roles of the pair (x_i, x_i) have the same derivative: twice the register-side gradient
             CHK(wave2_side(c, p, w2x, w2xG, mode, Xd, Xd, static_cast<double*>(dgX), N1, N1, L1, L1, d, true, Gd, N1, 1, 0, false, 2.0, dgb, 0.5));
@@ -464,7 +447,7 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
             CHK(wave2_side(c, p, w2x, w2xG, mode, Xd, Xd, static_cast<double*>(dgX), N1, N1, L1, L1, d, false, Gd, N1 * N1, N1, 1, true, 1.0, dgb, 0.5));
         } else {
             const double* Yd = static_cast<const double*>(dY);
-            HIPCHK(c, hipMemsetAsync(dgY, 0, yb, c->stream));
+            CHK(zero_async(c, dgY, yb));
             CHK(wave2_side(c, p, w2y, w2yG, mode, Xd, Yd, static_cast<double*>(dgY), N1, N2, L1, L2, d, false, Gd, N1 * N2, N2, 1, false, 1.0, dgb, 1.0));
             CHK(wave2_side(c, p, w2x, w2xG, mode, Yd, Xd, static_cast<double*>(dgX), N2, N1, L2, L1, d, false, Gd, N1 * N2, 1, N2, false, 1.0, nullptr, 0.0));
         }
@@ -481,12 +464,12 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
         CHK(ensure(c, B_GR0, xtb, &xT));
         CHK(ensure(c, B_GR2, xtb, &gxT));
         CHK(to_timemajor(c, static_cast<const double*>(dX), static_cast<double*>(xT), N1, L1, d, DP, s1));
-        HIPCHK(c, hipMemsetAsync(gxT, 0, xtb, c->stream));
+        CHK(zero_async(c, gxT, xtb));
         if (!diag && !sym) {
             CHK(ensure(c, B_GR1, ytb, &yT));
             CHK(ensure(c, B_GR3, ytb, &gyT));
             CHK(to_timemajor(c, static_cast<const double*>(dY), static_cast<double*>(yT), N2, L2, d, DP, s2));
-            HIPCHK(c, hipMemsetAsync(gyT, 0, ytb, c->stream));
+            CHK(zero_async(c, gyT, ytb));
         }
         const int dr = mode == MODE_PT_NODIFF ? 0 : 1;
         const int R1 = L1 - dr, R2 = L2 - dr;
@@ -599,7 +582,7 @@ int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void*
         CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
         CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
         CHK(pad_rows(c, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
-        HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
+        CHK(zero_async(c, gzp, sizeof(double) * size_t(rows) * DP));
         TensGradArgs A;
         memset(&A, 0, sizeof(A));
         A.z = static_cast<const double*>(zp); A.gz = static_cast<double*>(gzp);
@@ -643,15 +626,15 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     double* dgb;
     CHK(gbase_begin(c, &dgb));
     if (T == 0 || N == 0) {
-        if (zb) HIPCHK(c, hipMemsetAsync(dgZ, 0, zb, c->stream));
-        if (xb) HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
+        if (zb) CHK(zero_async(c, dgZ, zb));
+        if (xb) CHK(zero_async(c, dgX, xb));
     } else if (c->grad_impl == 0 && tvs_lanet_available(c, DP, M, L)) {
         void *zp, *gzp;
         CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
         CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
         CHK(pad_z(c, collapse, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
-        HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
-        HIPCHK(c, hipMemsetAsync(dgX, 0, xb, c->stream));
+        CHK(zero_async(c, gzp, sizeof(double) * size_t(rows) * DP));
+        CHK(zero_async(c, dgX, xb));
         TvsLaneTGradArgs A;
         memset(&A, 0, sizeof(A));
         A.z = static_cast<const double*>(zp); A.gz = static_cast<double*>(gzp);
@@ -679,8 +662,8 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         CHK(ensure(c, B_GR3, xtb, &gxT));
         CHK(pad_z(c, collapse, static_cast<const double*>(dZ), static_cast<double*>(zp), rows, d, DP));
         CHK(to_timemajor(c, static_cast<const double*>(dX), static_cast<double*>(xT), N, L, d, DP, s));
-        HIPCHK(c, hipMemsetAsync(gzp, 0, sizeof(double) * size_t(rows) * DP, c->stream));
-        HIPCHK(c, hipMemsetAsync(gxT, 0, xtb, c->stream));
+        CHK(zero_async(c, gzp, sizeof(double) * size_t(rows) * DP));
+        CHK(zero_async(c, gxT, xtb));
         const int R = p->difference ? L - 1 : L;
         const bool fused = c->grad_impl != 1 && tvs_fused_available(DP, M, E);     // grad_impl 2: one pair per thread, scratch-free
         const size_t per_t = sizeof(double) * size_t(lt + M * (M - 1) / 2) * size_t(R > 0 ? R : 0) * size_t(s);

@@ -102,9 +102,26 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "tvs_zreg"    tensor-lane gradient: components in registers (1) or LDS (0), -1 automatic */
 int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
 /* HIP-event timing of the dominant kernel (the pair recursion) launched by the calls since the last
- * reset, measured on the ctx stream: total milliseconds and number of launches. */
+ * reset, measured on the ctx stream: total milliseconds and number of launches (the first 4096 timed
+ * launches after a reset; none inside a graph capture). */
 int gpsig_timing_reset(gpsig_ctx* ctx);
 int gpsig_timing_get(gpsig_ctx* ctx, double* kernel_ms, int64_t* launches, int64_t* pairs);
+
+/* ---- HIP graphs for launch-bound evaluations (no reference analogue) -------------------------------------
+ * An end-to-end evaluation is 5-15 short kernels.  The calls made between gpsig_graph_begin and gpsig_graph_end are
+ * recorded from the ctx stream instead of executed; gpsig_graph_launch replays them with one launch, reading and writing
+ * the same device buffers (refresh the inputs in place).  What it saves is host time per evaluation; the device time of a
+ * small evaluation is the serial sweep of one pair's lattice and is the same either way (profiles/r01_graph_latency.txt).
+ * Conditions, all checked: device-pointer mode; a context created on a stream of its own (not the default stream);
+ * every recorded call was made once before with the same shapes and
+ * hyper-parameters on this ctx (so that scratch buffers, task lists and level weights are in place -- a call that would
+ * allocate, upload or wait fails with GPSIG_ERR_INVALID and the capture ends); a graph is replayable until a later call
+ * moves a scratch buffer (gpsig_graph_launch then returns GPSIG_ERR_INVALID: capture again). */
+typedef struct gpsig_graph gpsig_graph;
+int gpsig_graph_begin(gpsig_ctx* ctx);
+int gpsig_graph_end(gpsig_ctx* ctx, gpsig_graph** out);
+int gpsig_graph_launch(gpsig_ctx* ctx, gpsig_graph* graph);
+void gpsig_graph_destroy(gpsig_graph* graph);
 
 /* ---- unnormalised level tensors (the signature_algs.py layer) ----------------------------- */
 /* SignatureKernel._K_seq (kernels.py:208-237) -> signature_kern_first_order / _higher_order
