@@ -418,6 +418,8 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     if (!diag && !sym) CHK(out_dev(c, B_OUT1, gY, yb, &dgY));
     double* dgb;
     CHK(gbase_begin(c, &dgb));
+    // kernels without a differentiable base parameter skip the accumulation (one same-address atomic per wavefront otherwise)
+    double* const kgb = (p->base_kernel == GPSIG_BASE_POLY || p->base_kernel == GPSIG_BASE_MIX) ? dgb : nullptr;
     WaveLaunchFn wfn = nullptr;
     Wave2LaunchFn w2x = nullptr, w2y = nullptr;            // scratch-free kernels with x resp. y as the register-resident side
     int wG = 0, wC = 0, w2xG = 0, w2xC = 0, w2yG = 0, w2yC = 0;
@@ -441,22 +443,22 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
         CHK(zero_async(c, dgX, xb));
         if (diag) {
             // both roles of the pair (x_i, x_i) have the same derivative: twice the register-side gradient
-            CHK(wave2_side(c, p, w2x, w2xG, mode, Xd, Xd, static_cast<double*>(dgX), N1, N1, L1, L1, d, true, Gd, N1, 1, 0, false, 2.0, dgb, 0.5));
+            CHK(wave2_side(c, p, w2x, w2xG, mode, Xd, Xd, static_cast<double*>(dgX), N1, N1, L1, L1, d, true, Gd, N1, 1, 0, false, 2.0, kgb, 0.5));
         } else if (sym) {
             // k(x_s, x_r) = k(x_r, x_s): the gradient of x_r collects G[s][r] + G[r][s] over all s
-            CHK(wave2_side(c, p, w2x, w2xG, mode, Xd, Xd, static_cast<double*>(dgX), N1, N1, L1, L1, d, false, Gd, N1 * N1, N1, 1, true, 1.0, dgb, 0.5));
+            CHK(wave2_side(c, p, w2x, w2xG, mode, Xd, Xd, static_cast<double*>(dgX), N1, N1, L1, L1, d, false, Gd, N1 * N1, N1, 1, true, 1.0, kgb, 0.5));
         } else {
             const double* Yd = static_cast<const double*>(dY);
             CHK(zero_async(c, dgY, yb));
-            CHK(wave2_side(c, p, w2y, w2yG, mode, Xd, Yd, static_cast<double*>(dgY), N1, N2, L1, L2, d, false, Gd, N1 * N2, N2, 1, false, 1.0, dgb, 1.0));
+            CHK(wave2_side(c, p, w2y, w2yG, mode, Xd, Yd, static_cast<double*>(dgY), N1, N2, L1, L2, d, false, Gd, N1 * N2, N2, 1, false, 1.0, kgb, 1.0));
             CHK(wave2_side(c, p, w2x, w2xG, mode, Yd, Xd, static_cast<double*>(dgX), N2, N1, L2, L1, d, false, Gd, N1 * N2, 1, N2, false, 1.0, nullptr, 0.0));
         }
     } else if (lfn) {
         CHK(seq_grad_undo(c, p, lfn, lG, DP, mode, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, d,
-                          diag, sym, static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), dgb));
+                          diag, sym, static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), kgb));
     } else if (wfn) {
         CHK(seq_grad_wave(c, p, wfn, wG, wC, DP, mode, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, d,
-                          diag, sym, static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), dgb));
+                          diag, sym, static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), kgb));
     } else {
         const int64_t s1 = pad64(N1), s2 = pad64(N2);
         void *xT, *yT = nullptr, *gxT, *gyT = nullptr;
@@ -496,7 +498,7 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
         A.gm = diag ? N1 : N1 * N2; A.gi = diag ? 1 : N2; A.gj = diag ? 0 : 1;
         A.scratch = static_cast<double*>(scr);
         A.levels = nullptr;
-        A.gbase = dgb;
+        A.gbase = kgb;
         const unsigned gx_ = unsigned(s1 / 64);
         if (diag) {
             A.j0 = 0; A.nj = 1; A.pairs = s1;
@@ -577,6 +579,8 @@ int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void*
     CHK(out_dev(c, B_OUT0, gZ, zb, &dgZ));
     double* dgb;
     CHK(gbase_begin(c, &dgb));
+    // kernels without a differentiable base parameter skip the accumulation (one same-address atomic per wavefront otherwise)
+    double* const kgb = (p->base_kernel == GPSIG_BASE_POLY || p->base_kernel == GPSIG_BASE_MIX) ? dgb : nullptr;
     if (T > 0) {
         void *zp, *gzp;
         CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
@@ -589,12 +593,19 @@ int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void*
         A.T = int(T); A.M = M; A.kind = p->base_kernel; A.incr = increments ? 1 : 0;
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         A.G = static_cast<const double*>(dG); A.gm = T * T; A.gt = T; A.gn = 1;
-        A.gbase = dgb;
+        A.gbase = kgb;
         if (c->grad_impl == 0) {
             const int64_t tb = (T + 63) / 64;
             int64_t slices = (1024 + tb - 1) / tb;
             if (slices > T) slices = T;
+            void* part;
+            A.part_stride = rows * DP;
+            CHK(ensure(c, B_GR4, sizeof(double) * size_t(slices) * size_t(A.part_stride) + 64, &part));
+            A.part = static_cast<double*>(part);
             CHK(launch_tens_row(c, DP, E, dim3(unsigned(tb), unsigned(slices), unsigned(M * (M + 1) / 2)), A));
+            hipLaunchKernelGGL(tens_row_reduce_kernel, dim3(unsigned((A.part_stride + 255) / 256)), dim3(256), 0, c->stream, A.part,
+                               static_cast<double*>(gzp), int(slices), A.part_stride);
+            HIPCHK(c, hipGetLastError());
         } else {
             CHK(launch_tens(c, DP, dim3(unsigned((T + 63) / 64), unsigned(T)), A));
         }
@@ -625,6 +636,8 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     CHK(out_dev(c, B_OUT1, gX, xb, &dgX));
     double* dgb;
     CHK(gbase_begin(c, &dgb));
+    // kernels without a differentiable base parameter skip the accumulation (one same-address atomic per wavefront otherwise)
+    double* const kgb = (p->base_kernel == GPSIG_BASE_POLY || p->base_kernel == GPSIG_BASE_MIX) ? dgb : nullptr;
     if (T == 0 || N == 0) {
         if (zb) CHK(zero_async(c, dgZ, zb));
         if (xb) CHK(zero_async(c, dgX, xb));
@@ -642,7 +655,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         A.T = int(T); A.N = int(N); A.L = L; A.d = d; A.M = M; A.kind = p->base_kernel; A.diff = p->difference ? 1 : 0;
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         A.G = static_cast<const double*>(dG); A.gm = T * N; A.gt = N; A.gn = 1;
-        A.gbase = dgb;
+        A.gbase = kgb;
         const int tpw = E == 2 ? 32 : 64;              // tensors per wavefront
         const int64_t tb = (T + tpw - 1) / tpw;
         int64_t runs = (2048 + tb - 1) / tb;
@@ -680,7 +693,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         A.T = int(T); A.N = int(N); A.L = L; A.M = M; A.kind = p->base_kernel; A.incr = E == 2 ? 1 : 0; A.diff = p->difference ? 1 : 0;
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         A.G = static_cast<const double*>(dG); A.gm = T * N; A.gt = N; A.gn = 1;
-        A.gbase = dgb;
+        A.gbase = kgb;
         if (fused) {
             if (T > 65535) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 65535 inducing tensors");
             CHK(launch_tvs_fused(c, DP, E, dim3(unsigned(s / 64), unsigned(T)), A));

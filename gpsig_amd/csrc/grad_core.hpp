@@ -866,6 +866,8 @@ struct TensGradArgs {
     const double* G;     // G[m * gm + t * gt + t2 * gn], m = 0..M
     int64_t gm, gt, gn;
     double* gbase;
+    double* part;        // row-owned kernel: per-slice partial sums (nslices, rows, DP) instead of atomics on gz, or null
+    int64_t part_stride; // rows * DP
 };
 
 template <int DP>
@@ -1008,9 +1010,18 @@ struct TensRowGrad {
                 }
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    double* gz = A.gz + ((int64_t(k0 + j) * A.T + t) * E + e) * DP;
+                    const int64_t at = ((int64_t(k0 + j) * A.T + t) * E + e) * DP;
+                    if (A.part) {
+                        // same-address atomics from hundreds of workgroups queue up at the memory side of the chip (about a
+                        // microsecond each): partial sums per slice, added up by tens_row_reduce_kernel
+                        if (valid) {
 #pragma unroll
-                    for (int f = 0; f < DP; ++f) grad_add(&gz[f], acc[e][f], false, valid);
+                            for (int f = 0; f < DP; ++f) A.part[slice * A.part_stride + at + f] = acc[e][f];
+                        }
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < DP; ++f) grad_add(&A.gz[at + f], acc[e][f], false, valid);
+                    }
                 }
             }
             k0 += i;

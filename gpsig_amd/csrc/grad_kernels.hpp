@@ -270,6 +270,20 @@ __global__ void __launch_bounds__(64) tens_row_grad_kernel(const TensGradArgs A)
     TensRowGrad<DP, E>(A, valid ? t : 0, valid).run(blockIdx.y, gridDim.y, gridDim.z > 1 ? int(blockIdx.z) : -1);
 }
 
+// gz[i] = sum over slices of part[s * n + i]
+static __global__ void tens_row_reduce_kernel(const double* __restrict__ part, double* __restrict__ gz, int nslices, int64_t n) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // eight loads in flight per thread
+    int k = 0;
+    for (; k + 8 <= nslices; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += part[int64_t(k + u) * n + i];
+    }
+    for (; k < nslices; ++k) s[0] += part[int64_t(k) * n + i];
+    gz[i] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
 // grid (ceil(T / 64), T); block 64: lanes = t2, blockIdx.y = t
 template <int DP>
 __global__ void __launch_bounds__(64) tens_pair_grad_kernel(const TensGradArgs A) {
