@@ -663,7 +663,9 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         if (runs > 65535) runs = 65535;
         A.nrun = int((N + runs - 1) / runs);
         runs = (N + A.nrun - 1) / A.nrun;
-        CHK(launch_tvs_lanet(c, DP, E == 2, dim3(unsigned(tb), unsigned(runs)), A));
+        // few workgroups: the serial sweep of one (tensor, sequence, level) chain bounds the launch -- one level per workgroup
+        const unsigned zl = tb * runs < 1024 ? unsigned(M) : 1u;
+        CHK(launch_tvs_lanet(c, DP, E == 2, dim3(unsigned(tb), unsigned(runs), zl), A));
         CHK(unpad_z(c, collapse, static_cast<const double*>(gzp), static_cast<double*>(dgZ), rows, d, DP));
     } else {
         const int64_t s = pad64(N);

@@ -180,7 +180,7 @@ struct TvsLaneTIO {
     }
 };
 
-// grid (ceil(T / 64), runs); block 64; dynamic LDS: ((ZREG ? 0 : MMAX * E * 64 * (DP + 2)) + L * DP + L + 2 * 64 * (DP + 2)) doubles
+// grid (ceil(T / 64), runs[, levels]); block 64; dynamic LDS: ((ZREG ? 0 : MMAX * E * 64 * (DP + 2)) + L * DP + L + 2 * 64 * (DP + 2)) doubles
 // PAIRED (E == 1 in the template, two points per tensor in the data): 32 tensors per wavefront, lane 2t + e holds point e
 template <int DP, int MMAX, int E, int KIND, bool ZREG, bool PAIRED = false>
 __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradArgs A) {
@@ -201,6 +201,7 @@ __global__ void __launch_bounds__(64) tvs_grad_lanet_kernel(const TvsLaneTGradAr
     int k0 = 0;
     double gp0 = 0.0;
     for (int i = 1; i <= A.M; ++i) {
+        if (gridDim.z > 1 && i != int(blockIdx.z) + 1) { k0 += i; continue; }      // small problems: one level per workgroup
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < MMAX; ++j)
