@@ -20,7 +20,17 @@ struct SeqConfig {
 #define GPSIG_SEQ_CONFIGS_EXACT(X) \
     X(16, 2, 4, 4, true)  X(16, 2, 4, 5, true)  \
     X(16, 4, 4, 4, true)  X(16, 4, 4, 5, true)  \
-    X(16, 4, 8, 4, true)  X(16, 4, 8, 5, true)
+    X(16, 4, 8, 4, true)  X(16, 4, 8, 5, true)  \
+    X(64, 2, 16, 6, true)
+// num_levels 4 and 5 fixed at compile time for the other shapes up to D = 16 (float64): the run-time-M kernels of these shapes
+// sit at one wavefront per SIMD, where the level predicates cost a factor 1.7-2 (C5 in float64: 301 -> 179 ms)
+#define GPSIG_SEQ_CONFIGS_EX_G16_D4(X) X(16, 1, 4, 4, true) X(16, 1, 4, 5, true) X(16, 8, 4, 4, true) X(16, 8, 4, 5, true)
+#define GPSIG_SEQ_CONFIGS_EX_G16_D8(X) X(16, 1, 8, 4, true) X(16, 1, 8, 5, true) X(16, 2, 8, 4, true) X(16, 2, 8, 5, true) X(16, 8, 8, 4, true) X(16, 8, 8, 5, true)
+#define GPSIG_SEQ_CONFIGS_EX_G16_D16(X) X(16, 1, 16, 4, true) X(16, 1, 16, 5, true) X(16, 2, 16, 4, true) X(16, 2, 16, 5, true) X(16, 4, 16, 4, true) X(16, 4, 16, 5, true)
+#define GPSIG_SEQ_CONFIGS_EX_G64_D4(X) X(64, 1, 4, 4, true) X(64, 1, 4, 5, true) X(64, 2, 4, 4, true) X(64, 2, 4, 5, true) X(64, 4, 4, 4, true) X(64, 4, 4, 5, true) X(64, 8, 4, 4, true) X(64, 8, 4, 5, true)
+#define GPSIG_SEQ_CONFIGS_EX_G64_D8(X) X(64, 1, 8, 4, true) X(64, 1, 8, 5, true) X(64, 2, 8, 4, true) X(64, 2, 8, 5, true) X(64, 4, 8, 4, true) X(64, 4, 8, 5, true) X(64, 8, 8, 4, true) X(64, 8, 8, 5, true)
+#define GPSIG_SEQ_CONFIGS_EX_G64_D16(X) X(64, 1, 16, 4, true) X(64, 1, 16, 5, true) X(64, 2, 16, 4, true) X(64, 2, 16, 5, true) X(64, 4, 16, 4, true) X(64, 4, 16, 5, true)
+#define GPSIG_SEQ_CONFIGS_EX_MORE(X) GPSIG_SEQ_CONFIGS_EX_G16_D4(X) GPSIG_SEQ_CONFIGS_EX_G16_D8(X) GPSIG_SEQ_CONFIGS_EX_G16_D16(X) GPSIG_SEQ_CONFIGS_EX_G64_D4(X) GPSIG_SEQ_CONFIGS_EX_G64_D8(X) GPSIG_SEQ_CONFIGS_EX_G64_D16(X)
 #define GPSIG_SEQ_CONFIGS_G16(X) \
     X(16, 1, 4, 8, false) X(16, 2, 4, 8, false) X(16, 4, 4, 8, false) X(16, 8, 4, 8, false) \
     X(16, 1, 8, 8, false) X(16, 2, 8, 8, false) X(16, 4, 8, 8, false) X(16, 8, 8, 8, false) \
@@ -38,7 +48,7 @@ struct SeqConfig {
 #define GPSIG_SEQ_CONFIGS_F32_G16(X) GPSIG_SEQ_CONFIGS_G16(X) X(16, 8, 16, 8, false)
 #define GPSIG_SEQ_CONFIGS_F32_G64(X) GPSIG_SEQ_CONFIGS_G64(X) X(64, 8, 16, 8, false)
 #define GPSIG_SEQ_CONFIGS_F32_ALL(X) GPSIG_SEQ_CONFIGS_F32_EXACT(X) GPSIG_SEQ_CONFIGS_F32_G16(X) GPSIG_SEQ_CONFIGS_F32_G64(X)
-#define GPSIG_SEQ_CONFIGS_ALL(X) GPSIG_SEQ_CONFIGS_EXACT(X) GPSIG_SEQ_CONFIGS_GENERIC(X)
+#define GPSIG_SEQ_CONFIGS_ALL(X) GPSIG_SEQ_CONFIGS_EXACT(X) GPSIG_SEQ_CONFIGS_EX_MORE(X) GPSIG_SEQ_CONFIGS_GENERIC(X)
 
 // Higher-order kernels (run-time num_levels <= MMAX, run-time order <= OMAX), MODE_INC and MODE_PT_DIFF.
 // X(G, C, D, MMAX, OMAX).  State and temporaries grow with C * OMAX^2, so wide lanes come with small orders.
