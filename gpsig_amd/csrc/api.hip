@@ -37,6 +37,13 @@ SeqLaunchFn seq_lookup_ptd_ex_g64_d16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_inc_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_inc_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptd_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdrbf_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d4(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d8(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdrbf_ex_g64_d4(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdrbf_ex_g64_d8(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdrbf_ex_g64_d16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptd_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptd_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptn_g16(int, int, int, int, bool);
@@ -98,7 +105,7 @@ constexpr int N_SEQ_TABLE_F32 = int(sizeof(SEQ_TABLE_F32) / sizeof(SEQ_TABLE_F32
 constexpr int N_SEQ_TABLE = int(sizeof(SEQ_TABLE) / sizeof(SEQ_TABLE[0]));
 constexpr int N_SEQ_TABLE_GENERIC = int(sizeof(SEQ_TABLE_GENERIC) / sizeof(SEQ_TABLE_GENERIC[0]));
 
-SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32) {
+SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32, int kind) {
     SeqLaunchFn f = nullptr;
     if (f32) {
         if (mode == MODE_INC) {
@@ -127,6 +134,15 @@ SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32) {
         return seq_lookup_inc_g64(c.G, c.C, c.D, c.MMAX, c.exact);
     }
     if (mode == MODE_PT_DIFF) {
+        if (kind == BASE_RBF && c.exact) {      // the RBF kernel at compile time
+            if ((f = seq_lookup_ptdrbf_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if ((f = seq_lookup_ptdrbf_ex_g16_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if ((f = seq_lookup_ptdrbf_ex_g16_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if ((f = seq_lookup_ptdrbf_ex_g16_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if ((f = seq_lookup_ptdrbf_ex_g64_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if ((f = seq_lookup_ptdrbf_ex_g64_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if ((f = seq_lookup_ptdrbf_ex_g64_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+        }
         if ((f = seq_lookup_ptd_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
         if (c.exact && (f = seq_lookup_ptd_ex_g16_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
         if (c.exact && (f = seq_lookup_ptd_ex_g16_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
@@ -383,7 +399,7 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
     out->cfg = tab[k];
     out->mode = g0.mode;
     out->d_eff = d_eff;
-    out->fn = seq_launcher(g0.mode, tab[k], sizeof(TT) == 4);
+    out->fn = seq_launcher(g0.mode, tab[k], sizeof(TT) == 4, p->base_kernel);
     if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "seq-gram kernel shape missing from this build");
     return GPSIG_OK;
 }

@@ -41,7 +41,9 @@ __device__ __forceinline__ float shr1(float v) {
 // otherwise any num_levels <= MMAX is accepted at run time.
 // OMAX == 0: first-order algorithm (signature_algs.py:8-35).  OMAX >= 2: higher-order algorithm
 // (signature_algs.py:37-74) for any run-time order <= OMAX.
-template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0>
+// KIND >= 0: the base kernel at compile time (built for the RBF kernel with differences, exact shapes): the C + 1 evaluations
+// of a step interleave instead of queueing behind a switch -- 5 % at the headline shape, 18 % at one wavefront per SIMD.
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1>
 __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1) void seq_gram_kernel(const SeqGramArgs A) {
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
     static_assert((D * sizeof(T)) % 16 == 0, "record rows are read with 16-byte LDS loads");
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
         // if lane 0 opens a new x at the next step, its record (requested issue_at steps into this x) must have landed
         if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-        seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, A.kind, p0, p1);
+        seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, KIND >= 0 ? KIND : A.kind, p0, p1);
         ctl.end_step();
     };
     // two steps per trip: the loop-carried hand-over words (s, qold) alternate registers instead of being copied
@@ -184,10 +186,10 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
     }
 }
 
-template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0>
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1>
 hipError_t seq_gram_launch(const SeqGramArgs& A, int ntasks, size_t lds_bytes, hipStream_t stream) {
     if (ntasks <= 0) return hipSuccess;
-    auto kern = seq_gram_kernel<T, G, C, D, MMAX, MODE, EXACT, OMAX>;
+    auto kern = seq_gram_kernel<T, G, C, D, MMAX, MODE, EXACT, OMAX, KIND>;
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
         if (e != hipSuccess) return e;

@@ -6,13 +6,16 @@
 #ifndef GPSIG_INST_T
 #define GPSIG_INST_T double
 #endif
+#ifndef GPSIG_INST_KIND
+#define GPSIG_INST_KIND -1
+#endif
 
 namespace gpsig {
 typedef hipError_t (*SeqLaunchFn)(const SeqGramArgs&, int, size_t, hipStream_t);
 
 #define GPSIG_INST_CASE(G_, C_, D_, MM_, EX_) \
     if (G == G_ && C == C_ && D == D_ && MMAX == MM_ && exact == EX_) \
-        return &seq_gram_launch<GPSIG_INST_T, G_, C_, D_, MM_, GPSIG_INST_MODE, EX_>;
+        return &seq_gram_launch<GPSIG_INST_T, G_, C_, D_, MM_, GPSIG_INST_MODE, EX_, 0, GPSIG_INST_KIND>;
 
 SeqLaunchFn GPSIG_INST_NAME(int G, int C, int D, int MMAX, bool exact) {
     GPSIG_INST_LIST(GPSIG_INST_CASE)
