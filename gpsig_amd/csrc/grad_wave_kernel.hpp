@@ -232,34 +232,53 @@ __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs
                 // Gam[p][q] = Lam[p-1][q-1] - Lam[p-1][q] - Lam[p][q-1] + Lam[p][q]  (zero outside the lattice); nodiff: Gam = Lam
                 // SIDE 0: p = tp fixed, q runs; SIDE 1: q = tp fixed, p runs.
                 double lo_prev = 0.0, hi_prev = 0.0;      // Lam at (fixed-1, run-1), (fixed, run-1)
-                for (int r = 0; r < Lp; ++r) {
-                    double gam;
-                    if (nodiff) {
-                        gam = SIDE == 0 ? lm[int64_t(tp) * R2 + r] : lm[int64_t(r) * R2 + tp];
-                    } else {
-                        // along the running index r (cell index r-1 | r), across the fixed index (cell index tp-1 | tp)
-                        const int Rr = SIDE == 0 ? R2 : R1, Rf = SIDE == 0 ? R1 : R2;
-                        double lo = 0.0, hi = 0.0;                   // Lam at (fixed-1, r), (fixed, r)
-                        if (r < Rr) {
-                            if (tp > 0) lo = SIDE == 0 ? lm[int64_t(tp - 1) * R2 + r] : lm[int64_t(r) * R2 + tp - 1];
-                            if (tp < Rf) hi = SIDE == 0 ? lm[int64_t(tp) * R2 + r] : lm[int64_t(r) * R2 + tp];
-                        }
-                        gam = (lo_prev - lo) - (hi_prev - hi);
-                        lo_prev = lo;
-                        hi_prev = hi;
+                const int Rr = SIDE == 0 ? R2 : R1, Rf = SIDE == 0 ? R1 : R2;
+                const bool wave_first = (threadIdx.x & 63) == 0;
+                auto lam_at = [&](int fixed, int run) -> double { return SIDE == 0 ? lm[int64_t(fixed) * R2 + run] : lm[int64_t(run) * R2 + fixed]; };
+                for (int r0 = 0; r0 < Lp; r0 += 4) {
+                    // four cells of the running index at a time: their loads are in flight together, and the neighbouring
+                    // value across the fixed index is the previous lane's (one load per cell instead of two)
+                    double hi4[4], lo4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = r0 + u;
+                        if (nodiff) hi4[u] = r < Lp ? lam_at(tp, r) : 0.0;
+                        else hi4[u] = (r < Rr && tp < Rf) ? lam_at(tp, r) : 0.0;
                     }
-                    const double* yq = part + r * DP;
-                    double in = 0.0;
-                    const double ps = pnorm[r];
+                    if (!nodiff) {
 #pragma unroll
-                    for (int f = 0; f < DP; ++f) in = fma(xt[f], yq[f], in);
-                    // derivative with respect to the target point; base_eval_grad's first argument is x
-                    const BaseGrad g = SIDE == 0 ? base_eval_grad(kind, in, ts, ps, A.p0, A.p1) : base_eval_grad(kind, in, ps, ts, A.p0, A.p1);
-                    const double w = gam * (g.cy - g.cd);
-                    accs = fma(gam, (SIDE == 0 ? g.cx : g.cx2) + g.cd, accs);
-                    if (SIDE == 0) gp0 = fma(gam, g.dp0, gp0);
+                        for (int u = 0; u < 4; ++u) {
+                            const int r = r0 + u;
+                            double lo = __shfl_up(hi4[u], 1, 64);        // lane tp - 1 holds Lam(tp - 1, r) as its own cell
+                            if (wave_first) lo = (tp > 0 && r < Rr) ? lam_at(tp - 1, r) : 0.0;
+                            lo4[u] = lo;
+                        }
+                    }
 #pragma unroll
-                    for (int f = 0; f < DP; ++f) acc[f] = fma(w, yq[f], acc[f]);
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = r0 + u;
+                        if (r >= Lp) break;
+                        double gam;
+                        if (nodiff) {
+                            gam = hi4[u];
+                        } else {
+                            gam = (lo_prev - lo4[u]) - (hi_prev - hi4[u]);
+                            lo_prev = lo4[u];
+                            hi_prev = hi4[u];
+                        }
+                        const double* yq = part + r * DP;
+                        double in = 0.0;
+                        const double ps = pnorm[r];
+#pragma unroll
+                        for (int f = 0; f < DP; ++f) in = fma(xt[f], yq[f], in);
+                        // derivative with respect to the target point; base_eval_grad's first argument is x
+                        const BaseGrad g = SIDE == 0 ? base_eval_grad(kind, in, ts, ps, A.p0, A.p1) : base_eval_grad(kind, in, ps, ts, A.p0, A.p1);
+                        const double w = gam * (g.cy - g.cd);
+                        accs = fma(gam, (SIDE == 0 ? g.cx : g.cx2) + g.cd, accs);
+                        if (SIDE == 0) gp0 = fma(gam, g.dp0, gp0);
+#pragma unroll
+                        for (int f = 0; f < DP; ++f) acc[f] = fma(w, yq[f], acc[f]);
+                    }
                 }
             }
         }
