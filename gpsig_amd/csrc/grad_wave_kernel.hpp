@@ -234,20 +234,21 @@ __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs
                 double lo_prev = 0.0, hi_prev = 0.0;      // Lam at (fixed-1, run-1), (fixed, run-1)
                 const int Rr = SIDE == 0 ? R2 : R1, Rf = SIDE == 0 ? R1 : R2;
                 const bool wave_first = (threadIdx.x & 63) == 0;
+                constexpr int NU = 8;
                 auto lam_at = [&](int fixed, int run) -> double { return SIDE == 0 ? lm[int64_t(fixed) * R2 + run] : lm[int64_t(run) * R2 + fixed]; };
-                for (int r0 = 0; r0 < Lp; r0 += 4) {
-                    // four cells of the running index at a time: their loads are in flight together, and the neighbouring
+                for (int r0 = 0; r0 < Lp; r0 += NU) {
+                    // NU cells of the running index at a time: their loads are in flight together, and the neighbouring
                     // value across the fixed index is the previous lane's (one load per cell instead of two)
-                    double hi4[4], lo4[4];
+                    double hi4[NU], lo4[NU];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < NU; ++u) {
                         const int r = r0 + u;
                         if (nodiff) hi4[u] = r < Lp ? lam_at(tp, r) : 0.0;
                         else hi4[u] = (r < Rr && tp < Rf) ? lam_at(tp, r) : 0.0;
                     }
                     if (!nodiff) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < NU; ++u) {
                             const int r = r0 + u;
                             double lo = __shfl_up(hi4[u], 1, 64);        // lane tp - 1 holds Lam(tp - 1, r) as its own cell
                             if (wave_first) lo = (tp > 0 && r < Rr) ? lam_at(tp - 1, r) : 0.0;
@@ -255,7 +256,7 @@ __global__ void __launch_bounds__(256) lam_contract_kernel(const LamContractArgs
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < NU; ++u) {
                         const int r = r0 + u;
                         if (r >= Lp) break;
                         double gam;
