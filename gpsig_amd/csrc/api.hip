@@ -66,6 +66,18 @@ SeqLaunchFn seq_lookup_ho_ptn_d16(int, int, int, int, int);
 typedef hipError_t (*TvsLaunchFn)(const TvsArgs&, hipStream_t);
 TvsLaunchFn tvs_lookup(int M, int TT, bool incr, bool f32);
 SeqLaunchFn seq_lookup_f32_inc_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_inc_ex_g16_d4(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_inc_ex_g16_d8(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_inc_ex_g16_d16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_inc_ex_g64_d4(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_inc_ex_g64_d8(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_inc_ex_g64_d16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptd_ex_g16_d4(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptd_ex_g16_d8(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptd_ex_g16_d16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptd_ex_g64_d4(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptd_ex_g64_d8(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptd_ex_g64_d16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_inc_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_inc_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_ptd_exact(int, int, int, int, bool);
@@ -110,11 +122,23 @@ SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32, int kind) {
     if (f32) {
         if (mode == MODE_INC) {
             if ((f = seq_lookup_f32_inc_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_inc_ex_g16_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_inc_ex_g16_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_inc_ex_g16_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_inc_ex_g64_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_inc_ex_g64_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_inc_ex_g64_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
             if ((f = seq_lookup_f32_inc_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
             return seq_lookup_f32_inc_g64(c.G, c.C, c.D, c.MMAX, c.exact);
         }
         if (mode == MODE_PT_DIFF) {
             if ((f = seq_lookup_f32_ptd_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_ptd_ex_g16_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_ptd_ex_g16_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_ptd_ex_g16_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_ptd_ex_g64_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_ptd_ex_g64_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (c.exact && (f = seq_lookup_f32_ptd_ex_g64_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
             if ((f = seq_lookup_f32_ptd_g16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
             return seq_lookup_f32_ptd_g64(c.G, c.C, c.D, c.MMAX, c.exact);
         }

@@ -44,10 +44,12 @@ struct SeqConfig {
 #define GPSIG_SEQ_CONFIGS_GENERIC(X) GPSIG_SEQ_CONFIGS_G16(X) GPSIG_SEQ_CONFIGS_G64(X)
 // float32 halves the register cost of a lane's columns: the widest shapes exist for it only; the exact one is the
 // shape of BASELINE.json configs[4] (L=128, d=16, num_levels=6)
-#define GPSIG_SEQ_CONFIGS_F32_EXACT(X) X(16, 8, 16, 6, true) X(16, 4, 8, 5, true)
+#define GPSIG_SEQ_CONFIGS_F32_EXACT(X) X(16, 8, 16, 6, true) X(16, 4, 8, 5, true) \
+    X(16, 2, 4, 4, true) X(16, 2, 4, 5, true) X(16, 4, 4, 4, true) X(16, 4, 4, 5, true) X(16, 4, 8, 4, true)
 #define GPSIG_SEQ_CONFIGS_F32_G16(X) GPSIG_SEQ_CONFIGS_G16(X) X(16, 8, 16, 8, false)
 #define GPSIG_SEQ_CONFIGS_F32_G64(X) GPSIG_SEQ_CONFIGS_G64(X) X(64, 8, 16, 8, false)
-#define GPSIG_SEQ_CONFIGS_F32_ALL(X) GPSIG_SEQ_CONFIGS_F32_EXACT(X) GPSIG_SEQ_CONFIGS_F32_G16(X) GPSIG_SEQ_CONFIGS_F32_G64(X)
+// float32: num_levels 4 / 5 at compile time for the same shapes as float64 (a factor 1.4 on the run-time-M kernels)
+#define GPSIG_SEQ_CONFIGS_F32_ALL(X) GPSIG_SEQ_CONFIGS_F32_EXACT(X) GPSIG_SEQ_CONFIGS_EX_MORE(X) GPSIG_SEQ_CONFIGS_F32_G16(X) GPSIG_SEQ_CONFIGS_F32_G64(X)
 #define GPSIG_SEQ_CONFIGS_ALL(X) GPSIG_SEQ_CONFIGS_EXACT(X) GPSIG_SEQ_CONFIGS_EX_MORE(X) GPSIG_SEQ_CONFIGS_GENERIC(X)
 
 // Higher-order kernels (run-time num_levels <= MMAX, run-time order <= OMAX), MODE_INC and MODE_PT_DIFF.

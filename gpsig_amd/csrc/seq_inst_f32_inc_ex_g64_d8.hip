@@ -1,0 +1,6 @@
+// float32 seq-gram kernel instantiations: MODE_INC, list GPSIG_SEQ_CONFIGS_EX_G64_D8
+#define GPSIG_INST_T float
+#define GPSIG_INST_NAME seq_lookup_f32_inc_ex_g64_d8
+#define GPSIG_INST_MODE MODE_INC
+#define GPSIG_INST_LIST GPSIG_SEQ_CONFIGS_EX_G64_D8
+#include "seq_inst.hpp"

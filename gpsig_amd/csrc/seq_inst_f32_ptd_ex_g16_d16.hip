@@ -1,0 +1,6 @@
+// float32 seq-gram kernel instantiations: MODE_PT_DIFF, list GPSIG_SEQ_CONFIGS_EX_G16_D16
+#define GPSIG_INST_T float
+#define GPSIG_INST_NAME seq_lookup_f32_ptd_ex_g16_d16
+#define GPSIG_INST_MODE MODE_PT_DIFF
+#define GPSIG_INST_LIST GPSIG_SEQ_CONFIGS_EX_G16_D16
+#include "seq_inst.hpp"
