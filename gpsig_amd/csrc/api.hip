@@ -82,6 +82,12 @@ SeqLaunchFn seq_lookup_f32_inc_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_inc_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_ptd_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_ptdrbf_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptdrbf_ex_g16_d4(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptdrbf_ex_g16_d8(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptdrbf_ex_g16_d16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptdrbf_ex_g64_d4(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptdrbf_ex_g64_d8(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_f32_ptdrbf_ex_g64_d16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_ptd_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_ptd_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_f32_ptn_g16(int, int, int, int, bool);
@@ -134,6 +140,12 @@ SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32, int kind) {
         }
         if (mode == MODE_PT_DIFF) {
             if (kind == BASE_RBF && c.exact && (f = seq_lookup_f32_ptdrbf_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (kind == BASE_RBF && c.exact && (f = seq_lookup_f32_ptdrbf_ex_g16_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (kind == BASE_RBF && c.exact && (f = seq_lookup_f32_ptdrbf_ex_g16_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (kind == BASE_RBF && c.exact && (f = seq_lookup_f32_ptdrbf_ex_g16_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (kind == BASE_RBF && c.exact && (f = seq_lookup_f32_ptdrbf_ex_g64_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (kind == BASE_RBF && c.exact && (f = seq_lookup_f32_ptdrbf_ex_g64_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+            if (kind == BASE_RBF && c.exact && (f = seq_lookup_f32_ptdrbf_ex_g64_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
             if ((f = seq_lookup_f32_ptd_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
             if (c.exact && (f = seq_lookup_f32_ptd_ex_g16_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
             if (c.exact && (f = seq_lookup_f32_ptd_ex_g16_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
