@@ -216,6 +216,29 @@ class Graph:
             self._g = None
 
 
+_holders = {}
+
+
+def hold(device, stream):
+    """A recorded call starts using the context of (device, stream): torch hands out side streams from a pool, so several
+    recordings can end up on one stream and share its context."""
+    key = (int(device), int(stream or 0))
+    _holders[key] = _holders.get(key, 0) + 1
+
+
+def release(device, stream):
+    """The counterpart of hold(): the last holder drops the cached context and frees its scratch memory."""
+    key = (int(device), int(stream or 0))
+    n = _holders.get(key, 0) - 1
+    if n > 0:
+        _holders[key] = n
+        return
+    _holders.pop(key, None)
+    ctx = _contexts.pop(key, None)
+    if ctx is not None:
+        ctx.close()
+
+
 _contexts = {}
 
 

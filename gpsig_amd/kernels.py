@@ -77,6 +77,18 @@ class GraphedCall:
     def __init__(self, graph, inputs, out, stream):
         self.graph, self.inputs, self.out, self.stream = graph, inputs, out, stream
 
+    def __del__(self):
+        # the side stream and its context (scratch buffers, task lists) belong to this recording alone
+        try:
+            g, self.graph = self.graph, None
+            if g is not None:
+                g.__del__()
+            dev = self.out[0].device if isinstance(self.out, (tuple, list)) else self.out.device
+            self.stream.synchronize()
+            _lib.release(dev.index or 0, self.stream.cuda_stream)
+        except Exception:
+            pass
+
     def replay(self):
         cur = torch.cuda.current_stream(self.out[0].device if isinstance(self.out, (tuple, list)) else self.out.device)
         self.stream.wait_stream(cur)             # the inputs were refreshed on the caller's stream
@@ -306,8 +318,13 @@ class SignatureKernel:
         with torch.cuda.stream(side):
             fn(*tensors, **kwargs)               # scratch buffers, task lists and level weights in place
             ctx = _lib.context(dev.index or 0, side.cuda_stream)
-            with ctx.graph() as g:
-                out = fn(*tensors, **kwargs)
+            _lib.hold(dev.index or 0, side.cuda_stream)
+            try:
+                with ctx.graph() as g:
+                    out = fn(*tensors, **kwargs)
+            except Exception:
+                _lib.release(dev.index or 0, side.cuda_stream)
+                raise
         torch.cuda.current_stream(dev).wait_stream(side)
         return GraphedCall(g, tensors, out, side)
 

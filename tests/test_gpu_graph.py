@@ -83,3 +83,19 @@ def test_capture_refuses_what_needs_the_host(env):
         with pytest.raises(ValueError, match="default stream"):
             with dctx.graph():
                 pass
+
+
+def test_recordings_release_their_context(env):
+    torch, K, dev = env
+    from gpsig_amd import _lib
+    kern = K.SignatureRBF(12 * 2, 2, 3)
+    X = torch.tensor(np.random.default_rng(7).standard_normal((16, 24)), device=dev)
+    before = len(_lib._contexts)
+    for _ in range(5):
+        g = kern.graphed("K", X)
+        want = kern.K(X)
+        assert torch.equal(g.replay(), want)
+        del g
+    import gc
+    gc.collect()
+    assert len(_lib._contexts) <= before + 1
