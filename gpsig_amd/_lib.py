@@ -52,6 +52,7 @@ _KERNEL_FUNCS = {
     "gpsig_tens_vs_seq_levels": [_vp, _vp, _i64, _i64, _i32, _i32, _vp],
     "gpsig_kernel_K": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "gpsig_kernel_K_symm_rows": [_vp, _i64, _i32, _i64, _i64, _vp],
+    "gpsig_kernel_K_symm_rows_compact": [_vp, _i64, _i32, _i64, _i64, _vp],
     "gpsig_kernel_Kdiag": [_vp, _i64, _i32, _i32, _vp],
     "gpsig_kernel_K_tens": [_vp, _i64, _i32, _i32, _vp],
     "gpsig_kernel_K_tens_vs_seq": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
@@ -78,6 +79,7 @@ _PLAIN = {
     "gpsig_set_shard": ([_vp, C.c_int, C.c_int], C.c_int),
     "gpsig_set_option": ([_vp, C.c_char_p, C.c_int], C.c_int),
     "gpsig_symmetrize_owned_rows": ([_vp, _i32, _vp, _i64, _vp], C.c_int),
+    "gpsig_symmetrize_compact_rows": ([_vp, _i32, _vp, _i64, _vp], C.c_int),
     "gpsig_timing_reset": ([_vp], C.c_int),
     "gpsig_timing_get": ([_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)], C.c_int),
     "gpsig_graph_begin": ([_vp], C.c_int),
@@ -167,6 +169,9 @@ class Context:
 
     def sync(self):
         self.check(self._lib.gpsig_sync(self._h))
+
+    def symmetrize_compact_rows(self, dtype_id, half_ptr, n, out_ptr):
+        self.check(self._lib.gpsig_symmetrize_compact_rows(self._h, int(dtype_id), half_ptr, int(n), out_ptr))
 
     def graph(self):
         """HIP-graph capture of the calls made in the with-block (include/gpsig_hip.h: gpsig_graph_begin):

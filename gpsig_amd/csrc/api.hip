@@ -493,6 +493,7 @@ struct SeqRun {
     int sum_levels, pred, mirror;
     bool timed;
     int64_t y_begin, y_end;   // y-block range (0, 0) = all
+    int compact;              // SeqGramArgs::compact
 };
 
 static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const SeqRun& r) {
@@ -500,7 +501,7 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     if (r.N1 > 0x7fffffff || r.N2 > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 sequences");
     const int ypb = 64 / pl.cfg.G;
     // aim for ~64k independent tasks (about 20 per resident wave slot) so the tail is a few per cent
-    const int64_t nblocks = (r.N2 + ypb - 1) / ypb;
+    const int64_t nblocks = ((r.y_end > 0 ? r.y_end - r.y_begin : r.N2) + ypb - 1) / ypb;
     const int64_t xtot = r.pred == PRED_ALL ? r.N1 : (r.pred == PRED_DIAG ? ypb : r.N1 / 2 + ypb);
     // ... unless the whole problem is smaller than that: then short runs, so that a small evaluation is spread over the chip
     // instead of a few wavefronts sweeping eight pairs in a row
@@ -535,7 +536,7 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     base_p(p, &A.p0, &A.p1);
     A.out = r.out; A.si = r.si; A.sj = r.sj; A.sm = r.sm;
     A.ax = r.ax; A.by = r.by; A.jitter_diag = r.jitter_diag;
-    A.sum_levels = r.sum_levels; A.pred = r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds;
+    A.sum_levels = r.sum_levels; A.pred = r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds; A.compact = r.compact;
     const size_t lds = sizeof(TT) * (size_t(A.RS) + size_t(A.nslot) * A.slot_elems);
     if (lds > 160 * 1024) return fail(c, GPSIG_ERR_UNSUPPORTED, "x-side records of %d rows do not fit the LDS ring (%zu bytes)", A.R1, lds);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -715,7 +716,7 @@ static int diag_levels_mn(gpsig_ctx* c, const gpsig_params* p, bool apply_scalin
 // x_squared: X-side factor 1/(diag+jitter) instead of 1/sqrt(diag+jitter) (K_seq_n_seq_covs quirk, kernels.py:713+:750).
 static int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, const void* X2, int64_t N1, int64_t N2,
                  int L1, int L2, int return_levels, void* out, bool timed, int x_squared = 0, int64_t row_begin = 0,
-                 int64_t row_end = 0) {
+                 int64_t row_end = 0, int compact = 0) {
     if (L1 < 1 || L2 < 1) return fail(c, GPSIG_ERR_INVALID, "sequence length must be >= 1");
     const bool sym = X2 == nullptr;
     const int M1 = p->num_levels + 1;
@@ -766,9 +767,9 @@ static int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const voi
     if (row_end > 0) {   // owned-row block of the symmetric Gram: row = y index, no mirror, block-local row offset
         r.xrec = rec1; r.yrec = rec1; r.gx = g1; r.gy = g1; r.N1 = N1;
         r.N2 = row_end;          // y indices >= row_end belong to the next block: never loaded, never emitted
-        r.si = 1; r.sj = N1; r.ax = fa; r.by = fb; r.mirror = 0;
+        r.si = 1; r.sj = compact ? N1 / 2 + 1 : N1; r.ax = fa; r.by = fb; r.mirror = 0; r.compact = compact;
         r.y_begin = row_begin; r.y_end = row_end;
-        r.out = static_cast<TT*>(out) - row_begin * N1;
+        r.out = static_cast<TT*>(out) - row_begin * r.sj;
         return launch_seq(c, p, pl, r);
     }
     if (!swap) {   // x = X (rows of the output), y = X2 (columns)
@@ -1002,17 +1003,17 @@ static int e_kernel_K(gpsig_ctx* c, const gpsig_params* p, const void* X, const 
 }
 
 static int e_kernel_K_symm_rows(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int64_t row_begin,
-                             int64_t row_end, void* out_rows) {
+                             int64_t row_end, void* out_rows, int compact) {
     ENTER(c, p);
     if (row_begin < 0 || row_end > N || row_begin > row_end || ((row_begin % 4) != 0 && row_begin != row_end))
         return fail(c, GPSIG_ERR_INVALID, "bad row range [%lld, %lld) of %lld (row_begin must be a multiple of 4)",
                     (long long)row_begin, (long long)row_end, (long long)N);
     const void* dX;
     CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N) * L * p->num_features, &dX));
-    const size_t ob = sizeof(TT) * size_t(row_end - row_begin) * N;
+    const size_t ob = sizeof(TT) * size_t(row_end - row_begin) * (compact ? N / 2 + 1 : N);
     void* dout;
     CHK(out_dev(c, B_OUT0, out_rows, ob, &dout));
-    if (row_end > row_begin) CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, 0, dout, true, 0, row_begin, row_end));
+    if (row_end > row_begin) CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, 0, dout, true, 0, row_begin, row_end, compact));
     CHK(out_done(c, out_rows, dout, ob));
     return finish(c);
 }
@@ -1032,6 +1033,25 @@ static int e_symmetrize_owned_rows(gpsig_ctx* c, int32_t dtype, const void* half
         HIPCHK(c, hipGetLastError());
     }
     CHK(out_done(c, out, dout, b));
+    return finish(c);
+}
+
+static int e_symmetrize_compact_rows(gpsig_ctx* c, int32_t dtype, const void* half, int64_t N, void* out) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (half == out) return fail(c, GPSIG_ERR_INVALID, "symmetrize needs distinct buffers");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bi = sizeof(TT) * size_t(N) * (N / 2 + 1), bo = sizeof(TT) * size_t(N) * N;
+    const void* dh;
+    CHK(in_dev(c, B_IN0, half, bi, &dh));
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, bo, &dout));
+    if (N > 0) {
+        const int64_t tpr = (N + 63) / 64, ntiles = tpr * tpr;
+        hipLaunchKernelGGL(symmetrize_compact_rows_kernel<TT>, dim3(unsigned(ntiles < 65536 ? ntiles : 65536)), dim3(64, 4), 0, c->stream,
+                           static_cast<const TT*>(dh), N, static_cast<TT*>(dout));
+        HIPCHK(c, hipGetLastError());
+    }
+    CHK(out_done(c, out, dout, bo));
     return finish(c);
 }
 
@@ -1407,12 +1427,23 @@ int gpsig_kernel_K(gpsig_ctx* c, const gpsig_params* p, const void* X, const voi
 int gpsig_kernel_K_symm_rows(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int64_t row_begin,
                              int64_t row_end, void* out_rows) {
     if (!c || !p) return GPSIG_ERR_INVALID;
-    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K_symm_rows(c, p, X, N, L, row_begin, row_end, out_rows) : Impl<double>::e_kernel_K_symm_rows(c, p, X, N, L, row_begin, row_end, out_rows);
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K_symm_rows(c, p, X, N, L, row_begin, row_end, out_rows, 0) : Impl<double>::e_kernel_K_symm_rows(c, p, X, N, L, row_begin, row_end, out_rows, 0);
 }
 
 int gpsig_symmetrize_owned_rows(gpsig_ctx* c, int32_t dtype, const void* half, int64_t N, void* out) {
     if (!c) return GPSIG_ERR_INVALID;
     return dtype == GPSIG_F32 ? Impl<float>::e_symmetrize_owned_rows(c, dtype, half, N, out) : Impl<double>::e_symmetrize_owned_rows(c, dtype, half, N, out);
+}
+
+int gpsig_kernel_K_symm_rows_compact(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int64_t row_begin,
+                                     int64_t row_end, void* out_rows) {
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_kernel_K_symm_rows(c, p, X, N, L, row_begin, row_end, out_rows, 1) : Impl<double>::e_kernel_K_symm_rows(c, p, X, N, L, row_begin, row_end, out_rows, 1);
+}
+
+int gpsig_symmetrize_compact_rows(gpsig_ctx* c, int32_t dtype, const void* half, int64_t N, void* out) {
+    if (!c) return GPSIG_ERR_INVALID;
+    return dtype == GPSIG_F32 ? Impl<float>::e_symmetrize_compact_rows(c, dtype, half, N, out) : Impl<double>::e_symmetrize_compact_rows(c, dtype, half, N, out);
 }
 
 int gpsig_kernel_Kdiag(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, int32_t return_levels, void* out) {

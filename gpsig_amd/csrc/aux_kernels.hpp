@@ -157,6 +157,38 @@ __global__ void symmetrize_owned_rows_kernel(const T* __restrict__ half, int64_t
     }
 }
 
+// The same from COMPACT row blocks (gpsig_kernel_K_symm_rows_compact): half is (N, N/2+1), row r holding its owned columns
+// r-N/2 .. r (mod N) side by side, half[r][N/2 - (r-c) mod N].  One 64 x 64 tile of `out` per block iteration: the entries the
+// rows of the tile own are copied straight (coalesced along c); the others belong to the tile's columns and are contiguous in
+// half along r, so they are read with r varying fastest and turned through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void symmetrize_compact_rows_kernel(const T* __restrict__ half, int64_t N, T* __restrict__ out) {
+    __shared__ T tile[64][65];
+    const int64_t H = N / 2, W = H + 1, tpr = (N + 63) / 64, ntiles = tpr * tpr;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    auto owns = [&](int64_t r, int64_t c, int64_t* dlt) {      // does row r own column c
+        int64_t d = r - c;
+        if (d < 0) d += N;
+        *dlt = d;
+        return d < H || (d == H && ((N & 1) || c < r));
+    };
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t r0 = (t / tpr) * 64, c0 = (t % tpr) * 64;
+        for (int k = ty; k < 64; k += 4) {                       // tile[c - c0][r - r0] = half[c][.] where column c owns (r, c)
+            const int64_t c = c0 + k, r = r0 + tx;
+            int64_t d;
+            if (r < N && c < N && r != c && owns(c, r, &d)) tile[k][tx] = half[c * W + H - d];
+        }
+        __syncthreads();
+        for (int k = ty; k < 64; k += 4) {
+            const int64_t r = r0 + k, c = c0 + tx;
+            int64_t d;
+            if (r < N && c < N) out[r * N + c] = owns(r, c, &d) ? half[r * W + H - d] : tile[tx][k];
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ void fill_kernel(T* __restrict__ p, int64_t n, T v) {
     for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < n; idx += int64_t(gridDim.x) * blockDim.x) p[idx] = v;

@@ -43,6 +43,8 @@ struct SeqGramArgs {
     int32_t pred;           // PRED_*
     int32_t mirror;         // also store at (j, i)
     int32_t use_glds;       // stage x records with global_load_lds (LDS DMA) instead of load + ds_write
+    int32_t compact;        // PRED_CIRCULANT only: owned entries of row j packed as out[j*sj + (N/2 - (j-i) mod N)], i.e. row j's
+                            // N/2+1 owned columns j-N/2 .. j side by side (multi-GPU row blocks: half the bytes to gather)
     const double* spec;     // BASE_SPECTRAL: alpha[Q], omega[Q][D], gamma[Q][D] (Q = p0, family = p1, D = the kernel's padded width)
 };
 
@@ -53,11 +55,13 @@ struct SeqGramArgs {
 template <typename T, class Lane, class Store>
 GPSIG_HD void seq_emit(const Lane& L, const SeqGramArgs& A, int64_t i, int64_t j, int M, Store store) {
     bool emit = true;
+    int64_t cdlt = 0;
     if (A.pred == PRED_CIRCULANT) {
         const int64_t N = A.N1, H = N / 2;
         int64_t dlt = j - i;
         if (dlt < 0) dlt += N;
         emit = dlt < H || (dlt == H && ((N & 1) || i < j));
+        cdlt = H - dlt;
     } else if (A.pred == PRED_DIAG) {
         emit = (i == j);
     }
@@ -66,6 +70,7 @@ GPSIG_HD void seq_emit(const Lane& L, const SeqGramArgs& A, int64_t i, int64_t j
     const T* by = A.by ? static_cast<const T*>(A.by) + j * (M + 1) : nullptr;
     const T dj = (i == j) ? T(A.jitter_diag) : T(0);
     int64_t o1 = i * A.si + j * A.sj, o2 = j * A.si + i * A.sj;
+    if (A.compact) o1 = j * A.sj + cdlt;
     const bool mir = A.mirror && i != j;
     T acc = T(0);
     for (int m = 0; m <= M; ++m) {

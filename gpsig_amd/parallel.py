@@ -1,11 +1,14 @@
 """Multi-GPU evaluation of the symmetric Gram K(X): one process per GPU, independent pair blocks,
-one RCCL gather.
+one gather (RCCL over xGMI) overlapped with the computation.
 
 The reference is single-device; this is the MI355X-native counterpart for
-BASELINE.json configs[3].  Every unordered pair {i, j} is owned by exactly one ROW of the Gram (row j
-owns the columns i with (j - i) mod N <= N/2), so contiguous row blocks carry equal work, need no
-exchange while computing, and the only communication is the gather of the row blocks to rank 0
-(each peer sends its block over its own xGMI link), followed by one symmetrisation pass there.
+BASELINE.json configs[3] (N = 32768 over 8 GPUs).  Every unordered pair {i, j} is owned by exactly one
+ROW of the Gram -- row j owns the N/2+1 columns j-N/2 .. j (mod N) -- so contiguous row blocks carry
+equal work and need no exchange while computing.  A rank writes the owned entries of its rows side by
+side (`gpsig_kernel_K_symm_rows_compact`: a (rows, N/2+1) block, half the bytes of full rows), in a few
+chunks; each finished chunk is handed to an asynchronous `dist.gather` (every peer sends over its own
+xGMI link to rank 0) while the next chunk is being computed, and rank 0 turns the stacked blocks into
+the full symmetric matrix in one tiled pass (`gpsig_symmetrize_compact_rows`).
 """
 import ctypes as C
 
@@ -18,76 +21,130 @@ except Exception:  # pragma: no cover
     torch = None
     dist = None
 
+ALIGN = 4   # the pair kernel's y-block size (64 lanes / 16 lanes per pair): row ranges start at multiples of it
 
-def row_partition(n, world, align=4):
-    """Contiguous row blocks, starts aligned to `align` (the kernel's y-block size)."""
+
+def block_rows(n, world, align=ALIGN):
+    """Rows per rank block (the same on every rank, so that gathers move equal-sized tensors)."""
+    per = -(-n // world)
+    return max(align, -(-per // align) * align)
+
+
+def row_partition(n, world, align=ALIGN):
+    """Contiguous row blocks, starts aligned to `align`."""
     per = block_rows(n, world, align)
     bounds = [min(r * per, n) for r in range(world + 1)]
     bounds[-1] = n
     return bounds
 
 
-def block_rows(n, world, align=4):
-    """Rows per rank block (the same on every rank, so that one gather of equal-sized tensors moves them)."""
-    per = -(-n // world)
-    return max(align, -(-per // align) * align)
-
-
 class ShardedGram:
-    """kern.K(X) for X replicated on every rank; the result lands on rank 0 (None elsewhere)."""
+    """kern.K(X) for X replicated on every rank; the result lands on rank 0 (None elsewhere).
 
-    def __init__(self, kern, n, device, rank=0, world=1):
-        self.kern, self.n, self.dev, self.rank, self.world = kern, int(n), device, rank, world
-        stream = torch.cuda.current_stream(device).cuda_stream
-        self.ctx = _lib.context(device.index or 0, stream)
-        self.bounds = row_partition(self.n, world)
+    chunks: pieces a rank's row block is computed and gathered in (the gather of piece k runs while piece k+1 is computed).
+    ctx:    the library context to use (default: the one of `device` and the stream current at call time).  The CPU test-suite
+            passes a stand-in that runs the kernel's lock-step emulator, so that this very code runs under gloo without a GPU.
+    Shapes the wavefront pair kernels are not built for (gpsig_amd/csrc/seq_configs.hpp) raise NotImplementedError here, although
+    the single-GPU kern.K falls back to the any-shape kernel for them."""
+
+    def __init__(self, kern, n, device, rank=0, world=1, chunks=4, ctx=None):
+        self.kern, self.n, self.dev, self.rank, self.world = kern, int(n), torch.device(device), int(rank), int(world)
+        self._ctx = ctx
+        self.width = self.n // 2 + 1
+        chunks = max(1, int(chunks))
+        self.per = block_rows(self.n, world, ALIGN * chunks)
+        self.chunk_rows = self.per // chunks
+        self.chunks = chunks
+        self.bounds = row_partition(self.n, world, ALIGN * chunks)
         if world > 1:
-            per = block_rows(self.n, world)
-            self.rows = torch.zeros((per, self.n), dtype=torch.float64, device=device)      # equal-sized blocks
+            self.rows = torch.zeros((self.per, self.width), dtype=torch.float64, device=self.dev)        # equal-sized blocks
             if rank == 0:
-                self.half = torch.zeros((per * world, self.n), dtype=torch.float64, device=device)
-                self.parts = list(self.half.split(per, dim=0))                                  # gather straight into place
-                self.out = torch.empty((self.n, self.n), dtype=torch.float64, device=device)
+                self.half = torch.zeros((self.per * world, self.width), dtype=torch.float64, device=self.dev)
+                self.out = torch.empty((self.n, self.n), dtype=torch.float64, device=self.dev)
+
+    def _context(self):
+        if self._ctx is not None:
+            return self._ctx
+        ctx = _lib.context(self.dev.index or 0, torch.cuda.current_stream(self.dev).cuda_stream)
+        ctx.set_pointer_mode(_lib.PTR_DEVICE)
+        return ctx
+
+    def _gather(self, k):
+        """Start the gather of chunk k of every rank's block into rank 0's `half`; returns the pending work (or None)."""
+        cr = self.chunk_rows
+        mine = self.rows[k * cr:(k + 1) * cr]
+        parts = None
+        if self.rank == 0:
+            parts = [self.half[r * self.per + k * cr: r * self.per + (k + 1) * cr] for r in range(self.world)]
+        if mine.is_cuda and dist.get_backend() != "nccl":
+            # CPU collectives on GPU data (tests on a box with fewer GPUs than ranks): stage through the host
+            torch.cuda.synchronize(self.dev)
+            host = mine.cpu()
+            if self.rank == 0:
+                hp = [torch.empty_like(host) for _ in range(self.world)]
+                dist.gather(host, gather_list=hp, dst=0)
+                for dst_t, src_t in zip(parts, hp):
+                    dst_t.copy_(src_t)
+            else:
+                dist.gather(host, dst=0)
+            return None
+        return dist.gather(mine, gather_list=parts, dst=0, async_op=True)
 
     def __call__(self, X):
         if self.world == 1:
             return self.kern.K(X)
+        X, _ = self.kern._slice(X, None)
+        if X.dtype != torch.float64 or X.device != self.dev:
+            raise ValueError("ShardedGram takes a float64 tensor on %s" % (self.dev,))
+        X = X.contiguous()
+        n, L = self.kern._seq_dims(X)
+        if n != self.n:
+            raise ValueError("ShardedGram was built for %d sequences, got %d" % (self.n, n))
         keep = []
         p = self.kern._params(keep)
-        n, width = X.shape
-        L = width // self.kern.num_features
+        ctx = self._context()
         b0, b1 = self.bounds[self.rank], self.bounds[self.rank + 1]
-        self.ctx.set_pointer_mode(_lib.PTR_DEVICE)
-        self.ctx.call("gpsig_kernel_K_symm_rows", p, C.c_void_p(X.data_ptr()), n, L, b0, b1, C.c_void_p(self.rows.data_ptr()))
-        if dist.get_backend() != "nccl":            # CPU collectives (tests on a box with fewer GPUs than ranks): stage through the host
-            torch.cuda.synchronize(self.dev)
-            host = self.rows.cpu()
-            if self.rank == 0:
-                parts = [torch.empty_like(host) for _ in range(self.world)]
-                dist.gather(host, gather_list=parts, dst=0)
-                for dst_t, src_t in zip(self.parts, parts):
-                    dst_t.copy_(src_t)
-            else:
-                dist.gather(host, dst=0)
-                return None
-        elif self.rank == 0:
-            dist.gather(self.rows, gather_list=self.parts, dst=0)
-        else:
-            dist.gather(self.rows, dst=0)
+        pending = []
+        for k in range(self.chunks):
+            r0 = min(b0 + k * self.chunk_rows, b1)
+            r1 = min(r0 + self.chunk_rows, b1)
+            if r1 > r0:
+                blk = self.rows[k * self.chunk_rows:]
+                ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), n, L, r0, r1, C.c_void_p(blk.data_ptr()))
+            w = self._gather(k)       # enqueued behind chunk k on the collective's own stream; chunk k+1 starts meanwhile
+            if w is not None:
+                pending.append(w)
+        for w in pending:
+            w.wait()
+        if self.rank != 0:
             return None
-        if self.rank == 0:
-            self.ctx.check(self.ctx._lib.gpsig_symmetrize_owned_rows(self.ctx._h, _lib.F64, C.c_void_p(self.half.data_ptr()), n,
-                                                                       C.c_void_p(self.out.data_ptr())))
-            return self.out
-        return None
+        ctx.symmetrize_compact_rows(_lib.F64, C.c_void_p(self.half.data_ptr()), n, C.c_void_p(self.out.data_ptr()))
+        return self.out
+
+
+def owned_mask(n):
+    """owned[r, c]: row r owns column c (the emission predicate PRED_CIRCULANT of csrc/seq_args.hpp with i = c, j = r)."""
+    import numpy as np
+    r, c = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    dlt = (r - c) % n
+    h = n // 2
+    return (dlt < h) | ((dlt == h) & ((n % 2 == 1) | (c < r)))
 
 
 def symmetrize_reference(half):
     """NumPy statement of gpsig_symmetrize_owned_rows (used by the CPU tests of the partition logic)."""
     import numpy as np
-    n = half.shape[0]
-    r, c = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
-    dlt = (r - c) % n
-    h = n // 2
-    owned = (dlt < h) | ((dlt == h) & ((n % 2 == 1) | (c < r)))
+    owned = owned_mask(half.shape[0])
     return np.where(owned, half, half.T), owned
+
+
+def symmetrize_compact_reference(half):
+    """NumPy statement of gpsig_symmetrize_compact_rows: half (n, n//2+1) -> (n, n)."""
+    import numpy as np
+    n = half.shape[0]
+    h = n // 2
+    owned = owned_mask(n)
+    r, c = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    own_rows = half[r, np.clip(h - (r - c) % n, 0, h)]          # valid where owned
+    own_cols = half[c, np.clip(h - (c - r) % n, 0, h)]          # valid where the column's row owns the entry
+    return np.where(owned, own_rows, own_cols)

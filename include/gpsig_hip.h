@@ -152,6 +152,13 @@ int gpsig_kernel_K_symm_rows(gpsig_ctx* ctx, const gpsig_params* p, const void* 
                              int64_t row_begin, int64_t row_end, void* out_rows);
 /* out[r][c] = half[r][c] if row r owns column c, else half[c][r].  half, out: (N, N), distinct buffers. */
 int gpsig_symmetrize_owned_rows(gpsig_ctx* ctx, int32_t dtype, const void* half, int64_t N, void* out);
+/* The same two steps with COMPACT row blocks: row j's N/2+1 owned columns j-N/2 .. j (mod N) are stored side by side,
+ * out_rows[(j - row_begin) * (N/2+1) + N/2 - ((j-i) mod N)] -- half the bytes to move between GPUs; the one slot per row of an
+ * even N that belongs to the other row of its pair (the tie at distance N/2) is left untouched.  half: the stacked blocks,
+ * (N, N/2+1); out: (N, N). */
+int gpsig_kernel_K_symm_rows_compact(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L,
+                                     int64_t row_begin, int64_t row_end, void* out_rows);
+int gpsig_symmetrize_compact_rows(gpsig_ctx* ctx, int32_t dtype, const void* half, int64_t N, void* out);
 /* SignatureKernel.Kdiag (kernels.py:479-510).  out: (N,) or (M+1, N). */
 int gpsig_kernel_Kdiag(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L,
                        int32_t return_levels, void* out);

@@ -32,7 +32,7 @@ class SeqGramArgs(C.Structure):
         ("out", C.c_void_p), ("si", C.c_int64), ("sj", C.c_int64), ("sm", C.c_int64),
         ("ax", C.c_void_p), ("by", C.c_void_p), ("jitter_diag", C.c_double),
         ("sum_levels", C.c_int32), ("pred", C.c_int32), ("mirror", C.c_int32), ("use_glds", C.c_int32),
-        ("spec", C.c_void_p),
+        ("compact", C.c_int32), ("spec", C.c_void_p),
     ]
 
 
@@ -92,7 +92,7 @@ def tasks_for(N1, N2, ypb, pred, max_run=64, shard=(0, 1), yrange=(0, -1)):
 
 
 def run(cfg, geom_x, geom_y, xrec, yrec, N1, N2, M, kind, p0, p1, out, si, sj, sm, ax, by, jitter_diag, sum_levels,
-        pred, mirror, max_run=64, shard=(0, 1), yrange=(0, -1), out_offset=0, order=1):
+        pred, mirror, max_run=64, shard=(0, 1), yrange=(0, -1), out_offset=0, order=1, compact=0):
     tasks, nt = tasks_for(N1, N2, 64 // cfg["G"], pred, max_run, shard, yrange)
     A = SeqGramArgs()
     A.xrec, A.yrec, A.tasks = xrec.ctypes.data, yrec.ctypes.data, C.addressof(tasks)
@@ -107,6 +107,7 @@ def run(cfg, geom_x, geom_y, xrec, yrec, N1, N2, M, kind, p0, p1, out, si, sj, s
     A.ax = ax.ctypes.data if ax is not None else None
     A.by = by.ctypes.data if by is not None else None
     A.jitter_diag, A.sum_levels, A.pred, A.mirror, A.use_glds = jitter_diag, int(sum_levels), pred, int(mirror), 0
+    A.compact = int(compact)
     if cfg.get("OMAX"):
         rc = lib().emu_seq_gram_ho(cfg["G"], cfg["C"], cfg["D"], cfg["MMAX"], cfg["OMAX"], geom_x["mode"], C.byref(A), nt)
     else:
@@ -172,9 +173,9 @@ def kernel_K(X1s, X2s, base, M, variances, sigma, normalization, difference=True
     return out
 
 
-def kernel_K_owned_rows(Xs, base, M, variances, sigma, normalization, row_begin, row_end, jitter=1e-6):
-    """Emulator counterpart of gpsig_kernel_K_symm_rows: the owned entries of rows [row_begin, row_end) of the
-    symmetric, normalised, weighted, level-summed Gram; everything else is left at zero."""
+def kernel_K_owned_rows(Xs, base, M, variances, sigma, normalization, row_begin, row_end, jitter=1e-6, compact=False):
+    """Emulator counterpart of gpsig_kernel_K_symm_rows[_compact]: the owned entries of rows [row_begin, row_end) of the
+    symmetric, normalised, weighted, level-summed Gram; everything else is left at zero.  compact: (rows, N//2+1) blocks."""
     N, L, d = Xs.shape
     w = sigma * np.asarray(variances, dtype=np.float64)
     if normalization:
@@ -187,10 +188,12 @@ def kernel_K_owned_rows(Xs, base, M, variances, sigma, normalization, row_begin,
     cfg = select(gy["rows"], d, M)
     g = geometry(base, True, L, cfg["D"])
     rec = build_records(Xs, g, True, cfg["D"])
-    out = np.zeros((row_end - row_begin, N))
-    # as the C API does: x index = column (si = 1), y index = row (sj = N), y indices >= row_end are invalid (N2 = row_end)
-    run(cfg, g, g, rec, rec, N, row_end, M, BASE_IDS[base], 0.0, 0.0, out, 1, N, 0, ax, by,
-        jitter if normalization else 0.0, True, PRED_CIRCULANT, False, yrange=(row_begin, row_end), out_offset=-row_begin * N)
+    sj = N // 2 + 1 if compact else N
+    out = np.zeros((row_end - row_begin, sj))
+    # as the C API does: x index = column (si = 1), y index = row (sj), y indices >= row_end are invalid (N2 = row_end)
+    run(cfg, g, g, rec, rec, N, row_end, M, BASE_IDS[base], 0.0, 0.0, out, 1, sj, 0, ax, by,
+        jitter if normalization else 0.0, True, PRED_CIRCULANT, False, yrange=(row_begin, row_end), out_offset=-row_begin * sj,
+        compact=compact)
     return out
 
 

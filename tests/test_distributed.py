@@ -1,6 +1,8 @@
-"""The N > 1 path on CPU: two processes over the gloo backend run the owned-row-block decomposition of the
-symmetric Gram (gpsig_amd.parallel) with the kernel replaced by its lock-step CPU emulator, gather the blocks to
-rank 0 and symmetrise -- the same partition, ownership rule, task lists and epilogue the 8-GPU run uses."""
+"""The N > 1 path on CPU: two processes over the gloo backend run gpsig_amd.parallel.ShardedGram.__call__ ITSELF -- row
+partition, chunked compact row blocks, asynchronous gathers, symmetrisation -- with the library context replaced by a stand-in
+that executes the two C-ABI calls with the kernel's lock-step CPU emulator (tests/emu) and the NumPy statement of the
+symmetrisation.  The same partition, ownership rule, task lists and epilogue the 8-GPU run uses."""
+import ctypes as C
 import os
 import socket
 
@@ -13,12 +15,13 @@ from gpsig_amd import parallel
 
 
 def test_row_partition_is_aligned_and_complete():
-    for n in (1, 4, 7, 64, 100, 4096, 11584):
+    for n in (1, 4, 7, 64, 100, 4096, 11584, 32768):
         for world in (1, 2, 3, 8):
-            b = parallel.row_partition(n, world)
-            assert b[0] == 0 and b[-1] == n and len(b) == world + 1
-            assert all(b[r] <= b[r + 1] for r in range(world))
-            assert all(b[r] % 4 == 0 or b[r] == b[r + 1] for r in range(world))   # aligned, or an empty block
+            for align in (4, 16):
+                b = parallel.row_partition(n, world, align)
+                assert b[0] == 0 and b[-1] == n and len(b) == world + 1
+                assert all(b[r] <= b[r + 1] for r in range(world))
+                assert all(b[r] % align == 0 or b[r] == b[r + 1] for r in range(world))   # aligned, or an empty block
 
 
 def test_ownership_rule_covers_each_unordered_pair_once():
@@ -28,41 +31,77 @@ def test_ownership_rule_covers_each_unordered_pair_once():
         assert (owned ^ owned.T)[off].all() and owned.diagonal().all()
 
 
-def _worker(rank, world, port, n, ret):
+def test_compact_layout_round_trip():
+    """Packing the owned entries of a symmetric matrix row by row and unpacking them gives the matrix back."""
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 12, 65):
+        A = rng.standard_normal((n, n))
+        A = A + A.T
+        h = n // 2
+        owned = parallel.owned_mask(n)
+        half = np.full((n, h + 1), np.nan)
+        for r in range(n):
+            for c in range(n):
+                if owned[r, c]:
+                    half[r, h - (r - c) % n] = A[r, c]
+        assert np.isnan(half).sum() == (n // 2 if n % 2 == 0 else 0)   # even n: the tie at distance n/2 goes to one row of the pair
+        np.testing.assert_array_equal(parallel.symmetrize_compact_reference(np.nan_to_num(half)), A)
+
+
+class EmulatorContext:
+    """Stand-in for gpsig_amd._lib.Context on CPU tensors: the two calls ShardedGram makes, executed by the emulator."""
+    BASE = {0: "linear", 1: "rbf"}
+
+    def call(self, name, p, Xp, n, L, r0, r1, outp):
+        import emu_util as E
+        assert name == "gpsig_kernel_K_symm_rows_compact"
+        d, M = p.num_features, p.num_levels
+        X = np.ctypeslib.as_array(C.cast(Xp, C.POINTER(C.c_double)), shape=(n, L, d))
+        var = np.ctypeslib.as_array(p.variances, shape=(M + 1,))
+        assert not p.lengthscales and p.num_lags == 0 and p.order == 1
+        blk = E.kernel_K_owned_rows(X, self.BASE[p.base_kernel], M, var, p.sigma, bool(p.normalization), r0, r1, jitter=p.jitter,
+                                    compact=True)
+        out = np.ctypeslib.as_array(C.cast(outp, C.POINTER(C.c_double)), shape=(r1 - r0, n // 2 + 1))
+        np.copyto(out, blk, where=blk != 0)            # "entries it does not own are left untouched"
+
+    def symmetrize_compact_rows(self, dtype_id, halfp, n, outp):
+        half = np.ctypeslib.as_array(C.cast(halfp, C.POINTER(C.c_double)), shape=(n, n // 2 + 1))
+        out = np.ctypeslib.as_array(C.cast(outp, C.POINTER(C.c_double)), shape=(n, n))
+        out[...] = parallel.symmetrize_compact_reference(half)
+
+
+def _worker(rank, world, port, n, chunks, ret):
     import torch
-    import emu_util as E
+    from gpsig_amd import kernels
     from oracle import sigkern_oracle as O
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         L, d, M = 9, 3, 3
         rng = np.random.default_rng(0)
-        X = np.cumsum(0.3 * rng.standard_normal((n, L, d)), axis=1)       # replicated input
+        X = np.cumsum(0.3 * rng.standard_normal((n, L, d)), axis=1).reshape(n, L * d)       # replicated input
         var = np.array([0.7, 1.1, 0.9, 1.3])
-        b = parallel.row_partition(n, world)
-        per = parallel.block_rows(n, world)
-        t = torch.zeros((per, n), dtype=torch.float64)                       # equal-sized blocks, as ShardedGram allocates
-        t[: b[rank + 1] - b[rank]] = torch.from_numpy(E.kernel_K_owned_rows(X, "rbf", M, var, 1.0, True, b[rank], b[rank + 1]))
+        kern = kernels.SignatureRBF(L * d, d, M, variances=var, lengthscales=None)
+        gram = parallel.ShardedGram(kern, n, torch.device("cpu"), rank, world, chunks=chunks, ctx=EmulatorContext())
+        out = gram(torch.from_numpy(X))
         if rank == 0:
-            half_t = torch.zeros((per * world, n), dtype=torch.float64)
-            dist.gather(t, gather_list=list(half_t.split(per, dim=0)), dst=0)
-            half = half_t.numpy()[:n]
-            full, _ = parallel.symmetrize_reference(half)
-            want = O.SignatureKernelOracle(L * d, d, M, base="rbf", variances=var, lengthscales=None).K(X.reshape(n, -1))
-            ret["err"] = float(np.abs(full - want).max() / np.abs(want).max())
+            want = O.SignatureKernelOracle(L * d, d, M, base="rbf", variances=var, lengthscales=None).K(X)
+            got = out.numpy()
+            ret["err"] = float(np.abs(got - want).max() / np.abs(want).max())
+            ret["sym"] = bool((got == got.T).all())
         else:
-            dist.gather(t, dst=0)
+            assert out is None
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [22, 37])
-def test_two_rank_gloo_owned_rows_gather(n):
+@pytest.mark.parametrize("n,chunks", [(22, 1), (37, 2), (64, 4)])
+def test_two_rank_gloo_sharded_gram(n, chunks):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(2, port, n, ret), nprocs=2, join=True)
-        assert ret["err"] < 1e-12
+        mp.spawn(_worker, args=(2, port, n, chunks, ret), nprocs=2, join=True)
+        assert ret["err"] < 1e-12 and ret["sym"]

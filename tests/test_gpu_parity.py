@@ -515,6 +515,118 @@ def test_owned_row_blocks_reassemble_the_symmetric_gram(K):
     assert torch.equal(g(X), full)
 
 
+@pytest.mark.parametrize("n,world,chunks", [(90, 3, 1), (37, 2, 2), (4096, 8, 4)])
+def test_compact_row_blocks_reassemble_the_symmetric_gram(K, n, world, chunks):
+    """What every rank of ShardedGram does, rank after rank on one GPU: chunked compact row blocks
+    (gpsig_kernel_K_symm_rows_compact) of a `world`-rank partition, stacked and symmetrised
+    (gpsig_symmetrize_compact_rows), are bit-identical to K(X) -- at BASELINE configs[1]'s size for an 8-rank partition."""
+    import ctypes as C
+    import torch
+    from gpsig_amd import _lib, parallel
+    rng = np.random.default_rng(n)
+    L, d, M = (64, 8, 5) if n >= 4096 else (16, 3, 3)
+    X = torch.as_tensor(rng.standard_normal((n, L * d)), device="cuda:0")
+    kern = K.SignatureLinear(L * d, d, M) if n >= 4096 else K.SignatureRBF(L * d, d, M)
+    full = kern.K(X)
+    ctx = _lib.context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_pointer_mode(_lib.PTR_DEVICE)
+    g = parallel.ShardedGram(kern, n, torch.device("cuda", 0), 0, world, chunks=chunks)
+    W = n // 2 + 1
+    half = torch.full((g.per * world, W), float("nan"), dtype=torch.float64, device="cuda:0")
+    keep = []
+    p = kern._params(keep)
+    for r in range(world):
+        b0, b1 = g.bounds[r], g.bounds[r + 1]
+        for k in range(chunks):
+            r0 = min(b0 + k * g.chunk_rows, b1)
+            r1 = min(r0 + g.chunk_rows, b1)
+            if r1 > r0:
+                blk = half[r * g.per + k * g.chunk_rows:]
+                ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), n, L, r0, r1, C.c_void_p(blk.data_ptr()))
+    out = torch.empty((n, n), dtype=torch.float64, device="cuda:0")
+    ctx.symmetrize_compact_rows(_lib.F64, C.c_void_p(half.data_ptr()), n, C.c_void_p(out.data_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, full)
+    h = half[:n].cpu().numpy()
+    assert np.isnan(h).sum() == (n // 2 if n % 2 == 0 else 0)      # every owned slot written, the tie slots untouched
+    if n <= 128:
+        np.testing.assert_array_equal(parallel.symmetrize_compact_reference(np.nan_to_num(h)), full.cpu().numpy())
+
+
+def test_full_config4_single_gpu_properties(K):
+    """BASELINE configs[3]'s problem (N=32768, L=64, d=8, num_levels=5) on ONE GPU: the 8-rank compact row blocks, stacked and
+    symmetrised, against size-independent properties and against the oracle / the single-call K on sub-blocks."""
+    import ctypes as C
+    import torch
+    from gpsig_amd import _lib, parallel
+    rng = np.random.default_rng(4)
+    N, L, d, M, world, chunks = 32768, 64, 8, 5, 8, 4
+    Xh = rng.standard_normal((N, L * d))
+    X = torch.as_tensor(Xh, device="cuda:0")
+    kw = dict(input_dim=L * d, num_features=d, num_levels=M, base="linear")
+    kern = make_kernel(K, kw)
+    ctx = _lib.context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_pointer_mode(_lib.PTR_DEVICE)
+    g = parallel.ShardedGram(kern, N, torch.device("cuda", 0), 0, world, chunks=chunks)
+    keep = []
+    p = kern._params(keep)
+    for r in range(world):
+        for k in range(chunks):
+            r0 = g.bounds[r] + k * g.chunk_rows
+            blk = g.half[r * g.per + k * g.chunk_rows:]
+            ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), N, L, r0, r0 + g.chunk_rows, C.c_void_p(blk.data_ptr()))
+    ctx.symmetrize_compact_rows(_lib.F64, C.c_void_p(g.half.data_ptr()), N, C.c_void_p(g.out.data_ptr()))
+    G = g.out
+    torch.cuda.synchronize()
+    assert torch.isfinite(G).all()
+    for r0 in range(0, N, 4096):                                           # exactly symmetric, block by block (no N x N temporary)
+        assert torch.equal(G[r0:r0 + 4096], G[:, r0:r0 + 4096].T)
+    assert (G.diagonal() - (M + 1.0)).abs().max().item() < 1e-12
+    # sub-blocks near the diagonal, across the wrap-around and at the ownership tie (distance N/2) against the oracle
+    idx = np.concatenate([np.arange(0, 12), np.arange(N // 2 - 6, N // 2 + 6), np.arange(N - 12, N)])
+    want = make_oracle(kw).K(Xh[idx])
+    got = G[torch.as_tensor(idx, device="cuda:0")][:, torch.as_tensor(idx, device="cuda:0")].cpu().numpy()
+    assert relerr(got, want) <= TOL
+    # a block of rows of one rank against the cross Gram of the same sequences (different code path: PRED_ALL)
+    A, B = X[20000:20256], X[3000:3300]
+    assert relerr(G[20000:20256, 3000:3300].cpu().numpy(), kern.K(A, B).cpu().numpy()) <= 1e-9
+    # the leading 4096 x 4096 block is the Gram of the first 4096 sequences (normalisation is per sequence)
+    assert relerr(G[:4096, :4096].cpu().numpy(), kern.K(X[:4096]).cpu().numpy()) <= 1e-9
+
+
+def _sharded_worker(rank, world, port, n, ret):
+    import os
+    import torch
+    import torch.distributed as dist
+    from gpsig_amd import kernels, parallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, d, M = 16, 3, 4
+        X = torch.as_tensor(np.random.default_rng(5).standard_normal((n, L * d)), device="cuda:0")
+        kern = kernels.SignatureRBF(L * d, d, M)
+        out = parallel.ShardedGram(kern, n, torch.device("cuda", 0), rank, world, chunks=2)(X)
+        if rank == 0:
+            ret["equal"] = bool(torch.equal(out, kern.K(X)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gram_two_processes_one_gpu(K):
+    """ShardedGram.__call__ on the real library with two ranks (two processes sharing cuda:0, gloo collectives staged through
+    the host): rank 0's gathered, symmetrised Gram is bit-identical to K(X)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_sharded_worker, args=(2, port, 203, ret), nprocs=2, join=True)
+        assert ret["equal"]
+
+
 @pytest.mark.parametrize("T", [5, 40, 130])
 def test_tensor_vs_sequence_lane_mappings_agree(K, T):
     """Kzx has two kernels: one lane per sequence (few tensors) and one lane per tensor (>= 32 tensors).  Both must
