@@ -18,8 +18,13 @@
 #include "lowrank_kernels.hpp"
 #include "seq_args.hpp"
 #include "seq_configs.hpp"
+#include "tvs_tile_kernel.hpp"
 
 namespace gpsig {
+typedef hipError_t (*TvsTileLaunchFn)(const TvsTileArgs&, size_t, hipStream_t);
+TvsTileLaunchFn tvs_tile_lookup(int M, int NW, int D, bool incr, int kind);
+int tvs_tile_width(int d);
+int tvs_tile_waves(int M, int D, int E, int kind);
 typedef hipError_t (*SeqLaunchFn)(const SeqGramArgs&, int, size_t, hipStream_t);
 SeqLaunchFn seq_lookup_inc_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_inc_ex_g16_d4(int, int, int, int, bool);
@@ -862,11 +867,79 @@ static int tens_vs_seq_lanet_device(gpsig_ctx* c, const gpsig_params* p, bool ra
     return GPSIG_OK;
 }
 
+// Kzx through the tile kernel (tvs_tile_kernel.hpp): float64, order 1, many tensors.  Returns GPSIG_OK with *done = false
+// when the kernel is not built for the shape (the caller goes on to the older mappings).
+static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Zdev, const void* X, int64_t Tn,
+                                   int64_t N, int L, int increments, const void* fx, const double* w, int return_levels, void* out,
+                                   bool* done) {
+    *done = false;
+    if (sizeof(TT) != 8 || p->order > 1 || p->base_kernel == GPSIG_BASE_SPECTRAL || c->tvs_tile == 0) return GPSIG_OK;
+    const int M = p->num_levels, lt = M * (M + 1) / 2;
+    ScaleParams s = scale_of(p, !raw);
+    const int d_eff = s.d_eff();
+    const int D = tvs_tile_width(d_eff);
+    if (D == 0) return GPSIG_OK;
+    const int kind = p->base_kernel == GPSIG_BASE_LINEAR ? BASE_LINEAR : (p->base_kernel == GPSIG_BASE_RBF ? BASE_RBF : -1);
+    const bool collapse = increments && kind == BASE_LINEAR;              // <x, z1> - <x, z0> = <x, z1 - z0>
+    const int E = (increments && !collapse) ? 2 : 1;
+    const int NW = c->tvs_tile_nw > 0 ? c->tvs_tile_nw : tvs_tile_waves(M, D, E, kind);
+    TvsTileLaunchFn fn = NW > 0 ? tvs_tile_lookup(M, NW, D, E == 2, kind) : nullptr;
+    if (!fn) return GPSIG_OK;
+    const int rec_elems = (L * D + L + TVS_REC_ALIGN - 1) / TVS_REC_ALIGN * TVS_REC_ALIGN;
+    const bool sum_levels = !(raw || return_levels);
+    const size_t lds = tvs_tile_lds_bytes(M, NW, rec_elems, sum_levels);
+    if (lds > 64 * 1024) return GPSIG_OK;
+    const int64_t Tpad = (Tn + 63) / 64 * 64, TB = Tpad / 64;
+    // sequences per workgroup: whole tiles of 16 once there are enough workgroups to fill the chip a few times over
+    int64_t runs = 4096 / TB < 1 ? 1 : 4096 / TB;
+    if (runs > N) runs = N;
+    int64_t run = (N + runs - 1) / runs;
+    if (run >= TVS_TILE_S) run = (run + TVS_TILE_S - 1) / TVS_TILE_S * TVS_TILE_S;
+    if (run > 4 * TVS_TILE_S) run = 4 * TVS_TILE_S;
+    if ((N + run - 1) / run > 65535) return GPSIG_OK;
+    const double pre = kind == BASE_RBF ? EXP_PRESCALE : 1.0;
+    const int rows_are_increments = kind == BASE_LINEAR && p->difference;
+    void *zl, *zn, *xr;
+    CHK(ensure(c, B_ZL, sizeof(double) * size_t(lt) * E * D * Tpad + 8, &zl));
+    CHK(ensure(c, B_ZN, sizeof(double) * size_t(lt) * E * Tpad + 8, &zn));
+    CHK(ensure(c, B_XT, sizeof(double) * size_t(N) * rec_elems + 8, &xr));
+    hipLaunchKernelGGL(prep_tensors_tile_kernel, dim3(grid_for(Tpad * lt * E)), dim3(256), 0, c->stream,
+                       static_cast<const double*>(Zdev), lt, Tn, Tpad, increments ? 2 : 1, collapse ? 1 : 0, pre, s, D,
+                       static_cast<double*>(zl), static_cast<double*>(zn));
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(prep_seq_tile_records_kernel, dim3(grid_for(N * int64_t(rec_elems))), dim3(256), 0, c->stream,
+                       static_cast<const double*>(X), N, L, s, pre, rows_are_increments, D, rec_elems, static_cast<double*>(xr));
+    HIPCHK(c, hipGetLastError());
+    TvsTileArgs A;
+    memset(&A, 0, sizeof(A));
+    A.XR = xr; A.ZL = zl; A.ZN = zn; A.N = N; A.Tn = Tn; A.Tpad = Tpad;
+    A.L = L; A.d = d_eff; A.kind = p->base_kernel; A.difference = p->difference; A.M = M;
+    A.run = int(run); A.rec_elems = rec_elems;
+    base_p(p, &A.p0, &A.p1);
+    A.fx = fx; A.w = w; A.out = out; A.sum_levels = sum_levels ? 1 : 0;
+    hipEvent_t e0, e1;
+    bool timed;
+    CHK(timing_begin(c, &e0, &e1, &timed));
+    HIPCHK(c, fn(A, lds, c->stream));
+    if (timed) {
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        c->t_launches += 1;
+        c->t_pairs += Tn * N;
+    }
+    *done = true;
+    return GPSIG_OK;
+}
+
 // Kzx on device pointers.  Zdev: the caller's (lt, T, E, d') tensor array; ZT/ZS: its sequence-lane preparation.
 static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Zdev, const void* ZT, const void* ZS,
                        const void* X, int64_t Tn, int64_t N, int L, int increments, const void* fx, const double* w,
                        int return_levels, void* out) {
     const int M = p->num_levels;
+    if (N > 0 && Tn > 0 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1 || c->tvs_tile == 1)) {
+        bool done = false;
+        CHK(tens_vs_seq_tile_device(c, p, raw, Zdev, X, Tn, N, L, increments, fx, w, return_levels, out, &done));
+        if (done) return GPSIG_OK;
+    }
     if (N > 0 && Tn > 0 && N <= 65535 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1) && p->base_kernel != GPSIG_BASE_SPECTRAL &&
         size_t(L) * scale_of(p, !raw).d_eff() * sizeof(TT) <= 48 * 1024) {
         TvsLaneTLaunchFn fns[8];
@@ -1299,6 +1372,8 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "grad_scratch_mb")) c->grad_scratch_mb = value > 0 ? value : 4096;
     else if (!strcmp(name, "grad_impl")) c->grad_impl = value;
     else if (!strcmp(name, "tvs_zreg")) c->tvs_zreg = value;
+    else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
+    else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);
     return GPSIG_OK;
 }

@@ -1,0 +1,41 @@
+// One translation unit of tvs_tile_kernel instantiations: #define TVS_TILE_M and TVS_TILE_NWS(X) (the waves-per-workgroup
+// values built for that num_levels) before including.  Feature widths: 4, 6, 8.
+#include "tvs_tile_kernel.hpp"
+
+namespace gpsig {
+typedef hipError_t (*TvsTileLaunchFn)(const TvsTileArgs&, size_t, hipStream_t);
+
+template <int M, int NW, int D, bool INCR, int KIND>
+static hipError_t tvs_tile_launch(const TvsTileArgs& A, size_t lds, hipStream_t stream) {
+    auto kern = tvs_tile_kernel<M, NW, D, INCR, KIND>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid((unsigned)(A.Tpad / 64), (unsigned)((A.N + A.run - 1) / A.run));
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, A);
+    return hipGetLastError();
+}
+
+template <int M, int NW, int D>
+static TvsTileLaunchFn tvs_tile_pick(bool incr, int kind) {
+    if (kind == BASE_LINEAR) return &tvs_tile_launch<M, NW, D, false, BASE_LINEAR>;       // increments arrive collapsed
+    if (kind == BASE_RBF) return incr ? &tvs_tile_launch<M, NW, D, true, BASE_RBF> : &tvs_tile_launch<M, NW, D, false, BASE_RBF>;
+    return incr ? &tvs_tile_launch<M, NW, D, true, -1> : &tvs_tile_launch<M, NW, D, false, -1>;
+}
+
+#define TVS_TILE_CAT2(a, b) a##b
+#define TVS_TILE_CAT(a, b) TVS_TILE_CAT2(a, b)
+// kind: BASE_LINEAR, BASE_RBF or -1 (any other family, evaluated by base_eval_n at run time)
+TvsTileLaunchFn TVS_TILE_CAT(tvs_tile_lookup_m, TVS_TILE_M)(int NW, int D, bool incr, int kind) {
+#define TVS_TILE_CASE(NW_)                                                              \
+    if (NW == NW_) {                                                                    \
+        if (D == 4) return tvs_tile_pick<TVS_TILE_M, NW_, 4>(incr, kind);               \
+        if (D == 6) return tvs_tile_pick<TVS_TILE_M, NW_, 6>(incr, kind);               \
+        if (D == 8) return tvs_tile_pick<TVS_TILE_M, NW_, 8>(incr, kind);               \
+    }
+    TVS_TILE_NWS(TVS_TILE_CASE)
+#undef TVS_TILE_CASE
+    return nullptr;
+}
+}  // namespace gpsig

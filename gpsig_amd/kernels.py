@@ -101,6 +101,15 @@ def _shape(a):
     return tuple(a.shape)
 
 
+def _launch_f64(*arrays):
+    """_Launch for the low-rank entry points, which are built for float64 only: all-float32 arguments raise (and
+    _f32_upcast retries the call in float64) instead of handing float32 buffers to entry points that read doubles."""
+    L_ = _Launch(*arrays)
+    if L_.f32:
+        raise NotImplementedError("low-rank mode is built for float64 only")
+    return L_
+
+
 def _is_f32(a):
     return a is not None and hasattr(a, "dtype") and str(a.dtype).endswith("float32")
 
@@ -354,8 +363,8 @@ class SignatureKernel:
         if not presliced:
             X, _ = self._slice(X, None)
         if self.low_rank and not self.normalization:
+            L_ = _launch_f64(X)
             st = lr_state or self.draw_low_rank(X=X)
-            L_ = _Launch(X)
             p = self._params(L_.keep)
             lr = st.as_c(L_.keep)
             Phi, pp, n = self._lr_features(L_, p, lr, X)
@@ -373,8 +382,8 @@ class SignatureKernel:
     def K_tens(self, Z, return_levels=False, increments=False, lr_state=None):
         """Reference: kernels.py:513-536.  (T, T) or (M+1, T, T); never normalised."""
         if self.low_rank:
+            L_ = _launch_f64(Z)
             st = lr_state or self.draw_low_rank(Z=Z, increments=increments)
-            L_ = _Launch(Z)
             p = self._params(L_.keep)
             lr = st.as_c(L_.keep)
             Phi, pp, t = self._lr_features(L_, p, lr, Z, tensors=True, increments=increments)
@@ -394,8 +403,8 @@ class SignatureKernel:
         if not presliced:
             X, _ = self._slice(X, None)
         if self.low_rank:
+            L_ = _launch_f64(Z, X)
             st = lr_state or self.draw_low_rank(X=X, Z=Z, increments=increments)
-            L_ = _Launch(Z, X)
             p = self._params(L_.keep)
             lr = st.as_c(L_.keep)
             PZ, pz, t = self._lr_features(L_, p, lr, Z, tensors=True, increments=increments)
@@ -479,9 +488,7 @@ class SignatureKernel:
         kernels.py:444-446, :562-563), whiten their Gram (low_rank_calculations.py:50-57) and draw one projection
         per level (low_rank_calculations.py:76-193).  Returns a LowRankState that can be passed to K(..., lr_state=)."""
         cands = []
-        L_ = _Launch(X, X2)
-        if L_.f32:
-            raise NotImplementedError("low-rank mode is built for float64 only")
+        L_ = _launch_f64(X, X2)
         p = self._params(L_.keep, _lib.F64)
         total = 0
         seqs = []
@@ -533,10 +540,8 @@ class SignatureKernel:
         return Phi, pp, n
 
     def _K_lr(self, X, X2, return_levels, lr_state):
+        L_ = _launch_f64(X, X2)
         st = lr_state or self.draw_low_rank(X=X, X2=X2)
-        L_ = _Launch(X, X2)
-        if L_.f32:
-            raise NotImplementedError("low-rank mode is built for float64 only")
         p = self._params(L_.keep)
         lr = st.as_c(L_.keep)
         PA, pa, n1 = self._lr_features(L_, p, lr, X)
@@ -552,10 +557,8 @@ class SignatureKernel:
     def _K_seq_n_seq_covs_lr(self, X, X2, full_X2_cov, return_levels, lr_state):
         """kernels.py:696-761, low-rank branch: level Grams of the factor matrices (HIP: features + fp64-MFMA GEMMs), then the
         normalisation / weighting of :706-761 as elementwise torch ops on the device."""
+        L_ = _launch_f64(X, X2)
         st = lr_state or self.draw_low_rank(X=X, X2=X2)
-        L_ = _Launch(X, X2)
-        if L_.f32:
-            raise NotImplementedError("low-rank mode is built for float64 only")
         p = self._params(L_.keep)
         ones = np.ones(self.num_levels + 1)
         L_.keep.append(ones)

@@ -1,0 +1,46 @@
+// Host check of gpsig_amd/csrc/fast_exp.hpp (the same arithmetic the device runs: fma, rint, ldexp are exact operations)
+// against the long-double library exp.  Prints the worst error in ulps for both entry points.
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include "fast_exp.hpp"
+
+static const double tab[64] = {GPSIG_EXP2_TABLE};
+
+static double ulps(double got, long double want) {
+    if (want == 0.0L) return got == 0.0 ? 0.0 : 1e9;
+    int e;
+    frexpl(want, &e);
+    const long double ulp = ldexpl(1.0L, e - 53);
+    return double(fabsl((long double)got - want) / ulp);
+}
+
+int main(int argc, char** argv) {
+    const long n = argc > 1 ? atol(argv[1]) : 2000000;
+    unsigned long long s = 88172645463325252ull;
+    double worst1 = 0, worst2 = 0;
+    for (long i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        const double u = double(s >> 11) / 9007199254740992.0;
+        double a;
+        switch (i & 3) {
+            case 0: a = -700.0 * u; break;
+            case 1: a = -40.0 * u; break;
+            case 2: a = -1.0 * u * u; break;
+            default: a = 700.0 * (u - 0.5); break;
+        }
+        const double g1 = gpsig::kexp_tab(a, tab);
+        const double w1 = ulps(g1, expl((long double)a));
+        if (w1 > worst1) worst1 = w1;
+        const double t = a * gpsig::EXP_T_PER_A;                          // the argument kexp2_tab sees IS t: reference 2^(t/64)
+        const double g2 = gpsig::kexp2_tab(t, tab);
+        const double w2 = ulps(g2, exp2l((long double)t / 64.0L));
+        if (w2 > worst2) worst2 = w2;
+    }
+    // edge cases: huge negative arguments give 0, zero gives 1
+    const double e0 = gpsig::kexp_tab(0.0, tab), e1 = gpsig::kexp_tab(-1e300, tab), e2 = gpsig::kexp2_tab(-1e300, tab),
+                 e3 = gpsig::kexp_tab(-800.0, tab), e4 = gpsig::kexp2_tab(0.0, tab);
+    const bool scale_ok = fabs(gpsig::EXP_PRESCALE * gpsig::EXP_PRESCALE / gpsig::EXP_T_PER_A - 1.0) < 4e-16;
+    printf("%.4f %.4f %d\n", worst1, worst2, int(e0 == 1.0 && e1 == 0.0 && e2 == 0.0 && e3 == 0.0 && e4 == 1.0 && scale_ok));
+    return 0;
+}

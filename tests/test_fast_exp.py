@@ -1,0 +1,15 @@
+"""gpsig_amd/csrc/fast_exp.hpp (the table-driven float64 exp of the RBF / Matern envelopes) against the long-double library
+exp, on the host: the header's arithmetic is fma / rint / ldexp only, so the device computes the same bits."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fast_exp_within_one_and_a_half_ulp(tmp_path):
+    exe = str(tmp_path / "test_fast_exp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "gpsig_amd", "csrc"),
+                           "-o", exe, os.path.join(ROOT, "tests", "emu", "test_fast_exp.cpp")])
+    worst_a, worst_t, edges = subprocess.check_output([exe, "2000000"]).split()
+    assert float(worst_a) < 1.5 and float(worst_t) < 1.5, (worst_a, worst_t)
+    assert int(edges) == 1

@@ -645,12 +645,47 @@ def test_tensor_vs_sequence_lane_mappings_agree(K, T):
                     kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, order=order, num_lags=lags,
                               lengthscales=0.5 + rng.random(d))
                     want = make_oracle(kw).K_tens_vs_seq(Z, X, increments=incr, return_levels=True)
-                    for mode in (0, 1):
+                    for mode, tile in ((0, -1), (1, 0), (1, 1)):      # sequence lanes, tensor lanes, tile kernel (order 1)
                         ctx.set_option("tensor_lanes", mode)
+                        ctx.set_option("tvs_tile", tile)
                         got = make_kernel(K, kw).K_tens_vs_seq(Z, X, increments=incr, return_levels=True)
-                        assert relerr(got, want) <= TOL, (base, incr, order, lags, mode)
+                        assert relerr(got, want) <= TOL, (base, incr, order, lags, mode, tile)
     finally:
         ctx.set_option("tensor_lanes", -1)
+        ctx.set_option("tvs_tile", -1)
+
+
+@pytest.mark.parametrize("base", ["linear", "rbf", "matern52", "poly"])
+@pytest.mark.parametrize("incr", [False, True])
+def test_tile_kernel_for_many_tensors(K, base, incr):
+    """The Kzx tile kernel (tvs_tile_kernel.hpp: levels split over the waves of a workgroup, records by LDS-DMA, table-driven
+    exp for RBF, result tiles of 16 sequences): ragged tensor / sequence counts across tile, run and workgroup boundaries, one
+    and two waves per workgroup, with and without the difference along time, level tensors and the normalised weighted sum."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(5)
+    L = 19
+    ctx = _lib.context(0, 0)
+    try:
+        for T, N, nw, diff, M, d in ((70, 37, 1, True, 4, 5), (130, 83, 2, True, 4, 5), (64, 16, 2, False, 4, 6), (33, 49, 1, False, 3, 4),
+                                     (65, 21, 3, True, 5, 3), (40, 17, 0, True, 5, 6), (40, 35, 0, True, 2, 8), (64, 33, 3, True, 6, 4),
+                                     (50, 20, 0, False, 6, 7)):
+            X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+            Z = 0.7 * rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d))
+            kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, difference=diff, lengthscales=0.6 + rng.random(d),
+                      variances=0.5 + rng.random(M + 1))
+            ko = make_oracle(kw)
+            ctx.set_option("tvs_tile", 1)
+            ctx.set_option("tvs_tile_nw", nw)
+            kx = make_kernel(K, kw)
+            assert relerr(kx.K_tens_vs_seq(Z, X, increments=incr, return_levels=True),
+                          ko.K_tens_vs_seq(Z, X, increments=incr, return_levels=True)) <= TOL, (T, N, nw, diff, "levels")
+            got = kx.K_tens_vs_seq(Z, X, increments=incr)
+            assert relerr(got, ko.K_tens_vs_seq(Z, X, increments=incr)) <= TOL, (T, N, nw, diff, "sum")
+            ctx.set_option("tvs_tile", 0)                          # the older tensor-lane kernel writes the same matrix
+            assert relerr(make_kernel(K, kw).K_tens_vs_seq(Z, X, increments=incr), got) <= 1e-9
+    finally:
+        ctx.set_option("tvs_tile", -1)
+        ctx.set_option("tvs_tile_nw", 0)
 
 
 # ------------------------------------------------------------------------------------------------
