@@ -60,6 +60,7 @@ _KERNEL_FUNCS = {
     "gpsig_kernel_K_seq_n_seq_covs": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "gpsig_lr_gather_points": [_vp, _i64, _i32, C.POINTER(_i64), _i64, C.POINTER(C.c_double)],
     "gpsig_base_kernel_matrix": [C.POINTER(C.c_double), C.POINTER(C.c_double), _i64, _i64, _i32, C.POINTER(C.c_double)],
+    "gpsig_lr_whitening": [C.POINTER(C.c_double), _i32, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gpsig_lr_seq_features": [_LR, _vp, _i64, _i32, _vp],
     "gpsig_lr_tens_features": [_LR, _vp, _i64, _i32, _vp],
     "gpsig_lr_kernel": [_LR, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],

@@ -24,6 +24,8 @@ namespace gpsig {
 typedef hipError_t (*TvsTileLaunchFn)(const TvsTileArgs&, size_t, hipStream_t);
 TvsTileLaunchFn tvs_tile_lookup(int M, int NW, int D, bool incr, int kind);
 int tvs_tile_width(int d);
+bool solver_dsyevd(void** handle_slot, hipStream_t stream, int n, double* A, double* ev, double* work, int* info, std::string* err);
+void solver_release(void* handle);
 int tvs_tile_waves(int M, int D, int E, int kind);
 typedef hipError_t (*SeqLaunchFn)(const SeqGramArgs&, int, size_t, hipStream_t);
 SeqLaunchFn seq_lookup_inc_exact(int, int, int, int, bool);
@@ -129,6 +131,19 @@ constexpr int N_SEQ_TABLE_F32 = int(sizeof(SEQ_TABLE_F32) / sizeof(SEQ_TABLE_F32
 constexpr int N_SEQ_TABLE = int(sizeof(SEQ_TABLE) / sizeof(SEQ_TABLE[0]));
 constexpr int N_SEQ_TABLE_GENERIC = int(sizeof(SEQ_TABLE_GENERIC) / sizeof(SEQ_TABLE_GENERIC[0]));
 
+// float64, differences, the RBF kernel at compile time.  These instances use the table-driven exp on prescaled records
+// (SEQ_FAST_RBF in seq_gram_kernel.hpp): whoever launches one prepares the records with the prescale and the norm column.
+SeqLaunchFn seq_launcher_rbf(const SeqConfig& c) {
+    SeqLaunchFn f = nullptr;
+    if ((f = seq_lookup_ptdrbf_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+    if ((f = seq_lookup_ptdrbf_ex_g16_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+    if ((f = seq_lookup_ptdrbf_ex_g16_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+    if ((f = seq_lookup_ptdrbf_ex_g16_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+    if ((f = seq_lookup_ptdrbf_ex_g64_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+    if ((f = seq_lookup_ptdrbf_ex_g64_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
+    return seq_lookup_ptdrbf_ex_g64_d16(c.G, c.C, c.D, c.MMAX, c.exact);
+}
+
 SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32, int kind) {
     SeqLaunchFn f = nullptr;
     if (f32) {
@@ -177,15 +192,6 @@ SeqLaunchFn seq_launcher(int mode, const SeqConfig& c, bool f32, int kind) {
         return seq_lookup_inc_g64(c.G, c.C, c.D, c.MMAX, c.exact);
     }
     if (mode == MODE_PT_DIFF) {
-        if (kind == BASE_RBF && c.exact) {      // the RBF kernel at compile time
-            if ((f = seq_lookup_ptdrbf_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
-            if ((f = seq_lookup_ptdrbf_ex_g16_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
-            if ((f = seq_lookup_ptdrbf_ex_g16_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
-            if ((f = seq_lookup_ptdrbf_ex_g16_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
-            if ((f = seq_lookup_ptdrbf_ex_g64_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
-            if ((f = seq_lookup_ptdrbf_ex_g64_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
-            if ((f = seq_lookup_ptdrbf_ex_g64_d16(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
-        }
         if ((f = seq_lookup_ptd_exact(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
         if (c.exact && (f = seq_lookup_ptd_ex_g16_d4(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
         if (c.exact && (f = seq_lookup_ptd_ex_g16_d8(c.G, c.C, c.D, c.MMAX, c.exact))) return f;
@@ -409,12 +415,14 @@ struct SeqPlanned {
     SeqConfig cfg;
     SeqLaunchFn fn;
     int mode, d_eff;
+    bool rbf_prescaled;      // fn is a float64 RBF instance with the table-driven exp: records carry prescaled points + norms
 };
 
 static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
     if (p->base_kernel == GPSIG_BASE_SPECTRAL)      // takes the points, not inner products: one-pair-per-thread kernel only
         return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for float64 only");
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
+    out->rbf_prescaled = false;
     if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
         int k = seq_select_ho(SEQ_HO_TABLE, N_SEQ_HO_TABLE, g0.rows, d_eff, p->num_levels, p->order);
         if (k < 0)
@@ -442,7 +450,12 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
     out->cfg = tab[k];
     out->mode = g0.mode;
     out->d_eff = d_eff;
-    out->fn = seq_launcher(g0.mode, tab[k], sizeof(TT) == 4, p->base_kernel);
+    out->fn = nullptr;
+    if (!f32 && g0.mode == MODE_PT_DIFF && p->base_kernel == GPSIG_BASE_RBF && tab[k].exact) {
+        out->fn = seq_launcher_rbf(tab[k]);
+        out->rbf_prescaled = out->fn != nullptr;
+    }
+    if (!out->fn) out->fn = seq_launcher(g0.mode, tab[k], sizeof(TT) == 4, p->base_kernel);
     if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "seq-gram kernel shape missing from this build");
     return GPSIG_OK;
 }
@@ -460,7 +473,8 @@ static int make_records(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling,
         const int64_t total = N * geom->rows * s.d_eff();
         hipLaunchKernelGGL(prep_seq_records_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, c->stream,
                            static_cast<const TT*>(Xdev), N, L, s, geom->mode, p->difference, geom->rows, geom->RS,
-                           int64_t(geom->rec_elems), static_cast<TT*>(d));
+                           int64_t(geom->rec_elems), static_cast<TT*>(d), pl.rbf_prescaled ? TT(EXP_PRESCALE) : TT(1),
+                           pl.rbf_prescaled ? pl.cfg.D : -1);
         HIPCHK(c, hipGetLastError());
     }
     *rec = d;
@@ -1337,6 +1351,7 @@ void gpsig_ctx_destroy(gpsig_ctx* c) {
     for (TaskSlot& t : c->task_slots)
         if (t.buf.p) (void)hipFree(t.buf.p);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    solver_release(c->blas_handle);
     delete c;
 }
 
@@ -1599,6 +1614,80 @@ int gpsig_base_kernel_matrix(gpsig_ctx* c, const gpsig_params* p, const double* 
         HIPCHK(c, hipMemcpyAsync(out_host, dout, sizeof(double) * size_t(na) * nb, hipMemcpyDeviceToHost, c->stream));
     }
     CHK(host_sync(c));
+    return GPSIG_OK;
+}
+
+namespace {
+// W (c x c, symmetric) += diag(jd)                                                        low_rank_calculations.py:52
+__global__ void add_diag_kernel(double* __restrict__ W, const double* __restrict__ jd, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) W[int64_t(i) * c + i] += jd[i];
+}
+// Sign convention of the eigenvectors (an eigensolver returns each up to sign, the reference's tf.self_adjoint_eig included):
+// the component of largest magnitude is made positive (the first such component on ties).  sgn[j] = +-1.
+// The level >= 2 features contract coordinate pairs of the whitened features with a fixed random projection, so their
+// values -- not their distribution -- depend on these signs; fixing them makes an evaluation a function of its random objects.
+__global__ void eig_sign_kernel(const double* __restrict__ Ucm, int c, double* __restrict__ sgn) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c) return;
+    double best = 0.0, s = 1.0;
+    for (int i = 0; i < c; ++i) {
+        const double v = Ucm[int64_t(j) * c + i];
+        if (fabs(v) > best) { best = fabs(v); s = v < 0.0 ? -1.0 : 1.0; }
+    }
+    sgn[j] = s;
+}
+// Wh[i][j] = sgn[j] U[i][j] / sqrt(ev[j] + jitter), U column-major as dsyevd leaves it    low_rank_calculations.py:56-57, :60
+__global__ void whiten_kernel(const double* __restrict__ Ucm, const double* __restrict__ ev, const double* __restrict__ sgn, int c,
+                              double jitter, double* __restrict__ Wh) {
+    const int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+    if (idx >= int64_t(c) * c) return;
+    const int i = int(idx / c), j = int(idx - int64_t(i) * c);
+    Wh[idx] = sgn[j] * Ucm[int64_t(j) * c + i] / sqrt(ev[j] + jitter);
+}
+}  // namespace
+
+int gpsig_lr_whitening(gpsig_ctx* c, const gpsig_params* p, const double* S_host, int32_t nc, int32_t d, const double* jitter_diag_host,
+                       double* Wh_host, double* ev_host) {
+    ENTER(c, p);
+    if (!S_host || !jitter_diag_host || !Wh_host || nc < 1 || d < 1) return fail(c, GPSIG_ERR_INVALID, "bad whitening request");
+    CHK(no_capture(c, "the Nystrom whitening copies to and from the host"));
+    void *dS, *dW, *dJ, *dWh;
+    CHK(ensure(c, B_LR2, sizeof(double) * size_t(nc) * d + 8, &dS));
+    CHK(ensure(c, B_LR4, sizeof(double) * size_t(nc) * nc + 8, &dW));
+    CHK(ensure(c, B_LR3, sizeof(double) * size_t(nc) * 3 + 64, &dJ));
+    CHK(ensure(c, B_LR5, sizeof(double) * size_t(nc) * nc + 8, &dWh));
+    double* const dEv = static_cast<double*>(dJ) + nc;
+    double* const dWork = static_cast<double*>(dJ) + 2 * size_t(nc);
+    int* const dInfo = reinterpret_cast<int*>(static_cast<double*>(dJ) + 3 * size_t(nc));
+    HIPCHK(c, hipMemcpyAsync(dS, S_host, sizeof(double) * size_t(nc) * d, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dJ, jitter_diag_host, sizeof(double) * size_t(nc), hipMemcpyHostToDevice, c->stream));
+    double p0, p1;
+    base_p(p, &p0, &p1);
+    const double* spec;
+    CHK(spectral_table(c, p, &spec));
+    const int64_t total = int64_t(nc) * nc;
+    hipLaunchKernelGGL(base_kernel_matrix_kernel<double>, dim3(grid_for(total)), dim3(256), 0, c->stream, static_cast<const double*>(dS),
+                       static_cast<const double*>(dS), int64_t(nc), int64_t(nc), int(d), int(p->base_kernel), p0, p1, spec,
+                       static_cast<double*>(dW));                                                         // low_rank_calculations.py:51
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(add_diag_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, static_cast<double*>(dW),
+                       static_cast<const double*>(dJ), int(nc));
+    HIPCHK(c, hipGetLastError());
+    std::string err;
+    if (!solver_dsyevd(&c->blas_handle, c->stream, nc, static_cast<double*>(dW), dEv, dWork, dInfo, &err))    // :55
+        return fail(c, GPSIG_ERR_HIP, "%s", err.c_str());
+    hipLaunchKernelGGL(eig_sign_kernel, dim3((nc + 63) / 64), dim3(64), 0, c->stream, static_cast<const double*>(dW), int(nc), dWork);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(whiten_kernel, dim3(unsigned((total + 255) / 256)), dim3(256), 0, c->stream, static_cast<const double*>(dW),
+                       static_cast<const double*>(dEv), static_cast<const double*>(dWork), int(nc), p->jitter, static_cast<double*>(dWh));
+    HIPCHK(c, hipGetLastError());
+    int info = 0;
+    HIPCHK(c, hipMemcpyAsync(Wh_host, dWh, sizeof(double) * size_t(total), hipMemcpyDeviceToHost, c->stream));
+    if (ev_host) HIPCHK(c, hipMemcpyAsync(ev_host, dEv, sizeof(double) * size_t(nc), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&info, dInfo, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+    CHK(host_sync(c));
+    if (info != 0) return fail(c, GPSIG_ERR_HIP, "rocsolver_dsyevd did not converge (info = %d)", info);
     return GPSIG_OK;
 }
 

@@ -53,9 +53,12 @@ __device__ __forceinline__ T scaled_point(const T* __restrict__ Xn, int L, int t
 
 // Records for the seq-gram kernel (layout: seq_configs.hpp / SeqGeom).  One thread per (n, row, fe).
 // `out` must have been zero-filled (padding columns and the record tail stay zero).
+// norm_col >= 0 (point rows, float64 RBF kernels with the table-driven exp): the values are multiplied by `pre`
+// (EXP_PRESCALE) and column norm_col of every row receives -|row|^2 / 2 (seq_step_rbf_prescaled in seq_core.hpp).
 template <typename T>
 __global__ void prep_seq_records_kernel(const T* __restrict__ X, int64_t N, int L, ScaleParams P, int mode,
-                                        int difference, int rows, int RS, int64_t rec_elems, T* __restrict__ out) {
+                                        int difference, int rows, int RS, int64_t rec_elems, T* __restrict__ out,
+                                        T pre = T(1), int norm_col = -1) {
     const int d_eff = P.d_eff();
     const int64_t total = N * rows * d_eff;
     for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
@@ -66,6 +69,17 @@ __global__ void prep_seq_records_kernel(const T* __restrict__ X, int64_t N, int 
         T v = T(0);
         if (mode == MODE_PT_DIFF) {
             v = scaled_point<T>(Xn, L, row, fe, P);
+            if (norm_col >= 0) {
+                v *= pre;
+                if (fe == 0) {
+                    T ss = v * v;
+                    for (int g = 1; g < d_eff; ++g) {
+                        const T u = pre * scaled_point<T>(Xn, L, row, g, P);
+                        ss = fma(u, u, ss);
+                    }
+                    out[n * rec_elems + int64_t(row) * RS + norm_col] = T(-0.5) * ss;
+                }
+            }
         } else if (row >= 1) {   // leading zero row
             if (mode == MODE_INC && difference) v = scaled_point<T>(Xn, L, row, fe, P) - scaled_point<T>(Xn, L, row - 1, fe, P);
             else v = scaled_point<T>(Xn, L, row - 1, fe, P);

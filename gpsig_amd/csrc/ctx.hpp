@@ -68,6 +68,7 @@ struct gpsig_ctx {
     int grad_scratch_mb = 4096;   // lattice scratch of one gradient launch
     int grad_impl = 0;            // 0: planner's choice, 1: one pair per thread + stored lattice, 2: one pair per thread scratch-free (tensor-vs-seq),
                                   // 3: wavefront kernel + stored lattice, 4: scratch-free wavefront kernel wherever it is built
+    void* blas_handle = nullptr;  // rocBLAS handle of gpsig_lr_whitening (lowrank_solver.hip), created at first use
     int tvs_tile = -1;            // Kzx tile kernel (tvs_tile_kernel.hpp): -1 where it is built, 0 never, 1 also below 32 tensors
     int tvs_tile_nw = 0;          // its waves per workgroup: 0 = planner's choice
     int tvs_zreg = -1;            // tensor-lane gradient: components in registers (1) or LDS (0); -1 = planner's choice

@@ -24,6 +24,8 @@
 
 #include <cmath>
 
+#include "fast_exp.hpp"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define GPSIG_HD __host__ __device__ __forceinline__
@@ -429,6 +431,27 @@ GPSIG_HD void seq_ho_level(SeqLaneHO<T, C, D, MMAX, OMAX, MODE>& L, const Nbr& n
 }
 }  // namespace detail
 
+// dM from the kernel values of this x point against the lane's C columns (point modes): the double increment of
+// signature_algs.py:26 with the previous row kept in the lane and the left neighbour's last column handed over
+template <typename T, int C, int MODE, class Lane, class Nbr>
+GPSIG_HD void seq_point_increments(Lane& L, const Nbr& nbr, const T (&knew)[C], bool dummy, int rlo, int rhi, T (&dm)[C]) {
+    if constexpr (MODE == MODE_PT_DIFF) {
+        const T kleft_new = nbr.kleft();
+        dm[0] = (knew[0] - kleft_new) - (L.kprev[0] - L.kleft);
+#pragma unroll
+        for (int r = 1; r < C; ++r) dm[r] = (knew[r] - knew[r - 1]) - (L.kprev[r] - L.kprev[r - 1]);
+#pragma unroll
+        for (int r = 0; r < C; ++r) L.kprev[r] = knew[r];
+        L.kleft = kleft_new;
+    } else {
+#pragma unroll
+        for (int r = 0; r < C; ++r) dm[r] = knew[r];
+    }
+#pragma unroll
+    for (int r = 0; r < C; ++r)
+        if (dummy || r < rlo || r >= rhi) dm[r] = T(0);
+}
+
 // dM for the lane's C columns from the x-side row (shared by both algorithms)
 template <typename T, int C, int D, int MODE, class Lane, class Nbr>
 GPSIG_HD void seq_increments(Lane& L, const Nbr& nbr, const T (&xr)[D], bool dummy, int rlo, int rhi, int kind, T p0, T p1,
@@ -454,21 +477,7 @@ GPSIG_HD void seq_increments(Lane& L, const Nbr& nbr, const T (&xr)[D], bool dum
             knew[r] = acc;
         }
         base_eval_n<T, C>(kind, knew, L.y2, xs, p0, p1);
-        if constexpr (MODE == MODE_PT_DIFF) {
-            const T kleft_new = nbr.kleft();
-            dm[0] = (knew[0] - kleft_new) - (L.kprev[0] - L.kleft);
-#pragma unroll
-            for (int r = 1; r < C; ++r) dm[r] = (knew[r] - knew[r - 1]) - (L.kprev[r] - L.kprev[r - 1]);
-#pragma unroll
-            for (int r = 0; r < C; ++r) L.kprev[r] = knew[r];
-            L.kleft = kleft_new;
-        } else {
-#pragma unroll
-            for (int r = 0; r < C; ++r) dm[r] = knew[r];
-        }
-#pragma unroll
-        for (int r = 0; r < C; ++r)
-            if (dummy || r < rlo || r >= rhi) dm[r] = T(0);
+        seq_point_increments<T, C, MODE>(L, nbr, knew, dummy, rlo, rhi, dm);
     }
 }
 
@@ -487,6 +496,26 @@ GPSIG_HD void seq_step(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T 
                        bool dummy, int rlo, int rhi, int kind, T p0, T p1) {
     T dm[C];
     seq_increments<T, C, D, MODE>(L, nbr, xr, dummy, rlo, rhi, kind, p0, p1, dm);
+    seq_recursion(L, nbr, dm, M);
+}
+
+// First-order step for the RBF kernel on PRESCALED records (float64, point modes): both sides' points were multiplied by
+// EXP_PRESCALE when the records were made, L.y2[r] holds -|y'_r|^2 / 2 and hx = -|x'|^2 / 2 comes with the x row (the spare
+// column of the record), so  <x', y'_r> + y2[r] + hx  =  -|x - y_r|^2 / 2 * 64/ln2  is the argument of the table-driven
+// 2^(t/64) (fast_exp.hpp).  Per column: D FMAs, one add, 13 instructions of exp -- against D + 3 and the ~20 of the library exp.
+template <int C, int D, int MMAX, int MODE, class Nbr>
+GPSIG_HD void seq_step_rbf_prescaled(SeqLane<double, C, D, MMAX, MODE>& L, const Nbr& nbr, const double (&xr)[D], double hx,
+                                     const double* etab, int M, bool dummy, int rlo, int rhi) {
+    static_assert(MODE != MODE_INC, "point modes only");
+    double knew[C], dm[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+        double acc = fma(xr[0], L.y[r][0], L.y2[r]);
+#pragma unroll
+        for (int f = 1; f < D; ++f) acc = fma(xr[f], L.y[r][f], acc);
+        knew[r] = kexp2_tab(acc + hx, etab);
+    }
+    seq_point_increments<double, C, MODE>(L, nbr, knew, dummy, rlo, rhi, dm);
     seq_recursion(L, nbr, dm, M);
 }
 

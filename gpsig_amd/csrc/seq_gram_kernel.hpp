@@ -43,6 +43,7 @@ __device__ __forceinline__ float shr1(float v) {
 // (signature_algs.py:37-74) for any run-time order <= OMAX.
 // KIND >= 0: the base kernel at compile time (built for the RBF kernel with differences, exact shapes): the C + 1 evaluations
 // of a step interleave instead of queueing behind a switch -- 5 % at the headline shape, 18 % at one wavefront per SIMD.
+#define SEQ_FAST_RBF(T, MODE, OMAX, KIND) (sizeof(T) == 8 && (KIND) == BASE_RBF && (MODE) == MODE_PT_DIFF && (OMAX) == 0)
 template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1>
 __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1) void seq_gram_kernel(const SeqGramArgs A) {
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
@@ -50,6 +51,12 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
     using Lane = typename std::conditional<OMAX == 0, SeqLane<T, C, D, MMAX, MODE>, SeqLaneHO<T, C, D, MMAX, (OMAX > 0 ? OMAX : 1), MODE>>::type;
     constexpr int VEC = 16 / sizeof(T);                  // elements per 16-byte piece
     typedef T vecT __attribute__((ext_vector_type(VEC)));
+
+    // float64 RBF at compile time: prescaled records + table-driven exp (seq_step_rbf_prescaled in seq_core.hpp); the host
+    // prepares the records accordingly whenever it launches such an instance (SeqPlanned::rbf_prescaled in api.hip)
+    constexpr bool FAST_RBF = SEQ_FAST_RBF(T, MODE, OMAX, KIND);
+    __shared__ double etab[FAST_RBF ? EXP_TAB_N : 1];
+    if constexpr (FAST_RBF) etab[threadIdx.x & (EXP_TAB_N - 1)] = g_exp2_tab[threadIdx.x & (EXP_TAB_N - 1)];
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* const zero_row = reinterpret_cast<T*>(smem_raw);   // RS elements of zeros (rows of idle lanes); LaneCtl offsets start here
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { L.y[r][f + e] = v[e]; ys = fma(v[e], v[e], ys); }
         }
-        L.y2[r] = ys;
+        L.y2[r] = FAST_RBF ? T(-0.5) * ys : ys;
     }
     // real lattice columns among the owned ones (point modes; see seq_core.hpp)
     const int rlo = (lam == 0) ? 1 : 0;
@@ -164,12 +171,15 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
 
         T xr[D];
         load_row(ctl, xr);
+        T hx = T(0);
+        if constexpr (FAST_RBF) hx = zero_row[ctl.rowoff + D];            // -|x'|^2 / 2, the record row's spare column
         const bool dummy = ctl.row0;
 
         // if lane 0 opens a new x at the next step, its record (requested issue_at steps into this x) must have landed
         if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-        seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, KIND >= 0 ? KIND : A.kind, p0, p1);
+        if constexpr (FAST_RBF) seq_step_rbf_prescaled(L, DevNbr{L}, xr, hx, etab, M, dummy, rlo, rhi);
+        else seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, KIND >= 0 ? KIND : A.kind, p0, p1);
         ctl.end_step();
     };
     // two steps per trip: the loop-carried hand-over words (s, qold) alternate registers instead of being copied

@@ -138,9 +138,11 @@ class LowRankState:
     """The random objects of one low-rank evaluation (reference: drawn inside the TF graph, kernels.py:443-449,
     low_rank_calculations.py:47-57): landmarks (c, d') -- scaled points --, whitening (c, c), one sketch per level >= 2."""
 
-    def __init__(self, landmarks, whitening, sketches, rank_bound):
+    def __init__(self, landmarks, whitening, sketches, rank_bound, jitter_diag=None, eigenvalues=None):
         self.landmarks = np.ascontiguousarray(landmarks, dtype=np.float64)
         self.whitening = np.ascontiguousarray(whitening, dtype=np.float64)
+        self.jitter_diag = jitter_diag            # the draw of low_rank_calculations.py:52 the whitening was computed with
+        self.eigenvalues = eigenvalues            # of the jittered landmark Gram, ascending (before :56 adds the jitter)
         self.sketches = list(sketches)
         self.rank_bound = int(rank_bound)
         self.num_components = self.landmarks.shape[0]
@@ -518,14 +520,13 @@ class SignatureKernel:
                             out.ctypes.data_as(C.POINTER(C.c_double)))
             parts.append(out)
         S = np.ascontiguousarray(np.concatenate(parts, axis=0))
-        W = np.empty((c, c))
-        L_.ctx.call("gpsig_base_kernel_matrix", p, S.ctypes.data_as(C.POINTER(C.c_double)), S.ctypes.data_as(C.POINTER(C.c_double)), c, c,
-                    d_eff, W.ctypes.data_as(C.POINTER(C.c_double)))
-        W = W + np.diag(JITTER * self.rng.random(c))                              # low_rank_calculations.py:52
-        ev, U = np.linalg.eigh(W)                                                 # :55
-        Wh = U / np.sqrt(ev + JITTER)[None, :]                                    # :56-57, :60
+        jd = np.ascontiguousarray(JITTER * self.rng.random(c))                    # low_rank_calculations.py:52
+        Wh, ev = np.empty((c, c)), np.empty(c)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))                    # noqa: E731
+        # landmark Gram + jitter, eigendecomposition (rocSOLVER dsyevd) and U / sqrt(S + jitter) on the device (:50-57, :60)
+        L_.ctx.call("gpsig_lr_whitening", p, dp(S), c, d_eff, dp(jd), dp(Wh), dp(ev))
         sk = _lr.draw_level_sketches(self.rng, self.num_levels, c, int(self.rank_bound), self.sparsity)
-        return LowRankState(S, Wh, sk, self.rank_bound)
+        return LowRankState(S, Wh, sk, self.rank_bound, jitter_diag=jd, eigenvalues=ev)
 
     def _lr_features(self, L_, p, lr, A, tensors=False, increments=False):
         F = 1 + lr.num_components + (self.num_levels - 1) * lr.rank_bound

@@ -211,6 +211,12 @@ int gpsig_lr_gather_points(gpsig_ctx* ctx, const gpsig_params* p, const void* X,
 /* kappa(A, B) of already scaled points, all on the HOST: A (na, d'), B (nb, d') -> out (na, nb) */
 int gpsig_base_kernel_matrix(gpsig_ctx* ctx, const gpsig_params* p, const double* A_host, const double* B_host, int64_t na,
                              int64_t nb, int32_t d, double* out_host);
+/* Nystrom whitening (low_rank_calculations.py:50-57, :60) of c landmarks S (c, d') -- already scaled points, HOST --:
+ * W = kappa(S, S) + diag(jitter_diag) on the device, rocSOLVER dsyevd, whitening (c, c) = U / sqrt(eigenvalues + p->jitter) back
+ * on the HOST (the layout gpsig_lowrank.whitening takes).  eigenvalues_host: (c) ascending, or NULL.  The reference draws
+ * jitter_diag as settings.jitter * uniform(0, 1) per landmark (:52); it is an argument here so that the caller owns the RNG. */
+int gpsig_lr_whitening(gpsig_ctx* ctx, const gpsig_params* p, const double* landmarks_host, int32_t c, int32_t d,
+                       const double* jitter_diag_host, double* whitening_host, double* eigenvalues_host);
 /* SignatureKernel._K_seq_lr_feat (kernels.py:239-261): Nystrom_map + signature_kern_first_order_lr_feature.  Phi: (N, F). */
 int gpsig_lr_seq_features(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowrank* lr, const void* X, int64_t N, int32_t L, void* Phi);
 /* SignatureKernel._K_tens_lr_feat (kernels.py:285-311): Nystrom_map + tensor_kern_lr_feature.  Phi: (T, F). */

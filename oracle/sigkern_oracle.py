@@ -619,17 +619,36 @@ def inducing_sequences_Kuu_Kuf_Kff(kern, Z, X, W=None, jitter=0.0, full_f_cov=Fa
 # ---------------------------------------------------------------------------
 # Low-rank algorithms: gpsig/low_rank_calculations.py, gpsig/signature_algs.py:162-222, gpsig/kernels.py:239-311.
 # The reference draws landmarks and projections with TensorFlow's RNG inside the graph (not reproducible), so these
-# restatements take the random objects as ARGUMENTS: `landmarks` (c, d') and `sketches` (one per level >= 2, anything
-# with an .apply(A, B) -> (..., r) method; the tests pass the very objects the product uses, gpsig_amd.low_rank.Sketch,
-# whose apply() is a plain NumPy sum).  Parity with the reference is therefore statistical only;
+# restatements take the random objects as ARGUMENTS: `landmarks` (c, d') and `sketches` (one per level >= 2: plain data
+# -- r outputs, column pointers colptr (r+1), coordinate pairs i1 / i2 and values val (nnz) -- applied by apply_sketch
+# below; no code of the product is called).  Parity with the reference is therefore statistical only;
 # parity between the HIP path and this restatement, given the same random objects, is exact.
 # Q6 (reference bugs NOT reproduced): signature_algs.py:191 appends reduce_sum(U) instead of reduce_sum(P);
 # kernels.py:425,448-449 pass the unscaled X to the low-rank feature map while Kdiag (:500) passes the scaled one.
 # ---------------------------------------------------------------------------
+def apply_sketch(sk, A, B):
+    """lr_hadamard_prod_rand (low_rank_calculations.py:76-193) given its random matrix: output column j of the projected
+    row-wise Kronecker product is  sum_e val[e] * A[..., i1[e]] * B[..., i2[e]]  over the entries e of column j
+    ('lin', :104-127: one entry per column with a Rademacher sign; 'sqrt' / 'log', :152-193: the non-zeros of the very
+    sparse Gaussian matrix, already scaled by sqrt(s / r)).  (..., k1), (..., k2) -> (..., r)."""
+    colptr, i1, i2, val = (np.asarray(getattr(sk, n)) for n in ("colptr", "i1", "i2", "val"))
+    out = np.zeros(A.shape[:-1] + (int(sk.r),), dtype=np.result_type(A, B))
+    for j in range(int(sk.r)):
+        e = slice(int(colptr[j]), int(colptr[j + 1]))
+        out[..., j] = np.einsum("...e,...e,e->...", A[..., i1[e]], B[..., i2[e]], val[e])
+    return out
+
+
 def nystrom_whitening(kern_fn, landmarks, jitter_diag):
-    """low_rank_calculations.py:50-57: W = k(S,S) + diag(jitter_diag); eig; S += jitter; returns U / sqrt(S) (c, c)."""
+    """low_rank_calculations.py:50-57: W = k(S,S) + diag(jitter_diag); eig; S += jitter; returns U / sqrt(S) (c, c).
+    An eigensolver fixes each eigenvector up to sign only (tf.self_adjoint_eig at :55 as much as LAPACK here), and the
+    level >= 2 features depend on those signs through the random projections of coordinate pairs; to make an evaluation a
+    function of its random objects the component of largest magnitude of every eigenvector is taken positive -- a
+    convention, not something the reference states."""
     W = kern_fn(landmarks, landmarks) + np.diag(jitter_diag)                      # :51-52
     S, U = np.linalg.eigh(W)                                                     # :55
+    top = np.argmax(np.abs(U), axis=0)
+    U = U * np.where(U[top, np.arange(U.shape[1])] < 0, -1.0, 1.0)[None, :]
     S = S + JITTER                                                               # :56
     return U / np.sqrt(S)[None, :]                                               # :57, :60
 
@@ -648,7 +667,7 @@ def signature_kern_first_order_lr_feature(U, num_levels, sketches, difference=Tr
     P = U                                                                        # :184
     for i in range(2, num_levels + 1):                                           # :185
         P = _excumsum(P, 1)                                                      # :186
-        P = sketches[i - 2].apply(U, P)                                          # :188/:190  lr_hadamard_prod_rand(U, P, ...)
+        P = apply_sketch(sketches[i - 2], U, P)                                         # :188/:190  lr_hadamard_prod_rand(U, P, ...)
         Phi.append(P.sum(axis=1))                                                # :191 (Q6: the reference sums U here)
     return Phi
 
@@ -660,7 +679,7 @@ def tensor_kern_lr_feature(U, num_levels, sketches):
     for i in range(1, num_levels + 1):                                           # :212
         R = U[k]; k += 1                                                         # :213-214
         for j in range(1, i):                                                    # :215
-            R = sketches[j - 1].apply(U[k], R); k += 1                           # :217/:219  lr_hadamard_prod_rand(U[k], R, ...)
+            R = apply_sketch(sketches[j - 1], U[k], R); k += 1                           # :217/:219  lr_hadamard_prod_rand(U[k], R, ...)
         Phi.append(R)                                                            # :221
     return Phi
 
