@@ -12,7 +12,8 @@ gpsig/models.py:40-59).  Here the same role is split in two:
 ``SignatureKernelModule`` holds the hyper-parameters as unconstrained ``torch.nn.Parameter``s with GPflow 1.5.1's transforms
 (``transforms.positive`` = softplus + 1e-6 for variances, sigma, lengthscales, gamma, the base-kernel parameter;
 ``transforms.Logistic`` for lags; kernels.py:65-88) so that an optimiser step means what it means in the reference.
-First-order algorithm (order = 1), float64, exact (non low-rank) mode.  No CPU fallback: tensors must live on the GPU.
+Exact (non low-rank) mode, first- and higher-order algorithms; computed by the float64 kernels (float32 tensors -- a module after
+.float() -- are converted on the way in, results and gradients rounded on the way out).  No CPU fallback: tensors must live on the GPU.
 """
 import ctypes as C
 import math
@@ -45,14 +46,15 @@ def logistic_inverse(value):
 class _Spec:
     """What a level primitive needs besides its tensors."""
 
-    def __init__(self, base, num_levels, difference, p1=0.0):
+    def __init__(self, base, num_levels, difference, p1=0.0, order=1):
         self.base, self.num_levels, self.difference, self.p1 = base, int(num_levels), bool(difference), float(p1)
+        self.order = max(1, min(int(order), self.num_levels))          # kernels.py:57 clamps to num_levels
 
     def params(self, d_cols, p0, keep):
         p = _lib.Params()
         p.base_kernel = _lib.BASE[self.base]
         p.dtype = _lib.F64
-        p.num_features, p.num_levels, p.order = int(d_cols), self.num_levels, 1
+        p.num_features, p.num_levels, p.order = int(d_cols), self.num_levels, self.order
         p.difference, p.normalization, p.num_lags = int(self.difference), 0, 0
         p.sigma, p.jitter = 1.0, JITTER
         p.base_params[0], p.base_params[1] = float(p0), self.p1
@@ -73,6 +75,13 @@ def _ctx_for(t):
 
 def _c(t):
     return t.detach().to(torch.float64).contiguous()
+
+
+def _out_dtype(*ts):
+    """float32 only if every tensor argument is float32 (then the float64 kernels' result is rounded, as the evaluation
+    path does for float32 requests it has no float32 kernel for); anything else is float64."""
+    ts = [t for t in ts if t is not None]
+    return torch.float32 if ts and all(t.dtype == torch.float32 for t in ts) else torch.float64
 
 
 def _ptr(t):
@@ -96,8 +105,9 @@ class _SeqGramLevels(torch.autograd.Function):
         out = torch.empty((spec.num_levels + 1, n1, n2), dtype=torch.float64, device=X.device)
         _ctx_for(X).call("gpsig_seq_gram_levels", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(out))
         ctx.spec, ctx.has_x2, ctx.has_p0 = spec, X2 is not None, p0 is not None
+        ctx.dt = (Xs.dtype, None if X2s is None else X2s.dtype)
         ctx.save_for_backward(X, X2 if X2 is not None else X.new_empty(0), p0 if p0 is not None else X.new_empty(0))
-        return out
+        return out.to(_out_dtype(Xs, X2s))
 
     @staticmethod
     def backward(ctx, G):
@@ -113,8 +123,8 @@ class _SeqGramLevels(torch.autograd.Function):
         gb = torch.zeros(2, dtype=torch.float64, device=X.device)
         _ctx_for(X).call("gpsig_seq_gram_levels_grad", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(G), _ptr(gX),
                          None if gX2 is None else _ptr(gX2), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
-        gp0 = gb[0].to(p0.device).reshape(p0.shape) if ctx.has_p0 else None
-        return gX, gX2, gp0, None
+        gp0 = gb[0].to(p0.device).reshape(p0.shape).to(p0.dtype) if ctx.has_p0 else None
+        return gX.to(ctx.dt[0]), None if gX2 is None else gX2.to(ctx.dt[1]), gp0, None
 
 
 class _SeqDiagLevels(torch.autograd.Function):
@@ -129,8 +139,9 @@ class _SeqDiagLevels(torch.autograd.Function):
         out = torch.empty((spec.num_levels + 1, n), dtype=torch.float64, device=X.device)
         _ctx_for(X).call("gpsig_seq_diag_levels", p, _ptr(X), n, l, _ptr(out))
         ctx.spec, ctx.has_p0 = spec, p0 is not None
+        ctx.dt = Xs.dtype
         ctx.save_for_backward(X, p0 if p0 is not None else X.new_empty(0))
-        return out
+        return out.to(_out_dtype(Xs))
 
     @staticmethod
     def backward(ctx, G):
@@ -142,8 +153,8 @@ class _SeqDiagLevels(torch.autograd.Function):
         gX = torch.empty_like(X)
         gb = torch.zeros(2, dtype=torch.float64, device=X.device)
         _ctx_for(X).call("gpsig_seq_diag_levels_grad", p, _ptr(X), n, l, _ptr(G), _ptr(gX), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
-        gp0 = gb[0].to(p0.device).reshape(p0.shape) if ctx.has_p0 else None
-        return gX, gp0, None
+        gp0 = gb[0].to(p0.device).reshape(p0.shape).to(p0.dtype) if ctx.has_p0 else None
+        return gX.to(ctx.dt), gp0, None
 
 
 class _TensGramLevels(torch.autograd.Function):
@@ -158,8 +169,9 @@ class _TensGramLevels(torch.autograd.Function):
         out = torch.empty((spec.num_levels + 1, t, t), dtype=torch.float64, device=Z.device)
         _ctx_for(Z).call("gpsig_tens_gram_levels", p, _ptr(Z), t, int(bool(increments)), _ptr(out))
         ctx.spec, ctx.has_p0, ctx.increments = spec, p0 is not None, bool(increments)
+        ctx.dt = Zs.dtype
         ctx.save_for_backward(Z, p0 if p0 is not None else Z.new_empty(0))
-        return out
+        return out.to(_out_dtype(Zs))
 
     @staticmethod
     def backward(ctx, G):
@@ -172,8 +184,8 @@ class _TensGramLevels(torch.autograd.Function):
         gb = torch.zeros(2, dtype=torch.float64, device=Z.device)
         _ctx_for(Z).call("gpsig_tens_gram_levels_grad", p, _ptr(Z), t, int(ctx.increments), _ptr(G), _ptr(gZ),
                          C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
-        gp0 = gb[0].to(p0.device).reshape(p0.shape) if ctx.has_p0 else None
-        return gZ, gp0, None, None
+        gp0 = gb[0].to(p0.device).reshape(p0.shape).to(p0.dtype) if ctx.has_p0 else None
+        return gZ.to(ctx.dt), gp0, None, None
 
 
 class _TensVsSeqLevels(torch.autograd.Function):
@@ -189,8 +201,9 @@ class _TensVsSeqLevels(torch.autograd.Function):
         out = torch.empty((spec.num_levels + 1, t, n), dtype=torch.float64, device=Z.device)
         _ctx_for(Z).call("gpsig_tens_vs_seq_levels", p, _ptr(Z), _ptr(X), t, n, l, int(bool(increments)), _ptr(out))
         ctx.spec, ctx.has_p0, ctx.increments = spec, p0 is not None, bool(increments)
+        ctx.dt = (Zs.dtype, Xs.dtype)
         ctx.save_for_backward(Z, X, p0 if p0 is not None else Z.new_empty(0))
-        return out
+        return out.to(_out_dtype(Zs, Xs))
 
     @staticmethod
     def backward(ctx, G):
@@ -204,8 +217,8 @@ class _TensVsSeqLevels(torch.autograd.Function):
         gb = torch.zeros(2, dtype=torch.float64, device=Z.device)
         _ctx_for(Z).call("gpsig_tens_vs_seq_levels_grad", p, _ptr(Z), _ptr(X), t, n, l, int(ctx.increments), _ptr(G), _ptr(gZ), _ptr(gX),
                          C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
-        gp0 = gb[0].to(p0.device).reshape(p0.shape) if ctx.has_p0 else None
-        return gZ, gX, gp0, None, None
+        gp0 = gb[0].to(p0.device).reshape(p0.shape).to(p0.dtype) if ctx.has_p0 else None
+        return gZ.to(ctx.dt[0]), gX.to(ctx.dt[1]), gp0, None, None
 
 
 # ---- scaling (gpsig/kernels.py:343-398, gpsig/lags.py) in torch ------------------------------------------------------
@@ -229,7 +242,8 @@ def _add_lags(X, lags):
 
 
 class SignatureKernelModule(torch.nn.Module):
-    """Trainable view of a ``gpsig_amd.kernels.SignatureKernel`` (order 1, exact mode).
+    """Trainable view of a ``gpsig_amd.kernels.SignatureKernel`` (exact mode; any order -- the higher-order algorithms'
+    gradients run through scratch-based kernels built for coverage rather than speed, grad_ho_kernels.hpp).
 
     ``kern`` supplies the structure (base kernel, levels, normalisation, lags, ...) and the initial hyper-parameter values;
     ``write_back()`` copies the trained values into it so that the fused inference path (``kern.K`` etc.) uses them."""
@@ -238,8 +252,6 @@ class SignatureKernelModule(torch.nn.Module):
         super().__init__()
         if kern._base is None:
             raise NotImplementedError("SignatureKernel is abstract: use SignatureLinear, SignatureRBF, ...")
-        if kern.order != 1 and kern.num_levels > 1:
-            raise NotImplementedError("gradients are built for the first-order algorithm (order=1) only")
         if kern.low_rank:
             raise NotImplementedError("gradients are built for the exact (non low-rank) mode only")
         self.kern = kern
@@ -254,7 +266,7 @@ class SignatureKernelModule(torch.nn.Module):
         bp = kern._current_base_params()
         self._has_p0 = kern._base in ("poly", "mix")
         self.raw_p0 = par(positive_inverse(bp[0])) if self._has_p0 else None
-        self._spec = _Spec(kern._base, kern.num_levels, kern.difference, p1=float(bp[1]) if len(bp) > 1 else 0.0)
+        self._spec = _Spec(kern._base, kern.num_levels, kern.difference, p1=float(bp[1]) if len(bp) > 1 else 0.0, order=kern.order)
 
     # constrained values
     @property

@@ -19,15 +19,18 @@
 #include "seq_args.hpp"
 #include "seq_configs.hpp"
 #include "tvs_tile_kernel.hpp"
+#include "seq_pk2_kernel.hpp"
 
 namespace gpsig {
 typedef hipError_t (*TvsTileLaunchFn)(const TvsTileArgs&, size_t, hipStream_t);
 TvsTileLaunchFn tvs_tile_lookup(int M, int NW, int D, bool incr, int kind);
 int tvs_tile_width(int d);
+bool seq_pk2_select(int rows, int d, int M, int* G, int* C, int* D);
 bool solver_dsyevd(void** handle_slot, hipStream_t stream, int n, double* A, double* ev, double* work, int* info, std::string* err);
 void solver_release(void* handle);
 int tvs_tile_waves(int M, int D, int E, int kind);
 typedef hipError_t (*SeqLaunchFn)(const SeqGramArgs&, int, size_t, hipStream_t);
+SeqLaunchFn seq_pk2_lookup(int G, int C, int D, int M, int mode);
 SeqLaunchFn seq_lookup_inc_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_inc_ex_g16_d4(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_inc_ex_g16_d8(int, int, int, int, bool);
@@ -415,7 +418,9 @@ struct SeqPlanned {
     SeqConfig cfg;
     SeqLaunchFn fn;
     int mode, d_eff;
-    bool rbf_prescaled;      // fn is a float64 RBF instance with the table-driven exp: records carry prescaled points + norms
+    bool rbf_prescaled;      // fn is an RBF instance that takes prescaled records: points x prescale, -|row|^2/2 in the spare column
+    double prescale;         // EXP_PRESCALE (float64, table-driven exp) or PK2_RBF_PRESCALE (float32, v_exp_f32)
+    bool pk2;                // fn is a seq_pk2_kernel instance: a pair group serves two y sequences
 };
 
 static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
@@ -423,6 +428,8 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
         return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for float64 only");
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
     out->rbf_prescaled = false;
+    out->prescale = 1.0;
+    out->pk2 = false;
     if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
         int k = seq_select_ho(SEQ_HO_TABLE, N_SEQ_HO_TABLE, g0.rows, d_eff, p->num_levels, p->order);
         if (k < 0)
@@ -439,6 +446,21 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
         return GPSIG_OK;
     }
     const bool f32 = sizeof(TT) == 4;
+    // (the linear kernel only on request, allow_pk2 == 2: it is slower there than the one-sequence kernels, seq_pk2_kernel.hpp)
+    if (f32 && c->allow_pk2 && c->allow_exact && ((g0.mode == MODE_INC && c->allow_pk2 == 2) || (g0.mode == MODE_PT_DIFF && p->base_kernel == GPSIG_BASE_RBF))) {
+        int G, C, D;                                   // two y sequences per pair group on the packed float32 instructions
+        if (seq_pk2_select(g0.rows, d_eff, p->num_levels, &G, &C, &D)) {
+            out->cfg = SeqConfig{G, C, D, p->num_levels, true};
+            out->mode = g0.mode;
+            out->d_eff = d_eff;
+            out->fn = seq_pk2_lookup(G, C, D, p->num_levels, g0.mode);
+            out->pk2 = true;
+            out->rbf_prescaled = g0.mode == MODE_PT_DIFF;
+            out->prescale = PK2_RBF_PRESCALE;
+            if (out->fn) return GPSIG_OK;
+        }
+    }
+    out->pk2 = false; out->rbf_prescaled = false; out->prescale = 1.0;
     const SeqConfig* tab = f32 ? SEQ_TABLE_F32 : (g0.mode == MODE_PT_NODIFF ? SEQ_TABLE_GENERIC : SEQ_TABLE);
     const int ntab = f32 ? N_SEQ_TABLE_F32 : (g0.mode == MODE_PT_NODIFF ? N_SEQ_TABLE_GENERIC : N_SEQ_TABLE);
     int k = seq_select(tab, ntab, g0.rows, d_eff, p->num_levels, c->allow_exact != 0 && g0.mode != MODE_PT_NODIFF);
@@ -454,6 +476,7 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
     if (!f32 && g0.mode == MODE_PT_DIFF && p->base_kernel == GPSIG_BASE_RBF && tab[k].exact) {
         out->fn = seq_launcher_rbf(tab[k]);
         out->rbf_prescaled = out->fn != nullptr;
+        out->prescale = EXP_PRESCALE;
     }
     if (!out->fn) out->fn = seq_launcher(g0.mode, tab[k], sizeof(TT) == 4, p->base_kernel);
     if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "seq-gram kernel shape missing from this build");
@@ -473,7 +496,7 @@ static int make_records(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling,
         const int64_t total = N * geom->rows * s.d_eff();
         hipLaunchKernelGGL(prep_seq_records_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, c->stream,
                            static_cast<const TT*>(Xdev), N, L, s, geom->mode, p->difference, geom->rows, geom->RS,
-                           int64_t(geom->rec_elems), static_cast<TT*>(d), pl.rbf_prescaled ? TT(EXP_PRESCALE) : TT(1),
+                           int64_t(geom->rec_elems), static_cast<TT*>(d), pl.rbf_prescaled ? TT(pl.prescale) : TT(1),
                            pl.rbf_prescaled ? pl.cfg.D : -1);
         HIPCHK(c, hipGetLastError());
     }
@@ -518,7 +541,7 @@ struct SeqRun {
 static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const SeqRun& r) {
     if (r.N1 <= 0 || r.N2 <= 0) return GPSIG_OK;
     if (r.N1 > 0x7fffffff || r.N2 > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 sequences");
-    const int ypb = 64 / pl.cfg.G;
+    const int ypb = (64 / pl.cfg.G) * (pl.pk2 ? 2 : 1);
     // aim for ~64k independent tasks (about 20 per resident wave slot) so the tail is a few per cent
     const int64_t nblocks = ((r.y_end > 0 ? r.y_end - r.y_begin : r.N2) + ypb - 1) / ypb;
     const int64_t xtot = r.pred == PRED_ALL ? r.N1 : (r.pred == PRED_DIAG ? ypb : r.N1 / 2 + ypb);
@@ -1387,6 +1410,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "grad_scratch_mb")) c->grad_scratch_mb = value > 0 ? value : 4096;
     else if (!strcmp(name, "grad_impl")) c->grad_impl = value;
     else if (!strcmp(name, "tvs_zreg")) c->tvs_zreg = value;
+    else if (!strcmp(name, "pk2")) c->allow_pk2 = value;
     else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);

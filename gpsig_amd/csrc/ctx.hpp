@@ -63,6 +63,7 @@ struct gpsig_ctx {
     int shard_i = 0, shard_n = 1;
     int use_glds = 1;
     int allow_exact = 1;
+    int allow_pk2 = 1;            // float32: the packed two-sequence kernels (seq_pk2_kernel.hpp) where they are built
     int max_run = 0;
     int tens_lanes = -1;   // -1 auto, 0 sequence lanes, 1 tensor lanes
     int grad_scratch_mb = 4096;   // lattice scratch of one gradient launch

@@ -6,6 +6,7 @@
 // to cite, the formulas are in grad_core.hpp.  Host side only: staging, chunking by the scratch budget, launches.
 #include "ctx.hpp"
 #include "grad_kernels.hpp"
+#include "grad_ho_kernels.hpp"
 #include "grad_wave_kernel.hpp"
 
 namespace gpsig {
@@ -31,7 +32,7 @@ int grad_check(gpsig_ctx* c, const gpsig_params* p, int* d, int* DP) {
     if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for float64 only");
     if (p->num_levels < 1) return fail(c, GPSIG_ERR_INVALID, "num_levels must be >= 1");
     if (p->num_levels > GRAD_MAX_LEVELS) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for num_levels <= %d", GRAD_MAX_LEVELS);
-    if (p->order != 1 && p->num_levels > 1) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for the first-order algorithm (order=1) only");
+    if (p->order < 1 || p->order > p->num_levels) return fail(c, GPSIG_ERR_INVALID, "order=%d outside [1, num_levels]", p->order);
     if (p->base_kernel < GPSIG_BASE_LINEAR || p->base_kernel > GPSIG_BASE_MATERN52) return fail(c, GPSIG_ERR_INVALID, "unknown base kernel %d", p->base_kernel);
     if (p->num_features < 1 || p->num_lags < 0) return fail(c, GPSIG_ERR_INVALID, "bad num_features / num_lags");
     *d = p->num_features * (p->num_lags + 1);      // raw entry points: columns are taken as they come
@@ -396,6 +397,123 @@ int seq_grad_undo(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, 
     return GPSIG_OK;
 }
 
+// ---- higher-order algorithm (order > 1): lattice operations over blocks of pairs (grad_ho_kernels.hpp) + lam_contract_kernel ----
+int seq_grad_ho(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2,
+                int d, bool diag, bool sym, const double* Gup, double* gX, double* gY, double* gbase) {
+    const int M = p->num_levels, D = p->order, dr = mode == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = L1 - dr, R2 = L2 - dr;
+    CHK(zero_async(c, gX, sizeof(double) * size_t(N1) * L1 * d));
+    if (!diag && !sym) CHK(zero_async(c, gY, sizeof(double) * size_t(N2) * L2 * d));
+    if (R1 <= 0 || R2 <= 0) return GPSIG_OK;
+    auto dm_of = [&](int m) { return m < D ? m : D; };
+    // slots: dM | R_m[r][s] for m = 2 .. M-1 | two grids of adjoints | two temporaries | Lam
+    std::vector<int> roff(M + 1, 0);
+    int nslots = 1;
+    for (int m = 2; m <= M - 1; ++m) { roff[m] = nslots; nslots += dm_of(m) * dm_of(m); }
+    const int u0 = nslots, u1 = u0 + D * D, t0 = u1 + D * D, t1 = t0 + 1, lamslot = t1 + 1;
+    nslots = lamslot + 1;
+    const size_t cells = size_t(R1) * R2, per_pair = sizeof(double) * cells * size_t(nslots);
+    const int64_t gm = diag ? N1 : N1 * N2, gi = diag ? 1 : N2, gj = diag ? 0 : 1;
+    LamContractArgs K;
+    memset(&K, 0, sizeof(K));
+    // the double increment of <x, y> is the lattice of the linear kernel on increments: the contraction takes it as a point kernel
+    K.X = X; K.Y = Y; K.L1 = L1; K.L2 = L2; K.d = d; K.kind = p->base_kernel; K.mode = mode == MODE_INC ? MODE_PT_DIFF : mode;
+    K.p0 = p->base_params[0]; K.p1 = p->base_params[1]; K.diag = diag ? 1 : 0;
+    for (int64_t i0 = 0; i0 < N1;) {
+        const int64_t nj = diag ? 1 : N2;
+        int64_t ni = int64_t(scratch_budget(c) / (per_pair * size_t(nj)));
+        if (ni < 1) ni = 1;
+        if (ni > N1 - i0) ni = N1 - i0;
+        if (ni > 65535) ni = 65535;
+        void* scr;
+        CHK(ensure(c, B_GR5, per_pair * size_t(nj) * size_t(ni) + 64, &scr));
+        const int64_t npairs = ni * nj, P = npairs * int64_t(cells);
+        double* const base = static_cast<double*>(scr);
+        auto slot = [&](int k) { return base + int64_t(k) * P; };
+        auto Rm = [&](int m, int r, int s) { return m == 1 ? slot(0) : slot(roff[m] + r * dm_of(m) + s); };
+        const HoBlock B{i0, ni, diag ? i0 : 0, nj, diag ? 1 : 0};
+        auto mul = [&](const double* A_, const double* B_, double* dst, double scale, int acc) {
+            hipLaunchKernelGGL(ho_mul_kernel, dim3(grid_for(P)), dim3(256), 0, c->stream, A_, B_, dst, P, scale, acc);
+        };
+        auto cum = [&](const double* src, double* dst, int axis, int reverse) {
+            hipLaunchKernelGGL(ho_cumsum_kernel, dim3(grid_for(npairs * (axis == 0 ? R2 : R1), 64)), dim3(64), 0, c->stream, src, dst, npairs, R1,
+                               R2, axis, reverse, 1.0, 0);
+        };
+        auto bcast = [&](int m, double* dst, int acc) {
+            hipLaunchKernelGGL(ho_bcast_kernel, dim3(grid_for(P)), dim3(256), 0, c->stream, Gup, int64_t(m) * gm, gi, gj, B, int64_t(cells), dst, acc);
+        };
+        // sums of the previous level's grid into t0: all of it, column j2 (over r), row j2 (over s)
+        auto sum_all = [&](int m) { const int dp = dm_of(m); for (int r = 0; r < dp; ++r) for (int s = 0; s < dp; ++s) mul(Rm(m, r, s), nullptr, slot(t0), 1.0, r + s > 0); };
+        auto sum_col = [&](int m, int j2) { const int dp = dm_of(m); for (int r = 0; r < dp; ++r) mul(Rm(m, r, j2), nullptr, slot(t0), 1.0, r > 0); };
+        auto sum_row = [&](int m, int j2) { const int dp = dm_of(m); for (int s = 0; s < dp; ++s) mul(Rm(m, j2, s), nullptr, slot(t0), 1.0, s > 0); };
+        hipLaunchKernelGGL(ho_dm_kernel, dim3(grid_for(P)), dim3(256), 0, c->stream, X, Y, L1, L2, d, int(p->base_kernel), mode == MODE_PT_NODIFF ? 1 : 0,
+                           K.p0, K.p1, B, R1, R2, slot(0));
+        // forward: the grids of levels 2 .. M-1 (signature_algs.py:61-69); level M's own grid is never needed
+        for (int m = 2; m <= M - 1; ++m) {
+            const int dc = dm_of(m);
+            sum_all(m - 1); cum(slot(t0), slot(t1), 0, 0); cum(slot(t1), slot(t0), 1, 0);
+            mul(slot(0), slot(t0), Rm(m, 0, 0), 1.0, 0);                                                   // :64
+            for (int j = 2; j <= dc; ++j) {
+                sum_col(m - 1, j - 2); cum(slot(t0), slot(t1), 0, 0);
+                mul(slot(0), slot(t1), Rm(m, 0, j - 1), 1.0 / j, 0);                                       // :66
+                sum_row(m - 1, j - 2); cum(slot(t0), slot(t1), 1, 0);
+                mul(slot(0), slot(t1), Rm(m, j - 1, 0), 1.0 / j, 0);                                       // :67
+                for (int k = 2; k <= dc; ++k) mul(slot(0), Rm(m - 1, j - 2, k - 2), Rm(m, j - 1, k - 1), 1.0 / (double(j) * k), 0);   // :69
+            }
+        }
+        // backward
+        int ucur = u0, unext = u1;
+        auto U = [&](int set, int r, int s) { return slot(set + r * D + s); };
+        for (int r = 0; r < dm_of(M); ++r) for (int s = 0; s < dm_of(M); ++s) bcast(M, U(ucur, r, s), 0);
+        CHK(zero_async(c, slot(lamslot), sizeof(double) * size_t(P)));
+        for (int m = M; m >= 2; --m) {
+            const int dc = dm_of(m), dp = dm_of(m - 1);
+            // Lam += U_m[r][s] * (multiplier of dM in R_m[r][s])
+            sum_all(m - 1); cum(slot(t0), slot(t1), 0, 0); cum(slot(t1), slot(t0), 1, 0);
+            mul(U(ucur, 0, 0), slot(t0), slot(lamslot), 1.0, 1);
+            for (int j = 2; j <= dc; ++j) {
+                sum_col(m - 1, j - 2); cum(slot(t0), slot(t1), 0, 0);
+                mul(U(ucur, 0, j - 1), slot(t1), slot(lamslot), 1.0 / j, 1);
+                sum_row(m - 1, j - 2); cum(slot(t0), slot(t1), 1, 0);
+                mul(U(ucur, j - 1, 0), slot(t1), slot(lamslot), 1.0 / j, 1);
+                for (int k = 2; k <= dc; ++k) mul(U(ucur, j - 1, k - 1), Rm(m - 1, j - 2, k - 2), slot(lamslot), 1.0 / (double(j) * k), 1);
+            }
+            // U_{m-1}: upstream of K_{m-1} + the transposed operations of level m
+            mul(slot(0), U(ucur, 0, 0), slot(t0), 1.0, 0); cum(slot(t0), slot(t1), 0, 1); cum(slot(t1), slot(t0), 1, 1);
+            for (int r = 0; r < dp; ++r)
+                for (int s = 0; s < dp; ++s) { bcast(m - 1, U(unext, r, s), 0); mul(slot(t0), nullptr, U(unext, r, s), 1.0, 1); }
+            for (int j = 2; j <= dc; ++j) {
+                mul(slot(0), U(ucur, 0, j - 1), slot(t0), 1.0 / j, 0); cum(slot(t0), slot(t1), 0, 1);
+                for (int r = 0; r < dp; ++r) mul(slot(t1), nullptr, U(unext, r, j - 2), 1.0, 1);
+                mul(slot(0), U(ucur, j - 1, 0), slot(t0), 1.0 / j, 0); cum(slot(t0), slot(t1), 1, 1);
+                for (int s = 0; s < dp; ++s) mul(slot(t1), nullptr, U(unext, j - 2, s), 1.0, 1);
+                for (int k = 2; k <= dc; ++k) mul(slot(0), U(ucur, j - 1, k - 1), U(unext, j - 2, k - 2), 1.0 / (double(j) * k), 1);
+            }
+            std::swap(ucur, unext);
+        }
+        mul(U(ucur, 0, 0), nullptr, slot(lamslot), 1.0, 1);                                              // level 1: R_1 = dM
+        HIPCHK(c, hipGetLastError());
+        // Lam -> gradients of both sides
+        K.lam = slot(lamslot); K.i0 = i0; K.ni = ni; K.j0 = B.j0; K.nj = nj;
+        auto slices = [](int64_t targets, int64_t partners) {
+            int64_t s = (CONTRACT_BLOCKS + targets - 1) / targets;
+            if (s > partners) s = partners;
+            if (s > 1024) s = 1024;
+            return s < 1 ? int64_t(1) : s;
+        };
+        K.gT = gX; K.gbase = gbase;
+        K.nslices = int(diag ? 1 : slices(ni, nj));
+        int blk = L1 >= 256 ? 256 : int((L1 + 63) / 64 * 64);
+        CHK(launch_contract<0>(c, DP, dim3(unsigned(ni), unsigned(K.nslices)), blk, sizeof(double) * size_t(L2) * (DP + 1), K));
+        K.gT = (diag || sym) ? gX : gY; K.gbase = nullptr;
+        K.nslices = int(diag ? 1 : slices(nj, ni));
+        blk = L2 >= 256 ? 256 : int((L2 + 63) / 64 * 64);
+        CHK(launch_contract<1>(c, DP, dim3(unsigned(diag ? ni : nj), unsigned(K.nslices)), blk, sizeof(double) * size_t(L1) * (DP + 1), K));
+        i0 += ni;
+    }
+    return GPSIG_OK;
+}
+
 // shared body of the Gram and the diagonal gradient
 int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
              const void* G, void* gX, void* gY, double* g_base) {
@@ -437,6 +555,10 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     if (N1 == 0 || N2 == 0) {
         if (xb) CHK(zero_async(c, dgX, xb));
         if (dgY && yb) CHK(zero_async(c, dgY, yb));
+    } else if (p->order > 1 && M > 1) {
+        // the symmetric Gram is taken as the cross Gram of X with itself: both sides' gradients land in gX
+        CHK(seq_grad_ho(c, p, DP, mode, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, d, diag, sym,
+                        static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), kgb));
     } else if (w2x) {
         const double* Xd = static_cast<const double*>(dX);
         const double* Gd = static_cast<const double*>(dG);
@@ -641,7 +763,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     if (T == 0 || N == 0) {
         if (zb) CHK(zero_async(c, dgZ, zb));
         if (xb) CHK(zero_async(c, dgX, xb));
-    } else if (c->grad_impl == 0 && tvs_lanet_available(c, DP, M, L)) {
+    } else if (c->grad_impl == 0 && !(p->order > 1 && M > 1) && tvs_lanet_available(c, DP, M, L)) {
         void *zp, *gzp;
         CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
         CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));
@@ -680,8 +802,10 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         CHK(zero_async(c, gzp, sizeof(double) * size_t(rows) * DP));
         CHK(zero_async(c, gxT, xtb));
         const int R = p->difference ? L - 1 : L;
-        const bool fused = c->grad_impl != 1 && tvs_fused_available(DP, M, E);     // grad_impl 2: one pair per thread, scratch-free
-        const size_t per_t = sizeof(double) * size_t(lt + M * (M - 1) / 2) * size_t(R > 0 ? R : 0) * size_t(s);
+        const bool ho = p->order > 1 && M > 1;        // higher-order chains (signature_algs.py:129-160): one pair per thread with scratch
+        const bool fused = !ho && c->grad_impl != 1 && tvs_fused_available(DP, M, E);     // grad_impl 2: one pair per thread, scratch-free
+        const size_t nslots = ho ? size_t(TvsPairGrad<4>::ho_slots(M, p->order)) : size_t(lt + M * (M - 1) / 2);
+        const size_t per_t = sizeof(double) * nslots * size_t(R > 0 ? R : 0) * size_t(s);
         int64_t chunk = int64_t(scratch_budget(c) / (per_t ? per_t : 1));
         if (chunk < 1) chunk = 1;
         if (chunk > T) chunk = T;
@@ -693,6 +817,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
         A.xT = static_cast<const double*>(xT); A.gxT = static_cast<double*>(gxT);
         A.xstride = s;
         A.T = int(T); A.N = int(N); A.L = L; A.M = M; A.kind = p->base_kernel; A.incr = E == 2 ? 1 : 0; A.diff = p->difference ? 1 : 0;
+        A.order = ho ? p->order : 1;
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         A.G = static_cast<const double*>(dG); A.gm = T * N; A.gt = N; A.gn = 1;
         A.gbase = kgb;

@@ -406,6 +406,7 @@ struct TvsGradArgs {
     double* gxT;            // same layout as xT, accumulated
     int64_t xstride;
     int T, N, L, M, kind, incr, diff;
+    int order;              // > 1: higher-order chains (signature_algs.py:129-160), forward_ho / backward_ho
     double p0, p1;
     int t0, nt;             // this launch covers tensors t0 .. t0+nt-1
     const double* G;        // G[m * gm + t * gt + n * gn], m = 0..M
@@ -457,7 +458,7 @@ struct TvsPairGrad {
         return v;
     }
 
-    GPSIG_HD void forward() const {
+    GPSIG_HD void forward_m() const {
         // slots [0, lt): m_k[tau]
         double x[DP];
         for (int k = 0; k < lt; ++k) {
@@ -476,6 +477,10 @@ struct TvsPairGrad {
                 }
             }
         }
+    }
+
+    GPSIG_HD void forward() const {
+        forward_m();
         if (A.levels && valid) A.levels[pidx] = 1.0;
         int k0 = 0, us = lt;
         for (int i = 1; i <= A.M; ++i) {
@@ -526,6 +531,99 @@ struct TvsPairGrad {
             k0 += i;
             us += i - 1;
         }
+    }
+
+
+    // ---- higher-order chains (signature_kern_tens_vs_seq_higher_order, signature_algs.py:129-160) ---------------------
+    // Level i, chain position j = 0 .. i-1 (component k0 + j), D_j = min(j + 1, order) repeat counts l:
+    //     R_0[0] = m_{k0};   R_j[0] = m_{k0+j} * P_j,  P_j = excumsum_tau( sum_l R_{j-1}[l] )              (:153)
+    //                        R_j[l] = m_{k0+j} * R_{j-1}[l-1] / (l + 1),  l = 1 .. D_j - 1                  (:155)
+    //     K_i = sum_tau sum_l R_{i-1}[l]                                                                   (:158)
+    // Reverse mode, U_j[l] := dL/dR_j[l]:  U_{i-1}[l] = c_i;
+    //     dL/dm_{k0+j} = U_j[0] P_j + sum_{l>=1} U_j[l] R_{j-1}[l-1] / (l + 1)
+    //     U_{j-1}[l'] = revexcumsum_tau( m_{k0+j} U_j[0] ) + [l' + 1 < D_j] m_{k0+j} U_j[l'+1] / (l' + 2)
+    // Scratch per pair: slots [0, lt): m_k, then dL/dm_k;  per level (reused): R_j[l] at ho_slot(j, l) for j = 0 .. i-2, P_j at
+    // ho_pslot(j) for j = 1 .. i-1.  U_j[l] overwrites R_j[l] once position j+1 has used it.
+    GPSIG_HD int ho_d(int j) const { return j + 1 < A.order ? j + 1 : A.order; }
+    GPSIG_HD int ho_slot(int j, int l) const {
+        int s_ = lt;
+        for (int jj = 0; jj < j; ++jj) s_ += ho_d(jj);
+        return s_ + l;
+    }
+    GPSIG_HD int ho_pslot(int j) const {           // after the R slots of the deepest level
+        int s_ = lt;
+        for (int jj = 0; jj + 1 < A.M; ++jj) s_ += ho_d(jj);
+        return s_ + j - 1;
+    }
+    static GPSIG_HD int ho_slots(int M, int order) {
+        int s_ = M * (M + 1) / 2;
+        for (int jj = 0; jj + 1 < M; ++jj) s_ += (jj + 1 < order ? jj + 1 : order);
+        return s_ + (M > 1 ? M - 1 : 0);
+    }
+
+    GPSIG_HD void forward_ho() const {
+        forward_m();
+        if (A.levels && valid) A.levels[pidx] = 1.0;
+        int k0 = 0;
+        for (int i = 1; i <= A.M; ++i) {
+            double ki = 0.0;
+            if (i == 1) {
+                for (int tau = 0; tau < R; ++tau) ki += cell(k0, tau);
+            } else {
+                for (int tau = 0; tau < R; ++tau) cell(ho_slot(0, 0), tau) = cell(k0, tau);          // R_0[0]
+                for (int j = 1; j < i; ++j) {
+                    const int dp = ho_d(j - 1), dc = ho_d(j);
+                    double run = 0.0;
+                    for (int tau = 0; tau < R; ++tau) {
+                        const double m = cell(k0 + j, tau);
+                        double sum = 0.0, prev[GRAD_MAX_LEVELS];
+                        for (int l = 0; l < dp; ++l) { prev[l] = cell(ho_slot(j - 1, l), tau); sum += prev[l]; }
+                        cell(ho_pslot(j), tau) = run;                                                 // P_j[tau]
+                        if (j < i - 1) {
+                            cell(ho_slot(j, 0), tau) = m * run;
+                            for (int l = 1; l < dc; ++l) cell(ho_slot(j, l), tau) = (m * (1.0 / double(l + 1))) * prev[l - 1];
+                        } else {                                                                       // last position: only K_i is needed
+                            ki += m * run;
+                            for (int l = 1; l < dc; ++l) ki += (m * (1.0 / double(l + 1))) * prev[l - 1];
+                        }
+                        run += sum;
+                    }
+                }
+            }
+            if (A.levels && valid) A.levels[int64_t(i) * A.pairs + pidx] = ki;
+            // the backward pass of this level runs right away: the level scratch is reused by the next level
+            backward_ho_level(i, k0);
+            k0 += i;
+        }
+    }
+
+    GPSIG_HD void backward_ho_level(int i, int k0) const {
+        const double c = valid ? A.G[i * A.gm + t * A.gt + n * A.gn] : 0.0;
+        if (i == 1) {
+            for (int tau = 0; tau < R; ++tau) cell(k0, tau) = c;
+            return;
+        }
+        for (int j = i - 1; j >= 1; --j) {
+            const int dp = ho_d(j - 1), dc = ho_d(j);
+            double suf = 0.0;                                   // revexcumsum of m * U_j[0]
+            for (int tau = R - 1; tau >= 0; --tau) {
+                const double m = cell(k0 + j, tau);
+                double U[GRAD_MAX_LEVELS];
+                for (int l = 0; l < dc; ++l) U[l] = (j == i - 1) ? c : cell(ho_slot(j, l), tau);
+                double prev[GRAD_MAX_LEVELS];
+                for (int l = 0; l < dp; ++l) prev[l] = cell(ho_slot(j - 1, l), tau);
+                double gm_ = U[0] * cell(ho_pslot(j), tau);
+                for (int l = 1; l < dc; ++l) gm_ = fma(U[l] * (1.0 / double(l + 1)), prev[l - 1], gm_);
+                cell(k0 + j, tau) = gm_;                                                               // dL/dm_{k0+j}
+                for (int l = 0; l < dp; ++l) {
+                    double u = suf;
+                    if (l + 1 < dc) u = fma(m * (1.0 / double(l + 2)), U[l + 1], u);
+                    cell(ho_slot(j - 1, l), tau) = u;                                                  // U_{j-1}[l] over R_{j-1}[l]
+                }
+                suf = fma(m, U[0], suf);
+            }
+        }
+        for (int tau = 0; tau < R; ++tau) cell(k0, tau) = cell(ho_slot(0, 0), tau);                   // dL/dm_{k0} = U_0[0]
     }
 
     // gk(k, tt) = dL/d kz_k(x_tt)

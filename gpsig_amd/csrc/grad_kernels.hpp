@@ -92,8 +92,12 @@ __global__ void __launch_bounds__(64) tvs_pair_grad_kernel(const TvsGradArgs A) 
     const int t = A.t0 + int(blockIdx.y);
     const int64_t pidx = (int64_t(blockIdx.y) * gridDim.x + blockIdx.x) * 64 + threadIdx.x;
     TvsPairGrad<DP> P(A, t, n, pidx, n < A.N);
-    P.forward();
-    P.backward();
+    if (A.order > 1) {
+        P.forward_ho();          // higher-order chains: every level's backward pass follows its forward pass
+    } else {
+        P.forward();
+        P.backward();
+    }
     P.contract();
 }
 

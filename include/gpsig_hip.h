@@ -93,6 +93,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
 /* Tuning / debugging knobs; unknown names return GPSIG_ERR_INVALID.
  *   "glds"        1: stage x-side records with LDS-DMA (global_load_lds), 0: load + ds_write
  *   "exact"       1: allow the kernels specialised on num_levels, 0: generic kernels only
+ *   "pk2"         float32 kernels with two y sequences per pair group on the packed v_pk_* instructions: 1 (default) for the RBF
+ *                 family, where they are the faster ones, 2 for the linear kernel too, 0 never
  *   "max_run"     >0: x-side run length per task, 0: automatic
  *   "tensor_lanes" tensor-vs-sequence kernel: 1 one lane per tensor, 0 one lane per sequence, -1 automatic
  *   "grad_scratch_mb" lattice scratch of one gradient / fallback launch in MiB (default 4096)

@@ -9,7 +9,7 @@ to reproduce are therefore "autodiff of that graph".  This file restates the gra
 torch (each function cites the reference lines it follows, paths relative to ``/root/reference``) and lets
 ``torch.autograd`` play TensorFlow's role.  It is pinned in two ways (``tests/test_oracle_torch.py``): its VALUES must
 equal the NumPy oracle's on the same inputs, and its GRADIENTS must pass ``torch.autograd.gradcheck``-style finite
-differences of the NumPy oracle.  First-order algorithm only (order = 1), exact (non low-rank) branches.
+differences of the NumPy oracle.  First- and higher-order algorithms, exact (non low-rank) branches.
 """
 from __future__ import annotations
 
@@ -38,6 +38,49 @@ def signature_kern_first_order(M, num_levels, difference=True):
     for _ in range(2, num_levels + 1):                                                              # :31
         R = M * _excumsum(_excumsum(R, 1), -1)                                                      # :32
         K.append(R.sum(dim=(1, -1)))                                                                # :33
+    return torch.stack(K, dim=0)
+
+
+def signature_kern_higher_order(M, num_levels, order=2, difference=True):
+    """gpsig/signature_algs.py:37-74.  M (N1, L1, N2, L2) or (N, L, L)."""
+    if M.dim() == 4:
+        K = [torch.ones((M.shape[0], M.shape[2]), dtype=M.dtype)]                                   # :48-50
+    else:
+        K = [torch.ones((M.shape[0],), dtype=M.dtype)]                                              # :52-53
+    if difference:
+        M = M[:, 1:, ..., 1:] + M[:, :-1, ..., :-1] - M[:, :-1, ..., 1:] - M[:, 1:, ..., :-1]      # :56
+    K.append(M.sum(dim=(1, -1)))                                                                    # :58
+    R = [[M]]                                                                                       # :60
+    for i in range(2, num_levels + 1):                                                              # :61
+        d = min(i, order)                                                                           # :62
+        dp = len(R)
+        Rn = [[None] * d for _ in range(d)]
+        Rn[0][0] = M * _excumsum(_excumsum(sum(R[r][s] for r in range(dp) for s in range(dp)), 1), -1)            # :64
+        for j in range(2, d + 1):                                                                   # :65
+            Rn[0][j - 1] = 1.0 / j * M * _excumsum(sum(R[r][j - 2] for r in range(dp)), 1)          # :66
+            Rn[j - 1][0] = 1.0 / j * M * _excumsum(sum(R[j - 2][s] for s in range(dp)), -1)         # :67
+            for k in range(2, d + 1):                                                               # :68
+                Rn[j - 1][k - 1] = 1.0 / (j * k) * M * R[j - 2][k - 2]                              # :69
+        K.append(sum(Rn[r][s] for r in range(d) for s in range(d)).sum(dim=(1, -1)))                # :71
+        R = Rn                                                                                      # :72
+    return torch.stack(K, dim=0)
+
+
+def signature_kern_tens_vs_seq_higher_order(M, num_levels, order=2, difference=True):
+    """gpsig/signature_algs.py:129-160.  M (lt, T, N, L)."""
+    if difference:
+        M = M[..., 1:] - M[..., :-1]                                                                # :142
+    K = [torch.ones(M.shape[1:3], dtype=M.dtype)]                                                   # :144
+    k = 0
+    for i in range(1, num_levels + 1):                                                              # :147
+        R = [M[k]]; k += 1                                                                          # :148-149
+        for j in range(1, i):                                                                       # :150
+            d = min(j + 1, order)                                                                   # :151
+            Rn = [M[k] * _excumsum(sum(R), 2)]                                                      # :153
+            for l in range(1, d):                                                                   # :154
+                Rn.append(1.0 / (l + 1) * M[k] * R[l - 1])                                          # :155
+            R = Rn; k += 1                                                                          # :156-157
+        K.append(sum(R).sum(dim=2))                                                                 # :158
     return torch.stack(K, dim=0)
 
 
@@ -135,7 +178,7 @@ class SignatureKernelTorchOracle:
     p0 (base-kernel parameter: gamma of poly, mixing of mix)."""
 
     def __init__(self, num_features, num_levels, base="linear", variances=None, sigma=1.0, lengthscales=None, normalization=True,
-                 difference=True, num_lags=0, lags=None, gamma=None, p0=None, p1=None):
+                 difference=True, num_lags=0, lags=None, gamma=None, p0=None, p1=None, order=1):
         t = lambda v: v if isinstance(v, torch.Tensor) else torch.as_tensor(v, dtype=torch.float64)
         self.num_features, self.num_levels, self.base = num_features, num_levels, base
         self.normalization, self.difference, self.num_lags = normalization, difference, num_lags
@@ -146,6 +189,7 @@ class SignatureKernelTorchOracle:
         self.gamma = None if gamma is None else t(gamma)
         self.p0 = None if p0 is None else t(p0)
         self.p1 = p1
+        self.order = num_levels if (order <= 0 or order >= num_levels) else order                   # kernels.py:57
 
     def _base(self, X, X2=None):
         return base_kernel(self.base, X, X2, self.p0, self.p1)
@@ -174,8 +218,13 @@ class SignatureKernelTorchOracle:
         return Z
 
     # level primitives on scaled inputs
+    def _seq_alg(self, M):
+        if self.order == 1:                                                                         # kernels.py:201-204, :233-236
+            return signature_kern_first_order(M, self.num_levels, self.difference)
+        return signature_kern_higher_order(M, self.num_levels, self.order, self.difference)
+
     def K_seq_diag_levels(self, Xs):
-        return signature_kern_first_order(self._base(Xs), self.num_levels, self.difference)          # kernels.py:188-205
+        return self._seq_alg(self._base(Xs))                                                        # kernels.py:188-205
 
     def K_seq_levels(self, Xs, X2s=None):
         N, L, d = Xs.shape                                                                          # kernels.py:208-237
@@ -184,7 +233,7 @@ class SignatureKernelTorchOracle:
         else:
             N2, L2 = X2s.shape[:2]
             M = self._base(Xs.reshape(N * L, d), X2s.reshape(N2 * L2, d)).reshape(N, L, N2, L2)
-        return signature_kern_first_order(M, self.num_levels, self.difference)
+        return self._seq_alg(M)
 
     def K_tens_levels(self, Zs, increments):
         lt, T, nf = Zs.shape[0], Zs.shape[1], Zs.shape[-1]                                          # kernels.py:263-283
@@ -204,7 +253,9 @@ class SignatureKernelTorchOracle:
             M = M[:, :, 1] - M[:, :, 0]
         else:
             M = self._base(Zs.reshape(T * lt, nf), Xf).reshape(lt, T, N, L)
-        return signature_kern_tens_vs_seq_first_order(M, self.num_levels, self.difference)
+        if self.order == 1:                                                                         # kernels.py:336-339
+            return signature_kern_tens_vs_seq_first_order(M, self.num_levels, self.difference)
+        return signature_kern_tens_vs_seq_higher_order(M, self.num_levels, self.order, self.difference)
 
     def _w(self):
         return self.sigma * self.variances

@@ -40,10 +40,10 @@ def _host_ctx():
     return ctx
 
 
-def _params(base, d, M, difference, keep):
+def _params(base, d, M, difference, keep, order=1):
     from gpsig_amd.autodiff import _Spec
     p0, p1 = _bp(base)
-    return _Spec(base, M, difference, p1).params(d, p0, keep)
+    return _Spec(base, M, difference, p1, order=order).params(d, p0, keep)
 
 
 def _vp(a):
@@ -211,12 +211,64 @@ def test_tensor_level_gradients(base, difference, increments):
         assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
 
 
-def _module_and_oracle(base, d, M, L, num_lags=0, normalization=True, difference=True, lengthscales=True):
+@pytest.mark.parametrize("base", ["linear", "rbf", "poly", "matern32"])
+@pytest.mark.parametrize("order,difference", [(2, True), (3, True), (4, True), (2, False)])
+def test_higher_order_level_gradients(base, order, difference):
+    """Reverse mode of the higher-order algorithms (signature_algs.py:37-74 as lattice operations over blocks of pairs,
+    :129-160 one pair per thread) against autograd of their torch restatement: cross / symmetric / diagonal sequence levels in
+    several scratch blocks, tensor-vs-sequence levels with and without increments."""
+    rng = np.random.default_rng(51)
+    ctx = _host_ctx()
+    M = 4
+    for (N1, N2, L1, L2, d, kind) in [(9, 4, 7, 6, 3, "cross"), (6, 6, 5, 5, 2, "sym"), (11, 11, 6, 6, 5, "diag")]:
+        X = rng.standard_normal((N1, L1, d)) * 0.5
+        Y = rng.standard_normal((N2, L2, d)) * 0.5 if kind == "cross" else None
+        G = rng.standard_normal((M + 1, N1) if kind == "diag" else (M + 1, N1, N2 if kind == "cross" else N1))
+        kt = _t_kern(base, d, M, difference=difference, order=order)
+        tX = torch.tensor(X, requires_grad=True)
+        tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+        lev = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
+        (lev * torch.tensor(G)).sum().backward()
+        keep = []
+        p = _params(base, d, M, difference, keep, order=order)
+        for mb in (4096, 1):                       # one block of pairs / several
+            gX, gY, gb = np.empty_like(X), (None if Y is None else np.empty_like(Y)), np.zeros(2)
+            ctx.set_option("grad_scratch_mb", mb)
+            if kind == "diag":
+                ctx.call("gpsig_seq_diag_levels_grad", p, _vp(X), N1, L1, _vp(G), _vp(gX), gb.ctypes.data_as(_P))
+            else:
+                ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2 if Y is not None else N1, L1, L2 if Y is not None else L1,
+                         _vp(G), _vp(gX), _vp(gY), gb.ctypes.data_as(_P))
+            ctx.set_option("grad_scratch_mb", 4096)
+            assert rel(gX, tX.grad) < 1e-9, (kind, mb, rel(gX, tX.grad))
+            if Y is not None:
+                assert rel(gY, tY.grad) < 1e-9
+            if base == "poly":
+                assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
+    T, N, L, d = 5, 70, 8, 3
+    lt = M * (M + 1) // 2
+    for increments in (False, True):
+        Z = rng.standard_normal((lt, T, 2, d) if increments else (lt, T, d)) * 0.5
+        X = rng.standard_normal((N, L, d)) * 0.5
+        G = rng.standard_normal((M + 1, T, N))
+        kt = _t_kern(base, d, M, difference=difference, order=order)
+        tZ, tX = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+        (kt.K_tens_vs_seq_levels(tZ, tX, increments) * torch.tensor(G)).sum().backward()
+        keep = []
+        p = _params(base, d, M, difference, keep, order=order)
+        gZ, gX, gb = np.empty_like(Z), np.empty_like(X), np.zeros(2)
+        ctx.call("gpsig_tens_vs_seq_levels_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(G), _vp(gZ), _vp(gX), gb.ctypes.data_as(_P))
+        assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9, (increments, rel(gZ, tZ.grad), rel(gX, tX.grad))
+        if base == "poly":
+            assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
+
+
+def _module_and_oracle(base, d, M, L, num_lags=0, normalization=True, difference=True, lengthscales=True, order=1):
     from gpsig_amd import kernels, autodiff
     cls = {"linear": kernels.SignatureLinear, "rbf": kernels.SignatureRBF, "poly": kernels.SignaturePoly, "mix": kernels.SignatureMix,
            "matern32": kernels.SignatureMatern32, "cosine": kernels.SignatureCosine}[base]
     rng = np.random.default_rng(31)
-    kern = cls(L * d, d, M, normalization=normalization, difference=difference, num_lags=num_lags or None,
+    kern = cls(L * d, d, M, normalization=normalization, difference=difference, num_lags=num_lags or None, order=order,
                lengthscales=(rng.uniform(0.8, 1.6, d) if lengthscales else None), variances=rng.uniform(0.5, 1.5, M + 1))
     kern.sigma = 1.3
     mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
@@ -224,7 +276,7 @@ def _module_and_oracle(base, d, M, L, num_lags=0, normalization=True, difference
     orc = OT.SignatureKernelTorchOracle(d, M, base, variances=leaf(mod.variances), sigma=leaf(mod.sigma), lengthscales=leaf(mod.lengthscales),
                                         normalization=normalization, difference=difference, num_lags=num_lags,
                                         lags=leaf(mod.lags) if num_lags else None, gamma=leaf(mod.gamma) if num_lags else None,
-                                        p0=leaf(mod.p0), p1=kern._current_base_params()[1])
+                                        p0=leaf(mod.p0), p1=kern._current_base_params()[1], order=order)
     return mod, orc
 
 
@@ -236,12 +288,13 @@ def _constrained_grads(mod, loss):
     return vals
 
 
-@pytest.mark.parametrize("base,num_lags,normalization,difference",
-                         [("rbf", 0, True, True), ("linear", 1, True, True), ("poly", 0, False, True), ("mix", 0, True, False),
-                          ("matern32", 2, True, True), ("cosine", 0, True, True), ("linear", 0, False, False)])
-def test_module_gradients_match_oracle_autograd(base, num_lags, normalization, difference):
+@pytest.mark.parametrize("base,num_lags,normalization,difference,order",
+                         [("rbf", 0, True, True, 1), ("linear", 1, True, True, 1), ("poly", 0, False, True, 1), ("mix", 0, True, False, 1),
+                          ("matern32", 2, True, True, 1), ("cosine", 0, True, True, 1), ("linear", 0, False, False, 1),
+                          ("rbf", 1, True, True, 2), ("linear", 0, True, True, 3)])
+def test_module_gradients_match_oracle_autograd(base, num_lags, normalization, difference, order):
     d, M, L, N, N2, T = 3, 3, 8, 7, 5, 4
-    mod, orc = _module_and_oracle(base, d, M, L, num_lags, normalization, difference, lengthscales=(base != "cosine"))
+    mod, orc = _module_and_oracle(base, d, M, L, num_lags, normalization, difference, lengthscales=(base != "cosine"), order=order)
     rng = np.random.default_rng(32)
     X, X2 = rng.standard_normal((N, L * d)) * 0.5, rng.standard_normal((N2, L * d)) * 0.5
     de = d * (num_lags + 1)
@@ -283,6 +336,30 @@ def test_module_gradients_match_oracle_autograd(base, num_lags, normalization, d
             jac = torch.sigmoid(r) if kind == "pos" else torch.sigmoid(r) * (1 - torch.sigmoid(r))
             want = con.grad * jac
             assert rel(raw.grad, want) < 1e-8, (kind, raw.grad, want)
+
+
+def test_float32_module_is_computed_in_float64_and_rounded():
+    """A module after .float() (float32 parameters and data): the level primitives run on the float64 kernels, values and
+    gradients come back as float32 and agree with the float64 module to float32 rounding."""
+    d, M, L, N, T = 3, 3, 8, 6, 4
+    mod, _ = _module_and_oracle("rbf", d, M, L)
+    rng = np.random.default_rng(33)
+    X, Z = rng.standard_normal((N, L * d)) * 0.5, rng.standard_normal((M * (M + 1) // 2, T, 2, d)) * 0.5
+    W = torch.tensor(rng.standard_normal((T, N)), device="cuda:0")
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        m = mod.double() if dt == torch.float64 else mod.float()
+        Xg = torch.tensor(X, device="cuda:0", dtype=dt, requires_grad=True)
+        Zg = torch.tensor(Z, device="cuda:0", dtype=dt, requires_grad=True)
+        Kzz, Kzx, Kxx = m.K_tens_n_seq_covs(Zg, Xg, increments=True)
+        assert Kzx.dtype == dt and Kzz.dtype == dt and Kxx.dtype == dt
+        m.zero_grad()
+        ((Kzx * W.to(dt)).sum() + Kzz.sum() + Kxx.sum() + m.K(Xg).sum()).backward()
+        assert Xg.grad.dtype == dt and Zg.grad.dtype == dt and m.raw_lengthscales.grad.dtype == dt
+        res[dt] = [t.detach().double().cpu() for t in (Kzx, Xg.grad, Zg.grad, m.raw_lengthscales.grad, m.raw_variances.grad)]
+    mod.double()
+    for a, b in zip(res[torch.float32], res[torch.float64]):
+        assert rel(a, b) < 2e-5
 
 
 def test_hyperparameters_can_be_trained():

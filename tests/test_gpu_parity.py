@@ -744,6 +744,59 @@ def test_float32_config5_shape_reduced_n(K):
     assert torch.equal(got, got.T)
 
 
+@pytest.mark.parametrize("base", ["linear", "rbf"])
+def test_float32_packed_kernels(K, base):
+    """seq_pk2_kernel.hpp (two y sequences per pair group on the packed float32 instructions) against the float64 oracle and
+    against the one-sequence float32 kernels: odd sequence counts (the second sequence of the last group is missing), cross
+    Grams with both sides odd, diagonals, level tensors, both built lane shapes (16 lanes x 4 columns, 64 x 2)."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(77)
+    ctx = _lib.context(0, 0)
+    try:
+        for N, N2, L, d, M in ((41, 17, 30, 5, 4), (23, 9, 61, 8, 5), (19, 7, 128, 16, 6), (12, 5, 100, 7, 5)):
+            X = np.cumsum(0.15 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1).astype(np.float32)
+            Y = np.cumsum(0.15 * rng.standard_normal((N2, L - 3, d)), axis=1).reshape(N2, -1).astype(np.float32)
+            kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, lengthscales=(0.8 + rng.random(d)) * np.sqrt(d))
+            kx, ko = make_kernel(K, kw), make_oracle(kw)
+            X64, Y64 = X.astype(np.float64), Y.astype(np.float64)
+            res = {}
+            for pk2 in (2, 0):                                # 2: the packed kernels for the linear family too
+                ctx.set_option("pk2", pk2)
+                res[pk2] = (kx.K(X), kx.K(X, Y), kx.K(Y, X), kx.Kdiag(X, return_levels=True), kx.K(X, return_levels=True))
+            want = (ko.K(X64), ko.K(X64, Y64), ko.K(Y64, X64), ko.Kdiag(X64, return_levels=True), ko.K(X64, return_levels=True))
+            for got, unpacked, w in zip(res[2], res[0], want):
+                assert got.dtype == np.float32 and relerr32(got, w) <= TOL32, (N, L, d, M)
+                assert relerr32(got, unpacked.astype(np.float64)) <= TOL32
+            assert np.array_equal(res[2][0], res[2][0].T)
+    finally:
+        ctx.set_option("pk2", 1)
+
+
+def test_float32_full_config5_properties(K):
+    """BASELINE.json configs[4] at its full size (N=2048, L=128, d=16, num_levels=6, fp32, RBF): exact symmetry, unit diagonal,
+    sub-blocks against the float64 oracle, and the cross Gram of a row block against the symmetric one."""
+    import torch
+    rng = np.random.default_rng(0)
+    N, L, d, M = 2048, 128, 16, 6
+    X = np.cumsum(0.1 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1).astype(np.float32)
+    kw = dict(input_dim=L * d, num_features=d, num_levels=M, base="rbf", lengthscales=np.sqrt(d) * np.ones(d))
+    kx, ko = make_kernel(K, kw), make_oracle(kw)
+    Xd = torch.as_tensor(X, device="cuda:0")
+    G = kx.K(Xd)
+    assert G.dtype == torch.float32 and torch.equal(G, G.T) and bool(torch.isfinite(G).all())
+    Gh = G.cpu().numpy().astype(np.float64)
+    assert np.abs(np.diag(Gh) - (M + 1)).max() <= 1e-4 * (M + 1)          # normalised levels: diagonal = sum of the variances
+    for rows, cols in ((np.arange(0, 12), None), (np.arange(1000, 1008), np.arange(2040, 2048)),
+                       (np.array([3, 1025, 2047]), np.array([0, 1023, 1024, 1026]))):
+        # a diagonal block is the symmetric branch (jitter before normalising, kernels.py:431), anything else the cross one
+        want = ko.K(X[rows].astype(np.float64)) if cols is None else ko.K(X[rows].astype(np.float64), X[cols].astype(np.float64))
+        assert np.abs(Gh[np.ix_(rows, rows if cols is None else cols)] - want).max() <= TOL32 * np.abs(want).max()
+    blk = kx.K(Xd[512:640], Xd).cpu().numpy().astype(np.float64)
+    off = np.ones_like(blk, dtype=bool)
+    off[np.arange(128), 512 + np.arange(128)] = False      # K(x, x) differs between the two branches by the jitter placement
+    assert np.abs(blk - Gh[512:640])[off].max() <= TOL32 * np.abs(Gh).max()
+
+
 # ------------------------------------------------------------------------------------------------
 # low-rank mode (gpsig/low_rank_calculations.py, signature_algs.py:162-222): the reference's randomness is TF's and
 # cannot be reproduced, so (i) given the SAME landmarks and projections the HIP path must equal the restatement of

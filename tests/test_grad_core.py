@@ -62,6 +62,29 @@ def test_torch_oracle_values_equal_numpy_oracle(base, normalization):
             assert rel(u.detach(), v) < tol
 
 
+@pytest.mark.parametrize("base", ["linear", "rbf"])
+@pytest.mark.parametrize("order", [2, 3, 4])
+def test_torch_oracle_higher_order_equals_numpy_oracle(base, order):
+    """signature_algs.py:37-74 and :129-160 restated in torch (the gradient oracle of the higher-order algorithms) against the
+    NumPy oracle, which the notebook identities pin at order = num_levels (tests/test_oracle.py)."""
+    rng = np.random.default_rng(11)
+    N, N2, L, d, M, T = 4, 3, 7, 3, 4, 3
+    X, X2 = rng.standard_normal((N, L * d)) * 0.6, rng.standard_normal((N2, L * d)) * 0.6
+    ls, var = rng.uniform(0.7, 1.5, d), rng.uniform(0.5, 1.5, M + 1)
+    for norm in (True, False):
+        kn = _np_kern(base, d, M, normalization=norm, lengthscales=ls, variances=var, order=order)
+        kn.input_dim = L * d
+        kt = _t_kern(base, d, M, normalization=norm, lengthscales=ls, variances=var, order=order)
+        tX, tX2 = torch.tensor(X), torch.tensor(X2)
+        assert rel(kt.K(tX).detach(), kn.K(X)) < 1e-11
+        assert rel(kt.K(tX, tX2, return_levels=True).detach(), kn.K(X, X2, return_levels=True)) < 1e-11
+        assert rel(kt.Kdiag(tX).detach(), kn.Kdiag(X)) < 1e-11
+        for incr in (False, True):
+            Z = rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d))
+            assert rel(kt.K_tens_vs_seq(torch.tensor(Z), tX, increments=incr, return_levels=True).detach(),
+                       kn.K_tens_vs_seq(Z, X, increments=incr, return_levels=True)) < 1e-11
+
+
 def test_torch_oracle_with_lags_equals_numpy_oracle():
     rng = np.random.default_rng(4)
     N, L, d, M = 3, 7, 2, 3
