@@ -273,14 +273,17 @@ def main():
         tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tf):
             try:
-                ent = json.load(open(tf)).get(cfg if cfg != "c2" or base != "rbf" else "c2_rbf")
+                key = ("c2" if cfg == "c4" else cfg) + "_" + base + ("_increments" if args.increments else "")
+                ent = json.load(open(tf)).get(key) if cfg != "c4" else None
                 if ent:
                     traffic = ent.get("bytes_per_launch")
                     traffic_src = "static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %s)" % (
                         "profiles/hbm_traffic.json", ent.get("source", "round %s" % ent.get("round")))
             except Exception:
                 traffic = None
-        kernel_name = "tens_vs_seq_lanet_kernel (tensor-vs-sequence chains)" if T else "seq_gram_kernel (pair recursion)"
+        kernel_name = ("tvs_tile_kernel (tensor-vs-sequence chains)" if T else
+                       ("seq_pk2_kernel (pair recursion, two sequences per pair group)" if (w["dtype"] == "f32" and base == "rbf")
+                        else "seq_gram_kernel (pair recursion)"))
         what = ("SVGP inducing-tensor path Kzz + Kzx + Kxx-diag (K_tens_n_seq_covs), T=%d inducing tensors%s, " % (T, " (increments)" if args.increments else "")
                 if T else "full N x N Gram%s, " % (" sharded over %d GPUs, RCCL gather to rank 0" % n_gpus if n_gpus > 1 else ""))
         cname = "Signature" + ("Linear" if base == "linear" else "RBF")
