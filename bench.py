@@ -304,6 +304,9 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms_per_launch": per_launch_ms, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_pair": b_pair, "pairs_per_launch": pairs_launch,
+                         "binding_limit": ("float64 vector-ALU issue (the kernel runs within a few per cent of instructions x 4 cycles; "
+                                           "DESIGN.md section 4)" if w["dtype"] == "f64" else
+                                           "float32 dependent-instruction latency at 3 wavefronts per SIMD (DESIGN.md section 2.4)"),
                          "note": "frac is the ALGORITHMIC pair-stream rate of SURVEY 8(d) (every delivered entry priced at its two "
                                  "input streams + its result) over the HBM peak, NOT measured DRAM bandwidth: the streams are served "
                                  "from L2 / LDS, `traffic` is what HBM saw.  The binding limit of the pair recursion is vector-ALU "

@@ -30,7 +30,7 @@ bool solver_dsyevd(void** handle_slot, hipStream_t stream, int n, double* A, dou
 void solver_release(void* handle);
 int tvs_tile_waves(int M, int D, int E, int kind);
 typedef hipError_t (*SeqLaunchFn)(const SeqGramArgs&, int, size_t, hipStream_t);
-SeqLaunchFn seq_pk2_lookup(int G, int C, int D, int M, int mode);
+SeqLaunchFn seq_pk2_lookup(int G, int C, int D, int M, int mode, int pack, int waves);
 SeqLaunchFn seq_lookup_inc_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_inc_ex_g16_d4(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_inc_ex_g16_d8(int, int, int, int, bool);
@@ -420,16 +420,19 @@ struct SeqPlanned {
     int mode, d_eff;
     bool rbf_prescaled;      // fn is an RBF instance that takes prescaled records: points x prescale, -|row|^2/2 in the spare column
     double prescale;         // EXP_PRESCALE (float64, table-driven exp) or PK2_RBF_PRESCALE (float32, v_exp_f32)
-    bool pk2;                // fn is a seq_pk2_kernel instance: a pair group serves two y sequences
+    bool pk2;                // fn is a seq_pk2_kernel instance:
+    int ny, waves;           //   a pair group serves ny y sequences, a workgroup has `waves` wavefronts on one x ring
 };
 
-static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out) {
+// pairs_hint: how many pairs the launch this plan is for will evaluate (0: unknown / small)
+static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out, int64_t pairs_hint = 0) {
     if (p->base_kernel == GPSIG_BASE_SPECTRAL)      // takes the points, not inner products: one-pair-per-thread kernel only
         return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for float64 only");
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
     out->rbf_prescaled = false;
     out->prescale = 1.0;
     out->pk2 = false;
+    out->ny = 1; out->waves = 1;
     if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
         int k = seq_select_ho(SEQ_HO_TABLE, N_SEQ_HO_TABLE, g0.rows, d_eff, p->num_levels, p->order);
         if (k < 0)
@@ -446,21 +449,29 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
         return GPSIG_OK;
     }
     const bool f32 = sizeof(TT) == 4;
-    // (the linear kernel only on request, allow_pk2 == 2: it is slower there than the one-sequence kernels, seq_pk2_kernel.hpp)
-    if (f32 && c->allow_pk2 && c->allow_exact && ((g0.mode == MODE_INC && c->allow_pk2 == 2) || (g0.mode == MODE_PT_DIFF && p->base_kernel == GPSIG_BASE_RBF))) {
-        int G, C, D;                                   // two y sequences per pair group on the packed float32 instructions
-        if (seq_pk2_select(g0.rows, d_eff, p->num_levels, &G, &C, &D)) {
+    // float32, first order, exact num_levels: seq_pk2_kernel -- two y sequences per pair group on the packed instructions, and for
+    // launches large enough to fill the chip with 4-wave workgroups, four wavefronts on one x ring (BASELINE configs[4], RBF / linear:
+    // 41.6 / 28.0 ms one-sequence kernels, 38.6 / 33.5 ms packed, 30.5 / 26.2 ms packed + shared ring; profiles/r02_bench_c5_variants.txt).
+    // The linear kernel gains only with the shared ring, so small launches keep the one-sequence kernels for it.
+    if (f32 && c->allow_pk2 && c->allow_exact && (g0.mode == MODE_INC || (g0.mode == MODE_PT_DIFF && p->base_kernel == GPSIG_BASE_RBF))) {
+        int G, C, D;
+        const bool big = pairs_hint >= (int64_t(1) << 18);
+        const int waves = c->f32_waves > 0 ? c->f32_waves : (big ? 4 : 1);
+        const bool take = g0.mode == MODE_PT_DIFF || waves == 4 || c->allow_pk2 == 2;
+        if (take && seq_pk2_select(g0.rows, d_eff, p->num_levels, &G, &C, &D)) {
             out->cfg = SeqConfig{G, C, D, p->num_levels, true};
             out->mode = g0.mode;
             out->d_eff = d_eff;
-            out->fn = seq_pk2_lookup(G, C, D, p->num_levels, g0.mode);
+            out->ny = c->f32_pack == 1 ? 1 : 2;
+            out->waves = waves == 4 ? 4 : 1;
+            out->fn = seq_pk2_lookup(G, C, D, p->num_levels, g0.mode, out->ny, out->waves);
             out->pk2 = true;
             out->rbf_prescaled = g0.mode == MODE_PT_DIFF;
             out->prescale = PK2_RBF_PRESCALE;
             if (out->fn) return GPSIG_OK;
         }
     }
-    out->pk2 = false; out->rbf_prescaled = false; out->prescale = 1.0;
+    out->pk2 = false; out->rbf_prescaled = false; out->prescale = 1.0; out->ny = 1; out->waves = 1;
     const SeqConfig* tab = f32 ? SEQ_TABLE_F32 : (g0.mode == MODE_PT_NODIFF ? SEQ_TABLE_GENERIC : SEQ_TABLE);
     const int ntab = f32 ? N_SEQ_TABLE_F32 : (g0.mode == MODE_PT_NODIFF ? N_SEQ_TABLE_GENERIC : N_SEQ_TABLE);
     int k = seq_select(tab, ntab, g0.rows, d_eff, p->num_levels, c->allow_exact != 0 && g0.mode != MODE_PT_NODIFF);
@@ -541,7 +552,7 @@ struct SeqRun {
 static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl, const SeqRun& r) {
     if (r.N1 <= 0 || r.N2 <= 0) return GPSIG_OK;
     if (r.N1 > 0x7fffffff || r.N2 > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 sequences");
-    const int ypb = (64 / pl.cfg.G) * (pl.pk2 ? 2 : 1);
+    const int ypb = (64 / pl.cfg.G) * pl.ny * pl.waves;
     // aim for ~64k independent tasks (about 20 per resident wave slot) so the tail is a few per cent
     const int64_t nblocks = ((r.y_end > 0 ? r.y_end - r.y_begin : r.N2) + ypb - 1) / ypb;
     const int64_t xtot = r.pred == PRED_ALL ? r.N1 : (r.pred == PRED_DIAG ? ypb : r.N1 / 2 + ypb);
@@ -578,7 +589,7 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     base_p(p, &A.p0, &A.p1);
     A.out = r.out; A.si = r.si; A.sj = r.sj; A.sm = r.sm;
     A.ax = r.ax; A.by = r.by; A.jitter_diag = r.jitter_diag;
-    A.sum_levels = r.sum_levels; A.pred = r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds; A.compact = r.compact;
+    A.sum_levels = r.sum_levels; A.pred = r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds; A.compact = r.compact; A.keep_reset = c->keep_reset;
     const size_t lds = sizeof(TT) * (size_t(A.RS) + size_t(A.nslot) * A.slot_elems);
     if (lds > 160 * 1024) return fail(c, GPSIG_ERR_UNSUPPORTED, "x-side records of %d rows do not fit the LDS ring (%zu bytes)", A.R1, lds);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -767,10 +778,11 @@ static int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const voi
     bool swap = false;
     if (!sym && L1 < L2) swap = true;
     SeqPlanned pl;
-    int rc = plan_seq(c, p, d_eff, sym ? L1 : (swap ? L1 : L2), &pl);
+    const int64_t pairs_hint = sym ? N1 * (N1 / 2 + 1) : N1 * N2;
+    int rc = plan_seq(c, p, d_eff, sym ? L1 : (swap ? L1 : L2), &pl, pairs_hint);
     if (rc != GPSIG_OK && !sym) {       // maybe the other side fits
         swap = !swap;
-        rc = plan_seq(c, p, d_eff, swap ? L1 : L2, &pl);
+        rc = plan_seq(c, p, d_eff, swap ? L1 : L2, &pl, pairs_hint);
     }
     if (rc == GPSIG_ERR_UNSUPPORTED && generic_ok(p) && row_end == 0) {     // any-shape fallback, orders of magnitude slower per pair
         if (timed) { c->t_launches += 0; }
@@ -1410,7 +1422,10 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "grad_scratch_mb")) c->grad_scratch_mb = value > 0 ? value : 4096;
     else if (!strcmp(name, "grad_impl")) c->grad_impl = value;
     else if (!strcmp(name, "tvs_zreg")) c->tvs_zreg = value;
+    else if (!strcmp(name, "keep_reset")) c->keep_reset = value ? 1 : 0;
     else if (!strcmp(name, "pk2")) c->allow_pk2 = value;
+    else if (!strcmp(name, "f32_pack")) c->f32_pack = value;
+    else if (!strcmp(name, "f32_waves")) c->f32_waves = value;
     else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);

@@ -63,6 +63,8 @@ struct gpsig_ctx {
     int shard_i = 0, shard_n = 1;
     int use_glds = 1;
     int allow_exact = 1;
+    int keep_reset = 1;           // pair kernels: accumulators cleared through SeqLane::keep (1) or by reset() at pair boundaries (0)
+    int f32_pack = 2, f32_waves = 0;   // seq_pk2_kernel variant: y sequences per pair group (1 / 2); wavefronts per workgroup (1 / 4, 0 = by launch size)
     int allow_pk2 = 1;            // float32: the packed two-sequence kernels (seq_pk2_kernel.hpp) where they are built
     int max_run = 0;
     int tens_lanes = -1;   // -1 auto, 0 sequence lanes, 1 tensor lanes

@@ -45,6 +45,7 @@ struct SeqGramArgs {
     int32_t use_glds;       // stage x records with global_load_lds (LDS DMA) instead of load + ds_write
     int32_t compact;        // PRED_CIRCULANT only: owned entries of row j packed as out[j*sj + (N/2 - (j-i) mod N)], i.e. row j's
                             // N/2+1 owned columns j-N/2 .. j side by side (multi-GPU row blocks: half the bytes to gather)
+    int32_t keep_reset;     // 1: first-order lanes clear their accumulators through SeqLane::keep, 0: explicit reset() at pair boundaries
     const double* spec;     // BASE_SPECTRAL: alpha[Q], omega[Q][D], gamma[Q][D] (Q = p0, family = p1, D = the kernel's padded width)
 };
 

@@ -169,6 +169,11 @@ struct SeqLane {
                     // so the diagonal term Q_{m-1}[a-1][b-1] of a lane's first column costs one add instead of a hand-over
     T s[MMAX];      // end-of-chunk row prefix of R_m for the last processed row (the carry handed right)
     T ktop;         // running K_M (only the row totals of the top level are needed)
+    T keep;         // 1, or 0 at a step that opens a new pair: the accumulators are updated as  acc = acc * keep + increment,
+                    // which is acc + increment bit for bit while keep == 1 and clears them, at no cost, in the one step where the
+                    // increment is zero anyway (row 0 of an x).  It replaces reset() at pair boundaries on the GPU: there the
+                    // boundary block runs for 4 lanes of 64 in 16 of every R1 steps, and clearing 4M+1 registers in it was ~8 %
+                    // of the headline kernel's instructions.  (0 * inf is NaN: the kernel falls back to reset() when ktop is not finite.)
     // point modes only
     T y2[C];        // |y|^2 per owned column
     T kprev[C];     // kappa(previous x point, owned y columns)
@@ -189,6 +194,7 @@ struct SeqLane {
     }
     GPSIG_HD void init() {
         reset();
+        keep = T(1);
 #pragma unroll
         for (int m = 0; m < MMAX; ++m) s[m] = T(0);
 #pragma unroll
@@ -240,18 +246,18 @@ GPSIG_HD void seq_level(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T
 #pragma unroll
                 for (int r = 1; r < C; ++r) sm = fma(dm[r], L.q[MI - 1][r - 1], sm);
             }
-            L.ktop += sm;
+            L.ktop = fma(L.ktop, L.keep, sm);
         } else if constexpr (MI < MMAX - 1) {
             if constexpr (MI == 0) {
 #pragma unroll
-                for (int r = 0; r < C; ++r) { sm += dm[r]; L.q[0][r] += sm; }
+                for (int r = 0; r < C; ++r) { sm += dm[r]; L.q[0][r] = fma(L.q[0][r], L.keep, sm); }
             } else {
                 sm = fma(dm[0], L.qg[MI - 1], sm);
-                L.q[MI][0] += sm;
+                L.q[MI][0] = fma(L.q[MI][0], L.keep, sm);
 #pragma unroll
-                for (int r = 1; r < C; ++r) { sm = fma(dm[r], L.q[MI - 1][r - 1], sm); L.q[MI][r] += sm; }
+                for (int r = 1; r < C; ++r) { sm = fma(dm[r], L.q[MI - 1][r - 1], sm); L.q[MI][r] = fma(L.q[MI][r], L.keep, sm); }
             }
-            L.qg[MI] += cin;            // the ghost column moves past this row (read by level MI+2 ... already done: descending order)
+            L.qg[MI] = fma(L.qg[MI], L.keep, cin);   // the ghost column moves past this row (read by level MI+2 ... already done: descending order)
         }
         L.s[MI] = sm;
     }

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <limits>
 #include <type_traits>
 
 #include "seq_args.hpp"
@@ -45,7 +46,7 @@ __device__ __forceinline__ float shr1(float v) {
 // of a step interleave instead of queueing behind a switch -- 5 % at the headline shape, 18 % at one wavefront per SIMD.
 #define SEQ_FAST_RBF(T, MODE, OMAX, KIND) (sizeof(T) == 8 && (KIND) == BASE_RBF && (MODE) == MODE_PT_DIFF && (OMAX) == 0)
 template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1>
-__global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1) void seq_gram_kernel(const SeqGramArgs A) {
+__global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 32 ? 3 : ((MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1)) void seq_gram_kernel(const SeqGramArgs A) {
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
     static_assert((D * sizeof(T)) % 16 == 0, "record rows are read with 16-byte LDS loads");
     using Lane = typename std::conditional<OMAX == 0, SeqLane<T, C, D, MMAX, MODE>, SeqLaneHO<T, C, D, MMAX, (OMAX > 0 ? OMAX : 1), MODE>>::type;
@@ -166,7 +167,10 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
                 T* const out = static_cast<T*>(A.out);
                 seq_emit<T>(L, A, i, j, M, [&](int64_t off, T v) { out[off] = v; });
             }
-            L.reset();
+            // first-order lanes clear their accumulators through L.keep (below); only a pair that overflowed needs the explicit
+            // reset, so that its inf / NaN does not outlive it in this lane
+            if constexpr (Lane::HIGHER_ORDER) L.reset();
+            else if (!A.keep_reset || !(fabs(L.ktop) <= std::numeric_limits<T>::max())) L.reset();
         }
 
         T xr[D];
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(64, (MODE != MODE_INC && OMAX == 0 && C * D <= 32) 
         T hx = T(0);
         if constexpr (FAST_RBF) hx = zero_row[ctl.rowoff + D];            // -|x'|^2 / 2, the record row's spare column
         const bool dummy = ctl.row0;
+        if constexpr (!Lane::HIGHER_ORDER) L.keep = (dummy && A.keep_reset) ? T(0) : T(1);     // row 0 of an x (or an idle lane): see SeqLane::keep
 
         // if lane 0 opens a new x at the next step, its record (requested issue_at steps into this x) must have landed
         if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

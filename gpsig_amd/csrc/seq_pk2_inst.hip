@@ -25,12 +25,20 @@ bool seq_pk2_select(int rows, int d, int M, int* G, int* C, int* D) {
     return best >= 0;
 }
 
-SeqLaunchFn seq_pk2_lookup(int G, int C, int D, int M, int mode) {
-#define X_CASE(G_, C_, D_, M_)                                                                   \
-    if (G == G_ && C == C_ && D == D_ && M == M_)                                                \
-        return mode == MODE_INC ? &seq_pk2_launch<G_, C_, D_, M_, MODE_INC> : &seq_pk2_launch<G_, C_, D_, M_, MODE_PT_DIFF>;
+// pack: 2 = two y sequences per pair group (f2), 1 = one (float);  waves: wavefronts per workgroup on one x ring (1 or 4)
+SeqLaunchFn seq_pk2_lookup(int G, int C, int D, int M, int mode, int pack, int waves) {
+#define X_PICK(V_, W_, G_, C_, D_, M_) \
+    return mode == MODE_INC ? &seq_pk2_launch<V_, W_, G_, C_, D_, M_, MODE_INC> : &seq_pk2_launch<V_, W_, G_, C_, D_, M_, MODE_PT_DIFF>;
+#define X_CASE(G_, C_, D_, M_)                                            \
+    if (G == G_ && C == C_ && D == D_ && M == M_) {                       \
+        if (pack == 2 && waves == 1) { X_PICK(f2, 1, G_, C_, D_, M_) }    \
+        if (pack == 2 && waves == 4) { X_PICK(f2, 4, G_, C_, D_, M_) }    \
+        if (pack == 1 && waves == 1) { X_PICK(float, 1, G_, C_, D_, M_) } \
+        if (pack == 1 && waves == 4) { X_PICK(float, 4, G_, C_, D_, M_) } \
+    }
     GPSIG_PK2_SHAPES(X_CASE)
 #undef X_CASE
+#undef X_PICK
     return nullptr;
 }
 }  // namespace gpsig

@@ -80,11 +80,11 @@ class GraphedCall:
     def __del__(self):
         # the side stream and its context (scratch buffers, task lists) belong to this recording alone
         try:
+            dev = self.out[0].device if isinstance(self.out, (tuple, list)) else self.out.device
+            self.stream.synchronize()            # no replay may still be in flight when the executable graph goes away
             g, self.graph = self.graph, None
             if g is not None:
                 g.__del__()
-            dev = self.out[0].device if isinstance(self.out, (tuple, list)) else self.out.device
-            self.stream.synchronize()
             _lib.release(dev.index or 0, self.stream.cuda_stream)
         except Exception:
             pass
@@ -322,6 +322,15 @@ class SignatureKernel:
             raise ValueError("graphed() takes contiguous CUDA tensors")
         if self.low_rank:
             raise NotImplementedError("low-rank evaluations draw random objects on the host and cannot be recorded")
+        # nothing torch allocates may end up inside the capture (its memory is recycled after the call, a replay would write into
+        # whatever lives there then): the tensors must be what the library reads as they are -- one dtype, all columns active
+        given = [t for t in tensors if t is not None]
+        if len({t.dtype for t in given}) != 1 or given[0].dtype not in (torch.float32, torch.float64):
+            raise ValueError("graphed() takes tensors of one dtype, float32 or float64 (a conversion would be recorded with a temporary)")
+        ad = self.active_dims
+        if not (ad is None or (isinstance(ad, slice) and ad == slice(None)) or (isinstance(ad, slice) and ad.start in (None, 0)
+                and ad.step in (None, 1) and (ad.stop is None or ad.stop >= self.input_dim))):
+            raise ValueError("graphed() needs the default active_dims (a column gather would be recorded with a temporary)")
         fn = getattr(self, method)
         dev = next(t for t in tensors if t is not None).device
         side = torch.cuda.Stream(dev)            # the default stream cannot be captured

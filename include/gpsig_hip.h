@@ -93,8 +93,13 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
 /* Tuning / debugging knobs; unknown names return GPSIG_ERR_INVALID.
  *   "glds"        1: stage x-side records with LDS-DMA (global_load_lds), 0: load + ds_write
  *   "exact"       1: allow the kernels specialised on num_levels, 0: generic kernels only
- *   "pk2"         float32 kernels with two y sequences per pair group on the packed v_pk_* instructions: 1 (default) for the RBF
- *                 family, where they are the faster ones, 2 for the linear kernel too, 0 never
+ *   "pk2"         float32 kernels with two y sequences per pair group on the packed v_pk_* instructions (seq_pk2_kernel.hpp):
+ *                 1 (default) wherever they are the faster ones, 2 always where built, 0 never
+ *   "f32_waves"   their wavefronts per workgroup on one LDS ring of x records: 4, 1, or 0 = by launch size
+ *   "f32_pack"    their y sequences per pair group: 2 (packed) or 1 (the same code on scalar instructions; for A/B runs)
+ *   "keep_reset"  1 (default): the first-order pair kernels clear a lane's accumulators at a pair boundary through the
+ *                 recursion's own FMAs (acc = acc * keep + inc with keep = 0 for one step), 0: by an explicit reset in the
+ *                 boundary block (round 1; for A/B runs)
  *   "max_run"     >0: x-side run length per task, 0: automatic
  *   "tensor_lanes" tensor-vs-sequence kernel: 1 one lane per tensor, 0 one lane per sequence, -1 automatic
  *   "grad_scratch_mb" lattice scratch of one gradient / fallback launch in MiB (default 4096)

@@ -6,7 +6,10 @@ import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gpsig_amd import kernels as K
+from gpsig_amd import _lib
 from oracle import sigkern_oracle as O
+
+CTX = _lib.context(0, 0)
 
 CLASS = {"linear": K.SignatureLinear, "rbf": K.SignatureRBF, "cosine": K.SignatureCosine, "poly": K.SignaturePoly, "mix": K.SignatureMix,
          "matern12": K.SignatureMatern12, "matern32": K.SignatureMatern32, "matern52": K.SignatureMatern52}
@@ -49,7 +52,13 @@ def main():
             dt = np.float32 if f32 else np.float64
             lt = M * (M + 1) // 2
             incr = bool(rng.integers(0, 2))
-            T = int(rng.integers(1, 9))
+            T = int(rng.integers(1, 9)) if rng.integers(0, 4) else int(rng.choice([33, 64, 70, 130]))
+            # library knobs that route a case through the round-2 kernels whatever its size: the Kzx tile kernel below 32 tensors,
+            # the packed float32 kernels with one or four waves per ring, for the linear family too
+            opts = dict(tvs_tile=int(rng.choice([-1, 1])), f32_waves=int(rng.choice([0, 1, 4])), pk2=int(rng.choice([1, 2])))
+            for k_, v_ in opts.items():
+                CTX.set_option(k_, v_)
+            desc.update(opts)
             de = d * (lags + 1)
             Z = 0.5 * rng.standard_normal((lt, T, 2, de) if incr else (lt, T, de)) + (1.0 if base == "cosine" else 0.0)
             kx1 = CLASS[base](L1 * d, d, **kw)
