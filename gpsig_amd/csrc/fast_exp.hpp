@@ -8,7 +8,7 @@
 // degree-5 Taylor polynomial (|r ln2/64| <= 0.0055: the first omitted term is 3.5e-17 relative), 2^k by v_ldexp_f64 (which
 // also flushes to zero where the result underflows; v_cvt_i32_f64 saturates, so any finite argument is safe).
 // Measured against the long-double exp over [-745, 350]: <= 1.3 ulp (half an ulp of it is the rounding of the table entry;
-// tests/emu/test_fast_exp.cpp, run by tests/test_fast_exp.py).
+// tests/emu/test_fast_exp.cpp, run by tests/test_device_headers.py).
 //
 // Two entries: kexp_tab(a, tab) takes the argument itself; kexp2_tab(t, tab) takes t = a * 64/ln2 already scaled -- a
 // kernel that forms a = <x,z> - |x|^2/2 - |z|^2/2 from points it prepared itself scales the points by sqrt(64/ln2) once

@@ -1,4 +1,5 @@
-"""gpsig_amd/csrc/fast_exp.hpp (the table-driven float64 exp of the RBF / Matern envelopes) against the long-double library
+"""Host checks of device headers that are plain C++: gpsig_amd/csrc/fast_exp.hpp (the table-driven float64 exp of the RBF / Matern
+envelopes) against the long-double library
 exp, on the host: the header's arithmetic is fma / rint / ldexp only, so the device computes the same bits."""
 import os
 import subprocess
@@ -13,3 +14,11 @@ def test_fast_exp_within_one_and_a_half_ulp(tmp_path):
     worst_a, worst_t, edges = subprocess.check_output([exe, "2000000"]).split()
     assert float(worst_a) < 1.5 and float(worst_t) < 1.5, (worst_a, worst_t)
     assert int(edges) == 1
+
+
+def test_tile_kernel_level_partition(tmp_path):
+    """gpsig_amd/csrc/tvs_plan.hpp: how the Kzx tile kernel deals the signature levels to the waves of a workgroup."""
+    exe = str(tmp_path / "test_tvs_plan")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "gpsig_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "emu", "test_tvs_plan.cpp")])
+    assert subprocess.check_output([exe]).split() == [b"0"]
