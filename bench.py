@@ -115,15 +115,15 @@ def cpu_tile(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(cfg, increments, budget_s=15.0):
-    """The reference's TF-CPU graph restated op for op in NumPy (oracle/, kind 'port'), on tiles of sequences at the benchmark
-    shape, spread over single-threaded worker processes.  Bounded sample; see DESIGN.md section 4."""
+def cpu_baseline_numpy(cfg, increments, budget_s=8.0):
+    """The reference's TF-CPU graph restated op for op in NumPy (oracle/sigkern_oracle.py), on tiles of sequences at the benchmark
+    shape, spread over single-threaded worker processes.  Bounded sample."""
     import multiprocessing as mp
     w = WORKLOADS[cfg]
     workers = max(1, min(64, (os.cpu_count() or 2) // 2))
     tile = 64 if w["T"] else (32 if w["L"] <= 64 else 16)
     ctx = mp.get_context("spawn")
-    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    for v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ.setdefault(v, "1")
     with ctx.Pool(workers) as pool:
         t1 = pool.map(cpu_tile, [(cfg, tile, increments)] * workers)          # warm-up + calibration
@@ -132,12 +132,53 @@ def cpu_baseline(cfg, increments, budget_s=15.0):
         t0 = time.perf_counter()
         pool.map(cpu_tile, [(cfg, tile, increments)] * ntiles)
         wall = time.perf_counter() - t0
-    what = ("Kzx levels of %d inducing tensors x %d sequences (gpsig/kernels.py:313-340, signature_algs.py:101-127)" % (tile, tile)
-            if w["T"] else "%dx%d sequence pairs (unnormalised levels: matmul, 4-slice difference, 2 cumsums + multiply + reduce per "
-                           "level; gpsig/kernels.py:226, gpsig/signature_algs.py:25-35)" % (tile, tile))
-    return {"value": ntiles * tile * tile / wall, "unit": "sequence-pairs/s", "cores": workers, "kind": "port",
-            "sample": f"{ntiles} tiles of {what} at L={w['L']}, d={w['d']}, num_levels={w['M']}, {w['base']}, fp64 NumPy, "
-                      f"{workers} single-threaded worker processes, {wall:.1f} s wall"}
+    return {"value": ntiles * tile * tile / wall, "unit": "sequence-pairs/s", "cores": workers,
+            "sample": f"{ntiles} tiles of {tile}x{tile} pairs, whole-tensor NumPy ops (matmul, 4-slice difference, 2 cumsums + multiply + "
+                      f"reduce per level), {workers} single-threaded worker processes, {wall:.1f} s wall"}
+
+
+def cpu_baseline(cfg, base, increments, budget_s=10.0):
+    """cpu_baseline of the bench line: the oracle's C restatement of the reference's graph (oracle/sigkern_ref.c: kappa lattice,
+    double difference, per level two exclusive cumsums + multiply + reduce -- gpsig/kernels.py:225-230, signature_algs.py:25-35 /
+    :114-125 -- one pair at a time so that a lattice stays in cache, OpenMP over pairs on every host thread), on a bounded sample
+    of the benchmark shape; `numpy` beside it is the whole-tensor NumPy restatement the reference's TensorFlow ops map to one to
+    one.  kind "port": TensorFlow 1.15 is not installable here."""
+    from oracle import cref
+    w = WORKLOADS[cfg]
+    rng = np.random.default_rng(0)
+    L, d, M = w["L"], w["d"], w["M"]
+    threads = cref.threads()
+    if w["T"]:
+        lt = M * (M + 1) // 2
+        t_t, n_t = 64, 64 * max(1, threads // 8)
+        X = np.cumsum(0.2 * rng.standard_normal((n_t, L, d)), axis=1)
+        Z = rng.standard_normal((lt, t_t, 2, d) if increments else (lt, t_t, d))
+        call = lambda: cref.tens_vs_seq_levels(Z, X, M, base)                      # noqa: E731
+        pairs_call = t_t * n_t
+        what = f"Kzx levels of {t_t} inducing tensors x {n_t} sequences"
+    else:
+        n_t = 64 * max(1, int(round(math.sqrt(threads))))
+        X = rng.standard_normal((n_t, L, d)) if w["data"] == "white" else np.cumsum(0.1 * rng.standard_normal((n_t, L, d)), axis=1)
+        call = lambda: cref.seq_levels(X, X, M, base)                              # noqa: E731
+        pairs_call = n_t * n_t
+        what = f"all {n_t}x{n_t} sequence pairs of {n_t} sequences (levels 0..{M})"
+    call()                                                                          # warm-up (thread pool, page faults)
+    t0 = time.perf_counter()
+    call()
+    t1 = time.perf_counter() - t0
+    reps = max(1, int(budget_s / max(t1, 1e-3)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    wall = time.perf_counter() - t0
+    res = {"value": reps * pairs_call / wall, "unit": "sequence-pairs/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} x {what} at L={L}, d={d}, num_levels={M}, {base}, fp64, oracle/sigkern_ref.c (gcc -O3 -fopenmp, "
+                     f"{threads} OpenMP threads), {wall:.1f} s wall"}
+    try:
+        res["numpy"] = cpu_baseline_numpy(cfg, increments)
+    except Exception as e:                                                          # the NumPy leg is a side note: never lose the line over it
+        res["numpy"] = {"error": repr(e)}
+    return res
 
 
 def rel_err(got, want):
@@ -197,7 +238,7 @@ def main():
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, args.increments)            # before CUDA is initialised in this process
+        cpu = cpu_baseline(cfg, base, args.increments)      # before CUDA is initialised in this process
 
     import torch
     import torch.distributed as dist

@@ -221,3 +221,23 @@ def test_spectral_base_kernel_reduces_to_rbf_and_matern12():
     assert np.allclose(mixed, want, rtol=1e-13)
     # symmetric in its arguments, unit-free diagonal sum_q alpha_q
     assert np.allclose(np.diag(O.base_spectral(X, None, a, om, ga, "mixed")), a.sum())
+
+
+@pytest.mark.parametrize("base", ["linear", "rbf"])
+@pytest.mark.parametrize("difference", [True, False])
+def test_c_restatement_equals_numpy_oracle(base, difference):
+    """oracle/sigkern_ref.c (the C restatement timed as the all-cores CPU baseline of bench.py) against the NumPy oracle's level
+    primitives, to rounding: sequence vs sequence (ragged lengths, every level) and tensor vs sequence with / without increments."""
+    from oracle import cref
+    rng = np.random.default_rng(8)
+    M, d = 5, 3
+    X, Y = rng.standard_normal((7, 12, d)) * 0.5, rng.standard_normal((5, 9, d)) * 0.5
+    ko = O.SignatureKernelOracle(12 * d, d, M, base=base, difference=difference, lengthscales=None)
+    for A, B in ((X, Y), (Y, X), (X, X)):
+        got, want = cref.seq_levels(A, B, M, base, difference), ko._K_seq(A, B)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    for incr in (False, True):
+        Z = rng.standard_normal((M * (M + 1) // 2, 6, 2, d) if incr else (M * (M + 1) // 2, 6, d)) * 0.5
+        got, want = cref.tens_vs_seq_levels(Z, X, M, base, difference), ko._K_tens_vs_seq(Z, X, increments=incr)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    assert cref.threads() >= 1
