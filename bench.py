@@ -174,10 +174,20 @@ def cpu_baseline(cfg, base, increments, budget_s=10.0):
     res = {"value": reps * pairs_call / wall, "unit": "sequence-pairs/s", "cores": threads, "kind": "port",
            "sample": f"{reps} x {what} at L={L}, d={d}, num_levels={M}, {base}, fp64, oracle/sigkern_ref.c (gcc -O3 -fopenmp, "
                      f"{threads} OpenMP threads), {wall:.1f} s wall"}
+    res["implementation"] = "C restatement, OpenMP"
     try:
-        res["numpy"] = cpu_baseline_numpy(cfg, increments)
+        alt = cpu_baseline_numpy(cfg, increments)
+        alt["implementation"] = "NumPy whole-tensor ops, one process per core"
     except Exception as e:                                                          # the NumPy leg is a side note: never lose the line over it
-        res["numpy"] = {"error": repr(e)}
+        res["other"] = {"error": repr(e)}
+        return res
+    # `value` is the faster of the two restatements on this host (the C one for the pair lattices; vectorised exp makes the
+    # NumPy one the faster for the RBF tensor-vs-sequence chains); the other is kept beside it
+    if alt["value"] > res["value"]:
+        alt["kind"] = "port"
+        res, alt = alt, res
+        alt.pop("kind", None)
+    res["other"] = alt
     return res
 
 

@@ -946,7 +946,7 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     if (run >= TVS_TILE_S) run = (run + TVS_TILE_S - 1) / TVS_TILE_S * TVS_TILE_S;
     if (run > 4 * TVS_TILE_S) run = 4 * TVS_TILE_S;
     if ((N + run - 1) / run > 65535) return GPSIG_OK;
-    const double pre = kind == BASE_RBF ? EXP_PRESCALE : 1.0;
+    const double pre = kind == BASE_RBF ? TVS_RBF_PRESCALE : 1.0;
     const int rows_are_increments = kind == BASE_LINEAR && p->difference;
     void *zl, *zn, *xr;
     CHK(ensure(c, B_ZL, sizeof(double) * size_t(lt) * E * D * Tpad + 8, &zl));

@@ -16,8 +16,8 @@
 //
 // Base kernel at compile time: KIND = BASE_LINEAR (records hold increments of the scaled sequence when difference is on,
 // tensors with increments are collapsed to z1 - z0 on the way in: one inner product per component and time step),
-// KIND = BASE_RBF (points prepared in units of sqrt(ln2/64), so the inner products are the argument of the table-driven
-// 2^(t/64), fast_exp.hpp), or KIND = -1: the family is a run-time value (base_eval_n of seq_core.hpp).
+// KIND = BASE_RBF (points prepared in units of sqrt(ln2/256), so the inner products are the argument of the table-driven
+// 2^(t/256), fast_exp.hpp), or KIND = -1: the family is a run-time value (base_eval_n of seq_core.hpp).
 #pragma once
 
 #include "aux_kernels.hpp"
@@ -26,6 +26,12 @@
 
 namespace gpsig {
 
+#ifndef TVS_EXP256
+#define TVS_EXP256 1                     // 1: the 256-entry exp table with the degree-4 tail (fast_exp.hpp), 0: 64 entries / degree 5.  Same box,
+                                         // alternating (profiles/r02_ab_exp256.txt): Kzx RBF 3.20 -> 3.07 ms, with increments 6.49 -> 6.17 ms
+#endif
+constexpr int TVS_ETAB_N = TVS_EXP256 ? EXP_TAB256_N : EXP_TAB_N;
+constexpr double TVS_RBF_PRESCALE = TVS_EXP256 ? EXP_PRESCALE256 : EXP_PRESCALE;
 constexpr int TVS_TILE_S = 16;           // sequences per output flush: 16 doubles = one 128-byte line per tensor row
 constexpr int TVS_REC_ALIGN = 128;       // record length granule in elements of double: 64 lanes x 16 bytes of LDS-DMA
 
@@ -48,7 +54,7 @@ struct TvsTileArgs {
 // LDS bytes of one workgroup
 inline size_t tvs_tile_lds_bytes(int M, int NW, int rec_elems, bool sum_levels) {
     const size_t slots = sum_levels ? size_t(NW) : size_t(M + 1);
-    return sizeof(double) * (EXP_TAB_N + 2 * size_t(rec_elems) + slots * 64 * (TVS_TILE_S + 1));
+    return sizeof(double) * (TVS_ETAB_N + 2 * size_t(rec_elems) + slots * 64 * (TVS_TILE_S + 1));
 }
 
 template <int M, int NW, int D, bool INCR, int KIND, int MASK>
@@ -99,7 +105,7 @@ struct TvsTileWave {
                     double t = zn[c][e] + hx;
 #pragma unroll
                     for (int f = 0; f < D; ++f) t = fma(z[c][e][f], x[f], t);
-                    kv[c * E + e] = kexp2_tab(t, etab);
+                    kv[c * E + e] = TVS_EXP256 ? kexp2_tab256(t, etab) : kexp2_tab(t, etab);
                 }
         } else {
 #pragma unroll
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tvs_tile_kernel(const TvsTileArgs 
     constexpr int TS = TVS_TILE_S + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char tvs_tile_smem[];
     double* const etab = reinterpret_cast<double*>(tvs_tile_smem);
-    double* const recs = etab + EXP_TAB_N;                        // 2 x rec_elems
+    double* const recs = etab + TVS_ETAB_N;                        // 2 x rec_elems
     double* const tile = recs + 2 * A.rec_elems;                  // [slots][64][TS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,7 +209,10 @@ __global__ __launch_bounds__(NW * 64, 2) void tvs_tile_kernel(const TvsTileArgs 
     const double* __restrict__ fx = static_cast<const double*>(A.fx);
     double* __restrict__ out = static_cast<double*>(A.out);
 
-    if constexpr (KIND != BASE_LINEAR) exp_tab_fill(etab, tid, NW * 64);
+    if constexpr (KIND != BASE_LINEAR) {
+        if constexpr (TVS_EXP256) exp_tab256_fill(etab, tid, NW * 64);
+        else exp_tab_fill(etab, tid, NW * 64);
+    }
 
     // records arrive by LDS-DMA: 64 lanes x 16 bytes per instruction, the waves take alternate kilobytes
     auto stage = [&](int64_t n, int buf) {

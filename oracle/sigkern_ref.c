@@ -36,7 +36,7 @@ void sigkern_seq_levels(const double* X, const double* Y, int n1, int n2, int L1
         double* dM = (double*)malloc(sizeof(double) * (size_t)(R1 > 0 ? R1 : 1) * (R2 > 0 ? R2 : 1));
         double* R = (double*)malloc(sizeof(double) * (size_t)(R1 > 0 ? R1 : 1) * (R2 > 0 ? R2 : 1));
         double* S = (double*)malloc(sizeof(double) * (size_t)(R1 > 0 ? R1 : 1) * (R2 > 0 ? R2 : 1));
-#pragma omp for collapse(2) schedule(dynamic, 4)
+#pragma omp for collapse(2) schedule(static)
         for (int i = 0; i < n1; ++i)
             for (int j = 0; j < n2; ++j) {
                 const double *x = X + (size_t)i * L1 * d, *y = Y + (size_t)j * L2 * d;
@@ -84,7 +84,7 @@ void sigkern_tens_vs_seq_levels(const double* Z, const double* X, int T, int n, 
     {
         double* Mk = (double*)malloc(sizeof(double) * (size_t)lt * (R > 0 ? R : 1));
         double* Rv = (double*)malloc(sizeof(double) * (size_t)(R > 0 ? R : 1));
-#pragma omp for collapse(2) schedule(dynamic, 16)
+#pragma omp for collapse(2) schedule(static)
         for (int t = 0; t < T; ++t)
             for (int i = 0; i < n; ++i) {
                 const double* x = X + (size_t)i * L * d;
