@@ -6,6 +6,7 @@
 #include "fast_exp.hpp"
 
 static const double tab[64] = {GPSIG_EXP2_TABLE};
+static const double tab256[256] = {GPSIG_EXP2_TABLE256};
 
 static double ulps(double got, long double want) {
     if (want == 0.0L) return got == 0.0 ? 0.0 : 1e9;
@@ -36,11 +37,16 @@ int main(int argc, char** argv) {
         const double g2 = gpsig::kexp2_tab(t, tab);
         const double w2 = ulps(g2, exp2l((long double)t / 64.0L));
         if (w2 > worst2) worst2 = w2;
+        const double g3 = gpsig::kexp2_tab256(4.0 * t, tab256);                 // the 256-entry variant: 2^(t'/256), t' = 4 t
+        const double w3 = ulps(g3, exp2l((long double)(4.0 * t) / 256.0L));
+        if (w3 > worst2) worst2 = w3;
     }
     // edge cases: huge negative arguments give 0, zero gives 1
     const double e0 = gpsig::kexp_tab(0.0, tab), e1 = gpsig::kexp_tab(-1e300, tab), e2 = gpsig::kexp2_tab(-1e300, tab),
                  e3 = gpsig::kexp_tab(-800.0, tab), e4 = gpsig::kexp2_tab(0.0, tab);
-    const bool scale_ok = fabs(gpsig::EXP_PRESCALE * gpsig::EXP_PRESCALE / gpsig::EXP_T_PER_A - 1.0) < 4e-16;
+    const bool e256 = gpsig::kexp2_tab256(0.0, tab256) == 1.0 && gpsig::kexp2_tab256(-1e300, tab256) == 0.0 &&
+                      fabs(gpsig::EXP_PRESCALE256 * gpsig::EXP_PRESCALE256 / (4.0 * gpsig::EXP_T_PER_A) - 1.0) < 4e-16;
+    const bool scale_ok = e256 && fabs(gpsig::EXP_PRESCALE * gpsig::EXP_PRESCALE / gpsig::EXP_T_PER_A - 1.0) < 4e-16;
     printf("%.4f %.4f %d\n", worst1, worst2, int(e0 == 1.0 && e1 == 0.0 && e2 == 0.0 && e3 == 0.0 && e4 == 1.0 && scale_ok));
     return 0;
 }
