@@ -487,7 +487,7 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
     if (!f32 && g0.mode == MODE_PT_DIFF && p->base_kernel == GPSIG_BASE_RBF && tab[k].exact) {
         out->fn = seq_launcher_rbf(tab[k]);
         out->rbf_prescaled = out->fn != nullptr;
-        out->prescale = EXP_PRESCALE;
+        out->prescale = SEQ_RBF_PRESCALE;
     }
     if (!out->fn) out->fn = seq_launcher(g0.mode, tab[k], sizeof(TT) == 4, p->base_kernel);
     if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "seq-gram kernel shape missing from this build");

@@ -26,6 +26,11 @@
 
 #include "fast_exp.hpp"
 
+#ifndef SEQ_EXP256
+#define SEQ_EXP256 1      // float64 RBF pair kernels: 1 = the 256-entry exp table with the degree-4 tail, 0 = 64 entries / degree 5
+                          // (same box, alternating, BASELINE configs[1] RBF: 45.44 -> 44.04 ms; profiles/r02_ab_exp256.txt)
+#endif
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define GPSIG_HD __host__ __device__ __forceinline__
@@ -34,6 +39,9 @@
 #endif
 
 namespace gpsig {
+
+constexpr int SEQ_ETAB_N = SEQ_EXP256 ? EXP_TAB256_N : EXP_TAB_N;
+constexpr double SEQ_RBF_PRESCALE = SEQ_EXP256 ? EXP_PRESCALE256 : EXP_PRESCALE;
 
 // values equal enum gpsig_base_kernel in include/gpsig_hip.h
 enum : int { BASE_LINEAR = 0, BASE_RBF = 1, BASE_COSINE = 2, BASE_POLY = 3, BASE_MIX = 4,
@@ -519,7 +527,7 @@ GPSIG_HD void seq_step_rbf_prescaled(SeqLane<double, C, D, MMAX, MODE>& L, const
         double acc = fma(xr[0], L.y[r][0], L.y2[r]);
 #pragma unroll
         for (int f = 1; f < D; ++f) acc = fma(xr[f], L.y[r][f], acc);
-        knew[r] = kexp2_tab(acc + hx, etab);
+        knew[r] = SEQ_EXP256 ? kexp2_tab256(acc + hx, etab) : kexp2_tab(acc + hx, etab);
     }
     seq_point_increments<double, C, MODE>(L, nbr, knew, dummy, rlo, rhi, dm);
     seq_recursion(L, nbr, dm, M);

@@ -56,8 +56,11 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
     // float64 RBF at compile time: prescaled records + table-driven exp (seq_step_rbf_prescaled in seq_core.hpp); the host
     // prepares the records accordingly whenever it launches such an instance (SeqPlanned::rbf_prescaled in api.hip)
     constexpr bool FAST_RBF = SEQ_FAST_RBF(T, MODE, OMAX, KIND);
-    __shared__ double etab[FAST_RBF ? EXP_TAB_N : 1];
-    if constexpr (FAST_RBF) etab[threadIdx.x & (EXP_TAB_N - 1)] = g_exp2_tab[threadIdx.x & (EXP_TAB_N - 1)];
+    __shared__ double etab[FAST_RBF ? SEQ_ETAB_N : 1];
+    if constexpr (FAST_RBF) {
+        if constexpr (SEQ_EXP256) exp_tab256_fill(etab, int(threadIdx.x), 64);
+        else exp_tab_fill(etab, int(threadIdx.x), 64);
+    }
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* const zero_row = reinterpret_cast<T*>(smem_raw);   // RS elements of zeros (rows of idle lanes); LaneCtl offsets start here
