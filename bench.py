@@ -115,12 +115,36 @@ def cpu_tile(args):
     return time.perf_counter() - t0
 
 
+def host_cpus():
+    """CPUs this process can actually use: the cgroup quota where there is one (the GPU boxes run the container with
+    cpu.max = 16 CPUs on a 256-thread host; oversubscribing it with one thread per visible CPU throttles everything)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline_numpy(cfg, increments, budget_s=8.0):
     """The reference's TF-CPU graph restated op for op in NumPy (oracle/sigkern_oracle.py), on tiles of sequences at the benchmark
     shape, spread over single-threaded worker processes.  Bounded sample."""
     import multiprocessing as mp
     w = WORKLOADS[cfg]
-    workers = max(1, min(64, (os.cpu_count() or 2) // 2))
+    workers = max(1, min(64, host_cpus()))
     tile = 64 if w["T"] else (32 if w["L"] <= 64 else 16)
     ctx = mp.get_context("spawn")
     for v in ("OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -143,6 +167,7 @@ def cpu_baseline(cfg, base, increments, budget_s=10.0):
     :114-125 -- one pair at a time so that a lattice stays in cache, OpenMP over pairs on every host thread), on a bounded sample
     of the benchmark shape; `numpy` beside it is the whole-tensor NumPy restatement the reference's TensorFlow ops map to one to
     one.  kind "port": TensorFlow 1.15 is not installable here."""
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cpus()))      # before libgomp starts: one thread per usable CPU
     from oracle import cref
     w = WORKLOADS[cfg]
     rng = np.random.default_rng(0)
