@@ -16,6 +16,7 @@
 #include "../../include/gpsig_hip.h"
 #include "aux_kernels.hpp"
 #include "lowrank_kernels.hpp"
+#include "lr_fused_args.hpp"
 #include "seq_args.hpp"
 #include "seq_configs.hpp"
 #include "tvs_tile_kernel.hpp"
@@ -331,6 +332,7 @@ struct LrDev {                 // device copies of a gpsig_lowrank
     int c, r, nsk;
     std::vector<const int32_t*> colptr, i1, i2;
     std::vector<const double*> val;
+    std::vector<const LrEntry*> ent;        // the same entries packed (value, i1, i2) for the fused feature kernel
     std::vector<int> k1, k2;
 };
 
@@ -358,7 +360,8 @@ int lr_upload(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, int 
     const int cc = lr->num_components;
     size_t bytes = sizeof(double) * (size_t(cc) * d_eff + size_t(cc) * cc);
     for (int i = 0; i < lr->num_sketches; ++i)
-        bytes += sizeof(int32_t) * (size_t(lr->sketches[i].r) + 1 + 2 * size_t(lr->sketches[i].nnz)) + sizeof(double) * size_t(lr->sketches[i].nnz) + 64;
+        bytes += sizeof(int32_t) * (size_t(lr->sketches[i].r) + 1 + 2 * size_t(lr->sketches[i].nnz)) + sizeof(double) * size_t(lr->sketches[i].nnz) +
+                 sizeof(LrEntry) * size_t(lr->sketches[i].nnz) + 96;
     std::vector<unsigned char> h(bytes + 64);
     void* dbase;
     CHK(ensure(c, B_LR0, h.size(), &dbase));
@@ -380,6 +383,10 @@ int lr_upload(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, int 
         D->i1.push_back(reinterpret_cast<const int32_t*>(db + put(sk.i1, sizeof(int32_t) * size_t(sk.nnz))));
         D->i2.push_back(reinterpret_cast<const int32_t*>(db + put(sk.i2, sizeof(int32_t) * size_t(sk.nnz))));
         D->val.push_back(reinterpret_cast<const double*>(db + put(sk.val, sizeof(double) * size_t(sk.nnz))));
+        std::vector<LrEntry> packed(size_t(sk.nnz) + 1);
+        for (int64_t e = 0; e < sk.nnz; ++e) packed[size_t(e)] = LrEntry{sk.val[e], sk.i1[e], sk.i2[e]};
+        o = (o + 15) / 16 * 16;
+        D->ent.push_back(reinterpret_cast<const LrEntry*>(db + put(packed.data(), sizeof(LrEntry) * size_t(sk.nnz))));
         D->k1.push_back(sk.k1); D->k2.push_back(sk.k2);
     }
     HIPCHK(c, hipMemcpyAsync(dbase, h.data(), o, hipMemcpyHostToDevice, c->stream));
@@ -1428,6 +1435,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "f32_waves")) c->f32_waves = value;
     else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
+    else if (!strcmp(name, "lr_fused")) c->lr_fused = value;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);
     return GPSIG_OK;
 }
@@ -1748,6 +1756,24 @@ int gpsig_lr_seq_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowra
     double* phi = static_cast<double*>(dPhi);
     double p0, p1;
     base_p(p, &p0, &p1);
+    // One kernel, one workgroup per sequence, intermediates in LDS (lr_fused_kernel.hpp) when a sequence's three arrays fit
+    const size_t fused_lds = lr_fused_lds_bytes(cc, r, d_eff, L);
+    if (c->lr_fused != 0 && fused_lds <= LR_FUSED_MAX_LDS && M - 1 <= LR_FUSED_MAX_SKETCHES) {
+        if (N <= 0) return finish(c);
+        LrFusedArgs A;
+        A.X = static_cast<const double*>(dX); A.N = N; A.L = L; A.P = s; A.S = D.S; A.Wh = D.Wh;
+        A.c = cc; A.r = r; A.M = M; A.difference = p->difference; A.kind = int(p->base_kernel); A.p0 = p0; A.p1 = p1;
+        for (int i = 0; i < LR_FUSED_MAX_SKETCHES; ++i) A.sk[i] = LrFusedSketch{nullptr, nullptr};
+        for (int i = 0; i < D.nsk; ++i) A.sk[i] = LrFusedSketch{D.colptr[i], D.ent[i]};
+        A.Phi = phi; A.F = F;
+        A.lp = (L + 63) / 64 * 64 + 1;
+        A.rows_b = cc > r ? cc : r;
+        if (d_eff > A.rows_b) A.rows_b = d_eff;
+        const int rc = lr_fused_launch(c->stream, A, unsigned(N < (int64_t(1) << 20) ? N : (int64_t(1) << 20)));
+        if (rc != 0) return fail(c, GPSIG_ERR_HIP, "fused low-rank feature kernel: %s", hipGetErrorString(hipError_t(rc)));
+        CHK(out_done(c, Phi, dPhi, sizeof(double) * size_t(N) * F));
+        return finish(c);
+    }
     void *kxs, *feat, *U, *Pa, *Pb;
     const int wmax = cc > r ? cc : r;
     CHK(ensure(c, B_LR2, sizeof(double) * size_t(N) * L * cc + 8, &kxs));

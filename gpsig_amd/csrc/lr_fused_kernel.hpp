@@ -1,0 +1,162 @@
+// lr_fused_kernel.hpp -- the low-rank feature map of a batch of sequences in ONE kernel
+// (gpsig/low_rank_calculations.py:59-60 Nystrom features, gpsig/signature_algs.py:166-193 signature_kern_first_order_lr_feature).
+//
+// The multi-pass form (lowrank_kernels.hpp, one elementwise kernel per reference op) moves every (N, L, c) intermediate through
+// HBM about two dozen times; here a workgroup owns one sequence and keeps its three (width, L) arrays in LDS, so that HBM sees
+// the sequence once (L * d values in) and its feature row once (F values out).
+//
+//   phase 0   scaled observations x~[t]                                                   (kernels.py:343-364, lags.py)
+//   phase 1   kxs[t][i] = kappa(x~[t], S_i) against the c landmarks                        (low_rank_calculations.py:59)
+//   phase 2   feat[t][j] = sum_i kxs[t][i] Wh[i][j];  U[t] = feat[t+1] - feat[t]           (:60, signature_algs.py:180)
+//   level 1   Phi_1 = sum_t U[t]                                                           (:182)
+//   level i   E = excumsum_t(P_{i-1});  P_i[t] = sketch_i(U[t], E[t]);  Phi_i = sum_t P_i  (:186-191)
+//
+// Layout: every array is stored [column][time] with an odd row stride, so that both access patterns are conflict-free:
+// lane = time (phases 0-2 and the sketches: 64 consecutive doubles of one column) and lane = column (running sums over
+// time: 64 addresses at an odd stride).  The sketch of a level -- the dominant cost, nnz multiply-adds per time step -- runs
+// with lane = time: its entries (value, i1, i2) are the same for every lane, so they arrive through the scalar unit
+// (one 16-byte s_load per entry) and the two operands are full-width LDS reads; the four wavefronts of the workgroup split
+// the output columns.  Bound by LDS bandwidth: two 512-byte reads per entry and 64 time steps.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aux_kernels.hpp"
+#include "lr_fused_args.hpp"
+#include "seq_core.hpp"
+
+namespace gpsig {
+
+// Landmarks, whitening matrix and sketch entries are read-only for the whole launch and addressed wave-uniformly: in the
+// constant address space the compiler may serve them through the scalar unit (s_load) instead of broadcasting vector loads.
+template <typename T>
+using lr_const_ptr = const __attribute__((address_space(4))) T*;
+template <typename T>
+__device__ __forceinline__ lr_const_ptr<T> lr_as_const(const T* p) { return (lr_const_ptr<T>)(p); }
+
+__global__ __launch_bounds__(LR_FUSED_THREADS) void lr_seq_features_fused_kernel(LrFusedArgs A) {
+    extern __shared__ double lr_lds[];
+    const int lp = A.lp, c = A.c, r = A.r, L = A.L;
+    double* const U = lr_lds;                               // [c][lp]
+    double* bufA = U + size_t(c) * lp;                      // [rows_b][lp]
+    double* bufB = bufA + size_t(A.rows_b) * lp;            // [rows_b][lp]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NW = LR_FUSED_THREADS / 64;
+    const int d_eff = A.P.d_eff();
+    const int l = A.difference ? L - 1 : L;                 // time steps of U
+    const int nchunk = (L + 63) / 64;
+
+    for (int64_t n = blockIdx.x; n < A.N; n += gridDim.x) {
+        const double* Xn = A.X + n * int64_t(L) * A.P.d_in;
+        double* phi = A.Phi + n * int64_t(A.F);
+        // ---- phase 0: scaled observations, bufB[fe][t]
+        for (int q = threadIdx.x; q < L * d_eff; q += LR_FUSED_THREADS) {
+            const int t = q / d_eff, fe = q - t * d_eff;
+            bufB[fe * lp + t] = scaled_point<double>(Xn, L, t, fe, A.P);
+        }
+        __syncthreads();
+        // ---- phase 1: kxs, bufA[i][t]
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int t = ch * 64 + lane;
+            if (t < L) {
+                double xs = 0.0;
+                for (int fe = 0; fe < d_eff; ++fe) { const double x = bufB[fe * lp + t]; xs = fma(x, x, xs); }
+                for (int i = wave; i < c; i += NW) {
+                    const lr_const_ptr<double> Si = lr_as_const(A.S) + size_t(i) * d_eff;
+                    double ip = 0.0, ss = 0.0;
+                    for (int fe = 0; fe < d_eff; ++fe) {
+                        const double y = Si[fe];
+                        ip = fma(bufB[fe * lp + t], y, ip);
+                        ss = fma(y, y, ss);
+                    }
+                    bufA[i * lp + t] = base_eval<double>(A.kind, ip, xs, ss, A.p0, A.p1);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: whitening, bufB[j][t] = sum_i bufA[i][t] * Wh[i][j]
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int t = ch * 64 + lane;
+            if (t < L) {
+                const lr_const_ptr<double> Wh = lr_as_const(A.Wh);
+                for (int j = wave; j < c; j += NW) {
+                    double acc = 0.0;
+#pragma unroll 4
+                    for (int i = 0; i < c; ++i) acc = fma(bufA[i * lp + t], Wh[size_t(i) * c + j], acc);
+                    bufB[j * lp + t] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        // time difference (signature_algs.py:180) or a copy
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int t = ch * 64 + lane;
+            if (t < l) {
+                for (int j = wave; j < c; j += NW) {
+                    const double f0 = bufB[j * lp + t];
+                    U[j * lp + t] = A.difference ? bufB[j * lp + t + 1] - f0 : f0;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- level 1 and the exclusive running sums for level 2: thread = column
+        if (threadIdx.x == 0) phi[0] = 1.0;
+        for (int j = threadIdx.x; j < c; j += LR_FUSED_THREADS) {
+            double run = 0.0;
+            const double* u = U + size_t(j) * lp;
+            double* e = bufA + size_t(j) * lp;
+            const bool more = A.M >= 2;
+#pragma unroll 8
+            for (int t = 0; t < l; ++t) {
+                const double v = u[t];
+                if (more) e[t] = run;
+                run += v;
+            }
+            phi[1 + j] = run;                                                                   // signature_algs.py:182
+        }
+        __syncthreads();
+        double* cur = bufA;
+        double* nxt = bufB;
+        for (int lev = 2; lev <= A.M; ++lev) {
+            const lr_const_ptr<int32_t> colptr = lr_as_const(A.sk[lev - 2].colptr);
+            const lr_const_ptr<LrEntry> ent = lr_as_const(A.sk[lev - 2].ent);
+            // P_lev[t][j] = sum_e val * U[t][i1] * E[t][i2]                                   low_rank_calculations.py:64-193
+            for (int j = wave; j < r; j += NW) {
+                const int e0 = colptr[j], e1 = colptr[j + 1];
+                for (int ch = 0; ch < nchunk; ++ch) {
+                    const int t = ch * 64 + lane;
+                    const int tt = t < l ? t : 0;                 // idle lanes read a valid address
+                    double acc = 0.0;
+#pragma unroll 4
+                    for (int e = e0; e < e1; ++e) {
+                        const double val = ent[e].val;            // (member by member: an address-space-4 struct has no copy constructor)
+                        const int i1 = ent[e].i1, i2 = ent[e].i2;
+                        acc = fma(val * U[i1 * lp + tt], cur[i2 * lp + tt], acc);
+                    }
+                    if (t < l) nxt[j * lp + t] = acc;
+                }
+            }
+            __syncthreads();
+            const int off = 1 + c + (lev - 2) * r;
+            const bool more = lev < A.M;
+            for (int j = threadIdx.x; j < r; j += LR_FUSED_THREADS) {
+                double run = 0.0;
+                double* e = nxt + size_t(j) * lp;
+#pragma unroll 8
+                for (int t = 0; t < l; ++t) {
+                    const double v = e[t];
+                    if (more) e[t] = run;                                                       // signature_algs.py:186
+                    run += v;
+                }
+                phi[off + j] = run;                                                             // :191
+            }
+            __syncthreads();
+            double* tmp = cur; cur = nxt; nxt = tmp;
+        }
+        // cur / nxt are read again by the next sequence's phase 0 (bufB) only after the barrier above
+    }
+}
+
+}  // namespace gpsig

@@ -109,7 +109,9 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "tvs_zreg"    tensor-lane gradient: components in registers (1) or LDS (0), -1 automatic
  *   "tvs_tile"    tensor-vs-sequence tile kernel (levels split over the waves of a workgroup, coalesced result tiles):
  *                 -1 wherever it is built and there are at least 32 tensors, 0 never, 1 also for fewer tensors
- *   "tvs_tile_nw" its waves per workgroup (1 or 2), 0 automatic */
+ *   "tvs_tile_nw" its waves per workgroup (1 or 2), 0 automatic
+ *   "lr_fused"    low-rank sequence features (gpsig_lr_seq_features): 1 (default) one fused kernel, a workgroup per sequence with
+ *                 the (width, length) intermediates in LDS, wherever they fit; 0 one elementwise kernel per reference op */
 int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
 /* HIP-event timing of the dominant kernel (the pair recursion) launched by the calls since the last
  * reset, measured on the ctx stream: total milliseconds and number of launches (the first 4096 timed
