@@ -1436,6 +1436,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else if (!strcmp(name, "lr_fused")) c->lr_fused = value;
+    else if (!strcmp(name, "lr_fused_variant")) c->lr_fused_variant = value;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);
     return GPSIG_OK;
 }
@@ -1769,7 +1770,7 @@ int gpsig_lr_seq_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowra
         A.lp = (L + 63) / 64 * 64 + 1;
         A.rows_b = cc > r ? cc : r;
         if (d_eff > A.rows_b) A.rows_b = d_eff;
-        const int rc = lr_fused_launch(c->stream, A, unsigned(N < (int64_t(1) << 20) ? N : (int64_t(1) << 20)));
+        const int rc = lr_fused_launch(c->stream, A, unsigned(N < (int64_t(1) << 20) ? N : (int64_t(1) << 20)), c->lr_fused_variant);
         if (rc != 0) return fail(c, GPSIG_ERR_HIP, "fused low-rank feature kernel: %s", hipGetErrorString(hipError_t(rc)));
         CHK(out_done(c, Phi, dPhi, sizeof(double) * size_t(N) * F));
         return finish(c);

@@ -13,7 +13,6 @@ struct LrEntry { double val; int32_t i1, i2; };     // one entry of a sketch, st
 struct LrFusedSketch { const int32_t* colptr; const LrEntry* ent; };
 
 constexpr int LR_FUSED_MAX_SKETCHES = 7;            // levels 2 .. 8
-constexpr int LR_FUSED_THREADS = 256;
 constexpr size_t LR_FUSED_MAX_LDS = 156 * 1024;     // of the 160 KB a CU has (one workgroup per CU at that size)
 
 struct LrFusedArgs {
@@ -37,6 +36,6 @@ inline size_t lr_fused_lds_bytes(int c, int r, int d_eff, int L) {
 }
 
 // lr_fused_inst.hip: launches the kernel on `stream` with `grid` workgroups; returns the hipError_t of the launch
-int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid);
+int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, int variant);
 
 }  // namespace gpsig

@@ -3,17 +3,31 @@
 
 namespace gpsig {
 
-int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid) {
-    const size_t lds = lr_fused_lds_bytes(A.c, A.r, A.P.d_eff(), A.L);
-    static size_t allowed = 0;                       // dynamic LDS beyond 64 KB has to be requested once per process
+namespace {
+template <int THREADS, int UNROLL>
+int launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, size_t lds) {
+    static size_t allowed = 0;                       // dynamic LDS beyond 64 KB has to be requested once per process and kernel
     if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_seq_features_fused_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_seq_features_fused_kernel<THREADS, UNROLL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return int(e);
         allowed = lds;
     }
-    hipLaunchKernelGGL(lr_seq_features_fused_kernel, dim3(grid), dim3(LR_FUSED_THREADS), lds, stream, A);
+    hipLaunchKernelGGL((lr_seq_features_fused_kernel<THREADS, UNROLL>), dim3(grid), dim3(THREADS), lds, stream, A);
     return int(hipGetLastError());
+}
+}  // namespace
+
+int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, int variant) {
+    const size_t lds = lr_fused_lds_bytes(A.c, A.r, A.P.d_eff(), A.L);
+    // BASELINE configs[2]'s sequences (L=50, c=r=50, 'sqrt'), same box: 256 threads / 4 entries per batch 4.32 ms, 256 / 8 3.84,
+    // 512 / 4 2.71, 512 / 8 2.57, 1024 / 4 3.09, 1024 / 8 4.01 (profiles/r02_lowrank.txt)
+    switch (variant) {
+        case 1: return launch<256, 4>(stream, A, grid, lds);
+        case 2: return launch<256, 8>(stream, A, grid, lds);
+        case 3: return launch<512, 4>(stream, A, grid, lds);
+        default: return launch<512, 8>(stream, A, grid, lds);
+    }
 }
 
 }  // namespace gpsig

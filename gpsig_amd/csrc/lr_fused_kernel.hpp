@@ -35,7 +35,10 @@ using lr_const_ptr = const __attribute__((address_space(4))) T*;
 template <typename T>
 __device__ __forceinline__ lr_const_ptr<T> lr_as_const(const T* p) { return (lr_const_ptr<T>)(p); }
 
-__global__ __launch_bounds__(LR_FUSED_THREADS) void lr_seq_features_fused_kernel(LrFusedArgs A) {
+// THREADS: workgroup size (the LDS footprint of a sequence does not depend on it, so more wavefronts per workgroup are more
+// wavefronts per CU to hide the scalar-load latency of the sketch entries behind); UNROLL: sketch entries per scalar-load batch.
+template <int THREADS, int UNROLL>
+__global__ __launch_bounds__(THREADS) void lr_seq_features_fused_kernel(LrFusedArgs A) {
     extern __shared__ double lr_lds[];
     const int lp = A.lp, c = A.c, r = A.r, L = A.L;
     double* const U = lr_lds;                               // [c][lp]
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(LR_FUSED_THREADS) void lr_seq_features_fused_kernel
     double* bufB = bufA + size_t(A.rows_b) * lp;            // [rows_b][lp]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int NW = LR_FUSED_THREADS / 64;
+    constexpr int NW = THREADS / 64;
     const int d_eff = A.P.d_eff();
     const int l = A.difference ? L - 1 : L;                 // time steps of U
     const int nchunk = (L + 63) / 64;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(LR_FUSED_THREADS) void lr_seq_features_fused_kernel
         const double* Xn = A.X + n * int64_t(L) * A.P.d_in;
         double* phi = A.Phi + n * int64_t(A.F);
         // ---- phase 0: scaled observations, bufB[fe][t]
-        for (int q = threadIdx.x; q < L * d_eff; q += LR_FUSED_THREADS) {
+        for (int q = threadIdx.x; q < L * d_eff; q += THREADS) {
             const int t = q / d_eff, fe = q - t * d_eff;
             bufB[fe * lp + t] = scaled_point<double>(Xn, L, t, fe, A.P);
         }
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(LR_FUSED_THREADS) void lr_seq_features_fused_kernel
         __syncthreads();
         // ---- level 1 and the exclusive running sums for level 2: thread = column
         if (threadIdx.x == 0) phi[0] = 1.0;
-        for (int j = threadIdx.x; j < c; j += LR_FUSED_THREADS) {
+        for (int j = threadIdx.x; j < c; j += THREADS) {
             double run = 0.0;
             const double* u = U + size_t(j) * lp;
             double* e = bufA + size_t(j) * lp;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(LR_FUSED_THREADS) void lr_seq_features_fused_kernel
                     const int t = ch * 64 + lane;
                     const int tt = t < l ? t : 0;                 // idle lanes read a valid address
                     double acc = 0.0;
-#pragma unroll 4
+#pragma unroll UNROLL
                     for (int e = e0; e < e1; ++e) {
                         const double val = ent[e].val;            // (member by member: an address-space-4 struct has no copy constructor)
                         const int i1 = ent[e].i1, i2 = ent[e].i2;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(LR_FUSED_THREADS) void lr_seq_features_fused_kernel
             __syncthreads();
             const int off = 1 + c + (lev - 2) * r;
             const bool more = lev < A.M;
-            for (int j = threadIdx.x; j < r; j += LR_FUSED_THREADS) {
+            for (int j = threadIdx.x; j < r; j += THREADS) {
                 double run = 0.0;
                 double* e = nxt + size_t(j) * lp;
 #pragma unroll 8

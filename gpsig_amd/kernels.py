@@ -440,14 +440,26 @@ class SignatureKernel:
         if self.low_rank:
             # one shared draw of landmarks / projections for all three matrices (kernels.py:613-621)
             st = self.draw_low_rank(X=X, Z=Z, increments=increments)
-            Kzz = self.K_tens(Z, return_levels=return_levels, increments=increments, lr_state=st)
-            Kzx = self.K_tens_vs_seq(Z, X, return_levels=return_levels, increments=increments, presliced=True, lr_state=st)
+            L_ = _launch_f64(Z, X)
+            p = self._params(L_.keep)
+            lr = st.as_c(L_.keep)
+            lv, nrm = int(bool(return_levels)), int(bool(self.normalization))
+            m1 = (self.num_levels + 1,) if return_levels else ()
+            # the two factor matrices once (kernels.py:613-621), then the three products of :623-661
+            PZ, pz, t = self._lr_features(L_, p, lr, Z, tensors=True, increments=increments)
+            PX, px, n = self._lr_features(L_, p, lr, X)
+            Kzz, ozz = L_.out(m1 + (t, t))
+            L_.ctx.call("gpsig_lr_kernel", p, lr, pz, None, t, t, 0, 0, lv, ozz)
+            Kzx, ozx = L_.out(m1 + (t, n))
+            L_.ctx.call("gpsig_lr_kernel", p, lr, pz, px, t, n, 0, nrm, lv, ozx)      # :638 == :581: divided by the X side's norms only
             if full_X_cov:
-                Kxx = self.K(X, presliced=True, return_levels=return_levels, lr_state=st)
-                if self.normalization:
-                    pass   # Kzx is already divided by sqrt(diag + jitter) of the same factors (kernels.py:638 == :581)
+                Kxx, oxx = L_.out(m1 + (n, n))
+                L_.ctx.call("gpsig_lr_kernel", p, lr, px, None, n, n, nrm, nrm, lv, oxx)
+            elif self.normalization:
+                Kxx = self.Kdiag(X, presliced=True, return_levels=return_levels, lr_state=st)     # sigma * variances: no features needed
             else:
-                Kxx = self.Kdiag(X, presliced=True, return_levels=return_levels, lr_state=st)
+                Kxx, oxx = L_.out(m1 + (n,))
+                L_.ctx.call("gpsig_lr_kernel_diag", p, lr, px, n, lv, oxx)
             return Kzz, Kzx, Kxx
         L_ = _Launch(Z, X)
         t = self._tens_dims(Z, increments)

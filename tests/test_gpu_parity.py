@@ -901,6 +901,55 @@ def test_low_rank_equals_restatement_given_the_same_randomness(K, sparsity, base
                             assert relerr(g, w) <= LR_TOL, (full, lev)
 
 
+@pytest.mark.parametrize("shape", [dict(N=37, L=50, d=6, M=4, c=50, r=50, sp="sqrt"),      # BASELINE configs[2]'s sequences, default ranks
+                                   dict(N=9, L=131, d=2, M=3, c=20, r=33, sp="log"),       # three time chunks of 64, r > c
+                                   dict(N=5, L=7, d=3, M=5, c=4, r=3, sp="lin", lags=2),   # d_eff = 9 > max(c, r): the staging rows; lags
+                                   dict(N=6, L=2, d=2, M=2, c=3, r=2, sp="sqrt"),          # one increment
+                                   dict(N=4, L=20, d=3, M=1, c=8, r=8, sp="sqrt")])        # level 1 only: no sketch
+@pytest.mark.parametrize("base", ["rbf", "linear", "matern32"])
+def test_low_rank_fused_feature_kernel(K, shape, base):
+    """gpsig_lr_seq_features through the fused kernel (lr_fused_kernel.hpp: a workgroup per sequence, intermediates in LDS)
+    against the one-kernel-per-op path it replaces (same random objects: differences are summation order in the whitening
+    product only) and, through K / Kdiag, against the oracle's restatement of signature_algs.py:166-193."""
+    import ctypes as C
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(77)
+    N, L, d, M, c, r = (shape[k] for k in ("N", "L", "d", "M", "c", "r"))
+    lags = shape.get("lags")
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+    for difference in (True, False):
+        if not difference and L == 2:
+            continue
+        kw = dict(normalization=False, num_components=c, rank_bound=r, sparsity=shape["sp"], lengthscales=0.6 + rng.random(d),
+                  difference=difference)
+        if lags:
+            kw["num_lags"] = lags
+        kx, ko = _lr_pair(K, base, L, d, M, **kw)
+        kx.rng = np.random.default_rng(5)
+        st = kx.draw_low_rank(X=X)
+        ctx = _lib.context(0, 0)
+        ctx.set_pointer_mode(_lib.PTR_HOST)
+        keep = []
+        p, lr = kx._params(keep), st.as_c(keep)
+        F = 1 + c + (M - 1) * r
+        out = {}
+        try:
+            for fused in (1, 0):
+                ctx.set_option("lr_fused", fused)
+                Phi = np.full((N, F), np.nan)
+                ctx.call("gpsig_lr_seq_features", p, lr, X.ctypes.data_as(C.c_void_p), N, L, Phi.ctypes.data_as(C.c_void_p))
+                out[fused] = Phi
+        finally:
+            ctx.set_option("lr_fused", 1)
+        assert np.isfinite(out[1]).all() and (out[1][:, 0] == 1.0).all()
+        scale = np.abs(out[0]).max(axis=0, keepdims=True) + 1e-300          # per feature column
+        assert (np.abs(out[1] - out[0]) / scale).max() <= 1e-9, (difference, (np.abs(out[1] - out[0]) / scale).max())
+        lo = O.LowRankOracle(ko, st.landmarks, st.jitter_diag, st.sketches)
+        tol = 1e-5 if base == "linear" else 1e-7                             # comment above LR_TOLS
+        want = lo.K(X)
+        assert np.abs(kx.K(X, lr_state=st) - want).max() <= tol * np.abs(want).max(), difference
+
+
 def test_low_rank_exact_limit_and_convergence(K):
     rng = np.random.default_rng(43)
     N, L, d = 8, 5, 2
