@@ -562,7 +562,9 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     const int ypb = (64 / pl.cfg.G) * pl.ny * pl.waves;
     // aim for ~64k independent tasks (about 20 per resident wave slot) so the tail is a few per cent
     const int64_t nblocks = ((r.y_end > 0 ? r.y_end - r.y_begin : r.N2) + ypb - 1) / ypb;
-    const int64_t xtot = r.pred == PRED_ALL ? r.N1 : (r.pred == PRED_DIAG ? ypb : r.N1 / 2 + ypb);
+    // diagonal with several pair groups per wavefront: each group sweeps its own sequence (SeqGramArgs::diag_own)
+    const bool diag_own = r.pred == PRED_DIAG && !pl.pk2 && ypb > 1 && ypb == 64 / pl.cfg.G && c->diag_own != 0;
+    const int64_t xtot = r.pred == PRED_ALL ? r.N1 : (r.pred == PRED_DIAG ? (diag_own ? 1 : ypb) : r.N1 / 2 + ypb);
     // ... unless the whole problem is smaller than that: then short runs, so that a small evaluation is spread over the chip
     // instead of a few wavefronts sweeping eight pairs in a row
     int64_t max_run = (xtot * nblocks + 65535) / 65536;
@@ -571,12 +573,14 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     if (max_run > 256) max_run = 256;
     if (c->max_run > 0) max_run = c->max_run;
     // the task list is a function of these integers only: reuse the device copy while they stay the same
-    const int64_t key[10] = {r.N1, r.N2, ypb, r.pred, max_run, c->shard_i, c->shard_n, r.y_begin, r.y_end > 0 ? r.y_end : -1, 1};
+    const int64_t key[10] = {r.N1, r.N2, ypb, r.pred, max_run, c->shard_i, c->shard_n, r.y_begin, r.y_end > 0 ? r.y_end : -1, diag_own ? 2 : 1};
     const SeqTask* dt = nullptr;
     int ntasks = 0;
     int64_t npairs = 0;
     CHK(task_list(c, key, [&](std::vector<SeqTask>& T) {
-        T = seq_build_tasks(r.N1, r.N2, ypb, r.pred, int(max_run), c->shard_i, c->shard_n, r.y_begin, r.y_end > 0 ? r.y_end : -1);
+        T = seq_build_tasks(r.N1, r.N2, ypb, r.pred, diag_own ? ypb : int(max_run), c->shard_i, c->shard_n, r.y_begin, r.y_end > 0 ? r.y_end : -1);
+        if (diag_own)
+            for (SeqTask& t : T) t.nx = 1;               // (y0, x0 = y0): one sweep, group g against sequence y0 + g
         int64_t pairs = 0;
         for (const SeqTask& t : T) pairs += int64_t(t.nx) * ypb;
         return pairs;
@@ -590,6 +594,8 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     A.xrec_stride = r.gx.rec_elems; A.yrec_stride = r.gy.rec_elems;
     A.R1 = r.gx.rows; A.R2 = r.gy.rows; A.RS = r.gx.RS; A.M = p->num_levels; A.order = p->order;
     A.nslot = seq_ring(pl.cfg.G, r.gx.rows).nslot;
+    A.diag_own = diag_own ? 1 : 0;
+    if (diag_own && A.nslot < ypb) A.nslot = ypb;
     A.issue_at = seq_ring(pl.cfg.G, r.gx.rows).issue_at;
     A.slot_elems = r.gx.rec_elems;
     A.kind = p->base_kernel;
@@ -881,7 +887,15 @@ static int tens_gram_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const
     A.out = out;
     A.sum_levels = (raw || return_levels) ? 0 : 1;
     if (Tn > 0) {
-        hipLaunchKernelGGL(tens_gram_kernel<TT>, dim3(grid_for(Tn * Tn)), dim3(256), 0, c->stream, A);
+        const int lt = A.M * (A.M + 1) / 2;
+        const int RSZ = tens_gram_tile_stride(A.d_eff, lt, E);
+        const size_t lds = sizeof(TT) * 2 * TENS_TILE * size_t(RSZ);
+        if (p->base_kernel != GPSIG_BASE_SPECTRAL && lds <= 64 * 1024 && c->tens_tile != 0) {       // 16 x 16 tiles, tensors staged in LDS
+            const unsigned nb = unsigned((Tn + TENS_TILE - 1) / TENS_TILE);
+            hipLaunchKernelGGL(tens_gram_tile_kernel<TT>, dim3(nb, nb), dim3(TENS_TILE * TENS_TILE), lds, c->stream, A, RSZ);
+        } else {
+            hipLaunchKernelGGL(tens_gram_kernel<TT>, dim3(grid_for(Tn * Tn)), dim3(256), 0, c->stream, A);
+        }
         HIPCHK(c, hipGetLastError());
     }
     return GPSIG_OK;
@@ -1435,6 +1449,8 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "f32_waves")) c->f32_waves = value;
     else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
+    else if (!strcmp(name, "diag_own")) c->diag_own = value;
+    else if (!strcmp(name, "tens_tile")) c->tens_tile = value;
     else if (!strcmp(name, "lr_fused")) c->lr_fused = value;
     else if (!strcmp(name, "lr_fused_variant")) c->lr_fused_variant = value;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);

@@ -607,6 +607,67 @@ __global__ void tens_gram_kernel(const TensGramArgs A) {
     }
 }
 
+// The same in tiles of 16 x 16 entries per workgroup: the 16 + 16 tensors a tile touches (contiguous records of
+// d_eff * lt * E components + lt * E squared norms each) are copied to LDS once, coalesced, instead of every thread
+// gathering its 2 * lt * E * d_eff components from HBM at a stride of one record per lane (Kzz at T = 512, M = 4, d = 6:
+// 101 -> about 10 us).  Row stride of the LDS copies odd: the 16 different t2 of a wavefront hit 16 different banks, the 4
+// different t1 are broadcasts.  Not for the spectral kernel (it takes the points through its own accessors).
+constexpr int TENS_TILE = 16;
+inline int tens_gram_tile_stride(int d_eff, int lt, int E) { return (d_eff * lt * E + lt * E) | 1; }
+template <typename T>
+__global__ __launch_bounds__(TENS_TILE * TENS_TILE) void tens_gram_tile_kernel(const TensGramArgs A, int RSZ) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tens_tile_lds[];
+    T* const za = reinterpret_cast<T*>(tens_tile_lds);          // [16][RSZ]: components then squared norms of tensors ta ..
+    T* const zb = za + TENS_TILE * RSZ;                          //            the same for tb ..
+    const T* __restrict__ ZT = static_cast<const T*>(A.ZT);
+    const T* __restrict__ ZS = static_cast<const T*>(A.ZS);
+    T* out = static_cast<T*>(A.out);
+    const int lt = A.M * (A.M + 1) / 2, E = A.E, d = A.d_eff;
+    const int nc = d * lt * E, ns = lt * E;
+    const int64_t ta = int64_t(blockIdx.y) * TENS_TILE, tb = int64_t(blockIdx.x) * TENS_TILE;
+    for (int q = threadIdx.x; q < TENS_TILE * (nc + ns); q += TENS_TILE * TENS_TILE) {
+        const int r = q / (nc + ns), o = q - r * (nc + ns);
+        const int64_t t1 = ta + r < A.Tn ? ta + r : A.Tn - 1, t2 = tb + r < A.Tn ? tb + r : A.Tn - 1;
+        za[r * RSZ + o] = o < nc ? ZT[t1 * nc + o] : ZS[t1 * ns + (o - nc)];
+        zb[r * RSZ + o] = o < nc ? ZT[t2 * nc + o] : ZS[t2 * ns + (o - nc)];
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / TENS_TILE, tx = threadIdx.x % TENS_TILE;
+    const int64_t t1 = ta + ty, t2 = tb + tx;
+    if (t1 >= A.Tn || t2 >= A.Tn) return;
+    const T* a = za + ty * RSZ;
+    const T* b = zb + tx * RSZ;
+    const int64_t total = A.Tn * A.Tn, idx = t1 * A.Tn + t2;
+    const T p0 = T(A.p0), p1 = T(A.p1);
+    T acc = T(0);
+    int k = 0;
+    for (int i = 0; i <= A.M; ++i) {
+        T R = T(1);
+        for (int j = 0; j < i; ++j, ++k) {
+            T mk;
+            if (E == 1) {
+                T ip = T(0);
+                for (int f = 0; f < d; ++f) ip = fma(a[f * lt + k], b[f * lt + k], ip);
+                mk = base_eval<T>(A.kind, ip, a[nc + k], b[nc + k], p0, p1);
+            } else {   // kernels.py:275-277
+                T kv[2][2];
+                for (int u = 0; u < 2; ++u)
+                    for (int v = 0; v < 2; ++v) {
+                        T ip = T(0);
+                        for (int f = 0; f < d; ++f) ip = fma(a[(f * lt + k) * 2 + u], b[(f * lt + k) * 2 + v], ip);
+                        kv[u][v] = base_eval<T>(A.kind, ip, a[nc + k * 2 + u], b[nc + k * 2 + v], p0, p1);
+                    }
+                mk = kv[1][1] + kv[0][0] - kv[1][0] - kv[0][1];
+            }
+            R = (j == 0) ? mk : mk * R;                           // signature_algs.py:92-96
+        }
+        T v = R;
+        if (A.w) v *= T(A.w[i]);
+        if (A.sum_levels) acc += v; else out[int64_t(i) * total + idx] = v;
+    }
+    if (A.sum_levels) out[idx] = acc;
+}
+
 // ---- any-shape fallback of the sequence-vs-sequence recursion (first-order algorithm, signature_algs.py:8-35) -------------
 // One pair per thread, 64 consecutive x sequences against one y sequence per wavefront (or the pairs (i, i) for the
 // diagonal).  The previous lattice row of Q_1..Q_{M-1} sits in an HBM scratch array laid out [level][column][pair], so a

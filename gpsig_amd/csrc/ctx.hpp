@@ -74,6 +74,8 @@ struct gpsig_ctx {
     void* blas_handle = nullptr;  // rocBLAS handle of gpsig_lr_whitening (lowrank_solver.hip), created at first use
     int tvs_tile = -1;            // Kzx tile kernel (tvs_tile_kernel.hpp): -1 where it is built, 0 never, 1 also below 32 tensors
     int tvs_tile_nw = 0;          // its waves per workgroup: 0 = planner's choice
+    int tens_tile = 1;            // Kzz in 16 x 16 tiles with the tensors staged in LDS (tens_gram_tile_kernel); 0: one gathering thread per entry
+    int diag_own = 1;             // diagonal pass: every pair group sweeps its own sequence (SeqGramArgs::diag_own); 0: round-1 form, for A/B runs
     int lr_fused_variant = 0;     // its workgroup size / unrolling (lr_fused_inst.hip), for A/B runs
     int lr_fused = 1;             // low-rank sequence features: 1 = the fused kernel where a sequence's arrays fit LDS, 0 = one kernel per op
     int tvs_zreg = -1;            // tensor-lane gradient: components in registers (1) or LDS (0); -1 = planner's choice

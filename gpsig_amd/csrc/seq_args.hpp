@@ -46,6 +46,9 @@ struct SeqGramArgs {
     int32_t compact;        // PRED_CIRCULANT only: owned entries of row j packed as out[j*sj + (N/2 - (j-i) mod N)], i.e. row j's
                             // N/2+1 owned columns j-N/2 .. j side by side (multi-GPU row blocks: half the bytes to gather)
     int32_t keep_reset;     // 1: first-order lanes clear their accumulators through SeqLane::keep, 0: explicit reset() at pair boundaries
+    int32_t diag_own;       // PRED_DIAG with several pair groups per wavefront: every group sweeps ITS OWN sequence (task.nx == 1, the
+                            // records of x0 .. x0 + 64/G - 1 staged side by side in the ring) instead of all groups sweeping
+                            // the same 64/G sequences with one emitted pair each -- a quarter of the work at G = 16
     const double* spec;     // BASE_SPECTRAL: alpha[Q], omega[Q][D], gamma[Q][D] (Q = p0, family = p1, D = the kernel's padded width)
 };
 

@@ -110,6 +110,10 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "tvs_tile"    tensor-vs-sequence tile kernel (levels split over the waves of a workgroup, coalesced result tiles):
  *                 -1 wherever it is built and there are at least 32 tensors, 0 never, 1 also for fewer tensors
  *   "tvs_tile_nw" its waves per workgroup (1 or 2), 0 automatic
+ *   "tens_tile"   tensor-vs-tensor kernel (Kzz): 1 (default) 16 x 16 tiles with the tensors staged in LDS, 0 one thread per entry
+ *                 gathering its components from HBM (round 1)
+ *   "diag_own"    diagonal pass of the pair kernel (level diagonals for normalisation, Kdiag): 1 (default) every pair group of a
+ *                 wavefront sweeps its own sequence, 0 all groups sweep the same 64/G sequences and emit one pair each (round 1)
  *   "lr_fused"    low-rank sequence features (gpsig_lr_seq_features): 1 (default) one fused kernel, a workgroup per sequence with
  *                 the (width, length) intermediates in LDS, wherever they fit; 0 one elementwise kernel per reference op */
 int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);

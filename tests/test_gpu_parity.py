@@ -901,6 +901,64 @@ def test_low_rank_equals_restatement_given_the_same_randomness(K, sparsity, base
                             assert relerr(g, w) <= LR_TOL, (full, lev)
 
 
+@pytest.mark.parametrize("base", ["linear", "rbf", "poly", "matern52"])
+def test_tensor_gram_tiles(K, base):
+    """Kzz in 16 x 16 tiles with the tensors staged in LDS (tens_gram_tile_kernel) against the one-thread-per-entry kernel
+    (bit-identical: the same operations in the same order) and the oracle; ragged tensor counts, both layouts, float32."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(93)
+    for T, d, M, lags in ((1, 2, 2, 0), (37, 6, 4, 0), (64, 3, 5, 1), (100, 16, 3, 0)):
+        kw = dict(input_dim=10 * d, num_features=d, num_levels=M, base=base, lengthscales=0.7 + rng.random(d), variances=0.5 + rng.random(M + 1))
+        if base == "poly":
+            lags = 0                        # SignaturePoly has no lags (the reference overwrites the lag weights)
+        if lags:
+            kw["num_lags"] = lags
+        kx, ko = make_kernel(K, kw), make_oracle(kw)
+        for incr in (False, True):
+            Z = rng.standard_normal((M * (M + 1) // 2, T, 2, d * (lags + 1)) if incr else (M * (M + 1) // 2, T, d * (lags + 1)))
+            ctx = _lib.context(0, 0)
+            got = {}
+            try:
+                for tile in (1, 0):
+                    ctx.set_option("tens_tile", tile)
+                    got[tile] = (kx.K_tens(Z, increments=incr), kx.K_tens(Z, increments=incr, return_levels=True),
+                                 kx.K_tens(Z.astype(np.float32), increments=incr))
+            finally:
+                ctx.set_option("tens_tile", 1)
+            for a, b in zip(got[1], got[0]):
+                assert np.array_equal(a, b), (T, d, M, incr)
+            assert relerr(got[1][0], ko.K_tens(Z, increments=incr)) <= TOL
+            assert relerr(got[1][1], ko.K_tens(Z, increments=incr, return_levels=True)) <= TOL
+
+
+@pytest.mark.parametrize("base,order", [("linear", 1), ("rbf", 1), ("matern32", 1), ("linear", 3), ("rbf", 2)])
+def test_diagonal_pass_with_one_sequence_per_pair_group(K, base, order):
+    """The diagonal pass (level diagonals for normalisation, Kdiag) with every pair group of a wavefront sweeping its own
+    sequence (SeqGramArgs::diag_own) against the round-1 form (all groups sweep the same 64/G sequences, one emitted pair each):
+    the same per-pair arithmetic, so bit-identical; and against the oracle."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(91)
+    for N, L, d, M in ((37, 20, 3, 4), (5, 64, 8, 5), (130, 9, 2, 3)):        # ragged last block; the headline shape; short records (deeper ring)
+        X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+        Y = np.cumsum(0.3 * rng.standard_normal((7, L, d)), axis=1).reshape(7, -1)
+        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, order=order, lengthscales=0.7 + rng.random(d))
+        ctx = _lib.context(0, 0)
+        got = {}
+        try:
+            for own in (1, 0):
+                ctx.set_option("diag_own", own)
+                kx = make_kernel(K, dict(kw, normalization=False))
+                kn = make_kernel(K, dict(kw, normalization=True))
+                got[own] = (kx.Kdiag(X, return_levels=True), kn.K(X), kn.K(Y, X))
+        finally:
+            ctx.set_option("diag_own", 1)
+        for a, b in zip(got[1], got[0]):
+            assert np.array_equal(a, b), (N, L, base, order)
+        ko = make_oracle(dict(kw, normalization=False))
+        assert relerr(got[1][0], ko.Kdiag(X, return_levels=True)) <= TOL
+        assert relerr(got[1][2], make_oracle(dict(kw, normalization=True)).K(Y, X)) <= TOL
+
+
 @pytest.mark.parametrize("shape", [dict(N=37, L=50, d=6, M=4, c=50, r=50, sp="sqrt"),      # BASELINE configs[2]'s sequences, default ranks
                                    dict(N=9, L=131, d=2, M=3, c=20, r=33, sp="log"),       # three time chunks of 64, r > c
                                    dict(N=5, L=7, d=3, M=5, c=4, r=3, sp="lin", lags=2),   # d_eff = 9 > max(c, r): the staging rows; lags
