@@ -527,7 +527,7 @@ class SignatureKernel:
         c = int(self.num_components)
         if c > total + ztot:
             raise ValueError("num_components exceeds the number of available points")
-        pick = np.sort(self.rng.permutation(total + ztot)[:c])
+        pick = np.sort(self.rng.choice(total + ztot, size=c, replace=False, shuffle=False))      # c of all points, without shuffling them all
         d_eff = self.num_features * (self.num_lags + 1)
         parts = []
         if Z is not None:

@@ -40,7 +40,7 @@ def draw_sketch(rng, k1, k2, rank_bound, sparsity):
     if sparsity == 'lin':                                    # low_rank_calculations.py:104-127
         if r > D:
             raise ValueError("rank_bound exceeds the number of coordinate pairs")
-        sel = rng.permutation(D)[:r]
+        sel = rng.choice(D, size=r, replace=False)           # the first r of a shuffle of all pairs (:120-122), without shuffling all D
         i1, i2 = sel % k1, sel // k1                         # combinations[...] = (idx1 over k1 fastest, idx2)
         sign = np.where(rng.random(r) <= 0.5, 1.0, -1.0)
         return Sketch(k1, k2, r, np.arange(r + 1), i1, i2, sign)
@@ -50,15 +50,18 @@ def draw_sketch(rng, k1, k2, rank_bound, sparsity):
         s = float(D) / np.log(float(D))
     else:
         raise ValueError("Unknown sparsity argument %s. Possible values are 'sqrt', 'log', 'lin'" % sparsity)
-    keep = rng.random((D, r)) <= 1.0 / s                     # :144-149
-    R = np.where(keep, rng.standard_normal((D, r)), 0.0) * np.sqrt(s / r)   # :177, :192
-    colptr, i1, i2, val = [0], [], [], []
-    for j in range(r):
-        nz = np.nonzero(R[:, j])[0]
-        i1.append(nz % k1); i2.append(nz // k1); val.append(R[nz, j])
-        colptr.append(colptr[-1] + nz.size)
-    return Sketch(k1, k2, r, colptr, np.concatenate(i1) if i1 else [], np.concatenate(i2) if i2 else [],
-                  np.concatenate(val) if val else [])
+    # R (D, r): every entry N(0, 1) with probability 1/s, else 0 (:144-149, :177), times sqrt(s / r) (:192).  Drawn as what it is --
+    # a Binomial(D r, 1/s) number of entries at uniformly distributed distinct positions -- instead of D r uniforms and normals
+    # (the dense draw was a third of the 12 ms one evaluation's random objects took at num_components = 50).
+    total = D * r
+    nnz = int(rng.binomial(total, min(1.0, 1.0 / s)))
+    pos = rng.choice(total, size=nnz, replace=False, shuffle=False) if nnz else np.zeros(0, dtype=np.int64)
+    row, col = pos // r, pos % r
+    order = np.lexsort((row, col))                           # by output column, rows ascending within a column
+    row, col = row[order], col[order]
+    val = rng.standard_normal(nnz) * np.sqrt(s / r)
+    colptr = np.concatenate(([0], np.cumsum(np.bincount(col, minlength=r)))) if nnz else np.zeros(r + 1, dtype=np.int64)
+    return Sketch(k1, k2, r, colptr, row % k1, row // k1, val)
 
 
 def draw_level_sketches(rng, num_levels, num_components, rank_bound, sparsity):
@@ -75,4 +78,4 @@ def draw_landmarks(rng, points, num_components):
     n = points.shape[0]
     if num_components > n:
         raise ValueError("num_components exceeds the number of available points")
-    return points[rng.permutation(n)[:num_components]]
+    return points[rng.choice(n, size=num_components, replace=False)]
