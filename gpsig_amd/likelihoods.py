@@ -13,9 +13,17 @@ import torch
 NUM_GH = 20
 
 
+_GH_CACHE = {}
+
+
 def _gh(dtype, device, n=NUM_GH):
-    x, w = np.polynomial.hermite.hermgauss(n)
-    return torch.as_tensor(x, dtype=dtype, device=device), torch.as_tensor(w, dtype=dtype, device=device)
+    """Gauss-Hermite nodes and weights on the device, uploaded once per (dtype, device) -- a host-to-device copy per call would
+    also keep a training step from being recorded as a HIP graph."""
+    key = (dtype, str(device), n)
+    if key not in _GH_CACHE:
+        x, w = np.polynomial.hermite.hermgauss(n)
+        _GH_CACHE[key] = (torch.as_tensor(x, dtype=dtype, device=device), torch.as_tensor(w, dtype=dtype, device=device))
+    return _GH_CACHE[key]
 
 
 def inv_probit(x):
@@ -81,7 +89,10 @@ class MultiClass(torch.nn.Module):
         cdfs = cdfs * (1 - 2e-4) + 1e-4
         oh_off = 1.0 - oh_on
         cdfs = cdfs * oh_off[:, :, None] + oh_on[:, :, None]
-        return (torch.prod(cdfs, dim=1) @ (w / math.sqrt(math.pi))[:, None])                            # (N, 1)
+        # product over the classes as exp(sum(log)): every factor lies in [1e-4, 1], and torch.prod's backward inspects its
+        # input for zeros on the host (a stream synchronisation per step, and nothing a HIP-graph capture can contain)
+        prod = torch.exp(torch.log(cdfs).sum(dim=1))
+        return (prod @ (w / math.sqrt(math.pi))[:, None])                                               # (N, 1)
 
     def variational_expectations(self, Fmu, Fvar, Y):
         p = self.prob_is_largest(Y, Fmu, Fvar)
