@@ -184,8 +184,11 @@ struct SeqLane {
                     // of the headline kernel's instructions.  (0 * inf is NaN: the kernel falls back to reset() when ktop is not finite.)
     // point modes only
     T y2[C];        // |y|^2 per owned column
-    T kprev[C];     // kappa(previous x point, owned y columns)
-    T kleft;        // kappa(previous x point, last column of the left neighbour)
+    T eprev[C];     // kappa(previous x point, owned column r) - kappa(previous x point, column r - 1): the column difference of the
+                    // previous row, kept so that the double increment of signature_algs.py:26 costs two subtractions per cell
+                    // instead of three (the same operations on the same operands as (k[a][b] - k[a][b-1]) - (k[a-1][b] - k[a-1][b-1]):
+                    // bit-identical)
+    T klast;        // kappa(previous x point, last owned column): what the right neighbour reads as its column -1
     static constexpr bool HIGHER_ORDER = false;
 
     // Pair boundary.  Only the accumulators are cleared: s[] holds the hand-over words that the RIGHT neighbour
@@ -206,8 +209,8 @@ struct SeqLane {
 #pragma unroll
         for (int m = 0; m < MMAX; ++m) s[m] = T(0);
 #pragma unroll
-        for (int r = 0; r < C; ++r) { kprev[r] = T(0); y2[r] = T(0); }
-        kleft = T(0);
+        for (int r = 0; r < C; ++r) { eprev[r] = T(0); y2[r] = T(0); }
+        klast = T(0);
     }
     // K_m for m = 1..M as seen by the LAST lane of the pair's group
     GPSIG_HD T level_value(int m, int M) const {
@@ -222,7 +225,7 @@ struct SeqLane {
 // Cross-lane inputs are fetched through a policy object `Nbr` with three members, each returning the
 // LEFT neighbour's copy of one of this lane's own state words as of the end of the previous step:
 //     T cin(int m)      left neighbour's s[m]
-//     T kleft()         left neighbour's kprev[C-1]      (MODE_PT_DIFF)
+//     T kleft()         left neighbour's klast           (MODE_PT_DIFF)
 //     T win(int m, int r)  left neighbour's w[m][r]      (higher-order lanes)
 // (zero for the first lane of a pair group).  On the GPU they are DPP row/wave shifts issued right
 // where the value is consumed -- legal because s[m] / kprev are only overwritten later in
@@ -314,7 +317,7 @@ struct SeqLaneHO {
     T pc[NQ][NO][C];   // PC_{m,s}
     T w[NQ][NO];       // chunk-end row prefix of sum_s R_m[r][s] for r < order-1   (hand-over)
     T ktop;
-    T y2[C], kprev[C], kleft;
+    T y2[C], eprev[C], klast;      // as in SeqLane
 
     GPSIG_HD void reset() {
 #pragma unroll
@@ -339,8 +342,8 @@ struct SeqLaneHO {
 #pragma unroll
         for (int m = 0; m < MMAX; ++m) s[m] = T(0);
 #pragma unroll
-        for (int r = 0; r < C; ++r) { kprev[r] = T(0); y2[r] = T(0); }
-        kleft = T(0);
+        for (int r = 0; r < C; ++r) { eprev[r] = T(0); y2[r] = T(0); }
+        klast = T(0);
     }
     GPSIG_HD T level_value(int m, int M) const {
         T v = ktop;
@@ -450,13 +453,14 @@ GPSIG_HD void seq_ho_level(SeqLaneHO<T, C, D, MMAX, OMAX, MODE>& L, const Nbr& n
 template <typename T, int C, int MODE, class Lane, class Nbr>
 GPSIG_HD void seq_point_increments(Lane& L, const Nbr& nbr, const T (&knew)[C], bool dummy, int rlo, int rhi, T (&dm)[C]) {
     if constexpr (MODE == MODE_PT_DIFF) {
-        const T kleft_new = nbr.kleft();
-        dm[0] = (knew[0] - kleft_new) - (L.kprev[0] - L.kleft);
+        const T kl = nbr.kleft();              // kappa(this x point, the left neighbour's last column): it was on this row one step ago
 #pragma unroll
-        for (int r = 1; r < C; ++r) dm[r] = (knew[r] - knew[r - 1]) - (L.kprev[r] - L.kprev[r - 1]);
-#pragma unroll
-        for (int r = 0; r < C; ++r) L.kprev[r] = knew[r];
-        L.kleft = kleft_new;
+        for (int r = 0; r < C; ++r) {
+            const T e = knew[r] - (r == 0 ? kl : knew[r == 0 ? 0 : r - 1]);
+            dm[r] = e - L.eprev[r];
+            L.eprev[r] = e;
+        }
+        L.klast = knew[C - 1];
     } else {
 #pragma unroll
         for (int r = 0; r < C; ++r) dm[r] = knew[r];

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
     struct DevNbr {
         const Lane& L;
         __device__ __forceinline__ T cin(int m) const { return shr1<G>(L.s[m]); }
-        __device__ __forceinline__ T kleft() const { return shr1<G>(L.kprev[C - 1]); }
+        __device__ __forceinline__ T kleft() const { return shr1<G>(L.klast); }
         __device__ __forceinline__ T win(int m, int r) const {
             if constexpr (Lane::HIGHER_ORDER) return shr1<G>(L.w[m][r]); else return T(0);
         }

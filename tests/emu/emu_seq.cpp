@@ -84,7 +84,7 @@ static void emu_task(const SeqGramArgs& A, const SeqTask& tk) {
             const int lam = lane & (G - 1);
             NbrSnapshot<T, MMAX>& S = snap[lane];
             for (int m = 0; m < MMAX; ++m) S.s[m] = lam ? L[lane - 1].s[m] : T(0);
-            S.klast = lam ? L[lane - 1].kprev[C - 1] : T(0);
+            S.klast = lam ? L[lane - 1].klast : T(0);
             if constexpr (Lane::HIGHER_ORDER) {
                 for (int m = 0; m < Lane::NQ; ++m)
                     for (int r = 0; r < Lane::NO; ++r) S.w[m][r] = lam ? L[lane - 1].w[m][r] : T(0);
