@@ -398,6 +398,12 @@ int lr_upload(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, int 
 int lr_gemm(gpsig_ctx* c, const double* A, const double* B, int64_t N1, int64_t N2, int K, int64_t lda, int64_t ldb, double* C_,
             int64_t ldc) {
     if (N1 <= 0 || N2 <= 0) return GPSIG_OK;
+    if (c->lr_gemm != 0 && N1 * N2 >= int64_t(GEMM_BM) * GEMM_BN) {       // 128 x 128 tiles through LDS
+        dim3 grid((unsigned)((N2 + GEMM_BN - 1) / GEMM_BN), (unsigned)((N1 + GEMM_BM - 1) / GEMM_BM));
+        hipLaunchKernelGGL(gemm_abt_f64_tiled_kernel, grid, dim3(256), 0, c->stream, A, B, N1, N2, K, lda, ldb, C_, ldc);
+        HIPCHK(c, hipGetLastError());
+        return GPSIG_OK;
+    }
     dim3 grid((unsigned)((N2 + 63) / 64), (unsigned)((N1 + 63) / 64));
     hipLaunchKernelGGL(gemm_abt_f64_mfma_kernel, grid, dim3(256), 0, c->stream, A, B, N1, N2, K, lda, ldb, C_, ldc);
     HIPCHK(c, hipGetLastError());
@@ -1451,6 +1457,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else if (!strcmp(name, "diag_own")) c->diag_own = value;
     else if (!strcmp(name, "tens_tile")) c->tens_tile = value;
+    else if (!strcmp(name, "lr_gemm")) c->lr_gemm = value;
     else if (!strcmp(name, "lr_fused")) c->lr_fused = value;
     else if (!strcmp(name, "lr_fused_variant")) c->lr_fused_variant = value;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);

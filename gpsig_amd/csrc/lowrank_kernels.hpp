@@ -292,4 +292,75 @@ __global__ __launch_bounds__(256) void gemm_abt_f64_mfma_kernel(const double* __
             }
 }
 
+// The same product in 128 x 128 tiles per workgroup of four wavefronts (64 x 64 = 4 x 4 MFMA tiles each), operands staged
+// through LDS: a k-slab of 16 columns of both operands is fetched coalesced (every thread 8 consecutive doubles of one row)
+// into registers while the previous slab is multiplied, then written to LDS rows padded to 17 doubles (the 16 rows x 4 k a
+// fragment read touches fall on different banks).  gemm_abt_f64_mfma_kernel above reads every fragment straight from L2 at a
+// stride of one row per lane: 23-26 TFLOP/s at the low-rank Grams' shapes (K = 201 .. 251); this one is bound by the matrix
+// pipe once K is a few slabs deep.
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16, GEMM_LDK = GEMM_BK + 1;
+__global__ __launch_bounds__(256, 2) void gemm_abt_f64_tiled_kernel(const double* __restrict__ A, const double* __restrict__ B, int64_t N1,
+                                                                   int64_t N2, int K, int64_t lda, int64_t ldb, double* __restrict__ C,
+                                                                   int64_t ldc) {
+    __shared__ double As[GEMM_BM * GEMM_LDK];
+    __shared__ double Bs[GEMM_BN * GEMM_LDK];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const int64_t tile_i = int64_t(blockIdx.y) * GEMM_BM, tile_j = int64_t(blockIdx.x) * GEMM_BN;
+    // staging: thread t fetches columns [8 h, 8 h + 8) of row t >> 1 of the slab, h = t & 1
+    const int srow = tid >> 1, scol = (tid & 1) * 8;
+    const int64_t ai = tile_i + srow, bj = tile_j + srow;
+    const double* arow = A + (ai < N1 ? ai : 0) * lda;
+    const double* brow = B + (bj < N2 ? bj : 0) * ldb;
+    const bool aok = ai < N1, bok = bj < N2;
+    double pa[8], pb[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + scol + e;
+            pa[e] = (aok && k < K) ? arow[k] : 0.0;
+            pb[e] = (bok && k < K) ? brow[k] : 0.0;
+        }
+    };
+    mfma_f64x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = mfma_f64x4{0.0, 0.0, 0.0, 0.0};
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            As[srow * GEMM_LDK + scol + e] = pa[e];
+            Bs[srow * GEMM_LDK + scol + e] = pb[e];
+        }
+        __syncthreads();
+        if (k0 + GEMM_BK < K) fetch(k0 + GEMM_BK);          // in flight while this slab is multiplied
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK; kk += 4) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                av[m] = As[(wr * 64 + m * 16 + li) * GEMM_LDK + kk + lk];
+                bv[m] = Bs[(wc * 64 + m * 16 + li) * GEMM_LDK + kk + lk];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = tile_i + wr * 64 + m * 16 + lk + 4 * r, j = tile_j + wc * 64 + n * 16 + li;
+                if (i < N1 && j < N2) C[i * ldc + j] = acc[m][n][r];
+            }
+}
+
 }  // namespace gpsig

@@ -114,6 +114,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 gathering its components from HBM (round 1)
  *   "diag_own"    diagonal pass of the pair kernel (level diagonals for normalisation, Kdiag): 1 (default) every pair group of a
  *                 wavefront sweeps its own sequence, 0 all groups sweep the same 64/G sequences and emit one pair each (round 1)
+ *   "lr_gemm"     low-rank Gram products on the fp64 matrix cores: 1 (default) 128 x 128 tiles with k-slabs staged through LDS,
+ *                 0 operand fragments read straight from L2 (round 1)
  *   "lr_fused"    low-rank sequence features (gpsig_lr_seq_features): 1 (default) one fused kernel, a workgroup per sequence with
  *                 the (width, length) intermediates in LDS, wherever they fit; 0 one elementwise kernel per reference op */
 int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);

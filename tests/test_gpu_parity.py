@@ -1008,6 +1008,37 @@ def test_low_rank_fused_feature_kernel(K, shape, base):
         assert np.abs(kx.K(X, lr_state=st) - want).max() <= tol * np.abs(want).max(), difference
 
 
+def test_low_rank_gram_products_in_lds_tiles(K):
+    """The low-rank Gram products (Phi_a Phi_b^T per level, or summed) through the 128 x 128-tile MFMA kernel with k-slabs staged
+    in LDS against the round-1 kernel (fragments straight from L2) and the oracle: ragged sizes across tile boundaries, feature
+    widths that are no multiple of the 16-column slab, levels and sums, symmetric and cross."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(57)
+    L, d, M = 6, 2, 3
+    X = np.cumsum(0.3 * rng.standard_normal((261, L, d)), axis=1).reshape(261, -1)
+    Y = np.cumsum(0.3 * rng.standard_normal((130, L, d)), axis=1).reshape(130, -1)
+    for c_, r_ in ((11, 9), (16, 16), (37, 21)):
+        kx, ko = _lr_pair(K, "rbf", L, d, M, normalization=True, num_components=c_, rank_bound=r_, sparsity="sqrt",
+                          lengthscales=0.6 + rng.random(d), variances=0.5 + rng.random(M + 1))
+        kx.rng = np.random.default_rng(9)
+        st = kx.draw_low_rank(X=X, X2=Y)
+        ctx = _lib.context(0, 0)
+        got = {}
+        try:
+            for tiled in (1, 0):
+                ctx.set_option("lr_gemm", tiled)
+                got[tiled] = (kx.K(X, lr_state=st), kx.K(X, Y, lr_state=st, return_levels=True), kx.K(Y, X, lr_state=st))
+        finally:
+            ctx.set_option("lr_gemm", 1)
+        for a, b in zip(got[1], got[0]):
+            assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
+        # against the oracle on the scale of the whole array: up to 37 landmarks in a 2-dimensional state space make a landmark
+        # Gram whose small eigenvalues sit at the jitter, where rocSOLVER and LAPACK eigenvectors differ (comment above LR_TOLS)
+        lo = O.LowRankOracle(ko, st.landmarks, st.jitter_diag, st.sketches)
+        for g, w in ((got[1][0], lo.K(X)), (got[1][1], lo.K(X, Y, return_levels=True))):
+            assert np.abs(g - w).max() <= 1e-4 * np.abs(w).max()
+
+
 def test_low_rank_exact_limit_and_convergence(K):
     rng = np.random.default_rng(43)
     N, L, d = 8, 5, 2
