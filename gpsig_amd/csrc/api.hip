@@ -1880,6 +1880,18 @@ int gpsig_lr_tens_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowr
     if (T <= 0) return finish(c);
     double p0, p1;
     base_p(p, &p0, &p1);
+    if (c->lr_fused != 0 && lr_tens_fused_lds_bytes(cc, r, d_eff, lt, E) <= 64 * 1024 && M - 1 <= LR_FUSED_MAX_SKETCHES && T <= 0x7fffffff) {
+        LrTensFusedArgs A;
+        A.Z = static_cast<const double*>(dZ); A.T = T; A.lt = lt; A.E = E; A.P = s; A.S = D.S; A.Wh = D.Wh;
+        A.c = cc; A.r = r; A.M = M; A.kind = int(p->base_kernel); A.p0 = p0; A.p1 = p1;
+        for (int i = 0; i < LR_FUSED_MAX_SKETCHES; ++i) A.sk[i] = LrFusedSketch{nullptr, nullptr};
+        for (int i = 0; i < D.nsk; ++i) A.sk[i] = LrFusedSketch{D.colptr[i], D.ent[i]};
+        A.Phi = phi; A.F = F;
+        const int rc = lr_tens_fused_launch(c->stream, A);
+        if (rc != 0) return fail(c, GPSIG_ERR_HIP, "fused low-rank tensor feature kernel: %s", hipGetErrorString(hipError_t(rc)));
+        CHK(out_done(c, Phi, dPhi, sizeof(double) * size_t(T) * F));
+        return finish(c);
+    }
     const int64_t rows = int64_t(lt) * T * E;
     void *kxs, *feat, *U, *Ra, *Rb, *wht;
     const int wmax = cc > r ? cc : r;

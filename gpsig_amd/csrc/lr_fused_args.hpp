@@ -35,6 +35,23 @@ inline size_t lr_fused_lds_bytes(int c, int r, int d_eff, int L) {
     return sizeof(double) * size_t(lp) * (size_t(c) + 2 * size_t(kb));
 }
 
+// Feature map of inducing tensors (gpsig/kernels.py:285-311 _K_tens_lr_feat, signature_algs.py:194-222 tensor_kern_lr_feature),
+// one workgroup per tensor: its lt * E components are whitened and chained through the sketches in LDS.
+struct LrTensFusedArgs {
+    const double* Z; int64_t T; int lt, E;      // Z (lt, T, E, d_eff) as the caller gives it
+    ScaleParams P;
+    const double* S; const double* Wh;
+    int c, r, M, kind;
+    double p0, p1;
+    LrFusedSketch sk[LR_FUSED_MAX_SKETCHES];
+    double* Phi; int F;
+};
+inline size_t lr_tens_fused_lds_bytes(int c, int r, int d_eff, int lt, int E) {
+    const size_t rows = size_t(lt) * E, w = size_t(c > r ? c : r);
+    return sizeof(double) * (rows * (size_t(d_eff) + 2 * size_t(c)) + size_t(lt) * c + 2 * w);
+}
+int lr_tens_fused_launch(hipStream_t stream, const LrTensFusedArgs& A);
+
 // lr_fused_inst.hip: launches the kernel on `stream` with `grid` workgroups; returns the hipError_t of the launch
 int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, int variant);
 

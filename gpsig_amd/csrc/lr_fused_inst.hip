@@ -30,4 +30,10 @@ int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, int
     }
 }
 
+int lr_tens_fused_launch(hipStream_t stream, const LrTensFusedArgs& A) {
+    const size_t lds = lr_tens_fused_lds_bytes(A.c, A.r, A.P.d_eff(), A.lt, A.E);
+    hipLaunchKernelGGL(lr_tens_features_fused_kernel, dim3(unsigned(A.T)), dim3(LR_TENS_THREADS), lds, stream, A);
+    return int(hipGetLastError());
+}
+
 }  // namespace gpsig

@@ -162,4 +162,85 @@ __global__ __launch_bounds__(THREADS) void lr_seq_features_fused_kernel(LrFusedA
     }
 }
 
+// ---- inducing tensors ---------------------------------------------------------------------------------------------------
+// One workgroup per tensor t.  Rows (k, e) of the tensor's lt * E components: scaled (kernels.py:367-398), kappa against the
+// landmarks (low_rank_calculations.py:59), whitened (:60), differenced over e for incremental tensors (kernels.py:304); then
+// level i is the chain  R = U[k];  R = sketch_{j-1}(U[k + j], R), j = 1 .. i-1  (signature_algs.py:211-221), thread = output
+// column.  The sketches' entries come from L2 (they are the same for every tensor).  A few hundred multiply-adds per thread:
+// the point is one launch instead of about twenty.
+constexpr int LR_TENS_THREADS = 128;
+__global__ __launch_bounds__(LR_TENS_THREADS) void lr_tens_features_fused_kernel(LrTensFusedArgs A) {
+    extern __shared__ double lr_lds[];
+    const int c = A.c, r = A.r, lt = A.lt, E = A.E, d_eff = A.P.d_eff();
+    const int rows = lt * E, w = c > r ? c : r;
+    double* const zs = lr_lds;                       // [rows][d_eff]
+    double* const kx = zs + rows * d_eff;            // [rows][c]
+    double* const ft = kx + rows * c;                // [rows][c]
+    double* const U = ft + rows * c;                 // [lt][c]
+    double* Ra = U + lt * c;                         // [w]
+    double* Rb = Ra + w;                             // [w]
+    const int64_t t = blockIdx.x;
+    double* phi = A.Phi + t * int64_t(A.F);
+    for (int q = threadIdx.x; q < rows * d_eff; q += LR_TENS_THREADS) {
+        const int row = q / d_eff, fe = q - row * d_eff;
+        const int k = row / E, e = row - k * E;
+        const int lag = fe / A.P.d_in, f = fe - lag * A.P.d_in;
+        double x = A.Z[((int64_t(k) * A.T + t) * E + e) * d_eff + fe];
+        if (A.P.has_ls) {                            // kernels.py:374-379 / :391-395
+            x = x / A.P.ls[f];
+            if (A.P.num_lags > 0) x = x * A.P.gamma[lag];
+        }
+        zs[q] = x;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < rows * c; q += LR_TENS_THREADS) {
+        const int row = q / c, i = q - row * c;
+        double ip = 0.0, xs = 0.0, ss = 0.0;
+        for (int fe = 0; fe < d_eff; ++fe) {
+            const double x = zs[row * d_eff + fe], y = A.S[size_t(i) * d_eff + fe];
+            ip = fma(x, y, ip); xs = fma(x, x, xs); ss = fma(y, y, ss);
+        }
+        kx[q] = base_eval<double>(A.kind, ip, xs, ss, A.p0, A.p1);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < rows * c; q += LR_TENS_THREADS) {
+        const int row = q / c, j = q - row * c;
+        double acc = 0.0;
+        for (int i = 0; i < c; ++i) acc = fma(kx[row * c + i], A.Wh[size_t(i) * c + j], acc);
+        ft[q] = acc;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < lt * c; q += LR_TENS_THREADS) {
+        const int k = q / c, j = q - k * c;
+        U[q] = E == 2 ? ft[(k * 2 + 1) * c + j] - ft[(k * 2) * c + j] : ft[k * c + j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) phi[0] = 1.0;
+    int k = 0;
+    for (int i = 1; i <= A.M; ++i) {
+        const double* R = U + k * c;
+        int kw = c;
+        ++k;
+        double* cur = Ra;
+        double* nxt = Rb;
+        for (int j = 1; j < i; ++j) {
+            const LrFusedSketch sk = A.sk[j - 1];
+            const double* Uk = U + k * c;
+            for (int jo = threadIdx.x; jo < r; jo += LR_TENS_THREADS) {
+                double acc = 0.0;
+                for (int e = sk.colptr[jo]; e < sk.colptr[jo + 1]; ++e) acc = fma(sk.ent[e].val * Uk[sk.ent[e].i1], R[sk.ent[e].i2], acc);
+                cur[jo] = acc;
+            }
+            __syncthreads();
+            R = cur;
+            kw = r;
+            double* tmp = cur; cur = nxt; nxt = tmp;
+            ++k;
+        }
+        const int off = i == 1 ? 1 : 1 + c + (i - 2) * r;
+        for (int jo = threadIdx.x; jo < kw; jo += LR_TENS_THREADS) phi[off + jo] = R[jo];
+        __syncthreads();                             // R (Ra / Rb) is rewritten by the next level's chain
+    }
+}
+
 }  // namespace gpsig

@@ -1008,6 +1008,49 @@ def test_low_rank_fused_feature_kernel(K, shape, base):
         assert np.abs(kx.K(X, lr_state=st) - want).max() <= tol * np.abs(want).max(), difference
 
 
+@pytest.mark.parametrize("base", ["rbf", "linear", "matern12"])
+def test_low_rank_fused_tensor_features(K, base):
+    """gpsig_lr_tens_features through the one-workgroup-per-tensor kernel (lr_tens_features_fused_kernel) against the
+    one-kernel-per-op path (same random objects) and, through K_tens, against the oracle's tensor_kern_lr_feature restatement."""
+    import ctypes as C
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(79)
+    for T, d, M, c, r, sp, lags in ((37, 6, 4, 50, 50, "sqrt", 0), (5, 2, 5, 9, 13, "log", 0), (130, 3, 3, 12, 7, "lin", 1), (3, 2, 1, 4, 4, "sqrt", 0)):
+        kw = dict(normalization=False, num_components=c, rank_bound=r, sparsity=sp, lengthscales=0.6 + rng.random(d))
+        if lags:
+            kw["num_lags"] = lags
+        kx, ko = _lr_pair(K, base, 8, d, M, **kw)
+        kx.rng = np.random.default_rng(6)
+        de = d * (lags + 1)
+        lt = M * (M + 1) // 2
+        for incr in (False, True):
+            Z = rng.standard_normal((lt, T, 2, de) if incr else (lt, T, de))
+            X = np.cumsum(0.3 * rng.standard_normal((max(c, 8), 8, d)), axis=1).reshape(max(c, 8), -1)     # enough points for the landmarks
+            st = kx.draw_low_rank(X=X, Z=Z, increments=incr)
+            ctx = _lib.context(0, 0)
+            ctx.set_pointer_mode(_lib.PTR_HOST)
+            keep = []
+            p, lr = kx._params(keep), st.as_c(keep)
+            F = 1 + c + (M - 1) * r
+            out = {}
+            Zc = np.ascontiguousarray(Z)
+            try:
+                for fused in (1, 0):
+                    ctx.set_option("lr_fused", fused)
+                    Phi = np.full((T, F), np.nan)
+                    ctx.call("gpsig_lr_tens_features", p, lr, Zc.ctypes.data_as(C.c_void_p), T, int(incr), Phi.ctypes.data_as(C.c_void_p))
+                    out[fused] = Phi
+            finally:
+                ctx.set_option("lr_fused", 1)
+            assert np.isfinite(out[1]).all() and (out[1][:, 0] == 1.0).all()
+            scale = np.abs(out[0]).max(axis=0, keepdims=True) + 1e-300
+            assert (np.abs(out[1] - out[0]) / scale).max() <= 1e-9, (T, incr)
+            lo = O.LowRankOracle(ko, st.landmarks, st.jitter_diag, st.sketches)
+            want = lo.K_tens(Z, increments=incr)
+            # (1e-7 for RBF; the linear kernel's rank-deficient and Matern-1/2's non-smooth landmark Grams: comment above LR_TOLS)
+            assert np.abs(kx.K_tens(Z, increments=incr, lr_state=st) - want).max() <= (1e-7 if base == "rbf" else 1e-5) * np.abs(want).max()
+
+
 def test_low_rank_gram_products_in_lds_tiles(K):
     """The low-rank Gram products (Phi_a Phi_b^T per level, or summed) through the 128 x 128-tile MFMA kernel with k-slabs staged
     in LDS against the round-1 kernel (fragments straight from L2) and the oracle: ragged sizes across tile boundaries, feature
