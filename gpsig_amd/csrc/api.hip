@@ -600,7 +600,6 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     A.xrec_stride = r.gx.rec_elems; A.yrec_stride = r.gy.rec_elems;
     A.R1 = r.gx.rows; A.R2 = r.gy.rows; A.RS = r.gx.RS; A.M = p->num_levels; A.order = p->order;
     A.nslot = seq_ring(pl.cfg.G, r.gx.rows).nslot;
-    A.diag_own = diag_own ? 1 : 0;
     if (diag_own && A.nslot < ypb) A.nslot = ypb;
     A.issue_at = seq_ring(pl.cfg.G, r.gx.rows).issue_at;
     A.slot_elems = r.gx.rec_elems;
@@ -608,7 +607,7 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     base_p(p, &A.p0, &A.p1);
     A.out = r.out; A.si = r.si; A.sj = r.sj; A.sm = r.sm;
     A.ax = r.ax; A.by = r.by; A.jitter_diag = r.jitter_diag;
-    A.sum_levels = r.sum_levels; A.pred = r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds; A.compact = r.compact; A.keep_reset = c->keep_reset;
+    A.sum_levels = r.sum_levels; A.pred = diag_own ? int(PRED_DIAG_OWN) : r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds; A.compact = r.compact; A.keep_reset = c->keep_reset;
     const size_t lds = sizeof(TT) * (size_t(A.RS) + size_t(A.nslot) * A.slot_elems);
     if (lds > 160 * 1024) return fail(c, GPSIG_ERR_UNSUPPORTED, "x-side records of %d rows do not fit the LDS ring (%zu bytes)", A.R1, lds);
     hipEvent_t e0 = nullptr, e1 = nullptr;

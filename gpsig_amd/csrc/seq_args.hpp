@@ -16,7 +16,12 @@ struct SeqTask {
     int32_t nx;   // run length
 };
 
-enum : int { PRED_ALL = 0, PRED_CIRCULANT = 1, PRED_DIAG = 2 };
+// PRED_DIAG_OWN: the diagonal with several pair groups per wavefront, every group sweeping ITS OWN sequence (task.nx == 1, the
+// records of x0 .. x0 + 64/G - 1 staged side by side in the ring) instead of all groups sweeping the same 64/G sequences with one
+// emitted pair each (PRED_DIAG) -- a quarter of the work at G = 16.  A value of `pred` rather than a field of its own: the pair
+// kernels read `pred` at pair boundaries anyway, and one more live scalar cost the headline instance its third wavefront per
+// SIMD (168 -> 171 VGPRs, 24.7 -> 26.9 ms).
+enum : int { PRED_ALL = 0, PRED_CIRCULANT = 1, PRED_DIAG = 2, PRED_DIAG_OWN = 3 };
 
 struct SeqGramArgs {
     const void* xrec;       // x-side records: N1 x rec_stride elements
@@ -46,9 +51,6 @@ struct SeqGramArgs {
     int32_t compact;        // PRED_CIRCULANT only: owned entries of row j packed as out[j*sj + (N/2 - (j-i) mod N)], i.e. row j's
                             // N/2+1 owned columns j-N/2 .. j side by side (multi-GPU row blocks: half the bytes to gather)
     int32_t keep_reset;     // 1: first-order lanes clear their accumulators through SeqLane::keep, 0: explicit reset() at pair boundaries
-    int32_t diag_own;       // PRED_DIAG with several pair groups per wavefront: every group sweeps ITS OWN sequence (task.nx == 1, the
-                            // records of x0 .. x0 + 64/G - 1 staged side by side in the ring) instead of all groups sweeping
-                            // the same 64/G sequences with one emitted pair each -- a quarter of the work at G = 16
     const double* spec;     // BASE_SPECTRAL: alpha[Q], omega[Q][D], gamma[Q][D] (Q = p0, family = p1, D = the kernel's padded width)
 };
 
@@ -68,6 +70,8 @@ GPSIG_HD void seq_emit(const Lane& L, const SeqGramArgs& A, int64_t i, int64_t j
         cdlt = H - dlt;
     } else if (A.pred == PRED_DIAG) {
         emit = (i == j);
+    } else if (A.pred == PRED_DIAG_OWN) {
+        i = j;                                   // the group swept its own sequence (the caller's run index is meaningless here)
     }
     if (!emit) return;
     const T* ax = A.ax ? static_cast<const T*>(A.ax) + i * (M + 1) : nullptr;

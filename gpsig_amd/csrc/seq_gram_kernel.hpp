@@ -119,12 +119,12 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
         }
     };
     stage(0, 0);
-    if (A.diag_own)                                       // one record per pair group, side by side
+    if (A.pred == PRED_DIAG_OWN)                          // one record per pair group, side by side
         for (int g = 1; g < 64 / G; ++g) stage(g, g);
 
     LaneCtl ctl;
     ctl.init(lam, RS);
-    if (A.diag_own) ctl.sbase += grp * A.slot_elems;
+    if (A.pred == PRED_DIAG_OWN) ctl.sbase += grp * A.slot_elems;
     const int ring_elems = nslot * A.slot_elems;
     const T p0 = T(A.p0), p1 = T(A.p1);
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
         // pair boundary: the pair that just finished is complete in the last lane of the group
         if (ctl.begin_step(nx, R1, RS, A.slot_elems, ring_elems)) {
             if (lam == G - 1 && ctl.p >= 1 && jvalid) {
-                int64_t i = int64_t(tk.x0) + (A.diag_own ? grp : ctl.p - 1);
+                int64_t i = int64_t(tk.x0) + (ctl.p - 1);
                 if (i >= A.N1) i -= A.N1;
                 T* const out = static_cast<T*>(A.out);
                 seq_emit<T>(L, A, i, j, M, [&](int64_t off, T v) { out[off] = v; });

@@ -14,3 +14,15 @@ db=$(find $O/prof -name '*.db' | head -1)
 python tools/rocprof_summary.py stats "$db" > $O/kernel_stats_lr_c3.txt 2>&1 || true
 rm -rf $O/prof
 head -30 $O/kernel_stats_lr_c3.txt | cut -c1-220
+# PMC passes of the fused feature kernel (each counter set in its own pass, no tracing)
+: > $O/pmc_lr_c3.txt
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT"; do
+  rm -rf /tmp/pmc_run
+  timeout 600 rocprofv3 --pmc $set -d /tmp/pmc_run -o p -- python tools/bench_lr.py --config c3 --steps 2 > $O/pmc_run.log 2>&1
+  db=$(find /tmp/pmc_run -name '*.db' | head -1)
+  echo "## rocprofv3 --pmc $set   (tools/bench_lr.py --config c3 --steps 2)" >> $O/pmc_lr_c3.txt
+  python tools/rocprof_summary.py pmc "$db" "lr_seq_features_fused" 2>&1 | cut -c1-260 >> $O/pmc_lr_c3.txt
+  echo >> $O/pmc_lr_c3.txt
+done
+rm -rf /tmp/pmc_run
+cat $O/pmc_lr_c3.txt | cut -c1-230
