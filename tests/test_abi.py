@@ -103,3 +103,26 @@ def test_inducing_classes_validate_like_reference():
     assert f.W.shape == (M, 5, 5)                                     # :26
     s = IV.InducingSequences(np.zeros((4, 7, 2)), M, learn_weights=True)
     assert len(s) == 4 and s.len_inducing == 7 and s.W.shape == (M, 4, 4)
+
+
+def test_headline_kernel_keeps_three_wavefronts_per_simd(tmp_path):
+    """seq_gram_kernel<double,16,4,8,5,MODE_INC,exact> (BASELINE configs[1]) sits at 168 VGPRs, the last count that leaves three
+    wavefronts per SIMD (512 / 168); three more registers -- one more live scalar in the pair-boundary block was enough once --
+    cost 10 % of the headline number (profiles/r02_ab_variants.txt).  Compiles the translation unit to assembly and reads the
+    compiler's own report."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "gpsig_amd", "csrc", "seq_inst_inc_exact.hip")
+    out = str(tmp_path / "inc_exact.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    name = "_ZN5gpsig15seq_gram_kernelIdLi16ELi4ELi8ELi5ELi0ELb1ELi0ELin1EEEvNS_11SeqGramArgsE"
+    start = text.index(name + ":")
+    m = re.search(r"; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", text[start:], re.S)
+    vgprs, scratch, occupancy = (int(g) for g in m.groups())
+    assert vgprs <= 168 and scratch == 0 and occupancy >= 3, (vgprs, scratch, occupancy)
