@@ -962,7 +962,7 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     if (!fn) return GPSIG_OK;
     const int rec_elems = (L * D + L + TVS_REC_ALIGN - 1) / TVS_REC_ALIGN * TVS_REC_ALIGN;
     const bool sum_levels = !(raw || return_levels);
-    const size_t lds = tvs_tile_lds_bytes(M, NW, rec_elems, sum_levels);
+    const size_t lds = tvs_tile_lds_bytes(M, NW, rec_elems, sum_levels, E == 2);
     if (lds > 64 * 1024) return GPSIG_OK;
     const int64_t Tpad = (Tn + 63) / 64 * 64, TB = Tpad / 64;
     // sequences per workgroup: whole tiles of 16 once there are enough workgroups to fill the chip a few times over
@@ -972,7 +972,7 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     if (run >= TVS_TILE_S) run = (run + TVS_TILE_S - 1) / TVS_TILE_S * TVS_TILE_S;
     if (run > 4 * TVS_TILE_S) run = 4 * TVS_TILE_S;
     if ((N + run - 1) / run > 65535) return GPSIG_OK;
-    const double pre = kind == BASE_RBF ? TVS_RBF_PRESCALE : 1.0;
+    const double pre = kind == BASE_RBF ? tvs_rbf_prescale(E == 2) : 1.0;
     const int rows_are_increments = kind == BASE_LINEAR && p->difference;
     void *zl, *zn, *xr;
     CHK(ensure(c, B_ZL, sizeof(double) * size_t(lt) * E * D * Tpad + 8, &zl));

@@ -17,6 +17,8 @@
 
 #include <cmath>
 
+#include "fast_exp_tables.hpp"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define GPSIG_FX __host__ __device__ __forceinline__
@@ -193,6 +195,42 @@ GPSIG_FX double kexp2_tab256(double t, const double* tab) {
     const int ni = exp_tab_int(n);
     const double tj = tab[ni & (EXP_TAB256_N - 1)];
     return ldexp(fma(tj, s, tj), ni >> 8);
+}
+
+// ---- 1024- and 2048-entry variants: 2^(t/N), degree-3 tail, 11 instructions.  |r ln2/N| <= 3.4e-4 / 1.7e-4: the first omitted term
+// is 5.5e-16 / 3.4e-17 relative (N = 1024: up to 5.8 ulp in all at the ends of the reduction interval; N = 2048: 1.3 ulp like the others).  Tables of 8 /
+// 16 KB: for kernels whose LDS budget has the room (the Kzx tile kernel), t = a * N/ln2, points prescaled by sqrt(N / ln 2).
+template <int N> struct ExpTabN;
+template <> struct ExpTabN<1024> {
+    static constexpr int SHIFT = 10;
+    static constexpr double C1 = GPSIG_EXP_TAIL1024_C1, C2 = GPSIG_EXP_TAIL1024_C2, C3 = GPSIG_EXP_TAIL1024_C3;
+    static constexpr double PRESCALE = 4.0 * EXP_PRESCALE;         // sqrt(1024 / ln 2)
+};
+template <> struct ExpTabN<2048> {
+    static constexpr int SHIFT = 11;
+    static constexpr double C1 = GPSIG_EXP_TAIL2048_C1, C2 = GPSIG_EXP_TAIL2048_C2, C3 = GPSIG_EXP_TAIL2048_C3;
+    static constexpr double PRESCALE = 0x1.b2da4e9808a53p+5;       // sqrt(2048 / ln 2)
+};
+#if defined(__HIPCC__)
+static __device__ const double g_exp2_tab1024[1024] = {GPSIG_EXP2_TABLE1024};
+static __device__ const double g_exp2_tab2048[2048] = {GPSIG_EXP2_TABLE2048};
+template <int N>
+__device__ __forceinline__ void exp_tabn_fill(double* lds_tab, int tid, int nthreads) {
+    const double* src = N == 1024 ? g_exp2_tab1024 : g_exp2_tab2048;
+    for (int j = tid; j < N; j += nthreads) lds_tab[j] = src[j];
+}
+#endif
+template <int N>
+GPSIG_FX double kexp2_tabn(double t, const double* tab) {
+    const double n = rint(t);
+    const double r = t - n;
+    double q = ExpTabN<N>::C3;
+    q = fma(q, r, ExpTabN<N>::C2);
+    q = fma(q, r, ExpTabN<N>::C1);
+    const double s = q * r;
+    const int ni = exp_tab_int(n);
+    const double tj = tab[ni & (N - 1)];
+    return ldexp(fma(tj, s, tj), ni >> ExpTabN<N>::SHIFT);
 }
 
 }  // namespace gpsig

@@ -26,12 +26,25 @@
 
 namespace gpsig {
 
-#ifndef TVS_EXP256
-#define TVS_EXP256 1                     // 1: the 256-entry exp table with the degree-4 tail (fast_exp.hpp), 0: 64 entries / degree 5.  Same box,
-                                         // alternating (profiles/r02_ab_exp256.txt): Kzx RBF 3.20 -> 3.07 ms, with increments 6.49 -> 6.17 ms
+// Entries of the exp table (fast_exp.hpp): 64 (degree-5 tail), 256 (degree 4), 1024 / 2048 (degree 3, one instruction fewer per exp).
+// Same box, alternating processes: 64 -> 256 entries: Kzx RBF 3.20 -> 3.07 ms, with increments 6.49 -> 6.17 ms (profiles/r02_ab_exp256.txt);
+// 256 -> 1024 -> 2048 entries: 2.93 -> 3.34 -> 3.70 ms WITHOUT increments (8 / 16 KB more LDS per workgroup cost the stream-bound case
+// its occupancy), 6.07 -> 5.88 -> 5.89 ms WITH increments (ten exps per step and wave: the instruction counts) -- profiles/r02_ab_exptab.txt.
+// Hence by kernel: incremental tensors take 1024 entries, the others 256.  TVS_EXPTAB (64 ... 2048) forces one size for A/B builds.
+#ifdef TVS_EXPTAB
+constexpr int tvs_etab_n(bool) { return TVS_EXPTAB; }
+#else
+constexpr int tvs_etab_n(bool two_points) { return two_points ? 1024 : 256; }
 #endif
-constexpr int TVS_ETAB_N = TVS_EXP256 ? EXP_TAB256_N : EXP_TAB_N;
-constexpr double TVS_RBF_PRESCALE = TVS_EXP256 ? EXP_PRESCALE256 : EXP_PRESCALE;
+constexpr double tvs_rbf_prescale(bool two_points) {
+    return tvs_etab_n(two_points) == 64 ? EXP_PRESCALE : (tvs_etab_n(two_points) == 256 ? EXP_PRESCALE256 : (tvs_etab_n(two_points) == 1024 ? 4.0 * EXP_PRESCALE : 0x1.b2da4e9808a53p+5));
+}
+template <int NTAB>
+__device__ __forceinline__ double tvs_exp2(double t, const double* etab) {
+    if constexpr (NTAB == 64) return kexp2_tab(t, etab);
+    else if constexpr (NTAB == 256) return kexp2_tab256(t, etab);
+    else return kexp2_tabn<NTAB>(t, etab);
+}
 constexpr int TVS_TILE_S = 16;           // sequences per output flush: 16 doubles = one 128-byte line per tensor row
 constexpr int TVS_REC_ALIGN = 128;       // record length granule in elements of double: 64 lanes x 16 bytes of LDS-DMA
 
@@ -52,9 +65,9 @@ struct TvsTileArgs {
 };
 
 // LDS bytes of one workgroup
-inline size_t tvs_tile_lds_bytes(int M, int NW, int rec_elems, bool sum_levels) {
+inline size_t tvs_tile_lds_bytes(int M, int NW, int rec_elems, bool sum_levels, bool two_points) {
     const size_t slots = sum_levels ? size_t(NW) : size_t(M + 1);
-    return sizeof(double) * (TVS_ETAB_N + 2 * size_t(rec_elems) + slots * 64 * (TVS_TILE_S + 1));
+    return sizeof(double) * (tvs_etab_n(two_points) + 2 * size_t(rec_elems) + slots * 64 * (TVS_TILE_S + 1));
 }
 
 template <int M, int NW, int D, bool INCR, int KIND, int MASK>
@@ -105,7 +118,7 @@ struct TvsTileWave {
                     double t = zn[c][e] + hx;
 #pragma unroll
                     for (int f = 0; f < D; ++f) t = fma(z[c][e][f], x[f], t);
-                    kv[c * E + e] = TVS_EXP256 ? kexp2_tab256(t, etab) : kexp2_tab(t, etab);
+                    kv[c * E + e] = tvs_exp2<tvs_etab_n(E == 2)>(t, etab);
                 }
         } else {
 #pragma unroll
@@ -198,7 +211,8 @@ __global__ __launch_bounds__(NW * 64, 2) void tvs_tile_kernel(const TvsTileArgs 
     constexpr int TS = TVS_TILE_S + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char tvs_tile_smem[];
     double* const etab = reinterpret_cast<double*>(tvs_tile_smem);
-    double* const recs = etab + TVS_ETAB_N;                        // 2 x rec_elems
+    constexpr int NTAB = tvs_etab_n(INCR && KIND != BASE_LINEAR);
+    double* const recs = etab + NTAB;                              // 2 x rec_elems
     double* const tile = recs + 2 * A.rec_elems;                  // [slots][64][TS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -210,8 +224,9 @@ __global__ __launch_bounds__(NW * 64, 2) void tvs_tile_kernel(const TvsTileArgs 
     double* __restrict__ out = static_cast<double*>(A.out);
 
     if constexpr (KIND != BASE_LINEAR) {
-        if constexpr (TVS_EXP256) exp_tab256_fill(etab, tid, NW * 64);
-        else exp_tab_fill(etab, tid, NW * 64);
+        if constexpr (NTAB == 64) exp_tab_fill(etab, tid, NW * 64);
+        else if constexpr (NTAB == 256) exp_tab256_fill(etab, tid, NW * 64);
+        else exp_tabn_fill<NTAB>(etab, tid, NW * 64);
     }
 
     // records arrive by LDS-DMA: 64 lanes x 16 bytes per instruction, the waves take alternate kilobytes

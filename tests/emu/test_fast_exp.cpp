@@ -7,6 +7,8 @@
 
 static const double tab[64] = {GPSIG_EXP2_TABLE};
 static const double tab256[256] = {GPSIG_EXP2_TABLE256};
+static const double tab1024[1024] = {GPSIG_EXP2_TABLE1024};
+static const double tab2048[2048] = {GPSIG_EXP2_TABLE2048};
 
 static double ulps(double got, long double want) {
     if (want == 0.0L) return got == 0.0 ? 0.0 : 1e9;
@@ -19,7 +21,7 @@ static double ulps(double got, long double want) {
 int main(int argc, char** argv) {
     const long n = argc > 1 ? atol(argv[1]) : 2000000;
     unsigned long long s = 88172645463325252ull;
-    double worst1 = 0, worst2 = 0;
+    double worst1 = 0, worst2 = 0, worst1024 = 0, worst2048 = 0;
     for (long i = 0; i < n; ++i) {
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
         const double u = double(s >> 11) / 9007199254740992.0;
@@ -40,13 +42,21 @@ int main(int argc, char** argv) {
         const double g3 = gpsig::kexp2_tab256(4.0 * t, tab256);                 // the 256-entry variant: 2^(t'/256), t' = 4 t
         const double w3 = ulps(g3, exp2l((long double)(4.0 * t) / 256.0L));
         if (w3 > worst2) worst2 = w3;
+        const double w4 = ulps(gpsig::kexp2_tabn<1024>(16.0 * t, tab1024), exp2l((long double)(16.0 * t) / 1024.0L));   // 2^(t'/1024)
+        if (w4 > worst1024) worst1024 = w4;
+        const double w5 = ulps(gpsig::kexp2_tabn<2048>(32.0 * t, tab2048), exp2l((long double)(32.0 * t) / 2048.0L));
+        if (w5 > worst2048) worst2048 = w5;
     }
     // edge cases: huge negative arguments give 0, zero gives 1
     const double e0 = gpsig::kexp_tab(0.0, tab), e1 = gpsig::kexp_tab(-1e300, tab), e2 = gpsig::kexp2_tab(-1e300, tab),
                  e3 = gpsig::kexp_tab(-800.0, tab), e4 = gpsig::kexp2_tab(0.0, tab);
     const bool e256 = gpsig::kexp2_tab256(0.0, tab256) == 1.0 && gpsig::kexp2_tab256(-1e300, tab256) == 0.0 &&
                       fabs(gpsig::EXP_PRESCALE256 * gpsig::EXP_PRESCALE256 / (4.0 * gpsig::EXP_T_PER_A) - 1.0) < 4e-16;
-    const bool scale_ok = e256 && fabs(gpsig::EXP_PRESCALE * gpsig::EXP_PRESCALE / gpsig::EXP_T_PER_A - 1.0) < 4e-16;
-    printf("%.4f %.4f %d\n", worst1, worst2, int(e0 == 1.0 && e1 == 0.0 && e2 == 0.0 && e3 == 0.0 && e4 == 1.0 && scale_ok));
+    const bool en = gpsig::kexp2_tabn<1024>(0.0, tab1024) == 1.0 && gpsig::kexp2_tabn<1024>(-1e300, tab1024) == 0.0 &&
+                    gpsig::kexp2_tabn<2048>(0.0, tab2048) == 1.0 && gpsig::kexp2_tabn<2048>(-1e300, tab2048) == 0.0 &&
+                    fabs(gpsig::ExpTabN<1024>::PRESCALE * gpsig::ExpTabN<1024>::PRESCALE / (16.0 * gpsig::EXP_T_PER_A) - 1.0) < 4e-16 &&
+                    fabs(gpsig::ExpTabN<2048>::PRESCALE * gpsig::ExpTabN<2048>::PRESCALE / (32.0 * gpsig::EXP_T_PER_A) - 1.0) < 4e-16;
+    const bool scale_ok = e256 && en && fabs(gpsig::EXP_PRESCALE * gpsig::EXP_PRESCALE / gpsig::EXP_T_PER_A - 1.0) < 4e-16;
+    printf("%.4f %.4f %.4f %.4f %d\n", worst1, worst2, worst1024, worst2048, int(e0 == 1.0 && e1 == 0.0 && e2 == 0.0 && e3 == 0.0 && e4 == 1.0 && scale_ok));
     return 0;
 }
