@@ -55,7 +55,9 @@ def main():
             T = int(rng.integers(1, 9)) if rng.integers(0, 4) else int(rng.choice([33, 64, 70, 130]))
             # library knobs that route a case through the round-2 kernels whatever its size: the Kzx tile kernel below 32 tensors,
             # the packed float32 kernels with one or four waves per ring, for the linear family too
-            opts = dict(tvs_tile=int(rng.choice([-1, 1])), f32_waves=int(rng.choice([0, 1, 4])), pk2=int(rng.choice([1, 2])))
+            opts = dict(tvs_tile=int(rng.choice([-1, 1])), f32_waves=int(rng.choice([0, 1, 4])), pk2=int(rng.choice([1, 2])),
+                        diag_own=int(rng.choice([1, 1, 0])), tens_tile=int(rng.choice([1, 1, 0])), lr_fused=int(rng.choice([1, 1, 0])),
+                        lr_gemm=int(rng.choice([1, 1, 0])))
             for k_, v_ in opts.items():
                 CTX.set_option(k_, v_)
             desc.update(opts)
@@ -84,6 +86,29 @@ def main():
                     os.makedirs("gpurun_out", exist_ok=True)
                     np.savez(f"gpurun_out/fuzz_fail_{it}_{name}.npz", X=Xo, X2=X2o, Z=Zo, got=np.asarray(got, dtype=np.float64), want=w(),
                              ls=kw["lengthscales"], var=kw["variances"], desc=str(desc), incr=incr)
+            # low-rank mode (order 1, float64): the product against the oracle's restatement GIVEN THE SAME random objects; judged on
+            # the scale of each array (two correct eigensolvers differ in the near-null space of an ill-conditioned landmark Gram)
+            if order == 1 and not f32 and base != "cosine" and rng.integers(0, 3) == 0 and min(L1, L2) >= 2:
+                c_ = int(rng.choice([3, 8, 17, 50]))
+                r_ = int(rng.choice([2, 9, 30, 50]))
+                sp = str(rng.choice(["sqrt", "log", "lin"]))
+                npts = N1 * L1 + Zo.reshape(-1, de).shape[0]          # the landmarks are drawn from X and Z
+                c_ = min(c_, npts)
+                if sp == "lin":
+                    r_ = min(r_, c_ * min(c_, r_))
+                kxl = CLASS[base](L1 * d, d, low_rank=True, num_components=c_, rank_bound=r_, sparsity=sp, **kw)
+                kxl.rng = np.random.default_rng(int(rng.integers(1 << 30)))
+                st = kxl.draw_low_rank(X=Xo, Z=Zo, increments=incr)
+                lo = O.LowRankOracle(ko1, st.landmarks, st.jitter_diag, st.sketches)
+                ldesc = dict(desc, c=c_, r=r_, sparsity=sp)
+                for name, g, w in (("lrK", lambda: kxl.K(Xo, lr_state=st), lambda: lo.K(Xo)),
+                                   ("lrKzx", lambda: kxl.K_tens_vs_seq(Zo, Xo, increments=incr, lr_state=st), lambda: lo.K_tens_vs_seq(Zo, Xo, increments=incr)),
+                                   ("lrKzz", lambda: kxl.K_tens(Zo, increments=incr, lr_state=st), lambda: lo.K_tens(Zo, increments=incr))):
+                    got, want = np.asarray(g()), w()
+                    err = float(np.abs(got - want).max() / (np.abs(want).max() + 1e-300))
+                    if not (err <= 1e-4):
+                        bad += 1
+                        print(f"[{it}] {name}: rel.err {err:.3e} > 1e-4  {ldesc} incr={incr} T={T}")
         except Exception:
             bad += 1
             print(f"[{it}] EXCEPTION {desc}")
