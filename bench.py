@@ -15,6 +15,8 @@ Workloads (BASELINE.json configs; the names C1..C5 are SURVEY.md section 8's):
       With --gpus 1 the whole N=32768 Gram is evaluated on one GPU.
   c3  configs[2]: SVGP inducing-tensor path, Kzz + Kzx + Kxx-diag (K_tens_n_seq_covs), T=512 inducing tensors, N=16384, L=50,
       d=6, num_levels=4, fp64, SignatureRBF (--increments: Z holds increments).  A pair is one (tensor, sequence) entry.
+      With --gpus N > 1 the sequences are split over the ranks (parallel.ShardedCovs; 3 ms of work: a functional path, not a
+      scaling benchmark).
   c5  configs[4]: N=2048, L=128, d=16, num_levels=6, fp32, SignatureRBF, full Gram.
 One step = one complete evaluation with the inputs already resident in HBM and the result left in HBM.  Prints ONE JSON line
 on rank 0: the driver's contract fields + `roofline` (pair-stream fraction AND executed-flop ALU fraction of the dominant
@@ -263,8 +265,9 @@ def main():
     if args.gpus != n_gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cfg = args.config or ("c2" if n_gpus == 1 else "c4")
-    if n_gpus > 1 and cfg not in ("c2", "c4"):
-        raise SystemExit("--gpus N > 1 runs the sharded symmetric Gram (c4, or c2 with --weak); c3 / c5 are single-GPU workloads")
+    if n_gpus > 1 and cfg not in ("c2", "c3", "c4"):
+        raise SystemExit("--gpus N > 1 runs the sharded symmetric Gram (c4, or c2 with --weak) or the sequence-sharded SVGP covariances (c3); "
+                         "c5 is a single-GPU workload")
     w = dict(WORKLOADS[cfg])
     base = args.base or w["base"]
     w["base"] = base
@@ -300,10 +303,11 @@ def main():
     cls = kernels.SignatureLinear if base == "linear" else kernels.SignatureRBF
     kern = cls(L * D, D, M, lengthscales=lengthscales(w))
     gram = parallel.ShardedGram(kern, N, dev, rank, world, chunks=args.chunks) if not T else None
+    covs = parallel.ShardedCovs(kern, N, dev, rank, world) if T else None      # world == 1: kern.K_tens_n_seq_covs itself
 
     def step():
         if T:
-            return kern.K_tens_n_seq_covs(Z, X, increments=args.increments)
+            return covs(Z, X, increments=args.increments)
         return gram(X)
 
     def barrier():
@@ -374,8 +378,9 @@ def main():
                                    f"{'white-noise' if w['data'] == 'white' else 'random-walk'} inputs",
                        "name": cfg, "N": N, "L": L, "d": D, "num_levels": M, "order": 1, "normalization": True,
                        "pairs_per_step": pairs,
-                       "parallelism": (f"owned-row blocks x{n_gpus}, {args.chunks} chunks per rank, compact (N/2+1 wide) rows gathered "
-                                       f"asynchronously to rank 0 over RCCL, symmetrised there" if n_gpus > 1 else "single GPU")},
+                       "parallelism": ((f"sequence blocks x{n_gpus} (Z replicated), Kzx / Kxx-diag blocks gathered to rank 0 over RCCL" if T else
+                                        f"owned-row blocks x{n_gpus}, {args.chunks} chunks per rank, compact (N/2+1 wide) rows gathered "
+                                        f"asynchronously to rank 0 over RCCL, symmetrised there") if n_gpus > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms_per_launch": per_launch_ms, "launches_per_step": launches_per_step,
@@ -406,7 +411,10 @@ def main():
         assert res["rel_err"] <= (1e-6 if w["dtype"] == "f64" else 1e-4), res["rel_err"]
         if not T:
             assert np.allclose(out[:8, :8].diagonal().cpu().numpy(), M + 1.0, atol=1e-9 if w["dtype"] == "f64" else 1e-4)
-        if n_gpus > 1:        # the gathered Gram against single-context evaluations: leading block, and a block across rank boundaries
+        if n_gpus > 1 and T:  # the gathered covariances against one single-context evaluation
+            one = kern.K_tens_n_seq_covs(Z, X, increments=args.increments)
+            res["verify_max_abs_diff_vs_single_rank"] = max(float((a - b).abs().max().item()) for a, b in zip(out, one))
+        elif n_gpus > 1:      # the gathered Gram against single-context evaluations: leading block, and a block across rank boundaries
             nb = min(N, 1024)
             d1 = float((out[:nb, :nb] - kern.K(X[:nb])).abs().max().item())
             a, b = N - 300, N // 2 - 100

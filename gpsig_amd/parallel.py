@@ -122,6 +122,55 @@ class ShardedGram:
         return self.out
 
 
+class ShardedCovs:
+    """The three SVGP covariances of ``kern.K_tens_n_seq_covs(Z, X)`` (gpsig/kernels.py:591-671; BASELINE configs[2]) with the N
+    sequences split over the ranks: the (tensor, sequence) chains are independent, so rank r evaluates Kzx[:, n_r] and the
+    Kxx diagonal of its contiguous block of sequences (Z is replicated: a few hundred KB) and the blocks are gathered on rank 0
+    -- the "N x M batch shards embarrassingly" half of the north star; no exchange while computing.  Kzz (T x T, independent of
+    X) is evaluated on rank 0 only.  Returns (Kzz, Kzx, Kxx_diag) on rank 0, None elsewhere.
+
+    evaluate: what computes a block, ``kern.K_tens_n_seq_covs`` by default (the CPU test-suite passes a stand-in: there is no CPU
+    path in the product)."""
+
+    def __init__(self, kern, n, device, rank=0, world=1, evaluate=None):
+        self.kern, self.n, self.dev, self.rank, self.world = kern, int(n), torch.device(device), int(rank), int(world)
+        self.per = -(-self.n // self.world)                    # equal-sized blocks (the last one padded) so that gathers are regular
+        self.n0 = min(self.rank * self.per, self.n)
+        self.n1 = min(self.n0 + self.per, self.n)
+        self._evaluate = evaluate
+
+    def __call__(self, Z, X, increments=False):
+        f = self._evaluate or (lambda Zb, Xb, inc: self.kern.K_tens_n_seq_covs(Zb, Xb, increments=inc))
+        if self.world == 1:
+            return f(Z, X, increments)
+        if X.shape[0] != self.n:
+            raise ValueError("ShardedCovs was built for %d sequences, got %d" % (self.n, X.shape[0]))
+        T = Z.shape[1]
+        if self.n1 > self.n0:
+            Kzz, Kzx, Kxx = f(Z, X[self.n0:self.n1].contiguous(), increments)
+        else:                                                   # more ranks than sequences
+            Kzz = Kzx = Kxx = None
+        # one regular block per rank: [Kzx block transposed | Kxx-diag block], (per, T + 1), zero beyond the rank's sequences
+        blk = torch.zeros((self.per, T + 1), dtype=X.dtype, device=X.device)
+        if Kzx is not None:
+            blk[: self.n1 - self.n0, :T] = Kzx.T
+            blk[: self.n1 - self.n0, T] = Kxx
+        parts = [torch.empty_like(blk) for _ in range(self.world)] if self.rank == 0 else None
+        if blk.is_cuda and dist.get_backend() != "nccl":        # CPU collectives on GPU data: stage through the host (tests)
+            host = blk.cpu()
+            hp = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, gather_list=hp, dst=0)
+            if self.rank == 0:
+                for d_, s_ in zip(parts, hp):
+                    d_.copy_(s_)
+        else:
+            dist.gather(blk, gather_list=parts, dst=0)
+        if self.rank != 0:
+            return None
+        allb = torch.cat(parts, dim=0)[: self.n]
+        return Kzz, allb[:, :T].T.contiguous(), allb[:, T].contiguous()
+
+
 def owned_mask(n):
     """owned[r, c]: row r owns column c (the emission predicate PRED_CIRCULANT of csrc/seq_args.hpp with i = c, j = r)."""
     import numpy as np

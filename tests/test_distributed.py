@@ -105,3 +105,46 @@ def test_two_rank_gloo_sharded_gram(n, chunks):
         ret = mgr.dict()
         mp.spawn(_worker, args=(2, port, n, chunks, ret), nprocs=2, join=True)
         assert ret["err"] < 1e-12 and ret["sym"]
+
+
+def _covs_worker(rank, world, port, n, increments, ret):
+    import torch
+    from gpsig_amd import kernels
+    from oracle import sigkern_oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, d, M, T = 8, 2, 3, 5
+        rng = np.random.default_rng(1)
+        X = np.cumsum(0.3 * rng.standard_normal((n, L, d)), axis=1).reshape(n, L * d)
+        Z = rng.standard_normal((M * (M + 1) // 2, T, 2, d) if increments else (M * (M + 1) // 2, T, d))
+        kern = kernels.SignatureRBF(L * d, d, M, lengthscales=1.3)
+        ko = O.SignatureKernelOracle(L * d, d, M, base="rbf", lengthscales=1.3)
+
+        def evaluate(Zb, Xb, inc):          # stand-in for the HIP evaluation of one block (no CPU path in the product)
+            return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in ko.K_tens_n_seq_covs(Zb.numpy(), Xb.numpy(), increments=inc))
+
+        covs = parallel.ShardedCovs(kern, n, torch.device("cpu"), rank, world, evaluate=evaluate)
+        out = covs(torch.from_numpy(Z), torch.from_numpy(X), increments=increments)
+        if rank == 0:
+            want = ko.K_tens_n_seq_covs(Z, X, increments=increments)
+            ret["err"] = max(float(np.abs(g.numpy() - w).max()) for g, w in zip(out, want))
+            ret["shapes"] = [tuple(g.shape) for g in out]
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,increments", [(11, 2, False), (8, 2, True), (2, 3, False)])
+def test_gloo_sharded_covariances(n, world, increments):
+    """parallel.ShardedCovs: Kzx and the Kxx diagonal in contiguous blocks of sequences per rank, gathered on rank 0 (ragged
+    last block; more ranks than whole blocks)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_covs_worker, args=(world, port, n, increments, ret), nprocs=world, join=True)
+        assert ret["err"] == 0.0 and ret["shapes"] == [(5, 5), (5, n), (n,)]
