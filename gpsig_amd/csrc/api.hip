@@ -355,42 +355,85 @@ int lr_check(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr) {
     return GPSIG_OK;
 }
 
-// upload landmarks, whitening and sketches into one scratch block
+// FNV-1a over 64-bit words (a tail shorter than a word is folded in bytewise)
+static uint64_t lr_fnv(uint64_t h, const void* p, size_t n) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+    }
+    for (; i < n; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h;
+}
+
+// upload landmarks, whitening and sketches into one scratch block -- unless the block already holds exactly these (content hash):
+// the random objects of one evaluation go through several calls, and every upload is a host synchronisation
 int lr_upload(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, int d_eff, LrDev* D) {
     const int cc = lr->num_components;
+    uint64_t hsh = 0xcbf29ce484222325ull;
+    const int64_t dims[4] = {cc, d_eff, lr->rank_bound, lr->num_sketches};
+    hsh = lr_fnv(hsh, dims, sizeof(dims));
+    hsh = lr_fnv(hsh, lr->landmarks, sizeof(double) * size_t(cc) * d_eff);
+    hsh = lr_fnv(hsh, lr->whitening, sizeof(double) * size_t(cc) * cc);
+    for (int i = 0; i < lr->num_sketches; ++i) {
+        const gpsig_sketch& sk = lr->sketches[i];
+        const int64_t sd[4] = {sk.k1, sk.k2, sk.r, sk.nnz};
+        hsh = lr_fnv(hsh, sd, sizeof(sd));
+        hsh = lr_fnv(hsh, sk.colptr, sizeof(int32_t) * (size_t(sk.r) + 1));
+        hsh = lr_fnv(hsh, sk.i1, sizeof(int32_t) * size_t(sk.nnz));
+        hsh = lr_fnv(hsh, sk.i2, sizeof(int32_t) * size_t(sk.nnz));
+        hsh = lr_fnv(hsh, sk.val, sizeof(double) * size_t(sk.nnz));
+    }
+    if (hsh == 0) hsh = 1;
     size_t bytes = sizeof(double) * (size_t(cc) * d_eff + size_t(cc) * cc);
     for (int i = 0; i < lr->num_sketches; ++i)
         bytes += sizeof(int32_t) * (size_t(lr->sketches[i].r) + 1 + 2 * size_t(lr->sketches[i].nnz)) + sizeof(double) * size_t(lr->sketches[i].nnz) +
                  sizeof(LrEntry) * size_t(lr->sketches[i].nnz) + 96;
-    std::vector<unsigned char> h(bytes + 64);
     void* dbase;
-    CHK(ensure(c, B_LR0, h.size(), &dbase));
+    CHK(ensure(c, B_LR0, bytes + 64, &dbase));
+    const bool cached = c->lr_hash == hsh && c->lr_base == dbase && c->lr_offsets.size() == size_t(2 + 5 * lr->num_sketches);
+    std::vector<unsigned char> h(cached ? 0 : bytes + 64);
+    std::vector<size_t> offs;
     size_t o = 0;
-    auto put = [&](const void* src, size_t n) -> size_t {
-        o = (o + 7) / 8 * 8;
-        memcpy(h.data() + o, src, n);
-        size_t at = o;
-        o += n;
-        return at;
+    auto place = [&](const void* src, size_t n, size_t align = 8) -> unsigned char* {
+        size_t at;
+        if (cached) {
+            at = c->lr_offsets[offs.size()];
+        } else {
+            o = (o + align - 1) / align * align;
+            if (n) memcpy(h.data() + o, src, n);
+            at = o;
+            o += n;
+        }
+        offs.push_back(at);
+        return static_cast<unsigned char*>(dbase) + at;
     };
     D->c = cc; D->r = lr->rank_bound; D->nsk = lr->num_sketches;
-    unsigned char* db = static_cast<unsigned char*>(dbase);
-    D->S = reinterpret_cast<const double*>(db + put(lr->landmarks, sizeof(double) * size_t(cc) * d_eff));
-    D->Wh = reinterpret_cast<const double*>(db + put(lr->whitening, sizeof(double) * size_t(cc) * cc));
+    D->S = reinterpret_cast<const double*>(place(lr->landmarks, sizeof(double) * size_t(cc) * d_eff));
+    D->Wh = reinterpret_cast<const double*>(place(lr->whitening, sizeof(double) * size_t(cc) * cc));
     for (int i = 0; i < lr->num_sketches; ++i) {
         const gpsig_sketch& sk = lr->sketches[i];
-        D->colptr.push_back(reinterpret_cast<const int32_t*>(db + put(sk.colptr, sizeof(int32_t) * (size_t(sk.r) + 1))));
-        D->i1.push_back(reinterpret_cast<const int32_t*>(db + put(sk.i1, sizeof(int32_t) * size_t(sk.nnz))));
-        D->i2.push_back(reinterpret_cast<const int32_t*>(db + put(sk.i2, sizeof(int32_t) * size_t(sk.nnz))));
-        D->val.push_back(reinterpret_cast<const double*>(db + put(sk.val, sizeof(double) * size_t(sk.nnz))));
-        std::vector<LrEntry> packed(size_t(sk.nnz) + 1);
-        for (int64_t e = 0; e < sk.nnz; ++e) packed[size_t(e)] = LrEntry{sk.val[e], sk.i1[e], sk.i2[e]};
-        o = (o + 15) / 16 * 16;
-        D->ent.push_back(reinterpret_cast<const LrEntry*>(db + put(packed.data(), sizeof(LrEntry) * size_t(sk.nnz))));
+        D->colptr.push_back(reinterpret_cast<const int32_t*>(place(sk.colptr, sizeof(int32_t) * (size_t(sk.r) + 1))));
+        D->i1.push_back(reinterpret_cast<const int32_t*>(place(sk.i1, sizeof(int32_t) * size_t(sk.nnz))));
+        D->i2.push_back(reinterpret_cast<const int32_t*>(place(sk.i2, sizeof(int32_t) * size_t(sk.nnz))));
+        D->val.push_back(reinterpret_cast<const double*>(place(sk.val, sizeof(double) * size_t(sk.nnz))));
+        std::vector<LrEntry> packed;
+        if (!cached) {
+            packed.resize(size_t(sk.nnz) + 1);
+            for (int64_t e = 0; e < sk.nnz; ++e) packed[size_t(e)] = LrEntry{sk.val[e], sk.i1[e], sk.i2[e]};
+        }
+        D->ent.push_back(reinterpret_cast<const LrEntry*>(place(packed.data(), sizeof(LrEntry) * size_t(sk.nnz), 16)));
         D->k1.push_back(sk.k1); D->k2.push_back(sk.k2);
     }
-    HIPCHK(c, hipMemcpyAsync(dbase, h.data(), o, hipMemcpyHostToDevice, c->stream));
-    CHK(host_sync(c));
+    if (!cached) {
+        CHK(no_capture(c, "the low-rank objects changed and have to be uploaded"));
+        c->lr_hash = 0;
+        HIPCHK(c, hipMemcpyAsync(dbase, h.data(), o, hipMemcpyHostToDevice, c->stream));
+        CHK(host_sync(c));                       // h goes out of scope
+        c->lr_hash = hsh; c->lr_base = dbase; c->lr_offsets = offs;
+    }
     (void)p;
     return GPSIG_OK;
 }
@@ -418,8 +461,13 @@ int lr_level_offsets(gpsig_ctx* c, int M, int cc, int r, const int32_t** dev_off
     *F = off[M + 1];
     void* d;
     CHK(ensure(c, B_LR1, sizeof(int32_t) * off.size(), &d));
-    HIPCHK(c, hipMemcpyAsync(d, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice, c->stream));
-    CHK(host_sync(c));
+    if (!(c->lr_off_base == d && c->lr_off_key[0] == M && c->lr_off_key[1] == cc && c->lr_off_key[2] == r)) {     // (M, c, r) define them
+        CHK(no_capture(c, "the low-rank level offsets have to be uploaded"));
+        c->lr_off_base = nullptr;
+        HIPCHK(c, hipMemcpyAsync(d, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice, c->stream));
+        CHK(host_sync(c));
+        c->lr_off_base = d; c->lr_off_key[0] = M; c->lr_off_key[1] = cc; c->lr_off_key[2] = r;
+    }
     *dev_off = static_cast<const int32_t*>(d);
     return GPSIG_OK;
 }

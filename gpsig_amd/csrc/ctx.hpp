@@ -86,6 +86,13 @@ struct gpsig_ctx {
     std::vector<TaskSlot> task_slots;      // device-resident task lists, least recently used one replaced (task_list())
     uint64_t task_clock = 0;
     std::vector<double> last_weights;      // what B_W currently holds
+    // low-rank mode: what B_LR0 / B_LR1 currently hold (keyed by content: the random objects of an evaluation are handed to several
+    // calls -- tensor features, sequence features, products -- and every upload was a host synchronisation)
+    uint64_t lr_hash = 0;                  // 0: nothing uploaded
+    void* lr_base = nullptr;               // the B_LR0 block the offsets below refer to
+    std::vector<size_t> lr_offsets;        // byte offsets of the uploaded arrays inside it, in lr_upload's order
+    int64_t lr_off_key[3] = {-1, -1, -1};  // (M, c, r) of the level offsets in B_LR1
+    void* lr_off_base = nullptr;
     // timing of the pair-recursion launches
     std::vector<hipEvent_t> ev;     // pairs (start, stop)
     size_t ev_used = 0;
