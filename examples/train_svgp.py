@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=200)
     ap.add_argument("--num-inducing", type=int, default=64)
     ap.add_argument("--minibatch", type=int, default=64)
+    ap.add_argument("--graph", action="store_true", help="record the training step as one HIP graph (SVGPModule.fit(graph=True))")
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     classes, length, levels = 3, 40, 4
@@ -49,7 +50,8 @@ def main():
     X = torch.tensor(Xtr.reshape(len(Xtr), -1), device=dev)
     Y = torch.tensor(ytr[:, None].astype(np.float64), device=dev)
     trace = model.fit(X, Y, iterations=args.iterations, lr=2e-2, minibatch_size=args.minibatch,
-                      callback=lambda it, elbo: print(f"iteration {it:4d}  ELBO {elbo:10.2f}") if it % 25 == 0 else None)
+                      callback=lambda it, elbo: print(f"iteration {it:4d}  ELBO {elbo:10.2f}") if it % 25 == 0 else None,
+                      graph=args.graph)
     with torch.no_grad():
         p, _ = model.predict_y(torch.tensor(Xte.reshape(len(Xte), -1), device=dev))
     acc = float((p.argmax(dim=1).cpu().numpy() == yte).mean())
