@@ -56,9 +56,8 @@ def draw_sketch(rng, k1, k2, rank_bound, sparsity):
     total = D * r
     nnz = int(rng.binomial(total, min(1.0, 1.0 / s)))
     pos = rng.choice(total, size=nnz, replace=False, shuffle=False) if nnz else np.zeros(0, dtype=np.int64)
-    row, col = pos // r, pos % r
-    order = np.lexsort((row, col))                           # by output column, rows ascending within a column
-    row, col = row[order], col[order]
+    key = np.sort((pos % r) * D + pos // r)                  # by output column, rows ascending within a column (one sort of a combined
+    col, row = key // D, key % D                             # key: np.lexsort took more than half of a draw)
     val = rng.standard_normal(nnz) * np.sqrt(s / r)
     colptr = np.concatenate(([0], np.cumsum(np.bincount(col, minlength=r)))) if nnz else np.zeros(r + 1, dtype=np.int64)
     return Sketch(k1, k2, r, colptr, row % k1, row // k1, val)
