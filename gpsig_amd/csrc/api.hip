@@ -1507,6 +1507,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "lr_gemm")) c->lr_gemm = value;
     else if (!strcmp(name, "lr_fused")) c->lr_fused = value;
     else if (!strcmp(name, "lr_fused_variant")) c->lr_fused_variant = value;
+    else if (!strcmp(name, "lr_fused_pad")) c->lr_fused_pad = value > 0 ? value : 1;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);
     return GPSIG_OK;
 }
@@ -1828,7 +1829,7 @@ int gpsig_lr_seq_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowra
     double p0, p1;
     base_p(p, &p0, &p1);
     // One kernel, one workgroup per sequence, intermediates in LDS (lr_fused_kernel.hpp) when a sequence's three arrays fit
-    const size_t fused_lds = lr_fused_lds_bytes(cc, r, d_eff, L);
+    const size_t fused_lds = lr_fused_lds_bytes(cc, r, d_eff, L, c->lr_fused_pad);
     if (c->lr_fused != 0 && fused_lds <= LR_FUSED_MAX_LDS && M - 1 <= LR_FUSED_MAX_SKETCHES) {
         if (N <= 0) return finish(c);
         LrFusedArgs A;
@@ -1837,10 +1838,13 @@ int gpsig_lr_seq_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowra
         for (int i = 0; i < LR_FUSED_MAX_SKETCHES; ++i) A.sk[i] = LrFusedSketch{nullptr, nullptr};
         for (int i = 0; i < D.nsk; ++i) A.sk[i] = LrFusedSketch{D.colptr[i], D.ent[i]};
         A.Phi = phi; A.F = F;
-        A.lp = (L + 63) / 64 * 64 + 1;
+        A.lp = lr_fused_stride(L, c->lr_fused_pad);
         A.rows_b = cc > r ? cc : r;
         if (d_eff > A.rows_b) A.rows_b = d_eff;
-        const int rc = lr_fused_launch(c->stream, A, unsigned(N < (int64_t(1) << 20) ? N : (int64_t(1) << 20)), c->lr_fused_variant);
+        const unsigned grid = unsigned(N < (int64_t(1) << 20) ? N : (int64_t(1) << 20));
+        // two arrays in LDS instead of three where a wavefront can hold its output columns in registers (lr_fused2): a third workgroup per CU
+        const int rc = (c->lr_fused == 1 && lr_fused2_ok(cc, r, L)) ? lr_fused2_launch(c->stream, A, grid)
+                                                                    : lr_fused_launch(c->stream, A, grid, c->lr_fused_variant);
         if (rc != 0) return fail(c, GPSIG_ERR_HIP, "fused low-rank feature kernel: %s", hipGetErrorString(hipError_t(rc)));
         CHK(out_done(c, Phi, dPhi, sizeof(double) * size_t(N) * F));
         return finish(c);

@@ -77,6 +77,7 @@ struct gpsig_ctx {
     int tens_tile = 1;            // Kzz in 16 x 16 tiles with the tensors staged in LDS (tens_gram_tile_kernel); 0: one gathering thread per entry
     int diag_own = 1;             // diagonal pass: every pair group sweeps its own sequence (SeqGramArgs::diag_own); 0: round-1 form, for A/B runs
     int lr_gemm = 1;              // low-rank Gram products: 1 = 128 x 128 tiles staged through LDS, 0 = fragments straight from L2 (round 1)
+    int lr_fused_pad = 1;         // row stride of its LDS arrays beyond the time steps rounded up to 64, in doubles (A/B runs)
     int lr_fused_variant = 0;     // its workgroup size / unrolling (lr_fused_inst.hip), for A/B runs
     int lr_fused = 1;             // low-rank sequence features: 1 = the fused kernel where a sequence's arrays fit LDS, 0 = one kernel per op
     int tvs_zreg = -1;            // tensor-lane gradient: components in registers (1) or LDS (0); -1 = planner's choice

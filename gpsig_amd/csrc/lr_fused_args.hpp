@@ -28,8 +28,9 @@ struct LrFusedArgs {
     int rows_b;             // rows of the two work arrays: max(c, r, d_eff)
 };
 
-inline size_t lr_fused_lds_bytes(int c, int r, int d_eff, int L) {
-    const int lp = (L + 63) / 64 * 64 + 1;
+inline int lr_fused_stride(int L, int pad) { return (L + 63) / 64 * 64 + pad; }
+inline size_t lr_fused_lds_bytes(int c, int r, int d_eff, int L, int pad = 1) {
+    const int lp = lr_fused_stride(L, pad);
     int kb = c > r ? c : r;
     if (d_eff > kb) kb = d_eff;
     return sizeof(double) * size_t(lp) * (size_t(c) + 2 * size_t(kb));
@@ -51,6 +52,15 @@ inline size_t lr_tens_fused_lds_bytes(int c, int r, int d_eff, int lt, int E) {
     return sizeof(double) * (rows * (size_t(d_eff) + 2 * size_t(c)) + size_t(lt) * c + 2 * w);
 }
 int lr_tens_fused_launch(hipStream_t stream, const LrTensFusedArgs& A);
+
+// two-array form (lr_seq_features_fused2_kernel): usable for L <= 64 and at most 8 output columns per wavefront of the 512-thread workgroup
+inline bool lr_fused2_ok(int c, int r, int L) { return L <= 64 && c <= 64 && r <= 64; }
+inline size_t lr_fused2_lds_bytes(int c, int r, int d_eff, int L, int pad = 1) {
+    int kb = c > r ? c : r;
+    if (d_eff > kb) kb = d_eff;
+    return sizeof(double) * size_t(lr_fused_stride(L, pad)) * 2 * size_t(kb);
+}
+int lr_fused2_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid);
 
 // lr_fused_inst.hip: launches the kernel on `stream` with `grid` workgroups; returns the hipError_t of the launch
 int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, int variant);

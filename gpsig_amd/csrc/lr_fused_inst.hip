@@ -19,7 +19,7 @@ int launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, size_t lds) 
 }  // namespace
 
 int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, int variant) {
-    const size_t lds = lr_fused_lds_bytes(A.c, A.r, A.P.d_eff(), A.L);
+    const size_t lds = sizeof(double) * size_t(A.lp) * (size_t(A.c) + 2 * size_t(A.rows_b));
     // BASELINE configs[2]'s sequences (L=50, c=r=50, 'sqrt'), same box: 256 threads / 4 entries per batch 4.32 ms, 256 / 8 3.84,
     // 512 / 4 2.71, 512 / 8 2.57, 1024 / 4 3.09, 1024 / 8 4.01 (profiles/r02_lowrank.txt)
     switch (variant) {
@@ -28,6 +28,19 @@ int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, int
         case 3: return launch<512, 4>(stream, A, grid, lds);
         default: return launch<512, 8>(stream, A, grid, lds);
     }
+}
+
+int lr_fused2_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid) {
+    const size_t lds = sizeof(double) * size_t(A.lp) * 2 * size_t(A.rows_b);
+    static size_t allowed = 0;
+    auto kern = lr_seq_features_fused2_kernel<512, 8>;
+    if (lds > allowed) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return int(e);
+        allowed = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, A);
+    return int(hipGetLastError());
 }
 
 int lr_tens_fused_launch(hipStream_t stream, const LrTensFusedArgs& A) {

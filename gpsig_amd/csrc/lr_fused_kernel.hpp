@@ -162,6 +162,138 @@ __global__ __launch_bounds__(THREADS) void lr_seq_features_fused_kernel(LrFusedA
     }
 }
 
+// ---- the same with TWO arrays in LDS instead of three --------------------------------------------------------------------
+// For sequences of at most 64 time steps and at most LR_FUSED2_COLS output columns per wavefront, a wavefront keeps the columns it
+// produces in REGISTERS until every wavefront of the workgroup has finished reading the array they replace, and writes them in
+// place after a barrier: no third buffer (the output of a sketch / of the whitening product), 52 KB instead of 78 KB of LDS at
+// BASELINE configs[2]'s sequences with the reference's default ranks -- three workgroups per CU instead of two, i.e. half as many
+// wavefronts again to hide the scalar-load latency of the sketch entries and the phases in which one wavefront works.
+//   W holds: the scaled observations (transposed) -> kxs -> E_2 (running sums of U) -> P_2 -> E_3 -> ...;  U: feat -> U.
+constexpr int LR_FUSED2_COLS = 8;
+template <int THREADS, int UNROLL>
+__global__ __launch_bounds__(THREADS) void lr_seq_features_fused2_kernel(LrFusedArgs A) {
+    extern __shared__ double lr_lds[];
+    const int lp = A.lp, c = A.c, r = A.r, L = A.L;
+    double* const U = lr_lds;                               // [max(c, d_eff)][lp]
+    double* const W = U + size_t(A.rows_b) * lp;            // [rows_b][lp]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NW = THREADS / 64;
+    const int d_eff = A.P.d_eff();
+    const int l = A.difference ? L - 1 : L;
+    const int t = lane, tt = t < l ? t : 0;
+
+    for (int64_t n = blockIdx.x; n < A.N; n += gridDim.x) {
+        const double* Xn = A.X + n * int64_t(L) * A.P.d_in;
+        double* phi = A.Phi + n * int64_t(A.F);
+        // ---- scaled observations, U[fe][t]
+        for (int q = threadIdx.x; q < L * d_eff; q += THREADS) {
+            const int tq = q / d_eff, fe = q - tq * d_eff;
+            U[fe * lp + tq] = scaled_point<double>(Xn, L, tq, fe, A.P);
+        }
+        __syncthreads();
+        // ---- kxs, W[i][t]
+        if (t < L) {
+            double xs = 0.0;
+            for (int fe = 0; fe < d_eff; ++fe) { const double x = U[fe * lp + t]; xs = fma(x, x, xs); }
+            for (int i = wave; i < c; i += NW) {
+                const lr_const_ptr<double> Si = lr_as_const(A.S) + size_t(i) * d_eff;
+                double ip = 0.0, ss = 0.0;
+                for (int fe = 0; fe < d_eff; ++fe) {
+                    const double y = Si[fe];
+                    ip = fma(U[fe * lp + t], y, ip);
+                    ss = fma(y, y, ss);
+                }
+                W[i * lp + t] = base_eval<double>(A.kind, ip, xs, ss, A.p0, A.p1);
+            }
+        }
+        __syncthreads();
+        // ---- whitening into U (the observations are no longer needed): feat[j][t] = sum_i W[i][t] * Wh[i][j]
+        {
+            const lr_const_ptr<double> Wh = lr_as_const(A.Wh);
+            const int tr = t < L ? t : 0;
+#pragma unroll
+            for (int k = 0; k < LR_FUSED2_COLS; ++k) {
+                const int j = wave + k * NW;
+                if (j < c) {
+                    double acc = 0.0;
+#pragma unroll 4
+                    for (int i = 0; i < c; ++i) acc = fma(W[i * lp + tr], Wh[size_t(i) * c + j], acc);
+                    if (t < L) U[j * lp + t] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        // time difference in place (signature_algs.py:180): a column belongs to one wavefront, whose lanes all read before any writes
+#pragma unroll
+        for (int k = 0; k < LR_FUSED2_COLS; ++k) {
+            const int j = wave + k * NW;
+            if (j < c && A.difference) {
+                const double f0 = U[j * lp + tt], f1 = U[j * lp + tt + 1];
+                if (t < l) U[j * lp + t] = f1 - f0;
+            }
+        }
+        __syncthreads();
+        // ---- level 1 and the exclusive running sums for level 2 (thread = column), W = E_2
+        if (threadIdx.x == 0) phi[0] = 1.0;
+        for (int j = threadIdx.x; j < c; j += THREADS) {
+            double run = 0.0;
+            const double* u = U + size_t(j) * lp;
+            double* e = W + size_t(j) * lp;
+            const bool more = A.M >= 2;
+#pragma unroll 8
+            for (int q = 0; q < l; ++q) {
+                const double v = u[q];
+                if (more) e[q] = run;
+                run += v;
+            }
+            phi[1 + j] = run;                                                                   // signature_algs.py:182
+        }
+        __syncthreads();
+        for (int lev = 2; lev <= A.M; ++lev) {
+            const lr_const_ptr<int32_t> colptr = lr_as_const(A.sk[lev - 2].colptr);
+            const lr_const_ptr<LrEntry> ent = lr_as_const(A.sk[lev - 2].ent);
+            double out[LR_FUSED2_COLS];
+#pragma unroll
+            for (int k = 0; k < LR_FUSED2_COLS; ++k) {
+                const int j = wave + k * NW;
+                double acc = 0.0;
+                if (j < r) {
+                    const int e0 = colptr[j], e1 = colptr[j + 1];
+#pragma unroll UNROLL
+                    for (int e = e0; e < e1; ++e) {
+                        const double val = ent[e].val;
+                        const int i1 = ent[e].i1, i2 = ent[e].i2;
+                        acc = fma(val * U[i1 * lp + tt], W[i2 * lp + tt], acc);
+                    }
+                }
+                out[k] = acc;
+            }
+            __syncthreads();                                 // every wavefront has read E: P takes its place
+#pragma unroll
+            for (int k = 0; k < LR_FUSED2_COLS; ++k) {
+                const int j = wave + k * NW;
+                if (j < r && t < l) W[j * lp + t] = out[k];
+            }
+            __syncthreads();
+            const int off = 1 + c + (lev - 2) * r;
+            const bool more = lev < A.M;
+            for (int j = threadIdx.x; j < r; j += THREADS) {
+                double run = 0.0;
+                double* e = W + size_t(j) * lp;
+#pragma unroll 8
+                for (int q = 0; q < l; ++q) {
+                    const double v = e[q];
+                    if (more) e[q] = run;                                                       // signature_algs.py:186
+                    run += v;
+                }
+                phi[off + j] = run;                                                             // :191
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- inducing tensors ---------------------------------------------------------------------------------------------------
 // One workgroup per tensor t.  Rows (k, e) of the tensor's lt * E components: scaled (kernels.py:367-398), kappa against the
 // landmarks (low_rank_calculations.py:59), whitened (:60), differenced over e for incremental tensors (kernels.py:304); then

@@ -117,7 +117,9 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "lr_gemm"     low-rank Gram products on the fp64 matrix cores: 1 (default) 128 x 128 tiles with k-slabs staged through LDS,
  *                 0 operand fragments read straight from L2 (round 1)
  *   "lr_fused"    low-rank sequence features (gpsig_lr_seq_features): 1 (default) one fused kernel, a workgroup per sequence with
- *                 the (width, length) intermediates in LDS, wherever they fit; 0 one elementwise kernel per reference op */
+ *                 the (width, length) intermediates in LDS, wherever they fit -- two arrays where a wavefront can hold its output
+ *                 columns in registers (at most 64 time steps, components and rank bound), three otherwise; 2 always the three-array
+ *                 form; 0 one elementwise kernel per reference op */
 int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
 /* HIP-event timing of the dominant kernel (the pair recursion) launched by the calls since the last
  * reset, measured on the ctx stream: total milliseconds and number of launches (the first 4096 timed

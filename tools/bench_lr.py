@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--sparsity", default="sqrt", choices=["sqrt", "log", "lin"])
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--pad", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--verify", action="store_true")
     args = ap.parse_args()
@@ -53,6 +54,7 @@ def main():
     ctx = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
     ctx.set_option("lr_fused", args.fused)
     ctx.set_option("lr_fused_variant", args.variant)
+    ctx.set_option("lr_fused_pad", args.pad)
     st = kern.draw_low_rank(X=X, Z=Z)
 
     def timed(fn, steps=args.steps):
