@@ -1507,7 +1507,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "lr_gemm")) c->lr_gemm = value;
     else if (!strcmp(name, "lr_fused")) c->lr_fused = value;
     else if (!strcmp(name, "lr_fused_variant")) c->lr_fused_variant = value;
-    else if (!strcmp(name, "lr_fused_pad")) c->lr_fused_pad = value > 0 ? value : 1;
+    else if (!strcmp(name, "lr_fused_pad")) c->lr_fused_pad = value >= 0 ? value : 1;
     else return fail(c, GPSIG_ERR_INVALID, "unknown option '%s'", name);
     return GPSIG_OK;
 }
