@@ -542,12 +542,24 @@ class SignatureKernel:
             parts.append(out)
         S = np.ascontiguousarray(np.concatenate(parts, axis=0))
         jd = np.ascontiguousarray(JITTER * self.rng.random(c))                    # low_rank_calculations.py:52
+        sk = _lr.draw_level_sketches(self.rng, self.num_levels, c, int(self.rank_bound), self.sparsity)
+        return self.low_rank_state(S, jd, sk)
+
+    def low_rank_state(self, landmarks, jitter_diag, sketches):
+        """The LowRankState of GIVEN random objects: landmarks (c, d') -- scaled points --, the jitter draw (c,) and one sketch
+        per level >= 2 (objects with k1, k2, r, colptr, i1, i2, val); the whitening is computed here, on the device
+        (low_rank_calculations.py:50-57, :60: landmark Gram + jitter, rocSOLVER dsyevd, U / sqrt(S + jitter))."""
+        S = np.ascontiguousarray(landmarks, dtype=np.float64)
+        jd = np.ascontiguousarray(jitter_diag, dtype=np.float64)
+        c, d_eff = S.shape
+        L_ = _launch_f64()
+        p = self._params(L_.keep, _lib.F64)
         Wh, ev = np.empty((c, c)), np.empty(c)
         dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))                    # noqa: E731
-        # landmark Gram + jitter, eigendecomposition (rocSOLVER dsyevd) and U / sqrt(S + jitter) on the device (:50-57, :60)
         L_.ctx.call("gpsig_lr_whitening", p, dp(S), c, d_eff, dp(jd), dp(Wh), dp(ev))
-        sk = _lr.draw_level_sketches(self.rng, self.num_levels, c, int(self.rank_bound), self.sparsity)
-        return LowRankState(S, Wh, sk, self.rank_bound, jitter_diag=jd, eigenvalues=ev)
+        sk = [s_ if isinstance(s_, _lr.Sketch) else _lr.Sketch(s_.k1, s_.k2, s_.r, s_.colptr, s_.i1, s_.i2, s_.val) for s_ in sketches]
+        rb = sk[0].r if sk else int(self.rank_bound)
+        return LowRankState(S, Wh, sk, rb, jitter_diag=jd, eigenvalues=ev)
 
     def _lr_features(self, L_, p, lr, A, tensors=False, increments=False):
         F = 1 + lr.num_components + (self.num_levels - 1) * lr.rank_bound

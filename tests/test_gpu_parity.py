@@ -1082,6 +1082,26 @@ def test_low_rank_gram_products_in_lds_tiles(K):
             assert np.abs(g - w).max() <= 1e-4 * np.abs(w).max()
 
 
+def test_low_rank_golden_fixtures(K, golden_lowrank):
+    """The committed low-rank fixtures (tests/golden/lowrank.npz: inputs, random objects, oracle outputs) through the C ABI: the
+    whitening is computed on the device from the committed landmarks and jitter draw (kern.low_rank_state), the features by the
+    fused kernels, the products on the matrix cores."""
+    cases, arr, sketches = golden_lowrank
+    for c in cases:
+        n = c["name"]
+        kern = make_kernel(K, dict(c["kern"], low_rank=True, num_components=c["num_components"], rank_bound=c["rank_bound"], sparsity=c["sparsity"]))
+        st = kern.low_rank_state(arr[f"{n}/landmarks"], arr[f"{n}/jitter_diag"], sketches(n, c["kern"]["num_levels"]))
+        X, X2, Z, incr = arr[f"{n}/X"], arr[f"{n}/X2"], arr[f"{n}/Z"], c["increments"]
+        got = dict(K=kern.K(X, lr_state=st), Kx=kern.K(X, X2, return_levels=True, lr_state=st),
+                   Kzx=kern.K_tens_vs_seq(Z, X, increments=incr, lr_state=st), Kzz=kern.K_tens(Z, increments=incr, lr_state=st))
+        if "Kdiag" in c["outputs"]:
+            got["Kdiag"] = kern.Kdiag(X, lr_state=st)
+        tol = 1e-7 if c["kern"]["base"] == "rbf" else 1e-5         # comment above LR_TOLS
+        for k in c["outputs"]:
+            want = arr[f"{n}/out/{k}"]
+            assert np.abs(np.asarray(got[k]) - want).max() <= tol * np.abs(want).max(), (n, k, np.abs(np.asarray(got[k]) - want).max() / np.abs(want).max())
+
+
 def test_low_rank_exact_limit_and_convergence(K):
     rng = np.random.default_rng(43)
     N, L, d = 8, 5, 2

@@ -241,3 +241,22 @@ def test_c_restatement_equals_numpy_oracle(base, difference):
         got, want = cref.tens_vs_seq_levels(Z, X, M, base, difference), ko._K_tens_vs_seq(Z, X, increments=incr)
         assert got.shape == want.shape and np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
     assert cref.threads() >= 1
+
+
+def test_committed_low_rank_fixtures_match_oracle(golden_lowrank):
+    """tests/golden/lowrank.npz is what the low-rank restatement gives for the committed random objects (landmarks, jitter draw,
+    projections): a value pin of signature_algs.py:162-222 / low_rank_calculations.py:26-193 as restated, next to the statistical
+    checks above."""
+    cases, arr, sketches = golden_lowrank
+    assert len(cases) >= 5
+    for c in cases:
+        n = c["name"]
+        kw = {k: (np.asarray(v) if isinstance(v, list) else v) for k, v in c["kern"].items()}
+        lo = O.LowRankOracle(O.SignatureKernelOracle(**kw), arr[f"{n}/landmarks"], arr[f"{n}/jitter_diag"], sketches(n, kw["num_levels"]))
+        X, X2, Z, incr = arr[f"{n}/X"], arr[f"{n}/X2"], arr[f"{n}/Z"], c["increments"]
+        got = dict(K=lo.K(X), Kx=lo.K(X, X2, return_levels=True), Kzx=lo.K_tens_vs_seq(Z, X, increments=incr), Kzz=lo.K_tens(Z, increments=incr))
+        if "Kdiag" in c["outputs"]:
+            got["Kdiag"] = lo.Kdiag(X)
+        for k in c["outputs"]:
+            want = arr[f"{n}/out/{k}"]
+            assert np.abs(got[k] - want).max() <= 1e-11 * np.abs(want).max(), (n, k)
