@@ -56,6 +56,8 @@ SeqLaunchFn seq_lookup_ptdrbf_ex_g64_d4(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g64_d8(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g64_d16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptd_g16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptd_spectral_g16(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptd_spectral_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptd_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptn_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptn_g64(int, int, int, int, bool);
@@ -123,6 +125,7 @@ namespace {
 #define X_CFG(G_, C_, D_, MM_, EX_) {G_, C_, D_, MM_, EX_},
 const SeqConfig SEQ_TABLE[] = {GPSIG_SEQ_CONFIGS_ALL(X_CFG)};
 const SeqConfig SEQ_TABLE_GENERIC[] = {GPSIG_SEQ_CONFIGS_GENERIC(X_CFG)};
+const SeqConfig SEQ_TABLE_SPECTRAL[] = {GPSIG_SEQ_CONFIGS_SPECTRAL(X_CFG)};
 #undef X_CFG
 #define X_HO(G_, C_, D_, MM_, OM_) {G_, C_, D_, MM_, OM_},
 const SeqHOConfig SEQ_HO_TABLE[] = {GPSIG_SEQ_HO_ALL(X_HO)};
@@ -134,6 +137,7 @@ const SeqConfig SEQ_TABLE_F32[] = {GPSIG_SEQ_CONFIGS_F32_ALL(X_CFG2)};
 constexpr int N_SEQ_TABLE_F32 = int(sizeof(SEQ_TABLE_F32) / sizeof(SEQ_TABLE_F32[0]));
 constexpr int N_SEQ_TABLE = int(sizeof(SEQ_TABLE) / sizeof(SEQ_TABLE[0]));
 constexpr int N_SEQ_TABLE_GENERIC = int(sizeof(SEQ_TABLE_GENERIC) / sizeof(SEQ_TABLE_GENERIC[0]));
+constexpr int N_SEQ_TABLE_SPECTRAL = int(sizeof(SEQ_TABLE_SPECTRAL) / sizeof(SEQ_TABLE_SPECTRAL[0]));
 
 // float64, differences, the RBF kernel at compile time.  These instances use the table-driven exp on prescaled records
 // (SEQ_FAST_RBF in seq_gram_kernel.hpp): whoever launches one prepares the records with the prescale and the norm column.
@@ -487,13 +491,26 @@ struct SeqPlanned {
 
 // pairs_hint: how many pairs the launch this plan is for will evaluate (0: unknown / small)
 static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out, int64_t pairs_hint = 0) {
-    if (p->base_kernel == GPSIG_BASE_SPECTRAL)      // takes the points, not inner products: one-pair-per-thread kernel only
-        return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel is built for float64 only");
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
     out->rbf_prescaled = false;
     out->prescale = 1.0;
     out->pk2 = false;
     out->ny = 1; out->waves = 1;
+    if (p->base_kernel == GPSIG_BASE_SPECTRAL) {
+        // takes the points, not inner products: wavefront kernels with this family at compile time (seq_step_spectral) for float64,
+        // first order, with differences, d <= 16; everything else through the one-pair-per-thread kernel (the callers' fallback)
+        int k = -1;
+        if (sizeof(TT) == 8 && c->spectral_wave != 0 && g0.mode == MODE_PT_DIFF && !(p->order > 1 && p->num_levels > 1))
+            k = seq_select(SEQ_TABLE_SPECTRAL, N_SEQ_TABLE_SPECTRAL, g0.rows, d_eff, p->num_levels, false);
+        if (k < 0) return fail(c, GPSIG_ERR_UNSUPPORTED, "the spectral base kernel: no wavefront kernel for this shape / dtype / order");
+        out->cfg = SEQ_TABLE_SPECTRAL[k];
+        out->mode = g0.mode;
+        out->d_eff = d_eff;
+        out->fn = out->cfg.G == 16 ? seq_lookup_ptd_spectral_g16(out->cfg.G, out->cfg.C, out->cfg.D, out->cfg.MMAX, false)
+                                   : seq_lookup_ptd_spectral_g64(out->cfg.G, out->cfg.C, out->cfg.D, out->cfg.MMAX, false);
+        if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "spectral seq-gram kernel shape missing from this build");
+        return GPSIG_OK;
+    }
     if (p->order > 1 && p->num_levels > 1) {            // higher-order algorithm (signature_algs.py:37-74)
         int k = seq_select_ho(SEQ_HO_TABLE, N_SEQ_HO_TABLE, g0.rows, d_eff, p->num_levels, p->order);
         if (k < 0)
@@ -653,6 +670,7 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     A.slot_elems = r.gx.rec_elems;
     A.kind = p->base_kernel;
     base_p(p, &A.p0, &A.p1);
+    if (p->base_kernel == GPSIG_BASE_SPECTRAL) CHK(spectral_table(c, p, &A.spec));
     A.out = r.out; A.si = r.si; A.sj = r.sj; A.sm = r.sm;
     A.ax = r.ax; A.by = r.by; A.jitter_diag = r.jitter_diag;
     A.sum_levels = r.sum_levels; A.pred = diag_own ? int(PRED_DIAG_OWN) : r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds; A.compact = r.compact; A.keep_reset = c->keep_reset;
@@ -1503,6 +1521,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else if (!strcmp(name, "diag_own")) c->diag_own = value;
+    else if (!strcmp(name, "spectral_wave")) c->spectral_wave = value;
     else if (!strcmp(name, "tens_tile")) c->tens_tile = value;
     else if (!strcmp(name, "lr_gemm")) c->lr_gemm = value;
     else if (!strcmp(name, "lr_fused")) c->lr_fused = value;

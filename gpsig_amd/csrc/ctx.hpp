@@ -75,6 +75,7 @@ struct gpsig_ctx {
     int tvs_tile = -1;            // Kzx tile kernel (tvs_tile_kernel.hpp): -1 where it is built, 0 never, 1 also below 32 tensors
     int tvs_tile_nw = 0;          // its waves per workgroup: 0 = planner's choice
     int tens_tile = 1;            // Kzz in 16 x 16 tiles with the tensors staged in LDS (tens_gram_tile_kernel); 0: one gathering thread per entry
+    int spectral_wave = 1;        // SignatureSpectral sequence kernels: 1 = wavefront kernels where built, 0 = one pair per thread (round 1)
     int diag_own = 1;             // diagonal pass: every pair group sweeps its own sequence (SeqGramArgs::diag_own); 0: round-1 form, for A/B runs
     int lr_gemm = 1;              // low-rank Gram products: 1 = 128 x 128 tiles staged through LDS, 0 = fragments straight from L2 (round 1)
     int lr_fused_pad = 1;         // row stride of its LDS arrays beyond the time steps rounded up to 64, in doubles (A/B runs)

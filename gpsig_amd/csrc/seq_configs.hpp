@@ -42,6 +42,16 @@ struct SeqConfig {
     X(64, 1, 16, 8, false) X(64, 2, 16, 8, false) X(64, 4, 16, 8, false) \
     X(64, 1, 32, 8, false) X(64, 2, 32, 8, false)
 #define GPSIG_SEQ_CONFIGS_GENERIC(X) GPSIG_SEQ_CONFIGS_G16(X) GPSIG_SEQ_CONFIGS_G64(X)
+// SignatureSpectral (float64, MODE_PT_DIFF, first order; compile-time family: seq_step_spectral): run-time num_levels, d <= 16
+#define GPSIG_SEQ_CONFIGS_SPECTRAL_G16(X) \
+    X(16, 1, 4, 8, false) X(16, 2, 4, 8, false) X(16, 4, 4, 8, false) X(16, 8, 4, 8, false) \
+    X(16, 1, 8, 8, false) X(16, 2, 8, 8, false) X(16, 4, 8, 8, false) X(16, 8, 8, 8, false) \
+    X(16, 1, 16, 8, false) X(16, 2, 16, 8, false) X(16, 4, 16, 8, false)
+#define GPSIG_SEQ_CONFIGS_SPECTRAL_G64(X) \
+    X(64, 1, 4, 8, false) X(64, 2, 4, 8, false) X(64, 4, 4, 8, false) X(64, 8, 4, 8, false) \
+    X(64, 1, 8, 8, false) X(64, 2, 8, 8, false) X(64, 4, 8, 8, false) X(64, 8, 8, 8, false) \
+    X(64, 1, 16, 8, false) X(64, 2, 16, 8, false) X(64, 4, 16, 8, false)
+#define GPSIG_SEQ_CONFIGS_SPECTRAL(X) GPSIG_SEQ_CONFIGS_SPECTRAL_G16(X) GPSIG_SEQ_CONFIGS_SPECTRAL_G64(X)
 // float32 halves the register cost of a lane's columns: the widest shapes exist for it only; the exact one is the
 // shape of BASELINE.json configs[4] (L=128, d=16, num_levels=6)
 #define GPSIG_SEQ_CONFIGS_F32_EXACT(X) X(16, 8, 16, 6, true) X(16, 4, 8, 5, true) \

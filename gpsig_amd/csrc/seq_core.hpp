@@ -537,6 +537,22 @@ GPSIG_HD void seq_step_rbf_prescaled(SeqLane<double, C, D, MMAX, MODE>& L, const
     seq_recursion(L, nbr, dm, M);
 }
 
+// First-order step for SignatureSpectral's state-space kernel (spectral_eval above; gpsig/kernels.py:921-942), point modes: the kernel
+// takes the two points themselves, which a lane has -- its C columns of y in registers, the x row of the step -- so the wavefront
+// kernel carries it as a compile-time family of its own (KIND == BASE_SPECTRAL instances: no branch in anyone else's step).
+// tab: alpha[Q], omega[Q][SPECTRAL_STRIDE], gamma[Q][SPECTRAL_STRIDE], zero beyond the features (the padded columns of x and y are zero too).
+template <typename T, int C, int D, int MMAX, int MODE, class Nbr>
+GPSIG_HD void seq_step_spectral(SeqLane<T, C, D, MMAX, MODE>& L, const Nbr& nbr, const T (&xr)[D], const double* tab, int Q, int family,
+                                int M, bool dummy, int rlo, int rhi) {
+    static_assert(MODE != MODE_INC, "point modes only");
+    T knew[C], dm[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r)
+        knew[r] = spectral_eval<T>(tab, Q, family, D, [&](int f) { return xr[f]; }, [&](int f) { return L.y[r][f]; });
+    seq_point_increments<T, C, MODE>(L, nbr, knew, dummy, rlo, rhi, dm);
+    seq_recursion(L, nbr, dm, M);
+}
+
 // Per-lane position in the stream of x-side record rows, event driven: between events a step costs one add on the
 // row offset and one decrement.  Events (each `period` = R1 steps apart once the lane has started): the lane's start,
 // every pair boundary (row 0 of the next x: the pair that just ended is emitted, accumulators are cleared), and the

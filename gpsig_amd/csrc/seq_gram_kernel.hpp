@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
         if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
         if constexpr (FAST_RBF) seq_step_rbf_prescaled(L, DevNbr{L}, xr, hx, etab, M, dummy, rlo, rhi);
+        else if constexpr (KIND == BASE_SPECTRAL && OMAX == 0 && MODE != MODE_INC) seq_step_spectral(L, DevNbr{L}, xr, A.spec, int(A.p0), int(A.p1), M, dummy, rlo, rhi);
         else seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, KIND >= 0 ? KIND : A.kind, p0, p1);
         ctl.end_step();
     };

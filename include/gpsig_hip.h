@@ -112,6 +112,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "tvs_tile_nw" its waves per workgroup (1 or 2), 0 automatic
  *   "tens_tile"   tensor-vs-tensor kernel (Kzz): 1 (default) 16 x 16 tiles with the tensors staged in LDS, 0 one thread per entry
  *                 gathering its components from HBM (round 1)
+ *   "spectral_wave" SignatureSpectral's sequence kernels: 1 (default) the wavefront kernels with the family at compile time where they
+ *                 are built (float64, first order, differences, d <= 16), 0 one pair per thread (round 1)
  *   "diag_own"    diagonal pass of the pair kernel (level diagonals for normalisation, Kdiag): 1 (default) every pair group of a
  *                 wavefront sweeps its own sequence, 0 all groups sweep the same 64/G sequences and emit one pair each (round 1)
  *   "lr_gemm"     low-rank Gram products on the fp64 matrix cores: 1 (default) 128 x 128 tiles with k-slabs staged through LDS,

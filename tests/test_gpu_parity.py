@@ -418,6 +418,36 @@ def test_spectral_base_kernel(K, family):
     assert relerr(k2.K(X, X2), ko2.K(X, X2)) <= TOL
 
 
+@pytest.mark.parametrize("family", ["gauss", "exp", "mixed"])
+def test_spectral_wavefront_kernels(K, family):
+    """SignatureSpectral's sequence-vs-sequence evaluations through the wavefront kernels with the family at compile time
+    (seq_step_spectral; float64, first order, differences, d <= 16) against the one-pair-per-thread kernel they replace and the
+    oracle: 16- and 64-lane pair groups, ragged lengths on both sides, every padded width, symmetric / cross / diagonal."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(89)
+    fam = {"gauss": "rbf", "exp": "exp", "mixed": "mixed"}[family]
+    for N, N2, L, L2, d, M, Q in ((9, 6, 14, 14, 3, 4, 5), (5, 7, 70, 33, 6, 3, 2), (6, 4, 130, 9, 11, 5, 3), (4, 4, 300, 20, 2, 2, 4), (3, 5, 40, 40, 16, 3, 2)):
+        X = np.cumsum(0.2 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+        X2 = np.cumsum(0.2 * rng.standard_normal((N2, L2, d)), axis=1).reshape(N2, -1)
+        for norm in (True, False):
+            k = K.SignatureSpectral(L * d, d, M, family=family, Q=Q, normalization=norm, variances=rng.uniform(0.5, 1.5, M + 1))
+            k.alpha, k.omega, k.gamma = rng.uniform(0.3, 1.2, Q), 0.3 * rng.standard_normal((Q, d)), rng.uniform(0.4, 1.3, (Q, d))
+            ko = O.SignatureKernelOracle(L * d, d, M, base="spectral", normalization=norm, lengthscales=None, variances=k.variances,
+                                         base_params=dict(alpha=k.alpha, omega=k.omega, gamma=k.gamma, family=fam))
+            ctx = _lib.context(0, 0)
+            got = {}
+            try:
+                for wave in (1, 0):
+                    ctx.set_option("spectral_wave", wave)
+                    got[wave] = (k.K(X), k.K(X, X2, presliced=True, return_levels=True), k.Kdiag(X, return_levels=True))
+            finally:
+                ctx.set_option("spectral_wave", 1)
+            for a, b in zip(got[1], got[0]):
+                assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (N, L, d)
+            assert relerr(got[1][0], ko.K(X)) <= TOL
+            assert relerr(got[1][2], ko.Kdiag(X, return_levels=True)) <= TOL
+
+
 def test_any_shape_fallback(K):
     """Shapes the wavefront kernel is not built for -- both sides longer than its column capacity, more than 32 state-space
     dimensions after lags -- go through the one-pair-per-thread fallback (float64, order 1) and must match the oracle too."""
