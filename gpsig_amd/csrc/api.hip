@@ -284,7 +284,6 @@ int spectral_table(gpsig_ctx* c, const gpsig_params* p, const double** dev) {
     *dev = nullptr;
     if (p->base_kernel != GPSIG_BASE_SPECTRAL) return GPSIG_OK;
     const int Q = int(p->base_params[0]), d = p->num_features;
-    CHK(no_capture(c, "the spectral kernel's table is uploaded per call"));
     std::vector<double> h(size_t(Q) * (1 + 2 * SPECTRAL_STRIDE), 0.0);
     for (int q = 0; q < Q; ++q) {
         h[q] = p->base_table[q];
@@ -295,8 +294,14 @@ int spectral_table(gpsig_ctx* c, const gpsig_params* p, const double** dev) {
     }
     void* dp;
     CHK(ensure(c, B_SPEC, sizeof(double) * h.size(), &dp));
-    HIPCHK(c, hipMemcpyAsync(dp, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
-    CHK(host_sync(c));
+    if (!(c->spec_base == dp && c->last_spec == h)) {       // unchanged parameters: the device copy is still right (as the level weights)
+        CHK(no_capture(c, "the spectral kernel's table changed"));
+        c->spec_base = nullptr;
+        HIPCHK(c, hipMemcpyAsync(dp, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+        CHK(host_sync(c));
+        c->spec_base = dp;
+        c->last_spec = h;
+    }
     *dev = static_cast<const double*>(dp);
     return GPSIG_OK;
 }

@@ -88,6 +88,8 @@ struct gpsig_ctx {
     std::vector<TaskSlot> task_slots;      // device-resident task lists, least recently used one replaced (task_list())
     uint64_t task_clock = 0;
     std::vector<double> last_weights;      // what B_W currently holds
+    std::vector<double> last_spec;         // what B_SPEC currently holds (SignatureSpectral's parameter table)
+    void* spec_base = nullptr;
     // low-rank mode: what B_LR0 / B_LR1 currently hold (keyed by content: the random objects of an evaluation are handed to several
     // calls -- tensor features, sequence features, products -- and every upload was a host synchronisation)
     uint64_t lr_hash = 0;                  // 0: nothing uploaded
