@@ -18,3 +18,6 @@ for cfg in "c2" "c3" "c3 --increments" "c5"; do
   python tools/rocprof_summary.py stats "$db" > $O/kernel_stats_$tag.txt 2>&1 || true
   rm -rf $O/prof_$tag
 done
+# low-rank mode and the spectral kernel (tools of their own: their natural yard-sticks are not the pair-stream roofline)
+for cfg in "c3 --verify" "c2 --verify"; do timeout 600 python tools/bench_lr.py --config $cfg 2>/dev/null >> $O/bench_lowrank.jsonl; done
+timeout 600 python tools/bench_spectral.py > $O/bench_spectral.txt 2>&1
