@@ -246,8 +246,8 @@ int check_params(gpsig_ctx* c, const gpsig_params* p) {
     if (!p) return fail(c, GPSIG_ERR_INVALID, "params is NULL");
     if (p->dtype != GPSIG_F64 && p->dtype != GPSIG_F32) return fail(c, GPSIG_ERR_INVALID, "unknown dtype %d", p->dtype);
     if (p->num_levels < 1) return fail(c, GPSIG_ERR_INVALID, "num_levels must be >= 1");
-    if (p->num_features < 1 || p->num_features > MAX_FEATURES)
-        return fail(c, GPSIG_ERR_UNSUPPORTED, "num_features=%d outside [1, %d]", p->num_features, MAX_FEATURES);
+    if (p->num_features < 1 || p->num_features > MAX_FEATURES_WIDE)
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "num_features=%d outside [1, %d]", p->num_features, MAX_FEATURES_WIDE);
     if (p->num_lags < 0 || p->num_lags > MAX_LAGS) return fail(c, GPSIG_ERR_UNSUPPORTED, "num_lags=%d outside [0, %d]", p->num_lags, MAX_LAGS);
     if (p->base_kernel < GPSIG_BASE_LINEAR || p->base_kernel > GPSIG_BASE_SPECTRAL) return fail(c, GPSIG_ERR_INVALID, "unknown base kernel %d", p->base_kernel);
     if (p->base_kernel == GPSIG_BASE_SPECTRAL) {
@@ -272,11 +272,30 @@ ScaleParams scale_of(const gpsig_params* p, bool apply_scaling) {
     s.d_in = p->num_features;
     s.num_lags = apply_scaling ? p->num_lags : 0;
     s.has_ls = apply_scaling && p->lengthscales != nullptr;
-    for (int f = 0; f < p->num_features; ++f) s.ls[f] = s.has_ls ? p->lengthscales[f] : 1.0;
+    for (int f = 0; f < p->num_features && f < MAX_FEATURES; ++f) s.ls[f] = s.has_ls ? p->lengthscales[f] : 1.0;
     for (int l = 0; l < s.num_lags; ++l) s.lags[l] = p->lags[l];
     for (int l = 0; l <= s.num_lags; ++l) s.gamma[l] = s.num_lags > 0 ? p->gamma[l] : 1.0;
     s.jitter = 1e-6;   // settings.jitter inside lin_interp (gpsig/lags.py:22)
     return s;
+}
+
+// The same for a launch: state spaces wider than MAX_FEATURES read their lengthscales from a device copy (cached by content)
+int scale_params(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, ScaleParams* out) {
+    *out = scale_of(p, apply_scaling);
+    if (!out->has_ls || p->num_features <= MAX_FEATURES) return GPSIG_OK;
+    const size_t n = size_t(p->num_features);
+    void* d;
+    CHK(ensure(c, B_LS, sizeof(double) * n, &d));
+    if (!(c->ls_base == d && c->last_ls.size() == n && memcmp(c->last_ls.data(), p->lengthscales, sizeof(double) * n) == 0)) {
+        CHK(no_capture(c, "the lengthscales of a wide state space changed and have to be uploaded"));
+        c->ls_base = nullptr;
+        c->last_ls.assign(p->lengthscales, p->lengthscales + n);
+        HIPCHK(c, hipMemcpyAsync(d, c->last_ls.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        CHK(host_sync(c));
+        c->ls_base = d;
+    }
+    out->ls_dev = static_cast<const double*>(d);
+    return GPSIG_OK;
 }
 
 // BASE_SPECTRAL: alpha[Q], omega[Q][SPECTRAL_STRIDE], gamma[Q][SPECTRAL_STRIDE] on the device (zero padded); NULL otherwise
@@ -586,7 +605,8 @@ static int make_records(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling,
     CHK(ensure(c, id, bytes ? bytes : 8, &d));
     if (N > 0) {
         CHK(zero_async(c, d, bytes));
-        ScaleParams s = scale_of(p, apply_scaling);
+        ScaleParams s;
+    CHK(scale_params(c, p, apply_scaling, &s));
         const int64_t total = N * geom->rows * s.d_eff();
         hipLaunchKernelGGL(prep_seq_records_kernel<TT>, dim3(grid_for(total)), dim3(256), 0, c->stream,
                            static_cast<const TT*>(Xdev), N, L, s, geom->mode, p->difference, geom->rows, geom->RS,
@@ -734,7 +754,8 @@ static bool generic_ok(const gpsig_params* p) { return sizeof(TT) == 8 && p->num
 static int generic_levels(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* X, const void* Y, int64_t N1, int64_t N2,
                           int L1, int L2, bool diag, double* out, int64_t sm, int64_t si, int64_t sj) {
     if (N1 == 0 || N2 == 0) return GPSIG_OK;
-    ScaleParams sp = scale_of(p, apply_scaling);
+    ScaleParams sp;
+    CHK(scale_params(c, p, apply_scaling, &sp));
     const int d_eff = sp.d_eff(), M = p->num_levels;
     const int64_t s1 = (N1 + 63) / 64 * 64, s2 = (N2 + 63) / 64 * 64;
     void *xt, *yt = nullptr;
@@ -933,7 +954,8 @@ static size_t seq_out_elems(const gpsig_params* p, int64_t N1, int64_t N2, int l
 static int prep_tensors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, const void* Zdev, int64_t Tn, int E,
                  const void** ZT, const void** ZS) {
     const int lt = p->num_levels * (p->num_levels + 1) / 2;
-    ScaleParams s = scale_of(p, apply_scaling);
+    ScaleParams s;
+    CHK(scale_params(c, p, apply_scaling, &s));
     const int d_eff = s.d_eff();
     void *zt, *zs;
     CHK(ensure(c, B_ZT, sizeof(TT) * size_t(Tn) * d_eff * lt * E + 8, &zt));
@@ -982,7 +1004,8 @@ static int tens_vs_seq_lanet_device(gpsig_ctx* c, const gpsig_params* p, bool ra
                              int64_t N, int L, int increments, const void* fx, const double* w, int return_levels, void* out,
                              const TvsLaneTLaunchFn* fns, int ngroups) {
     const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
-    ScaleParams s = scale_of(p, !raw);
+    ScaleParams s;
+    CHK(scale_params(c, p, !raw, &s));
     const int d_eff = s.d_eff();
     const int64_t Tpad = (Tn + 63) / 64 * 64;
     void *zl, *zn, *xs;
@@ -1021,7 +1044,8 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     *done = false;
     if (sizeof(TT) != 8 || p->order > 1 || p->base_kernel == GPSIG_BASE_SPECTRAL || c->tvs_tile == 0) return GPSIG_OK;
     const int M = p->num_levels, lt = M * (M + 1) / 2;
-    ScaleParams s = scale_of(p, !raw);
+    ScaleParams s;
+    CHK(scale_params(c, p, !raw, &s));
     const int d_eff = s.d_eff();
     const int D = tvs_tile_width(d_eff);
     if (D == 0) return GPSIG_OK;
@@ -1094,7 +1118,8 @@ static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, con
             return tens_vs_seq_lanet_device(c, p, raw, Zdev, X, Tn, N, L, increments, fx, w, return_levels, out, fns, ng);
     }
     const int64_t Npad = (N + 63) / 64 * 64;
-    ScaleParams sx = scale_of(p, !raw);
+    ScaleParams sx;
+    CHK(scale_params(c, p, !raw, &sx));
     const int d_eff = sx.d_eff();
     void* xt;
     CHK(ensure(c, B_XT, sizeof(TT) * size_t(L) * d_eff * Npad + 8, &xt));
@@ -1717,7 +1742,8 @@ int gpsig_lr_gather_points(gpsig_ctx* c, const gpsig_params* p, const void* X, i
     if (!idx || !out_host || R < 0) return fail(c, GPSIG_ERR_INVALID, "bad landmark request");
     for (int64_t k = 0; k < R; ++k)
         if (idx[k] < 0 || idx[k] >= N * L) return fail(c, GPSIG_ERR_INVALID, "landmark index out of range");
-    ScaleParams s = scale_of(p, true);
+    ScaleParams s;
+    CHK(scale_params(c, p, true, &s));
     const int d_eff = s.d_eff();
     const void* dX;
     CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * p->num_features, &dX));
@@ -1838,7 +1864,8 @@ int gpsig_lr_seq_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowra
     ENTER(c, p);
     CHK(lr_check(c, p, lr));
     const int M = p->num_levels;
-    ScaleParams s = scale_of(p, true);
+    ScaleParams s;
+    CHK(scale_params(c, p, true, &s));
     const int d_eff = s.d_eff();
     LrDev D;
     CHK(lr_upload(c, p, lr, d_eff, &D));
@@ -1941,7 +1968,8 @@ int gpsig_lr_tens_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowr
     ENTER(c, p);
     CHK(lr_check(c, p, lr));
     const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
-    ScaleParams s = scale_of(p, true);
+    ScaleParams s;
+    CHK(scale_params(c, p, true, &s));
     const int d_eff = s.d_eff();
     LrDev D;
     CHK(lr_upload(c, p, lr, d_eff, &D));

@@ -10,7 +10,9 @@
 
 namespace gpsig {
 
-constexpr int MAX_FEATURES = 64;  // d (one lag copy); more than 32 columns after lags run through the any-shape kernels
+constexpr int MAX_FEATURES = 64;  // d (one lag copy) whose lengthscales travel by value in ScaleParams; wider state spaces read them from
+                                  // device memory (ScaleParams::ls_dev).  More than 32 columns after lags run through the any-shape kernels
+constexpr int MAX_FEATURES_WIDE = 4096;
 constexpr int MAX_LAGS = 8;
 
 // Scaling state of SignatureKernel (gpsig/kernels.py:343-398), by value in kernel arguments.
@@ -20,10 +22,12 @@ struct ScaleParams {
     int has_ls;
     double inv_unused;
     double ls[MAX_FEATURES];
+    const double* ls_dev;   // d_in > MAX_FEATURES with lengthscales: their device copy (NULL otherwise)
     double lags[MAX_LAGS];
     double gamma[MAX_LAGS + 1];
     double jitter;
     __host__ __device__ int d_eff() const { return d_in * (num_lags + 1); }
+    __host__ __device__ double lsv(int f) const { return ls_dev ? ls_dev[f] : ls[f]; }
 };
 
 // x~[n][t][fe]: observation t of sequence n after add_lags_to_sequences (gpsig/lags.py:41-63), division by
@@ -46,7 +50,7 @@ __device__ __forceinline__ T scaled_point(const T* __restrict__ Xn, int L, int t
         const T tl = T(left) / denom, tr = T(right) / denom;
         v = xl + (tq - tl) * (xr - xl) / (tr - tl);                     // lags.py:33
     }
-    if (P.has_ls) v = v / T(P.ls[f]);
+    if (P.has_ls) v = v / T(P.lsv(f));
     if (P.num_lags > 0) v = v * T(P.gamma[lag]);
     return v;
 }
@@ -118,7 +122,7 @@ __global__ void prep_tensors_kernel(const T* __restrict__ Z, int lt, int64_t Tn,
             const int lag = fe / P.d_in, f = fe - lag * P.d_in;
             T v = Z[((int64_t(k) * Tn + t) * E + e) * d_eff + fe];
             if (P.has_ls) {                                   // kernels.py:374-379 / :391-395: no lag weights without lengthscales
-                v = v / T(P.ls[f]);
+                v = v / T(P.lsv(f));
                 if (P.num_lags > 0) v = v * T(P.gamma[lag]);
             }
             ZT[((t * d_eff + fe) * lt + k) * E + e] = v;
@@ -517,7 +521,7 @@ __global__ void prep_tensors_lanet_kernel(const T* __restrict__ Z, int lt, int64
             if (t < Tn) {
                 v = Z[((int64_t(k) * Tn + t) * E + e) * d_eff + fe];
                 if (P.has_ls) {
-                    v = v / T(P.ls[f]);
+                    v = v / T(P.lsv(f));
                     if (P.num_lags > 0) v = v * T(P.gamma[lag]);
                 }
             }

@@ -26,7 +26,7 @@ enum BufId {
     B_DLEV0, B_DLEV1,             // diagonal levels
     B_FAC0, B_FAC1,               // per-sequence factors
     B_TASKS, B_W, B_XT, B_ZT, B_ZS, B_ZL, B_ZN, B_TMP0, B_TMP1,
-    B_LR0, B_LR1, B_LR2, B_LR3, B_LR4, B_LR5, B_LR6, B_LR7, B_LR8,
+    B_LS, B_LR0, B_LR1, B_LR2, B_LR3, B_LR4, B_LR5, B_LR6, B_LR7, B_LR8,
     B_GR0, B_GR1, B_GR2, B_GR3, B_GR4, B_GR5, B_GR6, B_GR7,   // gradient path scratch
     B_SPEC,                                                    // spectral base-kernel table
     B_COUNT
@@ -88,6 +88,8 @@ struct gpsig_ctx {
     std::vector<TaskSlot> task_slots;      // device-resident task lists, least recently used one replaced (task_list())
     uint64_t task_clock = 0;
     std::vector<double> last_weights;      // what B_W currently holds
+    std::vector<double> last_ls;           // what B_LS currently holds (lengthscales of a state space wider than MAX_FEATURES)
+    void* ls_base = nullptr;
     std::vector<double> last_spec;         // what B_SPEC currently holds (SignatureSpectral's parameter table)
     void* spec_base = nullptr;
     // low-rank mode: what B_LR0 / B_LR1 currently hold (keyed by content: the random objects of an evaluation are handed to several

@@ -84,7 +84,7 @@ __global__ void lr_tens_cross_kernel(const T* __restrict__ Z, int64_t rows, Scal
             const int lag = fe / P.d_in, f = fe - lag * P.d_in;
             T x = Z[r * d_eff + fe];
             if (P.has_ls) {                                  // kernels.py:374-379 / :391-395
-                x = x / T(P.ls[f]);
+                x = x / T(P.lsv(f));
                 if (P.num_lags > 0) x = x * T(P.gamma[lag]);
             }
             const T y = S[i * d_eff + fe];

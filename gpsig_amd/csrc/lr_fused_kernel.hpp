@@ -319,7 +319,7 @@ __global__ __launch_bounds__(LR_TENS_THREADS) void lr_tens_features_fused_kernel
         const int lag = fe / A.P.d_in, f = fe - lag * A.P.d_in;
         double x = A.Z[((int64_t(k) * A.T + t) * E + e) * d_eff + fe];
         if (A.P.has_ls) {                            // kernels.py:374-379 / :391-395
-            x = x / A.P.ls[f];
+            x = x / A.P.lsv(f);
             if (A.P.num_lags > 0) x = x * A.P.gamma[lag];
         }
         zs[q] = x;

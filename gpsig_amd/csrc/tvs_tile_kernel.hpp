@@ -320,7 +320,7 @@ static __global__ void prep_tensors_tile_kernel(const double* __restrict__ Z, in
                 const double* zp = Z + ((int64_t(k) * Tn + t) * E_in + e) * d_eff + fe;
                 v = collapse ? zp[d_eff] - zp[0] : zp[0];
                 if (P.has_ls) {
-                    v = v / P.ls[f];
+                    v = v / P.lsv(f);
                     if (P.num_lags > 0) v = v * P.gamma[lag];
                 }
                 v *= pre;

@@ -448,6 +448,31 @@ def test_spectral_wavefront_kernels(K, family):
             assert relerr(got[1][2], ko.Kdiag(X, return_levels=True)) <= TOL
 
 
+@pytest.mark.parametrize("base", ["linear", "rbf"])
+def test_state_spaces_wider_than_64_features(K, base):
+    """More than 64 features per lag copy (the reference's benchmark suite has PEMS with 963): the lengthscales travel to the kernels
+    through device memory instead of by value (ScaleParams::ls_dev) and the evaluations run through the any-shape kernels."""
+    rng = np.random.default_rng(97)
+    for N, L, d, M, T, lags in ((6, 9, 100, 3, 4, 0), (4, 7, 70, 2, 3, 1), (3, 6, 963, 2, 2, 0)):
+        X = np.cumsum(0.3 / np.sqrt(d) * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+        X2 = np.cumsum(0.3 / np.sqrt(d) * rng.standard_normal((5, L, d)), axis=1).reshape(5, -1)
+        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, lengthscales=0.7 + rng.random(d), variances=0.5 + rng.random(M + 1))
+        if lags:
+            kw["num_lags"] = lags
+        kx, ko = make_kernel(K, kw), make_oracle(kw)
+        de = d * (lags + 1)
+        assert relerr(kx.K(X), ko.K(X)) <= TOL
+        assert relerr(kx.K(X, X2), ko.K(X, X2)) <= TOL
+        assert relerr(kx.Kdiag(X), ko.Kdiag(X)) <= TOL
+        for incr in (False, True):
+            Z = rng.standard_normal((M * (M + 1) // 2, T, 2, de) if incr else (M * (M + 1) // 2, T, de)) / np.sqrt(d)
+            got, want = kx.K_tens_n_seq_covs(Z, X, increments=incr), ko.K_tens_n_seq_covs(Z, X, increments=incr)
+            for g, w in zip(got, want):
+                assert relerr(g, w) <= TOL, (d, incr)
+        got32 = kx.K(X.astype(np.float32))
+        assert got32.dtype == np.float32 and relerr32(got32, ko.K(X.astype(np.float32).astype(np.float64))) <= TOL32
+
+
 def test_any_shape_fallback(K):
     """Shapes the wavefront kernel is not built for -- both sides longer than its column capacity, more than 32 state-space
     dimensions after lags -- go through the one-pair-per-thread fallback (float64, order 1) and must match the oracle too."""
