@@ -499,8 +499,10 @@ def test_any_shape_fallback(K):
 
 def test_unsupported_shapes_fail_loudly(K):
     assert K.SignatureLinear(2 * 600, 2, 3, order=2).K(np.zeros((2, 1200), dtype=np.float32)).dtype == np.float32   # float64 fallback, rounded
+    wide = K.SignatureLinear(70 * 5, 70, 3).K(np.zeros((2, 350)))    # beyond 64 features per lag copy: any-shape kernels, lengthscales from device memory
+    assert np.isfinite(wide).all() and np.allclose(np.diag(wide), 4.0)
     with pytest.raises(NotImplementedError):
-        K.SignatureLinear(70 * 5, 70, 3).K(np.zeros((2, 350)))             # more than 64 features per lag copy
+        K.SignatureLinear(5000 * 2, 5000, 2).K(np.zeros((2, 10000)))      # more than 4096 features per lag copy
     assert K.SignatureRBF(12, 3, 3, low_rank=True, num_components=4).K(np.zeros((4, 12), dtype=np.float32)).dtype == np.float32   # via float64
     with pytest.raises(ValueError):
         K.SignatureLinear(12, 3, 3).K_tens(np.zeros((5, 4, 3)))            # lt must be 6
