@@ -70,6 +70,26 @@ class EmulatorContext:
         out[...] = parallel.symmetrize_compact_reference(half)
 
 
+def _spawn_with_retry(worker, world, args_after_port, attempts=3):
+    """Run `worker(rank, world, port, *args_after_port, ret)` on `world` gloo ranks.  The free port is found by binding and
+    releasing it, which another process can win in between (rendezvous then fails): a transient of the test harness, not of the
+    code under test -- retried on a fresh port."""
+    last = None
+    for _ in range(attempts):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            try:
+                mp.spawn(worker, args=(world, port) + tuple(args_after_port) + (ret,), nprocs=world, join=True)
+                return dict(ret)
+            except Exception as e:        # noqa: BLE001
+                last = e
+    raise last
+
+
 def _worker(rank, world, port, n, chunks, ret):
     import torch
     from gpsig_amd import kernels
@@ -97,14 +117,8 @@ def _worker(rank, world, port, n, chunks, ret):
 
 @pytest.mark.parametrize("n,chunks", [(22, 1), (37, 2), (64, 4)])
 def test_two_rank_gloo_sharded_gram(n, chunks):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    with mp.Manager() as mgr:
-        ret = mgr.dict()
-        mp.spawn(_worker, args=(2, port, n, chunks, ret), nprocs=2, join=True)
-        assert ret["err"] < 1e-12 and ret["sym"]
+    ret = _spawn_with_retry(_worker, 2, (n, chunks))
+    assert ret["err"] < 1e-12 and ret["sym"]
 
 
 def _covs_worker(rank, world, port, n, increments, ret):
@@ -140,11 +154,5 @@ def _covs_worker(rank, world, port, n, increments, ret):
 def test_gloo_sharded_covariances(n, world, increments):
     """parallel.ShardedCovs: Kzx and the Kxx diagonal in contiguous blocks of sequences per rank, gathered on rank 0 (ragged
     last block; more ranks than whole blocks)."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    with mp.Manager() as mgr:
-        ret = mgr.dict()
-        mp.spawn(_covs_worker, args=(world, port, n, increments, ret), nprocs=world, join=True)
-        assert ret["err"] == 0.0 and ret["shapes"] == [(5, 5), (5, n), (n,)]
+    ret = _spawn_with_retry(_covs_worker, world, (n, increments))
+    assert ret["err"] == 0.0 and ret["shapes"] == [(5, 5), (5, n), (n,)]
