@@ -19,10 +19,17 @@ Workloads (BASELINE.json configs; the names C1..C5 are SURVEY.md section 8's):
       scaling benchmark).
   c5  configs[4]: N=2048, L=128, d=16, num_levels=6, fp32, SignatureRBF, full Gram.
 One step = one complete evaluation with the inputs already resident in HBM and the result left in HBM.  Prints ONE JSON line
-on rank 0: the driver's contract fields + `roofline` (pair-stream fraction AND executed-flop ALU fraction of the dominant
-kernel, timed with HIP events on the library's stream), `cpu_baseline` (the oracle's op-for-op restatement of the reference's
-TF graph on the host cores, bounded sample), `rel_err` (a sub-sample of the timed output against the oracle, outside the timed
-region) and `end_to_end_ms_host_pointers` (the same evaluation from and to host memory: H2D + compute + D2H).
+on rank 0: the driver's contract fields + `roofline` (what binds the dominant kernel -- `bound`, `issue_frac`, `alu_frac` --, the
+pair-stream fraction of SURVEY 8(d) as `stream_frac`, the kernel's HIP-event time on the library's stream, the HBM traffic
+measured by two rocprofv3 --pmc passes of this very command), `clock_ghz` (the shader clock during the timed region, sampled
+on the device), `cpu_baseline` (the oracle's op-for-op restatement of the reference's TF graph on the host cores, bounded
+sample), `rel_err` (a sub-sample of the timed output against the oracle, outside the timed region),
+`end_to_end_ms_host_pointers` (the same evaluation from and to host memory: H2D + compute + D2H) and, on the default
+single-GPU line, `secondary`: the other single-GPU configurations (c2 RBF, c3, c3 with increments, c5), 3 warm-up + 10 steps each.
+
+--gpus N > 1 without a torchrun environment launches the N ranks itself (python -m torch.distributed.run, one process per
+GPU, rendezvous on 127.0.0.1) and fails when the node has fewer than N GPUs: a line with "n_gpus": N was computed by N ranks,
+listed in `ranks_seen`.
 """
 import argparse
 import json
@@ -163,7 +170,7 @@ def cpu_baseline_numpy(cfg, increments, budget_s=8.0):
                       f"reduce per level), {workers} single-threaded worker processes, {wall:.1f} s wall"}
 
 
-def cpu_baseline(cfg, base, increments, budget_s=10.0):
+def cpu_baseline(cfg, base, increments, budget_s=10.0, numpy_leg=True):
     """cpu_baseline of the bench line: the oracle's C restatement of the reference's graph (oracle/sigkern_ref.c: kappa lattice,
     double difference, per level two exclusive cumsums + multiply + reduce -- gpsig/kernels.py:225-230, signature_algs.py:25-35 /
     :114-125 -- one pair at a time so that a lattice stays in cache, OpenMP over pairs on every host thread), on a bounded sample
@@ -202,6 +209,8 @@ def cpu_baseline(cfg, base, increments, budget_s=10.0):
            "sample": f"{reps} x {what} at L={L}, d={d}, num_levels={M}, {base}, fp64, oracle/sigkern_ref.c (gcc -O3 -fopenmp, "
                      f"{threads} OpenMP threads), {wall:.1f} s wall"}
     res["implementation"] = "C restatement, OpenMP"
+    if not numpy_leg:
+        return res
     try:
         alt = cpu_baseline_numpy(cfg, increments)
         alt["implementation"] = "NumPy whole-tensor ops, one process per core"
@@ -245,7 +254,329 @@ def oracle_rel_err(cfg, w, base, increments, Xh, Zh, out):
     return rel_err(out[ti][:, ti].cpu().numpy(), want)
 
 
-def main():
+# ---- launching the ranks of an N > 1 run ------------------------------------------------------------------------------
+def rank_launch_command(n, argv):
+    """The command that runs this script on n ranks of one node: one process per GPU under torch.distributed.run; --standalone
+    lets the c10d rendezvous pick its own port (no bind-and-release race), on 127.0.0.1 (the container's host name may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+            f"--nproc-per-node={int(n)}", os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(n, argv):
+    """python bench.py --gpus N without a torchrun environment: start the ranks and hand their exit code on."""
+    import subprocess
+    return subprocess.call(rank_launch_command(n, argv), env=dict(os.environ, GPSIG_BENCH_LAUNCHED="1"))
+
+
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def rank_identity(rank, local_rank, dev_index, backend):
+    """What a rank reports into `ranks_seen`: its device as HIP sees it."""
+    import torch
+    ent = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "backend": backend, "device": None}
+    if torch.cuda.is_available() and dev_index is not None:
+        pr = torch.cuda.get_device_properties(dev_index)
+        ent.update({"device": int(dev_index), "name": pr.name, "arch": getattr(pr, "gcnArchName", None),
+                    "pci_bus_id": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+                    "uuid": str(getattr(pr, "uuid", ""))})
+    return ent
+
+
+# ---- HBM traffic of the dominant kernel: two rocprofv3 --pmc passes of this command (MI355X_MICROARCH.md, "HBM") ------------
+def measure_traffic(cfg, base, increments, timeout_s=240):
+    """FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots) and never ride with a trace; each pass runs
+    `bench.py --config ... --steps 2 --warmup 1` with nothing but the timed loop.  FETCH_SIZE is doubled (gfx950 tallies the
+    128-byte requests of 16-byte-per-lane loads at 64 bytes; every read of these kernels is such a load or an LDS-DMA of that
+    width), WRITE_SIZE is taken as is (KiB both).  Returns None where rocprofv3 is missing or already wraps this process."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ):
+        return None
+    got = {}
+    meta = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="gpsig_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--config", cfg, "--base", base,
+               "--steps", "2", "--warmup", "1", "--timed-loop-only"] + (["--increments"] if increments else [])
+        try:
+            pr = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True,
+                                  env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+            try:
+                pr.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, 9)
+                return None
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(tmp) for f in fs if f.endswith(".db")]
+            if not dbs:
+                return None
+            rows = list(sqlite3.connect(dbs[0]).cursor().execute(
+                "select dispatch_id, kernel_name, grid_size, value, duration from counters_collection where counter_name = ?", (counter,)))
+            per, info = {}, {}
+            for did, name, grid, val, dur in rows:
+                if "gpsig" not in name:
+                    continue
+                per[did] = per.get(did, 0.0) + val
+                info[did] = (name.split("(")[0], int(grid), dur)
+            tot = {}
+            for did, (name, grid, dur) in info.items():
+                tot[(name, grid)] = tot.get((name, grid), 0.0) + dur
+            if not tot:
+                return None
+            kname, kgrid = max(tot, key=tot.get)                      # the dominant kernel: the largest share of device time
+            vals = sorted(v for did, v in per.items() if info[did][:2] == (kname, kgrid))
+            got[counter] = vals[len(vals) // 2]
+            meta = (kname, kgrid, len(vals))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return {"fetch_size_kib": got["FETCH_SIZE"], "write_size_kib": got["WRITE_SIZE"],
+            "bytes_per_launch": got["FETCH_SIZE"] * 2.0 * 1024.0 + got["WRITE_SIZE"] * 1024.0,
+            "kernel": meta[0], "grid": meta[1], "dispatches": meta[2]}
+
+
+# vector instructions per wave-step of the dominant kernels (disassembly of the built instances, DESIGN.md section 4); float64
+# and DPP instructions take a SIMD's issue port for 4 cycles per wave64 instruction.  issue_frac = how much of the SIMDs'
+# issue time the kernel's vector instructions fill at the clock measured during the run.
+VALU_PER_STEP = {("c2", "linear"): 89, ("c4", "linear"): 89, ("c2", "rbf"): 174, ("c4", "rbf"): 174}
+SIMDS = 1024
+
+
+def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chunks=4, weak=False, checks=True, host_e2e=True,
+                 traffic="measure"):
+    """Times `steps` evaluations of one BASELINE configuration on this rank's device (inputs resident in HBM) and returns the
+    bench-line fields on rank 0 (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    from gpsig_amd import _lib, kernels, parallel
+
+    w = dict(WORKLOADS[cfg])
+    w["base"] = base
+    n_gpus = world
+    if n_gpus > 1 and (weak or cfg == "c2"):
+        w["N"] = int(round(4096 * math.sqrt(n_gpus) / 64.0)) * 64
+    N, L, D, M, T = w["N"], w["L"], w["d"], w["M"], w["T"]
+    tdt = torch.float64 if w["dtype"] == "f64" else torch.float32
+    Xh = make_inputs(w)                                              # same data on every rank
+    X = torch.as_tensor(Xh, device=dev).to(tdt)
+    Zh = make_tensors(w, increments) if T else None
+    Z = torch.as_tensor(Zh, device=dev).to(tdt) if T else None
+    cls = kernels.SignatureLinear if base == "linear" else kernels.SignatureRBF
+    kern = cls(L * D, D, M, lengthscales=lengthscales(w))
+    gram = parallel.ShardedGram(kern, N, dev, rank, world, chunks=chunks) if not T else None
+    covs = parallel.ShardedCovs(kern, N, dev, rank, world) if T else None      # world == 1: kern.K_tens_n_seq_covs itself
+
+    def step():
+        if T:
+            return covs(Z, X, increments=increments)
+        return gram(X)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    ctx = _lib.context(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
+    t_w = time.perf_counter()
+    for _ in range(warmup):
+        step()
+    barrier()
+    est_ms = (time.perf_counter() - t_w) * 1e3 / max(warmup, 1) * steps if warmup else 0.0
+    if not warmup:                                                   # no estimate of the timed region: one untimed step gives it
+        t_w = time.perf_counter()
+        step()
+        barrier()
+        est_ms = (time.perf_counter() - t_w) * 1e3 * steps
+    ctx.timing_reset()
+    probe = False
+    try:        # the shader clock over (most of) the timed region; the first warm-up step includes one-off work, so cap by it
+        ctx.clock_probe_start(max(0.2, min(est_ms * 0.9, 30000.0)), 64)
+        probe = True
+    except Exception:
+        probe = False
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches, _ = ctx.timing_get()      # HIP events around the dominant kernel, on the stream it was launched on
+    clock = None
+    if probe:
+        try:
+            g_mean, g_min, g_max, cov_ms = ctx.clock_probe_read()
+            clock = {"mean": g_mean, "min": g_min, "max": g_max, "window_ms": cov_ms, "timed_region_ms": dt * 1e3,
+                     "how": "one sleeping wavefront on a stream of its own: s_memtime (shader cycles) against s_memrealtime (100 MHz), "
+                            "64 readings spread over the window, started just before the timed region"}
+        except Exception:
+            clock = None
+
+    if world > 1:
+        tt = torch.tensor([dt, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt, per_launch_ms = float(tt[0].item()), float(tt[1].item())
+    else:
+        per_launch_ms = kernel_ms / max(launches, 1)
+    launches_per_step = launches / max(steps, 1)
+    if rank != 0:
+        if checks and n_gpus > 1:
+            pass
+        return None
+
+    pairs = float(T) * N if T else float(N) * N                    # entries delivered per step
+    value = pairs * steps / dt
+    b_pair = stream_bytes_per_pair(w, increments)
+    f_ref, f_exec = flops_per_pair(w, increments)
+    # one launch of the dominant kernel: this rank's share of a step, divided over the launches it took
+    pairs_launch = pairs / n_gpus / max(launches_per_step, 1)
+    evaluated_launch = pairs_launch if T else pairs_launch * (N + 1) / (2.0 * N)     # symmetric Gram: each unordered pair once
+    achieved = pairs_launch * b_pair / (per_launch_ms * 1e-3) / 1e9
+    alu_peak = FP64_VECTOR_PEAK_TFLOPS if w["dtype"] == "f64" else FP32_VECTOR_PEAK_TFLOPS
+    tflops_exec = evaluated_launch * f_exec / (per_launch_ms * 1e-3) / 1e12
+    stream_frac = achieved / HBM_PEAK_GBS
+    alu_frac = tflops_exec / alu_peak
+    ghz = clock["mean"] if clock else None
+    issue = None
+    vps = VALU_PER_STEP.get((cfg, base))
+    if vps and ghz:
+        pairs_per_wave = 4                                           # G = 16: four pair groups per wavefront
+        wave_steps = evaluated_launch / pairs_per_wave * L           # L lattice rows (L - 1 increments + the boundary row) per pair
+        issue = {"valu_per_wave_step": vps, "cycles_per_valu": 4, "wave_steps_per_launch": wave_steps, "simds": SIMDS,
+                 "issue_frac": wave_steps * vps * 4.0 / (SIMDS * ghz * 1e9 * per_launch_ms * 1e-3)}
+    if T:
+        bound = "valu-issue"
+        binding = ("vector issue: the table-driven exps of the base kernel (10 per step and wave with increments) and the chain FMAs; the sequence "
+                   "records are staged once per 64 tensors, so HBM sees ~2 % of the pair-stream bytes (DESIGN.md section 4)")
+    elif w["dtype"] == "f64":
+        bound = "valu-issue"
+        binding = "float64 vector-ALU issue (instructions x 4 cycles per wave; DESIGN.md section 4)"
+    else:
+        bound = "valu-latency"
+        binding = "float32 dependent-instruction latency at the kernel's wavefronts per SIMD (DESIGN.md section 2.4)"
+    kernel_name = ("tvs_tile_kernel (tensor-vs-sequence chains)" if T else
+                   ("seq_pk2_kernel (pair recursion, two sequences per pair group)" if (w["dtype"] == "f32" and base == "rbf")
+                    else "seq_gram_kernel (pair recursion)"))
+    # ---- HBM traffic: measured by this run (two rocprofv3 --pmc passes of the same command), else the committed passes
+    tr, tr_src = None, None
+    key = ("c2" if cfg == "c4" else cfg) + "_" + base + ("_increments" if increments else "")
+    if traffic == "measure" and n_gpus == 1 and cfg != "c4":
+        m = measure_traffic(cfg, base, increments)
+        if m:
+            tr = m["bytes_per_launch"]
+            tr_src = {"how": "measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, of `bench.py --config %s --base %s%s "
+                             "--steps 2 --warmup 1`; median over the dominant kernel's dispatches; FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE, KiB"
+                             % (cfg, base, " --increments" if increments else ""), **m}
+    if tr is None and traffic != "off":
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        try:
+            ent = json.load(open(tf)).get(key) if cfg != "c4" else None
+            if ent:
+                tr = ent.get("bytes_per_launch")
+                tr_src = {"how": "static: profiles/hbm_traffic.json (%s)" % ent.get("source", "round %s" % ent.get("round")),
+                          "kernel": ent.get("kernel"), "grid": ent.get("grid")}
+        except Exception:
+            tr = None
+    what = ("SVGP inducing-tensor path Kzz + Kzx + Kxx-diag (K_tens_n_seq_covs), T=%d inducing tensors%s, " % (T, " (increments)" if increments else "")
+            if T else "full N x N Gram%s, " % (" sharded over %d GPUs, RCCL gather to rank 0" % n_gpus if n_gpus > 1 else ""))
+    cname = "Signature" + ("Linear" if base == "linear" else "RBF")
+    res = {
+        "metric": METRIC,
+        "value": value, "unit": "sequence-pairs/s", "n_gpus": n_gpus, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak" if (n_gpus == 1 or weak or cfg == "c2") else "strong", "vs_baseline": None,
+        "dtype": w["dtype"], "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[{BASELINE_INDEX[cfg]}]: {what}{cname}, N={N}, L={L}, d={D}, num_levels={M}, "
+                               f"order=1, normalization=on, {'fp64' if w['dtype'] == 'f64' else 'fp32'}, "
+                               f"{'white-noise' if w['data'] == 'white' else 'random-walk'} inputs",
+                   "name": cfg, "N": N, "L": L, "d": D, "num_levels": M, "order": 1, "normalization": True,
+                   "pairs_per_step": pairs,
+                   "parallelism": ((f"sequence blocks x{n_gpus} (Z replicated), Kzx / Kxx-diag blocks gathered to rank 0 over RCCL" if T else
+                                    f"owned-row blocks x{n_gpus}, {chunks} chunks per rank, compact (N/2+1 wide) rows gathered "
+                                    f"asynchronously to rank 0 over RCCL, symmetrised there") if n_gpus > 1 else "single GPU")},
+        "clock_ghz": ghz, "clock": clock,
+        "roofline": {"bound": bound, "binding_limit": binding,
+                     "issue_frac": issue["issue_frac"] if issue else None, "issue_model": issue,
+                     "alu_frac": alu_frac,
+                     # the contract's fields: ALGORITHMIC bytes per launch / the kernel's HIP-event time, against the HBM peak
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": stream_frac if stream_frac <= 1.0 else None, "stream_frac": stream_frac,
+                     "frac_is": "stream_frac: the ALGORITHMIC pair-stream rate of SURVEY 8(d) (every delivered entry priced at its input streams + its "
+                                "result) over the HBM peak -- the number north_star's 60 % target is stated in -- NOT DRAM bandwidth: the streams are "
+                                "served from L2 / LDS, `traffic` is what the memory side saw, `bound` names what limits the kernel"
+                                + ("" if stream_frac <= 1.0 else "; above 1 here (a sequence record is staged once per 64 tensors), so it is not printed as a fraction of HBM"),
+                     "traffic": tr, "traffic_source": tr_src,
+                     "kernel": kernel_name, "kernel_ms_per_launch": per_launch_ms, "launches_per_step": launches_per_step,
+                     "algorithmic_bytes_per_pair": b_pair, "pairs_per_launch": pairs_launch,
+                     "alu": {"executed_flops_per_evaluated_pair": f_exec, "evaluated_pairs_per_launch": evaluated_launch,
+                             "achieved_tflops": tflops_exec, "peak_tflops": alu_peak, "alu_frac": alu_frac,
+                             "reference_flops_per_pair": f_ref,
+                             "reference_flops_frac": (pairs_launch * f_ref / (per_launch_ms * 1e-3) / 1e12) / alu_peak}},
+    }
+    if not T:
+        res["config"]["unique_pairs_computed_per_step"] = float(N) * (N + 1) / 2
+        res["config"]["note"] = ("a step delivers all N*N Gram entries; symmetry is exploited on chip (each unordered pair is "
+                                 "evaluated once and stored twice), as the reference's K(X) contract allows")
+        res["roofline"]["stream_frac_on_unique_pairs"] = stream_frac * (N + 1) / (2.0 * N)
+    if not checks:
+        return res
+    # ---- checks, outside the timed region -------------------------------------------------------------------
+    res["rel_err"] = oracle_rel_err(cfg, w, base, increments, Xh, Zh, out)
+    res["rel_err_note"] = ("max |K - K_oracle| / (|K_oracle| + 1e-6 max|K_oracle|) on a sub-sample of the timed output; "
+                           "tolerance " + ("1e-6 (fp64)" if w["dtype"] == "f64" else "1e-4 (fp32 against the fp64 oracle)"))
+    assert res["rel_err"] <= (1e-6 if w["dtype"] == "f64" else 1e-4), res["rel_err"]
+    if not T:
+        assert np.allclose(out[:8, :8].diagonal().cpu().numpy(), M + 1.0, atol=1e-9 if w["dtype"] == "f64" else 1e-4)
+    if n_gpus > 1 and T:  # the gathered covariances against one single-context evaluation
+        one = kern.K_tens_n_seq_covs(Z, X, increments=increments)
+        res["verify_max_abs_diff_vs_single_rank"] = max(float((a - b).abs().max().item()) for a, b in zip(out, one))
+    elif n_gpus > 1:      # the gathered Gram against single-context evaluations: leading block, and a block across rank boundaries
+        nb = min(N, 1024)
+        d1 = float((out[:nb, :nb] - kern.K(X[:nb])).abs().max().item())
+        a, b = N - 300, N // 2 - 100
+        d2 = float((out[a:a + 256, b:b + 256] - kern.K(X[a:a + 256], X[b:b + 256])).abs().max().item())
+        res["verify_max_abs_diff_vs_single_rank"] = max(d1, d2)
+    if host_e2e and n_gpus == 1 and cfg != "c4":      # the same evaluation from and to host memory (numpy in, numpy out)
+        Xn = Xh.astype(np.float64 if w["dtype"] == "f64" else np.float32)
+        Zn = Zh.astype(Xn.dtype) if T else None
+        f = (lambda: kern.K_tens_n_seq_covs(Zn, Xn, increments=increments)) if T else (lambda: kern.K(Xn))
+        f()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            f()
+        res["end_to_end_ms_host_pointers"] = (time.perf_counter() - t1) / 3 * 1e3
+    return res
+
+
+SECONDARY = [("c2", "rbf", False), ("c3", "rbf", False), ("c3", "rbf", True), ("c5", "rbf", False)]
+
+
+def secondary_lines(dev):
+    """The other single-GPU configurations, 3 warm-up + 10 steps each, as short records beside the headline."""
+    out = []
+    for cfg, base, inc in SECONDARY:
+        name = cfg + "-" + base + ("-increments" if inc else "")
+        try:
+            r = run_workload(cfg, base, inc, 10, 3, dev, host_e2e=False, traffic="static")
+            rf = r["roofline"]
+            out.append({"name": name, "workload": r["config"]["workload"], "dtype": r["dtype"], "value": r["value"], "unit": r["unit"],
+                        "ms_per_step": r["ms_per_step"], "kernel_ms": rf["kernel_ms_per_launch"] * rf["launches_per_step"],
+                        "kernel": rf["kernel"], "bound": rf["bound"], "alu_frac": rf["alu_frac"], "issue_frac": rf["issue_frac"],
+                        "stream_frac": rf["stream_frac"], "clock_ghz": r["clock_ghz"], "rel_err": r["rel_err"],
+                        "traffic": rf["traffic"], "traffic_source": (rf["traffic_source"] or {}).get("how")})
+        except Exception as e:                      # a side record never costs the headline its line
+            out.append({"name": name, "error": repr(e)})
+    return out
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -256,179 +587,90 @@ def main():
     ap.add_argument("--weak", action="store_true", help="--gpus N > 1: N_total = 4096 * sqrt(N) instead of configs[3]")
     ap.add_argument("--chunks", type=int, default=4, help="pieces a rank's row block is computed / gathered in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="default line only: leave out the other single-GPU configurations")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes (roofline.traffic falls back to profiles/hbm_traffic.json)")
+    ap.add_argument("--timed-loop-only", action="store_true", help="warm-up + timed steps and nothing else (what the --pmc passes run)")
+    ap.add_argument("--rendezvous-check", action="store_true", help="start the ranks, gather ranks_seen, print it; no evaluation (CPU-testable)")
+    args = ap.parse_args(argv)
+    argv = list(sys.argv[1:] if argv is None else argv)
+
+    backend = os.environ.get("GPSIG_BENCH_BACKEND", "nccl")       # "gloo": functional check of the N > 1 path on a box with fewer GPUs
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_torchrun:
+        # plain `python bench.py --gpus N`: be the launcher.  Never fall back to fewer ranks than asked for.
+        if backend == "nccl" and not args.rendezvous_check and visible_gpus() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: this node shows {visible_gpus()} GPU(s) to HIP; one rank per GPU over RCCL needs {args.gpus} "
+                             "(GPSIG_BENCH_BACKEND=gloo runs the ranks on the GPUs there are, as a functional check)")
+        raise SystemExit(launch_ranks(args.gpus, argv))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = max(world, 1)
-    if args.gpus != n_gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a line must say how many ranks computed it")
+    n_gpus = world
     cfg = args.config or ("c2" if n_gpus == 1 else "c4")
     if n_gpus > 1 and cfg not in ("c2", "c3", "c4"):
         raise SystemExit("--gpus N > 1 runs the sharded symmetric Gram (c4, or c2 with --weak) or the sequence-sharded SVGP covariances (c3); "
                          "c5 is a single-GPU workload")
-    w = dict(WORKLOADS[cfg])
-    base = args.base or w["base"]
-    w["base"] = base
-    if n_gpus > 1 and (args.weak or cfg == "c2"):
-        w["N"] = int(round(4096 * math.sqrt(n_gpus) / 64.0)) * 64
+    base = args.base or WORKLOADS[cfg]["base"]
 
     cpu = None
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, base, args.increments)      # before CUDA is initialised in this process
+    if rank == 0 and not (args.no_cpu_baseline or args.timed_loop_only or args.rendezvous_check):
+        # before CUDA is initialised in this process; the N > 1 lines carry the C restatement only (the other ranks wait in the rendezvous)
+        cpu = cpu_baseline(cfg, base, args.increments, numpy_leg=(n_gpus == 1))
 
     import torch
     import torch.distributed as dist
-    from gpsig_amd import _lib, kernels, parallel
 
-    backend = os.environ.get("GPSIG_BENCH_BACKEND", "nccl")       # "gloo": functional check of the N > 1 path on a box with one GPU
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    ndev = visible_gpus()
+    if args.rendezvous_check:
+        dev_index = (local_rank % ndev) if ndev else None
+    else:
+        if backend == "nccl" and ndev < max(n_gpus, 1):
+            raise SystemExit(f"rank {rank}: {ndev} GPU(s) visible, {n_gpus} ranks over RCCL need one each")
+        if ndev < 1:
+            raise SystemExit("no GPU visible: gpsig_amd has no CPU path")
+        dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    dev = None
+    if dev_index is not None:
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+    ranks_seen = [rank_identity(rank, local_rank, dev_index, backend if world > 1 else None)]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-
-    N, L, D, M, T = w["N"], w["L"], w["d"], w["M"], w["T"]
-    tdt = torch.float64 if w["dtype"] == "f64" else torch.float32
-    Xh = make_inputs(w)                                              # same data on every rank
-    X = torch.as_tensor(Xh, device=dev).to(tdt)
-    Zh = make_tensors(w, args.increments) if T else None
-    Z = torch.as_tensor(Zh, device=dev).to(tdt) if T else None
-    cls = kernels.SignatureLinear if base == "linear" else kernels.SignatureRBF
-    kern = cls(L * D, D, M, lengthscales=lengthscales(w))
-    gram = parallel.ShardedGram(kern, N, dev, rank, world, chunks=args.chunks) if not T else None
-    covs = parallel.ShardedCovs(kern, N, dev, rank, world) if T else None      # world == 1: kern.K_tens_n_seq_covs itself
-
-    def step():
-        if T:
-            return covs(Z, X, increments=args.increments)
-        return gram(X)
-
-    def barrier():
-        torch.cuda.synchronize(dev)
+        if dist.get_world_size() != n_gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {n_gpus}")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks_seen[0])
+        ranks_seen = gathered
+        if backend == "nccl" and len({(r["device"], r["pci_bus_id"]) for r in ranks_seen}) != world:
+            raise SystemExit(f"ranks share a GPU under the nccl backend: {ranks_seen}")
+    seen = {"world_size": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
+            "launched_by": "bench.py itself" if os.environ.get("GPSIG_BENCH_LAUNCHED") else ("torch.distributed.run" if in_torchrun else "single process"),
+            "ranks": ranks_seen}
+    if args.rendezvous_check:
+        if rank == 0:
+            print(json.dumps({"n_gpus": n_gpus, "rendezvous_check": True, "ranks_seen": seen}))
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            dist.destroy_process_group()
+        return
 
-    ctx = _lib.context(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.timing_reset()
-    t0 = time.perf_counter()
-    out = None
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms, launches, _ = ctx.timing_get()      # HIP events around the dominant kernel, on the stream it was launched on
-
-    if world > 1:
-        tt = torch.tensor([dt, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, per_launch_ms = float(tt[0].item()), float(tt[1].item())
-        launches_per_step = launches / max(args.steps, 1)
-    else:
-        per_launch_ms = kernel_ms / max(launches, 1)
-        launches_per_step = launches / max(args.steps, 1)
-
+    lean = args.timed_loop_only
+    res = run_workload(cfg, base, args.increments, args.steps, args.warmup, dev, rank, world, chunks=args.chunks, weak=args.weak,
+                       checks=not lean, host_e2e=not lean, traffic="off" if lean else ("static" if args.no_traffic else "measure"))
     if rank == 0:
-        pairs = float(T) * N if T else float(N) * N                    # entries delivered per step
-        value = pairs * args.steps / dt
-        b_pair = stream_bytes_per_pair(w, args.increments)
-        f_ref, f_exec = flops_per_pair(w, args.increments)
-        # one launch of the dominant kernel: this rank's share of a step, divided over the launches it took
-        pairs_launch = pairs / n_gpus / max(launches_per_step, 1)
-        evaluated_launch = pairs_launch if T else pairs_launch * (N + 1) / (2.0 * N)     # symmetric Gram: each unordered pair once
-        achieved = pairs_launch * b_pair / (per_launch_ms * 1e-3) / 1e9
-        alu_peak = FP64_VECTOR_PEAK_TFLOPS if w["dtype"] == "f64" else FP32_VECTOR_PEAK_TFLOPS
-        tflops_exec = evaluated_launch * f_exec / (per_launch_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                key = ("c2" if cfg == "c4" else cfg) + "_" + base + ("_increments" if args.increments else "")
-                ent = json.load(open(tf)).get(key) if cfg != "c4" else None
-                if ent:
-                    traffic = ent.get("bytes_per_launch")
-                    traffic_src = "static: %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %s)" % (
-                        "profiles/hbm_traffic.json", ent.get("source", "round %s" % ent.get("round")))
-            except Exception:
-                traffic = None
-        kernel_name = ("tvs_tile_kernel (tensor-vs-sequence chains)" if T else
-                       ("seq_pk2_kernel (pair recursion, two sequences per pair group)" if (w["dtype"] == "f32" and base == "rbf")
-                        else "seq_gram_kernel (pair recursion)"))
-        what = ("SVGP inducing-tensor path Kzz + Kzx + Kxx-diag (K_tens_n_seq_covs), T=%d inducing tensors%s, " % (T, " (increments)" if args.increments else "")
-                if T else "full N x N Gram%s, " % (" sharded over %d GPUs, RCCL gather to rank 0" % n_gpus if n_gpus > 1 else ""))
-        cname = "Signature" + ("Linear" if base == "linear" else "RBF")
-        res = {
-            "metric": METRIC,
-            "value": value, "unit": "sequence-pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if (n_gpus == 1 or args.weak or cfg == "c2") else "strong", "vs_baseline": None,
-            "dtype": w["dtype"], "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{BASELINE_INDEX[cfg]}]: {what}{cname}, N={N}, L={L}, d={D}, num_levels={M}, "
-                                   f"order=1, normalization=on, {'fp64' if w['dtype'] == 'f64' else 'fp32'}, "
-                                   f"{'white-noise' if w['data'] == 'white' else 'random-walk'} inputs",
-                       "name": cfg, "N": N, "L": L, "d": D, "num_levels": M, "order": 1, "normalization": True,
-                       "pairs_per_step": pairs,
-                       "parallelism": ((f"sequence blocks x{n_gpus} (Z replicated), Kzx / Kxx-diag blocks gathered to rank 0 over RCCL" if T else
-                                        f"owned-row blocks x{n_gpus}, {args.chunks} chunks per rank, compact (N/2+1 wide) rows gathered "
-                                        f"asynchronously to rank 0 over RCCL, symmetrised there") if n_gpus > 1 else "single GPU")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_name, "kernel_ms_per_launch": per_launch_ms, "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_pair": b_pair, "pairs_per_launch": pairs_launch,
-                         "binding_limit": ("float64 vector-ALU issue (the kernel runs within a few per cent of instructions x 4 cycles; "
-                                           "DESIGN.md section 4)" if w["dtype"] == "f64" else
-                                           "float32 dependent-instruction latency at 3 wavefronts per SIMD (DESIGN.md section 2.4)"),
-                         "note": "frac is the ALGORITHMIC pair-stream rate of SURVEY 8(d) (every delivered entry priced at its two "
-                                 "input streams + its result) over the HBM peak, NOT measured DRAM bandwidth: the streams are served "
-                                 "from L2 / LDS, `traffic` is what HBM saw.  The binding limit of the pair recursion is vector-ALU "
-                                 "issue: see alu_frac.",
-                         "alu": {"executed_flops_per_evaluated_pair": f_exec, "evaluated_pairs_per_launch": evaluated_launch,
-                                 "achieved_tflops": tflops_exec, "peak_tflops": alu_peak, "alu_frac": tflops_exec / alu_peak,
-                                 "reference_flops_per_pair": f_ref,
-                                 "reference_flops_frac": (pairs_launch * f_ref / (per_launch_ms * 1e-3) / 1e12) / alu_peak}},
-        }
-        if not T:
-            res["config"]["unique_pairs_computed_per_step"] = float(N) * (N + 1) / 2
-            res["config"]["note"] = ("a step delivers all N*N Gram entries; symmetry is exploited on chip (each unordered pair is "
-                                     "evaluated once and stored twice), as the reference's K(X) contract allows")
-            res["roofline"]["frac_on_unique_pairs"] = achieved / HBM_PEAK_GBS * (N + 1) / (2.0 * N)
+        res["ranks_seen"] = seen
         if cpu is not None:
             res["cpu_baseline"] = cpu
-        # ---- checks, outside the timed region -------------------------------------------------------------------
-        res["rel_err"] = oracle_rel_err(cfg, w, base, args.increments, Xh, Zh, out)
-        res["rel_err_note"] = ("max |K - K_oracle| / (|K_oracle| + 1e-6 max|K_oracle|) on a sub-sample of the timed output; "
-                               "tolerance " + ("1e-6 (fp64)" if w["dtype"] == "f64" else "1e-4 (fp32 against the fp64 oracle)"))
-        assert res["rel_err"] <= (1e-6 if w["dtype"] == "f64" else 1e-4), res["rel_err"]
-        if not T:
-            assert np.allclose(out[:8, :8].diagonal().cpu().numpy(), M + 1.0, atol=1e-9 if w["dtype"] == "f64" else 1e-4)
-        if n_gpus > 1 and T:  # the gathered covariances against one single-context evaluation
-            one = kern.K_tens_n_seq_covs(Z, X, increments=args.increments)
-            res["verify_max_abs_diff_vs_single_rank"] = max(float((a - b).abs().max().item()) for a, b in zip(out, one))
-        elif n_gpus > 1:      # the gathered Gram against single-context evaluations: leading block, and a block across rank boundaries
-            nb = min(N, 1024)
-            d1 = float((out[:nb, :nb] - kern.K(X[:nb])).abs().max().item())
-            a, b = N - 300, N // 2 - 100
-            d2 = float((out[a:a + 256, b:b + 256] - kern.K(X[a:a + 256], X[b:b + 256])).abs().max().item())
-            res["verify_max_abs_diff_vs_single_rank"] = max(d1, d2)
-        if n_gpus == 1 and cfg != "c4":      # the same evaluation from and to host memory (numpy in, numpy out)
-            Xn = Xh.astype(np.float64 if w["dtype"] == "f64" else np.float32)
-            Zn = Zh.astype(Xn.dtype) if T else None
-            f = (lambda: kern.K_tens_n_seq_covs(Zn, Xn, increments=args.increments)) if T else (lambda: kern.K(Xn))
-            f()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                f()
-            res["end_to_end_ms_host_pointers"] = (time.perf_counter() - t1) / 3 * 1e3
+        if n_gpus == 1 and args.config is None and args.base is None and not args.increments and not args.no_secondary and not lean:
+            res["secondary"] = secondary_lines(dev)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

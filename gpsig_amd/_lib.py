@@ -83,6 +83,8 @@ _PLAIN = {
     "gpsig_symmetrize_compact_rows": ([_vp, _i32, _vp, _i64, _vp], C.c_int),
     "gpsig_timing_reset": ([_vp], C.c_int),
     "gpsig_timing_get": ([_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)], C.c_int),
+    "gpsig_clock_probe_start": ([_vp, C.c_double, _i32], C.c_int),
+    "gpsig_clock_probe_read": ([_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
     "gpsig_graph_begin": ([_vp], C.c_int),
     "gpsig_graph_end": ([_vp, C.POINTER(_vp)], C.c_int),
     "gpsig_graph_launch": ([_vp, _vp], C.c_int),
@@ -190,6 +192,17 @@ class Context:
         ms, n, pairs = C.c_double(), _i64(), _i64()
         self.check(self._lib.gpsig_timing_get(self._h, C.byref(ms), C.byref(n), C.byref(pairs)))
         return ms.value, n.value, pairs.value
+
+
+    def clock_probe_start(self, duration_ms, samples=64):
+        """Sample the shader clock for `duration_ms` from now on, concurrently with whatever is launched next."""
+        self.check(self._lib.gpsig_clock_probe_start(self._h, float(duration_ms), int(samples)))
+
+    def clock_probe_read(self):
+        """(mean, min, max) GHz between consecutive readings and the milliseconds they span."""
+        a, b, c_, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self.check(self._lib.gpsig_clock_probe_read(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)))
+        return a.value, b.value, c_.value, d.value
 
 
 class Graph:

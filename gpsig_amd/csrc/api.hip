@@ -1508,6 +1508,8 @@ void gpsig_ctx_destroy(gpsig_ctx* c) {
     for (TaskSlot& t : c->task_slots)
         if (t.buf.p) (void)hipFree(t.buf.p);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->probe_stream) { (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
+    if (c->probe_buf) (void)hipFree(c->probe_buf);
     solver_release(c->blas_handle);
     delete c;
 }
@@ -1642,17 +1644,69 @@ int gpsig_timing_get(gpsig_ctx* c, double* kernel_ms, int64_t* launches, int64_t
     return GPSIG_OK;
 }
 
+// ---- effective shader clock while other kernels run -------------------------------------------------------------------
+// One wavefront on a non-blocking stream of its own sleeps and, every `interval` ticks of the constant 100 MHz counter
+// (s_memrealtime), stores that counter next to the shader-clock counter (s_memtime: one tick per shader cycle,
+// MI355X_MICROARCH.md "s_memtime tick vs SQ PMC units").  The ratio of the two differences is the clock the chip ran at --
+// float64-heavy kernels pull it from 2.4 GHz down to about 2.0 (DVFS), box by box and minute by minute.
+static __global__ void clock_probe_kernel(unsigned long long* out, int nsamp, unsigned long long interval) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int k = 0; k < nsamp; ++k) {
+        const unsigned long long target = r0 + (unsigned long long)k * interval;
+        while (__builtin_amdgcn_s_memrealtime() < target) __builtin_amdgcn_s_sleep(100);
+        const unsigned long long cyc = __builtin_amdgcn_s_memtime();
+        const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+        out[2 * k] = cyc;
+        out[2 * k + 1] = rt;
+    }
+}
 
+int gpsig_clock_probe_start(gpsig_ctx* c, double duration_ms, int32_t samples) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (c->capturing) return fail(c, GPSIG_ERR_INVALID, "no clock probe inside a graph capture");
+    if (!(duration_ms > 0.0) || duration_ms > 60000.0 || samples < 2 || samples > 4096)
+        return fail(c, GPSIG_ERR_INVALID, "clock probe: duration in (0, 60000] ms and 2..4096 samples");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->probe_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->probe_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipStreamSynchronize(c->probe_stream));
+    if (samples > c->probe_cap) {
+        if (c->probe_buf) HIPCHK(c, hipFree(c->probe_buf));
+        c->probe_buf = nullptr;
+        c->probe_cap = 0;
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->probe_buf), sizeof(unsigned long long) * 2 * size_t(samples)));
+        c->probe_cap = samples;
+    }
+    const unsigned long long interval = (unsigned long long)(duration_ms * 1e5 / double(samples - 1));    // 100 MHz ticks
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->probe_stream, c->probe_buf, int(samples), interval ? interval : 1ull);
+    HIPCHK(c, hipGetLastError());
+    c->probe_n = samples;
+    return GPSIG_OK;
+}
 
-
-
-
-
-
-
-
-
-
+int gpsig_clock_probe_read(gpsig_ctx* c, double* ghz_mean, double* ghz_min, double* ghz_max, double* covered_ms) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (!c->probe_stream || c->probe_n < 2) return fail(c, GPSIG_ERR_INVALID, "no clock probe was started");
+    HIPCHK(c, hipStreamSynchronize(c->probe_stream));
+    std::vector<unsigned long long> h(2 * size_t(c->probe_n));
+    HIPCHK(c, hipMemcpy(h.data(), c->probe_buf, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    const int n = c->probe_n;
+    double lo = 1e30, hi = 0.0;
+    for (int k = 1; k < n; ++k) {
+        const double dc = double(h[2 * k] - h[2 * (k - 1)]), dr = double(h[2 * k + 1] - h[2 * (k - 1) + 1]);
+        if (dr <= 0.0) continue;
+        const double g = dc / dr * 0.1;              // cycles per 10 ns -> GHz
+        if (g < lo) lo = g;
+        if (g > hi) hi = g;
+    }
+    const double dC = double(h[2 * (n - 1)] - h[0]), dR = double(h[2 * (n - 1) + 1] - h[1]);
+    if (ghz_mean) *ghz_mean = dR > 0.0 ? dC / dR * 0.1 : 0.0;
+    if (ghz_min) *ghz_min = lo < 1e29 ? lo : 0.0;
+    if (ghz_max) *ghz_max = hi;
+    if (covered_ms) *covered_ms = dR * 1e-5;
+    c->probe_n = 0;
+    return GPSIG_OK;
+}
 
 int gpsig_seq_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
                           int32_t L1, int32_t L2, void* out) {

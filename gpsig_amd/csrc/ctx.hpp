@@ -106,6 +106,10 @@ struct gpsig_ctx {
     // HIP-graph capture (gpsig_graph_begin .. gpsig_graph_end): launches only -- nothing may allocate, upload or synchronise
     bool capturing = false, capture_failed = false;
     uint64_t alloc_gen = 0;         // bumped whenever a scratch buffer moves; a graph replays only against the generation it saw
+    // effective shader clock (gpsig_clock_probe_*): one sleeping wavefront on a stream of its own samples s_memtime / s_memrealtime
+    hipStream_t probe_stream = nullptr;
+    unsigned long long* probe_buf = nullptr;   // device, 2 * probe_cap counters
+    int probe_cap = 0, probe_n = 0;
 };
 
 struct gpsig_graph {

@@ -156,3 +156,53 @@ def test_gloo_sharded_covariances(n, world, increments):
     last block; more ranks than whole blocks)."""
     ret = _spawn_with_retry(_covs_worker, world, (n, increments))
     assert ret["err"] == 0.0 and ret["shapes"] == [(5, 5), (5, n), (n,)]
+
+
+# ---- bench.py --gpus N starts its own ranks (round 3) ------------------------------------------------------------------
+def _run_bench(args, env_extra, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    return pr.returncode, (json.loads(lines[-1]) if lines else None), pr.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun: two ranks come up (gloo here), rank 0 reports both of them."""
+    rc, line, err = _run_bench(["--gpus", "2", "--rendezvous-check"], {"GPSIG_BENCH_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["ranks_seen"]["world_size"] == 2 and line["ranks_seen"]["backend"] == "gloo"
+    assert sorted(r["rank"] for r in line["ranks_seen"]["ranks"]) == [0, 1]
+    assert len({r["pid"] for r in line["ranks_seen"]["ranks"]}) == 2
+    assert line["ranks_seen"]["launched_by"] == "bench.py itself"
+
+
+def test_bench_refuses_fewer_gpus_than_ranks():
+    """Under the nccl backend a node with fewer GPUs than --gpus must fail, not report a smaller run as n_gpus = N."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 64:
+        pytest.skip("a node with 64 GPUs")
+    rc, line, err = _run_bench(["--gpus", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {"GPSIG_BENCH_BACKEND": "nccl"})
+    assert rc != 0 and line is None
+    assert "--gpus 64" in err
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    rc, line, err = _run_bench(["--gpus", "1", "--steps", "1", "--no-cpu-baseline"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and line is None and "WORLD_SIZE=2" in err
+
+
+def test_bench_rank_launch_command():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cmd = mod.rank_launch_command(8, ["--gpus", "8", "--steps", "5"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")

@@ -1,0 +1,69 @@
+"""bench.py on the GPU box: the N > 1 line is produced by N ranks bench.py starts itself, and the default line carries the
+measurement (clock, what binds, measured traffic)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    return json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_two_ranks_started_by_bench_itself():
+    """`python bench.py --gpus 2 --steps 1` WITHOUT torchrun (gloo: both ranks on the one GPU of this box): n_gpus is the number of
+    ranks that computed the line, and the gathered Gram equals single-rank evaluations."""
+    line = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--weak", "--no-cpu-baseline"], {"GPSIG_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2
+    seen = line["ranks_seen"]
+    assert seen["world_size"] == 2 and seen["backend"] == "gloo" and seen["launched_by"] == "bench.py itself"
+    assert sorted(r["rank"] for r in seen["ranks"]) == [0, 1] and all(r["arch"].startswith("gfx950") for r in seen["ranks"])
+    assert line["verify_max_abs_diff_vs_single_rank"] <= 1e-12
+    assert line["rel_err"] <= 1e-6
+
+
+def test_clock_probe_reads_a_plausible_shader_clock():
+    import torch
+    from gpsig_amd import _lib, kernels
+    dev = torch.device("cuda:0")
+    ctx = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
+    kern = kernels.SignatureLinear(64 * 8, 8, 5)
+    X = torch.randn(1024, 64 * 8, dtype=torch.float64, device=dev)
+    kern.K(X)
+    torch.cuda.synchronize()
+    ctx.clock_probe_start(8.0, 32)
+    for _ in range(6):
+        kern.K(X)
+    torch.cuda.synchronize()
+    mean, lo, hi, window = ctx.clock_probe_read()
+    assert 0.5 < lo <= mean <= hi < 3.0, (mean, lo, hi)      # MI355X: 2.4 GHz peak engine clock
+    assert 6.0 < window < 12.0, window
+    with pytest.raises(ValueError):
+        ctx.clock_probe_read()                               # one read per start
+
+
+def test_default_line_carries_the_measurement():
+    line = _bench(["--steps", "5", "--warmup", "2"])
+    assert line["n_gpus"] == 1 and line["config"]["name"] == "c2" and line["rel_err"] <= 1e-6
+    rf = line["roofline"]
+    assert rf["bound"] == "valu-issue" and 0.3 < rf["issue_frac"] <= 1.05 and 0.2 < rf["alu_frac"] < 1.0
+    assert rf["frac"] == rf["stream_frac"] and rf["unit"] == "GB/s"
+    assert 1.0 < line["clock_ghz"] < 2.6
+    assert rf["traffic"] and rf["traffic_source"]["how"].startswith("measured by this run")
+    assert "seq_gram_kernel" in rf["traffic_source"]["kernel"]
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    names = [s["name"] for s in line["secondary"]]
+    assert names == ["c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf"]
+    for s in line["secondary"]:
+        assert "error" not in s, s
+        assert s["rel_err"] <= (1e-4 if s["dtype"] == "f32" else 1e-6) and s["ms_per_step"] > 0 and s["clock_ghz"] > 1.0
+    assert line["secondary"][1]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
