@@ -395,29 +395,32 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
         barrier()
         est_ms = (time.perf_counter() - t_w) * 1e3 * steps
     ctx.timing_reset()
+    barrier()
     probe = False
-    try:        # the shader clock over (most of) the timed region; the first warm-up step includes one-off work, so cap by it
-        ctx.clock_probe_start(max(0.2, min(est_ms * 0.9, 30000.0)), 64)
+    try:        # the shader clock over the timed region: a sleeping wavefront on a stream of its own, told to leave below
+        ctx.clock_probe_start(max(1.0, min(est_ms * 1.2, 30000.0)), 128)
         probe = True
     except Exception:
         probe = False
-    barrier()
     t0 = time.perf_counter()
     out = None
     for _ in range(steps):
         out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms, launches, _ = ctx.timing_get()      # HIP events around the dominant kernel, on the stream it was launched on
     clock = None
-    if probe:
+    if probe:   # before the device-wide synchronisation of barrier(), which would wait for the probe's own deadline
         try:
+            torch.cuda.current_stream(dev).synchronize()
             g_mean, g_min, g_max, cov_ms = ctx.clock_probe_read()
-            clock = {"mean": g_mean, "min": g_min, "max": g_max, "window_ms": cov_ms, "timed_region_ms": dt * 1e3,
-                     "how": "one sleeping wavefront on a stream of its own: s_memtime (shader cycles) against s_memrealtime (100 MHz), "
-                            "64 readings spread over the window, started just before the timed region"}
+            clock = {"mean": g_mean, "min": g_min, "max": g_max, "window_ms": cov_ms,
+                     "how": "one sleeping wavefront on a stream of its own: s_memtime (shader cycles) against s_memrealtime (100 MHz), readings "
+                            "spread over the timed region (tools/clockcheck.hip checks the counter against an issue-bound loop)"}
         except Exception:
             clock = None
+    barrier()
+    dt = time.perf_counter() - t0
+    if clock:
+        clock["timed_region_ms"] = dt * 1e3
+    kernel_ms, launches, _ = ctx.timing_get()      # HIP events around the dominant kernel, on the stream it was launched on
 
     if world > 1:
         tt = torch.tensor([dt, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)

@@ -1508,8 +1508,9 @@ void gpsig_ctx_destroy(gpsig_ctx* c) {
     for (TaskSlot& t : c->task_slots)
         if (t.buf.p) (void)hipFree(t.buf.p);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    if (c->probe_stream) { (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
+    if (c->probe_stream) { if (c->probe_stop) *c->probe_stop = 1; (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
     if (c->probe_buf) (void)hipFree(c->probe_buf);
+    if (c->probe_stop) (void)hipHostFree(const_cast<int*>(c->probe_stop));
     solver_release(c->blas_handle);
     delete c;
 }
@@ -1646,20 +1647,31 @@ int gpsig_timing_get(gpsig_ctx* c, double* kernel_ms, int64_t* launches, int64_t
 
 // ---- effective shader clock while other kernels run -------------------------------------------------------------------
 // One wavefront on a non-blocking stream of its own sleeps and, every `interval` ticks of the constant 100 MHz counter
-// (s_memrealtime), stores that counter next to the shader-clock counter (s_memtime: one tick per shader cycle,
-// MI355X_MICROARCH.md "s_memtime tick vs SQ PMC units").  The ratio of the two differences is the clock the chip ran at --
-// float64-heavy kernels pull it from 2.4 GHz down to about 2.0 (DVFS), box by box and minute by minute.
-static __global__ void clock_probe_kernel(unsigned long long* out, int nsamp, unsigned long long interval) {
+// (s_memrealtime), stores that counter next to the shader-clock counter (s_memtime: one tick per shader cycle -- checked
+// against an issue-bound loop of known length, tools/clockcheck.hip: 2.40 GHz on an idle chip, 2.14 with every SIMD on
+// v_fma_f64).  The ratio of the two differences is the clock the chip ran at.  The wave leaves when the host raises `stop`
+// (pinned host memory, read over the bus between naps), after `nsamp` readings, or when `deadline` ticks have passed.
+static __global__ void clock_probe_kernel(unsigned long long* out, int* count, int nsamp, unsigned long long interval,
+                                          unsigned long long deadline, const int* stop) {
     if (threadIdx.x != 0) return;
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
-    for (int k = 0; k < nsamp; ++k) {
-        const unsigned long long target = r0 + (unsigned long long)k * interval;
-        while (__builtin_amdgcn_s_memrealtime() < target) __builtin_amdgcn_s_sleep(100);
-        const unsigned long long cyc = __builtin_amdgcn_s_memtime();
-        const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
-        out[2 * k] = cyc;
-        out[2 * k + 1] = rt;
+    unsigned long long next = r0;
+    int k = 0;
+    while (k < nsamp) {
+        const unsigned long long r = __builtin_amdgcn_s_memrealtime();
+        const bool leave = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || r - r0 > deadline;
+        if (r >= next || leave) {
+            const unsigned long long cyc = __builtin_amdgcn_s_memtime();
+            const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+            out[2 * k] = cyc;
+            out[2 * k + 1] = rt;
+            ++k;
+            next += interval;
+        }
+        if (leave) break;
+        __builtin_amdgcn_s_sleep(100);
     }
+    *count = k;
 }
 
 int gpsig_clock_probe_start(gpsig_ctx* c, double duration_ms, int32_t samples) {
@@ -1669,16 +1681,30 @@ int gpsig_clock_probe_start(gpsig_ctx* c, double duration_ms, int32_t samples) {
         return fail(c, GPSIG_ERR_INVALID, "clock probe: duration in (0, 60000] ms and 2..4096 samples");
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->probe_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->probe_stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamSynchronize(c->probe_stream));
+    if (!c->probe_stop) {
+        void* hp = nullptr;
+        HIPCHK(c, hipHostMalloc(&hp, 64, hipHostMallocMapped));
+        c->probe_stop = static_cast<volatile int*>(hp);
+    }
+    if (c->probe_n) {                       // a probe that was never read: let it go first
+        *c->probe_stop = 1;
+        HIPCHK(c, hipStreamSynchronize(c->probe_stream));
+    }
+    *c->probe_stop = 0;
     if (samples > c->probe_cap) {
         if (c->probe_buf) HIPCHK(c, hipFree(c->probe_buf));
         c->probe_buf = nullptr;
         c->probe_cap = 0;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->probe_buf), sizeof(unsigned long long) * 2 * size_t(samples)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->probe_buf), sizeof(unsigned long long) * (2 * size_t(samples) + 2)));
         c->probe_cap = samples;
     }
-    const unsigned long long interval = (unsigned long long)(duration_ms * 1e5 / double(samples - 1));    // 100 MHz ticks
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->probe_stream, c->probe_buf, int(samples), interval ? interval : 1ull);
+    unsigned long long interval = (unsigned long long)(duration_ms * 1e5 / double(samples - 1));    // 100 MHz ticks
+    if (!interval) interval = 1;
+    int* dstop = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&dstop), const_cast<int*>(c->probe_stop), 0));
+    int* count = reinterpret_cast<int*>(c->probe_buf + 2 * size_t(c->probe_cap));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->probe_stream, c->probe_buf, count, int(samples), interval,
+                       (unsigned long long)(duration_ms * 1e5 * 1.25) + 1000ull, dstop);
     HIPCHK(c, hipGetLastError());
     c->probe_n = samples;
     return GPSIG_OK;
@@ -1687,14 +1713,17 @@ int gpsig_clock_probe_start(gpsig_ctx* c, double duration_ms, int32_t samples) {
 int gpsig_clock_probe_read(gpsig_ctx* c, double* ghz_mean, double* ghz_min, double* ghz_max, double* covered_ms) {
     if (!c) return GPSIG_ERR_INVALID;
     if (!c->probe_stream || c->probe_n < 2) return fail(c, GPSIG_ERR_INVALID, "no clock probe was started");
+    *c->probe_stop = 1;                     // the wave takes one last reading and leaves
     HIPCHK(c, hipStreamSynchronize(c->probe_stream));
-    std::vector<unsigned long long> h(2 * size_t(c->probe_n));
+    c->probe_n = 0;
+    std::vector<unsigned long long> h(2 * size_t(c->probe_cap) + 2);
     HIPCHK(c, hipMemcpy(h.data(), c->probe_buf, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-    const int n = c->probe_n;
+    const int n = *reinterpret_cast<const int*>(&h[2 * size_t(c->probe_cap)]);
+    if (n < 2) return fail(c, GPSIG_ERR_INVALID, "the clock probe took %d reading(s): it was read before it ran", n);
     double lo = 1e30, hi = 0.0;
     for (int k = 1; k < n; ++k) {
         const double dc = double(h[2 * k] - h[2 * (k - 1)]), dr = double(h[2 * k + 1] - h[2 * (k - 1) + 1]);
-        if (dr <= 0.0) continue;
+        if (dr < 100.0) continue;                    // readings less than a microsecond apart (the last one, taken on leaving)
         const double g = dc / dr * 0.1;              // cycles per 10 ns -> GHz
         if (g < lo) lo = g;
         if (g > hi) hi = g;
@@ -1704,7 +1733,6 @@ int gpsig_clock_probe_read(gpsig_ctx* c, double* ghz_mean, double* ghz_min, doub
     if (ghz_min) *ghz_min = lo < 1e29 ? lo : 0.0;
     if (ghz_max) *ghz_max = hi;
     if (covered_ms) *covered_ms = dR * 1e-5;
-    c->probe_n = 0;
     return GPSIG_OK;
 }
 

@@ -110,6 +110,7 @@ struct gpsig_ctx {
     hipStream_t probe_stream = nullptr;
     unsigned long long* probe_buf = nullptr;   // device, 2 * probe_cap counters
     int probe_cap = 0, probe_n = 0;
+    volatile int* probe_stop = nullptr;        // pinned host memory the wave polls: raised by gpsig_clock_probe_read
 };
 
 struct gpsig_graph {

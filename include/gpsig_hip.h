@@ -129,10 +129,11 @@ int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
 int gpsig_timing_reset(gpsig_ctx* ctx);
 int gpsig_timing_get(gpsig_ctx* ctx, double* kernel_ms, int64_t* launches, int64_t* pairs);
 /* Effective shader clock while the calls that follow run (diagnostics for benchmarks; no reference analogue): a single sleeping
- * wavefront on a stream of its own takes `samples` readings of s_memtime (shader cycles) against s_memrealtime (100 MHz) spread
- * over `duration_ms`; _read waits for it and returns the mean / smallest / largest clock between consecutive readings in GHz
- * and the time the readings span.  float64-heavy kernels run this chip at about 2.0 GHz instead of 2.4 (DVFS), and the value
- * differs from box to box: a benchmark line should carry it. */
+ * wavefront on a stream of its own takes up to `samples` readings of s_memtime (shader cycles) against s_memrealtime (100 MHz),
+ * duration_ms / (samples - 1) apart; _read tells it to take a last reading and leave, waits for it, and returns the mean /
+ * smallest / largest clock between consecutive readings in GHz and the time the readings span (it leaves by itself after 1.25 x
+ * duration_ms).  Read it before any device-wide synchronisation, which would wait for the probe.  float64-heavy kernels run
+ * this chip at 2.0-2.2 GHz instead of 2.4 (DVFS), differently from box to box: a benchmark line should carry the value. */
 int gpsig_clock_probe_start(gpsig_ctx* ctx, double duration_ms, int32_t samples);
 int gpsig_clock_probe_read(gpsig_ctx* ctx, double* ghz_mean, double* ghz_min, double* ghz_max, double* covered_ms);
 

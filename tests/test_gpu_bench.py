@@ -4,6 +4,7 @@ import json
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -40,15 +41,19 @@ def test_clock_probe_reads_a_plausible_shader_clock():
     X = torch.randn(1024, 64 * 8, dtype=torch.float64, device=dev)
     kern.K(X)
     torch.cuda.synchronize()
-    ctx.clock_probe_start(8.0, 32)
+    ctx.clock_probe_start(200.0, 64)                        # far longer than the work: the read below ends it
+    t0 = time.perf_counter()
     for _ in range(6):
         kern.K(X)
-    torch.cuda.synchronize()
+    torch.cuda.current_stream(dev).synchronize()
+    busy_ms = (time.perf_counter() - t0) * 1e3
     mean, lo, hi, window = ctx.clock_probe_read()
-    assert 0.5 < lo <= mean <= hi < 3.0, (mean, lo, hi)      # MI355X: 2.4 GHz peak engine clock
-    assert 6.0 < window < 12.0, window
+    assert 1.0 < lo <= mean <= hi < 2.6, (mean, lo, hi)      # MI355X: 2.4 GHz peak engine clock, lower under float64 load
+    assert 0.5 * busy_ms < window < busy_ms + 5.0, (window, busy_ms)
     with pytest.raises(ValueError):
         ctx.clock_probe_read()                               # one read per start
+    ctx.clock_probe_start(2.0, 8)                            # a probe nobody reads leaves by itself
+    torch.cuda.synchronize()
 
 
 def test_default_line_carries_the_measurement():
