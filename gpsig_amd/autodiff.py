@@ -221,6 +221,42 @@ class _TensVsSeqLevels(torch.autograd.Function):
         return gZ.to(ctx.dt[0]), gX.to(ctx.dt[1]), gp0, None, None
 
 
+class _TensVsSeqWeighted(torch.autograd.Function):
+    """sum_m fac[m][n] * _K_tens_vs_seq(Z, X)[m][t][n] -> (T, N): the level sum of kernels.py:572-588 / :638-667 taken inside the HIP
+    kernel (gpsig_tens_vs_seq_weighted), so that a training step never holds the (M+1, T, N) level array or its gradient; the
+    per-sequence factors fac (M+1, N) -- sigma * variances / sqrt(level diagonals + jitter) -- are a differentiable input."""
+
+    @staticmethod
+    def forward(ctx, Zs, Xs, fac, p0, spec, increments):
+        Z, X = _c(Zs), _c(Xs)
+        F = _c(fac).t().contiguous()                                  # (N, M+1): what a lane reads per sequence
+        t, d = Z.shape[1], Z.shape[-1]
+        n, l = X.shape[:2]
+        keep = []
+        p = spec.params(d, _p0_value(p0), keep)
+        out = torch.empty((t, n), dtype=torch.float64, device=Z.device)
+        _ctx_for(Z).call("gpsig_tens_vs_seq_weighted", p, _ptr(Z), _ptr(X), t, n, l, int(bool(increments)), _ptr(F), _ptr(out))
+        ctx.spec, ctx.has_p0, ctx.increments = spec, p0 is not None, bool(increments)
+        ctx.dt = (Zs.dtype, Xs.dtype, fac.dtype)
+        ctx.save_for_backward(Z, X, F, p0 if p0 is not None else Z.new_empty(0))
+        return out.to(_out_dtype(Zs, Xs, fac))
+
+    @staticmethod
+    def backward(ctx, G):
+        Z, X, F, p0 = ctx.saved_tensors
+        t, d = Z.shape[1], Z.shape[-1]
+        n, l = X.shape[:2]
+        keep = []
+        p = ctx.spec.params(d, _p0_value(p0) if ctx.has_p0 else 0.0, keep)
+        G = _c(G)
+        gZ, gX, gF = torch.empty_like(Z), torch.empty_like(X), torch.empty_like(F)
+        gb = torch.zeros(2, dtype=torch.float64, device=Z.device)
+        _ctx_for(Z).call("gpsig_tens_vs_seq_weighted_grad", p, _ptr(Z), _ptr(X), t, n, l, int(ctx.increments), _ptr(F), _ptr(G), _ptr(gZ), _ptr(gX),
+                         _ptr(gF), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
+        gp0 = gb[0].to(p0.device).reshape(p0.shape).to(p0.dtype) if ctx.has_p0 else None
+        return gZ.to(ctx.dt[0]), gX.to(ctx.dt[1]), gF.t().to(ctx.dt[2]), gp0, None, None
+
+
 # ---- scaling (gpsig/kernels.py:343-398, gpsig/lags.py) in torch ------------------------------------------------------
 def _lin_interp(time, X, time_query):
     """gpsig/lags.py:7-38 (3-D branch :32-33).  X (N, L, d), time (L,), time_query (L, p) -> (N, L, p, d)."""
@@ -329,6 +365,7 @@ class SignatureKernelModule(torch.nn.Module):
     def _diag_levels(self, Xs): return _SeqDiagLevels.apply(Xs, self.p0, self._spec)
     def _tens_levels(self, Zs, increments): return _TensGramLevels.apply(Zs, self.p0, self._spec, increments)
     def _tvs_levels(self, Zs, Xs, increments): return _TensVsSeqLevels.apply(Zs, Xs, self.p0, self._spec, increments)
+    def _tvs_weighted(self, Zs, Xs, fac, increments): return _TensVsSeqWeighted.apply(Zs, Xs, fac, self.p0, self._spec, increments)
 
     def _w(self):
         return self.sigma * self.variances                                                          # kernels.py:471
@@ -371,11 +408,16 @@ class SignatureKernelModule(torch.nn.Module):
     def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False, presliced=False):
         """kernels.py:539-588."""
         Xs = self.scale_sequences(self._seq3(X, presliced))
+        if not return_levels:
+            # the same numbers with the level sum taken inside the kernel: (M+1, N) factors in, (T, N) out
+            fac = self._w()[:, None].expand(-1, Xs.shape[0])                                        # :584
+            if self.kern.normalization:
+                fac = fac / torch.sqrt(self._diag_levels(Xs) + JITTER)                              # :576-581
+            return self._tvs_weighted(self.scale_tensors(Z), Xs, fac, increments)                   # :588
         K = self._tvs_levels(self.scale_tensors(Z), Xs, increments)
         if self.kern.normalization:
             K = K / torch.sqrt(self._diag_levels(Xs) + JITTER)[:, None, :]                          # :576-581
-        K = K * self._w()[:, None, None]
-        return K if return_levels else K.sum(dim=0)
+        return K * self._w()[:, None, None]
 
     def K_tens_n_seq_covs(self, Z, X, full_X_cov=False, return_levels=False, increments=False, presliced=False):
         """kernels.py:591-671: Kzz, Kzx and Kxx (full or diagonal) from one scaling of the inputs."""
@@ -383,8 +425,29 @@ class SignatureKernelModule(torch.nn.Module):
         N = Xs.shape[0]
         Zs = self.scale_tensors(Z)
         Kzz = self._tens_levels(Zs, increments)                                                     # :623
-        Kzx = self._tvs_levels(Zs, Xs, increments)                                                  # :624
         w = self._w()
+        if not return_levels:
+            # Kzx as a weighted level sum taken inside the kernel (no (M+1, T, N) array in a training step): the factors are what
+            # :638 / :660 divide by and :667 multiplies with
+            if full_X_cov:
+                Kxx = self._seq_levels(Xs)                                                          # :630
+                fac = w[:, None].expand(-1, N)
+                if self.kern.normalization:
+                    Kxx = Kxx + JITTER * torch.eye(N, dtype=Kxx.dtype, device=Kxx.device)[None]     # :633
+                    dsq = torch.sqrt(torch.diagonal(Kxx, dim1=1, dim2=2))
+                    Kxx = Kxx / (dsq[:, :, None] * dsq[:, None, :])                                 # :637
+                    fac = fac / dsq                                                                 # :638
+                Kxx = (Kxx * w[:, None, None]).sum(dim=0)
+            else:
+                dl = self._diag_levels(Xs)                                                          # :653
+                if self.kern.normalization:
+                    fac = w[:, None] / torch.sqrt(dl + JITTER)                                      # :656-660
+                    Kxx = w.sum().expand(N)                                                         # :661
+                else:
+                    fac = w[:, None].expand(-1, N)
+                    Kxx = (dl * w[:, None]).sum(dim=0)
+            return (Kzz * w[:, None, None]).sum(dim=0), self._tvs_weighted(Zs, Xs, fac, increments), Kxx
+        Kzx = self._tvs_levels(Zs, Xs, increments)                                                  # :624
         if full_X_cov:
             Kxx = self._seq_levels(Xs)                                                              # :630
             if self.kern.normalization:
@@ -400,11 +463,7 @@ class SignatureKernelModule(torch.nn.Module):
                 Kxx = w[:, None].expand(-1, N)                                                      # :661
             else:
                 Kxx = Kxx * w[:, None]
-        Kzz = Kzz * w[:, None, None]
-        Kzx = Kzx * w[:, None, None]
-        if return_levels:
-            return Kzz, Kzx, Kxx
-        return Kzz.sum(dim=0), Kzx.sum(dim=0), Kxx.sum(dim=0)
+        return Kzz * w[:, None, None], Kzx * w[:, None, None], Kxx
 
     def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False, presliced=False):
         """kernels.py:674-761 (``X`` = inducing sequences, never sliced: :679-680; ``X2`` = data), including the double division

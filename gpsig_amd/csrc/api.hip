@@ -1230,6 +1230,29 @@ static int e_tens_vs_seq_levels(gpsig_ctx* c, const gpsig_params* p, const void*
     return finish(c);
 }
 
+// sum_m fac[n][m] level_m[t][n] of the raw levels (inputs as they come), the level sum taken inside the kernels' epilogue
+static int e_tens_vs_seq_weighted(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N, int32_t L,
+                               int32_t increments, const void* fac, void* out) {
+    ENTER(c, p);
+    const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
+    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    if (!fac && N > 0) return fail(c, GPSIG_ERR_INVALID, "null factor array");
+    const void *dZ, *dX, *dF;
+    CHK(in_dev(c, B_IN0, Z, sizeof(TT) * size_t(lt) * T * E * d, &dZ));
+    CHK(in_dev(c, B_IN1, X, sizeof(TT) * size_t(N) * L * d, &dX));
+    CHK(in_dev(c, B_IN2, fac, sizeof(TT) * size_t(N) * (p->num_levels + 1), &dF));
+    const size_t ob = sizeof(TT) * size_t(T) * N;
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    gpsig_params q = *p;
+    q.num_features = d; q.num_lags = 0; q.lengthscales = nullptr;      // raw entry point: columns are taken as they come
+    const void *ZT, *ZS;
+    CHK(prep_tensors(c, &q, false, dZ, T, E, &ZT, &ZS));
+    CHK(tens_vs_seq_device(c, &q, false, dZ, ZT, ZS, dX, T, N, L, increments, dF, nullptr, 0, dout));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
 static int e_kernel_K(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2, int32_t L1,
                    int32_t L2, int32_t return_levels, void* out) {
     ENTER(c, p);
@@ -1547,6 +1570,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "grad_scratch_mb")) c->grad_scratch_mb = value > 0 ? value : 4096;
     else if (!strcmp(name, "grad_impl")) c->grad_impl = value;
     else if (!strcmp(name, "tvs_zreg")) c->tvs_zreg = value;
+    else if (!strcmp(name, "tvs_grad_tile")) c->tvs_grad_tile = value;
     else if (!strcmp(name, "keep_reset")) c->keep_reset = value ? 1 : 0;
     else if (!strcmp(name, "pk2")) c->allow_pk2 = value;
     else if (!strcmp(name, "f32_pack")) c->f32_pack = value;
@@ -1756,6 +1780,13 @@ int gpsig_tens_vs_seq_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z,
                              int32_t L, int32_t increments, void* out) {
     if (!c || !p) return GPSIG_ERR_INVALID;
     return p->dtype == GPSIG_F32 ? Impl<float>::e_tens_vs_seq_levels(c, p, Z, X, T, N, L, increments, out) : Impl<double>::e_tens_vs_seq_levels(c, p, Z, X, T, N, L, increments, out);
+}
+
+int gpsig_tens_vs_seq_weighted(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N, int32_t L,
+                               int32_t increments, const void* fac, void* out) {
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_tens_vs_seq_weighted(c, p, Z, X, T, N, L, increments, fac, out)
+                                 : Impl<double>::e_tens_vs_seq_weighted(c, p, Z, X, T, N, L, increments, fac, out);
 }
 
 int gpsig_kernel_K(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2, int32_t L1,

@@ -28,6 +28,7 @@ enum BufId {
     B_TASKS, B_W, B_XT, B_ZT, B_ZS, B_ZL, B_ZN, B_TMP0, B_TMP1,
     B_LS, B_LR0, B_LR1, B_LR2, B_LR3, B_LR4, B_LR5, B_LR6, B_LR7, B_LR8,
     B_GR0, B_GR1, B_GR2, B_GR3, B_GR4, B_GR5, B_GR6, B_GR7,   // gradient path scratch
+    B_GR7B, B_TW0, B_TW1, B_TW2,                              // weighted tensor-vs-sequence sums: partial factor gradients; level arrays of the fallback
     B_SPEC,                                                    // spectral base-kernel table
     B_COUNT
 };
@@ -81,6 +82,7 @@ struct gpsig_ctx {
     int lr_fused_pad = 1;         // row stride of its LDS arrays beyond the time steps rounded up to 64, in doubles (A/B runs)
     int lr_fused_variant = 0;     // its workgroup size / unrolling (lr_fused_inst.hip), for A/B runs
     int lr_fused = 1;             // low-rank sequence features: 1 = the fused kernel where a sequence's arrays fit LDS, 0 = one kernel per op
+    int tvs_grad_tile = 1;        // tensor-vs-sequence reverse pass: 1 = the tile kernel (tvs_grad_tile_kernel.hpp) where built, 0 = the round-1 kernels
     int tvs_zreg = -1;            // tensor-lane gradient: components in registers (1) or LDS (0); -1 = planner's choice
     std::string err;
     DevBuf buf[B_COUNT];

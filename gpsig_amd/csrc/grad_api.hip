@@ -20,6 +20,9 @@ Wave2LaunchFn lam_undo_lookup_ptd_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptd_gen(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
+// tvs_grad_api.hip: the tile kernel of the tensor-vs-sequence reverse pass (tvs_grad_tile_kernel.hpp)
+int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, const double* X, const double* G, int64_t Tn, int64_t N,
+                         int L, int increments, const double* fac, double* gZ, double* gX, double* gfac, double* gb, size_t budget, bool* done);
 }  // namespace gpsig
 
 using namespace gpsig;
@@ -760,7 +763,13 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     CHK(gbase_begin(c, &dgb));
     // kernels without a differentiable base parameter skip the accumulation (one same-address atomic per wavefront otherwise)
     double* const kgb = (p->base_kernel == GPSIG_BASE_POLY || p->base_kernel == GPSIG_BASE_MIX) ? dgb : nullptr;
-    if (T == 0 || N == 0) {
+    bool tiled = false;
+    if (T > 0 && N > 0 && c->grad_impl == 0 && c->tvs_grad_tile != 0)
+        CHK(tvs_grad_tile_device(c, p, d, static_cast<const double*>(dZ), static_cast<const double*>(dX), static_cast<const double*>(dG), T, N, L,
+                                 increments, nullptr, static_cast<double*>(dgZ), static_cast<double*>(dgX), nullptr, kgb, scratch_budget(c), &tiled));
+    if (tiled) {
+        // both gradients were written by the tile kernel's reductions
+    } else if (T == 0 || N == 0) {
         if (zb) CHK(zero_async(c, dgZ, zb));
         if (xb) CHK(zero_async(c, dgX, xb));
     } else if (c->grad_impl == 0 && !(p->order > 1 && M > 1) && tvs_lanet_available(c, DP, M, L)) {
@@ -838,6 +847,71 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     CHK(out_done(c, gZ, dgZ, zb));
     CHK(out_done(c, gX, dgX, xb));
     CHK(gbase_end(c, dgb, g_base));
+    return finish(c);
+}
+
+// The weighted level sum of gpsig_tens_vs_seq_weighted: gradients with respect to Z, X and the factors.  The tile kernel takes the
+// (T, N) upstream gradient and the factors as they are; other shapes go through the level primitives (the level array and its
+// upstream gradient in scratch memory).
+int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N, int32_t L,
+                                    int32_t increments, const void* fac, const void* G, void* gZ, void* gX, void* gfac, double* g_base) {
+    int d, DP;
+    CHK(grad_check(c, p, &d, &DP));
+    if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
+    if (N > 0x7fffffff || T > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 items");
+    const int M = p->num_levels, M1 = M + 1, lt = M * (M + 1) / 2;
+    const size_t zb = sizeof(double) * size_t(lt) * T * (increments ? 2 : 1) * d, xb = sizeof(double) * size_t(N) * L * d;
+    const size_t gb = sizeof(double) * size_t(T) * N, fb = sizeof(double) * size_t(N) * M1;
+    const void *dZ, *dX, *dG, *dF;
+    CHK(in_dev(c, B_IN0, Z, zb, &dZ));
+    CHK(in_dev(c, B_IN1, X, xb, &dX));
+    CHK(in_dev(c, B_IN2, G, gb, &dG));
+    CHK(in_dev(c, B_TW2, fac, fb, &dF));
+    void *dgZ, *dgX, *dgF;
+    CHK(out_dev(c, B_OUT0, gZ, zb, &dgZ));
+    CHK(out_dev(c, B_OUT1, gX, xb, &dgX));
+    CHK(out_dev(c, B_OUT2, gfac, fb, &dgF));
+    const bool has_base = p->base_kernel == GPSIG_BASE_POLY || p->base_kernel == GPSIG_BASE_MIX;
+    bool tiled = false;
+    if (T > 0 && N > 0 && c->grad_impl == 0 && c->tvs_grad_tile != 0) {
+        double* dgb;
+        CHK(gbase_begin(c, &dgb));
+        CHK(tvs_grad_tile_device(c, p, d, static_cast<const double*>(dZ), static_cast<const double*>(dX), static_cast<const double*>(dG), T, N, L,
+                                 increments, static_cast<const double*>(dF), static_cast<double*>(dgZ), static_cast<double*>(dgX),
+                                 static_cast<double*>(dgF), has_base ? dgb : nullptr, scratch_budget(c), &tiled));
+        if (tiled) CHK(gbase_end(c, dgb, g_base));
+    }
+    if (!tiled) {
+        if (T == 0 || N == 0) {
+            if (zb) CHK(zero_async(c, dgZ, zb));
+            if (xb) CHK(zero_async(c, dgX, xb));
+            if (fb) CHK(zero_async(c, dgF, fb));
+            if (g_base && c->ptr_mode == GPSIG_PTR_HOST) g_base[0] = g_base[1] = 0.0;
+            else if (g_base) CHK(zero_async(c, g_base, 2 * sizeof(double)));
+        } else {
+            void *lev, *glev, *tgb;
+            CHK(ensure(c, B_TW0, sizeof(double) * size_t(M1) * T * N + 8, &lev));
+            CHK(ensure(c, B_TW1, sizeof(double) * size_t(M1) * T * N + 8, &glev));
+            CHK(ensure(c, B_GR7B, 2 * sizeof(double), &tgb));
+            const int mode = c->ptr_mode;
+            c->ptr_mode = GPSIG_PTR_DEVICE;                  // the operands are on the device by now
+            int rc = gpsig_tens_vs_seq_levels(c, p, dZ, dX, T, N, L, increments, lev);
+            if (rc == GPSIG_OK) {
+                hipLaunchKernelGGL(weighted_upstream_levels_kernel, dim3(grid_for(int64_t(M1) * T * N)), dim3(256), 0, c->stream,
+                                   static_cast<const double*>(dG), static_cast<const double*>(dF), M1, T, N, static_cast<double*>(glev));
+                hipLaunchKernelGGL(weighted_gfac_kernel, dim3(grid_for(N * M1)), dim3(256), 0, c->stream, static_cast<const double*>(dG),
+                                   static_cast<const double*>(lev), M1, T, N, static_cast<double*>(dgF));
+                rc = gpsig_tens_vs_seq_levels_grad(c, p, dZ, dX, T, N, L, increments, glev, dgZ, dgX, static_cast<double*>(tgb));
+            }
+            c->ptr_mode = mode;
+            CHK(rc);
+            HIPCHK(c, hipGetLastError());
+            if (g_base) HIPCHK(c, hipMemcpyAsync(g_base, tgb, 2 * sizeof(double), mode == GPSIG_PTR_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    CHK(out_done(c, gZ, dgZ, zb));
+    CHK(out_done(c, gX, dgX, xb));
+    CHK(out_done(c, gfac, dgF, fb));
     return finish(c);
 }
 

@@ -72,6 +72,29 @@ __global__ void grad_unpad_pm_rows_kernel(const double* __restrict__ ZP, double*
     }
 }
 
+// Weighted level sums  S[t][n] = sum_m fac[n][m] level_m[t][n]  (gpsig_tens_vs_seq_weighted) through the level primitives, for the shapes
+// the tile kernels are not built for: upstream gradient of the levels, and the gradient with respect to the factors.
+__global__ void weighted_upstream_levels_kernel(const double* __restrict__ G, const double* __restrict__ fac, int M1, int64_t T, int64_t N,
+                                                double* __restrict__ Glev) {
+    const int64_t total = int64_t(M1) * T * N;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t n = e % N, t = (e / N) % T;
+        const int m = int(e / (N * T));
+        Glev[e] = G[t * N + n] * fac[n * M1 + m];
+    }
+}
+__global__ void weighted_gfac_kernel(const double* __restrict__ G, const double* __restrict__ lev, int M1, int64_t T, int64_t N,
+                                     double* __restrict__ gfac) {
+    const int64_t total = N * M1;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t n = e % N;
+        const int m = int(e / N);
+        double s = 0.0;
+        for (int64_t t = 0; t < T; ++t) s = fma(G[t * N + n], lev[(int64_t(m) * T + t) * N + n], s);
+        gfac[n * M1 + m] = s;
+    }
+}
+
 // grid (ceil(N1 / 64), nj or 1); block 64
 template <int DP>
 __global__ void __launch_bounds__(64) seq_pair_grad_kernel(const SeqGradArgs A) {

@@ -106,6 +106,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "grad_impl"   gradient kernels: 0 planner's choice, 1 one pair per thread with the lattice in HBM scratch, 2 one pair per
  *                 thread scratch-free (tensor vs sequence), 3 wavefront kernel with the lattice in HBM scratch, 4 scratch-free wavefront
  *                 kernels (what the planner picks wherever they are built)
+ *   "tvs_grad_tile" reverse pass of the tensor-vs-sequence chains: 1 (default) the tile kernel (all levels in one reverse sweep per
+ *                 sequence, d/dx summed in LDS, no atomics) where it is built (order 1, at most 8 columns, at most 6 levels), 0 the round-1 kernels
  *   "tvs_zreg"    tensor-lane gradient: components in registers (1) or LDS (0), -1 automatic
  *   "tvs_tile"    tensor-vs-sequence tile kernel (levels split over the waves of a workgroup, coalesced result tiles):
  *                 -1 wherever it is built and there are at least 32 tensors, 0 never, 1 also for fewer tensors
@@ -167,6 +169,15 @@ int gpsig_tens_gram_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* Z,
  * _higher_order (signature_algs.py:101-160).  out: (M+1, T, N). */
 int gpsig_tens_vs_seq_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X,
                              int64_t T, int64_t N, int32_t L, int32_t increments, void* out);
+
+/* Weighted level sum of the tensor-vs-sequence levels,  out[t][n] = sum_m fac[n][m] * _K_tens_vs_seq(Z, X)[m][t][n]:  what
+ * K_tens_vs_seq (kernels.py:572-588) and the Kzx of K_tens_n_seq_covs (:638 / :660, :667) are once the per-sequence factors
+ * fac[n][m] = sigma variances[m] / sqrt(diag_m(x_n) + jitter) are known -- in one pass, the level sum taken in the kernel's
+ * epilogue, without the (M+1, T, N) level array ever reaching memory.  It is the form a training step uses (the factors are
+ * differentiable inputs; gpsig_tens_vs_seq_weighted_grad below).  Inputs are used as given, like the level primitives.
+ * fac: (N, M+1), out: (T, N), element type p->dtype. */
+int gpsig_tens_vs_seq_weighted(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
+                               int32_t L, int32_t increments, const void* fac, void* out);
 
 /* ---- end-to-end kernel evaluations (scaling, lags, normalisation, sigma*variances, level sum) */
 /* SignatureKernel.K (kernels.py:401-476).  out: (N1, N2), or (M+1, N1, N2) if return_levels. */
@@ -277,6 +288,13 @@ int gpsig_tens_gram_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const voi
 int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
                                   int32_t L, int32_t increments, const void* G /* (M+1, T, N) */, void* gZ, void* gX,
                                   double* g_base);
+
+/* Reverse pass of gpsig_tens_vs_seq_weighted: G (T, N) is the upstream gradient of the weighted sum; gZ, gX as above, gfac (N, M+1)
+ * the gradient with respect to the factors (through which the level diagonals of the sequences, sigma and the variances are
+ * reached: gpsig/kernels.py:572-581, :471).  float64. */
+int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
+                                    int32_t L, int32_t increments, const void* fac /* (N, M+1) */, const void* G /* (T, N) */,
+                                    void* gZ, void* gX, void* gfac /* (N, M+1) */, double* g_base);
 
 #ifdef __cplusplus
 }

@@ -190,16 +190,19 @@ def test_tensor_level_gradients(base, difference, increments):
     (kt.K_tens_vs_seq_levels(tZ, tX, increments) * torch.tensor(G)).sum().backward()
     keep = []
     p = _params(base, d, M, difference, keep)
-    for impl in (0, 1, 2):     # tensor lanes (default) / one pair per thread with a stored lattice / one pair per thread, scratch-free
+    # tile kernel (default) / tensor lanes, one level per sweep (round 1) / one pair per thread with a stored lattice / one pair per thread, scratch-free
+    for impl, tile in ((0, 1), (0, 0), (1, 1), (2, 1)):
         gZ, gX, gb = np.empty_like(Z), np.empty_like(X), np.zeros(2)
         ctx.set_option("grad_impl", impl)
+        ctx.set_option("tvs_grad_tile", tile)
         ctx.set_option("grad_scratch_mb", 1)     # several launches
         ctx.call("gpsig_tens_vs_seq_levels_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(G), _vp(gZ), _vp(gX), gb.ctypes.data_as(_P))
         ctx.set_option("grad_scratch_mb", 4096)
         ctx.set_option("grad_impl", 0)
-        assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9, (impl, rel(gZ, tZ.grad), rel(gX, tX.grad))
+        ctx.set_option("tvs_grad_tile", 1)
+        assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9, (impl, tile, rel(gZ, tZ.grad), rel(gX, tX.grad))
         if base in ("poly", "mix"):
-            assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
+            assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0])), (impl, tile)
     G2 = rng.standard_normal((M + 1, T, T))
     kt = _t_kern(base, d, M)
     tZ = torch.tensor(Z, requires_grad=True)
@@ -209,6 +212,102 @@ def test_tensor_level_gradients(base, difference, increments):
     assert rel(gZ, tZ.grad) < 1e-9
     if base in ("poly", "mix"):
         assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
+
+
+@pytest.mark.parametrize("M,T,N,L,d", [(1, 3, 5, 4, 2), (2, 70, 9, 1, 4), (3, 33, 130, 2, 5), (4, 65, 37, 13, 6), (4, 130, 20, 5, 3), (5, 40, 17, 6, 7),
+                                       (6, 9, 11, 7, 8), (4, 64, 64, 8, 1), (4, 130, 200, 50, 6)])
+@pytest.mark.parametrize("base", ["linear", "rbf", "matern32", "poly"])
+def test_tensor_vs_sequence_tile_gradient_kernel(M, T, N, L, d, base):
+    """tvs_grad_tile_kernel (round 3: every level of a wave in ONE reverse sweep per sequence, d/dx summed in LDS, no atomics) against
+    autograd of the oracle and against the round-1 kernels: 1 .. 6 levels (one to four waves per workgroup), widths 1 .. 8 (padded to
+    4 / 6 / 8), ragged tensor and sequence counts across lane, run and flush boundaries, a single time step, differences on / off,
+    increments on / off (lane pairs for the non-linear families, collapsed for the linear one), several sequence chunks."""
+    if N * T > 10000 and base in ("matern32", "poly"):
+        pytest.skip("the large case (two sequence chunks at a scratch budget of 1 MiB) runs for the two compile-time families")
+    rng = np.random.default_rng(1000 * M + T + d)
+    ctx = _host_ctx()
+    lt = M * (M + 1) // 2
+    for difference in (True, False):
+        for increments in (False, True):
+            if L == 1 and difference:
+                continue        # no increment to differentiate
+            Z = rng.standard_normal((lt, T, 2, d) if increments else (lt, T, d)) * 0.5
+            X = rng.standard_normal((N, L, d)) * 0.5
+            G = rng.standard_normal((M + 1, T, N))
+            kt = _t_kern(base, d, M, difference=difference)
+            tZ, tX = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+            (kt.K_tens_vs_seq_levels(tZ, tX, increments) * torch.tensor(G)).sum().backward()
+            keep = []
+            p = _params(base, d, M, difference, keep)
+            res = {}
+            for tile, mb in ((1, 4096), (1, 1), (0, 4096)):
+                if tile == 0 and M > 4:
+                    continue            # the round-1 tensor-lane kernel is built for four levels
+                gZ, gX, gb = np.empty_like(Z), np.empty_like(X), np.zeros(2)
+                ctx.set_option("tvs_grad_tile", tile)
+                ctx.set_option("grad_scratch_mb", mb)
+                try:
+                    ctx.call("gpsig_tens_vs_seq_levels_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(G), _vp(gZ), _vp(gX), gb.ctypes.data_as(_P))
+                finally:
+                    ctx.set_option("tvs_grad_tile", 1)
+                    ctx.set_option("grad_scratch_mb", 4096)
+                assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9, (tile, mb, difference, increments, rel(gZ, tZ.grad), rel(gX, tX.grad))
+                if base == "poly":
+                    assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0])), (tile, mb, difference, increments)
+                res[(tile, mb)] = (gZ, gX)
+
+
+@pytest.mark.parametrize("base,M,T,N,L,d,order", [("rbf", 4, 70, 45, 9, 6, 1), ("linear", 3, 33, 20, 5, 4, 1), ("poly", 4, 9, 70, 6, 3, 1),
+                                                   ("matern32", 2, 40, 12, 4, 2, 1), ("rbf", 4, 12, 9, 7, 12, 1), ("rbf", 3, 10, 8, 6, 3, 2),
+                                                   ("linear", 5, 66, 10, 8, 7, 1)])
+def test_weighted_tensor_vs_sequence_sum(base, M, T, N, L, d, order):
+    """gpsig_tens_vs_seq_weighted / _grad (round 3): sum_m fac[n][m] level_m[t][n] with the level sum inside the kernel, and its
+    gradients with respect to Z, X and the factors, against autograd of the oracle's level array -- through the tile kernels, through
+    the level primitives (tile kernels off; 12 columns; order 2), host and device pointers."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(7 * M + T)
+    lt = M * (M + 1) // 2
+    for increments in (False, True):
+        Z = rng.standard_normal((lt, T, 2, d) if increments else (lt, T, d)) * 0.5
+        X = rng.standard_normal((N, L, d)) * 0.5
+        F = rng.uniform(0.5, 1.5, (N, M + 1))
+        G = rng.standard_normal((T, N))
+        kt = _t_kern(base, d, M, order=order)
+        tZ, tX, tF = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True), torch.tensor(F, requires_grad=True)
+        want = (kt.K_tens_vs_seq_levels(tZ, tX, increments) * tF.t()[:, None, :]).sum(0)
+        (want * torch.tensor(G)).sum().backward()
+        keep = []
+        p = _params(base, d, M, True, keep, order=order)
+        ctx = _host_ctx()
+        for tile in (1, 0):
+            ctx.set_option("tvs_grad_tile", tile)
+            ctx.set_option("tvs_tile", -1 if tile else 0)
+            try:
+                out = np.empty((T, N))
+                ctx.call("gpsig_tens_vs_seq_weighted", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(F), _vp(out))
+                gZ, gX, gF, gb = np.empty_like(Z), np.empty_like(X), np.empty_like(F), np.zeros(2)
+                ctx.call("gpsig_tens_vs_seq_weighted_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(F), _vp(G), _vp(gZ), _vp(gX), _vp(gF),
+                         gb.ctypes.data_as(_P))
+            finally:
+                ctx.set_option("tvs_grad_tile", 1)
+                ctx.set_option("tvs_tile", -1)
+            assert rel(out, want) < 1e-10, (tile, increments, rel(out, want))
+            assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9 and rel(gF, tF.grad) < 1e-9, (
+                tile, increments, rel(gZ, tZ.grad), rel(gX, tX.grad), rel(gF, tF.grad))
+            if base == "poly":
+                assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0])), (tile, increments)
+        # device pointers (what gpsig_amd.autodiff passes)
+        dev = torch.device("cuda:0")
+        dctx = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
+        dctx.set_pointer_mode(_lib.PTR_DEVICE)
+        dZ, dX, dF, dG = (torch.tensor(a, device=dev) for a in (Z, X, F, G))
+        dgZ, dgX, dgF, dgb = torch.empty_like(dZ), torch.empty_like(dX), torch.empty_like(dF), torch.zeros(2, dtype=torch.float64, device=dev)
+        ptr = lambda t_: C.c_void_p(t_.data_ptr())
+        dctx.call("gpsig_tens_vs_seq_weighted_grad", p, ptr(dZ), ptr(dX), T, N, L, int(increments), ptr(dF), ptr(dG), ptr(dgZ), ptr(dgX), ptr(dgF),
+                  C.cast(dgb.data_ptr(), _P))
+        torch.cuda.synchronize()
+        assert rel(dgZ, tZ.grad) < 1e-9 and rel(dgX, tX.grad) < 1e-9 and rel(dgF, tF.grad) < 1e-9
+        kt.p0.grad = None
 
 
 @pytest.mark.parametrize("base", ["linear", "rbf", "poly", "matern32"])

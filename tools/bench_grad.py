@@ -8,7 +8,7 @@ import numpy as np, torch
 from gpsig_amd import kernels, models, likelihoods as LK, inducing_variables as iv, autodiff
 
 dev = torch.device("cuda:0")
-for _env, _opt in (("GPSIG_TVS_ZREG", "tvs_zreg"), ("GPSIG_GRAD_IMPL", "grad_impl")):
+for _env, _opt in (("GPSIG_TVS_ZREG", "tvs_zreg"), ("GPSIG_GRAD_IMPL", "grad_impl"), ("GPSIG_TVS_GRAD_TILE", "tvs_grad_tile")):
     if os.environ.get(_env):
         from gpsig_amd import _lib
         _lib.context(0, torch.cuda.current_stream(dev).cuda_stream).set_option(_opt, int(os.environ[_env]))
@@ -59,10 +59,10 @@ if "d" in which:
 if "b" in which:
     T, N, L, d, M = 512, 16384, 50, 6, 4
     X = torch.tensor(np.cumsum(0.2 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1), device=dev)
-    for base in ("rbf", "linear"):
+    for base in (os.environ.get("BENCH_GRAD_BASES") or "rbf,linear").split(","):
         kern = (kernels.SignatureRBF if base == "rbf" else kernels.SignatureLinear)(L * d, d, M, lengthscales=d ** 0.5)
         mod = autodiff.SignatureKernelModule(kern, device=dev)
-        for incr in (False, True):
+        for incr in [bool(int(v)) for v in (os.environ.get("BENCH_GRAD_INCR") or "0,1").split(",")]:
             Z = torch.tensor(rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d)), device=dev, requires_grad=True)
             W = torch.tensor(rng.standard_normal((T, N)), device=dev)
             def fwd():
