@@ -50,8 +50,8 @@ _KERNEL_FUNCS = {
     "gpsig_seq_diag_levels": [_vp, _i64, _i32, _vp],
     "gpsig_tens_gram_levels": [_vp, _i64, _i32, _vp],
     "gpsig_tens_vs_seq_levels": [_vp, _vp, _i64, _i64, _i32, _i32, _vp],
-    "gpsig_tens_vs_seq_weighted": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp],
-    "gpsig_tens_vs_seq_weighted_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)],
+    "gpsig_tens_vs_seq_weighted": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i32)],
+    "gpsig_tens_vs_seq_weighted_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)],
     "gpsig_kernel_K": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "gpsig_kernel_K_symm_rows": [_vp, _i64, _i32, _i64, _i64, _vp],
     "gpsig_kernel_K_symm_rows_compact": [_vp, _i64, _i32, _i64, _i64, _vp],
@@ -74,6 +74,7 @@ _KERNEL_FUNCS = {
 }
 _PLAIN = {
     "gpsig_abi_version": ([], C.c_int),
+    "gpsig_tens_vs_seq_aux_elems": ([_P, _i64, _i64], _i64),
     "gpsig_ctx_create": ([C.c_int, _vp, C.POINTER(_vp)], C.c_int),
     "gpsig_ctx_destroy": ([_vp], None),
     "gpsig_last_error": ([_vp], C.c_char_p),

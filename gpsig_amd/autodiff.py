@@ -235,15 +235,23 @@ class _TensVsSeqWeighted(torch.autograd.Function):
         keep = []
         p = spec.params(d, _p0_value(p0), keep)
         out = torch.empty((t, n), dtype=torch.float64, device=Z.device)
-        _ctx_for(Z).call("gpsig_tens_vs_seq_weighted", p, _ptr(Z), _ptr(X), t, n, l, int(bool(increments)), _ptr(F), _ptr(out))
-        ctx.spec, ctx.has_p0, ctx.increments = spec, p0 is not None, bool(increments)
+        # when a reverse pass will follow: room for the chain totals of every (tensor, sequence) pair, which the tile kernel leaves
+        # on its way and the reverse pass would otherwise rebuild with a forward sweep of its own
+        aux, wrote = None, C.c_int32(0)
+        if any(ctx.needs_input_grad[:4]):
+            aux = torch.empty(int(_lib.load().gpsig_tens_vs_seq_aux_elems(C.byref(p), t, n)), dtype=torch.float64, device=Z.device)
+        _ctx_for(Z).call("gpsig_tens_vs_seq_weighted", p, _ptr(Z), _ptr(X), t, n, l, int(bool(increments)), _ptr(F), _ptr(out),
+                         None if aux is None else _ptr(aux), C.byref(wrote))
+        if not wrote.value:
+            aux = None
+        ctx.spec, ctx.has_p0, ctx.increments, ctx.has_aux = spec, p0 is not None, bool(increments), aux is not None
         ctx.dt = (Zs.dtype, Xs.dtype, fac.dtype)
-        ctx.save_for_backward(Z, X, F, p0 if p0 is not None else Z.new_empty(0))
+        ctx.save_for_backward(Z, X, F, p0 if p0 is not None else Z.new_empty(0), aux if aux is not None else Z.new_empty(0))
         return out.to(_out_dtype(Zs, Xs, fac))
 
     @staticmethod
     def backward(ctx, G):
-        Z, X, F, p0 = ctx.saved_tensors
+        Z, X, F, p0, aux = ctx.saved_tensors
         t, d = Z.shape[1], Z.shape[-1]
         n, l = X.shape[:2]
         keep = []
@@ -251,8 +259,8 @@ class _TensVsSeqWeighted(torch.autograd.Function):
         G = _c(G)
         gZ, gX, gF = torch.empty_like(Z), torch.empty_like(X), torch.empty_like(F)
         gb = torch.zeros(2, dtype=torch.float64, device=Z.device)
-        _ctx_for(Z).call("gpsig_tens_vs_seq_weighted_grad", p, _ptr(Z), _ptr(X), t, n, l, int(ctx.increments), _ptr(F), _ptr(G), _ptr(gZ), _ptr(gX),
-                         _ptr(gF), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
+        _ctx_for(Z).call("gpsig_tens_vs_seq_weighted_grad", p, _ptr(Z), _ptr(X), t, n, l, int(ctx.increments), _ptr(F), _ptr(G),
+                         _ptr(aux) if ctx.has_aux else None, _ptr(gZ), _ptr(gX), _ptr(gF), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
         gp0 = gb[0].to(p0.device).reshape(p0.shape).to(p0.dtype) if ctx.has_p0 else None
         return gZ.to(ctx.dt[0]), gX.to(ctx.dt[1]), gF.t().to(ctx.dt[2]), gp0, None, None
 

@@ -1087,6 +1087,8 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     A.run = int(run); A.rec_elems = rec_elems;
     base_p(p, &A.p0, &A.p1);
     A.fx = fx; A.w = w; A.out = out; A.sum_levels = sum_levels ? 1 : 0;
+    A.aux = c->tvs_aux_out;
+    if (A.aux) c->tvs_aux_written = true;
     hipEvent_t e0, e1;
     bool timed;
     CHK(timing_begin(c, &e0, &e1, &timed));
@@ -1232,7 +1234,7 @@ static int e_tens_vs_seq_levels(gpsig_ctx* c, const gpsig_params* p, const void*
 
 // sum_m fac[n][m] level_m[t][n] of the raw levels (inputs as they come), the level sum taken inside the kernels' epilogue
 static int e_tens_vs_seq_weighted(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N, int32_t L,
-                               int32_t increments, const void* fac, void* out) {
+                               int32_t increments, const void* fac, void* out, void* aux, int32_t* aux_written) {
     ENTER(c, p);
     const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
     if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
@@ -1248,7 +1250,14 @@ static int e_tens_vs_seq_weighted(gpsig_ctx* c, const gpsig_params* p, const voi
     q.num_features = d; q.num_lags = 0; q.lengthscales = nullptr;      // raw entry point: columns are taken as they come
     const void *ZT, *ZS;
     CHK(prep_tensors(c, &q, false, dZ, T, E, &ZT, &ZS));
-    CHK(tens_vs_seq_device(c, &q, false, dZ, ZT, ZS, dX, T, N, L, increments, dF, nullptr, 0, dout));
+    if (aux_written) *aux_written = 0;
+    // the chain totals for the reverse pass: float64, device pointers (they stay on the device between the two passes)
+    c->tvs_aux_written = false;
+    c->tvs_aux_out = (aux && sizeof(TT) == 8 && c->ptr_mode == GPSIG_PTR_DEVICE) ? static_cast<double*>(aux) : nullptr;
+    const int rc = tens_vs_seq_device(c, &q, false, dZ, ZT, ZS, dX, T, N, L, increments, dF, nullptr, 0, dout);
+    c->tvs_aux_out = nullptr;
+    CHK(rc);
+    if (aux_written) *aux_written = c->tvs_aux_written ? 1 : 0;
     CHK(out_done(c, out, dout, ob));
     return finish(c);
 }
@@ -1280,7 +1289,14 @@ static int e_kernel_K_symm_rows(gpsig_ctx* c, const gpsig_params* p, const void*
     const size_t ob = sizeof(TT) * size_t(row_end - row_begin) * (compact ? N / 2 + 1 : N);
     void* dout;
     CHK(out_dev(c, B_OUT0, out_rows, ob, &dout));
-    if (row_end > row_begin) CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, 0, dout, true, 0, row_begin, row_end, compact));
+    if (row_end > row_begin) {
+        CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, 0, dout, true, 0, row_begin, row_end, compact));
+    } else {
+        // an empty block still reports whether the shape is one the row-block kernels take: every rank of a sharded evaluation
+        // must reach the same verdict, also the one that owns no rows
+        SeqPlanned pl;
+        CHK(plan_seq(c, p, p->num_features * (p->num_lags + 1), L, &pl, N * (N / 2 + 1)));
+    }
     CHK(out_done(c, out_rows, dout, ob));
     return finish(c);
 }
@@ -1533,6 +1549,10 @@ void gpsig_ctx_destroy(gpsig_ctx* c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->probe_stream) { if (c->probe_stop) *c->probe_stop = 1; (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
     if (c->probe_buf) (void)hipFree(c->probe_buf);
+    for (int k = 0; k < 2; ++k) {
+        if (c->pin[k]) (void)hipHostFree(c->pin[k]);
+        if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]);
+    }
     if (c->probe_stop) (void)hipHostFree(const_cast<int*>(c->probe_stop));
     solver_release(c->blas_handle);
     delete c;
@@ -1571,6 +1591,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "grad_impl")) c->grad_impl = value;
     else if (!strcmp(name, "tvs_zreg")) c->tvs_zreg = value;
     else if (!strcmp(name, "tvs_grad_tile")) c->tvs_grad_tile = value;
+    else if (!strcmp(name, "pinned_staging")) c->pinned_staging = value ? 1 : 0;
     else if (!strcmp(name, "keep_reset")) c->keep_reset = value ? 1 : 0;
     else if (!strcmp(name, "pk2")) c->allow_pk2 = value;
     else if (!strcmp(name, "f32_pack")) c->f32_pack = value;
@@ -1783,10 +1804,15 @@ int gpsig_tens_vs_seq_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z,
 }
 
 int gpsig_tens_vs_seq_weighted(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N, int32_t L,
-                               int32_t increments, const void* fac, void* out) {
+                               int32_t increments, const void* fac, void* out, void* aux, int32_t* aux_written) {
     if (!c || !p) return GPSIG_ERR_INVALID;
-    return p->dtype == GPSIG_F32 ? Impl<float>::e_tens_vs_seq_weighted(c, p, Z, X, T, N, L, increments, fac, out)
-                                 : Impl<double>::e_tens_vs_seq_weighted(c, p, Z, X, T, N, L, increments, fac, out);
+    return p->dtype == GPSIG_F32 ? Impl<float>::e_tens_vs_seq_weighted(c, p, Z, X, T, N, L, increments, fac, out, aux, aux_written)
+                                 : Impl<double>::e_tens_vs_seq_weighted(c, p, Z, X, T, N, L, increments, fac, out, aux, aux_written);
+}
+
+int64_t gpsig_tens_vs_seq_aux_elems(const gpsig_params* p, int64_t T, int64_t N) {
+    if (!p || T < 0 || N < 0) return 0;
+    return N * int64_t(p->num_levels * (p->num_levels + 1) / 2) * ((T + 63) / 64 * 64);
 }
 
 int gpsig_kernel_K(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2, int32_t L1,

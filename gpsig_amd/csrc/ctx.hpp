@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gpsig_hip.h"
@@ -82,6 +83,8 @@ struct gpsig_ctx {
     int lr_fused_pad = 1;         // row stride of its LDS arrays beyond the time steps rounded up to 64, in doubles (A/B runs)
     int lr_fused_variant = 0;     // its workgroup size / unrolling (lr_fused_inst.hip), for A/B runs
     int lr_fused = 1;             // low-rank sequence features: 1 = the fused kernel where a sequence's arrays fit LDS, 0 = one kernel per op
+    double* tvs_aux_out = nullptr;   // set by gpsig_tens_vs_seq_weighted around its launch: where the tile kernel leaves the chain totals
+    bool tvs_aux_written = false;    // ... and whether it did (only the tile kernel does)
     int tvs_grad_tile = 1;        // tensor-vs-sequence reverse pass: 1 = the tile kernel (tvs_grad_tile_kernel.hpp) where built, 0 = the round-1 kernels
     int tvs_zreg = -1;            // tensor-lane gradient: components in registers (1) or LDS (0); -1 = planner's choice
     std::string err;
@@ -112,6 +115,12 @@ struct gpsig_ctx {
     hipStream_t probe_stream = nullptr;
     unsigned long long* probe_buf = nullptr;   // device, 2 * probe_cap counters
     int probe_cap = 0, probe_n = 0;
+    // host-pointer mode: pinned bounce buffers for large transfers (pageable hipMemcpy runs at ~10 GB/s; pinned chunks + a threaded
+    // host copy reach several times that), created at first use
+    void* pin[2] = {nullptr, nullptr};
+    size_t pin_bytes = 0;
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    int pinned_staging = 1;                    // 0: plain hipMemcpyAsync on the caller's pageable memory (A/B runs)
     volatile int* probe_stop = nullptr;        // pinned host memory the wave polls: raised by gpsig_clock_probe_read
 };
 
@@ -251,13 +260,114 @@ inline int task_list(gpsig_ctx* c, const int64_t (&key)[10], Build build, const 
     return GPSIG_OK;
 }
 
+// ---- large host <-> device transfers through pinned bounce buffers ------------------------------------------------------
+// A numpy array is pageable memory: hipMemcpy stages it through the runtime's own small pinned buffers at about 10 GB/s, which made
+// 15 ms of a 42 ms host-pointer evaluation of BASELINE configs[1] (16.8 MB in, 134 MB out).  Here the transfer runs in chunks through
+// two pinned buffers of the context: the DMA of chunk k+1 overlaps with a threaded host copy of chunk k.
+constexpr size_t PIN_CHUNK_MAX = size_t(64) << 20;
+constexpr size_t PIN_MIN = size_t(2) << 20;          // smaller transfers take the plain path
+constexpr int PIN_THREADS_MAX = 16;
+inline size_t pin_chunk() {                           // GPSIG_PIN_CHUNK_MB / GPSIG_PIN_THREADS: for A/B runs
+    static const size_t v = [] { const char* e = getenv("GPSIG_PIN_CHUNK_MB"); size_t m = e ? size_t(atoi(e)) : 16; if (m < 1) m = 1; if (m > 64) m = 64; return m << 20; }();
+    return v;
+}
+inline int pin_threads() {
+    static const int v = [] { const char* e = getenv("GPSIG_PIN_THREADS"); int t = e ? atoi(e) : 4; if (t < 1) t = 1; if (t > PIN_THREADS_MAX) t = PIN_THREADS_MAX; return t; }();
+    return v;
+}
+#define PIN_CHUNK (pin_chunk())
+#define PIN_THREADS (pin_threads())
+
+inline void host_copy_threaded(void* dst, const void* src, size_t bytes) {
+    if (bytes < (size_t(1) << 20)) { memcpy(dst, src, bytes); return; }
+    const size_t part = (bytes / PIN_THREADS + 4095) / 4096 * 4096;
+    std::thread th[PIN_THREADS_MAX];
+    int nt = 0;
+    for (int k = 1; k < PIN_THREADS; ++k) {
+        const size_t o = part * k;
+        if (o >= bytes) break;
+        const size_t n = bytes - o < part ? bytes - o : part;
+        th[nt++] = std::thread([=] { memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, n); });
+    }
+    memcpy(dst, src, part < bytes ? part : bytes);
+    for (int k = 0; k < nt; ++k) th[k].join();
+}
+
+// is `p` page-locked host memory HIP knows (hipHostMalloc / hipHostRegister, e.g. a torch pinned tensor)?  Then the DMA engines read
+// and write it directly at full speed and no bounce buffer is needed.
+inline bool host_is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+inline int pin_ready(gpsig_ctx* c) {
+    if (c->pin[0]) return GPSIG_OK;
+    CHK(no_capture(c, "pinned staging buffers have to be allocated"));
+    for (int k = 0; k < 2; ++k) {
+        hipError_t e = hipHostMalloc(&c->pin[k], PIN_CHUNK_MAX, hipHostMallocDefault);
+        if (e != hipSuccess) { c->pin[k] = nullptr; return fail(c, GPSIG_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", PIN_CHUNK, hipGetErrorString(e)); }
+        HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming));
+    }
+    c->pin_bytes = PIN_CHUNK;
+    return GPSIG_OK;
+}
+
+// host -> device on the ctx stream; returns once `user` has been read (the device copy completes in stream order)
+inline int staged_h2d(gpsig_ctx* c, void* dev, const void* user, size_t bytes) {
+    if (!c->pinned_staging || bytes < PIN_MIN || c->capturing || host_is_pinned(user)) {
+        HIPCHK(c, hipMemcpyAsync(dev, user, bytes, hipMemcpyHostToDevice, c->stream));
+        return GPSIG_OK;
+    }
+    CHK(pin_ready(c));
+    size_t off = 0;
+    for (int k = 0; off < bytes; ++k, off += PIN_CHUNK) {
+        const int b = k & 1;
+        const size_t n = bytes - off < PIN_CHUNK ? bytes - off : PIN_CHUNK;
+        if (k >= 2) HIPCHK(c, hipEventSynchronize(c->pin_ev[b]));            // the DMA that last read this buffer is done
+        host_copy_threaded(c->pin[b], static_cast<const char*>(user) + off, n);
+        HIPCHK(c, hipMemcpyAsync(static_cast<char*>(dev) + off, c->pin[b], n, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipEventRecord(c->pin_ev[b], c->stream));
+    }
+    // both buffers may be reused by the next transfer only after their DMAs: wait here (the data is on its way; kernels queued
+    // behind it on the stream start as soon as it lands)
+    HIPCHK(c, hipEventSynchronize(c->pin_ev[0]));
+    HIPCHK(c, hipEventSynchronize(c->pin_ev[1]));
+    return GPSIG_OK;
+}
+
+// device -> host, ordered after everything queued on the ctx stream; returns when `user` holds the data
+inline int staged_d2h(gpsig_ctx* c, void* user, const void* dev, size_t bytes) {
+    if (!c->pinned_staging || bytes < PIN_MIN || c->capturing || host_is_pinned(user)) {
+        HIPCHK(c, hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        return GPSIG_OK;
+    }
+    CHK(pin_ready(c));
+    const size_t nchunks = (bytes + PIN_CHUNK - 1) / PIN_CHUNK;
+    for (size_t k = 0; k <= nchunks; ++k) {
+        if (k < nchunks) {
+            const size_t off = k * PIN_CHUNK, n = bytes - off < PIN_CHUNK ? bytes - off : PIN_CHUNK;
+            HIPCHK(c, hipMemcpyAsync(c->pin[k & 1], static_cast<const char*>(dev) + off, n, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipEventRecord(c->pin_ev[k & 1], c->stream));
+        }
+        if (k >= 1) {                                                         // chunk k-1 has landed: out of the bounce buffer while chunk k flies
+            const size_t off = (k - 1) * PIN_CHUNK, n = bytes - off < PIN_CHUNK ? bytes - off : PIN_CHUNK;
+            HIPCHK(c, hipEventSynchronize(c->pin_ev[(k - 1) & 1]));
+            host_copy_threaded(static_cast<char*>(user) + off, c->pin[(k - 1) & 1], n);
+        }
+    }
+    return GPSIG_OK;
+}
+
 // input pointer as the caller gave it -> device pointer
 inline int in_dev(gpsig_ctx* c, int id, const void* user, size_t bytes, const void** dev) {
     if (!user && bytes) return fail(c, GPSIG_ERR_INVALID, "null input pointer");
     if (c->ptr_mode == GPSIG_PTR_DEVICE && user) { *dev = user; return GPSIG_OK; }
     void* p;
     CHK(ensure(c, id, bytes ? bytes : 8, &p));
-    if (bytes && c->ptr_mode == GPSIG_PTR_HOST) HIPCHK(c, hipMemcpyAsync(p, user, bytes, hipMemcpyHostToDevice, c->stream));
+    if (bytes && c->ptr_mode == GPSIG_PTR_HOST) CHK(staged_h2d(c, p, user, bytes));
     *dev = p;
     return GPSIG_OK;
 }
@@ -268,7 +378,7 @@ inline int out_dev(gpsig_ctx* c, int id, void* user, size_t bytes, void** dev) {
 }
 inline int out_done(gpsig_ctx* c, void* user, const void* dev, size_t bytes) {
     if (c->ptr_mode == GPSIG_PTR_DEVICE || !user) return GPSIG_OK;
-    if (bytes) HIPCHK(c, hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (bytes) CHK(staged_d2h(c, user, dev, bytes));
     return GPSIG_OK;
 }
 inline int finish(gpsig_ctx* c) {

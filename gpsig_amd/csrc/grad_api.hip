@@ -22,7 +22,7 @@ Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
 // tvs_grad_api.hip: the tile kernel of the tensor-vs-sequence reverse pass (tvs_grad_tile_kernel.hpp)
 int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, const double* X, const double* G, int64_t Tn, int64_t N,
-                         int L, int increments, const double* fac, double* gZ, double* gX, double* gfac, double* gb, size_t budget, bool* done);
+                         int L, int increments, const double* fac, const double* aux, double* gZ, double* gX, double* gfac, double* gb, size_t budget, bool* done);
 }  // namespace gpsig
 
 using namespace gpsig;
@@ -766,7 +766,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     bool tiled = false;
     if (T > 0 && N > 0 && c->grad_impl == 0 && c->tvs_grad_tile != 0)
         CHK(tvs_grad_tile_device(c, p, d, static_cast<const double*>(dZ), static_cast<const double*>(dX), static_cast<const double*>(dG), T, N, L,
-                                 increments, nullptr, static_cast<double*>(dgZ), static_cast<double*>(dgX), nullptr, kgb, scratch_budget(c), &tiled));
+                                 increments, nullptr, nullptr, static_cast<double*>(dgZ), static_cast<double*>(dgX), nullptr, kgb, scratch_budget(c), &tiled));
     if (tiled) {
         // both gradients were written by the tile kernel's reductions
     } else if (T == 0 || N == 0) {
@@ -854,7 +854,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
 // (T, N) upstream gradient and the factors as they are; other shapes go through the level primitives (the level array and its
 // upstream gradient in scratch memory).
 int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N, int32_t L,
-                                    int32_t increments, const void* fac, const void* G, void* gZ, void* gX, void* gfac, double* g_base) {
+                                    int32_t increments, const void* fac, const void* G, const void* aux, void* gZ, void* gX, void* gfac, double* g_base) {
     int d, DP;
     CHK(grad_check(c, p, &d, &DP));
     if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
@@ -877,7 +877,7 @@ int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* c, const gpsig_params* p, const v
         double* dgb;
         CHK(gbase_begin(c, &dgb));
         CHK(tvs_grad_tile_device(c, p, d, static_cast<const double*>(dZ), static_cast<const double*>(dX), static_cast<const double*>(dG), T, N, L,
-                                 increments, static_cast<const double*>(dF), static_cast<double*>(dgZ), static_cast<double*>(dgX),
+                                 increments, static_cast<const double*>(dF), static_cast<const double*>(aux), static_cast<double*>(dgZ), static_cast<double*>(dgX),
                                  static_cast<double*>(dgF), has_base ? dgb : nullptr, scratch_budget(c), &tiled));
         if (tiled) CHK(gbase_end(c, dgb, g_base));
     }

@@ -37,8 +37,9 @@ static __global__ void tvs_grad_sum_kernel(const double* __restrict__ part, int6
 // Z (lt, T, E_in, d), X (N, L, d) on the device, already scaled; gZ, gX overwritten; gb: 2 doubles on the device ([0] accumulated) or NULL.
 // fac == NULL: G (M+1, T, N) is the upstream gradient of the level array.  fac (N, M+1): G (T, N) is the upstream gradient of the
 // weighted level sum  sum_m fac[n][m] level_m[t][n],  and gfac (N, M+1) receives the gradient with respect to the factors.
+// aux (N, lt, Tpad) or NULL: the chain totals the forward tile kernel left (tvs_tile_kernel.hpp), which save the forward sweep here.
 int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, const double* X, const double* G, int64_t Tn, int64_t N,
-                         int L, int increments, const double* fac, double* gZ, double* gX, double* gfac, double* gb, size_t budget, bool* done) {
+                         int L, int increments, const double* fac, const double* aux, double* gZ, double* gX, double* gfac, double* gb, size_t budget, bool* done) {
     *done = false;
     const int M = p->num_levels, lt = M * (M + 1) / 2;
     if (p->order > 1 && M > 1) return GPSIG_OK;
@@ -50,7 +51,7 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
     const int E = paired ? 2 : 1;
     TvsGradTileLaunchFn fn = tvs_grad_tile_lookup(M, D, kind, paired);
     if (!fn) return GPSIG_OK;
-    const int NR = tvs_grad_tile_roles(M);
+    const int NR = tvs_grad_tile_roles(M, kind);
     const int rec_elems = (L * D + L + TVSG_REC_ALIGN - 1) / TVSG_REC_ALIGN * TVSG_REC_ALIGN;
     const size_t lds = tvs_grad_tile_lds_bytes(D, rec_elems, kind == BASE_RBF);
     if (lds > 64 * 1024) return GPSIG_OK;
@@ -105,6 +106,7 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
         A.Gt = static_cast<const double*>(gt) + n0 * int64_t(GL) * Tpad;
         A.fac = fac ? fac + n0 * int64_t(M + 1) : nullptr;
         A.gfp = gfp ? static_cast<double*>(gfp) : nullptr;
+        A.aux = aux ? aux + n0 * int64_t(lt) * Tpad : nullptr;
         A.gzp = static_cast<double*>(gzp) + size_t(r0) * gz_stride;
         A.gxp = static_cast<double*>(gxp);
         A.gbp = gbp ? static_cast<double*>(gbp) + r0 * TB * NR : nullptr;

@@ -50,6 +50,7 @@ struct TvsGradTileArgs {
                          // fac != NULL: (N, Tpad) upstream gradient of the weighted level sum  sum_m fac[n][m] level_m[t][n]
     const double* fac;   // (N, M+1) per-sequence level factors, or NULL
     double* gfp;         // fac != NULL: (tensor blocks, N, M+1) partial d/d fac of every tensor block
+    const double* aux;   // (N, lt, Tpad) chain totals left by the forward tile kernel, or NULL: then this kernel sweeps forward itself
     double* gzp;         // (runs, lt, E, D, Tpad) partial d/dz' of every run
     double* gxp;         // (roles, tensor blocks, N, L, D) partial d/dx' of every (role, tensor block)
     double* gbp;         // (roles * runs * tensor blocks) partial d/d base_params[0], or NULL
@@ -63,7 +64,11 @@ struct TvsGradTileArgs {
 // roles (level subsets, one workgroup each): at most four components per role where the levels allow it -- z, d/dz and the chain state
 // of four components at six features fit the 256 registers of two wavefronts per SIMD; one wavefront per SIMD issues float64
 // instructions at half the rate of two (tools/clockcheck.hip)
-constexpr int tvs_grad_tile_roles(int M) { return (M * (M + 1) / 2 + 3) / 4 > 4 ? 4 : (M * (M + 1) / 2 + 3) / 4; }
+// (five components of the linear kernel, which carries no exp temporaries, still spill 100 bytes at six features: four for every family)
+constexpr int tvs_grad_tile_roles(int M, int /*kind*/) {
+    const int n = (M * (M + 1) / 2 + 3) / 4;
+    return n > 4 ? 4 : n;
+}
 
 inline size_t tvs_grad_tile_lds_bytes(int D, int rec_elems, bool rbf) {
     return sizeof(double) * ((rbf ? EXP_TAB256_N : 0) + 2 * size_t(rec_elems) + size_t(TVSG_TBT) * D * TVSG_ROW);
@@ -139,6 +144,17 @@ struct TvsGradWave {
             }
         }
         gp0 = 0.0;
+    }
+
+    // the chain totals as the forward tile kernel left them (TvsTileArgs::aux) instead of a forward sweep
+    __device__ __forceinline__ void load_totals(const TvsGradTileArgs& A, int64_t n, int64_t t) {
+        constexpr int lt = M * (M + 1) / 2;
+#pragma unroll
+        for (int i = 1; i <= M; ++i) {
+            if (!((MASK >> i) & 1)) continue;
+#pragma unroll
+            for (int j = 0; j < i; ++j) u[tvs_local_off(MASK, i) + j] = A.aux[(n * lt + i * (i - 1) / 2 + j) * A.Tpad + t];
+        }
     }
 
     // kappa of this lane's point for every component at time tau; WITH_GRAD also leaves the derivative coefficients
@@ -311,7 +327,7 @@ struct TvsGradWave {
 template <int M, int D, int KIND, bool PAIRED>
 __global__ __launch_bounds__(64, TVSG_WAVES_PER_EU) void tvs_grad_tile_kernel(const TvsGradTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tvsg_smem[];
-    constexpr int NR = tvs_grad_tile_roles(M);
+    constexpr int NR = tvs_grad_tile_roles(M, KIND);
     constexpr int NTAB = KIND == BASE_RBF ? EXP_TAB256_N : 0;
     constexpr int TPW = PAIRED ? 32 : 64;                          // tensors per workgroup
     constexpr int E = PAIRED ? 2 : 1;
@@ -358,7 +374,8 @@ __global__ __launch_bounds__(64, TVSG_WAVES_PER_EU) void tvs_grad_tile_kernel(co
                 for (int i = 0; i <= M; ++i) cup[i] = ((WT::MASK_ >> i) & 1) ? A.Gt[(n * (M + 1) + i) * A.Tpad + t] : 0.0;
             }
             const double* rec = recs + buf * A.rec_elems;
-            W.forward(A, rec, etab);
+            if (A.aux) W.load_totals(A, n, t);
+            else W.forward(A, rec, etab);
             if (A.fac) {
                 // d/d fac[n][i] = sum over the tensors of (upstream gradient) x (level value): the chain totals are at hand
                 // (lanes without a tensor carry a zero gradient; the two lanes of an incremental tensor hold the same numbers)
@@ -413,7 +430,8 @@ __global__ __launch_bounds__(64, TVSG_WAVES_PER_EU) void tvs_grad_tile_kernel(co
                 const int c = tvs_local_off(WT::MASK_, i) + j, k = i * (i - 1) / 2 + j;
 #pragma unroll
                 for (int f = 0; f < D; ++f)
-                    A.gzp[(((blockIdx.y * int64_t(lt) + k) * E + pe) * D + f) * A.Tpad + t] = fma(W.bz[c], W.z[c][f], W.gz[c][f]);
+                    A.gzp[(((blockIdx.y * int64_t(lt) + k) * E + pe) * D + f) * A.Tpad + t] =
+                        KIND == BASE_LINEAR ? W.gz[c][f] : fma(W.bz[c], W.z[c][f], W.gz[c][f]);     // the linear kernel has no z term
             }
         }
         if (A.gbp) {

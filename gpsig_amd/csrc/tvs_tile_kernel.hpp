@@ -62,6 +62,8 @@ struct TvsTileArgs {
     const double* w;    // (M+1) level weights or NULL
     void* out;          // (T, N) or (M+1, T, N)
     int32_t sum_levels;
+    double* aux;        // optional (N, lt, Tpad): the totals of EVERY chain, u_{j+1} of component k = i(i-1)/2 + j at [n][k][t] -- what the
+                        // reverse pass (tvs_grad_tile_kernel.hpp) would otherwise rebuild with a forward sweep of its own
 };
 
 // LDS bytes of one workgroup
@@ -184,6 +186,17 @@ struct TvsTileWave {
         }
     }
 
+    // the chain totals of the sequence just swept, for the reverse pass: consecutive lanes (tensors) write consecutive addresses
+    __device__ __forceinline__ void store_aux(const TvsTileArgs& A, int64_t n, int64_t t) const {
+        constexpr int lt = M * (M + 1) / 2;
+#pragma unroll
+        for (int i = 1; i <= M; ++i) {
+            if (!((MASK >> i) & 1)) continue;
+#pragma unroll
+            for (int j = 0; j < i; ++j) A.aux[(n * lt + i * (i - 1) / 2 + j) * A.Tpad + t] = u[tvs_local_off(MASK, i) + j];
+        }
+    }
+
     // weighted levels of the sequence just swept into the tile column `col`; resets the chains
     __device__ __forceinline__ void emit(const TvsTileArgs& A, const double (&fac)[M + 1], double* __restrict__ tile, int wave,
                                          int lane, int col, bool with_level0) {
@@ -254,6 +267,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tvs_tile_kernel(const TvsTileArgs 
                 fac[i] = f;
             }
             W.sweep(A, recs + buf * A.rec_elems, etab);
+            if (A.aux) W.store_aux(A, n, t);
             W.emit(A, fac, tile, wave, lane, col, wave == 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next record has landed
             __syncthreads();                                      // ... for every wave, and this record is no longer read

@@ -22,6 +22,7 @@ except Exception:  # pragma: no cover
     torch = None
 
 JITTER = 1e-6   # gpflow.settings.jitter
+_PINNED_OUT_MIN = 1 << 20   # host-array results of at least this many bytes are allocated page-locked
 
 
 def _is_torch(x):
@@ -67,7 +68,17 @@ class _Launch:
         if self.device_mode:
             t = torch.empty(tuple(int(s) for s in shape), dtype=torch.float32 if self.f32 else torch.float64, device=self.dev)
             return t, C.c_void_p(t.data_ptr())
-        t = np.empty(tuple(int(s) for s in shape), dtype=self.np_dtype)
+        shape = tuple(int(s) for s in shape)
+        if torch is not None and int(np.prod(shape)) * np.dtype(self.np_dtype).itemsize >= _PINNED_OUT_MIN:
+            # A large result in page-locked memory from torch's caching host allocator: the DMA engines write it directly (134 MB in
+            # 2.4 ms), where a fresh np.empty costs 10 ms of first-touch page faults on top of the copy (tools/bench_host_e2e.py).
+            # The array is an ordinary ndarray to the caller; its memory goes back to the allocator's pool with its last reference.
+            try:
+                t = torch.empty(shape, dtype=torch.float32 if self.f32 else torch.float64, pin_memory=True).numpy()
+                return t, C.c_void_p(t.ctypes.data)
+            except Exception:       # no page-locked memory to be had: pageable memory through the library's bounce buffers
+                pass
+        t = np.empty(shape, dtype=self.np_dtype)
         return t, C.c_void_p(t.ctypes.data)
 
 
@@ -543,20 +554,22 @@ class SignatureKernel:
         S = np.ascontiguousarray(np.concatenate(parts, axis=0))
         jd = np.ascontiguousarray(JITTER * self.rng.random(c))                    # low_rank_calculations.py:52
         sk = _lr.draw_level_sketches(self.rng, self.num_levels, c, int(self.rank_bound), self.sparsity)
-        return self.low_rank_state(S, jd, sk)
+        return self.low_rank_state(S, jd, sk, ctx=L_.ctx)
 
-    def low_rank_state(self, landmarks, jitter_diag, sketches):
+    def low_rank_state(self, landmarks, jitter_diag, sketches, ctx=None):
         """The LowRankState of GIVEN random objects: landmarks (c, d') -- scaled points --, the jitter draw (c,) and one sketch
         per level >= 2 (objects with k1, k2, r, colptr, i1, i2, val); the whitening is computed here, on the device
-        (low_rank_calculations.py:50-57, :60: landmark Gram + jitter, rocSOLVER dsyevd, U / sqrt(S + jitter))."""
+        (low_rank_calculations.py:50-57, :60: landmark Gram + jitter, rocSOLVER dsyevd, U / sqrt(S + jitter)).
+        ctx: the library context to whiten on (default: device 0's); its pointer mode is left alone -- gpsig_lr_whitening takes host
+        pointers in either mode, and the caller's evaluation may be half way through a sequence of device-pointer calls on it."""
         S = np.ascontiguousarray(landmarks, dtype=np.float64)
         jd = np.ascontiguousarray(jitter_diag, dtype=np.float64)
         c, d_eff = S.shape
-        L_ = _launch_f64()
-        p = self._params(L_.keep, _lib.F64)
+        keep = []
+        p = self._params(keep, _lib.F64)
         Wh, ev = np.empty((c, c)), np.empty(c)
         dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))                    # noqa: E731
-        L_.ctx.call("gpsig_lr_whitening", p, dp(S), c, d_eff, dp(jd), dp(Wh), dp(ev))
+        (ctx or _lib.context(0, 0)).call("gpsig_lr_whitening", p, dp(S), c, d_eff, dp(jd), dp(Wh), dp(ev))
         sk = [s_ if isinstance(s_, _lr.Sketch) else _lr.Sketch(s_.k1, s_.k2, s_.r, s_.colptr, s_.i1, s_.i2, s_.val) for s_ in sketches]
         rb = sk[0].r if sk else int(self.rank_bound)
         return LowRankState(S, Wh, sk, rb, jitter_diag=jd, eigenvalues=ev)

@@ -44,12 +44,23 @@ class ShardedGram:
     chunks: pieces a rank's row block is computed and gathered in (the gather of piece k runs while piece k+1 is computed).
     ctx:    the library context to use (default: the one of `device` and the stream current at call time).  The CPU test-suite
             passes a stand-in that runs the kernel's lock-step emulator, so that this very code runs under gloo without a GPU.
-    Shapes the wavefront pair kernels are not built for (gpsig_amd/csrc/seq_configs.hpp) raise NotImplementedError here, although
-    the single-GPU kern.K falls back to the any-shape kernel for them."""
+    Shapes the row-block kernels are not built for (gpsig_amd/csrc/seq_configs.hpp: both sequences longer than the register-resident
+    side holds, wide state spaces, ...) are evaluated by rank 0 alone through kern.K and its any-shape kernels (`self.fallback` then
+    says why); every rank takes that branch together, the shape being the same everywhere.
+
+    Stream ordering the RCCL branch relies on (torch.distributed's ProcessGroupNCCL): the library's kernels run on the stream that is
+    current when __call__ is entered (the context is looked up by it); `dist.gather(..., async_op=True)` makes the collective's own
+    stream wait for an event recorded on that current stream at the time of the call -- so the kernel that wrote chunk k is ordered
+    before the gather that sends it, while chunk k+1, launched afterwards on the current stream, overlaps with it (it writes other rows
+    of `self.rows`); `work.wait()` makes the CURRENT STREAM (not the host) wait for the collective, after which rank 0's
+    symmetrisation, launched on the current stream, reads `self.half`.  `self.rows` / `self.half` / `self.out` live as long as the
+    object, so nothing is handed back to the caching allocator while a collective may still read it; a second __call__ overwrites
+    `self.rows` only after the waits of the first."""
 
     def __init__(self, kern, n, device, rank=0, world=1, chunks=4, ctx=None):
         self.kern, self.n, self.dev, self.rank, self.world = kern, int(n), torch.device(device), int(rank), int(world)
         self._ctx = ctx
+        self.fallback = None                     # why rank 0 evaluated alone, when it did
         self.width = self.n // 2 + 1
         chunks = max(1, int(chunks))
         self.per = block_rows(self.n, world, ALIGN * chunks)
@@ -76,6 +87,10 @@ class ShardedGram:
         parts = None
         if self.rank == 0:
             parts = [self.half[r * self.per + k * cr: r * self.per + (k + 1) * cr] for r in range(self.world)]
+        # what a gather moves must be one contiguous block of the same size on every rank (block_rows() makes it so: `per` and
+        # `chunk_rows` depend on (n, world, chunks) only); a strided or short operand would be copied or mis-sized silently
+        assert mine.is_contiguous() and tuple(mine.shape) == (cr, self.width), (tuple(mine.shape), mine.is_contiguous())
+        assert parts is None or all(p_.is_contiguous() and p_.shape == mine.shape for p_ in parts)
         if mine.is_cuda and dist.get_backend() != "nccl":
             # CPU collectives on GPU data (tests on a box with fewer GPUs than ranks): stage through the host
             torch.cuda.synchronize(self.dev)
@@ -108,9 +123,15 @@ class ShardedGram:
         for k in range(self.chunks):
             r0 = min(b0 + k * self.chunk_rows, b1)
             r1 = min(r0 + self.chunk_rows, b1)
-            if r1 > r0:
+            if r1 > r0 or k == 0:
                 blk = self.rows[k * self.chunk_rows:]
-                ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), n, L, r0, r1, C.c_void_p(blk.data_ptr()))
+                try:
+                    # (an empty row range on the first chunk still validates the shape, so that every rank decides alike)
+                    ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), n, L, r0, r1, C.c_void_p(blk.data_ptr()))
+                except NotImplementedError as e:
+                    if k != 0:
+                        raise
+                    return self._rank0_alone(X, str(e))
             w = self._gather(k)       # enqueued behind chunk k on the collective's own stream; chunk k+1 starts meanwhile
             if w is not None:
                 pending.append(w)
@@ -122,12 +143,22 @@ class ShardedGram:
         return self.out
 
 
+    def _rank0_alone(self, X, why):
+        """A shape the row-block kernels do not take: rank 0 evaluates K(X) through the any-shape kernels, the others wait for it."""
+        self.fallback = why
+        out = self.kern.K(X, presliced=True) if self.rank == 0 else None
+        if dist is not None and dist.is_initialized():
+            dist.barrier()
+        return out
+
+
 class ShardedCovs:
     """The three SVGP covariances of ``kern.K_tens_n_seq_covs(Z, X)`` (gpsig/kernels.py:591-671; BASELINE configs[2]) with the N
     sequences split over the ranks: the (tensor, sequence) chains are independent, so rank r evaluates Kzx[:, n_r] and the
     Kxx diagonal of its contiguous block of sequences (Z is replicated: a few hundred KB) and the blocks are gathered on rank 0
     -- the "N x M batch shards embarrassingly" half of the north star; no exchange while computing.  Kzz (T x T, independent of
-    X) is evaluated on rank 0 only.  Returns (Kzz, Kzx, Kxx_diag) on rank 0, None elsewhere.
+    X: 0.02 ms at T = 512) comes out of the same call on every rank and is used on rank 0 only.  Returns (Kzz, Kzx, Kxx_diag) on
+    rank 0, None elsewhere.
 
     evaluate: what computes a block, ``kern.K_tens_n_seq_covs`` by default (the CPU test-suite passes a stand-in: there is no CPU
     path in the product)."""
@@ -145,6 +176,10 @@ class ShardedCovs:
             return f(Z, X, increments)
         if X.shape[0] != self.n:
             raise ValueError("ShardedCovs was built for %d sequences, got %d" % (self.n, X.shape[0]))
+        if torch.is_tensor(X) and self._evaluate is None and (not X.is_cuda or X.device != self.dev or Z.device != self.dev):
+            raise ValueError("ShardedCovs takes tensors on %s" % (self.dev,))
+        if X.dtype != Z.dtype:
+            raise ValueError("ShardedCovs takes Z and X of one dtype (got %s and %s)" % (Z.dtype, X.dtype))
         T = Z.shape[1]
         if self.n1 > self.n0:
             Kzz, Kzx, Kxx = f(Z, X[self.n0:self.n1].contiguous(), increments)

@@ -108,6 +108,9 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 kernels (what the planner picks wherever they are built)
  *   "tvs_grad_tile" reverse pass of the tensor-vs-sequence chains: 1 (default) the tile kernel (all levels in one reverse sweep per
  *                 sequence, d/dx summed in LDS, no atomics) where it is built (order 1, at most 8 columns, at most 6 levels), 0 the round-1 kernels
+ *   "pinned_staging" host-pointer mode: 1 (default) transfers of 2 MiB and more run in 16 MiB chunks through two pinned buffers of the
+ *                 context, the DMA of one chunk overlapping a threaded host copy of the previous one; 0 plain hipMemcpy on the caller's
+ *                 (pageable) memory
  *   "tvs_zreg"    tensor-lane gradient: components in registers (1) or LDS (0), -1 automatic
  *   "tvs_tile"    tensor-vs-sequence tile kernel (levels split over the waves of a workgroup, coalesced result tiles):
  *                 -1 wherever it is built and there are at least 32 tensors, 0 never, 1 also for fewer tensors
@@ -175,9 +178,13 @@ int gpsig_tens_vs_seq_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* 
  * fac[n][m] = sigma variances[m] / sqrt(diag_m(x_n) + jitter) are known -- in one pass, the level sum taken in the kernel's
  * epilogue, without the (M+1, T, N) level array ever reaching memory.  It is the form a training step uses (the factors are
  * differentiable inputs; gpsig_tens_vs_seq_weighted_grad below).  Inputs are used as given, like the level primitives.
- * fac: (N, M+1), out: (T, N), element type p->dtype. */
+ * fac: (N, M+1), out: (T, N), element type p->dtype.
+ * aux (optional; float64, device-pointer mode): gpsig_tens_vs_seq_aux_elems() doubles that receive the totals of every chain of
+ * every (tensor, sequence) pair when the tile kernel evaluates the call (*aux_written = 1); handed to _weighted_grad they save its
+ * forward sweep.  NULL, or *aux_written == 0 afterwards: the reverse pass rebuilds them itself. */
 int gpsig_tens_vs_seq_weighted(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
-                               int32_t L, int32_t increments, const void* fac, void* out);
+                               int32_t L, int32_t increments, const void* fac, void* out, void* aux, int32_t* aux_written);
+int64_t gpsig_tens_vs_seq_aux_elems(const gpsig_params* p, int64_t T, int64_t N);
 
 /* ---- end-to-end kernel evaluations (scaling, lags, normalisation, sigma*variances, level sum) */
 /* SignatureKernel.K (kernels.py:401-476).  out: (N1, N2), or (M+1, N1, N2) if return_levels. */
@@ -291,10 +298,11 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const v
 
 /* Reverse pass of gpsig_tens_vs_seq_weighted: G (T, N) is the upstream gradient of the weighted sum; gZ, gX as above, gfac (N, M+1)
  * the gradient with respect to the factors (through which the level diagonals of the sequences, sigma and the variances are
- * reached: gpsig/kernels.py:572-581, :471).  float64. */
+ * reached: gpsig/kernels.py:572-581, :471).  float64.  aux: device pointer in either pointer mode. */
 int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N,
                                     int32_t L, int32_t increments, const void* fac /* (N, M+1) */, const void* G /* (T, N) */,
-                                    void* gZ, void* gX, void* gfac /* (N, M+1) */, double* g_base);
+                                    const void* aux /* what the forward call wrote, or NULL */, void* gZ, void* gX,
+                                    void* gfac /* (N, M+1) */, double* g_base);
 
 #ifdef __cplusplus
 }

@@ -121,6 +121,47 @@ def test_two_rank_gloo_sharded_gram(n, chunks):
     assert ret["err"] < 1e-12 and ret["sym"]
 
 
+class RefusingContext(EmulatorContext):
+    """The row-block entry point refusing the shape, as libgpsig_hip does for shapes outside the wavefront kernels."""
+
+    def call(self, name, p, Xp, n, L, r0, r1, outp):
+        raise NotImplementedError("no sequence-pair kernel shape for these lengths")
+
+
+def _fallback_worker(rank, world, port, n, ret):
+    import torch
+    from gpsig_amd import kernels
+    from oracle import sigkern_oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, d, M = 7, 2, 3
+        rng = np.random.default_rng(4)
+        X = np.cumsum(0.3 * rng.standard_normal((n, L, d)), axis=1).reshape(n, L * d)
+        kern = kernels.SignatureRBF(L * d, d, M, lengthscales=None)
+        ko = O.SignatureKernelOracle(L * d, d, M, base="rbf", lengthscales=None)
+        calls = []
+
+        def K_stand_in(Xt, presliced=False):        # stand-in for the any-shape HIP evaluation (no CPU path in the product)
+            calls.append(rank)
+            return torch.from_numpy(ko.K(Xt.numpy()))
+        kern.K = K_stand_in
+        gram = parallel.ShardedGram(kern, n, torch.device("cpu"), rank, world, chunks=2, ctx=RefusingContext())
+        out = gram(torch.from_numpy(X))
+        ret[rank] = (gram.fallback is not None, len(calls), None if out is None else float(np.abs(out.numpy() - ko.K(X)).max()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gram_falls_back_to_rank_zero_for_unsupported_shapes():
+    """A shape the row-block kernels refuse: every rank takes the fallback together (also one that owns no rows: n = 3 on 3 ranks of
+    blocks of 8), rank 0 evaluates alone through kern.K, nobody hangs in a gather."""
+    for n, world in ((20, 2), (3, 3)):
+        ret = _spawn_with_retry(_fallback_worker, world, (n,))
+        assert ret[0] == (True, 1, 0.0), ret
+        assert all(ret[r] == (True, 0, None) for r in range(1, world)), ret
+
+
 def _covs_worker(rank, world, port, n, increments, ret):
     import torch
     from gpsig_amd import kernels

@@ -284,10 +284,10 @@ def test_weighted_tensor_vs_sequence_sum(base, M, T, N, L, d, order):
             ctx.set_option("tvs_tile", -1 if tile else 0)
             try:
                 out = np.empty((T, N))
-                ctx.call("gpsig_tens_vs_seq_weighted", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(F), _vp(out))
+                ctx.call("gpsig_tens_vs_seq_weighted", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(F), _vp(out), None, None)
                 gZ, gX, gF, gb = np.empty_like(Z), np.empty_like(X), np.empty_like(F), np.zeros(2)
-                ctx.call("gpsig_tens_vs_seq_weighted_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(F), _vp(G), _vp(gZ), _vp(gX), _vp(gF),
-                         gb.ctypes.data_as(_P))
+                ctx.call("gpsig_tens_vs_seq_weighted_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(F), _vp(G), None, _vp(gZ), _vp(gX),
+                         _vp(gF), gb.ctypes.data_as(_P))
             finally:
                 ctx.set_option("tvs_grad_tile", 1)
                 ctx.set_option("tvs_tile", -1)
@@ -303,10 +303,19 @@ def test_weighted_tensor_vs_sequence_sum(base, M, T, N, L, d, order):
         dZ, dX, dF, dG = (torch.tensor(a, device=dev) for a in (Z, X, F, G))
         dgZ, dgX, dgF, dgb = torch.empty_like(dZ), torch.empty_like(dX), torch.empty_like(dF), torch.zeros(2, dtype=torch.float64, device=dev)
         ptr = lambda t_: C.c_void_p(t_.data_ptr())
-        dctx.call("gpsig_tens_vs_seq_weighted_grad", p, ptr(dZ), ptr(dX), T, N, L, int(increments), ptr(dF), ptr(dG), ptr(dgZ), ptr(dgX), ptr(dgF),
-                  C.cast(dgb.data_ptr(), _P))
-        torch.cuda.synchronize()
-        assert rel(dgZ, tZ.grad) < 1e-9 and rel(dgX, tX.grad) < 1e-9 and rel(dgF, tF.grad) < 1e-9
+        # ... with the chain totals handed from the forward call to the reverse pass where the tile kernel leaves them
+        aux = torch.empty(int(_lib.load().gpsig_tens_vs_seq_aux_elems(C.byref(p), T, N)), dtype=torch.float64, device=dev)
+        dout, wrote = torch.empty((T, N), dtype=torch.float64, device=dev), C.c_int32(0)
+        dctx.call("gpsig_tens_vs_seq_weighted", p, ptr(dZ), ptr(dX), T, N, L, int(increments), ptr(dF), ptr(dout), ptr(aux), C.byref(wrote))
+        assert rel(dout, want) < 1e-10
+        assert wrote.value == (1 if (order == 1 and d <= 8 and T >= 32) else 0), (wrote.value, T, d, order)
+        for use_aux in (False, True):
+            if use_aux and not wrote.value:
+                continue
+            dctx.call("gpsig_tens_vs_seq_weighted_grad", p, ptr(dZ), ptr(dX), T, N, L, int(increments), ptr(dF), ptr(dG), ptr(aux) if use_aux else None,
+                      ptr(dgZ), ptr(dgX), ptr(dgF), C.cast(dgb.data_ptr(), _P))
+            torch.cuda.synchronize()
+            assert rel(dgZ, tZ.grad) < 1e-9 and rel(dgX, tX.grad) < 1e-9 and rel(dgF, tF.grad) < 1e-9, (use_aux, rel(dgZ, tZ.grad), rel(dgX, tX.grad))
         kt.p0.grad = None
 
 

@@ -1159,6 +1159,37 @@ def test_low_rank_golden_fixtures(K, golden_lowrank):
             assert np.abs(np.asarray(got[k]) - want).max() <= tol * np.abs(want).max(), (n, k, np.abs(np.asarray(got[k]) - want).max() / np.abs(want).max())
 
 
+def test_low_rank_fresh_draw_on_device_tensors(K):
+    """Low-rank evaluations of CUDA tensors WITHOUT lr_state: the draw (landmark gather, whitening) happens half way through a sequence
+    of device-pointer calls on the tensors' own context and must leave its pointer mode alone (round-2 advisor finding: the whitening
+    used to switch the shared context to host pointers).  Same generator state -> the same matrices as with the draw made up front,
+    and as the host-array evaluation."""
+    import torch
+    rng = np.random.default_rng(77)
+    N, N2, L, d, M, T = 20, 7, 9, 3, 3, 6
+    X = np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+    X2 = np.cumsum(0.4 * rng.standard_normal((N2, L, d)), axis=1).reshape(N2, -1)
+    Z = rng.standard_normal((M * (M + 1) // 2, T, d))
+    dev = torch.device("cuda:0")
+    Xc, X2c, Zc = (torch.tensor(a, device=dev) for a in (X, X2, Z))
+    kern = K.SignatureRBF(L * d, d, M, low_rank=True, num_components=14, rank_bound=9, lengthscales=1.2)
+    for call in (lambda k_, st: k_.K(Xc, lr_state=st), lambda k_, st: k_.K(Xc, X2c, lr_state=st), lambda k_, st: k_.Kdiag(Xc, lr_state=st),
+                 lambda k_, st: k_.K_tens_vs_seq(Zc, Xc, lr_state=st), lambda k_, st: k_.K_tens(Zc, lr_state=st)):
+        kern.rng = np.random.default_rng(5)
+        fresh = call(kern, None)
+        assert fresh.is_cuda and bool(torch.isfinite(fresh).all())
+    # the same draw made up front, on device tensors and on host arrays
+    kern.rng = np.random.default_rng(5)
+    fresh = kern.K(Xc, X2c)
+    kern.rng = np.random.default_rng(5)
+    st = kern.draw_low_rank(X=Xc, X2=X2c)
+    assert torch.equal(fresh, kern.K(Xc, X2c, lr_state=st))
+    np.testing.assert_allclose(fresh.cpu().numpy(), kern.K(X, X2, lr_state=st), rtol=0, atol=1e-12 * float(fresh.abs().max()))
+    kern.rng = np.random.default_rng(5)
+    Kzz, Kzx, Kxx = kern.K_tens_n_seq_covs(Zc, Xc)
+    assert Kzz.is_cuda and Kzx.shape == (T, N) and bool(torch.isfinite(Kzx).all())
+
+
 def test_low_rank_exact_limit_and_convergence(K):
     rng = np.random.default_rng(43)
     N, L, d = 8, 5, 2
