@@ -37,7 +37,8 @@ class SketchC(C.Structure):
 class LowRankC(C.Structure):
     """struct gpsig_lowrank."""
     _fields_ = [("num_components", C.c_int32), ("rank_bound", C.c_int32), ("num_sketches", C.c_int32),
-                ("landmarks", C.POINTER(C.c_double)), ("whitening", C.POINTER(C.c_double)), ("sketches", C.POINTER(SketchC))]
+                ("landmarks", C.POINTER(C.c_double)), ("whitening", C.POINTER(C.c_double)), ("sketches", C.POINTER(SketchC)),
+                ("device_state", C.c_void_p)]
 
 
 _P = C.POINTER(Params)
@@ -60,6 +61,7 @@ _KERNEL_FUNCS = {
     "gpsig_kernel_K_tens_vs_seq": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "gpsig_kernel_K_tens_n_seq_covs": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "gpsig_kernel_K_seq_n_seq_covs": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "gpsig_lr_draw": [_i32, _i32, _i32, C.c_uint64, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, C.POINTER(_vp)],
     "gpsig_lr_gather_points": [_vp, _i64, _i32, C.POINTER(_i64), _i64, C.POINTER(C.c_double)],
     "gpsig_base_kernel_matrix": [C.POINTER(C.c_double), C.POINTER(C.c_double), _i64, _i64, _i32, C.POINTER(C.c_double)],
     "gpsig_lr_whitening": [C.POINTER(C.c_double), _i32, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
@@ -74,6 +76,10 @@ _KERNEL_FUNCS = {
 }
 _PLAIN = {
     "gpsig_abi_version": ([], C.c_int),
+    "gpsig_lr_state_destroy": ([_vp], None),
+    "gpsig_lr_state_sizes": ([_vp, _vp, C.POINTER(_i32), C.POINTER(_i32)], C.c_int),
+    "gpsig_lr_state_export": ([_vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               C.POINTER(SketchC)], C.c_int),
     "gpsig_tens_vs_seq_aux_elems": ([_P, _i64, _i64], _i64),
     "gpsig_ctx_create": ([C.c_int, _vp, C.POINTER(_vp)], C.c_int),
     "gpsig_ctx_destroy": ([_vp], None),

@@ -17,6 +17,7 @@
 #include "aux_kernels.hpp"
 #include "lowrank_kernels.hpp"
 #include "lr_fused_args.hpp"
+#include "lr_draw_kernels.hpp"
 #include "seq_args.hpp"
 #include "seq_configs.hpp"
 #include "tvs_tile_kernel.hpp"
@@ -364,6 +365,72 @@ struct LrDev {                 // device copies of a gpsig_lowrank
     std::vector<int> k1, k2;
 };
 
+// entries a projection is given room for: the expected number plus twelve standard deviations (never more than all of them)
+int32_t lr_sketch_capacity(int64_t D, int r, int sparsity) {
+    if (sparsity == 2) return int32_t(r);
+    const double s = sparsity == 0 ? sqrt(double(D)) : double(D) / log(double(D));
+    const double mean = double(D) * r / (s < 1.0 ? 1.0 : s);
+    double cap = mean + 12.0 * sqrt(mean) + 64.0;
+    if (cap > double(D) * r) cap = double(D) * r;
+    return int32_t(cap);
+}
+
+int lr_state_layout(gpsig_lr_state* st, int M) {
+    using gpsig::LrEntry;
+    size_t o = 0;
+    auto take = [&](size_t n, size_t align = 16) { o = (o + align - 1) / align * align; const size_t at = o; o += n; return at; };
+    const int c = st->c;
+    const size_t o_idx = take(sizeof(int64_t) * (size_t(c) + size_t(st->r) + 8));
+    const size_t o_S = take(sizeof(double) * size_t(c) * st->d_eff);
+    const size_t o_jd = take(sizeof(double) * c), o_W = take(sizeof(double) * size_t(c) * c), o_Wh = take(sizeof(double) * size_t(c) * c);
+    const size_t o_WhT = take(sizeof(double) * size_t(c) * c), o_ev = take(sizeof(double) * c), o_work = take(sizeof(double) * c);
+    const size_t o_info = take(sizeof(int) * 4);
+    size_t o_sk[gpsig::LR_FUSED_MAX_SKETCHES][6];
+    int k2 = c;
+    for (int i = 0; i < st->nsk; ++i) {
+        gpsig_lr_state::Sk& s = st->sk[i];
+        s.k1 = c; s.k2 = k2;
+        s.cap = lr_sketch_capacity(int64_t(c) * k2, st->r, st->sparsity);
+        o_sk[i][0] = take(sizeof(int32_t) * (size_t(st->r) + 1));
+        o_sk[i][1] = take(sizeof(int32_t) * (size_t(st->r) + 1));
+        o_sk[i][2] = take(sizeof(int32_t) * size_t(s.cap));
+        o_sk[i][3] = take(sizeof(int32_t) * size_t(s.cap));
+        o_sk[i][4] = take(sizeof(double) * size_t(s.cap));
+        o_sk[i][5] = take(sizeof(LrEntry) * (size_t(s.cap) + 1));
+        k2 = st->r;
+    }
+    (void)M;
+    if (o > st->bytes) {
+        if (st->block) { (void)hipStreamSynchronize(st->ctx->stream); (void)hipFree(st->block); st->block = nullptr; st->bytes = 0; }
+        if (hipMalloc(&st->block, o + 256) != hipSuccess) return GPSIG_ERR_NOMEM;
+        st->bytes = o + 256;
+    }
+    char* b = static_cast<char*>(st->block);
+    st->idx = reinterpret_cast<int64_t*>(b + o_idx);
+    st->S = reinterpret_cast<double*>(b + o_S); st->jd = reinterpret_cast<double*>(b + o_jd); st->W = reinterpret_cast<double*>(b + o_W);
+    st->Wh = reinterpret_cast<double*>(b + o_Wh); st->WhT = reinterpret_cast<double*>(b + o_WhT); st->ev = reinterpret_cast<double*>(b + o_ev);
+    st->work = reinterpret_cast<double*>(b + o_work); st->info = reinterpret_cast<int*>(b + o_info);
+    for (int i = 0; i < st->nsk; ++i) {
+        gpsig_lr_state::Sk& s = st->sk[i];
+        s.counts = reinterpret_cast<int32_t*>(b + o_sk[i][0]); s.colptr = reinterpret_cast<int32_t*>(b + o_sk[i][1]);
+        s.i1 = reinterpret_cast<int32_t*>(b + o_sk[i][2]); s.i2 = reinterpret_cast<int32_t*>(b + o_sk[i][3]);
+        s.val = reinterpret_cast<double*>(b + o_sk[i][4]); s.ent = reinterpret_cast<LrEntry*>(b + o_sk[i][5]);
+    }
+    return GPSIG_OK;
+}
+
+// the LrDev view of a device-resident state (what lr_upload builds from host arrays)
+void lr_state_dev(const gpsig_lr_state* st, LrDev* D) {
+    D->c = st->c; D->r = st->r; D->nsk = st->nsk;
+    D->S = st->S; D->Wh = st->Wh;
+    for (int i = 0; i < st->nsk; ++i) {
+        D->colptr.push_back(st->sk[i].colptr); D->i1.push_back(st->sk[i].i1); D->i2.push_back(st->sk[i].i2);
+        D->val.push_back(st->sk[i].val); D->ent.push_back(st->sk[i].ent);
+        D->k1.push_back(st->sk[i].k1); D->k2.push_back(st->sk[i].k2);
+    }
+}
+
+
 int lr_check(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr) {
     if (!lr) return fail(c, GPSIG_ERR_INVALID, "lowrank descriptor is NULL");
     if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "low-rank mode is built for float64 only");
@@ -371,6 +438,13 @@ int lr_check(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr) {
     if (p->order != 1 && p->num_levels > 1) return fail(c, GPSIG_ERR_UNSUPPORTED, "Low-rank mode not implemented for order higher than 1.");
     if (lr->num_components < 1 || lr->rank_bound < 1) return fail(c, GPSIG_ERR_INVALID, "num_components and rank_bound must be positive");
     if (lr->num_sketches != p->num_levels - 1) return fail(c, GPSIG_ERR_INVALID, "need one sketch per level 2..num_levels");
+    if (lr->device_state) {                  // drawn on the device (gpsig_lr_draw): nothing on the host to check
+        const gpsig_lr_state* st = lr->device_state;
+        if (st->ctx != c) return fail(c, GPSIG_ERR_INVALID, "the low-rank state belongs to another context");
+        if (st->c != lr->num_components || st->r != lr->rank_bound || st->nsk != lr->num_sketches)
+            return fail(c, GPSIG_ERR_INVALID, "the low-rank state was drawn for other sizes");
+        return GPSIG_OK;
+    }
     if (!lr->landmarks || !lr->whitening || (lr->num_sketches > 0 && !lr->sketches)) return fail(c, GPSIG_ERR_INVALID, "NULL low-rank array");
     int k2 = lr->num_components;
     for (int i = 0; i < lr->num_sketches; ++i) {
@@ -399,6 +473,11 @@ static uint64_t lr_fnv(uint64_t h, const void* p, size_t n) {
 // upload landmarks, whitening and sketches into one scratch block -- unless the block already holds exactly these (content hash):
 // the random objects of one evaluation go through several calls, and every upload is a host synchronisation
 int lr_upload(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, int d_eff, LrDev* D) {
+    if (lr->device_state) {                  // already where the kernels read it
+        if (lr->device_state->d_eff != d_eff) return fail(c, GPSIG_ERR_INVALID, "the low-rank state was drawn for %d columns, the call has %d", lr->device_state->d_eff, d_eff);
+        lr_state_dev(lr->device_state, D);
+        return GPSIG_OK;
+    }
     const int cc = lr->num_components;
     uint64_t hsh = 0xcbf29ce484222325ull;
     const int64_t dims[4] = {cc, d_eff, lr->rank_bound, lr->num_sketches};
@@ -1549,6 +1628,9 @@ void gpsig_ctx_destroy(gpsig_ctx* c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->probe_stream) { if (c->probe_stop) *c->probe_stop = 1; (void)hipStreamSynchronize(c->probe_stream); (void)hipStreamDestroy(c->probe_stream); }
     if (c->probe_buf) (void)hipFree(c->probe_buf);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->side_fork) (void)hipEventDestroy(c->side_fork);
+    if (c->side_join) (void)hipEventDestroy(c->side_join);
     for (int k = 0; k < 2; ++k) {
         if (c->pin[k]) (void)hipHostFree(c->pin[k]);
         if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]);
@@ -1592,6 +1674,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "tvs_zreg")) c->tvs_zreg = value;
     else if (!strcmp(name, "tvs_grad_tile")) c->tvs_grad_tile = value;
     else if (!strcmp(name, "pinned_staging")) c->pinned_staging = value ? 1 : 0;
+    else if (!strcmp(name, "lr_jacobi")) c->lr_jacobi = value ? 1 : 0;
     else if (!strcmp(name, "keep_reset")) c->keep_reset = value ? 1 : 0;
     else if (!strcmp(name, "pk2")) c->allow_pk2 = value;
     else if (!strcmp(name, "f32_pack")) c->f32_pack = value;
@@ -1925,36 +2008,6 @@ int gpsig_base_kernel_matrix(gpsig_ctx* c, const gpsig_params* p, const double* 
     return GPSIG_OK;
 }
 
-namespace {
-// W (c x c, symmetric) += diag(jd)                                                        low_rank_calculations.py:52
-__global__ void add_diag_kernel(double* __restrict__ W, const double* __restrict__ jd, int c) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < c) W[int64_t(i) * c + i] += jd[i];
-}
-// Sign convention of the eigenvectors (an eigensolver returns each up to sign, the reference's tf.self_adjoint_eig included):
-// the component of largest magnitude is made positive (the first such component on ties).  sgn[j] = +-1.
-// The level >= 2 features contract coordinate pairs of the whitened features with a fixed random projection, so their
-// values -- not their distribution -- depend on these signs; fixing them makes an evaluation a function of its random objects.
-__global__ void eig_sign_kernel(const double* __restrict__ Ucm, int c, double* __restrict__ sgn) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= c) return;
-    double best = 0.0, s = 1.0;
-    for (int i = 0; i < c; ++i) {
-        const double v = Ucm[int64_t(j) * c + i];
-        if (fabs(v) > best) { best = fabs(v); s = v < 0.0 ? -1.0 : 1.0; }
-    }
-    sgn[j] = s;
-}
-// Wh[i][j] = sgn[j] U[i][j] / sqrt(ev[j] + jitter), U column-major as dsyevd leaves it    low_rank_calculations.py:56-57, :60
-__global__ void whiten_kernel(const double* __restrict__ Ucm, const double* __restrict__ ev, const double* __restrict__ sgn, int c,
-                              double jitter, double* __restrict__ Wh) {
-    const int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-    if (idx >= int64_t(c) * c) return;
-    const int i = int(idx / c), j = int(idx - int64_t(i) * c);
-    Wh[idx] = sgn[j] * Ucm[int64_t(j) * c + i] / sqrt(ev[j] + jitter);
-}
-}  // namespace
-
 int gpsig_lr_whitening(gpsig_ctx* c, const gpsig_params* p, const double* S_host, int32_t nc, int32_t d, const double* jitter_diag_host,
                        double* Wh_host, double* ev_host) {
     ENTER(c, p);
@@ -2055,7 +2108,9 @@ int gpsig_lr_seq_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowra
     // B[j][k] must be Wh[k][j]: use the transposed copy made below
     void* wht;
     CHK(ensure(c, B_LR7, sizeof(double) * size_t(cc) * cc + 8, &wht));
-    {
+    if (lr->device_state) {
+        wht = lr->device_state->WhT;
+    } else {
         std::vector<double> t(size_t(cc) * cc);
         for (int a = 0; a < cc; ++a)
             for (int b = 0; b < cc; ++b) t[size_t(b) * cc + a] = lr->whitening[size_t(a) * cc + b];
@@ -2143,7 +2198,9 @@ int gpsig_lr_tens_features(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowr
     CHK(ensure(c, B_LR5, sizeof(double) * size_t(T) * wmax + 8, &Ra));
     CHK(ensure(c, B_LR6, sizeof(double) * size_t(T) * wmax + 8, &Rb));
     CHK(ensure(c, B_LR7, sizeof(double) * size_t(cc) * cc + 8, &wht));
-    {
+    if (lr->device_state) {
+        wht = lr->device_state->WhT;
+    } else {
         std::vector<double> t(size_t(cc) * cc);
         for (int a = 0; a < cc; ++a)
             for (int b = 0; b < cc; ++b) t[size_t(b) * cc + a] = lr->whitening[size_t(a) * cc + b];
@@ -2288,5 +2345,162 @@ int gpsig_lr_kernel_diag(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowran
     CHK(out_done(c, out, dout, ob));
     return finish(c);
 }
+
+int gpsig_lr_draw(gpsig_ctx* c, const gpsig_params* p, int32_t num_components, int32_t rank_bound, int32_t sparsity, uint64_t seed,
+                  const void* X, int64_t N, int32_t L, const void* X2, int64_t N2, int32_t L2, const void* Z, int64_t T, int32_t increments,
+                  gpsig_lr_state** inout) {
+    ENTER(c, p);
+    using namespace gpsig;
+    if (!inout) return fail(c, GPSIG_ERR_INVALID, "null state slot");
+    if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "low-rank mode is built for float64 only");
+    if (c->ptr_mode != GPSIG_PTR_DEVICE) return fail(c, GPSIG_ERR_INVALID, "gpsig_lr_draw takes device pointers (the host-side draw is gpsig_amd/low_rank.py)");
+    if (num_components < 1 || rank_bound < 1 || sparsity < 0 || sparsity > 2) return fail(c, GPSIG_ERR_INVALID, "bad low-rank sizes");
+    if (num_components > LR_DRAW_MAX || rank_bound > LR_DRAW_MAX) return fail(c, GPSIG_ERR_UNSUPPORTED, "the device-side draw takes at most %d components / rank bound", LR_DRAW_MAX);
+    const int M = p->num_levels, nsk = M - 1;
+    if (nsk > LR_FUSED_MAX_SKETCHES) return fail(c, GPSIG_ERR_UNSUPPORTED, "low-rank mode is built for num_levels <= %d", LR_FUSED_MAX_SKETCHES + 1);
+    ScaleParams s;
+    CHK(scale_params(c, p, true, &s));
+    const int d_eff = s.d_eff();
+    const int lt = M * (M + 1) / 2;
+    const int64_t ztot = Z ? int64_t(lt) * T * (increments ? 2 : 1) : 0;
+    const int64_t total = ztot + (X ? N * L : 0) + (X2 ? N2 * L2 : 0);
+    if (num_components > total) return fail(c, GPSIG_ERR_INVALID, "num_components exceeds the number of available points");
+    if (sparsity == 2 && nsk > 0 && (rank_bound > int64_t(num_components) * num_components || (nsk > 1 && rank_bound > int64_t(num_components) * rank_bound)))
+        return fail(c, GPSIG_ERR_INVALID, "rank_bound exceeds the number of coordinate pairs");
+    gpsig_lr_state* st = *inout;
+    if (st && st->ctx != c) return fail(c, GPSIG_ERR_INVALID, "the state belongs to another context");
+    if (!st) {
+        st = new (std::nothrow) gpsig_lr_state();
+        if (!st) return fail(c, GPSIG_ERR_NOMEM, "out of host memory");
+        st->ctx = c;
+    }
+    st->c = num_components; st->d_eff = d_eff; st->r = rank_bound; st->nsk = nsk; st->sparsity = sparsity;
+    CHK(no_capture(c, "a low-rank draw may have to allocate"));
+    if (lr_state_layout(st, M) != GPSIG_OK) { if (!*inout) delete st; return fail(c, GPSIG_ERR_NOMEM, "hipMalloc failed for the low-rank state"); }
+    *inout = st;
+    const PhiloxKey key{uint32_t(seed), uint32_t(seed >> 32)};
+    const int cc = st->c;
+    HIPCHK(c, hipMemsetAsync(st->info, 0, sizeof(int) * 4, c->stream));
+    hipLaunchKernelGGL(lr_draw_indices_kernel, dim3(1), dim3(64), 0, c->stream, total, cc, key, uint32_t(LRS_LANDMARKS), st->idx);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(lr_gather_landmarks_kernel, dim3(grid_for(int64_t(cc) * d_eff)), dim3(256), 0, c->stream, st->idx, cc,
+                       static_cast<const double*>(Z), ztot, static_cast<const double*>(X), X ? N : 0, int(L), static_cast<const double*>(X2),
+                       X2 ? N2 : 0, int(L2), s, key, p->jitter, st->S, st->jd);
+    HIPCHK(c, hipGetLastError());
+    // the projections depend on the seed only: they are drawn on a side stream while the main one decomposes the landmark Gram
+    if (!c->side_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipEventRecord(c->side_fork, c->stream));            // after the memset of info and everything queued before this draw
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->side_fork, 0));
+    hipStream_t const ss = c->side_stream;
+    // W = kappa(S, S) + diag(jd)                                                          low_rank_calculations.py:51-52
+    double p0, p1;
+    base_p(p, &p0, &p1);
+    const double* spec;
+    CHK(spectral_table(c, p, &spec));
+    hipLaunchKernelGGL(base_kernel_matrix_kernel<double>, dim3(grid_for(int64_t(cc) * cc)), dim3(256), 0, c->stream, static_cast<const double*>(st->S),
+                       static_cast<const double*>(st->S), int64_t(cc), int64_t(cc), d_eff, int(p->base_kernel), p0, p1, spec, st->W);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(add_diag_kernel, dim3((cc + 255) / 256), dim3(256), 0, c->stream, st->W, static_cast<const double*>(st->jd), cc);
+    HIPCHK(c, hipGetLastError());
+    // eigendecomposition (:55), sign convention, U / sqrt(S + jitter) (:56-57, :60)
+    if (cc <= LR_JACOBI_MAX && c->lr_jacobi != 0) {
+        const size_t lds = sizeof(double) * (2 * size_t(cc) * (cc + 1) + 2 * size_t(LR_JACOBI_MAX));
+        // (the kernel has read W into LDS long before it writes the eigenvectors over it)
+        hipLaunchKernelGGL(lr_jacobi_eig_kernel, dim3(1), dim3(LR_JACOBI_THREADS), lds, c->stream, static_cast<const double*>(st->W), cc, st->W, st->ev, st->info);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        std::string err;
+        if (!solver_dsyevd(&c->blas_handle, c->stream, cc, st->W, st->ev, st->work, st->info, &err)) return fail(c, GPSIG_ERR_HIP, "%s", err.c_str());
+    }
+    hipLaunchKernelGGL(eig_sign_kernel, dim3((cc + 63) / 64), dim3(64), 0, c->stream, static_cast<const double*>(st->W), cc, st->work);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(whiten_kernel, dim3(unsigned((int64_t(cc) * cc + 255) / 256)), dim3(256), 0, c->stream, static_cast<const double*>(st->W),
+                       static_cast<const double*>(st->ev), static_cast<const double*>(st->work), cc, p->jitter, st->Wh);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(lr_transpose_kernel, dim3(unsigned((cc * cc + 255) / 256)), dim3(256), 0, c->stream, static_cast<const double*>(st->Wh), cc, st->WhT);
+    HIPCHK(c, hipGetLastError());
+    // one projection per level 2..M (signature_algs.py:184-191)
+    for (int i = 0; i < nsk; ++i) {
+        gpsig_lr_state::Sk& k = st->sk[i];
+        const int64_t D = int64_t(k.k1) * k.k2;
+        if (sparsity == 2) {
+            hipLaunchKernelGGL(lr_draw_lin_kernel, dim3(1), dim3(64), 0, ss, D, st->r, k.k1, key, uint32_t(i), k.colptr, k.i1, k.i2, k.val, k.ent);
+            HIPCHK(c, hipGetLastError());
+            continue;
+        }
+        const double sv = sparsity == 0 ? sqrt(double(D)) : double(D) / log(double(D));       // low_rank_calculations.py:172-175
+        const double inv_s = sv < 1.0 ? 1.0 : 1.0 / sv, scale = sqrt((sv < 1.0 ? 1.0 : sv) / double(st->r));   // :192
+        for (int fill = 0; fill < 2; ++fill) {
+            hipLaunchKernelGGL(lr_draw_sparse_kernel, dim3(unsigned(st->r)), dim3(64), 0, ss, D, st->r, k.k1, inv_s, scale, key, uint32_t(i), fill,
+                               k.cap, k.counts, static_cast<const int32_t*>(k.colptr), k.i1, k.i2, k.val, k.ent);
+            HIPCHK(c, hipGetLastError());
+            if (!fill) {
+                hipLaunchKernelGGL(lr_colptr_kernel, dim3(1), dim3(64), 0, ss, static_cast<const int32_t*>(k.counts), st->r, k.cap, k.colptr,
+                                   st->info + 1);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->side_join, ss));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_join, 0));
+    return GPSIG_OK;
+}
+
+void gpsig_lr_state_destroy(gpsig_lr_state* st) {
+    if (!st) return;
+    if (st->block) {
+        (void)hipSetDevice(st->ctx->device);
+        (void)hipStreamSynchronize(st->ctx->stream);
+        (void)hipFree(st->block);
+    }
+    delete st;
+}
+
+// sizes[0..4] = c, d_eff, r, number of projections, Jacobi sweeps taken (0: rocSOLVER); nnz[i] = entries of projection i.  Waits for the draw.
+int gpsig_lr_state_sizes(gpsig_ctx* c, const gpsig_lr_state* st, int32_t* sizes, int32_t* nnz) {
+    if (!c || !st || !sizes) return GPSIG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    sizes[0] = st->c; sizes[1] = st->d_eff; sizes[2] = st->r; sizes[3] = st->nsk; sizes[4] = 0;
+    int info[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(info, st->info, sizeof(info), hipMemcpyDeviceToHost, c->stream));
+    for (int i = 0; i < st->nsk && nnz; ++i)
+        HIPCHK(c, hipMemcpyAsync(&nnz[i], st->sk[i].colptr + st->r, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    sizes[4] = info[2];
+    if (info[0] != 0) return fail(c, GPSIG_ERR_HIP, "the eigendecomposition of the landmark Gram did not converge (info = %d)", info[0]);
+    if (info[1] != 0) return fail(c, GPSIG_ERR_HIP, "a random projection drew more entries than its capacity (a 12-sigma event: draw again)");
+    return GPSIG_OK;
+}
+
+// Copies of what was drawn, all HOST pointers: landmarks (c, d'), jitter_diag (c), whitening (c, c), eigenvalues (c) -- any may be
+// NULL --, and for projection i the arrays of sketches[i] (colptr r+1, i1 / i2 / val nnz[i] as reported by gpsig_lr_state_sizes).
+int gpsig_lr_state_export(gpsig_ctx* c, const gpsig_lr_state* st, double* landmarks, double* jitter_diag, double* whitening, double* eigenvalues,
+                          const gpsig_sketch* sketches) {
+    if (!c || !st) return GPSIG_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t cc = size_t(st->c);
+    if (landmarks) HIPCHK(c, hipMemcpyAsync(landmarks, st->S, sizeof(double) * cc * st->d_eff, hipMemcpyDeviceToHost, c->stream));
+    if (jitter_diag) HIPCHK(c, hipMemcpyAsync(jitter_diag, st->jd, sizeof(double) * cc, hipMemcpyDeviceToHost, c->stream));
+    if (whitening) HIPCHK(c, hipMemcpyAsync(whitening, st->Wh, sizeof(double) * cc * cc, hipMemcpyDeviceToHost, c->stream));
+    if (eigenvalues) HIPCHK(c, hipMemcpyAsync(eigenvalues, st->ev, sizeof(double) * cc, hipMemcpyDeviceToHost, c->stream));
+    for (int i = 0; i < st->nsk && sketches; ++i) {
+        const gpsig_sketch& h = sketches[i];
+        const gpsig_lr_state::Sk& k = st->sk[i];
+        if (h.nnz < 0 || h.nnz > k.cap) return fail(c, GPSIG_ERR_INVALID, "projection %d: %d entries asked for, capacity %d", i, h.nnz, k.cap);
+        HIPCHK(c, hipMemcpyAsync(const_cast<int32_t*>(h.colptr), k.colptr, sizeof(int32_t) * (size_t(st->r) + 1), hipMemcpyDeviceToHost, c->stream));
+        if (h.nnz) {
+            HIPCHK(c, hipMemcpyAsync(const_cast<int32_t*>(h.i1), k.i1, sizeof(int32_t) * size_t(h.nnz), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(const_cast<int32_t*>(h.i2), k.i2, sizeof(int32_t) * size_t(h.nnz), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(const_cast<double*>(h.val), k.val, sizeof(double) * size_t(h.nnz), hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return GPSIG_OK;
+}
+
 
 }  // extern "C"

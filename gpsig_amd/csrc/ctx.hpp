@@ -86,6 +86,7 @@ struct gpsig_ctx {
     double* tvs_aux_out = nullptr;   // set by gpsig_tens_vs_seq_weighted around its launch: where the tile kernel leaves the chain totals
     bool tvs_aux_written = false;    // ... and whether it did (only the tile kernel does)
     int tvs_grad_tile = 1;        // tensor-vs-sequence reverse pass: 1 = the tile kernel (tvs_grad_tile_kernel.hpp) where built, 0 = the round-1 kernels
+    int lr_jacobi = 1;            // gpsig_lr_draw: eigendecomposition of the landmark Gram by the one-workgroup Jacobi kernel (c <= 64), 0: rocSOLVER
     int tvs_zreg = -1;            // tensor-lane gradient: components in registers (1) or LDS (0); -1 = planner's choice
     std::string err;
     DevBuf buf[B_COUNT];
@@ -121,6 +122,9 @@ struct gpsig_ctx {
     size_t pin_bytes = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     int pinned_staging = 1;                    // 0: plain hipMemcpyAsync on the caller's pageable memory (A/B runs)
+    // gpsig_lr_draw: the projections are drawn on a stream of their own while the landmark Gram is being decomposed
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     volatile int* probe_stop = nullptr;        // pinned host memory the wave polls: raised by gpsig_clock_probe_read
 };
 

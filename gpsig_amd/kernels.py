@@ -175,6 +175,57 @@ class LowRankState:
         return lr
 
 
+class DeviceLowRankState:
+    """The random objects of one low-rank evaluation drawn and kept ON THE DEVICE (gpsig_lr_draw): what the reference draws inside its
+    TF graph at every evaluation.  ``export()`` copies them out as a host-side LowRankState (the CPU restatement then evaluates the very
+    same objects); a state is drawn into again by the next ``draw_low_rank`` of its kernel object."""
+
+    SPARSITY = {'sqrt': 0, 'log': 1, 'lin': 2}
+
+    def __init__(self, ctx, num_components, rank_bound, num_sketches):
+        self.ctx, self._h = ctx, C.c_void_p()
+        self.num_components, self.rank_bound, self.num_sketches = int(num_components), int(rank_bound), int(num_sketches)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.ctx._lib.gpsig_lr_state_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def as_c(self, keep):
+        lr = _lib.LowRankC()
+        lr.num_components, lr.rank_bound, lr.num_sketches = self.num_components, self.rank_bound, self.num_sketches
+        lr.device_state = self._h
+        keep.extend([lr, self])
+        return lr
+
+    def export(self):
+        """Host copies of what was drawn, as a LowRankState (waits for the stream)."""
+        lib, ctx = self.ctx._lib, self.ctx
+        sizes, nnz = (C.c_int32 * 5)(), (C.c_int32 * max(self.num_sketches, 1))()
+        ctx.check(lib.gpsig_lr_state_sizes(ctx._h, self._h, sizes, nnz))
+        c, d_eff, r, nsk, self.jacobi_sweeps = (int(v) for v in sizes)
+        S, jd, Wh, ev = np.empty((c, d_eff)), np.empty(c), np.empty((c, c)), np.empty(c)
+        arr = (_lib.SketchC * max(nsk, 1))()
+        host = []
+        k2 = c
+        for i in range(nsk):
+            n = int(nnz[i])
+            colptr, i1, i2, val = np.empty(r + 1, np.int32), np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n)
+            arr[i].k1, arr[i].k2, arr[i].r, arr[i].nnz = c, k2, r, n
+            arr[i].colptr = colptr.ctypes.data_as(C.POINTER(C.c_int32))
+            arr[i].i1 = i1.ctypes.data_as(C.POINTER(C.c_int32))
+            arr[i].i2 = i2.ctypes.data_as(C.POINTER(C.c_int32))
+            arr[i].val = val.ctypes.data_as(C.POINTER(C.c_double))
+            host.append((c, k2, r, colptr, i1, i2, val))
+            k2 = r
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))                    # noqa: E731
+        ctx.check(lib.gpsig_lr_state_export(ctx._h, self._h, dp(S), dp(jd), dp(Wh), dp(ev), arr))
+        return LowRankState(S, Wh, [_lr.Sketch(*h) for h in host], r, jitter_diag=jd, eigenvalues=ev)
+
+
 class SignatureKernel:
     """Reference: ``gpsig.kernels.SignatureKernel`` (gpsig/kernels.py:15-761).
 
@@ -227,6 +278,7 @@ class SignatureKernel:
             self.lengthscales = None
         self._base_params = (0.0, 0.0)
         self.rng = np.random.default_rng()   # low-rank mode: source of landmarks and projections (the reference uses TF's global RNG)
+        self.device_draw = True              # ... drawn on the device for CUDA tensors (gpsig_lr_draw), on the host for host arrays
 
     # ---- validators (kernels.py:94-133) ------------------------------------------------------
     @staticmethod
@@ -521,7 +573,9 @@ class SignatureKernel:
         """Draw the landmarks (uniformly, without replacement, from the scaled points of every given argument:
         kernels.py:444-446, :562-563), whiten their Gram (low_rank_calculations.py:50-57) and draw one projection
         per level (low_rank_calculations.py:76-193).  Returns a LowRankState that can be passed to K(..., lr_state=)."""
-        cands = []
+        L_ = _launch_f64(X, X2, Z)
+        if L_.device_mode and self.device_draw:
+            return self._draw_low_rank_on_device(L_, X, X2, Z, increments)
         L_ = _launch_f64(X, X2)
         p = self._params(L_.keep, _lib.F64)
         total = 0
@@ -555,6 +609,24 @@ class SignatureKernel:
         jd = np.ascontiguousarray(JITTER * self.rng.random(c))                    # low_rank_calculations.py:52
         sk = _lr.draw_level_sketches(self.rng, self.num_levels, c, int(self.rank_bound), self.sparsity)
         return self.low_rank_state(S, jd, sk, ctx=L_.ctx)
+
+    def _draw_low_rank_on_device(self, L_, X, X2, Z, increments):
+        """gpsig_lr_draw: landmark choice, gather, whitening (Jacobi eigendecomposition) and the projections of every level on the
+        tensors' own stream, seeded from ``self.rng``; nothing waits for the host.  Returns a DeviceLowRankState."""
+        p = self._params(L_.keep, _lib.F64)
+        n1, l1 = self._seq_dims(X) if X is not None else (0, 1)
+        n2, l2 = self._seq_dims(X2) if X2 is not None else (0, 1)
+        t = self._tens_dims(Z, increments) if Z is not None else 0
+        st = getattr(self, "_device_lr_state", None)
+        if st is None or st.ctx is not L_.ctx or (st.num_components, st.rank_bound, st.num_sketches) != (
+                int(self.num_components), int(self.rank_bound), self.num_levels - 1):
+            st = DeviceLowRankState(L_.ctx, self.num_components, self.rank_bound, self.num_levels - 1)
+        seed = int(self.rng.integers(0, 2 ** 63 - 1))
+        L_.ctx.call("gpsig_lr_draw", p, int(self.num_components), int(self.rank_bound), DeviceLowRankState.SPARSITY[self.sparsity], C.c_uint64(seed),
+                    L_.inp(X), n1, l1, L_.inp(X2), n2, l2, L_.inp(Z), t, int(bool(increments)), C.byref(st._h))
+        st.keep = L_.keep            # the (converted) inputs stay alive until the draw has read them
+        self._device_lr_state = st
+        return st
 
     def low_rank_state(self, landmarks, jitter_diag, sketches, ctx=None):
         """The LowRankState of GIVEN random objects: landmarks (c, d') -- scaled points --, the jitter draw (c,) and one sketch

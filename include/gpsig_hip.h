@@ -111,6 +111,7 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "pinned_staging" host-pointer mode: 1 (default) transfers of 2 MiB and more run in 16 MiB chunks through two pinned buffers of the
  *                 context, the DMA of one chunk overlapping a threaded host copy of the previous one; 0 plain hipMemcpy on the caller's
  *                 (pageable) memory
+ *   "lr_jacobi"   gpsig_lr_draw: 1 (default) the landmark Gram's eigendecomposition by the one-workgroup Jacobi kernel (c <= 64), 0 rocSOLVER
  *   "tvs_zreg"    tensor-lane gradient: components in registers (1) or LDS (0), -1 automatic
  *   "tvs_tile"    tensor-vs-sequence tile kernel (levels split over the waves of a workgroup, coalesced result tiles):
  *                 -1 wherever it is built and there are at least 32 tensors, 0 never, 1 also for fewer tensors
@@ -242,6 +243,7 @@ typedef struct gpsig_sketch {
     const int32_t* i2;       /* nnz, < k2 */
     const double* val;       /* nnz */
 } gpsig_sketch;
+typedef struct gpsig_lr_state gpsig_lr_state;   /* the same objects drawn and kept on the device: gpsig_lr_draw below */
 typedef struct gpsig_lowrank {
     int32_t num_components;  /* c */
     int32_t rank_bound;      /* r */
@@ -249,7 +251,23 @@ typedef struct gpsig_lowrank {
     const double* landmarks;
     const double* whitening;
     const gpsig_sketch* sketches;
+    const gpsig_lr_state* device_state;   /* non-NULL: the three arrays above are ignored */
 } gpsig_lowrank;
+/* The random objects of one low-rank evaluation drawn ON THE DEVICE, as the reference draws them inside its graph at every
+ * evaluation (low_rank_calculations.py:12-20, :47-57, :92-101, :104-127, :139-193): c landmark rows uniformly without replacement
+ * among the scaled components of Z (or NULL), the scaled observations of X and of X2 (or NULL) -- in this order --, the jitter
+ * diagonal, the whitening of the landmark Gram (a one-workgroup Jacobi eigendecomposition for c <= 64, rocSOLVER beyond), and one
+ * projection per level 2..M; sparsity 0 'sqrt', 1 'log', 2 'lin'.  A counter-based generator (Philox-4x32-10) keyed by `seed`: the same
+ * seed gives the same objects.  Device pointers; everything is queued on the ctx stream, nothing waits for the host.  *state: NULL to
+ * create, or a state of this context to draw into again.  gpsig_lr_state_sizes / _export copy what was drawn to the host (for the
+ * CPU restatement of the same evaluation); they wait for the stream. */
+int gpsig_lr_draw(gpsig_ctx* ctx, const gpsig_params* p, int32_t num_components, int32_t rank_bound, int32_t sparsity, uint64_t seed,
+                  const void* X, int64_t N, int32_t L, const void* X2, int64_t N2, int32_t L2, const void* Z, int64_t T,
+                  int32_t increments, gpsig_lr_state** state);
+void gpsig_lr_state_destroy(gpsig_lr_state* state);
+int gpsig_lr_state_sizes(gpsig_ctx* ctx, const gpsig_lr_state* state, int32_t* sizes /* 5: c, d', r, projections, Jacobi sweeps */, int32_t* nnz);
+int gpsig_lr_state_export(gpsig_ctx* ctx, const gpsig_lr_state* state, double* landmarks, double* jitter_diag, double* whitening,
+                          double* eigenvalues, const gpsig_sketch* sketches);
 /* scaled / lagged observations number idx[0..R) (flat index n*L + t) of X -> out (R, d') on the HOST (landmark candidates) */
 int gpsig_lr_gather_points(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L, const int64_t* idx,
                            int64_t R, double* out_host);

@@ -1184,10 +1184,136 @@ def test_low_rank_fresh_draw_on_device_tensors(K):
     kern.rng = np.random.default_rng(5)
     st = kern.draw_low_rank(X=Xc, X2=X2c)
     assert torch.equal(fresh, kern.K(Xc, X2c, lr_state=st))
-    np.testing.assert_allclose(fresh.cpu().numpy(), kern.K(X, X2, lr_state=st), rtol=0, atol=1e-12 * float(fresh.abs().max()))
+    np.testing.assert_allclose(fresh.cpu().numpy(), kern.K(X, X2, lr_state=st.export()), rtol=0, atol=1e-12 * float(fresh.abs().max()))
+    # the host-side draw on the same tensors still works (kern.device_draw = False) and goes through the same contexts
+    kern.device_draw = False
+    kern.rng = np.random.default_rng(5)
+    sth = kern.draw_low_rank(X=Xc, X2=X2c)
+    assert bool(torch.isfinite(kern.K(Xc, X2c, lr_state=sth)).all())
+    kern.device_draw = True
     kern.rng = np.random.default_rng(5)
     Kzz, Kzx, Kxx = kern.K_tens_n_seq_covs(Zc, Xc)
     assert Kzz.is_cuda and Kzx.shape == (T, N) and bool(torch.isfinite(Kzx).all())
+
+
+@pytest.mark.parametrize("sparsity", ["sqrt", "log", "lin"])
+@pytest.mark.parametrize("base", ["rbf", "linear"])
+def test_low_rank_objects_drawn_on_the_device(K, sparsity, base):
+    """gpsig_lr_draw (round 3): landmarks, jitter diagonal, whitening (one-workgroup Jacobi eigendecomposition) and the projections of
+    every level drawn on the device with a counter-based generator.  (i) what was drawn is well formed and a function of the seed;
+    (ii) exported to the host, the oracle -- which whitens the same landmarks itself with NumPy's eigh and applies the same
+    projections -- reproduces every covariance of the device evaluation; (iii) the Jacobi whitening equals rocSOLVER's."""
+    import torch
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(141)
+    LR_TOL = LR_TOLS[base]
+    N, N2, L, d, M, T = 23, 9, 12, 3, 4, 7
+    c, r = 11, 9
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+    Y = np.cumsum(0.3 * rng.standard_normal((N2, L, d)), axis=1).reshape(N2, -1)
+    dev = torch.device("cuda:0")
+    Xc, Yc = torch.tensor(X, device=dev), torch.tensor(Y, device=dev)
+
+    def rel(got, want):
+        got, want = np.asarray(got.cpu() if torch.is_tensor(got) else got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+        assert got.shape == want.shape and np.isfinite(got).all()
+        return float(np.abs(got - want).max() / np.abs(want).max())
+    for incr in (False, True):
+        Z = rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d))
+        Zc = torch.tensor(Z, device=dev)
+        kx, ko = _lr_pair(K, base, L, d, M, normalization=True, num_components=c, rank_bound=r, sparsity=sparsity,
+                          lengthscales=0.6 + rng.random(d), variances=0.5 + rng.random(M + 1))
+        kx.rng = np.random.default_rng(7)
+        st = kx.draw_low_rank(X=Xc, X2=Yc, Z=Zc, increments=incr)
+        assert isinstance(st, K.DeviceLowRankState)
+        h = st.export()
+        # (i) well formed: c distinct candidates in ascending order (so every landmark is a scaled point of Z, X or Y, in that order), a
+        # jitter draw inside (0, 1e-6), projections stored by column with rows ascending inside a column
+        ztot = Z.reshape(-1, d).shape[0]
+        cand = np.concatenate([Z.reshape(-1, d) / kx.lengthscales, X.reshape(-1, d) / kx.lengthscales, Y.reshape(-1, d) / kx.lengthscales])
+        where = [int(np.argmin(np.abs(cand - row).sum(1))) for row in h.landmarks]
+        assert all(np.abs(cand[w] - row).max() < 1e-12 for w, row in zip(where, h.landmarks)) and ztot > 0
+        assert where == sorted(where) and len(set(where)) == c
+        assert (h.jitter_diag > 0).all() and (h.jitter_diag < 1e-6).all()
+        k2 = c
+        for sk in h.sketches:
+            assert (sk.k1, sk.k2, sk.r) == (c, k2, r) and sk.colptr[0] == 0 and (np.diff(sk.colptr) >= 0).all() and sk.colptr[-1] == len(sk.val)
+            assert (sk.i1 >= 0).all() and (sk.i1 < c).all() and (sk.i2 >= 0).all() and (sk.i2 < k2).all()
+            if sparsity == "lin":
+                assert len(sk.val) == r and set(np.abs(sk.val)) == {1.0} and len(set(zip(sk.i1, sk.i2))) == r
+            else:
+                for j in range(r):
+                    rows = (sk.i1 + c * sk.i2)[sk.colptr[j]:sk.colptr[j + 1]]
+                    assert (np.diff(rows) > 0).all()
+            k2 = r
+        # ... a function of the seed
+        kx.rng = np.random.default_rng(7)
+        h2 = kx.draw_low_rank(X=Xc, X2=Yc, Z=Zc, increments=incr).export()
+        assert np.array_equal(h.landmarks, h2.landmarks) and np.array_equal(h.whitening, h2.whitening)
+        assert all(np.array_equal(a.val, b.val) and np.array_equal(a.i1, b.i1) for a, b in zip(h.sketches, h2.sketches))
+        kx.rng = np.random.default_rng(8)
+        h3 = kx.draw_low_rank(X=Xc, X2=Yc, Z=Zc, increments=incr).export()
+        assert not np.array_equal(h.landmarks, h3.landmarks)
+        # (ii) the restatement on the exported objects against the device evaluation on the device-resident ones
+        kx.rng = np.random.default_rng(7)
+        st = kx.draw_low_rank(X=Xc, X2=Yc, Z=Zc, increments=incr)
+        h = st.export()
+        lo = O.LowRankOracle(ko, h.landmarks, h.jitter_diag, h.sketches)
+        inv_p, inv_o = h.whitening @ h.whitening.T, lo.Wh @ lo.Wh.T
+        assert np.abs(inv_p - inv_o).max() <= 1e-7 * np.abs(inv_o).max()
+        assert rel(kx.K(Xc, lr_state=st), lo.K(X)) <= LR_TOL
+        assert rel(kx.K(Xc, Yc, lr_state=st, return_levels=True), lo.K(X, Y, return_levels=True)) <= LR_TOL
+        assert rel(kx.K_tens(Zc, increments=incr, lr_state=st), lo.K_tens(Z, increments=incr)) <= LR_TOL
+        assert rel(kx.K_tens_vs_seq(Zc, Xc, increments=incr, lr_state=st, return_levels=True), lo.K_tens_vs_seq(Z, X, increments=incr, return_levels=True)) <= LR_TOL
+        assert rel(kx.Kdiag(Xc, lr_state=st), lo.Kdiag(X)) <= LR_TOL
+        # the unfused per-op feature path reads the same state (its transposed whitening)
+        ctx = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
+        ctx.set_option("lr_fused", 0)
+        try:
+            assert rel(kx.K(Xc, Yc, lr_state=st), lo.K(X, Y)) <= LR_TOL
+        finally:
+            ctx.set_option("lr_fused", 1)
+        # (iii) rocSOLVER instead of the Jacobi kernel: the same (W + jitter)^-1
+        ctx.set_option("lr_jacobi", 0)
+        try:
+            kx.rng = np.random.default_rng(7)
+            hs = kx.draw_low_rank(X=Xc, X2=Yc, Z=Zc, increments=incr).export()
+        finally:
+            ctx.set_option("lr_jacobi", 1)
+        assert np.array_equal(hs.landmarks, h.landmarks)
+        assert np.abs(hs.whitening @ hs.whitening.T - inv_p).max() <= 1e-7 * np.abs(inv_p).max()
+        assert np.abs(hs.eigenvalues - h.eigenvalues).max() <= 1e-12 * np.abs(h.eigenvalues).max()
+
+
+def test_device_drawn_projections_are_unbiased(K):
+    """Statistics of the device generator: the number of entries of a 'sqrt' projection follows Binomial(D r, 1/s), its values are
+    N(0, s/r), and the sketched product is unbiased -- E[<P(a (x) b), P(a' (x) b')>] = <a, a'><b, b'> -- with an error that shrinks as
+    the rank bound grows (low_rank_calculations.py:152-193)."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    L, d, M, c = 10, 2, 2, 24
+    X = torch.tensor(np.cumsum(0.3 * rng.standard_normal((40, L, d)), axis=1).reshape(40, -1), device=dev)
+    a, b, a2, b2 = (rng.standard_normal(c) for _ in range(4))
+    exact = (a @ a2) * (b @ b2)
+    errs = {}
+    for r in (8, 64):
+        kx = K.SignatureRBF(L * d, d, M, low_rank=True, num_components=c, rank_bound=r, sparsity="sqrt")
+        est, counts, vals = [], [], []
+        for seed in range(200):
+            kx.rng = np.random.default_rng(seed)
+            sk = kx.draw_low_rank(X=X).export().sketches[0]
+            est.append(float(sk.apply(a, b) @ sk.apply(a2, b2)))
+            counts.append(len(sk.val))
+            vals.append(sk.val)
+        D, s = c * c, float(c)
+        mean_n, sd_n = D * r / s, np.sqrt(D * r / s * (1 - 1 / s))
+        assert abs(np.mean(counts) - mean_n) < 5 * sd_n / np.sqrt(len(counts))
+        v = np.concatenate(vals) / np.sqrt(s / r)
+        assert abs(v.mean()) < 5 / np.sqrt(len(v)) and abs(v.var() - 1.0) < 0.1 and abs((np.abs(v) < 1).mean() - 0.6827) < 0.03
+        errs[r] = float(np.std(est))
+        assert abs(np.mean(est) - exact) < 5 * errs[r] / np.sqrt(len(est)) + 1e-12
+    assert errs[64] < 0.6 * errs[8]
 
 
 def test_low_rank_exact_limit_and_convergence(K):

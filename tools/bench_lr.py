@@ -55,7 +55,8 @@ def main():
     ctx.set_option("lr_fused", args.fused)
     ctx.set_option("lr_fused_variant", args.variant)
     ctx.set_option("lr_fused_pad", args.pad)
-    st = kern.draw_low_rank(X=X, Z=Z)
+    st = kern.draw_low_rank(X=X, Z=Z)                 # CUDA tensors: drawn on the device (gpsig_lr_draw)
+    sth = st.export() if hasattr(st, "export") else st   # host copies: entry counts, the oracle's input
 
     def timed(fn, steps=args.steps):
         fn()
@@ -104,12 +105,16 @@ def main():
         ms_gemm, _ = timed(lambda: L_.ctx.call("gpsig_lr_kernel", p, lr, px, None, n, n, 1, 1, 0, oxx))
         stages.update(gram_product_ms=ms_gemm)
     F = 1 + args.components + (M - 1) * (args.rank or args.components)
-    nnz = [int(s.val.shape[0]) for s in st.sketches]
+    nnz = [int(s.val.shape[0]) for s in sth.sketches]
+    ms_draw, _ = timed(lambda: kern.draw_low_rank(X=X, Z=Z))
+    kern.device_draw = False
+    ms_draw_host, _ = timed(lambda: kern.draw_low_rank(X=X, Z=Z), steps=3)
+    kern.device_draw = True
     l = L - 1
     res = {"what": f"low-rank mode, {args.config} shape: " + (f"K_tens_n_seq_covs, T={T} inducing tensors, " if T else "K(X), ") +
                    f"N={N}, L={L}, d={d}, num_levels={M}, Signature{'Linear' if args.base == 'linear' else 'RBF'}, fp64, "
                    f"num_components={args.components}, rank_bound={args.rank or args.components}, sparsity={args.sparsity}",
-           "ms_per_evaluation": ms, "entries_per_s": pairs / (ms * 1e-3), "ms_with_fresh_draw": ms_fresh, "stages": stages,
+           "ms_per_evaluation": ms, "entries_per_s": pairs / (ms * 1e-3), "ms_with_fresh_draw": ms_fresh, "ms_draw_on_device": ms_draw, "ms_draw_on_host_round2": ms_draw_host, "stages": stages,
            "fused_feature_kernel": bool(args.fused), "feature_width": F, "sketch_nnz_per_level": nnz,
            # the fused kernel's model: per sequence and sketch entry two 512-byte LDS reads per 64 time steps (lr_fused_kernel.hpp)
            "seq_features_lds_bytes": float(N) * ((l + 63) // 64) * 64 * 8 * (2 * sum(nnz) + args.components ** 2),
@@ -118,7 +123,7 @@ def main():
     if args.verify:
         from oracle import sigkern_oracle as O
         ko = O.SignatureKernelOracle(L * d, d, M, base=args.base, lengthscales=ls)
-        lo = O.LowRankOracle(ko, st.landmarks, st.jitter_diag, st.sketches)
+        lo = O.LowRankOracle(ko, sth.landmarks, sth.jitter_diag, sth.sketches)
         ns, ts = 20, 12
         if T:
             want = lo.K_tens_vs_seq(Zh[:, :ts], Xh[:ns])
