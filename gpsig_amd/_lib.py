@@ -51,6 +51,10 @@ _KERNEL_FUNCS = {
     "gpsig_seq_diag_levels": [_vp, _i64, _i32, _vp],
     "gpsig_tens_gram_levels": [_vp, _i64, _i32, _vp],
     "gpsig_tens_vs_seq_levels": [_vp, _vp, _i64, _i64, _i32, _i32, _vp],
+    "gpsig_lattice_levels": [_vp, _i64, _i32, _i32, _vp],
+    "gpsig_lattice_levels_grad": [_vp, _i64, _i32, _i32, _vp, _vp],
+    "gpsig_chain_levels": [_vp, _i64, _i32, _vp],
+    "gpsig_chain_levels_grad": [_vp, _i64, _i32, _vp, _vp],
     "gpsig_tens_vs_seq_weighted": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i32)],
     "gpsig_tens_vs_seq_weighted_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)],
     "gpsig_kernel_K": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],

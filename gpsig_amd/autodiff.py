@@ -265,6 +265,119 @@ class _TensVsSeqWeighted(torch.autograd.Function):
         return gZ.to(ctx.dt[0]), gX.to(ctx.dt[1]), gF.t().to(ctx.dt[2]), gp0, None, None
 
 
+# ---- the "matrix route": base-kernel tensors built here, the recursions on them in the library --------------------------------------
+# For state spaces beyond the gradient kernels' 64 columns and for SignatureSpectral (whose alpha, omega, gamma are trained:
+# gpsig/kernels.py:912-914) the base-kernel tensor of kernels.py:188-340 is built with torch ops on the GPU -- at that width it is a
+# d-deep contraction, a rocBLAS GEMM (north_star: "MFMA only where it is a true contraction") -- and differentiated by autograd;
+# the library does what gpsig/signature_algs.py does with that tensor: the recursions on its increment lattices and their reverse
+# passes (gpsig_lattice_levels / gpsig_chain_levels and their _grad).  The lattices are held in memory: minibatch-sized problems.
+class _LatticeLevels(torch.autograd.Function):
+    """signature_kern_first_order / _higher_order (signature_algs.py:28-35, :58-74) on increment lattices dM (P, R1, R2) -> (M+1, P)."""
+
+    @staticmethod
+    def forward(ctx, dM, spec):
+        A = _c(dM)
+        P, R1, R2 = A.shape
+        keep = []
+        p = spec.params(1, 0.0, keep)
+        out = torch.empty((spec.num_levels + 1, P), dtype=torch.float64, device=A.device)
+        _ctx_for(A).call("gpsig_lattice_levels", p, _ptr(A), P, R1, R2, _ptr(out))
+        ctx.spec, ctx.dt = spec, dM.dtype
+        ctx.save_for_backward(A)
+        return out.to(_out_dtype(dM))
+
+    @staticmethod
+    def backward(ctx, G):
+        (A,) = ctx.saved_tensors
+        P, R1, R2 = A.shape
+        keep = []
+        p = ctx.spec.params(1, 0.0, keep)
+        gA = torch.empty_like(A)
+        _ctx_for(A).call("gpsig_lattice_levels_grad", p, _ptr(A), P, R1, R2, _ptr(_c(G)), _ptr(gA))
+        return gA.to(ctx.dt), None
+
+
+class _ChainLevels(torch.autograd.Function):
+    """signature_kern_tens_vs_seq_first_order (signature_algs.py:116-127) on component increments m (lt, R, P) -> (M+1, P)."""
+
+    @staticmethod
+    def forward(ctx, m, spec):
+        A = _c(m)
+        lt, R, P = A.shape
+        keep = []
+        p = spec.params(1, 0.0, keep)
+        out = torch.empty((spec.num_levels + 1, P), dtype=torch.float64, device=A.device)
+        _ctx_for(A).call("gpsig_chain_levels", p, _ptr(A), P, R, _ptr(out))
+        ctx.spec, ctx.dt = spec, m.dtype
+        ctx.save_for_backward(A)
+        return out.to(_out_dtype(m))
+
+    @staticmethod
+    def backward(ctx, G):
+        (A,) = ctx.saved_tensors
+        lt, R, P = A.shape
+        keep = []
+        p = ctx.spec.params(1, 0.0, keep)
+        gA = torch.empty_like(A)
+        _ctx_for(A).call("gpsig_chain_levels_grad", p, _ptr(A), P, R, _ptr(_c(G)), _ptr(gA))
+        return gA.to(ctx.dt), None
+
+
+class _SqrtZeroGrad(torch.autograd.Function):
+    """sqrt with derivative 0 at 0 (TensorFlow's, and torch's, is inf there, and 0 * inf = NaN reaches every parameter through the
+    zero distances of a symmetric base-kernel tensor: the reference's 'exp' spectral family cannot be trained on K(X, X) as written,
+    gpsig/kernels.py:924; the clamp of its own Matern kernels, :779-781, has the same effect as this)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.sqrt(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return torch.where(y > 0, g / (2 * y), torch.zeros_like(g))
+
+
+def base_kernel_matrix(base, A, B, p0=None, p1=0.0, spectral=None):
+    """kappa(a_i, b_j) of gpsig/kernels.py:765-781, :799-993 for A (..., P, d), B (..., Q, d) -> (..., P, Q), torch ops (autograd)."""
+    if base == "spectral":                                                                          # :921-942
+        family, alpha, omega, gamma = spectral
+        Q = alpha.shape[0]
+        out = 0.0
+        # on the difference tensor, as the reference (:923-925): the exponential envelope takes a square root of the squared distance,
+        # and a distance assembled from norms and an inner product is rounding noise -- 1e-8 after the root -- where it should be zero
+        diff = A[..., :, None, :] - B[..., None, :, :]
+        for q in range(Q):
+            sq = torch.square(diff * gamma[q]).sum(-1)
+            gauss = family == "rbf" or (family == "mixed" and q < Q // 2)
+            env = torch.exp(-sq / 2) if gauss else torch.exp(-_SqrtZeroGrad.apply(sq) / 2)          # :928 / :926
+            out = out + alpha[q] * env * torch.cos(2.0 * math.pi * (diff * omega[q]).sum(-1))       # :937, :942
+        return out
+    inner = torch.matmul(A, B.transpose(-1, -2))
+    if base == "linear":
+        return inner
+    As, Bs = (A * A).sum(-1), (B * B).sum(-1)
+    if base == "cosine":
+        return inner / (torch.sqrt(As)[..., :, None] * torch.sqrt(Bs)[..., None, :])
+    if base == "poly":
+        return (inner + p0) ** p1
+    dist = -2 * inner + As[..., :, None] + Bs[..., None, :]
+    if base == "rbf":
+        return torch.exp(-dist / 2)
+    if base == "mix":
+        return p0 * torch.exp(-dist / 2) + (1.0 - p0) * inner
+    r = torch.sqrt(torch.clamp(dist, min=1e-40))                                                    # :779-781
+    if base == "matern12":
+        return torch.exp(-r)
+    if base == "matern32":
+        return (1.0 + math.sqrt(3.0) * r) * torch.exp(-math.sqrt(3.0) * r)
+    if base == "matern52":
+        return (1.0 + math.sqrt(5.0) * r + 5.0 / 3.0 * r * r) * torch.exp(-math.sqrt(5.0) * r)
+    raise ValueError(base)
+
+
 # ---- scaling (gpsig/kernels.py:343-398, gpsig/lags.py) in torch ------------------------------------------------------
 def _lin_interp(time, X, time_query):
     """gpsig/lags.py:7-38 (3-D branch :32-33).  X (N, L, d), time (L,), time_query (L, p) -> (N, L, p, d)."""
@@ -299,6 +412,9 @@ class SignatureKernelModule(torch.nn.Module):
         if kern.low_rank:
             raise NotImplementedError("gradients are built for the exact (non low-rank) mode only")
         self.kern = kern
+        d_cols = kern.num_features * (kern.num_lags + 1)
+        # beyond 64 columns and for the spectral kernel: base-kernel tensors here (GEMMs, autograd), recursions in the library
+        self.matrix_route = kern._base == "spectral" or d_cols > 64
         dev = torch.device(device)
         par = lambda v: torch.nn.Parameter(torch.as_tensor(np.asarray(v, dtype=np.float64), device=dev))
         self.raw_variances = par(positive_inverse(kern.variances))
@@ -307,6 +423,10 @@ class SignatureKernelModule(torch.nn.Module):
         if kern.num_lags > 0:
             self.raw_lags = par(logistic_inverse(kern.lags))
             self.raw_gamma = par(positive_inverse(kern.gamma))
+        if kern._base == "spectral":
+            self.raw_alpha = par(positive_inverse(kern.alpha))                                      # kernels.py:912-914: transforms.positive
+            self.raw_omega = par(positive_inverse(kern.omega))
+            self.raw_sgamma = par(positive_inverse(kern.gamma))
         bp = kern._current_base_params()
         self._has_p0 = kern._base in ("poly", "mix")
         self.raw_p0 = par(positive_inverse(bp[0])) if self._has_p0 else None
@@ -336,6 +456,8 @@ class SignatureKernelModule(torch.nn.Module):
             k.lags, k.gamma = self.lags.detach().cpu().numpy(), self.gamma.detach().cpu().numpy()
         if self._has_p0:
             k._set_base_p0(float(self.p0.detach().cpu()))
+        if k._base == "spectral":
+            k.alpha, k.omega, k.gamma = (positive(r).detach().cpu().numpy() for r in (self.raw_alpha, self.raw_omega, self.raw_sgamma))
         return k
 
     # ---- scaling -------------------------------------------------------------------------------------------------
@@ -369,11 +491,77 @@ class SignatureKernelModule(torch.nn.Module):
         return Z.reshape(shape)
 
     # ---- level primitives ------------------------------------------------------------------------------------------
-    def _seq_levels(self, Xs, X2s=None): return _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
-    def _diag_levels(self, Xs): return _SeqDiagLevels.apply(Xs, self.p0, self._spec)
-    def _tens_levels(self, Zs, increments): return _TensGramLevels.apply(Zs, self.p0, self._spec, increments)
-    def _tvs_levels(self, Zs, Xs, increments): return _TensVsSeqLevels.apply(Zs, Xs, self.p0, self._spec, increments)
-    def _tvs_weighted(self, Zs, Xs, fac, increments): return _TensVsSeqWeighted.apply(Zs, Xs, fac, self.p0, self._spec, increments)
+    def _seq_levels(self, Xs, X2s=None):
+        return self._mx_seq_levels(Xs, X2s) if self.matrix_route else _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
+
+    def _diag_levels(self, Xs):
+        return self._mx_diag_levels(Xs) if self.matrix_route else _SeqDiagLevels.apply(Xs, self.p0, self._spec)
+
+    def _tens_levels(self, Zs, increments):
+        return self._mx_tens_levels(Zs, increments) if self.matrix_route else _TensGramLevels.apply(Zs, self.p0, self._spec, increments)
+
+    def _tvs_levels(self, Zs, Xs, increments):
+        return self._mx_tvs_levels(Zs, Xs, increments) if self.matrix_route else _TensVsSeqLevels.apply(Zs, Xs, self.p0, self._spec, increments)
+
+    def _tvs_weighted(self, Zs, Xs, fac, increments):
+        if self.matrix_route:
+            return (self._mx_tvs_levels(Zs, Xs, increments) * fac[:, None, :]).sum(dim=0)
+        return _TensVsSeqWeighted.apply(Zs, Xs, fac, self.p0, self._spec, increments)
+
+    # the same four primitives on the matrix route (kernels.py:188-340 with torch ops up to the differenced tensor)
+    def _kappa(self, A, B):
+        spec = None
+        if self.kern._base == "spectral":
+            spec = (self.kern.family, positive(self.raw_alpha), positive(self.raw_omega), positive(self.raw_sgamma))
+        return base_kernel_matrix(self.kern._base, A, B, self.p0, self._spec.p1, spec)
+
+    def _mx_lattices(self, K4):
+        """(P, L1, L2) base-kernel lattices -> levels (M+1, P): signature_algs.py:25-26 here, :28-74 in the library."""
+        if self.kern.difference:
+            K4 = K4[:, 1:, 1:] + K4[:, :-1, :-1] - K4[:, :-1, 1:] - K4[:, 1:, :-1]
+        return _LatticeLevels.apply(K4.contiguous(), self._spec)
+
+    def _mx_seq_levels(self, Xs, X2s=None):
+        N1, L1, d = Xs.shape                                                                        # kernels.py:208-237
+        Ys = Xs if X2s is None else X2s
+        N2, L2 = Ys.shape[:2]
+        Kt = self._kappa(Xs.reshape(N1 * L1, d), Ys.reshape(N2 * L2, d)).reshape(N1, L1, N2, L2)
+        return self._mx_lattices(Kt.permute(0, 2, 1, 3).reshape(N1 * N2, L1, L2)).reshape(-1, N1, N2)
+
+    def _mx_diag_levels(self, Xs):
+        return self._mx_lattices(self._kappa(Xs, Xs))                                               # kernels.py:188-205
+
+    def _mx_tens_levels(self, Zs, increments):
+        lt, T, d = Zs.shape[0], Zs.shape[1], Zs.shape[-1]                                           # kernels.py:263-283
+        if increments:
+            Mk = self._kappa(Zs.reshape(lt, 2 * T, d), Zs.reshape(lt, 2 * T, d)).reshape(lt, T, 2, T, 2)
+            Mk = Mk[:, :, 1, :, 1] + Mk[:, :, 0, :, 0] - Mk[:, :, 1, :, 0] - Mk[:, :, 0, :, 1]      # :276-277
+        else:
+            Mk = self._kappa(Zs, Zs)
+        lev, k = [torch.ones_like(Mk[0])], 0                                                        # signature_algs.py:76-99
+        for i in range(1, self._spec.num_levels + 1):
+            R = Mk[k]
+            for j in range(1, i):
+                R = R * Mk[k + j]
+            lev.append(R)
+            k += i
+        return torch.stack(lev, dim=0)
+
+    def _mx_tvs_levels(self, Zs, Xs, increments):
+        if self._spec.order > 1 and self._spec.num_levels > 1:
+            raise NotImplementedError("the matrix route (spectral kernel / more than 64 columns) has the tensor-vs-sequence chains at order 1")
+        lt, T, d = Zs.shape[0], Zs.shape[1], Zs.shape[-1]                                           # kernels.py:313-340
+        N, L = Xs.shape[:2]
+        Xf = Xs.reshape(N * L, d)
+        if increments:
+            Mk = self._kappa(Zs.reshape(lt * T * 2, d), Xf).reshape(lt, T, 2, N, L)
+            Mk = Mk[:, :, 1] - Mk[:, :, 0]                                                          # :329-330
+        else:
+            Mk = self._kappa(Zs.reshape(lt * T, d), Xf).reshape(lt, T, N, L)
+        if self.kern.difference:
+            Mk = Mk[..., 1:] - Mk[..., :-1]                                                         # signature_algs.py:114
+        m = Mk.permute(0, 3, 1, 2).reshape(lt, Mk.shape[-1], T * N)                                 # (lt, R, P), pair index fastest
+        return _ChainLevels.apply(m.contiguous(), self._spec).reshape(-1, T, N)
 
     def _w(self):
         return self.sigma * self.variances                                                          # kernels.py:471

@@ -850,6 +850,231 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     return finish(c);
 }
 
+}  // extern "C"
+
+// ---- the recursions on GIVEN base-kernel lattices ("matrix route") ------------------------------------------------------------
+// For state spaces wider than the gradient kernels' 64 columns, and for base kernels the kernels do not differentiate
+// (SignatureSpectral: alpha, omega, gamma are trainable, gpsig/kernels.py:912-914), the caller builds the base-kernel tensor itself --
+// a d-deep contraction: a library GEMM -- and differentiates it itself; what is left for this library is what the reference's
+// signature_algs.py does AFTER its lines :25-26 / :114: the recursion on the increment lattices, any order, and its reverse pass.
+// The lattices of a block of pairs live in scratch memory ((pairs, R1, R2) arrays, one pass over HBM per elementary operation, as in
+// seq_grad_ho above): a path for minibatch-sized problems, not for BASELINE-sized Grams.
+namespace {
+
+// levels (forward == true: out (M+1, P)) or dL/ddM (forward == false: G (M+1, P) in, gdM (P, R1, R2) out) of dM (P, R1, R2)
+int lattice_pass(gpsig_ctx* c, const gpsig_params* p, const double* dM, int64_t Ptot, int R1, int R2, bool forward, const double* Gup, double* out) {
+    const int M = p->num_levels, D = p->order;
+    const size_t cells = size_t(R1) * R2;
+    if (forward) {
+        hipLaunchKernelGGL(fill_pairs_kernel, dim3(grid_for(Ptot)), dim3(256), 0, c->stream, out, Ptot, 1.0);      // level 0 == 1
+        HIPCHK(c, hipGetLastError());
+    }
+    if (Ptot == 0) return GPSIG_OK;
+    if (cells == 0) {
+        if (forward) CHK(zero_async(c, out + Ptot, sizeof(double) * size_t(M) * Ptot));
+        return GPSIG_OK;
+    }
+    auto dm_of = [&](int m) { return m < D ? m : D; };
+    // scratch slots (slot 0 = the caller's dM, the last one = the caller's gdM): R_m[r][s] for m = 2 .. M-1 (backward) or two
+    // alternating grids (forward) | two grids of adjoints | two temporaries
+    std::vector<int> roff(M + 2, 0);
+    int nslots = 1;
+    if (forward) {
+        roff[0] = nslots; nslots += D * D;              // grid of the previous level
+        roff[1] = nslots; nslots += D * D;              // grid being built
+    } else {
+        for (int m = 2; m <= M - 1; ++m) { roff[m] = nslots; nslots += dm_of(m) * dm_of(m); }
+    }
+    const int u0 = nslots, u1 = u0 + (forward ? 0 : D * D), t0 = u1 + (forward ? 0 : D * D), t1 = t0 + 1;
+    nslots = t1 + 1;
+    const size_t per_pair = sizeof(double) * cells * size_t(nslots - 1);
+    int64_t chunk = int64_t(scratch_budget(c) / (per_pair ? per_pair : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > Ptot) chunk = Ptot;
+    void* scr;
+    CHK(ensure(c, B_GR5, per_pair * size_t(chunk) + 64, &scr));
+    for (int64_t p0 = 0; p0 < Ptot; p0 += chunk) {
+        const int64_t npairs = Ptot - p0 < chunk ? Ptot - p0 : chunk, P = npairs * int64_t(cells);
+        const double* const dm = dM + p0 * int64_t(cells);
+        double* const base = static_cast<double*>(scr);
+        double* const lam = forward ? nullptr : out + p0 * int64_t(cells);
+        auto slot = [&](int k) -> double* { return k == 0 ? const_cast<double*>(dm) : base + int64_t(k - 1) * P; };
+        const HoBlock B{p0, npairs, p0, 1, 1};
+        auto mul = [&](const double* A_, const double* B_, double* dst, double scale, int acc) {
+            hipLaunchKernelGGL(ho_mul_kernel, dim3(grid_for(P)), dim3(256), 0, c->stream, A_, B_, dst, P, scale, acc);
+        };
+        auto cum = [&](const double* src, double* dst, int axis, int reverse) {
+            hipLaunchKernelGGL(ho_cumsum_kernel, dim3(grid_for(npairs * (axis == 0 ? R2 : R1), 64)), dim3(64), 0, c->stream, src, dst, npairs, R1,
+                               R2, axis, reverse, 1.0, 0);
+        };
+        auto pairsum = [&](const double* src, int m, int acc) {
+            hipLaunchKernelGGL(ho_pairsum_kernel, dim3(unsigned(npairs < 65535 ? npairs : 65535)), dim3(64), 0, c->stream, src, npairs, int64_t(cells),
+                               out + int64_t(m) * Ptot + p0, acc);
+        };
+        if (forward) {
+            // grids alternate between two sets: prev (level m-1), cur (level m); level 1's grid is dM itself
+            int prev = roff[0], cur = roff[1];
+            auto G1 = [&](int set, int m, int r, int s) -> double* { return m == 1 ? slot(0) : slot(set + r * D + s); };
+            pairsum(slot(0), 1, 0);                                                                             // signature_algs.py:28 / :58
+            for (int m = 2; m <= M; ++m) {
+                const int dc = dm_of(m), dp = dm_of(m - 1);
+                auto Rp = [&](int r, int s) { return G1(prev, m - 1, r, s); };
+                auto sum_all = [&]() { for (int r = 0; r < dp; ++r) for (int s2 = 0; s2 < dp; ++s2) mul(Rp(r, s2), nullptr, slot(t0), 1.0, r + s2 > 0); };
+                auto sum_col = [&](int j2) { for (int r = 0; r < dp; ++r) mul(Rp(r, j2), nullptr, slot(t0), 1.0, r > 0); };
+                auto sum_row = [&](int j2) { for (int s2 = 0; s2 < dp; ++s2) mul(Rp(j2, s2), nullptr, slot(t0), 1.0, s2 > 0); };
+                sum_all(); cum(slot(t0), slot(t1), 0, 0); cum(slot(t1), slot(t0), 1, 0);
+                mul(slot(0), slot(t0), slot(cur), 1.0, 0);                                                      // :32 / :64
+                for (int j = 2; j <= dc; ++j) {
+                    sum_col(j - 2); cum(slot(t0), slot(t1), 0, 0);
+                    mul(slot(0), slot(t1), slot(cur + j - 1), 1.0 / j, 0);                                      // :66
+                    sum_row(j - 2); cum(slot(t0), slot(t1), 1, 0);
+                    mul(slot(0), slot(t1), slot(cur + (j - 1) * D), 1.0 / j, 0);                                // :67
+                    for (int k = 2; k <= dc; ++k) mul(slot(0), Rp(j - 2, k - 2), slot(cur + (j - 1) * D + k - 1), 1.0 / (double(j) * k), 0);   // :69
+                }
+                for (int r = 0; r < dc; ++r)
+                    for (int s2 = 0; s2 < dc; ++s2) pairsum(slot(cur + r * D + s2), m, r + s2 > 0);             // :33 / :71
+                std::swap(prev, cur);
+            }
+            HIPCHK(c, hipGetLastError());
+            continue;
+        }
+        auto Rm = [&](int m, int r, int s2) { return m == 1 ? slot(0) : slot(roff[m] + r * dm_of(m) + s2); };
+        auto bcast = [&](int m, double* dst, int acc) {
+            hipLaunchKernelGGL(ho_bcast_kernel, dim3(grid_for(P)), dim3(256), 0, c->stream, Gup, int64_t(m) * Ptot, int64_t(1), int64_t(0), B, int64_t(cells),
+                               dst, acc);
+        };
+        auto sum_all = [&](int m) { const int dp = dm_of(m); for (int r = 0; r < dp; ++r) for (int s2 = 0; s2 < dp; ++s2) mul(Rm(m, r, s2), nullptr, slot(t0), 1.0, r + s2 > 0); };
+        auto sum_col = [&](int m, int j2) { const int dp = dm_of(m); for (int r = 0; r < dp; ++r) mul(Rm(m, r, j2), nullptr, slot(t0), 1.0, r > 0); };
+        auto sum_row = [&](int m, int j2) { const int dp = dm_of(m); for (int s2 = 0; s2 < dp; ++s2) mul(Rm(m, j2, s2), nullptr, slot(t0), 1.0, s2 > 0); };
+        for (int m = 2; m <= M - 1; ++m) {                                                                      // forward grids, as seq_grad_ho
+            const int dc = dm_of(m);
+            sum_all(m - 1); cum(slot(t0), slot(t1), 0, 0); cum(slot(t1), slot(t0), 1, 0);
+            mul(slot(0), slot(t0), Rm(m, 0, 0), 1.0, 0);
+            for (int j = 2; j <= dc; ++j) {
+                sum_col(m - 1, j - 2); cum(slot(t0), slot(t1), 0, 0);
+                mul(slot(0), slot(t1), Rm(m, 0, j - 1), 1.0 / j, 0);
+                sum_row(m - 1, j - 2); cum(slot(t0), slot(t1), 1, 0);
+                mul(slot(0), slot(t1), Rm(m, j - 1, 0), 1.0 / j, 0);
+                for (int k = 2; k <= dc; ++k) mul(slot(0), Rm(m - 1, j - 2, k - 2), Rm(m, j - 1, k - 1), 1.0 / (double(j) * k), 0);
+            }
+        }
+        int ucur = u0, unext = u1;
+        auto U = [&](int set, int r, int s2) { return slot(set + r * D + s2); };
+        for (int r = 0; r < dm_of(M); ++r) for (int s2 = 0; s2 < dm_of(M); ++s2) bcast(M, U(ucur, r, s2), 0);
+        CHK(zero_async(c, lam, sizeof(double) * size_t(P)));
+        for (int m = M; m >= 2; --m) {
+            const int dc = dm_of(m), dp = dm_of(m - 1);
+            sum_all(m - 1); cum(slot(t0), slot(t1), 0, 0); cum(slot(t1), slot(t0), 1, 0);
+            mul(U(ucur, 0, 0), slot(t0), lam, 1.0, 1);
+            for (int j = 2; j <= dc; ++j) {
+                sum_col(m - 1, j - 2); cum(slot(t0), slot(t1), 0, 0);
+                mul(U(ucur, 0, j - 1), slot(t1), lam, 1.0 / j, 1);
+                sum_row(m - 1, j - 2); cum(slot(t0), slot(t1), 1, 0);
+                mul(U(ucur, j - 1, 0), slot(t1), lam, 1.0 / j, 1);
+                for (int k = 2; k <= dc; ++k) mul(U(ucur, j - 1, k - 1), Rm(m - 1, j - 2, k - 2), lam, 1.0 / (double(j) * k), 1);
+            }
+            mul(slot(0), U(ucur, 0, 0), slot(t0), 1.0, 0); cum(slot(t0), slot(t1), 0, 1); cum(slot(t1), slot(t0), 1, 1);
+            for (int r = 0; r < dp; ++r)
+                for (int s2 = 0; s2 < dp; ++s2) { bcast(m - 1, U(unext, r, s2), 0); mul(slot(t0), nullptr, U(unext, r, s2), 1.0, 1); }
+            for (int j = 2; j <= dc; ++j) {
+                mul(slot(0), U(ucur, 0, j - 1), slot(t0), 1.0 / j, 0); cum(slot(t0), slot(t1), 0, 1);
+                for (int r = 0; r < dp; ++r) mul(slot(t1), nullptr, U(unext, r, j - 2), 1.0, 1);
+                mul(slot(0), U(ucur, j - 1, 0), slot(t0), 1.0 / j, 0); cum(slot(t0), slot(t1), 1, 1);
+                for (int s2 = 0; s2 < dp; ++s2) mul(slot(t1), nullptr, U(unext, j - 2, s2), 1.0, 1);
+                for (int k = 2; k <= dc; ++k) mul(slot(0), U(ucur, j - 1, k - 1), U(unext, j - 2, k - 2), 1.0 / (double(j) * k), 1);
+            }
+            std::swap(ucur, unext);
+        }
+        mul(U(ucur, 0, 0), nullptr, lam, 1.0, 1);                                                               // level 1: R_1 = dM
+        HIPCHK(c, hipGetLastError());
+    }
+    return GPSIG_OK;
+}
+
+int lattice_check(gpsig_ctx* c, const gpsig_params* p) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (!p) return fail(c, GPSIG_ERR_INVALID, "params is NULL");
+    if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "the lattice primitives are built for float64 only");
+    if (p->num_levels < 1 || p->num_levels > GRAD_MAX_LEVELS) return fail(c, GPSIG_ERR_UNSUPPORTED, "num_levels outside [1, %d]", GRAD_MAX_LEVELS);
+    if (p->order < 1 || p->order > p->num_levels) return fail(c, GPSIG_ERR_INVALID, "order=%d outside [1, num_levels]", p->order);
+    HIPCHK(c, hipSetDevice(c->device));
+    return GPSIG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpsig_lattice_levels(gpsig_ctx* c, const gpsig_params* p, const void* dM, int64_t P, int32_t R1, int32_t R2, void* out) {
+    CHK(lattice_check(c, p));
+    if (P < 0 || R1 < 0 || R2 < 0) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
+    const size_t mb = sizeof(double) * size_t(P) * R1 * R2, ob = sizeof(double) * size_t(p->num_levels + 1) * P;
+    const void* dm;
+    CHK(in_dev(c, B_IN0, dM, mb, &dm));
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    CHK(lattice_pass(c, p, static_cast<const double*>(dm), P, R1, R2, true, nullptr, static_cast<double*>(dout)));
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_lattice_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* dM, int64_t P, int32_t R1, int32_t R2, const void* G, void* gdM) {
+    CHK(lattice_check(c, p));
+    if (P < 0 || R1 < 0 || R2 < 0) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
+    const size_t mb = sizeof(double) * size_t(P) * R1 * R2, gb = sizeof(double) * size_t(p->num_levels + 1) * P;
+    const void *dm, *dG;
+    CHK(in_dev(c, B_IN0, dM, mb, &dm));
+    CHK(in_dev(c, B_IN2, G, gb, &dG));
+    void* dg;
+    CHK(out_dev(c, B_OUT0, gdM, mb, &dg));
+    CHK(lattice_pass(c, p, static_cast<const double*>(dm), P, R1, R2, false, static_cast<const double*>(dG), static_cast<double*>(dg)));
+    CHK(out_done(c, gdM, dg, mb));
+    return finish(c);
+}
+
+int gpsig_chain_levels(gpsig_ctx* c, const gpsig_params* p, const void* m, int64_t P, int32_t R, void* out) {
+    CHK(lattice_check(c, p));
+    if (p->order > 1 && p->num_levels > 1) return fail(c, GPSIG_ERR_UNSUPPORTED, "the chain primitives are built for order 1");
+    if (P < 0 || R < 0) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
+    const int M = p->num_levels, lt = M * (M + 1) / 2;
+    const size_t mb = sizeof(double) * size_t(lt) * R * P, ob = sizeof(double) * size_t(M + 1) * P;
+    const void* dm;
+    CHK(in_dev(c, B_IN0, m, mb, &dm));
+    void* dout;
+    CHK(out_dev(c, B_OUT0, out, ob, &dout));
+    if (P > 0) {
+        hipLaunchKernelGGL(chain_levels_kernel, dim3(grid_for(P, 64)), dim3(64), 0, c->stream, static_cast<const double*>(dm), M, int64_t(R), P,
+                           static_cast<double*>(dout));
+        HIPCHK(c, hipGetLastError());
+    }
+    CHK(out_done(c, out, dout, ob));
+    return finish(c);
+}
+
+int gpsig_chain_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* m, int64_t P, int32_t R, const void* G, void* gm) {
+    CHK(lattice_check(c, p));
+    if (p->order > 1 && p->num_levels > 1) return fail(c, GPSIG_ERR_UNSUPPORTED, "the chain primitives are built for order 1");
+    if (P < 0 || R < 0) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
+    const int M = p->num_levels, lt = M * (M + 1) / 2;
+    const size_t mb = sizeof(double) * size_t(lt) * R * P, gb = sizeof(double) * size_t(M + 1) * P;
+    const void *dm, *dG;
+    CHK(in_dev(c, B_IN0, m, mb, &dm));
+    CHK(in_dev(c, B_IN2, G, gb, &dG));
+    void* dg;
+    CHK(out_dev(c, B_OUT0, gm, mb, &dg));
+    if (P > 0 && R > 0) {
+        hipLaunchKernelGGL(chain_levels_grad_kernel, dim3(grid_for(P, 64)), dim3(64), 0, c->stream, static_cast<const double*>(dm),
+                           static_cast<const double*>(dG), M, int64_t(R), P, static_cast<double*>(dg));
+        HIPCHK(c, hipGetLastError());
+    }
+    CHK(out_done(c, gm, dg, mb));
+    return finish(c);
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // The weighted level sum of gpsig_tens_vs_seq_weighted: gradients with respect to Z, X and the factors.  The tile kernel takes the
 // (T, N) upstream gradient and the factors as they are; other shapes go through the level primitives (the level array and its
 // upstream gradient in scratch memory).

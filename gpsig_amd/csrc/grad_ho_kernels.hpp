@@ -24,6 +24,8 @@
 
 namespace gpsig {
 
+constexpr int GRAD_HO_MAXLEV = 8;       // GRAD_MAX_LEVELS of grad_core.hpp
+
 struct HoBlock {
     int64_t i0, ni, j0, nj;     // pairs (i, j), i in [i0, i0+ni), j in [j0, j0+nj); pair index p = (i - i0) * nj + (j - j0)
     int diag;                   // pairs (i, i): p = i - i0, nj == 1
@@ -83,6 +85,70 @@ __global__ void ho_bcast_kernel(const double* __restrict__ G, int64_t goff, int6
         const int64_t i = B.i0 + (B.diag ? p : p / B.nj), j = B.diag ? i : B.j0 + p % B.nj;
         const double c = G[goff + i * gi + j * gj];
         dst[idx] = acc ? dst[idx] + c : c;
+    }
+}
+
+__global__ void fill_pairs_kernel(double* __restrict__ dst, int64_t n, double v) {
+    for (int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; e < n; e += int64_t(gridDim.x) * blockDim.x) dst[e] = v;
+}
+
+// out[pair] = (acc ? out[pair] : 0) + sum over the lattice cells of src[pair][:]  -- one wavefront per pair
+__global__ void __launch_bounds__(64) ho_pairsum_kernel(const double* __restrict__ src, int64_t npairs, int64_t cells, double* __restrict__ out, int acc) {
+    for (int64_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+        double s = 0.0;
+        for (int64_t e = threadIdx.x; e < cells; e += 64) s += src[p * cells + e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (threadIdx.x == 0) out[p] = acc ? out[p] + s : s;
+    }
+}
+
+// ---- tensor-vs-sequence chains from given component increments (signature_algs.py:101-127 after :114), order 1 -------------------
+// m: (lt, R, P) -- component k = i(i-1)/2 + j of level i, time step tau, pair p (pairs fastest: a wavefront reads 512 contiguous bytes).
+// One thread per pair.  out: (M+1, P).
+__global__ void chain_levels_kernel(const double* __restrict__ m, int M, int64_t R, int64_t P, double* __restrict__ out) {
+    for (int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; p < P; p += int64_t(gridDim.x) * blockDim.x) {
+        out[p] = 1.0;                                                              // :116
+        int k0 = 0;
+        for (int i = 1; i <= M; ++i) {
+            double u[GRAD_HO_MAXLEV];
+            for (int j = 0; j < i; ++j) u[j] = 0.0;
+            for (int64_t t = 0; t < R; ++t) {
+                for (int j = i - 1; j >= 1; --j) u[j] = fma(m[(int64_t(k0 + j) * R + t) * P + p], u[j - 1], u[j]);   // :120-124 (old values below)
+                u[0] += m[(int64_t(k0) * R + t) * P + p];
+            }
+            out[int64_t(i) * P + p] = u[i - 1];                                    // :125
+            k0 += i;
+        }
+    }
+}
+// gm[k][tau][p] = dL/dm[k][tau][p] for L = sum_i G[i][p] level_i[p]: forward totals, then the chains undone from the last step back
+// (u_{j+1}[tau-1] = u_{j+1}[tau] - m_j[tau] u_j[tau-1]) with W_j = dL/du_j alongside, as tvs_grad_tile_kernel.hpp does on kappa's it evaluates.
+__global__ void chain_levels_grad_kernel(const double* __restrict__ m, const double* __restrict__ G, int M, int64_t R, int64_t P,
+                                         double* __restrict__ gm) {
+    for (int64_t p = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; p < P; p += int64_t(gridDim.x) * blockDim.x) {
+        int k0 = 0;
+        for (int i = 1; i <= M; ++i) {
+            double u[GRAD_HO_MAXLEV], w[GRAD_HO_MAXLEV];
+            for (int j = 0; j < i; ++j) { u[j] = 0.0; w[j] = 0.0; }
+            for (int64_t t = 0; t < R; ++t) {
+                for (int j = i - 1; j >= 1; --j) u[j] = fma(m[(int64_t(k0 + j) * R + t) * P + p], u[j - 1], u[j]);
+                u[0] += m[(int64_t(k0) * R + t) * P + p];
+            }
+            const double c = G[int64_t(i) * P + p];
+            for (int64_t t = R - 1; t >= 0; --t) {
+                double below = 1.0;
+                for (int j = 0; j < i; ++j) {
+                    const double mj = m[(int64_t(k0 + j) * R + t) * P + p];
+                    const double wnext = (j == i - 1) ? c : w[j + 1];
+                    gm[(int64_t(k0 + j) * R + t) * P + p] = below * wnext;
+                    u[j] = fma(-mj, below, u[j]);
+                    below = u[j];
+                    if (j >= 1) w[j] = fma(mj, wnext, w[j]);
+                }
+            }
+            k0 += i;
+        }
     }
 }
 

@@ -322,6 +322,20 @@ int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* ctx, const gpsig_params* p, const
                                     const void* aux /* what the forward call wrote, or NULL */, void* gZ, void* gX,
                                     void* gfac /* (N, M+1) */, double* g_base);
 
+/* ---- the recursions on GIVEN increment lattices ("matrix route") ---------------------------------------------------------------
+ * What gpsig/signature_algs.py does after it has differenced the base-kernel tensor (:25-26, :55-56 / :114): for callers that
+ * build that tensor themselves -- state spaces wider than the gradient kernels' 64 columns, where it is a d-deep contraction and
+ * belongs on a library GEMM, and base kernels whose parameters are differentiated outside this library (SignatureSpectral's alpha,
+ * omega, gamma: gpsig/kernels.py:912-914).  The lattices of a block of pairs are held in scratch memory (option "grad_scratch_mb"):
+ * sized for training minibatches, not for BASELINE-sized Grams.  float64.
+ *   dM: (P, R1, R2) increment lattices of P pairs -> out (M+1, P): signature_kern_first_order / _higher_order (:28-35, :58-74), p->order;
+ *   m:  (lt, R, P) component increments, pair index fastest -> out (M+1, P): signature_kern_tens_vs_seq_first_order (:116-127), order 1.
+ * _grad: G (M+1, P) upstream -> the gradient with respect to dM / m, same layouts. */
+int gpsig_lattice_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* dM, int64_t P, int32_t R1, int32_t R2, void* out);
+int gpsig_lattice_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* dM, int64_t P, int32_t R1, int32_t R2, const void* G, void* gdM);
+int gpsig_chain_levels(gpsig_ctx* ctx, const gpsig_params* p, const void* m, int64_t P, int32_t R, void* out);
+int gpsig_chain_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* m, int64_t P, int32_t R, const void* G, void* gm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,7 +148,28 @@ def _euclid_dist(X, X2=None):
     return torch.sqrt(torch.clamp(_square_dist(X, X2), min=1e-40))                                 # tf.maximum(r2, 1e-40)
 
 
-def base_kernel(name, X, X2=None, p0=None, p1=None):
+def base_spectral(X, X2, alpha, omega, gamma, family):
+    """gpsig/kernels.py:921-942 (2-D or batched inputs; 'mixed' as evidently intended: the reference's branch has undefined names and a
+    sign slip, :932-936 -- the first floor(Q/2) components Gaussian, the rest exponential).  The square root of :924 is taken with
+    derivative 0 at 0: TensorFlow's is inf there, which makes every gradient of K(X, X) NaN in the reference itself."""
+    X2 = X if X2 is None else X2
+    diff = X[..., :, None, :] - X2[..., None, :, :]                                                 # :923 / :925 (one copy per q below)
+    Q = alpha.shape[0]
+    out = 0.0
+    for q in range(Q):
+        sq = torch.sum(torch.square(diff * gamma[q]), dim=-1)
+        if family == "rbf" or (family == "mixed" and q < Q // 2):
+            env = torch.exp(-sq / 2)                                                                # :928
+        else:
+            root = torch.where(sq > 0, torch.sqrt(torch.where(sq > 0, sq, torch.ones_like(sq))), torch.zeros_like(sq))
+            env = torch.exp(-root / 2)                                                              # :926
+        out = out + alpha[q] * env * torch.cos(2. * math.pi * torch.sum(diff * omega[q], dim=-1))   # :937, :942
+    return out
+
+
+def base_kernel(name, X, X2=None, p0=None, p1=None, spectral=None):
+    if name == "spectral":
+        return base_spectral(X, X2, *spectral)
     if name == "linear":
         return _mm_t(X, X if X2 is None else X2)
     if name == "cosine":
@@ -178,7 +199,7 @@ class SignatureKernelTorchOracle:
     p0 (base-kernel parameter: gamma of poly, mixing of mix)."""
 
     def __init__(self, num_features, num_levels, base="linear", variances=None, sigma=1.0, lengthscales=None, normalization=True,
-                 difference=True, num_lags=0, lags=None, gamma=None, p0=None, p1=None, order=1):
+                 difference=True, num_lags=0, lags=None, gamma=None, p0=None, p1=None, order=1, spectral=None):
         t = lambda v: v if isinstance(v, torch.Tensor) else torch.as_tensor(v, dtype=torch.float64)
         self.num_features, self.num_levels, self.base = num_features, num_levels, base
         self.normalization, self.difference, self.num_lags = normalization, difference, num_lags
@@ -189,10 +210,11 @@ class SignatureKernelTorchOracle:
         self.gamma = None if gamma is None else t(gamma)
         self.p0 = None if p0 is None else t(p0)
         self.p1 = p1
+        self.spectral = spectral                                                                    # (alpha (Q,), omega (Q, d), gamma (Q, d), family)
         self.order = num_levels if (order <= 0 or order >= num_levels) else order                   # kernels.py:57
 
     def _base(self, X, X2=None):
-        return base_kernel(self.base, X, X2, self.p0, self.p1)
+        return base_kernel(self.base, X, X2, self.p0, self.p1, self.spectral)
 
     def scale_sequences(self, X):
         """kernels.py:343-364.  X (N, L, d) -> (N, L, d*(num_lags+1))."""

@@ -704,3 +704,129 @@ def test_inducing_sequences_model(K=None):
     model = models.SVGPModule(kern2, iv.InducingSequences(Zs, M, learn_weights=True), LK.Bernoulli(), device="cuda:0")
     trace = model.fit(Xg, torch.tensor(Y, device=dev), iterations=25, lr=0.02)
     assert np.all(np.isfinite(trace)) and trace[-1] > trace[0]
+
+
+# ---- the matrix route (round 3): base-kernel tensors by torch GEMMs + autograd, recursions on their lattices in the library -----------
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_lattice_and_chain_primitives(order):
+    """gpsig_lattice_levels / gpsig_chain_levels and their _grad against autograd of the oracle's signature_kern_* on the same
+    increment lattices: several scratch chunks, single cells, empty lattices."""
+    ctx = _host_ctx()
+    rng = np.random.default_rng(60 + order)
+    for M, P, R1, R2 in ((4, 37, 6, 5), (3, 5, 1, 7), (1, 9, 3, 3), (5, 70, 4, 4)):
+        if order > M:
+            continue
+        dM = rng.standard_normal((P, R1, R2)) * 0.5
+        G = rng.standard_normal((M + 1, P))
+        t = torch.tensor(dM, requires_grad=True)
+        M4 = t.reshape(P, R1, 1, R2)
+        lev = (OT.signature_kern_first_order(M4, M, difference=False) if order == 1 else
+               OT.signature_kern_higher_order(M4, M, order=order, difference=False))[:, :, 0]
+        (lev * torch.tensor(G)).sum().backward()
+        keep = []
+        p = _params("linear", 1, M, True, keep, order=order)
+        for mb in (4096, 1):
+            ctx.set_option("grad_scratch_mb", mb)
+            try:
+                out, g = np.empty((M + 1, P)), np.empty_like(dM)
+                ctx.call("gpsig_lattice_levels", p, _vp(dM), P, R1, R2, _vp(out))
+                ctx.call("gpsig_lattice_levels_grad", p, _vp(dM), P, R1, R2, _vp(G), _vp(g))
+            finally:
+                ctx.set_option("grad_scratch_mb", 4096)
+            assert rel(out, lev) < 1e-12 and rel(g, t.grad) < 1e-11, (M, P, order, mb, rel(out, lev), rel(g, t.grad))
+        if order == 1:
+            lt, R = M * (M + 1) // 2, R2
+            m = rng.standard_normal((lt, R, P)) * 0.5
+            tm = torch.tensor(m, requires_grad=True)
+            lev = OT.signature_kern_tens_vs_seq_first_order(tm.permute(0, 2, 1)[:, :, None, :], M, difference=False)[:, :, 0]
+            (lev * torch.tensor(G)).sum().backward()
+            out, g = np.empty((M + 1, P)), np.empty_like(m)
+            ctx.call("gpsig_chain_levels", p, _vp(m), P, R, _vp(out))
+            ctx.call("gpsig_chain_levels_grad", p, _vp(m), P, R, _vp(G), _vp(g))
+            assert rel(out, lev) < 1e-12 and rel(g, tm.grad) < 1e-11
+
+
+def _compare_module_with_oracle(mod, orc, d_cols, M, L, extra_pairs, N=6, N2=4, T=5, tol=1e-8):
+    rng = np.random.default_rng(33)
+    d_in = mod.kern.num_features
+    X, X2 = rng.standard_normal((N, L * d_in)) * 0.4, rng.standard_normal((N2, L * d_in)) * 0.4
+    lt = M * (M + 1) // 2
+    dev = torch.device("cuda:0")
+    cu = lambda a: torch.tensor(a, device=dev)
+    for increments in (False, True):
+        Z = rng.standard_normal((lt, T, 2, d_cols) if increments else (lt, T, d_cols)) * 0.4
+        W1, W2, W3 = rng.standard_normal((T, T)), rng.standard_normal((T, N)), rng.standard_normal(N)
+        Wk, Wc = rng.standard_normal((N, N)), rng.standard_normal((N, N2))
+        Zg, Xg = torch.tensor(Z, device=dev, requires_grad=True), torch.tensor(X, device=dev, requires_grad=True)
+        Kzz, Kzx, Kxx = mod.K_tens_n_seq_covs(Zg, Xg, increments=increments)
+        loss = (Kzz * cu(W1)).sum() + (Kzx * cu(W2)).sum() + (Kxx * cu(W3)).sum() + (mod.K(Xg) * cu(Wk)).sum() + (mod.K(Xg, cu(X2)) * cu(Wc)).sum() \
+            + (mod.K_tens_vs_seq(Zg, Xg, increments=increments, return_levels=True)[1:] ** 2).sum()
+        mod.zero_grad()
+        loss.backward()
+        Zc, Xc = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+        for _, con, _k in extra_pairs:
+            con.grad = None
+        for t in (orc.variances, orc.sigma, orc.lengthscales):
+            if t is not None:
+                t.grad = None
+        oKzz, oKzx, oKxx = orc.K_tens_n_seq_covs(Zc, Xc, increments=increments)
+        oloss = (oKzz * torch.tensor(W1)).sum() + (oKzx * torch.tensor(W2)).sum() + (oKxx * torch.tensor(W3)).sum() + \
+            (orc.K(Xc) * torch.tensor(Wk)).sum() + (orc.K(Xc, torch.tensor(X2)) * torch.tensor(Wc)).sum() + \
+            (orc.K_tens_vs_seq(Zc, Xc, increments=increments, return_levels=True)[1:] ** 2).sum()
+        oloss.backward()
+        assert abs(loss.item() - oloss.item()) < 1e-9 * max(1.0, abs(oloss.item())), (loss.item(), oloss.item())
+        assert rel(Zg.grad, Zc.grad) < tol and rel(Xg.grad, Xc.grad) < tol, (rel(Zg.grad, Zc.grad), rel(Xg.grad, Xc.grad))
+        pairs = [(mod.raw_variances, orc.variances, "pos"), (mod.raw_sigma, orc.sigma, "pos")] + list(extra_pairs)
+        if mod.raw_lengthscales is not None:
+            pairs.append((mod.raw_lengthscales, orc.lengthscales, "pos"))
+        for raw, con, kind in pairs:
+            r = raw.detach().cpu()
+            jac = torch.sigmoid(r) if kind == "pos" else torch.sigmoid(r) * (1 - torch.sigmoid(r))
+            assert rel(raw.grad, con.grad * jac) < tol, (kind, rel(raw.grad, con.grad * jac))
+
+
+@pytest.mark.parametrize("family,normalization,difference,order", [("rbf", True, True, 1), ("exp", True, True, 1), ("mixed", False, True, 1),
+                                                                   ("rbf", True, False, 1)])
+def test_spectral_kernel_gradients(family, normalization, difference, order):
+    """SignatureSpectral can be trained (alpha, omega, gamma: gpsig/kernels.py:912-914): every covariance of the module and its
+    gradients with respect to Z, X, variances, sigma and the three spectral parameter arrays against autograd of the oracle --
+    base-kernel tensors by torch ops, the lattice / chain recursions and their reverse passes by the library."""
+    from gpsig_amd import kernels, autodiff
+    d, M, L, Q = 3, 3, 7, 3
+    rng = np.random.default_rng(35)
+    kern = kernels.SignatureSpectral(L * d, d, M, family=family, Q=Q, normalization=normalization, difference=difference, order=order,
+                                     variances=rng.uniform(0.5, 1.5, M + 1))
+    kern.alpha, kern.omega, kern.gamma = np.exp(0.3 * rng.standard_normal(Q)), 0.3 * np.exp(0.3 * rng.standard_normal((Q, d))), np.exp(0.3 * rng.standard_normal((Q, d)))
+    kern.sigma = 1.2
+    mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
+    assert mod.matrix_route
+    leaf = lambda t: t.detach().cpu().clone().requires_grad_(True)
+    al, om, ga = leaf(autodiff.positive(mod.raw_alpha)), leaf(autodiff.positive(mod.raw_omega)), leaf(autodiff.positive(mod.raw_sgamma))
+    orc = OT.SignatureKernelTorchOracle(d, M, "spectral", variances=leaf(mod.variances), sigma=leaf(mod.sigma), lengthscales=None,
+                                        normalization=normalization, difference=difference, order=order, spectral=(al, om, ga, kern.family))
+    _compare_module_with_oracle(mod, orc, d, M, L, [(mod.raw_alpha, al, "pos"), (mod.raw_omega, om, "pos"), (mod.raw_sgamma, ga, "pos")])
+    # the trained values reach the evaluation path: the fused forward kernels on the written-back parameters give the module's numbers
+    X = torch.tensor(rng.standard_normal((5, L * d)) * 0.4, device="cuda:0")
+    with torch.no_grad():
+        want = mod.K(X)
+    got = mod.write_back().K(X)
+    assert rel(got, want) < 1e-10
+
+
+@pytest.mark.parametrize("base,d,num_lags", [("rbf", 70, 0), ("linear", 40, 2), ("matern32", 200, 0), ("rbf", 100, 1)])
+def test_gradients_beyond_64_columns(base, d, num_lags):
+    """Training with state spaces the gradient kernels (64 columns after lags) do not reach: up to 256 columns and beyond through the
+    matrix route, against autograd of the oracle (the reference's benchmarks run num_lags = 1 on state spaces of up to 963 features:
+    benchmarks/run_gpsig_benchmarks.py:32)."""
+    from gpsig_amd import kernels, autodiff
+    M, L = 3, 6
+    cls = {"linear": kernels.SignatureLinear, "rbf": kernels.SignatureRBF, "matern32": kernels.SignatureMatern32}[base]
+    rng = np.random.default_rng(36)
+    kern = cls(L * d, d, M, num_lags=num_lags or None, lengthscales=rng.uniform(0.8, 1.6, d) * np.sqrt(d), variances=rng.uniform(0.5, 1.5, M + 1))
+    mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
+    assert mod.matrix_route
+    leaf = lambda t: None if t is None else t.detach().cpu().clone().requires_grad_(True)
+    orc = OT.SignatureKernelTorchOracle(d, M, base, variances=leaf(mod.variances), sigma=leaf(mod.sigma), lengthscales=leaf(mod.lengthscales),
+                                        num_lags=num_lags, lags=leaf(mod.lags) if num_lags else None, gamma=leaf(mod.gamma) if num_lags else None)
+    extra = [(mod.raw_lags, orc.lags, "logistic"), (mod.raw_gamma, orc.gamma, "pos")] if num_lags else []
+    _compare_module_with_oracle(mod, orc, d * (num_lags + 1), M, L, extra)

@@ -207,3 +207,23 @@ def test_wave_formulation_equals_autograd(base, difference, group, cols, scratch
             assert rel(gY, tY.grad) < tol
         if base == "poly":
             assert abs(gp0 - kt.p0.grad.item()) < 1e-10 * max(1.0, abs(gp0))
+
+
+def test_torch_spectral_kernel_equals_numpy_oracle():
+    """The torch restatement of SignatureSpectral's state-space kernel (gpsig/kernels.py:921-942), which the GPU gradient tests
+    differentiate, against the NumPy oracle's: values on random and on coincident points, all three families; and its derivative at
+    coincident points is finite (the reference's own, through tf.sqrt at 0, is not)."""
+    import torch
+    from oracle import sigkern_oracle as O, sigkern_oracle_torch as OT
+    rng = np.random.default_rng(5)
+    Q, d = 3, 4
+    alpha, omega, gamma = np.exp(0.3 * rng.standard_normal(Q)), np.exp(0.3 * rng.standard_normal((Q, d))), np.exp(0.3 * rng.standard_normal((Q, d)))
+    X, Y = rng.standard_normal((6, d)), rng.standard_normal((5, d))
+    for family in ("rbf", "exp", "mixed"):
+        for A, B in ((X, Y), (X, None)):
+            want = O.base_spectral(A, B, alpha=alpha, omega=omega, gamma=gamma, family=family)
+            tA = torch.tensor(A, requires_grad=True)
+            got = OT.base_spectral(tA, None if B is None else torch.tensor(B), torch.tensor(alpha), torch.tensor(omega), torch.tensor(gamma), family)
+            assert np.abs(got.detach().numpy() - want).max() < 1e-13
+            got.sum().backward()
+            assert bool(torch.isfinite(tA.grad).all())
