@@ -22,12 +22,17 @@
 #include "seq_configs.hpp"
 #include "tvs_tile_kernel.hpp"
 #include "seq_pk2_kernel.hpp"
+#include "sig_feat_kernel.hpp"
 
 namespace gpsig {
 typedef hipError_t (*TvsTileLaunchFn)(const TvsTileArgs&, size_t, hipStream_t);
 TvsTileLaunchFn tvs_tile_lookup(int M, int NW, int D, bool incr, int kind);
 int tvs_tile_width(int d);
 bool seq_pk2_select(int rows, int d, int M, int* G, int* C, int* D);
+typedef hipError_t (*SigFeatLaunchFn)(const SigFeatArgs&, unsigned, size_t, hipStream_t);
+SigFeatLaunchFn sig_feat_lookup(int d, int M);
+hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream);
+hipError_t sig_reduce_launch(const SigReduceArgs& R, hipStream_t stream);
 bool solver_dsyevd(void** handle_slot, hipStream_t stream, int n, double* A, double* ev, double* work, int* info, std::string* err);
 void solver_release(void* handle);
 int tvs_tile_waves(int M, int D, int E, int kind);
@@ -579,6 +584,144 @@ int lr_level_offsets(gpsig_ctx* c, int M, int cc, int r, const int32_t** dev_off
     return GPSIG_OK;
 }
 
+constexpr size_t TIMING_MAX_EVENTS = 8192;
+int timing_begin_any(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1, bool* on) {
+    *on = false;
+    if (c->capturing || c->ev_used + 2 > TIMING_MAX_EVENTS) return GPSIG_OK;
+    if (c->ev_used + 2 > c->ev.size()) {
+        hipEvent_t a, b;
+        HIPCHK(c, hipEventCreate(&a));
+        HIPCHK(c, hipEventCreate(&b));
+        c->ev.push_back(a);
+        c->ev.push_back(b);
+    }
+    *e0 = c->ev[c->ev_used];
+    *e1 = c->ev[c->ev_used + 1];
+    c->ev_used += 2;
+    HIPCHK(c, hipEventRecord(*e0, c->stream));
+    *on = true;
+    return GPSIG_OK;
+}
+
+
+// ---- SignatureLinear, first order: the Gram as a contraction of explicit level features (sig_feat_kernel.hpp) --------------------
+// Taken where it is the cheaper evaluation -- 2 sum_m d^m flops per entry on the matrix cores against the lattice sweep's
+// L1 L2 (2d + 3M - 1) on the vector unit at about 0.6 of the GEMM's efficiency -- and the feature matrices fit.  *done = false
+// leaves the call to the lattice kernels.  row_end > 0: the owned entries of rows [row_begin, row_end) (multi-GPU row blocks).
+int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, const void* X2, int64_t N1, int64_t N2, int L1, int L2,
+                   int return_levels, void* out, bool timed, int x_squared, int64_t row_begin, int64_t row_end, int compact, bool* done) {
+    *done = false;
+    if (c->sig_features == 0 || p->dtype != GPSIG_F64 || p->base_kernel != GPSIG_BASE_LINEAR || x_squared) return GPSIG_OK;
+    const int M = p->num_levels;
+    if (M < 2 || (p->order != 1)) return GPSIG_OK;
+    const int d = p->num_features * ((raw ? 0 : p->num_lags) + 1);
+    SigFeatLaunchFn ffn = sig_feat_lookup(d, M);
+    if (!ffn) return GPSIG_OK;
+    const bool sym = X2 == nullptr;
+    const int64_t F = sig_feature_count(d, M), ld = (F + 1 + 15) / 16 * 16;
+    const int r1 = p->difference ? L1 - 1 : L1, r2 = p->difference ? L2 - 1 : L2;
+    if (r1 < 1 || r2 < 1) return GPSIG_OK;
+    if (c->sig_features < 0) {
+        const double lattice = double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0), feat = 2.0 * double(F);
+        const double pairs = sym ? double(N1) * N1 / 2 : double(N1) * N2;
+        if (!(feat * 0.6 < lattice) || pairs < 16384.0) return GPSIG_OK;
+    }
+    const size_t lds = sig_features_lds_bytes(d, M, L1 > L2 ? L1 : L2);
+    if (lds > 150 * 1024) return GPSIG_OK;
+    const bool rows = row_end > 0;
+    const int64_t NA = rows ? row_end - row_begin : N1, H = N1 / 2;
+    int64_t NB = sym ? N1 : N2;
+    if (rows) NB = (NA + H < N1) ? NA + H : N1;
+    const int nti = int((NA + SG_BM - 1) / SG_BM), ntj = int((NB + SG_BN - 1) / SG_BN);
+    const bool symtiles = sym && !rows;
+    const int ntiles = symtiles ? nti * (nti + 1) / 2 : nti * ntj;
+    const int nslab_all = int((ld + SG_BK - 1) / SG_BK);
+    // workgroups per tile along the depth: the launch should come out in whole rounds of the 512 workgroups the chip holds (528 tiles
+    // in one piece each would take two rounds, the second nearly empty), against one more partial sum to write and add per split
+    int nsplit = 1;
+    {
+        const double slots = 512.0, flops = 2.0 * double(ntiles) * SG_BM * SG_BN * double(ld);
+        const double t_gemm = flops / 55e12, t_split = 2.0 * double(NA) * NB * 8.0 * (symtiles ? 0.5 : 1.0) / 3e12;
+        double best = 1e30;
+        for (int ns = 1; ns <= 64 && ns <= nslab_all / 8 + 1; ++ns) {
+            const double items = double(ntiles) * ns, rounds = ceil(items / slots);
+            const double t = t_gemm * rounds * slots / items + t_split * ns;
+            if (t < best) { best = t; nsplit = ns; }
+        }
+    }
+    const size_t part_one = sizeof(double) * size_t(NA) * NB;
+    while (nsplit > 1 && part_one * size_t(nsplit) > (size_t(8) << 30)) --nsplit;
+    const size_t feat_bytes = sizeof(double) * size_t(ld) * (size_t(N1) + (sym ? 0 : size_t(N2)));
+    if (feat_bytes + part_one * size_t(nsplit) > (size_t(64) << 30)) return GPSIG_OK;
+    const double* w = nullptr;
+    if (!raw) CHK(upload_weights(c, p, &w));
+    ScaleParams s;
+    CHK(scale_params(c, p, !raw, &s));
+    void *phi1, *phi2 = nullptr, *part;
+    CHK(ensure(c, B_SF0, sizeof(double) * size_t(ld) * N1 + 64, &phi1));
+    if (!sym) CHK(ensure(c, B_SF1, sizeof(double) * size_t(ld) * N2 + 64, &phi2));
+    CHK(ensure(c, B_SF2, part_one * size_t(nsplit) + 64, &part));
+    const int normalize = (!raw && p->normalization) ? 1 : 0;
+    auto features = [&](const void* Xs, int64_t N, int L, void* phi) -> int {
+        SigFeatArgs A;
+        memset(&A, 0, sizeof(A));
+        A.X = static_cast<const double*>(Xs); A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = s;
+        A.w = w; A.normalize = normalize; A.jitter = p->jitter; A.Phi = static_cast<double*>(phi); A.ld = ld; A.dlev = nullptr;
+        const unsigned grid = unsigned(N < 4096 ? N : 4096);
+        hipError_t e = ffn(A, grid, sig_features_lds_bytes(d, M, L), c->stream);
+        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
+        return GPSIG_OK;
+    };
+    if (N1 > 0) CHK(features(X, N1, L1, phi1));
+    if (!sym && N2 > 0) CHK(features(X2, N2, L2, phi2));
+    if (NA <= 0 || NB <= 0) { *done = true; return GPSIG_OK; }
+    // level sums of the weights: the exact diagonal of the normalised symmetric Gram (kernels.py:430-433: (K_ii + jitter) / (K_ii + jitter))
+    const int nlev = return_levels ? M + 1 : 1;
+    const int64_t Ncols = sym ? N1 : N2;
+    for (int lv = 0; lv < nlev; ++lv) {
+        int kb = 0, ke = int(F) + 1;                         // all levels and the level-0 column: the level sum is inside the contraction
+        double dval = 0.0;
+        if (return_levels) {
+            if (lv == 0) { kb = int(F); ke = int(F) + 1; }
+            else { kb = sig_feature_count(d, lv - 1); ke = sig_feature_count(d, lv); }
+            dval = raw ? 0.0 : p->sigma * p->variances[lv];
+        } else {
+            for (int m = 0; m <= M; ++m) dval += p->sigma * p->variances[m];
+        }
+        SigGramArgs G;
+        memset(&G, 0, sizeof(G));
+        G.A = static_cast<const double*>(phi1) + (rows ? row_begin * ld : 0);
+        G.B = static_cast<const double*>(sym ? phi1 : phi2);
+        G.NA = NA; G.NB = NB; G.lda = ld; G.ldb = ld;
+        G.b_off = rows ? ((row_begin - H) % N1 + N1) % N1 : 0; G.b_mod = sym ? N1 : N2;
+        G.k_begin = kb; G.k_end = ke;
+        int ns = nsplit;
+        const int nslab = (ke - kb + SG_BK - 1) / SG_BK;
+        if (ns > nslab) ns = nslab < 1 ? 1 : nslab;
+        G.nsplit = ns; G.symmetric = symtiles ? 1 : 0; G.ntj = ntj; G.part = static_cast<double*>(part);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool on = false;
+        if (timed) CHK(timing_begin_any(c, &e0, &e1, &on));
+        HIPCHK(c, sig_gram_launch(G, ntiles, c->stream));
+        if (on) {
+            HIPCHK(c, hipEventRecord(e1, c->stream));
+            c->t_launches += 1;
+            c->t_pairs += NA * NB;
+        }
+        SigReduceArgs R;
+        memset(&R, 0, sizeof(R));
+        R.part = static_cast<const double*>(part); R.nsplit = ns; R.NA = NA; R.NB = NB;
+        R.out = static_cast<double*>(out) + (return_levels ? int64_t(lv) * N1 * Ncols : 0);
+        R.so_i = Ncols; R.so_j = 1;
+        R.mode = rows ? 2 : (symtiles ? 1 : 0);
+        R.diag_set = (sym && normalize) ? 1 : 0; R.diag_value = dval;
+        R.N = N1; R.r0 = row_begin; R.c0 = G.b_off; R.compact = compact;
+        HIPCHK(c, sig_reduce_launch(R, c->stream));
+    }
+    *done = true;
+    return GPSIG_OK;
+}
+
 template <typename TT>
 struct Impl {
 // ---- seq-gram planning -----------------------------------------------------------------------------
@@ -699,24 +842,7 @@ static int make_records(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling,
 
 // Timing covers the launches since gpsig_timing_reset, up to TIMING_MAX_EVENTS of them (a long-running caller that never
 // reads the timing must not accumulate events); *on says whether this launch is timed.  Never inside a graph capture.
-static constexpr size_t TIMING_MAX_EVENTS = 8192;
-static int timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1, bool* on) {
-    *on = false;
-    if (c->capturing || c->ev_used + 2 > TIMING_MAX_EVENTS) return GPSIG_OK;
-    if (c->ev_used + 2 > c->ev.size()) {
-        hipEvent_t a, b;
-        HIPCHK(c, hipEventCreate(&a));
-        HIPCHK(c, hipEventCreate(&b));
-        c->ev.push_back(a);
-        c->ev.push_back(b);
-    }
-    *e0 = c->ev[c->ev_used];
-    *e1 = c->ev[c->ev_used + 1];
-    c->ev_used += 2;
-    HIPCHK(c, hipEventRecord(*e0, c->stream));
-    *on = true;
-    return GPSIG_OK;
-}
+static int timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1, bool* on) { return timing_begin_any(c, e0, e1, on); }
 
 struct SeqRun {
     const void* xrec; const void* yrec;
@@ -960,6 +1086,11 @@ static int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const voi
                  int L1, int L2, int return_levels, void* out, bool timed, int x_squared = 0, int64_t row_begin = 0,
                  int64_t row_end = 0, int compact = 0) {
     if (L1 < 1 || L2 < 1) return fail(c, GPSIG_ERR_INVALID, "sequence length must be >= 1");
+    if (sizeof(TT) == 8) {      // the linear kernel's Gram as one contraction of explicit level features, where that is the cheaper evaluation
+        bool done = false;
+        CHK(sig_features_K(c, p, raw, X, X2, N1, N2, L1, L2, return_levels, out, timed, x_squared, row_begin, row_end, compact, &done));
+        if (done) return GPSIG_OK;
+    }
     const bool sym = X2 == nullptr;
     const int M1 = p->num_levels + 1;
     const int d_eff = p->num_features * ((raw ? 0 : p->num_lags) + 1);
@@ -1675,6 +1806,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "tvs_grad_tile")) c->tvs_grad_tile = value;
     else if (!strcmp(name, "pinned_staging")) c->pinned_staging = value ? 1 : 0;
     else if (!strcmp(name, "lr_jacobi")) c->lr_jacobi = value ? 1 : 0;
+    else if (!strcmp(name, "sig_features")) c->sig_features = value;
     else if (!strcmp(name, "keep_reset")) c->keep_reset = value ? 1 : 0;
     else if (!strcmp(name, "pk2")) c->allow_pk2 = value;
     else if (!strcmp(name, "f32_pack")) c->f32_pack = value;

@@ -29,7 +29,8 @@ enum BufId {
     B_TASKS, B_W, B_XT, B_ZT, B_ZS, B_ZL, B_ZN, B_TMP0, B_TMP1,
     B_LS, B_LR0, B_LR1, B_LR2, B_LR3, B_LR4, B_LR5, B_LR6, B_LR7, B_LR8,
     B_GR0, B_GR1, B_GR2, B_GR3, B_GR4, B_GR5, B_GR6, B_GR7,   // gradient path scratch
-    B_GR7B, B_TW0, B_TW1, B_TW2,                              // weighted tensor-vs-sequence sums: partial factor gradients; level arrays of the fallback
+    B_GR7B, B_TW0, B_TW1, B_TW2,
+    B_SF0, B_SF1, B_SF2, B_SF3,                               // explicit level features (sig_feat_kernel.hpp): both sides, partial products, level diagonals                              // weighted tensor-vs-sequence sums: partial factor gradients; level arrays of the fallback
     B_SPEC,                                                    // spectral base-kernel table
     B_COUNT
 };
@@ -86,6 +87,7 @@ struct gpsig_ctx {
     double* tvs_aux_out = nullptr;   // set by gpsig_tens_vs_seq_weighted around its launch: where the tile kernel leaves the chain totals
     bool tvs_aux_written = false;    // ... and whether it did (only the tile kernel does)
     int tvs_grad_tile = 1;        // tensor-vs-sequence reverse pass: 1 = the tile kernel (tvs_grad_tile_kernel.hpp) where built, 0 = the round-1 kernels
+    int sig_features = -1;        // SignatureLinear Grams as a contraction of explicit level features: -1 where cheaper, 0 never, 1 wherever built
     int lr_jacobi = 1;            // gpsig_lr_draw: eigendecomposition of the landmark Gram by the one-workgroup Jacobi kernel (c <= 64), 0: rocSOLVER
     int tvs_zreg = -1;            // tensor-lane gradient: components in registers (1) or LDS (0); -1 = planner's choice
     std::string err;

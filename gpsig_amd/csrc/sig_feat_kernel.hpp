@@ -1,0 +1,400 @@
+// sig_feat_kernel.hpp -- SignatureLinear, first-order algorithm, as an inner product of explicit level features.
+//
+// For the LINEAR state-space kernel the increment lattice of a pair factorises, dM[a][b] = <dx_a, dy_b> (gpsig/kernels.py:799-806 into
+// signature_algs.py:25-26), and with it the whole first-order recursion (signature_algs.py:28-35): level m is the sum over strictly
+// increasing index tuples a_1 < .. < a_m, b_1 < .. < b_m of prod_i <dx_{a_i}, dy_{b_i}> (pinned by the oracle's brute-force test), i.e.
+//     K_m(x, y) = < Phi_m(x), Phi_m(y) >,     Phi_m(x) = sum_{a_1 < .. < a_m} dx_{a_1} (x) .. (x) dx_{a_m}   in (R^d)^{(x) m},
+// d^m numbers per sequence and level, built by one sweep over time,  Phi_m <- Phi_m + Phi_{m-1}(previous step) (x) dx_a.
+// A Gram entry then costs 2 sum_m d^m flops instead of the lattice sweep's L1 L2 (2d + 3M - 1): at BASELINE configs[1] (L = 64, d = 8,
+// M = 5) 74.9 k against 119 k -- and the N x N batch of them is ONE contraction of depth 37,448, which is what the matrix cores are
+// for (north_star: "MFMA only where it is a true contraction"; the float64 matrix rate of this chip equals its vector rate, but a GEMM
+// runs near it while the lattice sweep, with its hand-overs and latencies, reaches half).  The planner (sig_features_plan in api.hip)
+// takes this route where it is the cheaper one and the feature matrix fits; everything else -- every other base kernel, long state
+// spaces, many levels -- stays on the lattice kernels.  Results agree with them to rounding (different summation order).
+//
+//   sig_features_kernel   one workgroup per sequence, the whole state in registers (d^M / threads top-level values per thread plus a
+//                         private copy of their ancestors: no barrier, no LDS traffic in the sweep); then the level norms |Phi_m|^2 (= the level diagonal K_m(x, x)), and the features scaled
+//                         by sqrt(sigma variances[m] / (|Phi_m|^2 + jitter)) (kernels.py:430-433, :471) so that the level sum,
+//                         the normalisation and the weights are all inside the contraction.
+//   sig_gram_kernel       C = A B^T on v_mfma_f64_16x16x4 in 128 x 128 tiles staged through LDS; symmetric products visit the upper
+//                         tile triangle only; the depth is split over several workgroups per tile so that the launch fills the chip
+//                         evenly (528 tiles on 512 workgroup slots would take two rounds), each writing its own partial sum.
+//   sig_gram_reduce_kernel adds the partial sums in a fixed order (deterministic), mirrors, sets the exact diagonal, or packs the
+//                         owned entries of a row block (multi-GPU, gpsig_kernel_K_symm_rows_compact).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aux_kernels.hpp"
+
+namespace gpsig {
+
+constexpr int sig_ipow(int d, int m) { return m <= 0 ? 1 : d * sig_ipow(d, m - 1); }
+constexpr int sig_lower_total(int d, int M) { int s = 0; for (int m = 1; m < M; ++m) s += sig_ipow(d, m); return s; }
+constexpr int sig_feature_count(int d, int M) { int s = 0; for (int m = 1; m <= M; ++m) s += sig_ipow(d, m); return s; }
+constexpr int SIG_MAX_TOP = 32768;               // d^M values of the top level: 64 per thread of a 512-thread workgroup (two wavefronts per SIMD,
+                                                 // 256 registers; 1024 threads would have 128 and spill, fewer threads more than 64 values each)
+constexpr int sig_threads(int d, int M) {
+    int t = 64;
+    while (t < 512 && t * 64 < sig_ipow(d, M)) t *= 2;
+    return t;
+}
+
+struct SigFeatArgs {
+    const double* X;        // (N, L, d_in) as the caller gives it
+    int64_t N;
+    int L, difference;
+    ScaleParams P;
+    const double* w;        // (M+1) sigma * variances (device) or NULL = 1
+    int normalize;          // divide level m by sqrt(|Phi_m|^2 + jitter)
+    double jitter;
+    double* Phi;            // (N, ld): levels 1..M, then the level-0 column, then zeros up to ld
+    int64_t ld;
+    double* dlev;           // (N, M+1) raw level diagonals |Phi_m|^2 (level 0: 1), or NULL
+};
+
+// D = the number of columns after lags (not padded: the feature count is D^m), M = num_levels >= 2.
+// Everything a thread needs lives in its registers: thread t owns the entries t, t + T, .. of level M-1 (its "parents"), their D
+// children each of level M, and a private copy of every ANCESTOR of each parent (one entry per lower level -- M - 2 extra multiply-adds
+// per parent and step, recomputed by every thread that shares the ancestor, against D + 1 useful ones).  So the sweep over time needs no
+// barrier and no LDS traffic besides the broadcast reads of the increment: the first form kept the lower levels in LDS behind a barrier
+// per step and ran at a third of its issue rate on the LDS round trips (1.16 ms for BASELINE configs[1]'s 4,096 sequences; this: see DESIGN).
+template <int D, int M>
+__global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const SigFeatArgs A) {
+    constexpr int T = sig_threads(D, M);
+    constexpr int NTOP = sig_ipow(D, M), NPAR = sig_ipow(D, M - 1);     // top-level values, their parents (level M-1)
+    constexpr int PPT = (NPAR + T - 1) / T;                             // parents per thread
+    constexpr int NA = M - 1;                                           // ancestors kept per parent: levels M-1 (k = 0) .. 1 (k = M-2)
+    extern __shared__ double sf_sm[];
+    double* const dx = sf_sm;                       // R x D increments of this sequence
+    double* const red = dx + size_t(A.L) * D;       // T / 64 partial sums
+    __shared__ double norms[M + 1];
+    const int tid = threadIdx.x;
+    const int R = A.difference ? A.L - 1 : A.L;
+    // Which component of dx extends the ancestor at distance k of parent q (that ancestor's last index, (q T + tid) / D^k mod D):
+    // the same for every q where D^(k+1) divides T (one register per level), a compile-time constant where T divides D^k (the
+    // register of d_ itself), one register per (q, k) otherwise (small D^M only).
+    int comp_k[NA], comp_g[PPT][NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        comp_k[k] = (tid / sig_ipow(D, k)) % D;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) comp_g[q][k] = ((q * T + tid) / sig_ipow(D, k)) % D;
+    }
+    auto opaque = [](int i) { asm volatile("" : "+v"(i)); return i; };
+    // the thread that reports a shared ancestor: the first of the threads holding it
+    auto owner = [&](int q, int k) { const int idx = q * T + tid; return idx < NPAR && idx % sig_ipow(D, k) == 0; };
+    for (int64_t n = blockIdx.x; n < A.N; n += gridDim.x) {
+        const double* Xn = A.X + n * int64_t(A.L) * A.P.d_in;
+        __syncthreads();                            // the previous sequence's increments are no longer read
+        for (int e = tid; e < R * D; e += T) {
+            const int a = e / D, f = e - a * D;
+            dx[e] = A.difference ? scaled_point<double>(Xn, A.L, a + 1, f, A.P) - scaled_point<double>(Xn, A.L, a, f, A.P)
+                                 : scaled_point<double>(Xn, A.L, a, f, A.P);
+        }
+        double top[PPT][D], anc[PPT][NA];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+#pragma unroll
+            for (int k = 0; k < NA; ++k) anc[q][k] = 0.0;
+#pragma unroll
+            for (int f = 0; f < D; ++f) top[q][f] = 0.0;
+        }
+        __syncthreads();
+        for (int a = 0; a < R; ++a) {
+            const double* dxa = dx + a * D;
+            double d_[D];
+#pragma unroll
+            for (int f = 0; f < D; ++f) d_[f] = dxa[f];
+            // the ancestors' components of dx come from LDS by index (behind an opaque index: a select among the D registers of d_,
+            // which the compiler builds when it can see the index is one of them, costs 2 D instructions)
+            double dck[NA];
+#pragma unroll
+            for (int k = 0; k < NA; ++k) dck[k] = dxa[opaque(comp_k[k])];
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                // every level from the OLD value of the level below it: the top first, then the ancestors from the highest down
+#pragma unroll
+                for (int f = 0; f < D; ++f) top[q][f] = fma(anc[q][0], d_[f], top[q][f]);
+#pragma unroll
+                for (int k = 0; k < NA; ++k) {
+                    const double below = k + 1 < NA ? anc[q][k + 1] : 1.0;
+                    double dc;
+                    if (T % sig_ipow(D, k + 1) == 0) dc = dck[k];
+                    else if (sig_ipow(D, k) % T == 0) dc = d_[(q / (sig_ipow(D, k) / T > 0 ? sig_ipow(D, k) / T : 1)) % D];
+                    else dc = dxa[opaque(comp_g[q][k])];
+                    anc[q][k] = fma(below, dc, anc[q][k]);
+                }
+            }
+        }
+        // level norms: |Phi_m|^2 = K_m(x, x); an ancestor shared by several threads is counted by its owner
+        for (int m = 1; m <= M; ++m) {
+            double s = 0.0;
+            if (m == M) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q)
+                    if (owner(q, 0))
+#pragma unroll
+                        for (int f = 0; f < D; ++f) s = fma(top[q][f], top[q][f], s);
+            } else {
+                const int k = M - 1 - m;
+#pragma unroll
+                for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                    for (int kk = 0; kk < NA; ++kk)
+                        if (kk == k && owner(q, kk)) s = fma(anc[q][kk], anc[q][kk], s);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if ((tid & 63) == 0) red[tid >> 6] = s;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+                for (int k2 = 0; k2 < (T + 63) / 64; ++k2) t += red[k2];
+                norms[m] = t;
+            }
+            __syncthreads();
+        }
+        double* out = A.Phi + n * A.ld;
+        auto scale_of = [&](int m) {
+            const double w = A.w ? A.w[m] : 1.0;
+            const double nm = m == 0 ? 1.0 : norms[m];
+            return A.normalize ? sqrt(w / (nm + A.jitter)) : sqrt(w);
+        };
+        // levels 1 .. M-1 from their owners, level M from everybody
+        {
+            int off = 0;
+#pragma unroll
+            for (int m = 1; m < M; ++m) {
+                const int k = M - 1 - m;
+                const double sc = scale_of(m);
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+#pragma unroll
+                    for (int kk = 0; kk < NA; ++kk)
+                        if (kk == k && owner(q, kk)) out[off + (q * T + tid) / sig_ipow(D, kk)] = sc * anc[q][kk];
+                }
+                off += sig_ipow(D, m);
+            }
+            const double sc = scale_of(M);
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                const int pi = q * T + tid;
+                if (pi < NPAR) {
+                    double* o = out + off + pi * D;             // D consecutive doubles per lane, consecutive lanes side by side
+                    if constexpr (D % 2 == 0) {                 // 16-byte stores (even D: the level offsets and the row stride are even)
+                        double2* o2 = reinterpret_cast<double2*>(o);
+#pragma unroll
+                        for (int f = 0; f < D; f += 2) o2[f / 2] = double2{sc * top[q][f], sc * top[q][f + 1]};
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < D; ++f) o[f] = sc * top[q][f];
+                    }
+                }
+            }
+            const int F = off + NTOP;
+            for (int64_t e = F + tid; e < A.ld; e += T) out[e] = e == F ? scale_of(0) : 0.0;      // level 0 == 1 (signature_algs.py:20)
+        }
+        if (A.dlev && tid <= M) A.dlev[n * (M + 1) + tid] = tid == 0 ? 1.0 : norms[tid];
+    }
+}
+
+inline size_t sig_features_lds_bytes(int d, int M, int L) {
+    (void)M;
+    return sizeof(double) * (size_t(L) * d + 16);
+}
+
+// ---- C = A B^T, float64 matrix cores, depth split over workgroups ----------------------------------------------------------------
+typedef double sig_f64x4 __attribute__((ext_vector_type(4)));
+constexpr int SG_BM = 128, SG_BN = 128, SG_BK = 16, SG_LDK = SG_BK + 1;
+
+struct SigGramArgs {
+    const double* A; const double* B;     // (NA, lda), (NB, ldb) row-major; B row of output column c is (b_off + c) mod b_mod
+    int64_t NA, NB, lda, ldb;
+    int64_t b_off, b_mod;
+    int k_begin, k_end;                   // depth range of this product
+    int nsplit;                           // workgroups per tile along the depth
+    int symmetric;                        // A == B, NA == NB, b_off == 0: tiles (bi <= bj) only
+    int ntj;                              // tile columns
+    double* part;                         // (nsplit, NA, NB) partial sums
+};
+
+// grid: nsplit * ntiles workgroups, split-major (the tiles of one depth chunk run together: they share operand slabs in L2).
+// VEC: the depth range starts at an even column (16-byte loads of the operands); otherwise element by element.
+template <bool VEC>
+static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramArgs G) {
+    __shared__ double As[2][SG_BM * SG_LDK];            // two slabs: the next one is written while this one is multiplied (one barrier per slab)
+    __shared__ double Bs[2][SG_BN * SG_LDK];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ntiles = gridDim.x / G.nsplit;
+    const int split = blockIdx.x / ntiles;
+    int tile = blockIdx.x - split * ntiles, bi, bj;
+    if (G.symmetric) {                    // tile -> (bi <= bj), row by row of the upper triangle
+        bi = 0;
+        int rowlen = G.ntj;
+        while (tile >= rowlen) { tile -= rowlen; ++bi; --rowlen; }
+        bj = bi + tile;
+    } else {
+        bi = tile / G.ntj;
+        bj = tile - bi * G.ntj;
+    }
+    const int64_t tile_i = int64_t(bi) * SG_BM, tile_j = int64_t(bj) * SG_BN;
+    // depth chunk of this workgroup, in whole slabs
+    const int nslab = (G.k_end - G.k_begin + SG_BK - 1) / SG_BK;
+    const int s0 = int(int64_t(nslab) * split / G.nsplit), s1 = int(int64_t(nslab) * (split + 1) / G.nsplit);
+    const int kb = G.k_begin + s0 * SG_BK, ke = (G.k_begin + s1 * SG_BK < G.k_end) ? G.k_begin + s1 * SG_BK : G.k_end;
+    // staging: thread t fetches columns [8 h, 8 h + 8) of row t >> 1 of the slab, h = t & 1
+    const int srow = tid >> 1, scol = (tid & 1) * 8;
+    const int64_t ai = tile_i + srow, bjr = tile_j + srow;
+    const bool aok = ai < G.NA, bok = bjr < G.NB;
+    int64_t brow_i = G.b_off + (bok ? bjr : 0);
+    if (brow_i >= G.b_mod) brow_i -= G.b_mod;
+    const double* arow = G.A + (aok ? ai : 0) * G.lda;
+    const double* brow = G.B + brow_i * G.ldb;
+    double pa[8], pb[8];
+    auto fetch = [&](int k0) {
+        if (VEC && k0 + SG_BK <= ke) {
+            const double2* a2 = reinterpret_cast<const double2*>(arow + k0 + scol);
+            const double2* b2 = reinterpret_cast<const double2*>(brow + k0 + scol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // rows past the end read row 0 instead (arow / brow above): what they produce is never stored, and a select here
+                // would sit right behind the loads and make the wave wait for them before its multiplies instead of after
+                const double2 va = a2[e], vb = b2[e];
+                pa[2 * e] = va.x; pa[2 * e + 1] = va.y;
+                pb[2 * e] = vb.x; pb[2 * e + 1] = vb.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + scol + e;
+                pa[e] = (aok && k < ke) ? arow[k] : 0.0;
+                pb[e] = (bok && k < ke) ? brow[k] : 0.0;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            As[buf][srow * SG_LDK + scol + e] = pa[e];
+            Bs[buf][srow * SG_LDK + scol + e] = pb[e];
+        }
+    };
+    sig_f64x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = sig_f64x4{0.0, 0.0, 0.0, 0.0};
+    if (kb < ke) {
+        fetch(kb);
+        stash(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kb; k0 < ke; k0 += SG_BK, buf ^= 1) {
+        const bool more = k0 + SG_BK < ke;
+        if (more) fetch(k0 + SG_BK);                        // in flight while this slab is multiplied
+#pragma unroll
+        for (int kk = 0; kk < SG_BK; kk += 4) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                av[m] = As[buf][(wr * 64 + m * 16 + li) * SG_LDK + kk + lk];
+                bv[m] = Bs[buf][(wc * 64 + m * 16 + li) * SG_LDK + kk + lk];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc[m][n], 0, 0, 0);
+            // the next slab goes to the other buffer (last read one slab ago, before the barrier that ended it) ahead of the last
+            // quarter of this slab's multiplies: the loads have had three quarters of a slab to land, and the LDS writes finish
+            // under the multiplies instead of in front of the barrier
+            if (kk == SG_BK - 8 && more) stash(buf ^ 1);
+        }
+        __syncthreads();
+    }
+    double* const P = G.part + int64_t(split) * G.NA * G.NB;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = tile_i + wr * 64 + m * 16 + lk + 4 * r, j = tile_j + wc * 64 + n * 16 + li;
+                if (i < G.NA && j < G.NB) P[i * G.NB + j] = acc[m][n][r];
+            }
+}
+
+// mode 0: out[i * so_i + j * so_j] = sum_s part[s][i][j]                                              (general product)
+// mode 1: symmetric: tiles bi <= bj hold the sums; out[i][j] = out[j][i]; diag_set: out[i][i] = diag_value (the normalised diagonal is
+//         sum_m sigma variances[m] exactly, kernels.py:430-433)
+// mode 2: owned entries of rows [r0, r0 + NA) of the symmetric N x N Gram, packed (gpsig_kernel_K_symm_rows_compact): part row i =
+//         sequence r0 + i, part column c = sequence (c0 + c) mod N; row j owns column i iff (j - i) mod N < N/2, or == N/2 and (N odd
+//         or i < j) -- the rule of seq_emit in seq_args.hpp; out[(j - r0) * (N/2 + 1) + N/2 - (j - i) mod N]
+struct SigReduceArgs {
+    const double* part; int nsplit; int64_t NA, NB;
+    double* out; int64_t so_i, so_j;
+    int mode, diag_set; double diag_value;
+    int64_t N, r0, c0;
+    int compact;          // mode 2: packed rows (1) or full rows of N with only the owned entries written (0)
+};
+// mode 1 in 32 x 32 blocks of the computed (upper) tiles: partial sums read and the result written along rows, the mirror image written
+// along rows too after a transpose through LDS.  grid (blocks per tile side squared, upper tiles), block (32, 8).
+static __global__ void sig_gram_reduce_sym_kernel(const SigReduceArgs R, int nt) {
+    __shared__ double tile[32][33];
+    int t = blockIdx.y, bi = 0, rowlen = nt;
+    while (t >= rowlen) { t -= rowlen; ++bi; --rowlen; }
+    const int bj = bi + t;
+    constexpr int SB = SG_BM / 32;
+    const int sbi = blockIdx.x / SB, sbj = blockIdx.x - sbi * SB;
+    const int64_t i0 = int64_t(bi) * SG_BM + sbi * 32, j0 = int64_t(bj) * SG_BN + sbj * 32;
+    const int64_t stride = R.NA * R.NB;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int64_t i = i0 + r, j = j0 + threadIdx.x;
+        double s = 0.0;
+        if (i < R.NA && j < R.NB) {
+            for (int k = 0; k < R.nsplit; ++k) s += R.part[int64_t(k) * stride + i * R.NB + j];
+            if (i == j && R.diag_set) s = R.diag_value;
+            R.out[i * R.so_i + j * R.so_j] = s;
+        }
+        tile[r][threadIdx.x] = s;
+    }
+    if (bi == bj) return;                 // a diagonal tile was computed whole (and a_i . a_j == a_j . a_i bit for bit)
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int64_t j = j0 + r, i = i0 + threadIdx.x;
+        if (i < R.NA && j < R.NB) R.out[j * R.so_i + i * R.so_j] = tile[threadIdx.x][r];
+    }
+}
+
+static __global__ void sig_gram_reduce_kernel(const SigReduceArgs R) {
+    const int64_t total = R.NA * R.NB, stride = R.NA * R.NB;
+    for (int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t i = e / R.NB, j = e - i * R.NB;
+        int64_t src = e;
+        if (R.mode == 1 && (i / SG_BM) > (j / SG_BN)) src = j * R.NB + i;          // the tile that was computed is the transposed one
+        double s = 0.0;
+        for (int k = 0; k < R.nsplit; ++k) s += R.part[int64_t(k) * stride + src];
+        if (R.mode == 2) {
+            const int64_t seq_j = R.r0 + i;
+            int64_t seq_i = R.c0 + j;
+            if (seq_i >= R.N) seq_i -= R.N;
+            const int64_t H = R.N / 2;
+            int64_t dlt = seq_j - seq_i;
+            if (dlt < 0) dlt += R.N;
+            const bool own = dlt < H || (dlt == H && ((R.N & 1) || seq_i < seq_j));
+            if (!own) continue;
+            if (dlt == 0 && R.diag_set) s = R.diag_value;
+            if (R.compact) R.out[i * (H + 1) + H - dlt] = s;
+            else R.out[i * R.N + seq_i] = s;
+            continue;
+        }
+        if (R.mode == 1 && i == j && R.diag_set) s = R.diag_value;
+        R.out[i * R.so_i + j * R.so_j] = s;
+    }
+}
+
+}  // namespace gpsig

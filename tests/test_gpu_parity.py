@@ -892,6 +892,64 @@ def test_float32_full_config5_properties(K):
     assert np.abs(blk - Gh[512:640])[off].max() <= TOL32 * np.abs(Gh).max()
 
 
+def test_linear_gram_as_feature_contraction(K):
+    """SignatureLinear, order 1, evaluated as ONE contraction of explicit level features on the float64 matrix cores (round 3,
+    sig_feat_kernel.hpp: K_m(x, y) = <Phi_m(x), Phi_m(y)>) against the oracle and against the lattice kernels: symmetric and cross
+    Grams, unequal lengths, levels, normalisation on / off, differences off, lags, ragged sizes across tile and depth-split boundaries,
+    the raw level primitive, and the owned row blocks of the multi-GPU decomposition."""
+    import ctypes as C
+    from gpsig_amd import _lib, parallel
+    rng = np.random.default_rng(311)
+    ctx = _lib.context(0, 0)
+    cases = [dict(N=37, N2=21, L=9, L2=9, d=3, M=4), dict(N=130, N2=50, L=20, L2=7, d=2, M=6), dict(N=260, N2=129, L=15, L2=12, d=8, M=3),
+             dict(N=70, N2=9, L=11, L2=6, d=2, M=2, lags=1), dict(N=140, N2=33, L=10, L2=10, d=5, M=4, normalization=False),
+             dict(N=45, N2=45, L=8, L2=8, d=4, M=5, difference=False)]
+    for cs in cases:
+        N, N2, L, L2, d, M = (cs[k] for k in ("N", "N2", "L", "L2", "d", "M"))
+        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base="linear", lengthscales=0.7 + rng.random(d), variances=0.5 + rng.random(M + 1),
+                  normalization=cs.get("normalization", True), difference=cs.get("difference", True))
+        if cs.get("lags"):
+            kw["num_lags"] = cs["lags"]
+        kx, ko = make_kernel(K, kw), make_oracle(kw)
+        kx.sigma = ko.sigma = 1.3
+        X = np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
+        Y = np.cumsum(0.4 * rng.standard_normal((N2, L2, d)), axis=1).reshape(N2, -1)
+        got = {}
+        try:
+            for route in (1, 0):
+                ctx.set_option("sig_features", route)
+                got[route] = (kx.K(X), kx.K(X, Y), kx.K(X, return_levels=True), kx.K(X, Y, return_levels=True))
+        finally:
+            ctx.set_option("sig_features", -1)
+        want = (ko.K(X), ko.K(X, Y), ko.K(X, return_levels=True), ko.K(X, Y, return_levels=True))
+        for a, b, w in zip(got[1], got[0], want):
+            assert relerr(a, w) <= TOL and relerr(a, b) <= 1e-10, (cs, relerr(a, w), relerr(a, b))
+        assert np.array_equal(got[1][0], got[1][0].T)                               # mirrored, not recomputed
+        if kw["normalization"]:
+            assert np.array_equal(np.diag(got[1][0]), np.full(N, np.sum(kx.sigma * kx.variances)))       # kernels.py:430-433: exactly
+    # the unscaled level primitive (what gpsig_seq_gram_levels returns) and the packed row blocks of the multi-GPU path
+    N, L, d, M = 300, 14, 3, 4
+    X = np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1)
+    kx = make_kernel(K, dict(input_dim=L * d, num_features=d, num_levels=M, base="linear", lengthscales=None))
+    ko = make_oracle(dict(input_dim=L * d, num_features=d, num_levels=M, base="linear", lengthscales=None))
+    try:
+        ctx.set_option("sig_features", 1)
+        lev = kx._K_seq(X)
+        full = kx.K(X.reshape(N, -1))
+        keep = []
+        p = kx._params(keep)
+        H = N // 2
+        half = np.zeros((N, H + 1))
+        for r0, r1 in ((0, 96), (96, 100), (100, 300)):
+            blk = np.zeros((r1 - r0, H + 1))
+            ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.ctypes.data), N, L, r0, r1, C.c_void_p(blk.ctypes.data))
+            half[r0:r1] = blk
+    finally:
+        ctx.set_option("sig_features", -1)
+    assert relerr(lev, ko._K_seq(X)) <= TOL
+    assert np.abs(parallel.symmetrize_compact_reference(half) - full).max() <= 1e-12 * np.abs(full).max()
+
+
 # ------------------------------------------------------------------------------------------------
 # low-rank mode (gpsig/low_rank_calculations.py, signature_algs.py:162-222): the reference's randomness is TF's and
 # cannot be reproduced, so (i) given the SAME landmarks and projections the HIP path must equal the restatement of
