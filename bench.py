@@ -348,8 +348,11 @@ VALU_PER_STEP = {("c2", "linear"): 89, ("c4", "linear"): 89, ("c2", "rbf"): 174,
 SIMDS = 1024
 
 
+FP64_MATRIX_PEAK_TFLOPS = 78.6          # MI355X_MICROARCH.md: dense float64 MFMA peak (= the vector peak) at 2.4 GHz
+
+
 def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chunks=4, weak=False, checks=True, host_e2e=True,
-                 traffic="measure"):
+                 traffic="measure", lattice=False):
     """Times `steps` evaluations of one BASELINE configuration on this rank's device (inputs resident in HBM) and returns the
     bench-line fields on rank 0 (None elsewhere)."""
     import torch
@@ -384,6 +387,8 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
         torch.cuda.synchronize(dev)
 
     ctx = _lib.context(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
+    # lattice=True: SignatureLinear through the pair recursion (round 1-2's kernel) instead of the feature contraction
+    ctx.set_option("sig_features", 0 if lattice else -1)
     t_w = time.perf_counter()
     for _ in range(warmup):
         step()
@@ -421,6 +426,8 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     if clock:
         clock["timed_region_ms"] = dt * 1e3
     kernel_ms, launches, _ = ctx.timing_get()      # HIP events around the dominant kernel, on the stream it was launched on
+    timed_kernel, mfma_flops = ctx.timing_info()   # "sig_gram_kernel" + its matrix-core flops when the feature contraction ran
+    ctx.set_option("sig_features", -1)
 
     if world > 1:
         tt = torch.tensor([dt, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
@@ -448,7 +455,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     alu_frac = tflops_exec / alu_peak
     ghz = clock["mean"] if clock else None
     issue = None
-    vps = VALU_PER_STEP.get((cfg, base))
+    vps = VALU_PER_STEP.get((cfg, base)) if timed_kernel is None else None
     if vps and ghz:
         pairs_per_wave = 4                                           # G = 16: four pair groups per wavefront
         wave_steps = evaluated_launch / pairs_per_wave * L           # L lattice rows (L - 1 increments + the boundary row) per pair
@@ -464,12 +471,35 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     else:
         bound = "valu-latency"
         binding = "float32 dependent-instruction latency at the kernel's wavefronts per SIMD (DESIGN.md section 2.4)"
-    kernel_name = ("tvs_tile_kernel (tensor-vs-sequence chains)" if T else
+    mfma = None
+    if timed_kernel == "sig_gram_kernel":
+        fl_launch = mfma_flops / max(launches, 1)
+        F = sum(D ** m for m in range(1, M + 1))
+        ld = (F + 1 + 15) // 16 * 16
+        tf = fl_launch / (per_launch_ms * 1e-3) / 1e12
+        bound = "mfma"
+        binding = ("float64 matrix cores: the Gram is ONE contraction of depth sum_m d^m + 1 = %d (explicit signature-level features, "
+                   "v_mfma_f64_16x16x4), upper tile triangle only; DESIGN.md section 2.4" % (F + 1))
+        mfma = {"achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MATRIX_PEAK_TFLOPS,
+                "flops_per_launch": fl_launch, "depth": ld,
+                "frac_at_measured_clock": (tf / (FP64_MATRIX_PEAK_TFLOPS * ghz / 2.4)) if ghz else None,
+                "flops_per_evaluated_pair": fl_launch / evaluated_launch,
+                # what HBM has to see at least: the feature matrix once, the partial sums of the depth splits once
+                "algorithmic_bytes_per_launch": 8.0 * (N / n_gpus) * ld + 8.0 * evaluated_launch * max(1, round(ld / 16 / 146)),
+                "other_kernels_in_step": "sig_features_kernel (the level features of every sequence), sig_gram_reduce_sym_kernel (adds the "
+                                         "depth splits in a fixed order, mirrors); kernel_share_of_step says how much they and the launches cost",
+                "kernel_share_of_step": per_launch_ms * launches_per_step / (dt / steps * 1e3)}
+        tflops_exec = tf
+        alu_peak = FP64_MATRIX_PEAK_TFLOPS
+        alu_frac = tf / alu_peak
+        f_exec = fl_launch / evaluated_launch
+    kernel_name = ("sig_gram_kernel (feature contraction on the float64 matrix cores)" if mfma else
+                   "tvs_tile_kernel (tensor-vs-sequence chains)" if T else
                    ("seq_pk2_kernel (pair recursion, two sequences per pair group)" if (w["dtype"] == "f32" and base == "rbf")
                     else "seq_gram_kernel (pair recursion)"))
     # ---- HBM traffic: measured by this run (two rocprofv3 --pmc passes of the same command), else the committed passes
     tr, tr_src = None, None
-    key = ("c2" if cfg == "c4" else cfg) + "_" + base + ("_increments" if increments else "")
+    key = ("c2" if cfg == "c4" else cfg) + "_" + base + ("_increments" if increments else "") + ("_features" if mfma else "")
     if traffic == "measure" and n_gpus == 1 and cfg != "c4":
         m = measure_traffic(cfg, base, increments)
         if m:
@@ -509,9 +539,14 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
                      "issue_frac": issue["issue_frac"] if issue else None, "issue_model": issue,
                      "alu_frac": alu_frac,
                      # the contract's fields: ALGORITHMIC bytes per launch / the kernel's HIP-event time, against the HBM peak
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": stream_frac if stream_frac <= 1.0 else None, "stream_frac": stream_frac,
-                     "frac_is": "stream_frac: the ALGORITHMIC pair-stream rate of SURVEY 8(d) (every delivered entry priced at its input streams + its "
+                     "achieved": mfma["achieved"] if mfma else achieved, "peak": mfma["peak"] if mfma else HBM_PEAK_GBS,
+                     "unit": mfma["unit"] if mfma else "GB/s",
+                     "frac": mfma["frac"] if mfma else (stream_frac if stream_frac <= 1.0 else None), "stream_frac": stream_frac,
+                     "mfma": mfma, "stream_achieved_gbs": achieved,
+                     "frac_is": ("achieved / peak of the float64 matrix cores for the dominant kernel (`mfma`); stream_frac beside it is the ALGORITHMIC "
+                                 "pair-stream rate of SURVEY 8(d) over the HBM peak, the number north_star's 60 % target is stated in -- not DRAM "
+                                 "bandwidth (`traffic` is what the memory side saw)") if mfma else
+                                "stream_frac: the ALGORITHMIC pair-stream rate of SURVEY 8(d) (every delivered entry priced at its input streams + its "
                                 "result) over the HBM peak -- the number north_star's 60 % target is stated in -- NOT DRAM bandwidth: the streams are "
                                 "served from L2 / LDS, `traffic` is what the memory side saw, `bound` names what limits the kernel"
                                 + ("" if stream_frac <= 1.0 else "; above 1 here (a sequence record is staged once per 64 tensors), so it is not printed as a fraction of HBM"),
@@ -558,16 +593,17 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     return res
 
 
-SECONDARY = [("c2", "rbf", False), ("c3", "rbf", False), ("c3", "rbf", True), ("c5", "rbf", False)]
+SECONDARY = [("c2", "linear", False, True), ("c2", "rbf", False, False), ("c3", "rbf", False, False), ("c3", "rbf", True, False),
+             ("c5", "rbf", False, False)]
 
 
 def secondary_lines(dev):
     """The other single-GPU configurations, 3 warm-up + 10 steps each, as short records beside the headline."""
     out = []
-    for cfg, base, inc in SECONDARY:
-        name = cfg + "-" + base + ("-increments" if inc else "")
+    for cfg, base, inc, lattice in SECONDARY:
+        name = cfg + "-" + base + ("-increments" if inc else "") + ("-lattice" if lattice else "")
         try:
-            r = run_workload(cfg, base, inc, 10, 3, dev, host_e2e=False, traffic="static")
+            r = run_workload(cfg, base, inc, 10, 3, dev, host_e2e=False, traffic="static", lattice=lattice)
             rf = r["roofline"]
             out.append({"name": name, "workload": r["config"]["workload"], "dtype": r["dtype"], "value": r["value"], "unit": r["unit"],
                         "ms_per_step": r["ms_per_step"], "kernel_ms": rf["kernel_ms_per_launch"] * rf["launches_per_step"],

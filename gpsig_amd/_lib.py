@@ -96,6 +96,7 @@ _PLAIN = {
     "gpsig_symmetrize_compact_rows": ([_vp, _i32, _vp, _i64, _vp], C.c_int),
     "gpsig_timing_reset": ([_vp], C.c_int),
     "gpsig_timing_get": ([_vp, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(_i64)], C.c_int),
+    "gpsig_timing_info": ([_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double)], C.c_int),
     "gpsig_clock_probe_start": ([_vp, C.c_double, _i32], C.c_int),
     "gpsig_clock_probe_read": ([_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
     "gpsig_graph_begin": ([_vp], C.c_int),
@@ -206,6 +207,12 @@ class Context:
         self.check(self._lib.gpsig_timing_get(self._h, C.byref(ms), C.byref(n), C.byref(pairs)))
         return ms.value, n.value, pairs.value
 
+
+    def timing_info(self):
+        """(kernel name or None, matrix-core flops) of the timed launches since the last reset."""
+        k, f = C.c_char_p(), C.c_double()
+        self.check(self._lib.gpsig_timing_info(self._h, C.byref(k), C.byref(f)))
+        return (k.value.decode() if k.value else None), f.value
 
     def clock_probe_start(self, duration_ms, samples=64):
         """Sample the shader clock for `duration_ms` from now on, concurrently with whatever is launched next."""

@@ -636,21 +636,15 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     const bool symtiles = sym && !rows;
     const int ntiles = symtiles ? nti * (nti + 1) / 2 : nti * ntj;
     const int nslab_all = int((ld + SG_BK - 1) / SG_BK);
-    // workgroups per tile along the depth: the launch should come out in whole rounds of the 512 workgroups the chip holds (528 tiles
-    // in one piece each would take two rounds, the second nearly empty), against one more partial sum to write and add per split
-    int nsplit = 1;
-    {
-        const double slots = 512.0, flops = 2.0 * double(ntiles) * SG_BM * SG_BN * double(ld);
-        const double t_gemm = flops / 55e12, t_split = 2.0 * double(NA) * NB * 8.0 * (symtiles ? 0.5 : 1.0) / 3e12;
-        double best = 1e30;
-        for (int ns = 1; ns <= 64 && ns <= nslab_all / 8 + 1; ++ns) {
-            const double items = double(ntiles) * ns, rounds = ceil(items / slots);
-            const double t = t_gemm * rounds * slots / items + t_split * ns;
-            if (t < best) { best = t; nsplit = ns; }
-        }
-    }
+    // Workgroups per tile along the depth: 528 tiles in one piece each would take two rounds of the 512 workgroup slots the chip holds,
+    // the second nearly empty; cut ~146 slabs deep, a launch of any shape is many rounds long and the last one costs little.  The count
+    // is a function of the depth ALONE: the order in which an entry's products are added is then the same whichever tile, row block or
+    // rank computes it, so row blocks (gpsig_kernel_K_symm_rows*) reassemble the one-call Gram bit for bit.
+    int nsplit = (nslab_all + 73) / 146;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 32) nsplit = 32;
     const size_t part_one = sizeof(double) * size_t(NA) * NB;
-    while (nsplit > 1 && part_one * size_t(nsplit) > (size_t(8) << 30)) --nsplit;
+    while (nsplit > 1 && part_one * size_t(nsplit) > (size_t(16) << 30)) --nsplit;       // (the exception to the rule above: 16 GiB of partial sums)
     const size_t feat_bytes = sizeof(double) * size_t(ld) * (size_t(N1) + (sym ? 0 : size_t(N2)));
     if (feat_bytes + part_one * size_t(nsplit) > (size_t(64) << 30)) return GPSIG_OK;
     const double* w = nullptr;
@@ -707,6 +701,8 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
             HIPCHK(c, hipEventRecord(e1, c->stream));
             c->t_launches += 1;
             c->t_pairs += NA * NB;
+            c->t_kernel = "sig_gram_kernel";
+            c->t_flops += 2.0 * double(ntiles) * SG_BM * SG_BN * double(nslab) * SG_BK;
         }
         SigReduceArgs R;
         memset(&R, 0, sizeof(R));
@@ -1887,6 +1883,15 @@ int gpsig_timing_reset(gpsig_ctx* c) {
     c->ev_used = 0;
     c->t_launches = 0;
     c->t_pairs = 0;
+    c->t_kernel = nullptr;
+    c->t_flops = 0.0;
+    return GPSIG_OK;
+}
+
+int gpsig_timing_info(gpsig_ctx* c, const char** kernel, double* flops) {
+    if (!c) return GPSIG_ERR_INVALID;
+    if (kernel) *kernel = c->t_kernel;
+    if (flops) *flops = c->t_flops;
     return GPSIG_OK;
 }
 

@@ -111,6 +111,8 @@ struct gpsig_ctx {
     std::vector<hipEvent_t> ev;     // pairs (start, stop)
     size_t ev_used = 0;
     int64_t t_launches = 0, t_pairs = 0;
+    const char* t_kernel = nullptr;      // which kernel the timed launches were, where it is not the pair recursion (gpsig_timing_info)
+    double t_flops = 0.0;                // multiply-adds x 2 those launches executed on the matrix cores
     // HIP-graph capture (gpsig_graph_begin .. gpsig_graph_end): launches only -- nothing may allocate, upload or synchronise
     bool capturing = false, capture_failed = false;
     uint64_t alloc_gen = 0;         // bumped whenever a scratch buffer moves; a graph replays only against the generation it saw

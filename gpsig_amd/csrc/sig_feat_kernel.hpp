@@ -2,7 +2,7 @@
 //
 // For the LINEAR state-space kernel the increment lattice of a pair factorises, dM[a][b] = <dx_a, dy_b> (gpsig/kernels.py:799-806 into
 // signature_algs.py:25-26), and with it the whole first-order recursion (signature_algs.py:28-35): level m is the sum over strictly
-// increasing index tuples a_1 < .. < a_m, b_1 < .. < b_m of prod_i <dx_{a_i}, dy_{b_i}> (pinned by the oracle's brute-force test), i.e.
+// increasing index tuples a_1 < .. < a_m, b_1 < .. < b_m of prod_i <dx_{a_i}, dy_{b_i}>, i.e.
 //     K_m(x, y) = < Phi_m(x), Phi_m(y) >,     Phi_m(x) = sum_{a_1 < .. < a_m} dx_{a_1} (x) .. (x) dx_{a_m}   in (R^d)^{(x) m},
 // d^m numbers per sequence and level, built by one sweep over time,  Phi_m <- Phi_m + Phi_{m-1}(previous step) (x) dx_a.
 // A Gram entry then costs 2 sum_m d^m flops instead of the lattice sweep's L1 L2 (2d + 3M - 1): at BASELINE configs[1] (L = 64, d = 8,

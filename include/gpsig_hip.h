@@ -137,6 +137,10 @@ int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
  * launches after a reset; none inside a graph capture). */
 int gpsig_timing_reset(gpsig_ctx* ctx);
 int gpsig_timing_get(gpsig_ctx* ctx, double* kernel_ms, int64_t* launches, int64_t* pairs);
+/* What the timed launches were: *kernel = "sig_gram_kernel" when they were the matrix-core contraction of the explicit signature
+ * features (option "sig_features"), NULL for the pair recursion / chain kernels; *flops = the floating-point operations those
+ * launches executed on the matrix cores (whole tiles, padded depth), 0 otherwise. */
+int gpsig_timing_info(gpsig_ctx* ctx, const char** kernel, double* flops);
 /* Effective shader clock while the calls that follow run (diagnostics for benchmarks; no reference analogue): a single sleeping
  * wavefront on a stream of its own takes up to `samples` readings of s_memtime (shader cycles) against s_memrealtime (100 MHz),
  * duration_ms / (samples - 1) apart; _read tells it to take a last reading and leave, waits for it, and returns the mean /

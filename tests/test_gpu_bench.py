@@ -60,15 +60,20 @@ def test_default_line_carries_the_measurement():
     line = _bench(["--steps", "5", "--warmup", "2"])
     assert line["n_gpus"] == 1 and line["config"]["name"] == "c2" and line["rel_err"] <= 1e-6
     rf = line["roofline"]
-    assert rf["bound"] == "valu-issue" and 0.3 < rf["issue_frac"] <= 1.05 and 0.2 < rf["alu_frac"] < 1.0
-    assert rf["frac"] == rf["stream_frac"] and rf["unit"] == "GB/s"
+    # the headline Gram is the feature contraction on the float64 matrix cores: priced in TFLOP/s against their peak
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6
+    assert 0.5 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["mfma"]["depth"] == 37456 and 0.7 < rf["mfma"]["kernel_share_of_step"] <= 1.0
+    assert rf["issue_frac"] is None and rf["stream_frac"] > 0
     assert 1.0 < line["clock_ghz"] < 2.6
     assert rf["traffic"] and rf["traffic_source"]["how"].startswith("measured by this run")
-    assert "seq_gram_kernel" in rf["traffic_source"]["kernel"]
+    assert "sig_gram_kernel" in rf["traffic_source"]["kernel"]
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     names = [s["name"] for s in line["secondary"]]
-    assert names == ["c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf"]
+    assert names == ["c2-linear-lattice", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf"]
+    lat = line["secondary"][0]                          # the same Gram through the pair recursion: vector-issue bound, about twice the time
+    assert lat["bound"] == "valu-issue" and 0.3 < lat["issue_frac"] <= 1.05 and lat["ms_per_step"] > line["ms_per_step"]
     for s in line["secondary"]:
         assert "error" not in s, s
         assert s["rel_err"] <= (1e-4 if s["dtype"] == "f32" else 1e-6) and s["ms_per_step"] > 0 and s["clock_ghz"] > 1.0
-    assert line["secondary"][1]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
+    assert line["secondary"][2]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
