@@ -66,9 +66,11 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const S
     constexpr int NTOP = sig_ipow(D, M), NPAR = sig_ipow(D, M - 1);     // top-level values, their parents (level M-1)
     constexpr int PPT = (NPAR + T - 1) / T;                             // parents per thread
     constexpr int NA = M - 1;                                           // ancestors kept per parent: levels M-1 (k = 0) .. 1 (k = M-2)
+    constexpr int S = D <= 64 ? 64 / D : 1;                             // steps whose increments one wavefront register holds
+    static_assert(D <= 64, "one row of increments per wavefront register");
     extern __shared__ double sf_sm[];
-    double* const dx = sf_sm;                       // R x D increments of this sequence
-    double* const red = dx + size_t(A.L) * D;       // T / 64 partial sums
+    double* const dx = sf_sm;                       // R x D increments of this sequence, then zeros up to (L + S) x D + 64
+    double* const red = dx + (size_t(A.L) + S) * D + 64;       // T / 64 partial sums
     __shared__ double norms[M + 1];
     const int tid = threadIdx.x;
     const int R = A.difference ? A.L - 1 : A.L;
@@ -88,9 +90,9 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const S
     for (int64_t n = blockIdx.x; n < A.N; n += gridDim.x) {
         const double* Xn = A.X + n * int64_t(A.L) * A.P.d_in;
         __syncthreads();                            // the previous sequence's increments are no longer read
-        for (int e = tid; e < R * D; e += T) {
+        for (int e = tid; e < (A.L + S) * D + 64; e += T) {
             const int a = e / D, f = e - a * D;
-            dx[e] = A.difference ? scaled_point<double>(Xn, A.L, a + 1, f, A.P) - scaled_point<double>(Xn, A.L, a, f, A.P)
+            dx[e] = a >= R ? 0.0 : A.difference ? scaled_point<double>(Xn, A.L, a + 1, f, A.P) - scaled_point<double>(Xn, A.L, a, f, A.P)
                                  : scaled_point<double>(Xn, A.L, a, f, A.P);
         }
         double top[PPT][D], anc[PPT][NA];
@@ -102,29 +104,40 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const S
             for (int f = 0; f < D; ++f) top[q][f] = 0.0;
         }
         __syncthreads();
-        for (int a = 0; a < R; ++a) {
-            const double* dxa = dx + a * D;
-            double d_[D];
+        // The increment of a step is the same for every thread: it is read from LDS once per S steps -- lane l of a wavefront holds
+        // element l of the S rows dx[a0 .. a0 + S) -- and handed to the multiply-adds as a SCALAR operand (v_readlane), so a step waits
+        // for no LDS round trip of its own.  Rows past the last increment are zeros (they change nothing).
+        for (int a0 = 0; a0 < R; a0 += S) {
+            const double rows = dx[a0 * D + (tid & 63)];
 #pragma unroll
-            for (int f = 0; f < D; ++f) d_[f] = dxa[f];
-            // the ancestors' components of dx come from LDS by index (behind an opaque index: a select among the D registers of d_,
-            // which the compiler builds when it can see the index is one of them, costs 2 D instructions)
-            double dck[NA];
+            for (int i = 0; i < S; ++i) {
+                const double* dxa = dx + (a0 + i) * D;
+                double d_[D];
 #pragma unroll
-            for (int k = 0; k < NA; ++k) dck[k] = dxa[opaque(comp_k[k])];
+                for (int f = 0; f < D; ++f) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(rows), i * D + f);
+                    const int hi = __builtin_amdgcn_readlane(__double2hiint(rows), i * D + f);
+                    d_[f] = __hiloint2double(hi, lo);
+                }
+                // the ancestors' components of dx differ by lane: from LDS by index (behind an opaque index: a select among the D
+                // values of d_, which the compiler builds when it can see the index is one of them, costs 2 D instructions)
+                double dck[NA];
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                // every level from the OLD value of the level below it: the top first, then the ancestors from the highest down
+                for (int k = 0; k < NA; ++k) dck[k] = dxa[opaque(comp_k[k])];
 #pragma unroll
-                for (int f = 0; f < D; ++f) top[q][f] = fma(anc[q][0], d_[f], top[q][f]);
+                for (int q = 0; q < PPT; ++q) {
+                    // every level from the OLD value of the level below it: the top first, then the ancestors from the highest down
 #pragma unroll
-                for (int k = 0; k < NA; ++k) {
-                    const double below = k + 1 < NA ? anc[q][k + 1] : 1.0;
-                    double dc;
-                    if (T % sig_ipow(D, k + 1) == 0) dc = dck[k];
-                    else if (sig_ipow(D, k) % T == 0) dc = d_[(q / (sig_ipow(D, k) / T > 0 ? sig_ipow(D, k) / T : 1)) % D];
-                    else dc = dxa[opaque(comp_g[q][k])];
-                    anc[q][k] = fma(below, dc, anc[q][k]);
+                    for (int f = 0; f < D; ++f) top[q][f] = fma(anc[q][0], d_[f], top[q][f]);
+#pragma unroll
+                    for (int k = 0; k < NA; ++k) {
+                        const double below = k + 1 < NA ? anc[q][k + 1] : 1.0;
+                        double dc;
+                        if (T % sig_ipow(D, k + 1) == 0) dc = dck[k];
+                        else if (sig_ipow(D, k) % T == 0) dc = d_[(q / (sig_ipow(D, k) / T > 0 ? sig_ipow(D, k) / T : 1)) % D];
+                        else dc = dxa[opaque(comp_g[q][k])];
+                        anc[q][k] = fma(below, dc, anc[q][k]);
+                    }
                 }
             }
         }
@@ -202,7 +215,7 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const S
 
 inline size_t sig_features_lds_bytes(int d, int M, int L) {
     (void)M;
-    return sizeof(double) * (size_t(L) * d + 16);
+    return sizeof(double) * ((size_t(L) + (d <= 64 ? 64 / d : 1)) * d + 64 + 16);
 }
 
 // ---- C = A B^T, float64 matrix cores, depth split over workgroups ----------------------------------------------------------------
@@ -231,15 +244,47 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramAr
     const int li = lane & 15, lk = lane >> 4;
     const int ntiles = gridDim.x / G.nsplit;
     const int split = blockIdx.x / ntiles;
-    int tile = blockIdx.x - split * ntiles, bi, bj;
-    if (G.symmetric) {                    // tile -> (bi <= bj), row by row of the upper triangle
-        bi = 0;
-        int rowlen = G.ntj;
-        while (tile >= rowlen) { tile -= rowlen; ++bi; --rowlen; }
-        bj = bi + tile;
-    } else {
-        bi = tile / G.ntj;
-        bj = tile - bi * G.ntj;
+    int tile, bi, bj;
+    {
+        // Workgroups go to the 8 XCDs round robin by their index, and each XCD has an L2 of its own: give XCD x a CONTIGUOUS range of
+        // this split's tiles (in the block-major order below), so that the ~64 tiles it works on at a time share operand panels in its
+        // L2 -- an 8 x 8 block of tiles reads 16 panels, 64 tiles strided over the whole triangle read all of them.
+        const int j = blockIdx.x - split * ntiles, off = (split * ntiles) & 7, x = (off + j) & 7;
+        int start = 0;
+        for (int xp = 0; xp < x; ++xp) {
+            const int j0 = (xp - off + 8) & 7;
+            start += j0 < ntiles ? (ntiles - 1 - j0) / 8 + 1 : 0;
+        }
+        tile = start + ((j - ((x - off + 8) & 7)) >> 3);
+    }
+    {
+        // tile -> (bi, bj): 8 x 8 blocks of tiles, block rows first; symmetric products keep the blocks and tiles with bi <= bj
+        constexpr int SB = 8;
+        const int nti = G.symmetric ? G.ntj : (ntiles / G.ntj), nbi = (nti + SB - 1) / SB, nbj = (G.ntj + SB - 1) / SB;
+        int Bi = 0, Bj = 0, hi = 0, wj = 0;
+        bool found = false;
+        for (Bi = 0; Bi < nbi && !found; ++Bi) {
+            hi = nti - Bi * SB < SB ? nti - Bi * SB : SB;
+            for (Bj = G.symmetric ? Bi : 0; Bj < nbj; ++Bj) {
+                wj = G.ntj - Bj * SB < SB ? G.ntj - Bj * SB : SB;
+                const int cnt = (G.symmetric && Bj == Bi) ? hi * (hi + 1) / 2 : hi * wj;
+                if (tile < cnt) { found = true; break; }
+                tile -= cnt;
+            }
+            if (found) break;
+        }
+        int li_, lj_;
+        if (G.symmetric && Bj == Bi) {            // the upper triangle of a diagonal block, row by row
+            li_ = 0;
+            int rowlen = hi;
+            while (tile >= rowlen) { tile -= rowlen; ++li_; --rowlen; }
+            lj_ = li_ + tile;
+        } else {
+            li_ = tile / wj;
+            lj_ = tile - li_ * wj;
+        }
+        bi = Bi * SB + li_;
+        bj = Bj * SB + lj_;
     }
     const int64_t tile_i = int64_t(bi) * SG_BM, tile_j = int64_t(bj) * SG_BN;
     // depth chunk of this workgroup, in whole slabs
