@@ -625,6 +625,7 @@ def main(argv=None):
     ap.add_argument("--increments", action="store_true", help="c3: inducing tensors hold increments (kernels.py:329-330)")
     ap.add_argument("--weak", action="store_true", help="--gpus N > 1: N_total = 4096 * sqrt(N) instead of configs[3]")
     ap.add_argument("--chunks", type=int, default=4, help="pieces a rank's row block is computed / gathered in")
+    ap.add_argument("--lattice", action="store_true", help="SignatureLinear through the pair recursion instead of the feature contraction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="default line only: leave out the other single-GPU configurations")
     ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes (roofline.traffic falls back to profiles/hbm_traffic.json)")
@@ -703,12 +704,13 @@ def main(argv=None):
 
     lean = args.timed_loop_only
     res = run_workload(cfg, base, args.increments, args.steps, args.warmup, dev, rank, world, chunks=args.chunks, weak=args.weak,
-                       checks=not lean, host_e2e=not lean, traffic="off" if lean else ("static" if args.no_traffic else "measure"))
+                       checks=not lean, host_e2e=not lean, lattice=args.lattice,
+                       traffic="off" if lean else ("static" if (args.no_traffic or args.lattice) else "measure"))
     if rank == 0:
         res["ranks_seen"] = seen
         if cpu is not None:
             res["cpu_baseline"] = cpu
-        if n_gpus == 1 and args.config is None and args.base is None and not args.increments and not args.no_secondary and not lean:
+        if n_gpus == 1 and args.config is None and args.base is None and not args.increments and not args.no_secondary and not lean and not args.lattice:
             res["secondary"] = secondary_lines(dev)
         print(json.dumps(res))
     if world > 1:

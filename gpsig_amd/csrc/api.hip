@@ -31,7 +31,7 @@ int tvs_tile_width(int d);
 bool seq_pk2_select(int rows, int d, int M, int* G, int* C, int* D);
 typedef hipError_t (*SigFeatLaunchFn)(const SigFeatArgs&, unsigned, size_t, hipStream_t);
 SigFeatLaunchFn sig_feat_lookup(int d, int M);
-hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream);
+hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream, int dma);
 hipError_t sig_reduce_launch(const SigReduceArgs& R, hipStream_t stream);
 bool solver_dsyevd(void** handle_slot, hipStream_t stream, int n, double* A, double* ev, double* work, int* info, std::string* err);
 void solver_release(void* handle);
@@ -696,7 +696,8 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         hipEvent_t e0 = nullptr, e1 = nullptr;
         bool on = false;
         if (timed) CHK(timing_begin_any(c, &e0, &e1, &on));
-        HIPCHK(c, sig_gram_launch(G, ntiles, c->stream));
+        // the LDS-DMA form reads whole slabs: only where the columns behind k_end are the zero padding of the feature rows
+        HIPCHK(c, sig_gram_launch(G, ntiles, c->stream, (c->sig_gemm_dma && !return_levels) ? 1 : 0));
         if (on) {
             HIPCHK(c, hipEventRecord(e1, c->stream));
             c->t_launches += 1;
@@ -1803,6 +1804,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "pinned_staging")) c->pinned_staging = value ? 1 : 0;
     else if (!strcmp(name, "lr_jacobi")) c->lr_jacobi = value ? 1 : 0;
     else if (!strcmp(name, "sig_features")) c->sig_features = value;
+    else if (!strcmp(name, "sig_gemm_dma")) c->sig_gemm_dma = value;
     else if (!strcmp(name, "keep_reset")) c->keep_reset = value ? 1 : 0;
     else if (!strcmp(name, "pk2")) c->allow_pk2 = value;
     else if (!strcmp(name, "f32_pack")) c->f32_pack = value;

@@ -233,18 +233,11 @@ struct SigGramArgs {
     double* part;                         // (nsplit, NA, NB) partial sums
 };
 
-// grid: nsplit * ntiles workgroups, split-major (the tiles of one depth chunk run together: they share operand slabs in L2).
-// VEC: the depth range starts at an even column (16-byte loads of the operands); otherwise element by element.
-template <bool VEC>
-static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramArgs G) {
-    __shared__ double As[2][SG_BM * SG_LDK];            // two slabs: the next one is written while this one is multiplied (one barrier per slab)
-    __shared__ double Bs[2][SG_BN * SG_LDK];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int li = lane & 15, lk = lane >> 4;
+// Which depth piece and which tile this workgroup computes.
+__device__ inline void sig_tile_of(const SigGramArgs& G, int& split_out, int& bi, int& bj) {
     const int ntiles = gridDim.x / G.nsplit;
     const int split = blockIdx.x / ntiles;
-    int tile, bi, bj;
+    int tile;
     {
         // Workgroups go to the 8 XCDs round robin by their index, and each XCD has an L2 of its own: give XCD x a CONTIGUOUS range of
         // this split's tiles (in the block-major order below), so that the ~64 tiles it works on at a time share operand panels in its
@@ -286,6 +279,20 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramAr
         bi = Bi * SB + li_;
         bj = Bj * SB + lj_;
     }
+    split_out = split;
+}
+
+// grid: nsplit * ntiles workgroups, split-major (the tiles of one depth chunk run together: they share operand slabs in L2).
+// VEC: the depth range starts at an even column (16-byte loads of the operands); otherwise element by element.
+template <bool VEC>
+static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramArgs G) {
+    __shared__ double As[2][SG_BM * SG_LDK];            // two slabs: the next one is written while this one is multiplied (one barrier per slab)
+    __shared__ double Bs[2][SG_BN * SG_LDK];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    int split, bi, bj;
+    sig_tile_of(G, split, bi, bj);
     const int64_t tile_i = int64_t(bi) * SG_BM, tile_j = int64_t(bj) * SG_BN;
     // depth chunk of this workgroup, in whole slabs
     const int nslab = (G.k_end - G.k_begin + SG_BK - 1) / SG_BK;
@@ -360,6 +367,99 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramAr
             if (kk == SG_BK - 8 && more) stash(buf ^ 1);
         }
         __syncthreads();
+    }
+    double* const P = G.part + int64_t(split) * G.NA * G.NB;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t i = tile_i + wr * 64 + m * 16 + lk + 4 * r, j = tile_j + wc * 64 + n * 16 + li;
+                if (i < G.NA && j < G.NB) P[i * G.NB + j] = acc[m][n][r];
+            }
+}
+
+// The same product with the slabs brought in by LDS-DMA and the operand fragments prefetched across the barrier (whole slabs only:
+// k_begin a multiple of SG_BK, rows padded with zeros up to a multiple of SG_BK, 16-byte aligned).  A slab is 128 rows x 16 doubles per
+// operand, rows unpadded (the DMA writes lane-linear: 8 lanes x 16 bytes = one row) with the 16-byte slots of row r XORed by (r >> 1) & 7
+// ON THE GLOBAL SIDE -- lane (row, slot s) fetches columns 2 (s ^ swz) -- so that a fragment read (16 rows x 4 depth, 8 bytes per lane)
+// touches every bank pair once.  Per slab and wave: 8 DMA instructions at the top (no staging registers, no ds_write), fragments of
+// depth step k+1 read while step k multiplies, ONE barrier in front of the last step's multiplies -- by then the wave holds that
+// step's fragments, and the next slab's first fragments are read right behind the barrier, under 16 MFMAs.  Same summation order as
+// sig_gram_kernel: bit-identical results.
+static __global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGramArgs G) {
+    __shared__ __attribute__((aligned(16))) double As[2][SG_BM * SG_BK];
+    __shared__ __attribute__((aligned(16))) double Bs[2][SG_BN * SG_BK];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    int split, bi, bj;
+    sig_tile_of(G, split, bi, bj);
+    const int64_t tile_i = int64_t(bi) * SG_BM, tile_j = int64_t(bj) * SG_BN;
+    const int nslab = (G.k_end - G.k_begin + SG_BK - 1) / SG_BK;
+    const int s0 = int(int64_t(nslab) * split / G.nsplit), s1 = int(int64_t(nslab) * (split + 1) / G.nsplit);
+    const int nsl = s1 - s0;
+    const double* ga[4];
+    const double* gb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                   // piece q of this wave: rows (4 q + wave) 8 .. + 8, lane = (row, slot)
+        const int r = (q * 4 + wave) * 8 + (lane >> 3), p = (lane & 7) ^ ((r >> 1) & 7);
+        const int64_t ai = tile_i + r, bjr = tile_j + r;
+        int64_t brow_i = G.b_off + (bjr < G.NB ? bjr : 0);
+        if (brow_i >= G.b_mod) brow_i -= G.b_mod;
+        ga[q] = G.A + (ai < G.NA ? ai : 0) * G.lda + G.k_begin + int64_t(s0) * SG_BK + 2 * p;
+        gb[q] = G.B + brow_i * G.ldb + G.k_begin + int64_t(s0) * SG_BK + 2 * p;
+    }
+    auto dma = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga[q],
+                                             (__attribute__((address_space(3))) void*)(&As[buf][(q * 4 + wave) * 8 * SG_BK]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb[q],
+                                             (__attribute__((address_space(3))) void*)(&Bs[buf][(q * 4 + wave) * 8 * SG_BK]), 16, 0, 0);
+            ga[q] += SG_BK;
+            gb[q] += SG_BK;
+        }
+    };
+    const int swz = (lk >> 1) ^ ((li >> 1) & 7);
+    const int arow = (wr * 64 + li) * SG_BK + (lk & 1), brow = (wc * 64 + li) * SG_BK + (lk & 1);
+    auto frag = [&](int buf, int kq, double (&av)[4], double (&bv)[4]) {          // depth step kq of the slab: columns 4 kq + lk
+        const int o = ((2 * kq) ^ swz) << 1;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            av[m] = As[buf][arow + m * 16 * SG_BK + o];
+            bv[m] = Bs[buf][brow + m * 16 * SG_BK + o];
+        }
+    };
+    sig_f64x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = sig_f64x4{0.0, 0.0, 0.0, 0.0};
+    double fa[2][4], fb[2][4];
+    if (nsl > 0) dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nsl > 0) frag(0, 0, fa[0], fb[0]);
+    for (int s = 0, buf = 0; s < nsl; ++s, buf ^= 1) {
+        const bool more = s + 1 < nsl;
+        if (more) dma(buf ^ 1);             // the other buffer: every wave's reads of it were complete at the barrier of the previous slab
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            const int cur = kq & 1, nxt = cur ^ 1;
+            if (kq < 3) {
+                frag(buf, kq + 1, fa[nxt], fb[nxt]);
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the next slab have landed
+                __syncthreads();                                        // ... and everybody else's; all reads of this slab are done
+                if (more) frag(buf ^ 1, 0, fa[nxt], fb[nxt]);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][m], fb[cur][n], acc[m][n], 0, 0, 0);
+        }
     }
     double* const P = G.part + int64_t(split) * G.NA * G.NB;
 #pragma unroll

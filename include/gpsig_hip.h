@@ -114,6 +114,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "sig_features" SignatureLinear, order 1: the Gram as ONE contraction of explicit level features on the float64 matrix cores
  *                 (sig_feat_kernel.hpp: K_m(x, y) = <Phi_m(x), Phi_m(y)>, d^m numbers per level): -1 (default) where that costs fewer
  *                 flops than the lattice sweep and the feature matrices fit, 0 never, 1 wherever it is built (d <= 8, d^M <= 65536)
+ *   "sig_gemm_dma" that contraction's operand slabs by LDS-DMA into an XOR-swizzled image, fragments prefetched across the barrier
+ *                 (1, default) or staged through registers (0); bit-identical results
  *   "lr_jacobi"   gpsig_lr_draw: 1 (default) the landmark Gram's eigendecomposition by the one-workgroup Jacobi kernel (c <= 64), 0 rocSOLVER
  *   "tvs_zreg"    tensor-lane gradient: components in registers (1) or LDS (0), -1 automatic
  *   "tvs_tile"    tensor-vs-sequence tile kernel (levels split over the waves of a workgroup, coalesced result tiles):

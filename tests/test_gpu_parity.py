@@ -925,6 +925,13 @@ def test_linear_gram_as_feature_contraction(K):
         for a, b, w in zip(got[1], got[0], want):
             assert relerr(a, w) <= TOL and relerr(a, b) <= 1e-10, (cs, relerr(a, w), relerr(a, b))
         assert np.array_equal(got[1][0], got[1][0].T)                               # mirrored, not recomputed
+        try:            # the register-staged form of the contraction adds the same products in the same order as the LDS-DMA form
+            ctx.set_option("sig_features", 1)
+            ctx.set_option("sig_gemm_dma", 0)
+            assert np.array_equal(kx.K(X), got[1][0]) and np.array_equal(kx.K(X, Y), got[1][1])
+        finally:
+            ctx.set_option("sig_gemm_dma", 1)
+            ctx.set_option("sig_features", -1)
         if kw["normalization"]:
             assert np.array_equal(np.diag(got[1][0]), np.full(N, np.sum(kx.sigma * kx.variances)))       # kernels.py:430-433: exactly
     # the unscaled level primitive (what gpsig_seq_gram_levels returns) and the packed row blocks of the multi-GPU path
