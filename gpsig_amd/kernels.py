@@ -8,7 +8,7 @@ every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CU
 pointers, asynchronous on the current stream).
 
 float32 inputs are computed in float32 where the float32 kernels are built, else by the float64 kernels and rounded.
-Not built (raise NotImplementedError, never a silent CPU fallback): ``SignatureSpectral`` in low-rank mode / with gradients.  Training (gradients): ``gpsig_amd.autodiff``.
+Not built (raise NotImplementedError, never a silent CPU fallback): ``SignatureSpectral`` in low-rank mode; gradients of low-rank mode.  Training (gradients): ``gpsig_amd.autodiff``.
 """
 import ctypes as C
 
@@ -240,7 +240,7 @@ class SignatureKernel:
     :normalization:  normalise each level (kernels.py:430-433, :455-469)
     :difference:     difference the base-kernel tensor (signature_algs.py:25-26)
     :num_lags:       None or a non-negative int (kernels.py:70-82)
-    :low_rank, num_components, rank_bound, sparsity: validated as the reference does; low_rank=True is not built
+    :low_rank, num_components, rank_bound, sparsity: validated as the reference does (low-rank mode: gpsig_amd.low_rank, float64)
     """
     _base = None
 
