@@ -246,13 +246,17 @@ class Graph:
             raise ValueError("the graph was not recorded")
         self.ctx.check(self.ctx._lib.gpsig_graph_launch(self.ctx._h, self._g))
 
+    def destroy(self):
+        """Release the executable graph (no replay may be in flight)."""
+        g, self._g = getattr(self, "_g", None), None
+        if g is not None:
+            self.ctx._lib.gpsig_graph_destroy(g)
+
     def __del__(self):
-        if getattr(self, "_g", None) is not None:
-            try:
-                self.ctx._lib.gpsig_graph_destroy(self._g)
-            except Exception:
-                pass
-            self._g = None
+        try:
+            self.destroy()
+        except Exception:        # interpreter shutdown: the library may already be gone
+            pass
 
 
 _holders = {}

@@ -88,17 +88,26 @@ class GraphedCall:
     def __init__(self, graph, inputs, out, stream):
         self.graph, self.inputs, self.out, self.stream = graph, inputs, out, stream
 
+    def close(self):
+        """Release the recording: waits for replays in flight, destroys the executable graph, gives the side stream's context back.
+        Errors surface here; __del__ calls it and reports instead of raising (a destructor cannot)."""
+        if self.graph is None:
+            return
+        dev = self.out[0].device if isinstance(self.out, (tuple, list)) else self.out.device
+        self.stream.synchronize()            # no replay may still be in flight when the executable graph goes away
+        g, self.graph = self.graph, None
+        g.destroy()
+        _lib.release(dev.index or 0, self.stream.cuda_stream)      # the side stream's context belongs to this recording alone
+
     def __del__(self):
-        # the side stream and its context (scratch buffers, task lists) belong to this recording alone
         try:
-            dev = self.out[0].device if isinstance(self.out, (tuple, list)) else self.out.device
-            self.stream.synchronize()            # no replay may still be in flight when the executable graph goes away
-            g, self.graph = self.graph, None
-            if g is not None:
-                g.__del__()
-            _lib.release(dev.index or 0, self.stream.cuda_stream)
-        except Exception:
-            pass
+            self.close()
+        except Exception as e:               # not silently: a failed release leaks a context and its scratch buffers
+            import warnings
+            try:
+                warnings.warn("GraphedCall: releasing a recorded evaluation failed: %r" % (e,), ResourceWarning)
+            except Exception:
+                pass
 
     def replay(self):
         cur = torch.cuda.current_stream(self.out[0].device if isinstance(self.out, (tuple, list)) else self.out.device)

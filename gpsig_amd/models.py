@@ -283,14 +283,28 @@ class SVGPModule(torch.nn.Module if torch is not None else object):
             static_loss = -self.elbo(xs, ys)
             static_loss.backward()
             opt.step()
+        # Replays cannot raise from inside (the recorded Cholesky factorisations are the unchecked form): the losses go into one
+        # preallocated buffer, and a loss that stopped being finite -- a covariance that lost positive definiteness -- restores the
+        # last parameters seen with a finite loss and raises, instead of letting Adam run on NaNs.
+        trace_dev = torch.empty(iterations - warm, dtype=static_loss.dtype, device=dev)
+        check_every = 25
+        good = [p_.detach().clone() for p_ in params]
         for it in range(warm, iterations):
             xb, yb = batch()
             xs.copy_(xb); ys.copy_(yb)
             g.replay()
+            trace_dev[it - warm].copy_(static_loss.detach())
             if callback is not None:
-                trace.append(-static_loss.item())
-                callback(it, trace[-1])
-            else:
-                trace.append(static_loss.detach().neg().clone())      # no host synchronisation per iteration
+                callback(it, -float(static_loss.item()))
+            if (it - warm) % check_every == check_every - 1 or it == iterations - 1:
+                lo = (it - warm) // check_every * check_every
+                if not bool(torch.isfinite(trace_dev[lo:it - warm + 1]).all()):
+                    with torch.no_grad():
+                        for p_, g_ in zip(params, good):
+                            p_.copy_(g_)
+                    raise FloatingPointError("fit(graph=True): the ELBO stopped being finite between iterations %d and %d "
+                                             "(a covariance matrix lost positive definiteness?); parameters restored" % (warm + lo, it))
+                good = [p_.detach().clone() for p_ in params]
+        trace.extend((-trace_dev).tolist())
         self._step_graph = g             # keeps the recorded step (and the memory it owns) alive with the model
-        return [t if isinstance(t, float) else float(t) for t in trace]
+        return [float(t) for t in trace]
