@@ -12,7 +12,11 @@ gpsig/models.py:40-59).  Here the same role is split in two:
 ``SignatureKernelModule`` holds the hyper-parameters as unconstrained ``torch.nn.Parameter``s with GPflow 1.5.1's transforms
 (``transforms.positive`` = softplus + 1e-6 for variances, sigma, lengthscales, gamma, the base-kernel parameter;
 ``transforms.Logistic`` for lags; kernels.py:65-88) so that an optimiser step means what it means in the reference.
-Exact (non low-rank) mode, first- and higher-order algorithms; computed by the float64 kernels (float32 tensors -- a module after
+Exact mode: first- and higher-order algorithms through those kernels.  Low-rank mode (kernels.py:239-311, :424-426, :442-458; trained by
+the reference's benchmarks, benchmarks/models/train_gpsig.py:21): the Nystrom features, their whitening (an eigendecomposition that
+autograd differentiates, as TensorFlow does: low_rank_calculations.py:50-60), the running sums and the sparse projections are torch
+ops on the GPU (GEMMs, gathers, rocSOLVER), with the landmarks GATHERED from the scaled inputs so that gradients reach them too; sized
+for training batches (a projection materialises (N, L, non-zeros) products).  Computed by the float64 kernels (float32 tensors -- a module after
 .float() -- are converted on the way in, results and gradients rounded on the way out).  No CPU fallback: tensors must live on the GPU.
 """
 import ctypes as C
@@ -398,9 +402,125 @@ def _add_lags(X, lags):
     return torch.cat((X[:, :, None, :], _lin_interp(time, X, time_lags)), dim=2)                    # :59-61
 
 
+class LowRankDraw:
+    """The random objects of ONE low-rank evaluation that do not depend on values (the reference draws them inside the graph per
+    evaluation: kernels.py:443-446, low_rank_calculations.py:12-20, :52, :92-101): which ``num_components`` of the evaluation's points are
+    the Nystrom landmarks (indices into the concatenation the reference gathers from: [tensor points,] sequence points [, second
+    sequences' points]), the jitter added to the landmark Gram, one sparse projection per level >= 2 (``gpsig_amd.low_rank.Sketch``)."""
+
+    def __init__(self, idx, jitter_diag, sketches):
+        self.idx = np.ascontiguousarray(idx, dtype=np.int64)
+        self.jitter_diag = np.ascontiguousarray(jitter_diag, dtype=np.float64)
+        self.sketches = list(sketches)
+        self._dev = {}
+
+    def on(self, device):
+        """(idx, jitter_diag, [(i1, i2, val, column of every entry, r)]) as tensors on ``device``."""
+        key = str(device)
+        if key not in self._dev:
+            t = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt, device=device)
+            sk = []
+            for s_ in self.sketches:
+                col = np.repeat(np.arange(s_.r), np.diff(s_.colptr))
+                sk.append((t(s_.i1, torch.int64), t(s_.i2, torch.int64), t(s_.val, torch.float64), t(col, torch.int64), int(s_.r)))
+            self._dev[key] = (t(self.idx, torch.int64), t(self.jitter_diag, torch.float64), sk)
+        return self._dev[key]
+
+
+def _apply_sketch(sk, A, B):
+    """lr_hadamard_prod_rand (low_rank_calculations.py:76-193) given its random matrix: out[..., j] = sum over the entries e of
+    column j of val[e] A[..., i1[e]] B[..., i2[e]].  (..., k1), (..., k2) -> (..., r); rows in chunks of at most 2^27 products."""
+    i1, i2, val, col, r = sk
+    lead = A.shape[:-1]
+    A2, B2 = A.reshape(-1, A.shape[-1]), B.reshape(-1, B.shape[-1])
+    rows, nnz = A2.shape[0], max(int(i1.shape[0]), 1)
+    step = max(1, (1 << 27) // nnz)
+    outs = []
+    for r0 in range(0, rows, step):
+        a, b = A2[r0:r0 + step], B2[r0:r0 + step]
+        prod = a[:, i1] * b[:, i2] * val
+        outs.append(torch.zeros((a.shape[0], r), dtype=prod.dtype, device=prod.device).index_add(1, col, prod))
+    out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+    return out.reshape(*lead, r)
+
+
+class _LowRankScope:
+    """One low-rank evaluation: landmarks gathered from the evaluation's scaled points, their whitening, and the level features of
+    every input asked for (kept per tensor: Kzz, Kzx and Kxx of one call share them)."""
+
+    def __init__(self, mod, pool, draw):
+        idx, jd, self.sk = draw.on(pool.device)
+        if int(idx.max()) >= pool.shape[0]:
+            raise ValueError("the low-rank draw indexes %d points, the evaluation has %d" % (int(idx.max()) + 1, pool.shape[0]))
+        self.mod = mod
+        self.S = pool[idx]                                                                          # low_rank_calculations.py:47-48 (tf.gather: differentiable)
+        W = mod._kappa(self.S, self.S) + torch.diag(jd)                                             # :51-52
+        ev, U = torch.linalg.eigh(W)                                                                # :55
+        # an eigenvector is fixed up to sign; the level >= 2 features depend on it through the projections of coordinate pairs: the
+        # component of largest magnitude is taken positive (the library's and the checker's convention; constant under autograd)
+        with torch.no_grad():
+            top = U.abs().argmax(dim=0)
+            sgn = torch.where(U[top, torch.arange(U.shape[1], device=U.device)] < 0, -1.0, 1.0).to(U.dtype)
+        self.Wh = U * sgn[None, :] / torch.sqrt(ev + JITTER)[None, :]                               # :56-57, :60
+        self._seq, self._tens = {}, {}
+
+    def _nys(self, pts):
+        return self.mod._kappa(pts, self.S) @ self.Wh                                               # :59-61
+
+    def seq(self, Xs):
+        """signature_algs.py:162-192 (with :191 summing P, as evidently intended).  (N, L, d') -> [(N, 1), (N, c), (N, r), ...]."""
+        key = id(Xs)
+        if key not in self._seq:
+            N, L, d = Xs.shape
+            U = self._nys(Xs.reshape(N * L, d)).reshape(N, L, -1)                                   # kernels.py:252-254
+            if self.mod.kern.difference:
+                U = U[:, 1:] - U[:, :-1]                                                            # :180
+            Phi = [torch.ones((N, 1), dtype=U.dtype, device=U.device), U.sum(dim=1)]                # :177, :182
+            P = U
+            for i in range(2, self.mod.kern.num_levels + 1):
+                P = torch.cumsum(P, dim=1) - P                                                      # :186 exclusive
+                P = _apply_sketch(self.sk[i - 2], U, P)                                             # :188 / :190
+                Phi.append(P.sum(dim=1))
+            self._seq[key] = (Xs, Phi)                                                              # (the tensor is kept alive: its id is the key)
+        return self._seq[key][1]
+
+    def tens(self, Zs, increments):
+        """signature_algs.py:194-222, kernels.py:285-311.  (lt, T[, 2], d') -> [(T, 1), (T, c), (T, r), ...]."""
+        key = id(Zs)
+        if key not in self._tens:
+            lt, T, d = Zs.shape[0], Zs.shape[1], Zs.shape[-1]
+            if increments:
+                F = self._nys(Zs.reshape(lt * T * 2, d)).reshape(lt, T, 2, -1)
+                F = F[:, :, 1] - F[:, :, 0]                                                         # kernels.py:300-304
+            else:
+                F = self._nys(Zs.reshape(lt * T, d)).reshape(lt, T, -1)
+            Phi, k = [torch.ones((T, 1), dtype=F.dtype, device=F.device)], 0
+            for i in range(1, self.mod.kern.num_levels + 1):
+                R = F[k]; k += 1
+                for j in range(1, i):
+                    R = _apply_sketch(self.sk[j - 1], F[k], R); k += 1                              # signature_algs.py:217 / :219
+                Phi.append(R)
+            self._tens[key] = (Zs, Phi)
+        return self._tens[key][1]
+
+
+def _low_rank_scoped(fn):
+    """The low-rank scope of a public evaluation ends with it."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        try:
+            return fn(self, *a, **kw)
+        finally:
+            self._lr = None
+    return wrapped
+
+
 class SignatureKernelModule(torch.nn.Module):
-    """Trainable view of a ``gpsig_amd.kernels.SignatureKernel`` (exact mode; any order -- the higher-order algorithms'
-    gradients run through scratch-based kernels built for coverage rather than speed, grad_ho_kernels.hpp).
+    """Trainable view of a ``gpsig_amd.kernels.SignatureKernel`` (exact mode: any order -- the higher-order algorithms'
+    gradients run through scratch-based kernels built for coverage rather than speed, grad_ho_kernels.hpp; low-rank mode: torch
+    ops, see the module docstring; its evaluations take ``lr=`` -- a ``LowRankDraw`` -- and draw one per evaluation without).
 
     ``kern`` supplies the structure (base kernel, levels, normalisation, lags, ...) and the initial hyper-parameter values;
     ``write_back()`` copies the trained values into it so that the fused inference path (``kern.K`` etc.) uses them."""
@@ -409,12 +529,11 @@ class SignatureKernelModule(torch.nn.Module):
         super().__init__()
         if kern._base is None:
             raise NotImplementedError("SignatureKernel is abstract: use SignatureLinear, SignatureRBF, ...")
-        if kern.low_rank:
-            raise NotImplementedError("gradients are built for the exact (non low-rank) mode only")
         self.kern = kern
+        self._lr = None
         d_cols = kern.num_features * (kern.num_lags + 1)
         # beyond 64 columns and for the spectral kernel: base-kernel tensors here (GEMMs, autograd), recursions in the library
-        self.matrix_route = kern._base == "spectral" or d_cols > 64
+        self.matrix_route = (kern._base == "spectral" or d_cols > 64) and not kern.low_rank
         dev = torch.device(device)
         par = lambda v: torch.nn.Parameter(torch.as_tensor(np.asarray(v, dtype=np.float64), device=dev))
         self.raw_variances = par(positive_inverse(kern.variances))
@@ -492,20 +611,30 @@ class SignatureKernelModule(torch.nn.Module):
 
     # ---- level primitives ------------------------------------------------------------------------------------------
     def _seq_levels(self, Xs, X2s=None):
+        if self._lr is not None:                                                                    # kernels.py:426 / :451
+            P1 = self._lr.seq(Xs)
+            P2 = P1 if X2s is None else self._lr.seq(X2s)
+            return torch.stack([a @ b.T for a, b in zip(P1, P2)], dim=0)
         return self._mx_seq_levels(Xs, X2s) if self.matrix_route else _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
 
     def _diag_levels(self, Xs):
+        if self._lr is not None:                                                                    # kernels.py:457, :501
+            return torch.stack([torch.square(P).sum(dim=-1) for P in self._lr.seq(Xs)], dim=0)
         return self._mx_diag_levels(Xs) if self.matrix_route else _SeqDiagLevels.apply(Xs, self.p0, self._spec)
 
     def _tens_levels(self, Zs, increments):
+        if self._lr is not None:                                                                    # kernels.py:525-527
+            return torch.stack([P @ P.T for P in self._lr.tens(Zs, increments)], dim=0)
         return self._mx_tens_levels(Zs, increments) if self.matrix_route else _TensGramLevels.apply(Zs, self.p0, self._spec, increments)
 
     def _tvs_levels(self, Zs, Xs, increments):
+        if self._lr is not None:                                                                    # kernels.py:568
+            return torch.stack([a @ b.T for a, b in zip(self._lr.tens(Zs, increments), self._lr.seq(Xs))], dim=0)
         return self._mx_tvs_levels(Zs, Xs, increments) if self.matrix_route else _TensVsSeqLevels.apply(Zs, Xs, self.p0, self._spec, increments)
 
     def _tvs_weighted(self, Zs, Xs, fac, increments):
-        if self.matrix_route:
-            return (self._mx_tvs_levels(Zs, Xs, increments) * fac[:, None, :]).sum(dim=0)
+        if self.matrix_route or self._lr is not None:
+            return (self._tvs_levels(Zs, Xs, increments) * fac[:, None, :]).sum(dim=0)
         return _TensVsSeqWeighted.apply(Zs, Xs, fac, self.p0, self._spec, increments)
 
     # the same four primitives on the matrix route (kernels.py:188-340 with torch ops up to the differenced tensor)
@@ -566,12 +695,41 @@ class SignatureKernelModule(torch.nn.Module):
     def _w(self):
         return self.sigma * self.variances                                                          # kernels.py:471
 
+    # ---- low-rank mode ---------------------------------------------------------------------------------------------
+    def draw_low_rank(self, num_points):
+        """The value-independent random objects of one evaluation over ``num_points`` points (``kern.rng``, as ``kern.draw_low_rank``):
+        landmark indices, the jitter draw (low_rank_calculations.py:52), one projection per level >= 2."""
+        from . import low_rank as _lrm
+        k = self.kern
+        c = int(k.num_components)
+        if c > num_points:
+            raise ValueError("num_components exceeds the number of available points")
+        idx = np.sort(k.rng.choice(int(num_points), size=c, replace=False, shuffle=False))
+        return LowRankDraw(idx, JITTER * k.rng.random(c), _lrm.draw_level_sketches(k.rng, k.num_levels, c, int(k.rank_bound), k.sparsity))
+
+    def _lr_open(self, lr, *points):
+        """Low-rank mode: gather the landmarks from the concatenation of the evaluation's scaled points (the order the reference
+        concatenates in: tensors first, kernels.py:562-563, :614-615; X before X2, :445-446) and whiten them; a fresh draw per
+        evaluation unless one is handed in."""
+        if not self.kern.low_rank:
+            if lr is not None:
+                raise ValueError("lr= is for kernels in low-rank mode")
+            return
+        if self._spec.order > 1 and self.kern.num_levels > 1:
+            raise NotImplementedError('Higher-order algorithms not compatible with low-rank mode (yet).')   # kernels.py:59-60
+        if not all(p_.is_cuda for p_ in points):
+            raise RuntimeError("gpsig_amd.autodiff needs CUDA (ROCm) tensors: there is no CPU path")
+        pool = torch.cat([p_.reshape(-1, p_.shape[-1]) for p_ in points], dim=0)
+        self._lr = _LowRankScope(self, pool, lr if lr is not None else self.draw_low_rank(pool.shape[0]))
+
     # ---- kernel evaluations ----------------------------------------------------------------------------------------
-    def K(self, X, X2=None, presliced=False, return_levels=False, presliced_X=False, presliced_X2=False):
-        """kernels.py:401-476."""
+    @_low_rank_scoped
+    def K(self, X, X2=None, presliced=False, return_levels=False, presliced_X=False, presliced_X2=False, lr=None):
+        """kernels.py:401-476.  lr: a LowRankDraw (low-rank mode; drawn per evaluation when None)."""
         Xs = self.scale_sequences(self._seq3(X, presliced or presliced_X))
         N = Xs.shape[0]
         if X2 is None:
+            self._lr_open(lr, Xs)
             K = self._seq_levels(Xs)
             if self.kern.normalization:
                 K = K + JITTER * torch.eye(N, dtype=K.dtype, device=K.device)[None]                 # :431
@@ -579,6 +737,7 @@ class SignatureKernelModule(torch.nn.Module):
                 K = K / (dsq[:, :, None] * dsq[:, None, :])                                         # :433
         else:
             X2s = self.scale_sequences(self._seq3(X2, presliced or presliced_X2))
+            self._lr_open(lr, Xs, X2s)
             K = self._seq_levels(Xs, X2s)
             if self.kern.normalization:
                 d1 = torch.sqrt(self._diag_levels(Xs) + JITTER)                                     # :460-466
@@ -587,39 +746,50 @@ class SignatureKernelModule(torch.nn.Module):
         K = K * self._w()[:, None, None]
         return K if return_levels else K.sum(dim=0)
 
-    def Kdiag(self, X, presliced=False, return_levels=False):
+    @_low_rank_scoped
+    def Kdiag(self, X, presliced=False, return_levels=False, lr=None):
         """kernels.py:479-510."""
         N = X.shape[0]
         if self.kern.normalization:
             Kd = self._w()[:, None].expand(-1, N)                                                   # :486-490
         else:
-            Kd = self._diag_levels(self.scale_sequences(self._seq3(X, presliced))) * self._w()[:, None]
+            Xs = self.scale_sequences(self._seq3(X, presliced))
+            self._lr_open(lr, Xs)
+            Kd = self._diag_levels(Xs) * self._w()[:, None]
         return Kd if return_levels else Kd.sum(dim=0)
 
-    def K_tens(self, Z, return_levels=False, increments=False):
+    @_low_rank_scoped
+    def K_tens(self, Z, return_levels=False, increments=False, lr=None):
         """kernels.py:513-536."""
-        K = self._tens_levels(self.scale_tensors(Z), increments) * self._w()[:, None, None]
+        Zs = self.scale_tensors(Z)
+        self._lr_open(lr, Zs)
+        K = self._tens_levels(Zs, increments) * self._w()[:, None, None]
         return K if return_levels else K.sum(dim=0)
 
-    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False, presliced=False):
+    @_low_rank_scoped
+    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False, presliced=False, lr=None):
         """kernels.py:539-588."""
         Xs = self.scale_sequences(self._seq3(X, presliced))
+        Zs0 = self.scale_tensors(Z)
+        self._lr_open(lr, Zs0, Xs)
         if not return_levels:
             # the same numbers with the level sum taken inside the kernel: (M+1, N) factors in, (T, N) out
             fac = self._w()[:, None].expand(-1, Xs.shape[0])                                        # :584
             if self.kern.normalization:
                 fac = fac / torch.sqrt(self._diag_levels(Xs) + JITTER)                              # :576-581
-            return self._tvs_weighted(self.scale_tensors(Z), Xs, fac, increments)                   # :588
-        K = self._tvs_levels(self.scale_tensors(Z), Xs, increments)
+            return self._tvs_weighted(Zs0, Xs, fac, increments)                                     # :588
+        K = self._tvs_levels(Zs0, Xs, increments)
         if self.kern.normalization:
             K = K / torch.sqrt(self._diag_levels(Xs) + JITTER)[:, None, :]                          # :576-581
         return K * self._w()[:, None, None]
 
-    def K_tens_n_seq_covs(self, Z, X, full_X_cov=False, return_levels=False, increments=False, presliced=False):
+    @_low_rank_scoped
+    def K_tens_n_seq_covs(self, Z, X, full_X_cov=False, return_levels=False, increments=False, presliced=False, lr=None):
         """kernels.py:591-671: Kzz, Kzx and Kxx (full or diagonal) from one scaling of the inputs."""
         Xs = self.scale_sequences(self._seq3(X, presliced))
         N = Xs.shape[0]
         Zs = self.scale_tensors(Z)
+        self._lr_open(lr, Zs, Xs)
         Kzz = self._tens_levels(Zs, increments)                                                     # :623
         w = self._w()
         if not return_levels:
@@ -661,11 +831,13 @@ class SignatureKernelModule(torch.nn.Module):
                 Kxx = Kxx * w[:, None]
         return Kzz * w[:, None, None], Kzx * w[:, None, None], Kxx
 
-    def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False, presliced=False):
+    @_low_rank_scoped
+    def K_seq_n_seq_covs(self, X, X2, full_X2_cov=False, return_levels=False, presliced=False, lr=None):
         """kernels.py:674-761 (``X`` = inducing sequences, never sliced: :679-680; ``X2`` = data), including the double division
         of :713 + :750."""
         Xs = self.scale_sequences(self._seq3(X, True))
         X2s = self.scale_sequences(self._seq3(X2, presliced))
+        self._lr_open(lr, Xs, X2s)
         N, N2 = Xs.shape[0], X2s.shape[0]
         w = self._w()
         Kxx = self._seq_levels(Xs)

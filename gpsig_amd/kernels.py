@@ -8,7 +8,7 @@ every method is numpy-in / numpy-out (host pointers) or torch-CUDA-in / torch-CU
 pointers, asynchronous on the current stream).
 
 float32 inputs are computed in float32 where the float32 kernels are built, else by the float64 kernels and rounded.
-Not built (raise NotImplementedError, never a silent CPU fallback): ``SignatureSpectral`` in low-rank mode; gradients of low-rank mode.  Training (gradients): ``gpsig_amd.autodiff``.
+Not built (raise NotImplementedError, never a silent CPU fallback): ``SignatureSpectral`` in low-rank mode.  Training (gradients): ``gpsig_amd.autodiff``.
 """
 import ctypes as C
 

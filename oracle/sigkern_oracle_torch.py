@@ -355,3 +355,143 @@ class SignatureKernelTorchOracle:
         Kzz = Kzz * w[:, None, None]
         Kzx = Kzx * w[:, None, None]
         return Kzz.sum(dim=0), Kzx.sum(dim=0), Kxx.sum(dim=0)
+
+
+# ---------------------------------------------------------------------------
+# Low-rank mode (gpsig/low_rank_calculations.py, gpsig/signature_algs.py:162-222, gpsig/kernels.py:239-311 and the low_rank
+# branches of K / K_tens / K_tens_vs_seq / K_tens_n_seq_covs), differentiable: what TensorFlow's autodiff sees when the
+# reference trains in low-rank mode (benchmarks/models/train_gpsig.py:21).  As in oracle/sigkern_oracle.py the random objects are
+# ARGUMENTS -- here the landmark INDICES into the concatenation of scaled points the reference gathers from (tf.gather at
+# kernels.py:446, :563, :615, :700: gradients flow into the landmarks), the jitter draw of low_rank_calculations.py:52 and one
+# sparse projection per level >= 2 (plain data: r, colptr, i1, i2, val) -- and Q6 applies (scaled inputs; :191 sums P).
+# Test infrastructure: pinned to the NumPy restatement by value in tests/test_grad_core.py.
+# ---------------------------------------------------------------------------
+def apply_sketch(sk, A, B):
+    """out[..., j] = sum_{e in column j} val[e] A[..., i1[e]] B[..., i2[e]]   (low_rank_calculations.py:76-193 given the matrix)."""
+    colptr = [int(v) for v in sk.colptr]
+    i1 = torch.as_tensor([int(v) for v in sk.i1], dtype=torch.long)
+    i2 = torch.as_tensor([int(v) for v in sk.i2], dtype=torch.long)
+    val = torch.as_tensor([float(v) for v in sk.val], dtype=torch.float64)
+    cols = []
+    for j in range(int(sk.r)):
+        e = slice(colptr[j], colptr[j + 1])
+        cols.append((A[..., i1[e]] * B[..., i2[e]] * val[e]).sum(dim=-1))
+    return torch.stack(cols, dim=-1)
+
+
+class LowRankTorchOracle(SignatureKernelTorchOracle):
+    """The low_rank=True branches on top of the exact restatement: the level primitives become products of low-rank factors, the
+    normalisation / weighting code of the base class is what the reference shares between the two modes."""
+
+    def set_draw(self, idx, jitter_diag, sketches):
+        self._idx = torch.as_tensor([int(v) for v in idx], dtype=torch.long)
+        self._jd = torch.as_tensor([float(v) for v in jitter_diag], dtype=torch.float64)
+        self._sk = list(sketches)
+        return self
+
+    def _open(self, *points):
+        pool = torch.cat([p.reshape(-1, p.shape[-1]) for p in points], dim=0)
+        self._S = pool[self._idx]                                                                   # low_rank_calculations.py:47-48
+        W = self._base(self._S, self._S) + torch.diag(self._jd)                                     # :51-52
+        ev, U = torch.linalg.eigh(W)                                                                # :55
+        top = U.detach().abs().argmax(dim=0)                                                        # sign convention of oracle/sigkern_oracle.py:nystrom_whitening
+        sgn = torch.where(U.detach()[top, torch.arange(U.shape[1])] < 0, -1.0, 1.0).to(U.dtype)
+        self._Wh = U * sgn[None, :] / torch.sqrt(ev + JITTER)[None, :]                              # :56-57, :60
+        self._feat = {}
+
+    def _nys(self, pts):
+        return self._base(pts, self._S) @ self._Wh                                                  # :59-61
+
+    def _seq_feat(self, Xs):
+        if id(Xs) not in self._feat:
+            N, L, d = Xs.shape
+            U = self._nys(Xs.reshape(N * L, d)).reshape(N, L, -1)                                   # kernels.py:252-254
+            if self.difference:
+                U = U[:, 1:] - U[:, :-1]                                                            # signature_algs.py:180
+            Phi = [torch.ones((N, 1), dtype=U.dtype), U.sum(dim=1)]                                 # :177, :182
+            P = U
+            for i in range(2, self.num_levels + 1):
+                P = _excumsum(P, 1)                                                                 # :186
+                P = apply_sketch(self._sk[i - 2], U, P)                                             # :188 / :190
+                Phi.append(P.sum(dim=1))                                                            # :191 (Q6)
+            self._feat[id(Xs)] = (Xs, Phi)
+        return self._feat[id(Xs)][1]
+
+    def _tens_feat(self, Zs, increments):
+        if id(Zs) not in self._feat:
+            lt, T, d = Zs.shape[0], Zs.shape[1], Zs.shape[-1]
+            if increments:                                                                          # kernels.py:300-304
+                F = self._nys(Zs.reshape(lt * T * 2, d)).reshape(lt, T, 2, -1)
+                F = F[:, :, 1] - F[:, :, 0]
+            else:
+                F = self._nys(Zs.reshape(lt * T, d)).reshape(lt, T, -1)                             # :306-308
+            Phi, k = [torch.ones((T, 1), dtype=F.dtype)], 0                                         # signature_algs.py:209
+            for i in range(1, self.num_levels + 1):
+                R = F[k]; k += 1
+                for j in range(1, i):
+                    R = apply_sketch(self._sk[j - 1], F[k], R); k += 1                              # :217 / :219
+                Phi.append(R)
+            self._feat[id(Zs)] = (Zs, Phi)
+        return self._feat[id(Zs)][1]
+
+    # level primitives as products of factors (kernels.py:426, :451, :457, :501, :527, :568)
+    def K_seq_levels(self, Xs, X2s=None):
+        P1 = self._seq_feat(Xs)
+        P2 = P1 if X2s is None else self._seq_feat(X2s)
+        return torch.stack([a @ b.T for a, b in zip(P1, P2)], dim=0)
+
+    def K_seq_diag_levels(self, Xs):
+        return torch.stack([torch.square(P).sum(dim=-1) for P in self._seq_feat(Xs)], dim=0)
+
+    def K_tens_levels(self, Zs, increments):
+        return torch.stack([P @ P.T for P in self._tens_feat(Zs, increments)], dim=0)
+
+    def K_tens_vs_seq_levels(self, Zs, Xs, increments):
+        return torch.stack([a @ b.T for a, b in zip(self._tens_feat(Zs, increments), self._seq_feat(Xs))], dim=0)
+
+    # the public surface: gather the landmarks from this evaluation's points, then the shared code.  The base class scales its
+    # inputs itself; scaling is deterministic, so the features are keyed by the tensors it hands to the primitives.
+    def scale_sequences(self, X):
+        key = ("s", id(X))
+        if key not in self._scaled:
+            self._scaled[key] = (X, super().scale_sequences(X))
+        return self._scaled[key][1]
+
+    def scale_tensors(self, Z, increments):
+        key = ("t", id(Z))
+        if key not in self._scaled:
+            self._scaled[key] = (Z, super().scale_tensors(Z, increments))
+        return self._scaled[key][1]
+
+    def _seq3(self, X):
+        key = ("3", id(X))
+        if key not in self._scaled:
+            self._scaled[key] = (X, super()._seq3(X))
+        return self._scaled[key][1]
+
+    def K(self, X, X2=None, return_levels=False):
+        self._scaled = {}
+        pts = [self.scale_sequences(self._seq3(X))] + ([] if X2 is None else [self.scale_sequences(self._seq3(X2))])
+        self._open(*pts)                                                                            # kernels.py:445-446
+        return super().K(X, X2, return_levels)
+
+    def Kdiag(self, X, return_levels=False):
+        self._scaled = {}
+        if not self.normalization:
+            self._open(self.scale_sequences(self._seq3(X)))
+        return super().Kdiag(X, return_levels)
+
+    def K_tens(self, Z, return_levels=False, increments=False):
+        self._scaled = {}
+        self._open(self.scale_tensors(Z, increments))
+        return super().K_tens(Z, return_levels, increments)
+
+    def K_tens_vs_seq(self, Z, X, return_levels=False, increments=False):
+        self._scaled = {}
+        self._open(self.scale_tensors(Z, increments), self.scale_sequences(self._seq3(X)))          # kernels.py:562-563
+        return super().K_tens_vs_seq(Z, X, return_levels, increments)
+
+    def K_tens_n_seq_covs(self, Z, X, full_X_cov=False, increments=False):
+        self._scaled = {}
+        self._open(self.scale_tensors(Z, increments), self.scale_sequences(self._seq3(X)))          # kernels.py:614-615
+        return super().K_tens_n_seq_covs(Z, X, full_X_cov, increments)

@@ -830,3 +830,106 @@ def test_gradients_beyond_64_columns(base, d, num_lags):
                                         num_lags=num_lags, lags=leaf(mod.lags) if num_lags else None, gamma=leaf(mod.gamma) if num_lags else None)
     extra = [(mod.raw_lags, orc.lags, "logistic"), (mod.raw_gamma, orc.gamma, "pos")] if num_lags else []
     _compare_module_with_oracle(mod, orc, d * (num_lags + 1), M, L, extra)
+
+
+@pytest.mark.parametrize("base,sparsity,num_lags,normalization,difference",
+                         [("rbf", "sqrt", 0, True, True), ("rbf", "lin", 1, True, True), ("matern32", "log", 0, False, True),
+                          ("mix", "sqrt", 0, True, False), ("poly", "sqrt", 0, True, True)])
+def test_low_rank_module_gradients(base, sparsity, num_lags, normalization, difference):
+    """Gradients of LOW-RANK mode (kernels.py:239-311 and the low_rank branches of K / K_tens_vs_seq / K_tens_n_seq_covs, trained by
+    the reference's benchmarks): the module's torch-op route -- landmarks gathered from the scaled inputs, whitening through an
+    eigendecomposition, running sums, sparse projections -- against autograd of the checker's restatement given the same draw: values,
+    d/dZ, d/dX (which includes the path through the landmarks), every hyper-parameter.  And the forward values against the HIP
+    library's low-rank kernels fed the same landmarks / jitter / projections (kern.low_rank_state)."""
+    from gpsig_amd import kernels, autodiff
+    d, M, L, N, N2, T, c, r = 3, 3, 9, 8, 5, 4, 7, 6
+    cls = {"rbf": kernels.SignatureRBF, "matern32": kernels.SignatureMatern32, "mix": kernels.SignatureMix, "poly": kernels.SignaturePoly}[base]
+    rng = np.random.default_rng(77)
+    kern = cls(L * d, d, M, normalization=normalization, difference=difference, num_lags=num_lags or None,
+               lengthscales=rng.uniform(0.8, 1.6, d), variances=rng.uniform(0.5, 1.5, M + 1),
+               low_rank=True, num_components=c, rank_bound=r, sparsity=sparsity)
+    kern.sigma = 1.2
+    kern.rng = np.random.default_rng(5)
+    mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
+    leaf = lambda t: None if t is None else t.detach().cpu().clone().requires_grad_(True)
+    orc = OT.LowRankTorchOracle(d, M, base, variances=leaf(mod.variances), sigma=leaf(mod.sigma), lengthscales=leaf(mod.lengthscales),
+                                normalization=normalization, difference=difference, num_lags=num_lags,
+                                lags=leaf(mod.lags) if num_lags else None, gamma=leaf(mod.gamma) if num_lags else None,
+                                p0=leaf(mod.p0), p1=kern._current_base_params()[1])
+    de = d * (num_lags + 1)
+    lt = M * (M + 1) // 2
+    X, X2 = rng.standard_normal((N, L * d)) * 0.5, rng.standard_normal((N2, L * d)) * 0.5
+    dev = torch.device("cuda:0")
+    cu = lambda a: torch.tensor(a, device=dev)
+    for increments in (False, True):
+        Z = rng.standard_normal((lt, T, 2, de) if increments else (lt, T, de)) * 0.5
+        nz = lt * T * (2 if increments else 1)
+        dr_c = mod.draw_low_rank(nz + N * L)            # Kzz / Kzx / Kxx: tensors' points, then the sequences'
+        dr_k = mod.draw_low_rank(N * L)                 # K(X)
+        dr_x = mod.draw_low_rank(N * L + N2 * L)        # K(X, X2)
+        W1, W2, W3 = rng.standard_normal((T, T)), rng.standard_normal((T, N)), rng.standard_normal(N)
+        Wk, Wc = rng.standard_normal((N, N)), rng.standard_normal((N, N2))
+        Zg, Xg = torch.tensor(Z, device=dev, requires_grad=True), torch.tensor(X, device=dev, requires_grad=True)
+        Kzz, Kzx, Kxx = mod.K_tens_n_seq_covs(Zg, Xg, increments=increments, lr=dr_c)
+        Kk, Kc = mod.K(Xg, lr=dr_k), mod.K(Xg, cu(X2), lr=dr_x)
+        loss = (Kzz * cu(W1)).sum() + (Kzx * cu(W2)).sum() + (Kxx * cu(W3)).sum() + (Kk * cu(Wk)).sum() + (Kc * cu(Wc)).sum()
+        mod.zero_grad()
+        loss.backward()
+        Zc, Xc = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+        for t in (orc.variances, orc.sigma, orc.lengthscales, orc.lags, orc.gamma, orc.p0):
+            if t is not None and t.grad is not None:
+                t.grad = None
+        oKzz, oKzx, oKxx = orc.set_draw(dr_c.idx, dr_c.jitter_diag, dr_c.sketches).K_tens_n_seq_covs(Zc, Xc, increments=increments)
+        oKk = orc.set_draw(dr_k.idx, dr_k.jitter_diag, dr_k.sketches).K(Xc)
+        oKc = orc.set_draw(dr_x.idx, dr_x.jitter_diag, dr_x.sketches).K(Xc, torch.tensor(X2))
+        oloss = (oKzz * torch.tensor(W1)).sum() + (oKzx * torch.tensor(W2)).sum() + (oKxx * torch.tensor(W3)).sum() + \
+                (oKk * torch.tensor(Wk)).sum() + (oKc * torch.tensor(Wc)).sum()
+        oloss.backward()
+        for a, b in ((Kzz, oKzz), (Kzx, oKzx), (Kxx, oKxx), (Kk, oKk), (Kc, oKc)):
+            assert rel(a, b) < 1e-8, (increments, rel(a, b))
+        # gradients pass through the eigendecomposition of a c x c Gram whose smallest eigenvalue gaps are ~1e-3: rocSOLVER against LAPACK
+        assert rel(Zg.grad, Zc.grad) < 1e-6 and rel(Xg.grad, Xc.grad) < 1e-6, (rel(Zg.grad, Zc.grad), rel(Xg.grad, Xc.grad))
+        pairs = [(mod.raw_variances, orc.variances, "pos"), (mod.raw_sigma, orc.sigma, "pos"), (mod.raw_lengthscales, orc.lengthscales, "pos")]
+        if num_lags:
+            pairs += [(mod.raw_lags, orc.lags, "logistic"), (mod.raw_gamma, orc.gamma, "pos")]
+        if mod.raw_p0 is not None:
+            pairs.append((mod.raw_p0, orc.p0, "pos"))
+        for raw, con, kind in pairs:
+            rr = raw.detach().cpu()
+            jac = torch.sigmoid(rr) if kind == "pos" else torch.sigmoid(rr) * (1 - torch.sigmoid(rr))
+            assert rel(raw.grad, con.grad * jac) < 1e-6, (kind, raw.grad, con.grad * jac)
+        # the same numbers from the HIP library's low-rank kernels, given the landmarks this draw selects
+        with torch.no_grad():
+            pool = torch.cat([mod.scale_tensors(Zg).reshape(-1, de), mod.scale_sequences(mod._seq3(Xg)).reshape(-1, de)], dim=0)
+            st = kern.low_rank_state(pool[torch.as_tensor(dr_c.idx, device=dev)].cpu().numpy(), dr_c.jitter_diag, dr_c.sketches)
+        hzz, hzx = kern.K_tens(Z, increments=increments, lr_state=st), kern.K_tens_vs_seq(Z, X, increments=increments, lr_state=st)
+        hxx = kern.Kdiag(X, lr_state=st)
+        tol = 1e-7
+        assert rel(hzz, Kzz) < tol and rel(hzx, Kzx) < tol and rel(hxx, Kxx) < tol, (rel(hzz, Kzz), rel(hzx, Kzx), rel(hxx, Kxx))
+    # without lr=: a fresh draw per evaluation, as the reference's graph draws one; and an SVGP step in low-rank mode runs
+    a, b = mod.K(Xg), mod.K(Xg)
+    assert a.shape == (N, N) and not torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
+def test_low_rank_svgp_trains():
+    """The reference's benchmark configuration trains in low-rank mode (benchmarks/models/train_gpsig.py:21): an ELBO step through the
+    low-rank covariances has finite gradients for every parameter and Adam decreases the loss."""
+    from gpsig_amd import kernels, autodiff, models, inducing_variables, likelihoods
+    rng = np.random.default_rng(8)
+    N, L, d, M, T = 40, 12, 2, 3, 6
+    lab = np.repeat([0, 1], N // 2)
+    X = np.cumsum(rng.standard_normal((N, L, d)) * 0.3, axis=1) + lab[:, None, None] * np.linspace(0, 1, L)[None, :, None]
+    kern = kernels.SignatureRBF(L * d, d, M, lengthscales=np.ones(d), low_rank=True, num_components=10, rank_bound=8)
+    kern.rng = np.random.default_rng(3)
+    Z = rng.standard_normal((M * (M + 1) // 2, T, 2, d)) * 0.5
+    feat = inducing_variables.InducingTensors(Z, M, increments=True)
+    m = models.SVGPModule(kern, feat, likelihoods.Bernoulli(), num_data=N, device="cuda:0")
+    Xt = torch.tensor(X.reshape(N, -1), device="cuda:0")
+    Yt = torch.tensor(lab[:, None].astype(np.float64), device="cuda:0")
+    loss = -m.elbo(Xt, Yt)
+    loss.backward()
+    for n_, p_ in m.named_parameters():
+        if p_.requires_grad:
+            assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n_
+    trace = m.fit(Xt, Yt, iterations=30, lr=5e-2)
+    assert np.isfinite(trace).all() and np.mean(trace[-5:]) > np.mean(trace[:5])

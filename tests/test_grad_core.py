@@ -227,3 +227,64 @@ def test_torch_spectral_kernel_equals_numpy_oracle():
             assert np.abs(got.detach().numpy() - want).max() < 1e-13
             got.sum().backward()
             assert bool(torch.isfinite(tA.grad).all())
+
+
+@pytest.mark.parametrize("base", ["rbf", "linear", "matern32"])
+@pytest.mark.parametrize("normalization,difference", [(True, True), (False, False)])
+def test_torch_low_rank_restatement_equals_numpy_restatement(base, normalization, difference):
+    """The differentiable low-rank restatement (landmarks gathered by index from the evaluation's scaled points) against the NumPy
+    one (oracle/sigkern_oracle.py:LowRankOracle, given the landmark VALUES), same jitter draw and projections; and its gradient with
+    respect to the inputs against central differences of itself (which moves the landmarks too, as tf.gather lets TensorFlow do)."""
+    import types
+    rng = np.random.default_rng(12)
+    N, N2, L, d, M, T, c, r = 5, 3, 6, 2, 3, 4, 5, 4
+    X, X2 = rng.standard_normal((N, L * d)) * 0.6, rng.standard_normal((N2, L * d)) * 0.6
+    ls, var = rng.uniform(0.7, 1.5, d), rng.uniform(0.5, 1.5, M + 1)
+    kn = _np_kern(base, d, M, normalization=normalization, difference=difference, lengthscales=ls, variances=var)
+    kn.input_dim = L * d
+    p0, p1 = _bp(base)
+    kt = OT.LowRankTorchOracle(d, M, base, p0=torch.tensor(p0, dtype=torch.float64), p1=p1, normalization=normalization,
+                               difference=difference, lengthscales=ls, variances=var)
+
+    def sketch(k1, k2):
+        nnz = 3 * r
+        col = np.sort(rng.integers(0, r, nnz))
+        colptr = np.concatenate(([0], np.cumsum(np.bincount(col, minlength=r))))
+        return types.SimpleNamespace(k1=k1, k2=k2, r=r, colptr=colptr, i1=rng.integers(0, k1, nnz), i2=rng.integers(0, k2, nnz),
+                                     val=rng.standard_normal(nnz))
+    sks = [sketch(c, c)] + [sketch(c, r) for _ in range(M - 2)]
+    jd = O.JITTER * rng.random(c)
+    tol = 1e-9 if base != "linear" else 1e-5          # rank-deficient landmark Gram: INTEGRATION.md, "conventionally reproducible"
+    Xs, X2s = kn._apply_scaling_and_lags_to_sequences(kn._seq3(X)), kn._apply_scaling_and_lags_to_sequences(kn._seq3(X2))
+    # K(X), K(X, X2)
+    idx = np.sort(rng.choice(N * L, c, replace=False))
+    lo = O.LowRankOracle(kn, Xs.reshape(-1, d)[idx], jd, sks)
+    assert rel(kt.set_draw(idx, jd, sks).K(torch.tensor(X)), lo.K(X)) < tol
+    idx2 = np.sort(rng.choice((N + N2) * L, c, replace=False))
+    lo = O.LowRankOracle(kn, np.concatenate([Xs.reshape(-1, d), X2s.reshape(-1, d)])[idx2], jd, sks)
+    assert rel(kt.set_draw(idx2, jd, sks).K(torch.tensor(X), torch.tensor(X2), return_levels=True), lo.K(X, X2, return_levels=True)) < tol
+    for incr in (False, True):
+        Z = rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d)) * 0.6
+        Zs = kn._scale_Z(Z, incr)
+        pool = np.concatenate([Zs.reshape(-1, d), Xs.reshape(-1, d)])
+        idx3 = np.sort(rng.choice(pool.shape[0], c, replace=False))
+        lo = O.LowRankOracle(kn, pool[idx3], jd, sks)
+        kt.set_draw(idx3, jd, sks)
+        assert rel(kt.K_tens_vs_seq(torch.tensor(Z), torch.tensor(X), increments=incr), lo.K_tens_vs_seq(Z, X, increments=incr)) < tol
+        Kzz, Kzx, Kxx = kt.K_tens_n_seq_covs(torch.tensor(Z), torch.tensor(X), increments=incr)
+        assert rel(Kzx, lo.K_tens_vs_seq(Z, X, increments=incr)) < tol and rel(Kzz, lo.K_tens(Z, increments=incr)) < tol
+        assert rel(Kxx, lo.Kdiag(X)) < tol
+    if base == "linear":
+        return
+    # gradient with respect to X through features AND landmarks: central differences of the restatement itself
+    kt.set_draw(idx, jd, sks)
+    Wm = torch.tensor(rng.standard_normal((N, N)))
+    tX = torch.tensor(X, requires_grad=True)
+    (kt.K(tX) * Wm).sum().backward()
+    g = tX.grad.numpy()
+    for (i, j) in [(0, 0), (2, 5), (4, L * d - 1), (idx[0] // L, (idx[0] % L) * d)]:       # the last one is a landmark's coordinate
+        h = 1e-6
+        Xp, Xm = X.copy(), X.copy()
+        Xp[i, j] += h; Xm[i, j] -= h
+        fd = (float((kt.K(torch.tensor(Xp)) * Wm).sum()) - float((kt.K(torch.tensor(Xm)) * Wm).sum())) / (2 * h)
+        assert abs(fd - g[i, j]) < 1e-5 * max(1.0, np.abs(g).max()), (i, j, fd, g[i, j])
