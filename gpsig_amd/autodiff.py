@@ -12,8 +12,8 @@ gpsig/models.py:40-59).  Here the same role is split in two:
 ``SignatureKernelModule`` holds the hyper-parameters as unconstrained ``torch.nn.Parameter``s with GPflow 1.5.1's transforms
 (``transforms.positive`` = softplus + 1e-6 for variances, sigma, lengthscales, gamma, the base-kernel parameter;
 ``transforms.Logistic`` for lags; kernels.py:65-88) so that an optimiser step means what it means in the reference.
-Exact mode: first- and higher-order algorithms through those kernels.  Low-rank mode (kernels.py:239-311, :424-426, :442-458; trained by
-the reference's benchmarks, benchmarks/models/train_gpsig.py:21): the Nystrom features, their whitening (an eigendecomposition that
+Exact mode: first- and higher-order algorithms through those kernels.  Low-rank mode (kernels.py:239-311, :424-426, :442-458; a training
+option of the reference's benchmark driver, benchmarks/models/train_gpsig.py:21, :58): the Nystrom features, their whitening (an eigendecomposition that
 autograd differentiates, as TensorFlow does: low_rank_calculations.py:50-60), the running sums and the sparse projections are torch
 ops on the GPU (GEMMs, gathers, rocSOLVER), with the landmarks GATHERED from the scaled inputs so that gradients reach them too; sized
 for training batches (a projection materialises (N, L, non-zeros) products).  Computed by the float64 kernels (float32 tensors -- a module after

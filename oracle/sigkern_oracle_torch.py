@@ -360,7 +360,7 @@ class SignatureKernelTorchOracle:
 # ---------------------------------------------------------------------------
 # Low-rank mode (gpsig/low_rank_calculations.py, gpsig/signature_algs.py:162-222, gpsig/kernels.py:239-311 and the low_rank
 # branches of K / K_tens / K_tens_vs_seq / K_tens_n_seq_covs), differentiable: what TensorFlow's autodiff sees when the
-# reference trains in low-rank mode (benchmarks/models/train_gpsig.py:21).  As in oracle/sigkern_oracle.py the random objects are
+# reference trains with low_rank=True (an option of benchmarks/models/train_gpsig.py:21, :58).  As in oracle/sigkern_oracle.py the random objects are
 # ARGUMENTS -- here the landmark INDICES into the concatenation of scaled points the reference gathers from (tf.gather at
 # kernels.py:446, :563, :615, :700: gradients flow into the landmarks), the jitter draw of low_rank_calculations.py:52 and one
 # sparse projection per level >= 2 (plain data: r, colptr, i1, i2, val) -- and Q6 applies (scaled inputs; :191 sums P).

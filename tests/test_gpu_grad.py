@@ -836,8 +836,8 @@ def test_gradients_beyond_64_columns(base, d, num_lags):
                          [("rbf", "sqrt", 0, True, True), ("rbf", "lin", 1, True, True), ("matern32", "log", 0, False, True),
                           ("mix", "sqrt", 0, True, False), ("poly", "sqrt", 0, True, True)])
 def test_low_rank_module_gradients(base, sparsity, num_lags, normalization, difference):
-    """Gradients of LOW-RANK mode (kernels.py:239-311 and the low_rank branches of K / K_tens_vs_seq / K_tens_n_seq_covs, trained by
-    the reference's benchmarks): the module's torch-op route -- landmarks gathered from the scaled inputs, whitening through an
+    """Gradients of LOW-RANK mode (kernels.py:239-311 and the low_rank branches of K / K_tens_vs_seq / K_tens_n_seq_covs, a training option
+    of the reference's benchmark driver): the module's torch-op route -- landmarks gathered from the scaled inputs, whitening through an
     eigendecomposition, running sums, sparse projections -- against autograd of the checker's restatement given the same draw: values,
     d/dZ, d/dX (which includes the path through the landmarks), every hyper-parameter.  And the forward values against the HIP
     library's low-rank kernels fed the same landmarks / jitter / projections (kern.low_rank_state)."""
@@ -912,7 +912,7 @@ def test_low_rank_module_gradients(base, sparsity, num_lags, normalization, diff
 
 
 def test_low_rank_svgp_trains():
-    """The reference's benchmark configuration trains in low-rank mode (benchmarks/models/train_gpsig.py:21): an ELBO step through the
+    """The reference's benchmark driver can train in low-rank mode (benchmarks/models/train_gpsig.py:21, :58): an ELBO step through the
     low-rank covariances has finite gradients for every parameter and Adam decreases the loss."""
     from gpsig_amd import kernels, autodiff, models, inducing_variables, likelihoods
     rng = np.random.default_rng(8)
