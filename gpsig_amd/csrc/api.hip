@@ -666,7 +666,27 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
         return GPSIG_OK;
     };
-    if (N1 > 0) CHK(features(X, N1, L1, phi1));
+    // "sig_features_keep": between the calls of ONE decomposed evaluation (the chunks of a rank's row block: parallel.ShardedGram) the
+    // features of the same sequences under the same parameters are built once.  The caller promises not to write X in between.
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&](const void* ptr, size_t bytes) {
+        const unsigned char* b = static_cast<const unsigned char*>(ptr);
+        for (size_t i = 0; i < bytes; ++i) { key ^= b[i]; key *= 1099511628211ull; }
+    };
+    {
+        const int32_t head[8] = {p->base_kernel, p->dtype, p->num_features, p->num_levels, p->order, p->difference, p->normalization, p->num_lags};
+        mix(head, sizeof(head));
+        mix(&p->sigma, sizeof(double)); mix(&p->jitter, sizeof(double));
+        mix(p->variances, sizeof(double) * (M + 1));
+        if (p->lengthscales) mix(p->lengthscales, sizeof(double) * p->num_features);
+        if (p->num_lags > 0) { mix(p->lags, sizeof(double) * p->num_lags); mix(p->gamma, sizeof(double) * (p->num_lags + 1)); }
+        const int64_t tail[4] = {N1, L1, raw ? 1 : 0, ld};
+        mix(tail, sizeof(tail));
+    }
+    const bool reuse = c->sf_keep && c->sf_valid && c->sf_X == X && c->sf_phi == phi1 && c->sf_key == key;
+    if (N1 > 0 && !reuse) CHK(features(X, N1, L1, phi1));
+    c->sf_valid = c->sf_keep != 0 && N1 > 0;
+    c->sf_X = X; c->sf_phi = phi1; c->sf_key = key;
     if (!sym && N2 > 0) CHK(features(X2, N2, L2, phi2));
     if (NA <= 0 || NB <= 0) { *done = true; return GPSIG_OK; }
     // level sums of the weights: the exact diagonal of the normalised symmetric Gram (kernels.py:430-433: (K_ii + jitter) / (K_ii + jitter))
@@ -1805,6 +1825,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "lr_jacobi")) c->lr_jacobi = value ? 1 : 0;
     else if (!strcmp(name, "sig_features")) c->sig_features = value;
     else if (!strcmp(name, "sig_gemm_dma")) c->sig_gemm_dma = value;
+    else if (!strcmp(name, "sig_features_keep")) { c->sf_keep = value; c->sf_valid = false; }
     else if (!strcmp(name, "keep_reset")) c->keep_reset = value ? 1 : 0;
     else if (!strcmp(name, "pk2")) c->allow_pk2 = value;
     else if (!strcmp(name, "f32_pack")) c->f32_pack = value;

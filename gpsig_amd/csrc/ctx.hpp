@@ -88,6 +88,9 @@ struct gpsig_ctx {
     bool tvs_aux_written = false;    // ... and whether it did (only the tile kernel does)
     int tvs_grad_tile = 1;        // tensor-vs-sequence reverse pass: 1 = the tile kernel (tvs_grad_tile_kernel.hpp) where built, 0 = the round-1 kernels
     int sig_features = -1;        // SignatureLinear Grams as a contraction of explicit level features: -1 where cheaper, 0 never, 1 wherever built
+    int sf_keep = 0;                     // keep the feature matrix between calls ("sig_features_keep")
+    bool sf_valid = false;
+    const void* sf_X = nullptr; const void* sf_phi = nullptr; uint64_t sf_key = 0;
     int sig_gemm_dma = 1;                // the contraction's slabs by LDS-DMA with fragments prefetched across the barrier (0: register-staged form)
     int lr_jacobi = 1;            // gpsig_lr_draw: eigendecomposition of the landmark Gram by the one-workgroup Jacobi kernel (c <= 64), 0: rocSOLVER
     int tvs_zreg = -1;            // tensor-lane gradient: components in registers (1) or LDS (0); -1 = planner's choice

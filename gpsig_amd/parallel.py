@@ -120,6 +120,18 @@ class ShardedGram:
         ctx = self._context()
         b0, b1 = self.bounds[self.rank], self.bounds[self.rank + 1]
         pending = []
+        # the chunks of this block are row-block calls on the same X: SignatureLinear's feature matrix (csrc/sig_feat_kernel.hpp) is
+        # built by the first and kept for the others (7.6 ms per call at N = 32,768 against 18 ms of contraction per chunk on 8 ranks)
+        keep_features = getattr(ctx, "set_option", None)
+        if keep_features is not None:
+            keep_features("sig_features_keep", 1)
+        try:
+            return self._chunks(ctx, p, X, n, L, b0, b1, pending)
+        finally:
+            if keep_features is not None:
+                keep_features("sig_features_keep", 0)
+
+    def _chunks(self, ctx, p, X, n, L, b0, b1, pending):
         for k in range(self.chunks):
             r0 = min(b0 + k * self.chunk_rows, b1)
             r1 = min(r0 + self.chunk_rows, b1)

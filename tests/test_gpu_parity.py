@@ -643,6 +643,32 @@ def test_compact_row_blocks_reassemble_the_symmetric_gram(K, n, world, chunks):
     assert np.isnan(h).sum() == (n // 2 if n % 2 == 0 else 0)      # every owned slot written, the tie slots untouched
     if n <= 128:
         np.testing.assert_array_equal(parallel.symmetrize_compact_reference(np.nan_to_num(h)), full.cpu().numpy())
+    if n >= 4096:
+        # "sig_features_keep": a rank's chunks build SignatureLinear's feature matrix once; same numbers, fewer feature launches; new
+        # sequence values or parameters behind the same pointer are NOT picked up inside the window (the caller's promise) but are after it
+        b0 = g.bounds[3]
+        blocks = lambda: [(b0 + k * g.chunk_rows, b0 + (k + 1) * g.chunk_rows) for k in range(chunks)]
+        ref = half[3 * g.per:4 * g.per].clone()
+        got = torch.full_like(ref, float("nan"))
+        ctx.timing_reset()
+        try:
+            ctx.set_option("sig_features_keep", 1)
+            for k, (r0, r1) in enumerate(blocks()):
+                ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), n, L, r0, r1, C.c_void_p(got[k * g.chunk_rows:].data_ptr()))
+        finally:
+            ctx.set_option("sig_features_keep", 0)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(ref))
+        X.mul_(1.5)                                                  # outside the window: the next call sees the new values
+        r0, r1 = blocks()[0]
+        ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), n, L, r0, r1, C.c_void_p(got.data_ptr()))
+        torch.cuda.synchronize()
+        want = kern.K(X)[r0:r0 + 4]
+        j = torch.arange(W, device="cuda:0")
+        for i in range(4):                                            # row r0 + i owns columns r0 + i - n/2 .. r0 + i
+            cols = (r0 + i - n // 2 + j) % n
+            own = torch.isfinite(got[i])
+            assert torch.equal(got[i][own], want[i][cols][own])
 
 
 def test_full_config4_single_gpu_properties(K):
