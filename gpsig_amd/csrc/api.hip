@@ -612,6 +612,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
                    int return_levels, void* out, bool timed, int x_squared, int64_t row_begin, int64_t row_end, int compact, bool* done) {
     *done = false;
     if (c->sig_features == 0 || p->dtype != GPSIG_F64 || p->base_kernel != GPSIG_BASE_LINEAR || x_squared) return GPSIG_OK;
+    if (c->shard_n > 1) return GPSIG_OK;          // gpsig_set_shard: "entries outside the shard are left untouched" is the pair kernels' contract
     const int M = p->num_levels;
     if (M < 2 || (p->order != 1)) return GPSIG_OK;
     const int d = p->num_features * ((raw ? 0 : p->num_lags) + 1);
@@ -636,17 +637,27 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     const bool symtiles = sym && !rows;
     const int ntiles = symtiles ? nti * (nti + 1) / 2 : nti * ntj;
     const int nslab_all = int((ld + SG_BK - 1) / SG_BK);
-    // Workgroups per tile along the depth: 528 tiles in one piece each would take two rounds of the 512 workgroup slots the chip holds,
-    // the second nearly empty; cut ~146 slabs deep, a launch of any shape is many rounds long and the last one costs little.  The count
-    // is a function of the depth ALONE: the order in which an entry's products are added is then the same whichever tile, row block or
-    // rank computes it, so row blocks (gpsig_kernel_K_symm_rows*) reassemble the one-call Gram bit for bit.
-    int nsplit = (nslab_all + 73) / 146;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 32) nsplit = 32;
+    // Workgroups per tile along the depth.  One piece per tile leaves a launch of a few hundred tiles with a nearly empty last round
+    // (528 tiles on the chip's 512 workgroup slots: two rounds); many pieces cost a partial sum each to write and add (the whole
+    // result once per piece).  The count is a function of the depth and of the TOTAL number of sequences of the Gram alone -- not of
+    // the tile count of this call -- so that the order in which an entry's products are added is the same whichever tile, row block
+    // or rank computes it: row blocks (gpsig_kernel_K_symm_rows*) reassemble the one-call Gram bit for bit.  Aim: ~8,448 workgroups
+    // for the full symmetric problem (16 pieces at N = 4,096), never fewer than 4 pieces (a rank's chunk of a large Gram is a launch
+    // of ~1,000 tiles), pieces of at least 64 slabs.
+    int nsplit;
+    {
+        const int64_t nt_full = (N1 + SG_BM - 1) / SG_BM;
+        const int64_t tiles_full = sym ? nt_full * (nt_full + 1) / 2 : nt_full * ((N2 + SG_BN - 1) / SG_BN);
+        int64_t want = (8448 + tiles_full / 2) / (tiles_full > 0 ? tiles_full : 1);
+        if (want < 4) want = 4;
+        if (want > 32) want = 32;
+        const int64_t by_depth = nslab_all / 64 > 0 ? nslab_all / 64 : 1;
+        nsplit = int(want < by_depth ? want : by_depth);
+    }
     const size_t part_one = sizeof(double) * size_t(NA) * NB;
-    while (nsplit > 1 && part_one * size_t(nsplit) > (size_t(16) << 30)) --nsplit;       // (the exception to the rule above: 16 GiB of partial sums)
+    while (nsplit > 1 && part_one * size_t(nsplit) > (size_t(40) << 30)) --nsplit;       // (the exception to the rule above: 40 GiB of partial sums)
     const size_t feat_bytes = sizeof(double) * size_t(ld) * (size_t(N1) + (sym ? 0 : size_t(N2)));
-    if (feat_bytes + part_one * size_t(nsplit) > (size_t(64) << 30)) return GPSIG_OK;
+    if (feat_bytes + part_one * size_t(nsplit) > (size_t(96) << 30)) return GPSIG_OK;
     const double* w = nullptr;
     if (!raw) CHK(upload_weights(c, p, &w));
     ScaleParams s;
