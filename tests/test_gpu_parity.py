@@ -536,6 +536,17 @@ def test_full_config2_properties(K, base):
     # positive semi-definite up to rounding
     ev = torch.linalg.eigvalsh(G[:1024, :1024])
     assert ev.min().item() > -1e-8
+    if base == "linear":
+        # the two evaluations of the linear kernel -- the contraction of explicit level features on the matrix cores (what ran above)
+        # and the pair recursion on the vector unit -- agree entry by entry at full size
+        from gpsig_amd import _lib
+        ctx = _lib.context(0, torch.cuda.current_stream().cuda_stream)
+        try:
+            ctx.set_option("sig_features", 0)
+            G0 = kern.K(torch.as_tensor(X, device="cuda:0"))
+        finally:
+            ctx.set_option("sig_features", -1)
+        assert float((G - G0).abs().max()) <= 1e-11 * float(G0.abs().max())
 
 
 @pytest.mark.parametrize("base,incr", [("rbf", False), ("rbf", True), ("linear", True)])
