@@ -559,6 +559,10 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
                              "reference_flops_frac": (pairs_launch * f_ref / (per_launch_ms * 1e-3) / 1e12) / alu_peak}},
     }
     if not T:
+        res["config"]["route"] = ("explicit level features + one float64 matrix-core contraction (the linear base kernel has a finite feature space: "
+                                  "K_m(x, y) = <Phi_m(x), Phi_m(y)>, same numbers as the pair recursion to rounding; the recursion itself is the "
+                                  "`c2-linear-lattice` entry of `secondary`)" if mfma else
+                                  "pair recursion: one sweep over the increment lattice per sequence pair, 16 lanes per pair")
         res["config"]["unique_pairs_computed_per_step"] = float(N) * (N + 1) / 2
         res["config"]["note"] = ("a step delivers all N*N Gram entries; symmetry is exploited on chip (each unordered pair is "
                                  "evaluated once and stored twice), as the reference's K(X) contract allows")
