@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "aux_kernels.hpp"
 
 namespace gpsig {
@@ -389,9 +391,16 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramAr
 // step's fragments, and the next slab's first fragments are read right behind the barrier, under 16 MFMAs.  Same summation order as
 // sig_gram_kernel: bit-identical results.
 static __global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGramArgs G) {
-    __shared__ __attribute__((aligned(16))) double As[2][SG_BM * SG_BK];
-    __shared__ __attribute__((aligned(16))) double Bs[2][SG_BN * SG_BK];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (1 KiB unused in front: an LDS-DMA load adds its immediate offset to the LDS address as well as to the global one, so the
+    // destinations below are given minus that offset -- down to 1 KiB below the first buffer)
+    constexpr int SG_GUARD = 8 * SG_BK;
+    __shared__ __attribute__((aligned(16))) double lds_all[SG_GUARD + 2 * SG_BM * SG_BK + 2 * SG_BN * SG_BK];
+    double (*const As)[SG_BM * SG_BK] = reinterpret_cast<double (*)[SG_BM * SG_BK]>(lds_all + SG_GUARD);
+    double (*const Bs)[SG_BN * SG_BK] = reinterpret_cast<double (*)[SG_BN * SG_BK]>(lds_all + SG_GUARD + 2 * SG_BM * SG_BK);
+    // the wavefront's index as a SCALAR: everything that depends on it and on the buffer alone (the LDS-DMA destinations) stays in
+    // the scalar unit -- beside the multiplies every vector instruction costs: 38 of them per slab and wave (pointer increments, LDS
+    // address arithmetic, readfirstlanes) left the matrix pipes idle 7 % of a launch that never waited for memory
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
     const int li = lane & 15, lk = lane >> 4;
     int split, bi, bj;
@@ -400,7 +409,7 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGr
     const int nslab = (G.k_end - G.k_begin + SG_BK - 1) / SG_BK;
     const int s0 = int(int64_t(nslab) * split / G.nsplit), s1 = int(int64_t(nslab) * (split + 1) / G.nsplit);
     const int nsl = s1 - s0;
-    const double* ga[4];
+    const double* ga[4];          // this lane's 16 bytes of the CURRENT slab, piece q; the next slab is 128 bytes on
     const double* gb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                   // piece q of this wave: rows (4 q + wave) 8 .. + 8, lane = (row, slot)
@@ -411,25 +420,35 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGr
         ga[q] = G.A + (ai < G.NA ? ai : 0) * G.lda + G.k_begin + int64_t(s0) * SG_BK + 2 * p;
         gb[q] = G.B + brow_i * G.ldb + G.k_begin + int64_t(s0) * SG_BK + 2 * p;
     }
-    auto dma = [&](int buf) {
+    // slab (current + AHEAD) into buffer BUF; AHEAD is an immediate offset of the load, so the pointers move once per 8 slabs
+    auto dma = [&](auto buf_c, auto ahead_c) {
+        constexpr int BUF = decltype(buf_c)::value, OFF = decltype(ahead_c)::value * SG_BK * 8;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga[q],
-                                             (__attribute__((address_space(3))) void*)(&As[buf][(q * 4 + wave) * 8 * SG_BK]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(&As[BUF][(q * 4 + wave) * 8 * SG_BK] - OFF / 8), 16, OFF, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb[q],
-                                             (__attribute__((address_space(3))) void*)(&Bs[buf][(q * 4 + wave) * 8 * SG_BK]), 16, 0, 0);
-            ga[q] += SG_BK;
-            gb[q] += SG_BK;
+                                             (__attribute__((address_space(3))) void*)(&Bs[BUF][(q * 4 + wave) * 8 * SG_BK] - OFF / 8), 16, OFF, 0);
         }
     };
+    auto advance = [&](int slabs) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ga[q] += slabs * SG_BK; gb[q] += slabs * SG_BK; }
+    };
     const int swz = (lk >> 1) ^ ((li >> 1) & 7);
-    const int arow = (wr * 64 + li) * SG_BK + (lk & 1), brow = (wc * 64 + li) * SG_BK + (lk & 1);
-    auto frag = [&](int buf, int kq, double (&av)[4], double (&bv)[4]) {          // depth step kq of the slab: columns 4 kq + lk
-        const int o = ((2 * kq) ^ swz) << 1;
+    // fragment addresses: row base + 16-byte slot ((2 kq) ^ swz) + the half of it; one register per depth step, the buffer and the
+    // row block (m 16 rows = 2 KiB) are immediate offsets of the read
+    int fo[4];
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) fo[kq] = (((2 * kq) ^ swz) << 1) + (lk & 1) + li * SG_BK;
+    const double* const Aw = &As[0][wr * 64 * SG_BK];
+    const double* const Bw = &Bs[0][wc * 64 * SG_BK];
+    auto frag = [&](auto buf_c, int kq, double (&av)[4], double (&bv)[4]) {          // depth step kq of the slab: columns 4 kq + lk
+        constexpr int BUF = decltype(buf_c)::value;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            av[m] = As[buf][arow + m * 16 * SG_BK + o];
-            bv[m] = Bs[buf][brow + m * 16 * SG_BK + o];
+            av[m] = Aw[BUF * SG_BM * SG_BK + m * 16 * SG_BK + fo[kq]];
+            bv[m] = Bw[BUF * SG_BN * SG_BK + m * 16 * SG_BK + fo[kq]];
         }
     };
     sig_f64x4 acc[4][4];
@@ -438,29 +457,51 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGr
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = sig_f64x4{0.0, 0.0, 0.0, 0.0};
     double fa[2][4], fb[2][4];
-    if (nsl > 0) dma(0);
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    if (nsl > 0) dma(B0{}, B0{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (nsl > 0) frag(0, 0, fa[0], fb[0]);
-    for (int s = 0, buf = 0; s < nsl; ++s, buf ^= 1) {
-        const bool more = s + 1 < nsl;
-        if (more) dma(buf ^ 1);             // the other buffer: every wave's reads of it were complete at the barrier of the previous slab
+    if (nsl > 0) frag(B0{}, 0, fa[0], fb[0]);
+    // one slab out of buffer BUF, the next one (AHEAD slabs behind the pointers) into the other buffer
+    auto slab = [&](auto buf_c, auto ahead_c, bool more) {
+        constexpr int BUF = decltype(buf_c)::value;
+        using OTHER = std::integral_constant<int, BUF ^ 1>;
+        if (more) dma(OTHER{}, ahead_c);          // the other buffer: every wave's reads of it were complete at the barrier of the previous slab
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
             const int cur = kq & 1, nxt = cur ^ 1;
             if (kq < 3) {
-                frag(buf, kq + 1, fa[nxt], fb[nxt]);
+                frag(buf_c, kq + 1, fa[nxt], fb[nxt]);
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of the next slab have landed
                 __syncthreads();                                        // ... and everybody else's; all reads of this slab are done
-                if (more) frag(buf ^ 1, 0, fa[nxt], fb[nxt]);
+                if (more) frag(OTHER{}, 0, fa[nxt], fb[nxt]);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[cur][m], fb[cur][n], acc[m][n], 0, 0, 0);
         }
+    };
+    int s = 0;
+    for (; s + 8 <= nsl; s += 8) {               // eight slabs per pointer move: the buffer of each is a compile-time constant
+        slab(B0{}, std::integral_constant<int, 1>{}, true);
+        slab(B1{}, std::integral_constant<int, 2>{}, true);
+        slab(B0{}, std::integral_constant<int, 3>{}, true);
+        slab(B1{}, std::integral_constant<int, 4>{}, true);
+        slab(B0{}, std::integral_constant<int, 5>{}, true);
+        slab(B1{}, std::integral_constant<int, 6>{}, true);
+        slab(B0{}, std::integral_constant<int, 7>{}, true);
+        slab(B1{}, std::integral_constant<int, 8>{}, s + 8 < nsl);
+        advance(8);
     }
+    for (; s + 2 <= nsl; s += 2) {               // (s is even here)
+        slab(B0{}, std::integral_constant<int, 1>{}, true);
+        slab(B1{}, std::integral_constant<int, 2>{}, s + 2 < nsl);
+        advance(2);
+    }
+    if (s < nsl) slab(B0{}, std::integral_constant<int, 1>{}, false);
     double* const P = G.part + int64_t(split) * G.NA * G.NB;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
