@@ -426,7 +426,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     if clock:
         clock["timed_region_ms"] = dt * 1e3
     kernel_ms, launches, _ = ctx.timing_get()      # HIP events around the dominant kernel, on the stream it was launched on
-    timed_kernel, mfma_flops = ctx.timing_info()   # "sig_gram_kernel" + its matrix-core flops when the feature contraction ran
+    timed_kernel, mfma_flops = ctx.timing_info()   # "sig_gram_dma_kernel" + its matrix-core flops when the feature contraction ran
     ctx.set_option("sig_features", -1)
 
     if world > 1:
@@ -472,7 +472,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
         bound = "valu-latency"
         binding = "float32 dependent-instruction latency at the kernel's wavefronts per SIMD (DESIGN.md section 2.4)"
     mfma = None
-    if timed_kernel == "sig_gram_kernel":
+    if timed_kernel in ("sig_gram_kernel", "sig_gram_dma_kernel"):
         fl_launch = mfma_flops / max(launches, 1)
         F = sum(D ** m for m in range(1, M + 1))
         ld = (F + 1 + 15) // 16 * 16
@@ -493,7 +493,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
         alu_peak = FP64_MATRIX_PEAK_TFLOPS
         alu_frac = tf / alu_peak
         f_exec = fl_launch / evaluated_launch
-    kernel_name = ("sig_gram_kernel (feature contraction on the float64 matrix cores)" if mfma else
+    kernel_name = (timed_kernel + " (feature contraction on the float64 matrix cores)" if mfma else
                    "tvs_tile_kernel (tensor-vs-sequence chains)" if T else
                    ("seq_pk2_kernel (pair recursion, two sequences per pair group)" if (w["dtype"] == "f32" and base == "rbf")
                     else "seq_gram_kernel (pair recursion)"))

@@ -31,7 +31,7 @@ int tvs_tile_width(int d);
 bool seq_pk2_select(int rows, int d, int M, int* G, int* C, int* D);
 typedef hipError_t (*SigFeatLaunchFn)(const SigFeatArgs&, unsigned, size_t, hipStream_t);
 SigFeatLaunchFn sig_feat_lookup(int d, int M);
-hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream, int dma);
+hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream, int dma, int* used_dma);
 hipError_t sig_reduce_launch(const SigReduceArgs& R, hipStream_t stream);
 bool solver_dsyevd(void** handle_slot, hipStream_t stream, int n, double* A, double* ev, double* work, int* info, std::string* err);
 void solver_release(void* handle);
@@ -294,6 +294,7 @@ int scale_params(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling, ScaleP
     CHK(ensure(c, B_LS, sizeof(double) * n, &d));
     if (!(c->ls_base == d && c->last_ls.size() == n && memcmp(c->last_ls.data(), p->lengthscales, sizeof(double) * n) == 0)) {
         CHK(no_capture(c, "the lengthscales of a wide state space changed and have to be uploaded"));
+        ++c->alloc_gen;                  // a recorded graph read the old contents of this buffer: its replays are refused from here on
         c->ls_base = nullptr;
         c->last_ls.assign(p->lengthscales, p->lengthscales + n);
         HIPCHK(c, hipMemcpyAsync(d, c->last_ls.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
@@ -321,6 +322,7 @@ int spectral_table(gpsig_ctx* c, const gpsig_params* p, const double** dev) {
     CHK(ensure(c, B_SPEC, sizeof(double) * h.size(), &dp));
     if (!(c->spec_base == dp && c->last_spec == h)) {       // unchanged parameters: the device copy is still right (as the level weights)
         CHK(no_capture(c, "the spectral kernel's table changed"));
+        ++c->alloc_gen;                  // a recorded graph read the old contents of this buffer: its replays are refused from here on
         c->spec_base = nullptr;
         HIPCHK(c, hipMemcpyAsync(dp, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
         CHK(host_sync(c));
@@ -541,6 +543,7 @@ int lr_upload(gpsig_ctx* c, const gpsig_params* p, const gpsig_lowrank* lr, int 
     }
     if (!cached) {
         CHK(no_capture(c, "the low-rank objects changed and have to be uploaded"));
+        ++c->alloc_gen;                  // a recorded graph read the old contents of this buffer: its replays are refused from here on
         c->lr_hash = 0;
         HIPCHK(c, hipMemcpyAsync(dbase, h.data(), o, hipMemcpyHostToDevice, c->stream));
         CHK(host_sync(c));                       // h goes out of scope
@@ -575,6 +578,7 @@ int lr_level_offsets(gpsig_ctx* c, int M, int cc, int r, const int32_t** dev_off
     CHK(ensure(c, B_LR1, sizeof(int32_t) * off.size(), &d));
     if (!(c->lr_off_base == d && c->lr_off_key[0] == M && c->lr_off_key[1] == cc && c->lr_off_key[2] == r)) {     // (M, c, r) define them
         CHK(no_capture(c, "the low-rank level offsets have to be uploaded"));
+        ++c->alloc_gen;                  // a recorded graph read the old contents of this buffer: its replays are refused from here on
         c->lr_off_base = nullptr;
         HIPCHK(c, hipMemcpyAsync(d, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice, c->stream));
         CHK(host_sync(c));
@@ -728,12 +732,13 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         bool on = false;
         if (timed) CHK(timing_begin_any(c, &e0, &e1, &on));
         // the LDS-DMA form reads whole slabs: only where the columns behind k_end are the zero padding of the feature rows
-        HIPCHK(c, sig_gram_launch(G, ntiles, c->stream, (c->sig_gemm_dma && !return_levels) ? 1 : 0));
+        int used_dma = 0;
+        HIPCHK(c, sig_gram_launch(G, ntiles, c->stream, (c->sig_gemm_dma && !return_levels) ? 1 : 0, &used_dma));
         if (on) {
             HIPCHK(c, hipEventRecord(e1, c->stream));
             c->t_launches += 1;
             c->t_pairs += NA * NB;
-            c->t_kernel = "sig_gram_kernel";
+            c->t_kernel = used_dma ? "sig_gram_dma_kernel" : "sig_gram_kernel";
             c->t_flops += 2.0 * double(ntiles) * SG_BM * SG_BN * double(nslab) * SG_BK;
         }
         SigReduceArgs R;

@@ -43,12 +43,14 @@ SigFeatLaunchFn sig_feat_lookup(int d, int M) {
     }
 }
 
-hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream, int dma) {
+hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream, int dma, int* used_dma) {
+    if (used_dma) *used_dma = 0;
     const bool aligned = (G.lda % 2) == 0 && (G.ldb % 2) == 0 && (reinterpret_cast<uintptr_t>(G.A) % 16) == 0 &&
                          (reinterpret_cast<uintptr_t>(G.B) % 16) == 0;
     const int ke_pad = (G.k_end + SG_BK - 1) / SG_BK * SG_BK;
     if (dma && aligned && G.k_begin % SG_BK == 0 && ke_pad <= G.lda && ke_pad <= G.ldb) {     // whole slabs, zeros behind k_end
         hipLaunchKernelGGL(sig_gram_dma_kernel, dim3(unsigned(ntiles) * unsigned(G.nsplit)), dim3(256), 0, stream, G);
+        if (used_dma) *used_dma = 1;
         return hipGetLastError();
     }
     const bool vec = (G.k_begin % 2) == 0 && (G.lda % 2) == 0 && (G.ldb % 2) == 0 && (reinterpret_cast<uintptr_t>(G.A) % 16) == 0 &&

@@ -142,7 +142,7 @@ int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
  * launches after a reset; none inside a graph capture). */
 int gpsig_timing_reset(gpsig_ctx* ctx);
 int gpsig_timing_get(gpsig_ctx* ctx, double* kernel_ms, int64_t* launches, int64_t* pairs);
-/* What the timed launches were: *kernel = "sig_gram_kernel" when they were the matrix-core contraction of the explicit signature
+/* What the timed launches were: *kernel = "sig_gram_dma_kernel" (or "sig_gram_kernel", its register-staged form) when they were the matrix-core contraction of the explicit signature
  * features (option "sig_features"), NULL for the pair recursion / chain kernels; *flops = the floating-point operations those
  * launches executed on the matrix cores (whole tiles, padded depth), 0 otherwise. */
 int gpsig_timing_info(gpsig_ctx* ctx, const char** kernel, double* flops);
@@ -247,7 +247,11 @@ int gpsig_kernel_K_seq_n_seq_covs(gpsig_ctx* ctx, const gpsig_params* p, const v
  *              (low_rank_calculations.py:50-60);
  *   sketches   one per level 2..M: the projection of low_rank_calculations.py:104-193 stored by output column,
  *              out[j] = sum_{e in [colptr[j], colptr[j+1])} val[e] * A[i1[e]] * B[i2[e]].
- * Factor matrices Phi are (rows, F), F = 1 + c + (M-1) r, level blocks [1 | c | r | ... | r]. */
+ * Factor matrices Phi are (rows, F), F = 1 + c + (M-1) r, level blocks [1 | c | r | ... | r].
+ * Host-side objects are uploaded once and recognised on later calls by a 64-bit FNV-1a hash of their dimensions and contents (an
+ * evaluation hashes ~100 KB instead of uploading it); the parameter tables of the spectral kernel, wide lengthscales and the level
+ * offsets are compared in full.  A recorded graph (gpsig_graph_*) reads these device copies: a later eager call on the same ctx
+ * with other objects rewrites them in place, and replays of the earlier recording are refused. */
 typedef struct gpsig_sketch {
     int32_t k1, k2, r, nnz;
     const int32_t* colptr;   /* r + 1 */

@@ -67,7 +67,7 @@ def test_default_line_carries_the_measurement():
     assert rf["issue_frac"] is None and rf["stream_frac"] > 0
     assert 1.0 < line["clock_ghz"] < 2.6
     assert rf["traffic"] and rf["traffic_source"]["how"].startswith("measured by this run")
-    assert "sig_gram_kernel" in rf["traffic_source"]["kernel"]
+    assert "sig_gram_dma_kernel" in rf["traffic_source"]["kernel"]
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     names = [s["name"] for s in line["secondary"]]
     assert names == ["c2-linear-lattice", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf"]

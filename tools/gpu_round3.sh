@@ -36,3 +36,4 @@ done
 for cfg in "c3 --verify" "c2 --verify"; do timeout 600 python tools/bench_lr.py --config $cfg 2>/dev/null >> $O/bench_lowrank.jsonl; done
 timeout 600 python tools/bench_grad.py > $O/bench_grad.txt 2>&1
 timeout 300 python tools/bench_host_e2e.py > $O/bench_host_e2e.txt 2>&1
+timeout 600 python tools/bench_rank_share.py > $O/bench_rank_share.txt 2>&1
