@@ -3,12 +3,15 @@ GPU of this box: the `chunks` row-block calls of rank `--rank` (gpsig_kernel_K_s
 matrix between them.  No collective runs here; it is the compute share the scaling curve is made of."""
 import argparse
 import ctypes as C
+import os
+import sys
 import time
 
 import numpy as np
 import torch
 
-from gpsig_amd import _lib, kernels, parallel
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpsig_amd import _lib, kernels, parallel  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=32768)
