@@ -99,3 +99,26 @@ def test_recordings_release_their_context(env):
     import gc
     gc.collect()
     assert len(_lib._contexts) <= before + 1
+
+
+def test_replay_of_the_feature_contraction(env):
+    """SignatureLinear's Gram through the matrix-core contraction of explicit level features (three kernels, no host step once its
+    scratch exists) records and replays like the pair recursion."""
+    torch, K, dev = env
+    rng = np.random.default_rng(6)
+    N, N2, L, d, M = 200, 150, 12, 3, 4               # 20,100 / 30,000 pairs: the planner's feature route
+    kern = K.SignatureLinear(L * d, d, M, lengthscales=[0.8, 1.1, 1.3])
+    X = torch.tensor(rng.standard_normal((N, L * d)) * 0.4, device=dev)
+    X2 = torch.tensor(rng.standard_normal((N2, L * d)) * 0.4, device=dev)
+    g1, g2 = kern.graphed("K", X), kern.graphed("K", X, X2)
+    from gpsig_amd import _lib
+    ctx = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
+    try:                                                 # what ran is the contraction: the recursion gives other last digits
+        ctx.set_option("sig_features", 0)
+        lattice = kern.K(X)
+    finally:
+        ctx.set_option("sig_features", -1)
+    assert not torch.equal(g1.out, lattice) and float((g1.out - lattice).abs().max()) < 1e-12 * float(lattice.abs().max())
+    X.copy_(torch.tensor(rng.standard_normal((N, L * d)) * 0.4, device=dev))
+    a, b = g1.replay().clone(), g2.replay().clone()
+    assert torch.equal(a, kern.K(X)) and torch.equal(b, kern.K(X, X2))
