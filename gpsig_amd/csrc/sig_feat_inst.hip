@@ -7,6 +7,7 @@ typedef hipError_t (*SigFeatLaunchFn)(const SigFeatArgs&, unsigned, size_t, hipS
 template <int D, int M>
 static hipError_t sig_feat_launch(const SigFeatArgs& A, unsigned grid, size_t lds, hipStream_t stream) {
     auto kern = sig_features_kernel<D, M>;
+    if constexpr (sig_siblings(D, M)) kern = sig_features_sib_kernel<D, M>;      // sibling parents per thread: fewer multiply-adds
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;

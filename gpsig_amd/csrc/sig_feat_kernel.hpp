@@ -215,9 +215,150 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const S
     }
 }
 
+// The same features for shapes with D^(M-2) threads (d = 8: M = 4, 5 -- the headline): a thread's D parents are SIBLINGS (level M-1
+// entries t D .. t D + D-1), so it holds ONE entry of level M-2 (entry t: nobody else does), one of each lower level (shared with the
+// D^(k-1) threads below the same entry) and no redundant copies of level M-1: D^2 + D + (M-2) multiply-adds per step instead of
+// D (D + M - 1), 75 instead of 96 at d = 8, M = 5, and a parent's component of the increment is a compile-time lane of the row
+// register.  Within a level the features are stored in whatever order makes the stores whole lines (the contraction only needs both
+// of its operands in the same order, and levels in their places): level M as (child pair, thread), level M-1 as (sibling, thread).
+constexpr bool sig_siblings(int d, int M) { return M >= 3 && sig_threads(d, M) == sig_ipow(d, M - 2); }
+
+template <int D, int M>
+__global__ __launch_bounds__(sig_threads(D, M)) void sig_features_sib_kernel(const SigFeatArgs A) {
+    constexpr int T = sig_threads(D, M);
+    static_assert(T == sig_ipow(D, M - 2) && M >= 3 && D <= 64, "one level M-2 entry per thread");
+    constexpr int NW = (T + 63) / 64;
+    constexpr int NANC = M - 2;                                         // a[k], k = 1 .. M-2: level M-1-k, entry t / D^(k-1)
+    constexpr int S = 64 / D;
+    extern __shared__ double sf_sm[];
+    double* const dx = sf_sm;                       // R x D increments of this sequence, then zeros up to (L + S) x D + 64
+    double* const red = dx + (size_t(A.L) + S) * D + 64;       // NW x (M + 1) partial sums
+    __shared__ double norms[M + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = A.difference ? A.L - 1 : A.L;
+    int comp[NANC + 1];
+    bool own[NANC + 1];
+#pragma unroll
+    for (int k = 1; k <= NANC; ++k) {
+        comp[k] = (tid / sig_ipow(D, k - 1)) % D;
+        own[k] = tid % sig_ipow(D, k - 1) == 0;
+    }
+    auto opaque = [](int i) { asm volatile("" : "+v"(i)); return i; };
+    for (int64_t n = blockIdx.x; n < A.N; n += gridDim.x) {
+        const double* Xn = A.X + n * int64_t(A.L) * A.P.d_in;
+        __syncthreads();                            // the previous sequence's increments are no longer read
+        for (int e = tid; e < (A.L + S) * D + 64; e += T) {
+            const int a = e / D, f = e - a * D;
+            dx[e] = a >= R ? 0.0 : A.difference ? scaled_point<double>(Xn, A.L, a + 1, f, A.P) - scaled_point<double>(Xn, A.L, a, f, A.P)
+                                 : scaled_point<double>(Xn, A.L, a, f, A.P);
+        }
+        double top[D][D], par[D], anc[NANC + 1];
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+            par[q] = 0.0;
+#pragma unroll
+            for (int f = 0; f < D; ++f) top[q][f] = 0.0;
+        }
+#pragma unroll
+        for (int k = 1; k <= NANC; ++k) anc[k] = 0.0;
+        __syncthreads();
+        for (int a0 = 0; a0 < R; a0 += S) {
+            const double rows = dx[a0 * D + lane];                  // S rows of increments per wavefront register (zeros past the last)
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                const double* dxa = dx + (a0 + i) * D;
+                double d_[D], dc[NANC + 1];
+#pragma unroll
+                for (int f = 0; f < D; ++f) {
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(rows), i * D + f);
+                    const int hi = __builtin_amdgcn_readlane(__double2hiint(rows), i * D + f);
+                    d_[f] = __hiloint2double(hi, lo);
+                }
+#pragma unroll
+                for (int k = 1; k <= NANC; ++k) dc[k] = dxa[opaque(comp[k])];
+                // every level from the OLD value of the level below it: top, parents, then the ancestors from the highest down
+#pragma unroll
+                for (int q = 0; q < D; ++q)
+#pragma unroll
+                    for (int f = 0; f < D; ++f) top[q][f] = fma(par[q], d_[f], top[q][f]);
+#pragma unroll
+                for (int q = 0; q < D; ++q) par[q] = fma(anc[1], d_[q], par[q]);
+#pragma unroll
+                for (int k = 1; k < NANC; ++k) anc[k] = fma(anc[k + 1], dc[k], anc[k]);
+                anc[NANC] += dc[NANC];
+            }
+        }
+        // level norms |Phi_m|^2 (= K_m(x, x)), all levels in one pass
+        {
+            double sq[M + 1];
+#pragma unroll
+            for (int m = 1; m <= M; ++m) sq[m] = 0.0;
+#pragma unroll
+            for (int q = 0; q < D; ++q) {
+                sq[M - 1] = fma(par[q], par[q], sq[M - 1]);
+#pragma unroll
+                for (int f = 0; f < D; ++f) sq[M] = fma(top[q][f], top[q][f], sq[M]);
+            }
+#pragma unroll
+            for (int k = 1; k <= NANC; ++k)
+                if (own[k]) sq[M - 1 - k] = anc[k] * anc[k];
+#pragma unroll
+            for (int m = 1; m <= M; ++m) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sq[m] += __shfl_xor(sq[m], o, 64);
+                if (lane == 0) red[wave * (M + 1) + m] = sq[m];
+            }
+            __syncthreads();
+            if (tid >= 1 && tid <= M) {
+                double t = 0.0;
+                for (int k2 = 0; k2 < NW; ++k2) t += red[k2 * (M + 1) + tid];
+                norms[tid] = t;
+            }
+            __syncthreads();
+        }
+        double* out = A.Phi + n * A.ld;
+        auto scale_of = [&](int m) {
+            const double w = A.w ? A.w[m] : 1.0;
+            const double nm = m == 0 ? 1.0 : norms[m];
+            return A.normalize ? sqrt(w / (nm + A.jitter)) : sqrt(w);
+        };
+        int off = 0;
+#pragma unroll
+        for (int m = 1; m <= M - 2; ++m) {                       // levels 1 .. M-2 from the ancestors' owners
+            const int k = M - 1 - m;
+            if (own[k]) out[off + tid / sig_ipow(D, k - 1)] = scale_of(m) * anc[k];
+            off += sig_ipow(D, m);
+        }
+        {
+            const double sc = scale_of(M - 1);                   // level M-1: (sibling, thread)
+#pragma unroll
+            for (int q = 0; q < D; ++q) out[off + q * T + tid] = sc * par[q];
+            off += sig_ipow(D, M - 1);
+        }
+        {
+            const double sc = scale_of(M);                       // level M: (parent, child pair, thread), 16 bytes per lane
+            if constexpr (D % 2 == 0) {
+                double2* o2 = reinterpret_cast<double2*>(out + off);
+#pragma unroll
+                for (int q = 0; q < D; ++q)
+#pragma unroll
+                    for (int f = 0; f < D; f += 2) o2[(q * (D / 2) + f / 2) * T + tid] = double2{sc * top[q][f], sc * top[q][f + 1]};
+            } else {
+#pragma unroll
+                for (int q = 0; q < D; ++q)
+#pragma unroll
+                    for (int f = 0; f < D; ++f) out[off + (q * D + f) * T + tid] = sc * top[q][f];
+            }
+            off += sig_ipow(D, M);
+        }
+        for (int64_t e = off + tid; e < A.ld; e += T) out[e] = e == off ? scale_of(0) : 0.0;      // level 0 == 1 (signature_algs.py:20)
+        if (A.dlev && tid <= M) A.dlev[n * (M + 1) + tid] = tid == 0 ? 1.0 : norms[tid];
+    }
+}
+
 inline size_t sig_features_lds_bytes(int d, int M, int L) {
     (void)M;
-    return sizeof(double) * ((size_t(L) + (d <= 64 ? 64 / d : 1)) * d + 64 + 16);
+    return sizeof(double) * ((size_t(L) + (d <= 64 ? 64 / d : 1)) * d + 64 + 64);
 }
 
 // ---- C = A B^T, float64 matrix cores, depth split over workgroups ----------------------------------------------------------------
