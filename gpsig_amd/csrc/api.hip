@@ -724,6 +724,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         G.NA = NA; G.NB = NB; G.lda = ld; G.ldb = ld;
         G.b_off = rows ? ((row_begin - H) % N1 + N1) % N1 : 0; G.b_mod = sym ? N1 : N2;
         G.k_begin = kb; G.k_end = ke;
+        G.band = (rows && NA + H <= N1) ? H : 0;      // column c of the block is sequence row_begin - H + c (no wrap inside the block): row i owns c in [i, i + H]
         int ns = nsplit;
         const int nslab = (ke - kb + SG_BK - 1) / SG_BK;
         if (ns > nslab) ns = nslab < 1 ? 1 : nslab;

@@ -374,6 +374,7 @@ struct SigGramArgs {
     int symmetric;                        // A == B, NA == NB, b_off == 0: tiles (bi <= bj) only
     int ntj;                              // tile columns
     double* part;                         // (nsplit, NA, NB) partial sums
+    int64_t band;                         // > 0 (row blocks of a symmetric Gram): row i owns columns i .. i + band only -- tiles outside are skipped
 };
 
 // Which depth piece and which tile this workgroup computes.
@@ -437,6 +438,7 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramAr
     int split, bi, bj;
     sig_tile_of(G, split, bi, bj);
     const int64_t tile_i = int64_t(bi) * SG_BM, tile_j = int64_t(bj) * SG_BN;
+    if (G.band > 0 && (tile_j + SG_BN - 1 < tile_i || tile_j > tile_i + SG_BM - 1 + G.band)) return;      // nothing of this tile is owned
     // depth chunk of this workgroup, in whole slabs
     const int nslab = (G.k_end - G.k_begin + SG_BK - 1) / SG_BK;
     const int s0 = int(int64_t(nslab) * split / G.nsplit), s1 = int(int64_t(nslab) * (split + 1) / G.nsplit);
@@ -547,6 +549,7 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGr
     int split, bi, bj;
     sig_tile_of(G, split, bi, bj);
     const int64_t tile_i = int64_t(bi) * SG_BM, tile_j = int64_t(bj) * SG_BN;
+    if (G.band > 0 && (tile_j + SG_BN - 1 < tile_i || tile_j > tile_i + SG_BM - 1 + G.band)) return;      // nothing of this tile is owned
     const int nslab = (G.k_end - G.k_begin + SG_BK - 1) / SG_BK;
     const int s0 = int(int64_t(nslab) * split / G.nsplit), s1 = int(int64_t(nslab) * (split + 1) / G.nsplit);
     const int nsl = s1 - s0;
@@ -704,7 +707,6 @@ static __global__ void sig_gram_reduce_kernel(const SigReduceArgs R) {
         int64_t src = e;
         if (R.mode == 1 && (i / SG_BM) > (j / SG_BN)) src = j * R.NB + i;          // the tile that was computed is the transposed one
         double s = 0.0;
-        for (int k = 0; k < R.nsplit; ++k) s += R.part[int64_t(k) * stride + src];
         if (R.mode == 2) {
             const int64_t seq_j = R.r0 + i;
             int64_t seq_i = R.c0 + j;
@@ -713,12 +715,14 @@ static __global__ void sig_gram_reduce_kernel(const SigReduceArgs R) {
             int64_t dlt = seq_j - seq_i;
             if (dlt < 0) dlt += R.N;
             const bool own = dlt < H || (dlt == H && ((R.N & 1) || seq_i < seq_j));
-            if (!own) continue;
+            if (!own) continue;           // (tiles without an owned entry were not computed: SigGramArgs::band)
+            for (int k = 0; k < R.nsplit; ++k) s += R.part[int64_t(k) * stride + src];
             if (dlt == 0 && R.diag_set) s = R.diag_value;
             if (R.compact) R.out[i * (H + 1) + H - dlt] = s;
             else R.out[i * R.N + seq_i] = s;
             continue;
         }
+        for (int k = 0; k < R.nsplit; ++k) s += R.part[int64_t(k) * stride + src];
         if (R.mode == 1 && i == j && R.diag_set) s = R.diag_value;
         R.out[i * R.so_i + j * R.so_j] = s;
     }
