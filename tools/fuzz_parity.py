@@ -34,6 +34,9 @@ def main():
         lags = int(rng.choice([0, 0, 0, 1, 2])) if base != "poly" else 0
         L1, L2 = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 130])), int(rng.choice([1, 2, 5, 17, 32, 65, 90]))
         N1, N2 = int(rng.integers(1, 40)), int(rng.integers(1, 20))
+        if base == "linear" and rng.integers(0, 3) == 0:          # sizes that cross the contraction's 128-wide tiles and its depth pieces
+            N1, N2 = int(rng.choice([127, 129, 200, 300])), int(rng.choice([1, 64, 130, 260]))
+            L1, L2 = min(L1, 33), min(L2, 32)
         norm, diff = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) > 0)
         f32 = bool(rng.integers(0, 5) == 0)
         if (L1 == 1 or L2 == 1) and diff:
@@ -57,7 +60,10 @@ def main():
             # the packed float32 kernels with one or four waves per ring, for the linear family too
             opts = dict(tvs_tile=int(rng.choice([-1, 1])), f32_waves=int(rng.choice([0, 1, 4])), pk2=int(rng.choice([1, 2])),
                         diag_own=int(rng.choice([1, 1, 0])), tens_tile=int(rng.choice([1, 1, 0])), lr_fused=int(rng.choice([1, 1, 0])),
-                        lr_gemm=int(rng.choice([1, 1, 0])))
+                        lr_gemm=int(rng.choice([1, 1, 0])),
+                        # round 3: SignatureLinear's Gram as a contraction of explicit level features wherever it is built (1), by the
+                        # planner's choice (-1), never (0); its two contraction kernels
+                        sig_features=int(rng.choice([1, 1, -1, 0])), sig_gemm_dma=int(rng.choice([1, 1, 0])))
             for k_, v_ in opts.items():
                 CTX.set_option(k_, v_)
             desc.update(opts)
