@@ -126,3 +126,46 @@ def test_headline_kernel_keeps_three_wavefronts_per_simd(tmp_path):
     m = re.search(r"; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", text[start:], re.S)
     vgprs, scratch, occupancy = (int(g) for g in m.groups())
     assert vgprs <= 168 and scratch == 0 and occupancy >= 3, (vgprs, scratch, occupancy)
+
+
+def test_feature_contraction_loop_carries_no_vector_instruction_but_the_multiplies(tmp_path):
+    """sig_gram_dma_kernel (the headline since round 3): the slab loop holds 64 MFMAs per slab and wave and, besides them, LDS reads,
+    LDS-DMA loads and scalar instructions only -- every vector instruction beside the multiplies takes the issue port the next MFMA
+    needs (38 per slab cost 7 % of the launch).  Two wavefronts per SIMD without scratch; the sibling-parent
+    feature kernel of the headline shape without scratch either.  Read from the compiler's assembly."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "gpsig_amd", "csrc", "sig_feat_inst.hip")
+    out = str(tmp_path / "sig_feat.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+
+    def report(name):
+        start = text.index(name + ":")
+        m = re.search(r"; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", text[start:], re.S)
+        return tuple(int(g) for g in m.groups()), text[start:text.index(".Lfunc_end", start)]
+
+    (vgprs, scratch, occ), body = report("_ZN5gpsigL19sig_gram_dma_kernelENS_11SigGramArgsE")
+    assert vgprs <= 256 and scratch == 0 and occ >= 2, (vgprs, scratch, occ)
+    # the unrolled main loop: the backward branch that spans the most MFMAs
+    lines = body.split("\n")
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    best = None
+    for i, l in enumerate(lines):
+        m = re.search(r"s_cbranch\w+\s+(\.LBB\d+_\d+)", l)
+        if m and labels.get(m.group(1), 1 << 30) < i:
+            loop = [x.split()[0] for x in lines[labels[m.group(1)]:i] if x.strip() and not x.strip().startswith((".", ";")) and not x.strip().endswith(":")]
+            n = sum(op.startswith("v_mfma") for op in loop)
+            if n == 8 * 64:                                            # eight slabs of 64 MFMAs per pointer move
+                best = (n, loop)
+    assert best is not None, "the eight-slab loop of sig_gram_dma_kernel was not found"
+    n_mfma, loop = best
+    other_valu = [op for op in loop if op.startswith("v_") and not op.startswith("v_mfma")]
+    assert len(other_valu) <= 24, sorted(set(other_valu))              # the pointer moves (16 v_lshl_add_u64 per eight slabs)
+    (vgprs, scratch, occ), _ = report("_ZN5gpsig23sig_features_sib_kernelILi8ELi5EEEvNS_11SigFeatArgsE")
+    assert scratch == 0 and occ >= 2, (vgprs, scratch, occ)
