@@ -618,7 +618,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     if (c->sig_features == 0 || p->dtype != GPSIG_F64 || p->base_kernel != GPSIG_BASE_LINEAR || x_squared) return GPSIG_OK;
     if (c->shard_n > 1) return GPSIG_OK;          // gpsig_set_shard: "entries outside the shard are left untouched" is the pair kernels' contract
     const int M = p->num_levels;
-    if (M < 2 || (p->order != 1)) return GPSIG_OK;
+    if (M < 2 || p->order < 1 || p->order > M) return GPSIG_OK;
     const int d = p->num_features * ((raw ? 0 : p->num_lags) + 1);
     SigFeatLaunchFn ffn = sig_feat_lookup(d, M);
     if (!ffn) return GPSIG_OK;
@@ -627,7 +627,8 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     const int r1 = p->difference ? L1 - 1 : L1, r2 = p->difference ? L2 - 1 : L2;
     if (r1 < 1 || r2 < 1) return GPSIG_OK;
     if (c->sig_features < 0) {
-        const double lattice = double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0), feat = 2.0 * double(F);
+        // (the higher-order pair kernels carry order^2 grids per level: 34 to 150 times the first order's time at configs[1]'s size)
+        const double lattice = double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0) * (p->order > 1 ? 8.0 : 1.0), feat = 2.0 * double(F);
         const double pairs = sym ? double(N1) * N1 / 2 : double(N1) * N2;
         if (!(feat * 0.6 < lattice) || pairs < 16384.0) return GPSIG_OK;
     }
@@ -676,6 +677,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         memset(&A, 0, sizeof(A));
         A.X = static_cast<const double*>(Xs); A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = s;
         A.w = w; A.normalize = normalize; A.jitter = p->jitter; A.Phi = static_cast<double*>(phi); A.ld = ld; A.dlev = nullptr;
+        A.order = p->order;
         const unsigned grid = unsigned(N < 4096 ? N : 4096);
         hipError_t e = ffn(A, grid, sig_features_lds_bytes(d, M, L), c->stream);
         if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));

@@ -1,4 +1,4 @@
-// sig_feat_kernel.hpp -- SignatureLinear, first-order algorithm, as an inner product of explicit level features.
+// sig_feat_kernel.hpp -- SignatureLinear (first-order algorithm; higher orders: sig_horner below) as an inner product of explicit level features.
 //
 // For the LINEAR state-space kernel the increment lattice of a pair factorises, dM[a][b] = <dx_a, dy_b> (gpsig/kernels.py:799-806 into
 // signature_algs.py:25-26), and with it the whole first-order recursion (signature_algs.py:28-35): level m is the sum over strictly
@@ -54,7 +54,26 @@ struct SigFeatArgs {
     double* Phi;            // (N, ld): levels 1..M, then the level-0 column, then zeros up to ld
     int64_t ld;
     double* dlev;           // (N, M+1) raw level diagonals |Phi_m|^2 (level 0: 1), or NULL
+    int order;              // 1: signature_algs.py:8-35; > 1: the higher-order algorithm (:37-74), see sig_horner below
 };
+
+// Higher orders (signature_algs.py:37-74: a step may repeat an index up to `order` times, with 1 / k! for k repeats).  For the linear
+// base kernel that algorithm's level m is the inner product of the features obtained by multiplying, step by step, with the exponential
+// of the increment truncated at degree `order` (Chen; order = num_levels: the signature of the piecewise-linear path, what the
+// reference's notebook checks against esig):  Phi_m <- sum_{k = 0 .. min(order, m)} Phi_{m-k} (x) dx^(x)k / k!.  Along one chain of
+// entries -- V[m] the level-m entry, E[m] the component of dx that extends level m-1 to it -- the sum is a Horner form,
+//     new V[m] = V[m] + E[m] H_1,   H_j = V[m-j] + E[m-j] / (j+1) H_{j+1},   H_{min(order, m)} = V[m - min(order, m)],
+// and sig_horner returns H_jmin (1: the whole bracket; 2: what is left when the level below is folded in by the caller).  V[0] = 1,
+// E[0] = 0.  About d^(m-1) extra multiply-adds per level and step: the higher orders cost the features a fifth more, the contraction
+// nothing -- against pair kernels that take 34 to 150 times the first order's time at BASELINE configs[1]'s size.
+template <int MM>
+__device__ __forceinline__ double sig_horner(const double (&V)[MM], const double (&E)[MM], int m, int order, int jmin) {
+    double h = 0.0;
+#pragma unroll
+    for (int j = MM; j >= 1; --j)
+        if (j <= m && j >= jmin && j <= order) h = fma(h * E[m - j], 1.0 / (j + 1), V[m - j]);
+    return h;
+}
 
 // D = the number of columns after lags (not padded: the feature count is D^m), M = num_levels >= 2.
 // Everything a thread needs lives in its registers: thread t owns the entries t, t + T, .. of level M-1 (its "parents"), their D
@@ -62,7 +81,7 @@ struct SigFeatArgs {
 // per parent and step, recomputed by every thread that shares the ancestor, against D + 1 useful ones).  So the sweep over time needs no
 // barrier and no LDS traffic besides the broadcast reads of the increment: the first form kept the lower levels in LDS behind a barrier
 // per step and ran at a third of its issue rate on the LDS round trips (1.16 ms for BASELINE configs[1]'s 4,096 sequences; this: see DESIGN).
-template <int D, int M>
+template <int D, int M, bool HO>
 __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const SigFeatArgs A) {
     constexpr int T = sig_threads(D, M);
     constexpr int NTOP = sig_ipow(D, M), NPAR = sig_ipow(D, M - 1);     // top-level values, their parents (level M-1)
@@ -128,17 +147,30 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const S
                 for (int k = 0; k < NA; ++k) dck[k] = dxa[opaque(comp_k[k])];
 #pragma unroll
                 for (int q = 0; q < PPT; ++q) {
-                    // every level from the OLD value of the level below it: the top first, then the ancestors from the highest down
-#pragma unroll
-                    for (int f = 0; f < D; ++f) top[q][f] = fma(anc[q][0], d_[f], top[q][f]);
+                    double ec[NA];                  // the component of dx that extends the level below into ancestor k
 #pragma unroll
                     for (int k = 0; k < NA; ++k) {
-                        const double below = k + 1 < NA ? anc[q][k + 1] : 1.0;
-                        double dc;
-                        if (T % sig_ipow(D, k + 1) == 0) dc = dck[k];
-                        else if (sig_ipow(D, k) % T == 0) dc = d_[(q / (sig_ipow(D, k) / T > 0 ? sig_ipow(D, k) / T : 1)) % D];
-                        else dc = dxa[opaque(comp_g[q][k])];
-                        anc[q][k] = fma(below, dc, anc[q][k]);
+                        if (T % sig_ipow(D, k + 1) == 0) ec[k] = dck[k];
+                        else if (sig_ipow(D, k) % T == 0) ec[k] = d_[(q / (sig_ipow(D, k) / T > 0 ? sig_ipow(D, k) / T : 1)) % D];
+                        else ec[k] = dxa[opaque(comp_g[q][k])];
+                    }
+                    if constexpr (!HO) {
+                        // every level from the OLD value of the level below it: the top first, then the ancestors from the highest down
+#pragma unroll
+                        for (int f = 0; f < D; ++f) top[q][f] = fma(anc[q][0], d_[f], top[q][f]);
+#pragma unroll
+                        for (int k = 0; k < NA; ++k) anc[q][k] = fma(k + 1 < NA ? anc[q][k + 1] : 1.0, ec[k], anc[q][k]);
+                    } else {
+                        // higher orders: the chain of this parent by level (sig_horner above), old values throughout
+                        double V[M], E[M];
+                        V[0] = 1.0; E[0] = 0.0;
+#pragma unroll
+                        for (int m = 1; m < M; ++m) { V[m] = anc[q][M - 1 - m]; E[m] = ec[M - 1 - m]; }
+                        const double ht = sig_horner<M>(V, E, M, A.order, 1);
+#pragma unroll
+                        for (int f = 0; f < D; ++f) top[q][f] = fma(ht, d_[f], top[q][f]);
+#pragma unroll
+                        for (int k = 0; k < NA; ++k) anc[q][k] = fma(sig_horner<M>(V, E, M - 1 - k, A.order, 1), ec[k], anc[q][k]);
                     }
                 }
             }
@@ -223,7 +255,7 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const S
 // of its operands in the same order, and levels in their places): level M as (child pair, thread), level M-1 as (sibling, thread).
 constexpr bool sig_siblings(int d, int M) { return M >= 3 && sig_threads(d, M) == sig_ipow(d, M - 2); }
 
-template <int D, int M>
+template <int D, int M, bool HO>
 __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_sib_kernel(const SigFeatArgs A) {
     constexpr int T = sig_threads(D, M);
     static_assert(T == sig_ipow(D, M - 2) && M >= 3 && D <= 64, "one level M-2 entry per thread");
@@ -276,16 +308,36 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_sib_kernel(con
                 }
 #pragma unroll
                 for (int k = 1; k <= NANC; ++k) dc[k] = dxa[opaque(comp[k])];
-                // every level from the OLD value of the level below it: top, parents, then the ancestors from the highest down
+                if constexpr (!HO) {
+                    // every level from the OLD value of the level below it: top, parents, then the ancestors from the highest down
 #pragma unroll
-                for (int q = 0; q < D; ++q)
+                    for (int q = 0; q < D; ++q)
 #pragma unroll
-                    for (int f = 0; f < D; ++f) top[q][f] = fma(par[q], d_[f], top[q][f]);
+                        for (int f = 0; f < D; ++f) top[q][f] = fma(par[q], d_[f], top[q][f]);
 #pragma unroll
-                for (int q = 0; q < D; ++q) par[q] = fma(anc[1], d_[q], par[q]);
+                    for (int q = 0; q < D; ++q) par[q] = fma(anc[1], d_[q], par[q]);
 #pragma unroll
-                for (int k = 1; k < NANC; ++k) anc[k] = fma(anc[k + 1], dc[k], anc[k]);
-                anc[NANC] += dc[NANC];
+                    for (int k = 1; k < NANC; ++k) anc[k] = fma(anc[k + 1], dc[k], anc[k]);
+                    anc[NANC] += dc[NANC];
+                } else {
+                    // higher orders (sig_horner above): the thread's chain below the parents is the same for all of them
+                    double V[M], E[M];
+                    V[0] = 1.0; E[0] = 0.0; V[M - 1] = 0.0; E[M - 1] = 0.0;        // (level M-1: the parents, folded in below)
+#pragma unroll
+                    for (int m = 1; m <= M - 2; ++m) { V[m] = anc[M - 1 - m]; E[m] = dc[M - 1 - m]; }
+                    const double g2 = 0.5 * sig_horner<M>(V, E, M, A.order, 2);     // the bracket behind a parent's own term, over 2
+#pragma unroll
+                    for (int q = 0; q < D; ++q) {
+                        const double hq = fma(g2, d_[q], par[q]);
+#pragma unroll
+                        for (int f = 0; f < D; ++f) top[q][f] = fma(hq, d_[f], top[q][f]);
+                    }
+                    const double hp = sig_horner<M>(V, E, M - 1, A.order, 1);
+#pragma unroll
+                    for (int q = 0; q < D; ++q) par[q] = fma(hp, d_[q], par[q]);
+#pragma unroll
+                    for (int k = 1; k <= NANC; ++k) anc[k] = fma(sig_horner<M>(V, E, M - 1 - k, A.order, 1), dc[k], anc[k]);
+                }
             }
         }
         // level norms |Phi_m|^2 (= K_m(x, x)), all levels in one pass

@@ -941,11 +941,17 @@ def test_linear_gram_as_feature_contraction(K):
     cases = [dict(N=37, N2=21, L=9, L2=9, d=3, M=4), dict(N=130, N2=50, L=20, L2=7, d=2, M=6), dict(N=260, N2=129, L=15, L2=12, d=8, M=3),
              dict(N=70, N2=9, L=11, L2=6, d=2, M=2, lags=1), dict(N=140, N2=33, L=10, L2=10, d=5, M=4, normalization=False),
              dict(N=45, N2=45, L=8, L2=8, d=4, M=5, difference=False), dict(N=150, N2=66, L=12, L2=10, d=2, M=8),
-             dict(N=131, N2=40, L=10, L2=9, d=8, M=4, lags=0), dict(N=129, N2=3, L=66, L2=20, d=8, M=5)]
+             dict(N=131, N2=40, L=10, L2=9, d=8, M=4, lags=0), dict(N=129, N2=3, L=66, L2=20, d=8, M=5),
+             # the higher-order algorithm (signature_algs.py:37-74) as truncated-exponential features: every order up to num_levels,
+             # both feature kernels (strided parents: d = 3, 2; sibling parents: d = 8 M = 4, d = 4 M = 5)
+             dict(N=37, N2=21, L=9, L2=9, d=3, M=4, order=2), dict(N=40, N2=33, L=8, L2=7, d=3, M=4, order=4),
+             dict(N=130, N2=50, L=12, L2=7, d=2, M=6, order=3), dict(N=131, N2=40, L=10, L2=9, d=8, M=4, order=3),
+             dict(N=45, N2=45, L=8, L2=8, d=4, M=5, order=5, difference=False), dict(N=70, N2=9, L=11, L2=6, d=2, M=3, lags=1, order=2),
+             dict(N=60, N2=17, L=20, L2=13, d=8, M=5, order=2, normalization=False)]
     for cs in cases:
         N, N2, L, L2, d, M = (cs[k] for k in ("N", "N2", "L", "L2", "d", "M"))
         kw = dict(input_dim=L * d, num_features=d, num_levels=M, base="linear", lengthscales=0.7 + rng.random(d), variances=0.5 + rng.random(M + 1),
-                  normalization=cs.get("normalization", True), difference=cs.get("difference", True))
+                  normalization=cs.get("normalization", True), difference=cs.get("difference", True), order=cs.get("order", 1))
         if cs.get("lags"):
             kw["num_lags"] = cs["lags"]
         kx, ko = make_kernel(K, kw), make_oracle(kw)
