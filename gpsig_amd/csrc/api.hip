@@ -615,7 +615,9 @@ int timing_begin_any(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1, bool* on) {
 int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, const void* X2, int64_t N1, int64_t N2, int L1, int L2,
                    int return_levels, void* out, bool timed, int x_squared, int64_t row_begin, int64_t row_end, int compact, bool* done) {
     *done = false;
-    if (c->sig_features == 0 || p->dtype != GPSIG_F64 || p->base_kernel != GPSIG_BASE_LINEAR || x_squared) return GPSIG_OK;
+    // the linear kernel, and the cosine kernel as the linear kernel of the unit vectors x / |x| (kernels.py:820-828)
+    const bool cosine = p->base_kernel == GPSIG_BASE_COSINE;
+    if (c->sig_features == 0 || p->dtype != GPSIG_F64 || !(p->base_kernel == GPSIG_BASE_LINEAR || cosine) || x_squared) return GPSIG_OK;
     if (c->shard_n > 1) return GPSIG_OK;          // gpsig_set_shard: "entries outside the shard are left untouched" is the pair kernels' contract
     const int M = p->num_levels;
     if (M < 2 || p->order < 1 || p->order > M) return GPSIG_OK;
@@ -628,7 +630,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     if (r1 < 1 || r2 < 1) return GPSIG_OK;
     if (c->sig_features < 0) {
         // (the higher-order pair kernels carry order^2 grids per level: 34 to 150 times the first order's time at configs[1]'s size)
-        const double lattice = double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0) * (p->order > 1 ? 8.0 : 1.0), feat = 2.0 * double(F);
+        const double lattice = double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0) * (p->order > 1 ? 8.0 : 1.0) * (cosine ? 1.5 : 1.0), feat = 2.0 * double(F);
         const double pairs = sym ? double(N1) * N1 / 2 : double(N1) * N2;
         if (!(feat * 0.6 < lattice) || pairs < 16384.0) return GPSIG_OK;
     }
@@ -678,6 +680,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         A.X = static_cast<const double*>(Xs); A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = s;
         A.w = w; A.normalize = normalize; A.jitter = p->jitter; A.Phi = static_cast<double*>(phi); A.ld = ld; A.dlev = nullptr;
         A.order = p->order;
+        A.unit_points = cosine ? 1 : 0;
         const unsigned grid = unsigned(N < 4096 ? N : 4096);
         hipError_t e = ffn(A, grid, sig_features_lds_bytes(d, M, L), c->stream);
         if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));

@@ -55,6 +55,7 @@ struct SigFeatArgs {
     int64_t ld;
     double* dlev;           // (N, M+1) raw level diagonals |Phi_m|^2 (level 0: 1), or NULL
     int order;              // 1: signature_algs.py:8-35; > 1: the higher-order algorithm (:37-74), see sig_horner below
+    int unit_points;        // SignatureCosine (kernels.py:820-828): <x, y> / (|x| |y|) is the linear kernel of the points x / |x|
 };
 
 // Higher orders (signature_algs.py:37-74: a step may repeat an index up to `order` times, with 1 / k! for k repeats).  For the linear
@@ -111,10 +112,27 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const S
     for (int64_t n = blockIdx.x; n < A.N; n += gridDim.x) {
         const double* Xn = A.X + n * int64_t(A.L) * A.P.d_in;
         __syncthreads();                            // the previous sequence's increments are no longer read
-        for (int e = tid; e < (A.L + S) * D + 64; e += T) {
-            const int a = e / D, f = e - a * D;
-            dx[e] = a >= R ? 0.0 : A.difference ? scaled_point<double>(Xn, A.L, a + 1, f, A.P) - scaled_point<double>(Xn, A.L, a, f, A.P)
-                                 : scaled_point<double>(Xn, A.L, a, f, A.P);
+        if (!A.unit_points) {
+            for (int e = tid; e < (A.L + S) * D + 64; e += T) {
+                const int a = e / D, f = e - a * D;
+                dx[e] = a >= R ? 0.0 : A.difference ? scaled_point<double>(Xn, A.L, a + 1, f, A.P) - scaled_point<double>(Xn, A.L, a, f, A.P)
+                                     : scaled_point<double>(Xn, A.L, a, f, A.P);
+            }
+        } else {                                    // the scaled points, their norms, then the (increments of the) unit vectors
+            double* const pts = red + 64;           // L x D, then L reciprocal norms
+            double* const inv = pts + size_t(A.L) * D;
+            for (int e = tid; e < A.L * D; e += T) pts[e] = scaled_point<double>(Xn, A.L, e / D, e % D, A.P);
+            __syncthreads();
+            for (int a = tid; a < A.L; a += T) {
+                double ss = 0.0;
+                for (int f = 0; f < D; ++f) ss = fma(pts[a * D + f], pts[a * D + f], ss);
+                inv[a] = 1.0 / sqrt(ss);
+            }
+            __syncthreads();
+            for (int e = tid; e < (A.L + S) * D + 64; e += T) {
+                const int a = e / D, f = e - a * D;
+                dx[e] = a >= R ? 0.0 : A.difference ? pts[(a + 1) * D + f] * inv[a + 1] - pts[a * D + f] * inv[a] : pts[a * D + f] * inv[a];
+            }
         }
         double top[PPT][D], anc[PPT][NA];
 #pragma unroll
@@ -279,10 +297,27 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_sib_kernel(con
     for (int64_t n = blockIdx.x; n < A.N; n += gridDim.x) {
         const double* Xn = A.X + n * int64_t(A.L) * A.P.d_in;
         __syncthreads();                            // the previous sequence's increments are no longer read
-        for (int e = tid; e < (A.L + S) * D + 64; e += T) {
-            const int a = e / D, f = e - a * D;
-            dx[e] = a >= R ? 0.0 : A.difference ? scaled_point<double>(Xn, A.L, a + 1, f, A.P) - scaled_point<double>(Xn, A.L, a, f, A.P)
-                                 : scaled_point<double>(Xn, A.L, a, f, A.P);
+        if (!A.unit_points) {
+            for (int e = tid; e < (A.L + S) * D + 64; e += T) {
+                const int a = e / D, f = e - a * D;
+                dx[e] = a >= R ? 0.0 : A.difference ? scaled_point<double>(Xn, A.L, a + 1, f, A.P) - scaled_point<double>(Xn, A.L, a, f, A.P)
+                                     : scaled_point<double>(Xn, A.L, a, f, A.P);
+            }
+        } else {                                    // the scaled points, their norms, then the (increments of the) unit vectors
+            double* const pts = red + 64;           // L x D, then L reciprocal norms
+            double* const inv = pts + size_t(A.L) * D;
+            for (int e = tid; e < A.L * D; e += T) pts[e] = scaled_point<double>(Xn, A.L, e / D, e % D, A.P);
+            __syncthreads();
+            for (int a = tid; a < A.L; a += T) {
+                double ss = 0.0;
+                for (int f = 0; f < D; ++f) ss = fma(pts[a * D + f], pts[a * D + f], ss);
+                inv[a] = 1.0 / sqrt(ss);
+            }
+            __syncthreads();
+            for (int e = tid; e < (A.L + S) * D + 64; e += T) {
+                const int a = e / D, f = e - a * D;
+                dx[e] = a >= R ? 0.0 : A.difference ? pts[(a + 1) * D + f] * inv[a + 1] - pts[a * D + f] * inv[a] : pts[a * D + f] * inv[a];
+            }
         }
         double top[D][D], par[D], anc[NANC + 1];
 #pragma unroll
@@ -410,7 +445,7 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_sib_kernel(con
 
 inline size_t sig_features_lds_bytes(int d, int M, int L) {
     (void)M;
-    return sizeof(double) * ((size_t(L) + (d <= 64 ? 64 / d : 1)) * d + 64 + 64);
+    return sizeof(double) * ((size_t(L) + (d <= 64 ? 64 / d : 1)) * d + 64 + 64 + size_t(L) * d + size_t(L));      // (+ points and norms: SignatureCosine)
 }
 
 // ---- C = A B^T, float64 matrix cores, depth split over workgroups ----------------------------------------------------------------

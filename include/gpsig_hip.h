@@ -111,7 +111,7 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "pinned_staging" host-pointer mode: 1 (default) transfers of 2 MiB and more run in 16 MiB chunks through two pinned buffers of the
  *                 context, the DMA of one chunk overlapping a threaded host copy of the previous one; 0 plain hipMemcpy on the caller's
  *                 (pageable) memory
- *   "sig_features" SignatureLinear, any order: the Gram as ONE contraction of explicit level features on the float64 matrix cores
+ *   "sig_features" SignatureLinear and SignatureCosine, any order: the Gram as ONE contraction of explicit level features on the float64 matrix cores
  *                 (sig_feat_kernel.hpp: K_m(x, y) = <Phi_m(x), Phi_m(y)>, d^m numbers per level): -1 (default) where that costs fewer
  *                 flops than the lattice sweep and the feature matrices fit, 0 never, 1 wherever it is built (d <= 8, d^M <= 65536)
  *   "sig_features_keep" 1: the feature matrix built by the next such evaluation is kept and reused by the evaluations that follow with the

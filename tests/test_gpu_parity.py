@@ -947,17 +947,21 @@ def test_linear_gram_as_feature_contraction(K):
              dict(N=37, N2=21, L=9, L2=9, d=3, M=4, order=2), dict(N=40, N2=33, L=8, L2=7, d=3, M=4, order=4),
              dict(N=130, N2=50, L=12, L2=7, d=2, M=6, order=3), dict(N=131, N2=40, L=10, L2=9, d=8, M=4, order=3),
              dict(N=45, N2=45, L=8, L2=8, d=4, M=5, order=5, difference=False), dict(N=70, N2=9, L=11, L2=6, d=2, M=3, lags=1, order=2),
-             dict(N=60, N2=17, L=20, L2=13, d=8, M=5, order=2, normalization=False)]
+             dict(N=60, N2=17, L=20, L2=13, d=8, M=5, order=2, normalization=False),
+             # SignatureCosine = the linear kernel of the unit vectors x / |x| (kernels.py:820-828): the same route
+             dict(N=37, N2=21, L=9, L2=9, d=3, M=4, base="cosine"), dict(N=131, N2=40, L=10, L2=9, d=8, M=4, base="cosine", order=2),
+             dict(N=70, N2=9, L=11, L2=6, d=2, M=3, lags=1, base="cosine", difference=False)]
     for cs in cases:
         N, N2, L, L2, d, M = (cs[k] for k in ("N", "N2", "L", "L2", "d", "M"))
-        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base="linear", lengthscales=0.7 + rng.random(d), variances=0.5 + rng.random(M + 1),
+        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=cs.get("base", "linear"), lengthscales=0.7 + rng.random(d), variances=0.5 + rng.random(M + 1),
                   normalization=cs.get("normalization", True), difference=cs.get("difference", True), order=cs.get("order", 1))
         if cs.get("lags"):
             kw["num_lags"] = cs["lags"]
         kx, ko = make_kernel(K, kw), make_oracle(kw)
         kx.sigma = ko.sigma = 1.3
-        X = np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
-        Y = np.cumsum(0.4 * rng.standard_normal((N2, L2, d)), axis=1).reshape(N2, -1)
+        shift = 1.0 if cs.get("base") == "cosine" else 0.0          # (away from the origin, where x / |x| is undefined)
+        X = (shift + np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1)).reshape(N, -1)
+        Y = (shift + np.cumsum(0.4 * rng.standard_normal((N2, L2, d)), axis=1)).reshape(N2, -1)
         got = {}
         try:
             for route in (1, 0):
