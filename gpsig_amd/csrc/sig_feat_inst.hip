@@ -1,51 +1,20 @@
-// Instantiations of sig_features_kernel (sig_feat_kernel.hpp) and their lookup: D columns, M levels with D^M <= SIG_MAX_TOP.
+// Lookup of the feature kernels (instantiated in sig_feat_inst_{a..f}.hip: D <= 32 columns, M levels with D^M <= SIG_MAX_TOP) and the
+// launchers of the contraction and its reduce.
 #include "sig_feat_kernel.hpp"
 
 namespace gpsig {
 typedef hipError_t (*SigFeatLaunchFn)(const SigFeatArgs&, unsigned, size_t, hipStream_t);
-
-template <int D, int M>
-static hipError_t sig_feat_launch(const SigFeatArgs& A, unsigned grid, size_t lds, hipStream_t stream) {
-    auto kern = sig_features_kernel<D, M, false>;
-    if constexpr (sig_siblings(D, M)) kern = sig_features_sib_kernel<D, M, false>;      // sibling parents per thread: fewer multiply-adds
-    if (A.order > 1) {                               // the higher-order algorithm: truncated-exponential steps
-        kern = sig_features_kernel<D, M, true>;
-        if constexpr (sig_siblings(D, M)) kern = sig_features_sib_kernel<D, M, true>;
-    }
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(sig_threads(D, M)), lds, stream, A);
-    return hipGetLastError();
-}
-
-template <int D>
-static SigFeatLaunchFn sig_feat_pick(int M) {
-    switch (M) {
-        case 2: return &sig_feat_launch<D, 2>;
-        case 3: return &sig_feat_launch<D, 3>;
-        case 4: if constexpr (sig_ipow(D, 4) <= SIG_MAX_TOP) return &sig_feat_launch<D, 4>; else return nullptr;
-        case 5: if constexpr (sig_ipow(D, 5) <= SIG_MAX_TOP) return &sig_feat_launch<D, 5>; else return nullptr;
-        case 6: if constexpr (sig_ipow(D, 5) <= SIG_MAX_TOP && sig_ipow(D, 6) <= SIG_MAX_TOP) return &sig_feat_launch<D, 6>; else return nullptr;
-        case 7: if constexpr (sig_ipow(D, 6) <= SIG_MAX_TOP && sig_ipow(D, 7) <= SIG_MAX_TOP) return &sig_feat_launch<D, 7>; else return nullptr;
-        case 8: if constexpr (sig_ipow(D, 7) <= SIG_MAX_TOP && sig_ipow(D, 8) <= SIG_MAX_TOP) return &sig_feat_launch<D, 8>; else return nullptr;
-        default: return nullptr;
-    }
-}
+SigFeatLaunchFn sig_feat_pick_a(int d, int M);       // d = 1 .. 4     (sig_feat_inst_a.hip)
+SigFeatLaunchFn sig_feat_pick_b(int d, int M);       // d = 5 .. 8
+SigFeatLaunchFn sig_feat_pick_c(int d, int M);       // d = 9 .. 12
+SigFeatLaunchFn sig_feat_pick_d(int d, int M);       // d = 13 .. 16
+SigFeatLaunchFn sig_feat_pick_e(int d, int M);       // d = 17 .. 24
+SigFeatLaunchFn sig_feat_pick_f(int d, int M);       // d = 25 .. 32
 
 SigFeatLaunchFn sig_feat_lookup(int d, int M) {
-    switch (d) {
-        case 1: return sig_feat_pick<1>(M);
-        case 2: return sig_feat_pick<2>(M);
-        case 3: return sig_feat_pick<3>(M);
-        case 4: return sig_feat_pick<4>(M);
-        case 5: return sig_feat_pick<5>(M);
-        case 6: return sig_feat_pick<6>(M);
-        case 7: return sig_feat_pick<7>(M);
-        case 8: return sig_feat_pick<8>(M);
-        default: return nullptr;
-    }
+    if (d < 1 || d > 32) return nullptr;
+    return d <= 4 ? sig_feat_pick_a(d, M) : d <= 8 ? sig_feat_pick_b(d, M) : d <= 12 ? sig_feat_pick_c(d, M) : d <= 16 ? sig_feat_pick_d(d, M)
+         : d <= 24 ? sig_feat_pick_e(d, M) : sig_feat_pick_f(d, M);
 }
 
 hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream, int dma, int* used_dma) {

@@ -32,7 +32,11 @@
 
 namespace gpsig {
 
-constexpr int sig_ipow(int d, int m) { return m <= 0 ? 1 : d * sig_ipow(d, m - 1); }
+constexpr int sig_ipow(int d, int m) {           // d^m, saturating at 2^30 (the lookup asks about shapes far beyond what is built)
+    long long v = 1;
+    for (int i = 0; i < m; ++i) { v *= d; if (v > (1ll << 30)) return 1 << 30; }
+    return int(v);
+}
 constexpr int sig_lower_total(int d, int M) { int s = 0; for (int m = 1; m < M; ++m) s += sig_ipow(d, m); return s; }
 constexpr int sig_feature_count(int d, int M) { int s = 0; for (int m = 1; m <= M; ++m) s += sig_ipow(d, m); return s; }
 constexpr int SIG_MAX_TOP = 32768;               // d^M values of the top level: 64 per thread of a 512-thread workgroup (two wavefronts per SIMD,

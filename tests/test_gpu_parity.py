@@ -950,7 +950,13 @@ def test_linear_gram_as_feature_contraction(K):
              dict(N=60, N2=17, L=20, L2=13, d=8, M=5, order=2, normalization=False),
              # SignatureCosine = the linear kernel of the unit vectors x / |x| (kernels.py:820-828): the same route
              dict(N=37, N2=21, L=9, L2=9, d=3, M=4, base="cosine"), dict(N=131, N2=40, L=10, L2=9, d=8, M=4, base="cosine", order=2),
-             dict(N=70, N2=9, L=11, L2=6, d=2, M=3, lags=1, base="cosine", difference=False)]
+             dict(N=70, N2=9, L=11, L2=6, d=2, M=3, lags=1, base="cosine", difference=False),
+             # wider state spaces (d <= 16 with d^M <= 32,768), also reached through lags (5 features x 3 lag copies)
+             dict(N=50, N2=33, L=12, L2=9, d=16, M=3), dict(N=140, N2=20, L=9, L2=9, d=12, M=4, order=2), dict(N=60, N2=61, L=14, L2=8, d=16, M=2),
+             dict(N=45, N2=30, L=10, L2=7, d=10, M=3, order=3, normalization=False), dict(N=40, N2=12, L=12, L2=10, d=5, M=3, lags=2),
+             dict(N=33, N2=8, L=9, L2=9, d=13, M=3, base="cosine"),
+             dict(N=40, N2=20, L=8, L2=8, d=32, M=3), dict(N=36, N2=9, L=10, L2=7, d=24, M=3, order=3), dict(N=70, N2=31, L=9, L2=9, d=32, M=2),
+             dict(N=30, N2=14, L=12, L2=8, d=10, M=3, lags=1, order=2), dict(N=25, N2=11, L=7, L2=7, d=19, M=3, normalization=False)]
     for cs in cases:
         N, N2, L, L2, d, M = (cs[k] for k in ("N", "N2", "L", "L2", "d", "M"))
         kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=cs.get("base", "linear"), lengthscales=0.7 + rng.random(d), variances=0.5 + rng.random(M + 1),
