@@ -167,5 +167,10 @@ def test_feature_contraction_loop_carries_no_vector_instruction_but_the_multipli
     n_mfma, loop = best
     other_valu = [op for op in loop if op.startswith("v_") and not op.startswith("v_mfma")]
     assert len(other_valu) <= 24, sorted(set(other_valu))              # the pointer moves (16 v_lshl_add_u64 per eight slabs)
-    (vgprs, scratch, occ), _ = report("_ZN5gpsig23sig_features_sib_kernelILi8ELi5EEEvNS_11SigFeatArgsE")
-    assert scratch == 0 and occ >= 2, (vgprs, scratch, occ)
+    src_b, out_b = os.path.join(ROOT, "gpsig_amd", "csrc", "sig_feat_inst_b.hip"), str(tmp_path / "sig_feat_b.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out_b, src_b],
+                          stderr=subprocess.DEVNULL)
+    text = open(out_b).read()
+    for ho in ("0", "1"):                                               # first- and higher-order steps
+        (vgprs, scratch, occ), _ = report("_ZN5gpsig23sig_features_sib_kernelILi8ELi5ELb%sEEEvNS_11SigFeatArgsE" % ho)
+        assert scratch == 0 and occ >= 2, (ho, vgprs, scratch, occ)
