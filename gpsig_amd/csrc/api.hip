@@ -665,6 +665,21 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     while (nsplit > 1 && part_one * size_t(nsplit) > (size_t(40) << 30)) --nsplit;       // (the exception to the rule above: 40 GiB of partial sums)
     const size_t feat_bytes = sizeof(double) * size_t(ld) * (size_t(N1) + (sym ? 0 : size_t(N2)));
     if (feat_bytes + part_one * size_t(nsplit) > (size_t(96) << 30)) return GPSIG_OK;
+    {
+        // what the scratch buffers would have to grow by, against what the device has left: the pair recursion needs no such memory
+        // and is the better answer to a full device than an allocation error
+        auto grow = [&](int id, size_t bytes) { return bytes > c->buf[id].cap ? bytes + bytes / 8 + 256 : size_t(0); };
+        const size_t extra = grow(B_SF0, sizeof(double) * size_t(ld) * N1 + 64) + (sym ? 0 : grow(B_SF1, sizeof(double) * size_t(ld) * N2 + 64)) +
+                             grow(B_SF2, part_one * size_t(nsplit) + 64);
+        if (extra > (size_t(1) << 30) && !c->capturing) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                size_t held = 0;                // (a buffer that grows is freed first)
+                for (int id : {int(B_SF0), int(B_SF1), int(B_SF2)}) held += grow(id, id == B_SF0 ? sizeof(double) * size_t(ld) * N1 + 64 : id == B_SF1 ? (sym ? 0 : sizeof(double) * size_t(ld) * N2 + 64) : part_one * size_t(nsplit) + 64) ? c->buf[id].cap : 0;
+                if (extra > free_b + held - (free_b + held) / 16) return GPSIG_OK;
+            }
+        }
+    }
     const double* w = nullptr;
     if (!raw) CHK(upload_weights(c, p, &w));
     ScaleParams s;

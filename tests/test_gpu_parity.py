@@ -1522,3 +1522,32 @@ def test_svgp_predict_and_kl(K, whiten, q_diag):
             assert relerr(mean.cpu().numpy(), want_mean) <= 1e-6 and relerr(var.cpu().numpy(), want_var) <= 1e-6, (kind, full)
         want_kl = SO.gauss_kl(q_mu, q_sqrt, K=None if whiten else kzz)
         assert abs(float(m.prior_kl()) - want_kl) <= 1e-8 * abs(want_kl), kind
+
+
+def test_feature_contraction_gives_way_on_a_full_device(K):
+    """The contraction needs the feature matrix and its partial sums in scratch memory; where the device cannot hold them the
+    evaluation goes through the pair recursion (which needs neither) instead of failing with an allocation error."""
+    import torch
+    from gpsig_amd import _lib
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    N, L, d, M = 2048, 64, 8, 5                                  # 0.6 GB of features + 1.1 GB of partial sums
+    X = torch.as_tensor(rng.standard_normal((N, L * d)), device=dev)
+    kern = K.SignatureLinear(L * d, d, M)
+    want = kern.K(X)                                             # the contraction, on the default stream's context
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(dev)
+    hog = torch.empty(int(free - 0.9e9), dtype=torch.uint8, device=dev)      # leave 0.9 GB
+    side = torch.cuda.Stream(dev)                                # a stream of its own: a context without scratch buffers yet
+    side.wait_stream(torch.cuda.current_stream(dev))
+    try:
+        with torch.cuda.stream(side):
+            got = kern.K(X)
+        side.synchronize()
+    finally:
+        del hog
+        _lib.release(0, side.cuda_stream)
+        torch.cuda.empty_cache()
+    assert not torch.equal(got, want)                            # the pair recursion ran (other last digits) ...
+    assert float((got - want).abs().max()) <= 1e-11 * float(want.abs().max())      # ... and agrees
