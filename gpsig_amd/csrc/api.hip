@@ -33,6 +33,7 @@ typedef hipError_t (*SigFeatLaunchFn)(const SigFeatArgs&, unsigned, size_t, hipS
 SigFeatLaunchFn sig_feat_lookup(int d, int M);
 hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream, int dma, int* used_dma);
 hipError_t sig_reduce_launch(const SigReduceArgs& R, hipStream_t stream);
+hipError_t sig_convert_launch(const void* in, void* out, int64_t n, bool widen, hipStream_t stream);
 bool solver_dsyevd(void** handle_slot, hipStream_t stream, int n, double* A, double* ev, double* work, int* info, std::string* err);
 void solver_release(void* handle);
 int tvs_tile_waves(int M, int D, int E, int kind);
@@ -617,7 +618,11 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     *done = false;
     // the linear kernel, and the cosine kernel as the linear kernel of the unit vectors x / |x| (kernels.py:820-828)
     const bool cosine = p->base_kernel == GPSIG_BASE_COSINE;
-    if (c->sig_features == 0 || p->dtype != GPSIG_F64 || !(p->base_kernel == GPSIG_BASE_LINEAR || cosine) || x_squared) return GPSIG_OK;
+    // float32 calls too: computed in float64 (the matrix cores' own precision), inputs widened and the result rounded -- 29 -> 1.4 ms at
+    // d = 16, num_levels = 3, and closer to the reference than a float32 recursion; not for row blocks (float64 only)
+    const bool f32 = p->dtype == GPSIG_F32;
+    if (c->sig_features == 0 || !(p->dtype == GPSIG_F64 || f32) || !(p->base_kernel == GPSIG_BASE_LINEAR || cosine) || x_squared) return GPSIG_OK;
+    if (f32 && row_end > 0) return GPSIG_OK;
     if (c->shard_n > 1) return GPSIG_OK;          // gpsig_set_shard: "entries outside the shard are left untouched" is the pair kernels' contract
     const int M = p->num_levels;
     if (M < 2 || p->order < 1 || p->order > M) return GPSIG_OK;
@@ -625,12 +630,14 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     SigFeatLaunchFn ffn = sig_feat_lookup(d, M);
     if (!ffn) return GPSIG_OK;
     const bool sym = X2 == nullptr;
+    void* out32 = nullptr;                    // float32 calls: where the rounded result goes
+    const void* const X_given = X;            // (the caller's pointer: what "sig_features_keep" recognises)
     const int64_t F = sig_feature_count(d, M), ld = (F + 1 + 15) / 16 * 16;
     const int r1 = p->difference ? L1 - 1 : L1, r2 = p->difference ? L2 - 1 : L2;
     if (r1 < 1 || r2 < 1) return GPSIG_OK;
     if (c->sig_features < 0) {
         // (the higher-order pair kernels carry order^2 grids per level: 34 to 150 times the first order's time at configs[1]'s size)
-        const double lattice = double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0) * (p->order > 1 ? 8.0 : 1.0) * (cosine ? 1.5 : 1.0), feat = 2.0 * double(F);
+        const double lattice = double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0) * (p->order > 1 ? 8.0 : 1.0) * (cosine ? 1.5 : 1.0) * (f32 ? 0.5 : 1.0), feat = 2.0 * double(F);      // (the float32 pair kernels run at twice the float64 ones' rate)
         const double pairs = sym ? double(N1) * N1 / 2 : double(N1) * N2;
         if (!(feat * 0.6 < lattice) || pairs < 16384.0) return GPSIG_OK;
     }
@@ -688,6 +695,18 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     CHK(ensure(c, B_SF0, sizeof(double) * size_t(ld) * N1 + 64, &phi1));
     if (!sym) CHK(ensure(c, B_SF1, sizeof(double) * size_t(ld) * N2 + 64, &phi2));
     CHK(ensure(c, B_SF2, part_one * size_t(nsplit) + 64, &part));
+    if (f32) {
+        void *x64, *y64 = nullptr, *o64;
+        const int64_t per1 = int64_t(L1) * p->num_features, per2 = int64_t(L2) * p->num_features;
+        CHK(ensure(c, B_SF3, sizeof(double) * size_t(N1 * per1) + 64, &x64));
+        HIPCHK(c, sig_convert_launch(X, x64, N1 * per1, true, c->stream));
+        if (!sym) {
+            CHK(ensure(c, B_SF4, sizeof(double) * size_t(N2 * per2) + 64, &y64));
+            HIPCHK(c, sig_convert_launch(X2, y64, N2 * per2, true, c->stream));
+        }
+        CHK(ensure(c, B_SF5, sizeof(double) * size_t(return_levels ? M + 1 : 1) * size_t(N1) * size_t(sym ? N1 : N2) + 64, &o64));
+        out32 = out; X = x64; X2 = sym ? nullptr : y64; out = o64;
+    }
     const int normalize = (!raw && p->normalization) ? 1 : 0;
     auto features = [&](const void* Xs, int64_t N, int L, void* phi) -> int {
         SigFeatArgs A;
@@ -718,10 +737,10 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         const int64_t tail[4] = {N1, L1, raw ? 1 : 0, ld};
         mix(tail, sizeof(tail));
     }
-    const bool reuse = c->sf_keep && c->sf_valid && c->sf_X == X && c->sf_phi == phi1 && c->sf_key == key;
+    const bool reuse = c->sf_keep && c->sf_valid && c->sf_X == X_given && c->sf_phi == phi1 && c->sf_key == key;
     if (N1 > 0 && !reuse) CHK(features(X, N1, L1, phi1));
     c->sf_valid = c->sf_keep != 0 && N1 > 0;
-    c->sf_X = X; c->sf_phi = phi1; c->sf_key = key;
+    c->sf_X = X_given; c->sf_phi = phi1; c->sf_key = key;
     if (!sym && N2 > 0) CHK(features(X2, N2, L2, phi2));
     if (NA <= 0 || NB <= 0) { *done = true; return GPSIG_OK; }
     // level sums of the weights: the exact diagonal of the normalised symmetric Gram (kernels.py:430-433: (K_ii + jitter) / (K_ii + jitter))
@@ -772,6 +791,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         R.N = N1; R.r0 = row_begin; R.c0 = G.b_off; R.compact = compact;
         HIPCHK(c, sig_reduce_launch(R, c->stream));
     }
+    if (out32) HIPCHK(c, sig_convert_launch(out, out32, int64_t(return_levels ? M + 1 : 1) * N1 * (sym ? N1 : N2), false, c->stream));
     *done = true;
     return GPSIG_OK;
 }

@@ -30,7 +30,7 @@ enum BufId {
     B_LS, B_LR0, B_LR1, B_LR2, B_LR3, B_LR4, B_LR5, B_LR6, B_LR7, B_LR8,
     B_GR0, B_GR1, B_GR2, B_GR3, B_GR4, B_GR5, B_GR6, B_GR7,   // gradient path scratch
     B_GR7B, B_TW0, B_TW1, B_TW2,
-    B_SF0, B_SF1, B_SF2, B_SF3,                               // explicit level features (sig_feat_kernel.hpp): both sides, partial products, level diagonals                              // weighted tensor-vs-sequence sums: partial factor gradients; level arrays of the fallback
+    B_SF0, B_SF1, B_SF2, B_SF3, B_SF4, B_SF5,                               // explicit level features (sig_feat_kernel.hpp): both sides, partial products, level diagonals                              // weighted tensor-vs-sequence sums: partial factor gradients; level arrays of the fallback
     B_SPEC,                                                    // spectral base-kernel table
     B_COUNT
 };

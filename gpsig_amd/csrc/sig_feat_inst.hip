@@ -33,6 +33,14 @@ hipError_t sig_gram_launch(const SigGramArgs& G, int ntiles, hipStream_t stream,
     else hipLaunchKernelGGL(sig_gram_kernel<false>, dim3(unsigned(ntiles) * unsigned(G.nsplit)), dim3(256), 0, stream, G);
     return hipGetLastError();
 }
+hipError_t sig_convert_launch(const void* in, void* out, int64_t n, bool widen, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    int64_t g = (n + 255) / 256;
+    if (g > 16384) g = 16384;
+    if (widen) hipLaunchKernelGGL(sig_widen_kernel, dim3(unsigned(g)), dim3(256), 0, stream, static_cast<const float*>(in), static_cast<double*>(out), n);
+    else hipLaunchKernelGGL(sig_narrow_kernel, dim3(unsigned(g)), dim3(256), 0, stream, static_cast<const double*>(in), static_cast<float*>(out), n);
+    return hipGetLastError();
+}
 hipError_t sig_reduce_launch(const SigReduceArgs& R, hipStream_t stream) {
     if (R.mode == 1) {                   // symmetric: per computed tile, mirrored through LDS
         const int nt = int((R.NA + SG_BM - 1) / SG_BM);

@@ -452,6 +452,15 @@ inline size_t sig_features_lds_bytes(int d, int M, int L) {
     return sizeof(double) * ((size_t(L) + (d <= 64 ? 64 / d : 1)) * d + 64 + 64 + size_t(L) * d + size_t(L));      // (+ points and norms: SignatureCosine)
 }
 
+// float32 calls: the contraction is a float64 computation (float64 matrix cores; a float32 accumulation over 37,000 products would not
+// hold 1e-4 anyway) -- the sequences are widened on the way in, the result rounded on the way out.
+static __global__ void sig_widen_kernel(const float* __restrict__ in, double* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) out[i] = double(in[i]);
+}
+static __global__ void sig_narrow_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) out[i] = float(in[i]);
+}
+
 // ---- C = A B^T, float64 matrix cores, depth split over workgroups ----------------------------------------------------------------
 typedef double sig_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int SG_BM = 128, SG_BN = 128, SG_BK = 16, SG_LDK = SG_BK + 1;

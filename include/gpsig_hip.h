@@ -113,7 +113,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 (pageable) memory
  *   "sig_features" SignatureLinear and SignatureCosine, any order: the Gram as ONE contraction of explicit level features on the float64 matrix cores
  *                 (sig_feat_kernel.hpp: K_m(x, y) = <Phi_m(x), Phi_m(y)>, d^m numbers per level): -1 (default) where that costs fewer
- *                 flops than the lattice sweep and the feature matrices fit, 0 never, 1 wherever it is built (d <= 32 columns after lags, d^M <= 32768)
+ *                 flops than the lattice sweep and the feature matrices fit, 0 never, 1 wherever it is built (d <= 32 columns after lags, d^M <= 32768); float32 calls are
+ *                 computed in float64 on this route (inputs widened, result rounded)
  *   "sig_features_keep" 1: the feature matrix built by the next such evaluation is kept and reused by the evaluations that follow with the
  *                 same sequence pointer, shape and parameters -- the row-block calls of one decomposed Gram (gpsig_kernel_K_symm_rows*);
  *                 the caller must not write the sequences until it sets the option back to 0 (which also drops the matrix's validity)

@@ -988,6 +988,16 @@ def test_linear_gram_as_feature_contraction(K):
             ctx.set_option("sig_features", -1)
         if kw["normalization"]:
             assert np.array_equal(np.diag(got[1][0]), np.full(N, np.sum(kx.sigma * kx.variances)))       # kernels.py:430-433: exactly
+    # float32 calls take the same route: computed in float64, rounded on the way out -- float32 rounding of the result is all that is left
+    N, N2, L, d, M = 200, 90, 20, 16, 3
+    kw = dict(input_dim=L * d, num_features=d, num_levels=M, base="linear", lengthscales=0.7 + rng.random(d))
+    kx, ko = make_kernel(K, kw), make_oracle(kw)
+    X32 = np.cumsum(0.2 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1).astype(np.float32)
+    Y32 = np.cumsum(0.2 * rng.standard_normal((N2, L, d)), axis=1).reshape(N2, -1).astype(np.float32)
+    for got, want in ((kx.K(X32), ko.K(X32.astype(np.float64))), (kx.K(X32, Y32), ko.K(X32.astype(np.float64), Y32.astype(np.float64))),
+                      (kx.K(X32, return_levels=True), ko.K(X32.astype(np.float64), return_levels=True))):
+        assert got.dtype == np.float32
+        assert np.abs(got - want).max() <= 5e-7 * np.abs(want).max(), np.abs(got - want).max() / np.abs(want).max()
     # the unscaled level primitive (what gpsig_seq_gram_levels returns) and the packed row blocks of the multi-GPU path
     N, L, d, M = 300, 14, 3, 4
     X = np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1)
