@@ -1550,6 +1550,7 @@ def test_feature_contraction_gives_way_on_a_full_device(K):
     free, _ = torch.cuda.mem_get_info(dev)
     hog = torch.empty(int(free - 0.9e9), dtype=torch.uint8, device=dev)      # leave 0.9 GB
     side = torch.cuda.Stream(dev)                                # a stream of its own: a context without scratch buffers yet
+    _lib.release(0, side.cuda_stream)                            # (torch hands out side streams from a pool: drop what an earlier test left on it)
     side.wait_stream(torch.cuda.current_stream(dev))
     try:
         with torch.cuda.stream(side):
