@@ -25,7 +25,7 @@ measured by two rocprofv3 --pmc passes of this very command), `clock_ghz` (the s
 on the device), `cpu_baseline` (the oracle's op-for-op restatement of the reference's TF graph on the host cores, bounded
 sample), `rel_err` (a sub-sample of the timed output against the oracle, outside the timed region),
 `end_to_end_ms_host_pointers` (the same evaluation from and to host memory: H2D + compute + D2H) and, on the default
-single-GPU line, `secondary`: the other single-GPU configurations (c2 RBF, c3, c3 with increments, c5), 3 warm-up + 10 steps each.
+single-GPU line, `secondary`: the other single-GPU configurations (c2 through the pair recursion, c2 at order 5, c2 RBF, c3, c3 with increments, c5), 3 warm-up + 10 steps each.
 
 --gpus N > 1 without a torchrun environment launches the N ranks itself (python -m torch.distributed.run, one process per
 GPU, rendezvous on 127.0.0.1) and fails when the node has fewer than N GPUs: a line with "n_gpus": N was computed by N ranks,
@@ -235,7 +235,7 @@ def rel_err(got, want):
 def oracle_rel_err(cfg, w, base, increments, Xh, Zh, out):
     """max |K - K_ref| / (|K_ref| + 1e-6 max|K_ref|) on a sub-sample of the timed output against the oracle."""
     from oracle import sigkern_oracle as O
-    ko = O.SignatureKernelOracle(w["L"] * w["d"], w["d"], w["M"], base=base, lengthscales=lengthscales(dict(w, base=base)))
+    ko = O.SignatureKernelOracle(w["L"] * w["d"], w["d"], w["M"], base=base, lengthscales=lengthscales(dict(w, base=base)), order=w.get("order", 1))
     n = Xh.shape[0]
     if w["dtype"] == "f32":          # the oracle sees the inputs the kernel saw
         Xh = Xh.astype(np.float32).astype(np.float64)
@@ -352,7 +352,7 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6          # MI355X_MICROARCH.md: dense float64 MFM
 
 
 def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chunks=4, weak=False, checks=True, host_e2e=True,
-                 traffic="measure", lattice=False):
+                 traffic="measure", lattice=False, order=1):
     """Times `steps` evaluations of one BASELINE configuration on this rank's device (inputs resident in HBM) and returns the
     bench-line fields on rank 0 (None elsewhere)."""
     import torch
@@ -361,6 +361,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
 
     w = dict(WORKLOADS[cfg])
     w["base"] = base
+    w["order"] = int(order)         # 1: the first-order algorithm (signature_algs.py:8-35); > 1: the higher-order one (:37-74)
     n_gpus = world
     if n_gpus > 1 and (weak or cfg == "c2"):
         w["N"] = int(round(4096 * math.sqrt(n_gpus) / 64.0)) * 64
@@ -371,7 +372,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     Zh = make_tensors(w, increments) if T else None
     Z = torch.as_tensor(Zh, device=dev).to(tdt) if T else None
     cls = kernels.SignatureLinear if base == "linear" else kernels.SignatureRBF
-    kern = cls(L * D, D, M, lengthscales=lengthscales(w))
+    kern = cls(L * D, D, M, lengthscales=lengthscales(w), order=int(order))
     gram = parallel.ShardedGram(kern, N, dev, rank, world, chunks=chunks) if not T else None
     covs = parallel.ShardedCovs(kern, N, dev, rank, world) if T else None      # world == 1: kern.K_tens_n_seq_covs itself
 
@@ -527,9 +528,9 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
         "scaling": "weak" if (n_gpus == 1 or weak or cfg == "c2") else "strong", "vs_baseline": None,
         "dtype": w["dtype"], "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[{BASELINE_INDEX[cfg]}]: {what}{cname}, N={N}, L={L}, d={D}, num_levels={M}, "
-                               f"order=1, normalization=on, {'fp64' if w['dtype'] == 'f64' else 'fp32'}, "
+                               f"order={int(order)}, normalization=on, {'fp64' if w['dtype'] == 'f64' else 'fp32'}, "
                                f"{'white-noise' if w['data'] == 'white' else 'random-walk'} inputs",
-                   "name": cfg, "N": N, "L": L, "d": D, "num_levels": M, "order": 1, "normalization": True,
+                   "name": cfg, "N": N, "L": L, "d": D, "num_levels": M, "order": int(order), "normalization": True,
                    "pairs_per_step": pairs,
                    "parallelism": ((f"sequence blocks x{n_gpus} (Z replicated), Kzx / Kxx-diag blocks gathered to rank 0 over RCCL" if T else
                                     f"owned-row blocks x{n_gpus}, {chunks} chunks per rank, compact (N/2+1 wide) rows gathered "
@@ -597,17 +598,17 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     return res
 
 
-SECONDARY = [("c2", "linear", False, True), ("c2", "rbf", False, False), ("c3", "rbf", False, False), ("c3", "rbf", True, False),
-             ("c5", "rbf", False, False)]
+SECONDARY = [("c2", "linear", False, True, 1), ("c2", "linear", False, False, 5), ("c2", "rbf", False, False, 1), ("c3", "rbf", False, False, 1),
+             ("c3", "rbf", True, False, 1), ("c5", "rbf", False, False, 1)]
 
 
 def secondary_lines(dev):
     """The other single-GPU configurations, 3 warm-up + 10 steps each, as short records beside the headline."""
     out = []
-    for cfg, base, inc, lattice in SECONDARY:
-        name = cfg + "-" + base + ("-increments" if inc else "") + ("-lattice" if lattice else "")
+    for cfg, base, inc, lattice, order in SECONDARY:
+        name = cfg + "-" + base + ("-increments" if inc else "") + ("-lattice" if lattice else "") + ("-order%d" % order if order > 1 else "")
         try:
-            r = run_workload(cfg, base, inc, 10, 3, dev, host_e2e=False, traffic="static", lattice=lattice)
+            r = run_workload(cfg, base, inc, 10, 3, dev, host_e2e=False, traffic="static", lattice=lattice, order=order)
             rf = r["roofline"]
             out.append({"name": name, "workload": r["config"]["workload"], "dtype": r["dtype"], "value": r["value"], "unit": r["unit"],
                         "ms_per_step": r["ms_per_step"], "kernel_ms": rf["kernel_ms_per_launch"] * rf["launches_per_step"],

@@ -70,10 +70,12 @@ def test_default_line_carries_the_measurement():
     assert "sig_gram_dma_kernel" in rf["traffic_source"]["kernel"]
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     names = [s["name"] for s in line["secondary"]]
-    assert names == ["c2-linear-lattice", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf"]
+    assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf"]
+    ho = line["secondary"][1]                           # the higher-order algorithm at order = num_levels: the same contraction, the same time
+    assert ho["bound"] == "mfma" and ho["ms_per_step"] < 1.3 * line["ms_per_step"]
     lat = line["secondary"][0]                          # the same Gram through the pair recursion: vector-issue bound, about twice the time
     assert lat["bound"] == "valu-issue" and 0.3 < lat["issue_frac"] <= 1.05 and lat["ms_per_step"] > line["ms_per_step"]
     for s in line["secondary"]:
         assert "error" not in s, s
         assert s["rel_err"] <= (1e-4 if s["dtype"] == "f32" else 1e-6) and s["ms_per_step"] > 0 and s["clock_ghz"] > 1.0
-    assert line["secondary"][2]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
+    assert line["secondary"][3]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
