@@ -1160,7 +1160,7 @@ static int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const voi
                  int L1, int L2, int return_levels, void* out, bool timed, int x_squared = 0, int64_t row_begin = 0,
                  int64_t row_end = 0, int compact = 0) {
     if (L1 < 1 || L2 < 1) return fail(c, GPSIG_ERR_INVALID, "sequence length must be >= 1");
-    if (sizeof(TT) == 8) {      // the linear kernel's Gram as one contraction of explicit level features, where that is the cheaper evaluation
+    {       // the linear / cosine kernel's Gram as one contraction of explicit level features, where that is the cheaper evaluation (float32 calls: computed in float64)
         bool done = false;
         CHK(sig_features_K(c, p, raw, X, X2, N1, N2, L1, L2, return_levels, out, timed, x_squared, row_begin, row_end, compact, &done));
         if (done) return GPSIG_OK;

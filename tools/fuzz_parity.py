@@ -34,7 +34,7 @@ def main():
         lags = int(rng.choice([0, 0, 0, 1, 2])) if base != "poly" else 0
         L1, L2 = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 130])), int(rng.choice([1, 2, 5, 17, 32, 65, 90]))
         N1, N2 = int(rng.integers(1, 40)), int(rng.integers(1, 20))
-        if base == "linear" and rng.integers(0, 3) == 0:          # sizes that cross the contraction's 128-wide tiles and its depth pieces
+        if base in ("linear", "cosine") and rng.integers(0, 3) == 0:          # sizes that cross the contraction's 128-wide tiles and its depth pieces
             N1, N2 = int(rng.choice([127, 129, 200, 300])), int(rng.choice([1, 64, 130, 260]))
             L1, L2 = min(L1, 33), min(L2, 32)
         norm, diff = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) > 0)
