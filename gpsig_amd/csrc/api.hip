@@ -621,7 +621,8 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     // float32 calls too: computed in float64 (the matrix cores' own precision), inputs widened and the result rounded -- 29 -> 1.4 ms at
     // d = 16, num_levels = 3, and closer to the reference than a float32 recursion; not for row blocks (float64 only)
     const bool f32 = p->dtype == GPSIG_F32;
-    if (c->sig_features == 0 || !(p->dtype == GPSIG_F64 || f32) || !(p->base_kernel == GPSIG_BASE_LINEAR || cosine) || x_squared) return GPSIG_OK;
+    if (c->sig_features == 0 || !(p->dtype == GPSIG_F64 || f32) || !(p->base_kernel == GPSIG_BASE_LINEAR || cosine)) return GPSIG_OK;
+    if (x_squared && (X2 == nullptr || raw || !p->normalization)) return GPSIG_OK;       // (the quirk is a cross Gram's: its X side only)
     if (f32 && row_end > 0) return GPSIG_OK;
     if (c->shard_n > 1) return GPSIG_OK;          // gpsig_set_shard: "entries outside the shard are left untouched" is the pair kernels' contract
     const int M = p->num_levels;
@@ -708,13 +709,14 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         out32 = out; X = x64; X2 = sym ? nullptr : y64; out = o64;
     }
     const int normalize = (!raw && p->normalization) ? 1 : 0;
-    auto features = [&](const void* Xs, int64_t N, int L, void* phi) -> int {
+    auto features = [&](const void* Xs, int64_t N, int L, void* phi, bool squared) -> int {
         SigFeatArgs A;
         memset(&A, 0, sizeof(A));
         A.X = static_cast<const double*>(Xs); A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = s;
         A.w = w; A.normalize = normalize; A.jitter = p->jitter; A.Phi = static_cast<double*>(phi); A.ld = ld; A.dlev = nullptr;
         A.order = p->order;
         A.unit_points = cosine ? 1 : 0;
+        A.norm_squared = squared ? 1 : 0;
         const unsigned grid = unsigned(N < 4096 ? N : 4096);
         hipError_t e = ffn(A, grid, sig_features_lds_bytes(d, M, L), c->stream);
         if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
@@ -734,14 +736,14 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         mix(p->variances, sizeof(double) * (M + 1));
         if (p->lengthscales) mix(p->lengthscales, sizeof(double) * p->num_features);
         if (p->num_lags > 0) { mix(p->lags, sizeof(double) * p->num_lags); mix(p->gamma, sizeof(double) * (p->num_lags + 1)); }
-        const int64_t tail[4] = {N1, L1, raw ? 1 : 0, ld};
+        const int64_t tail[4] = {N1, L1, (raw ? 1 : 0) + (x_squared ? 2 : 0), ld};
         mix(tail, sizeof(tail));
     }
     const bool reuse = c->sf_keep && c->sf_valid && c->sf_X == X_given && c->sf_phi == phi1 && c->sf_key == key;
-    if (N1 > 0 && !reuse) CHK(features(X, N1, L1, phi1));
+    if (N1 > 0 && !reuse) CHK(features(X, N1, L1, phi1, x_squared != 0));
     c->sf_valid = c->sf_keep != 0 && N1 > 0;
     c->sf_X = X_given; c->sf_phi = phi1; c->sf_key = key;
-    if (!sym && N2 > 0) CHK(features(X2, N2, L2, phi2));
+    if (!sym && N2 > 0) CHK(features(X2, N2, L2, phi2, false));
     if (NA <= 0 || NB <= 0) { *done = true; return GPSIG_OK; }
     // level sums of the weights: the exact diagonal of the normalised symmetric Gram (kernels.py:430-433: (K_ii + jitter) / (K_ii + jitter))
     const int nlev = return_levels ? M + 1 : 1;

@@ -60,6 +60,7 @@ struct SigFeatArgs {
     double* dlev;           // (N, M+1) raw level diagonals |Phi_m|^2 (level 0: 1), or NULL
     int order;              // 1: signature_algs.py:8-35; > 1: the higher-order algorithm (:37-74), see sig_horner below
     int unit_points;        // SignatureCosine (kernels.py:820-828): <x, y> / (|x| |y|) is the linear kernel of the points x / |x|
+    int norm_squared;       // this side is divided by (|Phi_m|^2 + jitter), not by its square root (K_seq_n_seq_covs: kernels.py:713 + :750)
 };
 
 // Higher orders (signature_algs.py:37-74: a step may repeat an index up to `order` times, with 1 / k! for k repeats).  For the linear
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_kernel(const S
         auto scale_of = [&](int m) {
             const double w = A.w ? A.w[m] : 1.0;
             const double nm = m == 0 ? 1.0 : norms[m];
-            return A.normalize ? sqrt(w / (nm + A.jitter)) : sqrt(w);
+            return A.normalize ? (A.norm_squared ? sqrt(w) / (nm + A.jitter) : sqrt(w / (nm + A.jitter))) : sqrt(w);
         };
         // levels 1 .. M-1 from their owners, level M from everybody
         {
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_features_sib_kernel(con
         auto scale_of = [&](int m) {
             const double w = A.w ? A.w[m] : 1.0;
             const double nm = m == 0 ? 1.0 : norms[m];
-            return A.normalize ? sqrt(w / (nm + A.jitter)) : sqrt(w);
+            return A.normalize ? (A.norm_squared ? sqrt(w) / (nm + A.jitter) : sqrt(w / (nm + A.jitter))) : sqrt(w);
         };
         int off = 0;
 #pragma unroll

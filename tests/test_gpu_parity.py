@@ -979,6 +979,17 @@ def test_linear_gram_as_feature_contraction(K):
         for a, b, w in zip(got[1], got[0], want):
             assert relerr(a, w) <= TOL and relerr(a, b) <= 1e-10, (cs, relerr(a, w), relerr(a, b))
         assert np.array_equal(got[1][0], got[1][0].T)                               # mirrored, not recomputed
+        if L2 == L:         # the inducing-sequence covariances (kernels.py:674-761), including the X side divided twice (:713 + :750)
+            try:
+                ctx.set_option("sig_features", 1)
+                for full in (False, True):
+                    for lev in (False, True):
+                        g3 = kx.K_seq_n_seq_covs(Y.reshape(N2, L2, -1), X, full_X2_cov=full, return_levels=lev)
+                        w3 = ko.K_seq_n_seq_covs(Y.reshape(N2, L2, -1), X, full_X2_cov=full, return_levels=lev)
+                        for a, w in zip(g3, w3):
+                            assert relerr(a, w) <= TOL, (cs, full, lev, relerr(a, w))
+            finally:
+                ctx.set_option("sig_features", -1)
         try:            # the register-staged form of the contraction adds the same products in the same order as the LDS-DMA form
             ctx.set_option("sig_features", 1)
             ctx.set_option("sig_gemm_dma", 0)
