@@ -640,7 +640,12 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         // (the higher-order pair kernels carry order^2 grids per level: 34 to 150 times the first order's time at configs[1]'s size)
         const double lattice = double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0) * (p->order > 1 ? 8.0 : 1.0) * (cosine ? 1.5 : 1.0) * (f32 ? 0.5 : 1.0), feat = 2.0 * double(F);      // (the float32 pair kernels run at twice the float64 ones' rate)
         const double pairs = sym ? double(N1) * N1 / 2 : double(N1) * N2;
-        if (!(feat * 0.6 < lattice) || pairs < 16384.0) return GPSIG_OK;
+        if (!(feat * 0.6 < lattice)) return GPSIG_OK;
+        // small problems: the contraction is three or four launches with a floor of ~230 us (one depth piece of >= 64 slabs), the
+        // pair kernels one launch with a floor of ~100 us; rates as measured (tools/bench_crossover.py: the crossover sits near
+        // 50,000 pairs at the headline's sequence shape, near 5,000 at d = 16, num_levels = 3)
+        const double t_lattice = 100e-6 + pairs * lattice / (d > 8 ? 12.5e12 : 25e12), t_features = 230e-6 + pairs * feat / 60e12;
+        if (pairs < 2048.0 || !(t_features < t_lattice)) return GPSIG_OK;
     }
     const size_t lds = sig_features_lds_bytes(d, M, L1 > L2 ? L1 : L2);
     if (lds > 150 * 1024) return GPSIG_OK;

@@ -106,8 +106,8 @@ def test_replay_of_the_feature_contraction(env):
     scratch exists) records and replays like the pair recursion."""
     torch, K, dev = env
     rng = np.random.default_rng(6)
-    N, N2, L, d, M = 200, 150, 12, 3, 4               # 20,100 / 30,000 pairs: the planner's feature route
-    kern = K.SignatureLinear(L * d, d, M, lengthscales=[0.8, 1.1, 1.3])
+    N, N2, L, d, M = 400, 300, 64, 8, 3               # 80,200 / 120,000 pairs of 64-point sequences: the planner's feature route
+    kern = K.SignatureLinear(L * d, d, M, lengthscales=0.8 + 0.1 * np.arange(d))
     X = torch.tensor(rng.standard_normal((N, L * d)) * 0.4, device=dev)
     X2 = torch.tensor(rng.standard_normal((N2, L * d)) * 0.4, device=dev)
     g1, g2 = kern.graphed("K", X), kern.graphed("K", X, X2)
