@@ -348,6 +348,23 @@ VALU_PER_STEP = {("c2", "linear"): 89, ("c4", "linear"): 89, ("c2", "rbf"): 174,
 SIMDS = 1024
 
 
+def depth_pieces(n, nslab):
+    """Workgroups per tile along the contraction's depth for a symmetric Gram of n sequences: the library's model (csrc/api.hip,
+    sig_features_K), restated here only to price the partial sums in `algorithmic_bytes_per_launch`."""
+    nt = (n + 127) // 128
+    tiles = nt * (nt + 1) // 2
+    rb = 8.0 * n * n * 0.5
+    best, pieces = 1e300, 1
+    for ns in range(1, 129):
+        if ns * 8 > nslab + 7:
+            break
+        w, pp = tiles * ns, nslab / ns
+        t = (pp * 1.8e-6 + 10e-6 if w <= 256 else math.ceil(w / 512) * (pp * 3.6e-6 + 10e-6)) + (2 * ns * rb / 3e12 if ns > 1 else 0)
+        if t < best * 0.999:
+            best, pieces = t, ns
+    return max(pieces, 4) if (tiles > 1024 and nslab >= 32) else pieces
+
+
 FP64_MATRIX_PEAK_TFLOPS = 78.6          # MI355X_MICROARCH.md: dense float64 MFMA peak (= the vector peak) at 2.4 GHz
 
 
@@ -486,7 +503,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
                 "frac_at_measured_clock": (tf / (FP64_MATRIX_PEAK_TFLOPS * ghz / 2.4)) if ghz else None,
                 "flops_per_evaluated_pair": fl_launch / evaluated_launch,
                 # what HBM has to see at least: the feature matrix once, the partial sums of the depth splits once
-                "algorithmic_bytes_per_launch": 8.0 * (N / n_gpus) * ld + 8.0 * evaluated_launch * max(1, round(ld / 16 / 146)),
+                "algorithmic_bytes_per_launch": 8.0 * (N / n_gpus) * ld + 8.0 * evaluated_launch * depth_pieces(N, ld // 16),
                 "other_kernels_in_step": "sig_features_kernel (the level features of every sequence), sig_gram_reduce_sym_kernel (adds the "
                                          "depth splits in a fixed order, mirrors); kernel_share_of_step says how much they and the launches cost",
                 "kernel_share_of_step": per_launch_ms * launches_per_step / (dt / steps * 1e3)}

@@ -641,11 +641,13 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         const double lattice = double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0) * (p->order > 1 ? 8.0 : 1.0) * (cosine ? 1.5 : 1.0) * (f32 ? 0.5 : 1.0), feat = 2.0 * double(F);      // (the float32 pair kernels run at twice the float64 ones' rate)
         const double pairs = sym ? double(N1) * N1 / 2 : double(N1) * N2;
         if (!(feat * 0.6 < lattice)) return GPSIG_OK;
-        // small problems: the contraction is three or four launches with a floor of ~230 us (one depth piece of >= 64 slabs), the
-        // pair kernels one launch with a floor of ~100 us; rates as measured (tools/bench_crossover.py: the crossover sits near
-        // 50,000 pairs at the headline's sequence shape, near 5,000 at d = 16, num_levels = 3)
-        const double t_lattice = 100e-6 + pairs * lattice / (d > 8 ? 12.5e12 : 25e12), t_features = 230e-6 + pairs * feat / 60e12;
-        if (pairs < 2048.0 || !(t_features < t_lattice)) return GPSIG_OK;
+        // small problems: the contraction is three or four launches with a floor of ~60 us plus its feature kernel (60 us per sequence
+        // and CU at 32,768 top-level features), the pair kernels one launch with a floor of ~100 us; rates as measured
+        // (tools/bench_crossover.py, profiles/r03_crossover.txt)
+        const double seqs = double(N1) + (sym ? 0.0 : double(N2)), t_seq = 60e-6 * double(sig_ipow(d, M)) / 32768.0;
+        const double t_feat_kernel = ceil(seqs / 256.0) * t_seq > 15e-6 ? ceil(seqs / 256.0) * t_seq : 15e-6;
+        const double t_lattice = 100e-6 + pairs * lattice / (d > 8 ? 12.5e12 : 25e12), t_features = 60e-6 + t_feat_kernel + pairs * feat / 60e12;
+        if (pairs < 1024.0 || !(t_features < t_lattice)) return GPSIG_OK;
     }
     const size_t lds = sig_features_lds_bytes(d, M, L1 > L2 ? L1 : L2);
     if (lds > 150 * 1024) return GPSIG_OK;
@@ -658,21 +660,26 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     const int ntiles = symtiles ? nti * (nti + 1) / 2 : nti * ntj;
     const int nslab_all = int((ld + SG_BK - 1) / SG_BK);
     // Workgroups per tile along the depth.  One piece per tile leaves a launch of a few hundred tiles with a nearly empty last round
-    // (528 tiles on the chip's 512 workgroup slots: two rounds); many pieces cost a partial sum each to write and add (the whole
-    // result once per piece).  The count is a function of the depth and of the TOTAL number of sequences of the Gram alone -- not of
-    // the tile count of this call -- so that the order in which an entry's products are added is the same whichever tile, row block
-    // or rank computes it: row blocks (gpsig_kernel_K_symm_rows*) reassemble the one-call Gram bit for bit.  Aim: ~8,448 workgroups
-    // for the full symmetric problem (16 pieces at N = 4,096), never fewer than 4 pieces (a rank's chunk of a large Gram is a launch
-    // of ~1,000 tiles), pieces of at least 64 slabs.
-    int nsplit;
+    // (528 tiles on the chip's 512 workgroup slots: two rounds) and a launch of a few tiles with most of the chip idle; many pieces cost
+    // a partial sum each to write and add (the whole result once per piece).  The count minimises a small model of the launch --
+    // rounds of 512 workgroups x (slabs per piece x 3.6 us + 10 us; 1.8 us per slab while no CU holds two workgroups) + 2 x pieces x result bytes at 3 TB/s --
+    // evaluated for the FULL problem (the Gram's total size and the depth), not for the tiles of this call: the order in which an
+    // entry's products are added is then the same whichever tile, row block or rank computes it, and row blocks
+    // (gpsig_kernel_K_symm_rows*) reassemble the one-call Gram bit for bit.  16 pieces at N = 4,096 (configs[1]); large Grams keep
+    // at least 4 (a rank's chunk of one is a launch of ~1,000 tiles); pieces of at least 8 slabs.
+    int nsplit = 1;
     {
         const int64_t nt_full = (N1 + SG_BM - 1) / SG_BM;
         const int64_t tiles_full = sym ? nt_full * (nt_full + 1) / 2 : nt_full * ((N2 + SG_BN - 1) / SG_BN);
-        int64_t want = (8448 + tiles_full / 2) / (tiles_full > 0 ? tiles_full : 1);
-        if (want < 4) want = 4;
-        if (want > 32) want = 32;
-        const int64_t by_depth = nslab_all / 64 > 0 ? nslab_all / 64 : 1;
-        nsplit = int(want < by_depth ? want : by_depth);
+        const double result_bytes = 8.0 * double(N1) * double(sym ? N1 : N2) * (sym ? 0.5 : 1.0);
+        double best = 1e300;
+        for (int ns = 1; ns <= 128 && ns * 8 <= nslab_all + 7; ++ns) {
+            const double wgs = double(tiles_full) * ns, per_piece = double(nslab_all) / ns;
+            const double t = (wgs <= 256.0 ? per_piece * 1.8e-6 + 10e-6 : ceil(wgs / 512.0) * (per_piece * 3.6e-6 + 10e-6)) +
+                             (ns > 1 ? 2.0 * ns * result_bytes / 3e12 : 0.0);          // (a piece's sum is written, then read)
+            if (t < best * 0.999) { best = t; nsplit = ns; }
+        }
+        if (tiles_full > 1024 && nsplit < 4 && nslab_all >= 32) nsplit = 4;
     }
     const size_t part_one = sizeof(double) * size_t(NA) * NB;
     while (nsplit > 1 && part_one * size_t(nsplit) > (size_t(40) << 30)) --nsplit;       // (the exception to the rule above: 40 GiB of partial sums)
