@@ -149,7 +149,11 @@ static __global__ void lr_gather_landmarks_kernel(const int64_t* __restrict__ id
 // n/2 disjoint index pairs at once: the angles from the diagonal 2 x 2 blocks, then every 2 x 2 block of A (both rotations at once) and
 // the columns of V -- two barriers.
 constexpr int LR_JACOBI_MAX = 64;
-constexpr int LR_JACOBI_THREADS = 1024;
+#ifndef LR_JACOBI_NT
+#define LR_JACOBI_NT 1024
+#endif
+constexpr int LR_JACOBI_THREADS = LR_JACOBI_NT;
+constexpr int LR_JACOBI_ITEMS = ((LR_JACOBI_MAX / 2) * (LR_JACOBI_MAX / 2) + LR_JACOBI_MAX * (LR_JACOBI_MAX / 2) + LR_JACOBI_THREADS - 1) / LR_JACOBI_THREADS;
 // 1 / sqrt(x), x in [1, 2]: v_rsq_f64 (about 2^-26) and two Newton steps -- the rotation's cosine; any angle close to the annihilating
 // one makes the iteration converge, but c^2 + s^2 must be 1 to rounding for V to stay orthogonal
 __device__ __forceinline__ double lr_rsqrt(double x) {
@@ -177,10 +181,10 @@ static __global__ void __launch_bounds__(LR_JACOBI_THREADS) lr_jacobi_eig_kernel
     }
     const int np = n + (n & 1), m = np / 2;              // players (one bye when n is odd), pairs per step
     // what this thread updates in a step, decoded once: items [0, m*m) are the 2 x 2 blocks of A (pair k of rows, pair k2 of columns),
-    // items [m*m, m*m + n*m) one row of V against one pair; at most two items per thread (m <= 32, n <= 64, 1024 threads)
-    int it_a[2], it_b[2], it_kind[2];
+    // items [m*m, m*m + n*m) one row of V against one pair; LR_JACOBI_ITEMS per thread at most (m <= 32, n <= 64)
+    int it_a[LR_JACOBI_ITEMS], it_b[LR_JACOBI_ITEMS], it_kind[LR_JACOBI_ITEMS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < LR_JACOBI_ITEMS; ++u) {
         const int e = tid + u * nt;
         it_kind[u] = e < m * m ? 0 : (e < m * m + n * m ? 1 : -1);
         const int f = e < m * m ? e : e - m * m, dv = e < m * m ? m : n;
@@ -227,7 +231,7 @@ static __global__ void __launch_bounds__(LR_JACOBI_THREADS) lr_jacobi_eig_kernel
             // A <- J^T A J in one pass: the 2 x 2 block (rows of pair k, columns of pair k2) takes pair k's rotation from the left and
             // pair k2's from the right; the blocks of a step are disjoint.  V <- V J alongside.
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < LR_JACOBI_ITEMS; ++u) {
                 if (it_kind[u] == 0) {
                     const int k = it_a[u], k2 = it_b[u];
                     if (pq[k] < 0 || pq[k2] < 0) continue;      // the index that sits out (odd n): handled below
