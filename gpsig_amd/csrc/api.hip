@@ -614,7 +614,8 @@ int timing_begin_any(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1, bool* on) {
 // L1 L2 (2d + 3M - 1) on the vector unit at about 0.6 of the GEMM's efficiency -- and the feature matrices fit.  *done = false
 // leaves the call to the lattice kernels.  row_end > 0: the owned entries of rows [row_begin, row_end) (multi-GPU row blocks).
 int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X, const void* X2, int64_t N1, int64_t N2, int L1, int L2,
-                   int return_levels, void* out, bool timed, int x_squared, int64_t row_begin, int64_t row_end, int compact, bool* done) {
+                   int return_levels, void* out, bool timed, int x_squared, int64_t row_begin, int64_t row_end, int compact, bool* done,
+                   bool row_block_call = false) {
     *done = false;
     // the linear kernel, and the cosine kernel as the linear kernel of the unit vectors x / |x| (kernels.py:820-828)
     const bool cosine = p->base_kernel == GPSIG_BASE_COSINE;
@@ -623,7 +624,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     const bool f32 = p->dtype == GPSIG_F32;
     if (c->sig_features == 0 || !(p->dtype == GPSIG_F64 || f32) || !(p->base_kernel == GPSIG_BASE_LINEAR || cosine)) return GPSIG_OK;
     if (x_squared && (X2 == nullptr || raw || !p->normalization)) return GPSIG_OK;       // (the quirk is a cross Gram's: its X side only)
-    if (f32 && row_end > 0) return GPSIG_OK;
+    if (f32 && (row_end > 0 || row_block_call)) return GPSIG_OK;
     if (c->shard_n > 1) return GPSIG_OK;          // gpsig_set_shard: "entries outside the shard are left untouched" is the pair kernels' contract
     const int M = p->num_levels;
     if (M < 2 || p->order < 1 || p->order > M) return GPSIG_OK;
@@ -651,7 +652,8 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     }
     const size_t lds = sig_features_lds_bytes(d, M, L1 > L2 ? L1 : L2);
     if (lds > 150 * 1024) return GPSIG_OK;
-    const bool rows = row_end > 0;
+    // (row_block_call: an EMPTY row block -- a rank that owns no rows -- takes the decisions of a non-empty one and returns before launching)
+    const bool rows = row_end > 0 || row_block_call;
     const int64_t NA = rows ? row_end - row_begin : N1, H = N1 / 2;
     int64_t NB = sym ? N1 : N2;
     if (rows) NB = (NA + H < N1) ? NA + H : N1;
@@ -691,7 +693,9 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         auto grow = [&](int id, size_t bytes) { return bytes > c->buf[id].cap ? bytes + bytes / 8 + 256 : size_t(0); };
         const size_t extra = grow(B_SF0, sizeof(double) * size_t(ld) * N1 + 64) + (sym ? 0 : grow(B_SF1, sizeof(double) * size_t(ld) * N2 + 64)) +
                              grow(B_SF2, part_one * size_t(nsplit) + 64);
-        if (extra > (size_t(1) << 30) && !c->capturing) {
+        // (not for row blocks: the ranks of a sharded evaluation must all take the same route whatever each device has left -- there a
+        // full device is an allocation error of that rank, not a silent change of route that the other ranks do not follow)
+        if (extra > (size_t(1) << 30) && !c->capturing && !rows) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 size_t held = 0;                // (a buffer that grows is freed first)
@@ -700,6 +704,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
             }
         }
     }
+    if (rows && NA <= 0) { *done = true; return GPSIG_OK; }        // an empty row block: the route is decided, there is nothing to compute
     const double* w = nullptr;
     if (!raw) CHK(upload_weights(c, p, &w));
     ScaleParams s;
@@ -1591,9 +1596,14 @@ static int e_kernel_K_symm_rows(gpsig_ctx* c, const gpsig_params* p, const void*
         CHK(seq_K_device(c, p, false, dX, nullptr, N, N, L, L, 0, dout, true, 0, row_begin, row_end, compact));
     } else {
         // an empty block still reports whether the shape is one the row-block kernels take: every rank of a sharded evaluation
-        // must reach the same verdict, also the one that owns no rows
-        SeqPlanned pl;
-        CHK(plan_seq(c, p, p->num_features * (p->num_lags + 1), L, &pl, N * (N / 2 + 1)));
+        // must reach the same verdict, also the one that owns no rows -- so it asks the same routes in the same order as seq_K_device
+        // does for a block with rows: the feature contraction first (it takes shapes the pair kernels refuse), then the pair kernels
+        bool done = false;
+        CHK(sig_features_K(c, p, false, dX, nullptr, N, N, L, L, 0, dout, false, 0, row_begin, row_end, compact, &done, true));
+        if (!done) {
+            SeqPlanned pl;
+            CHK(plan_seq(c, p, p->num_features * (p->num_lags + 1), L, &pl, N * (N / 2 + 1)));
+        }
     }
     CHK(out_done(c, out_rows, dout, ob));
     return finish(c);
@@ -1856,6 +1866,7 @@ void gpsig_ctx_destroy(gpsig_ctx* c) {
     }
     if (c->probe_stop) (void)hipHostFree(const_cast<int*>(c->probe_stop));
     solver_release(c->blas_handle);
+    for (gpsig_lr_state* st : c->lr_states) { st->device = c->device; st->ctx = nullptr; }      // outlive the context as plain memory blocks
     delete c;
 }
 
@@ -2605,9 +2616,11 @@ int gpsig_lr_draw(gpsig_ctx* c, const gpsig_params* p, int32_t num_components, i
         if (!st) return fail(c, GPSIG_ERR_NOMEM, "out of host memory");
         st->ctx = c;
     }
+    if (!st->ctx) return fail(c, GPSIG_ERR_INVALID, "the state's context has been destroyed");
     st->c = num_components; st->d_eff = d_eff; st->r = rank_bound; st->nsk = nsk; st->sparsity = sparsity;
     CHK(no_capture(c, "a low-rank draw may have to allocate"));
     if (lr_state_layout(st, M) != GPSIG_OK) { if (!*inout) delete st; return fail(c, GPSIG_ERR_NOMEM, "hipMalloc failed for the low-rank state"); }
+    if (!*inout) c->lr_states.push_back(st);
     *inout = st;
     const PhiloxKey key{uint32_t(seed), uint32_t(seed >> 32)};
     const int cc = st->c;
@@ -2678,22 +2691,32 @@ int gpsig_lr_draw(gpsig_ctx* c, const gpsig_params* p, int32_t num_components, i
     }
     HIPCHK(c, hipEventRecord(c->side_join, ss));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->side_join, 0));
+    // A failed draw (eigensolver not converged, a projection over its capacity) must not give silently wrong features: nothing on the
+    // evaluation path reads the flags back (that would be a host synchronisation per evaluation), so the whitening is turned into NaNs
+    // and every feature, product and covariance computed from this state is NaN; gpsig_lr_state_sizes reports the cause.
+    hipLaunchKernelGGL(lr_poison_kernel, dim3(unsigned((int64_t(cc) * cc + 255) / 256)), dim3(256), 0, c->stream, static_cast<const int*>(st->info), cc, st->Wh, st->WhT);
+    HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
 }
 
 void gpsig_lr_state_destroy(gpsig_lr_state* st) {
     if (!st) return;
-    if (st->block) {
-        (void)hipSetDevice(st->ctx->device);
-        (void)hipStreamSynchronize(st->ctx->stream);
-        (void)hipFree(st->block);
+    if (gpsig_ctx* c = st->ctx) {            // still attached: wait for what reads the block, leave the context's registry
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        for (size_t i = 0; i < c->lr_states.size(); ++i)
+            if (c->lr_states[i] == st) { c->lr_states.erase(c->lr_states.begin() + i); break; }
+    } else {
+        (void)hipSetDevice(st->device);      // the context went first (it synchronised its streams then): only the block is left
     }
+    if (st->block) (void)hipFree(st->block);
     delete st;
 }
 
 // sizes[0..4] = c, d_eff, r, number of projections, Jacobi sweeps taken (0: rocSOLVER); nnz[i] = entries of projection i.  Waits for the draw.
 int gpsig_lr_state_sizes(gpsig_ctx* c, const gpsig_lr_state* st, int32_t* sizes, int32_t* nnz) {
     if (!c || !st || !sizes) return GPSIG_ERR_INVALID;
+    if (st->ctx != c) return fail(c, GPSIG_ERR_INVALID, "the low-rank state belongs to another (or a destroyed) context");
     HIPCHK(c, hipSetDevice(c->device));
     sizes[0] = st->c; sizes[1] = st->d_eff; sizes[2] = st->r; sizes[3] = st->nsk; sizes[4] = 0;
     int info[4] = {0, 0, 0, 0};
@@ -2712,6 +2735,7 @@ int gpsig_lr_state_sizes(gpsig_ctx* c, const gpsig_lr_state* st, int32_t* sizes,
 int gpsig_lr_state_export(gpsig_ctx* c, const gpsig_lr_state* st, double* landmarks, double* jitter_diag, double* whitening, double* eigenvalues,
                           const gpsig_sketch* sketches) {
     if (!c || !st) return GPSIG_ERR_INVALID;
+    if (st->ctx != c) return fail(c, GPSIG_ERR_INVALID, "the low-rank state belongs to another (or a destroyed) context");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t cc = size_t(st->c);
     if (landmarks) HIPCHK(c, hipMemcpyAsync(landmarks, st->S, sizeof(double) * cc * st->d_eff, hipMemcpyDeviceToHost, c->stream));

@@ -134,6 +134,9 @@ struct gpsig_ctx {
     hipStream_t side_stream = nullptr;
     hipEvent_t side_fork = nullptr, side_join = nullptr;
     volatile int* probe_stop = nullptr;        // pinned host memory the wave polls: raised by gpsig_clock_probe_read
+    // the low-rank states drawn on this context (gpsig_lr_draw) that are still alive: gpsig_ctx_destroy detaches them, so that a
+    // state destroyed after its context only frees its block instead of touching a stream that no longer exists
+    std::vector<struct gpsig_lr_state*> lr_states;
 };
 
 struct gpsig_graph {

@@ -391,10 +391,21 @@ static __global__ void lr_transpose_kernel(const double* __restrict__ A, int n, 
     if (e < n * n) At[(e % n) * n + e / n] = A[e];
 }
 
+// a failed draw poisons the whitening (and with it every feature computed from the state): info[0] eigensolver, info[1] capacity
+__global__ void lr_poison_kernel(const int* __restrict__ info, int c, double* __restrict__ Wh, double* __restrict__ WhT) {
+    if (info[0] == 0 && info[1] == 0) return;
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < int64_t(c) * c) {
+        const double nan = __longlong_as_double(0x7ff8000000000000ll);
+        Wh[i] = nan; WhT[i] = nan;
+    }
+}
+
 }  // namespace gpsig
 
 struct gpsig_lr_state {
-    gpsig_ctx* ctx = nullptr;
+    gpsig_ctx* ctx = nullptr;       // NULL once the context was destroyed (gpsig_ctx_destroy detaches its states)
+    int device = 0;                 // ... and then the device the block lives on
     int c = 0, d_eff = 0, r = 0, nsk = 0, sparsity = 0;
     void* block = nullptr;
     size_t bytes = 0;

@@ -193,13 +193,19 @@ class DeviceLowRankState:
 
     def __init__(self, ctx, num_components, rank_bound, num_sketches):
         self.ctx, self._h = ctx, C.c_void_p()
+        self._lib = ctx._lib                      # (the library handle outlives the context object's own handle)
         self.num_components, self.rank_bound, self.num_sketches = int(num_components), int(rank_bound), int(num_sketches)
+
+    def close(self):
+        """Free the device block.  Safe after the context was closed: gpsig_ctx_destroy detaches the states drawn on it, and a
+        detached state only frees its memory (it never touches the context's stream again)."""
+        if self._h:
+            h, self._h = self._h, C.c_void_p()
+            self._lib.gpsig_lr_state_destroy(h)
 
     def __del__(self):
         try:
-            if self._h:
-                self.ctx._lib.gpsig_lr_state_destroy(self._h)
-                self._h = C.c_void_p()
+            self.close()
         except Exception:
             pass
 
@@ -211,8 +217,11 @@ class DeviceLowRankState:
         return lr
 
     def export(self):
-        """Host copies of what was drawn, as a LowRankState (waits for the stream)."""
+        """Host copies of what was drawn, as a LowRankState (waits for the stream).  Raises if the draw failed (eigensolver not
+        converged / a projection over its capacity: the evaluations from such a state are NaN) or the context was closed."""
         lib, ctx = self.ctx._lib, self.ctx
+        if getattr(ctx, "_h", None) is None:
+            raise RuntimeError("the library context this low-rank state was drawn on has been closed")
         sizes, nnz = (C.c_int32 * 5)(), (C.c_int32 * max(self.num_sketches, 1))()
         ctx.check(lib.gpsig_lr_state_sizes(ctx._h, self._h, sizes, nnz))
         c, d_eff, r, nsk, self.jacobi_sweeps = (int(v) for v in sizes)
@@ -447,7 +456,7 @@ class SignatureKernel:
             X, _ = self._slice(X, None)
         if self.low_rank and not self.normalization:
             L_ = _launch_f64(X)
-            st = lr_state or self.draw_low_rank(X=X)
+            st = lr_state or self.draw_low_rank(X=X, _implicit=True)
             p = self._params(L_.keep)
             lr = st.as_c(L_.keep)
             Phi, pp, n = self._lr_features(L_, p, lr, X)
@@ -466,7 +475,7 @@ class SignatureKernel:
         """Reference: kernels.py:513-536.  (T, T) or (M+1, T, T); never normalised."""
         if self.low_rank:
             L_ = _launch_f64(Z)
-            st = lr_state or self.draw_low_rank(Z=Z, increments=increments)
+            st = lr_state or self.draw_low_rank(Z=Z, increments=increments, _implicit=True)
             p = self._params(L_.keep)
             lr = st.as_c(L_.keep)
             Phi, pp, t = self._lr_features(L_, p, lr, Z, tensors=True, increments=increments)
@@ -487,7 +496,7 @@ class SignatureKernel:
             X, _ = self._slice(X, None)
         if self.low_rank:
             L_ = _launch_f64(Z, X)
-            st = lr_state or self.draw_low_rank(X=X, Z=Z, increments=increments)
+            st = lr_state or self.draw_low_rank(X=X, Z=Z, increments=increments, _implicit=True)
             p = self._params(L_.keep)
             lr = st.as_c(L_.keep)
             PZ, pz, t = self._lr_features(L_, p, lr, Z, tensors=True, increments=increments)
@@ -578,13 +587,15 @@ class SignatureKernel:
                 Zf = Zf * np.asarray(self.gamma)[None, :, None]
         return Zf.reshape(-1, d_eff)
 
-    def draw_low_rank(self, X=None, X2=None, Z=None, increments=False):
+    def draw_low_rank(self, X=None, X2=None, Z=None, increments=False, _implicit=False):
         """Draw the landmarks (uniformly, without replacement, from the scaled points of every given argument:
         kernels.py:444-446, :562-563), whiten their Gram (low_rank_calculations.py:50-57) and draw one projection
-        per level (low_rank_calculations.py:76-193).  Returns a LowRankState that can be passed to K(..., lr_state=)."""
+        per level (low_rank_calculations.py:76-193).  Returns a LowRankState that can be passed to K(..., lr_state=).
+        A state returned to the caller is the caller's: later draws never write into it, for host arrays and CUDA tensors alike
+        (only the per-evaluation draws of K / Kdiag / K_tens / ... with lr_state=None reuse one device block of the kernel object)."""
         L_ = _launch_f64(X, X2, Z)
         if L_.device_mode and self.device_draw:
-            return self._draw_low_rank_on_device(L_, X, X2, Z, increments)
+            return self._draw_low_rank_on_device(L_, X, X2, Z, increments, reuse=_implicit)
         L_ = _launch_f64(X, X2)
         p = self._params(L_.keep, _lib.F64)
         total = 0
@@ -619,22 +630,26 @@ class SignatureKernel:
         sk = _lr.draw_level_sketches(self.rng, self.num_levels, c, int(self.rank_bound), self.sparsity)
         return self.low_rank_state(S, jd, sk, ctx=L_.ctx)
 
-    def _draw_low_rank_on_device(self, L_, X, X2, Z, increments):
+    def _draw_low_rank_on_device(self, L_, X, X2, Z, increments, reuse=False):
         """gpsig_lr_draw: landmark choice, gather, whitening (Jacobi eigendecomposition) and the projections of every level on the
-        tensors' own stream, seeded from ``self.rng``; nothing waits for the host.  Returns a DeviceLowRankState."""
+        tensors' own stream, seeded from ``self.rng``; nothing waits for the host.  Returns a DeviceLowRankState.
+        reuse: draw into the kernel object's own state (the implicit draw of an evaluation that was given no lr_state: nobody else
+        holds it, and a fresh device block per evaluation would be a hipMalloc -- a device-wide synchronisation -- each);
+        otherwise a fresh state that belongs to the caller."""
         p = self._params(L_.keep, _lib.F64)
         n1, l1 = self._seq_dims(X) if X is not None else (0, 1)
         n2, l2 = self._seq_dims(X2) if X2 is not None else (0, 1)
         t = self._tens_dims(Z, increments) if Z is not None else 0
-        st = getattr(self, "_device_lr_state", None)
-        if st is None or st.ctx is not L_.ctx or (st.num_components, st.rank_bound, st.num_sketches) != (
+        st = getattr(self, "_device_lr_state", None) if reuse else None
+        if st is None or st.ctx is not L_.ctx or getattr(st.ctx, "_h", None) is None or (st.num_components, st.rank_bound, st.num_sketches) != (
                 int(self.num_components), int(self.rank_bound), self.num_levels - 1):
             st = DeviceLowRankState(L_.ctx, self.num_components, self.rank_bound, self.num_levels - 1)
         seed = int(self.rng.integers(0, 2 ** 63 - 1))
         L_.ctx.call("gpsig_lr_draw", p, int(self.num_components), int(self.rank_bound), DeviceLowRankState.SPARSITY[self.sparsity], C.c_uint64(seed),
                     L_.inp(X), n1, l1, L_.inp(X2), n2, l2, L_.inp(Z), t, int(bool(increments)), C.byref(st._h))
         st.keep = L_.keep            # the (converted) inputs stay alive until the draw has read them
-        self._device_lr_state = st
+        if reuse:
+            self._device_lr_state = st
         return st
 
     def low_rank_state(self, landmarks, jitter_diag, sketches, ctx=None):
@@ -669,7 +684,7 @@ class SignatureKernel:
 
     def _K_lr(self, X, X2, return_levels, lr_state):
         L_ = _launch_f64(X, X2)
-        st = lr_state or self.draw_low_rank(X=X, X2=X2)
+        st = lr_state or self.draw_low_rank(X=X, X2=X2, _implicit=True)
         p = self._params(L_.keep)
         lr = st.as_c(L_.keep)
         PA, pa, n1 = self._lr_features(L_, p, lr, X)
@@ -686,7 +701,7 @@ class SignatureKernel:
         """kernels.py:696-761, low-rank branch: level Grams of the factor matrices (HIP: features + fp64-MFMA GEMMs), then the
         normalisation / weighting of :706-761 as elementwise torch ops on the device."""
         L_ = _launch_f64(X, X2)
-        st = lr_state or self.draw_low_rank(X=X, X2=X2)
+        st = lr_state or self.draw_low_rank(X=X, X2=X2, _implicit=True)
         p = self._params(L_.keep)
         ones = np.ones(self.num_levels + 1)
         L_.keep.append(ones)

@@ -10,6 +10,7 @@ algorithm) -- runs on the device through torch.linalg, i.e. rocSOLVER (potrf, tr
 ``fit`` is a plain Adam loop (the reference drives TF optimisers through GPflow actions, gpsig/training.py --
 control plane, not rebuilt).
 """
+import copy
 import numpy as np
 
 from . import inducing_variables as iv
@@ -289,6 +290,7 @@ class SVGPModule(torch.nn.Module if torch is not None else object):
         trace_dev = torch.empty(iterations - warm, dtype=static_loss.dtype, device=dev)
         check_every = 25
         good = [p_.detach().clone() for p_ in params]
+        good_opt = copy.deepcopy(opt.state_dict())
         for it in range(warm, iterations):
             xb, yb = batch()
             xs.copy_(xb); ys.copy_(yb)
@@ -298,13 +300,19 @@ class SVGPModule(torch.nn.Module if torch is not None else object):
                 callback(it, -float(static_loss.item()))
             if (it - warm) % check_every == check_every - 1 or it == iterations - 1:
                 lo = (it - warm) // check_every * check_every
-                if not bool(torch.isfinite(trace_dev[lo:it - warm + 1]).all()):
+                # (a recorded loss is the one of the parameters BEFORE that replay's update: finite losses alone do not say that the last
+                # update -- finite loss, infinite gradient -- left finite parameters, so those are looked at as well)
+                finite = bool(torch.isfinite(trace_dev[lo:it - warm + 1]).all()) and all(bool(torch.isfinite(p_).all()) for p_ in params)
+                if not finite:
                     with torch.no_grad():
                         for p_, g_ in zip(params, good):
                             p_.copy_(g_)
+                    opt.load_state_dict(good_opt)        # Adam's moments saw the same NaNs
                     raise FloatingPointError("fit(graph=True): the ELBO stopped being finite between iterations %d and %d "
-                                             "(a covariance matrix lost positive definiteness?); parameters restored" % (warm + lo, it))
+                                             "(a covariance matrix lost positive definiteness?); parameters and optimiser state "
+                                             "restored to iteration %d" % (warm + lo, it, warm + lo))
                 good = [p_.detach().clone() for p_ in params]
+                good_opt = copy.deepcopy(opt.state_dict())
         trace.extend((-trace_dev).tolist())
         self._step_graph = g             # keeps the recorded step (and the memory it owns) alive with the model
         return [float(t) for t in trace]

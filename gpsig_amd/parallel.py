@@ -57,9 +57,12 @@ class ShardedGram:
     object, so nothing is handed back to the caching allocator while a collective may still read it; a second __call__ overwrites
     `self.rows` only after the waits of the first."""
 
-    def __init__(self, kern, n, device, rank=0, world=1, chunks=4, ctx=None):
+    def __init__(self, kern, n, device, rank=0, world=1, chunks=4, ctx=None, force=False):
         self.kern, self.n, self.dev, self.rank, self.world = kern, int(n), torch.device(device), int(rank), int(world)
         self._ctx = ctx
+        # force: take the decomposed route (row-block calls, the verdict all-reduce, asynchronous gathers, symmetrisation) on ONE rank
+        # too -- a single MI355X then runs every collective of the N-rank path through RCCL itself (tests/test_gpu_parity.py)
+        self.force = bool(force)
         self.fallback = None                     # why rank 0 evaluated alone, when it did
         self.width = self.n // 2 + 1
         chunks = max(1, int(chunks))
@@ -67,7 +70,7 @@ class ShardedGram:
         self.chunk_rows = self.per // chunks
         self.chunks = chunks
         self.bounds = row_partition(self.n, world, ALIGN * chunks)
-        if world > 1:
+        if world > 1 or self.force:
             self.rows = torch.zeros((self.per, self.width), dtype=torch.float64, device=self.dev)        # equal-sized blocks
             if rank == 0:
                 self.half = torch.zeros((self.per * world, self.width), dtype=torch.float64, device=self.dev)
@@ -106,7 +109,7 @@ class ShardedGram:
         return dist.gather(mine, gather_list=parts, dst=0, async_op=True)
 
     def __call__(self, X):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return self.kern.K(X)
         X, _ = self.kern._slice(X, None)
         if X.dtype != torch.float64 or X.device != self.dev:
@@ -131,19 +134,32 @@ class ShardedGram:
             if keep_features is not None:
                 keep_features("sig_features_keep", 0)
 
+    def _agree(self, ok):
+        """True where EVERY rank's first chunk was taken by the row-block kernels.  One scalar all-reduce (MIN) per Gram: a rank whose
+        call was refused (or, on a full device, took another decision than its peers) must not leave the others inside a gather that
+        it never joins -- whatever the library decides per rank, the ranks leave this function on the same branch."""
+        nccl = dist.get_backend() == "nccl"
+        v = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.dev if nccl else "cpu")
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        return bool(int(v.item()))
+
     def _chunks(self, ctx, p, X, n, L, b0, b1, pending):
         for k in range(self.chunks):
             r0 = min(b0 + k * self.chunk_rows, b1)
             r1 = min(r0 + self.chunk_rows, b1)
             if r1 > r0 or k == 0:
                 blk = self.rows[k * self.chunk_rows:]
+                why = None
                 try:
-                    # (an empty row range on the first chunk still validates the shape, so that every rank decides alike)
+                    # (an empty row range on the first chunk still asks the library's routes for this shape, in the order a block with
+                    # rows does: api.hip, e_kernel_K_symm_rows)
                     ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), n, L, r0, r1, C.c_void_p(blk.data_ptr()))
                 except NotImplementedError as e:
                     if k != 0:
                         raise
-                    return self._rank0_alone(X, str(e))
+                    why = str(e)
+                if k == 0 and not self._agree(why is None):
+                    return self._rank0_alone(X, why or "another rank's row-block call was refused")
             w = self._gather(k)       # enqueued behind chunk k on the collective's own stream; chunk k+1 starts meanwhile
             if w is not None:
                 pending.append(w)

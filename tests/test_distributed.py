@@ -162,6 +162,50 @@ def test_sharded_gram_falls_back_to_rank_zero_for_unsupported_shapes():
         assert all(ret[r] == (True, 0, None) for r in range(1, world)), ret
 
 
+class RefusingOnOneRank(EmulatorContext):
+    """Only ONE rank's library refuses (a verdict that depends on the rank: an empty block planned by other rules than a block with
+    rows, a device without memory for one route) -- the divergence that would leave its peers in a gather it never joins."""
+
+    def __init__(self, refuse):
+        self.refuse = refuse
+
+    def call(self, name, p, Xp, n, L, r0, r1, outp):
+        if self.refuse:
+            raise NotImplementedError("no sequence-pair kernel shape for these lengths")
+        if r1 > r0:
+            EmulatorContext.call(self, name, p, Xp, n, L, r0, r1, outp)
+
+
+def _diverging_worker(rank, world, port, n, refusing_rank, ret):
+    import torch
+    from gpsig_amd import kernels
+    from oracle import sigkern_oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, d, M = 7, 2, 3
+        rng = np.random.default_rng(5)
+        X = np.cumsum(0.3 * rng.standard_normal((n, L, d)), axis=1).reshape(n, L * d)
+        kern = kernels.SignatureRBF(L * d, d, M, lengthscales=None)
+        ko = O.SignatureKernelOracle(L * d, d, M, base="rbf", lengthscales=None)
+        kern.K = lambda Xt, presliced=False: torch.from_numpy(ko.K(Xt.numpy()))       # stand-in for rank 0's any-shape evaluation
+        gram = parallel.ShardedGram(kern, n, torch.device("cpu"), rank, world, chunks=2, ctx=RefusingOnOneRank(rank == refusing_rank))
+        out = gram(torch.from_numpy(X))
+        ret[rank] = (gram.fallback is not None, None if out is None else float(np.abs(out.numpy() - ko.K(X)).max()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gram_ranks_agree_on_the_route_when_one_of_them_is_refused():
+    """The ranks all-reduce the verdict of their first chunk: when any single rank's call is refused -- the one that owns no rows
+    (n = 20 on 3 ranks of blocks of 8: rank 2 has 4 rows, so refuse rank 1; n = 8: rank 1 and 2 own nothing) or one that does --
+    ALL of them take the rank-0 fallback, and the job finishes instead of hanging."""
+    for n, world, refusing in ((20, 3, 1), (8, 3, 2), (20, 2, 0)):
+        ret = _spawn_with_retry(_diverging_worker, world, (n, refusing))
+        assert ret[0] == (True, 0.0), ret
+        assert all(ret[r] == (True, None) for r in range(1, world)), ret
+
+
 def _covs_worker(rank, world, port, n, increments, ret):
     import torch
     from gpsig_amd import kernels

@@ -1336,6 +1336,130 @@ def test_low_rank_fresh_draw_on_device_tensors(K):
     assert Kzz.is_cuda and Kzx.shape == (T, N) and bool(torch.isfinite(Kzx).all())
 
 
+def test_low_rank_states_handed_out_belong_to_the_caller(K):
+    """Round-3 advisor finding: for CUDA inputs draw_low_rank() used to hand out the kernel object's ONE cached device state, which
+    every later draw -- explicit or the implicit draw of an evaluation without lr_state -- overwrote.  A state the caller holds now
+    stays what it was: evaluations from it are reproducible across other draws and evaluations, as with host arrays; only the
+    implicit per-evaluation draws share a block.  And a state that outlives its context is released without touching the context."""
+    import torch
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(3)
+    N, L, d, M, T = 18, 8, 3, 3, 5
+    dev = torch.device("cuda:0")
+    Xc = torch.tensor(np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1), device=dev)
+    Yc = torch.tensor(np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1), device=dev)
+    Zc = torch.tensor(rng.standard_normal((M * (M + 1) // 2, T, d)), device=dev)
+    kern = K.SignatureRBF(L * d, d, M, low_rank=True, num_components=12, rank_bound=8)
+    kern.rng = np.random.default_rng(11)
+    st1 = kern.draw_low_rank(X=Xc)
+    ref1 = kern.K(Xc, lr_state=st1).clone()
+    landmarks1 = st1.export().landmarks.copy()
+    st2 = kern.draw_low_rank(X=Yc)                      # another explicit draw, from other sequences
+    assert st2 is not st1 and st2._h.value != st1._h.value
+    kern.K(Yc); kern.Kdiag(Yc); kern.K_tens_vs_seq(Zc, Yc); kern.K_tens(Zc)      # implicit draws: the kernel object's own block
+    assert kern._device_lr_state is not st1 and kern._device_lr_state is not st2
+    np.testing.assert_array_equal(st1.export().landmarks, landmarks1)
+    assert torch.equal(kern.K(Xc, lr_state=st1), ref1)
+    assert not torch.equal(kern.K(Xc, lr_state=st2), ref1)
+    # implicit draws reuse one block (no allocation per evaluation)
+    h = kern._device_lr_state._h.value
+    kern.K(Xc)
+    assert kern._device_lr_state._h.value == h
+    # a state outliving its context: the context detaches it; destroying it afterwards only frees the block
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        k2 = K.SignatureRBF(L * d, d, M, low_rank=True, num_components=12, rank_bound=8)
+        k2.rng = np.random.default_rng(12)
+        st3 = k2.draw_low_rank(X=Xc)
+        v = k2.K(Xc, lr_state=st3)
+        side.synchronize()
+        assert bool(torch.isfinite(v).all())
+    _lib.release(0, side.cuda_stream)                   # closes the side stream's context
+    with pytest.raises(RuntimeError):
+        st3.export()
+    st3.close()                                         # no use-after-free: a detached state frees its memory only
+    del st3, k2
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(kern.K(Xc)).all())
+
+
+def test_decomposed_gram_through_rccl_on_one_rank(K):
+    """Every collective of the N-rank path executed by RCCL itself (backend "nccl" on ROCm), on the one GPU a test box has: a
+    one-rank process group and ShardedGram(force=True) -- row-block calls in chunks, the all-reduced verdict, an asynchronous
+    dist.gather per chunk on the collective's own stream while the next chunk is computed, the stream-ordered wait, the tiled
+    symmetrisation.  Bit-identical to K(X) for both routes (feature contraction: SignatureLinear; pair recursion: SignatureRBF), and
+    a refused shape takes the rank-0 fallback through the same all-reduce."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from gpsig_amd import parallel
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        rng = np.random.default_rng(21)
+        dev = torch.device("cuda:0")
+        for cls, n, L, d, M in ((K.SignatureLinear, 1024, 32, 4, 4), (K.SignatureRBF, 520, 16, 3, 3)):
+            X = torch.as_tensor(rng.standard_normal((n, L * d)), device=dev)
+            kern = cls(L * d, d, M)
+            want = kern.K(X)
+            g = parallel.ShardedGram(kern, n, dev, 0, 1, chunks=4, force=True)
+            for _ in range(2):                       # a second call reuses rows / half / out behind the first one's waits
+                got = g(X)
+                torch.cuda.synchronize()
+                assert g.fallback is None
+                assert torch.equal(got, want)
+        # a shape the row-block kernels refuse: the verdict goes through RCCL's all-reduce, rank 0 evaluates alone
+        n, L, d, M = 40, 700, 3, 3
+        X = torch.as_tensor(0.1 * rng.standard_normal((n, L * d)), device=dev)
+        kern = K.SignatureRBF(L * d, d, M)
+        g = parallel.ShardedGram(kern, n, dev, 0, 1, chunks=2, force=True)
+        got = g(X)
+        assert g.fallback is not None
+        assert torch.equal(got, kern.K(X))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_empty_row_block_takes_the_routes_a_block_with_rows_takes(K):
+    """Round-3 advisor finding: a rank that owns no rows used to validate the shape with the pair kernels' planner only, while ranks
+    with rows ask the feature contraction first -- which takes shapes the pair kernels refuse (SignatureLinear with more than 512
+    lattice rows at d <= 8; orders beyond the higher-order tables).  The empty block now gives the same verdict as its peers:
+    accepted where a block with rows is accepted, refused where it is refused."""
+    import ctypes as C
+    import torch
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(8)
+    ctx = _lib.context(0, torch.cuda.current_stream().cuda_stream)
+    ctx.set_pointer_mode(_lib.PTR_DEVICE)
+    n, L, d, M = 64, 600, 4, 3                          # 599 lattice rows: beyond the pair kernels' register-resident side
+    X = torch.as_tensor(0.1 * rng.standard_normal((n, L * d)), device="cuda:0")
+    W = n // 2 + 1
+    out = torch.full((8, W), float("nan"), dtype=torch.float64, device="cuda:0")
+    for kern, accepted in ((K.SignatureLinear(L * d, d, M), True), (K.SignatureRBF(L * d, d, M), False)):
+        keep = []
+        p = kern._params(keep)
+        verdicts = []
+        for r0, r1 in ((8, 16), (n, n), (0, 0)):        # a block with rows, an empty block at the end, an empty block at the start
+            try:
+                ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), n, L, r0, r1, C.c_void_p(out.data_ptr()))
+                verdicts.append(True)
+            except NotImplementedError:
+                verdicts.append(False)
+        assert verdicts == [accepted] * 3, (type(kern).__name__, verdicts)
+    torch.cuda.synchronize()
+    # and what the accepted block computed is the Gram's owned entries
+    kern = K.SignatureLinear(L * d, d, M)
+    keep = []
+    ctx.call("gpsig_kernel_K_symm_rows_compact", kern._params(keep), C.c_void_p(X.data_ptr()), n, L, 8, 16, C.c_void_p(out.data_ptr()))
+    full = kern.K(X)
+    j = torch.arange(W, device="cuda:0")
+    for i in range(8):
+        cols = (8 + i - n // 2 + j) % n
+        own = torch.isfinite(out[i])
+        assert int(own.sum()) >= W - 1
+        assert torch.allclose(out[i][own], full[8 + i][cols][own], rtol=1e-12, atol=1e-13)
+
+
 @pytest.mark.parametrize("sparsity", ["sqrt", "log", "lin"])
 @pytest.mark.parametrize("base", ["rbf", "linear"])
 def test_low_rank_objects_drawn_on_the_device(K, sparsity, base):

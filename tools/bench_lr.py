@@ -106,7 +106,7 @@ def main():
         stages.update(gram_product_ms=ms_gemm)
     F = 1 + args.components + (M - 1) * (args.rank or args.components)
     nnz = [int(s.val.shape[0]) for s in sth.sketches]
-    ms_draw, _ = timed(lambda: kern.draw_low_rank(X=X, Z=Z))
+    ms_draw, _ = timed(lambda: kern.draw_low_rank(X=X, Z=Z, _implicit=True))
     kern.device_draw = False
     ms_draw_host, _ = timed(lambda: kern.draw_low_rank(X=X, Z=Z), steps=3)
     kern.device_draw = True

@@ -11,8 +11,8 @@ Z = torch.as_tensor(rng.standard_normal((M * (M + 1) // 2, T, d)), device="cuda:
 for sp in (sys.argv[1:] or ["sqrt"]):
     kern = kernels.SignatureRBF(L * d, d, M, lengthscales=float(np.sqrt(d)), low_rank=True, num_components=50, sparsity=sp)
     kern.rng = np.random.default_rng(3)
-    kern.draw_low_rank(X=X, Z=Z); torch.cuda.synchronize()
+    kern.draw_low_rank(X=X, Z=Z, _implicit=True); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(20): kern.draw_low_rank(X=X, Z=Z)
+    for _ in range(20): kern.draw_low_rank(X=X, Z=Z, _implicit=True)
     torch.cuda.synchronize()
     print(sp, "draw: %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
