@@ -156,6 +156,11 @@ class Context:
         if rc != GPSIG_OK:
             raise_for(rc, (lib.gpsig_last_error(None) or b"gpsig_ctx_create failed").decode())
         self._h, self._lib, self.device, self.stream = h, lib, int(device), int(stream or 0)
+        # GPSIG_OPTIONS="name=value,name=value": gpsig_set_option calls for every context of the process (A/B runs of one build:
+        # tools/gpu_round4.sh); an unknown name fails loudly
+        for item in filter(None, (os.environ.get("GPSIG_OPTIONS") or "").split(",")):
+            name, _, value = item.partition("=")
+            self.check(lib.gpsig_set_option(h, name.strip().encode(), int(value)))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -669,7 +669,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     // entry's products are added is then the same whichever tile, row block or rank computes it, and row blocks
     // (gpsig_kernel_K_symm_rows*) reassemble the one-call Gram bit for bit.  16 pieces at N = 4,096 (configs[1]); large Grams keep
     // at least 4 (a rank's chunk of one is a launch of ~1,000 tiles); pieces of at least 8 slabs.
-    int nsplit = 1;
+    int nsplit = 1, graded = 1;         // equal depth pieces; the last of them cut into `graded` finer ones
     {
         const int64_t nt_full = (N1 + SG_BM - 1) / SG_BM;
         const int64_t tiles_full = sym ? nt_full * (nt_full + 1) / 2 : nt_full * ((N2 + SG_BN - 1) / SG_BN);
@@ -682,24 +682,38 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
             if (t < best * 0.999) { best = t; nsplit = ns; }
         }
         if (tiles_full > 1024 && nsplit < 4 && nslab_all >= 32) nsplit = 4;
+        // Equal pieces end in a last round of workgroups that takes as long as the others but is only partly full (configs[1]: 528 tiles
+        // x 11 pieces = 11.34 rounds of 512, paid as 12).  Cutting the LAST piece into finer ones of halving size (sig_piece_bounds) lets
+        // the launch end within one small piece of (total work / slots): the waste of the equal pieces' last round against the finest
+        // piece plus a partial sum per extra piece (round 4; option "sig_graded" 0 keeps the equal pieces).
+        const double wgs = double(tiles_full) * nsplit, piece_t = double(nslab_all) / nsplit * 3.6e-6;
+        if (c->sig_graded != 0 && wgs > 512.0 && nslab_all / nsplit >= 32) {
+            const double rounds = wgs / 512.0, waste_equal = (ceil(rounds) - rounds) * piece_t;
+            double best_t = waste_equal;
+            for (int g = 2; g <= 5; ++g) {
+                const double t = piece_t / double(1 << (g - 1)) + (g - 1) * 2.0 * result_bytes / 3e12;
+                if (t < best_t * 0.95 && (nslab_all / nsplit) >> (g - 1) >= 8) { best_t = t; graded = g; }
+            }
+        }
     }
     const size_t part_one = sizeof(double) * size_t(NA) * NB;
-    while (nsplit > 1 && part_one * size_t(nsplit) > (size_t(40) << 30)) --nsplit;       // (the exception to the rule above: 40 GiB of partial sums)
+    while (nsplit > 1 && part_one * size_t(nsplit - 1 + graded) > (size_t(40) << 30)) { --nsplit; graded = 1; }       // (the exception to the rule above: 40 GiB of partial sums)
+    const int npieces = nsplit - 1 + graded;
     const size_t feat_bytes = sizeof(double) * size_t(ld) * (size_t(N1) + (sym ? 0 : size_t(N2)));
-    if (feat_bytes + part_one * size_t(nsplit) > (size_t(96) << 30)) return GPSIG_OK;
+    if (feat_bytes + part_one * size_t(npieces) > (size_t(96) << 30)) return GPSIG_OK;
     {
         // what the scratch buffers would have to grow by, against what the device has left: the pair recursion needs no such memory
         // and is the better answer to a full device than an allocation error
         auto grow = [&](int id, size_t bytes) { return bytes > c->buf[id].cap ? bytes + bytes / 8 + 256 : size_t(0); };
         const size_t extra = grow(B_SF0, sizeof(double) * size_t(ld) * N1 + 64) + (sym ? 0 : grow(B_SF1, sizeof(double) * size_t(ld) * N2 + 64)) +
-                             grow(B_SF2, part_one * size_t(nsplit) + 64);
+                             grow(B_SF2, part_one * size_t(npieces) + 64);
         // (not for row blocks: the ranks of a sharded evaluation must all take the same route whatever each device has left -- there a
         // full device is an allocation error of that rank, not a silent change of route that the other ranks do not follow)
         if (extra > (size_t(1) << 30) && !c->capturing && !rows) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 size_t held = 0;                // (a buffer that grows is freed first)
-                for (int id : {int(B_SF0), int(B_SF1), int(B_SF2)}) held += grow(id, id == B_SF0 ? sizeof(double) * size_t(ld) * N1 + 64 : id == B_SF1 ? (sym ? 0 : sizeof(double) * size_t(ld) * N2 + 64) : part_one * size_t(nsplit) + 64) ? c->buf[id].cap : 0;
+                for (int id : {int(B_SF0), int(B_SF1), int(B_SF2)}) held += grow(id, id == B_SF0 ? sizeof(double) * size_t(ld) * N1 + 64 : id == B_SF1 ? (sym ? 0 : sizeof(double) * size_t(ld) * N2 + 64) : part_one * size_t(npieces) + 64) ? c->buf[id].cap : 0;
                 if (extra > free_b + held - (free_b + held) / 16) return GPSIG_OK;
             }
         }
@@ -712,7 +726,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     void *phi1, *phi2 = nullptr, *part;
     CHK(ensure(c, B_SF0, sizeof(double) * size_t(ld) * N1 + 64, &phi1));
     if (!sym) CHK(ensure(c, B_SF1, sizeof(double) * size_t(ld) * N2 + 64, &phi2));
-    CHK(ensure(c, B_SF2, part_one * size_t(nsplit) + 64, &part));
+    CHK(ensure(c, B_SF2, part_one * size_t(npieces) + 64, &part));
     if (f32) {
         void *x64, *y64 = nullptr, *o64;
         const int64_t per1 = int64_t(L1) * p->num_features, per2 = int64_t(L2) * p->num_features;
@@ -783,9 +797,9 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         G.b_off = rows ? ((row_begin - H) % N1 + N1) % N1 : 0; G.b_mod = sym ? N1 : N2;
         G.k_begin = kb; G.k_end = ke;
         G.band = (rows && NA + H <= N1) ? H : 0;      // column c of the block is sequence row_begin - H + c (no wrap inside the block): row i owns c in [i, i + H]
-        int ns = nsplit;
         const int nslab = (ke - kb + SG_BK - 1) / SG_BK;
-        if (ns > nslab) ns = nslab < 1 ? 1 : nslab;
+        // (the per-level products of return_levels: equal pieces of their own, shorter depth)
+        const int ns = sig_piece_bounds(nslab, nsplit, return_levels ? 1 : graded, G.bound);
         G.nsplit = ns; G.symmetric = symtiles ? 1 : 0; G.ntj = ntj; G.part = static_cast<double*>(part);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         bool on = false;
@@ -1907,6 +1921,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "lr_jacobi")) c->lr_jacobi = value ? 1 : 0;
     else if (!strcmp(name, "sig_features")) c->sig_features = value;
     else if (!strcmp(name, "sig_gemm_dma")) c->sig_gemm_dma = value;
+    else if (!strcmp(name, "sig_graded")) c->sig_graded = value;
     else if (!strcmp(name, "sig_features_keep")) { c->sf_keep = value; c->sf_valid = false; }
     else if (!strcmp(name, "keep_reset")) c->keep_reset = value ? 1 : 0;
     else if (!strcmp(name, "pk2")) c->allow_pk2 = value;

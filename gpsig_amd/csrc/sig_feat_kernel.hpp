@@ -465,6 +465,7 @@ static __global__ void sig_narrow_kernel(const double* __restrict__ in, float* _
 // ---- C = A B^T, float64 matrix cores, depth split over workgroups ----------------------------------------------------------------
 typedef double sig_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int SG_BM = 128, SG_BN = 128, SG_BK = 16, SG_LDK = SG_BK + 1;
+constexpr int SG_MAX_PIECES = 144;        // depth pieces per tile (api.hip's planner: at most 128 equal ones, or a few more of graded sizes)
 
 struct SigGramArgs {
     const double* A; const double* B;     // (NA, lda), (NB, ldb) row-major; B row of output column c is (b_off + c) mod b_mod
@@ -472,11 +473,37 @@ struct SigGramArgs {
     int64_t b_off, b_mod;
     int k_begin, k_end;                   // depth range of this product
     int nsplit;                           // workgroups per tile along the depth
+    int bound[SG_MAX_PIECES + 1];         // piece s covers the slabs [bound[s], bound[s + 1]) of the depth range (sig_piece_bounds)
     int symmetric;                        // A == B, NA == NB, b_off == 0: tiles (bi <= bj) only
     int ntj;                              // tile columns
     double* part;                         // (nsplit, NA, NB) partial sums
     int64_t band;                         // > 0 (row blocks of a symmetric Gram): row i owns columns i .. i + band only -- tiles outside are skipped
 };
+
+// Slab ranges of the depth pieces.  `equal` pieces of the same size, the last of which is cut into `graded` finer ones of halving size
+// (1/2, 1/4, .., the last two alike) when graded > 1: workgroups are handed out piece after piece, so equal pieces end in a last round
+// that is as long as the others but only partly full (configs[1]: 528 tiles x 11 pieces on 512 workgroup slots = 11.34 rounds, paid as
+// 12), while finer pieces at the end fill the slots that fall free there, and the launch ends within one SMALL piece of
+// (total work / slots).  Returns the number of pieces.  Depends on the depth and the two counts alone (api.hip: chosen from the full
+// problem's size), so an entry's summation order is the same in every tile, row block and rank.
+inline int sig_piece_bounds(int nslab, int equal, int graded, int* bound) {
+    if (equal < 1) equal = 1;
+    if (equal > nslab) equal = nslab < 1 ? 1 : nslab;
+    int n = 0;
+    for (int s = 0; s < equal - 1; ++s) bound[n++] = int(int64_t(nslab) * s / equal);
+    const int last0 = int(int64_t(nslab) * (equal - 1) / equal), len = nslab - last0;
+    bound[n++] = last0;
+    if (graded > 1 && len >= 2 * graded) {
+        int at = last0, left = len;
+        for (int g = 1; g < graded; ++g) {         // 1/2, 1/4, ... of the last piece; the final one takes what is left
+            const int take = left / 2 > 0 ? left / 2 : 1;
+            at += take; left -= take;
+            bound[n++] = at;
+        }
+    }
+    bound[n] = nslab;
+    return n;
+}
 
 // Which depth piece and which tile this workgroup computes.
 __device__ inline void sig_tile_of(const SigGramArgs& G, int& split_out, int& bi, int& bj) {
@@ -541,8 +568,7 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramAr
     const int64_t tile_i = int64_t(bi) * SG_BM, tile_j = int64_t(bj) * SG_BN;
     if (G.band > 0 && (tile_j + SG_BN - 1 < tile_i || tile_j > tile_i + SG_BM - 1 + G.band)) return;      // nothing of this tile is owned
     // depth chunk of this workgroup, in whole slabs
-    const int nslab = (G.k_end - G.k_begin + SG_BK - 1) / SG_BK;
-    const int s0 = int(int64_t(nslab) * split / G.nsplit), s1 = int(int64_t(nslab) * (split + 1) / G.nsplit);
+    const int s0 = G.bound[split], s1 = G.bound[split + 1];
     const int kb = G.k_begin + s0 * SG_BK, ke = (G.k_begin + s1 * SG_BK < G.k_end) ? G.k_begin + s1 * SG_BK : G.k_end;
     // staging: thread t fetches columns [8 h, 8 h + 8) of row t >> 1 of the slab, h = t & 1
     const int srow = tid >> 1, scol = (tid & 1) * 8;
@@ -651,8 +677,7 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGr
     sig_tile_of(G, split, bi, bj);
     const int64_t tile_i = int64_t(bi) * SG_BM, tile_j = int64_t(bj) * SG_BN;
     if (G.band > 0 && (tile_j + SG_BN - 1 < tile_i || tile_j > tile_i + SG_BM - 1 + G.band)) return;      // nothing of this tile is owned
-    const int nslab = (G.k_end - G.k_begin + SG_BK - 1) / SG_BK;
-    const int s0 = int(int64_t(nslab) * split / G.nsplit), s1 = int(int64_t(nslab) * (split + 1) / G.nsplit);
+    const int s0 = G.bound[split], s1 = G.bound[split + 1];
     const int nsl = s1 - s0;
     const double* ga[4];          // this lane's 16 bytes of the CURRENT slab, piece q; the next slab is 128 bytes on
     const double* gb[4];

@@ -120,6 +120,10 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 the caller must not write the sequences until it sets the option back to 0 (which also drops the matrix's validity)
  *   "sig_gemm_dma" that contraction's operand slabs by LDS-DMA into an XOR-swizzled image, fragments prefetched across the barrier
  *                 (1, default) or staged through registers (0); bit-identical results
+ *   "sig_graded"  that contraction's depth pieces: 1 (default) the last of the equal pieces is cut into finer ones of halving size where a
+ *                 launch runs for several rounds of workgroups (they fill the slots that fall free at the end: 12 -> 11.5 rounds' time
+ *                 at BASELINE configs[1]), 0 equal pieces throughout (round 3).  The split depends on the Gram's total size and depth
+ *                 alone, so row blocks still reassemble the one-call Gram bit for bit
  *   "lr_jacobi"   gpsig_lr_draw: 1 (default) the landmark Gram's eigendecomposition by the one-workgroup Jacobi kernel (c <= 64), 0 rocSOLVER
  *   "tvs_zreg"    tensor-lane gradient: components in registers (1) or LDS (0), -1 automatic
  *   "tvs_tile"    tensor-vs-sequence tile kernel (levels split over the waves of a workgroup, coalesced result tiles):
