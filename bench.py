@@ -344,7 +344,11 @@ def measure_traffic(cfg, base, increments, timeout_s=240):
 # vector instructions per wave-step of the dominant kernels (disassembly of the built instances); float64
 # and DPP instructions take a SIMD's issue port for 4 cycles per wave64 instruction.  issue_frac = how much of the SIMDs'
 # issue time the kernel's vector instructions fill at the clock measured during the run.
-VALU_PER_STEP = {("c2", "linear"): 89, ("c4", "linear"): 89, ("c2", "rbf"): 174, ("c4", "rbf"): 174}
+VALU_PER_STEP = {("c2", "linear"): 89, ("c4", "linear"): 89, ("c2", "rbf"): 174, ("c4", "rbf"): 174,
+                 # configs[4], seq_pk2_kernel<f2, 4, 64, 2, 16, 6>: SQ_INSTS_VALU / wave-steps of profiles/r03_pmc_c5.txt (1.589e10 / 1.343e8; the
+                 # pair-boundary blocks included); SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.04 issue slots of 4 cycles per instruction there
+                 ("c5", "rbf"): 118.4}
+PAIRS_PER_WAVE = {"c5": 2}               # seq_pk2_kernel at G = 64: one pair group per wavefront, two y sequences packed (default 4: G = 16)
 SIMDS = 1024
 
 
@@ -475,7 +479,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     issue = None
     vps = VALU_PER_STEP.get((cfg, base)) if timed_kernel is None else None
     if vps and ghz:
-        pairs_per_wave = 4                                           # G = 16: four pair groups per wavefront
+        pairs_per_wave = PAIRS_PER_WAVE.get(cfg, 4)                  # G = 16: four pair groups per wavefront
         wave_steps = evaluated_launch / pairs_per_wave * L           # L lattice rows (L - 1 increments + the boundary row) per pair
         issue = {"valu_per_wave_step": vps, "cycles_per_valu": 4, "wave_steps_per_launch": wave_steps, "simds": SIMDS,
                  "issue_frac": wave_steps * vps * 4.0 / (SIMDS * ghz * 1e9 * per_launch_ms * 1e-3)}
@@ -486,6 +490,12 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     elif w["dtype"] == "f64":
         bound = "valu-issue"
         binding = "float64 vector-ALU issue (instructions x 4 cycles per wave; DESIGN.md section 4)"
+    elif issue:
+        # (round 4: the counters of profiles/r03_pmc_c5.txt show the vector ALU active 0.9-0.97 of the launch -- SQ_ACTIVE_INST_VALU x 4 /
+        # 1024 SIMDs against the kernel's cycles -- so this kernel, too, is bound by its instruction count, not by latency)
+        bound = "valu-issue"
+        binding = ("float32 vector-ALU issue: 118 vector instructions per wave-step (58 of them packed v_pk_fma_f32 at 4 cycles, the rest "
+                   "hand-overs, selects and address arithmetic), DESIGN.md section 4")
     else:
         bound = "valu-latency"
         binding = "float32 dependent-instruction latency at the kernel's wavefronts per SIMD (DESIGN.md section 2.4)"

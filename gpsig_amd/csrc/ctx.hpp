@@ -91,6 +91,7 @@ struct gpsig_ctx {
     int sf_keep = 0;                     // keep the feature matrix between calls ("sig_features_keep")
     bool sf_valid = false;
     const void* sf_X = nullptr; const void* sf_phi = nullptr; uint64_t sf_key = 0;
+    int sig_features_grad = -1;          // gradients of SignatureLinear's sequence levels through the feature contraction (sig_feat_grad_api.hip): -1 where cheaper, 0 never, 1 wherever built
     int sig_graded = 1;                  // the contraction's last depth piece cut into finer ones (sig_piece_bounds); 0: equal pieces (round 3)
     int sig_gemm_dma = 1;                // the contraction's slabs by LDS-DMA with fragments prefetched across the barrier (0: register-staged form)
     int lr_jacobi = 1;            // gpsig_lr_draw: eigendecomposition of the landmark Gram by the one-workgroup Jacobi kernel (c <= 64), 0: rocSOLVER

@@ -20,6 +20,9 @@ Wave2LaunchFn lam_undo_lookup_ptd_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptd_gen(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
+// sig_feat_grad_api.hip: SignatureLinear's levels differentiated through the feature contraction
+int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
+                      bool sym, const double* G, double* gX, double* gY, bool* done);
 // tvs_grad_api.hip: the tile kernel of the tensor-vs-sequence reverse pass (tvs_grad_tile_kernel.hpp)
 int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, const double* X, const double* G, int64_t Tn, int64_t N,
                          int L, int increments, const double* fac, const double* aux, double* gZ, double* gX, double* gfac, double* gb, size_t budget, bool* done);
@@ -555,7 +558,12 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     Wave2LaunchFn lfn = nullptr;                           // point kernels: scratch-free sweeps with Lam out
     int lG = 0, lC = 0;
     if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, p->base_kernel, L1 - drr, L2 - drr, DP, M, &lG, &lC);
-    if (N1 == 0 || N2 == 0) {
+    bool by_features = false;      // the linear kernel, first order: through the feature contraction where that is cheaper (round 4)
+    if (N1 > 0 && N2 > 0)
+        CHK(sig_features_grad(c, p, d, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, diag, sym,
+                              static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(dgY), &by_features));
+    if (by_features) {
+    } else if (N1 == 0 || N2 == 0) {
         if (xb) CHK(zero_async(c, dgX, xb));
         if (dgY && yb) CHK(zero_async(c, dgY, yb));
     } else if (p->order > 1 && M > 1) {

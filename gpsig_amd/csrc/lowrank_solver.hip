@@ -21,6 +21,9 @@ struct SolverApi {
     rocblas_status (*set_stream)(rocblas_handle, hipStream_t) = nullptr;
     rocblas_status (*dsyevd)(rocblas_handle, const rocblas_evect, const rocblas_fill, const rocblas_int, double*, const rocblas_int,
                              double*, double*, rocblas_int*) = nullptr;
+    rocblas_status (*dgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const double*, const double*,
+                            rocblas_int, const double*, rocblas_int, const double*, double*, rocblas_int) = nullptr;
+    rocblas_status (*set_pointer_mode)(rocblas_handle, rocblas_pointer_mode) = nullptr;
     std::string err;
 };
 
@@ -41,6 +44,12 @@ void load_api() {
     static const char* const solver_names[] = {"librocsolver.so.0", "/opt/rocm/lib/librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so", nullptr};
     g_api.blas = open_first(blas_names, &g_api.err);
     if (!g_api.blas) return;
+    // (rocBLAS alone serves solver_dgemm; rocSOLVER is needed by solver_dsyevd only)
+    g_api.dgemm = reinterpret_cast<decltype(g_api.dgemm)>(dlsym(g_api.blas, "rocblas_dgemm"));
+    g_api.set_pointer_mode = reinterpret_cast<decltype(g_api.set_pointer_mode)>(dlsym(g_api.blas, "rocblas_set_pointer_mode"));
+    g_api.create_handle = reinterpret_cast<decltype(g_api.create_handle)>(dlsym(g_api.blas, "rocblas_create_handle"));
+    g_api.destroy_handle = reinterpret_cast<decltype(g_api.destroy_handle)>(dlsym(g_api.blas, "rocblas_destroy_handle"));
+    g_api.set_stream = reinterpret_cast<decltype(g_api.set_stream)>(dlsym(g_api.blas, "rocblas_set_stream"));
     g_api.solver = open_first(solver_names, &g_api.err);
     if (!g_api.solver) return;
     g_api.create_handle = reinterpret_cast<decltype(g_api.create_handle)>(dlsym(g_api.blas, "rocblas_create_handle"));
@@ -71,6 +80,27 @@ bool solver_dsyevd(void** handle_slot, hipStream_t stream, int n, double* A, dou
         *err = "rocsolver_dsyevd failed";
         return false;
     }
+    return true;
+}
+
+// C (m x n, ldc) = alpha op(A) op(B) + beta C in rocBLAS's column-major convention, on `stream`; alpha / beta by value.  The gradient of
+// SignatureLinear's levels with respect to the level features is such a product per level (grad_api.hip, sig_features_grad): a plain
+// library GEMM, which is what north_star assigns to the BLAS.
+bool solver_dgemm(void** handle_slot, hipStream_t stream, bool transA, bool transB, int m, int n, int k, double alpha, const double* A, int lda,
+                  const double* B, int ldb, double beta, double* C, int ldc, std::string* err) {
+    std::call_once(g_api_once, load_api);
+    if (!g_api.dgemm || !g_api.create_handle || !g_api.set_stream) { *err = "rocBLAS is not available: " + g_api.err; return false; }
+    if (!*handle_slot) {
+        rocblas_handle h = nullptr;
+        if (g_api.create_handle(&h) != rocblas_status_success) { *err = "rocblas_create_handle failed"; return false; }
+        *handle_slot = h;
+    }
+    rocblas_handle h = static_cast<rocblas_handle>(*handle_slot);
+    if (g_api.set_stream(h, stream) != rocblas_status_success) { *err = "rocblas_set_stream failed"; return false; }
+    if (g_api.set_pointer_mode) (void)g_api.set_pointer_mode(h, rocblas_pointer_mode_host);
+    const rocblas_status st = g_api.dgemm(h, transA ? rocblas_operation_transpose : rocblas_operation_none,
+                                          transB ? rocblas_operation_transpose : rocblas_operation_none, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc);
+    if (st != rocblas_status_success) { *err = "rocblas_dgemm failed (status " + std::to_string(int(st)) + ")"; return false; }
     return true;
 }
 

@@ -61,6 +61,7 @@ struct SigFeatArgs {
     int order;              // 1: signature_algs.py:8-35; > 1: the higher-order algorithm (:37-74), see sig_horner below
     int unit_points;        // SignatureCosine (kernels.py:820-828): <x, y> / (|x| |y|) is the linear kernel of the points x / |x|
     int norm_squared;       // this side is divided by (|Phi_m|^2 + jitter), not by its square root (K_seq_n_seq_covs: kernels.py:713 + :750)
+    int natural_order;      // every level in the natural order of its multi-indices (last index fastest): not the sibling kernel's own order
 };
 
 // Higher orders (signature_algs.py:37-74: a step may repeat an index up to `order` times, with 1 / k! for k repeats).  For the linear

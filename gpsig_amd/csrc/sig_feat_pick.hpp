@@ -10,10 +10,12 @@ typedef hipError_t (*SigFeatLaunchFn)(const SigFeatArgs&, unsigned, size_t, hipS
 template <int D, int M>
 static hipError_t sig_feat_launch(const SigFeatArgs& A, unsigned grid, size_t lds, hipStream_t stream) {
     auto kern = sig_features_kernel<D, M, false>;
-    if constexpr (sig_siblings(D, M)) kern = sig_features_sib_kernel<D, M, false>;      // sibling parents per thread: fewer multiply-adds
+    // sibling parents per thread: fewer multiply-adds, levels stored in a line-friendly order of their own (natural_order: the reverse
+    // pass of sig_feat_grad_kernel.hpp reads the features by index)
+    if constexpr (sig_siblings(D, M)) if (!A.natural_order) kern = sig_features_sib_kernel<D, M, false>;
     if (A.order > 1) {                               // the higher-order algorithm: truncated-exponential steps
         kern = sig_features_kernel<D, M, true>;
-        if constexpr (sig_siblings(D, M)) kern = sig_features_sib_kernel<D, M, true>;
+        if constexpr (sig_siblings(D, M)) if (!A.natural_order) kern = sig_features_sib_kernel<D, M, true>;
     }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

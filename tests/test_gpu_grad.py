@@ -80,6 +80,95 @@ def test_seq_level_gradients(base, difference):
             assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0]))
 
 
+@pytest.mark.parametrize("M,d", [(2, 1), (2, 5), (2, 32), (3, 2), (3, 6), (3, 16), (4, 3), (4, 4), (4, 8), (5, 2), (5, 4), (5, 8), (6, 3), (7, 2)])
+@pytest.mark.parametrize("difference", [True, False])
+def test_linear_level_gradients_through_the_feature_contraction(M, d, difference):
+    """Round 4: gradients of SignatureLinear's sequence levels through the explicit level features (csrc/sig_feat_grad_api.hip:
+    features, one rocBLAS dgemm per level and side, the reverse sweep of sig_feat_grad_kernel.hpp).  Forced on
+    (option sig_features_grad = 1) for cross / symmetric / diagonal calls over the shapes the feature kernels are built for --
+    one- and several-wavefront workgroups, columns that do and do not divide the thread count, rows over several passes of the
+    reduction tile (d = 16, 32) -- against autograd of the differentiable oracle and against the pair kernels' reverse pass."""
+    rng = np.random.default_rng(100 * M + d)
+    ctx = _host_ctx()
+    shapes = [(7, 5, 9, 6, "cross"), (9, 9, 7, 7, "sym"), (11, 11, 5, 5, "diag"), (3, 4, 2, 12, "cross")]
+    if d ** M <= 4096:
+        shapes.append((70, 33, 17, 12, "cross"))
+    try:
+        for (N1, N2, L1, L2, kind) in shapes:
+            if not difference and kind == "cross" and L1 == 2:
+                L1 = 1                                               # a single observation: one increment-free step
+            X = rng.standard_normal((N1, L1, d)) * 0.6
+            Y = rng.standard_normal((N2, L2, d)) * 0.6 if kind == "cross" else None
+            G = rng.standard_normal((M + 1, N1) if kind == "diag" else (M + 1, N1, N2 if kind == "cross" else N1))
+            kt = _t_kern("linear", d, M, difference=difference)
+            tX = torch.tensor(X, requires_grad=True)
+            tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+            lev = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
+            (lev * torch.tensor(G)).sum().backward()
+            keep = []
+            p = _params("linear", d, M, difference, keep)
+            got = {}
+            for route in (1, 0):
+                ctx.set_option("sig_features_grad", route)
+                gX, gY, gb = np.full_like(X, np.nan), (None if Y is None else np.full_like(Y, np.nan)), np.zeros(2)
+                if kind == "diag":
+                    ctx.call("gpsig_seq_diag_levels_grad", p, _vp(X), N1, L1, _vp(G), _vp(gX), gb.ctypes.data_as(_P))
+                else:
+                    ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2 if Y is not None else N1, L1, L2 if Y is not None else L1,
+                             _vp(G), _vp(gX), _vp(gY), gb.ctypes.data_as(_P))
+                got[route] = (gX, gY)
+            for route in (1, 0):
+                gX, gY = got[route]
+                assert rel(gX, tX.grad) < 1e-9, (kind, route, N1, L1, rel(gX, tX.grad))
+                if Y is not None:
+                    assert rel(gY, tY.grad) < 1e-9, (kind, route, rel(gY, tY.grad))
+            assert rel(got[1][0], got[0][0]) < 1e-10
+    finally:
+        ctx.set_option("sig_features_grad", -1)
+
+
+def test_linear_gram_gradient_through_the_feature_contraction_at_training_size():
+    """The same route where it is the planner's own choice (option left at -1): a 512 x 512 symmetric Gram of sequences of 40 points in 4
+    columns, 4 levels, against the pair kernels' reverse pass; and a module-level check -- normalised, weighted K(X) with lengthscales
+    through SignatureKernelModule -- against the oracle's autograd."""
+    from gpsig_amd import autodiff, kernels
+    rng = np.random.default_rng(9)
+    ctx = _host_ctx()
+    N, L, d, M = 512, 40, 4, 4
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1)
+    G = rng.standard_normal((M + 1, N, N))
+    keep = []
+    p = _params("linear", d, M, True, keep)
+    got = {}
+    try:
+        for route in (-1, 0):
+            ctx.set_option("sig_features_grad", route)
+            gX, gb = np.full_like(X, np.nan), np.zeros(2)
+            ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), None, N, N, L, L, _vp(G), _vp(gX), None, gb.ctypes.data_as(_P))
+            got[route] = gX
+    finally:
+        ctx.set_option("sig_features_grad", -1)
+    assert np.isfinite(got[-1]).all()
+    assert rel(got[-1], got[0]) < 1e-9, rel(got[-1], got[0])
+    # through the module (scaling, normalisation, weights as torch ops around the level primitive), the route forced on the GPU context
+    from gpsig_amd import _lib
+    N, L, d, M = 96, 20, 3, 4
+    mod, orc = _module_and_oracle("linear", d, M, L)
+    Xs = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, L * d)
+    W = rng.standard_normal((N, N))
+    dctx = _lib.context(0, torch.cuda.current_stream(torch.device("cuda:0")).cuda_stream)
+    try:
+        dctx.set_option("sig_features_grad", 1)
+        xt = torch.tensor(Xs, device="cuda:0", requires_grad=True)
+        (mod.K(xt) * torch.tensor(W, device="cuda:0")).sum().backward()
+    finally:
+        dctx.set_option("sig_features_grad", -1)
+    xo = torch.tensor(Xs, requires_grad=True)
+    (orc.K(xo) * torch.tensor(W)).sum().backward()
+    assert rel(xt.grad, xo.grad) < 1e-8, rel(xt.grad, xo.grad)
+    assert rel(mod.raw_lengthscales.grad, orc.lengthscales.grad * torch.sigmoid(mod.raw_lengthscales.detach().cpu())) < 1e-8
+
+
 @pytest.mark.parametrize("base,difference", [("rbf", True), ("poly", True), ("matern32", False)])
 def test_point_kernel_gradients_in_blocks(base, difference):
     """seq_lam_undo_kernel + lam_contract_kernel over several blocks of pairs: a symmetric Gram visits the pairs beyond a
