@@ -33,6 +33,8 @@ struct SigFeatGradArgs {
     const double* dPhi;     // (N, ld) upstream gradient with respect to them, same layout
     int64_t ld;
     double* gX;             // (N, L, D) out
+    int unit_points;        // SignatureCosine: the features are those of the unit vectors x / |x| (SigFeatArgs::unit_points); the gradient is
+                            // taken on through the normalisation, d(x / |x|) = (I - u u^T) / |x|
 };
 
 constexpr int sig_geo(int D, int n) { int s = 0; for (int k = 0; k < n; ++k) s += sig_ipow(D, k); return s; }      // 1 + D + .. + D^(n-1)
@@ -121,9 +123,25 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_feat_reverse_kernel(con
         const double* Ph = A.Phi + sq * A.ld;
         const double* dP = A.dPhi + sq * A.ld;
         __syncthreads();
-        for (int e = tid; e < R * D; e += T) {
-            const int a = e / D, f = e - a * D;
-            dx[e] = A.difference ? Xn[(a + 1) * D + f] - Xn[a * D + f] : Xn[e];
+        if (!A.unit_points) {
+            for (int e = tid; e < R * D; e += T) {
+                const int a = e / D, f = e - a * D;
+                dx[e] = A.difference ? Xn[(a + 1) * D + f] - Xn[a * D + f] : Xn[e];
+            }
+        } else {                                    // the unit vectors first (in the space of the sum g, which is not written before the sweep)
+            for (int t = tid; t < A.L; t += T) {
+                double ss = 0.0;
+#pragma unroll
+                for (int f = 0; f < D; ++f) ss = fma(Xn[t * D + f], Xn[t * D + f], ss);
+                const double inv = 1.0 / sqrt(ss);
+#pragma unroll
+                for (int f = 0; f < D; ++f) gsum[t * D + f] = Xn[t * D + f] * inv;
+            }
+            __syncthreads();
+            for (int e = tid; e < R * D; e += T) {
+                const int a = e / D, f = e - a * D;
+                dx[e] = A.difference ? gsum[(a + 1) * D + f] - gsum[a * D + f] : gsum[e];
+            }
         }
         // state after the last step: the forward pass's final features, the upstream gradients
         for (int e = tid; e < NLOW; e += T) phiB[e] = e == 0 ? 1.0 : Ph[e - 1];            // level 0 == 1; levels 1 .. M-2 follow in natural order
@@ -225,12 +243,29 @@ __global__ __launch_bounds__(sig_threads(D, M)) void sig_feat_reverse_kernel(con
         __syncthreads();
         // d/dX from d/d(increments): signature_algs.py:25-26 takes differences of the kernel matrix = increments of the sequence here
         double* gx = A.gX + sq * int64_t(A.L) * D;
-        for (int e = tid; e < A.L * D; e += T) {
-            const int t = e / D, f = e - t * D;
-            double v;
-            if (A.difference) v = (t >= 1 ? gsum[(t - 1) * D + f] : 0.0) - (t < R ? gsum[t * D + f] : 0.0);
-            else v = gsum[e];
-            gx[e] = v;
+        if (!A.unit_points) {
+            for (int e = tid; e < A.L * D; e += T) {
+                const int t = e / D, f = e - t * D;
+                double v;
+                if (A.difference) v = (t >= 1 ? gsum[(t - 1) * D + f] : 0.0) - (t < R ? gsum[t * D + f] : 0.0);
+                else v = gsum[e];
+                gx[e] = v;
+            }
+        } else {                                    // through u = x / |x|:  gx = (gu - u <u, gu>) / |x|
+            for (int t = tid; t < A.L; t += T) {
+                double gu[D], u[D], ss = 0.0, dot = 0.0;
+#pragma unroll
+                for (int f = 0; f < D; ++f) {
+                    gu[f] = A.difference ? (t >= 1 ? gsum[(t - 1) * D + f] : 0.0) - (t < R ? gsum[t * D + f] : 0.0) : gsum[t * D + f];
+                    u[f] = Xn[t * D + f];
+                    ss = fma(u[f], u[f], ss);
+                }
+                const double inv = 1.0 / sqrt(ss);
+#pragma unroll
+                for (int f = 0; f < D; ++f) { u[f] *= inv; dot = fma(u[f], gu[f], dot); }
+#pragma unroll
+                for (int f = 0; f < D; ++f) gx[t * D + f] = (gu[f] - u[f] * dot) * inv;
+            }
         }
     }
 }
