@@ -644,6 +644,49 @@ def secondary_lines(dev):
                         "traffic": rf["traffic"], "traffic_source": (rf["traffic_source"] or {}).get("how")})
         except Exception as e:                      # a side record never costs the headline its line
             out.append({"name": name, "error": repr(e)})
+    out.extend(gradient_lines(dev))
+    return out
+
+
+def gradient_lines(dev):
+    """Forward + backward of K(X) through gpsig_amd.autodiff (what the reference's TensorFlow autodiff does when it trains,
+    training.py:149-164) at 1,024 sequences of BASELINE configs[1]'s shape: the linear kernel through the feature contraction's reverse
+    pass (round 4) and through the pair kernels' (option sig_features_grad = 0), and the RBF kernel.  Side records: ms per step only."""
+    import numpy as np
+    import torch
+    from gpsig_amd import _lib, autodiff, kernels
+    out = []
+    N, L, D, M = 1024, 64, 8, 5
+    rng = np.random.default_rng(0)
+    X = torch.tensor(rng.standard_normal((N, L * D)), device=dev)
+    W = torch.tensor(rng.standard_normal((N, N)), device=dev)
+    ctx = _lib.context(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
+    for name, cls, opt in (("grad-c2shape-n1024-linear", kernels.SignatureLinear, -1), ("grad-c2shape-n1024-linear-pair-kernels", kernels.SignatureLinear, 0),
+                           ("grad-c2shape-n1024-rbf", kernels.SignatureRBF, -1)):
+        try:
+            kern = cls(L * D, D, M, lengthscales=(math.sqrt(D) if cls is kernels.SignatureRBF else 1.0))
+            mod = autodiff.SignatureKernelModule(kern, device=dev)
+            ctx.set_option("sig_features_grad", opt)
+
+            def step():
+                mod.zero_grad()
+                (mod.K(X) * W).sum().backward()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                step()
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            out.append({"name": name, "workload": "K(X) forward + backward through gpsig_amd.autodiff.SignatureKernelModule, N=%d, L=%d, d=%d, num_levels=%d, "
+                                                  "normalization=on, fp64" % (N, L, D, M),
+                        "dtype": "f64", "ms_per_step": ms, "value": float(N) * N / (ms * 1e-3), "unit": "sequence-pairs/s (forward + backward)"})
+        except Exception as e:
+            out.append({"name": name, "error": repr(e)})
+        finally:
+            ctx.set_option("sig_features_grad", -1)
     return out
 
 

@@ -25,3 +25,12 @@ def test_tile_kernel_level_partition(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "gpsig_amd", "csrc"), "-o", exe,
                            os.path.join(ROOT, "tests", "emu", "test_tvs_plan.cpp")])
     assert subprocess.check_output([exe]).split() == [b"0"]
+
+
+def test_contraction_depth_pieces(tmp_path):
+    """gpsig_amd/csrc/sig_pieces.hpp: the depth pieces of the feature contraction (equal pieces as in round 3, the last one cut into
+    finer ones of halving size in round 4) cover every slab exactly once and depend on the depth and the two counts alone."""
+    exe = str(tmp_path / "test_sig_pieces")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "gpsig_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "emu", "test_sig_pieces.cpp")])
+    assert subprocess.check_output([exe]).split() == [b"0"]

@@ -70,12 +70,20 @@ def test_default_line_carries_the_measurement():
     assert "sig_gram_dma_kernel" in rf["traffic_source"]["kernel"]
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     names = [s["name"] for s in line["secondary"]]
-    assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf"]
+    assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf",
+                     "grad-c2shape-n1024-linear", "grad-c2shape-n1024-linear-pair-kernels", "grad-c2shape-n1024-rbf"]
     ho = line["secondary"][1]                           # the higher-order algorithm at order = num_levels: the same contraction, the same time
     assert ho["bound"] == "mfma" and ho["ms_per_step"] < 1.3 * line["ms_per_step"]
     lat = line["secondary"][0]                          # the same Gram through the pair recursion: vector-issue bound, about twice the time
     assert lat["bound"] == "valu-issue" and 0.3 < lat["issue_frac"] <= 1.05 and lat["ms_per_step"] > line["ms_per_step"]
     for s in line["secondary"]:
         assert "error" not in s, s
-        assert s["rel_err"] <= (1e-4 if s["dtype"] == "f32" else 1e-6) and s["ms_per_step"] > 0 and s["clock_ghz"] > 1.0
+        assert s["ms_per_step"] > 0
+        if not s["name"].startswith("grad-"):
+            assert s["rel_err"] <= (1e-4 if s["dtype"] == "f32" else 1e-6) and s["clock_ghz"] > 1.0
+    c5 = line["secondary"][5]                           # configs[4]: priced as issue-bound from its counters (round 4)
+    assert c5["bound"] == "valu-issue" and 0.5 < c5["issue_frac"] <= 1.1
+    g = {s["name"]: s["ms_per_step"] for s in line["secondary"] if s["name"].startswith("grad-")}
+    # the linear kernel's reverse pass through the feature contraction: several times faster than through the pair kernels
+    assert g["grad-c2shape-n1024-linear"] * 3 < g["grad-c2shape-n1024-linear-pair-kernels"]
     assert line["secondary"][3]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
