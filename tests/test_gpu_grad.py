@@ -131,6 +131,31 @@ def test_linear_level_gradients_through_the_feature_contraction(M, d, difference
         ctx.set_option("sig_features_grad", -1)
 
 
+def test_feature_route_gradient_undoes_long_sweeps_accurately():
+    """The reverse sweep stores nothing of the forward pass but its final features and UNDOES one step at a time: the early-time
+    features come out as differences of the (much larger) late-time ones.  White-noise sequences of 150 and 300 points, whose level-5
+    features reach 1e8 .. 1e11, against autograd of the differentiable oracle (which keeps every intermediate)."""
+    rng = np.random.default_rng(77)
+    ctx = _host_ctx()
+    try:
+        ctx.set_option("sig_features_grad", 1)
+        for (N, L, d, M) in ((6, 150, 3, 5), (4, 300, 2, 6), (5, 128, 8, 4)):
+            X = rng.standard_normal((N, L, d))
+            G = rng.standard_normal((M + 1, N, N))
+            kt = _t_kern("linear", d, M, difference=True)
+            tX = torch.tensor(X, requires_grad=True)
+            lev = kt.K_seq_levels(tX, None)
+            (lev * torch.tensor(G)).sum().backward()
+            keep = []
+            p = _params("linear", d, M, True, keep)
+            gX, gb = np.full_like(X, np.nan), np.zeros(2)
+            ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), None, N, N, L, L, _vp(G), _vp(gX), None, gb.ctypes.data_as(_P))
+            assert float(lev.detach().abs().max()) > 1e8
+            assert rel(gX, tX.grad) < 1e-9, (N, L, d, M, rel(gX, tX.grad))
+    finally:
+        ctx.set_option("sig_features_grad", -1)
+
+
 def test_linear_gram_gradient_through_the_feature_contraction_at_training_size():
     """The same route where it is the planner's own choice (option left at -1): a 512 x 512 symmetric Gram of sequences of 40 points in 4
     columns, 4 levels, against the pair kernels' reverse pass; and a module-level check -- normalised, weighted K(X) with lengthscales
