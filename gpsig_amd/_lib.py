@@ -71,6 +71,8 @@ _KERNEL_FUNCS = {
     "gpsig_lr_whitening": [C.POINTER(C.c_double), _i32, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "gpsig_lr_seq_features": [_LR, _vp, _i64, _i32, _vp],
     "gpsig_lr_tens_features": [_LR, _vp, _i64, _i32, _vp],
+    "gpsig_lr_seq_features_dev": [_i32, _i32, _i32, C.POINTER(SketchC), _vp, _i64, _i32, _vp, _vp, _vp],
+    "gpsig_lr_seq_features_grad": [_i32, _i32, _i32, C.POINTER(SketchC), _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)],
     "gpsig_lr_kernel": [_LR, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "gpsig_lr_kernel_diag": [_LR, _vp, _i64, _i32, _vp],
     "gpsig_seq_gram_levels_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(C.c_double)],

@@ -422,7 +422,25 @@ class LowRankDraw:
             sk = []
             for s_ in self.sketches:
                 col = np.repeat(np.arange(s_.r), np.diff(s_.colptr))
-                sk.append((t(s_.i1, torch.int64), t(s_.i2, torch.int64), t(s_.val, torch.float64), t(col, torch.int64), int(s_.r)))
+                i1, i2, val, colt = t(s_.i1, torch.int64), t(s_.i2, torch.int64), t(s_.val, torch.float64), t(col, torch.int64)
+                # the projection as a dense (entries, r) matrix holding each entry's value in its output column: summing an entry's product
+                # into its column is then a GEMM (index_add does it with atomics on r addresses per row: 6-14 ms for the inducing
+                # tensors' six chained projections at the reference's default ranks; this: well under a millisecond)
+                # ... and the two operand selections a[:, i1], b[:, i2] as products with 0 / 1 matrices (k1, entries), (k2, entries): the
+                # reverse pass of a gather is a scatter-add with atomics as well, that of a product another product
+                dense = None
+                nnz = int(val.shape[0])
+                if nnz * max(int(s_.r), int(s_.k1), int(s_.k2)) <= (1 << 24):
+                    ar = torch.arange(nnz, device=device)
+                    out_m = torch.zeros((nnz, int(s_.r)), dtype=torch.float64, device=device)
+                    sel1 = torch.zeros((int(s_.k1), nnz), dtype=torch.float64, device=device)
+                    sel2 = torch.zeros((int(s_.k2), nnz), dtype=torch.float64, device=device)
+                    if nnz:
+                        out_m[ar, colt] = val
+                        sel1[i1, ar] = 1.0
+                        sel2[i2, ar] = 1.0
+                    dense = (sel1, sel2, out_m)
+                sk.append((i1, i2, val, colt, int(s_.r), dense))
             self._dev[key] = (t(self.idx, torch.int64), t(self.jitter_diag, torch.float64), sk)
         return self._dev[key]
 
@@ -430,7 +448,7 @@ class LowRankDraw:
 def _apply_sketch(sk, A, B):
     """lr_hadamard_prod_rand (low_rank_calculations.py:76-193) given its random matrix: out[..., j] = sum over the entries e of
     column j of val[e] A[..., i1[e]] B[..., i2[e]].  (..., k1), (..., k2) -> (..., r); rows in chunks of at most 2^27 products."""
-    i1, i2, val, col, r = sk
+    i1, i2, val, col, r, dense = sk
     lead = A.shape[:-1]
     A2, B2 = A.reshape(-1, A.shape[-1]), B.reshape(-1, B.shape[-1])
     rows, nnz = A2.shape[0], max(int(i1.shape[0]), 1)
@@ -438,10 +456,68 @@ def _apply_sketch(sk, A, B):
     outs = []
     for r0 in range(0, rows, step):
         a, b = A2[r0:r0 + step], B2[r0:r0 + step]
+        if dense is not None and dense[0].dtype == a.dtype:
+            outs.append(((a @ dense[0]) * (b @ dense[1])) @ dense[2])
+            continue
         prod = a[:, i1] * b[:, i2] * val
         outs.append(torch.zeros((a.shape[0], r), dtype=prod.dtype, device=prod.device).index_add(1, col, prod))
     out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
     return out.reshape(*lead, r)
+
+
+def _sketch_array(sketches, keep):
+    """gpsig_sketch[] of host-side ``low_rank.Sketch`` objects (the arrays stay alive in ``keep``)."""
+    arr = (_lib.SketchC * max(len(sketches), 1))()
+    for k, sk in enumerate(sketches):
+        cp, i1, i2, val = (np.ascontiguousarray(sk.colptr, np.int32), np.ascontiguousarray(sk.i1, np.int32), np.ascontiguousarray(sk.i2, np.int32),
+                           np.ascontiguousarray(sk.val, np.float64))
+        keep.extend([cp, i1, i2, val])
+        arr[k].k1, arr[k].k2, arr[k].r, arr[k].nnz = int(sk.k1), int(sk.k2), int(sk.r), int(val.shape[0])
+        arr[k].colptr = cp.ctypes.data_as(C.POINTER(C.c_int32))
+        arr[k].i1 = i1.ctypes.data_as(C.POINTER(C.c_int32))
+        arr[k].i2 = i2.ctypes.data_as(C.POINTER(C.c_int32))
+        arr[k].val = val.ctypes.data_as(C.POINTER(C.c_double))
+    keep.append(arr)
+    return arr
+
+
+class _LrSeqFeatures(torch.autograd.Function):
+    """_K_seq_lr_feat (kernels.py:239-261) given the landmarks and the whitening: scaled sequences (N, L, d), S (c, d), Wh (c, c) ->
+    Phi (N, 1 + c + (M-1) r), by the fused HIP feature kernel; the reverse pass by lr_seq_features_grad_kernel (csrc/lr_grad_kernel.hpp):
+    dPhi -> dX, dS, dWh, d base parameter.  Round 3 ran both directions as torch ops (_LowRankScope._seq_torch below: gather x gather x
+    value + index_add over every (point, entry) product), 9.1 s for the SVGP covariances of BASELINE configs[2]."""
+
+    @staticmethod
+    def forward(ctx, Xs, S, Wh, p0, spec, sketches, r):
+        X, Sd, Whd = _c(Xs), _c(S), _c(Wh)
+        n, l, d = X.shape
+        cc = Sd.shape[0]
+        keep = []
+        p = spec.params(d, _p0_value(p0), keep)
+        arr = _sketch_array(sketches, keep)
+        F = 1 + cc + (spec.num_levels - 1) * int(r)
+        out = torch.empty((n, F), dtype=torch.float64, device=X.device)
+        _ctx_for(X).call("gpsig_lr_seq_features_dev", p, cc, int(r), len(sketches), arr, _ptr(X), n, l, _ptr(Sd), _ptr(Whd), _ptr(out))
+        ctx.spec, ctx.sketches, ctx.r, ctx.has_p0 = spec, sketches, int(r), p0 is not None
+        ctx.dt = (Xs.dtype, S.dtype, Wh.dtype)
+        ctx.save_for_backward(X, Sd, Whd, p0 if p0 is not None else X.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        X, Sd, Whd, p0 = ctx.saved_tensors
+        n, l, d = X.shape
+        cc = Sd.shape[0]
+        keep = []
+        p = ctx.spec.params(d, _p0_value(p0) if ctx.has_p0 else 0.0, keep)
+        arr = _sketch_array(ctx.sketches, keep)
+        G = _c(G)
+        gX, gS, gWh = torch.empty_like(X), torch.empty_like(Sd), torch.empty_like(Whd)
+        gb = torch.zeros(2, dtype=torch.float64, device=X.device)
+        _ctx_for(X).call("gpsig_lr_seq_features_grad", p, cc, ctx.r, len(ctx.sketches), arr, _ptr(X), n, l, _ptr(Sd), _ptr(Whd), _ptr(G),
+                         _ptr(gX), _ptr(gS), _ptr(gWh), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
+        gp0 = gb[0].to(p0.device).reshape(p0.shape).to(p0.dtype) if ctx.has_p0 else None
+        return gX.to(ctx.dt[0]), gS.to(ctx.dt[1]), gWh.to(ctx.dt[2]), gp0, None, None, None
 
 
 class _LowRankScope:
@@ -450,6 +526,7 @@ class _LowRankScope:
 
     def __init__(self, mod, pool, draw):
         idx, jd, self.sk = draw.on(pool.device)
+        self.host_sketches = draw.sketches
         if int(idx.max()) >= pool.shape[0]:
             raise ValueError("the low-rank draw indexes %d points, the evaluation has %d" % (int(idx.max()) + 1, pool.shape[0]))
         self.mod = mod
@@ -468,9 +545,32 @@ class _LowRankScope:
         return self.mod._kappa(pts, self.S) @ self.Wh                                               # :59-61
 
     def seq(self, Xs):
-        """signature_algs.py:162-192 (with :191 summing P, as evidently intended).  (N, L, d') -> [(N, 1), (N, c), (N, r), ...]."""
+        """signature_algs.py:162-192 (with :191 summing P, as evidently intended).  (N, L, d') -> [(N, 1), (N, c), (N, r), ...].
+        Through the HIP feature kernel and its reverse pass (_LrSeqFeatures) where they are built; torch ops otherwise (long sequences
+        at large ranks, more than 64 components, module option ``lr_hip = False``)."""
         key = id(Xs)
+        if key not in self._seq and getattr(self.mod, "lr_hip", True) and Xs.is_cuda:
+            mod, kern = self.mod, self.mod.kern
+            M, cc = kern.num_levels, int(self.S.shape[0])
+            r = int(self.host_sketches[0].r) if self.host_sketches else int(kern.rank_bound)
+            L, d = int(Xs.shape[1]), int(Xs.shape[2])
+            # what csrc/lr_grad_api.hip takes: four (width, L) arrays of a sequence in LDS, at most 64 components
+            rows, lp = max(cc, r, d, 16), (L + 63) // 64 * 64 + 1
+            if kern._base != "spectral" and cc <= 64 and cc * d <= 4096 and 8 * lp * 4 * rows <= 156 * 1024 and M - 1 <= 7:
+                try:
+                    Phi = _LrSeqFeatures.apply(Xs, self.S, self.Wh, mod.p0, mod._spec, self.host_sketches, r)
+                    cuts = [1, cc] + [r] * (M - 1)
+                    self._seq[key] = (Xs, list(torch.split(Phi, cuts, dim=1)))
+                except NotImplementedError:
+                    pass
         if key not in self._seq:
+            self._seq[key] = (Xs, self._seq_torch(Xs))
+        return self._seq[key][1]
+
+    def _seq_torch(self, Xs):
+        """The same feature map as torch ops (round 3's route; kept as the checker of the HIP reverse pass and for shapes it is not
+        built for)."""
+        if True:
             N, L, d = Xs.shape
             U = self._nys(Xs.reshape(N * L, d)).reshape(N, L, -1)                                   # kernels.py:252-254
             if self.mod.kern.difference:
@@ -481,8 +581,7 @@ class _LowRankScope:
                 P = torch.cumsum(P, dim=1) - P                                                      # :186 exclusive
                 P = _apply_sketch(self.sk[i - 2], U, P)                                             # :188 / :190
                 Phi.append(P.sum(dim=1))
-            self._seq[key] = (Xs, Phi)                                                              # (the tensor is kept alive: its id is the key)
-        return self._seq[key][1]
+            return Phi
 
     def tens(self, Zs, increments):
         """signature_algs.py:194-222, kernels.py:285-311.  (lt, T[, 2], d') -> [(T, 1), (T, c), (T, r), ...]."""

@@ -1922,6 +1922,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "sig_features")) c->sig_features = value;
     else if (!strcmp(name, "sig_gemm_dma")) c->sig_gemm_dma = value;
     else if (!strcmp(name, "sig_graded")) c->sig_graded = value;
+    else if (!strcmp(name, "lr_grad_threads")) c->lr_grad_threads = value;
     else if (!strcmp(name, "sig_features_grad")) c->sig_features_grad = value;
     else if (!strcmp(name, "sig_features_keep")) { c->sf_keep = value; c->sf_valid = false; }
     else if (!strcmp(name, "keep_reset")) c->keep_reset = value ? 1 : 0;

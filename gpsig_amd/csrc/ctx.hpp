@@ -92,6 +92,7 @@ struct gpsig_ctx {
     bool sf_valid = false;
     const void* sf_X = nullptr; const void* sf_phi = nullptr; uint64_t sf_key = 0;
     int sig_features_grad = -1;          // gradients of SignatureLinear's sequence levels through the feature contraction (sig_feat_grad_api.hip): -1 where cheaper, 0 never, 1 wherever built
+    int lr_grad_threads = 1024;          // workgroup size of the low-rank reverse kernel (lr_grad_kernel.hpp): 1024 or 512
     int sig_graded = 1;                  // the contraction's last depth piece cut into finer ones (sig_piece_bounds); 0: equal pieces (round 3)
     int sig_gemm_dma = 1;                // the contraction's slabs by LDS-DMA with fragments prefetched across the barrier (0: register-staged form)
     int lr_jacobi = 1;            // gpsig_lr_draw: eigendecomposition of the landmark Gram by the one-workgroup Jacobi kernel (c <= 64), 0: rocSOLVER
@@ -113,6 +114,10 @@ struct gpsig_ctx {
     std::vector<size_t> lr_offsets;        // byte offsets of the uploaded arrays inside it, in lr_upload's order
     int64_t lr_off_key[3] = {-1, -1, -1};  // (M, c, r) of the level offsets in B_LR1
     void* lr_off_base = nullptr;
+    // the projections of the training path's low-rank entry points (lr_grad_api.hip), kept in B_LR8 by content
+    uint64_t lrg_hash = 0;
+    void* lrg_base = nullptr;
+    std::vector<size_t> lrg_offsets;
     // timing of the pair-recursion launches
     std::vector<hipEvent_t> ev;     // pairs (start, stop)
     size_t ev_used = 0;

@@ -8,6 +8,13 @@
 
 namespace gpsig {
 
+// Landmarks, whitening matrix and sketch entries are read-only for the whole launch and addressed wave-uniformly: in the
+// constant address space the compiler may serve them through the scalar unit (s_load) instead of broadcasting vector loads.
+template <typename T>
+using lr_const_ptr = const __attribute__((address_space(4))) T*;
+template <typename T>
+__device__ __forceinline__ lr_const_ptr<T> lr_as_const(const T* p) { return (lr_const_ptr<T>)(p); }
+
 struct LrEntry { double val; int32_t i1, i2; };     // one entry of a sketch, stored by output column (16 bytes: one s_load_dwordx4)
 
 struct LrFusedSketch { const int32_t* colptr; const LrEntry* ent; };

@@ -28,13 +28,6 @@
 
 namespace gpsig {
 
-// Landmarks, whitening matrix and sketch entries are read-only for the whole launch and addressed wave-uniformly: in the
-// constant address space the compiler may serve them through the scalar unit (s_load) instead of broadcasting vector loads.
-template <typename T>
-using lr_const_ptr = const __attribute__((address_space(4))) T*;
-template <typename T>
-__device__ __forceinline__ lr_const_ptr<T> lr_as_const(const T* p) { return (lr_const_ptr<T>)(p); }
-
 // THREADS: workgroup size (the LDS footprint of a sequence does not depend on it, so more wavefronts per workgroup are more
 // wavefronts per CU to hide the scalar-load latency of the sketch entries behind); UNROLL: sketch entries per scalar-load batch.
 template <int THREADS, int UNROLL>

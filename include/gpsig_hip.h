@@ -304,6 +304,19 @@ int gpsig_base_kernel_matrix(gpsig_ctx* ctx, const gpsig_params* p, const double
  * jitter_diag as settings.jitter * uniform(0, 1) per landmark (:52); it is an argument here so that the caller owns the RNG. */
 int gpsig_lr_whitening(gpsig_ctx* ctx, const gpsig_params* p, const double* landmarks_host, int32_t c, int32_t d,
                        const double* jitter_diag_host, double* whitening_host, double* eigenvalues_host);
+/* The same feature map for the TRAINING path (round 4): when the reference trains in low-rank mode the landmarks are gathered from the
+ * scaled inputs and their Gram is decomposed inside the differentiated graph (low_rank_calculations.py:47-60), so landmarks S (c, d) and
+ * whitening Wh (c, c) are functions of the trainable parameters and live on the device -- DEVICE pointers, like X (N, L, d: columns as
+ * they come, no scaling inside, p->num_lags = 0) and Phi (N, F = 1 + c + (M-1) r); device-pointer mode only.  The projections of
+ * levels 2..M are value-independent random objects: HOST arrays, kept on the device by content across calls.
+ * _grad: dPhi (N, F) -> gX (N, L, d), gS (c, d), gWh (c, c), g_base[0] (the base kernel's own parameter, or NULL) -- what tf.gradients
+ * returns for _K_seq_lr_feat (kernels.py:239-261) given the landmarks and the whitening; the caller chains gS and gWh through the
+ * gather and the eigendecomposition (gpsig_amd/autodiff.py).  num_components <= 64. */
+int gpsig_lr_seq_features_dev(gpsig_ctx* ctx, const gpsig_params* p, int32_t num_components, int32_t rank_bound, int32_t num_sketches,
+                              const gpsig_sketch* sketches, const void* X, int64_t N, int32_t L, const double* S, const double* Wh, void* Phi);
+int gpsig_lr_seq_features_grad(gpsig_ctx* ctx, const gpsig_params* p, int32_t num_components, int32_t rank_bound, int32_t num_sketches,
+                               const gpsig_sketch* sketches, const void* X, int64_t N, int32_t L, const double* S, const double* Wh,
+                               const void* dPhi, void* gX, double* gS, double* gWh, double* g_base);
 /* SignatureKernel._K_seq_lr_feat (kernels.py:239-261): Nystrom_map + signature_kern_first_order_lr_feature.  Phi: (N, F). */
 int gpsig_lr_seq_features(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowrank* lr, const void* X, int64_t N, int32_t L, void* Phi);
 /* SignatureKernel._K_tens_lr_feat (kernels.py:285-311): Nystrom_map + tensor_kern_lr_feature.  Phi: (T, F). */

@@ -1029,6 +1029,56 @@ def test_low_rank_module_gradients(base, sparsity, num_lags, normalization, diff
     assert a.shape == (N, N) and not torch.equal(a, b) and bool(torch.isfinite(a).all())
 
 
+@pytest.mark.parametrize("base,M,L,d,c,r,difference,sparsity",
+                         [("rbf", 4, 50, 6, 50, 50, True, "sqrt"), ("rbf", 3, 9, 3, 7, 6, True, "sqrt"), ("linear", 3, 70, 4, 12, 20, True, "log"),
+                          ("matern32", 5, 33, 2, 9, 5, False, "sqrt"), ("poly", 2, 17, 5, 20, 8, True, "lin"), ("mix", 1, 12, 3, 10, 4, True, "sqrt"),
+                          ("rbf", 3, 130, 3, 16, 16, True, "sqrt"), ("cosine", 3, 20, 4, 6, 64, False, "sqrt"), ("matern52", 4, 1, 3, 5, 5, False, "sqrt"),
+                          ("matern12", 3, 2, 3, 5, 7, True, "log")])
+def test_low_rank_sequence_features_and_their_reverse_pass(base, M, L, d, c, r, difference, sparsity):
+    """Round 4: gpsig_lr_seq_features_dev / gpsig_lr_seq_features_grad (csrc/lr_grad_api.hip, lr_grad_kernel.hpp) -- the low-rank feature
+    map of a batch of sequences given landmarks and whitening on the device, and its reverse pass in one kernel (the forward sweep
+    repeated into a per-workgroup scratch, the projections' adjoints as gathers over transposed copies of the projections, the base
+    kernel's derivatives) -- against the torch-op route of round 3 (gather x gather x value + index_add, differentiated by autograd):
+    the feature values, d/dX, d/d landmarks, d/d whitening and the base kernel's own parameter.  Shapes: BASELINE configs[2]'s at the
+    reference's default ranks, several time chunks of 64, r > c and c > r, one and two observations, every base-kernel family."""
+    from gpsig_amd import autodiff, kernels, low_rank as lrm
+    rng = np.random.default_rng(1000 + M * 10 + d)
+    dev = torch.device("cuda:0")
+    cls = {"rbf": kernels.SignatureRBF, "linear": kernels.SignatureLinear, "matern32": kernels.SignatureMatern32, "poly": kernels.SignaturePoly,
+           "mix": kernels.SignatureMix, "cosine": kernels.SignatureCosine, "matern52": kernels.SignatureMatern52, "matern12": kernels.SignatureMatern12}[base]
+    kern = cls(L * d, d, M, difference=difference, lengthscales=None, low_rank=True, num_components=c, rank_bound=r, sparsity=sparsity)
+    mod = autodiff.SignatureKernelModule(kern, device=dev)
+    N = 37
+    sk = lrm.draw_level_sketches(rng, M, c, r, sparsity)
+    draw = autodiff.LowRankDraw(np.arange(c), 1e-6 * rng.random(c), sk)
+    X0 = np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1)
+    S0 = 0.7 * rng.standard_normal((c, d))
+    W0 = rng.standard_normal((c, c)) / np.sqrt(c)
+    G0 = rng.standard_normal((N, 1 + c + (M - 1) * r))
+    out = {}
+    for route in ("hip", "torch"):
+        X = torch.tensor(X0, device=dev, requires_grad=True)
+        S = torch.tensor(S0, device=dev, requires_grad=True)
+        Wh = torch.tensor(W0, device=dev, requires_grad=True)
+        mod.zero_grad()
+        scope = autodiff._LowRankScope.__new__(autodiff._LowRankScope)         # a scope around GIVEN landmarks / whitening
+        scope.mod, scope.S, scope.Wh, scope._seq, scope._tens = mod, S, Wh, {}, {}
+        _, _, scope.sk = draw.on(dev)
+        scope.host_sketches = draw.sketches
+        mod.lr_hip = route == "hip"
+        try:
+            Phi = torch.cat(scope.seq(X), dim=1)
+        finally:
+            mod.lr_hip = True
+        (Phi * torch.tensor(G0, device=dev)).sum().backward()
+        out[route] = (Phi.detach(), X.grad, S.grad, Wh.grad, None if mod.raw_p0 is None else mod.raw_p0.grad.clone())
+    assert rel(out["hip"][0], out["torch"][0]) < 1e-11, rel(out["hip"][0], out["torch"][0])
+    for k, name in ((1, "dX"), (2, "dS"), (3, "dWh")):
+        assert rel(out["hip"][k], out["torch"][k]) < 1e-9, (name, rel(out["hip"][k], out["torch"][k]))
+    if out["torch"][4] is not None:
+        assert rel(out["hip"][4], out["torch"][4]) < 1e-9
+
+
 def test_low_rank_svgp_trains():
     """The reference's benchmark driver can train in low-rank mode (benchmarks/models/train_gpsig.py:21, :58): an ELBO step through the
     low-rank covariances has finite gradients for every parameter and Adam decreases the loss."""
