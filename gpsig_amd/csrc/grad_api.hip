@@ -197,7 +197,10 @@ int launch_contract(gpsig_ctx* c, int DP, dim3 grid, int block, size_t lds, cons
             else hipLaunchKernelGGL((lam_contract_kernel<DP_, SIDE, -1, false>), grid, dim3(block), lds, c->stream, a);                 \
         }                                                                                                                               \
     } while (0)
-    if (DP == 4) LC(4); else if (DP == 8) LC(8); else LC(16);
+    // (round 4: DP = 32 / 64 used to fall into the 16-column instance, which silently dropped the columns beyond 16 -- reached by the
+    // higher-order route only, whose callers pad 17 .. 64 columns to 32 / 64; found by the feature route's parity test at d = 32)
+    if (DP == 4) LC(4); else if (DP == 8) LC(8); else if (DP == 16) LC(16); else if (DP == 32) LC(32); else if (DP == 64) LC(64);
+    else return fail(c, GPSIG_ERR_UNSUPPORTED, "no contraction kernel for %d padded columns", DP);
 #undef LC
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;

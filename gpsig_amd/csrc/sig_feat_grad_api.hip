@@ -66,7 +66,8 @@ int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     const int M = p->num_levels;
     // the linear kernel, and the cosine kernel as the linear kernel of the unit vectors x / |x| (kernels.py:820-828)
     const bool cosine = p->base_kernel == GPSIG_BASE_COSINE;
-    if (c->sig_features_grad == 0 || !(p->base_kernel == GPSIG_BASE_LINEAR || cosine) || p->order != 1 || M < 2 || c->capturing) return GPSIG_OK;
+    const int order = p->order < 1 ? 1 : (p->order > M ? M : p->order);
+    if (c->sig_features_grad == 0 || !(p->base_kernel == GPSIG_BASE_LINEAR || cosine) || M < 2 || M > 8 || c->capturing) return GPSIG_OK;
     if (N1 <= 0 || N2 <= 0 || N1 > 0x3fffffff || N2 > 0x3fffffff) return GPSIG_OK;
     SigFeatLaunchFn ffn = sig_feat_lookup(d, M);
     SigFeatGradLaunchFn rfn = sig_feat_grad_lookup(d, M);
@@ -75,7 +76,8 @@ int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     if (r1 < 1 || r2 < 1) return GPSIG_OK;
     const int64_t F = sig_feature_count(d, M), ld = (F + 1 + 15) / 16 * 16;
     const int Lmax = L1 > L2 ? L1 : L2;
-    const size_t lds_f = sig_features_lds_bytes(d, M, Lmax), lds_r = sig_feat_grad_lds_bytes(d, M, Lmax);
+    const size_t lds_f = sig_features_lds_bytes(d, M, Lmax);
+    const size_t lds_r = order > 1 ? sig_feat_grad_ho_lds_bytes(d, M, Lmax) : sig_feat_grad_lds_bytes(d, M, Lmax);
     if (lds_f > 150 * 1024 || lds_r > 158 * 1024) return GPSIG_OK;
     const bool two = !diag && !sym;
     const size_t bytes = sizeof(double) * size_t(ld) * (size_t(N1) + (two ? size_t(N2) : 0)) * 2 + (sym ? sizeof(double) * size_t(N1) * N1 : 0);
@@ -85,7 +87,8 @@ int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         // F per pair near the matrix peak (one with the symmetrised upstream; the diagonal: none) and, per sequence, the forward sweep plus a reverse sweep of three times its
         // arithmetic at a fraction of the vector rate; a dozen launches against one or two
         const double pairs = diag ? double(N1) : double(N1) * double(N2), seqs = double(N1) + (two ? double(N2) : 0.0);
-        const double lattice = 3.0 * double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0) * (cosine ? 1.5 : 1.0);      // (cosine: the point kernels' two-step reverse pass)
+        // (cosine: the point kernels' two-step reverse pass; higher orders: the scratch-based kernels, hundreds of launches per block of pairs)
+        const double lattice = 3.0 * double(r1) * r2 * (2.0 * d + 3.0 * M - 1.0) * (cosine ? 1.5 : 1.0) * (order > 1 ? 50.0 : 1.0);
         const double t_lat = 100e-6 + pairs * lattice / 20e12;
         const double t_feat = 150e-6 + 15e-6 * M + (diag ? 0.0 : pairs * (sym ? 2.0 : 4.0) * double(F) / 45e12) + seqs * double(Lmax) * double(sig_ipow(d, M)) * 8.0 / 8e12;
         if (!(t_feat < t_lat)) return GPSIG_OK;
@@ -108,7 +111,7 @@ int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         memset(&A, 0, sizeof(A));
         A.X = Xs; A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = s;
         A.w = nullptr; A.normalize = 0; A.jitter = 0.0; A.Phi = static_cast<double*>(phi); A.ld = ld; A.dlev = nullptr;
-        A.order = 1; A.natural_order = 1; A.unit_points = cosine ? 1 : 0;
+        A.order = order; A.natural_order = 1; A.unit_points = cosine ? 1 : 0;
         hipError_t e = ffn(A, unsigned(N < 4096 ? N : 4096), sig_features_lds_bytes(d, M, L), c->stream);
         if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
         return GPSIG_OK;
@@ -151,7 +154,23 @@ int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         memset(&A, 0, sizeof(A));
         A.X = Xs; A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.Phi = Ph; A.dPhi = dP; A.ld = ld; A.gX = gx;
         A.unit_points = cosine ? 1 : 0;
-        hipError_t e = rfn(A, unsigned(N < 8192 ? N : 8192), sig_feat_grad_lds_bytes(d, M, L), c->stream);
+        A.order = order;
+        if (order > 1) {
+            // E(dx) = sum_{k <= order} dx^(x)k / k!: its inverse series, and the weights of the Horner sub-steps' intermediates
+            double fact[10];
+            fact[0] = 1.0;
+            for (int k = 1; k < 10; ++k) fact[k] = fact[k - 1] * k;
+            A.cinv[0] = 1.0;
+            for (int k = 1; k <= 8; ++k) {
+                double v = 0.0;
+                for (int j = 1; j <= k && j <= order; ++j) v -= A.cinv[k - j] / fact[j];
+                A.cinv[k] = v;
+            }
+            for (int j = 0; j <= 8; ++j)
+                for (int k = 0; k <= 8; ++k) A.w[j][k] = (j + k <= 9) ? fact[j] / fact[j + k] : 0.0;
+        }
+        const size_t lds_rev = order > 1 ? sig_feat_grad_ho_lds_bytes(d, M, L) : sig_feat_grad_lds_bytes(d, M, L);
+        hipError_t e = rfn(A, unsigned(N < 8192 ? N : 8192), lds_rev, c->stream);
         if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_feat_reverse_kernel: %s", hipGetErrorString(e));
         return GPSIG_OK;
     };

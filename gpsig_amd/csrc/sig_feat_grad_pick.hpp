@@ -10,6 +10,7 @@ typedef hipError_t (*SigFeatGradLaunchFn)(const SigFeatGradArgs&, unsigned, size
 template <int D, int M>
 static hipError_t sig_feat_grad_launch(const SigFeatGradArgs& A, unsigned grid, size_t lds, hipStream_t stream) {
     auto kern = sig_feat_reverse_kernel<D, M>;
+    if (A.order > 1) kern = sig_feat_reverse_ho_kernel<D, M>;       // the higher-order algorithm: Horner sub-steps (one more LDS layout: the caller sized `lds` for it)
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;

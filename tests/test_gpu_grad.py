@@ -131,6 +131,79 @@ def test_linear_level_gradients_through_the_feature_contraction(M, d, difference
         ctx.set_option("sig_features_grad", -1)
 
 
+@pytest.mark.parametrize("M,d,order", [(2, 3, 2), (3, 2, 2), (3, 2, 3), (3, 6, 2), (4, 3, 2), (4, 3, 3), (4, 3, 4), (4, 8, 4), (5, 2, 3), (5, 4, 5), (5, 8, 2),
+                                       (5, 8, 5), (6, 3, 6), (6, 2, 4), (3, 16, 3), (2, 32, 2)])
+@pytest.mark.parametrize("base", ["linear", "cosine"])
+def test_higher_order_linear_gradients_through_the_feature_contraction(M, d, order, base):
+    """Round 4: the higher-order algorithm (signature_algs.py:37-74; order = num_levels is the signature kernel the reference's notebook
+    checks against esig) of the linear / cosine kernel differentiates through the feature contraction too: the step is a multiplication
+    by the truncated exponential of the increment, undone by its inverse series, its adjoint taken through `order` Horner sub-steps
+    (sig_feat_reverse_ho_kernel).  Cross / symmetric / diagonal calls against autograd of the differentiable oracle, and against the
+    scratch-based higher-order kernels (which took 13 s for one 2,048 x 2,048 Gram at order 3: tools/bench_train_paths.py)."""
+    if base == "cosine" and (M, d, order) not in ((3, 2, 2), (4, 3, 4), (5, 4, 5), (3, 6, 2)):
+        pytest.skip("cosine: a sample of the shapes")
+    rng = np.random.default_rng(1000 * order + 10 * M + d)
+    ctx = _host_ctx()
+    try:
+        for (N1, N2, L1, L2, kind) in [(6, 5, 8, 5, "cross"), (7, 7, 6, 6, "sym"), (9, 9, 5, 5, "diag"), (3, 4, 2, 9, "cross")]:
+            X = rng.standard_normal((N1, L1, d)) * 0.6
+            Y = rng.standard_normal((N2, L2, d)) * 0.6 if kind == "cross" else None
+            G = rng.standard_normal((M + 1, N1) if kind == "diag" else (M + 1, N1, N2 if kind == "cross" else N1))
+            kt = _t_kern(base, d, M, difference=True, order=order)
+            tX = torch.tensor(X, requires_grad=True)
+            tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+            lev = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
+            (lev * torch.tensor(G)).sum().backward()
+            keep = []
+            p = _params(base, d, M, True, keep, order=order)
+            got = {}
+            for route in ((1, 0) if d ** M <= 1024 else (1,)):
+                ctx.set_option("sig_features_grad", route)
+                gX, gY, gb = np.full_like(X, np.nan), (None if Y is None else np.full_like(Y, np.nan)), np.zeros(2)
+                if kind == "diag":
+                    ctx.call("gpsig_seq_diag_levels_grad", p, _vp(X), N1, L1, _vp(G), _vp(gX), gb.ctypes.data_as(_P))
+                else:
+                    ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2 if Y is not None else N1, L1, L2 if Y is not None else L1,
+                             _vp(G), _vp(gX), _vp(gY), gb.ctypes.data_as(_P))
+                got[route] = (gX, gY)
+                assert rel(gX, tX.grad) < 1e-9, (kind, route, rel(gX, tX.grad))
+                if Y is not None:
+                    assert rel(gY, tY.grad) < 1e-9, (kind, route, rel(gY, tY.grad))
+    finally:
+        ctx.set_option("sig_features_grad", -1)
+
+
+@pytest.mark.parametrize("base,d", [("rbf", 20), ("linear", 32), ("matern32", 40), ("rbf", 64)])
+def test_higher_order_gradients_beyond_16_columns(base, d):
+    """Regression (round 4): the higher-order gradient route pads 17 .. 64 columns to 32 / 64, and the contraction of Lam with the base
+    kernel's derivatives used to fall into its 16-column instance for them -- the gradient's columns beyond 16 came out wrong, silently
+    (found by the feature route's parity test at d = 32; the higher-order tests had stopped at 5 columns).  The scratch-based route
+    (option sig_features_grad = 0) against the oracle's autograd, cross and symmetric."""
+    rng = np.random.default_rng(d)
+    ctx = _host_ctx()
+    M, order = 2, 2
+    try:
+        ctx.set_option("sig_features_grad", 0)
+        for (N1, N2, L1, L2, kind) in [(4, 3, 6, 4, "cross"), (5, 5, 5, 5, "sym")]:
+            X = rng.standard_normal((N1, L1, d)) * 0.3
+            Y = rng.standard_normal((N2, L2, d)) * 0.3 if kind == "cross" else None
+            G = rng.standard_normal((M + 1, N1, N2 if kind == "cross" else N1))
+            kt = _t_kern(base, d, M, difference=True, order=order)
+            tX = torch.tensor(X, requires_grad=True)
+            tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+            (kt.K_seq_levels(tX, tY) * torch.tensor(G)).sum().backward()
+            keep = []
+            p = _params(base, d, M, True, keep, order=order)
+            gX, gY, gb = np.full_like(X, np.nan), (None if Y is None else np.full_like(Y, np.nan)), np.zeros(2)
+            ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2 if Y is not None else N1, L1, L2 if Y is not None else L1,
+                     _vp(G), _vp(gX), _vp(gY), gb.ctypes.data_as(_P))
+            assert rel(gX, tX.grad) < 1e-9, (kind, rel(gX, tX.grad))
+            if Y is not None:
+                assert rel(gY, tY.grad) < 1e-9, (kind, rel(gY, tY.grad))
+    finally:
+        ctx.set_option("sig_features_grad", -1)
+
+
 def test_feature_route_gradient_undoes_long_sweeps_accurately():
     """The reverse sweep stores nothing of the forward pass but its final features and UNDOES one step at a time: the early-time
     features come out as differences of the (much larger) late-time ones.  White-noise sequences of 150 and 300 points, whose level-5
