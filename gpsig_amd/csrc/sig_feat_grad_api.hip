@@ -5,7 +5,8 @@
 //     Phi(X), Phi(Y)          sig_features_kernel, raw (no weights, no normalisation), natural order
 //     dPhi_m(X) = G_m Phi_m(Y),  dPhi_m(Y) = G_m^T Phi_m(X)      one rocBLAS dgemm per level and side  (symmetric: (G_m + G_m^T) Phi_m(X), one;
 //                                                                 diagonal: 2 G_m[i] Phi_m(x_i), elementwise)
-//     gX, gY                  sig_feat_reverse_kernel (sig_feat_grad_kernel.hpp): dPhi back through the feature sweep
+//     gX, gY                  sig_feat_reverse_kernel / sig_feat_reverse_ho_kernel (sig_feat_grad_kernel.hpp): dPhi back through the feature sweep
+//                             (first order / the higher orders' truncated-exponential steps; SignatureCosine: on the unit vectors)
 // The pair kernels' reverse pass costs about three lattice sweeps per pair, L1 L2 (2d + 3M - 1) flops each; this costs 4 sum_m d^m per
 // pair on the matrix cores plus a sweep per SEQUENCE.  Reference: TensorFlow's autodiff of signature_algs.py:8-35 behind
 // kernels.py:208-237 (no gradient code of its own to cite).

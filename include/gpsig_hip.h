@@ -120,7 +120,7 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 the caller must not write the sequences until it sets the option back to 0 (which also drops the matrix's validity)
  *   "sig_gemm_dma" that contraction's operand slabs by LDS-DMA into an XOR-swizzled image, fragments prefetched across the barrier
  *                 (1, default) or staged through registers (0); bit-identical results
- *   "sig_features_grad" gpsig_seq_gram_levels_grad / gpsig_seq_diag_levels_grad of SignatureLinear (order 1) through the same feature space
+ *   "sig_features_grad" gpsig_seq_gram_levels_grad / gpsig_seq_diag_levels_grad of SignatureLinear / SignatureCosine (every order) through the same feature space
  *                 (features, one rocBLAS dgemm per level and side, a reverse sweep per sequence: csrc/sig_feat_grad_api.hip): -1 (default)
  *                 where a time model says it is cheaper than the pair kernels' reverse pass, 0 never, 1 wherever it is built
  *   "sig_graded"  that contraction's depth pieces: 1 (default) the last of the equal pieces is cut into finer ones of halving size where a
