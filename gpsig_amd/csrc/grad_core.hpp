@@ -46,8 +46,9 @@ GPSIG_HD BaseGrad base_eval_grad(int kind, double inner, double xs, double ys, d
         }
         case BASE_POLY: {
             const double b = inner + p0;
-            g.k = pow(b, p1);
-            g.cy = p1 * pow(b, p1 - 1.0);
+            const double bm = poly_pow(b, p1 - 1.0);     // (seq_core.hpp: a whole exponent by repeated squaring)
+            g.k = (double(int(p1)) == p1 && p1 >= 1.0 && p1 <= 9.0) ? bm * b : pow(b, p1);
+            g.cy = p1 * bm;
             g.dp0 = g.cy;
             return g;
         }

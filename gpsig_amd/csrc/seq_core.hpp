@@ -95,13 +95,31 @@ GPSIG_HD T spectral_eval(const double* __restrict__ tab, int Q, int family, int 
     return acc;
 }
 
+// b^p for SignaturePoly (kernels.py:844-848: tf.pow(x y^T + gamma, degree)).  The degree is an integer in every use the reference makes of
+// it (default 3): a small whole exponent is taken by repeated squaring -- three multiplications at most for p <= 8 against the ~150
+// instructions of the library's float64 pow, which made the polynomial kernel's evaluations 3-6 times the RBF kernel's (round 4:
+// tools/bench_train_paths.py); any other exponent goes to pow.  The branch is uniform: p is a kernel argument.
+template <typename T>
+GPSIG_HD T poly_pow(T b, T p) {
+    const int n = int(p);
+    if (T(n) == p && n >= 0 && n <= 8) {
+        T r = (n & 1) ? b : T(1), x = b * b;
+        if (n & 2) r *= x;
+        x *= x;
+        if (n & 4) r *= x;
+        if (n & 8) r *= x * x;
+        return r;
+    }
+    return pow(b, p);
+}
+
 // Static kernel on R^d from the inner product and the two squared norms (gpsig/kernels.py:765-781, 799-993).
 template <typename T>
 GPSIG_HD T base_eval(int kind, T inner, T xs, T ys, T p0, T p1) {
     switch (kind) {
         case BASE_LINEAR: return inner;                                            // :799-806
         case BASE_COSINE: return inner / (sqrt(xs) * sqrt(ys));                     // :820-828
-        case BASE_POLY: return pow(inner + p0, p1);                                 // :844-848
+        case BASE_POLY: return poly_pow(inner + p0, p1);                            // :844-848
         default: break;
     }
     const T dist = fma(T(-2), inner, xs + ys);                                      // _square_dist :765-776
@@ -132,7 +150,7 @@ GPSIG_HD void base_eval_n(int kind, T (&v)[NV], const T (&a2)[NV], T b2, T p0, T
         }
         case BASE_POLY:
 #pragma unroll
-            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = pow(v[i] + p0, p1);
+            for (int i = 0; i < NV; ++i) if (i < nvalid) v[i] = poly_pow(v[i] + p0, p1);
             return;
         case BASE_RBF:
 #pragma unroll
