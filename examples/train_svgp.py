@@ -4,7 +4,10 @@ The reference's counterpart is notebooks/ts_classification.ipynb (GPflow SVGP + 
 TensorFlow optimisers); here the same model is `gpsig_amd.models.SVGPModule`, whose kernel evaluations and their gradients
 run in the HIP library.
 
-    python examples/train_svgp.py [--iterations 200]
+    python examples/train_svgp.py [--iterations 200] [--kernel rbf|linear] [--order 1] [--low-rank] [--graph]
+
+--kernel linear --order 4 is the signature kernel proper (the variant the reference's notebook validates against esig); --low-rank
+trains through the Nystrom / sparse-projection features (low_rank=True of the reference), whose reverse pass is a HIP kernel too.
 """
 import argparse
 import os
@@ -34,6 +37,9 @@ def main():
     ap.add_argument("--num-inducing", type=int, default=64)
     ap.add_argument("--minibatch", type=int, default=64)
     ap.add_argument("--graph", action="store_true", help="record the training step as one HIP graph (SVGPModule.fit(graph=True))")
+    ap.add_argument("--kernel", choices=["rbf", "linear"], default="rbf")
+    ap.add_argument("--order", type=int, default=1, help="1: the reference's default; num_levels: the signature of the piecewise-linear path")
+    ap.add_argument("--low-rank", action="store_true", help="low_rank=True (Nystrom features + sparse projections, default ranks 20)")
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     classes, length, levels = 3, 40, 4
@@ -41,7 +47,10 @@ def main():
     Xte, yte = make_data(rng, 200, length, classes)
     d = Xtr.shape[2]
 
-    kern = kernels.SignatureRBF(length * d, d, levels, lengthscales=utils.suggest_initial_lengthscales(Xtr, 1000, rng=rng))
+    cls = kernels.SignatureRBF if args.kernel == "rbf" else kernels.SignatureLinear
+    extra = dict(low_rank=True, num_components=20, rank_bound=20) if args.low_rank else {}
+    kern = cls(length * d, d, levels, lengthscales=utils.suggest_initial_lengthscales(Xtr, 1000, rng=rng), order=args.order, **extra)
+    kern.rng = np.random.default_rng(1)
     Z = utils.suggest_initial_inducing_tensors(Xtr, levels, args.num_inducing, labels=ytr, increments=True, rng=rng)
     feat = inducing_variables.InducingTensors(Z, levels, increments=True)
     model = models.SVGPModule(kern, feat, likelihoods.MultiClass(classes), num_latent=classes, num_data=Xtr.shape[0], device="cuda:0")
