@@ -439,7 +439,8 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
             torch.cuda.current_stream(dev).synchronize()
             g_mean, g_min, g_max, cov_ms = ctx.clock_probe_read()
             clock = {"mean": g_mean, "min": g_min, "max": g_max, "window_ms": cov_ms,
-                     "how": "one sleeping wavefront on a stream of its own: s_memtime (shader cycles) against s_memrealtime (100 MHz), readings "
+                     "per_xcd": [{"xcd": x, "ghz": g} for x, g in ctx.clock_probe_xcds()],
+                     "how": "one sleeping wavefront per XCD on a stream of its own (mean = average over them): s_memtime (shader cycles) against s_memrealtime (100 MHz), readings "
                             "spread over the timed region (tools/clockcheck.hip checks the counter against an issue-bound loop)"}
         except Exception:
             clock = None
@@ -640,7 +641,10 @@ def secondary_lines(dev):
             out.append({"name": name, "workload": r["config"]["workload"], "dtype": r["dtype"], "value": r["value"], "unit": r["unit"],
                         "ms_per_step": r["ms_per_step"], "kernel_ms": rf["kernel_ms_per_launch"] * rf["launches_per_step"],
                         "kernel": rf["kernel"], "bound": rf["bound"], "alu_frac": rf["alu_frac"], "issue_frac": rf["issue_frac"],
-                        "stream_frac": rf["stream_frac"], "clock_ghz": r["clock_ghz"], "rel_err": r["rel_err"],
+                        "stream_frac": rf["stream_frac"], "clock_ghz": r["clock_ghz"],
+                        "clock_ghz_xcd_min_max": ([min(q["ghz"] for q in r["clock"]["per_xcd"]), max(q["ghz"] for q in r["clock"]["per_xcd"])]
+                                                  if r.get("clock") and r["clock"].get("per_xcd") else None),
+                        "rel_err": r["rel_err"],
                         "traffic": rf["traffic"], "traffic_source": (rf["traffic_source"] or {}).get("how")})
         except Exception as e:                      # a side record never costs the headline its line
             out.append({"name": name, "error": repr(e)})

@@ -101,6 +101,7 @@ _PLAIN = {
     "gpsig_timing_info": ([_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double)], C.c_int),
     "gpsig_clock_probe_start": ([_vp, C.c_double, _i32], C.c_int),
     "gpsig_clock_probe_read": ([_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
+    "gpsig_clock_probe_xcds": ([_vp, C.POINTER(C.c_double), C.POINTER(_i32), _i32, C.POINTER(_i32)], C.c_int),
     "gpsig_graph_begin": ([_vp], C.c_int),
     "gpsig_graph_end": ([_vp, C.POINTER(_vp)], C.c_int),
     "gpsig_graph_launch": ([_vp, _vp], C.c_int),
@@ -230,6 +231,12 @@ class Context:
         a, b, c_, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         self.check(self._lib.gpsig_clock_probe_read(self._h, C.byref(a), C.byref(b), C.byref(c_), C.byref(d)))
         return a.value, b.value, c_.value, d.value
+
+    def clock_probe_xcds(self):
+        """[(XCD id, mean GHz)] of the last read: one sampling wavefront per XCD."""
+        g, x, n = (C.c_double * 8)(), (_i32 * 8)(), _i32()
+        self.check(self._lib.gpsig_clock_probe_xcds(self._h, g, x, 8, C.byref(n)))
+        return [(int(x[k]), float(g[k])) for k in range(n.value)]
 
 
 class Graph:

@@ -2038,9 +2038,12 @@ int gpsig_timing_get(gpsig_ctx* c, double* kernel_ms, int64_t* launches, int64_t
 // against an issue-bound loop of known length, tools/clockcheck.hip: 2.40 GHz on an idle chip, 2.14 with every SIMD on
 // v_fma_f64).  The ratio of the two differences is the clock the chip ran at.  The wave leaves when the host raises `stop`
 // (pinned host memory, read over the bus between naps), after `nsamp` readings, or when `deadline` ticks have passed.
-static __global__ void clock_probe_kernel(unsigned long long* out, int* count, int nsamp, unsigned long long interval,
+static constexpr int PROBE_WAVES = gpsig_ctx::PROBE_WAVES;
+static __global__ void clock_probe_kernel(unsigned long long* out_all, int cap, int nsamp, unsigned long long interval,
                                           unsigned long long deadline, const int* stop) {
+    // one wavefront per workgroup; the dispatcher deals consecutive workgroups to consecutive XCDs, whose clocks differ
     if (threadIdx.x != 0) return;
+    unsigned long long* out = out_all + size_t(blockIdx.x) * (2 * size_t(cap) + 2);
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long next = r0;
     int k = 0;
@@ -2058,7 +2061,8 @@ static __global__ void clock_probe_kernel(unsigned long long* out, int* count, i
         if (leave) break;
         __builtin_amdgcn_s_sleep(100);
     }
-    *count = k;
+    out[2 * size_t(cap)] = (unsigned long long)k;
+    out[2 * size_t(cap) + 1] = __builtin_amdgcn_s_getreg((3 << 11) | 20);        // HW_REG_XCC_ID, bits 3:0
 }
 
 int gpsig_clock_probe_start(gpsig_ctx* c, double duration_ms, int32_t samples) {
@@ -2082,15 +2086,15 @@ int gpsig_clock_probe_start(gpsig_ctx* c, double duration_ms, int32_t samples) {
         if (c->probe_buf) HIPCHK(c, hipFree(c->probe_buf));
         c->probe_buf = nullptr;
         c->probe_cap = 0;
-        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->probe_buf), sizeof(unsigned long long) * (2 * size_t(samples) + 2)));
+        HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&c->probe_buf), sizeof(unsigned long long) * (2 * size_t(samples) + 2) * PROBE_WAVES));
         c->probe_cap = samples;
     }
     unsigned long long interval = (unsigned long long)(duration_ms * 1e5 / double(samples - 1));    // 100 MHz ticks
     if (!interval) interval = 1;
     int* dstop = nullptr;
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&dstop), const_cast<int*>(c->probe_stop), 0));
-    int* count = reinterpret_cast<int*>(c->probe_buf + 2 * size_t(c->probe_cap));
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, c->probe_stream, c->probe_buf, count, int(samples), interval,
+    HIPCHK(c, hipMemsetAsync(c->probe_buf, 0, sizeof(unsigned long long) * (2 * size_t(c->probe_cap) + 2) * PROBE_WAVES, c->probe_stream));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(PROBE_WAVES), dim3(64), 0, c->probe_stream, c->probe_buf, c->probe_cap, int(samples), interval,
                        (unsigned long long)(duration_ms * 1e5 * 1.25) + 1000ull, dstop);
     HIPCHK(c, hipGetLastError());
     c->probe_n = samples;
@@ -2103,23 +2107,47 @@ int gpsig_clock_probe_read(gpsig_ctx* c, double* ghz_mean, double* ghz_min, doub
     *c->probe_stop = 1;                     // the wave takes one last reading and leaves
     HIPCHK(c, hipStreamSynchronize(c->probe_stream));
     c->probe_n = 0;
-    std::vector<unsigned long long> h(2 * size_t(c->probe_cap) + 2);
+    const size_t per = 2 * size_t(c->probe_cap) + 2;
+    std::vector<unsigned long long> h(per * PROBE_WAVES);
     HIPCHK(c, hipMemcpy(h.data(), c->probe_buf, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-    const int n = *reinterpret_cast<const int*>(&h[2 * size_t(c->probe_cap)]);
-    if (n < 2) return fail(c, GPSIG_ERR_INVALID, "the clock probe took %d reading(s): it was read before it ran", n);
-    double lo = 1e30, hi = 0.0;
-    for (int k = 1; k < n; ++k) {
-        const double dc = double(h[2 * k] - h[2 * (k - 1)]), dr = double(h[2 * k + 1] - h[2 * (k - 1) + 1]);
-        if (dr < 100.0) continue;                    // readings less than a microsecond apart (the last one, taken on leaving)
-        const double g = dc / dr * 0.1;              // cycles per 10 ns -> GHz
-        if (g < lo) lo = g;
-        if (g > hi) hi = g;
+    double lo = 1e30, hi = 0.0, sum = 0.0, cov = 0.0;
+    int waves = 0;
+    for (int w = 0; w < PROBE_WAVES; ++w) {
+        const unsigned long long* q = h.data() + per * size_t(w);
+        const int n = int(q[2 * size_t(c->probe_cap)]);
+        if (n < 2) continue;                             // a wave that was never scheduled before the stop
+        for (int k = 1; k < n; ++k) {
+            const double dc = double(q[2 * k] - q[2 * (k - 1)]), dr = double(q[2 * k + 1] - q[2 * (k - 1) + 1]);
+            if (dr < 100.0) continue;                    // readings less than a microsecond apart (the last one, taken on leaving)
+            const double g = dc / dr * 0.1;              // cycles per 10 ns -> GHz
+            if (g < lo) lo = g;
+            if (g > hi) hi = g;
+        }
+        const double dC = double(q[2 * (n - 1)] - q[0]), dR = double(q[2 * (n - 1) + 1] - q[1]);
+        if (!(dR > 0.0)) continue;
+        c->probe_ghz[waves] = dC / dR * 0.1;
+        c->probe_xcc[waves] = int(q[2 * size_t(c->probe_cap) + 1] & 15);
+        sum += c->probe_ghz[waves];
+        if (dR * 1e-5 > cov) cov = dR * 1e-5;
+        ++waves;
     }
-    const double dC = double(h[2 * (n - 1)] - h[0]), dR = double(h[2 * (n - 1) + 1] - h[1]);
-    if (ghz_mean) *ghz_mean = dR > 0.0 ? dC / dR * 0.1 : 0.0;
+    c->probe_waves = waves;
+    if (!waves) return fail(c, GPSIG_ERR_INVALID, "the clock probe took fewer than two readings: it was read before it ran");
+    if (ghz_mean) *ghz_mean = sum / waves;               // mean over the XCDs that were sampled
     if (ghz_min) *ghz_min = lo < 1e29 ? lo : 0.0;
     if (ghz_max) *ghz_max = hi;
-    if (covered_ms) *covered_ms = dR * 1e-5;
+    if (covered_ms) *covered_ms = cov;
+    return GPSIG_OK;
+}
+
+int gpsig_clock_probe_xcds(gpsig_ctx* c, double* ghz, int32_t* xcc, int32_t cap, int32_t* n) {
+    if (!c || !n) return GPSIG_ERR_INVALID;
+    const int m = c->probe_waves < cap ? c->probe_waves : cap;
+    for (int w = 0; w < m; ++w) {
+        if (ghz) ghz[w] = c->probe_ghz[w];
+        if (xcc) xcc[w] = c->probe_xcc[w];
+    }
+    *n = m;
     return GPSIG_OK;
 }
 

@@ -131,6 +131,10 @@ struct gpsig_ctx {
     hipStream_t probe_stream = nullptr;
     unsigned long long* probe_buf = nullptr;   // device, 2 * probe_cap counters
     int probe_cap = 0, probe_n = 0;
+    static constexpr int PROBE_WAVES = 8;      // one sleeping wavefront per XCD (consecutive workgroups go to consecutive XCDs)
+    double probe_ghz[PROBE_WAVES] = {};        // the last read: each wave's mean clock and the XCD it sat on
+    int probe_xcc[PROBE_WAVES] = {};
+    int probe_waves = 0;
     // host-pointer mode: pinned bounce buffers for large transfers (pageable hipMemcpy runs at ~10 GB/s; pinned chunks + a threaded
     // host copy reach several times that), created at first use
     void* pin[2] = {nullptr, nullptr};

@@ -155,13 +155,15 @@ int gpsig_timing_get(gpsig_ctx* ctx, double* kernel_ms, int64_t* launches, int64
  * launches executed on the matrix cores (whole tiles, padded depth), 0 otherwise. */
 int gpsig_timing_info(gpsig_ctx* ctx, const char** kernel, double* flops);
 /* Effective shader clock while the calls that follow run (diagnostics for benchmarks; no reference analogue): a single sleeping
- * wavefront on a stream of its own takes up to `samples` readings of s_memtime (shader cycles) against s_memrealtime (100 MHz),
+ * wavefront per XCD (eight one-wave workgroups) on a stream of its own takes up to `samples` readings of s_memtime (shader cycles) against s_memrealtime (100 MHz),
  * duration_ms / (samples - 1) apart; _read tells it to take a last reading and leave, waits for it, and returns the mean /
  * smallest / largest clock between consecutive readings in GHz and the time the readings span (it leaves by itself after 1.25 x
  * duration_ms).  Read it before any device-wide synchronisation, which would wait for the probe.  float64-heavy kernels run
  * this chip at 2.0-2.2 GHz instead of 2.4 (DVFS), differently from box to box: a benchmark line should carry the value. */
 int gpsig_clock_probe_start(gpsig_ctx* ctx, double duration_ms, int32_t samples);
 int gpsig_clock_probe_read(gpsig_ctx* ctx, double* ghz_mean, double* ghz_min, double* ghz_max, double* covered_ms);
+/* The last read's mean clock per sampled wavefront and the XCD each sat on (HW_REG_XCC_ID); ghz_mean above is their average. */
+int gpsig_clock_probe_xcds(gpsig_ctx* ctx, double* ghz, int32_t* xcc, int32_t cap, int32_t* n);
 
 /* ---- HIP graphs for launch-bound evaluations (no reference analogue) -------------------------------------
  * An end-to-end evaluation is 5-15 short kernels.  The calls made between gpsig_graph_begin and gpsig_graph_end are
