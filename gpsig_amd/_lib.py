@@ -58,6 +58,7 @@ _KERNEL_FUNCS = {
     "gpsig_tens_vs_seq_weighted": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i32)],
     "gpsig_tens_vs_seq_weighted_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)],
     "gpsig_kernel_K": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "gpsig_kernel_K_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)],
     "gpsig_kernel_K_symm_rows": [_vp, _i64, _i32, _i64, _i64, _vp],
     "gpsig_kernel_K_symm_rows_compact": [_vp, _i64, _i32, _i64, _i64, _vp],
     "gpsig_kernel_Kdiag": [_vp, _i64, _i32, _i32, _vp],

@@ -131,6 +131,81 @@ class _SeqGramLevels(torch.autograd.Function):
         return gX.to(ctx.dt[0]), None if gX2 is None else gX2.to(ctx.dt[1]), gp0, None
 
 
+class _SeqGramSum(torch.autograd.Function):
+    """K = sum_m w_m K_m [normalised] (kernels.py:401-476 after the scaling) of SignatureLinear / SignatureCosine as ONE op: forward
+    gpsig_kernel_K (the evaluation path's feature contraction), backward gpsig_kernel_K_grad -- one product of the upstream with
+    the features of every level at once, so the (M+1, N1, N2) level arrays and their gradients never exist."""
+
+    @staticmethod
+    def weights_on_host(w):
+        return np.ascontiguousarray(w.detach().to(torch.float64).cpu().numpy())
+
+    @staticmethod
+    def _params(spec, d, wh, normalization, keep):
+        p = spec.params(d, 0.0, keep)
+        keep.append(wh)
+        p.variances = wh.ctypes.data_as(C.POINTER(C.c_double))
+        p.sigma, p.normalization = 1.0, int(bool(normalization))
+        return p
+
+    @staticmethod
+    def applies(Xs, X2s, wh, spec, normalization):
+        """Whether the library takes this shape through the feature space (asked before the forward pass commits to the route)."""
+        if spec.base not in ("linear", "cosine") or not Xs.is_cuda:
+            return False
+        X = _c(Xs)
+        X2 = None if X2s is None else _c(X2s)
+        n1, l1, d = X.shape
+        n2, l2 = (n1, l1) if X2 is None else X2.shape[:2]
+        keep = []
+        p = _SeqGramSum._params(spec, d, wh, normalization, keep)
+        taken = C.c_int32(0)
+        _ctx_for(X).call("gpsig_kernel_K_grad", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, None, None, None, None, C.byref(taken))
+        return bool(taken.value)
+
+    @staticmethod
+    def forward(ctx, Xs, X2s, w, wh, spec, normalization):
+        X, X2 = _c(Xs), (None if X2s is None else _c(X2s))
+        n1, l1, d = X.shape
+        n2, l2 = (n1, l1) if X2 is None else X2.shape[:2]
+        keep = []
+        p = _SeqGramSum._params(spec, d, wh, normalization, keep)
+        ctx.wh = wh
+        out = torch.empty((n1, n2), dtype=torch.float64, device=X.device)
+        _ctx_for(X).call("gpsig_kernel_K", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, 0, _ptr(out))
+        ctx.spec, ctx.has_x2, ctx.normalization = spec, X2 is not None, bool(normalization)
+        ctx.dt = (Xs.dtype, None if X2s is None else X2s.dtype)
+        ctx.save_for_backward(X, X2 if X2 is not None else X.new_empty(0), w)
+        return out.to(_out_dtype(Xs, X2s))
+
+    @staticmethod
+    def backward(ctx, g):
+        X, X2, w = ctx.saved_tensors
+        X2 = X2 if ctx.has_x2 else None
+        n1, l1, d = X.shape
+        n2, l2 = (n1, l1) if X2 is None else X2.shape[:2]
+        keep = []
+        p = _SeqGramSum._params(ctx.spec, d, ctx.wh, ctx.normalization, keep)
+        g = _c(g)
+        gX = torch.empty_like(X)
+        gX2 = None if X2 is None else torch.empty_like(X2)
+        gw = torch.zeros(ctx.spec.num_levels + 1, dtype=torch.float64, device=X.device)
+        taken = C.c_int32(0)
+        _ctx_for(X).call("gpsig_kernel_K_grad", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(g), _ptr(gX),
+                         None if gX2 is None else _ptr(gX2), _ptr(gw), C.byref(taken))
+        if not taken.value:
+            raise RuntimeError("gpsig_kernel_K_grad declined a call its probe had accepted")
+        # level 0 is constant (1; normalised: 1 / (1 + jitter) off the diagonal), a normalised symmetric Gram's diagonal is sum_m w_m
+        tot = g.sum()
+        if ctx.normalization and X2 is None:
+            tr = torch.diagonal(g).sum()
+            gw[0] = (tot - tr) / (1.0 + JITTER) + tr
+            gw[1:] += tr
+        else:
+            gw[0] = tot / (1.0 + JITTER) if ctx.normalization else tot
+        return gX.to(ctx.dt[0]), None if gX2 is None else gX2.to(ctx.dt[1]), gw.to(w.dtype), None, None, None
+
+
 class _SeqDiagLevels(torch.autograd.Function):
     """_K_seq_diag (kernels.py:188-205): (N, L, d) -> (M+1, N)."""
 
@@ -630,6 +705,7 @@ class SignatureKernelModule(torch.nn.Module):
             raise NotImplementedError("SignatureKernel is abstract: use SignatureLinear, SignatureRBF, ...")
         self.kern = kern
         self._lr = None
+        self.sum_route = True          # K(X [, X2]) of the linear / cosine kernel: level sum and gradient as one op where the library offers it
         d_cols = kern.num_features * (kern.num_lags + 1)
         # beyond 64 columns and for the spectral kernel: base-kernel tensors here (GEMMs, autograd), recursions in the library
         self.matrix_route = (kern._base == "spectral" or d_cols > 64) and not kern.low_rank
@@ -827,6 +903,14 @@ class SignatureKernelModule(torch.nn.Module):
         """kernels.py:401-476.  lr: a LowRankDraw (low-rank mode; drawn per evaluation when None)."""
         Xs = self.scale_sequences(self._seq3(X, presliced or presliced_X))
         N = Xs.shape[0]
+        X2s = None if X2 is None else self.scale_sequences(self._seq3(X2, presliced or presliced_X2))
+        if (self.sum_route and not return_levels and not self.kern.low_rank and not self.matrix_route and lr is None
+                and self._spec.base in ("linear", "cosine") and Xs.is_cuda):
+            # the linear / cosine kernel's level sum and its gradient as one op through the feature space (no level arrays)
+            w = self._w()
+            wh = _SeqGramSum.weights_on_host(w)
+            if _SeqGramSum.applies(Xs, X2s, wh, self._spec, self.kern.normalization):
+                return _SeqGramSum.apply(Xs, X2s, w, wh, self._spec, self.kern.normalization)
         if X2 is None:
             self._lr_open(lr, Xs)
             K = self._seq_levels(Xs)
@@ -835,7 +919,6 @@ class SignatureKernelModule(torch.nn.Module):
                 dsq = torch.sqrt(torch.diagonal(K, dim1=1, dim2=2))                                 # :432
                 K = K / (dsq[:, :, None] * dsq[:, None, :])                                         # :433
         else:
-            X2s = self.scale_sequences(self._seq3(X2, presliced or presliced_X2))
             self._lr_open(lr, Xs, X2s)
             K = self._seq_levels(Xs, X2s)
             if self.kern.normalization:

@@ -345,6 +345,19 @@ int gpsig_lr_kernel_diag(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowr
 /* X2 == NULL: symmetric Gram, gX receives both roles of every sequence. */
 int gpsig_seq_gram_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
                                int32_t L1, int32_t L2, const void* G /* (M+1, N1, N2) */, void* gX, void* gX2, double* g_base);
+/* The gradient of gpsig_kernel_K's level SUM (return_levels = 0) for SignatureLinear / SignatureCosine of every order through the
+ * feature space (round 4): with K[i][j] = sum_m w_m <u_m(x_i), u_m(y_j)>, u_m = Phi_m / sqrt(|Phi_m|^2 + jitter) when p->normalization
+ * (else Phi_m) and w_m = sigma variances[m], every level shares the upstream g (N1, N2), so ONE product g U(Y) over the whole feature
+ * width (rocBLAS dgemm), the normalisation's reverse step per row and one reverse sweep per sequence give gX [, gX2] -- the
+ * (M+1, N1, N2) level arrays of the level primitives and their upstream gradients never exist (what tf.gradients does through
+ * kernels.py:401-476 for these kernels).  Inputs as they come, like the level primitives (p->lengthscales NULL, no lags); float64,
+ * device-pointer mode.  X2 == NULL: symmetric Gram (a normalised one has a constant diagonal: no gradient from it).
+ * g_weights: (M+1) doubles on the device or NULL; entries 1..M receive d/dw_m from the feature products; entry 0 (level 0 is constant)
+ * and a normalised symmetric Gram's diagonal terms (trace of g) are plain sums of g left to the caller.
+ * *taken = 0: the route does not apply (another base kernel, a shape the feature kernels are not built for, inside a graph capture,
+ * option "sig_features_grad" 0 ...): nothing was written, use the level primitives.  g == NULL: only answer that question. */
+int gpsig_kernel_K_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2, int32_t L1, int32_t L2,
+                        const void* g /* (N1, N2) */, void* gX, void* gX2, void* g_weights, int32_t* taken);
 int gpsig_seq_diag_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L,
                                const void* G /* (M+1, N) */, void* gX, double* g_base);
 int gpsig_tens_gram_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* Z, int64_t T, int32_t increments,

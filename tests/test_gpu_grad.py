@@ -271,6 +271,89 @@ def test_linear_gram_gradient_through_the_feature_contraction_at_training_size()
     assert rel(mod.raw_lengthscales.grad, orc.lengthscales.grad * torch.sigmoid(mod.raw_lengthscales.detach().cpu())) < 1e-8
 
 
+@pytest.mark.parametrize("base,normalization,difference,order,num_lags",
+                         [("linear", True, True, 1, 0), ("linear", False, True, 1, 0), ("linear", True, False, 1, 1), ("cosine", True, True, 1, 0),
+                          ("cosine", False, False, 1, 0), ("linear", True, True, 3, 0), ("linear", False, True, 2, 0), ("cosine", True, True, 4, 0)])
+def test_level_sum_gradient_as_one_op(base, normalization, difference, order, num_lags):
+    """gpsig_kernel_K_grad (autodiff._SeqGramSum): K(X) and K(X, X2) of the linear / cosine kernel with the level sum, the normalisation and
+    the weights inside the op -- one product of the upstream with the features of all levels -- against the oracle's autograd of
+    kernels.py:401-476 (sequences, variances, sigma, lengthscales, lags) and against the route through the level primitives."""
+    from gpsig_amd import _lib
+    d, M, L, N, N2 = 3, 4, 12, 40, 28
+    mod, orc = _module_and_oracle(base, d, M, L, num_lags=num_lags, normalization=normalization, difference=difference, order=order)
+    rng = np.random.default_rng(77)
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, L * d)
+    X2 = np.cumsum(0.3 * rng.standard_normal((N2, L - 3, d)), axis=1).reshape(N2, (L - 3) * d)
+    Wa, Wb = rng.standard_normal((N, N)), rng.standard_normal((N, N2))
+    dev = torch.device("cuda:0")
+    dctx = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
+    names = ["raw_variances", "raw_sigma", "raw_lengthscales"] + (["raw_lags", "raw_gamma"] if num_lags else [])
+
+    def run(sum_route):
+        mod.sum_route = sum_route
+        mod.zero_grad()
+        xt = torch.tensor(X, device=dev, requires_grad=True)
+        x2 = torch.tensor(X2, device=dev, requires_grad=True)
+        Ka, Kb = mod.K(xt), mod.K(xt, x2)
+        assert ("SeqGramSum" in type(Ka.grad_fn).__name__) == sum_route and ("SeqGramSum" in type(Kb.grad_fn).__name__) == sum_route
+        ((Ka * torch.tensor(Wa, device=dev)).sum() + (Kb * torch.tensor(Wb, device=dev)).sum()).backward()
+        return Ka.detach().cpu(), Kb.detach().cpu(), xt.grad.cpu(), x2.grad.cpu(), {n: getattr(mod, n).grad.cpu().clone() for n in names}
+
+    try:
+        dctx.set_option("sig_features_grad", 1)
+        one = run(True)
+        levels = run(False)
+    finally:
+        dctx.set_option("sig_features_grad", -1)
+        mod.sum_route = True
+    xo, x2o = torch.tensor(X, requires_grad=True), torch.tensor(X2, requires_grad=True)
+    Koa, Kob = orc.K(xo), orc.K(xo, x2o)
+    ((Koa * torch.tensor(Wa)).sum() + (Kob * torch.tensor(Wb)).sum()).backward()
+    assert rel(one[0], Koa.detach()) < 1e-10 and rel(one[1], Kob.detach()) < 1e-10
+    assert rel(one[2], xo.grad) < 1e-8, rel(one[2], xo.grad)
+    assert rel(one[3], x2o.grad) < 1e-8, rel(one[3], x2o.grad)
+    assert rel(one[2], levels[2]) < 1e-9 and rel(one[3], levels[3]) < 1e-9
+    for n in names:
+        assert rel(one[4][n], levels[4][n]) < 1e-8, (n, one[4][n], levels[4][n])
+    # the oracle's leaves are the constrained values: d/d raw = d/d value * d value / d raw
+    assert rel(one[4]["raw_variances"], orc.variances.grad * torch.sigmoid(mod.raw_variances.detach().cpu())) < 1e-8
+    assert rel(one[4]["raw_sigma"], orc.sigma.grad * torch.sigmoid(mod.raw_sigma.detach().cpu())) < 1e-8
+
+
+def test_level_sum_op_is_the_route_taken_and_can_be_declined():
+    """The one-op route answers its probe before the forward pass commits to it: taken for the linear kernel at a training-size shape with
+    the planner's own choice, declined for the RBF kernel and with option sig_features_grad = 0 (then K runs through the level primitives)."""
+    from gpsig_amd import _lib, autodiff
+    dev = torch.device("cuda:0")
+    dctx = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
+    rng = np.random.default_rng(5)
+    N, L, d, M = 256, 32, 4, 4
+    X = torch.tensor(np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1), device=dev)
+    spec = autodiff._Spec("linear", M, True)
+    wh = np.ones(M + 1)
+    assert autodiff._SeqGramSum.applies(X, None, wh, spec, True)
+    assert autodiff._SeqGramSum.applies(X, X[:100, :20].contiguous(), wh, spec, False)
+    assert not autodiff._SeqGramSum.applies(X, None, wh, autodiff._Spec("rbf", M, True), True)
+    try:
+        dctx.set_option("sig_features_grad", 0)
+        assert not autodiff._SeqGramSum.applies(X, None, wh, spec, True)
+    finally:
+        dctx.set_option("sig_features_grad", -1)
+    # at this size: value and gradient against the level route, planner's choice
+    mod, _ = _module_and_oracle("linear", d, M, L)
+    res = {}
+    for sum_route in (True, False):
+        mod.sum_route = sum_route
+        mod.zero_grad()
+        xt = X.reshape(N, L * d).clone().requires_grad_(True)
+        K = mod.K(xt)
+        (K * torch.cos(torch.arange(N * N, device=dev, dtype=torch.float64).reshape(N, N))).sum().backward()
+        res[sum_route] = (K.detach().cpu(), xt.grad.cpu(), mod.raw_variances.grad.cpu().clone())
+    mod.sum_route = True
+    for a, b in zip(res[True], res[False]):
+        assert rel(a, b) < 1e-9, rel(a, b)
+
+
 @pytest.mark.parametrize("base,difference", [("rbf", True), ("poly", True), ("matern32", False)])
 def test_point_kernel_gradients_in_blocks(base, difference):
     """seq_lam_undo_kernel + lam_contract_kernel over several blocks of pairs: a symmetric Gram visits the pairs beyond a

@@ -19,6 +19,7 @@ if os.environ.get("GPSIG_GRAD_IMPL"):
 X = torch.tensor(rng.standard_normal((N, L * d)), device=dev)
 kern = (kernels.SignatureRBF if base == "rbf" else kernels.SignatureLinear)(L * d, d, M, lengthscales=(d ** 0.5 if base == "rbf" else 1.0))
 mod = autodiff.SignatureKernelModule(kern, device=dev)
+mod.sum_route = os.environ.get("GPSIG_SUM_ROUTE", "1") != "0"       # 0: level primitives + torch ops for the normalisation and the level sum
 W = torch.tensor(rng.standard_normal((N, N)), device=dev)
 def step():
     mod.zero_grad(); (mod.K(X) * W).sum().backward()
@@ -26,4 +27,4 @@ for _ in range(2): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(reps): step()
 torch.cuda.synchronize()
-print(f"full Gram N={N} L={L} d={d} M={M} {base} [{os.environ.get('GPSIG_OPTIONS', '')}]: forward+backward {(time.perf_counter() - t0) / reps * 1e3:.1f} ms")
+print(f"full Gram N={N} L={L} d={d} M={M} {base} [{os.environ.get('GPSIG_OPTIONS', '')}{'' if mod.sum_route else ' level primitives'}]: forward+backward {(time.perf_counter() - t0) / reps * 1e3:.1f} ms")
