@@ -655,7 +655,8 @@ def secondary_lines(dev):
 def gradient_lines(dev):
     """Forward + backward of K(X) through gpsig_amd.autodiff (what the reference's TensorFlow autodiff does when it trains,
     training.py:149-164) at 1,024 sequences of BASELINE configs[1]'s shape: the linear kernel through the feature contraction's reverse
-    pass (round 4) and through the pair kernels' (option sig_features_grad = 0), and the RBF kernel.  Side records: ms per step only."""
+    pass (round 4: level sum, normalisation and weights inside one op, gpsig_kernel_K_grad; and through the level primitives with torch ops
+    around them) and through the pair kernels' (option sig_features_grad = 0), and the RBF kernel.  Side records: ms per step only."""
     import numpy as np
     import torch
     from gpsig_amd import _lib, autodiff, kernels
@@ -665,11 +666,15 @@ def gradient_lines(dev):
     X = torch.tensor(rng.standard_normal((N, L * D)), device=dev)
     W = torch.tensor(rng.standard_normal((N, N)), device=dev)
     ctx = _lib.context(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
-    for name, cls, opt in (("grad-c2shape-n1024-linear", kernels.SignatureLinear, -1), ("grad-c2shape-n1024-linear-pair-kernels", kernels.SignatureLinear, 0),
-                           ("grad-c2shape-n1024-rbf", kernels.SignatureRBF, -1)):
+    # (name, class, option sig_features_grad, level sum and its gradient as one op -- gpsig_kernel_K_grad -- or level primitives + torch ops)
+    for name, cls, opt, one_op in (("grad-c2shape-n1024-linear", kernels.SignatureLinear, -1, True),
+                                   ("grad-c2shape-n1024-linear-level-primitives", kernels.SignatureLinear, -1, False),
+                                   ("grad-c2shape-n1024-linear-pair-kernels", kernels.SignatureLinear, 0, False),
+                                   ("grad-c2shape-n1024-rbf", kernels.SignatureRBF, -1, True)):
         try:
             kern = cls(L * D, D, M, lengthscales=(math.sqrt(D) if cls is kernels.SignatureRBF else 1.0))
             mod = autodiff.SignatureKernelModule(kern, device=dev)
+            mod.sum_route = one_op
             ctx.set_option("sig_features_grad", opt)
 
             def step():

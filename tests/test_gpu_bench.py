@@ -71,7 +71,8 @@ def test_default_line_carries_the_measurement():
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     names = [s["name"] for s in line["secondary"]]
     assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf",
-                     "grad-c2shape-n1024-linear", "grad-c2shape-n1024-linear-pair-kernels", "grad-c2shape-n1024-rbf"]
+                     "grad-c2shape-n1024-linear", "grad-c2shape-n1024-linear-level-primitives", "grad-c2shape-n1024-linear-pair-kernels",
+                     "grad-c2shape-n1024-rbf"]
     ho = line["secondary"][1]                           # the higher-order algorithm at order = num_levels: the same contraction, the same time
     assert ho["bound"] == "mfma" and ho["ms_per_step"] < 1.3 * line["ms_per_step"]
     lat = line["secondary"][0]                          # the same Gram through the pair recursion: vector-issue bound, about twice the time
@@ -86,4 +87,5 @@ def test_default_line_carries_the_measurement():
     g = {s["name"]: s["ms_per_step"] for s in line["secondary"] if s["name"].startswith("grad-")}
     # the linear kernel's reverse pass through the feature contraction: several times faster than through the pair kernels
     assert g["grad-c2shape-n1024-linear"] * 3 < g["grad-c2shape-n1024-linear-pair-kernels"]
+    assert g["grad-c2shape-n1024-linear"] < 1.1 * g["grad-c2shape-n1024-linear-level-primitives"]     # the level sum as one op is not slower
     assert line["secondary"][3]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
