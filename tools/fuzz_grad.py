@@ -1,5 +1,7 @@
 """Randomised sweep of the gradient path against torch.autograd of the differentiable oracle (run on a GPU box):
-    python tools/fuzz_grad.py [cases] [seed]"""
+    python tools/fuzz_grad.py [cases] [seed]
+FUZZ_ORDER=1 also draws the algorithm's order (1 .. num_levels); GPSIG_OPTIONS="sig_features_grad=1" sends the linear / cosine kernel's
+K(X), K(X, X2) through the feature space (the one-op level sum, gpsig_kernel_K_grad) at these small sizes too."""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -28,15 +30,16 @@ def main():
         L1, L2 = int(rng.choice([3, 4, 9, 20, 40, 70])), int(rng.choice([3, 5, 12, 33]))
         N1, N2, T = int(rng.integers(1, 9)), int(rng.integers(1, 7)), int(rng.integers(1, 7))
         norm, diff, incr = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) > 0), bool(rng.integers(0, 2))
-        desc = dict(base=base, M=M, d=d, lags=lags, L1=L1, L2=L2, N1=N1, N2=N2, T=T, norm=norm, diff=diff, incr=incr)
+        order = int(rng.integers(1, M + 1)) if os.environ.get("FUZZ_ORDER") and rng.integers(0, 2) else 1
+        desc = dict(base=base, M=M, d=d, lags=lags, L1=L1, L2=L2, N1=N1, N2=N2, T=T, norm=norm, diff=diff, incr=incr, order=order)
         try:
-            kern = CLASS[base](max(L1, L2) * d, d, M, normalization=norm, difference=diff, num_lags=lags or None,
+            kern = CLASS[base](max(L1, L2) * d, d, M, normalization=norm, difference=diff, num_lags=lags or None, order=order,
                                lengthscales=rng.uniform(0.8, 1.6, d), variances=rng.uniform(0.5, 1.5, M + 1))
             mod = autodiff.SignatureKernelModule(kern, device=dev)
             leaf = lambda t: None if t is None else t.detach().cpu().clone().requires_grad_(True)
             orc = OT.SignatureKernelTorchOracle(d, M, base, variances=leaf(mod.variances), sigma=leaf(mod.sigma), lengthscales=leaf(mod.lengthscales),
                                                 normalization=norm, difference=diff, num_lags=lags, lags=leaf(mod.lags) if lags else None,
-                                                gamma=leaf(mod.gamma) if lags else None, p0=leaf(mod.p0), p1=kern._current_base_params()[1])
+                                                gamma=leaf(mod.gamma) if lags else None, p0=leaf(mod.p0), p1=kern._current_base_params()[1], order=order)
             sc = 0.4 / np.sqrt(d)
             off = 1.0 if base == "cosine" else 0.0
             X = np.cumsum(sc * rng.standard_normal((N1, L1, d)), axis=1).reshape(N1, -1) + off
