@@ -341,13 +341,18 @@ def measure_traffic(cfg, base, increments, timeout_s=240):
             "kernel": meta[0], "grid": meta[1], "dispatches": meta[2]}
 
 
-# vector instructions per wave-step of the dominant kernels (disassembly of the built instances); float64
-# and DPP instructions take a SIMD's issue port for 4 cycles per wave64 instruction.  issue_frac = how much of the SIMDs'
-# issue time the kernel's vector instructions fill at the clock measured during the run.
-VALU_PER_STEP = {("c2", "linear"): 89, ("c4", "linear"): 89, ("c2", "rbf"): 174, ("c4", "rbf"): 174,
+# vector instructions per wave-step of the dominant kernels; float64 and DPP instructions take a SIMD's issue port for 4 cycles per
+# wave64 instruction.  issue_frac = how much of the SIMDs' issue time the kernel's vector instructions fill at the clock measured
+# during the run.  Counts are what the kernels EXECUTE -- SQ_INSTS_VALU / wave-steps of profiles/r04_pmc_c2lattice.txt (1.33606e10 /
+# 1.3425e8), r04_pmc_c2rbf.txt (2.43674e10 / 1.3425e8) --, i.e. the inner loop of the disassembly (89 / 174 per step, what rounds 2-3
+# priced) plus the pair-boundary blocks, prologue and epilogue amortised over a pair's 64 steps.
+VALU_PER_STEP = {("c2", "linear"): 99.5, ("c4", "linear"): 99.5, ("c2", "rbf"): 181.5, ("c4", "rbf"): 181.5,
                  # configs[4], seq_pk2_kernel<f2, 4, 64, 2, 16, 6>: SQ_INSTS_VALU / wave-steps of profiles/r03_pmc_c5.txt (1.589e10 / 1.343e8; the
                  # pair-boundary blocks included); SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.04 issue slots of 4 cycles per instruction there
                  ("c5", "rbf"): 118.4}
+# configs[2]: the tile kernel's vector instructions per LAUNCH at this exact shape (SQ_INSTS_VALU of profiles/r04_pmc_c3.txt / r04_pmc_c3incr.txt,
+# tvs_tile_kernel<4, 2, 6, false | true, 1>, grid 524,288: the count does not depend on the data); SQ_ACTIVE_INST_VALU equals it
+VALU_PER_LAUNCH = {("c3", "rbf", False): 1.40617e9, ("c3", "rbf", True): 2.58674e9}
 PAIRS_PER_WAVE = {"c5": 2}               # seq_pk2_kernel at G = 64: one pair group per wavefront, two y sequences packed (default 4: G = 16)
 SIMDS = 1024
 
@@ -484,6 +489,9 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
         wave_steps = evaluated_launch / pairs_per_wave * L           # L lattice rows (L - 1 increments + the boundary row) per pair
         issue = {"valu_per_wave_step": vps, "cycles_per_valu": 4, "wave_steps_per_launch": wave_steps, "simds": SIMDS,
                  "issue_frac": wave_steps * vps * 4.0 / (SIMDS * ghz * 1e9 * per_launch_ms * 1e-3)}
+    vpl = VALU_PER_LAUNCH.get((cfg, base, bool(increments))) if timed_kernel is None else None
+    if vpl and ghz and launches:
+        issue = {"valu_per_launch": vpl, "cycles_per_valu": 4, "simds": SIMDS, "issue_frac": vpl * 4.0 / (SIMDS * ghz * 1e9 * per_launch_ms * 1e-3)}
     if T:
         bound = "valu-issue"
         binding = ("vector issue: the table-driven exps of the base kernel (10 per step and wave with increments) and the chain FMAs; the sequence "
