@@ -347,7 +347,7 @@ def measure_traffic(cfg, base, increments, timeout_s=240):
 # 1.3425e8), r04_pmc_c2rbf.txt (2.43674e10 / 1.3425e8) --, i.e. the inner loop of the disassembly (89 / 174 per step, what rounds 2-3
 # priced) plus the pair-boundary blocks, prologue and epilogue amortised over a pair's 64 steps.
 VALU_PER_STEP = {("c2", "linear"): 99.5, ("c4", "linear"): 99.5, ("c2", "rbf"): 181.5, ("c4", "rbf"): 181.5,
-                 # configs[4], seq_pk2_kernel<f2, 4, 64, 2, 16, 6>: SQ_INSTS_VALU / wave-steps of profiles/r03_pmc_c5.txt (1.589e10 / 1.343e8; the
+                 # configs[4], seq_pk2_kernel<f2, 4, 64, 2, 16, 6>: SQ_INSTS_VALU / wave-steps of profiles/r04_pmc_c5.txt (1.589e10 / 1.343e8; the
                  # pair-boundary blocks included); SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.04 issue slots of 4 cycles per instruction there
                  ("c5", "rbf"): 118.4}
 # configs[2]: the tile kernel's vector instructions per LAUNCH at this exact shape (SQ_INSTS_VALU of profiles/r04_pmc_c3.txt / r04_pmc_c3incr.txt,
@@ -500,7 +500,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
         bound = "valu-issue"
         binding = "float64 vector-ALU issue (instructions x 4 cycles per wave; DESIGN.md section 4)"
     elif issue:
-        # (round 4: the counters of profiles/r03_pmc_c5.txt show the vector ALU active 0.9-0.97 of the launch -- SQ_ACTIVE_INST_VALU x 4 /
+        # (round 4: the counters of profiles/r04_pmc_c5.txt show the vector ALU active 0.9-0.97 of the launch -- SQ_ACTIVE_INST_VALU x 4 /
         # 1024 SIMDs against the kernel's cycles -- so this kernel, too, is bound by its instruction count, not by latency)
         bound = "valu-issue"
         binding = ("float32 vector-ALU issue: 118 vector instructions per wave-step (58 of them packed v_pk_fma_f32 at 4 cycles, the rest "

@@ -905,7 +905,7 @@ class SignatureKernelModule(torch.nn.Module):
         N = Xs.shape[0]
         X2s = None if X2 is None else self.scale_sequences(self._seq3(X2, presliced or presliced_X2))
         if (self.sum_route and not return_levels and not self.kern.low_rank and not self.matrix_route and lr is None
-                and self._spec.base in ("linear", "cosine") and Xs.is_cuda):
+                and self._spec.base in ("linear", "cosine") and Xs.is_cuda and not torch.cuda.is_current_stream_capturing()):
             # the linear / cosine kernel's level sum and its gradient as one op through the feature space (no level arrays)
             w = self._w()
             wh = _SeqGramSum.weights_on_host(w)
