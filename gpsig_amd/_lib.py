@@ -58,6 +58,8 @@ _KERNEL_FUNCS = {
     "gpsig_tens_vs_seq_weighted": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i32)],
     "gpsig_tens_vs_seq_weighted_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)],
     "gpsig_kernel_K": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
+    "gpsig_seq_features": [_vp, _i64, _i32, _vp],
+    "gpsig_seq_features_grad": [_vp, _i64, _i32, _vp, _vp, _vp],
     "gpsig_kernel_K_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(_i32)],
     "gpsig_kernel_K_symm_rows": [_vp, _i64, _i32, _i64, _i64, _vp],
     "gpsig_kernel_K_symm_rows_compact": [_vp, _i64, _i32, _i64, _i64, _vp],
@@ -88,6 +90,7 @@ _PLAIN = {
     "gpsig_lr_state_export": ([_vp, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                C.POINTER(SketchC)], C.c_int),
     "gpsig_tens_vs_seq_aux_elems": ([_P, _i64, _i64], _i64),
+    "gpsig_seq_features_ld": ([_P, _i32], _i64),
     "gpsig_ctx_create": ([C.c_int, _vp, C.POINTER(_vp)], C.c_int),
     "gpsig_ctx_destroy": ([_vp], None),
     "gpsig_last_error": ([_vp], C.c_char_p),

@@ -206,6 +206,171 @@ class _SeqGramSum(torch.autograd.Function):
         return gX.to(ctx.dt[0]), None if gX2 is None else gX2.to(ctx.dt[1]), gw.to(w.dtype), None, None, None
 
 
+class _SigFeatures(torch.autograd.Function):
+    """The explicit level features Phi(x) of the linear (cosine: of the unit vectors) kernel: scaled sequences (N, L, d) -> (N, ld), columns
+    [0, F) = levels 1..M in the natural order of their multi-indices (gpsig_seq_features; backward: the reverse feature sweep,
+    gpsig_seq_features_grad).  K_m(x, y) = <Phi_m(x), Phi_m(y)> (signature_algs.py:8-74), K_m(z, x) = <z_1 (x) .. (x) z_m, Phi_m(x)> (:101-160)."""
+
+    @staticmethod
+    def ld(spec, d, L):
+        """Row stride of the features, or 0 where the feature kernels are not built (then the callers use the recursions)."""
+        if spec.base not in ("linear", "cosine"):
+            return 0
+        keep = []
+        return int(_lib.load().gpsig_seq_features_ld(C.byref(spec.params(d, 0.0, keep)), int(L)))
+
+    @staticmethod
+    def forward(ctx, Xs, spec):
+        X = _c(Xs)
+        n, l, d = X.shape
+        keep = []
+        p = spec.params(d, 0.0, keep)
+        ld = int(_lib.load().gpsig_seq_features_ld(C.byref(p), l))
+        out = torch.empty((n, ld), dtype=torch.float64, device=X.device)
+        _ctx_for(X).call("gpsig_seq_features", p, _ptr(X), n, l, _ptr(out))
+        ctx.spec, ctx.dt = spec, Xs.dtype
+        ctx.save_for_backward(X, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        X, Phi = ctx.saved_tensors
+        n, l, d = X.shape
+        keep = []
+        p = ctx.spec.params(d, 0.0, keep)
+        G = _c(G)
+        gX = torch.empty_like(X)
+        _ctx_for(X).call("gpsig_seq_features_grad", p, _ptr(X), n, l, _ptr(Phi), _ptr(G), _ptr(gX))
+        return gX.to(ctx.dt), None
+
+
+def signature_features(X, num_levels, order=1, difference=True, unit_points=False):
+    """Explicit signature-level features of a batch of sequences X (N, L, d) on the GPU, differentiable: a list of M tensors, level m of
+    shape (N, d^m) (views into one buffer), with <Phi_m(x), Phi_m(y)> = level m of SignatureLinear(order=order, difference=difference)
+    (unit_points: of SignatureCosine).  order = num_levels and difference = True: the signature of the piecewise-linear path through the
+    points, truncated at num_levels -- what the reference's notebook compares its kernel against (esig)."""
+    spec = _Spec("cosine" if unit_points else "linear", num_levels, difference, order=order)
+    n, l, d = X.shape
+    if not _SigFeatures.ld(spec, d, l):
+        raise NotImplementedError("signature_features: 2 <= num_levels <= 8, d <= 32 and a sequence's arrays within the LDS")
+    return _split_levels(_SigFeatures.apply(X, spec), d, num_levels)
+
+
+def _split_levels(Phi, d, M):
+    out, off = [], 0
+    for m in range(1, M + 1):
+        out.append(Phi[:, off:off + d ** m])
+        off += d ** m
+    return out
+
+
+_COL_LEVELS = {}
+
+
+def _col_levels(d, M, ld, device):
+    """Level of every column of a feature buffer (N, ld): 1..M for the levels' columns, 0 for the level-0 column, M+1 for the padding."""
+    key = (d, M, ld, str(device))
+    if key not in _COL_LEVELS:
+        idx = np.full(ld, M + 1, dtype=np.int64)
+        off = 0
+        for m in range(1, M + 1):
+            idx[off:off + d ** m] = m
+            off += d ** m
+        idx[off] = 0
+        _COL_LEVELS[key] = torch.as_tensor(idx, device=device)
+    return _COL_LEVELS[key]
+
+
+class _ScaleLevels(torch.autograd.Function):
+    """Phi (N, ld) with level m's columns multiplied by fac[m][n] (fac: (M+1, N); padding columns stay zero): the per-sequence factors of
+    kernels.py:576-584 / :656-667 put onto the features, whole-buffer operations instead of one autograd slice per level."""
+
+    @staticmethod
+    def forward(ctx, Phi, fac, d):
+        M = fac.shape[0] - 1
+        col = _col_levels(d, M, Phi.shape[1], Phi.device)
+        facx = torch.cat([fac, fac.new_zeros(1, fac.shape[1])], dim=0)                              # level M+1: the padding
+        colfac = facx.T[:, col]                                                                     # (N, ld)
+        ctx.save_for_backward(Phi, colfac)
+        ctx.d, ctx.M = d, M
+        return Phi * colfac
+
+    @staticmethod
+    def backward(ctx, G):
+        Phi, colfac = ctx.saved_tensors
+        d, M = ctx.d, ctx.M
+        gp = G * Phi
+        rows, off = [None] * (M + 1), 0
+        for m in range(1, M + 1):
+            rows[m] = gp[:, off:off + d ** m].sum(dim=1)
+            off += d ** m
+        rows[0] = gp[:, off]
+        return G * colfac, torch.stack(rows, dim=0), None
+
+
+class _LevelNorms(torch.autograd.Function):
+    """K_m(x, x) = |Phi_m(x)|^2 of every level: (N, ld) -> (M+1, N) (level 0: 1)."""
+
+    @staticmethod
+    def forward(ctx, Phi, d, M):
+        sq = Phi * Phi
+        rows, off = [None] * (M + 1), 0
+        for m in range(1, M + 1):
+            rows[m] = sq[:, off:off + d ** m].sum(dim=1)
+            off += d ** m
+        rows[0] = sq[:, off]
+        ctx.save_for_backward(Phi)
+        ctx.d, ctx.M = d, M
+        return torch.stack(rows, dim=0)
+
+    @staticmethod
+    def backward(ctx, G):
+        (Phi,) = ctx.saved_tensors
+        col = _col_levels(ctx.d, ctx.M, Phi.shape[1], Phi.device)
+        Gx = torch.cat([G, G.new_zeros(1, G.shape[1])], dim=0)
+        Gx = Gx.clone()
+        Gx[0] = 0.0                                                                                 # level 0 is the constant 1
+        return 2.0 * Phi * Gx.T[:, col], None, None
+
+
+class _FeatureProduct(torch.autograd.Function):
+    """A (T, F) @ B (N, F)^T with T << N: the backward's dA = G B has few result tiles and depth N, which the library's GEMM selection runs at a
+    quarter of the speed of the same flops as a batch of products over chunks of N (1.78 -> 0.51 ms at T = 512, N = 16,384, F = 1,568)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        ctx.save_for_backward(A, B)
+        return A @ B.T
+
+    @staticmethod
+    def backward(ctx, G):
+        A, B = ctx.saved_tensors
+        T, N = G.shape
+        ch = next((c for c in (32, 16, 8, 4, 2) if N % c == 0 and N // c >= 256), 1)
+        if ch > 1:
+            dA = torch.bmm(G.reshape(T, ch, N // ch).permute(1, 0, 2), B.reshape(ch, N // ch, B.shape[1])).sum(dim=0)
+        else:
+            dA = G @ B
+        return dA, G.T @ A
+
+
+def _tensor_features(Zs, M, increments, unit):
+    """Rank-one inducing tensors as level features: Z (lt, T, d) [(lt, T, 2, d): increments, kernels.py:329-330] -> [(T, d^m)], level m the outer
+    product of its m components, first index = the component paired with the earliest time (signature_algs.py:118-125)."""
+    if unit:                                                                                        # kernels.py:820-828 on the tensors' side
+        Zs = Zs / torch.sqrt(torch.square(Zs).sum(dim=-1, keepdim=True))
+    if increments:
+        Zs = Zs[:, :, 1] - Zs[:, :, 0]
+    out, k = [], 0
+    for m in range(1, M + 1):
+        f = Zs[k]
+        for j in range(1, m):
+            f = (f[:, :, None] * Zs[k + j][:, None, :]).reshape(f.shape[0], -1)
+        out.append(f)
+        k += m
+    return out
+
+
 class _SeqDiagLevels(torch.autograd.Function):
     """_K_seq_diag (kernels.py:188-205): (N, L, d) -> (M+1, N)."""
 
@@ -688,6 +853,7 @@ def _low_rank_scoped(fn):
             return fn(self, *a, **kw)
         finally:
             self._lr = None
+            self._phi_memo = None
     return wrapped
 
 
@@ -705,6 +871,8 @@ class SignatureKernelModule(torch.nn.Module):
             raise NotImplementedError("SignatureKernel is abstract: use SignatureLinear, SignatureRBF, ...")
         self.kern = kern
         self._lr = None
+        self._phi_memo = None
+        self.feature_route = True      # linear / cosine kernel: Kzx and the level diagonals from explicit level features (one feature sweep per sequence)
         self.sum_route = True          # K(X [, X2]) of the linear / cosine kernel: level sum and gradient as one op where the library offers it
         d_cols = kern.num_features * (kern.num_lags + 1)
         # beyond 64 columns and for the spectral kernel: base-kernel tensors here (GEMMs, autograd), recursions in the library
@@ -792,9 +960,26 @@ class SignatureKernelModule(torch.nn.Module):
             return torch.stack([a @ b.T for a, b in zip(P1, P2)], dim=0)
         return self._mx_seq_levels(Xs, X2s) if self.matrix_route else _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
 
+    def _phi(self, Xs):
+        """The level features (N, ld) of the scaled sequences where the feature route applies (one sweep per evaluation, shared by the
+        level diagonals and Kzx), else None."""
+        if not (self.feature_route and self._lr is None and not self.matrix_route and self._spec.base in ("linear", "cosine") and Xs.is_cuda):
+            return None
+        if self._phi_memo is not None and self._phi_memo[0] is Xs:
+            return self._phi_memo[1]
+        n, l, d = Xs.shape
+        if not _SigFeatures.ld(self._spec, d, l):
+            return None
+        Phi = _SigFeatures.apply(Xs, self._spec)
+        self._phi_memo = (Xs, Phi)
+        return Phi
+
     def _diag_levels(self, Xs):
         if self._lr is not None:                                                                    # kernels.py:457, :501
             return torch.stack([torch.square(P).sum(dim=-1) for P in self._lr.seq(Xs)], dim=0)
+        Phi = self._phi(Xs)
+        if Phi is not None:                                                                         # K_m(x, x) = |Phi_m(x)|^2
+            return _LevelNorms.apply(Phi, Xs.shape[2], self._spec.num_levels)
         return self._mx_diag_levels(Xs) if self.matrix_route else _SeqDiagLevels.apply(Xs, self.p0, self._spec)
 
     def _tens_levels(self, Zs, increments):
@@ -805,11 +990,25 @@ class SignatureKernelModule(torch.nn.Module):
     def _tvs_levels(self, Zs, Xs, increments):
         if self._lr is not None:                                                                    # kernels.py:568
             return torch.stack([a @ b.T for a, b in zip(self._lr.tens(Zs, increments), self._lr.seq(Xs))], dim=0)
+        Phi = self._phi(Xs)
+        if Phi is not None:                                                                         # K_m(z, x) = <z_1 (x) .. (x) z_m, Phi_m(x)>
+            lev = _split_levels(Phi, Xs.shape[2], self._spec.num_levels)
+            zf = _tensor_features(Zs, self._spec.num_levels, increments, self._spec.base == "cosine")
+            ones = torch.ones((zf[0].shape[0], Xs.shape[0]), dtype=lev[0].dtype, device=Xs.device)
+            return torch.stack([ones] + [a @ b.T for a, b in zip(zf, lev)], dim=0)
         return self._mx_tvs_levels(Zs, Xs, increments) if self.matrix_route else _TensVsSeqLevels.apply(Zs, Xs, self.p0, self._spec, increments)
 
     def _tvs_weighted(self, Zs, Xs, fac, increments):
         if self.matrix_route or self._lr is not None:
             return (self._tvs_levels(Zs, Xs, increments) * fac[:, None, :]).sum(dim=0)
+        Phi = self._phi(Xs)
+        if Phi is not None:             # sum_m fac[m][n] <Z_m[t], Phi_m[n]>: the factors go onto the features, no level arrays
+            # ONE product of depth ld (the library's per-level GEMMs of depth d, d^2 run at the speed of the widest): level 0 (= 1 on both sides)
+            # rides along as the column it has in the feature buffer, whose zero padding keeps the rows 16-aligned
+            zl = _tensor_features(Zs, self._spec.num_levels, increments, self._spec.base == "cosine")
+            F, T = sum(a.shape[1] for a in zl), zl[0].shape[0]
+            zf = torch.cat(zl + [zl[0].new_ones(T, 1), zl[0].new_zeros(T, Phi.shape[1] - F - 1)], dim=1)
+            return _FeatureProduct.apply(zf, _ScaleLevels.apply(Phi, fac, Xs.shape[2]))
         return _TensVsSeqWeighted.apply(Zs, Xs, fac, self.p0, self._spec, increments)
 
     # the same four primitives on the matrix route (kernels.py:188-340 with torch ops up to the differenced tensor)

@@ -47,6 +47,39 @@ static void sig_ho_tables(int order, SigFeatGradArgs& A) {
         for (int k = 0; k <= 8; ++k) A.w[j][k] = (j + k <= 9) ? fact[j] / fact[j + k] : 0.0;
 }
 
+// raw level features of N sequences (no weights, no normalisation), natural order, into Phi (N, ld); dlev: (N, M+1) level diagonals or NULL
+static int sig_launch_features(gpsig_ctx* c, SigFeatLaunchFn ffn, const gpsig_params* p, int d, int order, bool cosine, int64_t ld, const double* Xs,
+                               int64_t N, int L, double* phi, double* dlev) {
+    const int M = p->num_levels;
+    ScaleParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.d_in = d;                                  // the level primitives take their inputs as they come: no lengthscales, no lags
+    SigFeatArgs A;
+    memset(&A, 0, sizeof(A));
+    A.X = Xs; A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = sp;
+    A.w = nullptr; A.normalize = 0; A.jitter = 0.0; A.Phi = phi; A.ld = ld; A.dlev = dlev;
+    A.order = order; A.natural_order = 1; A.unit_points = cosine ? 1 : 0;
+    hipError_t e = ffn(A, unsigned(N < 4096 ? N : 4096), sig_features_lds_bytes(d, M, L), c->stream);
+    if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
+    return GPSIG_OK;
+}
+
+// dPhi (N, ld) back through the feature sweep of N sequences: gx (N, L, d)
+static int sig_launch_reverse(gpsig_ctx* c, SigFeatGradLaunchFn rfn, const gpsig_params* p, int d, int order, bool cosine, int64_t ld, const double* Xs,
+                              int64_t N, int L, const double* Ph, const double* dP, double* gx) {
+    const int M = p->num_levels;
+    SigFeatGradArgs A;
+    memset(&A, 0, sizeof(A));
+    A.X = Xs; A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.Phi = Ph; A.dPhi = dP; A.ld = ld; A.gX = gx;
+    A.unit_points = cosine ? 1 : 0;
+    A.order = order;
+    if (order > 1) sig_ho_tables(order, A);
+    const size_t lds_rev = order > 1 ? sig_feat_grad_ho_lds_bytes(d, M, L) : sig_feat_grad_lds_bytes(d, M, L);
+    hipError_t e = rfn(A, unsigned(N < 8192 ? N : 8192), lds_rev, c->stream);
+    if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_feat_reverse_kernel: %s", hipGetErrorString(e));
+    return GPSIG_OK;
+}
+
 // dPhi[i][k] = 2 G[level(k)][i] Phi[i][k]: the diagonal K_m(x_i, x_i) = |Phi_m(x_i)|^2
 static __global__ void sig_diag_dphi_kernel(const double* __restrict__ Phi, const double* __restrict__ G, int64_t N, int64_t ld, int D, int M,
                                             double* __restrict__ dPhi) {
@@ -203,21 +236,8 @@ int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     void* gsym = nullptr;
     if (sym) CHK(ensure(c, B_SF5, sizeof(double) * size_t(N1) * N1 + 64, &gsym));
     c->sf_valid = false;                          // (B_SF0 no longer holds what "sig_features_keep" remembers)
-    ScaleParams s;
-    memset(&s, 0, sizeof(s));
-    s.d_in = d;                                   // the level primitives take their inputs as they come: no lengthscales, no lags
-    auto features = [&](const double* Xs, int64_t N, int L, void* phi) -> int {
-        SigFeatArgs A;
-        memset(&A, 0, sizeof(A));
-        A.X = Xs; A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = s;
-        A.w = nullptr; A.normalize = 0; A.jitter = 0.0; A.Phi = static_cast<double*>(phi); A.ld = ld; A.dlev = nullptr;
-        A.order = order; A.natural_order = 1; A.unit_points = cosine ? 1 : 0;
-        hipError_t e = ffn(A, unsigned(N < 4096 ? N : 4096), sig_features_lds_bytes(d, M, L), c->stream);
-        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
-        return GPSIG_OK;
-    };
-    CHK(features(X, N1, L1, phi1));
-    if (two) CHK(features(Y, N2, L2, phi2));
+    CHK(sig_launch_features(c, ffn, p, d, order, cosine, ld, X, N1, L1, static_cast<double*>(phi1), nullptr));
+    if (two) CHK(sig_launch_features(c, ffn, p, d, order, cosine, ld, Y, N2, L2, static_cast<double*>(phi2), nullptr));
     const double* P1 = static_cast<const double*>(phi1);
     const double* P2 = two ? static_cast<const double*>(phi2) : P1;
     double* D1 = static_cast<double*>(dphi1);
@@ -249,22 +269,8 @@ int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
             w *= d;
         }
     }
-    auto reverse = [&](const double* Xs, int64_t N, int L, const double* Ph, const double* dP, double* gx) -> int {
-        SigFeatGradArgs A;
-        memset(&A, 0, sizeof(A));
-        A.X = Xs; A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.Phi = Ph; A.dPhi = dP; A.ld = ld; A.gX = gx;
-        A.unit_points = cosine ? 1 : 0;
-        A.order = order;
-        if (order > 1) {
-            sig_ho_tables(order, A);
-        }
-        const size_t lds_rev = order > 1 ? sig_feat_grad_ho_lds_bytes(d, M, L) : sig_feat_grad_lds_bytes(d, M, L);
-        hipError_t e = rfn(A, unsigned(N < 8192 ? N : 8192), lds_rev, c->stream);
-        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_feat_reverse_kernel: %s", hipGetErrorString(e));
-        return GPSIG_OK;
-    };
-    CHK(reverse(X, N1, L1, P1, D1, gX));
-    if (two) CHK(reverse(Y, N2, L2, P2, D2, gY));
+    CHK(sig_launch_reverse(c, rfn, p, d, order, cosine, ld, X, N1, L1, P1, D1, gX));
+    if (two) CHK(sig_launch_reverse(c, rfn, p, d, order, cosine, ld, Y, N2, L2, P2, D2, gY));
     *done = true;
     return GPSIG_OK;
 }
@@ -319,21 +325,8 @@ int sig_features_sum_grad(gpsig_ctx* c, const gpsig_params* p, int d, const doub
     void* gsym = nullptr;
     if (sym) CHK(ensure(c, B_SF5, sizeof(double) * size_t(N1) * N1 + 64, &gsym));
     c->sf_valid = false;
-    ScaleParams s;
-    memset(&s, 0, sizeof(s));
-    s.d_in = d;
-    auto features = [&](const double* Xs, int64_t N, int L, void* phi, double* dlev) -> int {
-        SigFeatArgs A;
-        memset(&A, 0, sizeof(A));
-        A.X = Xs; A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = s;
-        A.w = nullptr; A.normalize = 0; A.jitter = 0.0; A.Phi = static_cast<double*>(phi); A.ld = ld; A.dlev = dlev;
-        A.order = order; A.natural_order = 1; A.unit_points = cosine ? 1 : 0;
-        hipError_t e = ffn(A, unsigned(N < 4096 ? N : 4096), sig_features_lds_bytes(d, M, L), c->stream);
-        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
-        return GPSIG_OK;
-    };
-    CHK(features(X, N1, L1, phi1, dl1));
-    if (!sym) CHK(features(Y, N2, L2, phi2, dl2));
+    CHK(sig_launch_features(c, ffn, p, d, order, cosine, ld, X, N1, L1, static_cast<double*>(phi1), dl1));
+    if (!sym) CHK(sig_launch_features(c, ffn, p, d, order, cosine, ld, Y, N2, L2, static_cast<double*>(phi2), dl2));
     const double* P1 = static_cast<const double*>(phi1);
     const double* P2 = sym ? P1 : static_cast<const double*>(phi2);
     const double *U1 = P1, *U2 = P2;
@@ -379,20 +372,8 @@ int sig_features_sum_grad(gpsig_ctx* c, const gpsig_params* p, int d, const doub
         hipLaunchKernelGGL(sig_weight_grad_kernel, dim3(1), dim3(256), 0, c->stream, cdot, N1, M, sym ? 0.5 : 1.0, gw);
         HIPCHK(c, hipGetLastError());
     }
-    auto reverse = [&](const double* Xs, int64_t N, int L, const double* Ph, const double* dP, double* gx) -> int {
-        SigFeatGradArgs A;
-        memset(&A, 0, sizeof(A));
-        A.X = Xs; A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.Phi = Ph; A.dPhi = dP; A.ld = ld; A.gX = gx;
-        A.unit_points = cosine ? 1 : 0;
-        A.order = order;
-        if (order > 1) sig_ho_tables(order, A);
-        const size_t lds_rev = order > 1 ? sig_feat_grad_ho_lds_bytes(d, M, L) : sig_feat_grad_lds_bytes(d, M, L);
-        hipError_t e = rfn(A, unsigned(N < 8192 ? N : 8192), lds_rev, c->stream);
-        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_feat_reverse_kernel: %s", hipGetErrorString(e));
-        return GPSIG_OK;
-    };
-    CHK(reverse(X, N1, L1, P1, D1, gX));
-    if (!sym) CHK(reverse(Y, N2, L2, P2, D2, gY));
+    CHK(sig_launch_reverse(c, rfn, p, d, order, cosine, ld, X, N1, L1, P1, D1, gX));
+    if (!sym) CHK(sig_launch_reverse(c, rfn, p, d, order, cosine, ld, Y, N2, L2, P2, D2, gY));
     *done = true;
     return GPSIG_OK;
 }
@@ -417,4 +398,66 @@ extern "C" int gpsig_kernel_K_grad(gpsig_ctx* c, const gpsig_params* p, const vo
                               static_cast<double*>(g_weights), probe, &done));
     *taken = done ? 1 : 0;
     return GPSIG_OK;
+}
+
+// ---- the explicit level features as an op of their own (round 4) ----------------------------------------------------------------------
+// Phi(x) = (Phi_1, .., Phi_M)(x), Phi_m in (R^d)^(x)m: for SignatureLinear K_m(x, y) = <Phi_m(x), Phi_m(y)> (signature_algs.py:8-35 unrolled;
+// order > 1: the truncated-exponential steps of :37-74, order = num_levels and difference on: the signature of the piecewise-linear path, what
+// the reference's notebook checks against esig).  With them <z_1 (x) .. (x) z_m, Phi_m(x)> is the tensor-vs-sequence kernel of a rank-one
+// inducing tensor (signature_algs.py:101-127), so the linear kernel's Kzx is a plain product of (T, F) and (N, F) matrices.
+namespace gpsig {
+static bool sig_features_plan(const gpsig_params* p, int L, SigFeatLaunchFn* ffn, SigFeatGradLaunchFn* rfn, int64_t* ld, int* order, bool* cosine) {
+    const int M = p->num_levels, d = p->num_features;
+    *cosine = p->base_kernel == GPSIG_BASE_COSINE;
+    *order = p->order < 1 ? 1 : (p->order > M ? M : p->order);
+    if (!(p->base_kernel == GPSIG_BASE_LINEAR || *cosine) || M < 2 || M > 8 || d < 1 || d > 32) return false;
+    if (p->lengthscales || p->num_lags != 0 || p->dtype != GPSIG_F64) return false;
+    *ffn = sig_feat_lookup(d, M);
+    *rfn = sig_feat_grad_lookup(d, M);
+    if (!*ffn || !*rfn) return false;
+    if ((p->difference ? L - 1 : L) < 1) return false;
+    const size_t lds_f = sig_features_lds_bytes(d, M, L);
+    const size_t lds_r = *order > 1 ? sig_feat_grad_ho_lds_bytes(d, M, L) : sig_feat_grad_lds_bytes(d, M, L);
+    if (lds_f > 150 * 1024 || lds_r > 158 * 1024) return false;
+    *ld = (int64_t(sig_feature_count(d, M)) + 1 + 15) / 16 * 16;
+    return true;
+}
+}  // namespace gpsig
+
+extern "C" int64_t gpsig_seq_features_ld(const gpsig_params* p, int32_t L) {
+    using namespace gpsig;
+    SigFeatLaunchFn ffn; SigFeatGradLaunchFn rfn; int64_t ld = 0; int order; bool cosine;
+    if (!p || !sig_features_plan(p, L, &ffn, &rfn, &ld, &order, &cosine)) return 0;
+    return ld;
+}
+
+extern "C" int gpsig_seq_features(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, void* out) {
+    using namespace gpsig;
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    SigFeatLaunchFn ffn; SigFeatGradLaunchFn rfn; int64_t ld = 0; int order; bool cosine;
+    if (!sig_features_plan(p, L, &ffn, &rfn, &ld, &order, &cosine))
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "gpsig_seq_features: linear / cosine kernel, float64, 2 <= num_levels <= 8, d <= 32, inputs as they come, a sequence's arrays within the LDS (gpsig_seq_features_ld says 0 otherwise)");
+    if (N <= 0 || !X || !out) return fail(c, GPSIG_ERR_INVALID, "gpsig_seq_features: null or empty argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int d = p->num_features;
+    const void* dx;
+    void* dout;
+    CHK(in_dev(c, B_IN0, X, sizeof(double) * size_t(N) * L * d, &dx));
+    CHK(out_dev(c, B_OUT0, out, sizeof(double) * size_t(N) * ld, &dout));
+    CHK(sig_launch_features(c, ffn, p, d, order, cosine, ld, static_cast<const double*>(dx), N, L, static_cast<double*>(dout), nullptr));
+    CHK(out_done(c, out, dout, sizeof(double) * size_t(N) * ld));
+    return finish(c);
+}
+
+extern "C" int gpsig_seq_features_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, const void* Phi, const void* dPhi,
+                                       void* gX) {
+    using namespace gpsig;
+    if (!c || !p) return GPSIG_ERR_INVALID;
+    SigFeatLaunchFn ffn; SigFeatGradLaunchFn rfn; int64_t ld = 0; int order; bool cosine;
+    if (!sig_features_plan(p, L, &ffn, &rfn, &ld, &order, &cosine)) return fail(c, GPSIG_ERR_UNSUPPORTED, "gpsig_seq_features_grad: see gpsig_seq_features");
+    if (c->ptr_mode != GPSIG_PTR_DEVICE) return fail(c, GPSIG_ERR_INVALID, "gpsig_seq_features_grad takes device pointers");
+    if (N <= 0 || !X || !Phi || !dPhi || !gX) return fail(c, GPSIG_ERR_INVALID, "gpsig_seq_features_grad: null or empty argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    return sig_launch_reverse(c, rfn, p, p->num_features, order, cosine, ld, static_cast<const double*>(X), N, L, static_cast<const double*>(Phi),
+                              static_cast<const double*>(dPhi), static_cast<double*>(gX));
 }

@@ -345,6 +345,18 @@ int gpsig_lr_kernel_diag(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowr
 /* X2 == NULL: symmetric Gram, gX receives both roles of every sequence. */
 int gpsig_seq_gram_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
                                int32_t L1, int32_t L2, const void* G /* (M+1, N1, N2) */, void* gX, void* gX2, double* g_base);
+/* The explicit level features of the linear (cosine: of the unit vectors) kernel as an op of their own (round 4; no function of this name
+ * in the reference: signature_algs.py:8-35 unrolled -- level m of SignatureLinear is <Phi_m(x), Phi_m(y)> -- and, for order > 1, the
+ * truncated-exponential steps of :37-74; order = num_levels with difference on is the signature of the piecewise-linear path, what the
+ * reference's notebook checks against esig).  out: (N, ld) doubles, ld = gpsig_seq_features_ld(p, L): columns [0, F) hold levels 1..M one
+ * after the other, F = sum_m d^m, each in the natural order of its multi-indices (last index fastest, first index = earliest time), column F
+ * is level 0 (= 1), the rest zeros.  With them the tensor-vs-sequence kernel of a rank-one tensor is <z_1 (x) .. (x) z_m, Phi_m(x)>
+ * (signature_algs.py:101-127).  Inputs as they come (p->lengthscales NULL, no lags), float64; _ld returns 0 for shapes the feature kernels
+ * are not built for (then _seq_features fails with GPSIG_ERR_UNSUPPORTED).  _grad: dPhi (N, ld) back through the feature sweep to gX
+ * (N, L, d); Phi is the forward's output; device pointers.  Plain kernel launches on the context's stream: usable inside a graph capture. */
+int64_t gpsig_seq_features_ld(const gpsig_params* p, int32_t L);
+int gpsig_seq_features(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L, void* out);
+int gpsig_seq_features_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* X, int64_t N, int32_t L, const void* Phi, const void* dPhi, void* gX);
 /* The gradient of gpsig_kernel_K's level SUM (return_levels = 0) for SignatureLinear / SignatureCosine of every order through the
  * feature space (round 4): with K[i][j] = sum_m w_m <u_m(x_i), u_m(y_j)>, u_m = Phi_m / sqrt(|Phi_m|^2 + jitter) when p->normalization
  * (else Phi_m) and w_m = sigma variances[m], every level shares the upstream g (N1, N2), so ONE product g U(Y) over the whole feature

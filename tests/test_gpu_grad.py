@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle import sigkern_oracle_torch as OT
+from oracle import sigkern_oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -352,6 +353,96 @@ def test_level_sum_op_is_the_route_taken_and_can_be_declined():
     mod.sum_route = True
     for a, b in zip(res[True], res[False]):
         assert rel(a, b) < 1e-9, rel(a, b)
+
+
+def test_signature_features_are_the_truncated_signature_and_differentiate():
+    """gpsig_seq_features: at order = num_levels with differences the level features are the signature of the piecewise-linear path (Chen's
+    identity, the oracle's independent validator standing in for esig, notebook cells 6-7); at order 1 their inner products are the first-order
+    levels of signature_algs.py:8-35; gpsig_seq_features_grad against central differences of a random functional."""
+    from gpsig_amd import autodiff
+    rng = np.random.default_rng(3)
+    N, L, d, M = 6, 11, 3, 4
+    X = np.cumsum(0.4 * rng.standard_normal((N, L, d)), axis=1)
+    dev = torch.device("cuda:0")
+    lev = autodiff.signature_features(torch.tensor(X, device=dev), M, order=M, difference=True)
+    assert [tuple(a.shape) for a in lev] == [(N, d ** m) for m in range(1, M + 1)]
+    got = torch.cat(lev, dim=1).cpu().numpy()
+    want = np.stack([O.truncated_signature(x, M)[1:] for x in X])
+    assert np.abs(got - want).max() < 1e-12 * max(1.0, np.abs(want).max())
+    ko = O.SignatureKernelOracle(L * d, d, M, base="linear", order=1, normalization=False, difference=True, lengthscales=None)
+    lev1 = autodiff.signature_features(torch.tensor(X, device=dev), M, order=1)
+    Kl = ko.K(X.reshape(N, -1), return_levels=True)            # unit variances and sigma
+    for m in range(1, M + 1):
+        assert rel((lev1[m - 1] @ lev1[m - 1].T).cpu(), Kl[m]) < 1e-12
+    for order, difference, unit in ((1, True, False), (3, True, False), (2, False, True)):
+        W = [torch.tensor(rng.standard_normal((N, d ** m)), device=dev) for m in range(1, M + 1)]
+        f = lambda xt: sum((a * w).sum() for a, w in zip(autodiff.signature_features(xt, M, order=order, difference=difference, unit_points=unit), W))
+        xt = torch.tensor(X + (1.0 if unit else 0.0), device=dev, requires_grad=True)
+        f(xt).backward()
+        V = rng.standard_normal(X.shape)
+        h = 1e-5
+        with torch.no_grad():
+            num = (f(xt + h * torch.tensor(V, device=dev)) - f(xt - h * torch.tensor(V, device=dev))).item() / (2 * h)
+        ana = float((xt.grad.cpu().numpy() * V).sum())
+        assert abs(num - ana) < 1e-7 * max(1.0, abs(ana)), (order, difference, unit, num, ana)
+    with pytest.raises(NotImplementedError):
+        autodiff.signature_features(torch.tensor(X, device=dev), 1)
+
+
+@pytest.mark.parametrize("base,normalization,difference,order,increments,num_lags",
+                         [("linear", True, True, 1, False, 0), ("linear", False, True, 1, True, 0), ("linear", True, False, 1, True, 1),
+                          ("cosine", True, True, 1, True, 0), ("cosine", False, False, 1, False, 0), ("linear", True, True, 3, False, 0),
+                          ("linear", False, True, 2, True, 0), ("cosine", True, True, 4, True, 0)])
+def test_inducing_tensor_covariances_through_the_level_features(base, normalization, difference, order, increments, num_lags):
+    """Linear / cosine kernel: Kzx = <rank-one tensor features, level features of the sequences> and the level diagonals as squared norms
+    (autodiff feature_route) against the oracle's autograd of kernels.py:591-671 and against the tensor-vs-sequence recursions' route."""
+    d, M, L, N, T = 3, 4, 10, 30, 7
+    mod, orc = _module_and_oracle(base, d, M, L, num_lags=num_lags, normalization=normalization, difference=difference, order=order)
+    rng = np.random.default_rng(12)
+    de, lt = d * (num_lags + 1), M * (M + 1) // 2
+    off = 1.0 if base == "cosine" else 0.0
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, L * d) + off
+    Z = 0.5 * rng.standard_normal((lt, T, 2, de) if increments else (lt, T, de)) + off
+    W = [rng.standard_normal(sh) for sh in ((T, T), (T, N), (N,), (T, N))]
+    dev = torch.device("cuda:0")
+    names = ["raw_variances", "raw_sigma", "raw_lengthscales"] + (["raw_lags", "raw_gamma"] if num_lags else [])
+
+    def loss(m, Zt, Xt, cv):
+        Kzz, Kzx, Kxx = m.K_tens_n_seq_covs(Zt, Xt, increments=increments)
+        return (Kzz * cv(W[0])).sum() + (Kzx * cv(W[1])).sum() + (Kxx * cv(W[2])).sum() + (m.K_tens_vs_seq(Zt, Xt, increments=increments) * cv(W[3])).sum()
+
+    from gpsig_amd import autodiff
+    assert autodiff._SigFeatures.ld(mod._spec, de, L) > 0            # the route under test is the one the module takes
+
+    def run(feature_route):
+        mod.feature_route = feature_route
+        mod.zero_grad()
+        Zt, Xt = torch.tensor(Z, device=dev, requires_grad=True), torch.tensor(X, device=dev, requires_grad=True)
+        l = loss(mod, Zt, Xt, lambda a: torch.tensor(a, device=dev))
+        l.backward()
+        return l.item(), Zt.grad.cpu(), Xt.grad.cpu(), {n: getattr(mod, n).grad.cpu().clone() for n in names}
+
+    try:
+        feat = run(True)
+        rec = run(False)
+    finally:
+        mod.feature_route = True
+    Zc, Xc = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+    lo = loss(orc, Zc, Xc, torch.tensor)
+    lo.backward()
+    assert abs(feat[0] - lo.item()) < 1e-10 * max(1.0, abs(lo.item())), (feat[0], lo.item())
+    assert rel(feat[1], Zc.grad) < 1e-8 and rel(feat[2], Xc.grad) < 1e-8, (rel(feat[1], Zc.grad), rel(feat[2], Xc.grad))
+    assert abs(feat[0] - rec[0]) < 1e-10 * max(1.0, abs(rec[0]))
+    assert rel(feat[1], rec[1]) < 1e-8 and rel(feat[2], rec[2]) < 1e-8
+    for n in names:
+        assert rel(feat[3][n], rec[3][n]) < 1e-7, (n, feat[3][n], rec[3][n])
+    # return_levels through the same features
+    with torch.no_grad():
+        a = mod.K_tens_vs_seq(torch.tensor(Z, device=dev), torch.tensor(X, device=dev), return_levels=True, increments=increments)
+        mod.feature_route = False
+        b = mod.K_tens_vs_seq(torch.tensor(Z, device=dev), torch.tensor(X, device=dev), return_levels=True, increments=increments)
+        mod.feature_route = True
+    assert rel(a, b) < 1e-10
 
 
 @pytest.mark.parametrize("base,difference", [("rbf", True), ("poly", True), ("matern32", False)])

@@ -62,6 +62,7 @@ if "b" in which:
     for base in (os.environ.get("BENCH_GRAD_BASES") or "rbf,linear").split(","):
         kern = (kernels.SignatureRBF if base == "rbf" else kernels.SignatureLinear)(L * d, d, M, lengthscales=d ** 0.5)
         mod = autodiff.SignatureKernelModule(kern, device=dev)
+        mod.feature_route = os.environ.get("GPSIG_FEATURE_ROUTE", "1") != "0"     # 0: linear Kzx / diagonals through the recursions' kernels
         for incr in [bool(int(v)) for v in (os.environ.get("BENCH_GRAD_INCR") or "0,1").split(",")]:
             Z = torch.tensor(rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d)), device=dev, requires_grad=True)
             W = torch.tensor(rng.standard_normal((T, N)), device=dev)
@@ -72,7 +73,7 @@ if "b" in which:
                 Kzz, Kzx, Kxx = mod.K_tens_n_seq_covs(Z, X, increments=incr)
                 ((Kzx * W).sum() + Kzz.sum() + Kxx.sum()).backward()
             tf, tb = timeit(fwd, 3, 1), timeit(both, 3, 1)
-            print(f"(b) C3 {base} incr={incr}: forward {tf*1e3:.1f} ms, forward+backward {tb*1e3:.1f} ms")
+            print(f"(b) C3 {base} incr={incr}{'' if mod.feature_route or base != 'linear' else ' [recursion kernels]'}: forward {tf*1e3:.1f} ms, forward+backward {tb*1e3:.1f} ms")
 if "c" in which:
     for (N, L, d, M) in ((512, 64, 8, 5), (1024, 64, 8, 5)):
         X = torch.tensor(rng.standard_normal((N, L * d)), device=dev)
