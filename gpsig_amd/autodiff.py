@@ -965,13 +965,14 @@ class SignatureKernelModule(torch.nn.Module):
         level diagonals and Kzx), else None."""
         if not (self.feature_route and self._lr is None and not self.matrix_route and self._spec.base in ("linear", "cosine") and Xs.is_cuda):
             return None
-        if self._phi_memo is not None and self._phi_memo[0] is Xs:
-            return self._phi_memo[1]
+        for held, Phi in (self._phi_memo or ()):
+            if held is Xs:
+                return Phi
         n, l, d = Xs.shape
         if not _SigFeatures.ld(self._spec, d, l):
             return None
         Phi = _SigFeatures.apply(Xs, self._spec)
-        self._phi_memo = (Xs, Phi)
+        self._phi_memo = ((self._phi_memo or ())[-1:]) + ((Xs, Phi),)         # the evaluation's last two sets of sequences
         return Phi
 
     def _diag_levels(self, Xs):
@@ -1222,30 +1223,51 @@ class SignatureKernelModule(torch.nn.Module):
         N, N2 = Xs.shape[0], X2s.shape[0]
         w = self._w()
         Kxx = self._seq_levels(Xs)
-        Kxx2 = self._seq_levels(Xs, X2s)
         norm = self.kern.normalization
+        # linear / cosine kernel, level sum wanted: Kxx2 = sum_m facz[m][t] facx[m][n] <Phi_m(z_t), Phi_m(x_n)> as ONE product of scaled level features
+        Pz = Px = None
+        if not return_levels:
+            Pz = self._phi(Xs)
+            Px = self._phi(X2s) if Pz is not None else None
+        by_features = Px is not None
+        Kxx2 = None if by_features else self._seq_levels(Xs, X2s)
+        facz, facx = w[:, None].expand(-1, N), None
         if norm:
             Kxx = Kxx + JITTER * torch.eye(N, dtype=Kxx.dtype, device=Kxx.device)[None]             # :709
             dsq = torch.sqrt(torch.diagonal(Kxx, dim1=1, dim2=2))
             Kxx = Kxx / (dsq[:, :, None] * dsq[:, None, :])
-            Kxx2 = Kxx2 / dsq[:, :, None]                                                           # :713
+            if by_features:
+                facz = facz / dsq
+            else:
+                Kxx2 = Kxx2 / dsq[:, :, None]                                                       # :713
         if full_X2_cov:
             Kx2x2 = self._seq_levels(X2s)
             if norm:
                 Kx2x2 = Kx2x2 + JITTER * torch.eye(N2, dtype=Kxx.dtype, device=Kxx.device)[None]
                 d2 = torch.sqrt(torch.diagonal(Kx2x2, dim1=1, dim2=2))
-                Kxx2 = Kxx2 / d2[:, None, :]
+                if by_features:
+                    facx = 1.0 / d2
+                else:
+                    Kxx2 = Kxx2 / d2[:, None, :]
                 Kx2x2 = Kx2x2 / (d2[:, :, None] * d2[:, None, :])
             Kx2x2 = Kx2x2 * w[:, None, None]
         else:
             Kx2x2 = self._diag_levels(X2s)
             if norm:
                 d2 = torch.sqrt(Kx2x2 + JITTER)
-                Kxx2 = Kxx2 / (dsq[:, :, None] * d2[:, None, :])                                    # :750 (second division by dsq: reference quirk)
+                if by_features:
+                    facz, facx = facz / dsq, 1.0 / d2                                               # :750 (second division by dsq: reference quirk)
+                else:
+                    Kxx2 = Kxx2 / (dsq[:, :, None] * d2[:, None, :])                                # :750 (second division by dsq: reference quirk)
                 Kx2x2 = w[:, None].expand(-1, N2)
             else:
                 Kx2x2 = Kx2x2 * w[:, None]
         Kxx = Kxx * w[:, None, None]
+        if by_features:
+            d = Xs.shape[2]
+            A = _ScaleLevels.apply(Pz, facz, d)
+            B = Px if facx is None else _ScaleLevels.apply(Px, facx, d)
+            return Kxx.sum(dim=0), _FeatureProduct.apply(A, B), Kx2x2.sum(dim=0)
         Kxx2 = Kxx2 * w[:, None, None]
         if return_levels:
             return Kxx, Kxx2, Kx2x2

@@ -1071,6 +1071,39 @@ def test_inducing_sequences_model(K=None):
     assert np.all(np.isfinite(trace)) and trace[-1] > trace[0]
 
 
+@pytest.mark.parametrize("base,normalization,order", [("linear", True, 1), ("linear", False, 1), ("cosine", True, 1), ("linear", True, 3)])
+def test_inducing_sequence_covariances_through_the_level_features(base, normalization, order):
+    """K_seq_n_seq_covs of the linear / cosine kernel (InducingSequences, kernels.py:674-761 with its double division): the cross block as ONE
+    product of scaled level features, against the fused evaluation path and, with gradients, against the route through the level primitives."""
+    from gpsig_amd import autodiff
+    d, M, L, Lz, N, T = 3, 4, 12, 6, 40, 9
+    mod, _ = _module_and_oracle(base, d, M, L, normalization=normalization, order=order)
+    rng = np.random.default_rng(8)
+    off = 1.0 if base == "cosine" else 0.0
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, L * d) + off
+    Zs = 0.4 * rng.standard_normal((T, Lz, d)) + off
+    dev = torch.device("cuda:0")
+    assert autodiff._SigFeatures.ld(mod._spec, d, L) > 0 and autodiff._SigFeatures.ld(mod._spec, d, Lz) > 0
+    names = ["raw_variances", "raw_sigma", "raw_lengthscales"]
+    for full in (False, True):
+        W = [torch.tensor(rng.standard_normal(sh), device=dev) for sh in ((T, T), (T, N), (N, N) if full else (N,))]
+        res = {}
+        for route in (True, False):
+            mod.feature_route = route
+            mod.zero_grad()
+            Zg, Xg = torch.tensor(Zs, device=dev, requires_grad=True), torch.tensor(X, device=dev, requires_grad=True)
+            out = mod.K_seq_n_seq_covs(Zg, Xg, full_X2_cov=full)
+            sum((a * w).sum() for a, w in zip(out, W)).backward()
+            res[route] = ([o.detach().cpu() for o in out], Zg.grad.cpu(), Xg.grad.cpu(), {n: getattr(mod, n).grad.cpu().clone() for n in names})
+        mod.feature_route = True
+        want = mod.kern.K_seq_n_seq_covs(Zs, X, full_X2_cov=full)
+        for g, w_, r in zip(res[True][0], want, res[False][0]):
+            assert rel(g, w_) < 1e-9 and rel(g, r) < 1e-10
+        assert rel(res[True][1], res[False][1]) < 1e-8 and rel(res[True][2], res[False][2]) < 1e-8
+        for n in names:
+            assert rel(res[True][3][n], res[False][3][n]) < 1e-7, (full, n)
+
+
 # ---- the matrix route (round 3): base-kernel tensors by torch GEMMs + autograd, recursions on their lattices in the library -----------
 @pytest.mark.parametrize("order", [1, 2, 3])
 def test_lattice_and_chain_primitives(order):
