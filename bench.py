@@ -530,7 +530,22 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
         alu_peak = FP64_MATRIX_PEAK_TFLOPS
         alu_frac = tf / alu_peak
         f_exec = fl_launch / evaluated_launch
-    kernel_name = (timed_kernel + " (feature contraction on the float64 matrix cores)" if mfma else
+    if timed_kernel == "tvs_features_dgemm":      # the linear kernel's Kzx: one product of the tensors' and the sequences' level features
+        fl_launch = mfma_flops / max(launches, 1)
+        tf = fl_launch / (per_launch_ms * 1e-3) / 1e12
+        bound = "mfma"
+        binding = ("float64 matrix cores (rocBLAS dgemm): Kzx of the linear kernel is ONE product of the inducing tensors' rank-one level features "
+                   "(T x ld) and the sequences' level features (N x ld), ld = sum_m d^m + 1 padded to 16; DESIGN.md section 6")
+        mfma = {"achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "flops_per_launch": fl_launch,
+                "frac_at_measured_clock": (tf / (FP64_MATRIX_PEAK_TFLOPS * ghz / 2.4)) if ghz else None,
+                "other_kernels_in_step": "sig_features_kernel (the sequences' level features, weights and normalisation on them), "
+                                         "tens_level_features_kernel, tens_gram_tile_kernel (Kzz)",
+                "kernel_share_of_step": per_launch_ms * launches_per_step / (dt / steps * 1e3)}
+        tflops_exec, alu_peak, alu_frac = tf, FP64_MATRIX_PEAK_TFLOPS, tf / FP64_MATRIX_PEAK_TFLOPS
+        f_exec = fl_launch / evaluated_launch
+        issue = None
+    kernel_name = ("rocBLAS dgemm (product of level features)" if timed_kernel == "tvs_features_dgemm" else
+                   timed_kernel + " (feature contraction on the float64 matrix cores)" if mfma else
                    "tvs_tile_kernel (tensor-vs-sequence chains)" if T else
                    ("seq_pk2_kernel (pair recursion, two sequences per pair group)" if (w["dtype"] == "f32" and base == "rbf")
                     else "seq_gram_kernel (pair recursion)"))

@@ -36,6 +36,8 @@ hipError_t sig_reduce_launch(const SigReduceArgs& R, hipStream_t stream);
 hipError_t sig_convert_launch(const void* in, void* out, int64_t n, bool widen, hipStream_t stream);
 bool solver_dsyevd(void** handle_slot, hipStream_t stream, int n, double* A, double* ev, double* work, int* info, std::string* err);
 void solver_release(void* handle);
+bool solver_dgemm(void** handle_slot, hipStream_t stream, bool transA, bool transB, int m, int n, int k, double alpha, const double* A, int lda,
+                  const double* B, int ldb, double beta, double* C, int ldc, std::string* err);      // lowrank_solver.hip
 int tvs_tile_waves(int M, int D, int E, int kind);
 typedef hipError_t (*SeqLaunchFn)(const SeqGramArgs&, int, size_t, hipStream_t);
 SeqLaunchFn seq_pk2_lookup(int G, int C, int D, int M, int mode, int pack, int waves);
@@ -608,6 +610,47 @@ int timing_begin_any(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1, bool* on) {
     return GPSIG_OK;
 }
 
+
+// ---- the linear / cosine kernel's Kzx as a product of level features (round 4) ------------------------------------------------------
+// An inducing tensor's level m is the rank-one tensor z_1 (x) .. (x) z_m (first factor <-> earliest time, signature_algs.py:118-125), and
+// K_m(z, x) = <z_1 (x) .. (x) z_m, Phi_m(x)> with the level features of sig_feat_kernel.hpp (every order: :129-160 too).
+// Zf[t][k]: the tensors' features in the layout of the sequences' (natural order, level-0 column = 1, zero padding).  ZT / ZS as
+// prep_tensors_kernel leaves them: ZT[((t * d + f) * lt + c) * E + e], ZS[(t * lt + c) * E + e] = |z|^2.
+static __global__ void tens_level_features_kernel(const double* __restrict__ ZT, const double* __restrict__ ZS, int lt, int E, int d, int64_t Tn,
+                                                  int M, int unit, int64_t ld, double* __restrict__ Zf) {
+    const int64_t total = Tn * ld;
+    for (int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t t = e / ld;
+        int k = int(e - t * ld), m = 1, w = d, off = 0;
+        while (m <= M && k >= off + w) { off += w; ++m; w *= d; }
+        double v;
+        if (m > M) {
+            v = k == off ? 1.0 : 0.0;                                 // level 0, then the padding
+        } else {
+            int idx = k - off;
+            const int c0 = m * (m - 1) / 2;
+            v = 1.0;
+            for (int j = m - 1; j >= 0; --j) {                        // last index fastest = the component paired with the latest time
+                const int f = idx % d;
+                idx /= d;
+                const int c = c0 + j;
+                double z = ZT[((t * d + f) * lt + c) * E + (E - 1)];
+                if (unit) z *= rsqrt(ZS[(t * lt + c) * E + (E - 1)]);  // SignatureCosine: unit vectors (kernels.py:820-828)
+                if (E == 2) {                                         // increments: k(z1, x) - k(z0, x) is linear in z (kernels.py:329-330)
+                    double z0 = ZT[((t * d + f) * lt + c) * E];
+                    if (unit) z0 *= rsqrt(ZS[(t * lt + c) * E]);
+                    z -= z0;
+                }
+                v *= z;
+            }
+        }
+        Zf[e] = v;
+    }
+}
+
+static __global__ void square_small_kernel(const double* __restrict__ a, int n, double* __restrict__ b) {
+    if (int(threadIdx.x) < n) b[threadIdx.x] = a[threadIdx.x] * a[threadIdx.x];
+}
 
 // ---- SignatureLinear, first order: the Gram as a contraction of explicit level features (sig_feat_kernel.hpp) --------------------
 // Taken where it is the cheaper evaluation -- 2 sum_m d^m flops per entry on the matrix cores against the lattice sweep's
@@ -1420,10 +1463,88 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
 }
 
 // Kzx on device pointers.  Zdev: the caller's (lt, T, E, d') tensor array; ZT/ZS: its sequence-lane preparation.
+static bool tvs_features_plan(gpsig_ctx* c, const gpsig_params* p, int64_t Tn, int64_t N, int L) {
+    const bool cosine = p->base_kernel == GPSIG_BASE_COSINE;
+    const int M = p->num_levels;
+    if (sizeof(TT) != 8 || c->tvs_features == 0 || c->capturing || !(p->base_kernel == GPSIG_BASE_LINEAR || cosine)) return false;
+    if (M < 2 || M > 8 || p->order < 1 || p->order > M || Tn <= 0 || N <= 0 || Tn > 0x3fffffff || N > 0x3fffffff) return false;
+    const int d = p->num_features * (p->num_lags + 1);
+    SigFeatLaunchFn ffn = sig_feat_lookup(d, M);
+    if (!ffn || (p->difference ? L - 1 : L) < 1) return false;
+    if (sig_features_lds_bytes(d, M, L) > 150 * 1024) return false;
+    for (int m = 0; m <= M; ++m)
+        if (!(p->sigma * p->variances[m] >= 0.0)) return false;             // (the weights go in squared: sqrt(w^2 / (diag + jitter)))
+    const int64_t F = sig_feature_count(d, M), ld = (F + 1 + 15) / 16 * 16;
+    if (sizeof(double) * size_t(ld) * (size_t(N) + size_t(Tn)) > (size_t(16) << 30)) return false;
+    if (c->tvs_features < 0) {
+        // rates as measured at BASELINE configs[2] (512 x 16,384, L = 50, d = 6, M = 4): the tile kernel 1.05 ms, here 0.18 + 0.42 ms
+        const int lt = M * (M + 1) / 2;
+        const double t_tile = 40e-6 + double(Tn) * double(N) * L * lt / 4.0e12;
+        const double t_seq = 60e-6 * double(sig_ipow(d, M)) / 32768.0, rounds = ceil(double(N) / 256.0);
+        const double t_feat = 80e-6 + (rounds * t_seq > 15e-6 ? rounds * t_seq : 15e-6) + 2.0 * double(Tn) * double(N) * double(ld) / 50e12;
+        if (!(t_feat < t_tile)) return false;
+    }
+    return true;
+}
+// Kzx = sum_m w_m / sqrt(K_m(x, x) + jitter) K_m(z, x) (kernels.py:572-588) of the linear / cosine kernel as ONE product of the tensors' and the
+// sequences' level features (rocBLAS dgemm): the weights and the normalisation ride on the sequences' features.  *done = false: the tile kernel.
+static int tens_vs_seq_features_device(gpsig_ctx* c, const gpsig_params* p, const void* ZT, const void* ZS, const void* X, int64_t Tn, int64_t N,
+                                       int L, int increments, const double* w, void* out, bool* done) {
+    *done = false;
+    if (!tvs_features_plan(c, p, Tn, N, L)) return GPSIG_OK;
+    const bool cosine = p->base_kernel == GPSIG_BASE_COSINE;
+    const int M = p->num_levels, d = p->num_features * (p->num_lags + 1);
+    SigFeatLaunchFn ffn = sig_feat_lookup(d, M);
+    const int64_t F = sig_feature_count(d, M), ld = (F + 1 + 15) / 16 * 16;
+    void *phi, *zf, *w2;
+    CHK(ensure(c, B_SF0, sizeof(double) * size_t(ld) * N + 64, &phi));
+    CHK(ensure(c, B_SF1, sizeof(double) * size_t(ld) * Tn + 64, &zf));
+    CHK(ensure(c, B_TW2, sizeof(double) * 16, &w2));
+    c->sf_valid = false;                          // (B_SF0 no longer holds what "sig_features_keep" remembers)
+    hipLaunchKernelGGL(square_small_kernel, dim3(1), dim3(64), 0, c->stream, w, M + 1, static_cast<double*>(w2));
+    HIPCHK(c, hipGetLastError());
+    ScaleParams s;
+    CHK(scale_params(c, p, true, &s));
+    SigFeatArgs A;
+    memset(&A, 0, sizeof(A));
+    A.X = static_cast<const double*>(X); A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = s;
+    A.w = static_cast<const double*>(w2); A.normalize = p->normalization ? 1 : 0; A.jitter = p->jitter; A.Phi = static_cast<double*>(phi); A.ld = ld;
+    A.dlev = nullptr; A.order = p->order; A.unit_points = cosine ? 1 : 0; A.norm_squared = 0; A.natural_order = 1;
+    {
+        hipError_t e = ffn(A, unsigned(N < 4096 ? N : 4096), sig_features_lds_bytes(d, M, L), c->stream);
+        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(tens_level_features_kernel, dim3(grid_for(Tn * ld)), dim3(256), 0, c->stream, static_cast<const double*>(ZT),
+                       static_cast<const double*>(ZS), M * (M + 1) / 2, increments ? 2 : 1, d, Tn, M, cosine ? 1 : 0, ld, static_cast<double*>(zf));
+    HIPCHK(c, hipGetLastError());
+    hipEvent_t e0, e1;
+    bool timed;
+    CHK(timing_begin(c, &e0, &e1, &timed));
+    // row-major out (T, N) = Zf (T, ld) Phi (N, ld)^T  ==  column-major out^T (N x T) = Phi_cm^T (N x ld) Zf_cm (ld x T)
+    std::string err;
+    if (!solver_dgemm(&c->blas_handle, c->stream, true, false, int(N), int(Tn), int(ld), 1.0, static_cast<const double*>(phi), int(ld),
+                      static_cast<const double*>(zf), int(ld), 0.0, static_cast<double*>(out), int(N), &err))
+        return fail(c, GPSIG_ERR_HIP, "%s", err.c_str());
+    if (timed) {
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        c->t_launches += 1;
+        c->t_pairs += Tn * N;
+        c->t_kernel = "tvs_features_dgemm";
+        c->t_flops += 2.0 * double(Tn) * double(N) * double(ld);
+    }
+    *done = true;
+    return GPSIG_OK;
+}
+
 static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Zdev, const void* ZT, const void* ZS,
                        const void* X, int64_t Tn, int64_t N, int L, int increments, const void* fx, const double* w,
                        int return_levels, void* out) {
     const int M = p->num_levels;
+    if (!raw && !return_levels && w) {      // the linear / cosine kernel's weighted level sum: one product of level features
+        bool done = false;
+        CHK(tens_vs_seq_features_device(c, p, ZT, ZS, X, Tn, N, L, increments, w, out, &done));
+        if (done) return GPSIG_OK;
+    }
     if (N > 0 && Tn > 0 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1 || c->tvs_tile == 1)) {
         bool done = false;
         CHK(tens_vs_seq_tile_device(c, p, raw, Zdev, X, Tn, N, L, increments, fx, w, return_levels, out, &done));
@@ -1714,7 +1835,7 @@ static int e_kernel_K_tens_vs_seq(gpsig_ctx* c, const gpsig_params* p, const voi
     void* dout;
     CHK(out_dev(c, B_OUT0, out, ob, &dout));
     const void* fx = nullptr;
-    if (p->normalization) CHK(seq_diag_factors(c, p, dX, N, L, &fx));     // kernels.py:572-581
+    if (p->normalization && !(!return_levels && tvs_features_plan(c, p, T, N, L))) CHK(seq_diag_factors(c, p, dX, N, L, &fx));     // kernels.py:572-581
     const double* w;
     CHK(upload_weights(c, p, &w));
     const void *ZT, *ZS;
@@ -1747,7 +1868,7 @@ static int e_kernel_K_tens_n_seq_covs(gpsig_ctx* c, const gpsig_params* p, const
     // Kzx: divided by sqrt(diag_x + jitter) when normalising (kernels.py:638 / :660) -- with full_X_cov the
     // diagonal of (Kxx + jitter*I) is the same number
     const void* fx = nullptr;
-    if (p->normalization) CHK(seq_diag_factors(c, p, dX, N, L, &fx));
+    if (p->normalization && !(!return_levels && tvs_features_plan(c, p, T, N, L))) CHK(seq_diag_factors(c, p, dX, N, L, &fx));
     const void *ZT, *ZS;
     CHK(prep_tensors(c, p, true, dZ, T, E, &ZT, &ZS));
     CHK(tens_vs_seq_device(c, p, false, dZ, ZT, ZS, dX, T, N, L, increments, fx, w, return_levels, dzx));
@@ -1930,6 +2051,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "f32_pack")) c->f32_pack = value;
     else if (!strcmp(name, "f32_waves")) c->f32_waves = value;
     else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
+    else if (!strcmp(name, "tvs_features")) c->tvs_features = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else if (!strcmp(name, "diag_own")) c->diag_own = value;
     else if (!strcmp(name, "spectral_wave")) c->spectral_wave = value;

@@ -76,6 +76,7 @@ struct gpsig_ctx {
                                   // 3: wavefront kernel + stored lattice, 4: scratch-free wavefront kernel wherever it is built
     void* blas_handle = nullptr;  // rocBLAS handle of gpsig_lr_whitening (lowrank_solver.hip), created at first use
     int tvs_tile = -1;            // Kzx tile kernel (tvs_tile_kernel.hpp): -1 where it is built, 0 never, 1 also below 32 tensors
+    int tvs_features = -1;        // Kzx of the linear / cosine kernel as one product of level features: -1 where a time model prefers it, 0 never, 1 wherever built
     int tvs_tile_nw = 0;          // its waves per workgroup: 0 = planner's choice
     int tens_tile = 1;            // Kzz in 16 x 16 tiles with the tensors staged in LDS (tens_gram_tile_kernel); 0: one gathering thread per entry
     int spectral_wave = 1;        // SignatureSpectral sequence kernels: 1 = wavefront kernels where built, 0 = one pair per thread (round 1)

@@ -129,6 +129,9 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 alone, so row blocks still reassemble the one-call Gram bit for bit
  *   "lr_jacobi"   gpsig_lr_draw: 1 (default) the landmark Gram's eigendecomposition by the one-workgroup Jacobi kernel (c <= 64), 0 rocSOLVER
  *   "tvs_zreg"    tensor-lane gradient: components in registers (1) or LDS (0), -1 automatic
+ *   "tvs_features" K_tens_vs_seq / the Kzx of K_tens_n_seq_covs (level sum) of SignatureLinear / SignatureCosine as ONE product of the tensors'
+ *                 rank-one level features and the sequences' level features (rocBLAS dgemm; round 4): -1 (default) where a time model
+ *                 prefers it to the tile kernel, 0 never, 1 wherever built (float64, 2 <= num_levels <= 8, not inside a graph capture)
  *   "tvs_tile"    tensor-vs-sequence tile kernel (levels split over the waves of a workgroup, coalesced result tiles):
  *                 -1 wherever it is built and there are at least 32 tensors, 0 never, 1 also for fewer tensors
  *   "tvs_tile_nw" its waves per workgroup (1 or 2), 0 automatic

@@ -817,6 +817,44 @@ def test_tile_kernel_for_many_tensors(K, base, incr):
         ctx.set_option("tvs_tile_nw", 0)
 
 
+@pytest.mark.parametrize("base", ["linear", "cosine"])
+@pytest.mark.parametrize("incr", [False, True])
+def test_tensor_vs_sequence_through_level_features(K, base, incr):
+    """K_tens_vs_seq and the Kzx of K_tens_n_seq_covs of the linear / cosine kernel as ONE product of the tensors' rank-one level features
+    and the sequences' level features (option tvs_features = 1; signature_algs.py:101-160: K_m(z, x) = <z_1 (x) .. (x) z_m, Phi_m(x)>) against
+    the oracle and against the tile kernel: normalisation on and off, differences, lags, higher orders, ragged sizes, host and device pointers."""
+    import torch
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(15)
+    ctx = _lib.context(0, 0)
+    off = 1.0 if base == "cosine" else 0.0
+    try:
+        for T, N, L, diff, M, d, norm, lags, order in ((70, 37, 19, True, 4, 5, True, 0, 1), (130, 83, 12, True, 4, 3, False, 1, 1),
+                                                      (64, 16, 9, False, 3, 6, True, 0, 1), (33, 49, 15, True, 5, 3, True, 0, 3),
+                                                      (40, 35, 8, True, 2, 8, False, 0, 2), (9, 200, 30, True, 4, 4, True, 2, 1)):
+            X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1) + off
+            de = d * (lags + 1)
+            Z = 0.7 * rng.standard_normal((M * (M + 1) // 2, T, 2, de) if incr else (M * (M + 1) // 2, T, de)) + off
+            kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, difference=diff, lengthscales=0.6 + rng.random(d),
+                      variances=0.5 + rng.random(M + 1), normalization=norm, num_lags=lags or None, order=order)
+            ko = make_oracle(kw)
+            want = ko.K_tens_vs_seq(Z, X, increments=incr)
+            ctx.set_option("tvs_features", 1)
+            kx = make_kernel(K, kw)
+            got = kx.K_tens_vs_seq(Z, X, increments=incr)
+            assert relerr(got, want) <= TOL, (T, N, M, d, norm, lags, order)
+            covs = kx.K_tens_n_seq_covs(Z, X, increments=incr)
+            for a, b in zip(covs, ko.K_tens_n_seq_covs(Z, X, increments=incr)):
+                assert relerr(a, b) <= TOL, (T, N, M, d, norm, lags, order, "covs")
+            gd = kx.K_tens_vs_seq(torch.tensor(Z, device="cuda:0"), torch.tensor(X, device="cuda:0"), increments=incr)
+            assert np.array_equal(gd.cpu().numpy(), got)                                   # device pointers: the same evaluation
+            ctx.set_option("tvs_features", 0)                                               # the tile kernel writes the same matrix
+            ref = make_kernel(K, kw).K_tens_vs_seq(Z, X, increments=incr)
+            assert np.abs(ref - got).max() <= 1e-11 * max(1.0, np.abs(ref).max()), (T, N, M, d, norm, lags, order)
+    finally:
+        ctx.set_option("tvs_features", -1)
+
+
 # ------------------------------------------------------------------------------------------------
 # float32 (BASELINE.json configs[4]: RBF, fp32).  Tolerance, stated by SURVEY.md 8(d): 1e-4 on normalised entries
 # (float32 rounding of O(1e-7) per operation through an L1 x L2 x M recursion; the fp64 oracle is the reference).
