@@ -487,6 +487,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     if vps and ghz:
         pairs_per_wave = PAIRS_PER_WAVE.get(cfg, 4)                  # G = 16: four pair groups per wavefront
         wave_steps = evaluated_launch / pairs_per_wave * L           # L lattice rows (L - 1 increments + the boundary row) per pair
+        # (a value a per cent or two above 1 is the resolution of the clock probe -- eight sampling wavefronts, one per XCD -- not a faster chip)
         issue = {"valu_per_wave_step": vps, "cycles_per_valu": 4, "wave_steps_per_launch": wave_steps, "simds": SIMDS,
                  "issue_frac": wave_steps * vps * 4.0 / (SIMDS * ghz * 1e9 * per_launch_ms * 1e-3)}
     vpl = VALU_PER_LAUNCH.get((cfg, base, bool(increments))) if timed_kernel is None else None
