@@ -963,7 +963,8 @@ class SignatureKernelModule(torch.nn.Module):
     def _phi(self, Xs):
         """The level features (N, ld) of the scaled sequences where the feature route applies (one sweep per evaluation, shared by the
         level diagonals and Kzx), else None."""
-        if not (self.feature_route and self._lr is None and not self.matrix_route and self._spec.base in ("linear", "cosine") and Xs.is_cuda):
+        if not (self.feature_route and self._lr is None and not self.matrix_route and self._spec.base in ("linear", "cosine") and Xs.is_cuda
+                and Xs.dtype == torch.float64):        # (float32 modules: the recursions' ops convert on the way in and round on the way out)
             return None
         for held, Phi in (self._phi_memo or ()):
             if held is Xs:

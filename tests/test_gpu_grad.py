@@ -811,11 +811,13 @@ def test_module_gradients_match_oracle_autograd(base, num_lags, normalization, d
             assert rel(raw.grad, want) < 1e-8, (kind, raw.grad, want)
 
 
-def test_float32_module_is_computed_in_float64_and_rounded():
+@pytest.mark.parametrize("base", ["rbf", "linear"])
+def test_float32_module_is_computed_in_float64_and_rounded(base):
     """A module after .float() (float32 parameters and data): the level primitives run on the float64 kernels, values and
-    gradients come back as float32 and agree with the float64 module to float32 rounding."""
+    gradients come back as float32 and agree with the float64 module to float32 rounding (linear: the one-op level sum converts
+    the same way; the level-feature route of Kzx is float64's)."""
     d, M, L, N, T = 3, 3, 8, 6, 4
-    mod, _ = _module_and_oracle("rbf", d, M, L)
+    mod, _ = _module_and_oracle(base, d, M, L)
     rng = np.random.default_rng(33)
     X, Z = rng.standard_normal((N, L * d)) * 0.5, rng.standard_normal((M * (M + 1) // 2, T, 2, d)) * 0.5
     W = torch.tensor(rng.standard_normal((T, N)), device="cuda:0")
