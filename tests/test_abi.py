@@ -128,6 +128,29 @@ def test_headline_kernel_keeps_three_wavefronts_per_simd(tmp_path):
     assert vgprs <= 168 and scratch == 0 and occupancy >= 3, (vgprs, scratch, occupancy)
 
 
+def test_low_rank_feature_kernel_keeps_four_wavefronts_per_simd(tmp_path):
+    """lr_seq_features_fused2_kernel<512, 8> (low-rank mode's feature map of a batch of sequences): 8 wavefronts per workgroup, so four per
+    SIMD = two workgroups per CU.  It sat at exactly 128 registers; one more (the repeated-squaring helper round 4 added to base_eval, inlined)
+    left one workgroup per CU and took BASELINE configs[2] in low-rank mode from 2.8 to 4.6 ms unnoticed.  The polynomial kernel's power is out
+    of line there now (116 registers; 2.75 ms); this reads the compiler's report."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "gpsig_amd", "csrc", "lr_fused_inst.hip")
+    out = str(tmp_path / "lr_fused.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                          stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    name = "_ZN5gpsig29lr_seq_features_fused2_kernelILi512ELi8EEEvNS_11LrFusedArgsE"
+    start = text.index(name + ":")
+    m = re.search(r"; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", text[start:], re.S)
+    vgprs, scratch, occupancy = (int(g) for g in m.groups())
+    assert vgprs <= 128 and scratch == 0 and occupancy >= 4, (vgprs, scratch, occupancy)
+
+
 def test_feature_contraction_loop_carries_no_vector_instruction_but_the_multiplies(tmp_path):
     """sig_gram_dma_kernel (the headline since round 3): the slab loop holds 64 MFMAs per slab and wave and, besides them, LDS reads,
     LDS-DMA loads and scalar instructions only -- every vector instruction beside the multiplies takes the issue port the next MFMA
