@@ -149,18 +149,19 @@ class _SeqGramSum(torch.autograd.Function):
         return p
 
     @staticmethod
-    def applies(Xs, X2s, wh, spec, normalization):
-        """Whether the library takes this shape through the feature space (asked before the forward pass commits to the route)."""
+    def applies(Xs, X2s, spec, normalization, wh=None):
+        """Whether the library takes this shape through the feature space (asked before the forward pass commits to the route; the
+        answer does not depend on the weights' values, so none are fetched from the device for it)."""
         if spec.base not in ("linear", "cosine") or not Xs.is_cuda:
             return False
-        X = _c(Xs)
-        X2 = None if X2s is None else _c(X2s)
-        n1, l1, d = X.shape
-        n2, l2 = (n1, l1) if X2 is None else X2.shape[:2]
+        if wh is None:
+            wh = np.ones(spec.num_levels + 1)
+        n1, l1, d = Xs.shape                                    # (shapes only: the pointers say which arguments are there, nothing is read)
+        n2, l2 = (n1, l1) if X2s is None else X2s.shape[:2]
         keep = []
         p = _SeqGramSum._params(spec, d, wh, normalization, keep)
         taken = C.c_int32(0)
-        _ctx_for(X).call("gpsig_kernel_K_grad", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, None, None, None, None, C.byref(taken))
+        _ctx_for(Xs).call("gpsig_kernel_K_grad", p, _ptr(Xs), None if X2s is None else _ptr(X2s), n1, n2, l1, l2, None, None, None, None, C.byref(taken))
         return bool(taken.value)
 
     @staticmethod
@@ -299,6 +300,7 @@ class _ScaleLevels(torch.autograd.Function):
     def backward(ctx, G):
         Phi, colfac = ctx.saved_tensors
         d, M = ctx.d, ctx.M
+        G = G.contiguous()
         gp = G * Phi
         rows, off = [None] * (M + 1), 0
         for m in range(1, M + 1):
@@ -345,6 +347,7 @@ class _FeatureProduct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, G):
         A, B = ctx.saved_tensors
+        G = G.contiguous()              # (the gradient of a plain .sum() arrives as a stride-0 expansion, which the batched product runs 40 times slower on)
         T, N = G.shape
         ch = next((c for c in (32, 16, 8, 4, 2) if N % c == 0 and N // c >= 256), 1)
         if ch > 1:
@@ -872,7 +875,11 @@ class SignatureKernelModule(torch.nn.Module):
         self.kern = kern
         self._lr = None
         self._phi_memo = None
-        self.feature_route = True      # linear / cosine kernel: Kzx and the level diagonals from explicit level features (one feature sweep per sequence)
+        # linear / cosine kernel: Kzx and the level diagonals from explicit level features (one feature sweep per sequence + plain products).  True:
+        # where the recursion kernels' work (tensors x sequences x steps x components x columns) exceeds feature_route_min_work -- a minibatch of 50
+        # against 200 tensors is a dozen small launches slower this way (1.2 -> 1.9 ms), BASELINE configs[2] 2.6 times faster; "always"; False
+        self.feature_route = True
+        self.feature_route_min_work = 1.0e10
         self.sum_route = True          # K(X [, X2]) of the linear / cosine kernel: level sum and gradient as one op where the library offers it
         d_cols = kern.num_features * (kern.num_lags + 1)
         # beyond 64 columns and for the spectral kernel: base-kernel tensors here (GEMMs, autograd), recursions in the library
@@ -960,21 +967,28 @@ class SignatureKernelModule(torch.nn.Module):
             return torch.stack([a @ b.T for a, b in zip(P1, P2)], dim=0)
         return self._mx_seq_levels(Xs, X2s) if self.matrix_route else _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
 
-    def _phi(self, Xs):
+    def _phi(self, Xs, work=None):
         """The level features (N, ld) of the scaled sequences where the feature route applies (one sweep per evaluation, shared by the
-        level diagonals and Kzx), else None."""
+        level diagonals and Kzx), else None.  work: the caller's estimate of what the recursion kernels would do instead; without one only
+        features that the evaluation has already built are handed out."""
         if not (self.feature_route and self._lr is None and not self.matrix_route and self._spec.base in ("linear", "cosine") and Xs.is_cuda
                 and Xs.dtype == torch.float64):        # (float32 modules: the recursions' ops convert on the way in and round on the way out)
             return None
         for held, Phi in (self._phi_memo or ()):
             if held is Xs:
                 return Phi
+        if self.feature_route != "always" and self._spec.order == 1 and (work is None or work < self.feature_route_min_work):
+            return None                                # (order > 1: the higher-order recursion kernels lose at every size -- 3.5 -> 2.0 ms at a minibatch of 50)
         n, l, d = Xs.shape
         if not _SigFeatures.ld(self._spec, d, l):
             return None
         Phi = _SigFeatures.apply(Xs, self._spec)
         self._phi_memo = ((self._phi_memo or ())[-1:]) + ((Xs, Phi),)         # the evaluation's last two sets of sequences
         return Phi
+
+    def _tvs_work(self, Zs, Xs):
+        """tensors x sequences x time steps x tensor components x columns: what the tensor-vs-sequence recursion kernels sweep."""
+        return float(Zs.shape[1]) * Xs.shape[0] * Xs.shape[1] * Zs.shape[0] * Xs.shape[2]
 
     def _diag_levels(self, Xs):
         if self._lr is not None:                                                                    # kernels.py:457, :501
@@ -992,7 +1006,7 @@ class SignatureKernelModule(torch.nn.Module):
     def _tvs_levels(self, Zs, Xs, increments):
         if self._lr is not None:                                                                    # kernels.py:568
             return torch.stack([a @ b.T for a, b in zip(self._lr.tens(Zs, increments), self._lr.seq(Xs))], dim=0)
-        Phi = self._phi(Xs)
+        Phi = self._phi(Xs, self._tvs_work(Zs, Xs))
         if Phi is not None:                                                                         # K_m(z, x) = <z_1 (x) .. (x) z_m, Phi_m(x)>
             lev = _split_levels(Phi, Xs.shape[2], self._spec.num_levels)
             zf = _tensor_features(Zs, self._spec.num_levels, increments, self._spec.base == "cosine")
@@ -1003,7 +1017,7 @@ class SignatureKernelModule(torch.nn.Module):
     def _tvs_weighted(self, Zs, Xs, fac, increments):
         if self.matrix_route or self._lr is not None:
             return (self._tvs_levels(Zs, Xs, increments) * fac[:, None, :]).sum(dim=0)
-        Phi = self._phi(Xs)
+        Phi = self._phi(Xs, self._tvs_work(Zs, Xs))
         if Phi is not None:             # sum_m fac[m][n] <Z_m[t], Phi_m[n]>: the factors go onto the features, no level arrays
             # ONE product of depth ld (the library's per-level GEMMs of depth d, d^2 run at the speed of the widest): level 0 (= 1 on both sides)
             # rides along as the column it has in the feature buffer, whose zero padding keeps the rows 16-aligned
@@ -1108,10 +1122,9 @@ class SignatureKernelModule(torch.nn.Module):
         if (self.sum_route and not return_levels and not self.kern.low_rank and not self.matrix_route and lr is None
                 and self._spec.base in ("linear", "cosine") and Xs.is_cuda and not torch.cuda.is_current_stream_capturing()):
             # the linear / cosine kernel's level sum and its gradient as one op through the feature space (no level arrays)
-            w = self._w()
-            wh = _SeqGramSum.weights_on_host(w)
-            if _SeqGramSum.applies(Xs, X2s, wh, self._spec, self.kern.normalization):
-                return _SeqGramSum.apply(Xs, X2s, w, wh, self._spec, self.kern.normalization)
+            if _SeqGramSum.applies(Xs, X2s, self._spec, self.kern.normalization):
+                w = self._w()
+                return _SeqGramSum.apply(Xs, X2s, w, _SeqGramSum.weights_on_host(w), self._spec, self.kern.normalization)
         if X2 is None:
             self._lr_open(lr, Xs)
             K = self._seq_levels(Xs)
@@ -1155,6 +1168,7 @@ class SignatureKernelModule(torch.nn.Module):
         Xs = self.scale_sequences(self._seq3(X, presliced))
         Zs0 = self.scale_tensors(Z)
         self._lr_open(lr, Zs0, Xs)
+        self._phi(Xs, self._tvs_work(Zs0, Xs))                                                      # (so that the level diagonals share the feature sweep)
         if not return_levels:
             # the same numbers with the level sum taken inside the kernel: (M+1, N) factors in, (T, N) out
             fac = self._w()[:, None].expand(-1, Xs.shape[0])                                        # :584
@@ -1173,6 +1187,7 @@ class SignatureKernelModule(torch.nn.Module):
         N = Xs.shape[0]
         Zs = self.scale_tensors(Z)
         self._lr_open(lr, Zs, Xs)
+        self._phi(Xs, self._tvs_work(Zs, Xs))                                                       # (so that the level diagonals share the feature sweep)
         Kzz = self._tens_levels(Zs, increments)                                                     # :623
         w = self._w()
         if not return_levels:
@@ -1228,8 +1243,9 @@ class SignatureKernelModule(torch.nn.Module):
         # linear / cosine kernel, level sum wanted: Kxx2 = sum_m facz[m][t] facx[m][n] <Phi_m(z_t), Phi_m(x_n)> as ONE product of scaled level features
         Pz = Px = None
         if not return_levels:
-            Pz = self._phi(Xs)
-            Px = self._phi(X2s) if Pz is not None else None
+            work = float(N) * N2 * Xs.shape[1] * X2s.shape[1] * Xs.shape[2]                        # pairs x lattice cells x columns
+            Pz = self._phi(Xs, work)
+            Px = self._phi(X2s, work) if Pz is not None else None
         by_features = Px is not None
         Kxx2 = None if by_features else self._seq_levels(Xs, X2s)
         facz, facx = w[:, None].expand(-1, N), None

@@ -331,13 +331,12 @@ def test_level_sum_op_is_the_route_taken_and_can_be_declined():
     N, L, d, M = 256, 32, 4, 4
     X = torch.tensor(np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1), device=dev)
     spec = autodiff._Spec("linear", M, True)
-    wh = np.ones(M + 1)
-    assert autodiff._SeqGramSum.applies(X, None, wh, spec, True)
-    assert autodiff._SeqGramSum.applies(X, X[:100, :20].contiguous(), wh, spec, False)
-    assert not autodiff._SeqGramSum.applies(X, None, wh, autodiff._Spec("rbf", M, True), True)
+    assert autodiff._SeqGramSum.applies(X, None, spec, True)
+    assert autodiff._SeqGramSum.applies(X, X[:100, :20].contiguous(), spec, False)
+    assert not autodiff._SeqGramSum.applies(X, None, autodiff._Spec("rbf", M, True), True)
     try:
         dctx.set_option("sig_features_grad", 0)
-        assert not autodiff._SeqGramSum.applies(X, None, wh, spec, True)
+        assert not autodiff._SeqGramSum.applies(X, None, spec, True)
     finally:
         dctx.set_option("sig_features_grad", -1)
     # at this size: value and gradient against the level route, planner's choice
@@ -415,7 +414,7 @@ def test_inducing_tensor_covariances_through_the_level_features(base, normalizat
     assert autodiff._SigFeatures.ld(mod._spec, de, L) > 0            # the route under test is the one the module takes
 
     def run(feature_route):
-        mod.feature_route = feature_route
+        mod.feature_route = "always" if feature_route else False       # (True would ask a work threshold these small shapes do not reach)
         mod.zero_grad()
         Zt, Xt = torch.tensor(Z, device=dev, requires_grad=True), torch.tensor(X, device=dev, requires_grad=True)
         l = loss(mod, Zt, Xt, lambda a: torch.tensor(a, device=dev))
@@ -438,11 +437,23 @@ def test_inducing_tensor_covariances_through_the_level_features(base, normalizat
         assert rel(feat[3][n], rec[3][n]) < 1e-7, (n, feat[3][n], rec[3][n])
     # return_levels through the same features
     with torch.no_grad():
+        mod.feature_route = "always"
         a = mod.K_tens_vs_seq(torch.tensor(Z, device=dev), torch.tensor(X, device=dev), return_levels=True, increments=increments)
         mod.feature_route = False
         b = mod.K_tens_vs_seq(torch.tensor(Z, device=dev), torch.tensor(X, device=dev), return_levels=True, increments=increments)
         mod.feature_route = True
     assert rel(a, b) < 1e-10
+    # the default (True) takes the route by the recursion kernels' work: not at this size, yes with the threshold lowered
+    mod.feature_route = True
+    mod.K_tens_vs_seq(torch.tensor(Z, device=dev), torch.tensor(X, device=dev), increments=increments)
+    assert (mod._phi(torch.tensor(X, device=dev).reshape(N, L, d), 1.0) is None) == (order == 1)      # (order > 1: at every size)
+    mod._phi_memo = None
+    saved, mod.feature_route_min_work = mod.feature_route_min_work, 0.0
+    try:
+        assert mod._phi(mod.scale_sequences(mod._seq3(torch.tensor(X, device=dev), False)), 1.0) is not None
+    finally:
+        mod.feature_route_min_work = saved
+        mod._phi_memo = None
 
 
 @pytest.mark.parametrize("base,difference", [("rbf", True), ("poly", True), ("matern32", False)])
@@ -1091,7 +1102,7 @@ def test_inducing_sequence_covariances_through_the_level_features(base, normaliz
         W = [torch.tensor(rng.standard_normal(sh), device=dev) for sh in ((T, T), (T, N), (N, N) if full else (N,))]
         res = {}
         for route in (True, False):
-            mod.feature_route = route
+            mod.feature_route = "always" if route else False
             mod.zero_grad()
             Zg, Xg = torch.tensor(Zs, device=dev, requires_grad=True), torch.tensor(X, device=dev, requires_grad=True)
             out = mod.K_seq_n_seq_covs(Zg, Xg, full_X2_cov=full)
