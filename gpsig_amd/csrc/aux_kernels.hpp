@@ -141,9 +141,11 @@ __global__ void factors_kernel(const T* __restrict__ dlev, int64_t N, int M1, co
     for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
         const int m = int(idx % M1);
         const T wm = w ? T(w[m]) : T(1);
+        // (K_m(x, x) >= 0; a float32 higher-order recursion can return a slightly negative one for a sequence whose level values cancel
+        // from 1e8 to 10 -- the fuzz sweep's case 153, round 4 -- and sqrt of that is a NaN column where the float64 result is finite: clamped)
         if (!dlev) fac[idx] = wm;
-        else if (squared) { const T s = sqrt(dlev[idx] + T(jitter)); fac[idx] = wm / s / s; }
-        else fac[idx] = wm / sqrt(dlev[idx] + T(jitter));
+        else if (squared) { const T s = sqrt(fmax(dlev[idx], T(0)) + T(jitter)); fac[idx] = wm / s / s; }
+        else fac[idx] = wm / sqrt(fmax(dlev[idx], T(0)) + T(jitter));
     }
 }
 

@@ -99,6 +99,12 @@ GPSIG_HD T spectral_eval(const double* __restrict__ tab, int Q, int family, int 
 // it (default 3): a small whole exponent is taken by repeated squaring -- three multiplications at most for p <= 8 against the ~150
 // instructions of the library's float64 pow, which made the polynomial kernel's evaluations 3-6 times the RBF kernel's (round 4:
 // tools/bench_train_paths.py); any other exponent goes to pow.  The branch is uniform: p is a kernel argument.
+// (The library pow stays OUT OF LINE: inlined into the kernels that switch over the base kernel at run time it had been their register hog --
+// seq_gram_kernel<double, 16, 2, 4, 8> 159 registers with it, 193 once this helper joined it: three wavefronts per SIMD -> two -- and a
+// one-register cliff in the low-rank feature kernel)
+template <typename T>
+GPSIG_HD __attribute__((noinline)) T poly_pow_general(T b, T p) { return pow(b, p); }
+
 template <typename T>
 GPSIG_HD T poly_pow(T b, T p) {
     const int n = int(p);
@@ -110,7 +116,7 @@ GPSIG_HD T poly_pow(T b, T p) {
         if (n & 8) r *= x * x;
         return r;
     }
-    return pow(b, p);
+    return poly_pow_general(b, p);
 }
 
 // Static kernel on R^d from the inner product and the two squared norms (gpsig/kernels.py:765-781, 799-993).
