@@ -12,6 +12,9 @@ Not built (raise NotImplementedError, never a silent CPU fallback): ``SignatureS
 """
 import ctypes as C
 
+import sys as _sys
+import warnings as _warnings
+
 import numpy as np
 
 from . import _lib, low_rank as _lr
@@ -100,12 +103,13 @@ class GraphedCall:
         _lib.release(dev.index or 0, self.stream.cuda_stream)      # the side stream's context belongs to this recording alone
 
     def __del__(self):
+        if _sys is None or _sys.meta_path is None or _sys.is_finalizing():
+            return                           # interpreter shutdown: the process gives the device back; modules this needs are already gone
         try:
             self.close()
         except Exception as e:               # not silently: a failed release leaks a context and its scratch buffers
-            import warnings
             try:
-                warnings.warn("GraphedCall: releasing a recorded evaluation failed: %r" % (e,), ResourceWarning)
+                _warnings.warn("GraphedCall: releasing a recorded evaluation failed: %r" % (e,), ResourceWarning)
             except Exception:
                 pass
 
