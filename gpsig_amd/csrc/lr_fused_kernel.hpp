@@ -30,18 +30,10 @@ namespace gpsig {
 
 // THREADS: workgroup size (the LDS footprint of a sequence does not depend on it, so more wavefronts per workgroup are more
 // wavefronts per CU to hide the scalar-load latency of the sketch entries behind); UNROLL: sketch entries per scalar-load batch.
-// The base kernel of the Nystrom cross matrix, with the polynomial kernel's power out of line.  The feature kernels below sit at exactly 128
-// registers = four wavefronts per SIMD = two workgroups per CU; the repeated-squaring helper round 4 added to base_eval (seq_core.hpp: poly_pow),
-// inlined here, cost ONE more register and with it a workgroup per CU: BASELINE configs[2] in low-rank mode 2.8 -> 4.6 ms, unnoticed until the
-// round's last bench (asking for four waves with __launch_bounds__ gives a 120-register schedule that runs at 3.4).  tests/test_abi.py reads
-// the compiler's report.
-__device__ __noinline__ inline double lr_poly_out_of_line(double b, double p) { return poly_pow(b, p); }
-__device__ __forceinline__ double lr_base_eval(int kind, double ip, double xs, double ss, double p0, double p1) {
-    if (kind == BASE_POLY) return lr_poly_out_of_line(ip + p0, p1);
-    __builtin_assume(kind != BASE_POLY);
-    return base_eval<double>(kind, ip, xs, ss, p0, p1);
-}
-
+// (These kernels switch over the base kernel at run time and sit on occupancy steps -- lr_seq_features_fused2_kernel at four wavefronts per SIMD =
+// two workgroups per CU.  The repeated-squaring helper round 4 added to base_eval cost it ONE register and with it a workgroup per CU: BASELINE
+// configs[2] in low-rank mode 2.8 -> 4.6 ms, unnoticed until the round's last bench.  The library pow is out of line everywhere since
+// (seq_core.hpp: poly_pow_general); tests/test_abi.py reads the compiler's report for this kernel.)
 template <int THREADS, int UNROLL>
 __global__ __launch_bounds__(THREADS) void lr_seq_features_fused_kernel(LrFusedArgs A) {
     extern __shared__ double lr_lds[];
@@ -79,7 +71,7 @@ __global__ __launch_bounds__(THREADS) void lr_seq_features_fused_kernel(LrFusedA
                         ip = fma(bufB[fe * lp + t], y, ip);
                         ss = fma(y, y, ss);
                     }
-                    bufA[i * lp + t] = lr_base_eval(A.kind, ip, xs, ss, A.p0, A.p1);
+                    bufA[i * lp + t] = base_eval<double>(A.kind, ip, xs, ss, A.p0, A.p1);
                 }
             }
         }
@@ -209,7 +201,7 @@ __global__ __launch_bounds__(THREADS) void lr_seq_features_fused2_kernel(LrFused
                     ip = fma(U[fe * lp + t], y, ip);
                     ss = fma(y, y, ss);
                 }
-                W[i * lp + t] = lr_base_eval(A.kind, ip, xs, ss, A.p0, A.p1);
+                W[i * lp + t] = base_eval<double>(A.kind, ip, xs, ss, A.p0, A.p1);
             }
         }
         __syncthreads();
@@ -337,7 +329,7 @@ __global__ __launch_bounds__(LR_TENS_THREADS) void lr_tens_features_fused_kernel
             const double x = zs[row * d_eff + fe], y = A.S[size_t(i) * d_eff + fe];
             ip = fma(x, y, ip); xs = fma(x, x, xs); ss = fma(y, y, ss);
         }
-        kx[q] = lr_base_eval(A.kind, ip, xs, ss, A.p0, A.p1);
+        kx[q] = base_eval<double>(A.kind, ip, xs, ss, A.p0, A.p1);
     }
     __syncthreads();
     for (int q = threadIdx.x; q < rows * c; q += LR_TENS_THREADS) {

@@ -131,8 +131,8 @@ def test_headline_kernel_keeps_three_wavefronts_per_simd(tmp_path):
 def test_low_rank_feature_kernel_keeps_four_wavefronts_per_simd(tmp_path):
     """lr_seq_features_fused2_kernel<512, 8> (low-rank mode's feature map of a batch of sequences): 8 wavefronts per workgroup, so four per
     SIMD = two workgroups per CU.  It sat at exactly 128 registers; one more (the repeated-squaring helper round 4 added to base_eval, inlined)
-    left one workgroup per CU and took BASELINE configs[2] in low-rank mode from 2.8 to 4.6 ms unnoticed.  The polynomial kernel's power is out
-    of line there now (116 registers; 2.75 ms); this reads the compiler's report."""
+    left one workgroup per CU and took BASELINE configs[2] in low-rank mode from 2.8 to 4.6 ms unnoticed.  The library pow is out of line in every
+    kernel since (seq_core.hpp: poly_pow_general; 117 registers here, 2.75 ms); this reads the compiler's report."""
     import re
     import shutil
     import subprocess

@@ -15,7 +15,7 @@ for cfg in "c2 --lattice" "c2 --base rbf" "c3" "c3 --increments" "c3 --base line
   timeout 600 python bench.py --config $cfg --no-cpu-baseline > $O/bench_$tag.json 2> $O/bench_$tag.err
 done
 timeout 900 python bench.py --config c4 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c4_1gpu.json 2> $O/bench_c4_1gpu.err
-for cfg in "c2" "c2 --lattice" "c2 --base rbf" "c3" "c3 --increments" "c5"; do
+for cfg in "c2" "c2 --lattice" "c2 --base rbf" "c3" "c3 --increments" "c3 --base linear" "c5"; do
   tag=$(echo $cfg | tr -d ' -')
   : > $O/pmc_$tag.txt
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F64"; do
@@ -37,3 +37,5 @@ for cfg in "c3 --verify" "c2 --verify"; do timeout 600 python tools/bench_lr.py 
 timeout 600 python tools/bench_grad.py > $O/bench_grad.txt 2>&1
 timeout 300 python tools/bench_host_e2e.py > $O/bench_host_e2e.txt 2>&1
 timeout 600 python tools/bench_rank_share.py > $O/bench_rank_share.txt 2>&1
+timeout 300 bash tools/gpu_sum_route.sh > $O/sum_route.log 2>&1
+BENCH_GRAD_BASES=linear GPSIG_FEATURE_ROUTE=0 timeout 300 python tools/bench_grad.py b 2>&1 | grep "(b)" > $O/bench_grad_c3_linear_recursion.txt
