@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of library builds on configs[2] (GPSIG_LIB), alternating processes: tools/gpu_ab_c3.sh libgpsig_hip_X.so
+cd "$(dirname "$0")/.."
+for rnd in 1 2 3; do
+  for cfg in "c3" "c3 --increments"; do
+    for lib in default "$@"; do
+      if [ $lib = default ]; then unset GPSIG_LIB; else export GPSIG_LIB=$PWD/gpsig_amd/lib/$lib; fi
+      python bench.py --config $cfg --steps 20 --warmup 3 --no-cpu-baseline --no-traffic 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('round $rnd  $cfg  lib=$lib  kernel ms %.3f  ms/step %.3f  rel_err %.2e  clock %.2f' % (d['roofline']['kernel_ms_per_launch'], d['ms_per_step'], d['rel_err'], d['clock_ghz']))"
+    done
+  done
+done
