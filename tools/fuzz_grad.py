@@ -1,7 +1,8 @@
 """Randomised sweep of the gradient path against torch.autograd of the differentiable oracle (run on a GPU box):
     python tools/fuzz_grad.py [cases] [seed]
 FUZZ_ORDER=1 also draws the algorithm's order (1 .. num_levels); GPSIG_OPTIONS="sig_features_grad=1" sends the linear / cosine kernel's
-K(X), K(X, X2) through the feature space (the one-op level sum, gpsig_kernel_K_grad) at these small sizes too."""
+K(X), K(X, X2) through the feature space (the one-op level sum, gpsig_kernel_K_grad) at these small sizes too; FUZZ_FEATURES=1 does the same for
+the training path's level-feature route of Kzx and the level diagonals (SignatureKernelModule.feature_route = "always")."""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -36,6 +37,8 @@ def main():
             kern = CLASS[base](max(L1, L2) * d, d, M, normalization=norm, difference=diff, num_lags=lags or None, order=order,
                                lengthscales=rng.uniform(0.8, 1.6, d), variances=rng.uniform(0.5, 1.5, M + 1))
             mod = autodiff.SignatureKernelModule(kern, device=dev)
+            if os.environ.get("FUZZ_FEATURES"):
+                mod.feature_route = "always"        # the linear / cosine kernel's Kzx and level diagonals through the level features at these sizes too
             leaf = lambda t: None if t is None else t.detach().cpu().clone().requires_grad_(True)
             orc = OT.SignatureKernelTorchOracle(d, M, base, variances=leaf(mod.variances), sigma=leaf(mod.sigma), lengthscales=leaf(mod.lengthscales),
                                                 normalization=norm, difference=diff, num_lags=lags, lags=leaf(mod.lags) if lags else None,
