@@ -25,7 +25,7 @@ measured by two rocprofv3 --pmc passes of this very command), `clock_ghz` (the s
 on the device), `cpu_baseline` (the oracle's op-for-op restatement of the reference's TF graph on the host cores, bounded
 sample), `rel_err` (a sub-sample of the timed output against the oracle, outside the timed region),
 `end_to_end_ms_host_pointers` (the same evaluation from and to host memory: H2D + compute + D2H) and, on the default
-single-GPU line, `secondary`: the other single-GPU configurations (c2 through the pair recursion, c2 at order 5, c2 RBF, c3, c3 with increments, c5), 3 warm-up + 10 steps each.
+single-GPU line, `secondary`: the other single-GPU configurations (c2 through the pair recursion, c2 at order 5, c2 RBF, c3, c3 with increments, c3 with SignatureLinear, c5), 3 warm-up + 10 steps each.
 
 --gpus N > 1 without a torchrun environment launches the N ranks itself (python -m torch.distributed.run, one process per
 GPU, rendezvous on 127.0.0.1) and fails when the node has fewer than N GPUs: a line with "n_gpus": N was computed by N ranks,
@@ -651,7 +651,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
 
 
 SECONDARY = [("c2", "linear", False, True, 1), ("c2", "linear", False, False, 5), ("c2", "rbf", False, False, 1), ("c3", "rbf", False, False, 1),
-             ("c3", "rbf", True, False, 1), ("c5", "rbf", False, False, 1)]
+             ("c3", "rbf", True, False, 1), ("c3", "linear", False, False, 1), ("c5", "rbf", False, False, 1)]
 
 
 def secondary_lines(dev):

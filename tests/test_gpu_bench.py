@@ -70,7 +70,7 @@ def test_default_line_carries_the_measurement():
     assert "sig_gram_dma_kernel" in rf["traffic_source"]["kernel"]
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     names = [s["name"] for s in line["secondary"]]
-    assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c5-rbf",
+    assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c3-linear", "c5-rbf",
                      "grad-c2shape-n1024-linear", "grad-c2shape-n1024-linear-level-primitives", "grad-c2shape-n1024-linear-pair-kernels",
                      "grad-c2shape-n1024-rbf"]
     ho = line["secondary"][1]                           # the higher-order algorithm at order = num_levels: the same contraction, the same time
@@ -82,7 +82,9 @@ def test_default_line_carries_the_measurement():
         assert s["ms_per_step"] > 0
         if not s["name"].startswith("grad-"):
             assert s["rel_err"] <= (1e-4 if s["dtype"] == "f32" else 1e-6) and s["clock_ghz"] > 1.0
-    c5 = line["secondary"][5]                           # configs[4]: priced as issue-bound from its counters (round 4)
+    c3l = line["secondary"][5]                          # configs[2] with SignatureLinear: Kzx as one product of level features (round 4)
+    assert c3l["bound"] == "mfma" and c3l["ms_per_step"] < line["secondary"][3]["ms_per_step"]
+    c5 = line["secondary"][6]                           # configs[4]: priced as issue-bound from its counters (round 4)
     assert c5["bound"] == "valu-issue" and 0.5 < c5["issue_frac"] <= 1.1
     g = {s["name"]: s["ms_per_step"] for s in line["secondary"] if s["name"].startswith("grad-")}
     # the linear kernel's reverse pass through the feature contraction: several times faster than through the pair kernels
