@@ -1511,7 +1511,9 @@ static int tens_vs_seq_features_device(gpsig_ctx* c, const gpsig_params* p, cons
     A.w = static_cast<const double*>(w2); A.normalize = p->normalization ? 1 : 0; A.jitter = p->jitter; A.Phi = static_cast<double*>(phi); A.ld = ld;
     A.dlev = nullptr; A.order = p->order; A.unit_points = cosine ? 1 : 0; A.norm_squared = 0; A.natural_order = 1;
     {
-        hipError_t e = ffn(A, unsigned(N < 4096 ? N : 4096), sig_features_lds_bytes(d, M, L), c->stream);
+        // (workgroups of one or two wavefronts -- small d^M -- are latency-bound at 16 per CU: up to 16,384 of them; 0.667 -> 0.647 ms at configs[2])
+        const int64_t cap = sig_threads(d, M) <= 128 ? 16384 : 4096;
+        hipError_t e = ffn(A, unsigned(N < cap ? N : cap), sig_features_lds_bytes(d, M, L), c->stream);
         if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL(tens_level_features_kernel, dim3(grid_for(Tn * ld)), dim3(256), 0, c->stream, static_cast<const double*>(ZT),
