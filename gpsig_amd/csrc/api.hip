@@ -791,7 +791,8 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
         A.order = p->order;
         A.unit_points = cosine ? 1 : 0;
         A.norm_squared = squared ? 1 : 0;
-        const unsigned grid = unsigned(N < 4096 ? N : 4096);
+        const int64_t cap = sig_threads(d, M) <= 128 ? 16384 : 4096;      // (one- or two-wavefront workgroups are latency-bound at 16 per CU)
+        const unsigned grid = unsigned(N < cap ? N : cap);
         hipError_t e = ffn(A, grid, sig_features_lds_bytes(d, M, L), c->stream);
         if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
         return GPSIG_OK;

@@ -59,7 +59,8 @@ static int sig_launch_features(gpsig_ctx* c, SigFeatLaunchFn ffn, const gpsig_pa
     A.X = Xs; A.N = N; A.L = L; A.difference = p->difference ? 1 : 0; A.P = sp;
     A.w = nullptr; A.normalize = 0; A.jitter = 0.0; A.Phi = phi; A.ld = ld; A.dlev = dlev;
     A.order = order; A.natural_order = 1; A.unit_points = cosine ? 1 : 0;
-    hipError_t e = ffn(A, unsigned(N < 4096 ? N : 4096), sig_features_lds_bytes(d, M, L), c->stream);
+    const int64_t cap = sig_threads(d, M) <= 128 ? 16384 : 4096;      // (one- or two-wavefront workgroups are latency-bound at 16 per CU)
+    hipError_t e = ffn(A, unsigned(N < cap ? N : cap), sig_features_lds_bytes(d, M, L), c->stream);
     if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "sig_features_kernel: %s", hipGetErrorString(e));
     return GPSIG_OK;
 }
