@@ -260,3 +260,44 @@ def test_committed_low_rank_fixtures_match_oracle(golden_lowrank):
         for k in c["outputs"]:
             want = arr[f"{n}/out/{k}"]
             assert np.abs(got[k] - want).max() <= 1e-11 * np.abs(want).max(), (n, k)
+
+
+def test_higher_order_levels_of_a_one_column_sequence_are_better_conditioned_as_features():
+    """Why a float64 outlier of the randomised sweep (profiles/r04_fuzz.txt, case 187: d = 1, 32 steps, order 3, normalised) is the ORACLE's: the
+    pair recursion (signature_algs.py:37-74, restated op for op) sums products over index tuples that cancel by many orders of magnitude for a
+    one-column sequence, the per-sequence truncated-exponential sweep (what the feature kernels run) does not.  Both against an 80-bit restatement
+    of the features: the float64 features stay within 1e-10 of it after the normalisation, the recursion is orders of magnitude further away."""
+    rng = np.random.default_rng(51)
+    N, L, M, order = 40, 33, 5, 3
+    X = np.cumsum(0.3 * rng.standard_normal((N, L, 1)), axis=1)
+
+    def feats(x, dt):
+        V = [dt(1)] + [dt(0)] * M
+        for v in np.diff(np.asarray(x, dtype=dt)):
+            new = list(V)
+            for m in range(1, M + 1):
+                acc, term = V[m], dt(1)
+                for k in range(1, min(order, m) + 1):
+                    term = term * v / dt(k)
+                    acc = acc + V[m - k] * term
+                new[m] = acc
+            V = new
+        return np.array(V, dtype=dt)
+
+    def gram(dt):
+        F = np.array([feats(x[:, 0], dt) for x in X])
+        K = np.zeros((N, N), dtype=dt)
+        for m in range(M + 1):
+            a = F[:, m]
+            s = np.sqrt(a * a + dt(1e-6))
+            Km = np.outer(a, a) + dt(1e-6) * np.eye(N, dtype=dt)
+            K += Km / np.outer(s, s)
+        return K.astype(np.float64)
+
+    ref, f64 = gram(np.longdouble), gram(np.float64)
+    ko = O.SignatureKernelOracle(L, 1, M, base="linear", order=order, normalization=True, lengthscales=None)
+    rec = ko.K(X.reshape(N, -1))
+    scale = np.abs(ref).max()
+    e_feat, e_rec = np.abs(f64 - ref).max() / scale, np.abs(rec - ref).max() / scale
+    assert e_feat < 1e-10                                     # (9e-13 on this draw)
+    assert 100.0 * e_feat < e_rec < 1e-2                      # (5e-8 on this draw, 1e-4 on the sweep's: the recursion's cancellation)
