@@ -285,12 +285,12 @@ def rank_identity(rank, local_rank, dev_index, backend):
     return ent
 
 
-# ---- HBM traffic of the dominant kernel: two rocprofv3 --pmc passes of this command (MI355X_MICROARCH.md, "HBM") ------------
-def measure_traffic(cfg, base, increments, timeout_s=240):
-    """FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots) and never ride with a trace; each pass runs
-    `bench.py --config ... --steps 2 --warmup 1` with nothing but the timed loop.  FETCH_SIZE is doubled (gfx950 tallies the
-    128-byte requests of 16-byte-per-lane loads at 64 bytes; every read of these kernels is such a load or an LDS-DMA of that
-    width), WRITE_SIZE is taken as is (KiB both).  Returns None where rocprofv3 is missing or already wraps this process."""
+# ---- counters of the dominant kernel: rocprofv3 --pmc passes of this command (MI355X_MICROARCH.md, "HBM" / "rocprofv3 PMC slots") ------------
+def measure_pmc(cfg, base, increments, counters, lattice=False, timeout_s=240):
+    """One rocprofv3 --pmc pass per counter (FETCH_SIZE and WRITE_SIZE cannot share a pass -- TCC slots -- and a pass never rides with a
+    trace) of `bench.py --config ... --steps 2 --warmup 1 --timed-loop-only`.  Returns {counter: median over the dominant kernel's
+    dispatches (summed over the counter's instances), "kernel", "grid", "dispatches"}, or None where rocprofv3 is missing or already
+    wraps this process."""
     import shutil
     import sqlite3
     import subprocess
@@ -300,10 +300,10 @@ def measure_traffic(cfg, base, increments, timeout_s=240):
         return None
     got = {}
     meta = None
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in counters:
         tmp = tempfile.mkdtemp(prefix="gpsig_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--config", cfg, "--base", base,
-               "--steps", "2", "--warmup", "1", "--timed-loop-only"] + (["--increments"] if increments else [])
+               "--steps", "2", "--warmup", "1", "--timed-loop-only"] + (["--increments"] if increments else []) + (["--lattice"] if lattice else [])
         try:
             pr = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True,
                                   env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
@@ -336,23 +336,25 @@ def measure_traffic(cfg, base, increments, timeout_s=240):
             return None
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
+    got.update({"kernel": meta[0], "grid": meta[1], "dispatches": meta[2]})
+    return got
+
+
+def measure_traffic(cfg, base, increments, lattice=False):
+    """HBM traffic of the dominant kernel.  FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of 16-byte-per-lane loads at 64
+    bytes; every read of these kernels is such a load or an LDS-DMA of that width), WRITE_SIZE is taken as is (KiB both)."""
+    got = measure_pmc(cfg, base, increments, ("FETCH_SIZE", "WRITE_SIZE"), lattice)
+    if not got:
+        return None
     return {"fetch_size_kib": got["FETCH_SIZE"], "write_size_kib": got["WRITE_SIZE"],
             "bytes_per_launch": got["FETCH_SIZE"] * 2.0 * 1024.0 + got["WRITE_SIZE"] * 1024.0,
-            "kernel": meta[0], "grid": meta[1], "dispatches": meta[2]}
+            "kernel": got["kernel"], "grid": got["grid"], "dispatches": got["dispatches"]}
 
 
-# vector instructions per wave-step of the dominant kernels; float64 and DPP instructions take a SIMD's issue port for 4 cycles per
-# wave64 instruction.  issue_frac = how much of the SIMDs' issue time the kernel's vector instructions fill at the clock measured
-# during the run.  Counts are what the kernels EXECUTE -- SQ_INSTS_VALU / wave-steps of profiles/r04_pmc_c2lattice.txt (1.33606e10 /
-# 1.3425e8), r04_pmc_c2rbf.txt (2.43674e10 / 1.3425e8) --, i.e. the inner loop of the disassembly (89 / 174 per step, what rounds 2-3
-# priced) plus the pair-boundary blocks, prologue and epilogue amortised over a pair's 64 steps.
-VALU_PER_STEP = {("c2", "linear"): 99.5, ("c4", "linear"): 99.5, ("c2", "rbf"): 181.5, ("c4", "rbf"): 181.5,
-                 # configs[4], seq_pk2_kernel<f2, 4, 64, 2, 16, 6>: SQ_INSTS_VALU / wave-steps of profiles/r04_pmc_c5.txt (1.589e10 / 1.343e8; the
-                 # pair-boundary blocks included); SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.04 issue slots of 4 cycles per instruction there
-                 ("c5", "rbf"): 118.4}
-# configs[2]: the tile kernel's vector instructions per LAUNCH at this exact shape (SQ_INSTS_VALU of profiles/r04_pmc_c3.txt / r04_pmc_c3incr.txt,
-# tvs_tile_kernel<4, 2, 6, false | true, 1>, grid 524,288: the count does not depend on the data); SQ_ACTIVE_INST_VALU equals it
-VALU_PER_LAUNCH = {("c3", "rbf", False): 1.40617e9, ("c3", "rbf", True): 2.58674e9}
+# issue_frac = how much of the SIMDs' issue time the dominant kernel's vector instructions fill at the clock measured during the run: float64
+# and DPP instructions take a SIMD's issue port for 4 cycles per wave64 instruction.  The instruction count is MEASURED BY THE RUN (round 5): one
+# rocprofv3 --pmc SQ_INSTS_VALU pass of the same command (measure_pmc), so a kernel change cannot leave a stale constant behind (rounds 2-4
+# priced the kernels with counts typed in from one profile pass).  No pass (rocprofv3 missing, already profiled, N > 1): issue_frac is null.
 PAIRS_PER_WAVE = {"c5": 2}               # seq_pk2_kernel at G = 64: one pair group per wavefront, two y sequences packed (default 4: G = 16)
 SIMDS = 1024
 
@@ -378,7 +380,7 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6          # MI355X_MICROARCH.md: dense float64 MFM
 
 
 def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chunks=4, weak=False, checks=True, host_e2e=True,
-                 traffic="measure", lattice=False, order=1):
+                 traffic="measure", lattice=False, order=1, issue_src="measure"):
     """Times `steps` evaluations of one BASELINE configuration on this rank's device (inputs resident in HBM) and returns the
     bench-line fields on rank 0 (None elsewhere)."""
     import torch
@@ -457,10 +459,17 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     timed_kernel, mfma_flops = ctx.timing_info()   # "sig_gram_dma_kernel" + its matrix-core flops when the feature contraction ran
     ctx.set_option("sig_features", -1)
 
+    rank_times = None
     if world > 1:
         tt = torch.tensor([dt, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, per_launch_ms = float(tt[0].item()), float(tt[1].item())
+        # where the LAST step's time went on every rank (ShardedGram.timings: stream time of its chunks' kernels, of the waits for the
+        # gathers, of rank 0's symmetrisation) -- so that a scaling curve says whether balance or the gather bends it
+        mine = gram.timings() if gram is not None else None
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        rank_times = gathered
     else:
         per_launch_ms = kernel_ms / max(launches, 1)
     launches_per_step = launches / max(steps, 1)
@@ -483,16 +492,18 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     alu_frac = tflops_exec / alu_peak
     ghz = clock["mean"] if clock else None
     issue = None
-    vps = VALU_PER_STEP.get((cfg, base)) if timed_kernel is None else None
-    if vps and ghz:
-        pairs_per_wave = PAIRS_PER_WAVE.get(cfg, 4)                  # G = 16: four pair groups per wavefront
-        wave_steps = evaluated_launch / pairs_per_wave * L           # L lattice rows (L - 1 increments + the boundary row) per pair
-        # (a value a per cent or two above 1 is the resolution of the clock probe -- eight sampling wavefronts, one per XCD -- not a faster chip)
-        issue = {"valu_per_wave_step": vps, "cycles_per_valu": 4, "wave_steps_per_launch": wave_steps, "simds": SIMDS,
-                 "issue_frac": wave_steps * vps * 4.0 / (SIMDS * ghz * 1e9 * per_launch_ms * 1e-3)}
-    vpl = VALU_PER_LAUNCH.get((cfg, base, bool(increments))) if timed_kernel is None else None
-    if vpl and ghz and launches:
-        issue = {"valu_per_launch": vpl, "cycles_per_valu": 4, "simds": SIMDS, "issue_frac": vpl * 4.0 / (SIMDS * ghz * 1e9 * per_launch_ms * 1e-3)}
+    if issue_src == "measure" and timed_kernel is None and n_gpus == 1 and cfg != "c4" and ghz and launches:
+        m = measure_pmc(cfg, base, increments, ("SQ_INSTS_VALU",), lattice)
+        if m:
+            vpl = m["SQ_INSTS_VALU"]
+            issue = {"valu_per_launch": vpl, "cycles_per_valu": 4, "simds": SIMDS,
+                     "issue_frac": vpl * 4.0 / (SIMDS * ghz * 1e9 * per_launch_ms * 1e-3),
+                     "source": "measured by this run: rocprofv3 --pmc SQ_INSTS_VALU, median over the dispatches of %s (grid %d)" % (m["kernel"], m["grid"])}
+            if not T:
+                pairs_per_wave = PAIRS_PER_WAVE.get(cfg, 4)              # G = 16: four pair groups per wavefront
+                wave_steps = evaluated_launch / pairs_per_wave * L       # L lattice rows (L - 1 increments + the boundary row) per pair
+                issue["wave_steps_per_launch"] = wave_steps
+                issue["valu_per_wave_step"] = vpl / wave_steps           # (pair-boundary blocks, prologue and epilogue amortised over the steps)
     if T:
         bound = "valu-issue"
         binding = ("vector issue: the table-driven exps of the base kernel (10 per step and wave with increments) and the chain FMAs; the sequence "
@@ -554,7 +565,7 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
     tr, tr_src = None, None
     key = ("c2" if cfg == "c4" else cfg) + "_" + base + ("_increments" if increments else "") + ("_features" if mfma else "")
     if traffic == "measure" and n_gpus == 1 and cfg != "c4":
-        m = measure_traffic(cfg, base, increments)
+        m = measure_traffic(cfg, base, increments, lattice)
         if m:
             tr = m["bytes_per_launch"]
             tr_src = {"how": "measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, of `bench.py --config %s --base %s%s "
@@ -611,6 +622,14 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
                              "reference_flops_per_pair": f_ref,
                              "reference_flops_frac": (pairs_launch * f_ref / (per_launch_ms * 1e-3) / 1e12) / alu_peak}},
     }
+    if rank_times and all(t is not None for t in rank_times):
+        comp = [t["compute_ms"] for t in rank_times]
+        res["per_rank"] = {"what": "the last timed step on every rank, ms of the stream it ran on: compute_ms = the row-block kernels of the rank's chunks, "
+                                   "gather_inline_ms = what the stream spent starting the gathers between chunks (asynchronous under RCCL), gather_wait_ms = "
+                                   "waiting for the gathers after the last chunk, symmetrise_ms = rank 0's pass from compact rows to the full matrix",
+                           "ranks": rank_times, "compute_ms_max": max(comp), "compute_ms_min": min(comp),
+                           "compute_max_over_min": (max(comp) / min(comp)) if min(comp) > 0 else None,
+                           "gather_wait_ms_rank0": rank_times[0]["gather_wait_ms"], "symmetrise_ms_rank0": rank_times[0]["symmetrise_ms"]}
     if not T:
         res["config"]["route"] = ("explicit level features + one float64 matrix-core contraction (the linear base kernel has a finite feature space: "
                                   "K_m(x, y) = <Phi_m(x), Phi_m(y)>, same numbers as the pair recursion to rounding; the recursion itself is the "
@@ -662,7 +681,7 @@ def secondary_lines(dev):
         try:
             r = run_workload(cfg, base, inc, 10, 3, dev, host_e2e=False, traffic="static", lattice=lattice, order=order)
             rf = r["roofline"]
-            out.append({"name": name, "workload": r["config"]["workload"], "dtype": r["dtype"], "value": r["value"], "unit": r["unit"],
+            out.append({"name": name, "workload": r["config"]["workload"], "issue_source": (rf["issue_model"] or {}).get("source"), "dtype": r["dtype"], "value": r["value"], "unit": r["unit"],
                         "ms_per_step": r["ms_per_step"], "kernel_ms": rf["kernel_ms_per_launch"] * rf["launches_per_step"],
                         "kernel": rf["kernel"], "bound": rf["bound"], "alu_frac": rf["alu_frac"], "issue_frac": rf["issue_frac"],
                         "stream_frac": rf["stream_frac"], "clock_ghz": r["clock_ghz"],
@@ -672,8 +691,23 @@ def secondary_lines(dev):
                         "traffic": rf["traffic"], "traffic_source": (rf["traffic_source"] or {}).get("how")})
         except Exception as e:                      # a side record never costs the headline its line
             out.append({"name": name, "error": repr(e)})
+    out.append(c4_single_gpu_line(dev))
     out.extend(gradient_lines(dev))
     return out
+
+
+def c4_single_gpu_line(dev):
+    """BASELINE configs[3] (N = 32,768) on ONE GPU: the same workload the N > 1 lines of a scaling series run, so that the series has an
+    N = 1 point of its own (the driver's N = 1 line is configs[1]).  1 warm-up + 3 steps of ~0.55 s."""
+    try:
+        r = run_workload("c4", "linear", False, 3, 1, dev, host_e2e=False, traffic="off", issue_src="off")
+        rf = r["roofline"]
+        return {"name": "c4-single-gpu", "workload": r["config"]["workload"], "dtype": r["dtype"], "value": r["value"], "unit": r["unit"],
+                "ms_per_step": r["ms_per_step"], "kernel_ms": rf["kernel_ms_per_launch"] * rf["launches_per_step"], "kernel": rf["kernel"],
+                "bound": rf["bound"], "alu_frac": rf["alu_frac"], "stream_frac": rf["stream_frac"], "clock_ghz": r["clock_ghz"], "rel_err": r["rel_err"],
+                "note": "the N = 1 point of the configs[3] scaling series: python bench.py --gpus N (N > 1) evaluates this very Gram sharded over N ranks"}
+    except Exception as e:
+        return {"name": "c4-single-gpu", "error": repr(e)}
 
 
 def gradient_lines(dev):
@@ -813,7 +847,8 @@ def main(argv=None):
     lean = args.timed_loop_only
     res = run_workload(cfg, base, args.increments, args.steps, args.warmup, dev, rank, world, chunks=args.chunks, weak=args.weak,
                        checks=not lean, host_e2e=not lean, lattice=args.lattice,
-                       traffic="off" if lean else ("static" if (args.no_traffic or args.lattice) else "measure"))
+                       traffic="off" if lean else ("static" if (args.no_traffic or args.lattice) else "measure"),
+                       issue_src="off" if (lean or args.no_traffic) else "measure")
     if rank == 0:
         res["ranks_seen"] = seen
         if cpu is not None:

@@ -25,7 +25,7 @@
 #include "sig_feat_kernel.hpp"
 
 namespace gpsig {
-typedef hipError_t (*TvsTileLaunchFn)(const TvsTileArgs&, size_t, hipStream_t);
+typedef hipError_t (*TvsTileLaunchFn)(TvsTileArgs&, size_t, hipStream_t, int);
 TvsTileLaunchFn tvs_tile_lookup(int M, int NW, int D, bool incr, int kind);
 int tvs_tile_width(int d);
 bool seq_pk2_select(int rows, int d, int M, int* G, int* C, int* D);
@@ -1416,36 +1416,33 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     const int NW = c->tvs_tile_nw > 0 ? c->tvs_tile_nw : tvs_tile_waves(M, D, E, kind);
     TvsTileLaunchFn fn = NW > 0 ? tvs_tile_lookup(M, NW, D, E == 2, kind) : nullptr;
     if (!fn) return GPSIG_OK;
-    const int rec_elems = (L * D + L + TVS_REC_ALIGN - 1) / TVS_REC_ALIGN * TVS_REC_ALIGN;
+    const int RS = tvs_row_stride(D);
     const bool sum_levels = !(raw || return_levels);
-    const size_t lds = tvs_tile_lds_bytes(M, NW, rec_elems, sum_levels, E == 2);
+    const size_t lds = tvs_tile_lds_bytes(M, NW, sum_levels, E == 2);
     if (lds > 64 * 1024) return GPSIG_OK;
     const int64_t Tpad = (Tn + 63) / 64 * 64, TB = Tpad / 64;
-    // sequences per workgroup: whole tiles of 16 once there are enough workgroups to fill the chip a few times over
-    int64_t runs = 4096 / TB < 1 ? 1 : 4096 / TB;
-    if (runs > N) runs = N;
-    int64_t run = (N + runs - 1) / runs;
-    if (run >= TVS_TILE_S) run = (run + TVS_TILE_S - 1) / TVS_TILE_S * TVS_TILE_S;
-    if (run > 4 * TVS_TILE_S) run = 4 * TVS_TILE_S;
-    if ((N + run - 1) / run > 65535) return GPSIG_OK;
+    if (N > (int64_t(1) << 30)) return GPSIG_OK;                          // (the item counters are 32-bit)
     const double pre = kind == BASE_RBF ? tvs_rbf_prescale(E == 2) : 1.0;
     const int rows_are_increments = kind == BASE_LINEAR && p->difference;
     void *zl, *zn, *xr;
     CHK(ensure(c, B_ZL, sizeof(double) * size_t(lt) * E * D * Tpad + 8, &zl));
     CHK(ensure(c, B_ZN, sizeof(double) * size_t(lt) * E * Tpad + 8, &zn));
-    CHK(ensure(c, B_XT, sizeof(double) * size_t(N) * rec_elems + 8, &xr));
+    const int64_t nrows = N * int64_t(L) + 1;                             // (one row behind the last sequence: the sweep asks one row ahead)
+    CHK(ensure(c, B_XT, sizeof(double) * size_t(nrows) * RS + 64, &xr));
+    void* tq;
+    CHK(ensure(c, B_TQ, sizeof(int32_t) * size_t(TB) + 8, &tq));
     hipLaunchKernelGGL(prep_tensors_tile_kernel, dim3(grid_for(Tpad * lt * E)), dim3(256), 0, c->stream,
                        static_cast<const double*>(Zdev), lt, Tn, Tpad, increments ? 2 : 1, collapse ? 1 : 0, pre, s, D,
-                       static_cast<double*>(zl), static_cast<double*>(zn));
+                       static_cast<double*>(zl), static_cast<double*>(zn), static_cast<int32_t*>(tq));
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(prep_seq_tile_records_kernel, dim3(grid_for(N * int64_t(rec_elems))), dim3(256), 0, c->stream,
-                       static_cast<const double*>(X), N, L, s, pre, rows_are_increments, D, rec_elems, static_cast<double*>(xr));
+    hipLaunchKernelGGL(prep_seq_tile_rows_kernel, dim3(grid_for(nrows * RS)), dim3(256), 0, c->stream,
+                       static_cast<const double*>(X), N, L, s, pre, rows_are_increments, D, RS, static_cast<double*>(xr));
     HIPCHK(c, hipGetLastError());
     TvsTileArgs A;
     memset(&A, 0, sizeof(A));
     A.XR = xr; A.ZL = zl; A.ZN = zn; A.N = N; A.Tn = Tn; A.Tpad = Tpad;
     A.L = L; A.d = d_eff; A.kind = p->base_kernel; A.difference = p->difference; A.M = M;
-    A.run = int(run); A.rec_elems = rec_elems;
+    A.queue = static_cast<int32_t*>(tq);          // (the launch plans the items: it knows the instance's occupancy)
     base_p(p, &A.p0, &A.p1);
     A.fx = fx; A.w = w; A.out = out; A.sum_levels = sum_levels ? 1 : 0;
     A.aux = c->tvs_aux_out;
@@ -1453,7 +1450,7 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     hipEvent_t e0, e1;
     bool timed;
     CHK(timing_begin(c, &e0, &e1, &timed));
-    HIPCHK(c, fn(A, lds, c->stream));
+    HIPCHK(c, fn(A, lds, c->stream, c->num_cus));
     if (timed) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
         c->t_launches += 1;
@@ -1975,6 +1972,7 @@ int gpsig_ctx_create(int device, void* stream, gpsig_ctx** out) {
         return fail(nullptr, GPSIG_ERR_UNSUPPORTED, "device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
     gpsig_ctx* c = new gpsig_ctx();
     c->device = device;
+    c->num_cus = prop.multiProcessorCount;
     c->stream = static_cast<hipStream_t>(stream);
     const char* g = getenv("GPSIG_GLDS");
     c->use_glds = g ? atoi(g) : 1;     // LDS-DMA staging is the default (bit-identical to load + ds_write, slightly faster)

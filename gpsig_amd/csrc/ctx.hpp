@@ -32,6 +32,7 @@ enum BufId {
     B_GR7B, B_TW0, B_TW1, B_TW2,
     B_SF0, B_SF1, B_SF2, B_SF3, B_SF4, B_SF5,                               // explicit level features (sig_feat_kernel.hpp): both sides, partial products, level diagonals                              // weighted tensor-vs-sequence sums: partial factor gradients; level arrays of the fallback
     B_SPEC,                                                    // spectral base-kernel table
+    B_TQ,                                                      // item counters of the Kzx tile kernel's persistent launch
     B_COUNT
 };
 
@@ -61,6 +62,7 @@ constexpr size_t TASK_SLOTS = 16;
 
 struct gpsig_ctx {
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     int ptr_mode = GPSIG_PTR_HOST;
     int shard_i = 0, shard_n = 1;

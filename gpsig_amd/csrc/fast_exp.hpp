@@ -233,4 +233,47 @@ GPSIG_FX double kexp2_tabn(double t, const double* tab) {
     return ldexp(fma(tj, s, tj), ni >> ExpTabN<N>::SHIFT);
 }
 
+// ---- the same routines in two halves, for kernels that issue the table read early and finish later (tvs_tile_kernel.hpp): with t = n + r,
+// n = rint(t), the result is ldexp(tab[n & (N-1)] * (1 + kexp2_tail<N>(r)), n >> kexp2_shift(N)) -- the operations of kexp2_tab / _tab256 / _tabn.
+constexpr int kexp2_shift(int N) { return N == 64 ? 6 : (N == 256 ? 8 : (N == 1024 ? 10 : 11)); }
+template <int N>
+GPSIG_FX double kexp2_tail(double r) {
+    if constexpr (N == 64) return exp_tab_tail(r);
+    else if constexpr (N == 256) {
+        double q = 0x1.3b2ab6fba4e77p-39;
+        q = fma(q, r, 0x1.c6b08d704a0c0p-29);
+        q = fma(q, r, 0x1.ebfbdff82c58fp-19);
+        q = fma(q, r, 0x1.62e42fefa39efp-9);
+        return q * r;
+    } else {
+        double q = ExpTabN<N>::C3;
+        q = fma(q, r, ExpTabN<N>::C2);
+        q = fma(q, r, ExpTabN<N>::C1);
+        return q * r;
+    }
+}
+
+// ---- two-level variant of the 1024-entry table: 2^(j/1024) = 2^(jh/32) * 2^(jl/1024), j = 32 jh + jl.  Two tables of 32 entries, 256 bytes each:
+// every entry sits on its own pair of LDS banks, so the 32 lanes an LDS cycle serves read any 32 indices without a bank conflict (the flat
+// 1024-entry table takes ~3.5 cycles per 32 lanes at random indices: SQ_LDS_BANK_CONFLICT 3.6 per LDS instruction in profiles/r04_pmc_c3incr.txt).
+// Costs a second read, a multiplication and two index operations; one more rounding (the product of the two entries).  Same scaling of the argument
+// as the 1024-entry variant (t = a * 1024/ln2), same degree-3 tail.  tab[0..31] = 2^(k/32), tab[32..63] = 2^(k/1024).
+constexpr int EXP_TAB2L_N = 64;
+#if defined(__HIPCC__)
+__device__ __forceinline__ void exp_tab2l_fill(double* lds_tab, int tid, int nthreads) {
+    for (int j = tid; j < 64; j += nthreads) lds_tab[j] = j < 32 ? g_exp2_tab1024[32 * j] : g_exp2_tab1024[j - 32];
+}
+#endif
+GPSIG_FX double kexp2_tab2l(double t, const double* tab) {
+    const double n = rint(t);
+    const double r = t - n;
+    double q = ExpTabN<1024>::C3;
+    q = fma(q, r, ExpTabN<1024>::C2);
+    q = fma(q, r, ExpTabN<1024>::C1);
+    const double s = q * r;
+    const int ni = exp_tab_int(n);
+    const double tj = tab[(ni >> 5) & 31] * tab[32 + (ni & 31)];
+    return ldexp(fma(tj, s, tj), ni >> 10);
+}
+
 }  // namespace gpsig

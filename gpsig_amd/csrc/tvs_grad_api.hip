@@ -88,7 +88,7 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
     if (gb) CHK(ensure(c, B_GR6, sizeof(double) * size_t(TB) * runs * NR + 8, &gbp));
     if (fac) CHK(ensure(c, B_GR7B, sizeof(double) * size_t(TB) * N * (M + 1) + 8, &gfp));
     hipLaunchKernelGGL(prep_tensors_tile_kernel, dim3(grid_for(Tpad * lt * E)), dim3(256), 0, c->stream, Z, lt, Tn, Tpad, increments ? 2 : 1,
-                       collapse ? 1 : 0, pre, s, D, static_cast<double*>(zl), static_cast<double*>(zn));
+                       collapse ? 1 : 0, pre, s, D, static_cast<double*>(zl), static_cast<double*>(zn), static_cast<int32_t*>(nullptr));
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(prep_seq_tile_records_kernel, dim3(grid_for(N * int64_t(rec_elems))), dim3(256), 0, c->stream, X, N, L, s, pre, 0, D,
                        rec_elems, static_cast<double*>(xr));

@@ -11,6 +11,7 @@ xGMI link to rank 0) while the next chunk is being computed, and rank 0 turns th
 the full symmetric matrix in one tiled pass (`gpsig_symmetrize_compact_rows`).
 """
 import ctypes as C
+import time
 
 from . import _lib
 
@@ -36,6 +37,32 @@ def row_partition(n, world, align=ALIGN):
     bounds = [min(r * per, n) for r in range(world + 1)]
     bounds[-1] = n
     return bounds
+
+
+class _Stopwatch:
+    """Marks on the current stream (CUDA events) or on the host clock (CPU tensors under gloo): where a sharded Gram's time went on THIS
+    rank.  Recording an event does not synchronise anything; elapsed() does, once, when somebody asks."""
+
+    def __init__(self, dev):
+        self.cuda = dev.type == "cuda"
+        self.dev = dev
+        self.marks = {}
+
+    def mark(self, name):
+        if self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.dev))
+            self.marks[name] = ev
+        else:
+            self.marks[name] = time.perf_counter()
+
+    def elapsed(self, a, b):
+        if a not in self.marks or b not in self.marks:
+            return 0.0
+        if self.cuda:
+            self.marks[b].synchronize()
+            return float(self.marks[a].elapsed_time(self.marks[b]))
+        return (self.marks[b] - self.marks[a]) * 1e3
 
 
 class ShardedGram:
@@ -64,6 +91,7 @@ class ShardedGram:
         # too -- a single MI355X then runs every collective of the N-rank path through RCCL itself (tests/test_gpu_parity.py)
         self.force = bool(force)
         self.fallback = None                     # why rank 0 evaluated alone, when it did
+        self._watch = None                       # marks of the last call (timings())
         self.width = self.n // 2 + 1
         chunks = max(1, int(chunks))
         self.per = block_rows(self.n, world, ALIGN * chunks)
@@ -144,12 +172,15 @@ class ShardedGram:
         return bool(int(v.item()))
 
     def _chunks(self, ctx, p, X, n, L, b0, b1, pending):
+        sw = self._watch = _Stopwatch(self.dev)
+        sw.chunks = 0
         for k in range(self.chunks):
             r0 = min(b0 + k * self.chunk_rows, b1)
             r1 = min(r0 + self.chunk_rows, b1)
+            sw.mark("b%d" % k)
             if r1 > r0 or k == 0:
                 blk = self.rows[k * self.chunk_rows:]
-                why = None
+                why, err = None, None
                 try:
                     # (an empty row range on the first chunk still asks the library's routes for this shape, in the order a block with
                     # rows does: api.hip, e_kernel_K_symm_rows)
@@ -158,25 +189,57 @@ class ShardedGram:
                     if k != 0:
                         raise
                     why = str(e)
+                except Exception as e:      # noqa: BLE001 -- a full device (MemoryError), a HIP error: this rank cannot go on, but its peers
+                    if k != 0:              # are about to enter the verdict's all-reduce and must not wait there for the collective's timeout
+                        raise
+                    why, err = repr(e), e
                 if k == 0 and not self._agree(why is None):
-                    return self._rank0_alone(X, why or "another rank's row-block call was refused")
+                    return self._rank0_alone(X, why or "another rank's row-block call was refused", err)
+            sw.mark("a%d" % k)
+            sw.chunks = k + 1
             w = self._gather(k)       # enqueued behind chunk k on the collective's own stream; chunk k+1 starts meanwhile
             if w is not None:
                 pending.append(w)
+        sw.mark("e0")
         for w in pending:
             w.wait()
+        sw.mark("e1")
         if self.rank != 0:
             return None
         ctx.symmetrize_compact_rows(_lib.F64, C.c_void_p(self.half.data_ptr()), n, C.c_void_p(self.out.data_ptr()))
+        sw.mark("e2")
         return self.out
 
+    def timings(self):
+        """Where the last decomposed call's time went on this rank, in ms of the stream it ran on (host clock for CPU tensors):
+        compute_ms -- the row-block kernels of its chunks; gather_inline_ms -- what the stream spent between chunks starting the gathers
+        (~0 for RCCL's asynchronous gathers, the whole staged transfer under gloo); gather_wait_ms -- what it waited for the gathers after
+        its last chunk; symmetrise_ms -- rank 0's pass from compact rows to the full matrix.  Synchronises with the events it reads.
+        None when the last call did not take the decomposed route."""
+        sw = self._watch
+        if sw is None or "e1" not in sw.marks:
+            return None
+        nk = sw.chunks
+        comp = sum(sw.elapsed("b%d" % k, "a%d" % k) for k in range(nk))
+        inline = sum(sw.elapsed("a%d" % k, "b%d" % (k + 1)) for k in range(nk - 1)) + sw.elapsed("a%d" % (nk - 1), "e0")
+        return {"rank": self.rank, "rows": int(self.bounds[self.rank + 1] - self.bounds[self.rank]), "chunks": nk, "compute_ms": comp,
+                "gather_inline_ms": inline, "gather_wait_ms": sw.elapsed("e0", "e1"),
+                "symmetrise_ms": sw.elapsed("e1", "e2") if "e2" in sw.marks else 0.0}
 
-    def _rank0_alone(self, X, why):
-        """A shape the row-block kernels do not take: rank 0 evaluates K(X) through the any-shape kernels, the others wait for it."""
+    def _rank0_alone(self, X, why, err=None):
+        """A shape the row-block kernels do not take: rank 0 evaluates K(X) through the any-shape kernels, the others wait for it.
+        err: this rank's own call failed for good (not a refusal): it still joins the barrier its peers wait in, then raises."""
         self.fallback = why
-        out = self.kern.K(X, presliced=True) if self.rank == 0 else None
-        if dist is not None and dist.is_initialized():
-            dist.barrier()
+        self._watch = None
+        out = None
+        try:
+            if err is None and self.rank == 0:
+                out = self.kern.K(X, presliced=True)
+        finally:
+            if dist is not None and dist.is_initialized():
+                dist.barrier()
+        if err is not None:
+            raise err
         return out
 
 

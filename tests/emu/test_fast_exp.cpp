@@ -21,7 +21,9 @@ static double ulps(double got, long double want) {
 int main(int argc, char** argv) {
     const long n = argc > 1 ? atol(argv[1]) : 2000000;
     unsigned long long s = 88172645463325252ull;
-    double worst1 = 0, worst2 = 0, worst1024 = 0, worst2048 = 0;
+    double worst1 = 0, worst2 = 0, worst1024 = 0, worst2048 = 0, worst2l = 0;
+    double tab2l[64];                                                     // what exp_tab2l_fill puts into LDS
+    for (int j = 0; j < 64; ++j) tab2l[j] = j < 32 ? tab1024[32 * j] : tab1024[j - 32];
     for (long i = 0; i < n; ++i) {
         s ^= s << 13; s ^= s >> 7; s ^= s << 17;
         const double u = double(s >> 11) / 9007199254740992.0;
@@ -46,6 +48,8 @@ int main(int argc, char** argv) {
         if (w4 > worst1024) worst1024 = w4;
         const double w5 = ulps(gpsig::kexp2_tabn<2048>(32.0 * t, tab2048), exp2l((long double)(32.0 * t) / 2048.0L));
         if (w5 > worst2048) worst2048 = w5;
+        const double w6 = ulps(gpsig::kexp2_tab2l(16.0 * t, tab2l), exp2l((long double)(16.0 * t) / 1024.0L));          // two tables of 32 entries
+        if (w6 > worst2l) worst2l = w6;
     }
     // edge cases: huge negative arguments give 0, zero gives 1
     const double e0 = gpsig::kexp_tab(0.0, tab), e1 = gpsig::kexp_tab(-1e300, tab), e2 = gpsig::kexp2_tab(-1e300, tab),
@@ -56,7 +60,8 @@ int main(int argc, char** argv) {
                     gpsig::kexp2_tabn<2048>(0.0, tab2048) == 1.0 && gpsig::kexp2_tabn<2048>(-1e300, tab2048) == 0.0 &&
                     fabs(gpsig::ExpTabN<1024>::PRESCALE * gpsig::ExpTabN<1024>::PRESCALE / (16.0 * gpsig::EXP_T_PER_A) - 1.0) < 4e-16 &&
                     fabs(gpsig::ExpTabN<2048>::PRESCALE * gpsig::ExpTabN<2048>::PRESCALE / (32.0 * gpsig::EXP_T_PER_A) - 1.0) < 4e-16;
-    const bool scale_ok = e256 && en && fabs(gpsig::EXP_PRESCALE * gpsig::EXP_PRESCALE / gpsig::EXP_T_PER_A - 1.0) < 4e-16;
-    printf("%.4f %.4f %.4f %.4f %d\n", worst1, worst2, worst1024, worst2048, int(e0 == 1.0 && e1 == 0.0 && e2 == 0.0 && e3 == 0.0 && e4 == 1.0 && scale_ok));
+    const bool e2l = gpsig::kexp2_tab2l(0.0, tab2l) == 1.0 && gpsig::kexp2_tab2l(-1e300, tab2l) == 0.0;
+    const bool scale_ok = e256 && en && e2l && fabs(gpsig::EXP_PRESCALE * gpsig::EXP_PRESCALE / gpsig::EXP_T_PER_A - 1.0) < 4e-16;
+    printf("%.4f %.4f %.4f %.4f %.4f %d\n", worst1, worst2, worst1024, worst2048, worst2l, int(e0 == 1.0 && e1 == 0.0 && e2 == 0.0 && e3 == 0.0 && e4 == 1.0 && scale_ok));
     return 0;
 }

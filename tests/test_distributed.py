@@ -104,6 +104,7 @@ def _worker(rank, world, port, n, chunks, ret):
         kern = kernels.SignatureRBF(L * d, d, M, variances=var, lengthscales=None)
         gram = parallel.ShardedGram(kern, n, torch.device("cpu"), rank, world, chunks=chunks, ctx=EmulatorContext())
         out = gram(torch.from_numpy(X))
+        ret["timings%d" % rank] = gram.timings()          # where this rank's time went (bench.py's per_rank record of an N > 1 line)
         if rank == 0:
             want = O.SignatureKernelOracle(L * d, d, M, base="rbf", variances=var, lengthscales=None).K(X)
             got = out.numpy()
@@ -119,6 +120,11 @@ def _worker(rank, world, port, n, chunks, ret):
 def test_two_rank_gloo_sharded_gram(n, chunks):
     ret = _spawn_with_retry(_worker, 2, (n, chunks))
     assert ret["err"] < 1e-12 and ret["sym"]
+    for r in (0, 1):
+        t = ret["timings%d" % r]
+        assert t["rank"] == r and t["chunks"] == chunks and t["compute_ms"] > 0 and t["gather_wait_ms"] >= 0 and t["gather_inline_ms"] >= 0
+        assert (t["symmetrise_ms"] > 0) == (r == 0)
+    assert ret["timings0"]["rows"] + ret["timings1"]["rows"] == n
 
 
 class RefusingContext(EmulatorContext):
@@ -204,6 +210,56 @@ def test_sharded_gram_ranks_agree_on_the_route_when_one_of_them_is_refused():
         ret = _spawn_with_retry(_diverging_worker, world, (n, refusing))
         assert ret[0] == (True, 0.0), ret
         assert all(ret[r] == (True, None) for r in range(1, world)), ret
+
+
+class FailingOnOneRank(EmulatorContext):
+    """ONE rank's first row-block call fails for good -- a full device (MemoryError from the library's scratch allocation), a HIP error --
+    instead of being refused (round 4's advisor: that rank used to raise before the verdict's all-reduce and leave its peers in it)."""
+
+    def __init__(self, fail):
+        self.fail = fail
+
+    def call(self, name, p, Xp, n, L, r0, r1, outp):
+        if self.fail:
+            raise MemoryError("libgpsig_hip: out of device memory")
+        if r1 > r0:
+            EmulatorContext.call(self, name, p, Xp, n, L, r0, r1, outp)
+
+
+def _failing_worker(rank, world, port, n, failing_rank, ret):
+    import torch
+    from gpsig_amd import kernels
+    from oracle import sigkern_oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, d, M = 7, 2, 3
+        rng = np.random.default_rng(6)
+        X = np.cumsum(0.3 * rng.standard_normal((n, L, d)), axis=1).reshape(n, L * d)
+        kern = kernels.SignatureRBF(L * d, d, M, lengthscales=None)
+        ko = O.SignatureKernelOracle(L * d, d, M, base="rbf", lengthscales=None)
+        kern.K = lambda Xt, presliced=False: torch.from_numpy(ko.K(Xt.numpy()))       # stand-in for rank 0's any-shape evaluation
+        gram = parallel.ShardedGram(kern, n, torch.device("cpu"), rank, world, chunks=2, ctx=FailingOnOneRank(rank == failing_rank))
+        try:
+            out = gram(torch.from_numpy(X))
+            ret[rank] = ("returned", gram.fallback is not None, None if out is None else float(np.abs(out.numpy() - ko.K(X)).max()))
+        except MemoryError as e:
+            ret[rank] = ("raised", str(e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gram_rank_that_fails_for_good_does_not_strand_its_peers():
+    """A MemoryError (or any other exception) on one rank's first chunk: that rank votes 'no' in the all-reduce, joins the fallback's
+    barrier and raises only then; its peers leave through the rank-0 fallback instead of waiting for the collective's timeout."""
+    for n, world, failing in ((20, 2, 1), (20, 3, 0)):
+        ret = _spawn_with_retry(_failing_worker, world, (n, failing))
+        assert ret[failing][0] == "raised" and "out of device memory" in ret[failing][1], ret
+        for r in range(world):
+            if r == failing:
+                continue
+            assert ret[r][0] == "returned" and ret[r][1] is True, ret
+            assert (ret[r][2] == 0.0) if r == 0 else (ret[r][2] is None), ret
 
 
 def _covs_worker(rank, world, port, n, increments, ret):

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(args, env_extra=None, timeout=900):
+def _bench(args, env_extra=None, timeout=1500):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
@@ -30,6 +30,10 @@ def test_two_ranks_started_by_bench_itself():
     assert sorted(r["rank"] for r in seen["ranks"]) == [0, 1] and all(r["arch"].startswith("gfx950") for r in seen["ranks"])
     assert line["verify_max_abs_diff_vs_single_rank"] <= 1e-12
     assert line["rel_err"] <= 1e-6
+    # where each rank's time went (round 5): the row-block kernels, the gathers, rank 0's symmetrisation
+    pr = line["per_rank"]
+    assert [t["rank"] for t in pr["ranks"]] == [0, 1] and all(t["compute_ms"] > 0 and t["chunks"] == 4 for t in pr["ranks"])
+    assert pr["compute_max_over_min"] >= 1.0 and pr["symmetrise_ms_rank0"] > 0 and pr["ranks"][1]["symmetrise_ms"] == 0.0
 
 
 def test_clock_probe_reads_a_plausible_shader_clock():
@@ -70,13 +74,18 @@ def test_default_line_carries_the_measurement():
     assert "sig_gram_dma_kernel" in rf["traffic_source"]["kernel"]
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     names = [s["name"] for s in line["secondary"]]
-    assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c3-linear", "c5-rbf",
+    assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c3-linear", "c5-rbf", "c4-single-gpu",
                      "grad-c2shape-n1024-linear", "grad-c2shape-n1024-linear-level-primitives", "grad-c2shape-n1024-linear-pair-kernels",
                      "grad-c2shape-n1024-rbf"]
     ho = line["secondary"][1]                           # the higher-order algorithm at order = num_levels: the same contraction, the same time
     assert ho["bound"] == "mfma" and ho["ms_per_step"] < 1.3 * line["ms_per_step"]
     lat = line["secondary"][0]                          # the same Gram through the pair recursion: vector-issue bound, about twice the time
     assert lat["bound"] == "valu-issue" and 0.3 < lat["issue_frac"] <= 1.05 and lat["ms_per_step"] > line["ms_per_step"]
+    # the instruction counts behind issue_frac are measured by the run itself (one rocprofv3 --pmc SQ_INSTS_VALU pass per record), not typed in
+    for i in (0, 2, 3, 4, 6):
+        assert line["secondary"][i]["issue_source"].startswith("measured by this run"), line["secondary"][i]
+    c4 = line["secondary"][7]                           # configs[3] on one GPU: the N = 1 point of the scaling series' own workload
+    assert c4["name"] == "c4-single-gpu" and c4["rel_err"] <= 1e-6 and "N=32768" in c4["workload"] and c4["ms_per_step"] > 100
     for s in line["secondary"]:
         assert "error" not in s, s
         assert s["ms_per_step"] > 0
