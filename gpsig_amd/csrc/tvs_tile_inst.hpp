@@ -5,8 +5,9 @@
 namespace gpsig {
 typedef hipError_t (*TvsTileLaunchFn)(TvsTileArgs&, size_t, hipStream_t, int);
 
-// Persistent launch: as many workgroups as the chip holds at once (the occupancy the runtime reports for this instance and its LDS), drawing
-// (tensor block, run of sequences) items from the per-block counters A.queue -- long runs first, short ones last (TvsTileArgs::plan_items).
+// Persistent launch: as many workgroups as the chip holds at once (the occupancy the runtime reports for this instance and its LDS), each of
+// their four wavefronts drawing (tensor block, run of sequences) items from the per-block counters A.queue -- long runs first, short ones last
+// (TvsTileArgs::plan_items).  NW: the number of level sets a wavefront sweeps a tile of sequences in.
 template <int M, int NW, int D, bool INCR, int KIND>
 static hipError_t tvs_tile_launch(TvsTileArgs& A, size_t lds, hipStream_t stream, int num_cus) {
     auto kern = tvs_tile_kernel<M, NW, D, INCR, KIND>;
@@ -15,14 +16,14 @@ static hipError_t tvs_tile_launch(TvsTileArgs& A, size_t lds, hipStream_t stream
         if (e != hipSuccess) return e;
     }
     int per_cu = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NW * 64, lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, TVS_WG_WAVES * 64, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
-    const int64_t TB = A.Tpad / 64, slots = int64_t(per_cu) * (num_cus > 0 ? num_cus : 256);
-    A.plan_items(slots / TB > 0 ? slots / TB : 1);
-    const int64_t all_items = TB * int64_t(A.items);
-    dim3 grid((unsigned)(slots < all_items ? slots : all_items));
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, A);
+    const int64_t TB = A.Tpad / 64, slots = int64_t(per_cu) * (num_cus > 0 ? num_cus : 256), workers = slots * TVS_WG_WAVES;
+    A.plan_items(workers / TB > 0 ? workers / TB : 1);
+    const int64_t all_items = TB * int64_t(A.items), need = (all_items + TVS_WG_WAVES - 1) / TVS_WG_WAVES;
+    dim3 grid((unsigned)(slots < need ? slots : need));
+    hipLaunchKernelGGL(kern, grid, dim3(TVS_WG_WAVES * 64), lds, stream, A);
     return hipGetLastError();
 }
 

@@ -2,17 +2,19 @@
 // signature_kern_tens_vs_seq_first_order (gpsig/kernels.py:313-340, gpsig/signature_algs.py:101-127) + the epilogue of
 // K_tens_vs_seq (kernels.py:572-588), order 1.
 //
-// Mapping.  A workgroup owns a block of 64 inducing tensors (lane = tensor) and a RUN of consecutive sequences.  Its NW
-// wavefronts split the LEVELS between them (a level's chain only involves its own components, signature_algs.py:118-125):
-// wave w keeps the components of its levels in registers for the whole run -- M = 4 with increments is 2 waves x 5
-// components x 2 points x d doubles, which fits 2-3 waves per SIMD where all 10 components in one lane would not fit one.
-// The sequence is staged ONCE per workgroup into LDS by LDS-DMA (global_load_lds, double-buffered: sequence n+1 lands
-// while n is swept) and read back as same-address broadcasts; one sweep over time per sequence with the running sums of
-// the chains in registers,
+// Mapping (round 5).  A WAVEFRONT owns a block of 64 inducing tensors (lane = tensor) and a run of consecutive sequences, which it draws
+// from a queue (persistent launch: as many workgroups as the chip holds, long runs first, short ones last).  The levels are split into P sets
+// (a level's chain only involves its own components, signature_algs.py:118-125; longest-processing-time assignment, tvs_plan.hpp) and the wave
+// sweeps a tile of 16 sequences once per set, with that set's components in registers: M = 4 with increments is three sets of 4 / 3 / 3
+// components x 2 points x d doubles, which fits the 168 registers of THREE wavefronts per SIMD where all ten components would not fit one.
+// (Rounds 2-4 gave the sets to the NW waves of a workgroup, which then waited for each other at a barrier per sequence -- the heaviest set has a
+// third more exps than the others -- and staged the sequence through LDS.)  A sequence's rows are wave-uniform, so they arrive by SCALAR loads
+// (one row ahead of the sweep) and feed the inner products as scalar operands: no LDS traffic, no vector registers.  One sweep over time per
+// sequence and set with the running sums of the chains in registers,
 //     u[k0+j] += dM[k0+j](tau) * u[k0+j-1]   (j = i-1 .. 1, old values),   u[k0] += dM[k0](tau),   K_i = u[k0+i-1],
-// no cross-lane traffic.  Results are collected in an LDS tile [tensor][sequence] and written out 16 sequences at a time,
-// so that every store instruction writes four full 128-byte lines of the (T, N) result (the previous tensor-lane kernel
-// stored one 8-byte value per lane at a stride of N).
+// no cross-lane traffic.  Results collect in the wave's own LDS tile [tensor][sequence], the sets adding up in a fixed order, and leave 16
+// sequences at a time, so that every store instruction writes four full 128-byte lines of the (T, N) result.  The four waves of a workgroup
+// share nothing but the exp table.
 //
 // Base kernel at compile time: KIND = BASE_LINEAR (records hold increments of the scaled sequence when difference is on,
 // tensors with increments are collapsed to z1 - z0 on the way in: one inner product per component and time step),
@@ -84,11 +86,13 @@ struct TvsTileArgs {
         *begin = b;
         *end = b + len < N ? b + len : N;
     }
-    // the item schedule for `wgs` workgroups sharing one tensor block: 70 % of the sequences in runs of r, 20 % in runs of r/2, the rest in runs of r/4
-    void plan_items(int64_t wgs) {
-        const int64_t share = (N + wgs - 1) / (wgs < 1 ? 1 : wgs);
-        int r = share >= 96 ? 32 : (share >= 48 ? 16 : (share >= 24 ? 8 : 4));
-        run = r; run2 = r / 2 > 0 ? r / 2 : 1; run3 = r / 4 > 0 ? r / 4 : 1;
+    // the item schedule for `workers` wavefronts sharing one tensor block: 70 % of the sequences in runs of r, 20 % in runs of r/2, the rest in
+    // runs of r/8.  A worker's share is small (configs[2]: 16,384 sequences over 256 workers per tensor block = 64), so the last items decide how
+    // evenly the launch ends: runs of (8, 4, 2) against (16, 8, 4) at a share of 43 were 5.44 against 5.80 ms (profiles/r05_ab_c3.txt)
+    void plan_items(int64_t workers) {
+        const int64_t share = (N + workers - 1) / (workers < 1 ? 1 : workers);
+        int r = share >= 512 ? 32 : (share >= 128 ? 16 : 8);
+        run = r; run2 = r / 2; run3 = r / 8;
         cnt1 = int32_t((N * 7 / 10) / run);
         cnt2 = int32_t((N * 2 / 10) / run2);
         const int64_t rest = N - int64_t(cnt1) * run - int64_t(cnt2) * run2;
@@ -96,10 +100,25 @@ struct TvsTileArgs {
     }
 };
 
-// LDS bytes of one workgroup: the exp table, the result tile and the item slot
-inline size_t tvs_tile_lds_bytes(int M, int NW, bool sum_levels, bool two_points) {
-    const size_t slots = sum_levels ? size_t(NW) : size_t(M + 1);
-    return sizeof(double) * (tvs_etab_doubles(two_points) + slots * 64 * (TVS_TILE_S + 1) + 2);
+constexpr int TVS_WG_WAVES = 4;          // independent wavefronts per workgroup (one per SIMD), sharing the exp table
+// tile slots of one wave: the level sum, or -- level arrays requested -- the levels of the largest set and level 0 (a set is flushed before the next)
+constexpr int tvs_set_levels(int mask) {
+    int n = 0;
+    for (int i = 1; i < 16; ++i) n += (mask >> i) & 1;
+    return n;
+}
+constexpr int tvs_tile_slots(int M, int P, bool sum_levels) {
+    if (sum_levels) return 1;
+    int b = 0;
+    for (int p = 0; p < P; ++p) {
+        const int c = tvs_set_levels(tvs_level_mask(M, P, p)) + (p == 0 ? 1 : 0);
+        if (c > b) b = c;
+    }
+    return b;
+}
+// LDS bytes of one workgroup: the exp table and the waves' result tiles
+inline size_t tvs_tile_lds_bytes(int M, int P, bool sum_levels, bool two_points) {
+    return sizeof(double) * (tvs_etab_doubles(two_points) + size_t(TVS_WG_WAVES) * tvs_tile_slots(M, P, sum_levels) * 64 * (TVS_TILE_S + 1));
 }
 
 // ---- The table-driven 2^(t/N) of fast_exp.hpp (kexp2_tabn / kexp2_tab256: same operations, same order, same bits) for TWO arguments at once, as one
@@ -192,7 +211,7 @@ __device__ __forceinline__ TvsRow<D> tvs_load_row(tvs_cptr rows, int64_t g) {
     return r;
 }
 
-template <int M, int NW, int D, bool INCR, int KIND, int MASK>
+template <int M, int P, int D, bool INCR, int KIND, int MASK>
 struct TvsTileWave {
     static constexpr int E = (INCR && KIND != BASE_LINEAR) ? 2 : 1;        // linear + increments arrives collapsed
     static constexpr int NC = tvs_mask_comps(MASK);
@@ -357,51 +376,50 @@ struct TvsTileWave {
         }
     }
 
-    // weighted levels of the sequence just swept into the tile column `col`; resets the chains
-    __device__ __forceinline__ void emit(const TvsTileArgs& A, const double (&fac)[M + 1], double* __restrict__ tile, int wave,
-                                         int lane, int col, bool with_level0) {
+    // weighted levels of the sequence just swept into column `col` of the wave's tile; resets the chains.  Level sum: the first set writes
+    // (level 0 with it), the others add -- a fixed order.  Level arrays: slot s of the tile holds the s-th level of this set (level 0 first).
+    __device__ __forceinline__ void emit(const TvsTileArgs& A, const double (&fac)[M + 1], double* __restrict__ tile, int lane, int col, bool first) {
         constexpr int TS = TVS_TILE_S + 1;
-        double acc = 0.0;
-        if (with_level0) {                                        // level 0 == 1 (signature_algs.py:116)
-            if (A.sum_levels) acc = fac[0];
-            else tile[(0 * 64 + lane) * TS + col] = fac[0];
-        }
+        if (A.sum_levels) {
+            double acc = first ? fac[0] : tile[lane * TS + col];      // level 0 == 1 (signature_algs.py:116)
 #pragma unroll
-        for (int i = 1; i <= M; ++i) {
-            if (!((MASK >> i) & 1)) continue;
-            const double v = u[tvs_local_off(MASK, i) + i - 1] * fac[i];
-            if (A.sum_levels) acc += v;
-            else tile[(i * 64 + lane) * TS + col] = v;
+            for (int i = 1; i <= M; ++i)
+                if ((MASK >> i) & 1) acc += u[tvs_local_off(MASK, i) + i - 1] * fac[i];
+            tile[lane * TS + col] = acc;
+        } else {
+            int slot = 0;
+            if (first) tile[(slot++ * 64 + lane) * TS + col] = fac[0];
+#pragma unroll
+            for (int i = 1; i <= M; ++i)
+                if ((MASK >> i) & 1) tile[(slot++ * 64 + lane) * TS + col] = u[tvs_local_off(MASK, i) + i - 1] * fac[i];
         }
-        if (A.sum_levels) tile[(wave * 64 + lane) * TS + col] = acc;
 #pragma unroll
         for (int c = 0; c < NC; ++c) u[c] = 0.0;
     }
 };
 
-// Wavefronts per SIMD the kernel is compiled for.  A gfx950 SIMD issues a float64 instruction every 4 cycles only with THREE wavefronts to pick
-// from -- two get one every 5.3, one every 8, however independent the instructions are (tools/clockcheck.hip, profiles/r03_clockcheck.txt) -- so a
-// lane state that fits 168 registers is worth a third of the kernel's time.  A lane's state in doubles: per component E points of D features + a
-// squared norm each, the chain value and a previous kernel value (the sequence's row is wave-uniform: scalar registers).
-constexpr int tvs_state_doubles(int M, int NW, int D, bool incr, int kind) {
+// A lane's state in doubles: per component E points of D features + a squared norm each, the chain value and a previous kernel value (the
+// sequence's row is wave-uniform: scalar registers).  The kernel is compiled for two wavefronts per SIMD (256 registers): three (the 168
+// registers a state of <= 70 doubles fits: M = 4 with increments in three sets) measured the SAME time as two with the levels in two sets -- 5.74
+// against 5.74 ms at configs[2] -- and fewer sets win where they fit (one set 2.66, two 2.98, three 3.09 ms without increments:
+// profiles/r05_bench_c3_variants.txt): every set sweeps the sequence again, and a float64-dense kernel runs at the chip's power limit from two
+// wavefronts per SIMD on (tools/microbench4.hip).
+constexpr int tvs_state_doubles(int M, int P, int D, bool incr, int kind) {
     const int E = (incr && kind != BASE_LINEAR) ? 2 : 1;
-    return tvs_max_comps(M, NW) * (E * (D + 1) + (kind == BASE_LINEAR ? 0 : 3));
+    return tvs_max_comps(M, P) * (E * (D + 1) + (kind == BASE_LINEAR ? 0 : 3));
 }
-constexpr int tvs_waves_per_simd(int M, int NW, int D, bool incr, int kind) {
-    return (kind != BASE_LINEAR && tvs_state_doubles(M, NW, D, incr, kind) <= 70) ? 3 : 2;
-}
+constexpr int tvs_waves_per_simd(int, int, int, bool, int) { return 2; }
 
-template <int M, int NW, int D, bool INCR, int KIND>
-__global__ __launch_bounds__(NW * 64, tvs_waves_per_simd(M, NW, D, INCR, KIND)) void tvs_tile_kernel(const TvsTileArgs A) {
+template <int M, int P, int D, bool INCR, int KIND>
+__global__ __launch_bounds__(TVS_WG_WAVES * 64, tvs_waves_per_simd(M, P, D, INCR, KIND)) void tvs_tile_kernel(const TvsTileArgs A) {
     constexpr int TS = TVS_TILE_S + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char tvs_tile_smem[];
     double* const etab = reinterpret_cast<double*>(tvs_tile_smem);
     constexpr int NTAB = tvs_etab_n(INCR && KIND != BASE_LINEAR);
-    double* const tile = etab + tvs_etab_doubles(INCR && KIND != BASE_LINEAR);     // [slots][64][TS]
-    const int nslots = A.sum_levels ? NW : M + 1;
-    int* const sh_item = reinterpret_cast<int*>(tile + size_t(nslots) * 64 * TS);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nslots = A.sum_levels ? 1 : tvs_tile_slots(M, P, false);
+    double* const tile = etab + tvs_etab_doubles(INCR && KIND != BASE_LINEAR) + size_t(wave) * nslots * 64 * TS;      // this wave's [slots][64][TS]
     const int TB = int(A.Tpad / 64);
     tvs_cptr rows = (tvs_cptr)(A.XR);
     tvs_cptr fx = (tvs_cptr)(A.fx);
@@ -409,90 +427,86 @@ __global__ __launch_bounds__(NW * 64, tvs_waves_per_simd(M, NW, D, INCR, KIND)) 
     double* __restrict__ out = static_cast<double*>(A.out);
 
     if constexpr (KIND != BASE_LINEAR) {
-        if constexpr (NTAB == 32) exp_tab2l_fill(etab, tid, NW * 64);
-        else if constexpr (NTAB == 64) exp_tab_fill(etab, tid, NW * 64);
-        else if constexpr (NTAB == 256) exp_tab256_fill(etab, tid, NW * 64);
-        else exp_tabn_fill<NTAB>(etab, tid, NW * 64);
+        if constexpr (NTAB == 32) exp_tab2l_fill(etab, tid, TVS_WG_WAVES * 64);
+        else if constexpr (NTAB == 64) exp_tab_fill(etab, tid, TVS_WG_WAVES * 64);
+        else if constexpr (NTAB == 256) exp_tab256_fill(etab, tid, TVS_WG_WAVES * 64);
+        else exp_tabn_fill<NTAB>(etab, tid, TVS_WG_WAVES * 64);
+        __syncthreads();                                          // the only barrier: from here on the waves go their own ways
     }
 
-    // the workgroup's next item of tensor block tb: one lane asks, everybody reads the answer behind a barrier
-    auto draw = [&](int tb) {
-        if (tid == 0) sh_item[0] = atomicAdd(A.queue + tb, 1);
-        __syncthreads();
-        const int it = __builtin_amdgcn_readfirstlane(sh_item[0]);
-        __syncthreads();
-        return it;
+    // this wave's next item of tensor block tb: one lane asks; the answer is read (and waited for) where it is needed
+    auto ask = [&](int tb) {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(A.queue + tb, 1);
+        return v;
     };
-
-    auto run_wave = [&](auto& W) {
-        // a workgroup starts at tensor block (its index mod TB) and moves on to the next block when that one's queue is empty
-        for (int q = 0; q < TB; ++q) {
-            const int tb = (int(blockIdx.x % unsigned(TB)) + q) % TB;
-            int it = draw(tb);
-            if (it >= A.items) continue;
-            const int64_t t = tb * int64_t(64) + lane;            // < Tpad
-            W.load(A, t);
-            while (it < A.items) {
-                int64_t n_begin, n_end;
-                A.item(it, &n_begin, &n_end);
-                int nxt = 0;
-                if (tid == 0) nxt = atomicAdd(A.queue + tb, 1);   // the item after this one: the answer is not needed before this item's last flush
-                TvsRow<D> row = tvs_load_row<D>(rows, n_begin * A.L);
-                for (int64_t n = n_begin; n < n_end; ++n) {
-                    const int idx = int(n - n_begin), col = idx % TVS_TILE_S;
-                    W.sweep(A, rows, n * A.L, etab, row);
-                    if (A.aux) W.store_aux(A, n, t);
-                    double fac[M + 1];
+    // levels of the tile's columns 0 .. ncols-1, tile slot `slot` -> level array lv of the result: 4 tensor rows x 16 sequences per store
+    auto flush = [&](int slot, int lv, int tb, int64_t nb, int ncols) {
+        __builtin_amdgcn_wave_barrier();
+        const int r4 = lane >> 4, cc = lane & 15;
+#pragma unroll 4
+        for (int r = r4; r < 64; r += 4) {
+            const int64_t tr = tb * int64_t(64) + r;
+            if (tr < A.Tn && cc < ncols) out[(int64_t(lv) * A.Tn + tr) * A.N + nb + cc] = tile[(slot * 64 + r) * TS + cc];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // one set of levels over the sequences n0 .. n1-1 (a tile's columns)
+    auto sweep_set = [&](auto& W, bool first, int tb, int64_t t, int64_t n0, int64_t n1) {
+        TvsRow<D> row = tvs_load_row<D>(rows, n0 * A.L);
+        for (int64_t n = n0; n < n1; ++n) {
+            W.sweep(A, rows, n * A.L, etab, row);
+            if (A.aux) W.store_aux(A, n, t);
+            double fac[M + 1];
 #pragma unroll
-                    for (int i = 0; i <= M; ++i) {
-                        double f = fx ? fx[n * (M + 1) + i] : 1.0;
-                        if (wts) f *= wts[i];
-                        fac[i] = f;
-                    }
-                    W.emit(A, fac, tile, wave, lane, col, wave == 0);
-                    if (col == TVS_TILE_S - 1 || n + 1 == n_end) {
-                        if (n + 1 == n_end && tid == 0) sh_item[0] = nxt;
-                        __syncthreads();                                  // every wave's columns are in the tile
-                        // flush: 4 tensor rows x 16 sequences per store instruction
-                        const int64_t nb = n - col;                       // first sequence of the tile
-                        const int r4 = lane >> 4, cc = lane & 15;
-                        const int nlev = A.sum_levels ? 1 : M + 1;
-                        for (int lv = 0; lv < nlev; ++lv)
-                            for (int r = wave * 4 + r4; r < 64; r += NW * 4) {
-                                const int64_t tr = tb * int64_t(64) + r;
-                                if (tr < A.Tn && cc <= col) {
-                                    double v;
-                                    if (A.sum_levels) {
-                                        v = tile[(0 * 64 + r) * TS + cc];
-#pragma unroll
-                                        for (int ww = 1; ww < NW; ++ww) v += tile[(ww * 64 + r) * TS + cc];
-                                    } else {
-                                        v = tile[(lv * 64 + r) * TS + cc];
-                                    }
-                                    out[(int64_t(lv) * A.Tn + tr) * A.N + nb + cc] = v;
-                                }
-                            }
-                        if (n + 1 == n_end) it = __builtin_amdgcn_readfirstlane(sh_item[0]);
-                        __syncthreads();                                  // the tile (and the item slot) is free again
-                    }
-                }
+            for (int i = 0; i <= M; ++i) {
+                double f = fx ? fx[n * (M + 1) + i] : 1.0;
+                if (wts) f *= wts[i];
+                fac[i] = f;
             }
+            W.emit(A, fac, tile, lane, int(n - n0), first);
         }
     };
+    auto flush_levels = [&](int mask, bool first, int tb, int64_t n0, int ncols) {
+        int slot = 0;
+        if (first) flush(slot++, 0, tb, n0, ncols);
+        for (int i = 1; i <= M; ++i)
+            if ((mask >> i) & 1) flush(slot++, i, tb, n0, ncols);
+    };
 
-    if constexpr (NW == 1) {
-        TvsTileWave<M, NW, D, INCR, KIND, tvs_level_mask(M, 1, 0)> W;
-        run_wave(W);
-    } else {
-        if (wave == 0) {
-            TvsTileWave<M, NW, D, INCR, KIND, tvs_level_mask(M, NW, 0)> W;
-            run_wave(W);
-        } else if (NW == 2 || wave == 1) {
-            TvsTileWave<M, NW, D, INCR, KIND, tvs_level_mask(M, NW, 1)> W;
-            run_wave(W);
-        } else {
-            TvsTileWave<M, NW, D, INCR, KIND, tvs_level_mask(M, NW, NW > 2 ? 2 : 0)> W;
-            run_wave(W);
+    // a wave starts at tensor block (its index mod TB) and moves on to the next block when that one's queue is empty
+    const unsigned worker = blockIdx.x * TVS_WG_WAVES + wave;
+    for (int q = 0; q < TB; ++q) {
+        const int tb = (int(worker % unsigned(TB)) + q) % TB;
+        int it = __builtin_amdgcn_readfirstlane(ask(tb));
+        if (it >= A.items) continue;
+        const int64_t t = tb * int64_t(64) + lane;                // < Tpad
+        TvsTileWave<M, P, D, INCR, KIND, tvs_level_mask(M, P, 0)> W0;
+        if constexpr (P == 1) W0.load(A, t);                      // one set: the components stay in registers across the items
+        while (it < A.items) {
+            int64_t n_begin, n_end;
+            A.item(it, &n_begin, &n_end);
+            const int nx = ask(tb);                               // the item after this one, asked for now
+            for (int64_t n0 = n_begin; n0 < n_end; n0 += TVS_TILE_S) {
+                const int64_t n1 = n0 + TVS_TILE_S < n_end ? n0 + TVS_TILE_S : n_end;
+                if constexpr (P > 1) W0.load(A, t);
+                sweep_set(W0, true, tb, t, n0, n1);
+                if (!A.sum_levels) flush_levels(tvs_level_mask(M, P, 0), true, tb, n0, int(n1 - n0));
+                if constexpr (P > 1) {
+                    TvsTileWave<M, P, D, INCR, KIND, tvs_level_mask(M, P, 1)> W1;
+                    W1.load(A, t);
+                    sweep_set(W1, false, tb, t, n0, n1);
+                    if (!A.sum_levels) flush_levels(tvs_level_mask(M, P, 1), false, tb, n0, int(n1 - n0));
+                }
+                if constexpr (P > 2) {
+                    TvsTileWave<M, P, D, INCR, KIND, tvs_level_mask(M, P, P > 2 ? 2 : 0)> W2;
+                    W2.load(A, t);
+                    sweep_set(W2, false, tb, t, n0, n1);
+                    if (!A.sum_levels) flush_levels(tvs_level_mask(M, P, P > 2 ? 2 : 0), false, tb, n0, int(n1 - n0));
+                }
+                if (A.sum_levels) flush(0, 0, tb, n0, int(n1 - n0));
+            }
+            it = __builtin_amdgcn_readfirstlane(nx);
         }
     }
 }

@@ -1,6 +1,7 @@
 """BASELINE.json configs[2]: SVGP inducing-tensor path, Kzz + Kzx + Kxx-diag, T=512, N=16384, L=50, d=6, num_levels=4.
 Times K_tens_n_seq_covs for RBF / linear, with / without increments, through each Kzx kernel the library has:
-the tile kernel (tvs_tile_kernel.hpp) with 1 or 2 waves per workgroup and the older tensor-lane kernel (tvs_tile = 0)."""
+the tile kernel (tvs_tile_kernel.hpp) with its levels in 1, 2 or 3 sets (option tvs_tile_nw; rounds 2-4: waves per workgroup) and the older
+tensor-lane kernel (tvs_tile = 0)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +10,7 @@ T, N, L, d, M = 512, 16384, 50, 6, 4
 rng = np.random.default_rng(0)
 X = torch.as_tensor(np.cumsum(0.2 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1), device="cuda:0")
 ctx = _lib.context(0, torch.cuda.current_stream().cuda_stream)
-variants = (("tile nw=auto", -1, 0), ("tile nw=1", -1, 1), ("tile nw=2", -1, 2), ("tensor lanes (round 1)", 0, 0))
+variants = (("tile sets=auto", -1, 0), ("tile sets=1", -1, 1), ("tile sets=2", -1, 2), ("tile sets=3", -1, 3), ("tensor lanes (round 1)", 0, 0))
 for base in ("rbf", "linear", "matern32"):
     for incr in (False, True):
         Z = torch.as_tensor(rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d)), device="cuda:0")
@@ -22,7 +23,7 @@ for base in ("rbf", "linear", "matern32"):
             kzx = out[1]
             if ref is None: ref = kzx.clone()
             dev = float((kzx - ref).abs().max() / ref.abs().max())
-            reps = 5
+            reps = 10
             ctx.timing_reset(); t0 = time.perf_counter()
             for _ in range(reps): kern.K_tens_n_seq_covs(Z, X, increments=incr)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps

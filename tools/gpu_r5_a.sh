@@ -4,14 +4,14 @@
 # round-4 library and the two-level exp table variant, (3) its counters.  Output under gpurun_out/r05a.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r05a; mkdir -p $O
+O=gpurun_out/${R5_OUT:-r05a}; mkdir -p $O
 export TMPDIR=/tmp
 timeout 300 tools/microbench4 20000 > $O/microbench4.txt 2>&1
 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "tile or tens or config3 or golden or covs or notebook or lane" > $O/pytest_tile.log 2>&1; echo "rc=$?" >> $O/pytest_tile.log
 tail -3 $O/pytest_tile.log
 for rnd in 1 2 3; do
   for cfg in "c3" "c3 --increments"; do
-    for lib in default libgpsig_hip_r4.so libgpsig_hip_e32.so; do
+    for lib in default libgpsig_hip_r4.so ${AB_LIBS:-}; do
       if [ $lib = default ]; then unset GPSIG_LIB; else export GPSIG_LIB=$PWD/gpsig_amd/lib/$lib; fi
       [ $lib = default ] || [ -f gpsig_amd/lib/$lib ] || continue
       timeout 300 python bench.py --config $cfg --steps 20 --warmup 3 --no-cpu-baseline --no-traffic 2>/dev/null | python -c "

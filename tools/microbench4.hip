@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) k(double* out, unsigned long long* t, dou
     int n[16];
     for (int i = 0; i < 16; ++i) { x[i] = threadIdx.x + i; f[i] = float(threadIdx.x) + i; n[i] = threadIdx.x * 7 + i; }
     const unsigned laddr = (threadIdx.x & 7) * 8;
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
 #define F64(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
 #define A64(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(x[i]) : "v"(b));
@@ -72,28 +72,38 @@ __global__ void __launch_bounds__(256) k(double* out, unsigned long long* t, dou
         else if constexpr (OP == MIX_FMA64_DSREAD) { MIXL(0) MIXL(1) MIXL(2) MIXL(3) MIXL(4) MIXL(5) MIXL(6) MIXL(7) asm volatile("s_waitcnt lgkmcnt(0)"); MIXL(0) MIXL(1) MIXL(2) MIXL(3) MIXL(4) MIXL(5) MIXL(6) MIXL(7) asm volatile("s_waitcnt lgkmcnt(0)"); }
         else if constexpr (OP == MIX_FMA64_FMA32) { REP16(MIXF) }
     }
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     double s = 0;
     for (int i = 0; i < 16; ++i) s += x[i] + f[i] + n[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if ((threadIdx.x & 63) == 0) t[blockIdx.x * 4 + threadIdx.x / 64] = c1 - c0;
+    if ((threadIdx.x & 63) == 0) { t[2 * (blockIdx.x * 4 + threadIdx.x / 64)] = c1 - c0; t[2 * (blockIdx.x * 4 + threadIdx.x / 64) + 1] = r1 - r0; }
 }
 
 template <int OP>
 void run(int iters, int wps) {
     const int blocks = 256 * wps, waves = blocks * 4;
     double* out; unsigned long long* t;
-    CK(hipMalloc(&out, sizeof(double) * 256 * blocks)); CK(hipMalloc(&t, 8 * waves));
+    CK(hipMalloc(&out, sizeof(double) * 256 * blocks)); CK(hipMalloc(&t, 16 * waves));
     hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, t, 0.999, 1e-3, 100);
     CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
     hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, t, 0.999, 1e-3, iters);
+    CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
-    std::vector<unsigned long long> h(waves);
-    CK(hipMemcpy(h.data(), t, 8 * waves, hipMemcpyDeviceToHost));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> hh(2 * waves), h(waves), hr(waves);
+    CK(hipMemcpy(hh.data(), t, 16 * waves, hipMemcpyDeviceToHost));
+    for (int i = 0; i < waves; ++i) { h[i] = hh[2 * i]; hr[i] = hh[2 * i + 1]; }
     std::sort(h.begin(), h.end());
+    std::sort(hr.begin(), hr.end());
     const double per_iter = OP >= MIX_FMA64_AND32 ? 32.0 : 16.0;
-    printf("%-34s %d wave(s)/SIMD: %.2f cycles per instruction and SIMD (median wave %.4g cycles)\n", names[OP], wps, double(h[waves / 2]) / (per_iter * iters * wps),
-           double(h[waves / 2]));
+    // wall clock: instructions one SIMD issued / the launch's event time -> ns per instruction and SIMD, and the clock that equates the two
+    const double ns = double(ms) * 1e6 / (per_iter * iters * wps), cyc = double(h[waves / 2]) / (per_iter * iters * wps);
+    // in-kernel wall clock: s_memrealtime counts at 100 MHz
+    const double wave_ns = double(hr[waves / 2]) * 10.0, ns_in = wave_ns / (per_iter * iters * wps);
+    printf("%-34s %d wave(s)/SIMD: %.2f s_memtime ticks per instruction and SIMD; in-kernel %.3f ns per instruction and SIMD (median wave %.3f ms; ticks/ns %.2f); event %.3f ms = %.3f ns\n",
+           names[OP], wps, cyc, ns_in, wave_ns * 1e-6, cyc / ns_in, ms, ns);
     CK(hipFree(out)); CK(hipFree(t));
 }
 
