@@ -1410,7 +1410,8 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     const int d_eff = s.d_eff();
     const int D = tvs_tile_width(d_eff);
     if (D == 0) return GPSIG_OK;
-    const int kind = p->base_kernel == GPSIG_BASE_LINEAR ? BASE_LINEAR : (p->base_kernel == GPSIG_BASE_RBF ? BASE_RBF : -1);
+    const int kind = p->base_kernel == GPSIG_BASE_LINEAR ? BASE_LINEAR : (p->base_kernel == GPSIG_BASE_RBF ? BASE_RBF :
+                     (tvs_is_matern(p->base_kernel) ? p->base_kernel : -1));              // (the enums of include/gpsig_hip.h and seq_core.hpp agree)
     const bool collapse = increments && kind == BASE_LINEAR;              // <x, z1> - <x, z0> = <x, z1 - z0>
     const int E = (increments && !collapse) ? 2 : 1;
     const int NW = c->tvs_tile_nw > 0 ? c->tvs_tile_nw : tvs_tile_waves(M, D, E, kind);
@@ -1422,7 +1423,10 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     if (lds > 64 * 1024) return GPSIG_OK;
     const int64_t Tpad = (Tn + 63) / 64 * 64, TB = Tpad / 64;
     if (N > (int64_t(1) << 30)) return GPSIG_OK;                          // (the item counters are 32-bit)
-    const double pre = kind == BASE_RBF ? tvs_rbf_prescale(E == 2) : 1.0;
+    // (a Matern family forced to another number of level sets than the planner's runs through the run-time-family instance: no prescale)
+    const bool matern = tvs_is_matern(kind) && NW == tvs_tile_waves(M, D, E, kind);
+    const double pre = kind == BASE_RBF ? tvs_rbf_prescale(E == 2) : (matern ? tvs_matern_prescale(kind, E == 2) : 1.0);
+    const double pre_z = matern ? -2.0 * pre : pre;                        // (tvs_tile_kernel.hpp: the Matern components carry a factor -2)
     const int rows_are_increments = kind == BASE_LINEAR && p->difference;
     void *zl, *zn, *xr;
     CHK(ensure(c, B_ZL, sizeof(double) * size_t(lt) * E * D * Tpad + 8, &zl));
@@ -1432,7 +1436,7 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     void* tq;
     CHK(ensure(c, B_TQ, sizeof(int32_t) * size_t(TB) + 8, &tq));
     hipLaunchKernelGGL(prep_tensors_tile_kernel, dim3(grid_for(Tpad * lt * E)), dim3(256), 0, c->stream,
-                       static_cast<const double*>(Zdev), lt, Tn, Tpad, increments ? 2 : 1, collapse ? 1 : 0, pre, s, D,
+                       static_cast<const double*>(Zdev), lt, Tn, Tpad, increments ? 2 : 1, collapse ? 1 : 0, pre_z, s, D,
                        static_cast<double*>(zl), static_cast<double*>(zn), static_cast<int32_t*>(tq));
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(prep_seq_tile_rows_kernel, dim3(grid_for(nrows * RS)), dim3(256), 0, c->stream,

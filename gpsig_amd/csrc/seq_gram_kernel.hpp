@@ -45,8 +45,19 @@ __device__ __forceinline__ float shr1(float v) {
 // KIND >= 0: the base kernel at compile time (built for the RBF kernel with differences, exact shapes): the C + 1 evaluations
 // of a step interleave instead of queueing behind a switch -- 5 % at the headline shape, 18 % at one wavefront per SIMD.
 #define SEQ_FAST_RBF(T, MODE, OMAX, KIND) (sizeof(T) == 8 && (KIND) == BASE_RBF && (MODE) == MODE_PT_DIFF && (OMAX) == 0)
+// The float64 RBF instances (round 5): two steps per loop trip -- the hand-over words alternate registers instead of being copied back, 12
+// v_mov_b64 of the 170 vector instructions of a step's body at the headline shape (tools/isa_loops.py --blocks: 170 -> 157) -- compiled for TWO
+// wavefronts per SIMD: the doubled live ranges need 197 registers, and held to the 168 of three wavefronts the body spills (69 ms).  Same box,
+// alternating processes, configs[1] with SignatureRBF (profiles/r05_ab_c2rbf.txt): 44.4 ms as built in rounds 2-4 (one step per trip, three
+// waves), 45.5 one step / two waves, 42.7 two steps / two waves.  SEQ_RBF_UNROLL2 / SEQ_RBF_WAVES rebuild the other forms for A/B runs.
+#ifndef SEQ_RBF_UNROLL2
+#define SEQ_RBF_UNROLL2 1
+#endif
+#ifndef SEQ_RBF_WAVES
+#define SEQ_RBF_WAVES 2
+#endif
 template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1>
-__global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 32 ? 3 : ((MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1)) void seq_gram_kernel(const SeqGramArgs A) {
+__global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 32 ? SEQ_RBF_WAVES : ((MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1)) void seq_gram_kernel(const SeqGramArgs A) {
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
     static_assert((D * sizeof(T)) % 16 == 0, "record rows are read with 16-byte LDS loads");
     using Lane = typename std::conditional<OMAX == 0, SeqLane<T, C, D, MMAX, MODE>, SeqLaneHO<T, C, D, MMAX, (OMAX > 0 ? OMAX : 1), MODE>>::type;
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
     // back every step.  An odd step count is rounded up; the extra step finds every lane past its last pair.
     // (only where it pays: the point-kernel and higher-order bodies are large enough to lose a wave per SIMD to
     // the doubled live ranges)
-    if constexpr (MODE == MODE_INC && OMAX == 0) {
+    if constexpr ((MODE == MODE_INC && OMAX == 0) || (SEQ_RBF_UNROLL2 && FAST_RBF && C * D <= 32)) {
         for (int t = 0; t < nsteps; t += 2) {
             one_step();
             one_step();

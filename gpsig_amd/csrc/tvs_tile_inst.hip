@@ -23,20 +23,24 @@ TvsTileLaunchFn tvs_tile_lookup(int M, int NW, int D, bool incr, int kind) {
     }
 }
 
-// Level sets (the option is still called tvs_tile_nw: rounds 2-4 gave the sets to the waves of a workgroup): the fewest whose largest set compiles
-// without spills inside the sweep at two wavefronts per SIMD -- every set sweeps the sequences again, and more wavefronts per SIMD buy a
-// float64-dense kernel nothing (tvs_tile_kernel.hpp, tvs_waves_per_simd).  A lane's state in doubles, per component: E points of D features + a
-// squared norm each, plus the chain value and two previous kernel values for the families that difference kappa along time.  Limits read off the
-// compiler's register reports for every built variant: 100 doubles for the linear and the RBF kernel (RBF, M = 4, D = 6: one set of 10 components
-// = 100 doubles = 227 registers, no scratch; with increments two sets of 5 = 85 doubles); the families evaluated through base_eval_n at run time
-// spill some tens of registers at 90 and are still faster there than the older kernels (Matern-3/2 with increments: 14.7 against 18.8 ms).
+// Level sets (the option is still called tvs_tile_nw: rounds 2-4 gave the sets to the waves of a workgroup): tvs_planned_sets of
+// tvs_tile_kernel.hpp -- the fewest whose largest set compiles without spills inside the sweep at two wavefronts per SIMD: every set sweeps the
+// sequences again, and more wavefronts per SIMD buy a float64-dense kernel nothing.  kind: BASE_LINEAR, BASE_RBF, a Matern family, or -1.
 int tvs_tile_waves(int M, int D, int E, int kind) {
-    const int per_comp = E * (D + 1) + (kind == BASE_LINEAR ? 0 : 3);
-    const int limit = (kind == BASE_LINEAR || kind == BASE_RBF) ? 100 : 90;
-    for (int NW = 1; NW <= 3; ++NW) {
-        if (NW > 1 && M < 3) break;
-        if (tvs_max_comps(M, NW) * per_comp <= limit && tvs_tile_lookup(M, NW, D, E == 2, kind)) return NW;
+    if (M < 2 || M > 6) return 0;
+    int P = 0;
+    switch (M * 16 + D) {
+#define TVS_PLAN_CASE(M_, D_) case M_ * 16 + D_: \
+        P = kind == BASE_LINEAR ? tvs_planned_sets(M_, D_, false, BASE_LINEAR) : \
+            kind == BASE_RBF ? (E == 2 ? tvs_planned_sets(M_, D_, true, BASE_RBF) : tvs_planned_sets(M_, D_, false, BASE_RBF)) : \
+            tvs_is_matern(kind) ? (E == 2 ? tvs_planned_sets(M_, D_, true, BASE_MATERN32) : tvs_planned_sets(M_, D_, false, BASE_MATERN32)) : \
+            (E == 2 ? tvs_planned_sets(M_, D_, true, -1) : tvs_planned_sets(M_, D_, false, -1)); break;
+        TVS_PLAN_CASE(2, 4) TVS_PLAN_CASE(2, 6) TVS_PLAN_CASE(2, 8) TVS_PLAN_CASE(3, 4) TVS_PLAN_CASE(3, 6) TVS_PLAN_CASE(3, 8)
+        TVS_PLAN_CASE(4, 4) TVS_PLAN_CASE(4, 6) TVS_PLAN_CASE(4, 8) TVS_PLAN_CASE(5, 4) TVS_PLAN_CASE(5, 6) TVS_PLAN_CASE(5, 8)
+        TVS_PLAN_CASE(6, 4) TVS_PLAN_CASE(6, 6) TVS_PLAN_CASE(6, 8)
+#undef TVS_PLAN_CASE
+        default: return 0;
     }
-    return 0;
+    return (P > 0 && tvs_tile_lookup(M, P, D, E == 2, kind)) ? P : 0;
 }
 }  // namespace gpsig

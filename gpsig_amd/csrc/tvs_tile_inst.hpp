@@ -27,16 +27,26 @@ static hipError_t tvs_tile_launch(TvsTileArgs& A, size_t lds, hipStream_t stream
     return hipGetLastError();
 }
 
+// The Matern families are built for the number of level sets the planner takes only (tvs_planned_sets): forcing another count through the option
+// tvs_tile_nw evaluates them through the run-time-family instance, as round 4 did for every count.
+template <int M, int NW, int D, bool INCR, int KIND>
+static TvsTileLaunchFn tvs_tile_planned() {
+    if constexpr (NW == tvs_planned_sets(M, D, INCR, KIND)) return &tvs_tile_launch<M, NW, D, INCR, KIND>;
+    else return &tvs_tile_launch<M, NW, D, INCR, -1>;
+}
 template <int M, int NW, int D>
 static TvsTileLaunchFn tvs_tile_pick(bool incr, int kind) {
     if (kind == BASE_LINEAR) return &tvs_tile_launch<M, NW, D, false, BASE_LINEAR>;       // increments arrive collapsed
     if (kind == BASE_RBF) return incr ? &tvs_tile_launch<M, NW, D, true, BASE_RBF> : &tvs_tile_launch<M, NW, D, false, BASE_RBF>;
+    if (kind == BASE_MATERN12) return incr ? tvs_tile_planned<M, NW, D, true, BASE_MATERN12>() : tvs_tile_planned<M, NW, D, false, BASE_MATERN12>();
+    if (kind == BASE_MATERN32) return incr ? tvs_tile_planned<M, NW, D, true, BASE_MATERN32>() : tvs_tile_planned<M, NW, D, false, BASE_MATERN32>();
+    if (kind == BASE_MATERN52) return incr ? tvs_tile_planned<M, NW, D, true, BASE_MATERN52>() : tvs_tile_planned<M, NW, D, false, BASE_MATERN52>();
     return incr ? &tvs_tile_launch<M, NW, D, true, -1> : &tvs_tile_launch<M, NW, D, false, -1>;
 }
 
 #define TVS_TILE_CAT2(a, b) a##b
 #define TVS_TILE_CAT(a, b) TVS_TILE_CAT2(a, b)
-// kind: BASE_LINEAR, BASE_RBF or -1 (any other family, evaluated by base_eval_n at run time)
+// kind: BASE_LINEAR, BASE_RBF, a Matern family or -1 (any other family, evaluated by base_eval_n at run time)
 TvsTileLaunchFn TVS_TILE_CAT(tvs_tile_lookup_m, TVS_TILE_M)(int NW, int D, bool incr, int kind) {
 #define TVS_TILE_CASE(NW_)                                                              \
     if (NW == NW_) {                                                                    \

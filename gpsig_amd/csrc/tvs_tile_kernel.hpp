@@ -51,6 +51,14 @@ __device__ __forceinline__ double tvs_exp2(double t, const double* etab) {
     else if constexpr (NTAB == 256) return kexp2_tab256(t, etab);
     else return kexp2_tabn<NTAB>(t, etab);
 }
+// Matern families at compile time (round 5).  With r = sqrt(max(|x - z|^2, 1e-40)) (kernels.py:779-781) the kernels are f(c r) exp(-c r), c = 1,
+// sqrt 3, sqrt 5 (:955-993).  Points prepared in units of 1/s, s = c N / ln2 (N the exp table's entries), the tensors' components times -2 on top:
+// then  q^2 = (|z'|^2 + |x'|^2) + sum_f (-2 z'_f) x'_f  costs what the RBF argument costs, q = s r IS minus the argument of the table-driven
+// 2^(t/N), and u = c r = q ln2 / N feeds the polynomial factor.  sqrt: v_rsq_f64 and one Newton step on the residual (5 instructions).
+constexpr bool tvs_is_matern(int kind) { return kind == BASE_MATERN12 || kind == BASE_MATERN32 || kind == BASE_MATERN52; }
+constexpr double tvs_matern_c(int kind) { return kind == BASE_MATERN12 ? 1.0 : (kind == BASE_MATERN32 ? 1.7320508075688772935 : 2.2360679774997896964); }
+constexpr double TVS_LN2 = 0x1.62e42fefa39efp-1;
+constexpr double tvs_matern_prescale(int kind, bool two_points) { return tvs_matern_c(kind) * double(tvs_etab_n(two_points)) / TVS_LN2; }
 constexpr int TVS_TILE_S = 16;           // sequences per output flush: 16 doubles = one 128-byte line per tensor row
 constexpr int TVS_REC_ALIGN = 128;       // (records of the reverse pass, tvs_grad_tile_kernel.hpp: granule of its LDS-DMA staging)
 // A sequence's record is L rows of RS = D + 1 doubles: the D prepared features and the squared norm of the row's POINT, read by scalar loads
@@ -125,70 +133,56 @@ inline size_t tvs_tile_lds_bytes(int M, int P, bool sum_levels, bool two_points)
 // block of hand-scheduled instructions: both roundings and both table reads first, the polynomial tails while the reads are in flight, one wait.
 // Left to the compiler each exp is one dependent chain that issues its read behind its tail and waits for it at once (and any attempt to steer it
 // with sched_barrier spilled the tensors' components).  11 vector instructions per exp.  tab: LDS byte address of the table (a scalar).
-template <int N>
+// NEG: the arguments are -t0, -t1 (the Matern families hand in q = s r and want 2^(-q/N): the sign rides on the source modifiers).
+#define TVS_EXP2_HEAD(SGN, BITS)                                                                        \
+    "v_rndne_f64 %[r0], " SGN "%[t0]\n\tv_rndne_f64 %[r1], " SGN "%[t1]\n\t"                         \
+    "v_cvt_i32_f64 %[i0], %[r0]\n\tv_cvt_i32_f64 %[i1], %[r1]\n\t"                                    \
+    "v_bfe_u32 %[a0], %[i0], 0, " BITS "\n\tv_bfe_u32 %[a1], %[i1], 0, " BITS "\n\t"                  \
+    "v_lshl_add_u32 %[a0], %[a0], 3, %[tab]\n\tv_lshl_add_u32 %[a1], %[a1], 3, %[tab]\n\t"            \
+    "ds_read_b64 %[e0], %[a0]\n\tds_read_b64 %[e1], %[a1]\n\t"                                        \
+    "v_add_f64 %[r0], " SGN "%[t0], -%[r0]\n\tv_add_f64 %[r1], " SGN "%[t1], -%[r1]\n\t"
+#define TVS_EXP2_TAIL(BITS)                                                                             \
+    "v_mul_f64 %[r0], %[q0], %[r0]\n\tv_mul_f64 %[r1], %[q1], %[r1]\n\t"                              \
+    "v_ashrrev_i32 %[i0], " BITS ", %[i0]\n\tv_ashrrev_i32 %[i1], " BITS ", %[i1]\n\t"                \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
+    "v_fma_f64 %[e0], %[e0], %[r0], %[e0]\n\tv_fma_f64 %[e1], %[e1], %[r1], %[e1]\n\t"                \
+    "v_ldexp_f64 %[e0], %[e0], %[i0]\n\tv_ldexp_f64 %[e1], %[e1], %[i1]"
+#define TVS_EXP2_DEG3                                                                                   \
+    "v_fma_f64 %[q0], %[c3], %[r0], %[c2]\n\tv_fma_f64 %[q1], %[c3], %[r1], %[c2]\n\t"                \
+    "v_fma_f64 %[q0], %[q0], %[r0], %[c1]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c1]\n\t"
+#define TVS_EXP2_DEG4                                                                                   \
+    "v_fma_f64 %[q0], %[c4], %[r0], %[c3]\n\tv_fma_f64 %[q1], %[c4], %[r1], %[c3]\n\t"                \
+    "v_fma_f64 %[q0], %[q0], %[r0], %[c2]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c2]\n\t"                \
+    "v_fma_f64 %[q0], %[q0], %[r0], %[c1]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c1]\n\t"
+#define TVS_EXP2_OUTS [e0] "=&v"(e0), [e1] "=&v"(e1), [r0] "=&v"(r0), [r1] "=&v"(r1), [q0] "=&v"(q0), [q1] "=&v"(q1), [i0] "=&v"(i0), [i1] "=&v"(i1), \
+                      [a0] "=&v"(a0), [a1] "=&v"(a1)
+template <int N, bool NEG = false>
 __device__ __forceinline__ void tvs_exp2_pair(double t0, double t1, unsigned tab, double& e0, double& e1) {
     static_assert(N == 256 || N == 1024 || N == 2048, "table sizes with an asm form");
     double r0, r1, q0, q1;
     int i0, i1, a0, a1;
     if constexpr (N == 256) {
         const double c4 = 0x1.3b2ab6fba4e77p-39, c3 = 0x1.c6b08d704a0c0p-29, c2 = 0x1.ebfbdff82c58fp-19, c1 = 0x1.62e42fefa39efp-9;
-        asm volatile(
-            "v_rndne_f64 %[r0], %[t0]\n\tv_rndne_f64 %[r1], %[t1]\n\t"
-            "v_cvt_i32_f64 %[i0], %[r0]\n\tv_cvt_i32_f64 %[i1], %[r1]\n\t"
-            "v_bfe_u32 %[a0], %[i0], 0, 8\n\tv_bfe_u32 %[a1], %[i1], 0, 8\n\t"
-            "v_lshl_add_u32 %[a0], %[a0], 3, %[tab]\n\tv_lshl_add_u32 %[a1], %[a1], 3, %[tab]\n\t"
-            "ds_read_b64 %[e0], %[a0]\n\tds_read_b64 %[e1], %[a1]\n\t"
-            "v_add_f64 %[r0], %[t0], -%[r0]\n\tv_add_f64 %[r1], %[t1], -%[r1]\n\t"
-            "v_fma_f64 %[q0], %[c4], %[r0], %[c3]\n\tv_fma_f64 %[q1], %[c4], %[r1], %[c3]\n\t"
-            "v_fma_f64 %[q0], %[q0], %[r0], %[c2]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c2]\n\t"
-            "v_fma_f64 %[q0], %[q0], %[r0], %[c1]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c1]\n\t"
-            "v_mul_f64 %[r0], %[q0], %[r0]\n\tv_mul_f64 %[r1], %[q1], %[r1]\n\t"
-            "v_ashrrev_i32 %[i0], 8, %[i0]\n\tv_ashrrev_i32 %[i1], 8, %[i1]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_fma_f64 %[e0], %[e0], %[r0], %[e0]\n\tv_fma_f64 %[e1], %[e1], %[r1], %[e1]\n\t"
-            "v_ldexp_f64 %[e0], %[e0], %[i0]\n\tv_ldexp_f64 %[e1], %[e1], %[i1]"
-            : [e0] "=&v"(e0), [e1] "=&v"(e1), [r0] "=&v"(r0), [r1] "=&v"(r1), [q0] "=&v"(q0), [q1] "=&v"(q1), [i0] "=&v"(i0), [i1] "=&v"(i1),
-              [a0] "=&v"(a0), [a1] "=&v"(a1)
-            : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c4] "s"(c4), [c3] "v"(c3), [c2] "s"(c2), [c1] "s"(c1));
-    } else {
-        constexpr double c3 = ExpTabN<N>::C3, c2 = ExpTabN<N>::C2, c1 = ExpTabN<N>::C1;
-        const double c3s = c3, c2v = c2, c1s = c1;
-        if constexpr (N == 1024)
-            asm volatile(
-                "v_rndne_f64 %[r0], %[t0]\n\tv_rndne_f64 %[r1], %[t1]\n\t"
-                "v_cvt_i32_f64 %[i0], %[r0]\n\tv_cvt_i32_f64 %[i1], %[r1]\n\t"
-                "v_bfe_u32 %[a0], %[i0], 0, 10\n\tv_bfe_u32 %[a1], %[i1], 0, 10\n\t"
-                "v_lshl_add_u32 %[a0], %[a0], 3, %[tab]\n\tv_lshl_add_u32 %[a1], %[a1], 3, %[tab]\n\t"
-                "ds_read_b64 %[e0], %[a0]\n\tds_read_b64 %[e1], %[a1]\n\t"
-                "v_add_f64 %[r0], %[t0], -%[r0]\n\tv_add_f64 %[r1], %[t1], -%[r1]\n\t"
-                "v_fma_f64 %[q0], %[c3], %[r0], %[c2]\n\tv_fma_f64 %[q1], %[c3], %[r1], %[c2]\n\t"
-                "v_fma_f64 %[q0], %[q0], %[r0], %[c1]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c1]\n\t"
-                "v_mul_f64 %[r0], %[q0], %[r0]\n\tv_mul_f64 %[r1], %[q1], %[r1]\n\t"
-                "v_ashrrev_i32 %[i0], 10, %[i0]\n\tv_ashrrev_i32 %[i1], 10, %[i1]\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_fma_f64 %[e0], %[e0], %[r0], %[e0]\n\tv_fma_f64 %[e1], %[e1], %[r1], %[e1]\n\t"
-                "v_ldexp_f64 %[e0], %[e0], %[i0]\n\tv_ldexp_f64 %[e1], %[e1], %[i1]"
-                : [e0] "=&v"(e0), [e1] "=&v"(e1), [r0] "=&v"(r0), [r1] "=&v"(r1), [q0] "=&v"(q0), [q1] "=&v"(q1), [i0] "=&v"(i0), [i1] "=&v"(i1),
-                  [a0] "=&v"(a0), [a1] "=&v"(a1)
-                : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3s), [c2] "v"(c2v), [c1] "s"(c1s));
+        if constexpr (NEG)
+            asm volatile(TVS_EXP2_HEAD("-", "8") TVS_EXP2_DEG4 TVS_EXP2_TAIL("8") : TVS_EXP2_OUTS
+                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c4] "s"(c4), [c3] "v"(c3), [c2] "s"(c2), [c1] "s"(c1));
         else
-            asm volatile(
-                "v_rndne_f64 %[r0], %[t0]\n\tv_rndne_f64 %[r1], %[t1]\n\t"
-                "v_cvt_i32_f64 %[i0], %[r0]\n\tv_cvt_i32_f64 %[i1], %[r1]\n\t"
-                "v_bfe_u32 %[a0], %[i0], 0, 11\n\tv_bfe_u32 %[a1], %[i1], 0, 11\n\t"
-                "v_lshl_add_u32 %[a0], %[a0], 3, %[tab]\n\tv_lshl_add_u32 %[a1], %[a1], 3, %[tab]\n\t"
-                "ds_read_b64 %[e0], %[a0]\n\tds_read_b64 %[e1], %[a1]\n\t"
-                "v_add_f64 %[r0], %[t0], -%[r0]\n\tv_add_f64 %[r1], %[t1], -%[r1]\n\t"
-                "v_fma_f64 %[q0], %[c3], %[r0], %[c2]\n\tv_fma_f64 %[q1], %[c3], %[r1], %[c2]\n\t"
-                "v_fma_f64 %[q0], %[q0], %[r0], %[c1]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c1]\n\t"
-                "v_mul_f64 %[r0], %[q0], %[r0]\n\tv_mul_f64 %[r1], %[q1], %[r1]\n\t"
-                "v_ashrrev_i32 %[i0], 11, %[i0]\n\tv_ashrrev_i32 %[i1], 11, %[i1]\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_fma_f64 %[e0], %[e0], %[r0], %[e0]\n\tv_fma_f64 %[e1], %[e1], %[r1], %[e1]\n\t"
-                "v_ldexp_f64 %[e0], %[e0], %[i0]\n\tv_ldexp_f64 %[e1], %[e1], %[i1]"
-                : [e0] "=&v"(e0), [e1] "=&v"(e1), [r0] "=&v"(r0), [r1] "=&v"(r1), [q0] "=&v"(q0), [q1] "=&v"(q1), [i0] "=&v"(i0), [i1] "=&v"(i1),
-                  [a0] "=&v"(a0), [a1] "=&v"(a1)
-                : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3s), [c2] "v"(c2v), [c1] "s"(c1s));
+            asm volatile(TVS_EXP2_HEAD("", "8") TVS_EXP2_DEG4 TVS_EXP2_TAIL("8") : TVS_EXP2_OUTS
+                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c4] "s"(c4), [c3] "v"(c3), [c2] "s"(c2), [c1] "s"(c1));
+    } else {
+        const double c3 = ExpTabN<N>::C3, c2 = ExpTabN<N>::C2, c1 = ExpTabN<N>::C1;
+        if constexpr (N == 1024 && NEG)
+            asm volatile(TVS_EXP2_HEAD("-", "10") TVS_EXP2_DEG3 TVS_EXP2_TAIL("10") : TVS_EXP2_OUTS
+                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3), [c2] "v"(c2), [c1] "s"(c1));
+        else if constexpr (N == 1024)
+            asm volatile(TVS_EXP2_HEAD("", "10") TVS_EXP2_DEG3 TVS_EXP2_TAIL("10") : TVS_EXP2_OUTS
+                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3), [c2] "v"(c2), [c1] "s"(c1));
+        else if constexpr (NEG)
+            asm volatile(TVS_EXP2_HEAD("-", "11") TVS_EXP2_DEG3 TVS_EXP2_TAIL("11") : TVS_EXP2_OUTS
+                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3), [c2] "v"(c2), [c1] "s"(c1));
+        else
+            asm volatile(TVS_EXP2_HEAD("", "11") TVS_EXP2_DEG3 TVS_EXP2_TAIL("11") : TVS_EXP2_OUTS
+                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3), [c2] "v"(c2), [c1] "s"(c1));
     }
 }
 
@@ -233,7 +227,7 @@ struct TvsTileWave {
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const double s = ZN[(int64_t(k) * E + e) * A.Tpad + t];
-                    zn[c][e] = KIND == BASE_RBF ? -0.5 * s : s;
+                    zn[c][e] = KIND == BASE_RBF ? -0.5 * s : (tvs_is_matern(KIND) ? 0.25 * s : s);     // (Matern: the components carry a factor -2)
 #pragma unroll
                     for (int f = 0; f < D; ++f)
                         z[c][e][f] = ZL[((int64_t(k) * E + e) * D + f) * A.Tpad + t];
@@ -277,6 +271,38 @@ struct TvsTileWave {
                         // that is already satisfied) -- otherwise its own bookkeeping waits for the row request at the head of the next step
                         __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
                     } else kv[p0] = tvs_exp2<NTAB>(t[0], etab);
+                }
+            }
+        } else if constexpr (tvs_is_matern(KIND)) {
+            constexpr int NTAB = tvs_etab_n(E == 2);
+            static_assert(NTAB == 256 || NTAB == 1024 || NTAB == 2048, "exp table sizes with an asm form");
+            constexpr double S = tvs_matern_prescale(KIND, E == 2), K = TVS_LN2 / NTAB;       // u = c r = q K
+            const unsigned tab_addr = __builtin_amdgcn_readfirstlane(unsigned(uintptr_t((__attribute__((address_space(3))) const void*)(etab))));
+#pragma unroll
+            for (int p0 = 0; p0 < NC * E; p0 += 2) {
+                double g[2], ev[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int p = p0 + q < NC * E ? p0 + q : p0;
+                    double d = zn[p / E][p % E] + row.xs;                                      // _square_dist, kernels.py:765-776
+#pragma unroll
+                    for (int f = 0; f < D; ++f) d = fma(z[p / E][p % E][f], row.x[f], d);
+                    d = fmax(d, 1e-40 * S * S);                                                // _euclid_dist, :779-781
+                    const double y = __builtin_amdgcn_rsq(d), h = 0.5 * y;
+                    double r = d * y;
+                    r = fma(fma(-r, r, d), h, r);                                              // one Newton step on the residual: ~1.5 ulp
+                    g[q] = r;
+                }
+                if (p0 + 1 < NC * E) {
+                    tvs_exp2_pair<NTAB, true>(g[0], g[1], tab_addr, ev[0], ev[1]);            // 2^(-q / N)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                } else ev[0] = tvs_exp2<NTAB>(-g[0], etab);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (p0 + q >= NC * E) continue;
+                    if constexpr (KIND == BASE_MATERN12) kv[p0 + q] = ev[q];                                        // :955-958
+                    else if constexpr (KIND == BASE_MATERN32) kv[p0 + q] = fma(g[q], K, 1.0) * ev[q];               // :974-977
+                    else kv[p0 + q] = fma(fma(g[q], K * K / 3.0, K), g[q], 1.0) * ev[q];                           // :991-993: 1 + u + u^2 / 3
                 }
             }
         } else {
@@ -409,6 +435,20 @@ constexpr int tvs_state_doubles(int M, int P, int D, bool incr, int kind) {
     return tvs_max_comps(M, P) * (E * (D + 1) + (kind == BASE_LINEAR ? 0 : 3));
 }
 constexpr int tvs_waves_per_simd(int, int, int, bool, int) { return 2; }
+// which numbers of level sets are built for num_levels = M (tvs_tile_inst_m*.hip)
+constexpr bool tvs_built_sets(int M, int P) { return M == 2 ? P == 1 : (M == 6 ? (P == 2 || P == 3) : (M >= 3 && M <= 5 && P >= 1 && P <= 3)); }
+// Level sets the planner takes: the fewest whose largest set compiles without spills inside the sweep at two wavefronts per SIMD.  Limits read off
+// the compiler's register reports: 100 doubles of lane state for the families fixed at compile time (RBF, M = 4, D = 6: one set of 10 components =
+// 100 doubles = 227 registers, no scratch; with increments two sets of 5 = 85 doubles), 90 for the families evaluated through base_eval_n at run
+// time (they spill some tens of registers there and are still faster than the older kernels).  0: no built variant fits.
+constexpr int tvs_planned_sets(int M, int D, bool incr, int kind) {
+    const int limit = kind == -1 ? 90 : 100;
+    for (int P = 1; P <= 3; ++P) {
+        if (P > 1 && M < 3) break;
+        if (tvs_built_sets(M, P) && tvs_state_doubles(M, P, D, incr, kind) <= limit) return P;
+    }
+    return 0;
+}
 
 template <int M, int P, int D, bool INCR, int KIND>
 __global__ __launch_bounds__(TVS_WG_WAVES * 64, tvs_waves_per_simd(M, P, D, INCR, KIND)) void tvs_tile_kernel(const TvsTileArgs A) {

@@ -784,12 +784,14 @@ def test_tensor_vs_sequence_lane_mappings_agree(K, T):
         ctx.set_option("tvs_tile", -1)
 
 
-@pytest.mark.parametrize("base", ["linear", "rbf", "matern52", "poly"])
+@pytest.mark.parametrize("base", ["linear", "rbf", "matern12", "matern32", "matern52", "poly"])
 @pytest.mark.parametrize("incr", [False, True])
 def test_tile_kernel_for_many_tensors(K, base, incr):
-    """The Kzx tile kernel (tvs_tile_kernel.hpp: levels split over the waves of a workgroup, records by LDS-DMA, table-driven
-    exp for RBF, result tiles of 16 sequences): ragged tensor / sequence counts across tile, run and workgroup boundaries, one
-    and two waves per workgroup, with and without the difference along time, level tensors and the normalised weighted sum."""
+    """The Kzx tile kernel (tvs_tile_kernel.hpp; round 5: a wavefront per (64 tensors, run of sequences) drawn from a queue, the levels in
+    one, two or three sets swept one after the other, rows by scalar loads, hand-scheduled table-driven exps for RBF and -- compile-time
+    instances of their own -- the Matern families, result tiles of 16 sequences): ragged tensor / sequence counts across tile, run and
+    tensor-block boundaries, every number of level sets, with and without the difference along time, level tensors and the normalised
+    weighted sum."""
     from gpsig_amd import _lib
     rng = np.random.default_rng(5)
     L = 19
@@ -797,7 +799,7 @@ def test_tile_kernel_for_many_tensors(K, base, incr):
     try:
         for T, N, nw, diff, M, d in ((70, 37, 1, True, 4, 5), (130, 83, 2, True, 4, 5), (64, 16, 2, False, 4, 6), (33, 49, 1, False, 3, 4),
                                      (65, 21, 3, True, 5, 3), (40, 17, 0, True, 5, 6), (40, 35, 0, True, 2, 8), (64, 33, 3, True, 6, 4),
-                                     (50, 20, 0, False, 6, 7)):
+                                     (50, 20, 0, False, 6, 7), (200, 150, 0, True, 4, 6), (520, 70, 0, True, 3, 4), (70, 300, 3, True, 4, 6)):
             X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
             Z = 0.7 * rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d))
             kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, difference=diff, lengthscales=0.6 + rng.random(d),
@@ -809,7 +811,11 @@ def test_tile_kernel_for_many_tensors(K, base, incr):
             assert relerr(kx.K_tens_vs_seq(Z, X, increments=incr, return_levels=True),
                           ko.K_tens_vs_seq(Z, X, increments=incr, return_levels=True)) <= TOL, (T, N, nw, diff, "levels")
             got = kx.K_tens_vs_seq(Z, X, increments=incr)
-            assert relerr(got, ko.K_tens_vs_seq(Z, X, increments=incr)) <= TOL, (T, N, nw, diff, "sum")
+            # (Matern-1/2's NORMALISED values inherit the rounding noise of kappa(x, x) = exp(-sqrt(max(noise, 1e-40))) at coincident points,
+            # kernels.py:779-781, through the sequences' level diagonals: NumPy's matmul-based squared distance and the GPU's leave different
+            # noise under the square root.  Seen: 2.8e-6 on one small entry of the 70 x 300 case, identically through the tile kernel in every
+            # form, the round-1 kernel and round 4's library -- the reference's own conditioning, not a kernel's.  Its levels pass at 1e-6.)
+            assert relerr(got, ko.K_tens_vs_seq(Z, X, increments=incr)) <= (1e-5 if base == "matern12" else TOL), (T, N, nw, diff, "sum")
             ctx.set_option("tvs_tile", 0)                          # the older tensor-lane kernel writes the same matrix
             assert relerr(make_kernel(K, kw).K_tens_vs_seq(Z, X, increments=incr), got) <= 1e-9
     finally:
@@ -1741,3 +1747,68 @@ def test_feature_contraction_gives_way_on_a_full_device(K):
         torch.cuda.empty_cache()
     assert not torch.equal(got, want)                            # the pair recursion ran (other last digits) ...
     assert float((got - want).abs().max()) <= 1e-11 * float(want.abs().max())      # ... and agrees
+
+
+# ------------------------------------------------------------------------------------------------
+# (e) the cases round 4's randomised sweeps reported above tolerance (profiles/r04_fuzz.txt), as fixtures with their adjudication
+#     (tests/golden/make_fuzz_cases.py)
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def fuzz_cases():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_cases.npz"))
+
+
+def _fuzz_kernel(K, fz, key):
+    M, order, d, lags, L1, L2, norm, diff, f32, incr, T = (int(v) for v in fz[key + "_meta"])
+    base = str(fz[key + "_base"])
+    kw = dict(input_dim=L1 * d, num_features=d, num_levels=M, base=base, order=order, normalization=bool(norm), difference=bool(diff),
+              num_lags=lags or None, lengthscales=fz[key + "_ls"], variances=fz[key + "_var"])
+    if base == "poly":
+        kw["base_params"] = {"gamma": 1.0, "degree": 3.0}
+    return make_kernel(K, kw), bool(incr)
+
+
+def test_where_the_product_is_knowingly_more_accurate_than_the_float64_restatement(K, fuzz_cases):
+    """Case 187 of `tools/fuzz_parity.py 1500 51`: SignatureLinear, order 3, ONE column, 33 / 32 observations, normalised, float64.  The
+    float64 oracle -- the reference's algorithm, the pair recursion's sums over index tuples -- is 1.06e-4 (K(X, X2)) / 1.05e-6 (K(X)) away from
+    the SAME algorithm evaluated in 80-bit arithmetic (numpy longdouble through the oracle's own code; stored beside it): for a one-column
+    sequence the sums cancel from ~1e8 to ~1e-3.  The product's feature route sums per sequence and does not cancel: it is held to the 80-bit
+    values at the contract's 1e-6, i.e. it departs from the float64 restatement where that restatement is the inaccurate one.  The pair
+    kernels (the reference's own summation, on the GPU) are held to EITHER value: they cancel like the oracle, in another order."""
+    from gpsig_amd import _lib
+    fz, key = fuzz_cases, "c187"
+    kern, _ = _fuzz_kernel(K, fz, key)
+    X, X2 = fz[key + "_X"], fz[key + "_X2"]
+    assert relerr(fz[key + "_Kx"], fz[key + "_Kx80"]) > 5e-5 and relerr(fz[key + "_K"], fz[key + "_K80"]) > 5e-7      # the oracle's own distance
+    ctx = _lib.context(0, 0)
+    try:
+        ctx.set_option("sig_features", 1)                   # the route the planner takes at this size (129 x 130 sequences)
+        assert relerr(kern.K(X, X2, presliced=True), fz[key + "_Kx80"]) <= TOL
+        assert relerr(kern.K(X), fz[key + "_K80"]) <= TOL
+        ctx.set_option("sig_features", -1)
+        assert relerr(kern.K(X, X2, presliced=True), fz[key + "_Kx80"]) <= TOL        # (the planner's choice is that route)
+        ctx.set_option("sig_features", 0)                   # the higher-order pair kernels: the reference's summation
+        got = kern.K(X, X2, presliced=True)
+        assert min(relerr(got, fz[key + "_Kx80"]), relerr(got, fz[key + "_Kx"])) <= 2e-4
+    finally:
+        ctx.set_option("sig_features", -1)
+
+
+def test_float32_requests_on_one_column_state_spaces(K, fuzz_cases):
+    """The float32 cases of the same sweep with num_features = 1 -- the class of every float32 miss the sweeps reported (1.2e-4 .. 5.6e-3
+    against the float32 tolerance 1e-4): since round 5 such requests are evaluated by the float64 kernels and rounded (kernels.py,
+    _f32_upcast), and meet the float32 tolerance on the matrix scale."""
+    fz = fuzz_cases
+    keys = [str(k) for k in fz["names"] if str(k) != "c187"]
+    assert len(keys) >= 5
+    for key in keys:
+        kern, incr = _fuzz_kernel(K, fz, key)
+        X, X2, Z = fz[key + "_X"], fz[key + "_X2"], fz[key + "_Z"]
+        assert X.dtype == np.float32
+        for name, got in (("K", kern.K(X)), ("Kx", kern.K(X, X2, presliced=True)), ("Kdiag", kern.Kdiag(X)),
+                          ("Kzx", kern.K_tens_vs_seq(Z, X, increments=incr)), ("Kzz", kern.K_tens(Z, increments=incr))):
+            want = fz[key + "_" + name]
+            assert np.asarray(got).dtype == np.float32, (key, name)
+            err = float(np.abs(np.asarray(got, dtype=np.float64) - want).max() / (np.abs(want).max() + 1e-300))
+            assert err <= 1e-4, (key, name, err)

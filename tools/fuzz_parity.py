@@ -5,14 +5,14 @@ the tolerance (float64 1e-6, float32 1e-4 on the matrix scale)."""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from gpsig_amd import kernels as K
-from gpsig_amd import _lib
-from oracle import sigkern_oracle as O
 
-CTX = _lib.context(0, 0)
+BASES = ["linear", "rbf", "cosine", "poly", "mix", "matern12", "matern32", "matern52"]
 
-CLASS = {"linear": K.SignatureLinear, "rbf": K.SignatureRBF, "cosine": K.SignatureCosine, "poly": K.SignaturePoly, "mix": K.SignatureMix,
-         "matern12": K.SignatureMatern12, "matern32": K.SignatureMatern32, "matern52": K.SignatureMatern52}
+
+def classes():
+    from gpsig_amd import kernels as K
+    return {"linear": K.SignatureLinear, "rbf": K.SignatureRBF, "cosine": K.SignatureCosine, "poly": K.SignaturePoly, "mix": K.SignatureMix,
+            "matern12": K.SignatureMatern12, "matern32": K.SignatureMatern32, "matern52": K.SignatureMatern52}
 
 
 def relerr(got, want, f32):
@@ -22,57 +22,90 @@ def relerr(got, want, f32):
     return float(np.max(np.abs(got - want) / (np.abs(want) + 1e-6 * np.abs(want).max() + 1e-300)))
 
 
+def draw_case(rng):
+    """One case of the sweep: every draw the sweep makes for it, in the sweep's order, and nothing that needs a GPU -- so that
+    tests/golden/make_fuzz_cases.py can replay a seed to the case a sweep reported (committed fixtures: tests/golden/fuzz_cases.npz)."""
+    base = rng.choice(BASES)
+    M = int(rng.integers(1, 7))
+    order = int(rng.choice([1, 1, 1, 2, 3, M]))
+    d = int(rng.choice([1, 2, 3, 5, 8, 11, 16, 20]))
+    lags = int(rng.choice([0, 0, 0, 1, 2])) if base != "poly" else 0
+    L1, L2 = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 130])), int(rng.choice([1, 2, 5, 17, 32, 65, 90]))
+    N1, N2 = int(rng.integers(1, 40)), int(rng.integers(1, 20))
+    if base in ("linear", "cosine") and rng.integers(0, 3) == 0:          # sizes that cross the contraction's 128-wide tiles and its depth pieces
+        N1, N2 = int(rng.choice([127, 129, 200, 300])), int(rng.choice([1, 64, 130, 260]))
+        L1, L2 = min(L1, 33), min(L2, 32)
+    norm, diff = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) > 0)
+    f32 = bool(rng.integers(0, 5) == 0)
+    if (L1 == 1 or L2 == 1) and diff:
+        L1, L2 = max(L1, 2), max(L2, 2)
+    if lags and min(L1, L2) < 3:
+        lags = 0
+    kw = dict(num_levels=M, order=order, normalization=norm, difference=diff, num_lags=lags or None,
+              lengthscales=rng.uniform(0.7, 1.6, d), variances=rng.uniform(0.5, 1.5, M + 1))
+    desc = dict(base=str(base), M=M, order=order, d=d, lags=lags, L1=L1, L2=L2, N1=N1, N2=N2, norm=norm, diff=diff, f32=f32)
+    scale = 0.3 / np.sqrt(d)
+    X = np.cumsum(scale * rng.standard_normal((N1, L1, d)), axis=1).reshape(N1, -1)
+    X2 = np.cumsum(scale * rng.standard_normal((N2, L2, d)), axis=1).reshape(N2, -1)
+    if base == "cosine":
+        X, X2 = X + 1.0, X2 + 1.0
+    lt = M * (M + 1) // 2
+    incr = bool(rng.integers(0, 2))
+    T = int(rng.integers(1, 9)) if rng.integers(0, 4) else int(rng.choice([33, 64, 70, 130]))
+    # library knobs that route a case through the round-2 kernels whatever its size: the Kzx tile kernel below 32 tensors,
+    # the packed float32 kernels with one or four waves per ring, for the linear family too
+    opts = dict(tvs_tile=int(rng.choice([-1, 1])), f32_waves=int(rng.choice([0, 1, 4])), pk2=int(rng.choice([1, 2])),
+                diag_own=int(rng.choice([1, 1, 0])), tens_tile=int(rng.choice([1, 1, 0])), lr_fused=int(rng.choice([1, 1, 0])),
+                lr_gemm=int(rng.choice([1, 1, 0])),
+                # round 3: SignatureLinear's Gram as a contraction of explicit level features wherever it is built (1), by the
+                # planner's choice (-1), never (0); its two contraction kernels
+                sig_features=int(rng.choice([1, 1, -1, 0])), sig_gemm_dma=int(rng.choice([1, 1, 0])))
+    de = d * (lags + 1)
+    Z = 0.5 * rng.standard_normal((lt, T, 2, de) if incr else (lt, T, de)) + (1.0 if base == "cosine" else 0.0)
+    dt = np.float32 if f32 else np.float64
+    Xq, X2q, Zq = X.astype(dt), X2.astype(dt), Z.astype(dt)
+    case = dict(base=str(base), M=M, order=order, d=d, lags=lags, L1=L1, L2=L2, N1=N1, N2=N2, norm=norm, diff=diff, f32=f32, kw=kw, desc=desc, opts=opts,
+                incr=incr, T=T, de=de, Xq=Xq, X2q=X2q, Zq=Zq, lowrank=None)
+    # low-rank mode (order 1, float64): drawn here so that the stream of a seed does not depend on what the evaluation does
+    if order == 1 and not f32 and base != "cosine" and rng.integers(0, 3) == 0 and min(L1, L2) >= 2:
+        c_ = int(rng.choice([3, 8, 17, 50]))
+        r_ = int(rng.choice([2, 9, 30, 50]))
+        sp = str(rng.choice(["sqrt", "log", "lin"]))
+        npts = N1 * L1 + Zq.reshape(-1, de).shape[0]          # the landmarks are drawn from X and Z
+        c_ = min(c_, npts)
+        if sp == "lin":
+            r_ = min(r_, c_ * min(c_, r_))
+        case["lowrank"] = dict(c=c_, r=r_, sparsity=sp, seed=int(rng.integers(1 << 30)))
+    return case
+
+
+def oracle_for(case, dtype=np.float64):
+    from oracle import sigkern_oracle as O
+    ko = O.SignatureKernelOracle(case["L1"] * case["d"], case["d"], base=case["base"], dtype=dtype, **case["kw"],
+                                 base_params=({"gamma": 1.0, "degree": 3.0} if case["base"] == "poly" else None))
+    ko.input_dim = case["L1"] * case["d"]
+    return ko
+
+
 def main():
+    from gpsig_amd import _lib
+    from oracle import sigkern_oracle as O
+    CTX = _lib.context(0, 0)
+    CLASS = classes()
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     bad = 0
     for it in range(cases):
-        base = rng.choice(list(CLASS))
-        M = int(rng.integers(1, 7))
-        order = int(rng.choice([1, 1, 1, 2, 3, M]))
-        d = int(rng.choice([1, 2, 3, 5, 8, 11, 16, 20]))
-        lags = int(rng.choice([0, 0, 0, 1, 2])) if base != "poly" else 0
-        L1, L2 = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 130])), int(rng.choice([1, 2, 5, 17, 32, 65, 90]))
-        N1, N2 = int(rng.integers(1, 40)), int(rng.integers(1, 20))
-        if base in ("linear", "cosine") and rng.integers(0, 3) == 0:          # sizes that cross the contraction's 128-wide tiles and its depth pieces
-            N1, N2 = int(rng.choice([127, 129, 200, 300])), int(rng.choice([1, 64, 130, 260]))
-            L1, L2 = min(L1, 33), min(L2, 32)
-        norm, diff = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) > 0)
-        f32 = bool(rng.integers(0, 5) == 0)
-        if (L1 == 1 or L2 == 1) and diff:
-            L1, L2 = max(L1, 2), max(L2, 2)
-        if lags and min(L1, L2) < 3:
-            lags = 0
-        kw = dict(num_levels=M, order=order, normalization=norm, difference=diff, num_lags=lags or None,
-                  lengthscales=rng.uniform(0.7, 1.6, d), variances=rng.uniform(0.5, 1.5, M + 1))
-        desc = dict(base=base, M=M, order=order, d=d, lags=lags, L1=L1, L2=L2, N1=N1, N2=N2, norm=norm, diff=diff, f32=f32)
+        desc = None
         try:
-            scale = 0.3 / np.sqrt(d)
-            X = np.cumsum(scale * rng.standard_normal((N1, L1, d)), axis=1).reshape(N1, -1)
-            X2 = np.cumsum(scale * rng.standard_normal((N2, L2, d)), axis=1).reshape(N2, -1)
-            if base == "cosine":
-                X, X2 = X + 1.0, X2 + 1.0
-            dt = np.float32 if f32 else np.float64
-            lt = M * (M + 1) // 2
-            incr = bool(rng.integers(0, 2))
-            T = int(rng.integers(1, 9)) if rng.integers(0, 4) else int(rng.choice([33, 64, 70, 130]))
-            # library knobs that route a case through the round-2 kernels whatever its size: the Kzx tile kernel below 32 tensors,
-            # the packed float32 kernels with one or four waves per ring, for the linear family too
-            opts = dict(tvs_tile=int(rng.choice([-1, 1])), f32_waves=int(rng.choice([0, 1, 4])), pk2=int(rng.choice([1, 2])),
-                        diag_own=int(rng.choice([1, 1, 0])), tens_tile=int(rng.choice([1, 1, 0])), lr_fused=int(rng.choice([1, 1, 0])),
-                        lr_gemm=int(rng.choice([1, 1, 0])),
-                        # round 3: SignatureLinear's Gram as a contraction of explicit level features wherever it is built (1), by the
-                        # planner's choice (-1), never (0); its two contraction kernels
-                        sig_features=int(rng.choice([1, 1, -1, 0])), sig_gemm_dma=int(rng.choice([1, 1, 0])))
-            for k_, v_ in opts.items():
+            cs = draw_case(rng)
+            base, M, order, d, L1, L2, f32, kw, desc, incr, T, de = (cs[k] for k in ("base", "M", "order", "d", "L1", "L2", "f32", "kw", "desc", "incr", "T", "de"))
+            for k_, v_ in cs["opts"].items():
                 CTX.set_option(k_, v_)
-            desc.update(opts)
-            de = d * (lags + 1)
-            Z = 0.5 * rng.standard_normal((lt, T, 2, de) if incr else (lt, T, de)) + (1.0 if base == "cosine" else 0.0)
+            desc = dict(desc, **cs["opts"])
             kx1 = CLASS[base](L1 * d, d, **kw)
-            ko1 = O.SignatureKernelOracle(L1 * d, d, base=base, **kw, base_params=({"gamma": 1.0, "degree": 3.0} if base == "poly" else None))
-            ko1.input_dim = L1 * d
-            Xq, X2q, Zq = X.astype(dt), X2.astype(dt), Z.astype(dt)
+            ko1 = oracle_for(cs)
+            Xq, X2q, Zq = cs["Xq"], cs["X2q"], cs["Zq"]
             Xo, X2o, Zo = Xq.astype(np.float64), X2q.astype(np.float64), Zq.astype(np.float64)
             tol = 1e-4 if f32 else 1e-6
             checks = [("K", lambda: kx1.K(Xq), lambda: ko1.K(Xo)), ("Kdiag", lambda: kx1.Kdiag(Xq), lambda: ko1.Kdiag(Xo)),
@@ -94,19 +127,13 @@ def main():
                              ls=kw["lengthscales"], var=kw["variances"], desc=str(desc), incr=incr)
             # low-rank mode (order 1, float64): the product against the oracle's restatement GIVEN THE SAME random objects; judged on
             # the scale of each array (two correct eigensolvers differ in the near-null space of an ill-conditioned landmark Gram)
-            if order == 1 and not f32 and base != "cosine" and rng.integers(0, 3) == 0 and min(L1, L2) >= 2:
-                c_ = int(rng.choice([3, 8, 17, 50]))
-                r_ = int(rng.choice([2, 9, 30, 50]))
-                sp = str(rng.choice(["sqrt", "log", "lin"]))
-                npts = N1 * L1 + Zo.reshape(-1, de).shape[0]          # the landmarks are drawn from X and Z
-                c_ = min(c_, npts)
-                if sp == "lin":
-                    r_ = min(r_, c_ * min(c_, r_))
-                kxl = CLASS[base](L1 * d, d, low_rank=True, num_components=c_, rank_bound=r_, sparsity=sp, **kw)
-                kxl.rng = np.random.default_rng(int(rng.integers(1 << 30)))
+            if cs["lowrank"]:
+                lr = cs["lowrank"]
+                kxl = CLASS[base](L1 * d, d, low_rank=True, num_components=lr["c"], rank_bound=lr["r"], sparsity=lr["sparsity"], **kw)
+                kxl.rng = np.random.default_rng(lr["seed"])
                 st = kxl.draw_low_rank(X=Xo, Z=Zo, increments=incr)
                 lo = O.LowRankOracle(ko1, st.landmarks, st.jitter_diag, st.sketches)
-                ldesc = dict(desc, c=c_, r=r_, sparsity=sp)
+                ldesc = dict(desc, c=lr["c"], r=lr["r"], sparsity=lr["sparsity"])
                 for name, g, w in (("lrK", lambda: kxl.K(Xo, lr_state=st), lambda: lo.K(Xo)),
                                    ("lrKzx", lambda: kxl.K_tens_vs_seq(Zo, Xo, increments=incr, lr_state=st), lambda: lo.K_tens_vs_seq(Zo, Xo, increments=incr)),
                                    ("lrKzz", lambda: kxl.K_tens(Zo, increments=incr, lr_state=st), lambda: lo.K_tens(Zo, increments=incr))):

@@ -59,5 +59,42 @@ def main():
             print(f"lines {a}-{k}: {n} instructions, {valu} vector | " + "  ".join(f"{c} {v}" for c, v in sorted(cnt.items())))
 
 
+
+
+def blocks(path, pat, min_len=60):
+    """Basic blocks (between labels / branches) of at least min_len instructions: the straight-line step bodies of a kernel whose loop also
+    holds conditionally executed blocks (pair boundaries)."""
+    name, lines = kernel_text(path, pat)
+    print("#", name)
+    start = 0
+    out = []
+    for k, l in enumerate(lines):
+        t = l.strip()
+        is_label = bool(re.match(r"^(\.LBB\d+_\d+):", t)) or t.startswith("; %bb")
+        is_branch = t.startswith("s_cbranch") or t.startswith("s_branch") or t.startswith("s_endpgm")
+        if is_label and k > start:
+            out.append((start, k - 1)); start = k
+        if is_branch:
+            out.append((start, k)); start = k + 1
+    for a, b in out:
+        cnt = {}
+        for t in lines[a:b + 1]:
+            t = t.strip()
+            if not t or t[0] in ";.": continue
+            c = classify(t.split()[0])
+            if " row_" in t or " wave_" in t or "quad_perm" in t: c = "v_dpp" if c.startswith("v_") else c
+            if t.startswith("v_mov_b64"): c = "v_mov64"
+            if t.startswith("v_cndmask"): c = "v_cndmask"
+            cnt[c] = cnt.get(c, 0) + 1
+        n = sum(cnt.values())
+        if n >= min_len:
+            valu = sum(v for c, v in cnt.items() if c.startswith("v_"))
+            print(f"lines {a}-{b}: {n} instructions, {valu} vector | " + "  ".join(f"{c} {v}" for c, v in sorted(cnt.items())))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--blocks":
+    blocks(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 60)
+    raise SystemExit(0)
+
 if __name__ == "__main__":
     main()
