@@ -1414,7 +1414,8 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
                      (tvs_is_matern(p->base_kernel) ? p->base_kernel : -1));              // (the enums of include/gpsig_hip.h and seq_core.hpp agree)
     const bool collapse = increments && kind == BASE_LINEAR;              // <x, z1> - <x, z0> = <x, z1 - z0>
     const int E = (increments && !collapse) ? 2 : 1;
-    const int NW = c->tvs_tile_nw > 0 ? c->tvs_tile_nw : tvs_tile_waves(M, D, E, kind);
+    // level sets: the planner's count, or the option's (A/B runs, tests) -- not for the Matern families, which are built for the planner's count only
+    const int NW = (c->tvs_tile_nw > 0 && !tvs_is_matern(kind)) ? c->tvs_tile_nw : tvs_tile_waves(M, D, E, kind);
     TvsTileLaunchFn fn = NW > 0 ? tvs_tile_lookup(M, NW, D, E == 2, kind) : nullptr;
     if (!fn) return GPSIG_OK;
     const int RS = tvs_row_stride(D);
@@ -1423,8 +1424,7 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     if (lds > 64 * 1024) return GPSIG_OK;
     const int64_t Tpad = (Tn + 63) / 64 * 64, TB = Tpad / 64;
     if (N > (int64_t(1) << 30)) return GPSIG_OK;                          // (the item counters are 32-bit)
-    // (a Matern family forced to another number of level sets than the planner's runs through the run-time-family instance: no prescale)
-    const bool matern = tvs_is_matern(kind) && NW == tvs_tile_waves(M, D, E, kind);
+    const bool matern = tvs_is_matern(kind);
     const double pre = kind == BASE_RBF ? tvs_rbf_prescale(E == 2) : (matern ? tvs_matern_prescale(kind, E == 2) : 1.0);
     const double pre_z = matern ? -2.0 * pre : pre;                        // (tvs_tile_kernel.hpp: the Matern components carry a factor -2)
     const int rows_are_increments = kind == BASE_LINEAR && p->difference;

@@ -709,7 +709,8 @@ __device__ __forceinline__ double generic_kappa(const GenericSeqArgs& A, int64_t
 }
 
 // grid (ceil(N1 / 64), number of y sequences of this launch or 1 for the diagonal); block 64
-static __global__ void __launch_bounds__(64) seq_levels_generic_kernel(const GenericSeqArgs A) {
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void __launch_bounds__(64) seq_levels_generic_kernel(const GenericSeqArgs A) {
     constexpr int MM = 8;
     const int64_t i = int64_t(blockIdx.x) * 64 + threadIdx.x;
     const bool valid = i < A.N1;
@@ -774,6 +775,9 @@ static __global__ void __launch_bounds__(64) seq_levels_generic_kernel(const Gen
         if (m < M) o[m * A.sm] = (R1 > 0 && R2 > 0) ? qlast[m] : 0.0;
     o[int64_t(M) * A.sm] = ktop;
 }
+#else
+__global__ void __launch_bounds__(64) seq_levels_generic_kernel(const GenericSeqArgs A);
+#endif
 
 // Higher-order algorithm (signature_algs.py:37-74) in the same any-shape, one-pair-per-thread form.  Per lattice cell and
 // level m the reference's d x d grid (d = min(m, order)) is
@@ -783,7 +787,8 @@ static __global__ void __launch_bounds__(64) seq_levels_generic_kernel(const Gen
 //     R_m[j-1][k-1] = dM / (j k) * R_{m-1}[j-2][k-2]   at the same cell                                    (:69)
 // and K_m = sum over cells and grid entries (:71).  Scratch per pair and lattice column: for each level m < M the inclusive
 // 2-D prefix Q_m of the previous row and the OM column prefixes; the row prefixes run in (private) registers along a row.
-static __global__ void __launch_bounds__(64) seq_levels_generic_ho_kernel(const GenericSeqArgs A, int order) {
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void __launch_bounds__(64) seq_levels_generic_ho_kernel(const GenericSeqArgs A, int order) {
     constexpr int MM = 8, OM = 8;
     const int64_t i = int64_t(blockIdx.x) * 64 + threadIdx.x;
     const bool valid = i < A.N1;
@@ -880,9 +885,13 @@ static __global__ void __launch_bounds__(64) seq_levels_generic_ho_kernel(const 
     o[0] = 1.0;
     for (int m = 1; m <= M; ++m) o[m * A.sm] = K[m];
 }
+#else
+__global__ void __launch_bounds__(64) seq_levels_generic_ho_kernel(const GenericSeqArgs A, int order);
+#endif
 
 // levels (M1, N1, N2) -> out[i][j] = sum_m (lev + jitter_diag * [i == j]) * ax[i][m] * by[j][m]   (or per level)
-static __global__ void levels_epilogue_kernel(const double* __restrict__ lev, int64_t N1, int64_t N2, int M1, const double* __restrict__ ax,
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void levels_epilogue_kernel(const double* __restrict__ lev, int64_t N1, int64_t N2, int M1, const double* __restrict__ ax,
                                        const double* __restrict__ by, double jitter_diag, int sum_levels, double* __restrict__ out) {
     const int64_t total = N1 * N2;
     for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
@@ -897,5 +906,9 @@ static __global__ void levels_epilogue_kernel(const double* __restrict__ lev, in
         if (sum_levels) out[idx] = acc;
     }
 }
+#else
+__global__ void levels_epilogue_kernel(const double* __restrict__ lev, int64_t N1, int64_t N2, int M1, const double* __restrict__ ax,
+                                       const double* __restrict__ by, double jitter_diag, int sum_levels, double* __restrict__ out);
+#endif
 
 }  // namespace gpsig

@@ -192,11 +192,15 @@ inline int no_capture(gpsig_ctx* c, const char* what) {
 // Zero fill on the ctx stream.  Inside a graph capture a kernel does it: memset nodes were seen to run out of order with the
 // kernel nodes around them when a recorded graph is replayed (ROCm 7.2), which left zeroed records behind a finished prep kernel.
 #ifdef __HIPCC__
-static __global__ void zero_fill_kernel(unsigned long long* p, size_t n8, unsigned char* tail, int ntail) {
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void zero_fill_kernel(unsigned long long* p, size_t n8, unsigned char* tail, int ntail) {
     const size_t stride = size_t(gridDim.x) * blockDim.x;
     for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n8; i += stride) p[i] = 0ull;
     if (blockIdx.x == 0 && int(threadIdx.x) < ntail) tail[threadIdx.x] = 0;
 }
+#else
+__global__ void zero_fill_kernel(unsigned long long* p, size_t n8, unsigned char* tail, int ntail);
+#endif
 #endif
 inline int zero_async(gpsig_ctx* c, void* p, size_t bytes) {
     if (!bytes) return GPSIG_OK;

@@ -440,8 +440,12 @@ __global__ void __launch_bounds__(64) seq_grad_wave2_kernel(const Wave2Args A) {
 // recursion state only, so the 16-lane shapes that hold 4 pairs per wavefront fit for every base kernel.
 // KIND >= 0 fixes the base kernel at compile time: the C + 1 evaluations of a row then interleave instead of queueing behind a
 // switch (1024 x 1024 RBF Gram: 56 -> 34 ms for the sweeps).
+#ifndef LAM_UNDO_WAVES
+#define LAM_UNDO_WAVES 1        // wavefronts per SIMD the sweeps are compiled for.  2: the 256 registers cost 12 scratch accesses per step of either
+                                // sweep -- K(X) forward + backward of 1,024 sequences at the headline shape 48.3 -> 77.4 ms (round 5, same box)
+#endif
 template <int G, int C, int DP, int LQ, int MODE, bool MX = false, int KIND = -1>
-__global__ void __launch_bounds__(64) seq_lam_undo_kernel(const Wave2Args A) {
+__global__ void __launch_bounds__(64, LAM_UNDO_WAVES) seq_lam_undo_kernel(const Wave2Args A) {
     extern __shared__ double w2_sm[];
     const int kind = KIND >= 0 ? KIND : A.kind;
     constexpr int PW = 64 / G;

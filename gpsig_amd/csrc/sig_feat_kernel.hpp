@@ -457,12 +457,20 @@ inline size_t sig_features_lds_bytes(int d, int M, int L) {
 
 // float32 calls: the contraction is a float64 computation (float64 matrix cores; a float32 accumulation over 37,000 products would not
 // hold 1e-4 anyway) -- the sequences are widened on the way in, the result rounded on the way out.
-static __global__ void sig_widen_kernel(const float* __restrict__ in, double* __restrict__ out, int64_t n) {
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void sig_widen_kernel(const float* __restrict__ in, double* __restrict__ out, int64_t n) {
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) out[i] = double(in[i]);
 }
-static __global__ void sig_narrow_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
+#else
+__global__ void sig_widen_kernel(const float* __restrict__ in, double* __restrict__ out, int64_t n);
+#endif
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void sig_narrow_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t n) {
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) out[i] = float(in[i]);
 }
+#else
+__global__ void sig_narrow_kernel(const double* __restrict__ in, float* __restrict__ out, int64_t n);
+#endif
 
 // ---- C = A B^T, float64 matrix cores, depth split over workgroups ----------------------------------------------------------------
 typedef double sig_f64x4 __attribute__((ext_vector_type(4)));
@@ -629,6 +637,7 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramAr
             }
 }
 
+
 // The same product with the slabs brought in by LDS-DMA and the operand fragments prefetched across the barrier (whole slabs only:
 // k_begin a multiple of SG_BK, rows padded with zeros up to a multiple of SG_BK, 16-byte aligned).  A slab is 128 rows x 16 doubles per
 // operand, rows unpadded (the DMA writes lane-linear: 8 lanes x 16 bytes = one row) with the 16-byte slots of row r XORed by (r >> 1) & 7
@@ -637,7 +646,8 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_kernel(const SigGramAr
 // depth step k+1 read while step k multiplies, ONE barrier in front of the last step's multiplies -- by then the wave holds that
 // step's fragments, and the next slab's first fragments are read right behind the barrier, under 16 MFMAs.  Same summation order as
 // sig_gram_kernel: bit-identical results.
-static __global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGramArgs G) {
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGramArgs G) {
     // (1 KiB unused in front: an LDS-DMA load adds its immediate offset to the LDS address as well as to the global one, so the
     // destinations below are given minus that offset -- down to 1 KiB below the first buffer)
     constexpr int SG_GUARD = 8 * SG_BK;
@@ -760,6 +770,9 @@ static __global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGr
                 if (i < G.NA && j < G.NB) P[i * G.NB + j] = acc[m][n][r];
             }
 }
+#else
+__global__ __launch_bounds__(256, 2) void sig_gram_dma_kernel(const SigGramArgs G);
+#endif
 
 // mode 0: out[i * so_i + j * so_j] = sum_s part[s][i][j]                                              (general product)
 // mode 1: symmetric: tiles bi <= bj hold the sums; out[i][j] = out[j][i]; diag_set: out[i][i] = diag_value (the normalised diagonal is
@@ -776,7 +789,8 @@ struct SigReduceArgs {
 };
 // mode 1 in 32 x 32 blocks of the computed (upper) tiles: partial sums read and the result written along rows, the mirror image written
 // along rows too after a transpose through LDS.  grid (blocks per tile side squared, upper tiles), block (32, 8).
-static __global__ void sig_gram_reduce_sym_kernel(const SigReduceArgs R, int nt) {
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void sig_gram_reduce_sym_kernel(const SigReduceArgs R, int nt) {
     __shared__ double tile[32][33];
     int t = blockIdx.y, bi = 0, rowlen = nt;
     while (t >= rowlen) { t -= rowlen; ++bi; --rowlen; }
@@ -802,8 +816,12 @@ static __global__ void sig_gram_reduce_sym_kernel(const SigReduceArgs R, int nt)
         if (i < R.NA && j < R.NB) R.out[j * R.so_i + i * R.so_j] = tile[threadIdx.x][r];
     }
 }
+#else
+__global__ void sig_gram_reduce_sym_kernel(const SigReduceArgs R, int nt);
+#endif
 
-static __global__ void sig_gram_reduce_kernel(const SigReduceArgs R) {
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void sig_gram_reduce_kernel(const SigReduceArgs R) {
     const int64_t total = R.NA * R.NB, stride = R.NA * R.NB;
     for (int64_t e = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
         const int64_t i = e / R.NB, j = e - i * R.NB;
@@ -830,5 +848,8 @@ static __global__ void sig_gram_reduce_kernel(const SigReduceArgs R) {
         R.out[i * R.so_i + j * R.so_j] = s;
     }
 }
+#else
+__global__ void sig_gram_reduce_kernel(const SigReduceArgs R);
+#endif
 
 }  // namespace gpsig

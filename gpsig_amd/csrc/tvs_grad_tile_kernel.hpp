@@ -459,7 +459,8 @@ __global__ __launch_bounds__(64, TVSG_WAVES_PER_EU) void tvs_grad_tile_kernel(co
 
 // G (M+1, T, N) -> Gt (N, M+1, Tpad), zero for t >= T: a lane (= tensor) of the tile kernel then reads its upstream gradients from
 // consecutive addresses.  grid (ceil(N / 32), Tpad / 32, M+1), block (32, 8).
-static __global__ void tvs_grad_transpose_G_kernel(const double* __restrict__ G, int64_t Tn, int64_t Tpad, int64_t N, int M1,
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void tvs_grad_transpose_G_kernel(const double* __restrict__ G, int64_t Tn, int64_t Tpad, int64_t N, int M1,
                                                    double* __restrict__ Gt) {
     __shared__ double tile[32][33];
     const int lv = blockIdx.z;
@@ -474,9 +475,14 @@ static __global__ void tvs_grad_transpose_G_kernel(const double* __restrict__ G,
         if (n < N) Gt[(n * M1 + lv) * Tpad + tt] = tile[threadIdx.x][r];
     }
 }
+#else
+__global__ void tvs_grad_transpose_G_kernel(const double* __restrict__ G, int64_t Tn, int64_t Tpad, int64_t N, int M1,
+                                                   double* __restrict__ Gt);
+#endif
 
 // gX[n][tau][f] = scale * sum over the (role, tensor block) partials of gxp[b][n][tau][f]      (D-wide rows -> the caller's d columns)
-static __global__ void tvs_grad_reduce_gx_kernel(const double* __restrict__ gxp, int nblocks, int64_t rows /* N * L */, int D, int d,
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void tvs_grad_reduce_gx_kernel(const double* __restrict__ gxp, int nblocks, int64_t rows /* N * L */, int D, int d,
                                                  double scale, double* __restrict__ gX) {
     const int64_t total = rows * d;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < total; e += int64_t(gridDim.x) * blockDim.x) {
@@ -487,19 +493,28 @@ static __global__ void tvs_grad_reduce_gx_kernel(const double* __restrict__ gxp,
         gX[e] = s * scale;
     }
 }
+#else
+__global__ void tvs_grad_reduce_gx_kernel(const double* __restrict__ gxp, int nblocks, int64_t rows /* N * L */, int D, int d,
+                                                 double scale, double* __restrict__ gX);
+#endif
 
 // gfac[n][i] = sum over the tensor blocks of gfp[b][n][i]
-static __global__ void tvs_grad_reduce_gf_kernel(const double* __restrict__ gfp, int nblocks, int64_t n, double* __restrict__ gfac) {
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void tvs_grad_reduce_gf_kernel(const double* __restrict__ gfp, int nblocks, int64_t n, double* __restrict__ gfac) {
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n; e += int64_t(gridDim.x) * blockDim.x) {
         double s = 0.0;
         for (int b = 0; b < nblocks; ++b) s += gfp[int64_t(b) * n + e];
         gfac[e] = s;
     }
 }
+#else
+__global__ void tvs_grad_reduce_gf_kernel(const double* __restrict__ gfp, int nblocks, int64_t n, double* __restrict__ gfac);
+#endif
 
 // gZ[k][t][e][f] = scale * sum over the runs of gzp[run][k][e][f][t].  collapse (linear kernel with incremental tensors: the
 // kernel saw z1 - z0): the caller's two points receive (-g, +g).
-static __global__ void tvs_grad_reduce_gz_kernel(const double* __restrict__ gzp, int nruns, int lt, int E, int D, int64_t Tpad, int64_t Tn,
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void tvs_grad_reduce_gz_kernel(const double* __restrict__ gzp, int nruns, int lt, int E, int D, int64_t Tpad, int64_t Tn,
                                                  int d, int collapse, double scale, double* __restrict__ gZ) {
     const int64_t total = int64_t(lt) * E * d * Tn;
     for (int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
@@ -528,5 +543,9 @@ static __global__ void tvs_grad_reduce_gz_kernel(const double* __restrict__ gzp,
         }
     }
 }
+#else
+__global__ void tvs_grad_reduce_gz_kernel(const double* __restrict__ gzp, int nruns, int lt, int E, int D, int64_t Tpad, int64_t Tn,
+                                                 int d, int collapse, double scale, double* __restrict__ gZ);
+#endif
 
 }  // namespace gpsig

@@ -27,12 +27,11 @@ static hipError_t tvs_tile_launch(TvsTileArgs& A, size_t lds, hipStream_t stream
     return hipGetLastError();
 }
 
-// The Matern families are built for the number of level sets the planner takes only (tvs_planned_sets): forcing another count through the option
-// tvs_tile_nw evaluates them through the run-time-family instance, as round 4 did for every count.
+// The Matern families are built for the number of level sets the planner takes only (tvs_planned_sets; the option tvs_tile_nw does not apply to them).
 template <int M, int NW, int D, bool INCR, int KIND>
 static TvsTileLaunchFn tvs_tile_planned() {
     if constexpr (NW == tvs_planned_sets(M, D, INCR, KIND)) return &tvs_tile_launch<M, NW, D, INCR, KIND>;
-    else return &tvs_tile_launch<M, NW, D, INCR, -1>;
+    else return nullptr;
 }
 template <int M, int NW, int D>
 static TvsTileLaunchFn tvs_tile_pick(bool incr, int kind) {

@@ -186,6 +186,26 @@ __device__ __forceinline__ void tvs_exp2_pair(double t0, double t1, unsigned tab
     }
 }
 
+// The families the run-time-family instance (KIND == -1) still serves -- cosine, poly, mix; linear, RBF and the Matern families have instances of
+// their own -- evaluated like base_eval_n of seq_core.hpp, whose switch over all nine families (library pow, exp and sqrt per value, unrolled)
+// made these instances 100-200 KB each.
+template <int NV>
+__device__ __forceinline__ void tvs_base_eval_rest(int kind, double (&v)[NV], const double (&a2)[NV], double b2, double p0, double p1) {
+    if (kind == BASE_COSINE) {
+        const double sb = sqrt(b2);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = v[i] / (sb * sqrt(a2[i]));
+    } else if (kind == BASE_POLY) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = poly_pow(v[i] + p0, p1);
+    } else if (kind == BASE_MIX) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = p0 * kexp(-fma(-2.0, v[i], b2 + a2[i]) / 2) + (1.0 - p0) * v[i];
+    } else {
+        __builtin_trap();                                          // the host's dispatch sends no other family here (api.hip, tens_vs_seq_tile_device)
+    }
+}
+
 template <int D>
 struct TvsRow {           // one row of a record: wave-uniform, i.e. scalar registers
     double x[D];
@@ -316,7 +336,7 @@ struct TvsTileWave {
                     kv[c * E + e] = ip;
                     a2[c * E + e] = zn[c][e];
                 }
-            if constexpr (KIND != BASE_LINEAR) base_eval_n<double, NC * E>(A.kind, kv, a2, row.xs, A.p0, A.p1);
+            if constexpr (KIND != BASE_LINEAR) tvs_base_eval_rest<NC * E>(A.kind, kv, a2, row.xs, A.p0, A.p1);
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) k1[c] = E == 2 ? kv[c * E + 1] - kv[c * E] : kv[c * E];       // kernels.py:329-330
@@ -436,7 +456,7 @@ constexpr int tvs_state_doubles(int M, int P, int D, bool incr, int kind) {
 }
 constexpr int tvs_waves_per_simd(int, int, int, bool, int) { return 2; }
 // which numbers of level sets are built for num_levels = M (tvs_tile_inst_m*.hip)
-constexpr bool tvs_built_sets(int M, int P) { return M == 2 ? P == 1 : (M == 6 ? (P == 2 || P == 3) : (M >= 3 && M <= 5 && P >= 1 && P <= 3)); }
+constexpr bool tvs_built_sets(int M, int P) { return M == 2 ? P == 1 : ((M == 3 || M == 4) ? (P == 1 || P == 2) : ((M == 5 || M == 6) && (P == 2 || P == 3))); }
 // Level sets the planner takes: the fewest whose largest set compiles without spills inside the sweep at two wavefronts per SIMD.  Limits read off
 // the compiler's register reports: 100 doubles of lane state for the families fixed at compile time (RBF, M = 4, D = 6: one set of 10 components =
 // 100 doubles = 227 registers, no scratch; with increments two sets of 5 = 85 doubles), 90 for the families evaluated through base_eval_n at run
@@ -555,7 +575,8 @@ __global__ __launch_bounds__(TVS_WG_WAVES * 64, tvs_waves_per_simd(M, P, D, INCR
 //   ZL[((k * E + e) * D + fe) * Tpad + t] = pre * z~ (zero for fe >= d_eff),   ZN[(k * E + e) * Tpad + t] = |pre * z~|^2   (zero for t >= T)
 // with z~ the scaled component (kernels.py:367-398) and, for collapse (linear kernel, E_in = 2, E = 1), the difference of the
 // component's two points (kernels.py:329-330 applied before the inner product, which is linear in it).
-static __global__ void prep_tensors_tile_kernel(const double* __restrict__ Z, int lt, int64_t Tn, int64_t Tpad, int E_in, int collapse,
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void prep_tensors_tile_kernel(const double* __restrict__ Z, int lt, int64_t Tn, int64_t Tpad, int E_in, int collapse,
                                          double pre, ScaleParams P, int D, double* __restrict__ ZL, double* __restrict__ ZN,
                                          int32_t* __restrict__ queue) {
     const int d_eff = P.d_eff();
@@ -587,10 +608,16 @@ static __global__ void prep_tensors_tile_kernel(const double* __restrict__ Z, in
         ZN[(int64_t(k) * E + e) * Tpad + t] = ss;
     }
 }
+#else
+__global__ void prep_tensors_tile_kernel(const double* __restrict__ Z, int lt, int64_t Tn, int64_t Tpad, int E_in, int collapse,
+                                         double pre, ScaleParams P, int D, double* __restrict__ ZL, double* __restrict__ ZN,
+                                         int32_t* __restrict__ queue);
+#endif
 
 // Records of the sequences: rec[n][tau * D + fe] = pre * x~[n][tau][fe]  (increments == 1: x~[tau] - x~[tau-1], row 0
 // zero; columns fe >= d_eff zero), then rec[n][L * D + tau] = |pre * x~[n][tau]|^2; the tail up to rec_elems is zero-filled here.
-static __global__ void prep_seq_tile_records_kernel(const double* __restrict__ X, int64_t N, int L, ScaleParams P, double pre,
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void prep_seq_tile_records_kernel(const double* __restrict__ X, int64_t N, int L, ScaleParams P, double pre,
                                              int increments, int D, int rec_elems, double* __restrict__ out) {
     const int d_eff = P.d_eff();
     const int64_t total = N * int64_t(rec_elems);
@@ -614,11 +641,16 @@ static __global__ void prep_seq_tile_records_kernel(const double* __restrict__ X
         out[idx] = v;
     }
 }
+#else
+__global__ void prep_seq_tile_records_kernel(const double* __restrict__ X, int64_t N, int L, ScaleParams P, double pre,
+                                             int increments, int D, int rec_elems, double* __restrict__ out);
+#endif
 
 // Rows of the sequences for the forward tile kernel (TvsTileArgs::XR): row[n * L + tau][fe] = pre * x~[n][tau][fe]  (increments == 1:
 // x~[tau] - x~[tau-1], row 0 of a sequence zero; columns fe >= d_eff zero), row[.][D] = |pre * x~[n][tau]|^2, the rest of the RS doubles and the one
 // extra row behind the last sequence zero.
-static __global__ void prep_seq_tile_rows_kernel(const double* __restrict__ X, int64_t N, int L, ScaleParams P, double pre,
+#ifdef GPSIG_KERNEL_DEFS          // defined once, in kernel_defs.hip; every other unit sees the declaration
+__global__ void prep_seq_tile_rows_kernel(const double* __restrict__ X, int64_t N, int L, ScaleParams P, double pre,
                                                  int increments, int D, int RS, double* __restrict__ out) {
     const int d_eff = P.d_eff();
     const int64_t total = (N * int64_t(L) + 1) * RS;
@@ -643,5 +675,9 @@ static __global__ void prep_seq_tile_rows_kernel(const double* __restrict__ X, i
         out[idx] = v;
     }
 }
+#else
+__global__ void prep_seq_tile_rows_kernel(const double* __restrict__ X, int64_t N, int L, ScaleParams P, double pre,
+                                                 int increments, int D, int RS, double* __restrict__ out);
+#endif
 
 }  // namespace gpsig

@@ -799,7 +799,7 @@ def test_tile_kernel_for_many_tensors(K, base, incr):
     try:
         for T, N, nw, diff, M, d in ((70, 37, 1, True, 4, 5), (130, 83, 2, True, 4, 5), (64, 16, 2, False, 4, 6), (33, 49, 1, False, 3, 4),
                                      (65, 21, 3, True, 5, 3), (40, 17, 0, True, 5, 6), (40, 35, 0, True, 2, 8), (64, 33, 3, True, 6, 4),
-                                     (50, 20, 0, False, 6, 7), (200, 150, 0, True, 4, 6), (520, 70, 0, True, 3, 4), (70, 300, 3, True, 4, 6)):
+                                     (50, 20, 0, False, 6, 7), (200, 150, 0, True, 4, 6), (520, 70, 0, True, 3, 4), (70, 300, 2, True, 4, 6)):
             X = np.cumsum(0.3 * rng.standard_normal((N, L, d)), axis=1).reshape(N, -1)
             Z = 0.7 * rng.standard_normal((M * (M + 1) // 2, T, 2, d) if incr else (M * (M + 1) // 2, T, d))
             kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, difference=diff, lengthscales=0.6 + rng.random(d),
