@@ -980,7 +980,16 @@ class SignatureKernelModule(torch.nn.Module):
         if self.feature_route != "always" and self._spec.order == 1 and (work is None or work < self.feature_route_min_work):
             return None                                # (order > 1: the higher-order recursion kernels lose at every size -- 3.5 -> 2.0 ms at a minibatch of 50)
         n, l, d = Xs.shape
-        if not _SigFeatures.ld(self._spec, d, l):
+        ld = _SigFeatures.ld(self._spec, d, l)
+        if not ld:
+            return None
+        # the (n, ld) feature buffer (37k doubles per sequence at d = 8, num_levels = 5) must fit beside what is already allocated: a large-n Kdiag
+        # or normalisation that needs O(n * levels) memory through the recursion kernels must not run out through this route (whatever the order)
+        try:
+            free_b, _ = torch.cuda.mem_get_info(Xs.device)
+        except Exception:  # noqa: BLE001
+            free_b = None
+        if free_b is not None and 2.5 * 8.0 * n * ld > free_b:     # features, their gradient and a working copy
             return None
         Phi = _SigFeatures.apply(Xs, self._spec)
         self._phi_memo = ((self._phi_memo or ())[-1:]) + ((Xs, Phi),)         # the evaluation's last two sets of sequences
@@ -1085,6 +1094,17 @@ class SignatureKernelModule(torch.nn.Module):
     def _w(self):
         return self.sigma * self.variances                                                          # kernels.py:471
 
+    def _w_host(self, w):
+        """The level weights on the host for the one-op level sum (the C ABI takes them by value): the copy is a blocking device-to-host
+        synchronisation, so it is made once per VALUE of the parameters -- keyed on their tensors' version counters, which every in-place
+        optimiser update bumps -- instead of once per forward pass."""
+        key = (self.raw_sigma.data_ptr(), self.raw_sigma._version, self.raw_variances.data_ptr(), self.raw_variances._version)
+        held = getattr(self, "_w_host_memo", None)
+        if held is None or held[0] != key:
+            held = (key, _SeqGramSum.weights_on_host(w))
+            self._w_host_memo = held
+        return held[1]
+
     # ---- low-rank mode ---------------------------------------------------------------------------------------------
     def draw_low_rank(self, num_points):
         """The value-independent random objects of one evaluation over ``num_points`` points (``kern.rng``, as ``kern.draw_low_rank``):
@@ -1124,7 +1144,7 @@ class SignatureKernelModule(torch.nn.Module):
             # the linear / cosine kernel's level sum and its gradient as one op through the feature space (no level arrays)
             if _SeqGramSum.applies(Xs, X2s, self._spec, self.kern.normalization):
                 w = self._w()
-                return _SeqGramSum.apply(Xs, X2s, w, _SeqGramSum.weights_on_host(w), self._spec, self.kern.normalization)
+                return _SeqGramSum.apply(Xs, X2s, w, self._w_host(w), self._spec, self.kern.normalization)
         if X2 is None:
             self._lr_open(lr, Xs)
             K = self._seq_levels(Xs)

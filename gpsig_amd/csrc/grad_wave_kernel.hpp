@@ -442,7 +442,11 @@ __global__ void __launch_bounds__(64) seq_grad_wave2_kernel(const Wave2Args A) {
 // switch (1024 x 1024 RBF Gram: 56 -> 34 ms for the sweeps).
 #ifndef LAM_UNDO_WAVES
 #define LAM_UNDO_WAVES 1        // wavefronts per SIMD the sweeps are compiled for.  2: the 256 registers cost 12 scratch accesses per step of either
-                                // sweep -- K(X) forward + backward of 1,024 sequences at the headline shape 48.3 -> 77.4 ms (round 5, same box)
+                                // sweep -- K(X) forward + backward of 1,024 sequences at the headline shape 48.3 -> 77.4 ms (round 5, same box).
+                                // Also tried there: the sweeps' five kernel values per row through the table-driven exp in hand-scheduled pairs
+                                // (exp_pair_asm.hpp): 20 % fewer vector instructions (274 -> 214 / 375 -> 328 per step) and SLOWER, 48.8 -> 51.1 ms --
+                                // at one wavefront per SIMD the table reads' latency is exposed where the library exps interleave (68.7 ms with two
+                                // waves).  The sweeps need a per-lane state that fits two wavefronts per SIMD before anything else pays.
 #endif
 template <int G, int C, int DP, int LQ, int MODE, bool MX = false, int KIND = -1>
 __global__ void __launch_bounds__(64, LAM_UNDO_WAVES) seq_lam_undo_kernel(const Wave2Args A) {

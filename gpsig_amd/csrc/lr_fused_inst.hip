@@ -6,12 +6,10 @@ namespace gpsig {
 namespace {
 template <int THREADS, int UNROLL>
 int launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, size_t lds) {
-    static size_t allowed = 0;                       // dynamic LDS beyond 64 KB has to be requested once per process and kernel
-    if (lds > allowed) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_seq_features_fused_kernel<THREADS, UNROLL>),
+    if (lds > 48 * 1024) {                           // dynamic LDS beyond the default has to be requested: per launch (no process-wide cache of what
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lr_seq_features_fused_kernel<THREADS, UNROLL>),   // one device was granted)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return int(e);
-        allowed = lds;
     }
     hipLaunchKernelGGL((lr_seq_features_fused_kernel<THREADS, UNROLL>), dim3(grid), dim3(THREADS), lds, stream, A);
     return int(hipGetLastError());
@@ -32,12 +30,10 @@ int lr_fused_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid, int
 
 int lr_fused2_launch(hipStream_t stream, const LrFusedArgs& A, unsigned grid) {
     const size_t lds = sizeof(double) * size_t(A.lp) * 2 * size_t(A.rows_b);
-    static size_t allowed = 0;
     auto kern = lr_seq_features_fused2_kernel<512, 8>;
-    if (lds > allowed) {
+    if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return int(e);
-        allowed = lds;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, A);
     return int(hipGetLastError());

@@ -199,12 +199,10 @@ int gpsig_lr_seq_features_grad(gpsig_ctx* c, const gpsig_params* p, int32_t cc, 
     A.rows_b = std::max(std::max(std::max(cc, r), d), 16);
     // one workgroup per CU at these LDS sizes: 1024 threads give the scalar loads of the projections' entries twice the wavefronts to hide behind
     const bool wide = c->lr_grad_threads != 512;
-    static size_t allowed[2] = {0, 0};
+    // (set on every launch that needs it, like sig_feat_grad_launch: a process-wide cache of the granted size would be wrong on a second device
+    // and racy between contexts)
     const void* kern = wide ? reinterpret_cast<const void*>(lr_seq_features_grad_kernel<1024>) : reinterpret_cast<const void*>(lr_seq_features_grad_kernel<512>);
-    if (lds > allowed[wide ? 1 : 0]) {
-        HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-        allowed[wide ? 1 : 0] = lds;
-    }
+    if (lds > 48 * 1024) HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
     if (wide) hipLaunchKernelGGL(lr_seq_features_grad_kernel<1024>, dim3(grid), dim3(1024), lds, c->stream, A);
     else hipLaunchKernelGGL(lr_seq_features_grad_kernel<512>, dim3(grid), dim3(512), lds, c->stream, A);
     HIPCHK(c, hipGetLastError());

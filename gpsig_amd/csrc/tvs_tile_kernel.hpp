@@ -24,6 +24,7 @@
 
 #include "aux_kernels.hpp"
 #include "fast_exp.hpp"
+#include "exp_pair_asm.hpp"
 #include "tvs_plan.hpp"
 
 namespace gpsig {
@@ -58,7 +59,7 @@ __device__ __forceinline__ double tvs_exp2(double t, const double* etab) {
 constexpr bool tvs_is_matern(int kind) { return kind == BASE_MATERN12 || kind == BASE_MATERN32 || kind == BASE_MATERN52; }
 constexpr double tvs_matern_c(int kind) { return kind == BASE_MATERN12 ? 1.0 : (kind == BASE_MATERN32 ? 1.7320508075688772935 : 2.2360679774997896964); }
 constexpr double TVS_LN2 = 0x1.62e42fefa39efp-1;
-constexpr double tvs_matern_prescale(int kind, bool two_points) { return tvs_matern_c(kind) * double(tvs_etab_n(two_points)) / TVS_LN2; }
+constexpr double tvs_matern_prescale(int kind, bool two_points) { return tvs_matern_c(kind) * double(tvs_etab_n(two_points) == 32 ? 1024 : tvs_etab_n(two_points)) / TVS_LN2; }
 constexpr int TVS_TILE_S = 16;           // sequences per output flush: 16 doubles = one 128-byte line per tensor row
 constexpr int TVS_REC_ALIGN = 128;       // (records of the reverse pass, tvs_grad_tile_kernel.hpp: granule of its LDS-DMA staging)
 // A sequence's record is L rows of RS = D + 1 doubles: the D prepared features and the squared norm of the row's POINT, read by scalar loads
@@ -129,62 +130,8 @@ inline size_t tvs_tile_lds_bytes(int M, int P, bool sum_levels, bool two_points)
     return sizeof(double) * (tvs_etab_doubles(two_points) + size_t(TVS_WG_WAVES) * tvs_tile_slots(M, P, sum_levels) * 64 * (TVS_TILE_S + 1));
 }
 
-// ---- The table-driven 2^(t/N) of fast_exp.hpp (kexp2_tabn / kexp2_tab256: same operations, same order, same bits) for TWO arguments at once, as one
-// block of hand-scheduled instructions: both roundings and both table reads first, the polynomial tails while the reads are in flight, one wait.
-// Left to the compiler each exp is one dependent chain that issues its read behind its tail and waits for it at once (and any attempt to steer it
-// with sched_barrier spilled the tensors' components).  11 vector instructions per exp.  tab: LDS byte address of the table (a scalar).
-// NEG: the arguments are -t0, -t1 (the Matern families hand in q = s r and want 2^(-q/N): the sign rides on the source modifiers).
-#define TVS_EXP2_HEAD(SGN, BITS)                                                                        \
-    "v_rndne_f64 %[r0], " SGN "%[t0]\n\tv_rndne_f64 %[r1], " SGN "%[t1]\n\t"                         \
-    "v_cvt_i32_f64 %[i0], %[r0]\n\tv_cvt_i32_f64 %[i1], %[r1]\n\t"                                    \
-    "v_bfe_u32 %[a0], %[i0], 0, " BITS "\n\tv_bfe_u32 %[a1], %[i1], 0, " BITS "\n\t"                  \
-    "v_lshl_add_u32 %[a0], %[a0], 3, %[tab]\n\tv_lshl_add_u32 %[a1], %[a1], 3, %[tab]\n\t"            \
-    "ds_read_b64 %[e0], %[a0]\n\tds_read_b64 %[e1], %[a1]\n\t"                                        \
-    "v_add_f64 %[r0], " SGN "%[t0], -%[r0]\n\tv_add_f64 %[r1], " SGN "%[t1], -%[r1]\n\t"
-#define TVS_EXP2_TAIL(BITS)                                                                             \
-    "v_mul_f64 %[r0], %[q0], %[r0]\n\tv_mul_f64 %[r1], %[q1], %[r1]\n\t"                              \
-    "v_ashrrev_i32 %[i0], " BITS ", %[i0]\n\tv_ashrrev_i32 %[i1], " BITS ", %[i1]\n\t"                \
-    "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
-    "v_fma_f64 %[e0], %[e0], %[r0], %[e0]\n\tv_fma_f64 %[e1], %[e1], %[r1], %[e1]\n\t"                \
-    "v_ldexp_f64 %[e0], %[e0], %[i0]\n\tv_ldexp_f64 %[e1], %[e1], %[i1]"
-#define TVS_EXP2_DEG3                                                                                   \
-    "v_fma_f64 %[q0], %[c3], %[r0], %[c2]\n\tv_fma_f64 %[q1], %[c3], %[r1], %[c2]\n\t"                \
-    "v_fma_f64 %[q0], %[q0], %[r0], %[c1]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c1]\n\t"
-#define TVS_EXP2_DEG4                                                                                   \
-    "v_fma_f64 %[q0], %[c4], %[r0], %[c3]\n\tv_fma_f64 %[q1], %[c4], %[r1], %[c3]\n\t"                \
-    "v_fma_f64 %[q0], %[q0], %[r0], %[c2]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c2]\n\t"                \
-    "v_fma_f64 %[q0], %[q0], %[r0], %[c1]\n\tv_fma_f64 %[q1], %[q1], %[r1], %[c1]\n\t"
-#define TVS_EXP2_OUTS [e0] "=&v"(e0), [e1] "=&v"(e1), [r0] "=&v"(r0), [r1] "=&v"(r1), [q0] "=&v"(q0), [q1] "=&v"(q1), [i0] "=&v"(i0), [i1] "=&v"(i1), \
-                      [a0] "=&v"(a0), [a1] "=&v"(a1)
 template <int N, bool NEG = false>
-__device__ __forceinline__ void tvs_exp2_pair(double t0, double t1, unsigned tab, double& e0, double& e1) {
-    static_assert(N == 256 || N == 1024 || N == 2048, "table sizes with an asm form");
-    double r0, r1, q0, q1;
-    int i0, i1, a0, a1;
-    if constexpr (N == 256) {
-        const double c4 = 0x1.3b2ab6fba4e77p-39, c3 = 0x1.c6b08d704a0c0p-29, c2 = 0x1.ebfbdff82c58fp-19, c1 = 0x1.62e42fefa39efp-9;
-        if constexpr (NEG)
-            asm volatile(TVS_EXP2_HEAD("-", "8") TVS_EXP2_DEG4 TVS_EXP2_TAIL("8") : TVS_EXP2_OUTS
-                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c4] "s"(c4), [c3] "v"(c3), [c2] "s"(c2), [c1] "s"(c1));
-        else
-            asm volatile(TVS_EXP2_HEAD("", "8") TVS_EXP2_DEG4 TVS_EXP2_TAIL("8") : TVS_EXP2_OUTS
-                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c4] "s"(c4), [c3] "v"(c3), [c2] "s"(c2), [c1] "s"(c1));
-    } else {
-        const double c3 = ExpTabN<N>::C3, c2 = ExpTabN<N>::C2, c1 = ExpTabN<N>::C1;
-        if constexpr (N == 1024 && NEG)
-            asm volatile(TVS_EXP2_HEAD("-", "10") TVS_EXP2_DEG3 TVS_EXP2_TAIL("10") : TVS_EXP2_OUTS
-                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3), [c2] "v"(c2), [c1] "s"(c1));
-        else if constexpr (N == 1024)
-            asm volatile(TVS_EXP2_HEAD("", "10") TVS_EXP2_DEG3 TVS_EXP2_TAIL("10") : TVS_EXP2_OUTS
-                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3), [c2] "v"(c2), [c1] "s"(c1));
-        else if constexpr (NEG)
-            asm volatile(TVS_EXP2_HEAD("-", "11") TVS_EXP2_DEG3 TVS_EXP2_TAIL("11") : TVS_EXP2_OUTS
-                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3), [c2] "v"(c2), [c1] "s"(c1));
-        else
-            asm volatile(TVS_EXP2_HEAD("", "11") TVS_EXP2_DEG3 TVS_EXP2_TAIL("11") : TVS_EXP2_OUTS
-                         : [t0] "v"(t0), [t1] "v"(t1), [tab] "s"(tab), [c3] "s"(c3), [c2] "v"(c2), [c1] "s"(c1));
-    }
-}
+__device__ __forceinline__ void tvs_exp2_pair(double t0, double t1, unsigned tab, double& e0, double& e1) { kexp2_pair_asm<N, NEG>(t0, t1, tab, e0, e1); }
 
 // The families the run-time-family instance (KIND == -1) still serves -- cosine, poly, mix; linear, RBF and the Matern families have instances of
 // their own -- evaluated like base_eval_n of seq_core.hpp, whose switch over all nine families (library pow, exp and sqrt per value, unrolled)
@@ -295,8 +242,8 @@ struct TvsTileWave {
             }
         } else if constexpr (tvs_is_matern(KIND)) {
             constexpr int NTAB = tvs_etab_n(E == 2);
-            static_assert(NTAB == 256 || NTAB == 1024 || NTAB == 2048, "exp table sizes with an asm form");
-            constexpr double S = tvs_matern_prescale(KIND, E == 2), K = TVS_LN2 / NTAB;       // u = c r = q K
+            constexpr int NRES = NTAB == 32 ? 1024 : NTAB;                                      // (the two-level A/B table has the 1,024-entry one's resolution)
+            constexpr double S = tvs_matern_prescale(KIND, E == 2), K = TVS_LN2 / NRES;       // u = c r = q K
             const unsigned tab_addr = __builtin_amdgcn_readfirstlane(unsigned(uintptr_t((__attribute__((address_space(3))) const void*)(etab))));
 #pragma unroll
             for (int p0 = 0; p0 < NC * E; p0 += 2) {
@@ -313,7 +260,10 @@ struct TvsTileWave {
                     r = fma(fma(-r, r, d), h, r);                                              // one Newton step on the residual: ~1.5 ulp
                     g[q] = r;
                 }
-                if (p0 + 1 < NC * E) {
+                if constexpr (NTAB == 32 || NTAB == 64) {
+                    ev[0] = tvs_exp2<NTAB>(-g[0], etab);
+                    if (p0 + 1 < NC * E) ev[1] = tvs_exp2<NTAB>(-g[1], etab);
+                } else if (p0 + 1 < NC * E) {
                     tvs_exp2_pair<NTAB, true>(g[0], g[1], tab_addr, ev[0], ev[1]);            // 2^(-q / N)
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                 } else ev[0] = tvs_exp2<NTAB>(-g[0], etab);
