@@ -331,12 +331,19 @@ def measure_pmc(cfg, base, increments, counters, lattice=False, timeout_s=240):
             kname, kgrid = max(tot, key=tot.get)                      # the dominant kernel: the largest share of device time
             vals = sorted(v for did, v in per.items() if info[did][:2] == (kname, kgrid))
             got[counter] = vals[len(vals) // 2]
+            durs = sorted(info[did][2] for did in per if info[did][:2] == (kname, kgrid))
+            got.setdefault("durations_ns", []).extend(durs)
             meta = (kname, kgrid, len(vals))
         except Exception:
             return None
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    got.update({"kernel": meta[0], "grid": meta[1], "dispatches": meta[2]})
+    durs = sorted(got.pop("durations_ns", []))
+    got.update({"kernel": meta[0], "grid": meta[1], "dispatches": meta[2],
+                # the dominant kernel's duration as the PROFILER saw it (median / mean over these passes' dispatches): a profiled launch runs at
+                # a lower clock than an un-profiled one (MI355X_MICROARCH.md, DVFS), so fractions from it are the pessimistic end
+                "kernel_us_profiled_median": (durs[len(durs) // 2] * 1e-3) if durs else None,
+                "kernel_us_profiled_mean": (sum(durs) / len(durs) * 1e-3) if durs else None})
     return got
 
 
@@ -348,7 +355,8 @@ def measure_traffic(cfg, base, increments, lattice=False):
         return None
     return {"fetch_size_kib": got["FETCH_SIZE"], "write_size_kib": got["WRITE_SIZE"],
             "bytes_per_launch": got["FETCH_SIZE"] * 2.0 * 1024.0 + got["WRITE_SIZE"] * 1024.0,
-            "kernel": got["kernel"], "grid": got["grid"], "dispatches": got["dispatches"]}
+            "kernel": got["kernel"], "grid": got["grid"], "dispatches": got["dispatches"],
+            "kernel_us_profiled_median": got["kernel_us_profiled_median"], "kernel_us_profiled_mean": got["kernel_us_profiled_mean"]}
 
 
 # issue_frac = how much of the SIMDs' issue time the dominant kernel's vector instructions fill at the clock measured during the run: float64
@@ -615,6 +623,10 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
                                 "served from L2 / LDS, `traffic` is what the memory side saw, `bound` names what limits the kernel"
                                 + ("" if stream_frac <= 1.0 else "; above 1 here (a sequence record is staged once per 64 tensors), so it is not printed as a fraction of HBM"),
                      "traffic": tr, "traffic_source": tr_src,
+                     # the same fraction with the kernel's duration as rocprofv3 recorded it in the traffic passes (mean over their dispatches):
+                     # `frac` is from HIP events of un-profiled launches -- the two bracket what a reader of profiles/ will compute
+                     "frac_profiled": ((mfma["flops_per_launch"] / (tr_src["kernel_us_profiled_mean"] * 1e-6) / 1e12 / FP64_MATRIX_PEAK_TFLOPS)
+                                       if (mfma and tr_src and tr_src.get("kernel_us_profiled_mean")) else None),
                      "kernel": kernel_name, "kernel_ms_per_launch": per_launch_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_pair": b_pair, "pairs_per_launch": pairs_launch,
                      "alu": {"executed_flops_per_evaluated_pair": f_exec, "evaluated_pairs_per_launch": evaluated_launch,

@@ -1,0 +1,379 @@
+// grad_fused_kernel.hpp -- reverse pass of the sequence-vs-sequence Gram for the RBF base kernel on points with differences
+// (SignatureRBF, order 1: gpsig/kernels.py:188-237 + signature_algs.py:8-35 differentiated), without Lam ever leaving the chip (round 5).
+//
+// A workgroup is TWO wavefronts working on the same four sequence pairs (four register-side sequences r0 .. r0+3, one per 16-lane
+// pair group, against a run of streamed sequences s they share; lane ln of a group owns the lattice columns 4 ln .. 4 ln + 3):
+//   wavefront 0, the EVALUATOR: keeps the lane's points of y, evaluates the kernel row of the step (table-driven exp on prescaled
+//       points), hands the double increments dm of the lane's columns to the sweeper, and -- in the backward sweep -- takes Lam
+//       back, differences it to the adjoint of the kernel values (H), multiplies by the kernel's derivative and contracts both
+//       sides: the y side into per-lane accumulators that live for the whole run, the x side as a partial row sum that travels
+//       from lane to lane with the skew of the sweep (one DPP shift per word and step) and leaves lane 0 into an LDS accumulator.
+//   wavefront 1, the SWEEPER: the forward recursion (WaveFwd) and its undoing (WaveUndo) of grad_wave_core.hpp, dm in, Lam out.
+// The two exchange dm / Lam through same-lane LDS slots, double buffered, one workgroup barrier per step; the kernel values a
+// contraction needs were evaluated four intervals earlier and wait in a five-deep same-lane ring.  Split this way each
+// wavefront's state fits the 256 registers of two wavefronts per SIMD, which the one-wavefront form (seq_lam_undo_kernel:
+// 256 + AGPRs, one wavefront per SIMD, Lam through HBM to lam_contract_kernel) does not.
+// The interval schedule is replayed lane by lane in tools/sim_fused_grad.py against autograd of the plain recursion.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fast_exp.hpp"
+#include "grad_wave_core.hpp"
+#include "grad_wave_kernel.hpp"
+#include "seq_args.hpp"
+
+namespace gpsig {
+
+struct FusedGradArgs {
+    const double* S; const double* R;      // streamed side / register-resident side, scaled observations, user layout (N, L, d)
+    double* gS; double* gR;                // their gradients, same layout, accumulated with atomics (the same array for a symmetric Gram)
+    int NS, NR, LS, LR, d;
+    const SeqTask* tasks;                  // y0 = first of four register-side sequences, x0 / nx = run of streamed sequences
+    const double* G; int64_t gm, gs, gr;   // upstream: G[m * gm + s * gs + r * gr], m = 1 .. M
+    int sym;                               // symmetric Gram: pairs s >= r only, s > r carries G[s][r] + G[r][s]
+};
+
+constexpr int FG_G = 16, FG_C = 4, FG_PW = 4, FG_KH = 5;
+
+// offsets (in doubles) into the dynamic LDS of one workgroup
+struct FusedLds { int etab, xs, gxa, rt, dm, lam, kh, total; };
+__host__ __device__ inline FusedLds fused_lds(int LS, int R1, int DP, int LQ) {
+    FusedLds o;
+    const int DS = DP + 2;                 // record row: DP prescaled features, -|x'|^2 / 2, one pad (rows 16-byte aligned, bank-conflict free)
+    int p = 0;
+    o.etab = p; p += EXP_TAB256_N;
+    o.xs = p; p += LS * DS;
+    o.gxa = p; p += LS * DS;
+    o.rt = p; p += FG_PW * (R1 > 0 ? R1 : 1) * LQ;
+    p = (p + 1) & ~1;
+    o.dm = p; p += 2 * FG_C * 64;          // [parity][half][lane] pairs of doubles
+    o.lam = p; p += 2 * FG_C * 64;
+    o.kh = p; p += FG_KH * FG_C * 64;
+    o.total = p;
+    return o;
+}
+
+typedef double fg_d2 __attribute__((ext_vector_type(2)));
+
+// kernel values of record row `xrow` (LDS) against the lane's C + 1 points
+template <int DP>
+__device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&y)[FG_C + 1][DP], const double (&hy)[FG_C + 1], const double* etab,
+                                             double (&k)[FG_C + 1]) {
+    double x[DP];
+#pragma unroll
+    for (int f = 0; f < DP; f += 2) {
+        const fg_d2 v = *reinterpret_cast<const fg_d2*>(xrow + f);
+        x[f] = v[0]; x[f + 1] = v[1];
+    }
+    const double hx = xrow[DP];
+#pragma unroll
+    for (int c = 0; c <= FG_C; ++c) {
+        double t = hx + hy[c];
+#pragma unroll
+        for (int f = 0; f < DP; ++f) t = fma(x[f], y[c][f], t);
+        k[c] = kexp2_tab256(t, etab);
+    }
+}
+
+__device__ __forceinline__ void fg_put(double* slot, int par, int lane, const double (&v)[FG_C]) {
+    fg_d2* s = reinterpret_cast<fg_d2*>(slot) + par * 2 * 64 + lane;
+    s[0] = fg_d2{v[0], v[1]};
+    s[64] = fg_d2{v[2], v[3]};
+}
+__device__ __forceinline__ void fg_get(const double* slot, int par, int lane, double (&v)[FG_C]) {
+    const fg_d2* s = reinterpret_cast<const fg_d2*>(slot) + par * 2 * 64 + lane;
+    const fg_d2 a = s[0], b = s[64];
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+}
+
+// Both wavefronts: the record of streamed sequence s -- prescaled rows and -|x'|^2 / 2 -- and a cleared x-side accumulator.
+template <int DP>
+__device__ __forceinline__ void fg_stage(const FusedGradArgs& A, double* sm, const FusedLds o, int64_t s) {
+    constexpr int DS = DP + 2;
+    for (int p = threadIdx.x; p < A.LS; p += 128) {
+        const double* src = A.S + (s * A.LS + p) * A.d;
+        double* xr = sm + o.xs + p * DS;
+        double* gr = sm + o.gxa + p * DS;
+        double hs = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) {
+            const double v = f < A.d ? src[f] * EXP_PRESCALE256 : 0.0;
+            xr[f] = v;
+            gr[f] = 0.0;
+            hs = fma(v, v, hs);
+        }
+        xr[DP] = -0.5 * hs;
+        xr[DP + 1] = 0.0;
+        gr[DP] = gr[DP + 1] = 0.0;
+    }
+}
+// Both wavefronts, after the last backward interval: gx[p] = (sum_q W[p][q]) x_p - sum_q W[p][q] y_q, back in the caller's scale.
+template <int DP>
+__device__ __forceinline__ void fg_flush(const FusedGradArgs& A, const double* sm, const FusedLds o, int64_t s) {
+    constexpr int DS = DP + 2;
+    constexpr double inv = 1.0 / EXP_PRESCALE256;
+    for (int e = threadIdx.x; e < A.LS * DP; e += 128) {
+        const int p = e / DP, f = e % DP;
+        if (f < A.d) {
+            const double* xr = sm + o.xs + p * DS;
+            const double* gr = sm + o.gxa + p * DS;
+            atomicAdd(&A.gS[(s * A.LS + p) * A.d + f], fma(gr[DP], xr[f], -gr[f]) * inv);
+        }
+    }
+}
+
+// ---- wavefront 0 ----------------------------------------------------------------------------------------------------------------
+template <int DP>
+__device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
+    constexpr int C = FG_C, G = FG_G, DS = DP + 2;
+    const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
+    const double* etab = sm + o.etab;
+    const double* xs = sm + o.xs;
+    double* gxa = sm + o.gxa;
+    const int64_t r = int64_t(tk.y0) + gw;
+    const bool rvalid = r < A.NR;
+    const int b0 = C * ln;
+    int nvalid = R2 - b0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
+
+    double y[C + 1][DP], hy[C + 1], ay[C][DP], by[C];
+#pragma unroll
+    for (int c = 0; c <= C; ++c) {
+        const int q = b0 + c;
+        const bool ok = rvalid && q < A.LR;
+        const double* src = A.R + ((rvalid ? r : 0) * A.LR + (ok ? q : 0)) * A.d;
+        double s = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) {
+            const double v = (ok && f < A.d) ? src[f] * EXP_PRESCALE256 : 0.0;
+            y[c][f] = v;
+            s = fma(v, v, s);
+        }
+        hy[c] = -0.5 * s;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        by[c] = 0.0;
+#pragma unroll
+        for (int f = 0; f < DP; ++f) ay[c][f] = 0.0;
+    }
+    const int lsm1 = A.LS - 1;
+    auto row_of = [&](int p) { return xs + (p < 0 ? 0 : (p > lsm1 ? lsm1 : p)) * DS; };
+
+    for (int it = 0; it < tk.nx; ++it) {
+        const int64_t s = int64_t(tk.x0) + it;
+        __syncthreads();                       // the flush of the previous streamed sequence has read gxa / xs
+        fg_stage<DP>(A, sm, o, s);
+        __syncthreads();
+        // ---- forward sweep: dm of step i in interval i
+        double rd[C];
+        {
+            double k[C + 1];
+            fg_kappa_row<DP>(row_of(0), y, hy, etab, k);
+#pragma unroll
+            for (int c = 0; c < C; ++c) rd[c] = k[c + 1] - k[c];
+        }
+        for (int i = 0; i <= TF; ++i) {
+            if (i < TF) {
+                const int a = i - ln;
+                const bool act = a >= 0 && a < R1;
+                double k[C + 1], dm[C];
+                fg_kappa_row<DP>(row_of(a + 1), y, hy, etab, k);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double nd = k[c + 1] - k[c];
+                    dm[c] = (act && c < nvalid) ? nd - rd[c] : 0.0;
+                    rd[c] = act ? nd : rd[c];
+                }
+                fg_put(sm + o.dm, i & 1, lane, dm);
+            }
+            __syncthreads();
+        }
+        // ---- backward sweep.  Interval i: kernel row of step i - 1 (the lane's row a = R1 + (G-1-ln) - i; a == R1 only primes rd);
+        // the sweeper runs step i - 2; the contraction takes Lam of step i - 3 and the kernel values of interval i - 4.
+        double lamk[C], ep[C], P[DP + 1];
+#pragma unroll
+        for (int c = 0; c < C; ++c) lamk[c] = ep[c] = 0.0;
+#pragma unroll
+        for (int f = 0; f <= DP; ++f) P[f] = 0.0;
+        int wr = 0;                            // i % FG_KH
+        for (int i = 0; i <= TF + 4; ++i) {
+            if (i <= TF) {
+                const int a = R1 + (G - 1 - ln) - i;
+                const bool in = a >= 0 && a <= R1;
+                double k[C + 1], dm[C], kk[C];
+                fg_kappa_row<DP>(row_of(a), y, hy, etab, k);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double nd = k[c + 1] - k[c];
+                    dm[c] = (in && a < R1 && c < nvalid) ? rd[c] - nd : 0.0;
+                    rd[c] = in ? nd : rd[c];
+                    kk[c] = k[c];
+                }
+                fg_put(sm + o.dm, i & 1, lane, dm);
+                fg_put(sm + o.kh, wr, lane, kk);
+            }
+            if (i >= 3) {
+                const int a = R1 - 1 - ((i - 3) - (G - 1 - ln));
+                const bool real = i <= TF + 2 && a >= 0 && a < R1;
+                double li[C], h[C], w[C], kp[C];
+                fg_get(sm + o.lam, (i - 1) & 1, lane, li);
+                fg_get(sm + o.kh, wr + 1 >= FG_KH ? wr + 1 - FG_KH : wr + 1, lane, kp);          // interval i - 4
+                double en[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    li[c] = (real && c < nvalid) ? li[c] : 0.0;
+                    en[c] = li[c] - lamk[c];
+                    lamk[c] = li[c];
+                }
+                const double eleft = wave_from_left<G>(en[C - 1]);
+                h[0] = eleft - ep[0];
+#pragma unroll
+                for (int c = 1; c < C; ++c) h[c] = ep[c - 1] - ep[c];
+#pragma unroll
+                for (int c = 0; c < C; ++c) ep[c] = en[c];
+                const int p = a + 2;
+                const bool ok = p >= 0 && p <= R1;
+#pragma unroll
+                for (int c = 0; c < C; ++c) w[c] = ok ? -(h[c] * kp[c]) : 0.0;
+                // y side: the lane's own points
+                {
+                    const double* xr = row_of(p);
+                    double x[DP];
+#pragma unroll
+                    for (int f = 0; f < DP; f += 2) {
+                        const fg_d2 v = *reinterpret_cast<const fg_d2*>(xr + f);
+                        x[f] = v[0]; x[f + 1] = v[1];
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        by[c] += w[c];
+#pragma unroll
+                        for (int f = 0; f < DP; ++f) ay[c][f] = fma(w[c], x[f], ay[c][f]);
+                    }
+                }
+                // x side: the row sum over the group's points, handed from right to left with the skew of the sweep
+#pragma unroll
+                for (int f = 0; f <= DP; ++f) P[f] = wave_from_right<G>(P[f]);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    P[DP] += w[c];
+#pragma unroll
+                    for (int f = 0; f < DP; ++f) P[f] = fma(w[c], y[c][f], P[f]);
+                }
+                if (ln == 0 && ok) {
+                    double* gr = gxa + p * DS;
+#pragma unroll
+                    for (int f = 0; f <= DP; ++f) atomicAdd(gr + f, P[f]);
+                }
+            }
+            wr = wr + 1 == FG_KH ? 0 : wr + 1;
+            __syncthreads();
+        }
+        fg_flush<DP>(A, sm, o, s);
+    }
+    if (rvalid) {
+        constexpr double inv = 1.0 / EXP_PRESCALE256;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int q = b0 + c;
+            if (q < A.LR) {
+#pragma unroll
+                for (int f = 0; f < DP; ++f)
+                    if (f < A.d) atomicAdd(&A.gR[(r * A.LR + q) * A.d + f], fma(by[c], y[c][f], -ay[c][f]) * inv);
+            }
+        }
+    }
+}
+
+// ---- wavefront 1 ----------------------------------------------------------------------------------------------------------------
+template <int DP, int LQ>
+__device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
+    constexpr int C = FG_C, G = FG_G, M = LQ + 1;
+    const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
+    double* rt = sm + o.rt + gw * (R1 > 0 ? R1 : 1) * LQ;
+    const int64_t r = int64_t(tk.y0) + gw;
+    const bool rvalid = r < A.NR;
+    const int last_lane = R2 > 0 ? (R2 - 1) / C : 0;
+
+    for (int it = 0; it < tk.nx; ++it) {
+        const int64_t s = int64_t(tk.x0) + it;
+        const bool have = rvalid && (!A.sym || s >= r);
+        double clev[LQ + 2];
+#pragma unroll
+        for (int p = 0; p < LQ + 2; ++p) {
+            double v = 0.0;
+            if (have && p >= 1 && p <= M) {
+                v = A.G[p * A.gm + s * A.gs + r * A.gr];
+                if (A.sym && s != r) v += A.G[p * A.gm + r * A.gs + s * A.gr];
+            }
+            clev[p] = v;
+        }
+        __syncthreads();
+        fg_stage<DP>(A, sm, o, s);
+        __syncthreads();
+        WaveFwd<C, LQ> fw;
+        fw.reset();
+        for (int i = 0; i <= TF; ++i) {
+            if (i >= 1) {
+                double cin[LQ + 2];
+                cin[0] = 0.0;
+#pragma unroll
+                for (int m = 1; m < LQ + 2; ++m) cin[m] = wave_from_left<G>(fw.sout[m]);
+                const int a = (i - 1) - ln;
+                if (a >= 0 && a < R1) {
+                    double dm[C];
+                    fg_get(sm + o.dm, (i - 1) & 1, lane, dm);
+                    fw.step(dm, cin, M);
+                    if (ln == last_lane) {
+#pragma unroll
+                        for (int m = 1; m <= LQ; ++m) rt[a * LQ + m - 1] = fw.sout[m];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        WaveUndo<C, LQ> bw;
+        bw.init(fw);
+        for (int i = 0; i <= TF + 4; ++i) {
+            if (i >= 2 && i <= TF + 1) {
+                double sufin[LQ], svin[LQ];
+#pragma unroll
+                for (int p = 0; p < LQ; ++p) {
+                    sufin[p] = wave_from_right<G>(bw.sufout[p]);
+                    svin[p] = wave_from_right<G>(bw.svout[p]);
+                }
+                const int a = R1 - 1 - ((i - 2) - (G - 1 - ln));
+                if (a >= 0 && a < R1) {
+                    double dm[C], rtv[LQ], lv[C];
+                    fg_get(sm + o.dm, (i - 1) & 1, lane, dm);
+#pragma unroll
+                    for (int p = 0; p < LQ; ++p) rtv[p] = rt[a * LQ + p];
+                    bw.step(dm, clev, rtv, sufin, svin, M, a == 0, ln == 0, lv);
+                    fg_put(sm + o.lam, i & 1, lane, lv);
+                }
+            }
+            __syncthreads();
+        }
+        fg_flush<DP>(A, sm, o, s);
+    }
+}
+
+// grid: one workgroup of 128 threads per task; dynamic LDS: fused_lds(LS, LS - 1, DP, LQ).total doubles
+template <int DP, int LQ>
+__global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double fg_sm[];
+    const int R1 = A.LS - 1, R2 = A.LR - 1, TF = R1 + FG_G - 1;
+    const FusedLds o = fused_lds(A.LS, R1, DP, LQ);
+    const SeqTask tk = A.tasks[blockIdx.x];
+    const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
+    exp_tab256_fill(fg_sm + o.etab, int(threadIdx.x), 128);
+    // Both wavefronts run the same barrier sequence: per streamed sequence two around the staging of its record (fg_stage), then
+    // TF + 1 forward and TF + 5 backward intervals; the flush of the x side (fg_flush) is covered by the next sequence's first barrier.
+    if (role == 0) fg_evaluator<DP>(A, tk, fg_sm, o, R1, R2, TF);
+    else fg_sweeper<DP, LQ>(A, tk, fg_sm, o, R1, R2, TF);
+}
+
+}  // namespace gpsig

@@ -1,0 +1,272 @@
+"""Lock-step model of grad_fused_kernel.hpp (round 5): the two-role reverse pass of one sequence pair, in numpy.
+
+One pair group = G lanes of C lattice columns.  Two wavefronts work on it: the EVALUATOR (base-kernel values of a row of the
+streamed sequence against the lane's points, the double increments dm, and -- in the backward sweep -- the contraction of
+Lam with the kernel's derivative for both sides) and the SWEEPER (forward recursion, then the recursion undone row by row,
+Lam out).  They exchange dm / Lam through same-lane slots, one barrier per interval.  This script replays the intervals with
+arrays over lanes, DPP shifts as shifted copies, and checks the gradients against torch autograd of the plain recursion.
+
+Run: python tools/sim_fused_grad.py
+"""
+import numpy as np
+import torch
+
+G, C = 16, 4
+
+
+def from_left(v):      # lane l <- lane l-1, 0 into lane 0
+    out = np.zeros_like(v)
+    out[1:] = v[:-1]
+    return out
+
+
+def from_right(v):     # lane l <- lane l+1, 0 into the last lane
+    out = np.zeros_like(v)
+    out[:-1] = v[1:]
+    return out
+
+
+def reference(x, y, clev):
+    """levels of the first-order signature kernel with the RBF base kernel on points, and d sum_m clev[m] K_m / d(x, y)"""
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yt = torch.tensor(y, dtype=torch.float64, requires_grad=True)
+    d2 = (xt * xt).sum(1)[:, None] + (yt * yt).sum(1)[None, :] - 2 * xt @ yt.T
+    k = torch.exp(-d2 / 2)
+    dm = k[1:, 1:] - k[1:, :-1] - k[:-1, 1:] + k[:-1, :-1]
+    M = len(clev) - 1
+    Rm = dm
+    loss = clev[1] * Rm.sum()
+    for m in range(2, M + 1):
+        Q = Rm.cumsum(0).cumsum(1)
+        Qs = torch.zeros_like(Q)
+        Qs[1:, 1:] = Q[:-1, :-1]
+        Rm = dm * Qs
+        loss = loss + clev[m] * Rm.sum()
+    loss.backward()
+    return xt.grad.numpy(), yt.grad.numpy()
+
+
+def fused(x, y, clev):
+    L1, D = x.shape
+    L2 = y.shape[0]
+    R1, R2 = L1 - 1, L2 - 1
+    M = len(clev) - 1
+    LQ = M - 1
+    TF = R1 + G - 1
+    ln = np.arange(G)
+    b0 = C * ln
+    nvalid = np.clip(R2 - b0, 0, C)
+    last_lane = (R2 - 1) // C
+    cs = np.sqrt(np.log2(np.e))
+    xs = x * cs                                  # staged record: prescaled rows and -|x'|^2 / 2
+    hx = -0.5 * (xs * xs).sum(1)
+    # evaluator: the lane's C + 1 points (beyond the sequence: zeros)
+    yp = np.zeros((G, C + 1, D))
+    for c in range(C + 1):
+        q = b0 + c
+        ok = q < L2
+        yp[ok, c] = y[q[ok]] * cs
+    hy = -0.5 * (yp * yp).sum(2)
+
+    def kappa_row(p):                            # p: per-lane row index (clamped), -> (G, C+1)
+        pc = np.clip(p, 0, L1 - 1)
+        return np.exp2(np.einsum('lf,lcf->lc', xs[pc], yp) + hx[pc][:, None] + hy)
+
+    def mask_cols(v):
+        out = v.copy()
+        for c in range(C):
+            out[nvalid <= c, c] = 0.0
+        return out
+
+    # ---------------- forward sweep: evaluator one interval ahead of the sweeper
+    dmslot = np.zeros((2, G, C))
+    q = np.zeros((G, LQ, C)); qg = np.zeros((G, LQ)); sout = np.zeros((G, LQ + 2))
+    rowtot = np.zeros((R1, LQ))
+    k0 = kappa_row(np.zeros(G, int))
+    rd = k0[:, 1:] - k0[:, :-1]
+    for tau in range(TF + 1):
+        # evaluator, step tau
+        if tau < TF:
+            a = tau - ln
+            act = (a >= 0) & (a < R1)
+            k = kappa_row(a + 1)
+            nd = k[:, 1:] - k[:, :-1]
+            dm = mask_cols(nd - rd)
+            rd = np.where(act[:, None], nd, rd)
+            dmslot_new = np.where(act[:, None], dm, 0.0)
+        # sweeper, step tau - 1 (reads the slot the evaluator filled in the previous interval)
+        if tau >= 1:
+            t = tau - 1
+            a = t - ln
+            act = (a >= 0) & (a < R1)
+            dm_in = dmslot[t % 2]
+            cin = np.zeros((G, LQ + 2))
+            for m in range(1, LQ + 2):
+                cin[:, m] = from_left(sout[:, m])
+            qn, qgn, soutn = q.copy(), qg.copy(), sout.copy()
+            for m in range(LQ + 1, 1, -1):
+                if m <= M:
+                    lo = m - 2
+                    s = cin[:, m].copy()
+                    for c in range(C):
+                        s = s + dm_in[:, c] * (qg[:, lo] if c == 0 else q[:, lo, c - 1])
+                        if m < M:
+                            qn[:, m - 1, c] = q[:, m - 1, c] + s
+                    soutn[:, m] = s
+                    if m < M:
+                        qgn[:, m - 1] = qg[:, m - 1] + cin[:, m]
+            s = cin[:, 1].copy()
+            for c in range(C):
+                s = s + dm_in[:, c]
+                if 1 < M:
+                    qn[:, 0, c] = q[:, 0, c] + s
+            soutn[:, 1] = s
+            if 1 < M:
+                qgn[:, 0] = qg[:, 0] + cin[:, 1]
+            # (the order above follows WaveFwd::step: level m reads level m-1's OLD q -- qn keeps them apart)
+            q = np.where(act[:, None, None], qn, q); qg = np.where(act[:, None], qgn, qg); sout = np.where(act[:, None], soutn, sout)
+            if act[last_lane]:
+                for m in range(1, LQ + 1):
+                    rowtot[a[last_lane], m - 1] = sout[last_lane, m] if m < M else 0.0
+        if tau < TF:
+            dmslot[tau % 2] = dmslot_new
+    levels = None
+
+    # ---------------- backward sweep
+    qf, qfg = q.copy(), qg.copy()
+    qb = np.zeros((G, LQ, C)); qbg = np.zeros((G, LQ)); svout = np.zeros((G, LQ)); sufout = np.zeros((G, LQ))
+    lamslot = np.zeros((2, G, C))
+    KH = 8
+    khist = np.full((KH, G, C), np.nan)           # same-lane ring keyed by the point row
+    kR = kappa_row(np.full(G, R1))
+    rd = kR[:, 1:] - kR[:, :-1]
+    khist[R1 % KH] = kR[:, :C]
+    lamk = np.zeros((G, C)); Eprev = np.zeros((G, C)); Pout = np.zeros((G, D + 1))
+    Ay = np.zeros((G, C, D)); By = np.zeros((G, C))
+    gxa = np.zeros((L1, D + 1))
+    for ups in range(TF + 4):
+        # ---- evaluator, eval part: step ups
+        if ups < TF:
+            a = R1 - 1 - (ups - (G - 1 - ln))
+            act = (a >= 0) & (a < R1)
+            k = kappa_row(a)
+            nd = k[:, 1:] - k[:, :-1]
+            dm = mask_cols(rd - nd)
+            rd = np.where(act[:, None], nd, rd)
+            dm_new = np.where(act[:, None], dm, 0.0)
+            for l in range(G):
+                if act[l]:
+                    khist[a[l] % KH, l] = k[l, :C]
+        # ---- evaluator, contraction part: Lam of sweeper step v = ups - 2
+        if ups >= 2:
+            v = ups - 2
+            a = R1 - 1 - (v - (G - 1 - ln))
+            lam_in = np.where(((a >= 0) & (a < R1))[:, None], mask_cols(lamslot[v % 2]), 0.0) if v < TF else np.zeros((G, C))
+            Enew = lam_in - lamk
+            lamk = lam_in
+            Eleft = from_left(Enew[:, C - 1])
+            H = np.zeros((G, C))
+            H[:, 0] = Eleft - Eprev[:, 0]
+            for c in range(1, C):
+                H[:, c] = Eprev[:, c - 1] - Eprev[:, c]
+            Eprev = Enew
+            p = a + 2
+            ok = (p >= 0) & (p <= R1)
+            pc = np.clip(p, 0, L1 - 1)
+            kp = np.stack([khist[pc[l] % KH, l] for l in range(G)])
+            W = np.where(ok[:, None], -H * kp, 0.0)
+            Ay += W[:, :, None] * xs[pc][:, None, :]
+            By += W
+            Pin = from_right(Pout)
+            Pout = Pin.copy()
+            Pout[:, :D] += np.einsum('lc,lcf->lf', W, yp[:, :C])
+            Pout[:, D] += W.sum(1)
+            if ok[0]:
+                gxa[p[0]] += Pout[0]
+        # ---- sweeper: step ups - 1
+        if 1 <= ups <= TF:
+            u = ups - 1
+            a = R1 - 1 - (u - (G - 1 - ln))
+            act = (a >= 0) & (a < R1)
+            dm_in = dmslot[u % 2]
+            sufin = np.stack([from_right(sufout[:, p_]) for p_ in range(LQ)], 1)
+            svin = np.stack([from_right(svout[:, p_]) for p_ in range(LQ)], 1)
+            rt = rowtot[np.clip(a, 0, R1 - 1)]
+            first_row = a == 0
+            first_lane = ln == 0
+            qfn, qfgn, sufn = qf.copy(), qfg.copy(), sufout.copy()
+            Dm = np.ones((G, LQ + 1, C))
+            for m in range(1, LQ + 1):
+                if m < M:
+                    vv = sufin[:, m - 1] - rt[:, m - 1]
+                    for c in range(C - 1, -1, -1):
+                        qfn[:, m - 1, c] = qf[:, m - 1, c] + vv
+                        vv = vv + dm_in[:, c] * Dm[:, m - 1, c]
+                    qfgn[:, m - 1] = qfg[:, m - 1] + vv
+                    sufn[:, m - 1] = vv + rt[:, m - 1]
+                for c in range(C):
+                    dd = qfgn[:, m - 1] if c == 0 else qfn[:, m - 1, c - 1]
+                    dd = np.where(first_row | (first_lane & (c == 0)) | (m >= M), 0.0, dd)
+                    Dm[:, m, c] = dd
+            U = np.zeros((G, LQ + 2, C))
+            for p_ in range(1, LQ + 2):
+                for c in range(C):
+                    pi = min(p_ - 1, LQ - 1)
+                    if p_ < M:
+                        U[:, p_, c] = clev[p_] + (qb[:, pi, c + 1] if c < C - 1 else qbg[:, pi])
+                    else:
+                        U[:, p_, c] = clev[p_] if p_ == M else 0.0
+            lam = np.zeros((G, C))
+            for c in range(C):
+                l_ = U[:, 1, c].copy()
+                for p_ in range(2, LQ + 2):
+                    if p_ <= M:
+                        l_ = l_ + Dm[:, p_ - 1, c] * U[:, p_, c]
+                lam[:, c] = l_
+            qbn, qbgn, svn = qb.copy(), qbg.copy(), svout.copy()
+            for p_ in range(1, LQ + 1):
+                if p_ < M:
+                    sv = svin[:, p_ - 1].copy()
+                    for c in range(C - 1, -1, -1):
+                        sv = sv + dm_in[:, c] * U[:, p_ + 1, c]
+                        qbn[:, p_ - 1, c] = qb[:, p_ - 1, c] + sv
+                    svn[:, p_ - 1] = sv
+                    qbgn[:, p_ - 1] = qbg[:, p_ - 1] + svin[:, p_ - 1]
+            A3, A2 = act[:, None, None], act[:, None]
+            qf = np.where(A3, qfn, qf); qfg = np.where(A2, qfgn, qfg); sufout = np.where(A2, sufn, sufout)
+            qb = np.where(A3, qbn, qb); qbg = np.where(A2, qbgn, qbg); svout = np.where(A2, svn, svout)
+            lam_new = np.where(A2, lam, 0.0)
+        if ups < TF:
+            dmslot[ups % 2] = dm_new
+        if 1 <= ups <= TF:
+            lamslot[(ups - 1) % 2] = lam_new
+    # flush
+    gx = (gxa[:, D:D + 1] * xs - gxa[:, :D]) / cs
+    gy = np.zeros_like(y)
+    for l in range(G):
+        for c in range(C):
+            qq = b0[l] + c
+            if qq < L2:
+                gy[qq] += (By[l, c] * yp[l, c] - Ay[l, c]) / cs
+    return gx, gy
+
+
+def main():
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for (L1, L2, D, M) in ((64, 64, 8, 5), (9, 64, 8, 4), (64, 33, 4, 3), (5, 7, 3, 2), (20, 62, 8, 5), (3, 2, 2, 3), (40, 64, 8, 1)):
+        x = np.cumsum(rng.standard_normal((L1, D)) * 0.3, 0)
+        y = np.cumsum(rng.standard_normal((L2, D)) * 0.3, 0)
+        clev = np.concatenate([[0.0], rng.standard_normal(M)])
+        gx0, gy0 = reference(x, y, clev)
+        gx1, gy1 = fused(x, y, clev)
+        ex = np.abs(gx1 - gx0).max() / max(np.abs(gx0).max(), 1e-300)
+        ey = np.abs(gy1 - gy0).max() / max(np.abs(gy0).max(), 1e-300)
+        print(f"L1={L1} L2={L2} d={D} M={M}: rel err x {ex:.2e}  y {ey:.2e}")
+        worst = max(worst, ex, ey)
+    print("worst", worst)
+    assert worst < 1e-9
+
+
+if __name__ == "__main__":
+    main()
