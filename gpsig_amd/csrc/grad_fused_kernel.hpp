@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "exp_pair_asm.hpp"
 #include "fast_exp.hpp"
 #include "grad_wave_core.hpp"
 #include "grad_wave_kernel.hpp"
@@ -57,11 +58,12 @@ __host__ __device__ inline FusedLds fused_lds(int LS, int R1, int DP, int LQ) {
 
 typedef double fg_d2 __attribute__((ext_vector_type(2)));
 
-// kernel values of record row `xrow` (LDS) against the lane's C + 1 points
-template <int DP>
+// kernel values of record row `xrow` (LDS) against points P0 .. P0 + NP - 1 of the lane: 2^(t / 256) with t = x'.y' - |x'|^2 / 2 - |y'|^2 / 2,
+// two at a time through the hand-scheduled table exp (exp_pair_asm.hpp), an odd last one through the plain routine
+template <int DP, int P0, int NP>
 __device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&y)[FG_C + 1][DP], const double (&hy)[FG_C + 1], const double* etab,
-                                             double (&k)[FG_C + 1]) {
-    double x[DP];
+                                             unsigned tab_addr, double (&k)[FG_C + 1]) {
+    double x[DP], t[NP];
 #pragma unroll
     for (int f = 0; f < DP; f += 2) {
         const fg_d2 v = *reinterpret_cast<const fg_d2*>(xrow + f);
@@ -69,12 +71,17 @@ __device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&
     }
     const double hx = xrow[DP];
 #pragma unroll
-    for (int c = 0; c <= FG_C; ++c) {
-        double t = hx + hy[c];
+    for (int c = 0; c < NP; ++c) {
+        t[c] = hx + hy[P0 + c];
 #pragma unroll
-        for (int f = 0; f < DP; ++f) t = fma(x[f], y[c][f], t);
-        k[c] = kexp2_tab256(t, etab);
+        for (int f = 0; f < DP; ++f) t[c] = fma(x[f], y[P0 + c][f], t[c]);
     }
+#pragma unroll
+    for (int c = 0; c + 1 < NP; c += 2) {
+        kexp2_pair_asm<256>(t[c], t[c + 1], tab_addr, k[P0 + c], k[P0 + c + 1]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // the block waited for its table reads: tell the compiler's counters
+    }
+    if constexpr (NP & 1) k[P0 + NP - 1] = kexp2_tab256(t[NP - 1], etab);
 }
 
 __device__ __forceinline__ void fg_put(double* slot, int par, int lane, const double (&v)[FG_C]) {
@@ -135,19 +142,19 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
     const int64_t r = int64_t(tk.y0) + gw;
     const bool rvalid = r < A.NR;
     const int b0 = C * ln;
-    int nvalid = R2 - b0;
-    nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
+    const unsigned tab_addr = __builtin_amdgcn_readfirstlane(unsigned(uintptr_t((__attribute__((address_space(3))) const void*)(etab))));
 
+    // The lane's points b0 .. b0 + C.  Beyond the sequence the LAST point repeats: the columns there get dm == 0 exactly (equal
+    // arguments, equal kernel values) without a mask in the evaluation.
     double y[C + 1][DP], hy[C + 1], ay[C][DP], by[C];
 #pragma unroll
     for (int c = 0; c <= C; ++c) {
-        const int q = b0 + c;
-        const bool ok = rvalid && q < A.LR;
-        const double* src = A.R + ((rvalid ? r : 0) * A.LR + (ok ? q : 0)) * A.d;
+        const int q = b0 + c < A.LR ? b0 + c : A.LR - 1;
+        const double* src = A.R + ((rvalid ? r : 0) * A.LR + q) * A.d;
         double s = 0.0;
 #pragma unroll
         for (int f = 0; f < DP; ++f) {
-            const double v = (ok && f < A.d) ? src[f] * EXP_PRESCALE256 : 0.0;
+            const double v = (rvalid && f < A.d) ? src[f] * EXP_PRESCALE256 : 0.0;
             y[c][f] = v;
             s = fma(v, v, s);
         }
@@ -168,76 +175,58 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         fg_stage<DP>(A, sm, o, s);
         __syncthreads();
         // ---- forward sweep: dm of step i in interval i
+        // (a lane ahead of its first row evaluates row 0 again and again -- row_of clamps -- so rd needs no guard; what it hands over outside
+        // its rows the sweeper does not read)
         double rd[C];
         {
             double k[C + 1];
-            fg_kappa_row<DP>(row_of(0), y, hy, etab, k);
+            fg_kappa_row<DP, 0, C + 1>(row_of(0), y, hy, etab, tab_addr, k);
 #pragma unroll
             for (int c = 0; c < C; ++c) rd[c] = k[c + 1] - k[c];
         }
         for (int i = 0; i <= TF; ++i) {
             if (i < TF) {
-                const int a = i - ln;
-                const bool act = a >= 0 && a < R1;
                 double k[C + 1], dm[C];
-                fg_kappa_row<DP>(row_of(a + 1), y, hy, etab, k);
+                fg_kappa_row<DP, 0, C + 1>(row_of(i - ln + 1), y, hy, etab, tab_addr, k);
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const double nd = k[c + 1] - k[c];
-                    dm[c] = (act && c < nvalid) ? nd - rd[c] : 0.0;
-                    rd[c] = act ? nd : rd[c];
+                    dm[c] = nd - rd[c];
+                    rd[c] = nd;
                 }
                 fg_put(sm + o.dm, i & 1, lane, dm);
             }
             __syncthreads();
         }
-        // ---- backward sweep.  Interval i: kernel row of step i - 1 (the lane's row a = R1 + (G-1-ln) - i; a == R1 only primes rd);
-        // the sweeper runs step i - 2; the contraction takes Lam of step i - 3 and the kernel values of interval i - 4.
-        double lamk[C], ep[C], P[DP + 1];
-#pragma unroll
-        for (int c = 0; c < C; ++c) lamk[c] = ep[c] = 0.0;
+        // ---- backward sweep.  Interval i: the kernel row a = R1 + (G-1-ln) - i of the lane (a == R1 primes rd; beyond it row R1 again),
+        // points b0 .. b0+3 only: the value at b0+4 is the right neighbour's first, one interval old (it runs one row ahead).  The
+        // sweeper takes dm in interval i + 1 and hands back W = -H * kappa (the adjoint of the kernel values times the kernel's
+        // derivative, formed there) of point row p = a + 4 in interval i + 2; it is contracted here in interval i + 3.
+        double k0 = 0.0, P[DP + 1];
 #pragma unroll
         for (int f = 0; f <= DP; ++f) P[f] = 0.0;
         int wr = 0;                            // i % FG_KH
         for (int i = 0; i <= TF + 4; ++i) {
             if (i <= TF) {
-                const int a = R1 + (G - 1 - ln) - i;
-                const bool in = a >= 0 && a <= R1;
                 double k[C + 1], dm[C], kk[C];
-                fg_kappa_row<DP>(row_of(a), y, hy, etab, k);
+                k[C] = wave_from_right<G>(k0);
+                fg_kappa_row<DP, 0, C>(row_of(R1 + (G - 1 - ln) - i), y, hy, etab, tab_addr, k);
+                if (ln == G - 1) k[C] = k[C - 1];      // no neighbour: column 63 is never a lattice column (at most 64 points), dm == 0 there
+                k0 = k[0];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const double nd = k[c + 1] - k[c];
-                    dm[c] = (in && a < R1 && c < nvalid) ? rd[c] - nd : 0.0;
-                    rd[c] = in ? nd : rd[c];
+                    dm[c] = rd[c] - nd;
+                    rd[c] = nd;
                     kk[c] = k[c];
                 }
                 fg_put(sm + o.dm, i & 1, lane, dm);
                 fg_put(sm + o.kh, wr, lane, kk);
             }
             if (i >= 3) {
-                const int a = R1 - 1 - ((i - 3) - (G - 1 - ln));
-                const bool real = i <= TF + 2 && a >= 0 && a < R1;
-                double li[C], h[C], w[C], kp[C];
-                fg_get(sm + o.lam, (i - 1) & 1, lane, li);
-                fg_get(sm + o.kh, wr + 1 >= FG_KH ? wr + 1 - FG_KH : wr + 1, lane, kp);          // interval i - 4
-                double en[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    li[c] = (real && c < nvalid) ? li[c] : 0.0;
-                    en[c] = li[c] - lamk[c];
-                    lamk[c] = li[c];
-                }
-                const double eleft = wave_from_left<G>(en[C - 1]);
-                h[0] = eleft - ep[0];
-#pragma unroll
-                for (int c = 1; c < C; ++c) h[c] = ep[c - 1] - ep[c];
-#pragma unroll
-                for (int c = 0; c < C; ++c) ep[c] = en[c];
-                const int p = a + 2;
-                const bool ok = p >= 0 && p <= R1;
-#pragma unroll
-                for (int c = 0; c < C; ++c) w[c] = ok ? -(h[c] * kp[c]) : 0.0;
+                const int p = R1 + 4 + (G - 1 - ln) - i;
+                double w[C];
+                fg_get(sm + o.lam, (i - 1) & 1, lane, w);           // zeros outside the lattice's point rows
                 // y side: the lane's own points
                 {
                     const double* xr = row_of(p);
@@ -263,7 +252,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
 #pragma unroll
                     for (int f = 0; f < DP; ++f) P[f] = fma(w[c], y[c][f], P[f]);
                 }
-                if (ln == 0 && ok) {
+                if (ln == 0 && p >= 0 && p <= R1) {
                     double* gr = gxa + p * DS;
 #pragma unroll
                     for (int f = 0; f <= DP; ++f) atomicAdd(gr + f, P[f]);
@@ -297,6 +286,8 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
     const int64_t r = int64_t(tk.y0) + gw;
     const bool rvalid = r < A.NR;
     const int last_lane = R2 > 0 ? (R2 - 1) / C : 0;
+    int nvalid = R2 - C * ln;
+    nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
 
     for (int it = 0; it < tk.nx; ++it) {
         const int64_t s = int64_t(tk.x0) + it;
@@ -337,24 +328,55 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
         }
         WaveUndo<C, LQ> bw;
         bw.init(fw);
+        // Interval i: step i - 2 of the undoing sweep (row a of the lane), then the adjoint of the kernel values from Lam:
+        //   E[p][b] = Lam[p-1][b] - Lam[p][b]  (formed for p = a + 1 as the rows come, Lam == 0 outside the lattice),
+        //   H[p][q] = E[p][q-1] - E[p][q]      (for p = a + 2: the left neighbour's last column is one interval behind),
+        //   W = -H * kappa(x_p, y_q)           (kappa from the evaluator's ring: evaluated in interval i - 3),
+        // handed to the evaluator for every lane and interval it reads (zeros outside the point rows 0 .. R1).
+        double lamk[C], ep[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) lamk[c] = ep[c] = 0.0;
+        int rdk = FG_KH - 3;                   // (i - 3) % FG_KH
         for (int i = 0; i <= TF + 4; ++i) {
-            if (i >= 2 && i <= TF + 1) {
-                double sufin[LQ], svin[LQ];
+            if (i >= 2 && i <= TF + 3) {
+                double sufin[LQ], svin[LQ], lv[C];
 #pragma unroll
                 for (int p = 0; p < LQ; ++p) {
                     sufin[p] = wave_from_right<G>(bw.sufout[p]);
                     svin[p] = wave_from_right<G>(bw.svout[p]);
                 }
                 const int a = R1 - 1 - ((i - 2) - (G - 1 - ln));
-                if (a >= 0 && a < R1) {
-                    double dm[C], rtv[LQ], lv[C];
+                const bool act = a >= 0 && a < R1;
+#pragma unroll
+                for (int c = 0; c < C; ++c) lv[c] = 0.0;
+                if (act) {
+                    double dm[C], rtv[LQ];
                     fg_get(sm + o.dm, (i - 1) & 1, lane, dm);
 #pragma unroll
                     for (int p = 0; p < LQ; ++p) rtv[p] = rt[a * LQ + p];
                     bw.step(dm, clev, rtv, sufin, svin, M, a == 0, ln == 0, lv);
-                    fg_put(sm + o.lam, i & 1, lane, lv);
                 }
+                double en[C], h[C], w[C], kp[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double li = (act && c < nvalid) ? lv[c] : 0.0;
+                    en[c] = li - lamk[c];
+                    lamk[c] = li;
+                }
+                const double eleft = wave_from_left<G>(en[C - 1]);
+                h[0] = eleft - ep[0];
+#pragma unroll
+                for (int c = 1; c < C; ++c) h[c] = ep[c - 1] - ep[c];
+#pragma unroll
+                for (int c = 0; c < C; ++c) ep[c] = en[c];
+                const int p = a + 2;
+                const bool ok = p >= 0 && p <= R1;
+                fg_get(sm + o.kh, rdk, lane, kp);
+#pragma unroll
+                for (int c = 0; c < C; ++c) w[c] = ok ? -(h[c] * kp[c]) : 0.0;
+                fg_put(sm + o.lam, i & 1, lane, w);
             }
+            rdk = rdk + 1 == FG_KH ? 0 : rdk + 1;
             __syncthreads();
         }
         fg_flush<DP>(A, sm, o, s);
@@ -372,8 +394,12 @@ __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradA
     exp_tab256_fill(fg_sm + o.etab, int(threadIdx.x), 128);
     // Both wavefronts run the same barrier sequence: per streamed sequence two around the staging of its record (fg_stage), then
     // TF + 1 forward and TF + 5 backward intervals; the flush of the x side (fg_flush) is covered by the next sequence's first barrier.
+#if defined(FG_ONLY_ROLE)          // register count of one role alone (compile-time experiment; such a kernel deadlocks at its first barrier)
+    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ>(A, tk, fg_sm, o, R1, R2, TF); }
+#else
     if (role == 0) fg_evaluator<DP>(A, tk, fg_sm, o, R1, R2, TF);
     else fg_sweeper<DP, LQ>(A, tk, fg_sm, o, R1, R2, TF);
+#endif
 }
 
 }  // namespace gpsig

@@ -11,8 +11,18 @@ them is a committed test instead of a note in a log:
     5.6e-3 against 1e-4): stored with the float64 oracle's values.  Round 5 evaluates float32 requests on one-column state spaces in float64
     (gpsig_amd/kernels.py, _f32_upcast), so they are held to the float32 tolerance again.
 
-Replays the sweep's random stream (tools/fuzz_parity.draw_case: no GPU needed); the 80-bit Gram takes about two minutes.
-    python tests/golden/make_fuzz_cases.py        -> tests/golden/fuzz_cases.npz"""
+Round 5's sweeps (seeds 71 and 72 with the rebuilt Kzx tile kernel, profiles/r05_fuzz.txt: 2,500 cases, 3 above tolerance, all float32) add a
+second file, fuzz_cases_r5.npz:
+  * seed 71, case 779 -- float32, SignatureLinear, order 5, ONE column, 16 / 90 observations: evaluated in float64 by the product (the class
+    above) and 8.7e-7 from the 80-bit values, while the float64 ORACLE is 2.3e-3 away from them: the miss was the oracle's.  Stored with both.
+  * seed 71 case 255 and seed 72 case 298 -- float32, SignatureCosine, inducing tensors against sequences of TWO / THREE observations,
+    normalised: 1.7e-4 / 3.9e-4 on the matrix scale.  The cosine kernel's values are ratios of float32 inner products and the levels of such a
+    short sequence are a handful of their double increments: float32 arithmetic, not a defect of a kernel.  Stored with the float64 oracle's
+    values; the test states 1e-3 for this class.
+
+Replays the sweep's random stream (tools/fuzz_parity.draw_case: no GPU needed); the 80-bit Grams take about two minutes each.
+    python tests/golden/make_fuzz_cases.py           -> tests/golden/fuzz_cases.npz
+    python tests/golden/make_fuzz_cases.py round5    -> tests/golden/fuzz_cases_r5.npz"""
 import os
 import sys
 
@@ -62,5 +72,34 @@ def main():
     print("wrote", len(names), "cases")
 
 
+def round5():
+    out, names = {}, []
+    for seed, picks in ((71, {255: "kzx", 779: "kx80"}), (72, {298: "kzx"})):
+        rng = np.random.default_rng(seed)
+        for it in range(max(picks) + 1):
+            cs = F.draw_case(rng)
+            if it not in picks:
+                continue
+            key = "s%dc%d" % (seed, it)
+            names.append(key)
+            X, X2, Z = (cs[k].astype(np.float64) for k in ("Xq", "X2q", "Zq"))
+            ko = F.oracle_for(cs)
+            out[key + "_X"], out[key + "_X2"], out[key + "_Z"] = cs["Xq"], cs["X2q"], cs["Zq"]
+            out[key + "_ls"], out[key + "_var"] = cs["kw"]["lengthscales"], cs["kw"]["variances"]
+            out[key + "_meta"] = np.array([cs["M"], cs["order"], cs["d"], cs["lags"], cs["L1"], cs["L2"], int(cs["norm"]), int(cs["diff"]), int(cs["f32"]),
+                                           int(cs["incr"]), cs["T"]], dtype=np.int64)
+            out[key + "_base"] = np.array(cs["base"])
+            if picks[it] == "kzx":
+                out[key + "_Kzx"] = ko.K_tens_vs_seq(Z, X, increments=cs["incr"])
+            else:
+                cross = (lambda k, a, b: k.K(a, b)) if cs["L1"] == cs["L2"] else (lambda k, a, b: F._cross(k, a, b, cs["d"]))
+                out[key + "_Kx"] = cross(ko, X, X2)
+                out[key + "_Kx80"] = np.asarray(cross(F.oracle_for(cs, np.longdouble), X.astype(np.longdouble), X2.astype(np.longdouble)), dtype=np.float64)
+            print(key, cs["desc"], flush=True)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "fuzz_cases_r5.npz"), **out)
+    print("wrote", len(names), "cases")
+
+
 if __name__ == "__main__":
-    main()
+    round5() if sys.argv[1:2] == ["round5"] else main()
