@@ -58,12 +58,12 @@ __host__ __device__ inline FusedLds fused_lds(int LS, int R1, int DP, int LQ) {
 
 typedef double fg_d2 __attribute__((ext_vector_type(2)));
 
-// kernel values of record row `xrow` (LDS) against points P0 .. P0 + NP - 1 of the lane: 2^(t / 256) with t = x'.y' - |x'|^2 / 2 - |y'|^2 / 2,
-// two at a time through the hand-scheduled table exp (exp_pair_asm.hpp), an odd last one through the plain routine
-template <int DP, int P0, int NP>
-__device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&y)[FG_C + 1][DP], const double (&hy)[FG_C + 1], const double* etab,
-                                             unsigned tab_addr, double (&k)[FG_C + 1]) {
-    double x[DP], t[NP];
+// kernel values of record row `xrow` (LDS) against the lane's four points: 2^(t / 256) with t = x'.y' - |x'|^2 / 2 - |y'|^2 / 2, two at a time
+// through the hand-scheduled table exp (exp_pair_asm.hpp)
+template <int DP>
+__device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&y)[FG_C][DP], const double (&hy)[FG_C], unsigned tab_addr, double (&k)[FG_C]) {
+    static_assert(FG_C % 2 == 0, "exps go in pairs");
+    double x[DP], t[FG_C];
 #pragma unroll
     for (int f = 0; f < DP; f += 2) {
         const fg_d2 v = *reinterpret_cast<const fg_d2*>(xrow + f);
@@ -71,17 +71,16 @@ __device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&
     }
     const double hx = xrow[DP];
 #pragma unroll
-    for (int c = 0; c < NP; ++c) {
-        t[c] = hx + hy[P0 + c];
+    for (int c = 0; c < FG_C; ++c) {
+        t[c] = hx + hy[c];
 #pragma unroll
-        for (int f = 0; f < DP; ++f) t[c] = fma(x[f], y[P0 + c][f], t[c]);
+        for (int f = 0; f < DP; ++f) t[c] = fma(x[f], y[c][f], t[c]);
     }
 #pragma unroll
-    for (int c = 0; c + 1 < NP; c += 2) {
-        kexp2_pair_asm<256>(t[c], t[c + 1], tab_addr, k[P0 + c], k[P0 + c + 1]);
+    for (int c = 0; c < FG_C; c += 2) {
+        kexp2_pair_asm<256>(t[c], t[c + 1], tab_addr, k[c], k[c + 1]);
         __builtin_amdgcn_s_waitcnt(0xc07f);          // the block waited for its table reads: tell the compiler's counters
     }
-    if constexpr (NP & 1) k[P0 + NP - 1] = kexp2_tab256(t[NP - 1], etab);
 }
 
 __device__ __forceinline__ void fg_put(double* slot, int par, int lane, const double (&v)[FG_C]) {
@@ -136,19 +135,18 @@ template <int DP>
 __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
     constexpr int C = FG_C, G = FG_G, DS = DP + 2;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
-    const double* etab = sm + o.etab;
     const double* xs = sm + o.xs;
     double* gxa = sm + o.gxa;
     const int64_t r = int64_t(tk.y0) + gw;
     const bool rvalid = r < A.NR;
     const int b0 = C * ln;
-    const unsigned tab_addr = __builtin_amdgcn_readfirstlane(unsigned(uintptr_t((__attribute__((address_space(3))) const void*)(etab))));
+    const unsigned tab_addr = __builtin_amdgcn_readfirstlane(unsigned(uintptr_t((__attribute__((address_space(3))) const void*)(sm + o.etab))));
 
-    // The lane's points b0 .. b0 + C.  Beyond the sequence the LAST point repeats: the columns there get dm == 0 exactly (equal
+    // The lane's points b0 .. b0 + 3.  Beyond the sequence the LAST point repeats: the columns there get dm == 0 exactly (equal
     // arguments, equal kernel values) without a mask in the evaluation.
-    double y[C + 1][DP], hy[C + 1], ay[C][DP], by[C];
+    double y[C][DP], hy[C], ay[C][DP], by[C];
 #pragma unroll
-    for (int c = 0; c <= C; ++c) {
+    for (int c = 0; c < C; ++c) {
         const int q = b0 + c < A.LR ? b0 + c : A.LR - 1;
         const double* src = A.R + ((rvalid ? r : 0) * A.LR + q) * A.d;
         double s = 0.0;
@@ -175,22 +173,31 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         fg_stage<DP>(A, sm, o, s);
         __syncthreads();
         // ---- forward sweep: dm of step i in interval i
-        // (a lane ahead of its first row evaluates row 0 again and again -- row_of clamps -- so rd needs no guard; what it hands over outside
-        // its rows the sweeper does not read)
-        double rd[C];
+        // ---- forward sweep: dm of step i in interval i.  Here the lane's four columns are b0-1 .. b0+2 -- the differences that END at its own
+        // points, the kernel value at b0-1 being the left neighbour's last, one interval old (it runs one row ahead): four evaluations per
+        // row, the evaluation kernel's convention (seq_core.hpp).  Lane 0's column -1 is no column: dm == 0 there.  A lane ahead of its first
+        // row evaluates row 0 again and again (row_of clamps), so rd needs no guard; what it hands over outside its rows the sweeper does not read.
+        double rd[C], k3;
         {
-            double k[C + 1];
-            fg_kappa_row<DP, 0, C + 1>(row_of(0), y, hy, etab, tab_addr, k);
+            double k[C];
+            fg_kappa_row<DP>(row_of(0), y, hy, tab_addr, k);
+            double kl = wave_from_left<G>(k[C - 1]);
+            if (ln == 0) kl = k[0];
+            rd[0] = k[0] - kl;
 #pragma unroll
-            for (int c = 0; c < C; ++c) rd[c] = k[c + 1] - k[c];
+            for (int c = 1; c < C; ++c) rd[c] = k[c] - k[c - 1];
+            k3 = k[C - 1];
         }
         for (int i = 0; i <= TF; ++i) {
             if (i < TF) {
-                double k[C + 1], dm[C];
-                fg_kappa_row<DP, 0, C + 1>(row_of(i - ln + 1), y, hy, etab, tab_addr, k);
+                double k[C], dm[C];
+                double kl = wave_from_left<G>(k3);
+                fg_kappa_row<DP>(row_of(i - ln + 1), y, hy, tab_addr, k);
+                if (ln == 0) kl = k[0];
+                k3 = k[C - 1];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const double nd = k[c + 1] - k[c];
+                    const double nd = k[c] - (c == 0 ? kl : k[c > 0 ? c - 1 : 0]);
                     dm[c] = nd - rd[c];
                     rd[c] = nd;
                 }
@@ -198,8 +205,9 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
             }
             __syncthreads();
         }
-        // ---- backward sweep.  Interval i: the kernel row a = R1 + (G-1-ln) - i of the lane (a == R1 primes rd; beyond it row R1 again),
-        // points b0 .. b0+3 only: the value at b0+4 is the right neighbour's first, one interval old (it runs one row ahead).  The
+        // ---- backward sweep.  The lane's columns are now b0 .. b0+3, the differences that START at its points.  Interval i: the kernel row
+        // a = R1 + (G-1-ln) - i (a == R1 primes rd; beyond it row R1 again); the value at b0+4 is the right neighbour's first, one interval
+        // old (it runs one row ahead in this direction); the last lane's column 63 is never a lattice column (at most 64 points).  The
         // sweeper takes dm in interval i + 1 and hands back W = -H * kappa (the adjoint of the kernel values times the kernel's
         // derivative, formed there) of point row p = a + 4 in interval i + 2; it is contracted here in interval i + 3.
         double k0 = 0.0, P[DP + 1];
@@ -208,20 +216,19 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         int wr = 0;                            // i % FG_KH
         for (int i = 0; i <= TF + 4; ++i) {
             if (i <= TF) {
-                double k[C + 1], dm[C], kk[C];
-                k[C] = wave_from_right<G>(k0);
-                fg_kappa_row<DP, 0, C>(row_of(R1 + (G - 1 - ln) - i), y, hy, etab, tab_addr, k);
-                if (ln == G - 1) k[C] = k[C - 1];      // no neighbour: column 63 is never a lattice column (at most 64 points), dm == 0 there
+                double k[C], dm[C];
+                double kr = wave_from_right<G>(k0);
+                fg_kappa_row<DP>(row_of(R1 + (G - 1 - ln) - i), y, hy, tab_addr, k);
+                if (ln == G - 1) kr = k[C - 1];
                 k0 = k[0];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const double nd = k[c + 1] - k[c];
+                    const double nd = (c == C - 1 ? kr : k[c < C - 1 ? c + 1 : c]) - k[c];
                     dm[c] = rd[c] - nd;
                     rd[c] = nd;
-                    kk[c] = k[c];
                 }
                 fg_put(sm + o.dm, i & 1, lane, dm);
-                fg_put(sm + o.kh, wr, lane, kk);
+                fg_put(sm + o.kh, wr, lane, k);
             }
             if (i >= 3) {
                 const int p = R1 + 4 + (G - 1 - ln) - i;
@@ -285,8 +292,7 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
     double* rt = sm + o.rt + gw * (R1 > 0 ? R1 : 1) * LQ;
     const int64_t r = int64_t(tk.y0) + gw;
     const bool rvalid = r < A.NR;
-    const int last_lane = R2 > 0 ? (R2 - 1) / C : 0;
-    int nvalid = R2 - C * ln;
+    int nvalid = R2 - C * ln;                 // lattice columns among b0 .. b0+3 (the backward sweep's)
     nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
 
     for (int it = 0; it < tk.nx; ++it) {
@@ -318,7 +324,7 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
                     double dm[C];
                     fg_get(sm + o.dm, (i - 1) & 1, lane, dm);
                     fw.step(dm, cin, M);
-                    if (ln == last_lane) {
+                    if (ln == G - 1) {                 // dm == 0 beyond the sequence: the last lane's row prefix is the row total whatever R2
 #pragma unroll
                         for (int m = 1; m <= LQ; ++m) rt[a * LQ + m - 1] = fw.sout[m];
                     }
@@ -326,13 +332,31 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
             }
             __syncthreads();
         }
+        // The forward sweep's columns were b0-1 .. b0+2 (the evaluator's forward convention), the backward sweep's are b0 .. b0+3: its state
+        // moves one column to the left, the last one arriving from the right neighbour.  The upstream gradients ride in the suffix sums from
+        // the start (U_p = c_p + Qb_p: one add per cell and level less) -- step() is handed -0.0 in their place, which the compiler folds away.
+        // Row 0's D is not forced to zero (first_row = false): the residue of the undoing there is that of any other row.
         WaveUndo<C, LQ> bw;
-        bw.init(fw);
+        double clevz[LQ + 2];
+#pragma unroll
+        for (int p = 0; p < LQ + 2; ++p) clevz[p] = p == M ? clev[p] : -0.0;
+#pragma unroll
+        for (int m = 0; m < LQ; ++m) {
+            bw.qfg[m] = fw.q[m][0];
+#pragma unroll
+            for (int c = 0; c + 1 < C; ++c) bw.qf[m][c] = fw.q[m][c + 1];
+            bw.qf[m][C - 1] = wave_from_right<G>(fw.q[m][0]);
+            bw.qbg[m] = clev[m + 1];
+#pragma unroll
+            for (int c = 0; c < C; ++c) bw.qb[m][c] = clev[m + 1];
+            bw.svout[m] = bw.sufout[m] = 0.0;
+        }
         // Interval i: step i - 2 of the undoing sweep (row a of the lane), then the adjoint of the kernel values from Lam:
         //   E[p][b] = Lam[p-1][b] - Lam[p][b]  (formed for p = a + 1 as the rows come, Lam == 0 outside the lattice),
         //   H[p][q] = E[p][q-1] - E[p][q]      (for p = a + 2: the left neighbour's last column is one interval behind),
         //   W = -H * kappa(x_p, y_q)           (kappa from the evaluator's ring: evaluated in interval i - 3),
-        // handed to the evaluator for every lane and interval it reads (zeros outside the point rows 0 .. R1).
+        // handed to the evaluator for every lane and interval it reads.  Outside the point rows 0 .. R1 H is zero by construction and the
+        // ring holds finite values (cleared at the start of the task), so W is zero there without a guard.
         double lamk[C], ep[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) lamk[c] = ep[c] = 0.0;
@@ -354,12 +378,12 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
                     fg_get(sm + o.dm, (i - 1) & 1, lane, dm);
 #pragma unroll
                     for (int p = 0; p < LQ; ++p) rtv[p] = rt[a * LQ + p];
-                    bw.step(dm, clev, rtv, sufin, svin, M, a == 0, ln == 0, lv);
+                    bw.step(dm, clevz, rtv, sufin, svin, M, false, ln == 0, lv);
                 }
                 double en[C], h[C], w[C], kp[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const double li = (act && c < nvalid) ? lv[c] : 0.0;
+                    const double li = c < nvalid ? lv[c] : 0.0;
                     en[c] = li - lamk[c];
                     lamk[c] = li;
                 }
@@ -369,11 +393,9 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
                 for (int c = 1; c < C; ++c) h[c] = ep[c - 1] - ep[c];
 #pragma unroll
                 for (int c = 0; c < C; ++c) ep[c] = en[c];
-                const int p = a + 2;
-                const bool ok = p >= 0 && p <= R1;
                 fg_get(sm + o.kh, rdk, lane, kp);
 #pragma unroll
-                for (int c = 0; c < C; ++c) w[c] = ok ? -(h[c] * kp[c]) : 0.0;
+                for (int c = 0; c < C; ++c) w[c] = -(h[c] * kp[c]);
                 fg_put(sm + o.lam, i & 1, lane, w);
             }
             rdk = rdk + 1 == FG_KH ? 0 : rdk + 1;
@@ -392,6 +414,7 @@ __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradA
     const SeqTask tk = A.tasks[blockIdx.x];
     const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
     exp_tab256_fill(fg_sm + o.etab, int(threadIdx.x), 128);
+    for (int e = threadIdx.x; e < FG_KH * FG_C * 64; e += 128) fg_sm[o.kh + e] = 0.0;
     // Both wavefronts run the same barrier sequence: per streamed sequence two around the staging of its record (fg_stage), then
     // TF + 1 forward and TF + 5 backward intervals; the flush of the x side (fg_flush) is covered by the next sequence's first barrier.
 #if defined(FG_ONLY_ROLE)          // register count of one role alone (compile-time experiment; such a kernel deadlocks at its first barrier)

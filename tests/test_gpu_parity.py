@@ -1823,17 +1823,29 @@ def fuzz_cases_r5():
 def test_round5_sweep_one_column_float32_case_and_the_oracle_it_was_judged_by(K, fuzz_cases_r5):
     """Case 779 of `tools/fuzz_parity.py 1500 71` (profiles/r05_fuzz.txt): float32, SignatureLinear, order 5, ONE column, 16 against 90
     observations, normalised -- reported 2.3e-3 above the float64 oracle.  The 80-bit evaluation of the oracle's own algorithm (stored beside
-    it) says the float64 ORACLE is the one 2.3e-3 off (the index-tuple sums of a one-column sequence cancel, as in case 187 above); the product
-    evaluates float32 requests on one-column state spaces in float64 along the per-sequence feature route and is held to the 80-bit values."""
+    it) says the float64 ORACLE is the one 2.3e-3 off (the index-tuple sums of a one-column sequence cancel, as in case 187 above) -- and so are
+    the product's float64 PAIR kernels (5e-3, the same cancellation in another order), which the planner would have picked for 19 x 12 sequences:
+    the sweep had drawn `sig_features = 1`.  Since then one-column state spaces take the per-sequence feature route whatever their size
+    (api.hip, sig_features_K), float32 requests on them are evaluated in float64, and the product is held to the 80-bit values."""
     fz, key = fuzz_cases_r5, "s71c779"
     kern, _ = _fuzz_kernel(K, fz, key)
     X, X2 = fz[key + "_X"], fz[key + "_X2"]
     assert X.dtype == np.float32
     scale = np.abs(fz[key + "_Kx80"]).max()
     assert np.abs(fz[key + "_Kx"] - fz[key + "_Kx80"]).max() / scale > 1e-3                 # the oracle's own distance
+    from gpsig_amd import _lib
+    ctx = _lib.context(0, 0)
     got = kern.K(X, X2, presliced=True)
     assert np.asarray(got).dtype == np.float32
     assert np.abs(np.asarray(got, dtype=np.float64) - fz[key + "_Kx80"]).max() / scale <= 1e-5
+    got64 = kern.K(X.astype(np.float64), X2.astype(np.float64), presliced=True)
+    assert np.abs(got64 - fz[key + "_Kx80"]).max() / scale <= TOL
+    try:
+        ctx.set_option("sig_features", 0)                   # the pair kernels: the reference's summation, cancelling like the oracle
+        pk = kern.K(X.astype(np.float64), X2.astype(np.float64), presliced=True)
+        assert np.abs(pk - fz[key + "_Kx80"]).max() / scale <= 2e-2
+    finally:
+        ctx.set_option("sig_features", -1)
 
 
 def test_round5_sweep_float32_cosine_on_sequences_of_two_or_three_observations(K, fuzz_cases_r5):

@@ -288,3 +288,15 @@ def test_torch_low_rank_restatement_equals_numpy_restatement(base, normalization
         Xp[i, j] += h; Xm[i, j] -= h
         fd = (float((kt.K(torch.tensor(Xp)) * Wm).sum()) - float((kt.K(torch.tensor(Xm)) * Wm).sum())) / (2 * h)
         assert abs(fd - g[i, j]) < 1e-5 * max(1.0, np.abs(g).max()), (i, j, fd, g[i, j])
+
+
+def test_lane_level_model_of_the_fused_reverse_kernel():
+    """tools/sim_fused_grad.py replays grad_fused_kernel.hpp's interval schedule (evaluator / sweeper wavefronts, same-lane slots, the kernel-value
+    ring, the skewed hand-overs) with arrays over lanes and checks both sides' gradients against torch.autograd of the plain recursion."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sim_fused_grad.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "worst" in r.stdout

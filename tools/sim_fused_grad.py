@@ -76,22 +76,32 @@ def fused(x, y, clev):
             out[nvalid <= c, c] = 0.0
         return out
 
-    # ---------------- forward sweep: evaluator one interval ahead of the sweeper
+    # ---------------- forward sweep, evaluator one interval ahead of the sweeper.  Here a lane's four columns are b0-1 .. b0+2 -- the
+    # differences that END at its own points b0 .. b0+3, the kernel value at b0-1 being the left neighbour's last, one interval old (it
+    # runs one row ahead): four evaluations per row, as in the evaluation kernel (seq_core.hpp).  Lane 0's column -1 is no column: dm == 0.
     dmslot = np.zeros((2, G, C))
     q = np.zeros((G, LQ, C)); qg = np.zeros((G, LQ)); sout = np.zeros((G, LQ + 2))
     rowtot = np.zeros((R1, LQ))
-    k0 = kappa_row(np.zeros(G, int))
-    rd = k0[:, 1:] - k0[:, :-1]
+
+    def col_diffs(k, kleft):
+        kl = kleft.copy()
+        kl[0] = k[0, 0]
+        nd = np.empty((G, C))
+        nd[:, 0] = k[:, 0] - kl
+        nd[:, 1:] = k[:, 1:C] - k[:, 0:C - 1]
+        return nd
+
+    k = kappa_row(np.zeros(G, int))
+    rd = col_diffs(k, from_left(k[:, C - 1]))
+    k3 = k[:, C - 1].copy()
     for tau in range(TF + 1):
-        # evaluator, step tau
         if tau < TF:
             a = tau - ln
-            act = (a >= 0) & (a < R1)
             k = kappa_row(a + 1)                  # (clamped: a lane ahead of its rows evaluates row 0 again, so rd needs no guard)
-            nd = k[:, 1:] - k[:, :-1]
+            nd = col_diffs(k, from_left(k3))
+            k3 = k[:, C - 1].copy()
             dmslot_new = nd - rd
             rd = nd
-        # sweeper, step tau - 1 (reads the slot the evaluator filled in the previous interval)
         if tau >= 1:
             t = tau - 1
             a = t - ln
@@ -104,39 +114,45 @@ def fused(x, y, clev):
             for m in range(LQ + 1, 1, -1):
                 if m <= M:
                     lo = m - 2
-                    s = cin[:, m].copy()
+                    s_ = cin[:, m].copy()
                     for c in range(C):
-                        s = s + dm_in[:, c] * (qg[:, lo] if c == 0 else q[:, lo, c - 1])
+                        s_ = s_ + dm_in[:, c] * (qg[:, lo] if c == 0 else q[:, lo, c - 1])
                         if m < M:
-                            qn[:, m - 1, c] = q[:, m - 1, c] + s
-                    soutn[:, m] = s
+                            qn[:, m - 1, c] = q[:, m - 1, c] + s_
+                    soutn[:, m] = s_
                     if m < M:
                         qgn[:, m - 1] = qg[:, m - 1] + cin[:, m]
-            s = cin[:, 1].copy()
+            s_ = cin[:, 1].copy()
             for c in range(C):
-                s = s + dm_in[:, c]
+                s_ = s_ + dm_in[:, c]
                 if 1 < M:
-                    qn[:, 0, c] = q[:, 0, c] + s
-            soutn[:, 1] = s
+                    qn[:, 0, c] = q[:, 0, c] + s_
+            soutn[:, 1] = s_
             if 1 < M:
                 qgn[:, 0] = qg[:, 0] + cin[:, 1]
-            # (the order above follows WaveFwd::step: level m reads level m-1's OLD q -- qn keeps them apart)
             q = np.where(act[:, None, None], qn, q); qg = np.where(act[:, None], qgn, qg); sout = np.where(act[:, None], soutn, sout)
-            if act[last_lane]:
+            if act[G - 1]:                        # dm == 0 beyond the sequence: the last lane's prefix is the row total whatever R2
                 for m in range(1, LQ + 1):
-                    rowtot[a[last_lane], m - 1] = sout[last_lane, m] if m < M else 0.0
+                    rowtot[a[G - 1], m - 1] = sout[G - 1, m]
         if tau < TF:
             dmslot[tau % 2] = dmslot_new
-    levels = None
 
     # ---------------- backward sweep.  Interval i: the evaluator's kernel row a = R1 + (G-1-ln) - i (points b0 .. b0+3; the value at
     # b0+4 is the right neighbour's first, one interval old); the sweeper's step i - 2 and the adjoint W = -H * kappa of point row a + 2
     # with the kernel values of interval i - 3; the evaluator's contraction of the W handed over in interval i - 1.
-    qf, qfg = q.copy(), qg.copy()
+    # the backward sweep's columns are b0 .. b0+3: one to the right of the forward sweep's
+    qf = np.zeros((G, LQ, C)); qfg = q[:, :, 0].copy()
+    qf[:, :, :C - 1] = q[:, :, 1:]
+    for m in range(LQ):
+        qf[:, m, C - 1] = from_right(q[:, m, 0])
+    # the upstream gradients ride in the suffix sums from the start (U_p = c_p + Qb_p: one add per cell less)
     qb = np.zeros((G, LQ, C)); qbg = np.zeros((G, LQ)); svout = np.zeros((G, LQ)); sufout = np.zeros((G, LQ))
+    for p_ in range(1, M):
+        qb[:, p_ - 1, :] = clev[p_]
+        qbg[:, p_ - 1] = clev[p_]
     wslot = np.full((2, G, C), np.nan)
     KH = 5
-    khist = np.full((KH, G, C), np.nan)           # same-lane ring keyed by the interval
+    khist = np.zeros((KH, G, C))                  # same-lane ring keyed by the interval (cleared once per task: finite whatever is read)
     k0 = np.zeros(G)
     lamk = np.zeros((G, C)); Eprev = np.zeros((G, C)); Pout = np.zeros((G, D + 1))
     Ay = np.zeros((G, C, D)); By = np.zeros((G, C))
@@ -189,14 +205,14 @@ def fused(x, y, clev):
                     sufn[:, m - 1] = vv + rt[:, m - 1]
                 for c in range(C):
                     dd = qfgn[:, m - 1] if c == 0 else qfn[:, m - 1, c - 1]
-                    dd = np.where(first_row | (first_lane & (c == 0)) | (m >= M), 0.0, dd)
+                    dd = np.where((first_lane & (c == 0)) | (m >= M), 0.0, dd)      # (row 0 is not forced to zero: its residue is any row's)
                     Dm[:, m, c] = dd
             U = np.zeros((G, LQ + 2, C))
             for p_ in range(1, LQ + 2):
                 for c in range(C):
                     pi = min(p_ - 1, LQ - 1)
                     if p_ < M:
-                        U[:, p_, c] = clev[p_] + (qb[:, pi, c + 1] if c < C - 1 else qbg[:, pi])
+                        U[:, p_, c] = qb[:, pi, c + 1] if c < C - 1 else qbg[:, pi]
                     else:
                         U[:, p_, c] = clev[p_] if p_ == M else 0.0
             lam = np.zeros((G, C))
@@ -227,10 +243,7 @@ def fused(x, y, clev):
             for c in range(1, C):
                 H[:, c] = Eprev[:, c - 1] - Eprev[:, c]
             Eprev = Enew
-            p = a + 2
-            ok = (p >= 0) & (p <= R1)
-            with np.errstate(invalid='ignore'):
-                w_new = np.where(ok[:, None], -H * khist[(i - 3) % KH], 0.0)
+            w_new = -H * khist[(i - 3) % KH]       # H == 0 outside the point rows 0 .. R1 by construction
         if i <= TF:
             dmslot[i % 2] = dm_new
         if 2 <= i <= TF + 3:
