@@ -22,7 +22,7 @@ Wave2LaunchFn lam_undo_lookup_ptd_gen(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
 typedef hipError_t (*FusedGradLaunchFn)(const FusedGradArgs&, int, size_t, hipStream_t);
-FusedGradLaunchFn fused_grad_lookup(int DP, int LQ);
+FusedGradLaunchFn fused_grad_lookup(int kind, int DP, int LQ);
 // sig_feat_grad_api.hip: SignatureLinear's levels differentiated through the feature contraction
 int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
                       bool sym, const double* G, double* gX, double* gY, bool* done);
@@ -410,45 +410,53 @@ int seq_grad_undo(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, 
 }
 
 // ---- RBF on points with differences, order 1: both sweeps and both sides' contractions in one launch (grad_fused_kernel.hpp) ----------
-constexpr size_t FUSED_LDS_MAX = 64 * 1024;
+constexpr size_t FUSED_LDS_MAX = 96 * 1024;
 
-// The register-resident side (the lattice's columns) is Y: at most 64 points.  nullptr where the fused kernel is not built.
-FusedGradLaunchFn fused_grad_plan(const gpsig_ctx* c, const gpsig_params* p, int mode, int L1, int L2, int DP, bool diag) {
-    if (c->grad_impl != 0 || diag || mode != MODE_PT_DIFF || p->base_kernel != GPSIG_BASE_RBF || p->order > 1) return nullptr;
+// The register-resident side (the lattice's columns) holds at most 64 points: Y, or -- for a cross Gram whose Y is longer -- X with the roles
+// exchanged (*swap; the lattice of (y, x) is the transpose of that of (x, y) and the levels are the same).  nullptr where the kernel is not built.
+FusedGradLaunchFn fused_grad_plan(const gpsig_ctx* c, const gpsig_params* p, int mode, int L1, int L2, int DP, bool diag, bool sym, bool* swap) {
+    *swap = false;
+    if (c->grad_impl != 0 || diag || mode != MODE_PT_DIFF || p->order > 1) return nullptr;
     const int M = p->num_levels;
-    if (M < 2 || M > 6 || DP > 8 || L1 < 2 || L2 < 2 || L2 > FG_G * FG_C) return nullptr;
-    if (sizeof(double) * size_t(fused_lds(L1, L1 - 1, DP, M - 1).total) > FUSED_LDS_MAX) return nullptr;
-    return fused_grad_lookup(DP, M - 1);
+    if (M < 2 || M > 6 || DP > 8 || L1 < 2 || L2 < 2) return nullptr;
+    if (L2 > FG_G * FG_C) {
+        if (sym || L1 > FG_G * FG_C) return nullptr;
+        *swap = true;
+    }
+    const int rows = *swap ? L2 : L1;
+    if (sizeof(double) * size_t(fused_lds(rows, rows - 1, DP, M - 1).total) > FUSED_LDS_MAX) return nullptr;
+    return fused_grad_lookup(p->base_kernel, DP, M - 1);        // RBF and the Matern families
 }
 
 // Tasks: four consecutive register-side sequences against a run of streamed ones.  Symmetric Gram: the runs start at the quad's
 // first sequence -- every unordered pair once (the kernel skips s < r inside the quad's own square), carrying G[s][r] + G[r][s].
-int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, int DP, const double* X, const double* Y, int64_t N1, int64_t N2, int L1,
-                   int L2, int d, bool sym, const double* Gup, double* gX, double* gY) {
-    CHK(zero_async(c, gX, sizeof(double) * size_t(N1) * L1 * d));
-    if (!sym) CHK(zero_async(c, gY, sizeof(double) * size_t(N2) * L2 * d));
-    const int64_t quads = (N2 + FG_PW - 1) / FG_PW;
-    const int64_t work = sym ? quads * (N1 + 1) / 2 : quads * N1;          // (quad, streamed sequence) units
+// S / R: the streamed / register-resident side (X / Y unless the plan exchanged them); gs / gr: the upstream's strides along them.
+int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, int DP, const double* S, const double* R, int64_t NS, int64_t NR, int LS,
+                   int LR, int d, bool sym, const double* Gup, int64_t gs, int64_t gr, double* gS, double* gR) {
+    CHK(zero_async(c, gS, sizeof(double) * size_t(NS) * LS * d));
+    if (!sym) CHK(zero_async(c, gR, sizeof(double) * size_t(NR) * LR * d));
+    const int64_t quads = (NR + FG_PW - 1) / FG_PW;
+    const int64_t work = sym ? quads * (NS + 1) / 2 : quads * NS;          // (quad, streamed sequence) units
     int64_t run = work / 8192;
     run = run < 1 ? 1 : (run > 32 ? 32 : run);
-    const int64_t key[10] = {N1, N2, run, sym ? 1 : 0, 0, 0, 0, 0, 0, 3};
+    const int64_t key[10] = {NS, NR, run, sym ? 1 : 0, 0, 0, 0, 0, 0, 3};
     const SeqTask* dt;
     int n = 0;
     CHK(task_list(c, key, [&](std::vector<SeqTask>& T) {
         T.clear();
-        for (int64_t r0 = 0; r0 < N2; r0 += FG_PW)
-            for (int64_t x0 = sym ? r0 : 0; x0 < N1; x0 += run) T.push_back(SeqTask{int32_t(r0), int32_t(x0), int32_t(N1 - x0 < run ? N1 - x0 : run)});
+        for (int64_t r0 = 0; r0 < NR; r0 += FG_PW)
+            for (int64_t x0 = sym ? r0 : 0; x0 < NS; x0 += run) T.push_back(SeqTask{int32_t(r0), int32_t(x0), int32_t(NS - x0 < run ? NS - x0 : run)});
         return int64_t(0);
     }, &dt, &n));
     if (n == 0) return GPSIG_OK;
     FusedGradArgs A;
     memset(&A, 0, sizeof(A));
-    A.S = X; A.R = Y; A.gS = gX; A.gR = sym ? gX : gY;
-    A.NS = int(N1); A.NR = int(N2); A.LS = L1; A.LR = L2; A.d = d;
+    A.S = S; A.R = R; A.gS = gS; A.gR = sym ? gS : gR;
+    A.NS = int(NS); A.NR = int(NR); A.LS = LS; A.LR = LR; A.d = d;
     A.tasks = dt;
-    A.G = Gup; A.gm = N1 * N2; A.gs = N2; A.gr = 1;
+    A.G = Gup; A.gm = NS * NR; A.gs = gs; A.gr = gr;
     A.sym = sym ? 1 : 0;
-    const hipError_t e = fn(A, n, sizeof(double) * size_t(fused_lds(L1, L1 - 1, DP, p->num_levels - 1).total), c->stream);
+    const hipError_t e = fn(A, n, sizeof(double) * size_t(fused_lds(LS, LS - 1, DP, p->num_levels - 1).total), c->stream);
     if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_fused_kernel launch failed: %s", hipGetErrorString(e));
     return GPSIG_OK;
 }
@@ -608,7 +616,8 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     Wave2LaunchFn lfn = nullptr;                           // point kernels: scratch-free sweeps with Lam out
     int lG = 0, lC = 0;
     if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, p->base_kernel, L1 - drr, L2 - drr, DP, M, &lG, &lC);
-    FusedGradLaunchFn ffn = (N1 > 0 && N2 > 0) ? fused_grad_plan(c, p, mode, L1, L2, DP, diag) : nullptr;
+    bool fswap = false;
+    FusedGradLaunchFn ffn = (N1 > 0 && N2 > 0) ? fused_grad_plan(c, p, mode, L1, L2, DP, diag, sym, &fswap) : nullptr;
     bool by_features = false;      // the linear kernel, first order: through the feature contraction where that is cheaper (round 4)
     if (N1 > 0 && N2 > 0)
         CHK(sig_features_grad(c, p, d, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, diag, sym,
@@ -622,8 +631,10 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
         CHK(seq_grad_ho(c, p, DP, mode, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, d, diag, sym,
                         static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym || diag ? dgX : dgY), kgb));
     } else if (ffn) {
-        CHK(seq_grad_fused(c, p, ffn, DP, static_cast<const double*>(dX), static_cast<const double*>(sym ? dX : dY), N1, N2, L1, L2, d, sym,
-                           static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(sym ? dgX : dgY)));
+        const double *Xd = static_cast<const double*>(dX), *Yd = static_cast<const double*>(sym ? dX : dY);
+        double *gXd = static_cast<double*>(dgX), *gYd = static_cast<double*>(sym ? dgX : dgY);
+        if (fswap) CHK(seq_grad_fused(c, p, ffn, DP, Yd, Xd, N2, N1, L2, L1, d, false, static_cast<const double*>(dG), 1, N2, gYd, gXd));
+        else CHK(seq_grad_fused(c, p, ffn, DP, Xd, Yd, N1, N2, L1, L2, d, sym, static_cast<const double*>(dG), N2, 1, gXd, gYd));
     } else if (w2x) {
         const double* Xd = static_cast<const double*>(dX);
         const double* Gd = static_cast<const double*>(dG);

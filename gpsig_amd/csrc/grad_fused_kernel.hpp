@@ -58,10 +58,24 @@ __host__ __device__ inline FusedLds fused_lds(int LS, int R1, int DP, int LQ) {
 
 typedef double fg_d2 __attribute__((ext_vector_type(2)));
 
-// kernel values of record row `xrow` (LDS) against the lane's four points: 2^(t / 256) with t = x'.y' - |x'|^2 / 2 - |y'|^2 / 2, two at a time
-// through the hand-scheduled table exp (exp_pair_asm.hpp)
-template <int DP>
-__device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&y)[FG_C][DP], const double (&hy)[FG_C], unsigned tab_addr, double (&k)[FG_C]) {
+// What the kernel is built for: the stationary base kernels kappa = phi(|x - y|^2) whose exp goes through the 256-entry table.  Their gradient
+// has one shape, d kappa / dx = g (x - y) with g = 2 phi', so the contraction is W = H * g whatever the family; the kernel-value ring holds -g.
+//   RBF: points prescaled by sqrt(256 / ln 2), t = x'.y' - |x'|^2/2 - |y'|^2/2, kappa = 2^(t/256), -g = kappa.
+//   Matern-nu: points prescaled by S = c 256 / ln 2 (c = 1, sqrt 3, sqrt 5), the record rows carry -2 x', q = |x' - y'| = S r, e = 2^(-q/256) =
+//   exp(-c r), u = c r = q ln2/256:  1/2: kappa = e, -g = e / r;  3/2: kappa = (1 + u) e, -g = 3 e;  5/2: kappa = (1 + u + u^2/3) e, -g = 5/3 (1 + u) e
+//   (kernels.py:955-993; the distance floored at 1e-40 as there, where g is taken as 0 like grad_core.hpp's base_eval_grad).
+constexpr bool fg_matern(int kind) { return kind == BASE_MATERN12 || kind == BASE_MATERN32 || kind == BASE_MATERN52; }
+constexpr double fg_matern_c(int kind) { return kind == BASE_MATERN12 ? 1.0 : (kind == BASE_MATERN32 ? 1.7320508075688772935 : 2.2360679774997896964); }
+constexpr double FG_LN2 = 0x1.62e42fefa39efp-1;
+constexpr double fg_prescale(int kind) { return fg_matern(kind) ? fg_matern_c(kind) * 256.0 / FG_LN2 : EXP_PRESCALE256; }
+constexpr double fg_row_factor(int kind) { return fg_matern(kind) ? -2.0 : 1.0; }          // record rows hold this times the prescaled point
+constexpr double fg_norm_factor(int kind) { return fg_matern(kind) ? 1.0 : -0.5; }          // ... and this times its squared norm
+
+// kernel values k (and -g, see above) of record row `xrow` (LDS) against the lane's four points, the exps two at a time through the
+// hand-scheduled table exp (exp_pair_asm.hpp)
+template <int DP, int KIND>
+__device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&y)[FG_C][DP], const double (&hy)[FG_C], unsigned tab_addr, double (&k)[FG_C],
+                                             double (&g)[FG_C]) {
     static_assert(FG_C % 2 == 0, "exps go in pairs");
     double x[DP], t[FG_C];
 #pragma unroll
@@ -76,10 +90,39 @@ __device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&
 #pragma unroll
         for (int f = 0; f < DP; ++f) t[c] = fma(x[f], y[c][f], t[c]);
     }
+    if constexpr (KIND == BASE_RBF) {
 #pragma unroll
-    for (int c = 0; c < FG_C; c += 2) {
-        kexp2_pair_asm<256>(t[c], t[c + 1], tab_addr, k[c], k[c + 1]);
-        __builtin_amdgcn_s_waitcnt(0xc07f);          // the block waited for its table reads: tell the compiler's counters
+        for (int c = 0; c < FG_C; c += 2) {
+            kexp2_pair_asm<256>(t[c], t[c + 1], tab_addr, k[c], k[c + 1]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // the block waited for its table reads: tell the compiler's counters
+        }
+#pragma unroll
+        for (int c = 0; c < FG_C; ++c) g[c] = k[c];
+    } else {
+        constexpr double S = fg_prescale(KIND), K = FG_LN2 / 256.0, FLOOR = 1e-40 * S * S;
+        double q[FG_C], yi[FG_C], e[FG_C];
+        bool floored[FG_C];
+#pragma unroll
+        for (int c = 0; c < FG_C; ++c) {
+            floored[c] = !(t[c] > FLOOR);
+            const double d = fmax(t[c], FLOOR);
+            const double r0 = __builtin_amdgcn_rsq(d), h = 0.5 * r0;
+            double r = d * r0;
+            r = fma(fma(-r, r, d), h, r);                // one Newton step on the residual: ~1.5 ulp
+            q[c] = r;
+            if constexpr (KIND == BASE_MATERN12) yi[c] = r0 * fma(-r, r0, 2.0);      // 1 / q, one Newton step
+        }
+#pragma unroll
+        for (int c = 0; c < FG_C; c += 2) {
+            kexp2_pair_asm<256, true>(q[c], q[c + 1], tab_addr, e[c], e[c + 1]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+#pragma unroll
+        for (int c = 0; c < FG_C; ++c) {
+            if constexpr (KIND == BASE_MATERN12) { k[c] = e[c]; g[c] = floored[c] ? 0.0 : e[c] * (yi[c] * S); }
+            else if constexpr (KIND == BASE_MATERN32) { k[c] = fma(q[c], K, 1.0) * e[c]; g[c] = floored[c] ? 0.0 : 3.0 * e[c]; }
+            else { const double u = q[c] * K; k[c] = fma(fma(u, 1.0 / 3.0, 1.0), u, 1.0) * e[c]; g[c] = floored[c] ? 0.0 : (5.0 / 3.0) * fma(q[c], K, 1.0) * e[c]; }
+        }
     }
 }
 
@@ -95,7 +138,7 @@ __device__ __forceinline__ void fg_get(const double* slot, int par, int lane, do
 }
 
 // Both wavefronts: the record of streamed sequence s -- prescaled rows and -|x'|^2 / 2 -- and a cleared x-side accumulator.
-template <int DP>
+template <int DP, int KIND>
 __device__ __forceinline__ void fg_stage(const FusedGradArgs& A, double* sm, const FusedLds o, int64_t s) {
     constexpr int DS = DP + 2;
     for (int p = threadIdx.x; p < A.LS; p += 128) {
@@ -105,33 +148,34 @@ __device__ __forceinline__ void fg_stage(const FusedGradArgs& A, double* sm, con
         double hs = 0.0;
 #pragma unroll
         for (int f = 0; f < DP; ++f) {
-            const double v = f < A.d ? src[f] * EXP_PRESCALE256 : 0.0;
-            xr[f] = v;
+            const double v = f < A.d ? src[f] * fg_prescale(KIND) : 0.0;
+            xr[f] = v * fg_row_factor(KIND);
             gr[f] = 0.0;
             hs = fma(v, v, hs);
         }
-        xr[DP] = -0.5 * hs;
+        xr[DP] = fg_norm_factor(KIND) * hs;
         xr[DP + 1] = 0.0;
         gr[DP] = gr[DP + 1] = 0.0;
     }
 }
-// Both wavefronts, after the last backward interval: gx[p] = (sum_q W[p][q]) x_p - sum_q W[p][q] y_q, back in the caller's scale.
-template <int DP>
+// Both wavefronts, after the last backward interval: gx[p] = (sum_q W[p][q]) x_p - sum_q W[p][q] y_q, back in the caller's scale
+// (the record rows hold fg_row_factor times the prescaled point, the accumulated sum the prescaled y's).
+template <int DP, int KIND>
 __device__ __forceinline__ void fg_flush(const FusedGradArgs& A, const double* sm, const FusedLds o, int64_t s) {
     constexpr int DS = DP + 2;
-    constexpr double inv = 1.0 / EXP_PRESCALE256;
+    constexpr double ca = 1.0 / (fg_prescale(KIND) * fg_row_factor(KIND)), cb = -1.0 / fg_prescale(KIND);
     for (int e = threadIdx.x; e < A.LS * DP; e += 128) {
         const int p = e / DP, f = e % DP;
         if (f < A.d) {
             const double* xr = sm + o.xs + p * DS;
             const double* gr = sm + o.gxa + p * DS;
-            atomicAdd(&A.gS[(s * A.LS + p) * A.d + f], fma(gr[DP], xr[f], -gr[f]) * inv);
+            atomicAdd(&A.gS[(s * A.LS + p) * A.d + f], fma(gr[DP] * ca, xr[f], cb * gr[f]));
         }
     }
 }
 
 // ---- wavefront 0 ----------------------------------------------------------------------------------------------------------------
-template <int DP>
+template <int DP, int KIND>
 __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
     constexpr int C = FG_C, G = FG_G, DS = DP + 2;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
@@ -152,11 +196,11 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         double s = 0.0;
 #pragma unroll
         for (int f = 0; f < DP; ++f) {
-            const double v = (rvalid && f < A.d) ? src[f] * EXP_PRESCALE256 : 0.0;
+            const double v = (rvalid && f < A.d) ? src[f] * fg_prescale(KIND) : 0.0;
             y[c][f] = v;
             s = fma(v, v, s);
         }
-        hy[c] = -0.5 * s;
+        hy[c] = fg_norm_factor(KIND) * s;
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -170,7 +214,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
     for (int it = 0; it < tk.nx; ++it) {
         const int64_t s = int64_t(tk.x0) + it;
         __syncthreads();                       // the flush of the previous streamed sequence has read gxa / xs
-        fg_stage<DP>(A, sm, o, s);
+        fg_stage<DP, KIND>(A, sm, o, s);
         __syncthreads();
         // ---- forward sweep: dm of step i in interval i
         // ---- forward sweep: dm of step i in interval i.  Here the lane's four columns are b0-1 .. b0+2 -- the differences that END at its own
@@ -179,8 +223,8 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         // row evaluates row 0 again and again (row_of clamps), so rd needs no guard; what it hands over outside its rows the sweeper does not read.
         double rd[C], k3;
         {
-            double k[C];
-            fg_kappa_row<DP>(row_of(0), y, hy, tab_addr, k);
+            double k[C], g[C];
+            fg_kappa_row<DP, KIND>(row_of(0), y, hy, tab_addr, k, g);
             double kl = wave_from_left<G>(k[C - 1]);
             if (ln == 0) kl = k[0];
             rd[0] = k[0] - kl;
@@ -190,9 +234,9 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         }
         for (int i = 0; i <= TF; ++i) {
             if (i < TF) {
-                double k[C], dm[C];
+                double k[C], g[C], dm[C];
                 double kl = wave_from_left<G>(k3);
-                fg_kappa_row<DP>(row_of(i - ln + 1), y, hy, tab_addr, k);
+                fg_kappa_row<DP, KIND>(row_of(i - ln + 1), y, hy, tab_addr, k, g);
                 if (ln == 0) kl = k[0];
                 k3 = k[C - 1];
 #pragma unroll
@@ -216,9 +260,9 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         int wr = 0;                            // i % FG_KH
         for (int i = 0; i <= TF + 4; ++i) {
             if (i <= TF) {
-                double k[C], dm[C];
+                double k[C], g[C], dm[C];
                 double kr = wave_from_right<G>(k0);
-                fg_kappa_row<DP>(row_of(R1 + (G - 1 - ln) - i), y, hy, tab_addr, k);
+                fg_kappa_row<DP, KIND>(row_of(R1 + (G - 1 - ln) - i), y, hy, tab_addr, k, g);
                 if (ln == G - 1) kr = k[C - 1];
                 k0 = k[0];
 #pragma unroll
@@ -228,7 +272,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
                     rd[c] = nd;
                 }
                 fg_put(sm + o.dm, i & 1, lane, dm);
-                fg_put(sm + o.kh, wr, lane, k);
+                fg_put(sm + o.kh, wr, lane, g);
             }
             if (i >= 3) {
                 const int p = R1 + 4 + (G - 1 - ln) - i;
@@ -268,24 +312,25 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
             wr = wr + 1 == FG_KH ? 0 : wr + 1;
             __syncthreads();
         }
-        fg_flush<DP>(A, sm, o, s);
+        fg_flush<DP, KIND>(A, sm, o, s);
     }
     if (rvalid) {
-        constexpr double inv = 1.0 / EXP_PRESCALE256;
+        // gy[q] = (sum_p W[p][q]) y_q - sum_p W[p][q] x_p: ay holds the record rows' multiple of x
+        constexpr double ca = 1.0 / fg_prescale(KIND), cb = -1.0 / (fg_prescale(KIND) * fg_row_factor(KIND));
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const int q = b0 + c;
             if (q < A.LR) {
 #pragma unroll
                 for (int f = 0; f < DP; ++f)
-                    if (f < A.d) atomicAdd(&A.gR[(r * A.LR + q) * A.d + f], fma(by[c], y[c][f], -ay[c][f]) * inv);
+                    if (f < A.d) atomicAdd(&A.gR[(r * A.LR + q) * A.d + f], fma(by[c] * ca, y[c][f], cb * ay[c][f]));
             }
         }
     }
 }
 
 // ---- wavefront 1 ----------------------------------------------------------------------------------------------------------------
-template <int DP, int LQ>
+template <int DP, int LQ, int KIND>
 __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
     constexpr int C = FG_C, G = FG_G, M = LQ + 1;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
@@ -309,7 +354,7 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
             clev[p] = v;
         }
         __syncthreads();
-        fg_stage<DP>(A, sm, o, s);
+        fg_stage<DP, KIND>(A, sm, o, s);
         __syncthreads();
         WaveFwd<C, LQ> fw;
         fw.reset();
@@ -354,7 +399,7 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
         // Interval i: step i - 2 of the undoing sweep (row a of the lane), then the adjoint of the kernel values from Lam:
         //   E[p][b] = Lam[p-1][b] - Lam[p][b]  (formed for p = a + 1 as the rows come, Lam == 0 outside the lattice),
         //   H[p][q] = E[p][q-1] - E[p][q]      (for p = a + 2: the left neighbour's last column is one interval behind),
-        //   W = -H * kappa(x_p, y_q)           (kappa from the evaluator's ring: evaluated in interval i - 3),
+        //   W = H * g(x_p, y_q)                (-g from the evaluator's ring, evaluated in interval i - 3; RBF: g = -kappa),
         // handed to the evaluator for every lane and interval it reads.  Outside the point rows 0 .. R1 H is zero by construction and the
         // ring holds finite values (cleared at the start of the task), so W is zero there without a guard.
         double lamk[C], ep[C];
@@ -401,12 +446,12 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
             rdk = rdk + 1 == FG_KH ? 0 : rdk + 1;
             __syncthreads();
         }
-        fg_flush<DP>(A, sm, o, s);
+        fg_flush<DP, KIND>(A, sm, o, s);
     }
 }
 
 // grid: one workgroup of 128 threads per task; dynamic LDS: fused_lds(LS, LS - 1, DP, LQ).total doubles
-template <int DP, int LQ>
+template <int DP, int LQ, int KIND>
 __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradArgs A) {
     extern __shared__ __attribute__((aligned(16))) double fg_sm[];
     const int R1 = A.LS - 1, R2 = A.LR - 1, TF = R1 + FG_G - 1;
@@ -418,10 +463,10 @@ __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradA
     // Both wavefronts run the same barrier sequence: per streamed sequence two around the staging of its record (fg_stage), then
     // TF + 1 forward and TF + 5 backward intervals; the flush of the x side (fg_flush) is covered by the next sequence's first barrier.
 #if defined(FG_ONLY_ROLE)          // register count of one role alone (compile-time experiment; such a kernel deadlocks at its first barrier)
-    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ>(A, tk, fg_sm, o, R1, R2, TF); }
+    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP, KIND>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ, KIND>(A, tk, fg_sm, o, R1, R2, TF); }
 #else
-    if (role == 0) fg_evaluator<DP>(A, tk, fg_sm, o, R1, R2, TF);
-    else fg_sweeper<DP, LQ>(A, tk, fg_sm, o, R1, R2, TF);
+    if (role == 0) fg_evaluator<DP, KIND>(A, tk, fg_sm, o, R1, R2, TF);
+    else fg_sweeper<DP, LQ, KIND>(A, tk, fg_sm, o, R1, R2, TF);
 #endif
 }
 

@@ -1405,23 +1405,26 @@ def test_low_rank_svgp_trains():
     (5, 37, 37, 64, 64, 8, "sym"),      # runs of streamed sequences that start inside a quad's own square
     (3, 40, 2, 100, 50, 6, "cross"),    # more rows than a wavefront has lanes; half a quad
     (4, 9, 7, 20, 31, 3, "cross"),
+    (4, 3, 5, 20, 100, 3, "cross"),     # the column side longer than 64 points, the row side not: the roles are exchanged
+    (3, 6, 5, 150, 40, 2, "cross"),     # 150 rows: two workgroups per CU's worth of LDS
 ])
-def test_rbf_reverse_pass_in_one_launch(M, N1, N2, L1, L2, d, kind):
-    """grad_fused_kernel.hpp (round 5): SignatureRBF on points with differences, order 1 -- an evaluator and a sweeper wavefront per four pairs,
-    Lam never leaving the chip -- is what the planner picks for these shapes.  Held to torch.autograd of the differentiable oracle at the
-    contract's 1e-6 (observed 1e-13), and to the two older GPU routes (one pair per thread with the stored lattice; the sweeps with Lam through
-    HBM + lam_contract_kernel) at 1e-9."""
+@pytest.mark.parametrize("base", ["rbf", "matern12", "matern32", "matern52"])
+def test_stationary_kernels_reverse_pass_in_one_launch(base, M, N1, N2, L1, L2, d, kind):
+    """grad_fused_kernel.hpp (round 5): SignatureRBF / SignatureMatern12 / 32 / 52 on points with differences, order 1 -- an evaluator and a
+    sweeper wavefront per four pairs, Lam never leaving the chip -- is what the planner picks for these shapes.  Held to torch.autograd of the
+    differentiable oracle at the contract's 1e-6 (observed 1e-13), and to the two older GPU routes (one pair per thread with the stored lattice;
+    the sweeps with Lam through HBM + lam_contract_kernel) at 1e-9."""
     rng = np.random.default_rng(77)
     ctx = _host_ctx()
     X = np.cumsum(rng.standard_normal((N1, L1, d)) * 0.3, 1)
     Y = np.cumsum(rng.standard_normal((N2, L2, d)) * 0.3, 1) if kind == "cross" else None
     G = rng.standard_normal((M + 1, N1, N2 if kind == "cross" else N1))
-    kt = _t_kern("rbf", d, M, difference=True)
+    kt = _t_kern(base, d, M, difference=True)
     tX = torch.tensor(X, requires_grad=True)
     tY = None if Y is None else torch.tensor(Y, requires_grad=True)
     (kt.K_seq_levels(tX, tY) * torch.tensor(G)).sum().backward()
     keep = []
-    p = _params("rbf", d, M, True, keep)
+    p = _params(base, d, M, True, keep)
     res = []
     try:
         for impl in (0, 1, 4):

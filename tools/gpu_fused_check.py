@@ -27,12 +27,13 @@ def main():
     worst = 0.0
     shapes = [(5, 6, 6, 64, 64, 8, "sym"), (4, 9, 7, 20, 31, 3, "cross"), (2, 13, 13, 5, 5, 1, "sym"), (6, 5, 9, 33, 64, 7, "cross"), (3, 1, 1, 2, 2, 4, "sym"),
               (5, 70, 70, 17, 17, 8, "sym"), (4, 3, 130, 64, 9, 5, "cross"), (5, 37, 37, 64, 64, 8, "sym"), (4, 5, 4, 2, 9, 3, "cross"), (3, 40, 2, 100, 50, 6, "cross")]
-    for (M, N1, N2, L1, L2, d, kind) in shapes:
+    for base in ("rbf", "matern12", "matern32", "matern52"):
+      for (M, N1, N2, L1, L2, d, kind) in (shapes if base == "rbf" else shapes[:4]):
         X = np.cumsum(rng.standard_normal((N1, L1, d)) * 0.3, 1)
         Y = np.cumsum(rng.standard_normal((N2, L2, d)) * 0.3, 1) if kind == "cross" else None
         G = rng.standard_normal((M + 1, N1, N2 if kind == "cross" else N1))
         keep = []
-        p = _Spec("rbf", M, True, 0.0, order=1).params(d, 0.0, keep)
+        p = _Spec(base, M, True, 0.0, order=1).params(d, 0.0, keep)
         res = []
         for impl in (1, 0, 4):
             ctx.set_option("grad_impl", impl)
@@ -43,7 +44,7 @@ def main():
         e = [rel(res[1][0], res[0][0]), rel(res[2][0], res[0][0])]
         if Y is not None:
             e += [rel(res[1][1], res[0][1]), rel(res[2][1], res[0][1])]
-        print(f"M={M} N1={N1} N2={N2} L1={L1} L2={L2} d={d} {kind}: planner vs stored {e[0]:.2e}" + (f" (y {e[2]:.2e})" if Y is not None else "")
+        print(f"{base} M={M} N1={N1} N2={N2} L1={L1} L2={L2} d={d} {kind}: planner vs stored {e[0]:.2e}" + (f" (y {e[2]:.2e})" if Y is not None else "")
               + f"; Lam-through-HBM vs stored {e[1]:.2e}", flush=True)
         worst = max(worst, e[0], e[2] if Y is not None else 0.0)
     print("worst planner-vs-stored", worst, flush=True)
@@ -56,10 +57,11 @@ def main():
     X = torch.tensor(np.random.default_rng(0).standard_normal((N, L * D)), device=dev)
     W = torch.tensor(np.random.default_rng(1).standard_normal((N, N)), device=dev)
     dctx = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
-    kern = kernels.SignatureRBF(L * D, D, M, lengthscales=math.sqrt(D))
-    mod = autodiff.SignatureKernelModule(kern, device=dev)
-    grads = {}
-    for impl in (0, 4, 0):
+    for cls in (kernels.SignatureRBF, kernels.SignatureMatern32):
+      kern = cls(L * D, D, M, lengthscales=math.sqrt(D))
+      mod = autodiff.SignatureKernelModule(kern, device=dev)
+      grads = {}
+      for impl in (0, 4, 0):
         dctx.set_option("grad_impl", impl)
 
         def step():
@@ -75,9 +77,9 @@ def main():
         ms = (time.perf_counter() - t0) / 5 * 1e3
         g = [q.grad.detach().cpu().numpy().copy() for q in mod.parameters() if q.grad is not None]
         grads[impl] = g
-        print(f"grad-c2shape-n1024-rbf grad_impl={impl}: {ms:.2f} ms per forward + backward", flush=True)
-    dctx.set_option("grad_impl", 0)
-    for a, b in zip(grads[0], grads[4]):
+        print(f"grad-c2shape-n1024 {cls.__name__} grad_impl={impl}: {ms:.2f} ms per forward + backward", flush=True)
+      dctx.set_option("grad_impl", 0)
+      for a, b in zip(grads[0], grads[4]):
         print("hyper-parameter gradient, planner vs Lam-through-HBM:", rel(a, b))
     return 0 if worst < 1e-9 else 1
 
