@@ -61,15 +61,18 @@ typedef double fg_d2 __attribute__((ext_vector_type(2)));
 // What the kernel is built for: the stationary base kernels kappa = phi(|x - y|^2) whose exp goes through the 256-entry table.  Their gradient
 // has one shape, d kappa / dx = g (x - y) with g = 2 phi', so the contraction is W = H * g whatever the family; the kernel-value ring holds -g.
 //   RBF: points prescaled by sqrt(256 / ln 2), t = x'.y' - |x'|^2/2 - |y'|^2/2, kappa = 2^(t/256), -g = kappa.
-//   Matern-nu: points prescaled by S = c 256 / ln 2 (c = 1, sqrt 3, sqrt 5), the record rows carry -2 x', q = |x' - y'| = S r, e = 2^(-q/256) =
-//   exp(-c r), u = c r = q ln2/256:  1/2: kappa = e, -g = e / r;  3/2: kappa = (1 + u) e, -g = 3 e;  5/2: kappa = (1 + u + u^2/3) e, -g = 5/3 (1 + u) e
-//   (kernels.py:955-993; the distance floored at 1e-40 as there, where g is taken as 0 like grad_core.hpp's base_eval_grad).
+//   Matern-nu: points prescaled by S = c 256 / ln 2 (c = 1, sqrt 3, sqrt 5), q = |x' - y'| = S r, e = 2^(-q/256) = exp(-c r), u = c r = q ln2/256:
+//   1/2: kappa = e, -g = e / r;  3/2: kappa = (1 + u) e, -g = 3 e;  5/2: kappa = (1 + u + u^2/3) e, -g = 5/3 (1 + u) e  (kernels.py:955-993; the
+//   distance floored at 1e-40 as there, where g is taken as 0 like grad_core.hpp's base_eval_grad).  The squared distance is summed from the
+//   DIFFERENCES of the coordinates (2 D instructions instead of D): |x|^2 + |y|^2 - 2 x.y leaves rounding noise of 1e-16 |x|^2 where the points
+//   coincide -- every diagonal cell of a sequence paired with itself -- and the Matern-1/2 kernel turns a noise eps into sqrt(eps) (kappa(x, x) =
+//   1 - 3e-8, g = 1e7 instead of 1 and 0: 8e-7 on the gradient in the first build of this family).
 constexpr bool fg_matern(int kind) { return kind == BASE_MATERN12 || kind == BASE_MATERN32 || kind == BASE_MATERN52; }
 constexpr double fg_matern_c(int kind) { return kind == BASE_MATERN12 ? 1.0 : (kind == BASE_MATERN32 ? 1.7320508075688772935 : 2.2360679774997896964); }
 constexpr double FG_LN2 = 0x1.62e42fefa39efp-1;
 constexpr double fg_prescale(int kind) { return fg_matern(kind) ? fg_matern_c(kind) * 256.0 / FG_LN2 : EXP_PRESCALE256; }
-constexpr double fg_row_factor(int kind) { return fg_matern(kind) ? -2.0 : 1.0; }          // record rows hold this times the prescaled point
-constexpr double fg_norm_factor(int kind) { return fg_matern(kind) ? 1.0 : -0.5; }          // ... and this times its squared norm
+constexpr double fg_row_factor(int kind) { return 1.0; }                                    // record rows hold this times the prescaled point
+constexpr double fg_norm_factor(int kind) { return -0.5; }                                  // ... and this times its squared norm (RBF's argument)
 
 // kernel values k (and -g, see above) of record row `xrow` (LDS) against the lane's four points, the exps two at a time through the
 // hand-scheduled table exp (exp_pair_asm.hpp)
@@ -83,12 +86,21 @@ __device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&
         const fg_d2 v = *reinterpret_cast<const fg_d2*>(xrow + f);
         x[f] = v[0]; x[f + 1] = v[1];
     }
-    const double hx = xrow[DP];
+    if constexpr (KIND == BASE_RBF) {
+        const double hx = xrow[DP];
 #pragma unroll
-    for (int c = 0; c < FG_C; ++c) {
-        t[c] = hx + hy[c];
+        for (int c = 0; c < FG_C; ++c) {
+            t[c] = hx + hy[c];
 #pragma unroll
-        for (int f = 0; f < DP; ++f) t[c] = fma(x[f], y[c][f], t[c]);
+            for (int f = 0; f < DP; ++f) t[c] = fma(x[f], y[c][f], t[c]);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < FG_C; ++c) {
+            t[c] = 0.0;
+#pragma unroll
+            for (int f = 0; f < DP; ++f) { const double df = x[f] - y[c][f]; t[c] = fma(df, df, t[c]); }
+        }
     }
     if constexpr (KIND == BASE_RBF) {
 #pragma unroll
