@@ -10,7 +10,7 @@ from gpsig_amd import kernels as K, autodiff
 from oracle import sigkern_oracle_torch as OT
 
 CLASS = {"linear": K.SignatureLinear, "rbf": K.SignatureRBF, "cosine": K.SignatureCosine, "poly": K.SignaturePoly, "mix": K.SignatureMix,
-         "matern32": K.SignatureMatern32, "matern52": K.SignatureMatern52}
+         "matern12": K.SignatureMatern12, "matern32": K.SignatureMatern32, "matern52": K.SignatureMatern52}
 
 
 def rel(a, b):
