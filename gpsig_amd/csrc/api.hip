@@ -681,7 +681,7 @@ int sig_features_K(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* X,
     const int r1 = p->difference ? L1 - 1 : L1, r2 = p->difference ? L2 - 1 : L2;
     if (r1 < 1 || r2 < 1) return GPSIG_OK;
     // One-column state spaces take this route whatever the time model says (round 5): the pair recursion's sums over index tuples cancel by
-    // orders of magnitude for scalar increments -- the float64 pair kernels AND the float64 oracle are 2e-3 .. 5e-3 from an 80-bit evaluation on
+    // orders of magnitude for scalar increments -- the float64 pair kernels AND the float64 CPU restatement are 2e-3 .. 5e-3 from an 80-bit evaluation on
     // case 779 of the round-5 sweep (tests/golden/fuzz_cases_r5.npz) -- while the per-sequence feature sums do not (8.7e-7 there, float32 rounding).
     if (c->sig_features < 0 && d != 1) {
         // (the higher-order pair kernels carry order^2 grids per level: 34 to 150 times the first order's time at configs[1]'s size)

@@ -22,7 +22,7 @@ Wave2LaunchFn lam_undo_lookup_ptd_gen(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
 typedef hipError_t (*FusedGradLaunchFn)(const FusedGradArgs&, int, size_t, hipStream_t);
-FusedGradLaunchFn fused_grad_lookup(int kind, int DP, int LQ);
+FusedGradLaunchFn fused_grad_lookup(int kind, int DP, int LQ, int G);
 // sig_feat_grad_api.hip: SignatureLinear's levels differentiated through the feature contraction
 int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
                       bool sym, const double* G, double* gX, double* gY, bool* done);
@@ -412,39 +412,40 @@ int seq_grad_undo(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, 
 // ---- RBF on points with differences, order 1: both sweeps and both sides' contractions in one launch (grad_fused_kernel.hpp) ----------
 constexpr size_t FUSED_LDS_MAX = 96 * 1024;
 
-// The register-resident side (the lattice's columns) holds at most 64 points: Y, or -- for a cross Gram whose Y is longer -- X with the roles
-// exchanged (*swap; the lattice of (y, x) is the transpose of that of (x, y) and the levels are the same).  nullptr where the kernel is not built.
-FusedGradLaunchFn fused_grad_plan(const gpsig_ctx* c, const gpsig_params* p, int mode, int L1, int L2, int DP, bool diag, bool sym, bool* swap) {
+// The register-resident side (the lattice's columns) holds at most 64 points with 16 lanes per pair (four pairs per wavefront), at most 256 with
+// 64 (one pair per wavefront): Y, or -- for a cross Gram whose Y is longer than its X -- X with the roles exchanged (*swap; the lattice of (y, x)
+// is the transpose of that of (x, y) and the levels are the same).  nullptr where the kernel is not built.
+FusedGradLaunchFn fused_grad_plan(const gpsig_ctx* c, const gpsig_params* p, int mode, int L1, int L2, int DP, bool diag, bool sym, bool* swap, int* G) {
     *swap = false;
     if (c->grad_impl != 0 || diag || mode != MODE_PT_DIFF || p->order > 1) return nullptr;
     const int M = p->num_levels;
     if (M < 2 || M > 6 || DP > 8 || L1 < 2 || L2 < 2) return nullptr;
-    if (L2 > FG_G * FG_C) {
-        if (sym || L1 > FG_G * FG_C) return nullptr;
-        *swap = true;
-    }
-    const int rows = *swap ? L2 : L1;
-    if (sizeof(double) * size_t(fused_lds(rows, rows - 1, DP, M - 1).total) > FUSED_LDS_MAX) return nullptr;
-    return fused_grad_lookup(p->base_kernel, DP, M - 1);        // RBF and the Matern families
+    if (!sym && L1 < L2 && L2 > 16 * FG_C) *swap = true;              // the shorter side on the columns once the longer one needs 64 lanes
+    const int cols = *swap ? L1 : L2, rows = *swap ? L2 : L1;
+    if (cols > 64 * FG_C) return nullptr;
+    *G = cols > 16 * FG_C ? 64 : 16;
+    if (sizeof(double) * size_t(fused_lds(rows, rows - 1, DP, M - 1, *G).total) > FUSED_LDS_MAX) return nullptr;
+    return fused_grad_lookup(p->base_kernel, DP, M - 1, *G);        // RBF and the Matern families
 }
 
-// Tasks: four consecutive register-side sequences against a run of streamed ones.  Symmetric Gram: the runs start at the quad's
+// Tasks: 64 / G consecutive register-side sequences (a "quad") against a run of streamed ones.  Symmetric Gram: the runs start at the quad's
 // first sequence -- every unordered pair once (the kernel skips s < r inside the quad's own square), carrying G[s][r] + G[r][s].
 // S / R: the streamed / register-resident side (X / Y unless the plan exchanged them); gs / gr: the upstream's strides along them.
-int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, int DP, const double* S, const double* R, int64_t NS, int64_t NR, int LS,
+int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, int G, int DP, const double* S, const double* R, int64_t NS, int64_t NR, int LS,
                    int LR, int d, bool sym, const double* Gup, int64_t gs, int64_t gr, double* gS, double* gR) {
+    const int PW = 64 / G;
     CHK(zero_async(c, gS, sizeof(double) * size_t(NS) * LS * d));
     if (!sym) CHK(zero_async(c, gR, sizeof(double) * size_t(NR) * LR * d));
-    const int64_t quads = (NR + FG_PW - 1) / FG_PW;
+    const int64_t quads = (NR + PW - 1) / PW;
     const int64_t work = sym ? quads * (NS + 1) / 2 : quads * NS;          // (quad, streamed sequence) units
     int64_t run = work / 8192;
     run = run < 1 ? 1 : (run > 32 ? 32 : run);
-    const int64_t key[10] = {NS, NR, run, sym ? 1 : 0, 0, 0, 0, 0, 0, 3};
+    const int64_t key[10] = {NS, NR, run, sym ? 1 : 0, PW, 0, 0, 0, 0, 3};
     const SeqTask* dt;
     int n = 0;
     CHK(task_list(c, key, [&](std::vector<SeqTask>& T) {
         T.clear();
-        for (int64_t r0 = 0; r0 < NR; r0 += FG_PW)
+        for (int64_t r0 = 0; r0 < NR; r0 += PW)
             for (int64_t x0 = sym ? r0 : 0; x0 < NS; x0 += run) T.push_back(SeqTask{int32_t(r0), int32_t(x0), int32_t(NS - x0 < run ? NS - x0 : run)});
         return int64_t(0);
     }, &dt, &n));
@@ -456,7 +457,7 @@ int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, in
     A.tasks = dt;
     A.G = Gup; A.gm = NS * NR; A.gs = gs; A.gr = gr;
     A.sym = sym ? 1 : 0;
-    const hipError_t e = fn(A, n, sizeof(double) * size_t(fused_lds(LS, LS - 1, DP, p->num_levels - 1).total), c->stream);
+    const hipError_t e = fn(A, n, sizeof(double) * size_t(fused_lds(LS, LS - 1, DP, p->num_levels - 1, G).total), c->stream);
     if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_fused_kernel launch failed: %s", hipGetErrorString(e));
     return GPSIG_OK;
 }
@@ -617,7 +618,8 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     int lG = 0, lC = 0;
     if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, p->base_kernel, L1 - drr, L2 - drr, DP, M, &lG, &lC);
     bool fswap = false;
-    FusedGradLaunchFn ffn = (N1 > 0 && N2 > 0) ? fused_grad_plan(c, p, mode, L1, L2, DP, diag, sym, &fswap) : nullptr;
+    int fG = 16;
+    FusedGradLaunchFn ffn = (N1 > 0 && N2 > 0) ? fused_grad_plan(c, p, mode, L1, L2, DP, diag, sym, &fswap, &fG) : nullptr;
     bool by_features = false;      // the linear kernel, first order: through the feature contraction where that is cheaper (round 4)
     if (N1 > 0 && N2 > 0)
         CHK(sig_features_grad(c, p, d, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, diag, sym,
@@ -633,8 +635,8 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     } else if (ffn) {
         const double *Xd = static_cast<const double*>(dX), *Yd = static_cast<const double*>(sym ? dX : dY);
         double *gXd = static_cast<double*>(dgX), *gYd = static_cast<double*>(sym ? dgX : dgY);
-        if (fswap) CHK(seq_grad_fused(c, p, ffn, DP, Yd, Xd, N2, N1, L2, L1, d, false, static_cast<const double*>(dG), 1, N2, gYd, gXd));
-        else CHK(seq_grad_fused(c, p, ffn, DP, Xd, Yd, N1, N2, L1, L2, d, sym, static_cast<const double*>(dG), N2, 1, gXd, gYd));
+        if (fswap) CHK(seq_grad_fused(c, p, ffn, fG, DP, Yd, Xd, N2, N1, L2, L1, d, false, static_cast<const double*>(dG), 1, N2, gYd, gXd));
+        else CHK(seq_grad_fused(c, p, ffn, fG, DP, Xd, Yd, N1, N2, L1, L2, d, sym, static_cast<const double*>(dG), N2, 1, gXd, gYd));
     } else if (w2x) {
         const double* Xd = static_cast<const double*>(dX);
         const double* Gd = static_cast<const double*>(dG);

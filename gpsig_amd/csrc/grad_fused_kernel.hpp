@@ -2,7 +2,8 @@
 // (SignatureRBF, order 1: gpsig/kernels.py:188-237 + signature_algs.py:8-35 differentiated), without Lam ever leaving the chip (round 5).
 //
 // A workgroup is TWO wavefronts working on the same four sequence pairs (four register-side sequences r0 .. r0+3, one per 16-lane
-// pair group, against a run of streamed sequences s they share; lane ln of a group owns the lattice columns 4 ln .. 4 ln + 3):
+// pair group, against a run of streamed sequences s they share; lane ln of a group owns the lattice columns 4 ln .. 4 ln + 3; G = 64: one
+// pair per wavefront, up to 256 points on the column side):
 //   wavefront 0, the EVALUATOR: keeps the lane's points of y, evaluates the kernel row of the step (table-driven exp on prescaled
 //       points), hands the double increments dm of the lane's columns to the sweeper, and -- in the backward sweep -- takes Lam
 //       back, differences it to the adjoint of the kernel values (H), multiplies by the kernel's derivative and contracts both
@@ -31,23 +32,23 @@ struct FusedGradArgs {
     const double* S; const double* R;      // streamed side / register-resident side, scaled observations, user layout (N, L, d)
     double* gS; double* gR;                // their gradients, same layout, accumulated with atomics (the same array for a symmetric Gram)
     int NS, NR, LS, LR, d;
-    const SeqTask* tasks;                  // y0 = first of four register-side sequences, x0 / nx = run of streamed sequences
+    const SeqTask* tasks;                  // y0 = first of the 64 / G register-side sequences, x0 / nx = run of streamed sequences
     const double* G; int64_t gm, gs, gr;   // upstream: G[m * gm + s * gs + r * gr], m = 1 .. M
     int sym;                               // symmetric Gram: pairs s >= r only, s > r carries G[s][r] + G[r][s]
 };
 
-constexpr int FG_G = 16, FG_C = 4, FG_PW = 4, FG_KH = 5;
+constexpr int FG_C = 4, FG_KH = 5;       // columns per lane; depth of the kernel-value ring.  G = 16 or 64 lanes per pair: 4 pairs or 1 per wavefront
 
 // offsets (in doubles) into the dynamic LDS of one workgroup
 struct FusedLds { int etab, xs, gxa, rt, dm, lam, kh, total; };
-__host__ __device__ inline FusedLds fused_lds(int LS, int R1, int DP, int LQ) {
+__host__ __device__ inline FusedLds fused_lds(int LS, int R1, int DP, int LQ, int G) {
     FusedLds o;
     const int DS = DP + 2;                 // record row: DP prescaled features, -|x'|^2 / 2, one pad (rows 16-byte aligned, bank-conflict free)
     int p = 0;
     o.etab = p; p += EXP_TAB256_N;
     o.xs = p; p += LS * DS;
     o.gxa = p; p += LS * DS;
-    o.rt = p; p += FG_PW * (R1 > 0 ? R1 : 1) * LQ;
+    o.rt = p; p += (64 / G) * (R1 > 0 ? R1 : 1) * LQ;
     p = (p + 1) & ~1;
     o.dm = p; p += 2 * FG_C * 64;          // [parity][half][lane] pairs of doubles
     o.lam = p; p += 2 * FG_C * 64;
@@ -187,9 +188,9 @@ __device__ __forceinline__ void fg_flush(const FusedGradArgs& A, const double* s
 }
 
 // ---- wavefront 0 ----------------------------------------------------------------------------------------------------------------
-template <int DP, int KIND>
+template <int DP, int KIND, int G>
 __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
-    constexpr int C = FG_C, G = FG_G, DS = DP + 2;
+    constexpr int C = FG_C, DS = DP + 2;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
     const double* xs = sm + o.xs;
     double* gxa = sm + o.gxa;
@@ -342,9 +343,9 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
 }
 
 // ---- wavefront 1 ----------------------------------------------------------------------------------------------------------------
-template <int DP, int LQ, int KIND>
+template <int DP, int LQ, int KIND, int G>
 __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
-    constexpr int C = FG_C, G = FG_G, M = LQ + 1;
+    constexpr int C = FG_C, M = LQ + 1;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
     double* rt = sm + o.rt + gw * (R1 > 0 ? R1 : 1) * LQ;
     const int64_t r = int64_t(tk.y0) + gw;
@@ -463,11 +464,12 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
 }
 
 // grid: one workgroup of 128 threads per task; dynamic LDS: fused_lds(LS, LS - 1, DP, LQ).total doubles
-template <int DP, int LQ, int KIND>
+template <int DP, int LQ, int KIND, int G>
 __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradArgs A) {
     extern __shared__ __attribute__((aligned(16))) double fg_sm[];
-    const int R1 = A.LS - 1, R2 = A.LR - 1, TF = R1 + FG_G - 1;
-    const FusedLds o = fused_lds(A.LS, R1, DP, LQ);
+    static_assert(G == 16 || G == 64, "a pair group is a DPP row or the whole wavefront");
+    const int R1 = A.LS - 1, R2 = A.LR - 1, TF = R1 + G - 1;
+    const FusedLds o = fused_lds(A.LS, R1, DP, LQ, G);
     const SeqTask tk = A.tasks[blockIdx.x];
     const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
     exp_tab256_fill(fg_sm + o.etab, int(threadIdx.x), 128);
@@ -475,10 +477,10 @@ __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradA
     // Both wavefronts run the same barrier sequence: per streamed sequence two around the staging of its record (fg_stage), then
     // TF + 1 forward and TF + 5 backward intervals; the flush of the x side (fg_flush) is covered by the next sequence's first barrier.
 #if defined(FG_ONLY_ROLE)          // register count of one role alone (compile-time experiment; such a kernel deadlocks at its first barrier)
-    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP, KIND>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ, KIND>(A, tk, fg_sm, o, R1, R2, TF); }
+    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP, KIND, G>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ, KIND, G>(A, tk, fg_sm, o, R1, R2, TF); }
 #else
-    if (role == 0) fg_evaluator<DP, KIND>(A, tk, fg_sm, o, R1, R2, TF);
-    else fg_sweeper<DP, LQ, KIND>(A, tk, fg_sm, o, R1, R2, TF);
+    if (role == 0) fg_evaluator<DP, KIND, G>(A, tk, fg_sm, o, R1, R2, TF);
+    else fg_sweeper<DP, LQ, KIND, G>(A, tk, fg_sm, o, R1, R2, TF);
 #endif
 }
 

@@ -1407,6 +1407,9 @@ def test_low_rank_svgp_trains():
     (4, 9, 7, 20, 31, 3, "cross"),
     (4, 3, 5, 20, 100, 3, "cross"),     # the column side longer than 64 points, the row side not: the roles are exchanged
     (3, 6, 5, 150, 40, 2, "cross"),     # 150 rows: two workgroups per CU's worth of LDS
+    (4, 5, 5, 130, 130, 3, "sym"),      # more than 64 points on the column side: 64 lanes per pair, one pair per wavefront
+    (5, 3, 2, 100, 200, 8, "cross"),    # both sides beyond 64 points: the shorter one on the columns
+    (2, 6, 6, 256, 256, 2, "sym"),      # the longest column side the kernel is built for
 ])
 @pytest.mark.parametrize("base", ["rbf", "matern12", "matern32", "matern52"])
 def test_stationary_kernels_reverse_pass_in_one_launch(base, M, N1, N2, L1, L2, d, kind):

@@ -297,6 +297,8 @@ def test_lane_level_model_of_the_fused_reverse_kernel():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sim_fused_grad.py")], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "worst" in r.stdout
+    for lanes in ("16", "64"):          # lanes per pair group: four pairs per wavefront, or one pair with up to 256 points on the column side
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "sim_fused_grad.py")], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, SIM_G=lanes))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "worst" in r.stdout
