@@ -413,18 +413,19 @@ int seq_grad_undo(gpsig_ctx* c, const gpsig_params* p, Wave2LaunchFn fn, int G, 
 constexpr size_t FUSED_LDS_MAX = 96 * 1024;
 
 // The register-resident side (the lattice's columns) holds at most 64 points with 16 lanes per pair (four pairs per wavefront), at most 256 with
-// 64 (one pair per wavefront): Y, or -- for a cross Gram whose Y is longer than its X -- X with the roles exchanged (*swap; the lattice of (y, x)
+// 64 (one pair per wavefront; half of either with the two columns per lane of 9 .. 16 state-space columns): Y, or -- for a cross Gram whose Y is longer than its X -- X with the roles exchanged (*swap; the lattice of (y, x)
 // is the transpose of that of (x, y) and the levels are the same).  nullptr where the kernel is not built.
 FusedGradLaunchFn fused_grad_plan(const gpsig_ctx* c, const gpsig_params* p, int mode, int L1, int L2, int DP, bool diag, bool sym, bool* swap, int* G) {
     *swap = false;
     if (c->grad_impl != 0 || diag || mode != MODE_PT_DIFF || p->order > 1) return nullptr;
     const int M = p->num_levels;
-    if (M < 2 || M > 6 || DP > 8 || L1 < 2 || L2 < 2) return nullptr;
-    if (!sym && L1 < L2 && L2 > 16 * FG_C) *swap = true;              // the shorter side on the columns once the longer one needs 64 lanes
+    if (M < 2 || M > 6 || DP > 16 || L1 < 2 || L2 < 2) return nullptr;
+    const int C = fused_grad_columns(DP);                            // 4 columns per lane; 2 for state spaces of 9 .. 16 columns
+    if (!sym && L1 < L2 && L2 > 16 * C) *swap = true;                 // the shorter side on the columns once the longer one needs 64 lanes
     const int cols = *swap ? L1 : L2, rows = *swap ? L2 : L1;
-    if (cols > 64 * FG_C) return nullptr;
-    *G = cols > 16 * FG_C ? 64 : 16;
-    if (sizeof(double) * size_t(fused_lds(rows, rows - 1, DP, M - 1, *G).total) > FUSED_LDS_MAX) return nullptr;
+    if (cols > 64 * C) return nullptr;
+    *G = cols > 16 * C ? 64 : 16;
+    if (sizeof(double) * size_t(fused_lds(rows, rows - 1, DP, M - 1, *G, C).total) > FUSED_LDS_MAX) return nullptr;
     return fused_grad_lookup(p->base_kernel, DP, M - 1, *G);        // RBF and the Matern families
 }
 
@@ -457,7 +458,7 @@ int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, in
     A.tasks = dt;
     A.G = Gup; A.gm = NS * NR; A.gs = gs; A.gr = gr;
     A.sym = sym ? 1 : 0;
-    const hipError_t e = fn(A, n, sizeof(double) * size_t(fused_lds(LS, LS - 1, DP, p->num_levels - 1, G).total), c->stream);
+    const hipError_t e = fn(A, n, sizeof(double) * size_t(fused_lds(LS, LS - 1, DP, p->num_levels - 1, G, fused_grad_columns(DP)).total), c->stream);
     if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_fused_kernel launch failed: %s", hipGetErrorString(e));
     return GPSIG_OK;
 }

@@ -1,4 +1,4 @@
-// seq_grad_fused_kernel instances (grad_fused_kernel.hpp): RBF and the Matern families, 16 or 64 lanes per pair, padded feature counts 4 / 8, num_levels 2 .. 6 at compile time
+// seq_grad_fused_kernel instances (grad_fused_kernel.hpp): RBF and the Matern families, 16 or 64 lanes per pair, padded feature counts 4 / 8 (four columns per lane) and 16 (two), num_levels 2 .. 6 at compile time
 #include "grad_fused_kernel.hpp"
 
 namespace gpsig {
@@ -7,7 +7,7 @@ typedef hipError_t (*FusedGradLaunchFn)(const FusedGradArgs&, int, size_t, hipSt
 
 template <int DP, int LQ, int KIND, int G>
 static hipError_t fused_grad_launch(const FusedGradArgs& a, int ntasks, size_t lds, hipStream_t s) {
-    auto kern = seq_grad_fused_kernel<DP, LQ, KIND, G>;
+    auto kern = seq_grad_fused_kernel<DP, LQ, KIND, G, fused_grad_columns(DP)>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return e;
@@ -29,6 +29,7 @@ static FusedGradLaunchFn fused_grad_lookup_kind(int DP, int LQ) {
     }
     FG_PICK(4)
     FG_PICK(8)
+    FG_PICK(16)
 #undef FG_PICK
     return nullptr;
 }

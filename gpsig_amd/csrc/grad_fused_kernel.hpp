@@ -37,11 +37,12 @@ struct FusedGradArgs {
     int sym;                               // symmetric Gram: pairs s >= r only, s > r carries G[s][r] + G[r][s]
 };
 
-constexpr int FG_C = 4, FG_KH = 5;       // columns per lane; depth of the kernel-value ring.  G = 16 or 64 lanes per pair: 4 pairs or 1 per wavefront
+constexpr int FG_KH = 5;                 // depth of the kernel-value ring.  G = 16 or 64 lanes per pair (4 pairs or 1 per wavefront), C = 4 columns per lane
+                                         // (2 where the state space has 9 .. 16 columns: the lane's points are C * DP doubles of registers)
 
 // offsets (in doubles) into the dynamic LDS of one workgroup
 struct FusedLds { int etab, xs, gxa, rt, dm, lam, kh, total; };
-__host__ __device__ inline FusedLds fused_lds(int LS, int R1, int DP, int LQ, int G) {
+__host__ __device__ inline FusedLds fused_lds(int LS, int R1, int DP, int LQ, int G, int C) {
     FusedLds o;
     const int DS = DP + 2;                 // record row: DP prescaled features, -|x'|^2 / 2, one pad (rows 16-byte aligned, bank-conflict free)
     int p = 0;
@@ -50,14 +51,17 @@ __host__ __device__ inline FusedLds fused_lds(int LS, int R1, int DP, int LQ, in
     o.gxa = p; p += LS * DS;
     o.rt = p; p += (64 / G) * (R1 > 0 ? R1 : 1) * LQ;
     p = (p + 1) & ~1;
-    o.dm = p; p += 2 * FG_C * 64;          // [parity][half][lane] pairs of doubles
-    o.lam = p; p += 2 * FG_C * 64;
-    o.kh = p; p += FG_KH * FG_C * 64;
+    o.dm = p; p += 2 * C * 64;             // [parity][half][lane] pairs of doubles
+    o.lam = p; p += 2 * C * 64;
+    o.kh = p; p += FG_KH * C * 64;
     o.total = p;
     return o;
 }
 
 typedef double fg_d2 __attribute__((ext_vector_type(2)));
+
+// columns per lane for a padded feature count: the lane keeps C points of DP doubles, and as many accumulators again
+constexpr int fused_grad_columns(int DP) { return DP > 8 ? 2 : 4; }
 
 // What the kernel is built for: the stationary base kernels kappa = phi(|x - y|^2) whose exp goes through the 256-entry table.  Their gradient
 // has one shape, d kappa / dx = g (x - y) with g = 2 phi', so the contraction is W = H * g whatever the family; the kernel-value ring holds -g.
@@ -77,11 +81,11 @@ constexpr double fg_norm_factor(int kind) { return -0.5; }                      
 
 // kernel values k (and -g, see above) of record row `xrow` (LDS) against the lane's four points, the exps two at a time through the
 // hand-scheduled table exp (exp_pair_asm.hpp)
-template <int DP, int KIND>
-__device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&y)[FG_C][DP], const double (&hy)[FG_C], unsigned tab_addr, double (&k)[FG_C],
-                                             double (&g)[FG_C]) {
-    static_assert(FG_C % 2 == 0, "exps go in pairs");
-    double x[DP], t[FG_C];
+template <int DP, int KIND, int C>
+__device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&y)[C][DP], const double (&hy)[C], unsigned tab_addr, double (&k)[C],
+                                             double (&g)[C]) {
+    static_assert(C % 2 == 0, "exps go in pairs");
+    double x[DP], t[C];
 #pragma unroll
     for (int f = 0; f < DP; f += 2) {
         const fg_d2 v = *reinterpret_cast<const fg_d2*>(xrow + f);
@@ -90,14 +94,14 @@ __device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&
     if constexpr (KIND == BASE_RBF) {
         const double hx = xrow[DP];
 #pragma unroll
-        for (int c = 0; c < FG_C; ++c) {
+        for (int c = 0; c < C; ++c) {
             t[c] = hx + hy[c];
 #pragma unroll
             for (int f = 0; f < DP; ++f) t[c] = fma(x[f], y[c][f], t[c]);
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < FG_C; ++c) {
+        for (int c = 0; c < C; ++c) {
             t[c] = 0.0;
 #pragma unroll
             for (int f = 0; f < DP; ++f) { const double df = x[f] - y[c][f]; t[c] = fma(df, df, t[c]); }
@@ -105,18 +109,18 @@ __device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&
     }
     if constexpr (KIND == BASE_RBF) {
 #pragma unroll
-        for (int c = 0; c < FG_C; c += 2) {
+        for (int c = 0; c < C; c += 2) {
             kexp2_pair_asm<256>(t[c], t[c + 1], tab_addr, k[c], k[c + 1]);
             __builtin_amdgcn_s_waitcnt(0xc07f);          // the block waited for its table reads: tell the compiler's counters
         }
 #pragma unroll
-        for (int c = 0; c < FG_C; ++c) g[c] = k[c];
+        for (int c = 0; c < C; ++c) g[c] = k[c];
     } else {
         constexpr double S = fg_prescale(KIND), K = FG_LN2 / 256.0, FLOOR = 1e-40 * S * S;
-        double q[FG_C], yi[FG_C], e[FG_C];
-        bool floored[FG_C];
+        double q[C], yi[C], e[C];
+        bool floored[C];
 #pragma unroll
-        for (int c = 0; c < FG_C; ++c) {
+        for (int c = 0; c < C; ++c) {
             floored[c] = !(t[c] > FLOOR);
             const double d = fmax(t[c], FLOOR);
             const double r0 = __builtin_amdgcn_rsq(d), h = 0.5 * r0;
@@ -126,12 +130,12 @@ __device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&
             if constexpr (KIND == BASE_MATERN12) yi[c] = r0 * fma(-r, r0, 2.0);      // 1 / q, one Newton step
         }
 #pragma unroll
-        for (int c = 0; c < FG_C; c += 2) {
+        for (int c = 0; c < C; c += 2) {
             kexp2_pair_asm<256, true>(q[c], q[c + 1], tab_addr, e[c], e[c + 1]);
             __builtin_amdgcn_s_waitcnt(0xc07f);
         }
 #pragma unroll
-        for (int c = 0; c < FG_C; ++c) {
+        for (int c = 0; c < C; ++c) {
             if constexpr (KIND == BASE_MATERN12) { k[c] = e[c]; g[c] = floored[c] ? 0.0 : e[c] * (yi[c] * S); }
             else if constexpr (KIND == BASE_MATERN32) { k[c] = fma(q[c], K, 1.0) * e[c]; g[c] = floored[c] ? 0.0 : 3.0 * e[c]; }
             else { const double u = q[c] * K; k[c] = fma(fma(u, 1.0 / 3.0, 1.0), u, 1.0) * e[c]; g[c] = floored[c] ? 0.0 : (5.0 / 3.0) * fma(q[c], K, 1.0) * e[c]; }
@@ -139,15 +143,20 @@ __device__ __forceinline__ void fg_kappa_row(const double* xrow, const double (&
     }
 }
 
-__device__ __forceinline__ void fg_put(double* slot, int par, int lane, const double (&v)[FG_C]) {
-    fg_d2* s = reinterpret_cast<fg_d2*>(slot) + par * 2 * 64 + lane;
-    s[0] = fg_d2{v[0], v[1]};
-    s[64] = fg_d2{v[2], v[3]};
+template <int C>
+__device__ __forceinline__ void fg_put(double* slot, int par, int lane, const double (&v)[C]) {
+    fg_d2* s = reinterpret_cast<fg_d2*>(slot) + par * (C / 2) * 64 + lane;
+#pragma unroll
+    for (int h = 0; h < C / 2; ++h) s[h * 64] = fg_d2{v[2 * h], v[2 * h + 1]};
 }
-__device__ __forceinline__ void fg_get(const double* slot, int par, int lane, double (&v)[FG_C]) {
-    const fg_d2* s = reinterpret_cast<const fg_d2*>(slot) + par * 2 * 64 + lane;
-    const fg_d2 a = s[0], b = s[64];
-    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+template <int C>
+__device__ __forceinline__ void fg_get(const double* slot, int par, int lane, double (&v)[C]) {
+    const fg_d2* s = reinterpret_cast<const fg_d2*>(slot) + par * (C / 2) * 64 + lane;
+#pragma unroll
+    for (int h = 0; h < C / 2; ++h) {
+        const fg_d2 a = s[h * 64];
+        v[2 * h] = a[0]; v[2 * h + 1] = a[1];
+    }
 }
 
 // Both wavefronts: the record of streamed sequence s -- prescaled rows and -|x'|^2 / 2 -- and a cleared x-side accumulator.
@@ -188,9 +197,9 @@ __device__ __forceinline__ void fg_flush(const FusedGradArgs& A, const double* s
 }
 
 // ---- wavefront 0 ----------------------------------------------------------------------------------------------------------------
-template <int DP, int KIND, int G>
+template <int DP, int KIND, int G, int C>
 __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
-    constexpr int C = FG_C, DS = DP + 2;
+    constexpr int DS = DP + 2;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
     const double* xs = sm + o.xs;
     double* gxa = sm + o.gxa;
@@ -237,7 +246,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         double rd[C], k3;
         {
             double k[C], g[C];
-            fg_kappa_row<DP, KIND>(row_of(0), y, hy, tab_addr, k, g);
+            fg_kappa_row<DP, KIND, C>(row_of(0), y, hy, tab_addr, k, g);
             double kl = wave_from_left<G>(k[C - 1]);
             if (ln == 0) kl = k[0];
             rd[0] = k[0] - kl;
@@ -249,7 +258,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
             if (i < TF) {
                 double k[C], g[C], dm[C];
                 double kl = wave_from_left<G>(k3);
-                fg_kappa_row<DP, KIND>(row_of(i - ln + 1), y, hy, tab_addr, k, g);
+                fg_kappa_row<DP, KIND, C>(row_of(i - ln + 1), y, hy, tab_addr, k, g);
                 if (ln == 0) kl = k[0];
                 k3 = k[C - 1];
 #pragma unroll
@@ -275,7 +284,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
             if (i <= TF) {
                 double k[C], g[C], dm[C];
                 double kr = wave_from_right<G>(k0);
-                fg_kappa_row<DP, KIND>(row_of(R1 + (G - 1 - ln) - i), y, hy, tab_addr, k, g);
+                fg_kappa_row<DP, KIND, C>(row_of(R1 + (G - 1 - ln) - i), y, hy, tab_addr, k, g);
                 if (ln == G - 1) kr = k[C - 1];
                 k0 = k[0];
 #pragma unroll
@@ -343,9 +352,9 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
 }
 
 // ---- wavefront 1 ----------------------------------------------------------------------------------------------------------------
-template <int DP, int LQ, int KIND, int G>
+template <int DP, int LQ, int KIND, int G, int C>
 __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
-    constexpr int C = FG_C, M = LQ + 1;
+    constexpr int M = LQ + 1;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
     double* rt = sm + o.rt + gw * (R1 > 0 ? R1 : 1) * LQ;
     const int64_t r = int64_t(tk.y0) + gw;
@@ -464,23 +473,23 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
 }
 
 // grid: one workgroup of 128 threads per task; dynamic LDS: fused_lds(LS, LS - 1, DP, LQ).total doubles
-template <int DP, int LQ, int KIND, int G>
+template <int DP, int LQ, int KIND, int G, int C>
 __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradArgs A) {
     extern __shared__ __attribute__((aligned(16))) double fg_sm[];
     static_assert(G == 16 || G == 64, "a pair group is a DPP row or the whole wavefront");
     const int R1 = A.LS - 1, R2 = A.LR - 1, TF = R1 + G - 1;
-    const FusedLds o = fused_lds(A.LS, R1, DP, LQ, G);
+    const FusedLds o = fused_lds(A.LS, R1, DP, LQ, G, C);
     const SeqTask tk = A.tasks[blockIdx.x];
     const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
     exp_tab256_fill(fg_sm + o.etab, int(threadIdx.x), 128);
-    for (int e = threadIdx.x; e < FG_KH * FG_C * 64; e += 128) fg_sm[o.kh + e] = 0.0;
+    for (int e = threadIdx.x; e < FG_KH * C * 64; e += 128) fg_sm[o.kh + e] = 0.0;
     // Both wavefronts run the same barrier sequence: per streamed sequence two around the staging of its record (fg_stage), then
     // TF + 1 forward and TF + 5 backward intervals; the flush of the x side (fg_flush) is covered by the next sequence's first barrier.
 #if defined(FG_ONLY_ROLE)          // register count of one role alone (compile-time experiment; such a kernel deadlocks at its first barrier)
-    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP, KIND, G>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ, KIND, G>(A, tk, fg_sm, o, R1, R2, TF); }
+    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP, KIND, G, C>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ, KIND, G, C>(A, tk, fg_sm, o, R1, R2, TF); }
 #else
-    if (role == 0) fg_evaluator<DP, KIND, G>(A, tk, fg_sm, o, R1, R2, TF);
-    else fg_sweeper<DP, LQ, KIND, G>(A, tk, fg_sm, o, R1, R2, TF);
+    if (role == 0) fg_evaluator<DP, KIND, G, C>(A, tk, fg_sm, o, R1, R2, TF);
+    else fg_sweeper<DP, LQ, KIND, G, C>(A, tk, fg_sm, o, R1, R2, TF);
 #endif
 }
 

@@ -105,7 +105,10 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "grad_scratch_mb" lattice scratch of one gradient / fallback launch in MiB (default 4096)
  *   "grad_impl"   gradient kernels: 0 planner's choice, 1 one pair per thread with the lattice in HBM scratch, 2 one pair per
  *                 thread scratch-free (tensor vs sequence), 3 wavefront kernel with the lattice in HBM scratch, 4 scratch-free wavefront
- *                 kernels (what the planner picks wherever they are built)
+ *                 kernels wherever they are built (rounds 3-4's choice: for the point kernels both sweeps in one wavefront, dL/d(increments)
+ *                 through HBM to a contraction kernel per side).  0 additionally picks the fused reverse kernel of round 5 (an evaluator and a
+ *                 sweeper wavefront per four sequence pairs, both sides contracted on chip) where it is built: RBF and the Matern families on
+ *                 points with differences, order 1, at most 256 points on one side, at most 8 columns of state space, 2 to 6 levels
  *   "tvs_grad_tile" reverse pass of the tensor-vs-sequence chains: 1 (default) the tile kernel (all levels in one reverse sweep per
  *                 sequence, d/dx summed in LDS, no atomics) where it is built (order 1, at most 8 columns, at most 6 levels), 0 the round-1 kernels
  *   "pinned_staging" host-pointer mode: 1 (default) transfers of 2 MiB and more run in 16 MiB chunks through two pinned buffers of the

@@ -1410,6 +1410,9 @@ def test_low_rank_svgp_trains():
     (4, 5, 5, 130, 130, 3, "sym"),      # more than 64 points on the column side: 64 lanes per pair, one pair per wavefront
     (5, 3, 2, 100, 200, 8, "cross"),    # both sides beyond 64 points: the shorter one on the columns
     (2, 6, 6, 256, 256, 2, "sym"),      # the longest column side the kernel is built for
+    (4, 5, 5, 20, 20, 12, "sym"),       # 9 .. 16 columns of state space: two lattice columns per lane
+    (3, 3, 4, 40, 100, 16, "cross"),    # ... with 64 lanes per pair and the roles exchanged
+    (5, 9, 9, 128, 128, 9, "sym"),      # ... at the longest column side of that form
 ])
 @pytest.mark.parametrize("base", ["rbf", "matern12", "matern32", "matern52"])
 def test_stationary_kernels_reverse_pass_in_one_launch(base, M, N1, N2, L1, L2, d, kind):

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import torch
 
-G, C = int(os.environ.get("SIM_G", "16")), 4       # lanes per pair group: 16 (four pairs per wavefront on the GPU) or 64 (one)
+G, C = int(os.environ.get("SIM_G", "16")), int(os.environ.get("SIM_C", "4"))    # lanes per pair group (16: four pairs per wavefront on the GPU, 64: one); columns per lane
 
 
 def from_left(v):      # lane l <- lane l-1, 0 into lane 0
@@ -265,7 +265,8 @@ def main():
     rng = np.random.default_rng(5)
     worst = 0.0
     shapes64 = ((70, 200, 4, 3), (130, 256, 2, 5), (5, 65, 3, 2))
-    for (L1, L2, D, M) in shapes64 if G == 64 else ((64, 64, 8, 5), (9, 64, 8, 4), (64, 33, 4, 3), (5, 7, 3, 2), (20, 62, 8, 5), (3, 2, 2, 3), (2, 64, 8, 5), (64, 64, 1, 2)):
+    shapes_c2 = ((40, 32, 12, 4), (9, 17, 16, 3), (3, 2, 9, 2))
+    for (L1, L2, D, M) in shapes64 if G == 64 else shapes_c2 if C == 2 else ((64, 64, 8, 5), (9, 64, 8, 4), (64, 33, 4, 3), (5, 7, 3, 2), (20, 62, 8, 5), (3, 2, 2, 3), (2, 64, 8, 5), (64, 64, 1, 2)):
         x = np.cumsum(rng.standard_normal((L1, D)) * 0.3, 0)
         y = np.cumsum(rng.standard_normal((L2, D)) * 0.3, 0)
         clev = np.concatenate([[0.0], rng.standard_normal(M)])
