@@ -22,7 +22,17 @@ Wave2LaunchFn lam_undo_lookup_ptd_gen(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
 typedef hipError_t (*FusedGradLaunchFn)(const FusedGradArgs&, int, size_t, hipStream_t);
-FusedGradLaunchFn fused_grad_lookup(int kind, int DP, int LQ, int G);
+FusedGradLaunchFn fused_grad_lookup_diff_g16(int kind, int DP, int LQ);
+FusedGradLaunchFn fused_grad_lookup_diff_g64(int kind, int DP, int LQ);
+FusedGradLaunchFn fused_grad_lookup_nodiff_g16(int kind, int DP, int LQ);
+FusedGradLaunchFn fused_grad_lookup_nodiff_g64(int kind, int DP, int LQ);
+// G: lanes per pair group -- 16 (four pairs per wavefront) or 64 (one); diff: the lattice of double increments (difference=True, the
+// reference's default) or the kernel matrix of the points itself
+static FusedGradLaunchFn fused_grad_lookup(int kind, int DP, int LQ, int G, bool diff) {
+    if (G == 16) return diff ? fused_grad_lookup_diff_g16(kind, DP, LQ) : fused_grad_lookup_nodiff_g16(kind, DP, LQ);
+    if (G == 64) return diff ? fused_grad_lookup_diff_g64(kind, DP, LQ) : fused_grad_lookup_nodiff_g64(kind, DP, LQ);
+    return nullptr;
+}
 // sig_feat_grad_api.hip: SignatureLinear's levels differentiated through the feature contraction
 int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
                       bool sym, const double* G, double* gX, double* gY, bool* done);
@@ -417,22 +427,23 @@ constexpr size_t FUSED_LDS_MAX = 96 * 1024;
 // is the transpose of that of (x, y) and the levels are the same).  nullptr where the kernel is not built.
 FusedGradLaunchFn fused_grad_plan(const gpsig_ctx* c, const gpsig_params* p, int mode, int L1, int L2, int DP, bool diag, bool sym, bool* swap, int* G) {
     *swap = false;
-    if (c->grad_impl != 0 || diag || mode != MODE_PT_DIFF || p->order > 1) return nullptr;
+    if (c->grad_impl != 0 || diag || mode == MODE_INC || p->order > 1) return nullptr;
+    const bool diff = mode == MODE_PT_DIFF;
     const int M = p->num_levels;
-    if (M < 2 || M > 6 || DP > 16 || L1 < 2 || L2 < 2) return nullptr;
+    if (M < 2 || M > 6 || DP > (diff ? 16 : 8) || L1 < 2 || L2 < 2) return nullptr;
     const int C = fused_grad_columns(DP);                            // 4 columns per lane; 2 for state spaces of 9 .. 16 columns
     if (!sym && L1 < L2 && L2 > 16 * C) *swap = true;                 // the shorter side on the columns once the longer one needs 64 lanes
     const int cols = *swap ? L1 : L2, rows = *swap ? L2 : L1;
     if (cols > 64 * C) return nullptr;
     *G = cols > 16 * C ? 64 : 16;
-    if (sizeof(double) * size_t(fused_lds(rows, rows - 1, DP, M - 1, *G, C).total) > FUSED_LDS_MAX) return nullptr;
-    return fused_grad_lookup(p->base_kernel, DP, M - 1, *G);        // RBF and the Matern families
+    if (sizeof(double) * size_t(fused_lds(rows, rows - (diff ? 1 : 0), DP, M - 1, *G, C).total) > FUSED_LDS_MAX) return nullptr;
+    return fused_grad_lookup(p->base_kernel, DP, M - 1, *G, diff);  // RBF and the Matern families
 }
 
 // Tasks: 64 / G consecutive register-side sequences (a "quad") against a run of streamed ones.  Symmetric Gram: the runs start at the quad's
 // first sequence -- every unordered pair once (the kernel skips s < r inside the quad's own square), carrying G[s][r] + G[r][s].
 // S / R: the streamed / register-resident side (X / Y unless the plan exchanged them); gs / gr: the upstream's strides along them.
-int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, int G, int DP, const double* S, const double* R, int64_t NS, int64_t NR, int LS,
+int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, int G, int DP, bool diff, const double* S, const double* R, int64_t NS, int64_t NR, int LS,
                    int LR, int d, bool sym, const double* Gup, int64_t gs, int64_t gr, double* gS, double* gR) {
     const int PW = 64 / G;
     CHK(zero_async(c, gS, sizeof(double) * size_t(NS) * LS * d));
@@ -458,7 +469,7 @@ int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, in
     A.tasks = dt;
     A.G = Gup; A.gm = NS * NR; A.gs = gs; A.gr = gr;
     A.sym = sym ? 1 : 0;
-    const hipError_t e = fn(A, n, sizeof(double) * size_t(fused_lds(LS, LS - 1, DP, p->num_levels - 1, G, fused_grad_columns(DP)).total), c->stream);
+    const hipError_t e = fn(A, n, sizeof(double) * size_t(fused_lds(LS, LS - (diff ? 1 : 0), DP, p->num_levels - 1, G, fused_grad_columns(DP)).total), c->stream);
     if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_fused_kernel launch failed: %s", hipGetErrorString(e));
     return GPSIG_OK;
 }
@@ -636,8 +647,8 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     } else if (ffn) {
         const double *Xd = static_cast<const double*>(dX), *Yd = static_cast<const double*>(sym ? dX : dY);
         double *gXd = static_cast<double*>(dgX), *gYd = static_cast<double*>(sym ? dgX : dgY);
-        if (fswap) CHK(seq_grad_fused(c, p, ffn, fG, DP, Yd, Xd, N2, N1, L2, L1, d, false, static_cast<const double*>(dG), 1, N2, gYd, gXd));
-        else CHK(seq_grad_fused(c, p, ffn, fG, DP, Xd, Yd, N1, N2, L1, L2, d, sym, static_cast<const double*>(dG), N2, 1, gXd, gYd));
+        if (fswap) CHK(seq_grad_fused(c, p, ffn, fG, DP, mode == MODE_PT_DIFF, Yd, Xd, N2, N1, L2, L1, d, false, static_cast<const double*>(dG), 1, N2, gYd, gXd));
+        else CHK(seq_grad_fused(c, p, ffn, fG, DP, mode == MODE_PT_DIFF, Xd, Yd, N1, N2, L1, L2, d, sym, static_cast<const double*>(dG), N2, 1, gXd, gYd));
     } else if (w2x) {
         const double* Xd = static_cast<const double*>(dX);
         const double* Gd = static_cast<const double*>(dG);

@@ -197,7 +197,7 @@ __device__ __forceinline__ void fg_flush(const FusedGradArgs& A, const double* s
 }
 
 // ---- wavefront 0 ----------------------------------------------------------------------------------------------------------------
-template <int DP, int KIND, int G, int C>
+template <int DP, int KIND, int G, int C, bool DIFF>
 __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
     constexpr int DS = DP + 2;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
@@ -207,6 +207,8 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
     const bool rvalid = r < A.NR;
     const int b0 = C * ln;
     const unsigned tab_addr = __builtin_amdgcn_readfirstlane(unsigned(uintptr_t((__attribute__((address_space(3))) const void*)(sm + o.etab))));
+    int nvalid = R2 - b0;                     // lattice columns among the lane's (difference=False: its points inside the sequence)
+    nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
 
     // The lane's points b0 .. b0 + 3.  Beyond the sequence the LAST point repeats: the columns there get dm == 0 exactly (equal
     // arguments, equal kernel values) without a mask in the evaluation.
@@ -238,13 +240,13 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         __syncthreads();                       // the flush of the previous streamed sequence has read gxa / xs
         fg_stage<DP, KIND>(A, sm, o, s);
         __syncthreads();
-        // ---- forward sweep: dm of step i in interval i
-        // ---- forward sweep: dm of step i in interval i.  Here the lane's four columns are b0-1 .. b0+2 -- the differences that END at its own
+        // ---- forward sweep: dm of step i in interval i.  (difference=False, DIFF == false: the lattice is the kernel matrix of the points itself --
+        // the lane's columns are its points in both sweeps, dm = kappa, forced to zero beyond the sequence.)  With differences: here the lane's four columns are b0-1 .. b0+2 -- the differences that END at its own
         // points, the kernel value at b0-1 being the left neighbour's last, one interval old (it runs one row ahead): four evaluations per
         // row, the evaluation kernel's convention (seq_core.hpp).  Lane 0's column -1 is no column: dm == 0 there.  A lane ahead of its first
         // row evaluates row 0 again and again (row_of clamps), so rd needs no guard; what it hands over outside its rows the sweeper does not read.
-        double rd[C], k3;
-        {
+        double rd[C], k3 = 0.0;
+        if constexpr (DIFF) {
             double k[C], g[C];
             fg_kappa_row<DP, KIND, C>(row_of(0), y, hy, tab_addr, k, g);
             double kl = wave_from_left<G>(k[C - 1]);
@@ -257,15 +259,21 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         for (int i = 0; i <= TF; ++i) {
             if (i < TF) {
                 double k[C], g[C], dm[C];
-                double kl = wave_from_left<G>(k3);
-                fg_kappa_row<DP, KIND, C>(row_of(i - ln + 1), y, hy, tab_addr, k, g);
-                if (ln == 0) kl = k[0];
-                k3 = k[C - 1];
+                if constexpr (DIFF) {
+                    double kl = wave_from_left<G>(k3);
+                    fg_kappa_row<DP, KIND, C>(row_of(i - ln + 1), y, hy, tab_addr, k, g);
+                    if (ln == 0) kl = k[0];
+                    k3 = k[C - 1];
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const double nd = k[c] - (c == 0 ? kl : k[c > 0 ? c - 1 : 0]);
-                    dm[c] = nd - rd[c];
-                    rd[c] = nd;
+                    for (int c = 0; c < C; ++c) {
+                        const double nd = k[c] - (c == 0 ? kl : k[c > 0 ? c - 1 : 0]);
+                        dm[c] = nd - rd[c];
+                        rd[c] = nd;
+                    }
+                } else {
+                    fg_kappa_row<DP, KIND, C>(row_of(i - ln), y, hy, tab_addr, k, g);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) dm[c] = c < nvalid ? k[c] : 0.0;
                 }
                 fg_put(sm + o.dm, i & 1, lane, dm);
             }
@@ -283,21 +291,27 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         for (int i = 0; i <= TF + 4; ++i) {
             if (i <= TF) {
                 double k[C], g[C], dm[C];
-                double kr = wave_from_right<G>(k0);
-                fg_kappa_row<DP, KIND, C>(row_of(R1 + (G - 1 - ln) - i), y, hy, tab_addr, k, g);
-                if (ln == G - 1) kr = k[C - 1];
-                k0 = k[0];
+                if constexpr (DIFF) {
+                    double kr = wave_from_right<G>(k0);
+                    fg_kappa_row<DP, KIND, C>(row_of(R1 + (G - 1 - ln) - i), y, hy, tab_addr, k, g);
+                    if (ln == G - 1) kr = k[C - 1];
+                    k0 = k[0];
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const double nd = (c == C - 1 ? kr : k[c < C - 1 ? c + 1 : c]) - k[c];
-                    dm[c] = rd[c] - nd;
-                    rd[c] = nd;
+                    for (int c = 0; c < C; ++c) {
+                        const double nd = (c == C - 1 ? kr : k[c < C - 1 ? c + 1 : c]) - k[c];
+                        dm[c] = rd[c] - nd;
+                        rd[c] = nd;
+                    }
+                } else {
+                    fg_kappa_row<DP, KIND, C>(row_of(R1 + (G - 1 - ln) - i), y, hy, tab_addr, k, g);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) dm[c] = c < nvalid ? k[c] : 0.0;
                 }
                 fg_put(sm + o.dm, i & 1, lane, dm);
                 fg_put(sm + o.kh, wr, lane, g);
             }
             if (i >= 3) {
-                const int p = R1 + 4 + (G - 1 - ln) - i;
+                const int p = R1 + (DIFF ? 4 : 2) + (G - 1 - ln) - i;      // the point row of the W handed over in the previous interval
                 double w[C];
                 fg_get(sm + o.lam, (i - 1) & 1, lane, w);           // zeros outside the lattice's point rows
                 // y side: the lane's own points
@@ -325,7 +339,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
 #pragma unroll
                     for (int f = 0; f < DP; ++f) P[f] = fma(w[c], y[c][f], P[f]);
                 }
-                if (ln == 0 && p >= 0 && p <= R1) {
+                if (ln == 0 && p >= 0 && p <= lsm1) {
                     double* gr = gxa + p * DS;
 #pragma unroll
                     for (int f = 0; f <= DP; ++f) atomicAdd(gr + f, P[f]);
@@ -352,7 +366,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
 }
 
 // ---- wavefront 1 ----------------------------------------------------------------------------------------------------------------
-template <int DP, int LQ, int KIND, int G, int C>
+template <int DP, int LQ, int KIND, int G, int C, bool DIFF>
 __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
     constexpr int M = LQ + 1;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
@@ -409,10 +423,16 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
         for (int p = 0; p < LQ + 2; ++p) clevz[p] = p == M ? clev[p] : -0.0;
 #pragma unroll
         for (int m = 0; m < LQ; ++m) {
-            bw.qfg[m] = fw.q[m][0];
+            if constexpr (DIFF) {
+                bw.qfg[m] = fw.q[m][0];
 #pragma unroll
-            for (int c = 0; c + 1 < C; ++c) bw.qf[m][c] = fw.q[m][c + 1];
-            bw.qf[m][C - 1] = wave_from_right<G>(fw.q[m][0]);
+                for (int c = 0; c + 1 < C; ++c) bw.qf[m][c] = fw.q[m][c + 1];
+                bw.qf[m][C - 1] = wave_from_right<G>(fw.q[m][0]);
+            } else {                                // difference=False: the same columns in both sweeps
+                bw.qfg[m] = fw.qg[m];
+#pragma unroll
+                for (int c = 0; c < C; ++c) bw.qf[m][c] = fw.q[m][c];
+            }
             bw.qbg[m] = clev[m + 1];
 #pragma unroll
             for (int c = 0; c < C; ++c) bw.qb[m][c] = clev[m + 1];
@@ -447,22 +467,29 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
                     for (int p = 0; p < LQ; ++p) rtv[p] = rt[a * LQ + p];
                     bw.step(dm, clevz, rtv, sufin, svin, M, false, ln == 0, lv);
                 }
-                double en[C], h[C], w[C], kp[C];
+                double w[C], kp[C];
+                if constexpr (DIFF) {
+                    double en[C], h[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const double li = c < nvalid ? lv[c] : 0.0;
-                    en[c] = li - lamk[c];
-                    lamk[c] = li;
+                    for (int c = 0; c < C; ++c) {
+                        const double li = c < nvalid ? lv[c] : 0.0;
+                        en[c] = li - lamk[c];
+                        lamk[c] = li;
+                    }
+                    const double eleft = wave_from_left<G>(en[C - 1]);
+                    h[0] = eleft - ep[0];
+#pragma unroll
+                    for (int c = 1; c < C; ++c) h[c] = ep[c - 1] - ep[c];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) ep[c] = en[c];
+                    fg_get(sm + o.kh, rdk, lane, kp);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) w[c] = -(h[c] * kp[c]);
+                } else {                            // difference=False: H = Lam; this row's kernel values were evaluated in the previous interval
+                    fg_get(sm + o.kh, rdk + 2 >= FG_KH ? rdk + 2 - FG_KH : rdk + 2, lane, kp);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) w[c] = c < nvalid ? -(lv[c] * kp[c]) : 0.0;
                 }
-                const double eleft = wave_from_left<G>(en[C - 1]);
-                h[0] = eleft - ep[0];
-#pragma unroll
-                for (int c = 1; c < C; ++c) h[c] = ep[c - 1] - ep[c];
-#pragma unroll
-                for (int c = 0; c < C; ++c) ep[c] = en[c];
-                fg_get(sm + o.kh, rdk, lane, kp);
-#pragma unroll
-                for (int c = 0; c < C; ++c) w[c] = -(h[c] * kp[c]);
                 fg_put(sm + o.lam, i & 1, lane, w);
             }
             rdk = rdk + 1 == FG_KH ? 0 : rdk + 1;
@@ -473,11 +500,11 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
 }
 
 // grid: one workgroup of 128 threads per task; dynamic LDS: fused_lds(LS, LS - 1, DP, LQ).total doubles
-template <int DP, int LQ, int KIND, int G, int C>
+template <int DP, int LQ, int KIND, int G, int C, bool DIFF>
 __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradArgs A) {
     extern __shared__ __attribute__((aligned(16))) double fg_sm[];
     static_assert(G == 16 || G == 64, "a pair group is a DPP row or the whole wavefront");
-    const int R1 = A.LS - 1, R2 = A.LR - 1, TF = R1 + G - 1;
+    const int R1 = A.LS - (DIFF ? 1 : 0), R2 = A.LR - (DIFF ? 1 : 0), TF = R1 + G - 1;
     const FusedLds o = fused_lds(A.LS, R1, DP, LQ, G, C);
     const SeqTask tk = A.tasks[blockIdx.x];
     const int role = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
@@ -486,10 +513,10 @@ __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradA
     // Both wavefronts run the same barrier sequence: per streamed sequence two around the staging of its record (fg_stage), then
     // TF + 1 forward and TF + 5 backward intervals; the flush of the x side (fg_flush) is covered by the next sequence's first barrier.
 #if defined(FG_ONLY_ROLE)          // register count of one role alone (compile-time experiment; such a kernel deadlocks at its first barrier)
-    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP, KIND, G, C>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ, KIND, G, C>(A, tk, fg_sm, o, R1, R2, TF); }
+    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP, KIND, G, C, DIFF>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ, KIND, G, C, DIFF>(A, tk, fg_sm, o, R1, R2, TF); }
 #else
-    if (role == 0) fg_evaluator<DP, KIND, G, C>(A, tk, fg_sm, o, R1, R2, TF);
-    else fg_sweeper<DP, LQ, KIND, G, C>(A, tk, fg_sm, o, R1, R2, TF);
+    if (role == 0) fg_evaluator<DP, KIND, G, C, DIFF>(A, tk, fg_sm, o, R1, R2, TF);
+    else fg_sweeper<DP, LQ, KIND, G, C, DIFF>(A, tk, fg_sm, o, R1, R2, TF);
 #endif
 }
 

@@ -1450,6 +1450,42 @@ def test_stationary_kernels_reverse_pass_in_one_launch(base, M, N1, N2, L1, L2, 
             assert rel(res[0][1], res[k][1]) < 1e-9, (k, rel(res[0][1], res[k][1]))
 
 
+@pytest.mark.parametrize("M,N1,N2,L1,L2,d,kind", [(5, 6, 6, 64, 64, 8, "sym"), (3, 7, 5, 9, 33, 3, "cross"), (4, 5, 5, 100, 100, 2, "sym"), (2, 3, 9, 30, 200, 4, "cross"),
+                                                  (6, 4, 4, 2, 2, 1, "sym")])
+@pytest.mark.parametrize("base", ["rbf", "matern12", "matern32", "matern52"])
+def test_stationary_kernels_reverse_pass_in_one_launch_without_differences(base, M, N1, N2, L1, L2, d, kind):
+    """The same kernel with difference=False (the lattice is the kernel matrix of the points itself: no increments along either side, no
+    neighbour values in the evaluation, the adjoint of the kernel values is Lam itself)."""
+    rng = np.random.default_rng(79)
+    ctx = _host_ctx()
+    X = np.cumsum(rng.standard_normal((N1, L1, d)) * 0.3, 1)
+    Y = np.cumsum(rng.standard_normal((N2, L2, d)) * 0.3, 1) if kind == "cross" else None
+    G = rng.standard_normal((M + 1, N1, N2 if kind == "cross" else N1)) * 0.01       # (without differences the levels grow like L^m)
+    kt = _t_kern(base, d, M, difference=False)
+    tX = torch.tensor(X, requires_grad=True)
+    tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+    (kt.K_seq_levels(tX, tY) * torch.tensor(G)).sum().backward()
+    keep = []
+    p = _params(base, d, M, False, keep)
+    res = []
+    try:
+        for impl in (0, 1, 4):
+            ctx.set_option("grad_impl", impl)
+            gX, gY = np.empty_like(X), (None if Y is None else np.empty_like(Y))
+            ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2 if Y is not None else N1, L1, L2 if Y is not None else L1,
+                     _vp(G), _vp(gX), _vp(gY), None)
+            res.append((gX, gY))
+    finally:
+        ctx.set_option("grad_impl", 0)
+    assert rel(res[0][0], tX.grad) < 1e-6, rel(res[0][0], tX.grad)
+    if Y is not None:
+        assert rel(res[0][1], tY.grad) < 1e-6, rel(res[0][1], tY.grad)
+    for k in (1, 2):
+        assert rel(res[0][0], res[k][0]) < 1e-9, (k, rel(res[0][0], res[k][0]))
+        if Y is not None:
+            assert rel(res[0][1], res[k][1]) < 1e-9, (k, rel(res[0][1], res[k][1]))
+
+
 def test_rbf_reverse_pass_in_one_launch_is_the_route_taken():
     """The fused kernel must be what runs at the bench's shape (a silent fall-back to the Lam-through-HBM sweeps is 2.7 times slower and would
     pass every parity test): 512 sequences of 64 x 8, forward + backward, timed against the older route on the same box."""

@@ -27,6 +27,9 @@ def main():
         base = str(rng.choice(list(CLASS)))
         M = int(rng.integers(1, 7))
         d = int(rng.choice([1, 2, 3, 5, 8, 11]))
+        if base == "cosine" and d == 1:
+            d = 2       # the cosine of two scalars is +-1 and the kernel ignores the one lengthscale: gradients that vanish identically, on both sides
+                        # rounding noise -- 21 of the 22 entries above tolerance in round 5's sweeps (profiles/r05_fuzz_grad.txt) were of this class
         lags = int(rng.choice([0, 0, 1, 2])) if base != "poly" else 0
         L1, L2 = int(rng.choice([3, 4, 9, 20, 40, 70])), int(rng.choice([3, 5, 12, 33]))
         N1, N2, T = int(rng.integers(1, 9)), int(rng.integers(1, 7)), int(rng.integers(1, 7))

@@ -13,6 +13,7 @@ import os
 import numpy as np
 import torch
 
+DIFF = os.environ.get("SIM_DIFF", "1") != "0"      # 0: difference=False (the lattice is the kernel matrix of the points)
 G, C = int(os.environ.get("SIM_G", "16")), int(os.environ.get("SIM_C", "4"))    # lanes per pair group (16: four pairs per wavefront on the GPU, 64: one); columns per lane
 
 
@@ -28,13 +29,13 @@ def from_right(v):     # lane l <- lane l+1, 0 into the last lane
     return out
 
 
-def reference(x, y, clev):
+def reference(x, y, clev, diff=True):
     """levels of the first-order signature kernel with the RBF base kernel on points, and d sum_m clev[m] K_m / d(x, y)"""
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     yt = torch.tensor(y, dtype=torch.float64, requires_grad=True)
     d2 = (xt * xt).sum(1)[:, None] + (yt * yt).sum(1)[None, :] - 2 * xt @ yt.T
     k = torch.exp(-d2 / 2)
-    dm = k[1:, 1:] - k[1:, :-1] - k[:-1, 1:] + k[:-1, :-1]
+    dm = k[1:, 1:] - k[1:, :-1] - k[:-1, 1:] + k[:-1, :-1] if diff else k
     M = len(clev) - 1
     Rm = dm
     loss = clev[1] * Rm.sum()
@@ -48,10 +49,10 @@ def reference(x, y, clev):
     return xt.grad.numpy(), yt.grad.numpy()
 
 
-def fused(x, y, clev):
+def fused(x, y, clev, diff=True):
     L1, D = x.shape
     L2 = y.shape[0]
-    R1, R2 = L1 - 1, L2 - 1
+    R1, R2 = (L1 - 1, L2 - 1) if diff else (L1, L2)      # difference=False: the lattice is the kernel matrix itself, no increments along either side
     M = len(clev) - 1
     LQ = M - 1
     TF = R1 + G - 1
@@ -96,14 +97,23 @@ def fused(x, y, clev):
     k = kappa_row(np.zeros(G, int))
     rd = col_diffs(k, from_left(k[:, C - 1]))
     k3 = k[:, C - 1].copy()
+
+    def mask_pts(v):                              # difference=False: columns are points; beyond the sequence dm must be forced to zero
+        out = v.copy()
+        for c in range(C):
+            out[nvalid <= c, c] = 0.0
+        return out
     for tau in range(TF + 1):
         if tau < TF:
             a = tau - ln
-            k = kappa_row(a + 1)                  # (clamped: a lane ahead of its rows evaluates row 0 again, so rd needs no guard)
-            nd = col_diffs(k, from_left(k3))
-            k3 = k[:, C - 1].copy()
-            dmslot_new = nd - rd
-            rd = nd
+            if diff:
+                k = kappa_row(a + 1)              # (clamped: a lane ahead of its rows evaluates row 0 again, so rd needs no guard)
+                nd = col_diffs(k, from_left(k3))
+                k3 = k[:, C - 1].copy()
+                dmslot_new = nd - rd
+                rd = nd
+            else:
+                dmslot_new = mask_pts(kappa_row(a)[:, :C])
         if tau >= 1:
             t = tau - 1
             a = t - ln
@@ -143,10 +153,13 @@ def fused(x, y, clev):
     # b0+4 is the right neighbour's first, one interval old); the sweeper's step i - 2 and the adjoint W = -H * kappa of point row a + 2
     # with the kernel values of interval i - 3; the evaluator's contraction of the W handed over in interval i - 1.
     # the backward sweep's columns are b0 .. b0+3: one to the right of the forward sweep's
-    qf = np.zeros((G, LQ, C)); qfg = q[:, :, 0].copy()
-    qf[:, :, :C - 1] = q[:, :, 1:]
-    for m in range(LQ):
-        qf[:, m, C - 1] = from_right(q[:, m, 0])
+    if diff:
+        qf = np.zeros((G, LQ, C)); qfg = q[:, :, 0].copy()
+        qf[:, :, :C - 1] = q[:, :, 1:]
+        for m in range(LQ):
+            qf[:, m, C - 1] = from_right(q[:, m, 0])
+    else:                                         # difference=False: columns are the lane's points in both sweeps
+        qf, qfg = q.copy(), qg.copy()
     # the upstream gradients ride in the suffix sums from the start (U_p = c_p + Qb_p: one add per cell less)
     qb = np.zeros((G, LQ, C)); qbg = np.zeros((G, LQ)); svout = np.zeros((G, LQ)); sufout = np.zeros((G, LQ))
     for p_ in range(1, M):
@@ -164,16 +177,19 @@ def fused(x, y, clev):
         if i <= TF:
             a = R1 + (G - 1 - ln) - i
             k = kappa_row(a)
-            k[:, C] = from_right(k0)
-            k[G - 1, C] = k[G - 1, C - 1]           # the last lane has no neighbour: its last column (63) is never a lattice column, dm == 0 there
-            k0 = k[:, 0].copy()
-            nd = k[:, 1:] - k[:, :-1]
-            dm_new = rd - nd
-            rd = nd
+            if diff:
+                k[:, C] = from_right(k0)
+                k[G - 1, C] = k[G - 1, C - 1]       # the last lane has no neighbour: its last column (63) is never a lattice column, dm == 0 there
+                k0 = k[:, 0].copy()
+                nd = k[:, 1:] - k[:, :-1]
+                dm_new = rd - nd
+                rd = nd
+            else:
+                dm_new = mask_pts(k[:, :C])
             khist[i % KH] = k[:, :C]
         # ---- evaluator, contraction of the W of interval i - 1
         if i >= 3:
-            p = R1 + 4 + (G - 1 - ln) - i
+            p = R1 + (4 if diff else 2) + (G - 1 - ln) - i
             W = wslot[(i - 1) % 2]
             assert np.isfinite(W).all()
             pc = np.clip(p, 0, L1 - 1)
@@ -183,7 +199,7 @@ def fused(x, y, clev):
             Pout = Pin.copy()
             Pout[:, :D] += np.einsum('lc,lcf->lf', W, yp[:, :C])
             Pout[:, D] += W.sum(1)
-            if 0 <= p[0] <= R1:
+            if 0 <= p[0] <= L1 - 1:
                 gxa[p[0]] += Pout[0]
         # ---- sweeper: step i - 2, then E / H / W
         if 2 <= i <= TF + 3:
@@ -237,6 +253,8 @@ def fused(x, y, clev):
             qf = np.where(A3, qfn, qf); qfg = np.where(A2, qfgn, qfg); sufout = np.where(A2, sufn, sufout)
             qb = np.where(A3, qbn, qb); qbg = np.where(A2, qbgn, qbg); svout = np.where(A2, svn, svout)
             li = np.where(A2, mask_cols(lam), 0.0)
+            if not diff:                          # H = Lam: the kernel values of this row were evaluated in the previous interval
+                w_new = -li * khist[(i - 1) % KH]
             Enew = li - lamk
             lamk = li
             Eleft = from_left(Enew[:, C - 1])
@@ -245,7 +263,8 @@ def fused(x, y, clev):
             for c in range(1, C):
                 H[:, c] = Eprev[:, c - 1] - Eprev[:, c]
             Eprev = Enew
-            w_new = -H * khist[(i - 3) % KH]       # H == 0 outside the point rows 0 .. R1 by construction
+            if diff:
+                w_new = -H * khist[(i - 3) % KH]   # H == 0 outside the point rows 0 .. R1 by construction
         if i <= TF:
             dmslot[i % 2] = dm_new
         if 2 <= i <= TF + 3:
@@ -270,8 +289,8 @@ def main():
         x = np.cumsum(rng.standard_normal((L1, D)) * 0.3, 0)
         y = np.cumsum(rng.standard_normal((L2, D)) * 0.3, 0)
         clev = np.concatenate([[0.0], rng.standard_normal(M)])
-        gx0, gy0 = reference(x, y, clev)
-        gx1, gy1 = fused(x, y, clev)
+        gx0, gy0 = reference(x, y, clev, DIFF)
+        gx1, gy1 = fused(x, y, clev, DIFF)
         ex = np.abs(gx1 - gx0).max() / max(np.abs(gx0).max(), 1e-300)
         ey = np.abs(gy1 - gy0).max() / max(np.abs(gy0).max(), 1e-300)
         print(f"L1={L1} L2={L2} d={D} M={M}: rel err x {ex:.2e}  y {ey:.2e}")
