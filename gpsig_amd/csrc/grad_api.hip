@@ -23,13 +23,16 @@ Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
 typedef hipError_t (*FusedGradLaunchFn)(const FusedGradArgs&, int, size_t, hipStream_t);
 FusedGradLaunchFn fused_grad_lookup_diff_g16(int kind, int DP, int LQ);
+FusedGradLaunchFn fused_grad_lookup_diff_g32(int kind, int DP, int LQ);
 FusedGradLaunchFn fused_grad_lookup_diff_g64(int kind, int DP, int LQ);
 FusedGradLaunchFn fused_grad_lookup_nodiff_g16(int kind, int DP, int LQ);
+FusedGradLaunchFn fused_grad_lookup_nodiff_g32(int kind, int DP, int LQ);
 FusedGradLaunchFn fused_grad_lookup_nodiff_g64(int kind, int DP, int LQ);
-// G: lanes per pair group -- 16 (four pairs per wavefront) or 64 (one); diff: the lattice of double increments (difference=True, the
+// G: lanes per pair group -- 16 (four pairs per wavefront), 32 (two) or 64 (one); diff: the lattice of double increments (difference=True, the
 // reference's default) or the kernel matrix of the points itself
 static FusedGradLaunchFn fused_grad_lookup(int kind, int DP, int LQ, int G, bool diff) {
     if (G == 16) return diff ? fused_grad_lookup_diff_g16(kind, DP, LQ) : fused_grad_lookup_nodiff_g16(kind, DP, LQ);
+    if (G == 32) return diff ? fused_grad_lookup_diff_g32(kind, DP, LQ) : fused_grad_lookup_nodiff_g32(kind, DP, LQ);
     if (G == 64) return diff ? fused_grad_lookup_diff_g64(kind, DP, LQ) : fused_grad_lookup_nodiff_g64(kind, DP, LQ);
     return nullptr;
 }
@@ -435,7 +438,7 @@ FusedGradLaunchFn fused_grad_plan(const gpsig_ctx* c, const gpsig_params* p, int
     if (!sym && L1 < L2 && L2 > 16 * C) *swap = true;                 // the shorter side on the columns once the longer one needs 64 lanes
     const int cols = *swap ? L1 : L2, rows = *swap ? L2 : L1;
     if (cols > 64 * C) return nullptr;
-    *G = cols > 16 * C ? 64 : 16;
+    *G = cols > 32 * C ? 64 : (cols > 16 * C ? 32 : 16);
     if (sizeof(double) * size_t(fused_lds(rows, rows - (diff ? 1 : 0), DP, M - 1, *G, C).total) > FUSED_LDS_MAX) return nullptr;
     return fused_grad_lookup(p->base_kernel, DP, M - 1, *G, diff);  // RBF and the Matern families
 }

@@ -1,0 +1,6 @@
+// seq_grad_fused_kernel instances: 32 lanes per pair (two pairs per wavefront), double increments (difference=True)
+#include "grad_fused_inst.hpp"
+
+namespace gpsig {
+FusedGradLaunchFn fused_grad_lookup_diff_g32(int kind, int DP, int LQ) { return fused_grad_lookup_g<32, true>(kind, DP, LQ); }
+}  // namespace gpsig

@@ -503,7 +503,7 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
 template <int DP, int LQ, int KIND, int G, int C, bool DIFF>
 __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradArgs A) {
     extern __shared__ __attribute__((aligned(16))) double fg_sm[];
-    static_assert(G == 16 || G == 64, "a pair group is a DPP row or the whole wavefront");
+    static_assert(G == 16 || G == 32 || G == 64, "a pair group is a DPP row, half the wavefront or all of it");
     const int R1 = A.LS - (DIFF ? 1 : 0), R2 = A.LR - (DIFF ? 1 : 0), TF = R1 + G - 1;
     const FusedLds o = fused_lds(A.LS, R1, DP, LQ, G, C);
     const SeqTask tk = A.tasks[blockIdx.x];

@@ -23,6 +23,10 @@ __device__ __forceinline__ double wave_from_left(double v) {      // lane l <- l
     } else {
         lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);     // wave_shr:1
         hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+        if constexpr (G == 32) {                                            // two groups per wavefront: lane 32 must not see lane 31
+            const int m = (threadIdx.x & 31) == 0 ? 0 : -1;
+            lo &= m; hi &= m;
+        }
     }
     return __hiloint2double(hi, lo);
 }
@@ -35,6 +39,10 @@ __device__ __forceinline__ double wave_from_right(double v) {     // lane l <- l
     } else {
         lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);     // wave_shl:1
         hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+        if constexpr (G == 32) {
+            const int m = (threadIdx.x & 31) == 31 ? 0 : -1;
+            lo &= m; hi &= m;
+        }
     }
     return __hiloint2double(hi, lo);
 }

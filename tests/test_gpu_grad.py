@@ -1413,6 +1413,9 @@ def test_low_rank_svgp_trains():
     (4, 5, 5, 20, 20, 12, "sym"),       # 9 .. 16 columns of state space: two lattice columns per lane
     (3, 3, 4, 40, 100, 16, "cross"),    # ... with 64 lanes per pair and the roles exchanged
     (5, 9, 9, 128, 128, 9, "sym"),      # ... at the longest column side of that form
+    (5, 6, 6, 100, 100, 8, "sym"),      # 65 .. 128 points on the column side: 32 lanes per pair, two pairs per wavefront
+    (3, 7, 5, 128, 70, 5, "cross"),
+    (4, 5, 5, 50, 50, 12, "sym"),       # ... and 33 .. 64 points with two columns per lane
 ])
 @pytest.mark.parametrize("base", ["rbf", "matern12", "matern32", "matern52"])
 def test_stationary_kernels_reverse_pass_in_one_launch(base, M, N1, N2, L1, L2, d, kind):

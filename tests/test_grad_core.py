@@ -299,7 +299,7 @@ def test_lane_level_model_of_the_fused_reverse_kernel():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # lanes per pair group (four pairs per wavefront, or one pair with up to 256 points on the column side) x lattice columns per lane x
     # difference (1: the lattice of double increments, 0: the kernel matrix of the points)
-    for lanes, cols, diff in (("16", "4", "1"), ("64", "4", "1"), ("16", "2", "1"), ("16", "4", "0")):
+    for lanes, cols, diff in (("16", "4", "1"), ("32", "4", "1"), ("64", "4", "1"), ("16", "2", "1"), ("16", "4", "0")):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "sim_fused_grad.py")], capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, SIM_G=lanes, SIM_C=cols, SIM_DIFF=diff))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

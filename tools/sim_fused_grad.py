@@ -285,7 +285,7 @@ def main():
     worst = 0.0
     shapes64 = ((70, 200, 4, 3), (130, 256, 2, 5), (5, 65, 3, 2))
     shapes_c2 = ((40, 32, 12, 4), (9, 17, 16, 3), (3, 2, 9, 2))
-    for (L1, L2, D, M) in shapes64 if G == 64 else shapes_c2 if C == 2 else ((64, 64, 8, 5), (9, 64, 8, 4), (64, 33, 4, 3), (5, 7, 3, 2), (20, 62, 8, 5), (3, 2, 2, 3), (2, 64, 8, 5), (64, 64, 1, 2)):
+    for (L1, L2, D, M) in ((100, 128, 4, 3), (70, 65, 8, 5)) if G == 32 else shapes64 if G == 64 else shapes_c2 if C == 2 else ((64, 64, 8, 5), (9, 64, 8, 4), (64, 33, 4, 3), (5, 7, 3, 2), (20, 62, 8, 5), (3, 2, 2, 3), (2, 64, 8, 5), (64, 64, 1, 2)):
         x = np.cumsum(rng.standard_normal((L1, D)) * 0.3, 0)
         y = np.cumsum(rng.standard_normal((L2, D)) * 0.3, 0)
         clev = np.concatenate([[0.0], rng.standard_normal(M)])
