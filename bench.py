@@ -737,12 +737,21 @@ def gradient_lines(dev):
     W = torch.tensor(rng.standard_normal((N, N)), device=dev)
     ctx = _lib.context(dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
     # (name, class, option sig_features_grad, level sum and its gradient as one op -- gpsig_kernel_K_grad -- or level primitives + torch ops)
-    for name, cls, opt, one_op in (("grad-c2shape-n1024-linear", kernels.SignatureLinear, -1, True),
-                                   ("grad-c2shape-n1024-linear-level-primitives", kernels.SignatureLinear, -1, False),
-                                   ("grad-c2shape-n1024-linear-pair-kernels", kernels.SignatureLinear, 0, False),
-                                   ("grad-c2shape-n1024-rbf", kernels.SignatureRBF, -1, True)):
+    # (name, class, option sig_features_grad, one op, (N, L): None = the headline shape's 1,024 x 64)
+    for name, cls, opt, one_op, shape in (("grad-c2shape-n1024-linear", kernels.SignatureLinear, -1, True, None),
+                                          ("grad-c2shape-n1024-linear-level-primitives", kernels.SignatureLinear, -1, False, None),
+                                          ("grad-c2shape-n1024-linear-pair-kernels", kernels.SignatureLinear, 0, False, None),
+                                          ("grad-c2shape-n1024-rbf", kernels.SignatureRBF, -1, True, None),
+                                          # round 5's fused reverse kernel beyond its headline instance: another stationary family, and 128
+                                          # observations per sequence (32 lanes per pair, two pairs per wavefront)
+                                          ("grad-c2shape-n1024-matern32", kernels.SignatureMatern32, -1, True, None),
+                                          ("grad-n512-l128-rbf", kernels.SignatureRBF, -1, True, (512, 128))):
         try:
-            kern = cls(L * D, D, M, lengthscales=(math.sqrt(D) if cls is kernels.SignatureRBF else 1.0))
+            if shape is not None:
+                N, L = shape
+                X = torch.tensor(np.random.default_rng(0).standard_normal((N, L * D)), device=dev)
+                W = torch.tensor(np.random.default_rng(1).standard_normal((N, N)), device=dev)
+            kern = cls(L * D, D, M, lengthscales=(math.sqrt(D) if cls is not kernels.SignatureLinear else 1.0))
             mod = autodiff.SignatureKernelModule(kern, device=dev)
             mod.sum_route = one_op
             ctx.set_option("sig_features_grad", opt)

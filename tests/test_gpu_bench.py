@@ -76,7 +76,7 @@ def test_default_line_carries_the_measurement():
     names = [s["name"] for s in line["secondary"]]
     assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c3-linear", "c5-rbf", "c4-single-gpu",
                      "grad-c2shape-n1024-linear", "grad-c2shape-n1024-linear-level-primitives", "grad-c2shape-n1024-linear-pair-kernels",
-                     "grad-c2shape-n1024-rbf"]
+                     "grad-c2shape-n1024-rbf", "grad-c2shape-n1024-matern32", "grad-n512-l128-rbf"]
     ho = line["secondary"][1]                           # the higher-order algorithm at order = num_levels: the same contraction, the same time
     assert ho["bound"] == "mfma" and ho["ms_per_step"] < 1.3 * line["ms_per_step"]
     lat = line["secondary"][0]                          # the same Gram through the pair recursion: vector-issue bound, about twice the time
@@ -99,4 +99,6 @@ def test_default_line_carries_the_measurement():
     # the linear kernel's reverse pass through the feature contraction: several times faster than through the pair kernels
     assert g["grad-c2shape-n1024-linear"] * 3 < g["grad-c2shape-n1024-linear-pair-kernels"]
     assert g["grad-c2shape-n1024-linear"] < 1.1 * g["grad-c2shape-n1024-linear-level-primitives"]     # the level sum as one op is not slower
+    # round 5's fused reverse kernel is what runs (the Lam-through-HBM route took 48 / 106 / 55 ms for these three)
+    assert g["grad-c2shape-n1024-rbf"] < 25 and g["grad-c2shape-n1024-matern32"] < 35 and g["grad-n512-l128-rbf"] < 32
     assert line["secondary"][3]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
