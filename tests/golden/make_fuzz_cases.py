@@ -74,7 +74,7 @@ def main():
 
 def round5():
     out, names = {}, []
-    for seed, picks in ((71, {255: "kzx", 779: "kx80"}), (72, {298: "kzx"})):
+    for seed, picks in ((71, {255: "kzx", 779: "kx80"}), (72, {298: "kzx"}), (73, {629: "kx", 736: "k80"})):
         rng = np.random.default_rng(seed)
         for it in range(max(picks) + 1):
             cs = F.draw_case(rng)
@@ -91,6 +91,11 @@ def round5():
             out[key + "_base"] = np.array(cs["base"])
             if picks[it] == "kzx":
                 out[key + "_Kzx"] = ko.K_tens_vs_seq(Z, X, increments=cs["incr"])
+            elif picks[it] == "k80":
+                out[key + "_K"] = ko.K(X)
+                out[key + "_K80"] = np.asarray(F.oracle_for(cs, np.longdouble).K(X.astype(np.longdouble)), dtype=np.float64)
+            elif picks[it] == "kx":
+                out[key + "_Kx"] = ko.K(X, X2) if cs["L1"] == cs["L2"] else F._cross(ko, X, X2, cs["d"])
             else:
                 cross = (lambda k, a, b: k.K(a, b)) if cs["L1"] == cs["L2"] else (lambda k, a, b: F._cross(k, a, b, cs["d"]))
                 out[key + "_Kx"] = cross(ko, X, X2)
