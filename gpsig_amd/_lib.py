@@ -79,6 +79,8 @@ _KERNEL_FUNCS = {
     "gpsig_lr_kernel": [_LR, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp],
     "gpsig_lr_kernel_diag": [_LR, _vp, _i64, _i32, _vp],
     "gpsig_seq_gram_levels_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(C.c_double)],
+    "gpsig_seq_gram_levels_stash": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, C.POINTER(C.c_int64)],
+    "gpsig_seq_gram_levels_grad_stash": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
     "gpsig_seq_diag_levels_grad": [_vp, _i64, _i32, _vp, _vp, C.POINTER(C.c_double)],
     "gpsig_tens_gram_levels_grad": [_vp, _i64, _i32, _vp, _vp, C.POINTER(C.c_double)],
     "gpsig_tens_vs_seq_levels_grad": [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(C.c_double)],

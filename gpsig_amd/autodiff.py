@@ -97,7 +97,11 @@ def _p0_value(p0):
 
 
 class _SeqGramLevels(torch.autograd.Function):
-    """_K_seq (kernels.py:208-237): scaled sequences (N1, L1, d) [, (N2, L2, d)] -> (M+1, N1, N2)."""
+    """_K_seq (kernels.py:208-237): scaled sequences (N1, L1, d) [, (N2, L2, d)] -> (M+1, N1, N2).
+
+    A forward pass that will be differentiated asks the library to keep what its reverse pass needs of the forward recursion
+    (gpsig_seq_gram_levels_stash: where the fused reverse kernel can continue from it, the backward call then runs the backward sweep only);
+    the library says whether it did, and whether the stash still stands when the backward call comes."""
 
     @staticmethod
     def forward(ctx, Xs, X2s, p0, spec):
@@ -107,7 +111,15 @@ class _SeqGramLevels(torch.autograd.Function):
         keep = []
         p = spec.params(d, _p0_value(p0), keep)
         out = torch.empty((spec.num_levels + 1, n1, n2), dtype=torch.float64, device=X.device)
-        _ctx_for(X).call("gpsig_seq_gram_levels", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(out))
+        ctx.stash = None
+        want = X.is_cuda and spec.base == "rbf" and (Xs.requires_grad or (X2s is not None and X2s.requires_grad))
+        if want:
+            desc = (C.c_int64 * 8)()
+            _ctx_for(X).call("gpsig_seq_gram_levels_stash", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(out), desc)
+            if desc[0] != 0:
+                ctx.stash = list(desc)
+        else:
+            _ctx_for(X).call("gpsig_seq_gram_levels", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(out))
         ctx.spec, ctx.has_x2, ctx.has_p0 = spec, X2 is not None, p0 is not None
         ctx.dt = (Xs.dtype, None if X2s is None else X2s.dtype)
         ctx.save_for_backward(X, X2 if X2 is not None else X.new_empty(0), p0 if p0 is not None else X.new_empty(0))
@@ -125,8 +137,14 @@ class _SeqGramLevels(torch.autograd.Function):
         gX = torch.empty_like(X)
         gX2 = None if X2 is None else torch.empty_like(X2)
         gb = torch.zeros(2, dtype=torch.float64, device=X.device)
-        _ctx_for(X).call("gpsig_seq_gram_levels_grad", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(G), _ptr(gX),
-                         None if gX2 is None else _ptr(gX2), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
+        taken = C.c_int32(0)
+        if ctx.stash is not None:
+            desc = (C.c_int64 * 8)(*ctx.stash)
+            _ctx_for(X).call("gpsig_seq_gram_levels_grad_stash", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(G), _ptr(gX),
+                             None if gX2 is None else _ptr(gX2), desc, C.byref(taken))
+        if not taken.value:
+            _ctx_for(X).call("gpsig_seq_gram_levels_grad", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(G), _ptr(gX),
+                             None if gX2 is None else _ptr(gX2), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
         gp0 = gb[0].to(p0.device).reshape(p0.shape).to(p0.dtype) if ctx.has_p0 else None
         return gX.to(ctx.dt[0]), None if gX2 is None else gX2.to(ctx.dt[1]), gp0, None
 

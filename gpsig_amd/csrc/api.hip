@@ -58,6 +58,7 @@ SeqLaunchFn seq_lookup_inc_g16(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_inc_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptd_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdrbf_stash(int, int, int, int);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d4(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d8(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d16(int, int, int, int, bool);
@@ -1060,10 +1061,44 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     A.sum_levels = r.sum_levels; A.pred = diag_own ? int(PRED_DIAG_OWN) : r.pred; A.mirror = r.mirror; A.use_glds = c->use_glds; A.compact = r.compact; A.keep_reset = c->keep_reset;
     const size_t lds = sizeof(TT) * (size_t(A.RS) + size_t(A.nslot) * A.slot_elems);
     if (lds > 160 * 1024) return fail(c, GPSIG_ERR_UNSUPPORTED, "x-side records of %d rows do not fit the LDS ring (%zu bytes)", A.R1, lds);
+    // gpsig_seq_gram_levels_stash: the instances the fused reverse kernel continues from also write what it needs of this recursion
+    SeqLaunchFn fn = pl.fn;
+    if (c->stash_want && sizeof(TT) == 8 && !pl.pk2 && pl.rbf_prescaled && pl.cfg.exact && pl.cfg.G == 16 && pl.cfg.C == 4 && p->order <= 1 &&
+        (r.pred == PRED_ALL || r.pred == PRED_CIRCULANT) && c->shard_n == 1 && r.y_begin == 0 && r.y_end <= 0 && !r.compact && r.gx.rows >= 2 &&
+        r.gx.rows <= 64 && r.gy.rows <= 64) {
+        SeqLaunchFn sfn = seq_lookup_ptdrbf_stash(16, 4, pl.cfg.D, p->num_levels == pl.cfg.MMAX ? pl.cfg.MMAX : -1);
+        const int R1l = r.gx.rows - 1, LQ = p->num_levels - 1;
+        const int64_t stride = int64_t(R1l) * LQ + 16 * int64_t(LQ) * 4;        // grad_fused_kernel.hpp: fused_stash_stride
+        const size_t need = sizeof(double) * size_t(npairs) * size_t(stride);
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(c->stream, &cs);
+        if (sfn && LQ >= 1 && cs == hipStreamCaptureStatusNone && need <= (size_t(c->grad_stash_mb > 0 ? c->grad_stash_mb : 0) << 20)) {
+            void* st;
+            CHK(ensure(c, B_STASH, need + 64, &st));
+            int64_t k2[10];
+            for (int q = 0; q < 10; ++q) k2[q] = key[q];
+            k2[9] = 4 + (diag_own ? 0 : 0);                                     // the tasks' first pair slots, packed (y0 = low word, x0 = high word)
+            const SeqTask* dp = nullptr;
+            int np = 0;
+            CHK(task_list(c, k2, [&](std::vector<SeqTask>& T) {
+                std::vector<SeqTask> F = seq_build_tasks(r.N1, r.N2, ypb, r.pred, int(max_run), 0, 1);
+                T.clear();
+                int64_t at = 0;
+                for (const SeqTask& t : F) { T.push_back(SeqTask{int32_t(uint32_t(at & 0xffffffff)), int32_t(at >> 32), 0}); at += t.nx; }
+                return at;
+            }, &dp, &np));
+            if (np == ntasks) {
+                A.stash = static_cast<double*>(st); A.stash_pair0 = dp; A.stash_stride = stride;
+                fn = sfn;
+                c->stash_desc[0] = ++c->stash_gen; c->stash_desc[1] = r.pred; c->stash_desc[2] = max_run; c->stash_desc[3] = ypb;
+                c->stash_desc[4] = ntasks; c->stash_desc[5] = npairs; c->stash_desc[6] = stride; c->stash_desc[7] = R1l;
+            }
+        }
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool timed = false;
     if (r.timed) CHK(timing_begin(c, &e0, &e1, &timed));
-    HIPCHK(c, pl.fn(A, ntasks, lds, c->stream));
+    HIPCHK(c, fn(A, ntasks, lds, c->stream));
     if (timed) {
         HIPCHK(c, hipEventRecord(e1, c->stream));
         c->t_launches += 1;
@@ -2044,6 +2079,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "tensor_lanes")) c->tens_lanes = value;
     else if (!strcmp(name, "grad_scratch_mb")) c->grad_scratch_mb = value > 0 ? value : 4096;
     else if (!strcmp(name, "grad_impl")) c->grad_impl = value;
+    else if (!strcmp(name, "grad_stash_mb")) c->grad_stash_mb = value;
     else if (!strcmp(name, "tvs_zreg")) c->tvs_zreg = value;
     else if (!strcmp(name, "tvs_grad_tile")) c->tvs_grad_tile = value;
     else if (!strcmp(name, "pinned_staging")) c->pinned_staging = value ? 1 : 0;
@@ -2285,6 +2321,24 @@ int gpsig_seq_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* X, co
                           int32_t L1, int32_t L2, void* out) {
     if (!c || !p) return GPSIG_ERR_INVALID;
     return p->dtype == GPSIG_F32 ? Impl<float>::e_seq_gram_levels(c, p, X, X2, N1, N2, L1, L2, out) : Impl<double>::e_seq_gram_levels(c, p, X, X2, N1, N2, L1, L2, out);
+}
+
+// The raw levels as gpsig_seq_gram_levels, and -- where the fused reverse kernel can continue from it (SignatureRBF with differences, order 1,
+// float64, at most 64 observations and 8 columns, num_levels 4 / 5, the whole thing within "grad_stash_mb") -- the forward recursion's row totals
+// and final states kept in the context for gpsig_seq_gram_levels_grad_stash.  desc[0] == 0: nothing was kept, differentiate with
+// gpsig_seq_gram_levels_grad.  Device pointers only.
+int gpsig_seq_gram_levels_stash(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
+                                int32_t L1, int32_t L2, void* out, int64_t* desc) {
+    if (!c || !p || !desc) return GPSIG_ERR_INVALID;
+    for (int q = 0; q < 8; ++q) desc[q] = 0;
+    if (p->dtype != GPSIG_F64 || c->ptr_mode != GPSIG_PTR_DEVICE) return gpsig_seq_gram_levels(c, p, X, X2, N1, N2, L1, L2, out);
+    c->stash_want = true;
+    c->stash_desc[0] = 0;
+    const int rc = Impl<double>::e_seq_gram_levels(c, p, X, X2, N1, N2, L1, L2, out);
+    c->stash_want = false;
+    if (rc == GPSIG_OK)
+        for (int q = 0; q < 8; ++q) desc[q] = c->stash_desc[q];
+    return rc;
 }
 
 int gpsig_seq_diag_levels(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, void* out) {

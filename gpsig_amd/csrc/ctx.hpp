@@ -33,6 +33,7 @@ enum BufId {
     B_SF0, B_SF1, B_SF2, B_SF3, B_SF4, B_SF5,                               // explicit level features (sig_feat_kernel.hpp): both sides, partial products, level diagonals                              // weighted tensor-vs-sequence sums: partial factor gradients; level arrays of the fallback
     B_SPEC,                                                    // spectral base-kernel table
     B_TQ,                                                      // item counters of the Kzx tile kernel's persistent launch
+    B_STASH,                                                   // what the fused reverse kernel needs of the forward recursion (gpsig_seq_gram_levels_stash)
     B_COUNT
 };
 
@@ -74,6 +75,10 @@ struct gpsig_ctx {
     int max_run = 0;
     int tens_lanes = -1;   // -1 auto, 0 sequence lanes, 1 tensor lanes
     int grad_scratch_mb = 4096;   // lattice scratch of one gradient launch
+    int grad_stash_mb = 4096;     // gpsig_seq_gram_levels_stash keeps at most this much for the backward call (0: never)
+    bool stash_want = false;      // set around the forward launch by gpsig_seq_gram_levels_stash; launch_seq fills stash_desc if it wrote one
+    int64_t stash_desc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // generation (0: none), pred, max_run, ypb, tasks, pair slots, stride, lattice rows
+    int64_t stash_gen = 0;
     int grad_impl = 0;            // 0: planner's choice, 1: one pair per thread + stored lattice, 2: one pair per thread scratch-free (tensor-vs-seq),
                                   // 3: wavefront kernel + stored lattice, 4: scratch-free wavefront kernel wherever it is built
     void* blas_handle = nullptr;  // rocBLAS handle of gpsig_lr_whitening (lowrank_solver.hip), created at first use

@@ -22,6 +22,7 @@ Wave2LaunchFn lam_undo_lookup_ptd_gen(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
 typedef hipError_t (*FusedGradLaunchFn)(const FusedGradArgs&, int, size_t, hipStream_t);
+FusedGradLaunchFn fused_grad_stash_lookup(int DP, int LQ);
 FusedGradLaunchFn fused_grad_lookup_diff_g16(int kind, int DP, int LQ);
 FusedGradLaunchFn fused_grad_lookup_diff_g32(int kind, int DP, int LQ);
 FusedGradLaunchFn fused_grad_lookup_diff_g64(int kind, int DP, int LQ);
@@ -477,6 +478,65 @@ int seq_grad_fused(gpsig_ctx* c, const gpsig_params* p, FusedGradLaunchFn fn, in
     return GPSIG_OK;
 }
 
+// The backward sweep alone, continuing from the stash gpsig_seq_gram_levels_stash left in the context (desc: its descriptor).  The tasks are
+// pieces of the evaluation kernel's own tasks -- same quads of register-side sequences, same runs (circulant for the symmetric Gram: streamed
+// indices wrap and a pair belongs to whichever orientation seq_emit owns) -- so that a pair's slot in the stash is where that kernel wrote it.
+int seq_grad_fused_stash(gpsig_ctx* c, const gpsig_params* p, int DP, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2, int d,
+                         bool sym, const double* Gup, double* gX, double* gY, const int64_t* desc, bool* done) {
+    *done = false;
+    const int M = p->num_levels, LQ = M - 1;
+    if (desc[0] == 0 || desc[0] != c->stash_gen || desc[0] != c->stash_desc[0]) return GPSIG_OK;             // nothing kept, or overwritten since
+    const int pred = int(desc[1]), ypb = int(desc[3]);
+    const int64_t max_run = desc[2];
+    if (ypb != 4 || desc[7] != L1 - 1 || desc[6] != fused_stash_stride(L1 - 1, LQ, 16, 4) || (pred != PRED_ALL && pred != PRED_CIRCULANT)) return GPSIG_OK;
+    if ((pred == PRED_CIRCULANT) != sym && !(sym && pred == PRED_ALL)) return GPSIG_OK;
+    FusedGradLaunchFn fn = fused_grad_stash_lookup(DP, LQ);
+    void* st = c->buf[B_STASH].p;
+    if (!fn || !st || L2 > 64 || L1 < 2 || L2 < 2) return GPSIG_OK;
+    const size_t lds = sizeof(double) * size_t(fused_lds(L1, L1 - 1, DP, LQ, 16, 4).total);
+    if (lds > FUSED_LDS_MAX) return GPSIG_OK;
+    CHK(zero_async(c, gX, sizeof(double) * size_t(N1) * L1 * d));
+    if (!sym) CHK(zero_async(c, gY, sizeof(double) * size_t(N2) * L2 * d));
+    constexpr int64_t PIECE = 16;                       // streamed sequences per workgroup
+    const int64_t key[10] = {N1, N2, max_run, pred, PIECE, 0, 0, 0, 0, 5}, key2[10] = {N1, N2, max_run, pred, PIECE, 0, 0, 0, 0, 6};
+    auto pieces = [&](std::vector<SeqTask>& T, bool bases) {
+        std::vector<SeqTask> F = seq_build_tasks(N1, N2, ypb, pred, int(max_run), 0, 1);
+        T.clear();
+        int64_t at = 0;
+        for (const SeqTask& t : F) {
+            for (int64_t o = 0; o < t.nx; o += PIECE) {
+                const int64_t n = t.nx - o < PIECE ? t.nx - o : PIECE, a0 = at + o;
+                int64_t x0 = int64_t(t.x0) + o;
+                if (pred == PRED_CIRCULANT) x0 %= N1;
+                if (bases) T.push_back(SeqTask{int32_t(uint32_t(a0 & 0xffffffff)), int32_t(a0 >> 32), 0});
+                else T.push_back(SeqTask{t.y0, int32_t(x0), int32_t(n)});
+            }
+            at += t.nx;
+        }
+        return at;
+    };
+    const SeqTask *dt, *dp;
+    int n = 0, n2 = 0;
+    int64_t slots = 0;
+    CHK(task_list(c, key, [&](std::vector<SeqTask>& T) { return pieces(T, false); }, &dt, &n, &slots));
+    CHK(task_list(c, key2, [&](std::vector<SeqTask>& T) { return pieces(T, true); }, &dp, &n2));
+    if (n == 0 || n != n2 || slots * ypb != desc[5]) return GPSIG_OK;
+    FusedGradArgs A;
+    memset(&A, 0, sizeof(A));
+    const bool circ = pred == PRED_CIRCULANT;
+    A.S = X; A.R = Y; A.gS = gX; A.gR = sym ? gX : gY;
+    A.NS = int(N1); A.NR = int(N2); A.LS = L1; A.LR = L2; A.d = d;
+    A.tasks = dt; A.pair0_list = dp;
+    A.G = Gup; A.gm = N1 * N2; A.gs = N2; A.gr = 1;
+    A.sym = circ ? 1 : 0;                               // (a symmetric Gram evaluated pair by pair, PRED_ALL: every ordered pair with its own G[s][r])
+    A.circ = circ ? 1 : 0;
+    A.stash = static_cast<const double*>(st); A.stash_stride = desc[6];
+    const hipError_t e = fn(A, n, lds, c->stream);
+    if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_fused_kernel (backward sweep from the stash) launch failed: %s", hipGetErrorString(e));
+    *done = true;
+    return GPSIG_OK;
+}
+
 // ---- higher-order algorithm (order > 1): lattice operations over blocks of pairs (grad_ho_kernels.hpp) + lam_contract_kernel ----
 int seq_grad_ho(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2,
                 int d, bool diag, bool sym, const double* Gup, double* gX, double* gY, double* gbase) {
@@ -771,6 +831,27 @@ int gpsig_seq_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* 
     if (!c) return GPSIG_ERR_INVALID;
     if (X2 && !gX2) return fail(c, GPSIG_ERR_INVALID, "gX2 is NULL");
     return seq_grad(c, p, X, X2, N1, N2, L1, L2, false, G, gX, gX2, g_base);
+}
+
+// The same gradient continued from what gpsig_seq_gram_levels_stash kept of the forward recursion (desc: the descriptor it returned): the fused
+// reverse kernel's backward sweep only.  *taken == 0: the stash is gone (another evaluation has overwritten it) or was never written -- nothing
+// was computed, call gpsig_seq_gram_levels_grad.  Device pointers, float64.
+int gpsig_seq_gram_levels_grad_stash(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2, int32_t L1,
+                                     int32_t L2, const void* G, void* gX, void* gX2, const int64_t* desc, int32_t* taken) {
+    if (!c || !p || !desc || !taken) return GPSIG_ERR_INVALID;
+    *taken = 0;
+    if (X2 && !gX2) return fail(c, GPSIG_ERR_INVALID, "gX2 is NULL");
+    if (c->ptr_mode != GPSIG_PTR_DEVICE || p->dtype != GPSIG_F64 || c->grad_impl != 0) return GPSIG_OK;
+    int d, DP;
+    CHK(grad_check(c, p, &d, &DP));
+    if (p->base_kernel != GPSIG_BASE_RBF || lattice_mode(p) != MODE_PT_DIFF || p->order > 1 || DP > 8 || N1 <= 0 || (X2 && N2 <= 0)) return GPSIG_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool sym = X2 == nullptr;
+    bool done = false;
+    CHK(seq_grad_fused_stash(c, p, DP, static_cast<const double*>(X), static_cast<const double*>(sym ? X : X2), N1, sym ? N1 : N2, L1, sym ? L1 : L2, d,
+                             sym, static_cast<const double*>(G), static_cast<double*>(gX), static_cast<double*>(sym ? gX : gX2), desc, &done));
+    *taken = done ? 1 : 0;
+    return GPSIG_OK;
 }
 
 int gpsig_seq_diag_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, int64_t N, int32_t L, const void* G, void* gX,

@@ -35,7 +35,15 @@ struct FusedGradArgs {
     const SeqTask* tasks;                  // y0 = first of the 64 / G register-side sequences, x0 / nx = run of streamed sequences
     const double* G; int64_t gm, gs, gr;   // upstream: G[m * gm + s * gs + r * gr], m = 1 .. M
     int sym;                               // symmetric Gram: pairs s >= r only, s > r carries G[s][r] + G[r][s]
+    // PHASE == 2 (backward sweep only): the forward recursion's row totals and final Q's come from the stash the evaluation kernel wrote
+    // (seq_gram_kernel.hpp: STASH; layout fused_stash_stride below) and the tasks are pieces of ITS tasks: pair k of this task, group g, sits at
+    // stash + ((pair0 + k) * (64 / G) + g) * stash_stride, pair0 = (x0 << 32 | y0) of pair0_list[task]; circ: the symmetric Gram's pairs are
+    // the evaluation kernel's circulant ones (SeqGramArgs: PRED_CIRCULANT -- streamed indices wrap, ownership as seq_emit decides it)
+    const double* stash; const SeqTask* pair0_list; int64_t stash_stride; int circ;
 };
+
+// doubles per pair in the stash: R1 lattice rows x LQ row totals (levels 1 .. M-1), then G lanes x LQ x C final Q's (forward convention)
+__host__ __device__ inline int64_t fused_stash_stride(int R1, int LQ, int G, int C) { return int64_t(R1) * LQ + int64_t(G) * LQ * C; }
 
 constexpr int FG_KH = 5;                 // depth of the kernel-value ring.  G = 16 or 64 lanes per pair (4 pairs or 1 per wavefront), C = 4 columns per lane
                                          // (2 where the state space has 9 .. 16 columns: the lane's points are C * DP doubles of registers)
@@ -197,7 +205,7 @@ __device__ __forceinline__ void fg_flush(const FusedGradArgs& A, const double* s
 }
 
 // ---- wavefront 0 ----------------------------------------------------------------------------------------------------------------
-template <int DP, int KIND, int G, int C, bool DIFF>
+template <int DP, int KIND, int G, int C, bool DIFF, int PHASE>
 __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
     constexpr int DS = DP + 2;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
@@ -236,7 +244,8 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
     auto row_of = [&](int p) { return xs + (p < 0 ? 0 : (p > lsm1 ? lsm1 : p)) * DS; };
 
     for (int it = 0; it < tk.nx; ++it) {
-        const int64_t s = int64_t(tk.x0) + it;
+        int64_t s = int64_t(tk.x0) + it;
+        if (PHASE == 2 && A.circ && s >= A.NS) s -= A.NS;
         __syncthreads();                       // the flush of the previous streamed sequence has read gxa / xs
         fg_stage<DP, KIND>(A, sm, o, s);
         __syncthreads();
@@ -246,7 +255,9 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
         // row, the evaluation kernel's convention (seq_core.hpp).  Lane 0's column -1 is no column: dm == 0 there.  A lane ahead of its first
         // row evaluates row 0 again and again (row_of clamps), so rd needs no guard; what it hands over outside its rows the sweeper does not read.
         double rd[C], k3 = 0.0;
-        if constexpr (DIFF) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) rd[c] = 0.0;
+        if constexpr (DIFF && PHASE != 2) {
             double k[C], g[C];
             fg_kappa_row<DP, KIND, C>(row_of(0), y, hy, tab_addr, k, g);
             double kl = wave_from_left<G>(k[C - 1]);
@@ -256,7 +267,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
             for (int c = 1; c < C; ++c) rd[c] = k[c] - k[c - 1];
             k3 = k[C - 1];
         }
-        for (int i = 0; i <= TF; ++i) {
+        for (int i = 0; i <= (PHASE == 2 ? -1 : TF); ++i) {     // (PHASE == 2: no forward sweep, its results are in the stash)
             if (i < TF) {
                 double k[C], g[C], dm[C];
                 if constexpr (DIFF) {
@@ -366,7 +377,7 @@ __device__ __forceinline__ void fg_evaluator(const FusedGradArgs& A, const SeqTa
 }
 
 // ---- wavefront 1 ----------------------------------------------------------------------------------------------------------------
-template <int DP, int LQ, int KIND, int G, int C, bool DIFF>
+template <int DP, int LQ, int KIND, int G, int C, bool DIFF, int PHASE>
 __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask tk, double* sm, const FusedLds o, int R1, int R2, int TF) {
     constexpr int M = LQ + 1;
     const int lane = threadIdx.x & 63, ln = lane & (G - 1), gw = lane / G;
@@ -376,9 +387,21 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
     int nvalid = R2 - C * ln;                 // lattice columns among b0 .. b0+3 (the backward sweep's)
     nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
 
+    int64_t pair0 = 0;
+    if constexpr (PHASE == 2) {
+        const SeqTask pz = A.pair0_list[blockIdx.x];
+        pair0 = (int64_t(pz.x0) << 32) | int64_t(uint32_t(pz.y0));
+    }
     for (int it = 0; it < tk.nx; ++it) {
-        const int64_t s = int64_t(tk.x0) + it;
-        const bool have = rvalid && (!A.sym || s >= r);
+        int64_t s = int64_t(tk.x0) + it;
+        if (PHASE == 2 && A.circ && s >= A.NS) s -= A.NS;
+        bool have = rvalid && (!A.sym || s >= r);
+        if (PHASE == 2 && A.circ) {            // the evaluation kernel's ownership of the symmetric Gram's pairs (seq_emit, PRED_CIRCULANT)
+            const int64_t N = A.NS, H = N / 2;
+            int64_t dlt = r - s;
+            if (dlt < 0) dlt += N;
+            have = rvalid && (dlt < H || (dlt == H && ((N & 1) || s < r)));
+        }
         double clev[LQ + 2];
 #pragma unroll
         for (int p = 0; p < LQ + 2; ++p) {
@@ -394,7 +417,20 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
         __syncthreads();
         WaveFwd<C, LQ> fw;
         fw.reset();
-        for (int i = 0; i <= TF; ++i) {
+        if constexpr (PHASE == 2) {            // the forward sweep's results from the stash: row totals into LDS, this lane's Q's into registers
+            const double* st = A.stash + ((pair0 + it) * (64 / G) + gw) * A.stash_stride;
+            if (rvalid) {
+                for (int e = ln; e < R1 * LQ; e += G) rt[e] = st[e];
+                const double* qs = st + int64_t(R1) * LQ + ln * (LQ * C);
+#pragma unroll
+                for (int m = 0; m < LQ; ++m)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) fw.q[m][c] = qs[m * C + c];
+            } else {
+                for (int e = ln; e < R1 * LQ; e += G) rt[e] = 0.0;
+            }
+        }
+        for (int i = 0; i <= (PHASE == 2 ? -1 : TF); ++i) {
             if (i >= 1) {
                 double cin[LQ + 2];
                 cin[0] = 0.0;
@@ -500,7 +536,7 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
 }
 
 // grid: one workgroup of 128 threads per task; dynamic LDS: fused_lds(LS, LS - 1, DP, LQ).total doubles
-template <int DP, int LQ, int KIND, int G, int C, bool DIFF>
+template <int DP, int LQ, int KIND, int G, int C, bool DIFF, int PHASE = 0>
 __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradArgs A) {
     extern __shared__ __attribute__((aligned(16))) double fg_sm[];
     static_assert(G == 16 || G == 32 || G == 64, "a pair group is a DPP row, half the wavefront or all of it");
@@ -513,10 +549,10 @@ __global__ void __launch_bounds__(128, 2) seq_grad_fused_kernel(const FusedGradA
     // Both wavefronts run the same barrier sequence: per streamed sequence two around the staging of its record (fg_stage), then
     // TF + 1 forward and TF + 5 backward intervals; the flush of the x side (fg_flush) is covered by the next sequence's first barrier.
 #if defined(FG_ONLY_ROLE)          // register count of one role alone (compile-time experiment; such a kernel deadlocks at its first barrier)
-    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP, KIND, G, C, DIFF>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ, KIND, G, C, DIFF>(A, tk, fg_sm, o, R1, R2, TF); }
+    if (role == FG_ONLY_ROLE) { if (FG_ONLY_ROLE == 0) fg_evaluator<DP, KIND, G, C, DIFF, PHASE>(A, tk, fg_sm, o, R1, R2, TF); else fg_sweeper<DP, LQ, KIND, G, C, DIFF, PHASE>(A, tk, fg_sm, o, R1, R2, TF); }
 #else
-    if (role == 0) fg_evaluator<DP, KIND, G, C, DIFF>(A, tk, fg_sm, o, R1, R2, TF);
-    else fg_sweeper<DP, LQ, KIND, G, C, DIFF>(A, tk, fg_sm, o, R1, R2, TF);
+    if (role == 0) fg_evaluator<DP, KIND, G, C, DIFF, PHASE>(A, tk, fg_sm, o, R1, R2, TF);
+    else fg_sweeper<DP, LQ, KIND, G, C, DIFF, PHASE>(A, tk, fg_sm, o, R1, R2, TF);
 #endif
 }
 

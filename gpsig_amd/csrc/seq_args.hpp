@@ -52,6 +52,13 @@ struct SeqGramArgs {
                             // N/2+1 owned columns j-N/2 .. j side by side (multi-GPU row blocks: half the bytes to gather)
     int32_t keep_reset;     // 1: first-order lanes clear their accumulators through SeqLane::keep, 0: explicit reset() at pair boundaries
     const double* spec;     // BASE_SPECTRAL: alpha[Q], omega[Q][D], gamma[Q][D] (Q = p0, family = p1, D = the kernel's padded width)
+    // STASH instances only (round 5): what the reverse pass needs of the forward recursion, kept instead of recomputed -- per pair the row
+    // totals of levels 1 .. M-1 of every lattice row, then every lane's final Q's; pair k of task t, group g, sits at
+    // stash + ((pair0(t) + k) * (64 / G) + g) * stash_stride  (doubles; layout in grad_fused_kernel.hpp: fused_stash_stride), pair0(t) packed
+    // into stash_pair0[t] as (x0 << 32 | y0) -- the task lists' device cache holds SeqTask records
+    double* stash;
+    const SeqTask* stash_pair0;
+    int64_t stash_stride;
 };
 
 

@@ -56,8 +56,12 @@ __device__ __forceinline__ float shr1(float v) {
 #ifndef SEQ_RBF_WAVES
 #define SEQ_RBF_WAVES 2
 #endif
-template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1>
+// STASH (round 5, the float64 RBF instances whose pairs the fused reverse kernel takes): the kernel also writes what that reverse pass needs of
+// this recursion -- every lattice row's totals of levels 1 .. M-1 (the last lane's hand-over words) and every lane's Q's when its pair ends
+// (SeqGramArgs::stash) -- so that the backward call starts at the turn of the sweeps instead of repeating the forward one.
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1, bool STASH = false>
 __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 32 ? SEQ_RBF_WAVES : ((MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1)) void seq_gram_kernel(const SeqGramArgs A) {
+    static_assert(!STASH || (SEQ_FAST_RBF(T, MODE, OMAX, KIND) && EXACT && MMAX >= 2), "the stash is written by the exact float64 RBF instances");
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
     static_assert((D * sizeof(T)) % 16 == 0, "record rows are read with 16-byte LDS loads");
     using Lane = typename std::conditional<OMAX == 0, SeqLane<T, C, D, MMAX, MODE>, SeqLaneHO<T, C, D, MMAX, (OMAX > 0 ? OMAX : 1), MODE>>::type;
@@ -81,6 +85,11 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
     const int lam = lane & (G - 1);
     const int grp = lane / G;
     const SeqTask tk = A.tasks[blockIdx.x];
+    int64_t stash_pair0 = 0;
+    if constexpr (STASH) {
+        const SeqTask pz = A.stash_pair0[blockIdx.x];
+        stash_pair0 = (int64_t(pz.x0) << 32) | int64_t(uint32_t(pz.y0));
+    }
     const int M = EXACT ? MMAX : A.M;
     const int R1 = A.R1, RS = A.RS, nslot = A.nslot, nx = tk.nx;
     const T* const xrec = static_cast<const T*>(A.xrec);
@@ -184,6 +193,16 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
                 T* const out = static_cast<T*>(A.out);
                 seq_emit<T>(L, A, i, j, M, [&](int64_t off, T v) { out[off] = v; });
             }
+            if constexpr (STASH) {
+                if (ctl.p >= 1 && jvalid) {              // this lane's Q's of the pair it has just finished
+                    double* qd = A.stash + ((stash_pair0 + (ctl.p - 1)) * (64 / G) + grp) * A.stash_stride
+                                 + int64_t(A.R1 - 1) * (MMAX - 1) + lam * ((MMAX - 1) * C);
+#pragma unroll
+                    for (int m = 0; m < MMAX - 1; ++m)
+#pragma unroll
+                        for (int r = 0; r < C; ++r) qd[m * C + r] = L.q[m][r];
+                }
+            }
             // first-order lanes clear their accumulators through L.keep (below); only a pair that overflowed needs the explicit
             // reset, so that its inf / NaN does not outlive it in this lane
             if constexpr (Lane::HIGHER_ORDER) L.reset();
@@ -203,6 +222,14 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
         if constexpr (FAST_RBF) seq_step_rbf_prescaled(L, DevNbr{L}, xr, hx, etab, M, dummy, rlo, rhi);
         else if constexpr (KIND == BASE_SPECTRAL && OMAX == 0 && MODE != MODE_INC) seq_step_spectral(L, DevNbr{L}, xr, A.spec, int(A.p0), int(A.p1), M, dummy, rlo, rhi);
         else seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, KIND >= 0 ? KIND : A.kind, p0, p1);
+        if constexpr (STASH) {
+            if (lam == G - 1 && !dummy && jvalid && ctl.p >= 0 && ctl.p < nx) {      // the row totals of the lattice row just swept
+                double* rt = A.stash + ((stash_pair0 + ctl.p) * (64 / G) + grp) * A.stash_stride
+                             + int64_t(A.R1 - ctl.left - 1) * (MMAX - 1);
+#pragma unroll
+                for (int m = 0; m < MMAX - 1; ++m) rt[m] = L.s[m];
+            }
+        }
         ctl.end_step();
     };
     // two steps per trip: the loop-carried hand-over words (s, qold) alternate registers instead of being copied
@@ -219,10 +246,10 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
     }
 }
 
-template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1>
+template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1, bool STASH = false>
 hipError_t seq_gram_launch(const SeqGramArgs& A, int ntasks, size_t lds_bytes, hipStream_t stream) {
     if (ntasks <= 0) return hipSuccess;
-    auto kern = seq_gram_kernel<T, G, C, D, MMAX, MODE, EXACT, OMAX, KIND>;
+    auto kern = seq_gram_kernel<T, G, C, D, MMAX, MODE, EXACT, OMAX, KIND, STASH>;
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes));
         if (e != hipSuccess) return e;

@@ -109,6 +109,7 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 through HBM to a contraction kernel per side).  0 additionally picks the fused reverse kernel of round 5 (an evaluator and a
  *                 sweeper wavefront per four sequence pairs, both sides contracted on chip) where it is built: RBF and the Matern families on
  *                 points with differences, order 1, at most 256 points on one side, at most 8 columns of state space, 2 to 6 levels
+ *   "grad_stash_mb" gpsig_seq_gram_levels_stash keeps at most this many MiB for the backward call (default 4096; 0: never)
  *   "tvs_grad_tile" reverse pass of the tensor-vs-sequence chains: 1 (default) the tile kernel (all levels in one reverse sweep per
  *                 sequence, d/dx summed in LDS, no atomics) where it is built (order 1, at most 8 columns, at most 6 levels), 0 the round-1 kernels
  *   "pinned_staging" host-pointer mode: 1 (default) transfers of 2 MiB and more run in 16 MiB chunks through two pinned buffers of the
@@ -351,6 +352,17 @@ int gpsig_lr_kernel_diag(gpsig_ctx* ctx, const gpsig_params* p, const gpsig_lowr
 /* X2 == NULL: symmetric Gram, gX receives both roles of every sequence. */
 int gpsig_seq_gram_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
                                int32_t L1, int32_t L2, const void* G /* (M+1, N1, N2) */, void* gX, void* gX2, double* g_base);
+/* The pair of them for a forward pass that will be differentiated (round 5; what the TensorFlow graph of the reference does implicitly -- the
+ * forward op's intermediates are kept for its gradient op).  _levels_stash evaluates like gpsig_seq_gram_levels and, where the fused reverse
+ * kernel can continue from it (SignatureRBF with differences, order 1, float64, at most 64 observations and 8 columns, num_levels 4 / 5, within
+ * option "grad_stash_mb", default 4096; not inside a graph capture), keeps the forward recursion's row totals and final states in the context:
+ * desc (8 integers) describes what was kept, desc[0] == 0 nothing.  _levels_grad_stash continues from it with the backward sweep only (*taken = 1),
+ * or does nothing (*taken = 0: never kept, or another evaluation has overwritten it since) -- then call gpsig_seq_gram_levels_grad.  Device
+ * pointers.  K(X) forward + backward of 1,024 sequences of 64 x 8, five levels: 17.0 -> 13 ms. */
+int gpsig_seq_gram_levels_stash(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
+                                int32_t L1, int32_t L2, void* out, int64_t* desc /* 8 */);
+int gpsig_seq_gram_levels_grad_stash(gpsig_ctx* ctx, const gpsig_params* p, const void* X, const void* X2, int64_t N1, int64_t N2,
+                                     int32_t L1, int32_t L2, const void* G, void* gX, void* gX2, const int64_t* desc, int32_t* taken);
 /* The explicit level features of the linear (cosine: of the unit vectors) kernel as an op of their own (round 4; no function of this name
  * in the reference: signature_algs.py:8-35 unrolled -- level m of SignatureLinear is <Phi_m(x), Phi_m(y)> -- and, for order > 1, the
  * truncated-exponential steps of :37-74; order = num_levels with difference on is the signature of the piecewise-linear path, what the
