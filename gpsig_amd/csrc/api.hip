@@ -2080,6 +2080,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "grad_scratch_mb")) c->grad_scratch_mb = value > 0 ? value : 4096;
     else if (!strcmp(name, "grad_impl")) c->grad_impl = value;
     else if (!strcmp(name, "grad_stash_mb")) c->grad_stash_mb = value;
+    else if (!strcmp(name, "grad_fused_piece")) c->grad_fused_piece = value;
     else if (!strcmp(name, "tvs_zreg")) c->tvs_zreg = value;
     else if (!strcmp(name, "tvs_grad_tile")) c->tvs_grad_tile = value;
     else if (!strcmp(name, "pinned_staging")) c->pinned_staging = value ? 1 : 0;

@@ -497,7 +497,7 @@ int seq_grad_fused_stash(gpsig_ctx* c, const gpsig_params* p, int DP, const doub
     if (lds > FUSED_LDS_MAX) return GPSIG_OK;
     CHK(zero_async(c, gX, sizeof(double) * size_t(N1) * L1 * d));
     if (!sym) CHK(zero_async(c, gY, sizeof(double) * size_t(N2) * L2 * d));
-    constexpr int64_t PIECE = 16;                       // streamed sequences per workgroup
+    const int64_t PIECE = c->grad_fused_piece > 0 ? c->grad_fused_piece : 16;       // streamed sequences per workgroup
     const int64_t key[10] = {N1, N2, max_run, pred, PIECE, 0, 0, 0, 0, 5}, key2[10] = {N1, N2, max_run, pred, PIECE, 0, 0, 0, 0, 6};
     auto pieces = [&](std::vector<SeqTask>& T, bool bases) {
         std::vector<SeqTask> F = seq_build_tasks(N1, N2, ypb, pred, int(max_run), 0, 1);

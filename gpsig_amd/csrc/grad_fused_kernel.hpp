@@ -420,7 +420,13 @@ __device__ __forceinline__ void fg_sweeper(const FusedGradArgs& A, const SeqTask
         if constexpr (PHASE == 2) {            // the forward sweep's results from the stash: row totals into LDS, this lane's Q's into registers
             const double* st = A.stash + ((pair0 + it) * (64 / G) + gw) * A.stash_stride;
             if (rvalid) {
-                for (int e = ln; e < R1 * LQ; e += G) rt[e] = st[e];
+                // (R1 <= 63 rows here: at most 16 words per lane -- all loads in flight before the first LDS store)
+                double v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const int e = ln + k * G; v[k] = e < R1 * LQ ? st[e] : 0.0; }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { const int e = ln + k * G; if (e < R1 * LQ) rt[e] = v[k]; }
+                for (int e = ln + 16 * G; e < R1 * LQ; e += G) rt[e] = st[e];
                 const double* qs = st + int64_t(R1) * LQ + ln * (LQ * C);
 #pragma unroll
                 for (int m = 0; m < LQ; ++m)

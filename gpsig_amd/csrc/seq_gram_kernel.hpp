@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
 #pragma unroll
                     for (int m = 0; m < MMAX - 1; ++m)
 #pragma unroll
-                        for (int r = 0; r < C; ++r) qd[m * C + r] = L.q[m][r];
+                        for (int r = 0; r < C; ++r) __builtin_nontemporal_store(L.q[m][r], qd + m * C + r);
                 }
             }
             // first-order lanes clear their accumulators through L.keep (below); only a pair that overflowed needs the explicit
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 3
                 double* rt = A.stash + ((stash_pair0 + ctl.p) * (64 / G) + grp) * A.stash_stride
                              + int64_t(A.R1 - ctl.left - 1) * (MMAX - 1);
 #pragma unroll
-                for (int m = 0; m < MMAX - 1; ++m) rt[m] = L.s[m];
+                for (int m = 0; m < MMAX - 1; ++m) __builtin_nontemporal_store(L.s[m], rt + m);      // written once, read by another launch
             }
         }
         ctl.end_step();

@@ -1514,3 +1514,49 @@ def test_rbf_reverse_pass_in_one_launch_is_the_route_taken():
     finally:
         ctx.set_option("grad_impl", 0)
     assert t[0] < 0.75 * t[4], t
+
+
+@pytest.mark.parametrize("M,N1,N2,L1,L2,d,kind", [(5, 64, 64, 64, 64, 8, "sym"), (4, 130, 130, 33, 33, 5, "sym"), (5, 37, 41, 64, 64, 8, "cross"),
+                                                  (4, 9, 7, 20, 31, 3, "cross"), (3, 10, 10, 12, 12, 4, "sym")])
+def test_forward_pass_keeps_what_its_reverse_pass_needs(M, N1, N2, L1, L2, d, kind):
+    """gpsig_seq_gram_levels_stash / _grad_stash through autodiff._SeqGramLevels (round 5): the evaluation kernel's stash instances write the
+    forward recursion's row totals and final states, the backward call runs the fused reverse kernel's backward sweep only.  Where the library
+    keeps nothing (shapes outside those instances: the last two cases) the route falls back by itself.  Held to torch.autograd of the oracle at
+    1e-6 and to the recompute route (option grad_stash_mb = 0) at 1e-9; a stash overwritten by a later evaluation is noticed and not used."""
+    from gpsig_amd import _lib
+    from gpsig_amd.autodiff import _SeqGramLevels, _Spec
+    dev = torch.device("cuda:0")
+    dctx = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
+    rng = np.random.default_rng(81)
+    X = np.cumsum(rng.standard_normal((N1, L1, d)) * 0.3, 1)
+    Y = np.cumsum(rng.standard_normal((N2, L2, d)) * 0.3, 1) if kind == "cross" else None
+    G = rng.standard_normal((M + 1, N1, N2 if kind == "cross" else N1))
+    kt = _t_kern("rbf", d, M, difference=True)
+    tX = torch.tensor(X, requires_grad=True)
+    tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+    (kt.K_seq_levels(tX, tY) * torch.tensor(G)).sum().backward()
+    spec = _Spec("rbf", M, True, 0.0, order=1)
+    Gd = torch.tensor(G, device=dev)
+    res, kept = [], []
+    try:
+        for mb, overwrite in ((4096, False), (0, False), (4096, True)):
+            dctx.set_option("grad_stash_mb", mb)
+            Xg = torch.tensor(X, device=dev, requires_grad=True)
+            Yg = None if Y is None else torch.tensor(Y, device=dev, requires_grad=True)
+            lev = _SeqGramLevels.apply(Xg, Yg, None, spec)
+            kept.append(lev.grad_fn.stash is not None)
+            if overwrite:                                   # another differentiated evaluation in between: this one's stash is gone
+                X2 = torch.tensor(X[::-1].copy(), device=dev, requires_grad=True)
+                _SeqGramLevels.apply(X2, None if Y is None else torch.tensor(Y, device=dev), None, spec)
+            (lev * Gd).sum().backward()
+            res.append((Xg.grad.cpu(), None if Yg is None else Yg.grad.cpu()))
+    finally:
+        dctx.set_option("grad_stash_mb", 4096)
+    assert kept[1] is False
+    if (M, L1, d) in ((5, 64, 8), (4, 33, 5)):
+        assert kept[0] and kept[2]                          # the instances the fused reverse kernel continues from
+    for gX, gY in res:
+        assert rel(gX, tX.grad) < 1e-6
+        assert rel(gX, res[1][0]) < 1e-9
+        if Y is not None:
+            assert rel(gY, tY.grad) < 1e-6 and rel(gY, res[1][1]) < 1e-9
