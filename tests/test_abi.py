@@ -121,7 +121,7 @@ def test_headline_kernel_keeps_three_wavefronts_per_simd(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
                           stderr=subprocess.DEVNULL)
     text = open(out).read()
-    name = "_ZN5gpsig15seq_gram_kernelIdLi16ELi4ELi8ELi5ELi0ELb1ELi0ELin1EEEvNS_11SeqGramArgsE"
+    name = "_ZN5gpsig15seq_gram_kernelIdLi16ELi4ELi8ELi5ELi0ELb1ELi0ELin1ELb0EEEvNS_11SeqGramArgsE"       # (..., STASH = false)
     start = text.index(name + ":")
     m = re.search(r"; NumVgprs: (\d+).*?; ScratchSize: (\d+).*?; Occupancy: (\d+)", text[start:], re.S)
     vgprs, scratch, occupancy = (int(g) for g in m.groups())
