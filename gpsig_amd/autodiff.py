@@ -112,7 +112,8 @@ class _SeqGramLevels(torch.autograd.Function):
         p = spec.params(d, _p0_value(p0), keep)
         out = torch.empty((spec.num_levels + 1, n1, n2), dtype=torch.float64, device=X.device)
         ctx.stash = None
-        want = X.is_cuda and spec.base == "rbf" and (Xs.requires_grad or (X2s is not None and X2s.requires_grad))
+        want = (X.is_cuda and spec.base in ("rbf", "matern12", "matern32", "matern52")
+                and (Xs.requires_grad or (X2s is not None and X2s.requires_grad)))
         if want:
             desc = (C.c_int64 * 8)()
             _ctx_for(X).call("gpsig_seq_gram_levels_stash", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(out), desc)

@@ -59,6 +59,7 @@ SeqLaunchFn seq_lookup_inc_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptd_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_stash(int, int, int, int);
+SeqLaunchFn seq_lookup_ptd_stash(int, int, int, int);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d4(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d8(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d16(int, int, int, int, bool);
@@ -1063,10 +1064,12 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     if (lds > 160 * 1024) return fail(c, GPSIG_ERR_UNSUPPORTED, "x-side records of %d rows do not fit the LDS ring (%zu bytes)", A.R1, lds);
     // gpsig_seq_gram_levels_stash: the instances the fused reverse kernel continues from also write what it needs of this recursion
     SeqLaunchFn fn = pl.fn;
-    if (c->stash_want && sizeof(TT) == 8 && !pl.pk2 && pl.rbf_prescaled && pl.cfg.exact && pl.cfg.G == 16 && pl.cfg.C == 4 && p->order <= 1 &&
+    const bool st_rbf = pl.rbf_prescaled, st_matern = !pl.rbf_prescaled && pl.mode == MODE_PT_DIFF &&
+        (p->base_kernel == GPSIG_BASE_MATERN12 || p->base_kernel == GPSIG_BASE_MATERN32 || p->base_kernel == GPSIG_BASE_MATERN52);
+    if (c->stash_want && sizeof(TT) == 8 && !pl.pk2 && (st_rbf || st_matern) && pl.cfg.exact && pl.cfg.G == 16 && pl.cfg.C == 4 && p->order <= 1 &&
         (r.pred == PRED_ALL || r.pred == PRED_CIRCULANT) && c->shard_n == 1 && r.y_begin == 0 && r.y_end <= 0 && !r.compact && r.gx.rows >= 2 &&
         r.gx.rows <= 64 && r.gy.rows <= 64) {
-        SeqLaunchFn sfn = seq_lookup_ptdrbf_stash(16, 4, pl.cfg.D, p->num_levels == pl.cfg.MMAX ? pl.cfg.MMAX : -1);
+        SeqLaunchFn sfn = (st_rbf ? seq_lookup_ptdrbf_stash : seq_lookup_ptd_stash)(16, 4, pl.cfg.D, p->num_levels == pl.cfg.MMAX ? pl.cfg.MMAX : -1);
         const int R1l = r.gx.rows - 1, LQ = p->num_levels - 1;
         const int64_t stride = int64_t(R1l) * LQ + 16 * int64_t(LQ) * 4;        // grad_fused_kernel.hpp: fused_stash_stride
         const size_t need = sizeof(double) * size_t(npairs) * size_t(stride);

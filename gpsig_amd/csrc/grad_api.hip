@@ -22,7 +22,7 @@ Wave2LaunchFn lam_undo_lookup_ptd_gen(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_rbf(int G, int C, int DP, int LQ);
 Wave2LaunchFn lam_undo_lookup_ptn_gen(int G, int C, int DP, int LQ);
 typedef hipError_t (*FusedGradLaunchFn)(const FusedGradArgs&, int, size_t, hipStream_t);
-FusedGradLaunchFn fused_grad_stash_lookup(int DP, int LQ);
+FusedGradLaunchFn fused_grad_stash_lookup(int kind, int DP, int LQ);
 FusedGradLaunchFn fused_grad_lookup_diff_g16(int kind, int DP, int LQ);
 FusedGradLaunchFn fused_grad_lookup_diff_g32(int kind, int DP, int LQ);
 FusedGradLaunchFn fused_grad_lookup_diff_g64(int kind, int DP, int LQ);
@@ -490,7 +490,7 @@ int seq_grad_fused_stash(gpsig_ctx* c, const gpsig_params* p, int DP, const doub
     const int64_t max_run = desc[2];
     if (ypb != 4 || desc[7] != L1 - 1 || desc[6] != fused_stash_stride(L1 - 1, LQ, 16, 4) || (pred != PRED_ALL && pred != PRED_CIRCULANT)) return GPSIG_OK;
     if ((pred == PRED_CIRCULANT) != sym && !(sym && pred == PRED_ALL)) return GPSIG_OK;
-    FusedGradLaunchFn fn = fused_grad_stash_lookup(DP, LQ);
+    FusedGradLaunchFn fn = fused_grad_stash_lookup(p->base_kernel, DP, LQ);
     void* st = c->buf[B_STASH].p;
     if (!fn || !st || L2 > 64 || L1 < 2 || L2 < 2) return GPSIG_OK;
     const size_t lds = sizeof(double) * size_t(fused_lds(L1, L1 - 1, DP, LQ, 16, 4).total);
@@ -844,7 +844,7 @@ int gpsig_seq_gram_levels_grad_stash(gpsig_ctx* c, const gpsig_params* p, const 
     if (c->ptr_mode != GPSIG_PTR_DEVICE || p->dtype != GPSIG_F64 || c->grad_impl != 0) return GPSIG_OK;
     int d, DP;
     CHK(grad_check(c, p, &d, &DP));
-    if (p->base_kernel != GPSIG_BASE_RBF || lattice_mode(p) != MODE_PT_DIFF || p->order > 1 || DP > 8 || N1 <= 0 || (X2 && N2 <= 0)) return GPSIG_OK;
+    if (lattice_mode(p) != MODE_PT_DIFF || p->order > 1 || DP > 8 || N1 <= 0 || (X2 && N2 <= 0)) return GPSIG_OK;      // (the base kernel: by the lookup)
     HIPCHK(c, hipSetDevice(c->device));
     const bool sym = X2 == nullptr;
     bool done = false;

@@ -56,12 +56,14 @@ __device__ __forceinline__ float shr1(float v) {
 #ifndef SEQ_RBF_WAVES
 #define SEQ_RBF_WAVES 2
 #endif
-// STASH (round 5, the float64 RBF instances whose pairs the fused reverse kernel takes): the kernel also writes what that reverse pass needs of
+// STASH (round 5, the float64 instances whose pairs the fused reverse kernel takes -- RBF at compile time, and the run-time-kind instances for the
+// Matern families): the kernel also writes what that reverse pass needs of
 // this recursion -- every lattice row's totals of levels 1 .. M-1 (the last lane's hand-over words) and every lane's Q's when its pair ends
 // (SeqGramArgs::stash) -- so that the backward call starts at the turn of the sweeps instead of repeating the forward one.
 template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1, bool STASH = false>
 __global__ __launch_bounds__(64, SEQ_FAST_RBF(T, MODE, OMAX, KIND) && C * D <= 32 ? SEQ_RBF_WAVES : ((MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1)) void seq_gram_kernel(const SeqGramArgs A) {
-    static_assert(!STASH || (SEQ_FAST_RBF(T, MODE, OMAX, KIND) && EXACT && MMAX >= 2), "the stash is written by the exact float64 RBF instances");
+    static_assert(!STASH || (sizeof(T) == 8 && MODE == MODE_PT_DIFF && OMAX == 0 && EXACT && MMAX >= 2),
+                  "the stash is written by exact float64 instances of the first-order algorithm on points with differences");
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
     static_assert((D * sizeof(T)) % 16 == 0, "record rows are read with 16-byte LDS loads");
     using Lane = typename std::conditional<OMAX == 0, SeqLane<T, C, D, MMAX, MODE>, SeqLaneHO<T, C, D, MMAX, (OMAX > 0 ? OMAX : 1), MODE>>::type;

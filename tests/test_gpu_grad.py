@@ -1518,7 +1518,8 @@ def test_rbf_reverse_pass_in_one_launch_is_the_route_taken():
 
 @pytest.mark.parametrize("M,N1,N2,L1,L2,d,kind", [(5, 64, 64, 64, 64, 8, "sym"), (4, 130, 130, 33, 33, 5, "sym"), (5, 37, 41, 64, 64, 8, "cross"),
                                                   (4, 9, 7, 20, 31, 3, "cross"), (3, 10, 10, 12, 12, 4, "sym")])
-def test_forward_pass_keeps_what_its_reverse_pass_needs(M, N1, N2, L1, L2, d, kind):
+@pytest.mark.parametrize("base", ["rbf", "matern12", "matern32", "matern52"])
+def test_forward_pass_keeps_what_its_reverse_pass_needs(base, M, N1, N2, L1, L2, d, kind):
     """gpsig_seq_gram_levels_stash / _grad_stash through autodiff._SeqGramLevels (round 5): the evaluation kernel's stash instances write the
     forward recursion's row totals and final states, the backward call runs the fused reverse kernel's backward sweep only.  Where the library
     keeps nothing (shapes outside those instances: the last two cases) the route falls back by itself.  Held to torch.autograd of the oracle at
@@ -1531,11 +1532,11 @@ def test_forward_pass_keeps_what_its_reverse_pass_needs(M, N1, N2, L1, L2, d, ki
     X = np.cumsum(rng.standard_normal((N1, L1, d)) * 0.3, 1)
     Y = np.cumsum(rng.standard_normal((N2, L2, d)) * 0.3, 1) if kind == "cross" else None
     G = rng.standard_normal((M + 1, N1, N2 if kind == "cross" else N1))
-    kt = _t_kern("rbf", d, M, difference=True)
+    kt = _t_kern(base, d, M, difference=True)
     tX = torch.tensor(X, requires_grad=True)
     tY = None if Y is None else torch.tensor(Y, requires_grad=True)
     (kt.K_seq_levels(tX, tY) * torch.tensor(G)).sum().backward()
-    spec = _Spec("rbf", M, True, 0.0, order=1)
+    spec = _Spec(base, M, True, 0.0, order=1)
     Gd = torch.tensor(G, device=dev)
     res, kept = [], []
     try:
