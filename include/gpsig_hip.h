@@ -354,7 +354,8 @@ int gpsig_seq_gram_levels_grad(gpsig_ctx* ctx, const gpsig_params* p, const void
                                int32_t L1, int32_t L2, const void* G /* (M+1, N1, N2) */, void* gX, void* gX2, double* g_base);
 /* The pair of them for a forward pass that will be differentiated (round 5; what the TensorFlow graph of the reference does implicitly -- the
  * forward op's intermediates are kept for its gradient op).  _levels_stash evaluates like gpsig_seq_gram_levels and, where the fused reverse
- * kernel can continue from it (SignatureRBF with differences, order 1, float64, at most 64 observations and 8 columns, num_levels 4 / 5, within
+ * kernel can continue from it (SignatureRBF / SignatureMatern12 / 32 / 52 with differences, order 1, float64, at most 64 observations and 8
+ * columns, num_levels 4 / 5, within
  * option "grad_stash_mb", default 4096; not inside a graph capture), keeps the forward recursion's row totals and final states in the context:
  * desc (8 integers) describes what was kept, desc[0] == 0 nothing.  _levels_grad_stash continues from it with the backward sweep only (*taken = 1),
  * or does nothing (*taken = 0: never kept, or another evaluation has overwritten it since) -- then call gpsig_seq_gram_levels_grad.  Device
