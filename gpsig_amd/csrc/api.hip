@@ -1075,7 +1075,14 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
         const size_t need = sizeof(double) * size_t(npairs) * size_t(stride);
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(c->stream, &cs);
-        if (sfn && LQ >= 1 && cs == hipStreamCaptureStatusNone && need <= (size_t(c->grad_stash_mb > 0 ? c->grad_stash_mb : 0) << 20)) {
+        // (kept only where the memory is there: a buffer that has to grow must leave a gibibyte free -- the stash is an optimisation, an
+        // evaluation never fails for want of it)
+        bool room = c->buf[B_STASH].cap >= need + 64;
+        if (!room) {
+            size_t free_b = 0, total_b = 0;
+            room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + c->buf[B_STASH].cap > need + (size_t(1) << 30);
+        }
+        if (sfn && LQ >= 1 && room && cs == hipStreamCaptureStatusNone && need <= (size_t(c->grad_stash_mb > 0 ? c->grad_stash_mb : 0) << 20)) {
             void* st;
             CHK(ensure(c, B_STASH, need + 64, &st));
             int64_t k2[10];
