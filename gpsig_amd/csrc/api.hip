@@ -59,7 +59,10 @@ SeqLaunchFn seq_lookup_inc_g64(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptd_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_stash(int, int, int, int);
-SeqLaunchFn seq_lookup_ptd_stash(int, int, int, int);
+SeqLaunchFn seq_lookup_ptdmatern_stash(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ptdm12_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdm32_exact(int, int, int, int, bool);
+SeqLaunchFn seq_lookup_ptdm52_exact(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d4(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d8(int, int, int, int, bool);
 SeqLaunchFn seq_lookup_ptdrbf_ex_g16_d16(int, int, int, int, bool);
@@ -885,7 +888,8 @@ struct SeqPlanned {
     SeqConfig cfg;
     SeqLaunchFn fn;
     int mode, d_eff;
-    bool rbf_prescaled;      // fn is an RBF instance that takes prescaled records: points x prescale, -|row|^2/2 in the spare column
+    bool rbf_prescaled;      // fn is an RBF (or, float64, Matern) instance that takes prescaled records: points x prescale, -|row|^2/2 in the spare column
+    int fast_kind;           // the base kernel fn has at compile time on prescaled records (float64: BASE_RBF or a Matern family), else -1
     double prescale;         // EXP_PRESCALE (float64, table-driven exp) or PK2_RBF_PRESCALE (float32, v_exp_f32)
     bool pk2;                // fn is a seq_pk2_kernel instance:
     int ny, waves;           //   a pair group serves ny y sequences, a workgroup has `waves` wavefronts on one x ring
@@ -895,6 +899,7 @@ struct SeqPlanned {
 static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqPlanned* out, int64_t pairs_hint = 0) {
     SeqGeom g0 = seq_geometry(p->base_kernel, p->difference, Ly, 4, int(sizeof(TT)));
     out->rbf_prescaled = false;
+    out->fast_kind = -1;
     out->prescale = 1.0;
     out->pk2 = false;
     out->ny = 1; out->waves = 1;
@@ -968,6 +973,17 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
         out->fn = seq_launcher_rbf(tab[k]);
         out->rbf_prescaled = out->fn != nullptr;
         out->prescale = SEQ_RBF_PRESCALE;
+        if (out->fn) out->fast_kind = BASE_RBF;
+    }
+    // the Matern families at compile time on prescaled records (round 5: seq_step_matern_prescaled), the shapes of GPSIG_SEQ_CONFIGS_EXACT
+    if (!f32 && g0.mode == MODE_PT_DIFF && seq_is_matern(p->base_kernel) && tab[k].exact && c->matern_fast != 0) {
+        const SeqConfig& t = tab[k];
+        out->fn = p->base_kernel == GPSIG_BASE_MATERN12 ? seq_lookup_ptdm12_exact(t.G, t.C, t.D, t.MMAX, t.exact)
+                  : (p->base_kernel == GPSIG_BASE_MATERN32 ? seq_lookup_ptdm32_exact(t.G, t.C, t.D, t.MMAX, t.exact)
+                                                           : seq_lookup_ptdm52_exact(t.G, t.C, t.D, t.MMAX, t.exact));
+        out->rbf_prescaled = out->fn != nullptr;            // (the records' spare column is written and ignored)
+        out->prescale = seq_matern_prescale(p->base_kernel);
+        if (out->fn) out->fast_kind = p->base_kernel;
     }
     if (!out->fn) out->fn = seq_launcher(g0.mode, tab[k], sizeof(TT) == 4, p->base_kernel);
     if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "seq-gram kernel shape missing from this build");
@@ -1064,12 +1080,12 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
     if (lds > 160 * 1024) return fail(c, GPSIG_ERR_UNSUPPORTED, "x-side records of %d rows do not fit the LDS ring (%zu bytes)", A.R1, lds);
     // gpsig_seq_gram_levels_stash: the instances the fused reverse kernel continues from also write what it needs of this recursion
     SeqLaunchFn fn = pl.fn;
-    const bool st_rbf = pl.rbf_prescaled, st_matern = !pl.rbf_prescaled && pl.mode == MODE_PT_DIFF &&
-        (p->base_kernel == GPSIG_BASE_MATERN12 || p->base_kernel == GPSIG_BASE_MATERN32 || p->base_kernel == GPSIG_BASE_MATERN52);
+    const bool st_rbf = pl.fast_kind == BASE_RBF, st_matern = pl.fast_kind >= 0 && seq_is_matern(pl.fast_kind);
     if (c->stash_want && sizeof(TT) == 8 && !pl.pk2 && (st_rbf || st_matern) && pl.cfg.exact && pl.cfg.G == 16 && pl.cfg.C == 4 && p->order <= 1 &&
         (r.pred == PRED_ALL || r.pred == PRED_CIRCULANT) && c->shard_n == 1 && r.y_begin == 0 && r.y_end <= 0 && !r.compact && r.gx.rows >= 2 &&
         r.gx.rows <= 64 && r.gy.rows <= 64) {
-        SeqLaunchFn sfn = (st_rbf ? seq_lookup_ptdrbf_stash : seq_lookup_ptd_stash)(16, 4, pl.cfg.D, p->num_levels == pl.cfg.MMAX ? pl.cfg.MMAX : -1);
+        const int mm = p->num_levels == pl.cfg.MMAX ? pl.cfg.MMAX : -1;
+        SeqLaunchFn sfn = st_rbf ? seq_lookup_ptdrbf_stash(16, 4, pl.cfg.D, mm) : seq_lookup_ptdmatern_stash(pl.fast_kind, 16, 4, pl.cfg.D, mm);
         const int R1l = r.gx.rows - 1, LQ = p->num_levels - 1;
         const int64_t stride = int64_t(R1l) * LQ + 16 * int64_t(LQ) * 4;        // grad_fused_kernel.hpp: fused_stash_stride
         const size_t need = sizeof(double) * size_t(npairs) * size_t(stride);
@@ -2090,6 +2106,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "grad_scratch_mb")) c->grad_scratch_mb = value > 0 ? value : 4096;
     else if (!strcmp(name, "grad_impl")) c->grad_impl = value;
     else if (!strcmp(name, "grad_stash_mb")) c->grad_stash_mb = value;
+    else if (!strcmp(name, "matern_fast")) c->matern_fast = value;
     else if (!strcmp(name, "grad_fused_piece")) c->grad_fused_piece = value;
     else if (!strcmp(name, "tvs_zreg")) c->tvs_zreg = value;
     else if (!strcmp(name, "tvs_grad_tile")) c->tvs_grad_tile = value;

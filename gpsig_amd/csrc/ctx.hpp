@@ -75,6 +75,7 @@ struct gpsig_ctx {
     int max_run = 0;
     int tens_lanes = -1;   // -1 auto, 0 sequence lanes, 1 tensor lanes
     int grad_scratch_mb = 4096;   // lattice scratch of one gradient launch
+    int matern_fast = 1;          // float64 sequence Grams of the Matern families: 1 = compile-time instances on prescaled records where built, 0 = run-time kind
     int grad_fused_piece = 0;     // streamed sequences per workgroup of the backward sweep from the stash (0: 16)
     int grad_stash_mb = 4096;     // gpsig_seq_gram_levels_stash keeps at most this much for the backward call (0: never)
     bool stash_want = false;      // set around the forward launch by gpsig_seq_gram_levels_stash; launch_seq fills stash_desc if it wrote one

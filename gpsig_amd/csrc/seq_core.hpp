@@ -561,6 +561,43 @@ GPSIG_HD void seq_step_rbf_prescaled(SeqLane<double, C, D, MMAX, MODE>& L, const
     seq_recursion(L, nbr, dm, M);
 }
 
+// First-order step for the Matern-1/2, 3/2, 5/2 kernels on PRESCALED records (float64, point modes; round 5): both sides' points were multiplied by
+// S = c 256 / ln 2 (c = 1, sqrt 3, sqrt 5) when the records were made, so q = |x' - y'| = S r and exp(-c r) = 2^(-q / 256) goes through the table
+// (fast_exp.hpp); u = c r = q ln2 / 256.  The squared distance is summed from the DIFFERENCES of the coordinates: exactly zero where the points
+// coincide (every diagonal cell of a sequence paired with itself), where |x|^2 + |y|^2 - 2 x.y would leave rounding noise that the Matern-1/2
+// kernel turns into its square root (kernels.py:765-781: the reference floors the distance at 1e-40 for the same reason).  Per column: 2 D
+// instructions, an inverse square root with one Newton step, 13 of exp, 1-3 of polynomial -- against D + 3 and the ~45 of the library sqrt + exp.
+constexpr bool seq_is_matern(int kind) { return kind == BASE_MATERN12 || kind == BASE_MATERN32 || kind == BASE_MATERN52; }
+constexpr double seq_matern_c(int kind) { return kind == BASE_MATERN12 ? 1.0 : (kind == BASE_MATERN32 ? 1.7320508075688772935 : 2.2360679774997896964); }
+constexpr double seq_matern_prescale(int kind) { return seq_matern_c(kind) * 256.0 / 0x1.62e42fefa39efp-1; }
+template <int KIND, int C, int D, int MMAX, int MODE, class Nbr>
+GPSIG_HD void seq_step_matern_prescaled(SeqLane<double, C, D, MMAX, MODE>& L, const Nbr& nbr, const double (&xr)[D], const double* etab, int M,
+                                        bool dummy, int rlo, int rhi) {
+    static_assert(MODE != MODE_INC && seq_is_matern(KIND), "point modes, Matern families");
+    constexpr double S = seq_matern_prescale(KIND), K = 0x1.62e42fefa39efp-1 / 256.0, FLOOR = 1e-40 * S * S;
+    double knew[C], dm[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+        double t = 0.0;
+#pragma unroll
+        for (int f = 0; f < D; ++f) { const double df = xr[f] - L.y[r][f]; t = fma(df, df, t); }
+        const double d = t > FLOOR ? t : FLOOR;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double r0 = __builtin_amdgcn_rsq(d);
+        double q = d * r0;
+        q = fma(fma(-q, q, d), 0.5 * r0, q);            // one Newton step on the residual: ~1.5 ulp
+#else
+        const double q = std::sqrt(d);
+#endif
+        const double e = kexp2_tab256(-q, etab);
+        if constexpr (KIND == BASE_MATERN12) knew[r] = e;                                               // kernels.py:955-958
+        else if constexpr (KIND == BASE_MATERN32) knew[r] = fma(q, K, 1.0) * e;                        // :974-977
+        else { const double u = q * K; knew[r] = fma(fma(u, 1.0 / 3.0, 1.0), u, 1.0) * e; }            // :991-993
+    }
+    seq_point_increments<double, C, MODE>(L, nbr, knew, dummy, rlo, rhi, dm);
+    seq_recursion(L, nbr, dm, M);
+}
+
 // First-order step for SignatureSpectral's state-space kernel (spectral_eval above; gpsig/kernels.py:921-942), point modes: the kernel
 // takes the two points themselves, which a lane has -- its C columns of y in registers, the x row of the step -- so the wavefront
 // kernel carries it as a compile-time family of its own (KIND == BASE_SPECTRAL instances: no branch in anyone else's step).

@@ -109,6 +109,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 through HBM to a contraction kernel per side).  0 additionally picks the fused reverse kernel of round 5 (an evaluator and a
  *                 sweeper wavefront per four sequence pairs, both sides contracted on chip) where it is built: RBF and the Matern families on
  *                 points with differences, order 1, at most 256 points on one side, at most 8 columns of state space, 2 to 6 levels
+ *   "matern_fast" float64 sequence Grams of SignatureMatern12 / 32 / 52: 1 (default) compile-time instances on prescaled records where the exact
+ *                 shapes are built (distances from coordinate differences, table exp), 0 the run-time-kind instances with the library sqrt / exp
  *   "grad_stash_mb" gpsig_seq_gram_levels_stash keeps at most this many MiB for the backward call (default 4096; 0: never)
  *   "tvs_grad_tile" reverse pass of the tensor-vs-sequence chains: 1 (default) the tile kernel (all levels in one reverse sweep per
  *                 sequence, d/dx summed in LDS, no atomics) where it is built (order 1, at most 8 columns, at most 6 levels), 0 the round-1 kernels

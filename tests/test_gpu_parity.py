@@ -1884,3 +1884,28 @@ def test_round5_closing_sweep_cases(K, fuzz_cases_r5):
     assert np.asarray(got).dtype == np.float32
     assert np.abs(np.asarray(got, dtype=np.float64) - want).max() / np.abs(want).max() <= 1e-3
     assert relerr(kern.K(X.astype(np.float64), X2.astype(np.float64), presliced=True), want) <= TOL
+
+
+@pytest.mark.parametrize("base", ["matern12", "matern32", "matern52"])
+def test_matern_families_at_compile_time_in_the_sequence_gram(K, base):
+    """Round 5: the float64 sequence Gram of the Matern families runs compile-time instances on prescaled records (seq_step_matern_prescaled:
+    distances from coordinate differences, inverse square root + Newton step, table exp) where the exact shapes are built; option matern_fast = 0
+    keeps the run-time-kind instances.  Both against the oracle, and against each other -- including a sequence paired with itself, whose diagonal
+    cells have distance exactly zero on either route."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(91)
+    ctx = _lib.context(0, 0)
+    for (N, L, d, M) in ((37, 64, 8, 5), (9, 33, 4, 4), (5, 20, 3, 5)):
+        X = np.cumsum(rng.standard_normal((N, L, d)) * 0.3, 1).reshape(N, -1)
+        X2 = np.cumsum(rng.standard_normal((N + 2, L, d)) * 0.3, 1).reshape(N + 2, -1)
+        kw = dict(input_dim=L * d, num_features=d, num_levels=M, base=base, normalization=False, lengthscales=np.full(d, 1.3))
+        kern, ko = make_kernel(K, kw), make_oracle(kw)
+        got = {}
+        try:
+            for fast in (1, 0):
+                ctx.set_option("matern_fast", fast)
+                got[fast] = (np.asarray(kern.K(X)), np.asarray(kern.K(X, X2)))
+        finally:
+            ctx.set_option("matern_fast", 1)
+        assert relerr(got[1][0], ko.K(X)) <= TOL and relerr(got[1][1], ko.K(X, X2)) <= TOL
+        assert relerr(got[1][0], got[0][0]) <= 1e-12 and relerr(got[1][1], got[0][1]) <= 1e-12
