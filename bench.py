@@ -775,6 +775,24 @@ def gradient_lines(dev):
             out.append({"name": name, "error": repr(e)})
         finally:
             ctx.set_option("sig_features_grad", -1)
+    # round 5: the Matern families at compile time in the sequence Gram's evaluation kernel -- configs[1]'s Gram with SignatureMatern32 (time only)
+    try:
+        N, L = 4096, 64
+        rng = np.random.default_rng(0)
+        Xh = torch.tensor(np.cumsum(rng.standard_normal((N, L, D)) * 0.3, axis=1).reshape(N, -1), device=dev)
+        kern = kernels.SignatureMatern32(L * D, D, M, lengthscales=math.sqrt(D))
+        kern.K(Xh)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            kern.K(Xh)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        out.append({"name": "c2-matern32", "workload": "BASELINE.json configs[1] with SignatureMatern32: full N x N Gram, N=%d, L=%d, d=%d, num_levels=%d, "
+                                                       "normalization=on, fp64, random-walk inputs (time only)" % (N, L, D, M),
+                    "dtype": "f64", "ms_per_step": ms, "value": float(N) * (N + 1) / 2 / (ms * 1e-3), "unit": "sequence-pairs/s"})
+    except Exception as e:
+        out.append({"name": "c2-matern32", "error": repr(e)})
     return out
 
 

@@ -76,7 +76,7 @@ def test_default_line_carries_the_measurement():
     names = [s["name"] for s in line["secondary"]]
     assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c3-linear", "c5-rbf", "c4-single-gpu",
                      "grad-c2shape-n1024-linear", "grad-c2shape-n1024-linear-level-primitives", "grad-c2shape-n1024-linear-pair-kernels",
-                     "grad-c2shape-n1024-rbf", "grad-c2shape-n1024-matern32", "grad-n512-l128-rbf"]
+                     "grad-c2shape-n1024-rbf", "grad-c2shape-n1024-matern32", "grad-n512-l128-rbf", "c2-matern32"]
     ho = line["secondary"][1]                           # the higher-order algorithm at order = num_levels: the same contraction, the same time
     assert ho["bound"] == "mfma" and ho["ms_per_step"] < 1.3 * line["ms_per_step"]
     lat = line["secondary"][0]                          # the same Gram through the pair recursion: vector-issue bound, about twice the time
@@ -89,7 +89,7 @@ def test_default_line_carries_the_measurement():
     for s in line["secondary"]:
         assert "error" not in s, s
         assert s["ms_per_step"] > 0
-        if not s["name"].startswith("grad-"):
+        if not s["name"].startswith("grad-") and s["name"] != "c2-matern32":
             assert s["rel_err"] <= (1e-4 if s["dtype"] == "f32" else 1e-6) and s["clock_ghz"] > 1.0
     c3l = line["secondary"][5]                          # configs[2] with SignatureLinear: Kzx as one product of level features (round 4)
     assert c3l["bound"] == "mfma" and c3l["ms_per_step"] < line["secondary"][3]["ms_per_step"]
@@ -101,4 +101,5 @@ def test_default_line_carries_the_measurement():
     assert g["grad-c2shape-n1024-linear"] < 1.1 * g["grad-c2shape-n1024-linear-level-primitives"]     # the level sum as one op is not slower
     # round 5's fused reverse kernel is what runs (the Lam-through-HBM route took 48 / 106 / 55 ms for these three)
     assert g["grad-c2shape-n1024-rbf"] < 25 and g["grad-c2shape-n1024-matern32"] < 35 and g["grad-n512-l128-rbf"] < 32
+    assert [s_ for s_ in line["secondary"] if s_["name"] == "c2-matern32"][0]["ms_per_step"] < 75       # (run-time-kind instances: 77-84 ms)
     assert line["secondary"][3]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
