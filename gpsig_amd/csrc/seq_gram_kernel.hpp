@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64, (SEQ_FAST_RBF(T, MODE, OMAX, KIND) || SEQ_FAST_
     // back every step.  An odd step count is rounded up; the extra step finds every lane past its last pair.
     // (only where it pays: the point-kernel and higher-order bodies are large enough to lose a wave per SIMD to
     // the doubled live ranges)
-    if constexpr ((MODE == MODE_INC && OMAX == 0) || (SEQ_RBF_UNROLL2 && FAST_RBF && C * D <= 32)) {
+    if constexpr ((MODE == MODE_INC && OMAX == 0) || (SEQ_RBF_UNROLL2 && (FAST_RBF || FAST_MATERN) && C * D <= 32)) {
         for (int t = 0; t < nsteps; t += 2) {
             one_step();
             one_step();
