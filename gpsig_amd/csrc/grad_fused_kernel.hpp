@@ -1,17 +1,21 @@
-// grad_fused_kernel.hpp -- reverse pass of the sequence-vs-sequence Gram for the RBF base kernel on points with differences
-// (SignatureRBF, order 1: gpsig/kernels.py:188-237 + signature_algs.py:8-35 differentiated), without Lam ever leaving the chip (round 5).
+// grad_fused_kernel.hpp -- reverse pass of the sequence-vs-sequence Gram for the stationary base kernels on points (SignatureRBF,
+// SignatureMatern12 / 32 / 52; order 1: gpsig/kernels.py:188-237 + signature_algs.py:8-35 differentiated), without Lam ever leaving the chip
+// (round 5).  Template parameters: DP padded state-space columns (4, 8; 16 with two lattice columns per lane), LQ = num_levels - 1, KIND, G lanes
+// per pair (16 / 32 / 64: four / two / one pair per wavefront, up to 64 / 128 / 256 points on the column side), C lattice columns per lane,
+// DIFF (the lattice of double increments, or -- difference=False -- the kernel matrix of the points itself), PHASE (0: both sweeps; 2: the
+// backward sweep only, continued from the stash the evaluation kernel wrote: gpsig_seq_gram_levels_stash).
 //
-// A workgroup is TWO wavefronts working on the same four sequence pairs (four register-side sequences r0 .. r0+3, one per 16-lane
-// pair group, against a run of streamed sequences s they share; lane ln of a group owns the lattice columns 4 ln .. 4 ln + 3; G = 64: one
-// pair per wavefront, up to 256 points on the column side):
+// A workgroup is TWO wavefronts working on the same 64 / G sequence pairs (register-side sequences r0 .. r0 + 64/G - 1, one per pair group
+// of G lanes, against a run of streamed sequences s they share; lane ln of a group owns the lattice columns C ln .. C ln + C - 1):
 //   wavefront 0, the EVALUATOR: keeps the lane's points of y, evaluates the kernel row of the step (table-driven exp on prescaled
-//       points), hands the double increments dm of the lane's columns to the sweeper, and -- in the backward sweep -- takes Lam
-//       back, differences it to the adjoint of the kernel values (H), multiplies by the kernel's derivative and contracts both
-//       sides: the y side into per-lane accumulators that live for the whole run, the x side as a partial row sum that travels
-//       from lane to lane with the skew of the sweep (one DPP shift per word and step) and leaves lane 0 into an LDS accumulator.
-//   wavefront 1, the SWEEPER: the forward recursion (WaveFwd) and its undoing (WaveUndo) of grad_wave_core.hpp, dm in, Lam out.
-// The two exchange dm / Lam through same-lane LDS slots, double buffered, one workgroup barrier per step; the kernel values a
-// contraction needs were evaluated four intervals earlier and wait in a five-deep same-lane ring.  Split this way each
+//       points), hands the double increments dm of the lane's columns to the sweeper, and -- in the backward sweep -- takes back
+//       W = H * g (the adjoint of the kernel values times the kernel's derivative factor) and contracts both sides: the y side into
+//       per-lane accumulators that live for the whole run, the x side as a partial row sum that travels from lane to lane with the
+//       skew of the sweep (one DPP shift per word and step) and leaves lane 0 into an LDS accumulator.
+//   wavefront 1, the SWEEPER: the forward recursion (WaveFwd) and its undoing (WaveUndo) of grad_wave_core.hpp, dm in; Lam, its double
+//       difference H and W out.
+// The two exchange dm / W through same-lane LDS slots, double buffered, one workgroup barrier per step; the kernel values a
+// contraction needs were evaluated three intervals earlier and wait in a five-deep same-lane ring.  Split this way each
 // wavefront's state fits the 256 registers of two wavefronts per SIMD, which the one-wavefront form (seq_lam_undo_kernel:
 // 256 + AGPRs, one wavefront per SIMD, Lam through HBM to lam_contract_kernel) does not.
 // The interval schedule is replayed lane by lane in tools/sim_fused_grad.py against autograd of the plain recursion.
