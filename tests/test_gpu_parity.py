@@ -1859,7 +1859,9 @@ def test_round5_sweep_float32_cosine_on_sequences_of_two_or_three_observations(K
         X, Z, want = fz[key + "_X"], fz[key + "_Z"], fz[key + "_Kzx"]
         got = kern.K_tens_vs_seq(Z, X, increments=incr)
         assert np.asarray(got).dtype == np.float32
-        assert np.abs(np.asarray(got, dtype=np.float64) - want).max() / np.abs(want).max() <= 1e-3, key
+        # (since the round's closing sweeps float32 requests of the cosine kernel are evaluated in float64 and rounded -- kernels.py, _f32_upcast --
+        # so these meet the float32 tolerance again; the stated 1e-3 stands for what float32 arithmetic itself delivers on this class)
+        assert np.abs(np.asarray(got, dtype=np.float64) - want).max() / np.abs(want).max() <= 1e-4, key
         got64 = kern.K_tens_vs_seq(Z.astype(np.float64), X.astype(np.float64), increments=incr)
         assert relerr(got64, want) <= TOL, key
 
