@@ -9,7 +9,7 @@ objs=""; skip=""
 for unit in ${units//,/ }; do
   b=$(basename $unit .hip)
   obj=build/ab/${name}_$b.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c gpsig_amd/csrc/$unit -o $obj &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-compress "$@" -c gpsig_amd/csrc/$unit -o $obj &
   objs="$objs $obj"; skip="$skip -e /$b.o\$"
 done
 wait
