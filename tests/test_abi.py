@@ -30,6 +30,13 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.load().gpsig_abi_version() == 1
 
 
+def test_library_stays_small(lib):
+    """Build hygiene (round 4's verdict: at most 40 MB): ~2,600 gfx950 kernels are 69 MB of device code stored plain, 16.7 MB with the code
+    objects compressed in the fat binary (gpsig_amd/csrc/Makefile: COMPRESS = --offload-compress).  A build that lost the flag, or an
+    instance list that doubled, shows up here."""
+    assert os.path.getsize(lib.LIB_PATH) <= 40 * 1024 * 1024, os.path.getsize(lib.LIB_PATH)
+
+
 def test_params_struct_matches_header_layout(lib):
     import ctypes as C
     # 8 int32, 2 double, 4 double, 4 pointers
