@@ -116,9 +116,11 @@ class _SeqGramLevels(torch.autograd.Function):
                 and (Xs.requires_grad or (X2s is not None and X2s.requires_grad)))
         if want:
             desc = (C.c_int64 * 8)()
-            _ctx_for(X).call("gpsig_seq_gram_levels_stash", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(out), desc)
+            lib_ctx = _ctx_for(X)
+            lib_ctx.call("gpsig_seq_gram_levels_stash", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(out), desc)
             if desc[0] != 0:
                 ctx.stash = list(desc)
+                ctx.stash_ctx = lib_ctx            # the stash lives in THIS context: a backward pass on another stream must not look for it elsewhere
         else:
             _ctx_for(X).call("gpsig_seq_gram_levels", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(out))
         ctx.spec, ctx.has_x2, ctx.has_p0 = spec, X2 is not None, p0 is not None
@@ -141,8 +143,9 @@ class _SeqGramLevels(torch.autograd.Function):
         taken = C.c_int32(0)
         if ctx.stash is not None:
             desc = (C.c_int64 * 8)(*ctx.stash)
-            _ctx_for(X).call("gpsig_seq_gram_levels_grad_stash", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(G), _ptr(gX),
-                             None if gX2 is None else _ptr(gX2), desc, C.byref(taken))
+            if ctx.stash_ctx is _ctx_for(X):       # same (device, stream) as the forward pass: its stream order makes the stash valid here
+                ctx.stash_ctx.call("gpsig_seq_gram_levels_grad_stash", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(G), _ptr(gX),
+                                   None if gX2 is None else _ptr(gX2), desc, C.byref(taken))
         if not taken.value:
             _ctx_for(X).call("gpsig_seq_gram_levels_grad", p, _ptr(X), None if X2 is None else _ptr(X2), n1, n2, l1, l2, _ptr(G), _ptr(gX),
                              None if gX2 is None else _ptr(gX2), C.cast(gb.data_ptr(), C.POINTER(C.c_double)))
@@ -919,6 +922,8 @@ class SignatureKernelModule(torch.nn.Module):
         self._has_p0 = kern._base in ("poly", "mix")
         self.raw_p0 = par(positive_inverse(bp[0])) if self._has_p0 else None
         self._spec = _Spec(kern._base, kern.num_levels, kern.difference, p1=float(bp[1]) if len(bp) > 1 else 0.0, order=kern.order)
+        # load_state_dict() copies through ``.data``-like paths that bump no version counter the weights' host memo is keyed on
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_host_copies())
 
     # constrained values
     @property
@@ -1006,6 +1011,9 @@ class SignatureKernelModule(torch.nn.Module):
         # or normalisation that needs O(n * levels) memory through the recursion kernels must not run out through this route (whatever the order)
         try:
             free_b, _ = torch.cuda.mem_get_info(Xs.device)
+            # + what torch's caching allocator holds but has not handed out: a warmed-up training process has reserved most of HBM, the driver's
+            # figure alone would send every linear / cosine evaluation to the pair recursion for good
+            free_b += max(0, torch.cuda.memory_reserved(Xs.device) - torch.cuda.memory_allocated(Xs.device))
         except Exception:  # noqa: BLE001
             free_b = None
         if free_b is not None and 2.5 * 8.0 * n * ld > free_b:     # features, their gradient and a working copy
@@ -1117,12 +1125,19 @@ class SignatureKernelModule(torch.nn.Module):
         """The level weights on the host for the one-op level sum (the C ABI takes them by value): the copy is a blocking device-to-host
         synchronisation, so it is made once per VALUE of the parameters -- keyed on their tensors' version counters, which every in-place
         optimiser update bumps -- instead of once per forward pass."""
+        # Writes through ``.data`` (p.data.fill_(), p.data.copy_()) bump no version counter: load_state_dict() drops the memo through the hook
+        # registered in __init__; after any other ``.data`` write call ``invalidate_host_copies()``.
         key = (self.raw_sigma.data_ptr(), self.raw_sigma._version, self.raw_variances.data_ptr(), self.raw_variances._version)
         held = getattr(self, "_w_host_memo", None)
         if held is None or held[0] != key:
             held = (key, _SeqGramSum.weights_on_host(w))
             self._w_host_memo = held
         return held[1]
+
+    def invalidate_host_copies(self):
+        """Forget the host copies of parameter values (the level weights the C ABI takes by value).  Needed only after writing parameters through
+        ``.data`` -- in-place updates through autograd-visible ops (every optimiser step) and load_state_dict() are noticed."""
+        self._w_host_memo = None
 
     # ---- low-rank mode ---------------------------------------------------------------------------------------------
     def draw_low_rank(self, num_points):

@@ -1116,7 +1116,7 @@ static int launch_seq(gpsig_ctx* c, const gpsig_params* p, const SeqPlanned& pl,
             if (np == ntasks) {
                 A.stash = static_cast<double*>(st); A.stash_pair0 = dp; A.stash_stride = stride;
                 fn = sfn;
-                c->stash_desc[0] = ++c->stash_gen; c->stash_desc[1] = r.pred; c->stash_desc[2] = max_run; c->stash_desc[3] = ypb;
+                c->stash_desc[0] = c->stash_gen = next_stash_generation(); c->stash_desc[1] = r.pred; c->stash_desc[2] = max_run; c->stash_desc[3] = ypb;
                 c->stash_desc[4] = ntasks; c->stash_desc[5] = npairs; c->stash_desc[6] = stride; c->stash_desc[7] = R1l;
             }
         }

@@ -1,6 +1,7 @@
 // ctx.hpp -- the gpsig_ctx object and the host-side helpers shared by the translation units that implement
 // the C ABI (api.hip: evaluation, grad_api.hip: gradients).
 #pragma once
+#include <atomic>
 
 #include <hip/hip_runtime.h>
 
@@ -61,6 +62,13 @@ struct TaskSlot {
 };
 constexpr size_t TASK_SLOTS = 16;
 
+// Stash generations are drawn from ONE counter per process (round 6): a descriptor handed to another context -- a backward pass on a different
+// stream than its forward pass, a C caller mixing contexts -- can then never match that context's own generation by coincidence.
+inline int64_t next_stash_generation() {
+    static std::atomic<int64_t> counter{0};
+    return ++counter;
+}
+
 struct gpsig_ctx {
     int device = 0;
     int num_cus = 256;
@@ -80,7 +88,7 @@ struct gpsig_ctx {
     int grad_stash_mb = 4096;     // gpsig_seq_gram_levels_stash keeps at most this much for the backward call (0: never)
     bool stash_want = false;      // set around the forward launch by gpsig_seq_gram_levels_stash; launch_seq fills stash_desc if it wrote one
     int64_t stash_desc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // generation (0: none), pred, max_run, ypb, tasks, pair slots, stride, lattice rows
-    int64_t stash_gen = 0;
+    int64_t stash_gen = 0;        // the generation of THIS context's stash: drawn from next_stash_generation(), unique in the process
     int grad_impl = 0;            // 0: planner's choice, 1: one pair per thread + stored lattice, 2: one pair per thread scratch-free (tensor-vs-seq),
                                   // 3: wavefront kernel + stored lattice, 4: scratch-free wavefront kernel wherever it is built
     void* blas_handle = nullptr;  // rocBLAS handle of gpsig_lr_whitening (lowrank_solver.hip), created at first use

@@ -159,6 +159,11 @@ def _f32_upcast(method):
             except NotImplementedError:
                 if not all_f32:
                     raise
+        if getattr(self, "_graph_recording", False):
+            # graphed(): the float64 copies, the float64 result and its rounding would be torch temporaries recorded inside the capture and
+            # recycled after it -- a replay would write into whatever lives there then
+            raise ValueError("graphed(): this float32 evaluation is computed in float64 and rounded (one-column state space, SignatureCosine or "
+                             "a shape the float32 kernels are not built for); record it with float64 tensors")
         up = lambda a: (a.double() if _is_torch(a) else np.asarray(a, dtype=np.float64)) if _is_f32(a) else a   # noqa: E731
         out = method(self, *[up(a) for a in args], **kwargs)
         down = lambda o: o.float() if _is_torch(o) else np.asarray(o, dtype=np.float32)                          # noqa: E731
@@ -428,16 +433,20 @@ class SignatureKernel:
         dev = next(t for t in tensors if t is not None).device
         side = torch.cuda.Stream(dev)            # the default stream cannot be captured
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            fn(*tensors, **kwargs)               # scratch buffers, task lists and level weights in place
-            ctx = _lib.context(dev.index or 0, side.cuda_stream)
-            _lib.hold(dev.index or 0, side.cuda_stream)
-            try:
-                with ctx.graph() as g:
-                    out = fn(*tensors, **kwargs)
-            except Exception:
-                _lib.release(dev.index or 0, side.cuda_stream)
-                raise
+        self._graph_recording = True             # _f32_upcast refuses instead of converting (its temporaries must not be recorded)
+        try:
+            with torch.cuda.stream(side):
+                fn(*tensors, **kwargs)           # scratch buffers, task lists and level weights in place
+                ctx = _lib.context(dev.index or 0, side.cuda_stream)
+                _lib.hold(dev.index or 0, side.cuda_stream)
+                try:
+                    with ctx.graph() as g:
+                        out = fn(*tensors, **kwargs)
+                except Exception:
+                    _lib.release(dev.index or 0, side.cuda_stream)
+                    raise
+        finally:
+            self._graph_recording = False
         torch.cuda.current_stream(dev).wait_stream(side)
         return GraphedCall(g, tensors, out, side)
 

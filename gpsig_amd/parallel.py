@@ -174,11 +174,12 @@ class ShardedGram:
     def _chunks(self, ctx, p, X, n, L, b0, b1, pending):
         sw = self._watch = _Stopwatch(self.dev)
         sw.chunks = 0
+        late = None                    # this rank's failure on a chunk after the first
         for k in range(self.chunks):
             r0 = min(b0 + k * self.chunk_rows, b1)
             r1 = min(r0 + self.chunk_rows, b1)
             sw.mark("b%d" % k)
-            if r1 > r0 or k == 0:
+            if (r1 > r0 or k == 0) and late is None:
                 blk = self.rows[k * self.chunk_rows:]
                 why, err = None, None
                 try:
@@ -187,11 +188,11 @@ class ShardedGram:
                     ctx.call("gpsig_kernel_K_symm_rows_compact", p, C.c_void_p(X.data_ptr()), n, L, r0, r1, C.c_void_p(blk.data_ptr()))
                 except NotImplementedError as e:
                     if k != 0:
-                        raise
+                        late = late or e
                     why = str(e)
                 except Exception as e:      # noqa: BLE001 -- a full device (MemoryError), a HIP error: this rank cannot go on, but its peers
                     if k != 0:              # are about to enter the verdict's all-reduce and must not wait there for the collective's timeout
-                        raise
+                        late = late or e    # (round 6) a later chunk: keep joining the gathers the peers are in, vote after the last one
                     why, err = repr(e), e
                 if k == 0 and not self._agree(why is None):
                     return self._rank0_alone(X, why or "another rank's row-block call was refused", err)
@@ -204,6 +205,13 @@ class ShardedGram:
         for w in pending:
             w.wait()
         sw.mark("e1")
+        # One more scalar vote where there was more than one chunk: a rank that failed after its first chunk (out of memory when its scratch grew,
+        # a HIP error) has still joined every gather -- with whatever its buffer held -- so nobody is left inside a collective; now every rank
+        # learns of it and none returns a matrix with that rank's rows missing.  (A sticky HIP error can break the failing rank's own
+        # collectives under RCCL: then its peers still depend on the collective's timeout.)
+        if self.chunks > 1 and not self._agree(late is None):
+            self._watch = None
+            raise late if late is not None else RuntimeError("ShardedGram: another rank failed in one of its later chunks")
         if self.rank != 0:
             return None
         ctx.symmetrize_compact_rows(_lib.F64, C.c_void_p(self.half.data_ptr()), n, C.c_void_p(self.out.data_ptr()))

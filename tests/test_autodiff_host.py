@@ -84,3 +84,16 @@ def test_feature_product_backward_in_chunks(N):
     A.grad = B.grad = None
     (autodiff._FeatureProduct.apply(A, B) * W).sum().backward()
     assert torch.allclose(A.grad, W @ B.detach()) and torch.allclose(B.grad, W.T @ A.detach())
+
+
+def test_host_copy_of_the_level_weights_is_dropped_by_load_state_dict():
+    """Round 6: the weights' host memo is keyed on the parameters' version counters, which load_state_dict() and ``.data`` writes
+    do not bump; the module drops the memo on load_state_dict() and offers invalidate_host_copies() for the rest."""
+    from gpsig_amd import kernels
+    mod = autodiff.SignatureKernelModule(kernels.SignatureLinear(12, 3, 3), device="cpu")
+    mod._w_host_memo = ("key", "stale")
+    mod.load_state_dict(mod.state_dict())
+    assert mod._w_host_memo is None
+    mod._w_host_memo = ("key", "stale")
+    mod.invalidate_host_copies()
+    assert mod._w_host_memo is None

@@ -262,6 +262,53 @@ def test_sharded_gram_rank_that_fails_for_good_does_not_strand_its_peers():
             assert (ret[r][2] == 0.0) if r == 0 else (ret[r][2] is None), ret
 
 
+class FailingOnALaterChunk(EmulatorContext):
+    """ONE rank's SECOND row-block call fails (round 5's advisor: out of memory when the scratch buffer grows, a HIP error): the first chunk's
+    verdict was unanimous, the peers are inside the chunks' gathers."""
+
+    def __init__(self, fail):
+        self.fail, self.calls = fail, 0
+
+    def call(self, name, p, Xp, n, L, r0, r1, outp):
+        self.calls += 1
+        if self.fail and self.calls >= 2:
+            raise MemoryError("libgpsig_hip: out of device memory")
+        EmulatorContext.call(self, name, p, Xp, n, L, r0, r1, outp)
+
+
+def _late_failing_worker(rank, world, port, n, failing_rank, ret):
+    import torch
+    from gpsig_amd import kernels
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, d, M = 7, 2, 3
+        rng = np.random.default_rng(7)
+        X = np.cumsum(0.3 * rng.standard_normal((n, L, d)), axis=1).reshape(n, L * d)
+        kern = kernels.SignatureRBF(L * d, d, M, lengthscales=None)
+        gram = parallel.ShardedGram(kern, n, torch.device("cpu"), rank, world, chunks=3, ctx=FailingOnALaterChunk(rank == failing_rank))
+        try:
+            gram(torch.from_numpy(X))
+            ret[rank] = ("returned",)
+        except MemoryError as e:
+            ret[rank] = ("raised", "MemoryError", str(e))
+        except RuntimeError as e:
+            ret[rank] = ("raised", "RuntimeError", str(e))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gram_failure_on_a_later_chunk_reaches_every_rank():
+    """The failing rank keeps joining the gathers its peers are in, then all ranks vote once more: the failing one raises its own error, the
+    others raise instead of returning a matrix with that rank's rows missing -- and nobody waits for a collective's timeout."""
+    for n, world, failing in ((48, 2, 1), (48, 3, 0)):
+        ret = _spawn_with_retry(_late_failing_worker, world, (n, failing))
+        assert ret[failing][:2] == ("raised", "MemoryError") and "out of device memory" in ret[failing][2], ret
+        for r in range(world):
+            if r != failing:
+                assert ret[r][:2] == ("raised", "RuntimeError") and "later chunks" in ret[r][2], ret
+
+
 def _covs_worker(rank, world, port, n, increments, ret):
     import torch
     from gpsig_amd import kernels

@@ -122,3 +122,28 @@ def test_replay_of_the_feature_contraction(env):
     X.copy_(torch.tensor(rng.standard_normal((N, L * d)) * 0.4, device=dev))
     a, b = g1.replay().clone(), g2.replay().clone()
     assert torch.equal(a, kern.K(X)) and torch.equal(b, kern.K(X, X2))
+
+
+def test_float32_requests_computed_in_float64_are_refused_by_capture(env):
+    """Round 6: float32 evaluations of SignatureCosine and of one-column state spaces are computed in float64 and rounded
+    (kernels._f32_upcast); their conversions would be torch temporaries recorded inside the capture.  graphed() refuses them; float32
+    requests the float32 kernels take as they are, and the float64 form of the refused ones, record and replay."""
+    torch, K, dev = env
+    rng = np.random.default_rng(8)
+    N, L, M = 12, 16, 3
+    for kern, d in ((K.SignatureCosine(L * 2, 2, M), 2), (K.SignatureRBF(L * 1, 1, M), 1)):
+        X32 = torch.tensor(rng.standard_normal((N, L * d)) * 0.5, device=dev, dtype=torch.float32)
+        with pytest.raises(ValueError, match="computed in float64"):
+            kern.graphed("K", X32)
+        assert not kern._graph_recording
+        eager = kern.K(X32)                                           # the eager float32 request still works (upcast + rounding)
+        assert eager.dtype == torch.float32
+        X64 = X32.double()
+        g = kern.graphed("K", X64)
+        assert torch.equal(g.replay(), kern.K(X64))
+        assert float((g.out.float() - eager).abs().max()) < 1e-5
+    kern = K.SignatureRBF(L * 3, 3, M)
+    X32 = torch.tensor(rng.standard_normal((N, L * 3)) * 0.5, device=dev, dtype=torch.float32)
+    g = kern.graphed("K", X32)                                        # float32 kernels proper: recorded as they are
+    X32.copy_(torch.tensor(rng.standard_normal((N, L * 3)) * 0.5, device=dev, dtype=torch.float32))
+    assert torch.equal(g.replay().clone(), kern.K(X32))
