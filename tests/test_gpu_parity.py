@@ -1911,3 +1911,51 @@ def test_matern_families_at_compile_time_in_the_sequence_gram(K, base):
             ctx.set_option("matern_fast", 1)
         assert relerr(got[1][0], ko.K(X)) <= TOL and relerr(got[1][1], ko.K(X, X2)) <= TOL
         assert relerr(got[1][0], got[0][0]) <= 1e-12 and relerr(got[1][1], got[0][1]) <= 1e-12
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: independent witness values (tests/golden/make_witness.py -- closed-form kappa in 50-digit arithmetic, literal tuple sums;
+# nothing of oracle/ or gpsig_amd/ was imported to produce them)
+# ------------------------------------------------------------------------------------------------
+def test_hip_path_against_independent_witness_values(K):
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "witness.json")) as f:
+        meta = json.load(f)
+    W = np.load(os.path.join(here, "witness.npz"))
+    lvl = lambda got, want: max(float(np.abs(g - w).max() / np.abs(w).max()) for g, w in zip(np.asarray(got), want))   # noqa: E731
+    worst = 0.0
+    for c in meta:
+        n = c["name"]
+        X, Y, Z, Zi = (W[n + "/" + k] for k in ("X", "Y", "Z", "Zi"))
+        nx, L1, d = X.shape
+        ny = Y.shape[0]
+
+        def kern(normalization=False, variances=1):
+            kw = dict(base=c["base"], input_dim=L1 * d, num_features=d, num_levels=c["M"], lengthscales=c["lengthscales"], base_params=c["params"],
+                      normalization=normalization, variances=variances, num_lags=(len(c["lags"]) if c["lags"] else None))
+            k = make_kernel(K, kw)
+            if c["lags"]:
+                k.lags, k.gamma = np.asarray(c["lags"], dtype=float), np.asarray(c["gamma"], dtype=float)
+            return k
+        k1 = kern()
+        Xf, Yf = X.reshape(nx, -1), Y.reshape(ny, -1)
+        errs = [lvl(k1.K(Xf, Yf, return_levels=True), W[n + "/K_cross_levels"])]
+        sym, want = np.asarray(k1.K(Xf, return_levels=True)), W[n + "/K_symm_levels"]
+        off = ~np.eye(nx, dtype=bool)
+        if c["base"] == "matern12":          # coinciding points: the closed form has r = 0 exactly where float64 squared distances are rounding noise
+            errs.append(max(float(np.abs(g[off] - w[off]).max() / np.abs(w).max()) for g, w in zip(sym, want)))
+        else:
+            errs.append(lvl(sym, want))
+            errs.append(float(np.abs(np.asarray(kern(True, W[n + "/variances"]).K(Xf)) - W[n + "/K_symm_normalised"]).max()))
+        for tag, ZZ, inc in (("", Z, False), ("_incr", Zi, True)):
+            errs.append(lvl(k1.K_tens_vs_seq(ZZ, Xf, return_levels=True, increments=inc), W[n + "/Kzx%s_levels" % tag]))
+            kzz, wzz = np.asarray(k1.K_tens(ZZ, return_levels=True, increments=inc)), W[n + "/Kzz%s_levels" % tag]
+            if c["base"] == "matern12":
+                offz = ~np.eye(kzz.shape[1], dtype=bool)
+                kzz, wzz = kzz[:, offz], wzz[:, offz]
+            errs.append(lvl(kzz, wzz))
+        assert max(errs) < 1e-10, (n, errs)
+        worst = max(worst, max(errs))
+    print(f"witness: {len(meta)} cases, worst {worst:.2e}")

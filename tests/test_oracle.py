@@ -301,3 +301,69 @@ def test_higher_order_levels_of_a_one_column_sequence_are_better_conditioned_as_
     e_feat, e_rec = np.abs(f64 - ref).max() / scale, np.abs(rec - ref).max() / scale
     assert e_feat < 1e-10                                     # (9e-13 on this draw)
     assert 100.0 * e_feat < e_rec < 1e-2                      # (5e-8 on this draw, 1e-4 on the sweep's: the recursion's cancellation)
+
+
+# ---- round 6: independent witness for the non-linear base kernels ------------------------------------------------------------
+def _witness():
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "witness.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(here, "witness.npz"))
+
+
+def witness_kernel(make, c, normalization=False, variances=1):
+    """make(input_dim, num_features, num_levels, **kw) -> kernel object (the oracle's class here, the product's in the GPU tests)."""
+    kw = dict(lengthscales=c["lengthscales"], normalization=normalization, variances=variances,
+              num_lags=(len(c["lags"]) if c["lags"] else None))
+    return kw
+
+
+def _oracle_for(c, L, normalization=False, variances=1):
+    k = O.SignatureKernelOracle(L * c["d"], c["d"], c["M"], base=c["base"], base_params=c["params"],
+                                **witness_kernel(None, c, normalization, variances))
+    if c["lags"]:
+        k.lags, k.gamma = np.asarray(c["lags"], dtype=float), np.asarray(c["gamma"], dtype=float)
+    return k
+
+
+def _lvl_err(got, want):
+    """max over levels of the matrix-relative error."""
+    return max(float(np.abs(g - w).max() / np.abs(w).max()) for g, w in zip(got, want))
+
+
+def test_oracle_against_independent_witness_values():
+    """tests/golden/make_witness.py: kappa from closed forms in 50-digit arithmetic (no oracle.base_*), levels as literal sums over increasing
+    index tuples.  rbf, matern12/32/52, poly, mix, cosine; with and without lengthscales and lags; seq x seq (cross, symmetric, normalised),
+    tensor x seq and tensor x tensor with and without increments.  The oracle stays within 1e-10 of every value."""
+    meta, W = _witness()
+    assert {c["base"] for c in meta} == {"rbf", "matern12", "matern32", "matern52", "poly", "mix", "cosine"}
+    for c in meta:
+        n = c["name"]
+        X, Y, Z, Zi = (W[n + "/" + k] for k in ("X", "Y", "Z", "Zi"))
+        nx, L1, d = X.shape
+        ny, L2, _ = Y.shape
+        k1 = _oracle_for(c, L1)
+        cross = k1.K(X.reshape(nx, -1), Y.reshape(ny, -1), return_levels=True) if L1 == L2 else None
+        if cross is None:                       # the class takes one length per object (input_dim): the levels come from _K_seq on scaled inputs
+            cross = k1._K_seq(k1._apply_scaling_and_lags_to_sequences(X), _oracle_for(c, L2)._apply_scaling_and_lags_to_sequences(Y))
+        assert _lvl_err(cross, W[n + "/K_cross_levels"]) < 1e-10, n
+        sym = k1.K(X.reshape(nx, -1), return_levels=True)
+        want = W[n + "/K_symm_levels"]
+        off = ~np.eye(nx, dtype=bool)
+        if c["base"] == "matern12":
+            # a sequence against itself: the reference's float64 squared distance of coinciding points is rounding noise, its root 1e-8 -- the
+            # closed form has exactly 0 there (DESIGN section 5); off-diagonal pairs are held as everything else
+            assert max(float(np.abs(g[off] - w[off]).max() / np.abs(w).max()) for g, w in zip(sym, want)) < 1e-10, n
+        else:
+            assert _lvl_err(sym, want) < 1e-10, n
+            kn = _oracle_for(c, L1, normalization=True, variances=W[n + "/variances"])
+            assert float(np.abs(kn.K(X.reshape(nx, -1)) - W[n + "/K_symm_normalised"]).max()) < 1e-10, n
+        for tag, ZZ, inc in (("", Z, False), ("_incr", Zi, True)):
+            assert _lvl_err(k1.K_tens_vs_seq(ZZ, X.reshape(nx, -1), return_levels=True, increments=inc), W[n + "/Kzx%s_levels" % tag]) < 1e-10, (n, tag)
+            kzz, wzz = k1.K_tens(ZZ, return_levels=True, increments=inc), W[n + "/Kzz%s_levels" % tag]
+            if c["base"] == "matern12":         # a tensor against itself: coinciding points again
+                offz = ~np.eye(kzz.shape[1], dtype=bool)
+                kzz, wzz = kzz[:, offz], wzz[:, offz]
+            assert _lvl_err(kzz, wzz) < 1e-10, (n, tag)
