@@ -69,11 +69,25 @@ class _Spec:
         return p
 
 
+# The library's "wide" option (state spaces beyond the exact-shape kernels' columns: kernel arguments by dgemm + fused map / difference / recursion
+# kernels, csrc/wide_api.hip): None = where the exact-shape kernels are not built (the library's default), True = wherever built, False = never.
+_WIDE = {"value": -1}
+WIDE_BASES = ("rbf", "matern12", "matern32", "matern52")
+WIDE_PRIMITIVES = {"tvs"}           # the level primitives the library has a wide route for
+
+
+def set_wide_route(mode):
+    _WIDE["value"] = {None: -1, True: 1, False: 0}[mode]
+
+
 def _ctx_for(t):
     if not t.is_cuda:
         raise RuntimeError("gpsig_amd.autodiff needs CUDA (ROCm) tensors: there is no CPU path")
     ctx = _lib.context(t.device.index or 0, torch.cuda.current_stream(t.device).cuda_stream)
     ctx.set_pointer_mode(_lib.PTR_DEVICE)
+    if getattr(ctx, "_wide_option", -1) != _WIDE["value"]:
+        ctx.set_option("wide", _WIDE["value"])
+        ctx._wide_option = _WIDE["value"]
     return ctx
 
 
@@ -905,7 +919,9 @@ class SignatureKernelModule(torch.nn.Module):
         self.sum_route = True          # K(X [, X2]) of the linear / cosine kernel: level sum and gradient as one op where the library offers it
         d_cols = kern.num_features * (kern.num_lags + 1)
         # beyond 64 columns and for the spectral kernel: base-kernel tensors here (GEMMs, autograd), recursions in the library
-        self.matrix_route = (kern._base == "spectral" or d_cols > 64) and not kern.low_rank
+        # (round 6: beyond 64 columns the library's wide route takes the primitives it is built for -- _mx below)
+        self.matrix_route = kern._base == "spectral" and not kern.low_rank
+        self._d_cols = d_cols
         dev = torch.device(device)
         par = lambda v: torch.nn.Parameter(torch.as_tensor(np.asarray(v, dtype=np.float64), device=dev))
         self.raw_variances = par(positive_inverse(kern.variances))
@@ -984,18 +1000,30 @@ class SignatureKernelModule(torch.nn.Module):
         return Z.reshape(shape)
 
     # ---- level primitives ------------------------------------------------------------------------------------------
+    def _mx(self, prim):
+        """Does level primitive ``prim`` ('seq', 'diag', 'tens', 'tvs') take the matrix route?  Always when ``matrix_route`` is set (the spectral
+        kernel; A/B runs).  Beyond 64 columns the library's exact-shape kernels are not built: the wide route takes what it is built for (the
+        distance kernels at order 1), the matrix route the rest."""
+        if self.matrix_route:
+            return True
+        if self._d_cols <= 64 or self.kern.low_rank:
+            return False
+        wide = (prim in WIDE_PRIMITIVES and self._spec.base in WIDE_BASES and (self._spec.order == 1 or self._spec.num_levels == 1)
+                and _WIDE["value"] != 0)
+        return not wide
+
     def _seq_levels(self, Xs, X2s=None):
         if self._lr is not None:                                                                    # kernels.py:426 / :451
             P1 = self._lr.seq(Xs)
             P2 = P1 if X2s is None else self._lr.seq(X2s)
             return torch.stack([a @ b.T for a, b in zip(P1, P2)], dim=0)
-        return self._mx_seq_levels(Xs, X2s) if self.matrix_route else _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
+        return self._mx_seq_levels(Xs, X2s) if self._mx("seq") else _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
 
     def _phi(self, Xs, work=None):
         """The level features (N, ld) of the scaled sequences where the feature route applies (one sweep per evaluation, shared by the
         level diagonals and Kzx), else None.  work: the caller's estimate of what the recursion kernels would do instead; without one only
         features that the evaluation has already built are handed out."""
-        if not (self.feature_route and self._lr is None and not self.matrix_route and self._spec.base in ("linear", "cosine") and Xs.is_cuda
+        if not (self.feature_route and self._lr is None and not self.matrix_route and self._d_cols <= 64 and self._spec.base in ("linear", "cosine") and Xs.is_cuda
                 and Xs.dtype == torch.float64):        # (float32 modules: the recursions' ops convert on the way in and round on the way out)
             return None
         for held, Phi in (self._phi_memo or ()):
@@ -1032,12 +1060,12 @@ class SignatureKernelModule(torch.nn.Module):
         Phi = self._phi(Xs)
         if Phi is not None:                                                                         # K_m(x, x) = |Phi_m(x)|^2
             return _LevelNorms.apply(Phi, Xs.shape[2], self._spec.num_levels)
-        return self._mx_diag_levels(Xs) if self.matrix_route else _SeqDiagLevels.apply(Xs, self.p0, self._spec)
+        return self._mx_diag_levels(Xs) if self._mx("diag") else _SeqDiagLevels.apply(Xs, self.p0, self._spec)
 
     def _tens_levels(self, Zs, increments):
         if self._lr is not None:                                                                    # kernels.py:525-527
             return torch.stack([P @ P.T for P in self._lr.tens(Zs, increments)], dim=0)
-        return self._mx_tens_levels(Zs, increments) if self.matrix_route else _TensGramLevels.apply(Zs, self.p0, self._spec, increments)
+        return self._mx_tens_levels(Zs, increments) if self._mx("tens") else _TensGramLevels.apply(Zs, self.p0, self._spec, increments)
 
     def _tvs_levels(self, Zs, Xs, increments):
         if self._lr is not None:                                                                    # kernels.py:568
@@ -1048,10 +1076,10 @@ class SignatureKernelModule(torch.nn.Module):
             zf = _tensor_features(Zs, self._spec.num_levels, increments, self._spec.base == "cosine")
             ones = torch.ones((zf[0].shape[0], Xs.shape[0]), dtype=lev[0].dtype, device=Xs.device)
             return torch.stack([ones] + [a @ b.T for a, b in zip(zf, lev)], dim=0)
-        return self._mx_tvs_levels(Zs, Xs, increments) if self.matrix_route else _TensVsSeqLevels.apply(Zs, Xs, self.p0, self._spec, increments)
+        return self._mx_tvs_levels(Zs, Xs, increments) if self._mx("tvs") else _TensVsSeqLevels.apply(Zs, Xs, self.p0, self._spec, increments)
 
     def _tvs_weighted(self, Zs, Xs, fac, increments):
-        if self.matrix_route or self._lr is not None:
+        if self._mx("tvs") or self._lr is not None:
             return (self._tvs_levels(Zs, Xs, increments) * fac[:, None, :]).sum(dim=0)
         Phi = self._phi(Xs, self._tvs_work(Zs, Xs))
         if Phi is not None:             # sum_m fac[m][n] <Z_m[t], Phi_m[n]>: the factors go onto the features, no level arrays
@@ -1173,7 +1201,7 @@ class SignatureKernelModule(torch.nn.Module):
         Xs = self.scale_sequences(self._seq3(X, presliced or presliced_X))
         N = Xs.shape[0]
         X2s = None if X2 is None else self.scale_sequences(self._seq3(X2, presliced or presliced_X2))
-        if (self.sum_route and not return_levels and not self.kern.low_rank and not self.matrix_route and lr is None
+        if (self.sum_route and not return_levels and not self.kern.low_rank and not self.matrix_route and self._d_cols <= 64 and lr is None
                 and self._spec.base in ("linear", "cosine") and Xs.is_cuda and not torch.cuda.is_current_stream_capturing()):
             # the linear / cosine kernel's level sum and its gradient as one op through the feature space (no level arrays)
             if _SeqGramSum.applies(Xs, X2s, self._spec, self.kern.normalization):

@@ -130,6 +130,10 @@ SeqLaunchFn seq_lookup_ho_f32_ptd_d32(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_f32_ptn_d32(int, int, int, int, int);
 typedef hipError_t (*TvsLaneTLaunchFn)(const TvsLaneTArgs&, hipStream_t);
 bool tvs_lanet_plan(int M, int d, bool incr, TvsLaneTLaunchFn* fns, int* ngroups);
+// wide_api.hip: state spaces beyond the exact-shape kernels' columns (kernel arguments by dgemm, fused map / difference / recursion kernels)
+bool wide_tvs_available(const gpsig_ctx* c, const gpsig_params* p, int d, int64_t Tn, int64_t N, int L);
+int wide_tvs_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz, int d, const double* Z, const double* Xs, int64_t Tn, int64_t N, int L,
+                     int increments, const double* fx, const double* w, int sum_levels, double* out, double* aux);
 }  // namespace gpsig
 
 using namespace gpsig;
@@ -1613,9 +1617,39 @@ static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, con
         CHK(tens_vs_seq_features_device(c, p, ZT, ZS, X, Tn, N, L, increments, w, out, &done));
         if (done) return GPSIG_OK;
     }
+    // wide state spaces (wide_api.hip): beyond the tile kernel's 8 columns, or wherever built when the option says so
+    auto wide = [&](bool* done) -> int {
+        *done = false;
+        if (sizeof(TT) != 8) return GPSIG_OK;
+        ScaleParams s;
+        CHK(scale_params(c, p, !raw, &s));
+        const int d_eff = s.d_eff();
+        if (!wide_tvs_available(c, p, d_eff, Tn, N, L) || !(c->wide == 1 || d_eff > 8)) return GPSIG_OK;
+        void* xs;
+        CHK(ensure(c, B_XT, sizeof(double) * size_t(N) * L * d_eff + 8, &xs));
+        hipLaunchKernelGGL(prep_seq_scaled_kernel<double>, dim3(grid_for(N * int64_t(L) * d_eff)), dim3(256), 0, c->stream,
+                           static_cast<const double*>(X), N, L, s, static_cast<double*>(xs));
+        HIPCHK(c, hipGetLastError());
+        double* aux = c->tvs_aux_out;
+        if (aux) c->tvs_aux_written = true;
+        CHK(wide_tvs_forward(c, p, s, d_eff, static_cast<const double*>(Zdev), static_cast<const double*>(xs), Tn, N, L, increments,
+                             static_cast<const double*>(fx), w, (raw || return_levels) ? 0 : 1, static_cast<double*>(out), aux));
+        *done = true;
+        return GPSIG_OK;
+    };
+    if (c->wide == 1) {
+        bool done = false;
+        CHK(wide(&done));
+        if (done) return GPSIG_OK;
+    }
     if (N > 0 && Tn > 0 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1 || c->tvs_tile == 1)) {
         bool done = false;
         CHK(tens_vs_seq_tile_device(c, p, raw, Zdev, X, Tn, N, L, increments, fx, w, return_levels, out, &done));
+        if (done) return GPSIG_OK;
+    }
+    if (c->wide != 1) {
+        bool done = false;
+        CHK(wide(&done));
         if (done) return GPSIG_OK;
     }
     if (N > 0 && Tn > 0 && N <= 65535 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1) && p->base_kernel != GPSIG_BASE_SPECTRAL &&
@@ -1722,7 +1756,9 @@ static int e_tens_vs_seq_levels(gpsig_ctx* c, const gpsig_params* p, const void*
                              int32_t L, int32_t increments, void* out) {
     ENTER(c, p);
     const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
-    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    // (beyond MAX_FEATURES columns only the wide route -- wide_api.hip -- takes the call)
+    if (d > MAX_FEATURES && !(sizeof(TT) == 8 && d <= MAX_FEATURES_WIDE && wide_tvs_available(c, p, d, T, N, L)))
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
     const void *dZ, *dX;
     CHK(in_dev(c, B_IN0, Z, sizeof(TT) * size_t(lt) * T * E * d, &dZ));
     CHK(in_dev(c, B_IN1, X, sizeof(TT) * size_t(N) * L * d, &dX));
@@ -1743,7 +1779,8 @@ static int e_tens_vs_seq_weighted(gpsig_ctx* c, const gpsig_params* p, const voi
                                int32_t increments, const void* fac, void* out, void* aux, int32_t* aux_written) {
     ENTER(c, p);
     const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
-    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    if (d > MAX_FEATURES && !(sizeof(TT) == 8 && d <= MAX_FEATURES_WIDE && wide_tvs_available(c, p, d, T, N, L)))
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
     if (!fac && N > 0) return fail(c, GPSIG_ERR_INVALID, "null factor array");
     const void *dZ, *dX, *dF;
     CHK(in_dev(c, B_IN0, Z, sizeof(TT) * size_t(lt) * T * E * d, &dZ));
@@ -2123,6 +2160,8 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "f32_pack")) c->f32_pack = value;
     else if (!strcmp(name, "f32_waves")) c->f32_waves = value;
     else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
+    else if (!strcmp(name, "wide")) c->wide = value;
+    else if (!strcmp(name, "wide_chunk_mb")) c->wide_chunk_mb = value > 0 ? value : 0;
     else if (!strcmp(name, "tvs_features")) c->tvs_features = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else if (!strcmp(name, "diag_own")) c->diag_own = value;

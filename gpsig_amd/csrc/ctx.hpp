@@ -35,6 +35,7 @@ enum BufId {
     B_SPEC,                                                    // spectral base-kernel table
     B_TQ,                                                      // item counters of the Kzx tile kernel's persistent launch
     B_STASH,                                                   // what the fused reverse kernel needs of the forward recursion (gpsig_seq_gram_levels_stash)
+    B_WD0, B_WD1, B_WD2, B_WD3, B_WD4, B_WD5, B_WD6, B_WD7, B_WD8, B_WD9,   // wide state spaces (wide_api.hip): augmented rows, kernel-argument chunks, their adjoints, lattice states
     B_COUNT
 };
 
@@ -93,6 +94,9 @@ struct gpsig_ctx {
                                   // 3: wavefront kernel + stored lattice, 4: scratch-free wavefront kernel wherever it is built
     void* blas_handle = nullptr;  // rocBLAS handle of gpsig_lr_whitening (lowrank_solver.hip), created at first use
     int tvs_tile = -1;            // Kzx tile kernel (tvs_tile_kernel.hpp): -1 where it is built, 0 never, 1 also below 32 tensors
+    int wide = -1;                // wide state spaces (wide_api.hip: kernel arguments by dgemm, fused map / difference / recursion kernels): -1 where the exact-shape
+                                  // kernels are not built (more than 8 columns for Kzx, more than 32 for the sequence lattices), 0 never, 1 wherever built
+    int wide_chunk_mb = 0;        // its argument chunk in HBM (0: a quarter of the gradient scratch budget)
     int tvs_features = -1;        // Kzx of the linear / cosine kernel as one product of level features: -1 where a time model prefers it, 0 never, 1 wherever built
     int tvs_tile_nw = 0;          // its waves per workgroup: 0 = planner's choice
     int tens_tile = 1;            // Kzz in 16 x 16 tiles with the tensors staged in LDS (tens_gram_tile_kernel); 0: one gathering thread per entry

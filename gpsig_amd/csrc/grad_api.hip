@@ -43,13 +43,17 @@ int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
 // tvs_grad_api.hip: the tile kernel of the tensor-vs-sequence reverse pass (tvs_grad_tile_kernel.hpp)
 int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, const double* X, const double* G, int64_t Tn, int64_t N,
                          int L, int increments, const double* fac, const double* aux, double* gZ, double* gX, double* gfac, double* gb, size_t budget, bool* done);
+// wide_api.hip: state spaces beyond the exact-shape kernels' columns
+bool wide_tvs_available(const gpsig_ctx* c, const gpsig_params* p, int d, int64_t Tn, int64_t N, int L);
+int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, const double* X, const double* G, int64_t Tn, int64_t N, int L,
+                      int increments, const double* fac, const double* aux, double* gZ, double* gX, double* gfac);
 }  // namespace gpsig
 
 using namespace gpsig;
 
 namespace {
 
-int grad_check(gpsig_ctx* c, const gpsig_params* p, int* d, int* DP) {
+int grad_check(gpsig_ctx* c, const gpsig_params* p, int* d, int* DP, int max_d = 64) {
     if (!c) return GPSIG_ERR_INVALID;
     if (!p) return fail(c, GPSIG_ERR_INVALID, "params is NULL");
     if (p->dtype != GPSIG_F64) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for float64 only");
@@ -59,8 +63,9 @@ int grad_check(gpsig_ctx* c, const gpsig_params* p, int* d, int* DP) {
     if (p->base_kernel < GPSIG_BASE_LINEAR || p->base_kernel > GPSIG_BASE_MATERN52) return fail(c, GPSIG_ERR_INVALID, "unknown base kernel %d", p->base_kernel);
     if (p->num_features < 1 || p->num_lags < 0) return fail(c, GPSIG_ERR_INVALID, "bad num_features / num_lags");
     *d = p->num_features * (p->num_lags + 1);      // raw entry points: columns are taken as they come
-    if (*d > 64) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns (got %d)", *d);
-    *DP = *d <= 4 ? 4 : (*d <= 8 ? 8 : (*d <= 16 ? 16 : (*d <= 32 ? 32 : 64)));
+    // (max_d > 64: entry points with a wide route -- wide_api.hip --, which is then the only one that takes such a call: *DP = 0)
+    if (*d > max_d) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most %d feature columns (got %d)", max_d, *d);
+    *DP = *d <= 4 ? 4 : (*d <= 8 ? 8 : (*d <= 16 ? 16 : (*d <= 32 ? 32 : (*d <= 64 ? 64 : 0))));
     HIPCHK(c, hipSetDevice(c->device));
     return GPSIG_OK;
 }
@@ -915,7 +920,10 @@ int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void*
 int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N, int32_t L,
                                   int32_t increments, const void* G, void* gZ, void* gX, double* g_base) {
     int d, DP;
-    CHK(grad_check(c, p, &d, &DP));
+    CHK(grad_check(c, p, &d, &DP, 4096));
+    // wide state spaces (wide_api.hip): beyond the tile kernel's 8 columns, or wherever built when the option says so
+    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8);
+    if (DP == 0 && !wide) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns here (got %d)", d);
     if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
     if (N > 0x7fffffff || T > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 items");
     const int M = p->num_levels, lt = M * (M + 1) / 2;
@@ -935,7 +943,12 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     // kernels without a differentiable base parameter skip the accumulation (one same-address atomic per wavefront otherwise)
     double* const kgb = (p->base_kernel == GPSIG_BASE_POLY || p->base_kernel == GPSIG_BASE_MIX) ? dgb : nullptr;
     bool tiled = false;
-    if (T > 0 && N > 0 && c->grad_impl == 0 && c->tvs_grad_tile != 0)
+    if (wide) {
+        CHK(wide_tvs_backward(c, p, d, static_cast<const double*>(dZ), static_cast<const double*>(dX), static_cast<const double*>(dG), T, N, L, increments,
+                              nullptr, nullptr, static_cast<double*>(dgZ), static_cast<double*>(dgX), nullptr));
+        tiled = true;
+    }
+    if (!tiled && T > 0 && N > 0 && c->grad_impl == 0 && c->tvs_grad_tile != 0)
         CHK(tvs_grad_tile_device(c, p, d, static_cast<const double*>(dZ), static_cast<const double*>(dX), static_cast<const double*>(dG), T, N, L,
                                  increments, nullptr, nullptr, static_cast<double*>(dgZ), static_cast<double*>(dgX), nullptr, kgb, scratch_budget(c), &tiled));
     if (tiled) {
@@ -1252,7 +1265,9 @@ extern "C" {
 int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* c, const gpsig_params* p, const void* Z, const void* X, int64_t T, int64_t N, int32_t L,
                                     int32_t increments, const void* fac, const void* G, const void* aux, void* gZ, void* gX, void* gfac, double* g_base) {
     int d, DP;
-    CHK(grad_check(c, p, &d, &DP));
+    CHK(grad_check(c, p, &d, &DP, 4096));
+    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8);
+    if (DP == 0 && !wide) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns here (got %d)", d);
     if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
     if (N > 0x7fffffff || T > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 items");
     const int M = p->num_levels, M1 = M + 1, lt = M * (M + 1) / 2;
@@ -1269,7 +1284,15 @@ int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* c, const gpsig_params* p, const v
     CHK(out_dev(c, B_OUT2, gfac, fb, &dgF));
     const bool has_base = p->base_kernel == GPSIG_BASE_POLY || p->base_kernel == GPSIG_BASE_MIX;
     bool tiled = false;
-    if (T > 0 && N > 0 && c->grad_impl == 0 && c->tvs_grad_tile != 0) {
+    if (wide) {
+        CHK(wide_tvs_backward(c, p, d, static_cast<const double*>(dZ), static_cast<const double*>(dX), static_cast<const double*>(dG), T, N, L, increments,
+                              static_cast<const double*>(dF), c->ptr_mode == GPSIG_PTR_DEVICE ? static_cast<const double*>(aux) : nullptr,
+                              static_cast<double*>(dgZ), static_cast<double*>(dgX), static_cast<double*>(dgF)));
+        if (g_base && c->ptr_mode == GPSIG_PTR_HOST) g_base[0] = g_base[1] = 0.0;
+        else if (g_base) CHK(zero_async(c, g_base, 2 * sizeof(double)));
+        tiled = true;
+    }
+    if (!tiled && T > 0 && N > 0 && c->grad_impl == 0 && c->tvs_grad_tile != 0) {
         double* dgb;
         CHK(gbase_begin(c, &dgb));
         CHK(tvs_grad_tile_device(c, p, d, static_cast<const double*>(dZ), static_cast<const double*>(dX), static_cast<const double*>(dG), T, N, L,

@@ -1,0 +1,357 @@
+// wide_kernels.hpp -- gfx950 kernels of the WIDE-STATE-SPACE route (round 6).
+//
+// Reference shapes: benchmarks/run_gpsig_benchmarks.py:32 runs every data set with num_lags=1 on time-augmented data, a state space of
+// 2 (n_features + 1) columns (gpsig/kernels.py:350): 10 .. 1,928 for 9 of the 16 data sets of benchmarks/datasets.json.  The exact-shape kernels
+// keep a lane's operands in registers (Kzx: <= 8 columns, the sequence lattices: <= 32); beyond that the base kernel's matrix of
+// kernels.py:226 / :329 / :333 is what the reference says it is, a d-deep contraction -- and north_star puts exactly that on the BLAS
+// ("MFMA only for the dense matmuls where it is a true contraction").  Here:
+//
+//   * rows are AUGMENTED so that one dgemm yields the kernel ARGUMENT of the distance kernels, not just the inner product:
+//         left form  [v, -|v|^2/2, 1],  right form [v, 1, -|v|^2/2]:   <left(z), right(x)> = <z, x> - |z|^2/2 - |x|^2/2 = -|z - x|^2 / 2 =: a
+//     (kernels.py:765-776 forms the same three terms); RBF (:862-864) is exp(a), the Matern families (:955-993) functions of r = sqrt(max(-2a, 1e-40));
+//     the reverse pass needs no norm bookkeeping either: the adjoint of a times the augmented rows IS the chain rule through the norms;
+//   * ONE kernel then maps arguments to kappa, takes the increments' difference (kernels.py:329-330), the time difference
+//     (signature_algs.py:114) and sweeps the chains of signature_algs.py:118-125 -- the argument array (rows = (sequence, time), columns =
+//     (component, endpoint, tensor), tensors fastest: a wavefront reads 512 contiguous bytes per component and step) is read once, nothing else
+//     of the (lt, T, N, L) tensor ever exists;
+//   * the reverse kernel undoes the chains from their totals (as tvs_grad_tile_kernel.hpp does) and writes the adjoint of the argument array, which
+//     two more dgemms contract with the augmented rows of the other side.
+// Lane = inducing tensor; levels one after the other (level i owns components i(i-1)/2 .. i(i-1)/2 + i - 1, so every column is read by one level).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "seq_core.hpp"
+
+namespace gpsig {
+
+constexpr int WIDE_MAX_LEVELS = 8;
+
+struct WideTvsArgs {
+    const double* arg;      // (Nc * L, CW): row (n - n0) * L + tau, column (k * E + e) * Tpad + t
+    int64_t CW, Tpad, Tn;
+    int64_t n0, Nc, N;      // this launch: sequences n0 .. n0 + Nc - 1 of N
+    int32_t L, M, kind, difference, sum_levels;
+    const double* fx;       // (N, M+1) per-sequence factors or NULL
+    const double* w;        // (M+1) level weights or NULL
+    double* out;            // forward: (T, N) level sum or (M+1, T, N)
+    double* aux;            // (N, lt, Tpad) chain totals: written by the forward kernel, read by the reverse kernel; NULL: neither
+    const double* G;        // reverse: upstream gradient, (T, N) of the weighted sum (weighted = 1) or (M+1, T, N) of the levels
+    double* W;              // reverse: adjoint of arg, same shape
+    double* gfac_part;      // reverse, weighted: (TB, N, M+1) partial sums of dL/dfac over the tensors of a block, or NULL
+    int32_t weighted;
+};
+
+__device__ __forceinline__ double wide_kappa(int kind, double a) {
+    if (kind == BASE_RBF) return exp(a);
+    const double r = sqrt(fmax(-2.0 * a, 1e-40));                      // kernels.py:779-781
+    if (kind == BASE_MATERN12) return exp(-r);
+    if (kind == BASE_MATERN32) { const double c = 1.7320508075688772935; return (1.0 + c * r) * exp(-c * r); }
+    const double c = 2.2360679774997896964;
+    return (1.0 + c * r + (5.0 / 3.0) * (r * r)) * exp(-c * r);
+}
+
+// kappa and d kappa / d a  (a = -dist / 2: d/da = -2 d/ddist; the clamp of kernels.py:781 passes no gradient, as grad_core.hpp: base_eval_grad)
+__device__ __forceinline__ void wide_kappa_grad(int kind, double a, double& k, double& dk) {
+    if (kind == BASE_RBF) { k = exp(a); dk = k; return; }
+    const double dist = -2.0 * a;
+    const bool clamped = !(dist > 1e-40);
+    const double r = sqrt(fmax(dist, 1e-40));
+    double dk_dr;
+    if (kind == BASE_MATERN12) {
+        k = exp(-r); dk_dr = -k;
+    } else if (kind == BASE_MATERN32) {
+        const double c = 1.7320508075688772935, e = exp(-c * r);
+        k = (1.0 + c * r) * e; dk_dr = -3.0 * r * e;
+    } else {
+        const double c = 2.2360679774997896964, e = exp(-c * r);
+        k = (1.0 + c * r + (5.0 / 3.0) * (r * r)) * e; dk_dr = -(5.0 / 3.0) * r * (1.0 + c * r) * e;
+    }
+    dk = clamped ? 0.0 : -dk_dr / r;
+}
+
+// value of component k at one argument row (r points at the lane's column 0 of that row)
+template <int E>
+__device__ __forceinline__ double wide_val(const double* __restrict__ r, int k, int64_t Tpad, int kind) {
+    if constexpr (E == 2) return wide_kappa(kind, r[(2 * k + 1) * Tpad]) - wide_kappa(kind, r[(2 * k) * Tpad]);      // kernels.py:330
+    else return wide_kappa(kind, r[k * Tpad]);
+}
+
+// the chains of ONE level (I components from k0) of one (tensor, sequence) pair: signature_algs.py:118-125 as one sweep
+template <int I, int E>
+__device__ __forceinline__ void wide_chain_fwd(const double* __restrict__ col, int64_t CW, int64_t Tpad, int k0, int L, int difference, int kind,
+                                               double (&u)[I]) {
+#pragma unroll
+    for (int j = 0; j < I; ++j) u[j] = 0.0;
+    double prev[I];
+    const double* r = col;
+    int steps = L;
+    if (difference) {                                                              // signature_algs.py:114
+#pragma unroll
+        for (int j = 0; j < I; ++j) prev[j] = wide_val<E>(r, k0 + j, Tpad, kind);
+        r += CW;
+        steps = L - 1;
+    }
+    for (int s = 0; s < steps; ++s, r += CW) {
+        double dk[I];
+#pragma unroll
+        for (int j = 0; j < I; ++j) {
+            const double v = wide_val<E>(r, k0 + j, Tpad, kind);
+            dk[j] = difference ? v - prev[j] : v;
+            prev[j] = v;
+        }
+#pragma unroll
+        for (int j = I - 1; j >= 1; --j) u[j] = fma(dk[j], u[j - 1], u[j]);          // :120-124 (old values below)
+        u[0] += dk[0];
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void wide_level_fwd(int i, const double* col, const WideTvsArgs& A, double* u /* [i] */) {
+    const int k0 = i * (i - 1) / 2;
+#define GPSIG_WIDE_CASE(I_)                                                                          \
+    case I_: {                                                                                       \
+        double v[I_];                                                                                \
+        wide_chain_fwd<I_, E>(col, A.CW, A.Tpad, k0, A.L, A.difference, A.kind, v);                  \
+        _Pragma("unroll") for (int j = 0; j < I_; ++j) u[j] = v[j];                                 \
+    } break;
+    switch (i) {
+        GPSIG_WIDE_CASE(1) GPSIG_WIDE_CASE(2) GPSIG_WIDE_CASE(3) GPSIG_WIDE_CASE(4)
+        GPSIG_WIDE_CASE(5) GPSIG_WIDE_CASE(6) GPSIG_WIDE_CASE(7) GPSIG_WIDE_CASE(8)
+        default: break;
+    }
+#undef GPSIG_WIDE_CASE
+}
+
+// grid: (Tpad / 64, sequences of the chunk (grid-stride)); block: one wavefront, lane = tensor
+template <int E>
+__global__ void __launch_bounds__(64) wide_tvs_fwd_kernel(const WideTvsArgs A) {
+    const int64_t t = int64_t(blockIdx.x) * 64 + threadIdx.x;
+    const int M = A.M, lt = M * (M + 1) / 2;
+    for (int64_t nl = blockIdx.y; nl < A.Nc; nl += gridDim.y) {
+        const int64_t n = A.n0 + nl;
+        const double* col = A.arg + nl * int64_t(A.L) * A.CW + t;
+        double acc = 0.0;
+        for (int i = 0; i <= M; ++i) {
+            double f = A.fx ? A.fx[n * (M + 1) + i] : 1.0;
+            if (A.w) f *= A.w[i];
+            double lev = 1.0;                                                          // signature_algs.py:116
+            if (i >= 1) {
+                double u[WIDE_MAX_LEVELS];
+                wide_level_fwd<E>(i, col, A, u);
+                lev = u[i - 1];                                                        // :125
+                if (A.aux) {
+                    const int k0 = i * (i - 1) / 2;
+                    for (int j = 0; j < i; ++j) A.aux[(n * lt + k0 + j) * A.Tpad + t] = u[j];
+                }
+            }
+            if (A.sum_levels) acc = fma(lev, f, acc);
+            else if (t < A.Tn) A.out[(int64_t(i) * A.Tn + t) * A.N + n] = lev * f;
+        }
+        if (A.sum_levels && t < A.Tn) A.out[t * A.N + n] = acc;
+    }
+}
+
+// ---- reverse pass ------------------------------------------------------------------------------------------------------------------
+// With u_j the chain values BEFORE a step and W_j = dL/du_j after it:  dL/dm_j = u_{j-1} W_j,  W_{j-1} += m_j W_j,  and the chain is undone
+// by u_j <- u_j - m_j u_{j-1} (tvs_grad_tile_kernel.hpp, grad_ho_kernels.hpp: chain_levels_grad_kernel).  m_j[tau] = v_j[tau + 1] - v_j[tau]
+// (signature_algs.py:114), so the adjoint of the VALUE row rho is g[rho - 1] - g[rho]; times d kappa / d a of each endpoint it is the adjoint of the
+// argument.  u: the level's totals (destroyed).  c: the level's upstream gradient.  Columns of tensors beyond Tn get zeros (valid = false).
+template <int I, int E>
+__device__ __forceinline__ void wide_chain_bwd(const double* __restrict__ col, double* __restrict__ wcol, int64_t CW, int64_t Tpad, int k0, int L,
+                                               int difference, int kind, double (&u)[I], double c, bool valid) {
+    double wv[I];
+#pragma unroll
+    for (int j = 0; j < I; ++j) wv[j] = 0.0;
+    auto eval = [&](const double* __restrict__ r, double (&v)[I], double (&d)[I][E]) {
+#pragma unroll
+        for (int j = 0; j < I; ++j) {
+            if constexpr (E == 2) {
+                double k1, d1, k0v, d0;
+                wide_kappa_grad(kind, r[(2 * (k0 + j) + 1) * Tpad], k1, d1);
+                wide_kappa_grad(kind, r[(2 * (k0 + j)) * Tpad], k0v, d0);
+                v[j] = k1 - k0v; d[j][1] = d1; d[j][0] = -d0;
+            } else {
+                wide_kappa_grad(kind, r[(k0 + j) * Tpad], v[j], d[j][0]);
+            }
+        }
+    };
+    auto store = [&](double* __restrict__ wr, const double (&g)[I], const double (&d)[I][E]) {
+#pragma unroll
+        for (int j = 0; j < I; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) wr[((k0 + j) * E + e) * Tpad] = valid ? g[j] * d[j][e] : 0.0;
+    };
+    auto undo = [&](const double (&dk)[I], double (&g)[I]) {
+        double below = 1.0;
+#pragma unroll
+        for (int j = 0; j < I; ++j) {
+            const double wnext = (j == I - 1) ? c : wv[j + 1 < I ? j + 1 : j];
+            g[j] = below * wnext;
+            u[j] = fma(-dk[j], below, u[j]);
+            below = u[j];
+            if (j >= 1) wv[j] = fma(dk[j], wnext, wv[j]);
+        }
+    };
+    if (difference) {
+        const double* r = col + int64_t(L - 1) * CW;
+        double* wr = wcol + int64_t(L - 1) * CW;
+        double nv[I], nd[I][E], gprev[I];
+        eval(r, nv, nd);
+#pragma unroll
+        for (int j = 0; j < I; ++j) gprev[j] = 0.0;
+        for (int s = L - 2; s >= 0; --s) {
+            r -= CW;
+            double cv[I], cd[I][E], dk[I], g[I], gv[I];
+            eval(r, cv, cd);
+#pragma unroll
+            for (int j = 0; j < I; ++j) dk[j] = nv[j] - cv[j];
+            undo(dk, g);
+#pragma unroll
+            for (int j = 0; j < I; ++j) gv[j] = g[j] - gprev[j];
+            store(wr, gv, nd);                                                         // row s + 1 is final
+            wr -= CW;
+#pragma unroll
+            for (int j = 0; j < I; ++j) {
+                gprev[j] = g[j]; nv[j] = cv[j];
+#pragma unroll
+                for (int e = 0; e < E; ++e) nd[j][e] = cd[j][e];
+            }
+        }
+        double gv[I];
+#pragma unroll
+        for (int j = 0; j < I; ++j) gv[j] = -gprev[j];
+        store(wr, gv, nd);                                                             // row 0
+    } else {
+        const double* r = col + int64_t(L - 1) * CW;
+        double* wr = wcol + int64_t(L - 1) * CW;
+        for (int s = L - 1; s >= 0; --s, r -= CW, wr -= CW) {
+            double cv[I], cd[I][E], g[I];
+            eval(r, cv, cd);
+            undo(cv, g);
+            store(wr, g, cd);
+        }
+    }
+}
+
+__device__ __forceinline__ double wide_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int E>
+__global__ void __launch_bounds__(64) wide_tvs_bwd_kernel(const WideTvsArgs A) {
+    const int64_t t = int64_t(blockIdx.x) * 64 + threadIdx.x;
+    const bool valid = t < A.Tn;
+    const int M = A.M, lt = M * (M + 1) / 2;
+    for (int64_t nl = blockIdx.y; nl < A.Nc; nl += gridDim.y) {
+        const int64_t n = A.n0 + nl;
+        const double* col = A.arg + nl * int64_t(A.L) * A.CW + t;
+        double* wcol = A.W + nl * int64_t(A.L) * A.CW + t;
+        const double gsum = (A.weighted && valid) ? A.G[t * A.N + n] : 0.0;
+        if (A.gfac_part) {                                                             // level 0 == 1: dL/dfac[n][0] = sum_t G[t][n]
+            const double s = wide_wave_sum(gsum);
+            if (threadIdx.x == 0) A.gfac_part[(int64_t(blockIdx.x) * A.N + n) * (M + 1)] = s;
+        }
+        for (int i = 1; i <= M; ++i) {
+            const int k0 = i * (i - 1) / 2;
+            double f = A.fx ? A.fx[n * (M + 1) + i] : 1.0;
+            if (A.w) f *= A.w[i];
+            const double c = A.weighted ? gsum * f : (valid ? A.G[(int64_t(i) * A.Tn + t) * A.N + n] * f : 0.0);
+            double u[WIDE_MAX_LEVELS];
+            if (A.aux) {
+                for (int j = 0; j < i; ++j) u[j] = A.aux[(n * lt + k0 + j) * A.Tpad + t];
+            } else {
+                wide_level_fwd<E>(i, col, A, u);
+            }
+            if (A.gfac_part) {
+                const double s = wide_wave_sum(gsum * u[i - 1]);
+                if (threadIdx.x == 0) A.gfac_part[(int64_t(blockIdx.x) * A.N + n) * (M + 1) + i] = s;
+            }
+#define GPSIG_WIDE_CASE(I_)                                                                                  \
+    case I_: {                                                                                               \
+        double v[I_];                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < I_; ++j) v[j] = u[j];                                         \
+        wide_chain_bwd<I_, E>(col, wcol, A.CW, A.Tpad, k0, A.L, A.difference, A.kind, v, c, valid);          \
+    } break;
+            switch (i) {
+                GPSIG_WIDE_CASE(1) GPSIG_WIDE_CASE(2) GPSIG_WIDE_CASE(3) GPSIG_WIDE_CASE(4)
+                GPSIG_WIDE_CASE(5) GPSIG_WIDE_CASE(6) GPSIG_WIDE_CASE(7) GPSIG_WIDE_CASE(8)
+                default: break;
+            }
+#undef GPSIG_WIDE_CASE
+        }
+    }
+}
+
+// gfac[n][m] = sum over the tensor blocks of the partial sums (a fixed order: the result does not depend on the schedule)
+__global__ void wide_gfac_reduce_kernel(const double* __restrict__ part, int TB, int64_t NM, double* __restrict__ gfac) {
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < NM; idx += int64_t(gridDim.x) * blockDim.x) {
+        double s = 0.0;
+        for (int b = 0; b < TB; ++b) s += part[int64_t(b) * NM + idx];
+        gfac[idx] = s;
+    }
+}
+
+// ---- augmented rows ------------------------------------------------------------------------------------------------------------------
+// dst row r (DA = d + 2 columns): the d values of the source row, then (-|v|^2/2, 1) [left form] or (1, -|v|^2/2) [right form].
+// Tensor rows are reordered on the way: dst row (k * E + e) * Tpad + t  <-  src row (k * Tn + t) * E + e (the caller's (lt, T, E, d) array), scaled by
+// lengthscales / lag weights where P.has_ls (kernels.py:367-398); rows of tensors beyond Tn are zero.  lt == 0: rows as they come (sequences, already scaled).
+// One wavefront per row.
+__global__ void __launch_bounds__(64) wide_aug_rows_kernel(const double* __restrict__ src, int64_t rows, int d, int right, int lt, int64_t Tn, int64_t Tpad,
+                                                           int E, ScaleParams P, double* __restrict__ dst) {
+    const int DA = d + 2;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const double* s = nullptr;
+        if (lt > 0) {
+            const int64_t t = r % Tpad;
+            const int ke = int(r / Tpad), k = ke / E, e = ke - k * E;
+            if (t < Tn) s = src + ((int64_t(k) * Tn + t) * E + e) * d;
+        } else {
+            s = src + r * d;
+        }
+        double ss = 0.0;
+        for (int f = threadIdx.x; f < d; f += 64) {
+            double v = 0.0;
+            if (s) {
+                v = s[f];
+                if (lt > 0 && P.has_ls) {
+                    const int lag = f / P.d_in, f0 = f - lag * P.d_in;
+                    v = v / P.lsv(f0);
+                    if (P.num_lags > 0) v = v * P.gamma[lag];
+                }
+            }
+            dst[r * DA + f] = v;
+            ss = fma(v, v, ss);
+        }
+        ss = wide_wave_sum(ss);
+        if (threadIdx.x == 0) {
+            const double h = s ? -0.5 * ss : 0.0, one = s ? 1.0 : 0.0;
+            dst[r * DA + d] = right ? one : h;
+            dst[r * DA + d + 1] = right ? h : one;
+        }
+    }
+}
+
+// The chain rule through the augmentation: g[f] = ga[f] - ga[norm column] * v[f]   (d(-|v|^2/2)/dv = -v; the constant column carries nothing).
+// Tensor rows go back to the caller's (lt, T, E, d) order; sequences as they come.  One thread per output element.
+__global__ void wide_unaug_rows_kernel(const double* __restrict__ ga, const double* __restrict__ va, int64_t rows_out, int d, int right, int lt, int64_t Tn,
+                                       int64_t Tpad, int E, double* __restrict__ g) {
+    const int DA = d + 2, nc = right ? d + 1 : d;
+    const int64_t total = rows_out * d;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int f = int(idx % d);
+        const int64_t ro = idx / d;
+        int64_t r = ro;
+        if (lt > 0) {
+            const int e = int(ro % E);
+            const int64_t t = (ro / E) % Tn;
+            const int k = int(ro / (int64_t(E) * Tn));
+            r = (int64_t(k) * E + e) * Tpad + t;
+        }
+        g[idx] = fma(-ga[r * DA + nc], va[r * DA + f], ga[r * DA + f]);
+    }
+}
+
+}  // namespace gpsig

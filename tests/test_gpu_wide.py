@@ -1,0 +1,209 @@
+"""Round 6: the wide-state-space route (csrc/wide_api.hip, wide_kernels.hpp) through the C ABI against the oracles.
+
+The reference's own benchmark settings (benchmarks/run_gpsig_benchmarks.py:32: num_lags=1 on time-augmented data) give state spaces of
+2 (n_features + 1) columns: 10, 14, 26, 28, 46, 126, 1,928 for 9 of its 16 data sets.  Shapes below follow them (12 / 16 / 28 / 46 / 126 columns; the
+route forced on at 3 and 8 as well); values against oracle/sigkern_oracle.py, gradients against autograd of oracle/sigkern_oracle_torch.py.
+Tolerances: 1e-9 relative to the largest entry (float64; observed ~1e-13) -- inside north_star's 1e-6."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sigkern_oracle as O
+from oracle import sigkern_oracle_torch as OT
+
+pytestmark = pytest.mark.gpu
+_P = C.POINTER(C.c_double)
+WIDE_BASES = ["rbf", "matern12", "matern32", "matern52"]
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-300))
+
+
+def _host_ctx():
+    from gpsig_amd import _lib
+    ctx = _lib.context(0, 0)
+    ctx.set_pointer_mode(_lib.PTR_HOST)
+    return ctx
+
+
+def _params(base, d, M, difference, keep):
+    from gpsig_amd.autodiff import _Spec
+    return _Spec(base, M, difference, 0.0, order=1).params(d, 0.0, keep)
+
+
+def _vp(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _data(rng, M, T, N, L, d, increments):
+    lt = M * (M + 1) // 2
+    s = 1.0 / np.sqrt(d)                  # distances of order one whatever the width
+    Z = rng.standard_normal((lt, T, 2, d) if increments else (lt, T, d)) * s
+    X = np.cumsum(rng.standard_normal((N, L, d)) * 0.5 * s, axis=1)
+    return Z, X
+
+
+@pytest.mark.parametrize("M,T,N,L,d", [(4, 70, 9, 13, 12), (4, 33, 21, 7, 16), (4, 130, 6, 9, 28), (3, 20, 5, 11, 46), (4, 65, 4, 17, 126), (1, 5, 3, 4, 3),
+                                       (2, 64, 7, 1, 8), (5, 12, 9, 6, 10), (8, 9, 3, 10, 14), (4, 7, 66, 5, 300)])
+@pytest.mark.parametrize("base", WIDE_BASES)
+def test_wide_tensor_vs_sequence_levels_and_gradient(M, T, N, L, d, base):
+    """gpsig_tens_vs_seq_levels / _grad on the wide route (forced: option wide = 1, so that widths the tile kernel serves are covered too): 1 .. 8
+    levels, ragged tensor counts across the 64-lane blocks, a single observation, differences on / off, increments on / off, the argument array in
+    one chunk and in several (wide_chunk_mb = 1)."""
+    if base != "rbf" and (M, d) in ((1, 3), (2, 8), (8, 14), (4, 300)):
+        pytest.skip("a sample of the shapes is enough for the Matern families")
+    rng = np.random.default_rng(1000 * M + T + d)
+    ctx = _host_ctx()
+    ctx.set_option("wide", 1)
+    try:
+        for difference in (True, False):
+            for increments in (False, True):
+                if L == 1 and difference:
+                    continue
+                Z, X = _data(rng, M, T, N, L, d, increments)
+                G = rng.standard_normal((M + 1, T, N))
+                kt = OT.SignatureKernelTorchOracle(d, M, base, difference=difference)
+                tZ, tX = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+                want = kt.K_tens_vs_seq_levels(tZ, tX, increments)
+                (want * torch.tensor(G)).sum().backward()
+                keep = []
+                p = _params(base, d, M, difference, keep)
+                for mb in (0, 1):
+                    ctx.set_option("wide_chunk_mb", mb)
+                    out = np.full((M + 1, T, N), np.nan)
+                    ctx.call("gpsig_tens_vs_seq_levels", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(out))
+                    assert rel(out, want) < 1e-10, (difference, increments, mb, rel(out, want))
+                    gZ, gX, gb = np.full_like(Z, np.nan), np.full_like(X, np.nan), np.zeros(2)
+                    ctx.call("gpsig_tens_vs_seq_levels_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(G), _vp(gZ), _vp(gX), gb.ctypes.data_as(_P))
+                    assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9, (difference, increments, mb, rel(gZ, tZ.grad), rel(gX, tX.grad))
+    finally:
+        ctx.set_option("wide", -1)
+        ctx.set_option("wide_chunk_mb", 0)
+
+
+@pytest.mark.parametrize("base,M,T,N,L,d", [("rbf", 4, 70, 45, 9, 12), ("matern32", 3, 40, 12, 6, 28), ("rbf", 4, 130, 9, 7, 126), ("matern52", 2, 10, 8, 6, 46),
+                                            ("rbf", 4, 66, 10, 8, 6)])
+def test_wide_weighted_sum_and_gradient(base, M, T, N, L, d):
+    """gpsig_tens_vs_seq_weighted / _grad on the wide route: the level sum inside the kernel, the chain totals handed from the forward to the
+    reverse call (device pointers) or rebuilt by it, gradients with respect to Z, X and the per-sequence factors."""
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(7 * M + T + d)
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(dev)               # (a stream of its own: the context of the default stream is the host-pointer one of _host_ctx)
+    dctx = _lib.context(0, side.cuda_stream)
+    dctx.set_pointer_mode(_lib.PTR_DEVICE)
+    hctx = _host_ctx()
+    ptr = lambda t_: C.c_void_p(t_.data_ptr())      # noqa: E731
+    for ctx_ in (dctx, hctx):
+        ctx_.set_option("wide", 1)
+    try:
+        for increments in (False, True):
+            Z, X = _data(rng, M, T, N, L, d, increments)
+            F = rng.uniform(0.5, 1.5, (N, M + 1))
+            G = rng.standard_normal((T, N))
+            kt = OT.SignatureKernelTorchOracle(d, M, base)
+            tZ, tX, tF = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True), torch.tensor(F, requires_grad=True)
+            want = (kt.K_tens_vs_seq_levels(tZ, tX, increments) * tF.t()[:, None, :]).sum(0)
+            (want * torch.tensor(G)).sum().backward()
+            keep = []
+            p = _params(base, d, M, True, keep)
+            out = np.empty((T, N))
+            hctx.call("gpsig_tens_vs_seq_weighted", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(F), _vp(out), None, None)
+            assert rel(out, want) < 1e-10
+            gZ, gX, gF, gb = np.empty_like(Z), np.empty_like(X), np.empty_like(F), np.zeros(2)
+            hctx.call("gpsig_tens_vs_seq_weighted_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(F), _vp(G), None, _vp(gZ), _vp(gX), _vp(gF),
+                      gb.ctypes.data_as(_P))
+            assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9 and rel(gF, tF.grad) < 1e-9, (increments, rel(gZ, tZ.grad), rel(gX, tX.grad), rel(gF, tF.grad))
+            dZ, dX, dF, dG = (torch.tensor(a, device=dev) for a in (Z, X, F, G))
+            dgZ, dgX, dgF, dgb = torch.empty_like(dZ), torch.empty_like(dX), torch.empty_like(dF), torch.zeros(2, dtype=torch.float64, device=dev)
+            aux = torch.empty(int(_lib.load().gpsig_tens_vs_seq_aux_elems(C.byref(p), T, N)), dtype=torch.float64, device=dev)
+            dout, wrote = torch.empty((T, N), dtype=torch.float64, device=dev), C.c_int32(0)
+            torch.cuda.synchronize()
+            dctx.call("gpsig_tens_vs_seq_weighted", p, ptr(dZ), ptr(dX), T, N, L, int(increments), ptr(dF), ptr(dout), ptr(aux), C.byref(wrote))
+            side.synchronize()
+            assert rel(dout, want) < 1e-10 and wrote.value == 1
+            for use_aux in (False, True):
+                dctx.call("gpsig_tens_vs_seq_weighted_grad", p, ptr(dZ), ptr(dX), T, N, L, int(increments), ptr(dF), ptr(dG), ptr(aux) if use_aux else None,
+                          ptr(dgZ), ptr(dgX), ptr(dgF), C.cast(dgb.data_ptr(), _P))
+                side.synchronize()
+                assert rel(dgZ, tZ.grad) < 1e-9 and rel(dgX, tX.grad) < 1e-9 and rel(dgF, tF.grad) < 1e-9, (use_aux, rel(dgZ, tZ.grad), rel(dgX, tX.grad))
+    finally:
+        for ctx_ in (dctx, hctx):
+            ctx_.set_option("wide", -1)
+
+
+@pytest.mark.parametrize("base,d,num_lags,L,increments", [("rbf", 14, 1, 9, True), ("rbf", 6, 1, 12, True), ("matern32", 23, 1, 7, False), ("rbf", 63, 1, 11, True),
+                                                          ("matern12", 16, 0, 8, True), ("rbf", 200, 0, 6, True)])
+def test_wide_evaluation_path_against_the_oracle(base, d, num_lags, L, increments):
+    """kernels.Signature*.K_tens_vs_seq / K_tens_n_seq_covs (the fused evaluation entry points: scaling by lengthscales, lags, normalisation, weights) at
+    the reference's own settings -- time-augmented data with num_lags = 1: 2 d columns -- against the NumPy oracle."""
+    from gpsig_amd import kernels
+    import test_gpu_parity as P
+    rng = np.random.default_rng(31 + d)
+    M, T, N = 4, 70, 9
+    lt = M * (M + 1) // 2
+    de = d * (num_lags + 1)
+    X = np.cumsum(rng.standard_normal((N, L, d)) * 0.4, axis=1)
+    Z = rng.standard_normal((lt, T, 2, de) if increments else (lt, T, de)) * 0.7
+    ls = rng.uniform(0.8, 1.6, d) * np.sqrt(d)
+    var = rng.uniform(0.5, 1.5, M + 1)
+    for normalization in (True, False):
+        kw = dict(base=base, input_dim=L * d, num_features=d, num_levels=M, lengthscales=ls, variances=var, normalization=normalization,
+                  num_lags=num_lags or None)
+        k, ko = P.make_kernel(kernels, kw), P.make_oracle(kw)
+        if num_lags:
+            k.lags = ko.lags = np.array([0.23])
+            k.gamma = ko.gamma = np.array([0.6, 0.45])
+        got = k.K_tens_vs_seq(Z, X.reshape(N, -1), increments=increments)
+        want = ko.K_tens_vs_seq(Z, X.reshape(N, -1), increments=increments)
+        assert rel(got, want) < 1e-10, (normalization, rel(got, want))
+        gl = k.K_tens_vs_seq(Z, X.reshape(N, -1), increments=increments, return_levels=True)
+        wl = ko.K_tens_vs_seq(Z, X.reshape(N, -1), increments=increments, return_levels=True)
+        assert max(rel(a, b) for a, b in zip(gl[1:], wl[1:])) < 1e-10
+        for a, b in zip(k.K_tens_n_seq_covs(Z, X.reshape(N, -1), increments=increments), ko.K_tens_n_seq_covs(Z, X.reshape(N, -1), increments=increments)):
+            assert rel(a, b) < 1e-10
+
+
+@pytest.mark.parametrize("base,d,num_lags", [("rbf", 14, 1), ("rbf", 63, 1), ("matern32", 23, 1), ("rbf", 150, 0)])
+def test_wide_module_gradients(base, d, num_lags):
+    """autodiff.SignatureKernelModule.K_tens_n_seq_covs at the reference's settings (increments, num_lags = 1): values and the gradients with respect to
+    the inducing tensors, lengthscales, lags, lag weights and variances against autograd of the differentiable oracle."""
+    from gpsig_amd import autodiff, kernels
+    import test_gpu_parity as P
+    rng = np.random.default_rng(5 + d)
+    M, T, N, L = 4, 40, 7, 9
+    lt = M * (M + 1) // 2
+    de = d * (num_lags + 1)
+    X = np.cumsum(rng.standard_normal((N, L, d)) * 0.4, axis=1).reshape(N, -1)
+    Z = rng.standard_normal((lt, T, 2, de)) * 0.7
+    ls = rng.uniform(0.8, 1.6, d) * np.sqrt(d)
+    kw = dict(base=base, input_dim=L * d, num_features=d, num_levels=M, lengthscales=ls, num_lags=num_lags or None)
+    kern = P.make_kernel(kernels, kw)
+    mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
+    Zg = torch.tensor(Z, device="cuda:0", requires_grad=True)
+    Wt = [rng.standard_normal(s) for s in ((T, T), (T, N), (N,))]
+    outs = mod.K_tens_n_seq_covs(Zg, torch.tensor(X, device="cuda:0"), increments=True)
+    sum((o * torch.tensor(w, device="cuda:0")).sum() for o, w in zip(outs, Wt)).backward()
+    lsr = torch.tensor(ls, requires_grad=True)
+    okw = dict(lengthscales=lsr)
+    if num_lags:
+        lagr, gamr = mod.lags.detach().cpu().clone().requires_grad_(True), mod.gamma.detach().cpu().clone().requires_grad_(True)
+        okw.update(num_lags=num_lags, lags=lagr, gamma=gamr)
+    orc = OT.SignatureKernelTorchOracle(d, M, base, **okw)
+    Zc = torch.tensor(Z, requires_grad=True)
+    wants = orc.K_tens_n_seq_covs(Zc, torch.tensor(X), increments=True)
+    sum((o * torch.tensor(w)).sum() for o, w in zip(wants, Wt)).backward()
+    for o, w in zip(outs, wants):
+        assert rel(o, w) < 1e-10
+    assert rel(Zg.grad, Zc.grad) < 1e-8
+    sig = lambda r: torch.sigmoid(r.detach().cpu())      # noqa: E731
+    assert rel(mod.raw_lengthscales.grad, lsr.grad * sig(mod.raw_lengthscales)) < 1e-8
+    if num_lags:
+        lg = mod.lags.detach().cpu()
+        assert rel(mod.raw_lags.grad, lagr.grad * lg * (1 - lg)) < 1e-8
+        assert rel(mod.raw_gamma.grad, gamr.grad * sig(mod.raw_gamma)) < 1e-8
