@@ -73,7 +73,8 @@ class _Spec:
 # kernels, csrc/wide_api.hip): None = where the exact-shape kernels are not built (the library's default), True = wherever built, False = never.
 _WIDE = {"value": -1}
 WIDE_BASES = ("rbf", "matern12", "matern32", "matern52")
-WIDE_PRIMITIVES = {"tvs"}           # the level primitives the library has a wide route for
+WIDE_PRIMITIVES = {"tvs", "diag", "seq"}           # the level primitives the library has a wide route for
+WIDE_LAT_MAX_COLS = 512                            # ... the sequence lattices up to this many columns (csrc/wide_api.hip)
 
 
 def set_wide_route(mode):
@@ -1000,16 +1001,16 @@ class SignatureKernelModule(torch.nn.Module):
         return Z.reshape(shape)
 
     # ---- level primitives ------------------------------------------------------------------------------------------
-    def _mx(self, prim):
+    def _mx(self, prim, cols=0):
         """Does level primitive ``prim`` ('seq', 'diag', 'tens', 'tvs') take the matrix route?  Always when ``matrix_route`` is set (the spectral
         kernel; A/B runs).  Beyond 64 columns the library's exact-shape kernels are not built: the wide route takes what it is built for (the
-        distance kernels at order 1), the matrix route the rest."""
+        distance kernels at order 1; sequence lattices of up to 512 columns -- ``cols``: the shorter side's length), the matrix route the rest."""
         if self.matrix_route:
             return True
         if self._d_cols <= 64 or self.kern.low_rank:
             return False
         wide = (prim in WIDE_PRIMITIVES and self._spec.base in WIDE_BASES and (self._spec.order == 1 or self._spec.num_levels == 1)
-                and _WIDE["value"] != 0)
+                and _WIDE["value"] != 0 and cols - int(self._spec.difference) <= WIDE_LAT_MAX_COLS)
         return not wide
 
     def _seq_levels(self, Xs, X2s=None):
@@ -1017,7 +1018,7 @@ class SignatureKernelModule(torch.nn.Module):
             P1 = self._lr.seq(Xs)
             P2 = P1 if X2s is None else self._lr.seq(X2s)
             return torch.stack([a @ b.T for a, b in zip(P1, P2)], dim=0)
-        return self._mx_seq_levels(Xs, X2s) if self._mx("seq") else _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
+        return self._mx_seq_levels(Xs, X2s) if self._mx("seq", (Xs if X2s is None else X2s).shape[1]) else _SeqGramLevels.apply(Xs, X2s, self.p0, self._spec)
 
     def _phi(self, Xs, work=None):
         """The level features (N, ld) of the scaled sequences where the feature route applies (one sweep per evaluation, shared by the
@@ -1060,7 +1061,7 @@ class SignatureKernelModule(torch.nn.Module):
         Phi = self._phi(Xs)
         if Phi is not None:                                                                         # K_m(x, x) = |Phi_m(x)|^2
             return _LevelNorms.apply(Phi, Xs.shape[2], self._spec.num_levels)
-        return self._mx_diag_levels(Xs) if self._mx("diag") else _SeqDiagLevels.apply(Xs, self.p0, self._spec)
+        return self._mx_diag_levels(Xs) if self._mx("diag", Xs.shape[1]) else _SeqDiagLevels.apply(Xs, self.p0, self._spec)
 
     def _tens_levels(self, Zs, increments):
         if self._lr is not None:                                                                    # kernels.py:525-527

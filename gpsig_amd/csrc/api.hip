@@ -134,6 +134,9 @@ bool tvs_lanet_plan(int M, int d, bool incr, TvsLaneTLaunchFn* fns, int* ngroups
 bool wide_tvs_available(const gpsig_ctx* c, const gpsig_params* p, int d, int64_t Tn, int64_t N, int L);
 int wide_tvs_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz, int d, const double* Z, const double* Xs, int64_t Tn, int64_t N, int L,
                      int increments, const double* fx, const double* w, int sum_levels, double* out, double* aux);
+bool wide_lat_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L2);
+int wide_lat_forward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag,
+                     double* out);
 }  // namespace gpsig
 
 using namespace gpsig;
@@ -1181,6 +1184,22 @@ static int generic_levels(gpsig_ctx* c, const gpsig_params* p, bool apply_scalin
     ScaleParams sp;
     CHK(scale_params(c, p, apply_scaling, &sp));
     const int d_eff = sp.d_eff(), M = p->num_levels;
+    // wide route (wide_api.hip): the argument lattices by dgemm, one wavefront per lattice -- the distance kernels at order 1, up to 512 lattice columns
+    if (wide_lat_available(c, p, L1, L2) && sm == (diag ? N1 : N1 * N2) && si == (diag ? 1 : N2) && sj == (diag ? 0 : 1)) {
+        const bool same_ = diag || Y == nullptr || Y == X;
+        void *xs, *ys = nullptr;
+        CHK(ensure(c, B_GR0, sizeof(double) * size_t(N1) * L1 * d_eff + 8, &xs));
+        hipLaunchKernelGGL(prep_seq_scaled_kernel<double>, dim3(grid_for(N1 * int64_t(L1) * d_eff)), dim3(256), 0, c->stream, static_cast<const double*>(X), N1,
+                           L1, sp, static_cast<double*>(xs));
+        HIPCHK(c, hipGetLastError());
+        if (!same_) {
+            CHK(ensure(c, B_GR1, sizeof(double) * size_t(N2) * L2 * d_eff + 8, &ys));
+            hipLaunchKernelGGL(prep_seq_scaled_kernel<double>, dim3(grid_for(N2 * int64_t(L2) * d_eff)), dim3(256), 0, c->stream, static_cast<const double*>(Y),
+                               N2, L2, sp, static_cast<double*>(ys));
+            HIPCHK(c, hipGetLastError());
+        }
+        return wide_lat_forward(c, p, d_eff, static_cast<const double*>(xs), static_cast<const double*>(ys), N1, N2, L1, L2, diag, out);
+    }
     const int64_t s1 = (N1 + 63) / 64 * 64, s2 = (N2 + 63) / 64 * 64;
     void *xt, *yt = nullptr;
     CHK(ensure(c, B_GR0, sizeof(double) * size_t(L1) * d_eff * s1 + 8, &xt));
@@ -1286,7 +1305,8 @@ static int diag_levels_mn(gpsig_ctx* c, const gpsig_params* p, bool apply_scalin
     const int d_eff = p->num_features * ((apply_scaling ? p->num_lags : 0) + 1);
     SeqPlanned pl;
     const int rc = plan_seq(c, p, d_eff, L, &pl);
-    if (rc == GPSIG_ERR_UNSUPPORTED && generic_ok(p))
+    // (option wide = 1: the wide route wherever built -- generic_levels takes it)
+    if ((rc == GPSIG_ERR_UNSUPPORTED || (rc == GPSIG_OK && c->wide == 1 && wide_lat_available(c, p, L, L))) && generic_ok(p))
         return generic_levels(c, p, apply_scaling, X, X, N, N, L, L, true, static_cast<double*>(out), N, 1, 0);
     CHK(rc);
     const void* rec;
@@ -1323,7 +1343,8 @@ static int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const voi
         swap = !swap;
         rc = plan_seq(c, p, d_eff, swap ? L1 : L2, &pl, pairs_hint);
     }
-    if (rc == GPSIG_ERR_UNSUPPORTED && generic_ok(p) && row_end == 0) {     // any-shape fallback, orders of magnitude slower per pair
+    if (rc == GPSIG_OK && c->wide == 1 && generic_ok(p) && row_end == 0 && wide_lat_available(c, p, L1, L2)) rc = GPSIG_ERR_UNSUPPORTED;   // (option wide = 1)
+    if (rc == GPSIG_ERR_UNSUPPORTED && generic_ok(p) && row_end == 0) {     // any-shape fallback (wide route where built; else orders of magnitude slower per pair)
         if (timed) { c->t_launches += 0; }
         return seq_K_generic(c, p, raw, X, X2, N1, N2, L1, L2, return_levels, out, x_squared);
     }
@@ -1707,7 +1728,8 @@ static int e_seq_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* X,
     const int d = p->num_features * (p->num_lags + 1);
     gpsig_params q = *p;
     q.num_features = d; q.num_lags = 0;      // raw entry point: columns are taken as they come
-    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    if (d > MAX_FEATURES && !(sizeof(TT) == 8 && d <= MAX_FEATURES_WIDE && wide_lat_available(c, p, L1, X2 ? L2 : L1)))
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
     const void *dX, *dX2 = nullptr;
     CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N1) * L1 * d, &dX));
     if (X2) CHK(in_dev(c, B_IN1, X2, sizeof(TT) * size_t(N2) * L2 * d, &dX2));
@@ -1725,7 +1747,8 @@ static int e_seq_diag_levels(gpsig_ctx* c, const gpsig_params* p, const void* X,
     const int d = p->num_features * (p->num_lags + 1);
     gpsig_params q = *p;
     q.num_features = d; q.num_lags = 0;
-    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    if (d > MAX_FEATURES && !(sizeof(TT) == 8 && d <= MAX_FEATURES_WIDE && wide_lat_available(c, p, L, L)))
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
     const int M1 = p->num_levels + 1;
     const void* dX;
     CHK(in_dev(c, B_IN0, X, sizeof(TT) * size_t(N) * L * d, &dX));

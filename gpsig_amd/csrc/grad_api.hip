@@ -47,6 +47,9 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
 bool wide_tvs_available(const gpsig_ctx* c, const gpsig_params* p, int d, int64_t Tn, int64_t N, int L);
 int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, const double* X, const double* G, int64_t Tn, int64_t N, int L,
                       int increments, const double* fac, const double* aux, double* gZ, double* gX, double* gfac);
+bool wide_lat_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L2);
+int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag,
+                      const double* G, double* gX, double* gY);
 }  // namespace gpsig
 
 using namespace gpsig;
@@ -663,8 +666,11 @@ int seq_grad_ho(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, const dou
 int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
              const void* G, void* gX, void* gY, double* g_base) {
     int d, DP;
-    CHK(grad_check(c, p, &d, &DP));
+    CHK(grad_check(c, p, &d, &DP, 4096));
     if (N1 < 0 || N2 < 0 || L1 < 1 || L2 < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
+    // wide route (wide_api.hip): argument lattices by dgemm, both sweeps by one wavefront per lattice, the adjoint contracted back by dgemms
+    const bool wide_ok = N1 > 0 && N2 > 0 && wide_lat_available(c, p, L1, (diag || Y == nullptr) ? L1 : L2);
+    if (DP == 0 && !wide_ok) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns here (got %d)", d);
     if (N1 > 0x7fffffff || N2 > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 sequences");
     const bool sym = !diag && Y == nullptr;
     if (sym) { N2 = N1; L2 = L1; }
@@ -699,7 +705,16 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     if ((c->grad_impl == 0 || c->grad_impl == 4) && N1 > 0 && N2 > 0) lfn = lam_undo_plan(mode, p->base_kernel, L1 - drr, L2 - drr, DP, M, &lG, &lC);
     bool fswap = false;
     int fG = 16;
-    FusedGradLaunchFn ffn = (N1 > 0 && N2 > 0) ? fused_grad_plan(c, p, mode, L1, L2, DP, diag, sym, &fswap, &fG) : nullptr;
+    FusedGradLaunchFn ffn = (N1 > 0 && N2 > 0 && DP > 0) ? fused_grad_plan(c, p, mode, L1, L2, DP, diag, sym, &fswap, &fG) : nullptr;
+    // where the fused reverse kernel is not built (more than 16 columns, long register sides) the wide route takes over; option wide = 1: wherever built
+    if (wide_ok && (c->wide == 1 || DP == 0 || (!ffn && c->grad_impl == 0))) {      // (grad_impl != 0: A/B runs of the exact-shape kernels)
+        CHK(wide_lat_backward(c, p, d, static_cast<const double*>(dX), static_cast<const double*>((diag || sym) ? nullptr : dY), N1, N2, L1, L2, diag,
+                              static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(dgY)));
+        CHK(out_done(c, gX, dgX, xb));
+        if (!diag && !sym) CHK(out_done(c, gY, dgY, yb));
+        CHK(gbase_end(c, dgb, g_base));
+        return finish(c);
+    }
     bool by_features = false;      // the linear kernel, first order: through the feature contraction where that is cheaper (round 4)
     if (N1 > 0 && N2 > 0)
         CHK(sig_features_grad(c, p, d, static_cast<const double*>(dX), static_cast<const double*>(sym || diag ? dX : dY), N1, N2, L1, L2, diag, sym,

@@ -23,6 +23,9 @@ struct SolverApi {
                              double*, double*, rocblas_int*) = nullptr;
     rocblas_status (*dgemm)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const double*, const double*,
                             rocblas_int, const double*, rocblas_int, const double*, double*, rocblas_int) = nullptr;
+    rocblas_status (*dgemm_sb)(rocblas_handle, rocblas_operation, rocblas_operation, rocblas_int, rocblas_int, rocblas_int, const double*, const double*,
+                               rocblas_int, rocblas_stride, const double*, rocblas_int, rocblas_stride, const double*, double*, rocblas_int, rocblas_stride,
+                               rocblas_int) = nullptr;
     rocblas_status (*set_pointer_mode)(rocblas_handle, rocblas_pointer_mode) = nullptr;
     std::string err;
 };
@@ -46,6 +49,7 @@ void load_api() {
     if (!g_api.blas) return;
     // (rocBLAS alone serves solver_dgemm; rocSOLVER is needed by solver_dsyevd only)
     g_api.dgemm = reinterpret_cast<decltype(g_api.dgemm)>(dlsym(g_api.blas, "rocblas_dgemm"));
+    g_api.dgemm_sb = reinterpret_cast<decltype(g_api.dgemm_sb)>(dlsym(g_api.blas, "rocblas_dgemm_strided_batched"));
     g_api.set_pointer_mode = reinterpret_cast<decltype(g_api.set_pointer_mode)>(dlsym(g_api.blas, "rocblas_set_pointer_mode"));
     g_api.create_handle = reinterpret_cast<decltype(g_api.create_handle)>(dlsym(g_api.blas, "rocblas_create_handle"));
     g_api.destroy_handle = reinterpret_cast<decltype(g_api.destroy_handle)>(dlsym(g_api.blas, "rocblas_destroy_handle"));
@@ -101,6 +105,26 @@ bool solver_dgemm(void** handle_slot, hipStream_t stream, bool transA, bool tran
     const rocblas_status st = g_api.dgemm(h, transA ? rocblas_operation_transpose : rocblas_operation_none,
                                           transB ? rocblas_operation_transpose : rocblas_operation_none, m, n, k, &alpha, A, lda, B, ldb, &beta, C, ldc);
     if (st != rocblas_status_success) { *err = "rocblas_dgemm failed (status " + std::to_string(int(st)) + ")"; return false; }
+    return true;
+}
+
+// The same for `batch` problems at constant strides (rocblas_dgemm_strided_batched): the per-sequence argument lattices of the wide route (wide_api.hip).
+bool solver_dgemm_batched(void** handle_slot, hipStream_t stream, bool transA, bool transB, int m, int n, int k, double alpha, const double* A, int lda,
+                          int64_t sa, const double* B, int ldb, int64_t sb, double beta, double* C, int ldc, int64_t sc, int batch, std::string* err) {
+    std::call_once(g_api_once, load_api);
+    if (!g_api.dgemm_sb || !g_api.create_handle || !g_api.set_stream) { *err = "rocBLAS is not available: " + g_api.err; return false; }
+    if (!*handle_slot) {
+        rocblas_handle h = nullptr;
+        if (g_api.create_handle(&h) != rocblas_status_success) { *err = "rocblas_create_handle failed"; return false; }
+        *handle_slot = h;
+    }
+    rocblas_handle h = static_cast<rocblas_handle>(*handle_slot);
+    if (g_api.set_stream(h, stream) != rocblas_status_success) { *err = "rocblas_set_stream failed"; return false; }
+    if (g_api.set_pointer_mode) (void)g_api.set_pointer_mode(h, rocblas_pointer_mode_host);
+    const rocblas_status st = g_api.dgemm_sb(h, transA ? rocblas_operation_transpose : rocblas_operation_none,
+                                             transB ? rocblas_operation_transpose : rocblas_operation_none, m, n, k, &alpha, A, lda, sa, B, ldb, sb, &beta, C, ldc, sc,
+                                             batch);
+    if (st != rocblas_status_success) { *err = "rocblas_dgemm_strided_batched failed (status " + std::to_string(int(st)) + ")"; return false; }
     return true;
 }
 

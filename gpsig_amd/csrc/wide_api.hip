@@ -14,6 +14,9 @@ namespace gpsig {
 bool solver_dgemm(void** handle_slot, hipStream_t stream, bool transA, bool transB, int m, int n, int k, double alpha, const double* A, int lda,
                   const double* B, int ldb, double beta, double* C, int ldc, std::string* err);          // lowrank_solver.hip
 
+bool solver_dgemm_batched(void** handle_slot, hipStream_t stream, bool transA, bool transB, int m, int n, int k, double alpha, const double* A, int lda,
+                          int64_t sa, const double* B, int ldb, int64_t sb, double beta, double* C, int ldc, int64_t sc, int batch, std::string* err);
+
 namespace {
 
 bool wide_kind(int base_kernel) {
@@ -35,6 +38,40 @@ int dgemm(gpsig_ctx* c, bool ta, bool tb, int64_t m, int64_t n, int64_t k, const
         return fail(c, GPSIG_ERR_HIP, "%s", err.c_str());
     return GPSIG_OK;
 }
+
+int dgemm_batched(gpsig_ctx* c, bool ta, bool tb, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, int64_t sa, const double* B, int64_t ldb,
+                  int64_t sb, double* C, int64_t ldc, int64_t sc, int64_t batch) {
+    if (m > 0x7fffffff || n > 0x7fffffff || k > 0x7fffffff || batch > 0x7fffffff)
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "wide route: a matrix dimension beyond 2^31");
+    if (m == 0 || n == 0 || batch == 0) return GPSIG_OK;
+    std::string err;
+    if (!solver_dgemm_batched(&c->blas_handle, c->stream, ta, tb, int(m), int(n), int(k), 1.0, A, int(lda), sa, B, int(ldb), sb, 0.0, C, int(ldc), sc, int(batch), &err))
+        return fail(c, GPSIG_ERR_HIP, "%s", err.c_str());
+    return GPSIG_OK;
+}
+
+int aug_rows(gpsig_ctx* c, const double* src, int64_t rows, int d, int right, double* dst) {
+    if (rows == 0) return GPSIG_OK;
+    ScaleParams none;
+    memset(&none, 0, sizeof(none));
+    none.d_in = d;
+    hipLaunchKernelGGL(wide_aug_rows_kernel, dim3(unsigned(rows < 65535 ? rows : 65535)), dim3(64), 0, c->stream, src, rows, d, right, 0, int64_t(0), int64_t(0), 1,
+                       none, dst);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+
+typedef void (*WideLatKernel)(const WideLatArgs);
+template <int LQ>
+WideLatKernel lat_kernel(int C, bool bwd) {
+    switch (C) {
+        case 1: return bwd ? wide_lattice_bwd_kernel<1, LQ> : wide_lattice_fwd_kernel<1, LQ>;
+        case 2: return bwd ? wide_lattice_bwd_kernel<2, LQ> : wide_lattice_fwd_kernel<2, LQ>;
+        case 4: return bwd ? wide_lattice_bwd_kernel<4, LQ> : wide_lattice_fwd_kernel<4, LQ>;
+        default: return bwd ? wide_lattice_bwd_kernel<8, LQ> : wide_lattice_fwd_kernel<8, LQ>;
+    }
+}
+int lat_columns(int R2) { return R2 <= 64 ? 1 : (R2 <= 128 ? 2 : (R2 <= 256 ? 4 : 8)); }
 
 // the augmented rows of both sides: ZA (lt * E * Tpad, DA) left form, XA (N * L, DA) right form
 int wide_tvs_rows(gpsig_ctx* c, const ScaleParams& sz, const double* Z, const double* Xs, int lt, int E, int64_t Tn, int64_t Tpad, int64_t NL, int d,
@@ -176,6 +213,159 @@ int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     if (fac) {
         hipLaunchKernelGGL(wide_gfac_reduce_kernel, dim3(grid_for(N * (M + 1))), dim3(256), 0, c->stream, static_cast<const double*>(gfp), int(TB),
                            N * int64_t(M + 1), gfac);
+        HIPCHK(c, hipGetLastError());
+    }
+    return GPSIG_OK;
+}
+
+
+// ---- sequence lattices ----------------------------------------------------------------------------------------------------------------------
+constexpr int WIDE_LAT_MAX_COLS = 512;            // 64 lanes x 8 columns
+
+bool wide_lat_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L2) {
+    if (c->wide == 0 || c->capturing) return false;
+    if (!wide_kind(p->base_kernel) || (p->order > 1 && p->num_levels > 1) || p->num_levels > WIDE_MAX_LEVELS || p->num_levels < 1) return false;
+    const int dr = p->difference ? 1 : 0;
+    return L1 >= 1 && L2 >= 1 && L2 - dr <= WIDE_LAT_MAX_COLS;
+}
+
+namespace {
+
+struct LatPlan {
+    int DA, dr, R1, R2, C;
+    int64_t P, Ptot, chunk_i, ld, si, sj, N2;      // chunk_i: left sequences per chunk (diag: sequences per chunk)
+    double *XL, *XR;
+};
+
+// augmented rows (left form of the left sequences, right form of the right ones) and the chunking of the argument lattices
+int lat_plan(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag, int bufs,
+             LatPlan* pl) {
+    pl->DA = d + 2; pl->dr = p->difference ? 1 : 0; pl->R1 = L1 - pl->dr; pl->R2 = L2 - pl->dr; pl->C = lat_columns(pl->R2);
+    void *xl, *xr;
+    CHK(ensure(c, B_WD0, sizeof(double) * size_t(N1) * L1 * pl->DA + 64, &xl));
+    CHK(ensure(c, B_WD1, sizeof(double) * size_t(N2) * L2 * pl->DA + 64, &xr));
+    CHK(aug_rows(c, Xs, N1 * int64_t(L1), d, 0, static_cast<double*>(xl)));
+    CHK(aug_rows(c, Ys ? Ys : Xs, N2 * int64_t(L2), d, 1, static_cast<double*>(xr)));
+    pl->XL = static_cast<double*>(xl); pl->XR = static_cast<double*>(xr);
+    const size_t per_i = sizeof(double) * size_t(L1) * L2 * size_t(diag ? 1 : N2) * size_t(bufs);
+    int64_t chunk = int64_t(wide_chunk_bytes(c) / (per_i ? per_i : 1));
+    if (chunk < 1) chunk = 1;
+    if (chunk > N1) chunk = N1;
+    pl->chunk_i = chunk;
+    pl->Ptot = diag ? N1 : N1 * N2;
+    if (diag) { pl->ld = L2; pl->si = int64_t(L1) * L2; pl->sj = 0; pl->N2 = 1; }
+    else { pl->ld = N2 * int64_t(L2); pl->si = int64_t(L1) * pl->ld; pl->sj = L2; pl->N2 = N2; }
+    return GPSIG_OK;
+}
+
+// the argument lattices of the left sequences i0 .. i0 + ni - 1 into `arg`
+int lat_arguments(gpsig_ctx* c, const LatPlan& pl, int64_t i0, int64_t ni, int64_t N2, int L1, int L2, bool diag, double* arg) {
+    const int DA = pl.DA;
+    if (diag)      // per sequence: row-major arg (L1, L2) = XL_n XR_n^T  ==  column-major (L2 x L1) = XR_n,cm^T (L2 x DA) XL_n,cm (DA x L1)
+        return dgemm_batched(c, true, false, L2, L1, DA, pl.XR + i0 * L2 * DA, DA, int64_t(L2) * DA, pl.XL + i0 * L1 * DA, DA, int64_t(L1) * DA, arg, L2,
+                             int64_t(L1) * L2, ni);
+    // row-major arg (ni L1, N2 L2) = XL_chunk XR^T  ==  column-major (N2 L2 x ni L1) = XR_cm^T XL_chunk,cm
+    return dgemm(c, true, false, N2 * L2, ni * L1, DA, pl.XR, DA, pl.XL + i0 * L1 * DA, DA, 0.0, arg, N2 * L2);
+}
+
+}  // namespace
+
+// Raw levels (M+1, P) of the lattices of pairs (i, j) -- P = N1 N2, pair index i N2 + j -- or (i, i) -- diag, P = N1.  Xs, Ys: scaled sequences
+// (Ys == NULL: Xs on both sides).  signature_algs.py:8-35 on kernels.py:188-237's tensors.
+int wide_lat_forward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag,
+                     double* out) {
+    LatPlan pl;
+    CHK(lat_plan(c, p, d, Xs, Ys, N1, N2, L1, L2, diag, 1, &pl));
+    const int M = p->num_levels;
+    void* arg;
+    CHK(ensure(c, B_WD2, sizeof(double) * size_t(pl.chunk_i) * L1 * L2 * size_t(diag ? 1 : N2) + 64, &arg));
+    WideLatKernel fn = M <= 4 ? lat_kernel<3>(pl.C, false) : lat_kernel<7>(pl.C, false);
+    hipEvent_t e0, e1;
+    bool timed;
+    CHK(wide_timing_begin(c, &e0, &e1, &timed));
+    for (int64_t i0 = 0; i0 < N1; i0 += pl.chunk_i) {
+        const int64_t ni = N1 - i0 < pl.chunk_i ? N1 - i0 : pl.chunk_i;
+        CHK(lat_arguments(c, pl, i0, ni, N2, L1, L2, diag, static_cast<double*>(arg)));
+        WideLatArgs A;
+        memset(&A, 0, sizeof(A));
+        A.arg = static_cast<const double*>(arg); A.ld = pl.ld; A.si = pl.si; A.sj = pl.sj; A.N2 = pl.N2;
+        A.P = diag ? ni : ni * N2; A.p0 = 0; A.Ptot = pl.Ptot;
+        A.L1 = L1; A.L2 = L2; A.M = M; A.kind = p->base_kernel; A.difference = pl.dr;
+        A.out = out + (diag ? i0 : i0 * N2);              // (the kernel's pair index starts at 0 in this chunk's lattices)
+        hipLaunchKernelGGL(fn, dim3(unsigned(A.P < 65535 ? A.P : 65535)), dim3(64), 0, c->stream, A);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (timed) {
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        c->t_launches += 1;
+        c->t_pairs += pl.Ptot;
+        c->t_kernel = "wide_lattice (dgemm + wide_lattice_fwd_kernel)";
+    }
+    return GPSIG_OK;
+}
+
+// Gradients of sum_m G[m][pair] level_m[pair] with respect to the scaled sequences.  G: (M+1, P).  Ys == NULL: Xs on both sides and both sides'
+// gradients land in gX (the symmetric Gram as the cross Gram of X with itself; the diagonal); else gX, gY.
+int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag,
+                      const double* G, double* gX, double* gY) {
+    LatPlan pl;
+    CHK(lat_plan(c, p, d, Xs, Ys, N1, N2, L1, L2, diag, 2, &pl));
+    const int M = p->num_levels, DA = pl.DA;
+    const int64_t per_i = int64_t(L1) * L2 * (diag ? 1 : N2);
+    void *arg, *lam, *gxl, *gxr, *scr;
+    CHK(ensure(c, B_WD2, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &arg));
+    CHK(ensure(c, B_WD3, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &lam));
+    CHK(ensure(c, B_WD4, sizeof(double) * size_t(N1) * L1 * DA + 64, &gxl));
+    CHK(ensure(c, B_WD5, sizeof(double) * size_t(N2) * L2 * DA + 64, &gxr));
+    const int TF = pl.R1 + 63;
+    const size_t per_group = sizeof(double) * size_t(M > 1 ? M - 1 : 1) * TF * 64 * pl.C;
+    const int64_t Pmax = diag ? pl.chunk_i : pl.chunk_i * N2;
+    int64_t groups = int64_t(wide_chunk_bytes(c) / per_group);
+    if (groups < 1) groups = 1;
+    if (groups > Pmax) groups = Pmax;
+    if (groups > 4096) groups = 4096;
+    CHK(ensure(c, B_WD7, per_group * size_t(groups) + 64, &scr));
+    WideLatKernel fn = M <= 4 ? lat_kernel<3>(pl.C, true) : lat_kernel<7>(pl.C, true);
+    for (int64_t i0 = 0; i0 < N1; i0 += pl.chunk_i) {
+        const int64_t ni = N1 - i0 < pl.chunk_i ? N1 - i0 : pl.chunk_i;
+        CHK(lat_arguments(c, pl, i0, ni, N2, L1, L2, diag, static_cast<double*>(arg)));
+        WideLatArgs A;
+        memset(&A, 0, sizeof(A));
+        A.arg = static_cast<const double*>(arg); A.ld = pl.ld; A.si = pl.si; A.sj = pl.sj; A.N2 = pl.N2;
+        A.P = diag ? ni : ni * N2; A.p0 = 0; A.Ptot = pl.Ptot;
+        A.L1 = L1; A.L2 = L2; A.M = M; A.kind = p->base_kernel; A.difference = pl.dr;
+        A.G = G + (diag ? i0 : i0 * N2);
+        A.scratch = static_cast<double*>(scr); A.lam = static_cast<double*>(lam);
+        const int64_t ng = A.P < groups ? A.P : groups;
+        A.ngroups = int(ng);
+        if (pl.R1 > 0 && pl.R2 > 0) {
+            hipLaunchKernelGGL(fn, dim3(unsigned(ng)), dim3(64), 0, c->stream, A);
+            HIPCHK(c, hipGetLastError());
+        }
+        // the adjoint of the arguments, in place of the arguments
+        hipLaunchKernelGGL(wide_lattice_adjoint_kernel, dim3(grid_for(A.P * int64_t(L1) * L2)), dim3(256), 0, c->stream, A, static_cast<double*>(arg));
+        HIPCHK(c, hipGetLastError());
+        const double* W = static_cast<const double*>(arg);
+        double* gl = static_cast<double*>(gxl) + i0 * L1 * DA;
+        if (diag) {
+            // gXL_n (L1, DA) = W_n XR_n: column-major (DA x L1) = XR_n,cm (DA x L2) W_n,cm (L2 x L1);  gXR_n (L2, DA) = W_n^T XL_n: (DA x L2) = XL_n,cm (DA x L1) W_n,cm^T
+            CHK(dgemm_batched(c, false, false, DA, L1, L2, pl.XR + i0 * L2 * DA, DA, int64_t(L2) * DA, W, L2, int64_t(L1) * L2, gl, DA, int64_t(L1) * DA, ni));
+            CHK(dgemm_batched(c, false, true, DA, L2, L1, pl.XL + i0 * L1 * DA, DA, int64_t(L1) * DA, W, L2, int64_t(L1) * L2,
+                              static_cast<double*>(gxr) + i0 * L2 * DA, DA, int64_t(L2) * DA, ni));
+        } else {
+            CHK(dgemm(c, false, false, DA, ni * L1, N2 * L2, pl.XR, DA, W, N2 * L2, 0.0, gl, DA));
+            CHK(dgemm(c, false, true, DA, N2 * L2, ni * L1, pl.XL + i0 * L1 * DA, DA, W, N2 * L2, i0 > 0 ? 1.0 : 0.0, static_cast<double*>(gxr), DA));
+        }
+    }
+    // through the augmentation: left form into gX; right form into gX as well (one array on both sides) or into gY
+    const int64_t xr_rows = N1 * int64_t(L1), yr_rows = N2 * int64_t(L2);
+    const bool same = Ys == nullptr;
+    hipLaunchKernelGGL(wide_unaug_pair_kernel, dim3(grid_for(xr_rows * d)), dim3(256), 0, c->stream, static_cast<const double*>(gxl), pl.XL,
+                       same ? static_cast<const double*>(gxr) : nullptr, same ? pl.XR : nullptr, xr_rows, d, gX);
+    HIPCHK(c, hipGetLastError());
+    if (!same) {
+        hipLaunchKernelGGL(wide_unaug_rows_kernel, dim3(grid_for(yr_rows * d)), dim3(256), 0, c->stream, static_cast<const double*>(gxr), pl.XR, yr_rows, d, 1, 0,
+                           int64_t(1), int64_t(0), 1, gY);
         HIPCHK(c, hipGetLastError());
     }
     return GPSIG_OK;

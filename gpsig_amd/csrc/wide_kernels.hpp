@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "seq_core.hpp"
+#include "grad_wave_core.hpp"
 
 namespace gpsig {
 
@@ -351,6 +352,249 @@ __global__ void wide_unaug_rows_kernel(const double* __restrict__ ga, const doub
             r = (int64_t(k) * E + e) * Tpad + t;
         }
         g[idx] = fma(-ga[r * DA + nc], va[r * DA + f], ga[r * DA + f]);
+    }
+}
+
+
+// =====================================================================================================================================
+// Sequence lattices from kernel-argument lattices in memory (the level diagonals of kernels.py:188-205, the sequence Grams of :208-237
+// beyond the exact-shape kernels' columns): the sweeps of grad_wave_core.hpp -- one wavefront per lattice, lane lam owns C consecutive columns
+// and works on row t - lam at step t, row prefixes handed to the right neighbour by one DPP shift -- fed by loads of the argument rows instead
+// of point rows.  arg lattice of pair p = (i, j): base (p / N2) * si + (p % N2) * sj, row stride ld (a batched product: N2 = 1, si = L1 * L2, ld = L2;
+// one product of all points: si = L1 * ld, sj = L2, ld = N2 * L2).
+struct WideLatArgs {
+    const double* arg;
+    int64_t ld, si, sj, N2;
+    int64_t P, p0, Ptot;        // this launch: lattices p0 .. p0 + P - 1 of Ptot (the level arrays' pair axis)
+    int32_t L1, L2, M, kind, difference;
+    double* out;                // forward: (M+1, Ptot) level values
+    const double* G;            // reverse: (M+1, Ptot) upstream gradient
+    double* scratch;            // reverse: per group (M-1) * TF * 64 * C doubles (forward Q's, as grad_wave_kernel.hpp)
+    double* lam;                // reverse: Lam = dL/ddM, (P, R1, R2) row-major
+    int32_t ngroups;
+};
+
+template <int C>
+struct WideLatDm {
+    double rd[C];
+    int nvalid, b0, L2, kind, diff;
+    int64_t ld;
+    const double* lat;
+
+    __device__ __forceinline__ void load(int r, bool ok, double (&raw)[C + 1]) const {
+        const double* p = lat + int64_t(r) * ld + b0;
+#pragma unroll
+        for (int c = 0; c <= C; ++c) raw[c] = (ok && b0 + c < L2 && (c < C || diff)) ? p[c] : 0.0;
+    }
+    // kappa differences along the row (diff) or kappa itself (no differences: signature_algs.py:18-19 with difference=False)
+    __device__ __forceinline__ void map(const double (&raw)[C + 1], double (&out)[C]) const {
+        double k[C + 1];
+#pragma unroll
+        for (int c = 0; c <= C; ++c) k[c] = (c < C || diff) ? wide_kappa(kind, raw[c]) : 0.0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[c] = diff ? k[c + 1] - k[c] : k[c];
+    }
+    __device__ __forceinline__ void prime(const double (&raw)[C + 1]) { map(raw, rd); }
+    // one lattice row from the raw arguments of its new point row (forward: a + 1, backward: a; no differences: a)
+    __device__ __forceinline__ void row(const double (&raw)[C + 1], bool forward, double (&dm)[C]) {
+        double nd[C];
+        map(raw, nd);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (diff) { dm[c] = forward ? nd[c] - rd[c] : rd[c] - nd[c]; rd[c] = nd[c]; }
+            else dm[c] = nd[c];
+            if (c >= nvalid) dm[c] = 0.0;
+        }
+    }
+};
+
+__device__ __forceinline__ double wide_from_left(double v) {       // lane l <- lane l-1, 0 into lane 0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);     // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wide_from_right(double v) {      // lane l <- lane l+1, 0 into lane 63
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);     // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Level values of P lattices: one wavefront per lattice (grid-stride).  K_m (m < M) = Q_m at the last cell, K_M = the sum of the row totals of R_M:
+// both arrive at lane 63 (columns beyond the lattice pass the row prefixes on unchanged).
+template <int C, int LQ>
+__global__ void __launch_bounds__(64) wide_lattice_fwd_kernel(const WideLatArgs A) {
+    const int lam = threadIdx.x, M = A.M;
+    const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr, TF = R1 + 63;
+    for (int64_t pp = blockIdx.x; pp < A.P; pp += gridDim.x) {
+        const int64_t pg = A.p0 + pp;
+        WideLatDm<C> dmg;
+        dmg.lat = A.arg + (pg / A.N2) * A.si + (pg % A.N2) * A.sj;
+        dmg.ld = A.ld; dmg.b0 = C * lam; dmg.L2 = A.L2; dmg.kind = A.kind; dmg.diff = dr;
+        { const int nv = R2 - C * lam; dmg.nvalid = nv < 0 ? 0 : (nv > C ? C : nv); }
+        WaveFwd<C, LQ> fw;
+        fw.reset();
+        double raw[C + 1];
+        if (dr) { dmg.load(0, true, raw); dmg.prime(raw); }
+        { const int r = 0 - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw); }
+        double kM = 0.0;
+        for (int t = 0; t < TF; ++t) {
+            double cin[LQ + 2], rnext[C + 1];
+            cin[0] = 0.0;
+#pragma unroll
+            for (int m = 1; m < LQ + 2; ++m) cin[m] = wide_from_left(fw.sout[m]);
+            const int a = t - lam;
+            { const int r = a + 1 + dr; dmg.load(r, r >= 0 && r < A.L1, rnext); }
+            if (a >= 0 && a < R1) {
+                double dm[C];
+                dmg.row(raw, true, dm);
+                fw.step(dm, cin, M);
+#pragma unroll
+                for (int m = 1; m <= LQ + 1; ++m)
+                    if (m == M) kM += fw.sout[m];
+            }
+#pragma unroll
+            for (int c = 0; c <= C; ++c) raw[c] = rnext[c];
+        }
+        if (lam == 63) {
+            A.out[pg] = 1.0;                                                       // signature_algs.py:20
+#pragma unroll
+            for (int m = 1; m <= LQ; ++m)
+                if (m < M) A.out[int64_t(m) * A.Ptot + pg] = fw.q[m - 1][C - 1];
+            A.out[int64_t(M) * A.Ptot + pg] = kM;
+        }
+    }
+}
+
+// Both sweeps (grad_wave_kernel.hpp: seq_grad_wave_kernel with the argument lattice in place of the point rows): Lam[a][b] = dL/ddM[a][b] out.
+// grid: ngroups workgroups of one wavefront; a group's pairs one after the other through its scratch slot.
+template <int C, int LQ>
+__global__ void __launch_bounds__(64) wide_lattice_bwd_kernel(const WideLatArgs A) {
+    const int lam = threadIdx.x, M = A.M;
+    const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr, TF = R1 + 63;
+    double* scr = A.scratch + size_t(blockIdx.x) * size_t(M - 1) * TF * 64 * C;
+    auto slot = [&](int m, int tf, int l, int c) -> double& { return scr[((size_t(m) * TF + tf) * 64 + l) * C + c]; };
+    for (int64_t pp = blockIdx.x; pp < A.P; pp += gridDim.x) {
+        const int64_t pg = A.p0 + pp;
+        WideLatDm<C> dmg;
+        dmg.lat = A.arg + (pg / A.N2) * A.si + (pg % A.N2) * A.sj;
+        dmg.ld = A.ld; dmg.b0 = C * lam; dmg.L2 = A.L2; dmg.kind = A.kind; dmg.diff = dr;
+        { const int nv = R2 - C * lam; dmg.nvalid = nv < 0 ? 0 : (nv > C ? C : nv); }
+        double clev[LQ + 2];
+#pragma unroll
+        for (int p = 0; p < LQ + 2; ++p) clev[p] = (p >= 1 && p <= M) ? A.G[int64_t(p) * A.Ptot + pg] : 0.0;
+        // ---- forward sweep, Q's of levels < M to the scratch slot
+        {
+            WaveFwd<C, LQ> fw;
+            fw.reset();
+            double raw[C + 1];
+            if (dr) { dmg.load(0, true, raw); dmg.prime(raw); }
+            { const int r = 0 - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw); }
+            for (int t = 0; t < TF; ++t) {
+                double cin[LQ + 2], rnext[C + 1];
+                cin[0] = 0.0;
+#pragma unroll
+                for (int m = 1; m < LQ + 2; ++m) cin[m] = wide_from_left(fw.sout[m]);
+                const int a = t - lam;
+                { const int r = a + 1 + dr; dmg.load(r, r >= 0 && r < A.L1, rnext); }
+                if (a >= 0 && a < R1) {
+                    double dm[C];
+                    dmg.row(raw, true, dm);
+                    fw.step(dm, cin, M);
+#pragma unroll
+                    for (int m = 0; m < LQ; ++m)
+                        if (m < M - 1) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) slot(m, t, lam, c) = fw.q[m][c];
+                        }
+                }
+#pragma unroll
+                for (int c = 0; c <= C; ++c) raw[c] = rnext[c];
+            }
+        }
+        __threadfence();        // the backward sweep reads what other lanes of this wavefront stored
+        // ---- backward sweep
+        {
+            WaveBwd<C, LQ> bw;
+            bw.reset();
+            double raw[C + 1];
+            if (dr) { dmg.load(R1, true, raw); dmg.prime(raw); }
+            double* lamrow = A.lam + size_t(pp) * R1 * R2;
+            double qcur[LQ][C];
+            { const int r = R1 - 1 + (63 - lam); dmg.load(r, r >= 0 && r < A.L1, raw); }      // the row of step 0 (beyond the sequence: zeros, not used)
+            auto fetch_q = [&](int a, double (&q)[LQ][C]) {
+                const int tf = a - 1 + lam;
+#pragma unroll
+                for (int m = 0; m < LQ; ++m)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        double v = 0.0;
+                        if (m < M - 1 && a > 0 && a < R1) {
+                            if (c > 0) v = slot(m, tf, lam, c - 1);
+                            else if (lam > 0) v = slot(m, tf - 1, lam - 1, C - 1);
+                        }
+                        q[m][c] = v;
+                    }
+            };
+            fetch_q(R1 - 1 + (63 - lam), qcur);
+            for (int u = 0; u < TF; ++u) {
+                double sin[LQ], rnext[C + 1], qnext[LQ][C];
+#pragma unroll
+                for (int p = 0; p < LQ; ++p) sin[p] = wide_from_right(bw.svout[p]);
+                const int a = R1 - 1 - (u - (63 - lam));
+                { const int r = a - 1; dmg.load(r, r >= 0 && r < R1, rnext); }
+                fetch_q(a - 1, qnext);
+                if (a >= 0 && a < R1) {
+                    double dm[C], lv[C];
+                    dmg.row(raw, false, dm);
+                    bw.step(dm, clev, qcur, sin, M, lv);
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (c < dmg.nvalid) lamrow[size_t(a) * R2 + C * lam + c] = lv[c];
+                }
+#pragma unroll
+                for (int c = 0; c <= C; ++c) raw[c] = rnext[c];
+#pragma unroll
+                for (int m = 0; m < LQ; ++m)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) qcur[m][c] = qnext[m][c];
+            }
+        }
+        __threadfence();        // the slot is rewritten by the next pair
+    }
+}
+
+// W[r][c] = adjoint of the argument at point pair (r, c): the adjoint of the double increment (signature_algs.py:26)
+//   Gam[r][c] = Lam[r-1][c-1] - Lam[r-1][c] - Lam[r][c-1] + Lam[r][c]   (zero outside the lattice; no differences: Gam = Lam)
+// times d kappa / d a.  One thread per point pair; W in the layout of arg.
+__global__ void wide_lattice_adjoint_kernel(const WideLatArgs A, double* __restrict__ W) {
+    const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr;
+    const int64_t cells = int64_t(A.L1) * A.L2, total = A.P * cells;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t pp = idx / cells, pg = A.p0 + pp;
+        const int r = int((idx % cells) / A.L2), c = int(idx % A.L2);
+        const double* lm = A.lam + pp * int64_t(R1) * R2;
+        auto at = [&](int a, int b) -> double { return (a >= 0 && a < R1 && b >= 0 && b < R2) ? lm[int64_t(a) * R2 + b] : 0.0; };
+        const double gam = dr ? at(r - 1, c - 1) - at(r - 1, c) - at(r, c - 1) + at(r, c) : at(r, c);
+        const int64_t off = (pg / A.N2) * A.si + (pg % A.N2) * A.sj + int64_t(r) * A.ld + c;
+        double k, dk;
+        wide_kappa_grad(A.kind, A.arg[off], k, dk);
+        W[off] = gam * dk;
+    }
+}
+
+// g[r][f] = left-form chain rule of (gl, vl) [+ right-form chain rule of (gr, vr) where given: one array on both sides of the lattices]
+__global__ void wide_unaug_pair_kernel(const double* __restrict__ gl, const double* __restrict__ vl, const double* __restrict__ gr, const double* __restrict__ vr,
+                                       int64_t rows, int d, double* __restrict__ g) {
+    const int DA = d + 2;
+    const int64_t total = rows * d;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int f = int(idx % d);
+        const int64_t r = idx / d;
+        double v = fma(-gl[r * DA + d], vl[r * DA + f], gl[r * DA + f]);
+        if (gr) v += fma(-gr[r * DA + d + 1], vr[r * DA + f], gr[r * DA + f]);
+        g[idx] = v;
     }
 }
 
