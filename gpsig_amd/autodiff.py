@@ -73,7 +73,7 @@ class _Spec:
 # kernels, csrc/wide_api.hip): None = where the exact-shape kernels are not built (the library's default), True = wherever built, False = never.
 _WIDE = {"value": -1}
 WIDE_BASES = ("rbf", "matern12", "matern32", "matern52")
-WIDE_PRIMITIVES = {"tvs", "diag", "seq"}           # the level primitives the library has a wide route for
+WIDE_PRIMITIVES = {"tvs", "diag", "seq", "tens"}           # the level primitives the library has a wide route for
 WIDE_LAT_MAX_COLS = 512                            # ... the sequence lattices up to this many columns (csrc/wide_api.hip)
 
 

@@ -134,6 +134,9 @@ bool tvs_lanet_plan(int M, int d, bool incr, TvsLaneTLaunchFn* fns, int* ngroups
 bool wide_tvs_available(const gpsig_ctx* c, const gpsig_params* p, int d, int64_t Tn, int64_t N, int L);
 int wide_tvs_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz, int d, const double* Z, const double* Xs, int64_t Tn, int64_t N, int L,
                      int increments, const double* fx, const double* w, int sum_levels, double* out, double* aux);
+bool wide_tens_available(const gpsig_ctx* c, const gpsig_params* p, int64_t Tn);
+int wide_tens_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz, int d, const double* Z, int64_t Tn, int increments, const double* w,
+                      int sum_levels, double* out);
 bool wide_lat_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L2);
 int wide_lat_forward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag,
                      double* out);
@@ -1422,6 +1425,15 @@ static int prep_tensors(gpsig_ctx* c, const gpsig_params* p, bool apply_scaling,
 static int tens_gram_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const void* Z, int64_t Tn, int increments,
                      int return_levels, void* out) {
     const int E = increments ? 2 : 1;
+    if (sizeof(TT) == 8 && Tn > 0) {        // wide state spaces (wide_api.hip): beyond 12 columns, or wherever built when the option says so
+        ScaleParams s;
+        CHK(scale_params(c, p, !raw, &s));
+        if (wide_tens_available(c, p, Tn) && (c->wide == 1 || s.d_eff() > 12)) {
+            const double* w = nullptr;
+            if (!raw) CHK(upload_weights(c, p, &w));
+            return wide_tens_forward(c, p, s, s.d_eff(), static_cast<const double*>(Z), Tn, increments, w, (raw || return_levels) ? 0 : 1, static_cast<double*>(out));
+        }
+    }
     const void *ZT, *ZS;
     CHK(prep_tensors(c, p, !raw, Z, Tn, E, &ZT, &ZS));
     TensGramArgs A;
@@ -1762,7 +1774,8 @@ static int e_seq_diag_levels(gpsig_ctx* c, const gpsig_params* p, const void* X,
 static int e_tens_gram_levels(gpsig_ctx* c, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, void* out) {
     ENTER(c, p);
     const int d = p->num_features * (p->num_lags + 1), lt = p->num_levels * (p->num_levels + 1) / 2, E = increments ? 2 : 1;
-    if (d > MAX_FEATURES) return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
+    if (d > MAX_FEATURES && !(sizeof(TT) == 8 && d <= MAX_FEATURES_WIDE && wide_tens_available(c, p, T)))
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "d=%d too large", d);
     const void* dZ;
     CHK(in_dev(c, B_IN0, Z, sizeof(TT) * size_t(lt) * T * E * d, &dZ));
     const size_t ob = sizeof(TT) * size_t(T) * T * (p->num_levels + 1);

@@ -47,6 +47,8 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
 bool wide_tvs_available(const gpsig_ctx* c, const gpsig_params* p, int d, int64_t Tn, int64_t N, int L);
 int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, const double* X, const double* G, int64_t Tn, int64_t N, int L,
                       int increments, const double* fac, const double* aux, double* gZ, double* gX, double* gfac);
+bool wide_tens_available(const gpsig_ctx* c, const gpsig_params* p, int64_t Tn);
+int wide_tens_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, int64_t Tn, int increments, const double* G, double* gZ);
 bool wide_lat_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L2);
 int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag,
                       const double* G, double* gX, double* gY);
@@ -883,8 +885,10 @@ int gpsig_seq_diag_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* 
 int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void* Z, int64_t T, int32_t increments, const void* G, void* gZ,
                                 double* g_base) {
     int d, DP;
-    CHK(grad_check(c, p, &d, &DP));
+    CHK(grad_check(c, p, &d, &DP, 4096));
     if (T < 0 || T > 65535) return fail(c, GPSIG_ERR_INVALID, "bad number of tensors");
+    const bool wide = T > 0 && wide_tens_available(c, p, T) && (c->wide == 1 || d > 12);      // wide_api.hip
+    if (DP == 0 && !wide) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns here (got %d)", d);
     const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
     const int64_t rows = int64_t(lt) * T * E;
     const size_t zb = sizeof(double) * size_t(rows) * d, gb = sizeof(double) * size_t(M + 1) * T * T;
@@ -897,7 +901,9 @@ int gpsig_tens_gram_levels_grad(gpsig_ctx* c, const gpsig_params* p, const void*
     CHK(gbase_begin(c, &dgb));
     // kernels without a differentiable base parameter skip the accumulation (one same-address atomic per wavefront otherwise)
     double* const kgb = (p->base_kernel == GPSIG_BASE_POLY || p->base_kernel == GPSIG_BASE_MIX) ? dgb : nullptr;
-    if (T > 0) {
+    if (wide) {
+        CHK(wide_tens_backward(c, p, d, static_cast<const double*>(dZ), T, increments, static_cast<const double*>(dG), static_cast<double*>(dgZ)));
+    } else if (T > 0) {
         void *zp, *gzp;
         CHK(ensure(c, B_GR0, sizeof(double) * size_t(rows) * DP, &zp));
         CHK(ensure(c, B_GR1, sizeof(double) * size_t(rows) * DP, &gzp));

@@ -137,6 +137,11 @@ int wide_tvs_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz,
     if (chunk > N) chunk = N;
     void* arg;
     CHK(ensure(c, B_WD2, per_seq * size_t(chunk) + 64, &arg));
+    if (!aux) {          // the chain totals the epilogue reads: the caller's array (kept for the reverse pass) or scratch
+        void* ax;
+        CHK(ensure(c, B_WD8, sizeof(double) * size_t(N) * lt * Tpad + 64, &ax));
+        aux = static_cast<double*>(ax);
+    }
     hipEvent_t e0, e1;
     bool timed;
     CHK(wide_timing_begin(c, &e0, &e1, &timed));
@@ -149,9 +154,11 @@ int wide_tvs_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz,
         A.arg = static_cast<const double*>(arg); A.CW = CW; A.Tpad = Tpad; A.Tn = Tn; A.n0 = n0; A.Nc = nc; A.N = N;
         A.L = L; A.M = M; A.kind = p->base_kernel; A.difference = p->difference ? 1 : 0; A.sum_levels = sum_levels;
         A.fx = fx; A.w = w; A.out = out; A.aux = aux;
-        const dim3 grid(unsigned(TB), unsigned(nc < 65535 ? nc : 65535));
+        const dim3 grid(unsigned(TB), unsigned(nc < 65535 ? nc : 65535), unsigned(M));
         if (E == 2) hipLaunchKernelGGL(wide_tvs_fwd_kernel<2>, grid, dim3(64), 0, c->stream, A);
         else hipLaunchKernelGGL(wide_tvs_fwd_kernel<1>, grid, dim3(64), 0, c->stream, A);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(wide_tvs_epilogue_kernel, dim3(grid_for(nc * Tn)), dim3(256), 0, c->stream, A);
         HIPCHK(c, hipGetLastError());
     }
     if (timed) {
@@ -194,7 +201,7 @@ int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         A.L = L; A.M = M; A.kind = p->base_kernel; A.difference = p->difference ? 1 : 0;
         A.fx = fac; A.w = nullptr; A.aux = const_cast<double*>(aux);
         A.G = G; A.W = static_cast<double*>(Wb); A.gfac_part = static_cast<double*>(gfp); A.weighted = fac ? 1 : 0;
-        const dim3 grid(unsigned(TB), unsigned(nc < 65535 ? nc : 65535));
+        const dim3 grid(unsigned(TB), unsigned(nc < 65535 ? nc : 65535), unsigned(M));
         if (E == 2) hipLaunchKernelGGL(wide_tvs_bwd_kernel<2>, grid, dim3(64), 0, c->stream, A);
         else hipLaunchKernelGGL(wide_tvs_bwd_kernel<1>, grid, dim3(64), 0, c->stream, A);
         HIPCHK(c, hipGetLastError());
@@ -368,6 +375,80 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
                            int64_t(1), int64_t(0), 1, gY);
         HIPCHK(c, hipGetLastError());
     }
+    return GPSIG_OK;
+}
+
+// ---- inducing tensors vs inducing tensors ----------------------------------------------------------------------------------------------------
+bool wide_tens_available(const gpsig_ctx* c, const gpsig_params* p, int64_t Tn) {
+    if (c->wide == 0 || c->capturing) return false;
+    if (!wide_kind(p->base_kernel) || p->num_levels > WIDE_MAX_LEVELS || p->num_levels < 1) return false;
+    const int64_t Tpad = (Tn + 63) / 64 * 64;
+    // the argument blocks of every component at once (10 components x 1,024^2 x 8 bytes = 84 MB at 500 tensors with increments)
+    return Tn >= 1 && size_t(p->num_levels * (p->num_levels + 1) / 2) * size_t(4 * Tpad * Tpad) * sizeof(double) <= (size_t(2) << 30);
+}
+
+namespace {
+// left- and right-form augmented rows of the tensors (B_WD0, B_WD6) and the argument blocks (B_WD2)
+int tens_arguments(gpsig_ctx* c, const ScaleParams& sz, int d, const double* Z, int lt, int E, int64_t Tn, int64_t Tpad, double** ZL, double** ZR, double** arg) {
+    const int DA = d + 2;
+    const int64_t zr = int64_t(lt) * E * Tpad, R = int64_t(E) * Tpad;
+    void *zl, *zrr, *ar;
+    CHK(ensure(c, B_WD0, sizeof(double) * size_t(zr) * DA + 64, &zl));
+    CHK(ensure(c, B_WD6, sizeof(double) * size_t(zr) * DA + 64, &zrr));
+    CHK(ensure(c, B_WD2, sizeof(double) * size_t(lt) * R * R + 64, &ar));
+    for (int right = 0; right < 2; ++right) {
+        hipLaunchKernelGGL(wide_aug_rows_kernel, dim3(unsigned(zr < 65535 ? zr : 65535)), dim3(64), 0, c->stream, Z, zr, d, right, lt, Tn, Tpad, E, sz,
+                           static_cast<double*>(right ? zrr : zl));
+        HIPCHK(c, hipGetLastError());
+    }
+    // block k, row-major (R, R) = ZL_k ZR_k^T  ==  column-major (R x R) = ZR_k,cm^T (R x DA) ZL_k,cm (DA x R)
+    CHK(dgemm_batched(c, true, false, R, R, DA, static_cast<const double*>(zrr), DA, R * DA, static_cast<const double*>(zl), DA, R * DA, static_cast<double*>(ar), R,
+                      R * R, lt));
+    *ZL = static_cast<double*>(zl); *ZR = static_cast<double*>(zrr); *arg = static_cast<double*>(ar);
+    return GPSIG_OK;
+}
+}  // namespace
+
+// Kzz: Z the caller's (lt, T, E, d) array (scaled here when sz.has_ls); w (M+1) or NULL; out (T, T) weighted sum or (M+1, T, T)
+int wide_tens_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz, int d, const double* Z, int64_t Tn, int increments, const double* w,
+                      int sum_levels, double* out) {
+    const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1;
+    const int64_t Tpad = (Tn + 63) / 64 * 64;
+    double *ZL, *ZR, *arg;
+    CHK(tens_arguments(c, sz, d, Z, lt, E, Tn, Tpad, &ZL, &ZR, &arg));
+    WideTensArgs A;
+    memset(&A, 0, sizeof(A));
+    A.arg = arg; A.Tpad = Tpad; A.Tn = Tn; A.M = M; A.E = E; A.kind = p->base_kernel; A.sum_levels = sum_levels; A.w = w; A.out = out;
+    hipLaunchKernelGGL(wide_tens_fwd_kernel, dim3(unsigned(Tpad / 64), unsigned(Tn < 65535 ? Tn : 65535)), dim3(64), 0, c->stream, A);
+    HIPCHK(c, hipGetLastError());
+    return GPSIG_OK;
+}
+
+// gradient of sum_m G[m][t][t'] level_m[t][t'] with respect to the scaled tensors Z (lt, T, E, d)
+int wide_tens_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, int64_t Tn, int increments, const double* G, double* gZ) {
+    const int M = p->num_levels, lt = M * (M + 1) / 2, E = increments ? 2 : 1, DA = d + 2;
+    const int64_t Tpad = (Tn + 63) / 64 * 64, R = int64_t(E) * Tpad, zr = int64_t(lt) * R;
+    ScaleParams none;
+    memset(&none, 0, sizeof(none));
+    none.d_in = d;
+    double *ZL, *ZR, *arg;
+    CHK(tens_arguments(c, none, d, Z, lt, E, Tn, Tpad, &ZL, &ZR, &arg));
+    void *Wb, *gzl, *gzr;
+    CHK(ensure(c, B_WD3, sizeof(double) * size_t(lt) * R * R + 64, &Wb));
+    CHK(ensure(c, B_WD4, sizeof(double) * size_t(zr) * DA + 64, &gzl));
+    CHK(ensure(c, B_WD5, sizeof(double) * size_t(zr) * DA + 64, &gzr));
+    WideTensArgs A;
+    memset(&A, 0, sizeof(A));
+    A.arg = arg; A.Tpad = Tpad; A.Tn = Tn; A.M = M; A.E = E; A.kind = p->base_kernel; A.G = G; A.W = static_cast<double*>(Wb);
+    hipLaunchKernelGGL(wide_tens_bwd_kernel, dim3(unsigned(Tpad / 64), unsigned(Tpad < 65535 ? Tpad : 65535)), dim3(64), 0, c->stream, A);
+    HIPCHK(c, hipGetLastError());
+    // gZL_k (R, DA) = W_k ZR_k: column-major (DA x R) = ZR_k,cm (DA x R) W_k,cm (R x R);   gZR_k = W_k^T ZL_k: (DA x R) = ZL_k,cm W_k,cm^T
+    CHK(dgemm_batched(c, false, false, DA, R, R, ZR, DA, R * DA, static_cast<const double*>(Wb), R, R * R, static_cast<double*>(gzl), DA, R * DA, lt));
+    CHK(dgemm_batched(c, false, true, DA, R, R, ZL, DA, R * DA, static_cast<const double*>(Wb), R, R * R, static_cast<double*>(gzr), DA, R * DA, lt));
+    const int64_t rows_out = int64_t(lt) * Tn * E;
+    hipLaunchKernelGGL(wide_unaug_tens_kernel, dim3(grid_for(rows_out * d)), dim3(256), 0, c->stream, static_cast<const double*>(gzl), ZL,
+                       static_cast<const double*>(gzr), ZR, rows_out, d, Tn, Tpad, E, gZ);
+    HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
 }
 

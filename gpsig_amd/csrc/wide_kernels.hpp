@@ -43,9 +43,16 @@ struct WideTvsArgs {
     int32_t weighted;
 };
 
+// Matern-1/2 is not differentiable at coinciding points, and the squared distance of two EQUAL rows out of a dgemm is rounding noise (~1e-16 |x|^2)
+// instead of the exact zero the exact-shape kernels get from coordinate differences: such distances count as zero (the clamp of kernels.py:781 then
+// gives kappa = 1 and passes no gradient, as it does there; the reference's own float64 value at such a pair is 1e-8 from one -- DESIGN section 5).
+constexpr double WIDE_M12_COINCIDE = 1e-13;
+
 __device__ __forceinline__ double wide_kappa(int kind, double a) {
     if (kind == BASE_RBF) return exp(a);
-    const double r = sqrt(fmax(-2.0 * a, 1e-40));                      // kernels.py:779-781
+    double dist = -2.0 * a;
+    if (kind == BASE_MATERN12 && !(dist > WIDE_M12_COINCIDE)) dist = 0.0;
+    const double r = sqrt(fmax(dist, 1e-40));                          // kernels.py:779-781
     if (kind == BASE_MATERN12) return exp(-r);
     if (kind == BASE_MATERN32) { const double c = 1.7320508075688772935; return (1.0 + c * r) * exp(-c * r); }
     const double c = 2.2360679774997896964;
@@ -55,7 +62,8 @@ __device__ __forceinline__ double wide_kappa(int kind, double a) {
 // kappa and d kappa / d a  (a = -dist / 2: d/da = -2 d/ddist; the clamp of kernels.py:781 passes no gradient, as grad_core.hpp: base_eval_grad)
 __device__ __forceinline__ void wide_kappa_grad(int kind, double a, double& k, double& dk) {
     if (kind == BASE_RBF) { k = exp(a); dk = k; return; }
-    const double dist = -2.0 * a;
+    double dist = -2.0 * a;
+    if (kind == BASE_MATERN12 && !(dist > WIDE_M12_COINCIDE)) dist = 0.0;
     const bool clamped = !(dist > 1e-40);
     const double r = sqrt(fmax(dist, 1e-40));
     double dk_dr;
@@ -93,6 +101,7 @@ __device__ __forceinline__ void wide_chain_fwd(const double* __restrict__ col, i
         r += CW;
         steps = L - 1;
     }
+#pragma unroll 4
     for (int s = 0; s < steps; ++s, r += CW) {
         double dk[I];
 #pragma unroll
@@ -124,32 +133,39 @@ __device__ __forceinline__ void wide_level_fwd(int i, const double* col, const W
 #undef GPSIG_WIDE_CASE
 }
 
-// grid: (Tpad / 64, sequences of the chunk (grid-stride)); block: one wavefront, lane = tensor
+// grid: (Tpad / 64, sequences of the chunk (grid-stride), levels); block: one wavefront, lane = tensor.  A launch of few sequences is bound by the
+// serial sweep of one chain: the levels of a (tensor, sequence) pair go to different workgroups (blockIdx.z + 1 = level), each leaving its chain totals
+// in aux (N, lt, Tpad) -- tensors fastest --, and wide_tvs_epilogue_kernel forms the outputs from them.
 template <int E>
 __global__ void __launch_bounds__(64) wide_tvs_fwd_kernel(const WideTvsArgs A) {
     const int64_t t = int64_t(blockIdx.x) * 64 + threadIdx.x;
     const int M = A.M, lt = M * (M + 1) / 2;
+    const int i = blockIdx.z + 1, k0 = i * (i - 1) / 2;
     for (int64_t nl = blockIdx.y; nl < A.Nc; nl += gridDim.y) {
         const int64_t n = A.n0 + nl;
         const double* col = A.arg + nl * int64_t(A.L) * A.CW + t;
+        double u[WIDE_MAX_LEVELS];
+        wide_level_fwd<E>(i, col, A, u);
+        for (int j = 0; j < i; ++j) A.aux[(n * lt + k0 + j) * A.Tpad + t] = u[j];
+    }
+}
+
+// out[t][n] = fac_0 + sum_i fac_i K_i  or  out[i][t][n] = fac_i K_i  (fac = fx[n][i] * w[i]: kernels.py:572-588), K_i = the total of level i's last chain
+// (signature_algs.py:125).  One thread per (t, n) of the chunk, tensors fastest.
+__global__ void wide_tvs_epilogue_kernel(const WideTvsArgs A) {
+    const int M = A.M, lt = M * (M + 1) / 2;
+    const int64_t total = A.Nc * A.Tn;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t t = idx % A.Tn, n = A.n0 + idx / A.Tn;
         double acc = 0.0;
         for (int i = 0; i <= M; ++i) {
             double f = A.fx ? A.fx[n * (M + 1) + i] : 1.0;
             if (A.w) f *= A.w[i];
-            double lev = 1.0;                                                          // signature_algs.py:116
-            if (i >= 1) {
-                double u[WIDE_MAX_LEVELS];
-                wide_level_fwd<E>(i, col, A, u);
-                lev = u[i - 1];                                                        // :125
-                if (A.aux) {
-                    const int k0 = i * (i - 1) / 2;
-                    for (int j = 0; j < i; ++j) A.aux[(n * lt + k0 + j) * A.Tpad + t] = u[j];
-                }
-            }
+            const double lev = i == 0 ? 1.0 : A.aux[(n * lt + i * (i - 1) / 2 + i - 1) * A.Tpad + t];       // signature_algs.py:116 / :125
             if (A.sum_levels) acc = fma(lev, f, acc);
-            else if (t < A.Tn) A.out[(int64_t(i) * A.Tn + t) * A.N + n] = lev * f;
+            else A.out[(int64_t(i) * A.Tn + t) * A.N + n] = lev * f;
         }
-        if (A.sum_levels && t < A.Tn) A.out[t * A.N + n] = acc;
+        if (A.sum_levels) A.out[t * A.N + n] = acc;
     }
 }
 
@@ -246,43 +262,45 @@ __global__ void __launch_bounds__(64) wide_tvs_bwd_kernel(const WideTvsArgs A) {
     const int64_t t = int64_t(blockIdx.x) * 64 + threadIdx.x;
     const bool valid = t < A.Tn;
     const int M = A.M, lt = M * (M + 1) / 2;
+    const int i = blockIdx.z + 1, k0 = i * (i - 1) / 2;          // one level per workgroup (as the forward kernel)
     for (int64_t nl = blockIdx.y; nl < A.Nc; nl += gridDim.y) {
         const int64_t n = A.n0 + nl;
         const double* col = A.arg + nl * int64_t(A.L) * A.CW + t;
         double* wcol = A.W + nl * int64_t(A.L) * A.CW + t;
         const double gsum = (A.weighted && valid) ? A.G[t * A.N + n] : 0.0;
-        if (A.gfac_part) {                                                             // level 0 == 1: dL/dfac[n][0] = sum_t G[t][n]
+        if (A.gfac_part && i == 1) {                                                   // level 0 == 1: dL/dfac[n][0] = sum_t G[t][n]
             const double s = wide_wave_sum(gsum);
             if (threadIdx.x == 0) A.gfac_part[(int64_t(blockIdx.x) * A.N + n) * (M + 1)] = s;
         }
-        for (int i = 1; i <= M; ++i) {
-            const int k0 = i * (i - 1) / 2;
-            double f = A.fx ? A.fx[n * (M + 1) + i] : 1.0;
-            if (A.w) f *= A.w[i];
-            const double c = A.weighted ? gsum * f : (valid ? A.G[(int64_t(i) * A.Tn + t) * A.N + n] * f : 0.0);
-            double u[WIDE_MAX_LEVELS];
-            if (A.aux) {
-                for (int j = 0; j < i; ++j) u[j] = A.aux[(n * lt + k0 + j) * A.Tpad + t];
-            } else {
-                wide_level_fwd<E>(i, col, A, u);
-            }
-            if (A.gfac_part) {
-                const double s = wide_wave_sum(gsum * u[i - 1]);
-                if (threadIdx.x == 0) A.gfac_part[(int64_t(blockIdx.x) * A.N + n) * (M + 1) + i] = s;
-            }
+        double f = A.fx ? A.fx[n * (M + 1) + i] : 1.0;
+        if (A.w) f *= A.w[i];
+        const double c = A.weighted ? gsum * f : (valid ? A.G[(int64_t(i) * A.Tn + t) * A.N + n] * f : 0.0);
+        double u[WIDE_MAX_LEVELS];
+        if (A.aux) {
+            for (int j = 0; j < i; ++j) u[j] = A.aux[(n * lt + k0 + j) * A.Tpad + t];
+        } else {
+            wide_level_fwd<E>(i, col, A, u);
+        }
+        if (A.gfac_part) {
+            double ui = 0.0;
+#pragma unroll
+            for (int j = 0; j < WIDE_MAX_LEVELS; ++j)
+                if (j == i - 1) ui = u[j];
+            const double s = wide_wave_sum(gsum * ui);
+            if (threadIdx.x == 0) A.gfac_part[(int64_t(blockIdx.x) * A.N + n) * (M + 1) + i] = s;
+        }
 #define GPSIG_WIDE_CASE(I_)                                                                                  \
     case I_: {                                                                                               \
         double v[I_];                                                                                        \
         _Pragma("unroll") for (int j = 0; j < I_; ++j) v[j] = u[j];                                         \
         wide_chain_bwd<I_, E>(col, wcol, A.CW, A.Tpad, k0, A.L, A.difference, A.kind, v, c, valid);          \
     } break;
-            switch (i) {
-                GPSIG_WIDE_CASE(1) GPSIG_WIDE_CASE(2) GPSIG_WIDE_CASE(3) GPSIG_WIDE_CASE(4)
-                GPSIG_WIDE_CASE(5) GPSIG_WIDE_CASE(6) GPSIG_WIDE_CASE(7) GPSIG_WIDE_CASE(8)
-                default: break;
-            }
-#undef GPSIG_WIDE_CASE
+        switch (i) {
+            GPSIG_WIDE_CASE(1) GPSIG_WIDE_CASE(2) GPSIG_WIDE_CASE(3) GPSIG_WIDE_CASE(4)
+            GPSIG_WIDE_CASE(5) GPSIG_WIDE_CASE(6) GPSIG_WIDE_CASE(7) GPSIG_WIDE_CASE(8)
+            default: break;
         }
+#undef GPSIG_WIDE_CASE
     }
 }
 
@@ -595,6 +613,98 @@ __global__ void wide_unaug_pair_kernel(const double* __restrict__ gl, const doub
         double v = fma(-gl[r * DA + d], vl[r * DA + f], gl[r * DA + f]);
         if (gr) v += fma(-gr[r * DA + d + 1], vr[r * DA + f], gr[r * DA + f]);
         g[idx] = v;
+    }
+}
+
+// =====================================================================================================================================
+// Inducing tensors vs inducing tensors (kernels.py:263-283 + signature_algs.py:76-99) from the argument blocks of every component:
+// arg (lt, E * Tpad, E * Tpad), block k = left-form rows of component k times its right-form rows; row / column (e, t) at e * Tpad + t.
+// One thread per (t, t'), lanes along t' (contiguous).
+struct WideTensArgs {
+    const double* arg;
+    int64_t Tpad, Tn;
+    int32_t M, E, kind, sum_levels;
+    const double* w;        // (M+1) weights or NULL
+    double* out;            // forward: (T, T) weighted level sum or (M+1, T, T)
+    const double* G;        // reverse: (M+1, T, T)
+    double* W;              // reverse: adjoint of arg, same layout
+};
+
+// value of component k at (t, t'): kappa, or the four-term difference of its two points on both sides (kernels.py:276-277)
+__device__ __forceinline__ double wide_tens_val(const double* __restrict__ blk, int64_t R, int64_t Tpad, int E, int kind, int64_t t, int64_t tp) {
+    if (E == 2)
+        return wide_kappa(kind, blk[(Tpad + t) * R + Tpad + tp]) + wide_kappa(kind, blk[t * R + tp]) - wide_kappa(kind, blk[(Tpad + t) * R + tp]) -
+               wide_kappa(kind, blk[t * R + Tpad + tp]);
+    return wide_kappa(kind, blk[t * R + tp]);
+}
+
+__global__ void __launch_bounds__(64) wide_tens_fwd_kernel(const WideTensArgs A) {
+    const int64_t tp = int64_t(blockIdx.x) * 64 + threadIdx.x, R = int64_t(A.E) * A.Tpad;
+    if (tp >= A.Tn) return;
+    for (int64_t t = blockIdx.y; t < A.Tn; t += gridDim.y) {
+        double acc = A.w ? A.w[0] : 1.0;                                   // level 0 == 1 (signature_algs.py:88)
+        if (!A.sum_levels) A.out[t * A.Tn + tp] = acc;
+        int k = 0;
+        for (int i = 1; i <= A.M; ++i) {
+            double prod = 1.0;
+            for (int j = 0; j < i; ++j, ++k) prod *= wide_tens_val(A.arg + int64_t(k) * R * R, R, A.Tpad, A.E, A.kind, t, tp);      // :91-97
+            const double f = A.w ? A.w[i] : 1.0;
+            if (A.sum_levels) acc = fma(prod, f, acc);
+            else A.out[(int64_t(i) * A.Tn + t) * A.Tn + tp] = prod * f;
+        }
+        if (A.sum_levels) A.out[t * A.Tn + tp] = acc;
+    }
+}
+
+// grid (Tpad / 64, Tpad rows (grid-stride)): every entry of W is written (zeros at padded tensors)
+__global__ void __launch_bounds__(64) wide_tens_bwd_kernel(const WideTensArgs A) {
+    const int64_t tp = int64_t(blockIdx.x) * 64 + threadIdx.x, R = int64_t(A.E) * A.Tpad;
+    for (int64_t t = blockIdx.y; t < A.Tpad; t += gridDim.y) {
+        const bool valid = t < A.Tn && tp < A.Tn;
+        int k0 = 0;
+        for (int i = 1; i <= A.M; ++i) {
+            const double c = valid ? A.G[(int64_t(i) * A.Tn + t) * A.Tn + tp] : 0.0;
+            double v[WIDE_MAX_LEVELS];
+#pragma unroll
+            for (int j = 0; j < WIDE_MAX_LEVELS; ++j) v[j] = j < i ? wide_tens_val(A.arg + int64_t(k0 + j) * R * R, R, A.Tpad, A.E, A.kind, t, tp) : 1.0;
+#pragma unroll
+            for (int j = 0; j < WIDE_MAX_LEVELS; ++j) {
+                if (j >= i) continue;
+                double g = c;                                              // dL/dval_j = c * prod of the other components
+#pragma unroll
+                for (int q = 0; q < WIDE_MAX_LEVELS; ++q)
+                    if (q != j && q < i) g *= v[q];
+                const double* blk = A.arg + int64_t(k0 + j) * R * R;
+                double* wb = A.W + int64_t(k0 + j) * R * R;
+                double kk, dk;
+                if (A.E == 2) {
+                    wide_kappa_grad(A.kind, blk[(A.Tpad + t) * R + A.Tpad + tp], kk, dk); wb[(A.Tpad + t) * R + A.Tpad + tp] = g * dk;
+                    wide_kappa_grad(A.kind, blk[t * R + tp], kk, dk);                     wb[t * R + tp] = g * dk;
+                    wide_kappa_grad(A.kind, blk[(A.Tpad + t) * R + tp], kk, dk);          wb[(A.Tpad + t) * R + tp] = -g * dk;
+                    wide_kappa_grad(A.kind, blk[t * R + A.Tpad + tp], kk, dk);            wb[t * R + A.Tpad + tp] = -g * dk;
+                } else {
+                    wide_kappa_grad(A.kind, blk[t * R + tp], kk, dk);
+                    wb[t * R + tp] = g * dk;
+                }
+            }
+            k0 += i;
+        }
+    }
+}
+
+// gZ in the caller's (lt, T, E, d) order from the adjoints of the left-form and the right-form augmented rows (rows (k * E + e) * Tpad + t)
+__global__ void wide_unaug_tens_kernel(const double* __restrict__ gl, const double* __restrict__ vl, const double* __restrict__ gr, const double* __restrict__ vr,
+                                       int64_t rows_out, int d, int64_t Tn, int64_t Tpad, int E, double* __restrict__ g) {
+    const int DA = d + 2;
+    const int64_t total = rows_out * d;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int f = int(idx % d);
+        const int64_t ro = idx / d;
+        const int e = int(ro % E);
+        const int64_t t = (ro / E) % Tn;
+        const int k = int(ro / (int64_t(E) * Tn));
+        const int64_t r = (int64_t(k) * E + e) * Tpad + t;
+        g[idx] = fma(-gl[r * DA + d], vl[r * DA + f], gl[r * DA + f]) + fma(-gr[r * DA + d + 1], vr[r * DA + f], gr[r * DA + f]);
     }
 }
 

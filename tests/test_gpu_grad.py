@@ -520,12 +520,19 @@ def test_gradients_with_wide_state_space():
         gZ = np.empty_like(Z)
         ctx.call("gpsig_tens_gram_levels_grad", p, _vp(Z), T, 1, _vp(Gz), _vp(gZ), None)
         assert rel(gZ, tZ.grad) < 1e-9, (base, rel(gZ, tZ.grad))
-    keep = []
-    p = _params("rbf", 65, M, True, keep)
-    X = rng.standard_normal((2, 4, 65))
+    # beyond 64 columns: the wide route (round 6, csrc/wide_api.hip) for the distance kernels, an error for the others
+    X = rng.standard_normal((2, 4, 65)) * 0.2
     G = rng.standard_normal((M + 1, 2, 2))
+    gX = np.empty_like(X)
+    keep = []
+    p = _params("poly", 65, M, True, keep)
     with pytest.raises(NotImplementedError, match="at most 64 feature columns"):
-        ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), None, 2, 2, 4, 4, _vp(G), _vp(np.empty_like(X)), None, None)
+        ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), None, 2, 2, 4, 4, _vp(G), _vp(gX), None, None)
+    p = _params("rbf", 65, M, True, keep)
+    ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), None, 2, 2, 4, 4, _vp(G), _vp(gX), None, None)
+    tX = torch.tensor(X, requires_grad=True)
+    (_t_kern("rbf", 65, M).K_seq_levels(tX, None) * torch.tensor(G)).sum().backward()
+    assert rel(gX, tX.grad) < 1e-9
 
 
 def test_seq_level_gradients_are_chunk_invariant():
