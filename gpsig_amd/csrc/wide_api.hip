@@ -62,14 +62,19 @@ int aug_rows(gpsig_ctx* c, const double* src, int64_t rows, int d, int right, do
 }
 
 typedef void (*WideLatKernel)(const WideLatArgs);
-template <int LQ>
-WideLatKernel lat_kernel(int C, bool bwd) {
+template <int LQ, bool RBF>
+WideLatKernel lat_kernel_of(int C, bool bwd) {
     switch (C) {
-        case 1: return bwd ? wide_lattice_bwd_kernel<1, LQ> : wide_lattice_fwd_kernel<1, LQ>;
-        case 2: return bwd ? wide_lattice_bwd_kernel<2, LQ> : wide_lattice_fwd_kernel<2, LQ>;
-        case 4: return bwd ? wide_lattice_bwd_kernel<4, LQ> : wide_lattice_fwd_kernel<4, LQ>;
-        default: return bwd ? wide_lattice_bwd_kernel<8, LQ> : wide_lattice_fwd_kernel<8, LQ>;
+        case 1: return bwd ? wide_lattice_bwd_kernel<1, LQ, RBF> : wide_lattice_fwd_kernel<1, LQ, RBF>;
+        case 2: return bwd ? wide_lattice_bwd_kernel<2, LQ, RBF> : wide_lattice_fwd_kernel<2, LQ, RBF>;
+        case 4: return bwd ? wide_lattice_bwd_kernel<4, LQ, RBF> : wide_lattice_fwd_kernel<4, LQ, RBF>;
+        default: return bwd ? wide_lattice_bwd_kernel<8, LQ, RBF> : wide_lattice_fwd_kernel<8, LQ, RBF>;
     }
+}
+// levels kept by a lane: 3 (num_levels <= 4) or 7; the RBF kernel at compile time, the Matern families at run time
+WideLatKernel lat_kernel(int M, int C, bool bwd, bool rbf) {
+    if (M <= 4) return rbf ? lat_kernel_of<3, true>(C, bwd) : lat_kernel_of<3, false>(C, bwd);
+    return rbf ? lat_kernel_of<7, true>(C, bwd) : lat_kernel_of<7, false>(C, bwd);
 }
 int lat_columns(int R2) { return R2 <= 64 ? 1 : (R2 <= 128 ? 2 : (R2 <= 256 ? 4 : 8)); }
 
@@ -155,8 +160,9 @@ int wide_tvs_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz,
         A.L = L; A.M = M; A.kind = p->base_kernel; A.difference = p->difference ? 1 : 0; A.sum_levels = sum_levels;
         A.fx = fx; A.w = w; A.out = out; A.aux = aux;
         const dim3 grid(unsigned(TB), unsigned(nc < 65535 ? nc : 65535), unsigned(M));
-        if (E == 2) hipLaunchKernelGGL(wide_tvs_fwd_kernel<2>, grid, dim3(64), 0, c->stream, A);
-        else hipLaunchKernelGGL(wide_tvs_fwd_kernel<1>, grid, dim3(64), 0, c->stream, A);
+        const bool rbf = p->base_kernel == GPSIG_BASE_RBF;
+        if (E == 2) { if (rbf) hipLaunchKernelGGL((wide_tvs_fwd_kernel<2, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_fwd_kernel<2, false>), grid, dim3(64), 0, c->stream, A); }
+        else { if (rbf) hipLaunchKernelGGL((wide_tvs_fwd_kernel<1, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_fwd_kernel<1, false>), grid, dim3(64), 0, c->stream, A); }
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL(wide_tvs_epilogue_kernel, dim3(grid_for(nc * Tn)), dim3(256), 0, c->stream, A);
         HIPCHK(c, hipGetLastError());
@@ -202,8 +208,9 @@ int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         A.fx = fac; A.w = nullptr; A.aux = const_cast<double*>(aux);
         A.G = G; A.W = static_cast<double*>(Wb); A.gfac_part = static_cast<double*>(gfp); A.weighted = fac ? 1 : 0;
         const dim3 grid(unsigned(TB), unsigned(nc < 65535 ? nc : 65535), unsigned(M));
-        if (E == 2) hipLaunchKernelGGL(wide_tvs_bwd_kernel<2>, grid, dim3(64), 0, c->stream, A);
-        else hipLaunchKernelGGL(wide_tvs_bwd_kernel<1>, grid, dim3(64), 0, c->stream, A);
+        const bool rbf = p->base_kernel == GPSIG_BASE_RBF;
+        if (E == 2) { if (rbf) hipLaunchKernelGGL((wide_tvs_bwd_kernel<2, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_bwd_kernel<2, false>), grid, dim3(64), 0, c->stream, A); }
+        else { if (rbf) hipLaunchKernelGGL((wide_tvs_bwd_kernel<1, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_bwd_kernel<1, false>), grid, dim3(64), 0, c->stream, A); }
         HIPCHK(c, hipGetLastError());
         // gZA (CW, DA) += W^T XA_chunk:  column-major gZA^T (DA x CW) = XA_cm (DA x nc L) W_cm^T (nc L x CW)
         CHK(dgemm(c, false, true, DA, CW, nc * L, XA + n0 * L * DA, DA, static_cast<const double*>(Wb), CW, n0 > 0 ? 1.0 : 0.0, static_cast<double*>(gza), DA));
@@ -286,7 +293,7 @@ int wide_lat_forward(gpsig_ctx* c, const gpsig_params* p, int d, const double* X
     const int M = p->num_levels;
     void* arg;
     CHK(ensure(c, B_WD2, sizeof(double) * size_t(pl.chunk_i) * L1 * L2 * size_t(diag ? 1 : N2) + 64, &arg));
-    WideLatKernel fn = M <= 4 ? lat_kernel<3>(pl.C, false) : lat_kernel<7>(pl.C, false);
+    WideLatKernel fn = lat_kernel(M, pl.C, false, p->base_kernel == GPSIG_BASE_RBF);
     hipEvent_t e0, e1;
     bool timed;
     CHK(wide_timing_begin(c, &e0, &e1, &timed));
@@ -332,7 +339,7 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     if (groups > Pmax) groups = Pmax;
     if (groups > 4096) groups = 4096;
     CHK(ensure(c, B_WD7, per_group * size_t(groups) + 64, &scr));
-    WideLatKernel fn = M <= 4 ? lat_kernel<3>(pl.C, true) : lat_kernel<7>(pl.C, true);
+    WideLatKernel fn = lat_kernel(M, pl.C, true, p->base_kernel == GPSIG_BASE_RBF);
     for (int64_t i0 = 0; i0 < N1; i0 += pl.chunk_i) {
         const int64_t ni = N1 - i0 < pl.chunk_i ? N1 - i0 : pl.chunk_i;
         CHK(lat_arguments(c, pl, i0, ni, N2, L1, L2, diag, static_cast<double*>(arg)));
@@ -350,7 +357,10 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
             HIPCHK(c, hipGetLastError());
         }
         // the adjoint of the arguments, in place of the arguments
-        hipLaunchKernelGGL(wide_lattice_adjoint_kernel, dim3(grid_for(A.P * int64_t(L1) * L2)), dim3(256), 0, c->stream, A, static_cast<double*>(arg));
+        if (p->base_kernel == GPSIG_BASE_RBF)
+            hipLaunchKernelGGL(wide_lattice_adjoint_kernel<true>, dim3(grid_for(A.P * int64_t(L1) * L2)), dim3(256), 0, c->stream, A, static_cast<double*>(arg));
+        else
+            hipLaunchKernelGGL(wide_lattice_adjoint_kernel<false>, dim3(grid_for(A.P * int64_t(L1) * L2)), dim3(256), 0, c->stream, A, static_cast<double*>(arg));
         HIPCHK(c, hipGetLastError());
         const double* W = static_cast<const double*>(arg);
         double* gl = static_cast<double*>(gxl) + i0 * L1 * DA;
@@ -419,7 +429,8 @@ int wide_tens_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz
     WideTensArgs A;
     memset(&A, 0, sizeof(A));
     A.arg = arg; A.Tpad = Tpad; A.Tn = Tn; A.M = M; A.E = E; A.kind = p->base_kernel; A.sum_levels = sum_levels; A.w = w; A.out = out;
-    hipLaunchKernelGGL(wide_tens_fwd_kernel, dim3(unsigned(Tpad / 64), unsigned(Tn < 65535 ? Tn : 65535)), dim3(64), 0, c->stream, A);
+    if (p->base_kernel == GPSIG_BASE_RBF) hipLaunchKernelGGL(wide_tens_fwd_kernel<true>, dim3(unsigned(Tpad / 64), unsigned(Tn < 65535 ? Tn : 65535)), dim3(64), 0, c->stream, A);
+    else hipLaunchKernelGGL(wide_tens_fwd_kernel<false>, dim3(unsigned(Tpad / 64), unsigned(Tn < 65535 ? Tn : 65535)), dim3(64), 0, c->stream, A);
     HIPCHK(c, hipGetLastError());
     return GPSIG_OK;
 }
@@ -440,7 +451,8 @@ int wide_tens_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double*
     WideTensArgs A;
     memset(&A, 0, sizeof(A));
     A.arg = arg; A.Tpad = Tpad; A.Tn = Tn; A.M = M; A.E = E; A.kind = p->base_kernel; A.G = G; A.W = static_cast<double*>(Wb);
-    hipLaunchKernelGGL(wide_tens_bwd_kernel, dim3(unsigned(Tpad / 64), unsigned(Tpad < 65535 ? Tpad : 65535)), dim3(64), 0, c->stream, A);
+    if (p->base_kernel == GPSIG_BASE_RBF) hipLaunchKernelGGL(wide_tens_bwd_kernel<true>, dim3(unsigned(Tpad / 64), unsigned(Tpad < 65535 ? Tpad : 65535)), dim3(64), 0, c->stream, A);
+    else hipLaunchKernelGGL(wide_tens_bwd_kernel<false>, dim3(unsigned(Tpad / 64), unsigned(Tpad < 65535 ? Tpad : 65535)), dim3(64), 0, c->stream, A);
     HIPCHK(c, hipGetLastError());
     // gZL_k (R, DA) = W_k ZR_k: column-major (DA x R) = ZR_k,cm (DA x R) W_k,cm (R x R);   gZR_k = W_k^T ZL_k: (DA x R) = ZL_k,cm W_k,cm^T
     CHK(dgemm_batched(c, false, false, DA, R, R, ZR, DA, R * DA, static_cast<const double*>(Wb), R, R * R, static_cast<double*>(gzl), DA, R * DA, lt));

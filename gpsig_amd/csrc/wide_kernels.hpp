@@ -23,6 +23,7 @@
 
 #include "seq_core.hpp"
 #include "grad_wave_core.hpp"
+#include "fast_exp.hpp"
 
 namespace gpsig {
 
@@ -43,86 +44,119 @@ struct WideTvsArgs {
     int32_t weighted;
 };
 
+// The base kernel as a function of the argument a = -|z - x|^2 / 2, described by wavefront-uniform numbers so that the three Matern families share
+// one instruction stream:  kappa = P(r') exp(-r'),  r' = c r,  P = 1 + a1 r' + a2 r'^2  (kernels.py:955-993: (c, a1, a2) = (1, 0, 0), (sqrt 3, 1, 0),
+// (sqrt 5, 1, 1/3)); RBF (:862-864) is exp(a) (compile-time: no square root, no polynomial).  exp through the 64-entry table of fast_exp.hpp in LDS
+// (13 instructions, <= 1.3 ulp) instead of the library routine (~50 with its special cases -- the first form of these kernels spent 10x the
+// instructions of the recursion on them).
 // Matern-1/2 is not differentiable at coinciding points, and the squared distance of two EQUAL rows out of a dgemm is rounding noise (~1e-16 |x|^2)
 // instead of the exact zero the exact-shape kernels get from coordinate differences: such distances count as zero (the clamp of kernels.py:781 then
 // gives kappa = 1 and passes no gradient, as it does there; the reference's own float64 value at such a pair is 1e-8 from one -- DESIGN section 5).
 constexpr double WIDE_M12_COINCIDE = 1e-13;
 
-__device__ __forceinline__ double wide_kappa(int kind, double a) {
-    if (kind == BASE_RBF) return exp(a);
-    double dist = -2.0 * a;
-    if (kind == BASE_MATERN12 && !(dist > WIDE_M12_COINCIDE)) dist = 0.0;
-    const double r = sqrt(fmax(dist, 1e-40));                          // kernels.py:779-781
-    if (kind == BASE_MATERN12) return exp(-r);
-    if (kind == BASE_MATERN32) { const double c = 1.7320508075688772935; return (1.0 + c * r) * exp(-c * r); }
-    const double c = 2.2360679774997896964;
-    return (1.0 + c * r + (5.0 / 3.0) * (r * r)) * exp(-c * r);
+struct WideKap {
+    const double* tab;      // 2^(j/64) in LDS
+    double c2, a1, a2, thr;
+};
+
+__device__ __forceinline__ WideKap wide_kap(int kind, const double* tab) {
+    WideKap K;
+    K.tab = tab;
+    K.c2 = kind == BASE_MATERN32 ? 3.0 : (kind == BASE_MATERN52 ? 5.0 : 1.0);
+    K.a1 = kind == BASE_MATERN12 ? 0.0 : 1.0;
+    K.a2 = kind == BASE_MATERN52 ? 1.0 / 3.0 : 0.0;
+    K.thr = kind == BASE_MATERN12 ? WIDE_M12_COINCIDE : 1e-40;
+    return K;
 }
 
-// kappa and d kappa / d a  (a = -dist / 2: d/da = -2 d/ddist; the clamp of kernels.py:781 passes no gradient, as grad_core.hpp: base_eval_grad)
-__device__ __forceinline__ void wide_kappa_grad(int kind, double a, double& k, double& dk) {
-    if (kind == BASE_RBF) { k = exp(a); dk = k; return; }
-    double dist = -2.0 * a;
-    if (kind == BASE_MATERN12 && !(dist > WIDE_M12_COINCIDE)) dist = 0.0;
-    const bool clamped = !(dist > 1e-40);
-    const double r = sqrt(fmax(dist, 1e-40));
-    double dk_dr;
-    if (kind == BASE_MATERN12) {
-        k = exp(-r); dk_dr = -k;
-    } else if (kind == BASE_MATERN32) {
-        const double c = 1.7320508075688772935, e = exp(-c * r);
-        k = (1.0 + c * r) * e; dk_dr = -3.0 * r * e;
+template <bool RBF>
+__device__ __forceinline__ double wide_kappa(const WideKap& K, double a) {
+    if constexpr (RBF) {
+        return kexp_tab(a, K.tab);
     } else {
-        const double c = 2.2360679774997896964, e = exp(-c * r);
-        k = (1.0 + c * r + (5.0 / 3.0) * (r * r)) * e; dk_dr = -(5.0 / 3.0) * r * (1.0 + c * r) * e;
+        double dist = -2.0 * a;
+        dist = dist > K.thr ? dist : 0.0;
+        const double rp = sqrt(fmax(dist, 1e-40) * K.c2);              // c * sqrt(max(r^2, 1e-40)): kernels.py:779-781
+        return fma(fma(K.a2, rp, K.a1), rp, 1.0) * kexp_tab(-rp, K.tab);
     }
-    dk = clamped ? 0.0 : -dk_dr / r;
 }
 
-// value of component k at one argument row (r points at the lane's column 0 of that row)
-template <int E>
-__device__ __forceinline__ double wide_val(const double* __restrict__ r, int k, int64_t Tpad, int kind) {
-    if constexpr (E == 2) return wide_kappa(kind, r[(2 * k + 1) * Tpad]) - wide_kappa(kind, r[(2 * k) * Tpad]);      // kernels.py:330
-    else return wide_kappa(kind, r[k * Tpad]);
+// kappa and d kappa / d a  (a = -dist / 2: d/da = -2 d/ddist; r' = c sqrt(-2a): dr'/da = -c^2 / r'; the clamp of kernels.py:781 passes no gradient, as
+// grad_core.hpp: base_eval_grad)
+template <bool RBF>
+__device__ __forceinline__ void wide_kappa_grad(const WideKap& K, double a, double& k, double& dk) {
+    if constexpr (RBF) {
+        k = kexp_tab(a, K.tab);
+        dk = k;
+    } else {
+        double dist = -2.0 * a;
+        dist = dist > K.thr ? dist : 0.0;
+        const bool clamped = !(dist > 1e-40);
+        const double rp = sqrt(fmax(dist, 1e-40) * K.c2);
+        const double e = kexp_tab(-rp, K.tab);
+        const double P = fma(fma(K.a2, rp, K.a1), rp, 1.0), dP = fma(2.0 * K.a2, rp, K.a1);
+        k = P * e;
+        dk = clamped ? 0.0 : (K.c2 / rp) * (P - dP) * e;
+    }
 }
 
-// the chains of ONE level (I components from k0) of one (tensor, sequence) pair: signature_algs.py:118-125 as one sweep
+// the raw arguments of I components at one argument row (r points at the lane's column 0 of that row): all loads first, so that they are in flight together
 template <int I, int E>
-__device__ __forceinline__ void wide_chain_fwd(const double* __restrict__ col, int64_t CW, int64_t Tpad, int k0, int L, int difference, int kind,
+__device__ __forceinline__ void wide_load_row(const double* __restrict__ r, int k0, int64_t Tpad, double (&raw)[I * E]) {
+#pragma unroll
+    for (int q = 0; q < I * E; ++q) raw[q] = r[(int64_t(k0) * E + q) * Tpad];
+}
+// the value of component j from them: kappa, or the difference of its two points' (kernels.py:330)
+template <int I, int E, bool RBF>
+__device__ __forceinline__ double wide_val(const double (&raw)[I * E], int j, const WideKap& K) {
+    if constexpr (E == 2) return wide_kappa<RBF>(K, raw[2 * j + 1]) - wide_kappa<RBF>(K, raw[2 * j]);
+    else return wide_kappa<RBF>(K, raw[j]);
+}
+
+// the chains of ONE level (I components from k0) of one (tensor, sequence) pair: signature_algs.py:118-125 as one sweep; the arguments of the next
+// step are requested before the current step is evaluated
+template <int I, int E, bool RBF>
+__device__ __forceinline__ void wide_chain_fwd(const double* __restrict__ col, int64_t CW, int64_t Tpad, int k0, int L, int difference, const WideKap& K,
                                                double (&u)[I]) {
 #pragma unroll
     for (int j = 0; j < I; ++j) u[j] = 0.0;
-    double prev[I];
+    double prev[I], cur[I * E];
     const double* r = col;
     int steps = L;
+    wide_load_row<I, E>(r, k0, Tpad, cur);
     if (difference) {                                                              // signature_algs.py:114
 #pragma unroll
-        for (int j = 0; j < I; ++j) prev[j] = wide_val<E>(r, k0 + j, Tpad, kind);
+        for (int j = 0; j < I; ++j) prev[j] = wide_val<I, E, RBF>(cur, j, K);
         r += CW;
         steps = L - 1;
+        if (steps > 0) wide_load_row<I, E>(r, k0, Tpad, cur);
     }
-#pragma unroll 4
-    for (int s = 0; s < steps; ++s, r += CW) {
+    for (int s = 0; s < steps; ++s) {
+        double nxt[I * E];
+        r += CW;
+        if (s + 1 < steps) wide_load_row<I, E>(r, k0, Tpad, nxt);
         double dk[I];
 #pragma unroll
         for (int j = 0; j < I; ++j) {
-            const double v = wide_val<E>(r, k0 + j, Tpad, kind);
+            const double v = wide_val<I, E, RBF>(cur, j, K);
             dk[j] = difference ? v - prev[j] : v;
             prev[j] = v;
         }
 #pragma unroll
         for (int j = I - 1; j >= 1; --j) u[j] = fma(dk[j], u[j - 1], u[j]);          // :120-124 (old values below)
         u[0] += dk[0];
+#pragma unroll
+        for (int q = 0; q < I * E; ++q) cur[q] = nxt[q];
     }
 }
 
-template <int E>
-__device__ __forceinline__ void wide_level_fwd(int i, const double* col, const WideTvsArgs& A, double* u /* [i] */) {
+template <int E, bool RBF>
+__device__ __forceinline__ void wide_level_fwd(int i, const double* col, const WideTvsArgs& A, const WideKap& K, double* u /* [i] */) {
     const int k0 = i * (i - 1) / 2;
 #define GPSIG_WIDE_CASE(I_)                                                                          \
     case I_: {                                                                                       \
         double v[I_];                                                                                \
-        wide_chain_fwd<I_, E>(col, A.CW, A.Tpad, k0, A.L, A.difference, A.kind, v);                  \
+        wide_chain_fwd<I_, E, RBF>(col, A.CW, A.Tpad, k0, A.L, A.difference, K, v);                  \
         _Pragma("unroll") for (int j = 0; j < I_; ++j) u[j] = v[j];                                 \
     } break;
     switch (i) {
@@ -136,8 +170,12 @@ __device__ __forceinline__ void wide_level_fwd(int i, const double* col, const W
 // grid: (Tpad / 64, sequences of the chunk (grid-stride), levels); block: one wavefront, lane = tensor.  A launch of few sequences is bound by the
 // serial sweep of one chain: the levels of a (tensor, sequence) pair go to different workgroups (blockIdx.z + 1 = level), each leaving its chain totals
 // in aux (N, lt, Tpad) -- tensors fastest --, and wide_tvs_epilogue_kernel forms the outputs from them.
-template <int E>
+template <int E, bool RBF>
 __global__ void __launch_bounds__(64) wide_tvs_fwd_kernel(const WideTvsArgs A) {
+    __shared__ double etab[EXP_TAB_N];
+    exp_tab_fill(etab, threadIdx.x, 64);
+    __syncthreads();
+    const WideKap K = wide_kap(A.kind, etab);
     const int64_t t = int64_t(blockIdx.x) * 64 + threadIdx.x;
     const int M = A.M, lt = M * (M + 1) / 2;
     const int i = blockIdx.z + 1, k0 = i * (i - 1) / 2;
@@ -145,7 +183,7 @@ __global__ void __launch_bounds__(64) wide_tvs_fwd_kernel(const WideTvsArgs A) {
         const int64_t n = A.n0 + nl;
         const double* col = A.arg + nl * int64_t(A.L) * A.CW + t;
         double u[WIDE_MAX_LEVELS];
-        wide_level_fwd<E>(i, col, A, u);
+        wide_level_fwd<E, RBF>(i, col, A, K, u);
         for (int j = 0; j < i; ++j) A.aux[(n * lt + k0 + j) * A.Tpad + t] = u[j];
     }
 }
@@ -174,22 +212,22 @@ __global__ void wide_tvs_epilogue_kernel(const WideTvsArgs A) {
 // by u_j <- u_j - m_j u_{j-1} (tvs_grad_tile_kernel.hpp, grad_ho_kernels.hpp: chain_levels_grad_kernel).  m_j[tau] = v_j[tau + 1] - v_j[tau]
 // (signature_algs.py:114), so the adjoint of the VALUE row rho is g[rho - 1] - g[rho]; times d kappa / d a of each endpoint it is the adjoint of the
 // argument.  u: the level's totals (destroyed).  c: the level's upstream gradient.  Columns of tensors beyond Tn get zeros (valid = false).
-template <int I, int E>
+template <int I, int E, bool RBF>
 __device__ __forceinline__ void wide_chain_bwd(const double* __restrict__ col, double* __restrict__ wcol, int64_t CW, int64_t Tpad, int k0, int L,
-                                               int difference, int kind, double (&u)[I], double c, bool valid) {
+                                               int difference, const WideKap& K, double (&u)[I], double c, bool valid) {
     double wv[I];
 #pragma unroll
     for (int j = 0; j < I; ++j) wv[j] = 0.0;
-    auto eval = [&](const double* __restrict__ r, double (&v)[I], double (&d)[I][E]) {
+    auto eval = [&](const double (&raw)[I * E], double (&v)[I], double (&d)[I][E]) {
 #pragma unroll
         for (int j = 0; j < I; ++j) {
             if constexpr (E == 2) {
                 double k1, d1, k0v, d0;
-                wide_kappa_grad(kind, r[(2 * (k0 + j) + 1) * Tpad], k1, d1);
-                wide_kappa_grad(kind, r[(2 * (k0 + j)) * Tpad], k0v, d0);
+                wide_kappa_grad<RBF>(K, raw[2 * j + 1], k1, d1);
+                wide_kappa_grad<RBF>(K, raw[2 * j], k0v, d0);
                 v[j] = k1 - k0v; d[j][1] = d1; d[j][0] = -d0;
             } else {
-                wide_kappa_grad(kind, r[(k0 + j) * Tpad], v[j], d[j][0]);
+                wide_kappa_grad<RBF>(K, raw[j], v[j], d[j][0]);
             }
         }
     };
@@ -210,17 +248,22 @@ __device__ __forceinline__ void wide_chain_bwd(const double* __restrict__ col, d
             if (j >= 1) wv[j] = fma(dk[j], wnext, wv[j]);
         }
     };
+    // (the arguments of the row after next are requested before a row is evaluated: all its loads in flight together)
+    const double* r = col + int64_t(L - 1) * CW;
+    double* wr = wcol + int64_t(L - 1) * CW;
+    double raw[I * E], rnx[I * E];
+    wide_load_row<I, E>(r, k0, Tpad, raw);
     if (difference) {
-        const double* r = col + int64_t(L - 1) * CW;
-        double* wr = wcol + int64_t(L - 1) * CW;
         double nv[I], nd[I][E], gprev[I];
-        eval(r, nv, nd);
+        eval(raw, nv, nd);
 #pragma unroll
         for (int j = 0; j < I; ++j) gprev[j] = 0.0;
+        if (L >= 2) wide_load_row<I, E>(r - CW, k0, Tpad, raw);
         for (int s = L - 2; s >= 0; --s) {
             r -= CW;
+            if (s >= 1) wide_load_row<I, E>(r - CW, k0, Tpad, rnx);
             double cv[I], cd[I][E], dk[I], g[I], gv[I];
-            eval(r, cv, cd);
+            eval(raw, cv, cd);
 #pragma unroll
             for (int j = 0; j < I; ++j) dk[j] = nv[j] - cv[j];
             undo(dk, g);
@@ -234,19 +277,22 @@ __device__ __forceinline__ void wide_chain_bwd(const double* __restrict__ col, d
 #pragma unroll
                 for (int e = 0; e < E; ++e) nd[j][e] = cd[j][e];
             }
+#pragma unroll
+            for (int q = 0; q < I * E; ++q) raw[q] = rnx[q];
         }
         double gv[I];
 #pragma unroll
         for (int j = 0; j < I; ++j) gv[j] = -gprev[j];
         store(wr, gv, nd);                                                             // row 0
     } else {
-        const double* r = col + int64_t(L - 1) * CW;
-        double* wr = wcol + int64_t(L - 1) * CW;
         for (int s = L - 1; s >= 0; --s, r -= CW, wr -= CW) {
+            if (s >= 1) wide_load_row<I, E>(r - CW, k0, Tpad, rnx);
             double cv[I], cd[I][E], g[I];
-            eval(r, cv, cd);
+            eval(raw, cv, cd);
             undo(cv, g);
             store(wr, g, cd);
+#pragma unroll
+            for (int q = 0; q < I * E; ++q) raw[q] = rnx[q];
         }
     }
 }
@@ -257,8 +303,12 @@ __device__ __forceinline__ double wide_wave_sum(double v) {
     return v;
 }
 
-template <int E>
+template <int E, bool RBF>
 __global__ void __launch_bounds__(64) wide_tvs_bwd_kernel(const WideTvsArgs A) {
+    __shared__ double etab[EXP_TAB_N];
+    exp_tab_fill(etab, threadIdx.x, 64);
+    __syncthreads();
+    const WideKap K = wide_kap(A.kind, etab);
     const int64_t t = int64_t(blockIdx.x) * 64 + threadIdx.x;
     const bool valid = t < A.Tn;
     const int M = A.M, lt = M * (M + 1) / 2;
@@ -279,7 +329,7 @@ __global__ void __launch_bounds__(64) wide_tvs_bwd_kernel(const WideTvsArgs A) {
         if (A.aux) {
             for (int j = 0; j < i; ++j) u[j] = A.aux[(n * lt + k0 + j) * A.Tpad + t];
         } else {
-            wide_level_fwd<E>(i, col, A, u);
+            wide_level_fwd<E, RBF>(i, col, A, K, u);
         }
         if (A.gfac_part) {
             double ui = 0.0;
@@ -293,7 +343,7 @@ __global__ void __launch_bounds__(64) wide_tvs_bwd_kernel(const WideTvsArgs A) {
     case I_: {                                                                                               \
         double v[I_];                                                                                        \
         _Pragma("unroll") for (int j = 0; j < I_; ++j) v[j] = u[j];                                         \
-        wide_chain_bwd<I_, E>(col, wcol, A.CW, A.Tpad, k0, A.L, A.difference, A.kind, v, c, valid);          \
+        wide_chain_bwd<I_, E, RBF>(col, wcol, A.CW, A.Tpad, k0, A.L, A.difference, K, v, c, valid);          \
     } break;
         switch (i) {
             GPSIG_WIDE_CASE(1) GPSIG_WIDE_CASE(2) GPSIG_WIDE_CASE(3) GPSIG_WIDE_CASE(4)
@@ -392,10 +442,13 @@ struct WideLatArgs {
     int32_t ngroups;
 };
 
-template <int C>
+constexpr int WIDE_LAT_PF = 1;      // argument rows in flight ahead of a forward step
+
+template <int C, bool RBF>
 struct WideLatDm {
     double rd[C];
-    int nvalid, b0, L2, kind, diff;
+    int nvalid, b0, L2, diff;
+    WideKap K;
     int64_t ld;
     const double* lat;
 
@@ -408,7 +461,7 @@ struct WideLatDm {
     __device__ __forceinline__ void map(const double (&raw)[C + 1], double (&out)[C]) const {
         double k[C + 1];
 #pragma unroll
-        for (int c = 0; c <= C; ++c) k[c] = (c < C || diff) ? wide_kappa(kind, raw[c]) : 0.0;
+        for (int c = 0; c <= C; ++c) k[c] = (c < C || diff) ? wide_kappa<RBF>(K, raw[c]) : 0.0;
 #pragma unroll
         for (int c = 0; c < C; ++c) out[c] = diff ? k[c + 1] - k[c] : k[c];
     }
@@ -418,10 +471,12 @@ struct WideLatDm {
         double nd[C];
         map(raw, nd);
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            if (diff) { dm[c] = forward ? nd[c] - rd[c] : rd[c] - nd[c]; rd[c] = nd[c]; }
-            else dm[c] = nd[c];
-            if (c >= nvalid) dm[c] = 0.0;
+        for (int c = 0; c < C; ++c) {               // (selects, no branches: the arrays stay in registers)
+            const double o = rd[c];
+            const double df = forward ? nd[c] - o : o - nd[c];
+            const double v = diff ? df : nd[c];
+            rd[c] = nd[c];
+            dm[c] = c < nvalid ? v : 0.0;
         }
     }
 };
@@ -441,39 +496,50 @@ __device__ __forceinline__ double wide_from_right(double v) {      // lane l <- 
 
 // Level values of P lattices: one wavefront per lattice (grid-stride).  K_m (m < M) = Q_m at the last cell, K_M = the sum of the row totals of R_M:
 // both arrive at lane 63 (columns beyond the lattice pass the row prefixes on unchanged).
-template <int C, int LQ>
+template <int C, int LQ, bool RBF>
 __global__ void __launch_bounds__(64) wide_lattice_fwd_kernel(const WideLatArgs A) {
+    __shared__ double etab[EXP_TAB_N];
+    exp_tab_fill(etab, threadIdx.x, 64);
+    __syncthreads();
     const int lam = threadIdx.x, M = A.M;
     const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr, TF = R1 + 63;
     for (int64_t pp = blockIdx.x; pp < A.P; pp += gridDim.x) {
         const int64_t pg = A.p0 + pp;
-        WideLatDm<C> dmg;
+        WideLatDm<C, RBF> dmg;
         dmg.lat = A.arg + (pg / A.N2) * A.si + (pg % A.N2) * A.sj;
-        dmg.ld = A.ld; dmg.b0 = C * lam; dmg.L2 = A.L2; dmg.kind = A.kind; dmg.diff = dr;
+        dmg.ld = A.ld; dmg.b0 = C * lam; dmg.L2 = A.L2; dmg.K = wide_kap(A.kind, etab); dmg.diff = dr;
         { const int nv = R2 - C * lam; dmg.nvalid = nv < 0 ? 0 : (nv > C ? C : nv); }
         WaveFwd<C, LQ> fw;
         fw.reset();
-        double raw[C + 1];
-        if (dr) { dmg.load(0, true, raw); dmg.prime(raw); }
-        { const int r = 0 - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw); }
+        // the argument rows of the coming WIDE_LAT_PF steps are in flight while a step computes (a launch of a few lattices is one wavefront per
+        // SIMD: nothing else hides the latency of these strided loads)
+        double raw[WIDE_LAT_PF][C + 1];
+        if (dr) { dmg.load(0, true, raw[0]); dmg.prime(raw[0]); }
+#pragma unroll
+        for (int u = 0; u < WIDE_LAT_PF; ++u) { const int r = u - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
         double kM = 0.0;
-        for (int t = 0; t < TF; ++t) {
-            double cin[LQ + 2], rnext[C + 1];
-            cin[0] = 0.0;
+        for (int t0 = 0; t0 < TF; t0 += WIDE_LAT_PF) {
 #pragma unroll
-            for (int m = 1; m < LQ + 2; ++m) cin[m] = wide_from_left(fw.sout[m]);
-            const int a = t - lam;
-            { const int r = a + 1 + dr; dmg.load(r, r >= 0 && r < A.L1, rnext); }
-            if (a >= 0 && a < R1) {
-                double dm[C];
-                dmg.row(raw, true, dm);
-                fw.step(dm, cin, M);
+            for (int u = 0; u < WIDE_LAT_PF; ++u) {
+                const int t = t0 + u;
+                if (t >= TF) break;
+                double cin[LQ + 2], cur[C + 1];
+                cin[0] = 0.0;
 #pragma unroll
-                for (int m = 1; m <= LQ + 1; ++m)
-                    if (m == M) kM += fw.sout[m];
+                for (int m = 1; m < LQ + 2; ++m) cin[m] = wide_from_left(fw.sout[m]);
+#pragma unroll
+                for (int c = 0; c <= C; ++c) cur[c] = raw[u][c];
+                const int a = t - lam;
+                { const int r = a + WIDE_LAT_PF + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
+                if (a >= 0 && a < R1) {
+                    double dm[C];
+                    dmg.row(cur, true, dm);
+                    fw.step(dm, cin, M);
+#pragma unroll
+                    for (int m = 1; m <= LQ + 1; ++m)
+                        if (m == M) kM += fw.sout[m];
+                }
             }
-#pragma unroll
-            for (int c = 0; c <= C; ++c) raw[c] = rnext[c];
         }
         if (lam == 63) {
             A.out[pg] = 1.0;                                                       // signature_algs.py:20
@@ -487,17 +553,20 @@ __global__ void __launch_bounds__(64) wide_lattice_fwd_kernel(const WideLatArgs 
 
 // Both sweeps (grad_wave_kernel.hpp: seq_grad_wave_kernel with the argument lattice in place of the point rows): Lam[a][b] = dL/ddM[a][b] out.
 // grid: ngroups workgroups of one wavefront; a group's pairs one after the other through its scratch slot.
-template <int C, int LQ>
+template <int C, int LQ, bool RBF>
 __global__ void __launch_bounds__(64) wide_lattice_bwd_kernel(const WideLatArgs A) {
+    __shared__ double etab[EXP_TAB_N];
+    exp_tab_fill(etab, threadIdx.x, 64);
+    __syncthreads();
     const int lam = threadIdx.x, M = A.M;
     const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr, TF = R1 + 63;
     double* scr = A.scratch + size_t(blockIdx.x) * size_t(M - 1) * TF * 64 * C;
     auto slot = [&](int m, int tf, int l, int c) -> double& { return scr[((size_t(m) * TF + tf) * 64 + l) * C + c]; };
     for (int64_t pp = blockIdx.x; pp < A.P; pp += gridDim.x) {
         const int64_t pg = A.p0 + pp;
-        WideLatDm<C> dmg;
+        WideLatDm<C, RBF> dmg;
         dmg.lat = A.arg + (pg / A.N2) * A.si + (pg % A.N2) * A.sj;
-        dmg.ld = A.ld; dmg.b0 = C * lam; dmg.L2 = A.L2; dmg.kind = A.kind; dmg.diff = dr;
+        dmg.ld = A.ld; dmg.b0 = C * lam; dmg.L2 = A.L2; dmg.K = wide_kap(A.kind, etab); dmg.diff = dr;
         { const int nv = R2 - C * lam; dmg.nvalid = nv < 0 ? 0 : (nv > C ? C : nv); }
         double clev[LQ + 2];
 #pragma unroll
@@ -506,29 +575,35 @@ __global__ void __launch_bounds__(64) wide_lattice_bwd_kernel(const WideLatArgs 
         {
             WaveFwd<C, LQ> fw;
             fw.reset();
-            double raw[C + 1];
-            if (dr) { dmg.load(0, true, raw); dmg.prime(raw); }
-            { const int r = 0 - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw); }
-            for (int t = 0; t < TF; ++t) {
-                double cin[LQ + 2], rnext[C + 1];
-                cin[0] = 0.0;
+            double raw[WIDE_LAT_PF][C + 1];
+            if (dr) { dmg.load(0, true, raw[0]); dmg.prime(raw[0]); }
 #pragma unroll
-                for (int m = 1; m < LQ + 2; ++m) cin[m] = wide_from_left(fw.sout[m]);
-                const int a = t - lam;
-                { const int r = a + 1 + dr; dmg.load(r, r >= 0 && r < A.L1, rnext); }
-                if (a >= 0 && a < R1) {
-                    double dm[C];
-                    dmg.row(raw, true, dm);
-                    fw.step(dm, cin, M);
+            for (int u = 0; u < WIDE_LAT_PF; ++u) { const int r = u - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
+            for (int t0 = 0; t0 < TF; t0 += WIDE_LAT_PF) {
 #pragma unroll
-                    for (int m = 0; m < LQ; ++m)
-                        if (m < M - 1) {
+                for (int u = 0; u < WIDE_LAT_PF; ++u) {
+                    const int t = t0 + u;
+                    if (t >= TF) break;
+                    double cin[LQ + 2], cur[C + 1];
+                    cin[0] = 0.0;
 #pragma unroll
-                            for (int c = 0; c < C; ++c) slot(m, t, lam, c) = fw.q[m][c];
-                        }
+                    for (int m = 1; m < LQ + 2; ++m) cin[m] = wide_from_left(fw.sout[m]);
+#pragma unroll
+                    for (int c = 0; c <= C; ++c) cur[c] = raw[u][c];
+                    const int a = t - lam;
+                    { const int r = a + WIDE_LAT_PF + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
+                    if (a >= 0 && a < R1) {
+                        double dm[C];
+                        dmg.row(cur, true, dm);
+                        fw.step(dm, cin, M);
+#pragma unroll
+                        for (int m = 0; m < LQ; ++m)
+                            if (m < M - 1) {
+#pragma unroll
+                                for (int c = 0; c < C; ++c) slot(m, t, lam, c) = fw.q[m][c];
+                            }
+                    }
                 }
-#pragma unroll
-                for (int c = 0; c <= C; ++c) raw[c] = rnext[c];
             }
         }
         __threadfence();        // the backward sweep reads what other lanes of this wavefront stored
@@ -586,7 +661,12 @@ __global__ void __launch_bounds__(64) wide_lattice_bwd_kernel(const WideLatArgs 
 // W[r][c] = adjoint of the argument at point pair (r, c): the adjoint of the double increment (signature_algs.py:26)
 //   Gam[r][c] = Lam[r-1][c-1] - Lam[r-1][c] - Lam[r][c-1] + Lam[r][c]   (zero outside the lattice; no differences: Gam = Lam)
 // times d kappa / d a.  One thread per point pair; W in the layout of arg.
+template <bool RBF>
 __global__ void wide_lattice_adjoint_kernel(const WideLatArgs A, double* __restrict__ W) {
+    __shared__ double etab[EXP_TAB_N];
+    exp_tab_fill(etab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const WideKap K = wide_kap(A.kind, etab);
     const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr;
     const int64_t cells = int64_t(A.L1) * A.L2, total = A.P * cells;
     for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
@@ -597,7 +677,7 @@ __global__ void wide_lattice_adjoint_kernel(const WideLatArgs A, double* __restr
         const double gam = dr ? at(r - 1, c - 1) - at(r - 1, c) - at(r, c - 1) + at(r, c) : at(r, c);
         const int64_t off = (pg / A.N2) * A.si + (pg % A.N2) * A.sj + int64_t(r) * A.ld + c;
         double k, dk;
-        wide_kappa_grad(A.kind, A.arg[off], k, dk);
+        wide_kappa_grad<RBF>(K, A.arg[off], k, dk);
         W[off] = gam * dk;
     }
 }
@@ -631,14 +711,20 @@ struct WideTensArgs {
 };
 
 // value of component k at (t, t'): kappa, or the four-term difference of its two points on both sides (kernels.py:276-277)
-__device__ __forceinline__ double wide_tens_val(const double* __restrict__ blk, int64_t R, int64_t Tpad, int E, int kind, int64_t t, int64_t tp) {
+template <bool RBF>
+__device__ __forceinline__ double wide_tens_val(const double* __restrict__ blk, int64_t R, int64_t Tpad, int E, const WideKap& K, int64_t t, int64_t tp) {
     if (E == 2)
-        return wide_kappa(kind, blk[(Tpad + t) * R + Tpad + tp]) + wide_kappa(kind, blk[t * R + tp]) - wide_kappa(kind, blk[(Tpad + t) * R + tp]) -
-               wide_kappa(kind, blk[t * R + Tpad + tp]);
-    return wide_kappa(kind, blk[t * R + tp]);
+        return wide_kappa<RBF>(K, blk[(Tpad + t) * R + Tpad + tp]) + wide_kappa<RBF>(K, blk[t * R + tp]) - wide_kappa<RBF>(K, blk[(Tpad + t) * R + tp]) -
+               wide_kappa<RBF>(K, blk[t * R + Tpad + tp]);
+    return wide_kappa<RBF>(K, blk[t * R + tp]);
 }
 
+template <bool RBF>
 __global__ void __launch_bounds__(64) wide_tens_fwd_kernel(const WideTensArgs A) {
+    __shared__ double etab[EXP_TAB_N];
+    exp_tab_fill(etab, threadIdx.x, 64);
+    __syncthreads();
+    const WideKap K = wide_kap(A.kind, etab);
     const int64_t tp = int64_t(blockIdx.x) * 64 + threadIdx.x, R = int64_t(A.E) * A.Tpad;
     if (tp >= A.Tn) return;
     for (int64_t t = blockIdx.y; t < A.Tn; t += gridDim.y) {
@@ -647,7 +733,7 @@ __global__ void __launch_bounds__(64) wide_tens_fwd_kernel(const WideTensArgs A)
         int k = 0;
         for (int i = 1; i <= A.M; ++i) {
             double prod = 1.0;
-            for (int j = 0; j < i; ++j, ++k) prod *= wide_tens_val(A.arg + int64_t(k) * R * R, R, A.Tpad, A.E, A.kind, t, tp);      // :91-97
+            for (int j = 0; j < i; ++j, ++k) prod *= wide_tens_val<RBF>(A.arg + int64_t(k) * R * R, R, A.Tpad, A.E, K, t, tp);      // :91-97
             const double f = A.w ? A.w[i] : 1.0;
             if (A.sum_levels) acc = fma(prod, f, acc);
             else A.out[(int64_t(i) * A.Tn + t) * A.Tn + tp] = prod * f;
@@ -657,7 +743,12 @@ __global__ void __launch_bounds__(64) wide_tens_fwd_kernel(const WideTensArgs A)
 }
 
 // grid (Tpad / 64, Tpad rows (grid-stride)): every entry of W is written (zeros at padded tensors)
+template <bool RBF>
 __global__ void __launch_bounds__(64) wide_tens_bwd_kernel(const WideTensArgs A) {
+    __shared__ double etab[EXP_TAB_N];
+    exp_tab_fill(etab, threadIdx.x, 64);
+    __syncthreads();
+    const WideKap K = wide_kap(A.kind, etab);
     const int64_t tp = int64_t(blockIdx.x) * 64 + threadIdx.x, R = int64_t(A.E) * A.Tpad;
     for (int64_t t = blockIdx.y; t < A.Tpad; t += gridDim.y) {
         const bool valid = t < A.Tn && tp < A.Tn;
@@ -666,7 +757,7 @@ __global__ void __launch_bounds__(64) wide_tens_bwd_kernel(const WideTensArgs A)
             const double c = valid ? A.G[(int64_t(i) * A.Tn + t) * A.Tn + tp] : 0.0;
             double v[WIDE_MAX_LEVELS];
 #pragma unroll
-            for (int j = 0; j < WIDE_MAX_LEVELS; ++j) v[j] = j < i ? wide_tens_val(A.arg + int64_t(k0 + j) * R * R, R, A.Tpad, A.E, A.kind, t, tp) : 1.0;
+            for (int j = 0; j < WIDE_MAX_LEVELS; ++j) v[j] = j < i ? wide_tens_val<RBF>(A.arg + int64_t(k0 + j) * R * R, R, A.Tpad, A.E, K, t, tp) : 1.0;
 #pragma unroll
             for (int j = 0; j < WIDE_MAX_LEVELS; ++j) {
                 if (j >= i) continue;
@@ -678,12 +769,12 @@ __global__ void __launch_bounds__(64) wide_tens_bwd_kernel(const WideTensArgs A)
                 double* wb = A.W + int64_t(k0 + j) * R * R;
                 double kk, dk;
                 if (A.E == 2) {
-                    wide_kappa_grad(A.kind, blk[(A.Tpad + t) * R + A.Tpad + tp], kk, dk); wb[(A.Tpad + t) * R + A.Tpad + tp] = g * dk;
-                    wide_kappa_grad(A.kind, blk[t * R + tp], kk, dk);                     wb[t * R + tp] = g * dk;
-                    wide_kappa_grad(A.kind, blk[(A.Tpad + t) * R + tp], kk, dk);          wb[(A.Tpad + t) * R + tp] = -g * dk;
-                    wide_kappa_grad(A.kind, blk[t * R + A.Tpad + tp], kk, dk);            wb[t * R + A.Tpad + tp] = -g * dk;
+                    wide_kappa_grad<RBF>(K, blk[(A.Tpad + t) * R + A.Tpad + tp], kk, dk); wb[(A.Tpad + t) * R + A.Tpad + tp] = g * dk;
+                    wide_kappa_grad<RBF>(K, blk[t * R + tp], kk, dk);                     wb[t * R + tp] = g * dk;
+                    wide_kappa_grad<RBF>(K, blk[(A.Tpad + t) * R + tp], kk, dk);          wb[(A.Tpad + t) * R + tp] = -g * dk;
+                    wide_kappa_grad<RBF>(K, blk[t * R + A.Tpad + tp], kk, dk);            wb[t * R + A.Tpad + tp] = -g * dk;
                 } else {
-                    wide_kappa_grad(A.kind, blk[t * R + tp], kk, dk);
+                    wide_kappa_grad<RBF>(K, blk[t * R + tp], kk, dk);
                     wb[t * R + tp] = g * dk;
                 }
             }
