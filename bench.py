@@ -642,6 +642,22 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
                            "ranks": rank_times, "compute_ms_max": max(comp), "compute_ms_min": min(comp),
                            "compute_max_over_min": (max(comp) / min(comp)) if min(comp) > 0 else None,
                            "gather_wait_ms_rank0": rank_times[0]["gather_wait_ms"], "symmetrise_ms_rank0": rank_times[0]["symmetrise_ms"]}
+    if n_gpus > 1 and not T:
+        # What the measured step should be if nothing but the decomposition's own terms bends the curve: every rank rebuilds the
+        # full level features (not sharded: ~5 ms at N = 32,768, measured on one GPU), contracts its 1/n of the tile triangle, ships its compact rows
+        # to rank 0 over its own xGMI link (all but the last chunk under the next chunk's compute), and rank 0 symmetrises.
+        one_gpu_ms = 547.0 * (float(N) / 32768.0) ** 2          # c4-single-gpu of BENCH_r05 / profiles/r05_bench_default.json, scaled by pairs
+        feat_ms = 5.0 * (float(N) / 32768.0)
+        link_gbs = 120.0                                        # sustained per xGMI link (153 GB/s peak: /opt/skills/guides/MI355X_MICROARCH.md)
+        rows_bytes = float(N) * (N // 2 + 1) * 8.0 / n_gpus     # one rank's compact rows
+        last_gather_ms = rows_bytes / max(chunks, 1) / (link_gbs * 1e9) * 1e3
+        sym_ms = (float(N) * N * 8.0 + float(N) * (N // 2 + 1) * 8.0) / 4.0e12 * 1e3
+        pred = (one_gpu_ms - feat_ms) / n_gpus + feat_ms + last_gather_ms + sym_ms
+        res["predicted"] = {"ms_per_step": pred, "speedup_ceiling": one_gpu_ms / pred,
+                            "terms_ms": {"contraction_share": (one_gpu_ms - feat_ms) / n_gpus, "features_rebuilt_on_every_rank": feat_ms,
+                                         "last_chunk_gather_exposed": last_gather_ms, "symmetrise_on_rank0": sym_ms},
+                            "assumes": "one-GPU step %.0f ms (measured, round 5), %.0f GB/s per xGMI link, 4 TB/s for the symmetrisation pass; "
+                                       "compare with ms_per_step and per_rank" % (one_gpu_ms, link_gbs)}
     if not T:
         res["config"]["route"] = ("explicit level features + one float64 matrix-core contraction (the linear base kernel has a finite feature space: "
                                   "K_m(x, y) = <Phi_m(x), Phi_m(y)>, same numbers as the pair recursion to rounding; the recursion itself is the "
@@ -705,7 +721,79 @@ def secondary_lines(dev):
             out.append({"name": name, "error": repr(e)})
     out.append(c4_single_gpu_line(dev))
     out.extend(gradient_lines(dev))
+    out.extend(svgp_lines(dev))
     return out
+
+
+def svgp_lines(dev):
+    """Round 6.  (i) One SVGP training step -- -ELBO forward + backward: covariances, conditional, KL, likelihood -- at the reference's OWN run settings
+    (benchmarks/run_gpsig_benchmarks.py:32: 500 inducing tensors with increments, num_levels=4, num_lags=1, minibatch 50, SignatureRBF, time-augmented
+    data: 2 (n_features + 1) columns) for four of its data sets' shapes (benchmarks/datasets.json; synthetic paths): 8, 10, 28 and 126 columns.  The
+    last three run the wide route (csrc/wide_api.hip).  column_fma_per_s: tensors x sequences x observations x 20 component points x columns per second
+    of the covariances' forward + backward, the yardstick that compares widths.  (ii) BASELINE configs[2] end to end: models.SVGP.predict_f --
+    Kuu_Kuf_Kff (gpsig/inducing_variables.py:51-66) + Cholesky + two triangular solves + mean / variance (gpsig/models.py:62-73) -- at T = 512 inducing
+    tensors, N = 16,384 sequences, with the split covariances / linear algebra."""
+    import numpy as np
+    import torch
+    out = []
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    try:
+        import reference_shapes as RS
+    except Exception as e:              # noqa: BLE001
+        return [{"name": "svgp-step", "error": repr(e)}]
+    for ds in ("CharacterTrajectories", "NetFlow", "ArabicDigits", "CMUsubject16"):
+        name = "svgp-step-" + ds.lower()
+        try:
+            r = RS.measure(ds, ["auto"], 5, device=str(dev), quiet=True)
+            s, a = RS.shape_of(ds), r["auto"]
+            work = float(s["T"]) * s["N"] * s["L"] * 20 * s["d_eff"]
+            out.append({"name": name, "workload": "one SVGP step at the reference's settings for %s's shape: T=500 inducing tensors (increments), minibatch N=%d, "
+                                                  "L=%d, %d columns (num_lags=1, time-augmented), num_levels=4, SignatureRBF, %d classes, fp64, synthetic paths"
+                                                  % (ds, s["N"], s["L"], s["d_eff"], s["classes"]),
+                        "dtype": "f64", "ms_per_step": a.get("step_ms"), "covs_fwd_ms": a.get("covs_fwd_ms"), "covs_fwd_bwd_ms": a.get("covs_fwd_bwd_ms"),
+                        "kzx_fwd_bwd_ms": a.get("kzx_fwd_bwd_ms"), "kzz_fwd_bwd_ms": a.get("kzz_fwd_bwd_ms"), "kxx_diag_fwd_bwd_ms": a.get("kxx_diag_fwd_bwd_ms"),
+                        "column_fma_per_s": (work / (a["covs_fwd_bwd_ms"] * 1e-3)) if a.get("covs_fwd_bwd_ms") else None, "error": a.get("error")})
+        except Exception as e:          # noqa: BLE001
+            out.append({"name": name, "error": repr(e)})
+    out.append(c3_predict_line(dev))
+    return out
+
+
+def c3_predict_line(dev):
+    """BASELINE configs[2] end to end (see svgp_lines)."""
+    import numpy as np
+    import torch
+    out = []
+    try:
+        from gpsig_amd import inducing_variables as iv, kernels, models
+        w = WORKLOADS["c3"]
+        T, N, L, D, M = w["T"], w["N"], w["L"], w["d"], w["M"]
+        rng = np.random.default_rng(0)
+        X = torch.tensor(np.cumsum(rng.standard_normal((N, L, D)) * 0.3, axis=1).reshape(N, -1), device=dev)
+        Z = torch.tensor(rng.standard_normal((M * (M + 1) // 2, T, 2, D)), device=dev)          # (inputs resident in HBM, as the headline's)
+        kern = kernels.SignatureRBF(L * D, D, M, lengthscales=math.sqrt(D))
+        q_sqrt = np.tile((0.5 * np.eye(T))[None], [1, 1, 1])
+        m = models.SVGP(kern, iv.InducingTensors(Z, M, increments=True), num_latent=1, q_mu=rng.standard_normal((T, 1)), q_sqrt=q_sqrt, device=str(dev))
+
+        def timed(fn, reps=5):
+            fn(); torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / reps * 1e3
+        covs_ms = timed(lambda: m._covs(X, False))
+        total_ms = timed(lambda: m.predict_f(X))
+        fm, fv = m.predict_f(X)
+        out.append({"name": "c3-svgp-predict", "workload": "BASELINE.json configs[2] end to end: models.SVGP.predict_f (Kzz + Kzx + Kxx-diag, Cholesky, two triangular "
+                                                           "solves, mean / variance), T=%d inducing tensors (increments), N=%d, L=%d, d=%d, num_levels=%d, SignatureRBF, "
+                                                           "whitened, full q_sqrt, fp64" % (T, N, L, D, M),
+                    "dtype": "f64", "ms_per_step": total_ms, "covariances_ms": covs_ms, "linear_algebra_ms": total_ms - covs_ms,
+                    "value": float(T) * N / (total_ms * 1e-3), "unit": "(tensor, sequence) pairs/s, end to end",
+                    "finite": bool(torch.isfinite(fm).all() and torch.isfinite(fv).all() and (fv > 0).all())})
+    except Exception as e:              # noqa: BLE001
+        out.append({"name": "c3-svgp-predict", "error": repr(e)})
+    return out[0]
 
 
 def c4_single_gpu_line(dev):

@@ -1657,7 +1657,11 @@ static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, con
         ScaleParams s;
         CHK(scale_params(c, p, !raw, &s));
         const int d_eff = s.d_eff();
-        if (!wide_tvs_available(c, p, d_eff, Tn, N, L) || !(c->wide == 1 || d_eff > 8)) return GPSIG_OK;
+        // beyond the tile kernel's 8 columns -- and, at 5 / 6 columns with increments, launches of few sequences: the tile kernel's two level sets sweep a
+        // 16-sequence tile one after the other, 8 us per time step whatever the count, where the chains here take 2.4 (ECG's shape: 1.23 -> 0.36 ms,
+        // profiles/r06_ab_small_widths.txt); the reverse tile kernel continues from the same chain totals
+        const bool few = increments && d_eff > 4 && d_eff <= 6 && N <= 256 && p->base_kernel == GPSIG_BASE_RBF;
+        if (!wide_tvs_available(c, p, d_eff, Tn, N, L) || !(c->wide == 1 || d_eff > 8 || (few && c->wide != 0 && c->tvs_tile != 1))) return GPSIG_OK;
         void* xs;
         CHK(ensure(c, B_XT, sizeof(double) * size_t(N) * L * d_eff + 8, &xs));
         hipLaunchKernelGGL(prep_seq_scaled_kernel<double>, dim3(grid_for(N * int64_t(L) * d_eff)), dim3(256), 0, c->stream,
@@ -1670,19 +1674,14 @@ static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, con
         *done = true;
         return GPSIG_OK;
     };
-    if (c->wide == 1) {
-        bool done = false;
+    {
+        bool done = false;        // (the lambda declines where the tile kernel is the better choice)
         CHK(wide(&done));
         if (done) return GPSIG_OK;
     }
     if (N > 0 && Tn > 0 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1 || c->tvs_tile == 1)) {
         bool done = false;
         CHK(tens_vs_seq_tile_device(c, p, raw, Zdev, X, Tn, N, L, increments, fx, w, return_levels, out, &done));
-        if (done) return GPSIG_OK;
-    }
-    if (c->wide != 1) {
-        bool done = false;
-        CHK(wide(&done));
         if (done) return GPSIG_OK;
     }
     if (N > 0 && Tn > 0 && N <= 65535 && c->tens_lanes != 0 && (Tn >= 32 || c->tens_lanes == 1) && p->base_kernel != GPSIG_BASE_SPECTRAL &&

@@ -709,7 +709,9 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     int fG = 16;
     FusedGradLaunchFn ffn = (N1 > 0 && N2 > 0 && DP > 0) ? fused_grad_plan(c, p, mode, L1, L2, DP, diag, sym, &fswap, &fG) : nullptr;
     // where the fused reverse kernel is not built (more than 16 columns, long register sides) the wide route takes over; option wide = 1: wherever built
-    if (wide_ok && (c->wide == 1 || DP == 0 || (!ffn && c->grad_impl == 0))) {      // (grad_impl != 0: A/B runs of the exact-shape kernels)
+    // (beyond 8 columns, or where no wavefront kernel is built at all: at <= 8 columns the scratch-free sweeps measured 10-25 % ahead on the
+    // reference's shapes -- profiles/r06_ab_small_widths.txt; grad_impl != 0: A/B runs of the exact-shape kernels)
+    if (wide_ok && (c->wide == 1 || DP == 0 || (!ffn && c->grad_impl == 0 && (d > 8 || (!w2x && !lfn && !wfn))))) {
         CHK(wide_lat_backward(c, p, d, static_cast<const double*>(dX), static_cast<const double*>((diag || sym) ? nullptr : dY), N1, N2, L1, L2, diag,
                               static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(dgY)));
         CHK(out_done(c, gX, dgX, xb));

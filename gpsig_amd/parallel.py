@@ -262,7 +262,8 @@ class ShardedCovs:
     evaluate: what computes a block, ``kern.K_tens_n_seq_covs`` by default (the CPU test-suite passes a stand-in: there is no CPU
     path in the product)."""
 
-    def __init__(self, kern, n, device, rank=0, world=1, evaluate=None):
+    def __init__(self, kern, n, device, rank=0, world=1, evaluate=None, force=False):
+        self.force = bool(force)        # a one-rank group goes through the collectives too (the RCCL path on a single-GPU test box)
         self.kern, self.n, self.dev, self.rank, self.world = kern, int(n), torch.device(device), int(rank), int(world)
         self.per = -(-self.n // self.world)                    # equal-sized blocks (the last one padded) so that gathers are regular
         self.n0 = min(self.rank * self.per, self.n)
@@ -271,7 +272,7 @@ class ShardedCovs:
 
     def __call__(self, Z, X, increments=False):
         f = self._evaluate or (lambda Zb, Xb, inc: self.kern.K_tens_n_seq_covs(Zb, Xb, increments=inc))
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return f(Z, X, increments)
         if X.shape[0] != self.n:
             raise ValueError("ShardedCovs was built for %d sequences, got %d" % (self.n, X.shape[0]))

@@ -1464,6 +1464,59 @@ def test_decomposed_gram_through_rccl_on_one_rank(K):
         dist.destroy_process_group()
 
 
+def test_failure_votes_and_sharded_covariances_through_rccl_on_one_rank(K):
+    """Round 6: what a multi-GPU run does when something goes wrong, and the SVGP covariances' sequence split, executed by
+    RCCL itself on a one-rank group: (a) a row-block call that FAILS on the first chunk -- the MIN all-reduce of the verdict, the fallback's barrier,
+    the error raised after them; (b) a failure on a LATER chunk -- the rank keeps joining the asynchronous gathers, the closing vote, the error;
+    (c) ShardedCovs(force=True): Kzx / Kxx-diag blocks gathered by dist.gather on the nccl backend, equal to the direct evaluation."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from gpsig_amd import _lib, parallel
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        rng = np.random.default_rng(33)
+        dev = torch.device("cuda:0")
+
+        class FailingContext:
+            """the library's context, failing for good from the k-th row-block call on"""
+            def __init__(self, fail_from):
+                self.inner = _lib.context(0, torch.cuda.current_stream(dev).cuda_stream)
+                self.inner.set_pointer_mode(_lib.PTR_DEVICE)
+                self.fail_from, self.calls = fail_from, 0
+
+            def call(self, name, *a):
+                self.calls += 1
+                if self.calls >= self.fail_from:
+                    raise MemoryError("libgpsig_hip: out of device memory")
+                return self.inner.call(name, *a)
+
+            def __getattr__(self, k):
+                return getattr(self.inner, k)
+        n, L, d, M = 520, 16, 3, 3
+        X = torch.as_tensor(rng.standard_normal((n, L * d)), device=dev)
+        kern = K.SignatureRBF(L * d, d, M)
+        for fail_from in (1, 3):
+            g = parallel.ShardedGram(kern, n, dev, 0, 1, chunks=4, force=True, ctx=FailingContext(fail_from))
+            with pytest.raises(MemoryError, match="out of device memory"):
+                g(X)
+            torch.cuda.synchronize()
+        g = parallel.ShardedGram(kern, n, dev, 0, 1, chunks=4, force=True)              # and the group still works afterwards
+        assert torch.equal(g(X), kern.K(X))
+        T = 40
+        for increments in (False, True):
+            Z = torch.as_tensor(rng.standard_normal((M * (M + 1) // 2, T, 2, d) if increments else (M * (M + 1) // 2, T, d)), device=dev)
+            covs = parallel.ShardedCovs(kern, n, dev, 0, 1, force=True)
+            got = covs(Z, X, increments=increments)
+            want = kern.K_tens_n_seq_covs(Z, X, increments=increments)
+            torch.cuda.synchronize()
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
+
+
 def test_empty_row_block_takes_the_routes_a_block_with_rows_takes(K):
     """Round-3 advisor finding: a rank that owns no rows used to validate the shape with the pair kernels' planner only, while ranks
     with rows ask the feature contraction first -- which takes shapes the pair kernels refuse (SignatureLinear with more than 512

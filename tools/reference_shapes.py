@@ -105,7 +105,7 @@ def timed(fn, reps, budget_s=20.0):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def measure(name, routes, reps, device="cuda:0"):
+def measure(name, routes, reps, device="cuda:0", quiet=False):
     import torch
     s, model, X, Y = build(name, device)
     if not hasattr(model.kernel, "_auto_matrix_route"):
@@ -162,7 +162,8 @@ def measure(name, routes, reps, device="cuda:0"):
         except Exception as e:     # noqa: BLE001 -- a route that refuses a shape is a table entry, not a crash
             rec["error"] = "%s: %s" % (type(e).__name__, str(e)[:160])
         out[route] = rec
-        print(json.dumps({"dataset": name, "route": route, **{k: v for k, v in s.items() if k != "name"}, **rec}), flush=True)
+        if not quiet:
+            print(json.dumps({"dataset": name, "route": route, **{k: v for k, v in s.items() if k != "name"}, **rec}), flush=True)
     return out
 
 
