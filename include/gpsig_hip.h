@@ -152,7 +152,14 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "lr_fused"    low-rank sequence features (gpsig_lr_seq_features): 1 (default) one fused kernel, a workgroup per sequence with
  *                 the (width, length) intermediates in LDS, wherever they fit -- two arrays where a wavefront can hold its output
  *                 columns in registers (at most 64 time steps, components and rank bound), three otherwise; 2 always the three-array
- *                 form; 0 one elementwise kernel per reference op */
+ *                 form; 0 one elementwise kernel per reference op
+ *   "wide"        (round 6) the wide-state-space route (csrc/wide_api.hip): kernel arguments by rocBLAS dgemm on augmented rows, fused
+ *                 map / difference / recursion kernels, behind the levels, weighted-sum, fused-evaluation entry points and their gradients.
+ *                 -1 (default) where the exact-shape kernels are not built or lose: Kzx beyond 8 columns, the sequence lattices beyond
+ *                 32 columns / their register sides (reverse pass: beyond 8 columns where no fused kernel is built), Kzz beyond 12 --
+ *                 the reference's own run settings, benchmarks/run_gpsig_benchmarks.py:32; 0 never; 1 wherever built (float64, order 1,
+ *                 RBF and the Matern families, at most 8 levels, lattices of at most 512 columns).  Not taken inside a graph capture.
+ *   "wide_chunk_mb"  its argument chunk in HBM (0: a quarter of "grad_scratch_mb", 1 GB by default) */
 int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
 /* HIP-event timing of the dominant kernel (the pair recursion) launched by the calls since the last
  * reset, measured on the ctx stream: total milliseconds and number of launches (the first 4096 timed

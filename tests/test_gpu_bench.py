@@ -76,7 +76,8 @@ def test_default_line_carries_the_measurement():
     names = [s["name"] for s in line["secondary"]]
     assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c3-linear", "c5-rbf", "c4-single-gpu",
                      "grad-c2shape-n1024-linear", "grad-c2shape-n1024-linear-level-primitives", "grad-c2shape-n1024-linear-pair-kernels",
-                     "grad-c2shape-n1024-rbf", "grad-c2shape-n1024-matern32", "grad-n512-l128-rbf", "c2-matern32"]
+                     "grad-c2shape-n1024-rbf", "grad-c2shape-n1024-matern32", "grad-n512-l128-rbf", "c2-matern32",
+                     "svgp-step-charactertrajectories", "svgp-step-netflow", "svgp-step-arabicdigits", "svgp-step-cmusubject16", "c3-svgp-predict"]
     ho = line["secondary"][1]                           # the higher-order algorithm at order = num_levels: the same contraction, the same time
     assert ho["bound"] == "mfma" and ho["ms_per_step"] < 1.3 * line["ms_per_step"]
     lat = line["secondary"][0]                          # the same Gram through the pair recursion: vector-issue bound, about twice the time
@@ -87,14 +88,23 @@ def test_default_line_carries_the_measurement():
     c4 = line["secondary"][7]                           # configs[3] on one GPU: the N = 1 point of the scaling series' own workload
     assert c4["name"] == "c4-single-gpu" and c4["rel_err"] <= 1e-6 and "N=32768" in c4["workload"] and c4["ms_per_step"] > 100
     for s in line["secondary"]:
-        assert "error" not in s, s
+        assert not s.get("error"), s
         assert s["ms_per_step"] > 0
-        if not s["name"].startswith("grad-") and s["name"] != "c2-matern32":
+        if not s["name"].startswith(("grad-", "svgp-step-", "c3-svgp")) and s["name"] != "c2-matern32":
             assert s["rel_err"] <= (1e-4 if s["dtype"] == "f32" else 1e-6) and s["clock_ghz"] > 1.0
     c3l = line["secondary"][5]                          # configs[2] with SignatureLinear: Kzx as one product of level features (round 4)
     assert c3l["bound"] == "mfma" and c3l["ms_per_step"] < line["secondary"][3]["ms_per_step"]
     c5 = line["secondary"][6]                           # configs[4]: priced as issue-bound from its counters (round 4)
     assert c5["bound"] == "valu-issue" and 0.5 < c5["issue_frac"] <= 1.1
+    # round 6: one SVGP step at the reference's own run settings (benchmarks/run_gpsig_benchmarks.py:32) -- the wide shapes (10, 28, 126 columns) cost
+    # no more per column-FMA than the 8-column shape the tile kernels serve -- and configs[2] end to end
+    sv = {s["name"]: s for s in line["secondary"] if s["name"].startswith("svgp-step-")}
+    base = sv["svgp-step-charactertrajectories"]["column_fma_per_s"]
+    for name in ("svgp-step-netflow", "svgp-step-arabicdigits", "svgp-step-cmusubject16"):
+        assert sv[name]["column_fma_per_s"] > base / 3.0, (name, sv[name]["column_fma_per_s"], base)
+        assert sv[name]["ms_per_step"] < 40.0
+    pr = line["secondary"][-1]
+    assert pr["name"] == "c3-svgp-predict" and pr["finite"] and 0 < pr["covariances_ms"] < pr["ms_per_step"] < 30.0
     g = {s["name"]: s["ms_per_step"] for s in line["secondary"] if s["name"].startswith("grad-")}
     # the linear kernel's reverse pass through the feature contraction: several times faster than through the pair kernels
     assert g["grad-c2shape-n1024-linear"] * 3 < g["grad-c2shape-n1024-linear-pair-kernels"]
