@@ -128,6 +128,8 @@ SeqLaunchFn seq_lookup_ho_ptn_d32(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_f32_inc_d32(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_f32_ptd_d32(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_f32_ptn_d32(int, int, int, int, int);
+SeqLaunchFn seq_lookup_ho_ptdrbf_exact(int G, int C, int D, int M, int order);
+SeqLaunchFn seq_lookup_ho_ptdrbf_exact_o4(int G, int C, int D, int M, int order);
 typedef hipError_t (*TvsLaneTLaunchFn)(const TvsLaneTArgs&, hipStream_t);
 bool tvs_lanet_plan(int M, int d, bool incr, TvsLaneTLaunchFn* fns, int* ngroups);
 // wide_api.hip: state spaces beyond the exact-shape kernels' columns (kernel arguments by dgemm, fused map / difference / recursion kernels)
@@ -940,6 +942,17 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
         out->mode = g0.mode;
         out->d_eff = d_eff;
         out->fn = seq_launcher_ho(g0.mode, h, sizeof(TT) == 4);
+        // round 6: exact instances (num_levels and order at compile time, the RBF kernel on prescaled records with the table exp)
+        if (sizeof(TT) == 8 && c->allow_exact && g0.mode == MODE_PT_DIFF && p->base_kernel == GPSIG_BASE_RBF) {
+            SeqLaunchFn ex = seq_lookup_ho_ptdrbf_exact(h.G, h.C, h.D, p->num_levels, p->order);
+            if (!ex) ex = seq_lookup_ho_ptdrbf_exact_o4(h.G, h.C, h.D, p->num_levels, p->order);
+            if (ex) {
+                out->fn = ex;
+                out->cfg = SeqConfig{h.G, h.C, h.D, p->num_levels, true};
+                out->rbf_prescaled = true;               // (fast_kind stays -1: the stash instances are first-order)
+                out->prescale = SEQ_RBF_PRESCALE;
+            }
+        }
         if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "higher-order kernel shape missing from this build");
         return GPSIG_OK;
     }

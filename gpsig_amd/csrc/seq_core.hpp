@@ -561,6 +561,25 @@ GPSIG_HD void seq_step_rbf_prescaled(SeqLane<double, C, D, MMAX, MODE>& L, const
     seq_recursion(L, nbr, dm, M);
 }
 
+// The same for the HIGHER-ORDER algorithm (round 6: exact instances -- num_levels and order at compile time -- for the RBF kernel): the kernel values
+// of the row as above, then the grid recursion of seq_ho_level with constant bounds (its `r < dcur` predicates fold away).
+template <int C, int D, int MMAX, int OMAX, int MODE, class Nbr>
+GPSIG_HD void seq_step_rbf_prescaled_ho(SeqLaneHO<double, C, D, MMAX, OMAX, MODE>& L, const Nbr& nbr, const double (&xr)[D], double hx,
+                                        const double* etab, int M, int order, bool dummy, int rlo, int rhi) {
+    static_assert(MODE != MODE_INC, "point modes only");
+    double knew[C], dm[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+        double acc = fma(xr[0], L.y[r][0], L.y2[r]);
+#pragma unroll
+        for (int f = 1; f < D; ++f) acc = fma(xr[f], L.y[r][f], acc);
+        knew[r] = SEQ_EXP256 ? kexp2_tab256(acc + hx, etab) : kexp2_tab(acc + hx, etab);
+    }
+    seq_point_increments<double, C, MODE>(L, nbr, knew, dummy, rlo, rhi, dm);
+    double R0[OMAX][OMAX][C];
+    detail::seq_ho_level<1>(L, nbr, dm, M, order, R0);
+}
+
 // First-order step for the Matern-1/2, 3/2, 5/2 kernels on PRESCALED records (float64, point modes; round 5): both sides' points were multiplied by
 // S = c 256 / ln 2 (c = 1, sqrt 3, sqrt 5) when the records were made, so q = |x' - y'| = S r and exp(-c r) = 2^(-q / 256) goes through the table
 // (fast_exp.hpp); u = c r = q ln2 / 256.  The squared distance is summed from the DIFFERENCES of the coordinates: exactly zero where the points

@@ -44,7 +44,7 @@ __device__ __forceinline__ float shr1(float v) {
 // (signature_algs.py:37-74) for any run-time order <= OMAX.
 // KIND >= 0: the base kernel at compile time (built for the RBF kernel with differences, exact shapes): the C + 1 evaluations
 // of a step interleave instead of queueing behind a switch -- 5 % at the headline shape, 18 % at one wavefront per SIMD.
-#define SEQ_FAST_RBF(T, MODE, OMAX, KIND) (sizeof(T) == 8 && (KIND) == BASE_RBF && (MODE) == MODE_PT_DIFF && (OMAX) == 0)
+#define SEQ_FAST_RBF(T, MODE, OMAX, KIND) (sizeof(T) == 8 && (KIND) == BASE_RBF && (MODE) == MODE_PT_DIFF)      // (OMAX > 0: round 6's exact higher-order instances)
 // ... and the Matern families (round 5): prescaled records too, seq_step_matern_prescaled in seq_core.hpp
 #define SEQ_FAST_MATERN(T, MODE, OMAX, KIND) (sizeof(T) == 8 && seq_is_matern(KIND) && (MODE) == MODE_PT_DIFF && (OMAX) == 0)
 // The float64 RBF instances (round 5): two steps per loop trip -- the hand-over words alternate registers instead of being copied back, 12
@@ -63,7 +63,7 @@ __device__ __forceinline__ float shr1(float v) {
 // this recursion -- every lattice row's totals of levels 1 .. M-1 (the last lane's hand-over words) and every lane's Q's when its pair ends
 // (SeqGramArgs::stash) -- so that the backward call starts at the turn of the sweeps instead of repeating the forward one.
 template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1, bool STASH = false>
-__global__ __launch_bounds__(64, (SEQ_FAST_RBF(T, MODE, OMAX, KIND) || SEQ_FAST_MATERN(T, MODE, OMAX, KIND)) && C * D <= 32 ? SEQ_RBF_WAVES : ((MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1)) void seq_gram_kernel(const SeqGramArgs A) {
+__global__ __launch_bounds__(64, ((SEQ_FAST_RBF(T, MODE, OMAX, KIND) && OMAX == 0) || SEQ_FAST_MATERN(T, MODE, OMAX, KIND)) && C * D <= 32 ? SEQ_RBF_WAVES : ((MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1)) void seq_gram_kernel(const SeqGramArgs A) {
     static_assert(!STASH || (sizeof(T) == 8 && MODE == MODE_PT_DIFF && OMAX == 0 && EXACT && MMAX >= 2),
                   "the stash is written by exact float64 instances of the first-order algorithm on points with differences");
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(64, (SEQ_FAST_RBF(T, MODE, OMAX, KIND) || SEQ_FAST_
         // if lane 0 opens a new x at the next step, its record (requested issue_at steps into this x) must have landed
         if (a_u == 0 && A.use_glds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-        if constexpr (FAST_RBF) seq_step_rbf_prescaled(L, DevNbr{L}, xr, hx, etab, M, dummy, rlo, rhi);
+        if constexpr (FAST_RBF && OMAX > 0) seq_step_rbf_prescaled_ho(L, DevNbr{L}, xr, hx, etab, M, EXACT ? OMAX : A.order, dummy, rlo, rhi);
+        else if constexpr (FAST_RBF) seq_step_rbf_prescaled(L, DevNbr{L}, xr, hx, etab, M, dummy, rlo, rhi);
         else if constexpr (FAST_MATERN) seq_step_matern_prescaled<KIND>(L, DevNbr{L}, xr, etab, M, dummy, rlo, rhi);
         else if constexpr (KIND == BASE_SPECTRAL && OMAX == 0 && MODE != MODE_INC) seq_step_spectral(L, DevNbr{L}, xr, A.spec, int(A.p0), int(A.p1), M, dummy, rlo, rhi);
         else seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, KIND >= 0 ? KIND : A.kind, p0, p1);
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(64, (SEQ_FAST_RBF(T, MODE, OMAX, KIND) || SEQ_FAST_
     // back every step.  An odd step count is rounded up; the extra step finds every lane past its last pair.
     // (only where it pays: the point-kernel and higher-order bodies are large enough to lose a wave per SIMD to
     // the doubled live ranges)
-    if constexpr ((MODE == MODE_INC && OMAX == 0) || (SEQ_RBF_UNROLL2 && (FAST_RBF || FAST_MATERN) && C * D <= 32)) {
+    if constexpr ((MODE == MODE_INC && OMAX == 0) || (SEQ_RBF_UNROLL2 && (FAST_RBF || FAST_MATERN) && OMAX == 0 && C * D <= 32)) {
         for (int t = 0; t < nsteps; t += 2) {
             one_step();
             one_step();

@@ -2014,3 +2014,31 @@ def test_hip_path_against_independent_witness_values(K):
         assert max(errs) < 1e-10, (n, errs)
         worst = max(worst, max(errs))
     print(f"witness: {len(meta)} cases, worst {worst:.2e}")
+
+
+@pytest.mark.parametrize("M,order,d,L", [(5, 2, 8, 64), (4, 2, 8, 50), (3, 2, 6, 33), (5, 2, 4, 64), (4, 2, 3, 20), (5, 4, 8, 64), (5, 3, 7, 100), (4, 3, 8, 64), (4, 4, 8, 70)])
+def test_exact_higher_order_rbf_instances(K, M, order, d, L):
+    """Round 6: the higher-order algorithm (signature_algs.py:37-74) with num_levels AND order at compile time for SignatureRBF -- the exact instances
+    of seq_inst_ho_ptdrbf_exact*.hip (prescaled records, table exp): symmetric and cross Grams, normalised and not, against the oracle and against the
+    run-time instances (option exact = 0)."""
+    import torch
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(100 * M + 10 * order + d)
+    N, N2 = 37, 9
+    X = np.cumsum(rng.standard_normal((N, L, d)) * 0.3, axis=1).reshape(N, -1)
+    X2 = np.cumsum(rng.standard_normal((N2, L, d)) * 0.3, axis=1).reshape(N2, -1)
+    ctx = _lib.context(0, 0)
+    for normalization in (True, False):
+        kw = dict(base="rbf", input_dim=L * d, num_features=d, num_levels=M, order=order, lengthscales=np.sqrt(d) * np.ones(d), normalization=normalization)
+        k, ko = make_kernel(K, kw), make_oracle(kw)
+        got = {}
+        for exact in (1, 0):
+            ctx.set_option("exact", exact)
+            try:
+                got[exact] = (k.K(X), k.K(X, X2), k.K(X[:5], return_levels=True))
+            finally:
+                ctx.set_option("exact", 1)
+        for a, b in zip(got[1], (ko.K(X), ko.K(X, X2), ko.K(X[:5], return_levels=True))):
+            assert relerr(a, b) <= 1e-9, (normalization, relerr(a, b))
+        for a, b in zip(got[1], got[0]):
+            assert relerr(a, b) <= 1e-10
