@@ -27,6 +27,7 @@
 namespace gpsig {
 typedef hipError_t (*TvsTileLaunchFn)(TvsTileArgs&, size_t, hipStream_t, int);
 TvsTileLaunchFn tvs_tile_lookup(int M, int NW, int D, bool incr, int kind);
+TvsTileLaunchFn tvs_tile_lookup_ho(int M, int NW, int D, bool incr);
 int tvs_tile_width(int d);
 bool seq_pk2_select(int rows, int d, int M, int* G, int* C, int* D);
 typedef hipError_t (*SigFeatLaunchFn)(const SigFeatArgs&, unsigned, size_t, hipStream_t);
@@ -1517,8 +1518,10 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
                                    int64_t N, int L, int increments, const void* fx, const double* w, int return_levels, void* out,
                                    bool* done) {
     *done = false;
-    if (sizeof(TT) != 8 || p->order > 1 || p->base_kernel == GPSIG_BASE_SPECTRAL || c->tvs_tile == 0) return GPSIG_OK;
+    if (sizeof(TT) != 8 || p->base_kernel == GPSIG_BASE_SPECTRAL || c->tvs_tile == 0) return GPSIG_OK;
     const int M = p->num_levels, lt = M * (M + 1) / 2;
+    const bool ho = p->order > 1 && M > 1;                   // higher-order chains (signature_algs.py:129-160): the RBF instances of tvs_tile_inst_ho.hip
+    if (ho && p->base_kernel != GPSIG_BASE_RBF) return GPSIG_OK;
     ScaleParams s;
     CHK(scale_params(c, p, !raw, &s));
     const int d_eff = s.d_eff();
@@ -1530,7 +1533,7 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     const int E = (increments && !collapse) ? 2 : 1;
     // level sets: the planner's count, or the option's (A/B runs, tests) -- not for the Matern families, which are built for the planner's count only
     const int NW = (c->tvs_tile_nw > 0 && !tvs_is_matern(kind)) ? c->tvs_tile_nw : tvs_tile_waves(M, D, E, kind);
-    TvsTileLaunchFn fn = NW > 0 ? tvs_tile_lookup(M, NW, D, E == 2, kind) : nullptr;
+    TvsTileLaunchFn fn = NW > 0 ? (ho ? tvs_tile_lookup_ho(M, NW, D, E == 2) : tvs_tile_lookup(M, NW, D, E == 2, kind)) : nullptr;
     if (!fn) return GPSIG_OK;
     const int RS = tvs_row_stride(D);
     const bool sum_levels = !(raw || return_levels);
@@ -1560,6 +1563,7 @@ static int tens_vs_seq_tile_device(gpsig_ctx* c, const gpsig_params* p, bool raw
     memset(&A, 0, sizeof(A));
     A.XR = xr; A.ZL = zl; A.ZN = zn; A.N = N; A.Tn = Tn; A.Tpad = Tpad;
     A.L = L; A.d = d_eff; A.kind = p->base_kernel; A.difference = p->difference; A.M = M;
+    A.order = p->order;
     A.queue = static_cast<int32_t*>(tq);          // (the launch plans the items: it knows the instance's occupancy)
     base_p(p, &A.p0, &A.p1);
     A.fx = fx; A.w = w; A.out = out; A.sum_levels = sum_levels ? 1 : 0;

@@ -84,6 +84,7 @@ struct TvsTileArgs {
     const double* w;    // (M+1) level weights or NULL
     void* out;          // (T, N) or (M+1, T, N)
     int32_t sum_levels;
+    int32_t order;      // higher-order instances (HO): the reference's `order` >= 2 (signature_algs.py:129-160); first-order ones ignore it
     double* aux;        // optional (N, lt, Tpad): the totals of EVERY chain, u_{j+1} of component k = i(i-1)/2 + j at [n][k][t] -- what the
                         // reverse pass (tvs_grad_tile_kernel.hpp) would otherwise rebuild with a forward sweep of its own
     // first sequence and length of item i of a tensor block
@@ -172,7 +173,7 @@ __device__ __forceinline__ TvsRow<D> tvs_load_row(tvs_cptr rows, int64_t g) {
     return r;
 }
 
-template <int M, int P, int D, bool INCR, int KIND, int MASK>
+template <int M, int P, int D, bool INCR, int KIND, int MASK, bool HO = false>
 struct TvsTileWave {
     static constexpr int E = (INCR && KIND != BASE_LINEAR) ? 2 : 1;        // linear + increments arrives collapsed
     static constexpr int NC = tvs_mask_comps(MASK);
@@ -293,14 +294,38 @@ struct TvsTileWave {
     }
 
     // one time step of the chains of this wave's levels (signature_algs.py:120-124)
-    __device__ __forceinline__ void chains(const double (&dm)[NC]) {
+    // HO (round 6): the higher-order chains of signature_algs.py:129-160 at the run-time order A.order >= 2 -- per component the vector r_j[l] of
+    // repeat counts: r_j[0] = m_j U_{j-1} (U: the running totals, as at first order), r_j[l] = m_j r_{j-1}[l-1] / (l+1) of the SAME time step
+    // (:153-155), U_j += sum_l r_j[l]; the state between steps is what first order keeps.
+    __device__ __forceinline__ void chains(const double (&dm)[NC], int order) {
 #pragma unroll
         for (int i = 1; i <= M; ++i) {
             if (!((MASK >> i) & 1)) continue;
             const int c0 = tvs_local_off(MASK, i);
+            if constexpr (!HO) {
 #pragma unroll
-            for (int j = i - 1; j >= 1; --j) u[c0 + j] = fma(dm[c0 + j], u[c0 + j - 1], u[c0 + j]);
-            u[c0] += dm[c0];
+                for (int j = i - 1; j >= 1; --j) u[c0 + j] = fma(dm[c0 + j], u[c0 + j - 1], u[c0 + j]);
+                u[c0] += dm[c0];
+            } else {
+                double rp[M], uold = u[c0];
+                rp[0] = dm[c0];
+                u[c0] += dm[c0];
+#pragma unroll
+                for (int j = 1; j < i; ++j) {
+                    const double m = dm[c0 + j];
+                    double rc[M], tot = m * uold;
+                    rc[0] = tot;
+#pragma unroll
+                    for (int l = 1; l <= j; ++l) {
+                        rc[l] = l < order ? (m * (1.0 / double(l + 1))) * rp[l - 1] : 0.0;        // :155 (d = min(j + 1, order))
+                        tot += rc[l];
+                    }
+                    uold = u[c0 + j];
+                    u[c0 + j] += tot;
+#pragma unroll
+                    for (int l = 0; l <= j; ++l) rp[l] = rc[l];
+                }
+            }
         }
     }
 
@@ -316,7 +341,7 @@ struct TvsTileWave {
                 nxt = tvs_load_row<D>(rows, g0 + tau + 1);
                 __builtin_amdgcn_sched_barrier(0);            // (the request stays at the head of the step)
                 eval(A, cur, etab, ka);
-                chains(ka);
+                chains(ka, A.order);
                 cur = nxt;
             }
         } else if constexpr (KIND == BASE_LINEAR) {               // rows are increments already (row 0 unused)
@@ -325,7 +350,7 @@ struct TvsTileWave {
                 nxt = tvs_load_row<D>(rows, g0 + tau + 1);
                 __builtin_amdgcn_sched_barrier(0);            // (the request stays at the head of the step)
                 eval(A, cur, etab, ka);
-                chains(ka);
+                chains(ka, A.order);
                 cur = nxt;
             }
         } else {                                                  // signature_algs.py:114: difference along time
@@ -339,14 +364,14 @@ struct TvsTileWave {
                 eval(A, cur, etab, kb);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) dm[c] = kb[c] - ka[c];
-                chains(dm);
+                chains(dm, A.order);
                 cur = nxt;
                 nxt = tvs_load_row<D>(rows, g0 + tau + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 eval(A, cur, etab, ka);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) dm[c] = ka[c] - kb[c];
-                chains(dm);
+                chains(dm, A.order);
                 cur = nxt;
             }
             if (tau < L) {
@@ -355,7 +380,7 @@ struct TvsTileWave {
                 eval(A, cur, etab, kb);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) dm[c] = kb[c] - ka[c];
-                chains(dm);
+                chains(dm, A.order);
                 cur = nxt;
             }
         }
@@ -420,7 +445,7 @@ constexpr int tvs_planned_sets(int M, int D, bool incr, int kind) {
     return 0;
 }
 
-template <int M, int P, int D, bool INCR, int KIND>
+template <int M, int P, int D, bool INCR, int KIND, bool HO = false>
 __global__ __launch_bounds__(TVS_WG_WAVES * 64, tvs_waves_per_simd(M, P, D, INCR, KIND)) void tvs_tile_kernel(const TvsTileArgs A) {
     constexpr int TS = TVS_TILE_S + 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char tvs_tile_smem[];
@@ -491,7 +516,7 @@ __global__ __launch_bounds__(TVS_WG_WAVES * 64, tvs_waves_per_simd(M, P, D, INCR
         int it = __builtin_amdgcn_readfirstlane(ask(tb));
         if (it >= A.items) continue;
         const int64_t t = tb * int64_t(64) + lane;                // < Tpad
-        TvsTileWave<M, P, D, INCR, KIND, tvs_level_mask(M, P, 0)> W0;
+        TvsTileWave<M, P, D, INCR, KIND, tvs_level_mask(M, P, 0), HO> W0;
         if constexpr (P == 1) W0.load(A, t);                      // one set: the components stay in registers across the items
         while (it < A.items) {
             int64_t n_begin, n_end;
@@ -503,13 +528,13 @@ __global__ __launch_bounds__(TVS_WG_WAVES * 64, tvs_waves_per_simd(M, P, D, INCR
                 sweep_set(W0, true, tb, t, n0, n1);
                 if (!A.sum_levels) flush_levels(tvs_level_mask(M, P, 0), true, tb, n0, int(n1 - n0));
                 if constexpr (P > 1) {
-                    TvsTileWave<M, P, D, INCR, KIND, tvs_level_mask(M, P, 1)> W1;
+                    TvsTileWave<M, P, D, INCR, KIND, tvs_level_mask(M, P, 1), HO> W1;
                     W1.load(A, t);
                     sweep_set(W1, false, tb, t, n0, n1);
                     if (!A.sum_levels) flush_levels(tvs_level_mask(M, P, 1), false, tb, n0, int(n1 - n0));
                 }
                 if constexpr (P > 2) {
-                    TvsTileWave<M, P, D, INCR, KIND, tvs_level_mask(M, P, P > 2 ? 2 : 0)> W2;
+                    TvsTileWave<M, P, D, INCR, KIND, tvs_level_mask(M, P, P > 2 ? 2 : 0), HO> W2;
                     W2.load(A, t);
                     sweep_set(W2, false, tb, t, n0, n1);
                     if (!A.sum_levels) flush_levels(tvs_level_mask(M, P, P > 2 ? 2 : 0), false, tb, n0, int(n1 - n0));

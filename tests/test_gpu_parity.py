@@ -2042,3 +2042,31 @@ def test_exact_higher_order_rbf_instances(K, M, order, d, L):
             assert relerr(a, b) <= 1e-9, (normalization, relerr(a, b))
         for a, b in zip(got[1], got[0]):
             assert relerr(a, b) <= 1e-10
+
+
+@pytest.mark.parametrize("M,order,d,T,N,L", [(4, 2, 6, 70, 45, 50), (4, 4, 6, 512, 40, 9), (3, 2, 3, 33, 130, 7), (5, 3, 8, 65, 20, 13), (5, 5, 4, 40, 17, 6), (3, 3, 8, 64, 64, 2)])
+def test_higher_order_chains_in_the_tile_kernel(K, M, order, d, T, N, L):
+    """Round 6: signature_algs.py:129-160 in the Kzx tile kernel (tvs_tile_inst_ho.hip: the RBF kernel, the order a run-time argument): with and without
+    increments, level arrays and the normalised sum, against the oracle and against the older mappings (option tvs_tile = 0)."""
+    import torch
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(10 * M + order + d)
+    lt = M * (M + 1) // 2
+    X = np.cumsum(rng.standard_normal((N, L, d)) * 0.3, axis=1).reshape(N, -1)
+    ctx = _lib.context(0, 0)
+    for increments in (False, True):
+        Z = rng.standard_normal((lt, T, 2, d) if increments else (lt, T, d)) * 0.5
+        kw = dict(base="rbf", input_dim=L * d, num_features=d, num_levels=M, order=order, lengthscales=np.sqrt(d) * np.ones(d))
+        k, ko = make_kernel(K, kw), make_oracle(kw)
+        got = {}
+        for tile in (-1, 0):
+            ctx.set_option("tvs_tile", tile)
+            try:
+                ctx.timing_reset()
+                got[tile] = (k.K_tens_vs_seq(Z, X, increments=increments), k.K_tens_vs_seq(Z, X, increments=increments, return_levels=True))
+            finally:
+                ctx.set_option("tvs_tile", -1)
+        for a, b in zip(got[-1], (ko.K_tens_vs_seq(Z, X, increments=increments), ko.K_tens_vs_seq(Z, X, increments=increments, return_levels=True))):
+            assert relerr(a, b) <= 1e-9, (increments, relerr(a, b))
+        for a, b in zip(got[-1], got[0]):
+            assert relerr(a, b) <= 1e-9

@@ -14,12 +14,27 @@ T, N, L, d, M = 512, 16384, 50, 6, 4
 rng = np.random.default_rng(0)
 X = torch.as_tensor(rng.standard_normal((N, L * d)) * 0.3, device="cuda:0")
 Z = torch.as_tensor(rng.standard_normal((M * (M + 1) // 2, T, d)) * 0.3, device="cuda:0")
-for cls in (kernels.SignatureLinear, kernels.SignatureRBF):
-    for order in (1, 2, 4):
-        k = cls(L * d, d, M, order=order)
-        k.K_tens_vs_seq(Z, X); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            k.K_tens_vs_seq(Z, X)
-        torch.cuda.synchronize()
-        print(cls.__name__, "order", order, "%.2f ms" % ((time.perf_counter() - t0) / 3 * 1e3))
+from gpsig_amd import _lib  # noqa: E402
+from oracle import sigkern_oracle as O  # noqa: E402
+ctx = _lib.context(0, torch.cuda.current_stream(torch.device("cuda:0")).cuda_stream)
+Zi = torch.as_tensor(rng.standard_normal((M * (M + 1) // 2, T, 2, d)) * 0.3, device="cuda:0")
+for cls, base in ((kernels.SignatureLinear, "linear"), (kernels.SignatureRBF, "rbf")):
+    for inc in (False, True):
+        for order in (1, 2, 4):
+            k = cls(L * d, d, M, order=order)
+            Zu = Zi if inc else Z
+            res = {}
+            for tile in ((-1, 0) if (base == "rbf" and order > 1) else (-1,)):      # round 6: higher-order chains in the tile kernel; 0 = the older mappings
+                ctx.set_option("tvs_tile", tile)
+                G = k.K_tens_vs_seq(Zu, X, increments=inc); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    G = k.K_tens_vs_seq(Zu, X, increments=inc)
+                torch.cuda.synchronize()
+                res[tile] = ((time.perf_counter() - t0) / 3 * 1e3, G)
+            ctx.set_option("tvs_tile", -1)
+            ko = O.SignatureKernelOracle(L * d, d, M, base=base, order=order)
+            want = ko.K_tens_vs_seq(Zu[:, :16].cpu().numpy(), X[:32].cpu().numpy(), increments=inc)
+            err = float(np.abs(res[-1][1][:16, :32].cpu().numpy() - want).max() / np.abs(want).max())
+            print(cls.__name__, "increments" if inc else "plain", "order", order, "%.2f ms" % res[-1][0],
+                  ("(older mappings %.2f ms)" % res[0][0]) if 0 in res else "", "vs oracle %.1e" % err, flush=True)
