@@ -25,7 +25,9 @@ bool wide_kind(int base_kernel) {
 
 size_t wide_chunk_bytes(const gpsig_ctx* c) {
     if (c->wide_chunk_mb > 0) return size_t(c->wide_chunk_mb) << 20;
-    return (size_t(c->grad_scratch_mb > 0 ? c->grad_scratch_mb : 4096) << 20) / 4;       // a quarter of the gradient path's scratch budget
+    // 4 GB by default (the forward pass holds one such array, the reverse pass two and the partial sums of the narrow contraction: a launch of a
+    // minibatch is bound by the serial sweep of one chain, so halving it doubles that time -- NetFlow's shape is 2 GB); grad_scratch_mb scales it
+    return size_t(c->grad_scratch_mb > 0 ? c->grad_scratch_mb : 4096) << 20;
 }
 
 int dgemm(gpsig_ctx* c, bool ta, bool tb, int64_t m, int64_t n, int64_t k, const double* A, int64_t lda, const double* B, int64_t ldb, double beta,
@@ -212,10 +214,35 @@ int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         if (E == 2) { if (rbf) hipLaunchKernelGGL((wide_tvs_bwd_kernel<2, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_bwd_kernel<2, false>), grid, dim3(64), 0, c->stream, A); }
         else { if (rbf) hipLaunchKernelGGL((wide_tvs_bwd_kernel<1, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_bwd_kernel<1, false>), grid, dim3(64), 0, c->stream, A); }
         HIPCHK(c, hipGetLastError());
-        // gZA (CW, DA) += W^T XA_chunk:  column-major gZA^T (DA x CW) = XA_cm (DA x nc L) W_cm^T (nc L x CW)
-        CHK(dgemm(c, false, true, DA, CW, nc * L, XA + n0 * L * DA, DA, static_cast<const double*>(Wb), CW, n0 > 0 ? 1.0 : 0.0, static_cast<double*>(gza), DA));
-        // gXA_chunk (nc L, DA) = W ZA:   column-major gXA^T (DA x nc L) = ZA_cm (DA x CW) W_cm (CW x nc L)
-        CHK(dgemm(c, false, false, DA, nc * L, CW, ZA, DA, static_cast<const double*>(Wb), CW, 0.0, static_cast<double*>(gxa) + n0 * L * DA, DA));
+        if (DA <= 32 && c->wide_contract != 0) {
+            // narrow rows: both contractions in one hand-written pass over W (wide_contract_kernel); rocBLAS spreads such skinny products over too few tiles
+            const int64_t Rr = nc * int64_t(L), strips = (Rr + 63) / 64, ntiles = (CW + 63) / 64;
+            const int DAP = DA <= 16 ? 16 : 32;
+            int64_t groups = (4096 + strips - 1) / strips;            // about four wavefronts per SIMD
+            if (groups > ntiles) groups = ntiles;
+            if (groups < 1) groups = 1;
+            void *part, *gxp;
+            CHK(ensure(c, B_WD9, sizeof(double) * size_t(strips) * CW * DAP + 64, &part));
+            CHK(ensure(c, B_WD8, sizeof(double) * size_t(groups) * Rr * DAP + 64, &gxp));
+            WideContractArgs K;
+            memset(&K, 0, sizeof(K));
+            K.W = static_cast<const double*>(Wb); K.XA = XA + n0 * L * DA; K.ZA = ZA; K.R = Rr; K.CW = CW; K.DA = DA; K.groups = int(groups);
+            K.gXA_part = static_cast<double*>(gxp); K.part = static_cast<double*>(part);
+            const dim3 gridc(unsigned(strips < 65535 ? strips : 65535), unsigned(groups));
+            if (DAP == 16) hipLaunchKernelGGL(wide_contract_kernel<16>, gridc, dim3(64), 0, c->stream, K);
+            else hipLaunchKernelGGL(wide_contract_kernel<32>, gridc, dim3(64), 0, c->stream, K);
+            HIPCHK(c, hipGetLastError());
+            hipLaunchKernelGGL(wide_contract_reduce_kernel, dim3(grid_for(CW * DA)), dim3(256), 0, c->stream, static_cast<const double*>(part), strips, CW, DA, DAP,
+                               n0 > 0 ? 1 : 0, static_cast<double*>(gza));
+            hipLaunchKernelGGL(wide_contract_reduce_kernel, dim3(grid_for(Rr * DA)), dim3(256), 0, c->stream, static_cast<const double*>(gxp), groups, Rr, DA, DAP, 0,
+                               static_cast<double*>(gxa) + n0 * L * DA);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            // gZA (CW, DA) += W^T XA_chunk:  column-major gZA^T (DA x CW) = XA_cm (DA x nc L) W_cm^T (nc L x CW)
+            CHK(dgemm(c, false, true, DA, CW, nc * L, XA + n0 * L * DA, DA, static_cast<const double*>(Wb), CW, n0 > 0 ? 1.0 : 0.0, static_cast<double*>(gza), DA));
+            // gXA_chunk (nc L, DA) = W ZA:   column-major gXA^T (DA x nc L) = ZA_cm (DA x CW) W_cm (CW x nc L)
+            CHK(dgemm(c, false, false, DA, nc * L, CW, ZA, DA, static_cast<const double*>(Wb), CW, 0.0, static_cast<double*>(gxa) + n0 * L * DA, DA));
+        }
     }
     const int64_t zrows = int64_t(lt) * Tn * E;
     hipLaunchKernelGGL(wide_unaug_rows_kernel, dim3(grid_for(zrows * d)), dim3(256), 0, c->stream, static_cast<const double*>(gza), ZA, zrows, d, 0, lt, Tn,

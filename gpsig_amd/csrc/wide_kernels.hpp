@@ -799,4 +799,135 @@ __global__ void wide_unaug_tens_kernel(const double* __restrict__ gl, const doub
     }
 }
 
+// =====================================================================================================================================
+// The two contractions of the reverse pass in ONE pass over the adjoint array W (rows = (sequence, time), CW columns), for narrow augmented rows
+// (DA <= DAP = 16 / 32):   gZA[c][f] = sum_r W[r][c] XA[r][f]   and   gXA[r][f] = sum_c W[r][c] ZA[c][f].
+// rocBLAS runs these as 12 x 10,240-output products over K = 25,000 on 80 macro-tiles (1.1 + 0.7 ms per GB of W at NetFlow's shape: more than every
+// hand-written kernel of the step together); here a wavefront owns a strip of 64 rows and walks the columns in tiles of 64: the tile goes to LDS once,
+// phase 1 (lane = column) adds its 64 rows into the strip's partial sums of gZA -- XA rows are wavefront-uniform: scalar operands --, phase 2
+// (lane = row) adds its 64 columns into gXA, which is complete when the strip ends.  The partial sums (strips, CW, DA) are summed in a fixed order by
+// wide_contract_reduce_kernel (deterministic; a quarter of W's bytes at DAP = 16).
+struct WideContractArgs {
+    const double* W;        // (R, CW)
+    const double* XA;       // (R, DA)
+    const double* ZA;       // (CW, DA)
+    int64_t R, CW;
+    int32_t DA, groups;     // column tiles are dealt to `groups` workgroups per strip (grid y): enough wavefronts to fill the chip
+    double* gXA_part;       // (groups, R, DAP)
+    double* part;           // (strips, CW, DAP)
+};
+
+// grid (strips, groups), one wavefront each.  Both products of a tile on the float64 matrix cores (v_mfma_f64_16x16x4; operand layout as
+// lowrank_kernels.hpp: A: lane l holds A[l & 15][l >> 4], B: B[l >> 4][l & 15], results D[(l >> 4) + 4 r][l & 15]): per 64 x 64 tile and 16 columns of
+// the augmented rows 64 + 64 MFMAs against 80 + 80 LDS reads -- the first form (one broadcast LDS read per FMA) ran at rocBLAS's 3.5 ms.
+typedef double wide_f64x4 __attribute__((ext_vector_type(4)));
+
+template <int DAP>
+__global__ void __launch_bounds__(64) wide_contract_kernel(const WideContractArgs A) {
+    constexpr int TS = 65, NB = DAP / 16;
+    __shared__ double tile[64 * TS];
+    __shared__ double xs[64 * DAP], zs[64 * DAP];            // the strip's rows of XA, the tile's rows of ZA: zero beyond DA
+    const int lane = threadIdx.x, DA = A.DA, li = lane & 15, lk = lane >> 4;
+    const int64_t ntiles = (A.CW + 63) / 64;
+    for (int64_t strip = blockIdx.x; strip * 64 < A.R; strip += gridDim.x) {
+        const int64_t r0 = strip * 64;
+        const int nr = int(A.R - r0 < 64 ? A.R - r0 : 64);
+        __syncthreads();
+        for (int e = lane; e < 64 * DAP; e += 64) {
+            const int r = e / DAP, f = e % DAP;
+            xs[e] = (r < nr && f < DA) ? A.XA[(r0 + r) * DA + f] : 0.0;
+        }
+        wide_f64x4 acc2[4][NB];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc2[m][n] = wide_f64x4{0.0, 0.0, 0.0, 0.0};
+        // a tile's 64 rows of W are requested a whole tile ahead (64 registers): a wavefront has nothing else to hide that latency behind
+        double wn[64];
+        auto request = [&](int64_t ti) {
+            const int64_t c = ti * 64 + lane;
+            const double* __restrict__ src = A.W + r0 * A.CW + (c < A.CW ? c : 0);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) wn[r] = src[int64_t(r < nr ? r : 0) * A.CW];
+        };
+        if (int64_t(blockIdx.y) < ntiles) request(blockIdx.y);
+        for (int64_t ti = blockIdx.y; ti < ntiles; ti += A.groups) {
+            const int64_t c0 = ti * 64;
+            const bool cok = c0 + lane < A.CW;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 64; ++r) tile[r * TS + lane] = (r < nr && cok) ? wn[r] : 0.0;
+            if (ti + A.groups < ntiles) request(ti + A.groups);
+            for (int e = lane; e < 64 * DAP; e += 64) {
+                const int cc = e / DAP, f = e % DAP;
+                zs[e] = (c0 + cc < A.CW && f < DA) ? A.ZA[(c0 + cc) * DA + f] : 0.0;
+            }
+            __syncthreads();
+            // phase 1: D1[column][f] = sum over the strip's rows of W[row][column] XA[row][f]
+            wide_f64x4 acc1[4][NB];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc1[m][n] = wide_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                double av[4], bv[NB];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) av[m] = tile[(k0 + lk) * TS + m * 16 + li];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) bv[n] = xs[(k0 + lk) * DAP + n * 16 + li];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) acc1[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc1[m][n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t col = c0 + m * 16 + lk + 4 * r;
+                    if (col < A.CW) {
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) A.part[(strip * A.CW + col) * DAP + n * 16 + li] = acc1[m][n][r];
+                    }
+                }
+            // phase 2: D2[row][f] += sum over the tile's columns of W[row][column] ZA[column][f]
+#pragma unroll 4
+            for (int k0 = 0; k0 < 64; k0 += 4) {
+                double av[4], bv[NB];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) av[m] = tile[(m * 16 + li) * TS + k0 + lk];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) bv[n] = zs[(k0 + lk) * DAP + n * 16 + li];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[n], acc2[m][n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * 16 + lk + 4 * r;
+                if (row < nr) {
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) A.gXA_part[(int64_t(blockIdx.y) * A.R + r0 + row) * DAP + n * 16 + li] = acc2[m][n][r];
+                }
+            }
+    }
+}
+
+// dst[e][f] = (acc ? dst : 0) + sum over k of part[k][e][f], f < DA of DAP (a fixed order: deterministic)
+__global__ void wide_contract_reduce_kernel(const double* __restrict__ part, int64_t nparts, int64_t rows, int DA, int DAP, int acc, double* __restrict__ dst) {
+    const int64_t n = rows * DA;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < n; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t e = idx / DA;
+        const int f = int(idx % DA);
+        double s = acc ? dst[idx] : 0.0;
+        for (int64_t k = 0; k < nparts; ++k) s += part[(k * rows + e) * DAP + f];
+        dst[idx] = s;
+    }
+}
+
 }  // namespace gpsig
