@@ -1009,7 +1009,8 @@ class SignatureKernelModule(torch.nn.Module):
             return True
         if self._d_cols <= 64 or self.kern.low_rank:
             return False
-        wide = (prim in WIDE_PRIMITIVES and self._spec.base in WIDE_BASES and (self._spec.order == 1 or self._spec.num_levels == 1)
+        first = self._spec.order == 1 or self._spec.num_levels == 1 or prim == "tens"            # (Kzz has no order; the wide Kzx chains: order <= 4)
+        wide = (prim in WIDE_PRIMITIVES and self._spec.base in WIDE_BASES and (first or (prim == "tvs" and min(self._spec.order, self._spec.num_levels) <= 4))
                 and _WIDE["value"] != 0 and cols - int(self._spec.difference) <= WIDE_LAT_MAX_COLS)
         return not wide
 

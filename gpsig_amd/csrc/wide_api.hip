@@ -125,7 +125,7 @@ int wide_timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1, bool* on) {
 // Is the route built for this call?  (float64 is the caller's business.)
 bool wide_tvs_available(const gpsig_ctx* c, const gpsig_params* p, int d, int64_t Tn, int64_t N, int L) {
     if (c->wide == 0 || c->capturing) return false;
-    if (!wide_kind(p->base_kernel) || (p->order > 1 && p->num_levels > 1) || p->num_levels > WIDE_MAX_LEVELS || p->num_levels < 1) return false;
+    if (!wide_kind(p->base_kernel) || (p->order > WIDE_MAX_ORDER && p->num_levels > WIDE_MAX_ORDER) || p->num_levels > WIDE_MAX_LEVELS || p->num_levels < 1) return false;
     if (Tn < 1 || N < 1 || L < 1 || d < 1) return false;
     return true;
 }
@@ -160,7 +160,7 @@ int wide_tvs_forward(gpsig_ctx* c, const gpsig_params* p, const ScaleParams& sz,
         memset(&A, 0, sizeof(A));
         A.arg = static_cast<const double*>(arg); A.CW = CW; A.Tpad = Tpad; A.Tn = Tn; A.n0 = n0; A.Nc = nc; A.N = N;
         A.L = L; A.M = M; A.kind = p->base_kernel; A.difference = p->difference ? 1 : 0; A.sum_levels = sum_levels;
-        A.fx = fx; A.w = w; A.out = out; A.aux = aux;
+        A.fx = fx; A.w = w; A.out = out; A.aux = aux; A.order = p->order < p->num_levels ? p->order : p->num_levels;
         const dim3 grid(unsigned(TB), unsigned(nc < 65535 ? nc : 65535), unsigned(M));
         const bool rbf = p->base_kernel == GPSIG_BASE_RBF;
         if (E == 2) { if (rbf) hipLaunchKernelGGL((wide_tvs_fwd_kernel<2, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_fwd_kernel<2, false>), grid, dim3(64), 0, c->stream, A); }
@@ -209,6 +209,7 @@ int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         A.L = L; A.M = M; A.kind = p->base_kernel; A.difference = p->difference ? 1 : 0;
         A.fx = fac; A.w = nullptr; A.aux = const_cast<double*>(aux);
         A.G = G; A.W = static_cast<double*>(Wb); A.gfac_part = static_cast<double*>(gfp); A.weighted = fac ? 1 : 0;
+        A.order = p->order < p->num_levels ? p->order : p->num_levels;
         const dim3 grid(unsigned(TB), unsigned(nc < 65535 ? nc : 65535), unsigned(M));
         const bool rbf = p->base_kernel == GPSIG_BASE_RBF;
         if (E == 2) { if (rbf) hipLaunchKernelGGL((wide_tvs_bwd_kernel<2, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_bwd_kernel<2, false>), grid, dim3(64), 0, c->stream, A); }

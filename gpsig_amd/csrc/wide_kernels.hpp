@@ -28,6 +28,7 @@
 namespace gpsig {
 
 constexpr int WIDE_MAX_LEVELS = 8;
+constexpr int WIDE_MAX_ORDER = 4;       // higher-order chains: repeat counts kept per component inside a time step
 
 struct WideTvsArgs {
     const double* arg;      // (Nc * L, CW): row (n - n0) * L + tau, column (k * E + e) * Tpad + t
@@ -42,6 +43,7 @@ struct WideTvsArgs {
     double* W;              // reverse: adjoint of arg, same shape
     double* gfac_part;      // reverse, weighted: (TB, N, M+1) partial sums of dL/dfac over the tensors of a block, or NULL
     int32_t weighted;
+    int32_t order;          // > 1: the higher-order chains of signature_algs.py:129-160 (at most WIDE_MAX_ORDER)
 };
 
 // The base kernel as a function of the argument a = -|z - x|^2 / 2, described by wavefront-uniform numbers so that the three Matern families share
@@ -115,8 +117,32 @@ __device__ __forceinline__ double wide_val(const double (&raw)[I * E], int j, co
 
 // the chains of ONE level (I components from k0) of one (tensor, sequence) pair: signature_algs.py:118-125 as one sweep; the arguments of the next
 // step are requested before the current step is evaluated
+// One time step of the HIGHER-ORDER chains of a level (signature_algs.py:147-158): with U_j the running totals (what first order keeps),
+//   r_0 = [m_0],   r_j[0] = m_j U_{j-1},   r_j[l] = m_j r_{j-1}[l-1] / (l+1)  (l < min(j+1, order): the SAME time step),   U_j += sum_l r_j[l].
+template <int I>
+__device__ __forceinline__ void wide_ho_step(const double (&dk)[I], int order, double (&u)[I]) {
+    constexpr int O = WIDE_MAX_ORDER;
+    double rp[O], uold = u[0];
+    rp[0] = dk[0];
+    u[0] += dk[0];
+#pragma unroll
+    for (int j = 1; j < I; ++j) {
+        double rc[O], tot = dk[j] * uold;
+        rc[0] = tot;
+#pragma unroll
+        for (int l = 1; l < O; ++l) {
+            rc[l] = (l <= j && l < order) ? (dk[j] * (1.0 / double(l + 1))) * rp[l - 1] : 0.0;
+            tot += rc[l];
+        }
+        uold = u[j];
+        u[j] += tot;
+#pragma unroll
+        for (int l = 0; l < O; ++l) rp[l] = rc[l];
+    }
+}
+
 template <int I, int E, bool RBF>
-__device__ __forceinline__ void wide_chain_fwd(const double* __restrict__ col, int64_t CW, int64_t Tpad, int k0, int L, int difference, const WideKap& K,
+__device__ __forceinline__ void wide_chain_fwd(const double* __restrict__ col, int64_t CW, int64_t Tpad, int k0, int L, int difference, int order, const WideKap& K,
                                                double (&u)[I]) {
 #pragma unroll
     for (int j = 0; j < I; ++j) u[j] = 0.0;
@@ -142,9 +168,13 @@ __device__ __forceinline__ void wide_chain_fwd(const double* __restrict__ col, i
             dk[j] = difference ? v - prev[j] : v;
             prev[j] = v;
         }
+        if (I > 1 && order > 1) {
+            wide_ho_step<I>(dk, order, u);
+        } else {
 #pragma unroll
-        for (int j = I - 1; j >= 1; --j) u[j] = fma(dk[j], u[j - 1], u[j]);          // :120-124 (old values below)
-        u[0] += dk[0];
+            for (int j = I - 1; j >= 1; --j) u[j] = fma(dk[j], u[j - 1], u[j]);      // :120-124 (old values below)
+            u[0] += dk[0];
+        }
 #pragma unroll
         for (int q = 0; q < I * E; ++q) cur[q] = nxt[q];
     }
@@ -156,7 +186,7 @@ __device__ __forceinline__ void wide_level_fwd(int i, const double* col, const W
 #define GPSIG_WIDE_CASE(I_)                                                                          \
     case I_: {                                                                                       \
         double v[I_];                                                                                \
-        wide_chain_fwd<I_, E, RBF>(col, A.CW, A.Tpad, k0, A.L, A.difference, K, v);                  \
+        wide_chain_fwd<I_, E, RBF>(col, A.CW, A.Tpad, k0, A.L, A.difference, A.order, K, v);                  \
         _Pragma("unroll") for (int j = 0; j < I_; ++j) u[j] = v[j];                                 \
     } break;
     switch (i) {
@@ -214,7 +244,7 @@ __global__ void wide_tvs_epilogue_kernel(const WideTvsArgs A) {
 // argument.  u: the level's totals (destroyed).  c: the level's upstream gradient.  Columns of tensors beyond Tn get zeros (valid = false).
 template <int I, int E, bool RBF>
 __device__ __forceinline__ void wide_chain_bwd(const double* __restrict__ col, double* __restrict__ wcol, int64_t CW, int64_t Tpad, int k0, int L,
-                                               int difference, const WideKap& K, double (&u)[I], double c, bool valid) {
+                                               int difference, int order, const WideKap& K, double (&u)[I], double c, bool valid) {
     double wv[I];
 #pragma unroll
     for (int j = 0; j < I; ++j) wv[j] = 0.0;
@@ -237,7 +267,54 @@ __device__ __forceinline__ void wide_chain_bwd(const double* __restrict__ col, d
 #pragma unroll
             for (int e = 0; e < E; ++e) wr[((k0 + j) * E + e) * Tpad] = valid ? g[j] * d[j][e] : 0.0;
     };
-    auto undo = [&](const double (&dk)[I], double (&g)[I]) {
+    // higher-order chains: the step's repeat-count vectors are rebuilt from the totals BEFORE the step (U_j - sum_l r_j[l], ascending in j), then the
+    // adjoints run down: dL/dr_j[l] = W_j + m_{j+1} / (l+2) dL/dr_{j+1}[l+1],  dL/dm_j = dL/dr_j[0] U_{j-1} + sum_{l>=1} dL/dr_j[l] r_{j-1}[l-1] / (l+1),
+    // W_{j-1} += m_j dL/dr_j[0]   (W_j = dL/dU_j after the step; first order: one repeat count)
+    auto undo_ho = [&](const double (&dk)[I], double (&g)[I]) {
+        constexpr int O = WIDE_MAX_ORDER;
+        double r[I][O], ub[I];
+        ub[0] = u[0] - dk[0];
+#pragma unroll
+        for (int l = 0; l < O; ++l) r[0][l] = l == 0 ? dk[0] : 0.0;
+#pragma unroll
+        for (int j = 1; j < I; ++j) {
+            double tot = dk[j] * ub[j - 1];
+            r[j][0] = tot;
+#pragma unroll
+            for (int l = 1; l < O; ++l) {
+                r[j][l] = (l <= j && l < order) ? (dk[j] * (1.0 / double(l + 1))) * r[j - 1][l - 1] : 0.0;
+                tot += r[j][l];
+            }
+            ub[j] = u[j] - tot;
+        }
+        double gn[O], add[I];                             // dL/dr_{j+1}[.];  m_j dL/dr_j[0], added to W_{j-1} once the step's adjoints are through
+#pragma unroll
+        for (int l = 0; l < O; ++l) gn[l] = 0.0;
+#pragma unroll
+        for (int j = I - 1; j >= 0; --j) {
+            const double wj = (j == I - 1) ? c : wv[j + 1 < I ? j + 1 : j];
+            double gr[O];
+#pragma unroll
+            for (int l = 0; l < O; ++l) {
+                const bool live = l <= j && l < order;
+                const bool up = j + 1 < I && l + 1 < O && l + 1 <= j + 1 && l + 1 < order;
+                gr[l] = live ? wj + (up ? (dk[j + 1 < I ? j + 1 : j] * (1.0 / double(l + 2))) * gn[l + 1 < O ? l + 1 : l] : 0.0) : 0.0;
+            }
+            double gd = gr[0] * (j >= 1 ? ub[j >= 1 ? j - 1 : 0] : 1.0);
+#pragma unroll
+            for (int l = 1; l < O; ++l)
+                if (j >= 1) gd = fma(gr[l] * (1.0 / double(l + 1)), r[j >= 1 ? j - 1 : 0][l - 1], gd);
+            g[j] = gd;
+            add[j] = dk[j] * gr[0];
+#pragma unroll
+            for (int l = 0; l < O; ++l) gn[l] = gr[l];
+        }
+#pragma unroll
+        for (int j = 1; j < I; ++j) wv[j] += add[j];
+#pragma unroll
+        for (int j = 0; j < I; ++j) u[j] = ub[j];
+    };
+    auto undo1 = [&](const double (&dk)[I], double (&g)[I]) {
         double below = 1.0;
 #pragma unroll
         for (int j = 0; j < I; ++j) {
@@ -247,6 +324,10 @@ __device__ __forceinline__ void wide_chain_bwd(const double* __restrict__ col, d
             below = u[j];
             if (j >= 1) wv[j] = fma(dk[j], wnext, wv[j]);
         }
+    };
+    auto undo = [&](const double (&dk)[I], double (&g)[I]) {
+        if (I > 1 && order > 1) undo_ho(dk, g);
+        else undo1(dk, g);
     };
     // (the arguments of the row after next are requested before a row is evaluated: all its loads in flight together)
     const double* r = col + int64_t(L - 1) * CW;
@@ -343,7 +424,7 @@ __global__ void __launch_bounds__(64) wide_tvs_bwd_kernel(const WideTvsArgs A) {
     case I_: {                                                                                               \
         double v[I_];                                                                                        \
         _Pragma("unroll") for (int j = 0; j < I_; ++j) v[j] = u[j];                                         \
-        wide_chain_bwd<I_, E, RBF>(col, wcol, A.CW, A.Tpad, k0, A.L, A.difference, K, v, c, valid);          \
+        wide_chain_bwd<I_, E, RBF>(col, wcol, A.CW, A.Tpad, k0, A.L, A.difference, A.order, K, v, c, valid);          \
     } break;
         switch (i) {
             GPSIG_WIDE_CASE(1) GPSIG_WIDE_CASE(2) GPSIG_WIDE_CASE(3) GPSIG_WIDE_CASE(4)

@@ -316,3 +316,65 @@ def test_wide_tensor_gram_levels_and_gradient(M, T, d, base):
             assert rel(gZ, tZ.grad) < (1e-5 if base == "matern12" else 1e-8), (increments, rel(gZ, tZ.grad))      # (matern12: the oracle's 1 / r at rounding-noise distances)
     finally:
         ctx.set_option("wide", -1)
+
+
+@pytest.mark.parametrize("M,order,T,N,L,d", [(4, 2, 70, 9, 13, 12), (4, 4, 33, 6, 9, 28), (3, 2, 20, 5, 11, 6), (5, 3, 40, 4, 8, 46), (6, 4, 12, 5, 7, 10), (2, 2, 64, 7, 5, 3), (8, 2, 9, 3, 6, 14)])
+@pytest.mark.parametrize("base", ["rbf", "matern32"])
+def test_wide_higher_order_chains_and_gradient(M, order, T, N, L, d, base):
+    """Round 6: the higher-order tensor-vs-sequence chains (signature_algs.py:129-160, order <= 4) on the wide route: values, and the reverse pass that
+    rebuilds a step's repeat-count vectors from the chain totals -- levels and the weighted sum, against autograd of the oracle; at <= 8 columns too
+    (there the forward pass is the tile kernel's higher-order instance, the reverse pass this one, continuing from its chain totals)."""
+    if base != "rbf" and (M, order) in ((2, 2), (8, 2), (6, 4)):
+        pytest.skip("a sample of the shapes is enough for the Matern families")
+    from gpsig_amd import _lib
+    rng = np.random.default_rng(10 * M + order + d)
+    ctx = _host_ctx()
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(dev)
+    dctx = _lib.context(0, side.cuda_stream)
+    dctx.set_pointer_mode(_lib.PTR_DEVICE)
+    ptr = lambda t_: C.c_void_p(t_.data_ptr())      # noqa: E731
+    from gpsig_amd.autodiff import _Spec
+    for increments in (False, True):
+        for difference in (True, False):
+            Z, X = _data(rng, M, T, N, L, d, increments)
+            G = rng.standard_normal((M + 1, T, N))
+            kt = OT.SignatureKernelTorchOracle(d, M, base, difference=difference, order=order)
+            tZ, tX = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True)
+            want = kt.K_tens_vs_seq_levels(tZ, tX, increments)
+            (want * torch.tensor(G)).sum().backward()
+            keep = []
+            p = _Spec(base, M, difference, 0.0, order=order).params(d, 0.0, keep)
+            for wide in ((1, -1) if d <= 8 else (-1,)):
+                ctx.set_option("wide", wide)
+                try:
+                    out = np.full((M + 1, T, N), np.nan)
+                    ctx.call("gpsig_tens_vs_seq_levels", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(out))
+                    gZ, gX, gb = np.full_like(Z, np.nan), np.full_like(X, np.nan), np.zeros(2)
+                    ctx.call("gpsig_tens_vs_seq_levels_grad", p, _vp(Z), _vp(X), T, N, L, int(increments), _vp(G), _vp(gZ), _vp(gX), gb.ctypes.data_as(_P))
+                finally:
+                    ctx.set_option("wide", -1)
+                assert rel(out, want) < 1e-10, (increments, difference, wide, rel(out, want))
+                assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9, (increments, difference, wide, rel(gZ, tZ.grad), rel(gX, tX.grad))
+        # the weighted sum with the chain totals handed over (device pointers)
+        Z, X = _data(rng, M, T, N, L, d, increments)
+        F, G2 = rng.uniform(0.5, 1.5, (N, M + 1)), rng.standard_normal((T, N))
+        kt = OT.SignatureKernelTorchOracle(d, M, base, order=order)
+        tZ, tX, tF = torch.tensor(Z, requires_grad=True), torch.tensor(X, requires_grad=True), torch.tensor(F, requires_grad=True)
+        want = (kt.K_tens_vs_seq_levels(tZ, tX, increments) * tF.t()[:, None, :]).sum(0)
+        (want * torch.tensor(G2)).sum().backward()
+        keep = []
+        p = _Spec(base, M, True, 0.0, order=order).params(d, 0.0, keep)
+        dZ, dX, dF, dG = (torch.tensor(a, device=dev) for a in (Z, X, F, G2))
+        dgZ, dgX, dgF, dgb = torch.empty_like(dZ), torch.empty_like(dX), torch.empty_like(dF), torch.zeros(2, dtype=torch.float64, device=dev)
+        aux = torch.empty(int(_lib.load().gpsig_tens_vs_seq_aux_elems(C.byref(p), T, N)), dtype=torch.float64, device=dev)
+        dout, wrote = torch.empty((T, N), dtype=torch.float64, device=dev), C.c_int32(0)
+        torch.cuda.synchronize()
+        dctx.call("gpsig_tens_vs_seq_weighted", p, ptr(dZ), ptr(dX), T, N, L, int(increments), ptr(dF), ptr(dout), ptr(aux), C.byref(wrote))
+        side.synchronize()
+        assert rel(dout, want) < 1e-10
+        for use_aux in ((False, True) if wrote.value else (False,)):
+            dctx.call("gpsig_tens_vs_seq_weighted_grad", p, ptr(dZ), ptr(dX), T, N, L, int(increments), ptr(dF), ptr(dG), ptr(aux) if use_aux else None,
+                      ptr(dgZ), ptr(dgX), ptr(dgF), C.cast(dgb.data_ptr(), _P))
+            side.synchronize()
+            assert rel(dgZ, tZ.grad) < 1e-9 and rel(dgX, tX.grad) < 1e-9 and rel(dgF, tF.grad) < 1e-9, (use_aux, rel(dgZ, tZ.grad), rel(dgX, tX.grad), rel(dgF, tF.grad))

@@ -28,7 +28,8 @@ def draw_case(rng):
     base = rng.choice(BASES)
     M = int(rng.integers(1, 7))
     order = int(rng.choice([1, 1, 1, 2, 3, M]))
-    d = int(rng.choice([1, 2, 3, 5, 8, 11, 16, 20]))
+    # FUZZ_WIDE=1 (round 6): the widths of the reference's own run settings, where the wide route (csrc/wide_api.hip) takes Kzx / Kzz / the lattices
+    d = int(rng.choice([9, 12, 14, 23, 33, 50, 63, 130] if os.environ.get("FUZZ_WIDE") else [1, 2, 3, 5, 8, 11, 16, 20]))
     lags = int(rng.choice([0, 0, 0, 1, 2])) if base != "poly" else 0
     L1, L2 = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 130])), int(rng.choice([1, 2, 5, 17, 32, 65, 90]))
     N1, N2 = int(rng.integers(1, 40)), int(rng.integers(1, 20))
@@ -102,6 +103,9 @@ def main():
             base, M, order, d, L1, L2, f32, kw, desc, incr, T, de = (cs[k] for k in ("base", "M", "order", "d", "L1", "L2", "f32", "kw", "desc", "incr", "T", "de"))
             for k_, v_ in cs["opts"].items():
                 CTX.set_option(k_, v_)
+            if os.environ.get("FUZZ_WIDE"):
+                CTX.set_option("wide", 1 if it % 3 == 0 else -1)
+                CTX.set_option("wide_chunk_mb", 1 if it % 5 == 0 else 0)
             desc = dict(desc, **cs["opts"])
             kx1 = CLASS[base](L1 * d, d, **kw)
             ko1 = oracle_for(cs)
