@@ -7,11 +7,14 @@
 #include "ctx.hpp"
 #include "grad_kernels.hpp"
 #include "grad_ho_kernels.hpp"
+#include "grad_wave_ho_kernel.hpp"
 #include "grad_wave_kernel.hpp"
 #include "grad_fused_kernel.hpp"
 
 namespace gpsig {
 typedef hipError_t (*WaveLaunchFn)(const WaveGradArgs&, int, hipStream_t);
+typedef hipError_t (*WaveHoLaunchFn)(const WaveHoArgs&, int, hipStream_t);
+WaveHoLaunchFn wave_ho_lookup(int G, int C, int order, int M);      // grad_wave_ho_inst.hip
 WaveLaunchFn wave_lookup_inc(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptd(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptn(int G, int C, int DP, int LQ);
@@ -41,6 +44,7 @@ static FusedGradLaunchFn fused_grad_lookup(int kind, int DP, int LQ, int G, bool
 int sig_features_grad(gpsig_ctx* c, const gpsig_params* p, int d, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2, bool diag,
                       bool sym, const double* G, double* gX, double* gY, bool* done);
 // tvs_grad_api.hip: the tile kernel of the tensor-vs-sequence reverse pass (tvs_grad_tile_kernel.hpp)
+bool tvs_grad_tile_ho_available(const gpsig_ctx* c, const gpsig_params* p, int d, int L, int increments);
 int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, const double* X, const double* G, int64_t Tn, int64_t N,
                          int L, int increments, const double* fac, const double* aux, double* gZ, double* gX, double* gfac, double* gb, size_t budget, bool* done);
 // wide_api.hip: state spaces beyond the exact-shape kernels' columns
@@ -547,6 +551,86 @@ int seq_grad_fused_stash(gpsig_ctx* c, const gpsig_params* p, int DP, const doub
     return GPSIG_OK;
 }
 
+// ---- higher-order algorithm (order > 1), fused: ho_dm_kernel -> seq_grad_wave_ho_kernel (both sweeps of a pair in one wavefront,
+// grad_wave_ho_kernel.hpp) -> lam_contract_kernel.  num_levels <= 5, min(order, num_levels) <= 4, lattices of at most 512 columns;
+// option grad_impl != 0 keeps the lattice operations below (the A/B reference of the tests).
+int seq_grad_ho_wave(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2,
+                     int d, bool diag, bool sym, const double* Gup, double* gX, double* gY, double* gbase, bool* done) {
+    *done = false;
+    const int M = p->num_levels, order = p->order < M ? p->order : M, dr = mode == MODE_PT_NODIFF ? 0 : 1;
+    const int R1 = L1 - dr, R2 = L2 - dr;
+    if (c->grad_impl != 0 || order < 2) return GPSIG_OK;
+    static const int shapes[][2] = {{16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8}};
+    WaveHoLaunchFn fn = nullptr;
+    int G = 0, C = 0;
+    for (auto& sh : shapes) {
+        if (sh[0] * sh[1] < R2) continue;
+        fn = wave_ho_lookup(sh[0], sh[1], order, M);
+        G = sh[0]; C = sh[1];
+        break;
+    }
+    if (!fn) return GPSIG_OK;
+    const int PW = 64 / G, TF = R1 + G - 1;
+    const size_t cells = size_t(R1) * R2, per_pair = sizeof(double) * cells * 2;           // dM and Lam
+    const size_t slot = sizeof(double) * size_t(ho_stash_words(order, M)) * TF * G * C;
+    const int64_t gm = diag ? N1 : N1 * N2, gi = diag ? 1 : N2, gj = diag ? 0 : 1;
+    const int64_t nj = diag ? 1 : N2;
+    // half of the budget for the lattices of a pair block, half for the slots of the groups in flight
+    int64_t ni_max = int64_t(scratch_budget(c) / 2 / (per_pair * size_t(nj)));
+    if (ni_max < 1) ni_max = 1;
+    if (ni_max > N1) ni_max = N1;
+    if (ni_max > 65535) ni_max = 65535;
+    int64_t ngroups = int64_t(scratch_budget(c) / 2 / slot);
+    if (ngroups > 8192) ngroups = 8192;
+    if (ngroups > ni_max * nj) ngroups = ni_max * nj;
+    if (ngroups < PW) ngroups = PW;
+    ngroups = (ngroups + PW - 1) / PW * PW;
+    void *lat, *scr;
+    CHK(ensure(c, B_GR5, per_pair * size_t(nj) * size_t(ni_max) + 64, &lat));
+    CHK(ensure(c, B_GR6, slot * size_t(ngroups) + 64, &scr));
+    LamContractArgs K;
+    memset(&K, 0, sizeof(K));
+    K.X = X; K.Y = Y; K.L1 = L1; K.L2 = L2; K.d = d; K.kind = p->base_kernel; K.mode = mode == MODE_INC ? MODE_PT_DIFF : mode;
+    K.p0 = p->base_params[0]; K.p1 = p->base_params[1]; K.diag = diag ? 1 : 0;
+    WaveHoArgs A;
+    memset(&A, 0, sizeof(A));
+    A.G = Gup; A.gm = gm; A.gi = gi; A.gj = gj; A.N2 = int(N2); A.diag = diag ? 1 : 0;
+    A.R1 = R1; A.R2 = R2; A.M = M; A.scratch = static_cast<double*>(scr);
+    for (int64_t i0 = 0; i0 < N1; i0 += ni_max) {
+        const int64_t ni = (N1 - i0 < ni_max) ? N1 - i0 : ni_max;
+        const int64_t npairs = ni * nj, P = npairs * int64_t(cells);
+        double* const dmat = static_cast<double*>(lat);
+        double* const lam = dmat + P;
+        const HoBlock B{i0, ni, diag ? i0 : 0, nj, diag ? 1 : 0};
+        hipLaunchKernelGGL(ho_dm_kernel, dim3(grid_for(P)), dim3(256), 0, c->stream, X, Y, L1, L2, d, int(p->base_kernel), mode == MODE_PT_NODIFF ? 1 : 0,
+                           K.p0, K.p1, B, R1, R2, dmat);
+        HIPCHK(c, hipGetLastError());
+        A.dM = dmat; A.lam = lam; A.pair0 = i0 * nj; A.npairs = npairs;
+        int64_t ng = npairs < ngroups ? npairs : ngroups;
+        ng = (ng + PW - 1) / PW * PW;
+        A.ngroups = int(ng);
+        const hipError_t e = fn(A, int(ng / PW), c->stream);
+        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_wave_ho_kernel launch failed: %s", hipGetErrorString(e));
+        K.lam = lam; K.i0 = i0; K.ni = ni; K.j0 = B.j0; K.nj = nj;
+        auto slices = [](int64_t targets, int64_t partners) {
+            int64_t s = (CONTRACT_BLOCKS + targets - 1) / targets;
+            if (s > partners) s = partners;
+            if (s > 1024) s = 1024;
+            return s < 1 ? int64_t(1) : s;
+        };
+        K.gT = gX; K.gbase = gbase;
+        K.nslices = int(diag ? 1 : slices(ni, nj));
+        int blk = L1 >= 256 ? 256 : int((L1 + 63) / 64 * 64);
+        CHK(launch_contract<0>(c, DP, dim3(unsigned(ni), unsigned(K.nslices)), blk, sizeof(double) * size_t(L2) * (DP + 1), K));
+        K.gT = (diag || sym) ? gX : gY; K.gbase = nullptr;
+        K.nslices = int(diag ? 1 : slices(nj, ni));
+        blk = L2 >= 256 ? 256 : int((L2 + 63) / 64 * 64);
+        CHK(launch_contract<1>(c, DP, dim3(unsigned(diag ? ni : nj), unsigned(K.nslices)), blk, sizeof(double) * size_t(L1) * (DP + 1), K));
+    }
+    *done = true;
+    return GPSIG_OK;
+}
+
 // ---- higher-order algorithm (order > 1): lattice operations over blocks of pairs (grad_ho_kernels.hpp) + lam_contract_kernel ----
 int seq_grad_ho(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2,
                 int d, bool diag, bool sym, const double* Gup, double* gX, double* gY, double* gbase) {
@@ -555,6 +639,11 @@ int seq_grad_ho(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, const dou
     CHK(zero_async(c, gX, sizeof(double) * size_t(N1) * L1 * d));
     if (!diag && !sym) CHK(zero_async(c, gY, sizeof(double) * size_t(N2) * L2 * d));
     if (R1 <= 0 || R2 <= 0) return GPSIG_OK;
+    {
+        bool fused = false;
+        CHK(seq_grad_ho_wave(c, p, DP, mode, X, Y, N1, N2, L1, L2, d, diag, sym, Gup, gX, gY, gbase, &fused));
+        if (fused) return GPSIG_OK;
+    }
     auto dm_of = [&](int m) { return m < D ? m : D; };
     // slots: dM | R_m[r][s] for m = 2 .. M-1 | two grids of adjoints | two temporaries | Lam
     std::vector<int> roff(M + 1, 0);
@@ -946,7 +1035,7 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     CHK(grad_check(c, p, &d, &DP, 4096));
     // wide state spaces (wide_api.hip): beyond the tile kernel's 8 columns, or wherever built when the option says so
     // (higher orders: at any width -- the tile kernel's reverse pass is first-order, the older kernels go through scratch memory operation by operation)
-    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8 || (p->order > 1 && p->num_levels > 1 && c->wide != 0));
+    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8 || (p->order > 1 && p->num_levels > 1 && c->wide != 0 && !tvs_grad_tile_ho_available(c, p, d, L, increments)));
     if (DP == 0 && !wide) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns here (got %d)", d);
     if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
     if (N > 0x7fffffff || T > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 items");
@@ -1291,7 +1380,7 @@ int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* c, const gpsig_params* p, const v
     int d, DP;
     CHK(grad_check(c, p, &d, &DP, 4096));
     // (higher orders: at any width -- the tile kernel's reverse pass is first-order, the older kernels go through scratch memory operation by operation)
-    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8 || (p->order > 1 && p->num_levels > 1 && c->wide != 0));
+    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8 || (p->order > 1 && p->num_levels > 1 && c->wide != 0 && !tvs_grad_tile_ho_available(c, p, d, L, increments)));
     if (DP == 0 && !wide) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns here (got %d)", d);
     if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
     if (N > 0x7fffffff || T > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 items");

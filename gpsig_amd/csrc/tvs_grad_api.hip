@@ -13,6 +13,7 @@ TvsGradTileLaunchFn tvs_grad_tile_lookup_m3(int, int, bool);
 TvsGradTileLaunchFn tvs_grad_tile_lookup_m4(int, int, bool);
 TvsGradTileLaunchFn tvs_grad_tile_lookup_m5(int, int, bool);
 TvsGradTileLaunchFn tvs_grad_tile_lookup_m6(int, int, bool);
+TvsGradTileLaunchFn tvs_grad_tile_lookup_ho(int M, int D, bool paired);      // tvs_grad_tile_inst_ho.hip: SignatureRBF, order > 1
 int tvs_tile_width(int d);
 
 static TvsGradTileLaunchFn tvs_grad_tile_lookup(int M, int D, int kind, bool paired) {
@@ -34,6 +35,17 @@ static __global__ void tvs_grad_sum_kernel(const double* __restrict__ part, int6
     if (threadIdx.x == 0) out[0] += s;
 }
 
+// does the tile kernel hold a higher-order instance for this call?  (grad_api.hip prefers it to the wide route's chains at these widths)
+bool tvs_grad_tile_ho_available(const gpsig_ctx* c, const gpsig_params* p, int d, int L, int increments) {
+    const int M = p->num_levels;
+    if (!(p->order > 1 && M > 1) || p->base_kernel != GPSIG_BASE_RBF || (p->order < M ? p->order : M) > TVSG_MAX_ORDER) return false;
+    if (c->grad_impl != 0 || c->tvs_grad_tile == 0) return false;
+    const int D = tvs_tile_width(d);
+    if (D == 0 || !tvs_grad_tile_lookup_ho(M, D, increments != 0)) return false;
+    const int rec_elems = (L * D + L + TVSG_REC_ALIGN - 1) / TVSG_REC_ALIGN * TVSG_REC_ALIGN;
+    return tvs_grad_tile_lds_bytes(D, rec_elems, true) <= 64 * 1024;
+}
+
 // Z (lt, T, E_in, d), X (N, L, d) on the device, already scaled; gZ, gX overwritten; gb: 2 doubles on the device ([0] accumulated) or NULL.
 // fac == NULL: G (M+1, T, N) is the upstream gradient of the level array.  fac (N, M+1): G (T, N) is the upstream gradient of the
 // weighted level sum  sum_m fac[n][m] level_m[t][n],  and gfac (N, M+1) receives the gradient with respect to the factors.
@@ -42,14 +54,15 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
                          int L, int increments, const double* fac, const double* aux, double* gZ, double* gX, double* gfac, double* gb, size_t budget, bool* done) {
     *done = false;
     const int M = p->num_levels, lt = M * (M + 1) / 2;
-    if (p->order > 1 && M > 1) return GPSIG_OK;
+    const bool ho = p->order > 1 && M > 1;
+    if (ho && (p->base_kernel != GPSIG_BASE_RBF || (p->order < M ? p->order : M) > TVSG_MAX_ORDER)) return GPSIG_OK;
     const int D = tvs_tile_width(d);
     if (D == 0 || M > 6 || Tn < 1 || N < 1) return GPSIG_OK;
     const int kind = p->base_kernel == GPSIG_BASE_LINEAR ? BASE_LINEAR : (p->base_kernel == GPSIG_BASE_RBF ? BASE_RBF : -1);
     const bool collapse = increments && kind == BASE_LINEAR;              // <x, z1> - <x, z0> = <x, z1 - z0>
     const bool paired = increments && !collapse;
     const int E = paired ? 2 : 1;
-    TvsGradTileLaunchFn fn = tvs_grad_tile_lookup(M, D, kind, paired);
+    TvsGradTileLaunchFn fn = ho ? tvs_grad_tile_lookup_ho(M, D, paired) : tvs_grad_tile_lookup(M, D, kind, paired);
     if (!fn) return GPSIG_OK;
     const int NR = tvs_grad_tile_roles(M, kind);
     const int rec_elems = (L * D + L + TVSG_REC_ALIGN - 1) / TVSG_REC_ALIGN * TVSG_REC_ALIGN;
@@ -112,7 +125,7 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
         A.gbp = gbp ? static_cast<double*>(gbp) + r0 * TB * NR : nullptr;
         A.N = n1 - n0; A.Tn = Tn; A.Tpad = Tpad;
         A.L = L; A.d = d; A.kind = p->base_kernel; A.difference = p->difference; A.M = M;
-        A.run = int(run); A.rec_elems = rec_elems;
+        A.run = int(run); A.rec_elems = rec_elems; A.order = p->order < M ? p->order : M;
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
         HIPCHK(c, fn(A, dim3(unsigned(TB), unsigned(nr), unsigned(NR)), lds, c->stream));
         const int64_t rows = (n1 - n0) * L;

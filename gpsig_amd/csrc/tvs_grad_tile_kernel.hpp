@@ -58,8 +58,10 @@ struct TvsGradTileArgs {
     int32_t L, d, kind, difference, M;
     int32_t run;         // sequences per workgroup
     int32_t rec_elems;   // multiple of TVSG_REC_ALIGN
+    int32_t order;       // HO instances: min(order, num_levels) of the higher-order chains (signature_algs.py:129-160), <= TVSG_MAX_ORDER
     double p0, p1;
 };
+constexpr int TVSG_MAX_ORDER = 4;
 
 // roles (level subsets, one workgroup each): at most four components per role where the levels allow it -- z, d/dz and the chain state
 // of four components at six features fit the 256 registers of two wavefronts per SIMD; one wavefront per SIMD issues float64
@@ -99,7 +101,12 @@ struct TvsgCoef<BASE_RBF> { double k; };       // wz = k, vx = vz = -k
 template <>
 struct TvsgCoef<BASE_LINEAR> { double k; };    // wz = 1, vx = vz = 0
 
-template <int M, int D, int KIND, bool PAIRED, int MASK>
+// HO: the higher-order chains (signature_algs.py:129-160) at a run-time order.  Between time steps the state is the first-order one (the running
+// totals U_j of chain j); within a step chain j splits by repeat count, r_j[0] = m_j U_{j-1}, r_j[l] = m_j r_{j-1}[l-1] / (l+1), U_j += sum_l r_j[l].
+// The reverse step rebuilds the r of the step from the totals before it (ascending in j), then runs the adjoints down:
+//   dL/dr_j[l] = W_j + m_{j+1} / (l+2) dL/dr_{j+1}[l+1],   dL/dm_j = dL/dr_j[0] U_{j-1} + sum_{l>=1} dL/dr_j[l] r_{j-1}[l-1] / (l+1),   W_{j-1} += m_j dL/dr_j[0]
+// (wide_kernels.hpp: wide_chain_bwd holds the same step for the wide route).
+template <int M, int D, int KIND, bool PAIRED, int MASK, bool HO = false>
 struct TvsGradWave {
     static constexpr int NC = tvs_mask_comps(MASK);
     static constexpr int MASK_ = MASK;
@@ -206,6 +213,29 @@ struct TvsGradWave {
             for (int i = 1; i <= M; ++i) {
                 if (!((MASK >> i) & 1)) continue;
                 const int c0 = tvs_local_off(MASK, i);
+                if constexpr (HO) {
+                    if (i > 1) {
+                        constexpr int O = TVSG_MAX_ORDER;
+                        double rp[O], uold = u[c0];
+                        rp[0] = dm[c0];
+                        u[c0] += dm[c0];
+#pragma unroll
+                        for (int j = 1; j < i; ++j) {
+                            double rc[O], tot = dm[c0 + j] * uold;
+                            rc[0] = tot;
+#pragma unroll
+                            for (int l = 1; l < O; ++l) {
+                                rc[l] = (l <= j && l < A.order) ? (dm[c0 + j] * (1.0 / double(l + 1))) * rp[l - 1] : 0.0;
+                                tot += rc[l];
+                            }
+                            uold = u[c0 + j];
+                            u[c0 + j] += tot;
+#pragma unroll
+                            for (int l = 0; l < O; ++l) rp[l] = rc[l];
+                        }
+                        continue;
+                    }
+                }
 #pragma unroll
                 for (int j = i - 1; j >= 1; --j) u[c0 + j] = fma(dm[c0 + j], u[c0 + j - 1], u[c0 + j]);
                 u[c0] += dm[c0];
@@ -269,6 +299,56 @@ struct TvsGradWave {
         emit(time, gx);
     }
 
+    // one reverse step of level i's higher-order chains (components c0 .. c0 + i - 1): u back to the totals before the step, gm = dL/dm, w updated
+    __device__ __forceinline__ void undo_ho(const int i, const int c0, const double (&m)[NC], double (&gm)[NC], double up, int order) {
+        constexpr int O = TVSG_MAX_ORDER;
+        double r[M][O], ub[M];
+        ub[0] = u[c0] - m[c0];
+#pragma unroll
+        for (int l = 0; l < O; ++l) r[0][l] = l == 0 ? m[c0] : 0.0;
+#pragma unroll
+        for (int j = 1; j < M; ++j) {
+            if (j >= i) break;
+            double tot = m[c0 + j] * ub[j - 1];
+            r[j][0] = tot;
+#pragma unroll
+            for (int l = 1; l < O; ++l) {
+                r[j][l] = (l <= j && l < order) ? (m[c0 + j] * (1.0 / double(l + 1))) * r[j - 1][l - 1] : 0.0;
+                tot += r[j][l];
+            }
+            ub[j] = u[c0 + j] - tot;
+        }
+        double gn[O], add[M];
+#pragma unroll
+        for (int l = 0; l < O; ++l) gn[l] = 0.0;
+#pragma unroll
+        for (int j = M - 1; j >= 0; --j) {
+            if (j >= i) continue;
+            const double wj = (j == i - 1) ? up : w[c0 + (j + 1 < i ? j + 1 : j)];
+            double gr[O];
+#pragma unroll
+            for (int l = 0; l < O; ++l) {
+                const bool live = l <= j && l < order;
+                const bool upl = j + 1 < i && l + 1 < O && l + 1 < order;
+                gr[l] = live ? wj + (upl ? (m[c0 + (j + 1 < i ? j + 1 : j)] * (1.0 / double(l + 2))) * gn[l + 1 < O ? l + 1 : l] : 0.0) : 0.0;
+            }
+            double gd = gr[0] * (j >= 1 ? ub[j >= 1 ? j - 1 : 0] : 1.0);
+#pragma unroll
+            for (int l = 1; l < O; ++l)
+                if (j >= 1) gd = fma(gr[l] * (1.0 / double(l + 1)), r[j >= 1 ? j - 1 : 0][l - 1], gd);
+            gm[c0 + j] = gd;
+            add[j] = m[c0 + j] * gr[0];
+#pragma unroll
+            for (int l = 0; l < O; ++l) gn[l] = gr[l];
+        }
+#pragma unroll
+        for (int j = 1; j < M; ++j)
+            if (j < i) w[c0 + j] += add[j];
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            if (j < i) u[c0 + j] = ub[j];
+    }
+
     // backward sweep over one sequence; cup[i] = upstream gradient of level i for this (tensor, sequence)
     template <class Emit>
     __device__ __forceinline__ void backward(const TvsGradTileArgs& A, const double* __restrict__ rec, const double* __restrict__ etab,
@@ -288,6 +368,12 @@ struct TvsGradWave {
             for (int i = 1; i <= M; ++i) {
                 if (!((MASK >> i) & 1)) continue;
                 const int c0 = tvs_local_off(MASK, i);
+                if constexpr (HO) {
+                    if (i > 1) {
+                        undo_ho(i, c0, m, gm, cup[i], A.order);
+                        continue;
+                    }
+                }
                 // undo, lowest chain first: afterwards u[c0 + j] = u_{j+1}[tau-1]; `below` = u_j[tau-1], what m_j[tau] was multiplied with
                 double below = 1.0;
 #pragma unroll
@@ -324,7 +410,7 @@ struct TvsGradWave {
 #define TVSG_WAVES_PER_EU 2
 #endif
 // grid (tensor blocks, runs, roles); block 64
-template <int M, int D, int KIND, bool PAIRED>
+template <int M, int D, int KIND, bool PAIRED, bool HO = false>
 __global__ __launch_bounds__(64, TVSG_WAVES_PER_EU) void tvs_grad_tile_kernel(const TvsGradTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tvsg_smem[];
     constexpr int NR = tvs_grad_tile_roles(M, KIND);
@@ -442,7 +528,7 @@ __global__ __launch_bounds__(64, TVSG_WAVES_PER_EU) void tvs_grad_tile_kernel(co
 
 #define TVSG_ROLE(r_)                                                          \
     {                                                                          \
-        TvsGradWave<M, D, KIND, PAIRED, tvs_level_mask(M, NR, r_)> W;          \
+        TvsGradWave<M, D, KIND, PAIRED, tvs_level_mask(M, NR, r_), HO> W;         \
         run_role(W);                                                           \
     }
     if constexpr (NR == 1) {

@@ -1571,3 +1571,50 @@ def test_forward_pass_keeps_what_its_reverse_pass_needs(base, M, N1, N2, L1, L2,
         assert rel(gX, res[1][0]) < 1e-9
         if Y is not None:
             assert rel(gY, tY.grad) < 1e-6 and rel(gY, res[1][1]) < 1e-9
+
+
+@pytest.mark.parametrize("M,order,N1,N2,L1,L2,d,kind", [(4, 2, 9, 4, 7, 6, 3, "cross"), (4, 2, 40, 40, 50, 50, 6, "diag"), (5, 2, 6, 5, 33, 70, 4, "cross"),
+                                                       (3, 3, 7, 7, 12, 12, 2, "sym"), (4, 3, 5, 6, 20, 31, 5, "cross"), (4, 4, 30, 30, 18, 18, 3, "diag"),
+                                                       (5, 4, 4, 3, 9, 140, 2, "cross"), (2, 2, 6, 6, 8, 8, 20, "sym"), (5, 5, 3, 4, 11, 10, 3, "cross"),
+                                                       (3, 2, 2, 2, 5, 300, 2, "cross"), (4, 2, 300, 300, 6, 6, 3, "diag")])
+@pytest.mark.parametrize("base", ["rbf", "matern32", "linear"])
+def test_higher_order_reverse_pass_in_two_sweeps(M, order, N1, N2, L1, L2, d, kind, base):
+    """Round 6: the reverse pass of the higher-order sequence recursion (signature_algs.py:37-74) as two skewed sweeps of a wavefront per pair
+    (csrc/grad_wave_ho_kernel.hpp: the prefixes a cell reads kept per cell, the cell's grids rebuilt from them, the adjoints run down the levels)
+    against autograd of the oracle and against the lattice operations it replaces (option grad_impl = 1): every lane shape (lattices of 5 .. 299
+    columns), orders 2-4 (and order >= num_levels), 2-5 levels, several pair blocks and several rounds of the pair groups."""
+    if base != "rbf" and (M, order, kind) in ((5, 4, "cross"), (2, 2, "sym"), (3, 2, "cross"), (4, 2, "diag")) and N1 != 40:
+        pytest.skip("a sample of the shapes is enough for the other families")
+    rng = np.random.default_rng(7 * M + order + L2)
+    ctx = _host_ctx()
+    for difference in ((True, False) if L2 < 100 else (True,)):
+        X = rng.standard_normal((N1, L1, d)) * (0.5 if difference else 0.15)
+        Y = rng.standard_normal((N2, L2, d)) * (0.5 if difference else 0.15) if kind == "cross" else None
+        G = rng.standard_normal((M + 1, N1) if kind == "diag" else (M + 1, N1, N2 if kind == "cross" else N1))
+        kt = _t_kern(base, d, M, difference=difference, order=order)
+        tX = torch.tensor(X, requires_grad=True)
+        tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+        lev = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
+        (lev * torch.tensor(G)).sum().backward()
+        keep = []
+        p = _params(base, d, M, difference, keep, order=order)
+        got = {}
+        try:
+            for impl, mb in ((0, 4096), (0, 1), (1, 4096)):
+                ctx.set_option("grad_impl", impl)
+                ctx.set_option("grad_scratch_mb", mb)
+                gX, gY, gb = np.full_like(X, np.nan), (None if Y is None else np.full_like(Y, np.nan)), np.zeros(2)
+                if kind == "diag":
+                    ctx.call("gpsig_seq_diag_levels_grad", p, _vp(X), N1, L1, _vp(G), _vp(gX), gb.ctypes.data_as(_P))
+                else:
+                    ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2 if Y is not None else N1, L1, L2 if Y is not None else L1,
+                             _vp(G), _vp(gX), _vp(gY), gb.ctypes.data_as(_P))
+                got[(impl, mb)] = (gX, gY)
+        finally:
+            ctx.set_option("grad_impl", 0)
+            ctx.set_option("grad_scratch_mb", 4096)
+        for key, (gX, gY) in got.items():
+            assert rel(gX, tX.grad) < 1e-9, (difference, key, rel(gX, tX.grad))
+            if Y is not None:
+                assert rel(gY, tY.grad) < 1e-9, (difference, key, rel(gY, tY.grad))
+        assert rel(got[(0, 4096)][0], got[(1, 4096)][0]) < 1e-11

@@ -318,13 +318,15 @@ def test_wide_tensor_gram_levels_and_gradient(M, T, d, base):
         ctx.set_option("wide", -1)
 
 
-@pytest.mark.parametrize("M,order,T,N,L,d", [(4, 2, 70, 9, 13, 12), (4, 4, 33, 6, 9, 28), (3, 2, 20, 5, 11, 6), (5, 3, 40, 4, 8, 46), (6, 4, 12, 5, 7, 10), (2, 2, 64, 7, 5, 3), (8, 2, 9, 3, 6, 14)])
+@pytest.mark.parametrize("M,order,T,N,L,d", [(4, 2, 70, 9, 13, 12), (4, 4, 33, 6, 9, 28), (3, 2, 20, 5, 11, 6), (5, 3, 40, 4, 8, 46), (6, 4, 12, 5, 7, 10), (2, 2, 64, 7, 5, 3), (8, 2, 9, 3, 6, 14),
+                                            (4, 3, 70, 9, 13, 4), (5, 4, 33, 6, 9, 8), (4, 2, 140, 17, 12, 6), (5, 2, 20, 5, 10, 5), (3, 3, 65, 70, 6, 7)])
 @pytest.mark.parametrize("base", ["rbf", "matern32"])
 def test_wide_higher_order_chains_and_gradient(M, order, T, N, L, d, base):
     """Round 6: the higher-order tensor-vs-sequence chains (signature_algs.py:129-160, order <= 4) on the wide route: values, and the reverse pass that
-    rebuilds a step's repeat-count vectors from the chain totals -- levels and the weighted sum, against autograd of the oracle; at <= 8 columns too
-    (there the forward pass is the tile kernel's higher-order instance, the reverse pass this one, continuing from its chain totals)."""
-    if base != "rbf" and (M, order) in ((2, 2), (8, 2), (6, 4)):
+    rebuilds a step's repeat-count vectors from the chain totals -- levels and the weighted sum, against autograd of the oracle; at <= 8 columns too,
+    where SignatureRBF with 3-5 levels runs the tile kernels' higher-order instances (tvs_tile_inst_ho.hip forward, tvs_grad_tile_inst_ho.hip reverse, continuing
+    from the forward's chain totals) unless the wide route is forced: both are checked."""
+    if base != "rbf" and ((M, order) in ((2, 2), (8, 2), (6, 4)) or d in (4, 5, 7, 8)):
         pytest.skip("a sample of the shapes is enough for the Matern families")
     from gpsig_amd import _lib
     rng = np.random.default_rng(10 * M + order + d)

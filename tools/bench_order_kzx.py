@@ -38,3 +38,33 @@ for cls, base in ((kernels.SignatureLinear, "linear"), (kernels.SignatureRBF, "r
             err = float(np.abs(res[-1][1][:16, :32].cpu().numpy() - want).max() / np.abs(want).max())
             print(cls.__name__, "increments" if inc else "plain", "order", order, "%.2f ms" % res[-1][0],
                   ("(older mappings %.2f ms)" % res[0][0]) if 0 in res else "", "vs oracle %.1e" % err, flush=True)
+
+# the reverse pass (round 6: the wide route's chains of every order; the forward pass that feeds it is the tile kernel's where one is built)
+from gpsig_amd import autodiff  # noqa: E402
+print("\nforward + backward of Kzx (autodiff module; gradient w.r.t. the inducing tensors, the lengthscales and the variances):")
+for inc in (False, True):
+    base_t = None
+    for order in (1, 2, 4):
+        mod = autodiff.SignatureKernelModule(kernels.SignatureRBF(L * d, d, M, order=order), device="cuda:0")
+        Zp = (Zi if inc else Z).clone().requires_grad_(True)
+
+        def fwd():
+            with torch.no_grad():
+                return mod.K_tens_vs_seq(Zp, X, increments=inc)
+
+        def fb():
+            Zp.grad = None
+            mod.zero_grad(set_to_none=True)
+            o = mod.K_tens_vs_seq(Zp, X, increments=inc)
+            (o * o).sum().backward()
+        ts = []
+        for fn in (fwd, fb):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 3 * 1e3)
+        base_t = base_t or ts
+        print("SignatureRBF", "increments" if inc else "plain", "order", order, "forward %.2f ms, forward + backward %.2f ms (%.1f x its forward; %.2f x order 1's)"
+              % (ts[0], ts[1], ts[1] / ts[0], ts[1] / base_t[1]), flush=True)

@@ -38,3 +38,39 @@ for M in (5, 4):
             base = res[1][0]
         print(f"num_levels={M} order={order}: exact instances {res[1][0]:8.2f} ms ({res[1][0] / base:5.2f} x order 1)   run-time instances {res[0][0]:8.2f} ms   "
               f"difference {diff:.1e}   vs oracle {err:.1e}", flush=True)
+
+# the reverse pass (round 6: two sweeps of a wavefront per pair at order > 1, csrc/grad_wave_ho_kernel.hpp; option grad_impl = 1: the lattice operations it replaces)
+from gpsig_amd import autodiff  # noqa: E402
+print("\nforward and forward + backward of K(X) (autodiff module, gradient w.r.t. X, lengthscales, variances), N = 512, L = 64, d = 8, num_levels = 4:")
+Ng, M = 512, 4
+Xg = X[:Ng].clone().requires_grad_(True)
+for order in (1, 2, 4):
+    mod = autodiff.SignatureKernelModule(kernels.SignatureRBF(L * d, d, M, order=order, lengthscales=np.sqrt(d)), device="cuda:0")
+    out = {}
+    for impl in ((0, 1) if order > 1 else (0,)):
+        ctx.set_option("grad_impl", impl)
+
+        def fwd():
+            with torch.no_grad():
+                return mod.K(Xg)
+
+        def fb():
+            Xg.grad = None
+            mod.zero_grad(set_to_none=True)
+            o = mod.K(Xg)
+            (o * o).sum().backward()
+        ts = []
+        for fn in (fwd, fb):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 3 * 1e3)
+        out[impl] = (ts, Xg.grad.clone())
+    ctx.set_option("grad_impl", 0)
+    ts = out[0][0]
+    extra = ""
+    if 1 in out:
+        extra = "   lattice operations: %.1f ms, gradients differ by %.1e" % (out[1][0][1], float((out[0][1] - out[1][1]).abs().max() / out[1][1].abs().max()))
+    print(f"order={order}: forward {ts[0]:7.2f} ms, forward + backward {ts[1]:8.2f} ms ({ts[1] / ts[0]:.1f} x its forward){extra}", flush=True)
