@@ -13,8 +13,11 @@
 
 namespace gpsig {
 typedef hipError_t (*WaveLaunchFn)(const WaveGradArgs&, int, hipStream_t);
-typedef hipError_t (*WaveHoLaunchFn)(const WaveHoArgs&, int, hipStream_t);
-WaveHoLaunchFn wave_ho_lookup(int G, int C, int order, int M);      // grad_wave_ho_inst.hip
+typedef hipError_t (*WaveHoLaunchFn)(const WaveHoArgs&, int, size_t, hipStream_t);
+WaveHoLaunchFn wave_ho_lookup(int G, int C, int order, int M);      // grad_wave_ho_inst.hip: prefixes through an HBM slot
+WaveHoLaunchFn wave_ho_undo_lookup_g16(int C, int order, int M);    // grad_wave_ho_inst_u16.hip / _u64.hip: scratch-free
+WaveHoLaunchFn wave_ho_undo_lookup_g64(int C, int order, int M);
+struct HoSweeps { WaveHoLaunchFn fn; int G, C; size_t lds, slot; };
 WaveLaunchFn wave_lookup_inc(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptd(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptn(int G, int C, int DP, int LQ);
@@ -54,11 +57,55 @@ int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
 bool wide_tens_available(const gpsig_ctx* c, const gpsig_params* p, int64_t Tn);
 int wide_tens_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Z, int64_t Tn, int increments, const double* G, double* gZ);
 bool wide_lat_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L2);
+bool wide_lat_ho_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L2);
 int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag,
                       const double* G, double* gX, double* gY);
 }  // namespace gpsig
 
 using namespace gpsig;
+
+// ---- the sweeps of the higher-order reverse pass (grad_wave_ho_kernel.hpp), shared by the point route below and the wide route (wide_api.hip) ----
+namespace gpsig {
+bool ho_sweeps_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, HoSweeps* hs) {
+    const int M = p->num_levels, order = p->order < M ? p->order : M;
+    if ((c->grad_impl != 0 && c->grad_impl != 3) || order < 2 || R1 < 1 || R2 < 1) return false;
+    static const int shapes[][2] = {{16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8}};
+    hs->fn = nullptr;
+    for (auto& sh : shapes) {
+        if (sh[0] * sh[1] < R2) continue;
+        hs->G = sh[0]; hs->C = sh[1];
+        hs->lds = wave_ho_undo_lds(hs->G, R1, order, M);
+        if (c->grad_impl == 0 && hs->lds <= 64 * 1024)
+            hs->fn = hs->G == 16 ? wave_ho_undo_lookup_g16(hs->C, order, M) : wave_ho_undo_lookup_g64(hs->C, order, M);
+        if (!hs->fn) { hs->fn = wave_ho_lookup(hs->G, hs->C, order, M); hs->lds = 0; }
+        break;
+    }
+    if (!hs->fn) return false;
+    hs->slot = hs->lds == 0 ? sizeof(double) * size_t(ho_stash_words(order, M)) * size_t(R1 + hs->G - 1) * hs->G * hs->C : 0;
+    return true;
+}
+
+// dM (npairs, R1, R2) -> lam (npairs, R1, R2); G[level * gm + i * gi + j * gj] with (i, j) = divmod(pair0 + pair, N2) (diag: i = j = pair0 + pair)
+int ho_sweeps_launch(gpsig_ctx* c, const HoSweeps& hs, int M, int R1, int R2, const double* dM, double* lam, const double* G, int64_t gm, int64_t gi,
+                     int64_t gj, int64_t N2, bool diag, int64_t pair0, int64_t npairs) {
+    const int PW = 64 / hs.G;
+    int64_t ngroups = hs.slot ? int64_t((size_t(c->grad_scratch_mb > 0 ? c->grad_scratch_mb : 4096) << 20) / 2 / hs.slot) : 16384;
+    if (ngroups > (hs.slot ? 8192 : 16384)) ngroups = hs.slot ? 8192 : 16384;
+    if (ngroups > npairs) ngroups = npairs;
+    if (ngroups < PW) ngroups = PW;
+    ngroups = (ngroups + PW - 1) / PW * PW;
+    void* scr;
+    CHK(ensure(c, B_GR6, hs.slot * size_t(ngroups) + 64, &scr));
+    WaveHoArgs A;
+    memset(&A, 0, sizeof(A));
+    A.G = G; A.gm = gm; A.gi = gi; A.gj = gj; A.N2 = int(N2); A.diag = diag ? 1 : 0;
+    A.R1 = R1; A.R2 = R2; A.M = M; A.scratch = static_cast<double*>(scr);
+    A.dM = dM; A.lam = lam; A.pair0 = pair0; A.npairs = npairs; A.ngroups = int(ngroups);
+    const hipError_t e = hs.fn(A, int(ngroups / PW), hs.lds, c->stream);
+    if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "higher-order sweeps: launch failed: %s", hipGetErrorString(e));
+    return GPSIG_OK;
+}
+}  // namespace gpsig
 
 namespace {
 
@@ -551,51 +598,31 @@ int seq_grad_fused_stash(gpsig_ctx* c, const gpsig_params* p, int DP, const doub
     return GPSIG_OK;
 }
 
-// ---- higher-order algorithm (order > 1), fused: ho_dm_kernel -> seq_grad_wave_ho_kernel (both sweeps of a pair in one wavefront,
-// grad_wave_ho_kernel.hpp) -> lam_contract_kernel.  num_levels <= 5, min(order, num_levels) <= 4, lattices of at most 512 columns;
-// option grad_impl != 0 keeps the lattice operations below (the A/B reference of the tests).
+// ---- higher-order algorithm (order > 1), fused: ho_dm_kernel -> both sweeps of a pair in one wavefront (grad_wave_ho_kernel.hpp) ->
+// lam_contract_kernel.  num_levels <= 5, min(order, num_levels) <= 4, lattices of at most 512 columns.  The scratch-free sweeps where their
+// row totals fit LDS (option grad_impl = 0), otherwise -- or with grad_impl = 3 -- the sweeps with the prefixes in an HBM slot per pair group;
+// any other grad_impl keeps the lattice operations below (the A/B reference of the tests).
 int seq_grad_ho_wave(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, const double* X, const double* Y, int64_t N1, int64_t N2, int L1, int L2,
                      int d, bool diag, bool sym, const double* Gup, double* gX, double* gY, double* gbase, bool* done) {
     *done = false;
-    const int M = p->num_levels, order = p->order < M ? p->order : M, dr = mode == MODE_PT_NODIFF ? 0 : 1;
+    const int M = p->num_levels, dr = mode == MODE_PT_NODIFF ? 0 : 1;
     const int R1 = L1 - dr, R2 = L2 - dr;
-    if (c->grad_impl != 0 || order < 2) return GPSIG_OK;
-    static const int shapes[][2] = {{16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8}};
-    WaveHoLaunchFn fn = nullptr;
-    int G = 0, C = 0;
-    for (auto& sh : shapes) {
-        if (sh[0] * sh[1] < R2) continue;
-        fn = wave_ho_lookup(sh[0], sh[1], order, M);
-        G = sh[0]; C = sh[1];
-        break;
-    }
-    if (!fn) return GPSIG_OK;
-    const int PW = 64 / G, TF = R1 + G - 1;
+    HoSweeps hs;
+    if (!ho_sweeps_plan(c, p, R1, R2, &hs)) return GPSIG_OK;
     const size_t cells = size_t(R1) * R2, per_pair = sizeof(double) * cells * 2;           // dM and Lam
-    const size_t slot = sizeof(double) * size_t(ho_stash_words(order, M)) * TF * G * C;
     const int64_t gm = diag ? N1 : N1 * N2, gi = diag ? 1 : N2, gj = diag ? 0 : 1;
     const int64_t nj = diag ? 1 : N2;
-    // half of the budget for the lattices of a pair block, half for the slots of the groups in flight
-    int64_t ni_max = int64_t(scratch_budget(c) / 2 / (per_pair * size_t(nj)));
+    // slot kernel: half of the budget for the lattices of a pair block, half for the slots of the groups in flight
+    int64_t ni_max = int64_t(scratch_budget(c) / (hs.slot ? 2 : 1) / (per_pair * size_t(nj)));
     if (ni_max < 1) ni_max = 1;
     if (ni_max > N1) ni_max = N1;
     if (ni_max > 65535) ni_max = 65535;
-    int64_t ngroups = int64_t(scratch_budget(c) / 2 / slot);
-    if (ngroups > 8192) ngroups = 8192;
-    if (ngroups > ni_max * nj) ngroups = ni_max * nj;
-    if (ngroups < PW) ngroups = PW;
-    ngroups = (ngroups + PW - 1) / PW * PW;
-    void *lat, *scr;
+    void* lat;
     CHK(ensure(c, B_GR5, per_pair * size_t(nj) * size_t(ni_max) + 64, &lat));
-    CHK(ensure(c, B_GR6, slot * size_t(ngroups) + 64, &scr));
     LamContractArgs K;
     memset(&K, 0, sizeof(K));
     K.X = X; K.Y = Y; K.L1 = L1; K.L2 = L2; K.d = d; K.kind = p->base_kernel; K.mode = mode == MODE_INC ? MODE_PT_DIFF : mode;
     K.p0 = p->base_params[0]; K.p1 = p->base_params[1]; K.diag = diag ? 1 : 0;
-    WaveHoArgs A;
-    memset(&A, 0, sizeof(A));
-    A.G = Gup; A.gm = gm; A.gi = gi; A.gj = gj; A.N2 = int(N2); A.diag = diag ? 1 : 0;
-    A.R1 = R1; A.R2 = R2; A.M = M; A.scratch = static_cast<double*>(scr);
     for (int64_t i0 = 0; i0 < N1; i0 += ni_max) {
         const int64_t ni = (N1 - i0 < ni_max) ? N1 - i0 : ni_max;
         const int64_t npairs = ni * nj, P = npairs * int64_t(cells);
@@ -605,12 +632,7 @@ int seq_grad_ho_wave(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, cons
         hipLaunchKernelGGL(ho_dm_kernel, dim3(grid_for(P)), dim3(256), 0, c->stream, X, Y, L1, L2, d, int(p->base_kernel), mode == MODE_PT_NODIFF ? 1 : 0,
                            K.p0, K.p1, B, R1, R2, dmat);
         HIPCHK(c, hipGetLastError());
-        A.dM = dmat; A.lam = lam; A.pair0 = i0 * nj; A.npairs = npairs;
-        int64_t ng = npairs < ngroups ? npairs : ngroups;
-        ng = (ng + PW - 1) / PW * PW;
-        A.ngroups = int(ng);
-        const hipError_t e = fn(A, int(ng / PW), c->stream);
-        if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "seq_grad_wave_ho_kernel launch failed: %s", hipGetErrorString(e));
+        CHK(ho_sweeps_launch(c, hs, M, R1, R2, dmat, lam, Gup, gm, gi, gj, N2, diag, i0 * nj, npairs));
         K.lam = lam; K.i0 = i0; K.ni = ni; K.j0 = B.j0; K.nj = nj;
         auto slices = [](int64_t targets, int64_t partners) {
             int64_t s = (CONTRACT_BLOCKS + targets - 1) / targets;
@@ -760,7 +782,8 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     CHK(grad_check(c, p, &d, &DP, 4096));
     if (N1 < 0 || N2 < 0 || L1 < 1 || L2 < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
     // wide route (wide_api.hip): argument lattices by dgemm, both sweeps by one wavefront per lattice, the adjoint contracted back by dgemms
-    const bool wide_ok = N1 > 0 && N2 > 0 && wide_lat_available(c, p, L1, (diag || Y == nullptr) ? L1 : L2);
+    const bool wide_ho = N1 > 0 && N2 > 0 && wide_lat_ho_available(c, p, L1, (diag || Y == nullptr) ? L1 : L2);      // order > 1: the reverse pass only
+    const bool wide_ok = wide_ho || (N1 > 0 && N2 > 0 && wide_lat_available(c, p, L1, (diag || Y == nullptr) ? L1 : L2));
     if (DP == 0 && !wide_ok) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns here (got %d)", d);
     if (N1 > 0x7fffffff || N2 > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 sequences");
     const bool sym = !diag && Y == nullptr;
@@ -800,7 +823,9 @@ int seq_grad(gpsig_ctx* c, const gpsig_params* p, const void* X, const void* Y, 
     // where the fused reverse kernel is not built (more than 16 columns, long register sides) the wide route takes over; option wide = 1: wherever built
     // (beyond 8 columns, or where no wavefront kernel is built at all: at <= 8 columns the scratch-free sweeps measured 10-25 % ahead on the
     // reference's shapes -- profiles/r06_ab_small_widths.txt; grad_impl != 0: A/B runs of the exact-shape kernels)
-    if (wide_ok && (c->wide == 1 || DP == 0 || (!ffn && c->grad_impl == 0 && (d > 8 || (!w2x && !lfn && !wfn))))) {
+    // (higher order: the point route's dM and contraction kernels cost more than the sweeps -- ho_dm_kernel evaluates every kappa four times with the
+    // library's exp --, so the wide route's dgemms take RBF and the Matern families at every width)
+    if (wide_ok && (c->wide == 1 || DP == 0 || wide_ho || (!ffn && c->grad_impl == 0 && (d > 8 || (!w2x && !lfn && !wfn))))) {
         CHK(wide_lat_backward(c, p, d, static_cast<const double*>(dX), static_cast<const double*>((diag || sym) ? nullptr : dY), N1, N2, L1, L2, diag,
                               static_cast<const double*>(dG), static_cast<double*>(dgX), static_cast<double*>(dgY)));
         CHK(out_done(c, gX, dgX, xb));

@@ -384,4 +384,271 @@ __global__ void __launch_bounds__(64) seq_grad_wave_ho_kernel(const WaveHoArgs A
     }
 }
 
+// =====================================================================================================================================
+// Scratch-free form (the default where its row totals fit LDS).  The backward sweep does not read the prefixes back from memory, it UNDOES
+// the forward sweep row by row, level by level within a cell (as WaveUndo does for the first-order recursion, grad_wave_core.hpp):
+//     CP_j[k][a][b] = (column sum through row a) - col_j[k][a][b]                                      -- the lane's own accumulator
+//     RP_j[k][a][b] = rowtot(row_j[k])[a] - row_j[k][a][b] - (suffix beyond b)                         -- suffixes arrive from the right neighbour
+//     P_j[a][b]     = Q_j[a][b-1] - (rowtot(tot_j)[a] - suffix from b on),   Q_j[a][.] undone to Q_j[a-1][.] the same way
+// where level j's cell values (tot, col, row) come from its grid, rebuilt from level j-1's prefixes AT THE SAME CELL -- so the undo runs up
+// the levels inside a cell, then the adjoints run down.  The forward sweep leaves only the row totals (sum_j (1 + nk_j) words per lattice
+// row, in LDS) and every lane's final accumulators (registers).  num_levels and the order are compile-time parameters here: no branches
+// around loads, no dead levels in the register file.  HBM traffic per pair: M[a][b] twice, Lam once.
+template <int O, int MM> constexpr int ho_rowtot_words() {
+    int s = 0;
+    for (int j = 1; j < MM; ++j) s += 1 + ho_nk<O>(j);
+    return s;
+}
+template <int O> constexpr int ho_rowtot_off(int j) {
+    int s = 0;
+    for (int i = 1; i < j; ++i) s += 1 + ho_nk<O>(i);
+    return s;
+}
+
+template <int C, int MM, int O>
+struct WaveHoUndo {
+    static constexpr int LQ = MM - 1;
+    double qf[LQ][C], qfg[LQ], cpf[LQ][O - 1][C];     // forward accumulators, undone row by row
+    double qb[LQ][C], qbg[LQ], scp[LQ][O - 1][C];     // adjoint accumulators (as WaveHoBwd)
+    double sv[LQ], sw[LQ][O - 1];                     // adjoint row suffixes for the left neighbour
+    double ft[LQ], fr[LQ][O - 1];                     // forward row suffixes (tot_j, row_j[k]) from this lane's first column on
+
+    __device__ __forceinline__ void init(const WaveHoFwd<C, LQ, O>& fw) {
+#pragma unroll
+        for (int j = 0; j < LQ; ++j) {
+            qfg[j] = fw.qg[j];
+            qbg[j] = sv[j] = ft[j] = 0.0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { qf[j][c] = fw.q[j][c]; qb[j][c] = 0.0; }
+#pragma unroll
+            for (int k = 0; k < O - 1; ++k) {
+                sw[j][k] = fr[j][k] = 0.0;
+#pragma unroll
+                for (int c = 0; c < C; ++c) { cpf[j][k][c] = fw.cp[j][k][c]; scp[j][k][c] = 0.0; }
+            }
+        }
+    }
+    // tT[j], tR[j][k]: totals of lattice row a.  it, ir / iv, iw: the right neighbour's ft, fr / sv, sw of ITS previous step.
+    __device__ __forceinline__ void step(const double (&dm)[C], const double (&clev)[MM + 1], const double (&tT)[LQ], const double (&tR)[LQ][O - 1],
+                                         const double (&it)[LQ], const double (&ir)[LQ][O - 1], const double (&iv)[LQ], const double (&iw)[LQ][O - 1],
+                                         bool first_row, bool first_lane, double (&lam)[C]) {
+        double spv[LQ][C], rv[LQ], rw[LQ][O - 1], ut[LQ], ur[LQ][O - 1];
+#pragma unroll
+        for (int p = 0; p < LQ; ++p) {
+            rv[p] = iv[p]; ut[p] = it[p];
+#pragma unroll
+            for (int k = 0; k < O - 1; ++k) { rw[p][k] = iw[p][k]; ur[p][k] = ir[p][k]; }
+#pragma unroll
+            for (int c = 0; c < C; ++c) spv[p][c] = c < C - 1 ? qb[p][c < C - 1 ? c + 1 : c] : qbg[p];
+        }
+#pragma unroll
+        for (int c = C - 1; c >= 0; --c) {
+            const bool edge = first_row || (first_lane && c == 0);
+            double P[LQ], CP[LQ][O - 1], RP[LQ][O - 1], R[LQ][O][O];
+            R[0][0][0] = dm[c];
+            ho_static_for<1, LQ + 1>([&](auto jc) {
+                constexpr int J = decltype(jc)::value, dj = ho_dim<O>(J), nk = ho_nk<O>(J);
+                double tot = 0.0;
+#pragma unroll
+                for (int r = 0; r < dj; ++r)
+#pragma unroll
+                    for (int k = 0; k < dj; ++k) tot += R[J - 1][r][k];
+#pragma unroll
+                for (int k = 0; k < O - 1; ++k) {
+                    if (k < nk) {
+                        double sc = 0.0, sr = 0.0;
+#pragma unroll
+                        for (int r = 0; r < dj; ++r) { sc += R[J - 1][r][k]; sr += R[J - 1][k][r]; }
+                        cpf[J - 1][k][c] -= sc;
+                        CP[J - 1][k] = first_row ? 0.0 : cpf[J - 1][k][c];
+                        RP[J - 1][k] = (first_lane && c == 0) ? 0.0 : (tR[J - 1][k] - sr) - ur[J - 1][k];
+                        ur[J - 1][k] += sr;
+                    } else {
+                        CP[J - 1][k] = 0.0; RP[J - 1][k] = 0.0;
+                    }
+                }
+                qf[J - 1][c] -= tT[J - 1] - ut[J - 1];                       // Q_J[a-1][b_c]: minus the row's prefix through b_c
+                ut[J - 1] += tot;
+                const double left = c == 0 ? qfg[J - 1] : qf[J - 1][c > 0 ? c - 1 : 0];
+                P[J - 1] = edge ? 0.0 : left - (tT[J - 1] - ut[J - 1]);      // Q_J[a-1][b_c - 1]
+                if constexpr (J < LQ) ho_next_grid<O, J>(dm[c], P[J - 1], CP[J - 1], RP[J - 1], R[J - 1], R[J]);
+            });
+            double l = 0.0, gn[O][O];
+#pragma unroll
+            for (int r = 0; r < O; ++r)
+#pragma unroll
+                for (int k = 0; k < O; ++k) gn[r][k] = 0.0;
+            ho_static_for_down<MM, 0>([&](auto ic) {
+                constexpr int I = decltype(ic)::value, di = ho_dim<O>(I), dn = ho_dim<O>(I + 1);
+                double gc[O][O];
+#pragma unroll
+                for (int r = 0; r < di; ++r)
+#pragma unroll
+                    for (int k = 0; k < di; ++k) {
+                        double g = clev[I];
+                        if constexpr (I < MM) {
+                            g += spv[I - 1][c];
+                            if (k + 1 < dn) g += scp[I - 1][k < O - 1 ? k : 0][c];
+                            if (r + 1 < dn) g += rw[I - 1][r < O - 1 ? r : 0];
+                            if (r + 1 < dn && k + 1 < dn)
+                                g = fma(dm[c] * (1.0 / double((r + 2) * (k + 2))), gn[r + 1 < O ? r + 1 : 0][k + 1 < O ? k + 1 : 0], g);
+                        }
+                        gc[r][k] = g;
+                    }
+                if constexpr (I == 1) {
+                    l += gc[0][0];
+                } else {
+                    double s = gc[0][0] * P[I - 2];
+#pragma unroll
+                    for (int k = 1; k < di; ++k) {
+                        s = fma(gc[0][k] * (1.0 / double(k + 1)), CP[I - 2][k - 1], s);
+                        s = fma(gc[k][0] * (1.0 / double(k + 1)), RP[I - 2][k - 1], s);
+                    }
+#pragma unroll
+                    for (int r = 1; r < di; ++r)
+#pragma unroll
+                        for (int k = 1; k < di; ++k) s = fma(gc[r][k] * (1.0 / double((r + 1) * (k + 1))), R[I - 2][r - 1][k - 1], s);
+                    l += s;
+                }
+                if constexpr (I < MM) {
+                    rv[I - 1] = fma(dm[c], gn[0][0], rv[I - 1]);
+                    qb[I - 1][c] += rv[I - 1];
+#pragma unroll
+                    for (int k = 0; k + 1 < dn; ++k) {
+                        scp[I - 1][k][c] = fma(dm[c] * (1.0 / double(k + 2)), gn[0][k + 1], scp[I - 1][k][c]);
+                        rw[I - 1][k] = fma(dm[c] * (1.0 / double(k + 2)), gn[k + 1][0], rw[I - 1][k]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < di; ++r)
+#pragma unroll
+                    for (int k = 0; k < di; ++k) gn[r][k] = gc[r][k];
+            });
+            lam[c] = l;
+        }
+#pragma unroll
+        for (int p = 0; p < LQ; ++p) {
+            qfg[p] -= tT[p] - ut[p];
+            qbg[p] += iv[p];
+            sv[p] = rv[p]; ft[p] = ut[p];
+#pragma unroll
+            for (int k = 0; k < O - 1; ++k) { sw[p][k] = rw[p][k]; fr[p][k] = ur[p][k]; }
+        }
+    }
+};
+
+inline size_t wave_ho_undo_lds(int G, int R1, int order, int M) {
+    int w = 0;
+    for (int j = 1; j < M; ++j) w += 1 + (((j + 1) < order ? (j + 1) : order) - 1);
+    return sizeof(double) * size_t(64 / G) * size_t(R1) * size_t(w);
+}
+
+// grid: ngroups / (64 / G) workgroups of one wavefront; dynamic LDS: wave_ho_undo_lds
+template <int G, int C, int MM, int O>
+__global__ void __launch_bounds__(64) seq_grad_wave_ho_undo_kernel(const WaveHoArgs A) {
+    extern __shared__ double ho_rowtot[];
+    constexpr int PW = 64 / G, LQ = MM - 1, RW = ho_rowtot_words<O, MM>();
+    const int lane = threadIdx.x, lam = lane % G;
+    const int grp = blockIdx.x * PW + lane / G;
+    const int R1 = A.R1, R2 = A.R2;
+    const int TF = R1 + G - 1;
+    double* const rt = ho_rowtot + size_t(lane / G) * R1 * RW;
+    const int64_t rounds = (A.npairs + A.ngroups - 1) / A.ngroups;
+    int nvalid = R2 - C * lam;
+    nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
+
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t pp = rd * A.ngroups + grp;
+        const bool have = pp < A.npairs;
+        const int64_t pg = A.pair0 + (have ? pp : 0);
+        const int64_t i = A.diag ? pg : pg / A.N2, j = A.diag ? pg : pg % A.N2;
+        const double* const dmp = A.dM + size_t(have ? pp : 0) * R1 * R2;
+        auto load_dm = [&](int a, double (&dm)[C]) {                   // no branch around the loads: clamped addresses, values selected
+            const bool ok = a >= 0 && a < R1;
+            const size_t row = size_t(ok ? a : 0) * R2;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int b = C * lam + c;
+                const double v = dmp[row + (b < R2 ? b : R2 - 1)];
+                dm[c] = (ok && c < nvalid) ? v : 0.0;
+            }
+        };
+        double clev[MM + 1];
+#pragma unroll
+        for (int p = 0; p <= MM; ++p) clev[p] = (have && p >= 1) ? A.G[p * A.gm + i * A.gi + j * A.gj] : 0.0;
+
+        WaveHoUndo<C, MM, O> bw;
+        {
+            WaveHoFwd<C, LQ, O> fw;
+            fw.reset();
+            double dcur[C];
+            load_dm(0 - lam, dcur);
+            for (int t = 0; t < TF; ++t) {
+                double ct[LQ], cr[LQ][O - 1], dnext[C];
+#pragma unroll
+                for (int m = 0; m < LQ; ++m) {
+                    ct[m] = wave_from_left<G>(fw.st[m]);
+#pragma unroll
+                    for (int k = 0; k < O - 1; ++k) cr[m][k] = wave_from_left<G>(fw.sr[m][k]);
+                }
+                const int a = t - lam;
+                load_dm(a + 1, dnext);
+                if (a >= 0 && a < R1) {
+                    fw.step(dcur, ct, cr, MM, [](int, int, double) {});
+                    if (lam == G - 1) {                                  // the last lane's end-of-chunk prefixes are the row's totals
+                        ho_static_for<1, LQ + 1>([&](auto jc) {
+                            constexpr int J = decltype(jc)::value, nk = ho_nk<O>(J), off = ho_rowtot_off<O>(J);
+                            rt[a * RW + off] = fw.st[J - 1];
+#pragma unroll
+                            for (int k = 0; k < nk; ++k) rt[a * RW + off + 1 + k] = fw.sr[J - 1][k];
+                        });
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) dcur[c] = dnext[c];
+            }
+            bw.init(fw);
+        }
+        __syncthreads();                                                 // one wavefront: the row totals are in LDS
+        {
+            double* const lamrow = A.lam + size_t(have ? pp : 0) * R1 * R2 + C * lam;
+            double dcur[C];
+            load_dm(R1 - 1 + (G - 1 - lam), dcur);
+            for (int u = 0; u < TF; ++u) {
+                double it[LQ], ir[LQ][O - 1], iv[LQ], iw[LQ][O - 1], dnext[C];
+#pragma unroll
+                for (int p = 0; p < LQ; ++p) {
+                    it[p] = wave_from_right<G>(bw.ft[p]);
+                    iv[p] = wave_from_right<G>(bw.sv[p]);
+#pragma unroll
+                    for (int k = 0; k < O - 1; ++k) {
+                        ir[p][k] = wave_from_right<G>(bw.fr[p][k]);
+                        iw[p][k] = wave_from_right<G>(bw.sw[p][k]);
+                    }
+                }
+                const int a = R1 - 1 - (u - (G - 1 - lam));
+                load_dm(a - 1, dnext);
+                if (a >= 0 && a < R1) {
+                    double tT[LQ], tR[LQ][O - 1], lv[C];
+                    ho_static_for<1, LQ + 1>([&](auto jc) {
+                        constexpr int J = decltype(jc)::value, nk = ho_nk<O>(J), off = ho_rowtot_off<O>(J);
+                        tT[J - 1] = rt[a * RW + off];
+#pragma unroll
+                        for (int k = 0; k < O - 1; ++k) tR[J - 1][k] = k < nk ? rt[a * RW + off + 1 + (k < nk ? k : 0)] : 0.0;
+                    });
+                    bw.step(dcur, clev, tT, tR, it, ir, iv, iw, a == 0, lam == 0, lv);
+                    if (have) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            if (c < nvalid) lamrow[size_t(a) * R2 + c] = lv[c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) dcur[c] = dnext[c];
+            }
+        }
+        __syncthreads();                                                 // the next pair rewrites the row totals
+    }
+}
+
 }  // namespace gpsig

@@ -17,6 +17,14 @@ bool solver_dgemm(void** handle_slot, hipStream_t stream, bool transA, bool tran
 bool solver_dgemm_batched(void** handle_slot, hipStream_t stream, bool transA, bool transB, int m, int n, int k, double alpha, const double* A, int lda,
                           int64_t sa, const double* B, int ldb, int64_t sb, double beta, double* C, int ldc, int64_t sc, int batch, std::string* err);
 
+// grad_api.hip: the sweeps of the higher-order reverse pass (grad_wave_ho_kernel.hpp)
+struct WaveHoArgs;
+typedef hipError_t (*WaveHoLaunchFn)(const WaveHoArgs&, int, size_t, hipStream_t);
+struct HoSweeps { WaveHoLaunchFn fn; int G, C; size_t lds, slot; };
+bool ho_sweeps_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, HoSweeps* hs);
+int ho_sweeps_launch(gpsig_ctx* c, const HoSweeps& hs, int M, int R1, int R2, const double* dM, double* lam, const double* G, int64_t gm, int64_t gi,
+                     int64_t gj, int64_t N2, bool diag, int64_t pair0, int64_t npairs);
+
 namespace {
 
 bool wide_kind(int base_kernel) {
@@ -271,6 +279,15 @@ bool wide_lat_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L
     return L1 >= 1 && L2 >= 1 && L2 - dr <= WIDE_LAT_MAX_COLS;
 }
 
+// the reverse pass of the HIGHER-ORDER recursion on this route: argument lattices by dgemm -> dM lattices (wide_lattice_dm_kernel) -> both sweeps of a
+// pair in one wavefront (grad_wave_ho_kernel.hpp) -> the adjoint contracted back by dgemms; any number of columns
+bool wide_lat_ho_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L2) {
+    if (c->wide == 0 || c->capturing || !wide_kind(p->base_kernel) || !(p->order > 1 && p->num_levels > 1)) return false;
+    const int dr = p->difference ? 1 : 0;
+    HoSweeps hs;
+    return L1 >= 1 && L2 >= 1 && ho_sweeps_plan(c, p, L1 - dr, L2 - dr, &hs);
+}
+
 namespace {
 
 struct LatPlan {
@@ -351,10 +368,15 @@ int wide_lat_forward(gpsig_ctx* c, const gpsig_params* p, int d, const double* X
 int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag,
                       const double* G, double* gX, double* gY) {
     LatPlan pl;
-    CHK(lat_plan(c, p, d, Xs, Ys, N1, N2, L1, L2, diag, 2, &pl));
+    const bool ho = p->order > 1 && p->num_levels > 1;
+    HoSweeps hs;
+    if (ho && !ho_sweeps_plan(c, p, L1 - (p->difference ? 1 : 0), L2 - (p->difference ? 1 : 0), &hs))
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "no higher-order sweeps for this shape");
+    CHK(lat_plan(c, p, d, Xs, Ys, N1, N2, L1, L2, diag, ho ? 3 : 2, &pl));
     const int M = p->num_levels, DA = pl.DA;
     const int64_t per_i = int64_t(L1) * L2 * (diag ? 1 : N2);
-    void *arg, *lam, *gxl, *gxr, *scr;
+    void *arg, *lam, *gxl, *gxr, *scr, *dmat = nullptr;
+    if (ho) CHK(ensure(c, B_WD6, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &dmat));
     CHK(ensure(c, B_WD2, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &arg));
     CHK(ensure(c, B_WD3, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &lam));
     CHK(ensure(c, B_WD4, sizeof(double) * size_t(N1) * L1 * DA + 64, &gxl));
@@ -366,8 +388,9 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     if (groups < 1) groups = 1;
     if (groups > Pmax) groups = Pmax;
     if (groups > 4096) groups = 4096;
+    if (ho) groups = 1;                   // (the higher-order sweeps bring their own slots, if any)
     CHK(ensure(c, B_WD7, per_group * size_t(groups) + 64, &scr));
-    WideLatKernel fn = lat_kernel(M, pl.C, true, p->base_kernel == GPSIG_BASE_RBF);
+    WideLatKernel fn = ho ? nullptr : lat_kernel(M, pl.C, true, p->base_kernel == GPSIG_BASE_RBF);
     for (int64_t i0 = 0; i0 < N1; i0 += pl.chunk_i) {
         const int64_t ni = N1 - i0 < pl.chunk_i ? N1 - i0 : pl.chunk_i;
         CHK(lat_arguments(c, pl, i0, ni, N2, L1, L2, diag, static_cast<double*>(arg)));
@@ -380,7 +403,15 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         A.scratch = static_cast<double*>(scr); A.lam = static_cast<double*>(lam);
         const int64_t ng = A.P < groups ? A.P : groups;
         A.ngroups = int(ng);
-        if (pl.R1 > 0 && pl.R2 > 0) {
+        if (ho && pl.R1 > 0 && pl.R2 > 0) {
+            if (p->base_kernel == GPSIG_BASE_RBF)
+                hipLaunchKernelGGL(wide_lattice_dm_kernel<true>, dim3(grid_for(A.P * int64_t(pl.R1) * pl.R2)), dim3(256), 0, c->stream, A, static_cast<double*>(dmat));
+            else
+                hipLaunchKernelGGL(wide_lattice_dm_kernel<false>, dim3(grid_for(A.P * int64_t(pl.R1) * pl.R2)), dim3(256), 0, c->stream, A, static_cast<double*>(dmat));
+            HIPCHK(c, hipGetLastError());
+            CHK(ho_sweeps_launch(c, hs, M, pl.R1, pl.R2, static_cast<const double*>(dmat), static_cast<double*>(lam), G, pl.Ptot, diag ? 1 : N2, diag ? 0 : 1,
+                                 diag ? 1 : N2, diag, diag ? i0 : i0 * N2, A.P));
+        } else if (pl.R1 > 0 && pl.R2 > 0) {
             hipLaunchKernelGGL(fn, dim3(unsigned(ng)), dim3(64), 0, c->stream, A);
             HIPCHK(c, hipGetLastError());
         }

@@ -763,6 +763,26 @@ __global__ void wide_lattice_adjoint_kernel(const WideLatArgs A, double* __restr
     }
 }
 
+// dM[pair][a][b] (signature_algs.py:26 / :56) from the argument lattices, for the sweeps that read it from memory (the higher-order reverse pass,
+// grad_wave_ho_kernel.hpp).  One thread per lattice cell.
+template <bool RBF>
+__global__ void wide_lattice_dm_kernel(const WideLatArgs A, double* __restrict__ dM) {
+    __shared__ double etab[EXP_TAB_N];
+    exp_tab_fill(etab, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const WideKap K = wide_kap(A.kind, etab);
+    const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr;
+    const int64_t cells = int64_t(R1) * R2, total = A.P * cells;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t pp = idx / cells, pg = A.p0 + pp;
+        const int a = int((idx % cells) / R2), b = int(idx % R2);
+        const double* base = A.arg + (pg / A.N2) * A.si + (pg % A.N2) * A.sj + int64_t(a) * A.ld + b;
+        double v = wide_kappa<RBF>(K, base[0]);
+        if (dr) v = (wide_kappa<RBF>(K, base[A.ld + 1]) - wide_kappa<RBF>(K, base[A.ld])) - (wide_kappa<RBF>(K, base[1]) - v);
+        dM[idx] = v;
+    }
+}
+
 // g[r][f] = left-form chain rule of (gl, vl) [+ right-form chain rule of (gr, vr) where given: one array on both sides of the lattices]
 __global__ void wide_unaug_pair_kernel(const double* __restrict__ gl, const double* __restrict__ vl, const double* __restrict__ gr, const double* __restrict__ vr,
                                        int64_t rows, int d, double* __restrict__ g) {

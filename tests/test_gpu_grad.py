@@ -1580,8 +1580,9 @@ def test_forward_pass_keeps_what_its_reverse_pass_needs(base, M, N1, N2, L1, L2,
 @pytest.mark.parametrize("base", ["rbf", "matern32", "linear"])
 def test_higher_order_reverse_pass_in_two_sweeps(M, order, N1, N2, L1, L2, d, kind, base):
     """Round 6: the reverse pass of the higher-order sequence recursion (signature_algs.py:37-74) as two skewed sweeps of a wavefront per pair
-    (csrc/grad_wave_ho_kernel.hpp: the prefixes a cell reads kept per cell, the cell's grids rebuilt from them, the adjoints run down the levels)
-    against autograd of the oracle and against the lattice operations it replaces (option grad_impl = 1): every lane shape (lattices of 5 .. 299
+    (csrc/grad_wave_ho_kernel.hpp: the backward sweep undoes the forward one row by row and level by level within a cell, rebuilds the cell's grids,
+    runs the adjoints down the levels; option grad_impl = 3: the prefixes a cell reads kept per cell in an HBM slot instead)
+    against autograd of the oracle and against the lattice operations they replace (option grad_impl = 1): every lane shape (lattices of 5 .. 299
     columns), orders 2-4 (and order >= num_levels), 2-5 levels, several pair blocks and several rounds of the pair groups."""
     if base != "rbf" and (M, order, kind) in ((5, 4, "cross"), (2, 2, "sym"), (3, 2, "cross"), (4, 2, "diag")) and N1 != 40:
         pytest.skip("a sample of the shapes is enough for the other families")
@@ -1600,21 +1601,27 @@ def test_higher_order_reverse_pass_in_two_sweeps(M, order, N1, N2, L1, L2, d, ki
         p = _params(base, d, M, difference, keep, order=order)
         got = {}
         try:
-            for impl, mb in ((0, 4096), (0, 1), (1, 4096)):
+            # scratch-free sweeps / sweeps through HBM slots / lattice operations; wide = 0: the point route's dM and contraction kernels around the
+            # sweeps instead of the wide route's dgemms (which take RBF and the Matern families)
+            for impl, mb, wide in ((0, 4096, -1), (0, 1, -1), (3, 4096, -1), (3, 1, 0), (0, 4096, 0), (1, 4096, -1)):
                 ctx.set_option("grad_impl", impl)
                 ctx.set_option("grad_scratch_mb", mb)
+                ctx.set_option("wide", wide)
+                ctx.set_option("wide_chunk_mb", 1 if mb == 1 else 0)
                 gX, gY, gb = np.full_like(X, np.nan), (None if Y is None else np.full_like(Y, np.nan)), np.zeros(2)
                 if kind == "diag":
                     ctx.call("gpsig_seq_diag_levels_grad", p, _vp(X), N1, L1, _vp(G), _vp(gX), gb.ctypes.data_as(_P))
                 else:
                     ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, N2 if Y is not None else N1, L1, L2 if Y is not None else L1,
                              _vp(G), _vp(gX), _vp(gY), gb.ctypes.data_as(_P))
-                got[(impl, mb)] = (gX, gY)
+                got[(impl, mb, wide)] = (gX, gY)
         finally:
             ctx.set_option("grad_impl", 0)
             ctx.set_option("grad_scratch_mb", 4096)
+            ctx.set_option("wide", -1)
+            ctx.set_option("wide_chunk_mb", 0)
         for key, (gX, gY) in got.items():
             assert rel(gX, tX.grad) < 1e-9, (difference, key, rel(gX, tX.grad))
             if Y is not None:
                 assert rel(gY, tY.grad) < 1e-9, (difference, key, rel(gY, tY.grad))
-        assert rel(got[(0, 4096)][0], got[(1, 4096)][0]) < 1e-11
+        assert rel(got[(0, 4096, -1)][0], got[(1, 4096, -1)][0]) < 1e-10
