@@ -110,6 +110,39 @@ int wide_tvs_rows(gpsig_ctx* c, const ScaleParams& sz, const double* Z, const do
 }
 
 // a pair of events from the context's pool around the timed launches (gpsig_timing_*; as api.hip: timing_begin_any)
+// The two contractions of a reverse pass with the adjoint array W (R, CW) of an argument array  arg = XA (R, DA) ZA^T (CW, DA):
+//     gXA (R, DA) = W ZA   (overwritten),      gZA (CW, DA) (+)= W^T XA   (accumulated over the chunks of R).
+int contract_both(gpsig_ctx* c, const double* W, const double* XA, const double* ZA, int64_t R, int64_t CW, int DA, bool accumulate, double* gXA, double* gZA) {
+    if (DA <= 32 && c->wide_contract != 0) {
+        // narrow rows: both contractions in one hand-written pass over W (wide_contract_kernel); rocBLAS spreads such skinny products over too few tiles
+        const int64_t strips = (R + 63) / 64, ntiles = (CW + 63) / 64;
+        const int DAP = DA <= 16 ? 16 : 32;
+        int64_t groups = (4096 + strips - 1) / strips;            // about four wavefronts per SIMD
+        if (groups > ntiles) groups = ntiles;
+        if (groups < 1) groups = 1;
+        void *part, *gxp;
+        CHK(ensure(c, B_WD9, sizeof(double) * size_t(strips) * CW * DAP + 64, &part));
+        CHK(ensure(c, B_WD8, sizeof(double) * size_t(groups) * R * DAP + 64, &gxp));
+        WideContractArgs K;
+        memset(&K, 0, sizeof(K));
+        K.W = W; K.XA = XA; K.ZA = ZA; K.R = R; K.CW = CW; K.DA = DA; K.groups = int(groups);
+        K.gXA_part = static_cast<double*>(gxp); K.part = static_cast<double*>(part);
+        const dim3 gridc(unsigned(strips < 65535 ? strips : 65535), unsigned(groups));
+        if (DAP == 16) hipLaunchKernelGGL(wide_contract_kernel<16>, gridc, dim3(64), 0, c->stream, K);
+        else hipLaunchKernelGGL(wide_contract_kernel<32>, gridc, dim3(64), 0, c->stream, K);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(wide_contract_reduce_kernel, dim3(grid_for(CW * DA)), dim3(256), 0, c->stream, static_cast<const double*>(part), strips, CW, DA, DAP,
+                           accumulate ? 1 : 0, gZA);
+        hipLaunchKernelGGL(wide_contract_reduce_kernel, dim3(grid_for(R * DA)), dim3(256), 0, c->stream, static_cast<const double*>(gxp), groups, R, DA, DAP, 0, gXA);
+        HIPCHK(c, hipGetLastError());
+        return GPSIG_OK;
+    }
+    // gZA (CW, DA) += W^T XA:  column-major gZA^T (DA x CW) = XA_cm (DA x R) W_cm^T (R x CW)
+    CHK(dgemm(c, false, true, DA, CW, R, XA, DA, W, CW, accumulate ? 1.0 : 0.0, gZA, DA));
+    // gXA (R, DA) = W ZA:   column-major gXA^T (DA x R) = ZA_cm (DA x CW) W_cm (CW x R)
+    return dgemm(c, false, false, DA, R, CW, ZA, DA, W, CW, 0.0, gXA, DA);
+}
+
 int wide_timing_begin(gpsig_ctx* c, hipEvent_t* e0, hipEvent_t* e1, bool* on) {
     *on = false;
     if (c->capturing || c->ev_used + 2 > 8192) return GPSIG_OK;
@@ -223,35 +256,8 @@ int wide_tvs_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         if (E == 2) { if (rbf) hipLaunchKernelGGL((wide_tvs_bwd_kernel<2, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_bwd_kernel<2, false>), grid, dim3(64), 0, c->stream, A); }
         else { if (rbf) hipLaunchKernelGGL((wide_tvs_bwd_kernel<1, true>), grid, dim3(64), 0, c->stream, A); else hipLaunchKernelGGL((wide_tvs_bwd_kernel<1, false>), grid, dim3(64), 0, c->stream, A); }
         HIPCHK(c, hipGetLastError());
-        if (DA <= 32 && c->wide_contract != 0) {
-            // narrow rows: both contractions in one hand-written pass over W (wide_contract_kernel); rocBLAS spreads such skinny products over too few tiles
-            const int64_t Rr = nc * int64_t(L), strips = (Rr + 63) / 64, ntiles = (CW + 63) / 64;
-            const int DAP = DA <= 16 ? 16 : 32;
-            int64_t groups = (4096 + strips - 1) / strips;            // about four wavefronts per SIMD
-            if (groups > ntiles) groups = ntiles;
-            if (groups < 1) groups = 1;
-            void *part, *gxp;
-            CHK(ensure(c, B_WD9, sizeof(double) * size_t(strips) * CW * DAP + 64, &part));
-            CHK(ensure(c, B_WD8, sizeof(double) * size_t(groups) * Rr * DAP + 64, &gxp));
-            WideContractArgs K;
-            memset(&K, 0, sizeof(K));
-            K.W = static_cast<const double*>(Wb); K.XA = XA + n0 * L * DA; K.ZA = ZA; K.R = Rr; K.CW = CW; K.DA = DA; K.groups = int(groups);
-            K.gXA_part = static_cast<double*>(gxp); K.part = static_cast<double*>(part);
-            const dim3 gridc(unsigned(strips < 65535 ? strips : 65535), unsigned(groups));
-            if (DAP == 16) hipLaunchKernelGGL(wide_contract_kernel<16>, gridc, dim3(64), 0, c->stream, K);
-            else hipLaunchKernelGGL(wide_contract_kernel<32>, gridc, dim3(64), 0, c->stream, K);
-            HIPCHK(c, hipGetLastError());
-            hipLaunchKernelGGL(wide_contract_reduce_kernel, dim3(grid_for(CW * DA)), dim3(256), 0, c->stream, static_cast<const double*>(part), strips, CW, DA, DAP,
-                               n0 > 0 ? 1 : 0, static_cast<double*>(gza));
-            hipLaunchKernelGGL(wide_contract_reduce_kernel, dim3(grid_for(Rr * DA)), dim3(256), 0, c->stream, static_cast<const double*>(gxp), groups, Rr, DA, DAP, 0,
-                               static_cast<double*>(gxa) + n0 * L * DA);
-            HIPCHK(c, hipGetLastError());
-        } else {
-            // gZA (CW, DA) += W^T XA_chunk:  column-major gZA^T (DA x CW) = XA_cm (DA x nc L) W_cm^T (nc L x CW)
-            CHK(dgemm(c, false, true, DA, CW, nc * L, XA + n0 * L * DA, DA, static_cast<const double*>(Wb), CW, n0 > 0 ? 1.0 : 0.0, static_cast<double*>(gza), DA));
-            // gXA_chunk (nc L, DA) = W ZA:   column-major gXA^T (DA x nc L) = ZA_cm (DA x CW) W_cm (CW x nc L)
-            CHK(dgemm(c, false, false, DA, nc * L, CW, ZA, DA, static_cast<const double*>(Wb), CW, 0.0, static_cast<double*>(gxa) + n0 * L * DA, DA));
-        }
+        CHK(contract_both(c, static_cast<const double*>(Wb), XA + n0 * L * DA, ZA, nc * int64_t(L), CW, DA, n0 > 0, static_cast<double*>(gxa) + n0 * L * DA,
+                          static_cast<double*>(gza)));
     }
     const int64_t zrows = int64_t(lt) * Tn * E;
     hipLaunchKernelGGL(wide_unaug_rows_kernel, dim3(grid_for(zrows * d)), dim3(256), 0, c->stream, static_cast<const double*>(gza), ZA, zrows, d, 0, lt, Tn,
@@ -429,8 +435,7 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
             CHK(dgemm_batched(c, false, true, DA, L2, L1, pl.XL + i0 * L1 * DA, DA, int64_t(L1) * DA, W, L2, int64_t(L1) * L2,
                               static_cast<double*>(gxr) + i0 * L2 * DA, DA, int64_t(L2) * DA, ni));
         } else {
-            CHK(dgemm(c, false, false, DA, ni * L1, N2 * L2, pl.XR, DA, W, N2 * L2, 0.0, gl, DA));
-            CHK(dgemm(c, false, true, DA, N2 * L2, ni * L1, pl.XL + i0 * L1 * DA, DA, W, N2 * L2, i0 > 0 ? 1.0 : 0.0, static_cast<double*>(gxr), DA));
+            CHK(contract_both(c, W, pl.XL + i0 * L1 * DA, pl.XR, ni * int64_t(L1), N2 * int64_t(L2), DA, i0 > 0, gl, static_cast<double*>(gxr)));
         }
     }
     // through the augmentation: left form into gX; right form into gX as well (one array on both sides) or into gY
