@@ -157,9 +157,16 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 map / difference / recursion kernels, behind the levels, weighted-sum, fused-evaluation entry points and their gradients.
  *                 -1 (default) where the exact-shape kernels are not built or lose: Kzx beyond 8 columns, the sequence lattices beyond
  *                 32 columns / their register sides (reverse pass: beyond 8 columns where no fused kernel is built), Kzz beyond 12 --
- *                 the reference's own run settings, benchmarks/run_gpsig_benchmarks.py:32; 0 never; 1 wherever built (float64, order 1,
- *                 RBF and the Matern families, at most 8 levels, lattices of at most 512 columns).  Not taken inside a graph capture.
- *   "wide_chunk_mb"  its argument chunk in HBM (0: a quarter of "grad_scratch_mb", 1 GB by default) */
+ *                 the reference's own run settings, benchmarks/run_gpsig_benchmarks.py:32; 0 never; 1 wherever built (float64,
+ *                 RBF and the Matern families, at most 8 levels, lattices of at most 512 columns; order 1, and at order > 1 the
+ *                 tensor-vs-sequence chains (orders <= 4) and the sequence lattices' reverse pass (<= 5 levels)).  Not taken inside
+ *                 a graph capture.
+ *   "wide_chunk_mb"  its argument chunk in HBM (0: "grad_scratch_mb", 4 GB by default: a latency-bound launch split in two takes twice as long)
+ *   "wide_contract"  1 (default): the two contractions of a reverse pass with the adjoint array (rows of at most 32 augmented columns) as one
+ *                 hand-written MFMA pass (wide_contract_kernel); 0: two rocBLAS dgemms (for A/B runs)
+ *   order > 1 and "grad_impl": the sequence recursion's reverse pass runs as two sweeps of a wavefront per pair (csrc/grad_wave_ho_kernel.hpp;
+ *                 <= 5 levels, min(order, levels) <= 4, lattices of <= 512 columns): 0 scratch-free where the row totals fit LDS, 3 with
+ *                 the prefixes in an HBM slot per pair group, any other value the lattice operations of rounds 2-5 (tests' A/B reference) */
 int gpsig_set_option(gpsig_ctx* ctx, const char* name, int value);
 /* HIP-event timing of the dominant kernel (the pair recursion) launched by the calls since the last
  * reset, measured on the ctx stream: total milliseconds and number of launches (the first 4096 timed

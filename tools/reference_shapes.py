@@ -59,7 +59,7 @@ def build(name, device, seed=0):
     Z = np.tile(Z[:, :, :, None, :], (1, 1, 1, NUM_LAGS + 1, 1)).reshape(lt, T, 2, -1)
     Z = Z + 0.4 * rng.standard_normal(Z.shape)
     ls = np.sqrt(d) * np.ones(d) * 0.7                                                            # ~ utils.py:88-98 on unit-scale data
-    kern = kernels.SignatureRBF(L * d, d, M, lengthscales=ls, num_lags=NUM_LAGS)
+    kern = kernels.SignatureRBF(L * d, d, M, lengthscales=ls, num_lags=NUM_LAGS, order=int(os.environ.get("RS_ORDER", "1")))      # RS_ORDER: beyond the reference's runs
     feat = iv.InducingTensors(Z, M, increments=True)
     if s["classes"] == 2:
         lik, latent, Y = likelihoods.Bernoulli(), 1, rng.integers(0, 2, size=(N, 1)).astype(np.float64)
