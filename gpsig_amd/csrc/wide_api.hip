@@ -73,7 +73,10 @@ int aug_rows(gpsig_ctx* c, const double* src, int64_t rows, int d, int right, do
 
 typedef void (*WideLatKernel)(const WideLatArgs);
 template <int LQ, bool RBF>
-WideLatKernel lat_kernel_of(int C, bool bwd) {
+WideLatKernel lat_kernel_of(int C, bool bwd, int NW) {
+    if (NW == 2) return bwd ? wide_lattice_bwd_kernel<1, LQ, RBF, 2> : wide_lattice_fwd_kernel<1, LQ, RBF, 2>;
+    if (NW == 4) return bwd ? wide_lattice_bwd_kernel<1, LQ, RBF, 4> : wide_lattice_fwd_kernel<1, LQ, RBF, 4>;
+    if (NW == 8) return bwd ? wide_lattice_bwd_kernel<1, LQ, RBF, 8> : wide_lattice_fwd_kernel<1, LQ, RBF, 8>;
     switch (C) {
         case 1: return bwd ? wide_lattice_bwd_kernel<1, LQ, RBF> : wide_lattice_fwd_kernel<1, LQ, RBF>;
         case 2: return bwd ? wide_lattice_bwd_kernel<2, LQ, RBF> : wide_lattice_fwd_kernel<2, LQ, RBF>;
@@ -81,10 +84,20 @@ WideLatKernel lat_kernel_of(int C, bool bwd) {
         default: return bwd ? wide_lattice_bwd_kernel<8, LQ, RBF> : wide_lattice_fwd_kernel<8, LQ, RBF>;
     }
 }
-// levels kept by a lane: 3 (num_levels <= 4) or 7; the RBF kernel at compile time, the Matern families at run time
-WideLatKernel lat_kernel(int M, int C, bool bwd, bool rbf) {
-    if (M <= 4) return rbf ? lat_kernel_of<3, true>(C, bwd) : lat_kernel_of<3, false>(C, bwd);
-    return rbf ? lat_kernel_of<7, true>(C, bwd) : lat_kernel_of<7, false>(C, bwd);
+// levels kept by a lane: 3 (num_levels <= 4) or 7; the RBF kernel at compile time, the Matern families at run time.  NW > 1: NW wavefronts per
+// lattice with one column per lane (C is ignored)
+WideLatKernel lat_kernel(int M, int C, bool bwd, bool rbf, int NW = 1) {
+    if (M <= 4) return rbf ? lat_kernel_of<3, true>(C, bwd, NW) : lat_kernel_of<3, false>(C, bwd, NW);
+    return rbf ? lat_kernel_of<7, true>(C, bwd, NW) : lat_kernel_of<7, false>(C, bwd, NW);
+}
+// wavefronts per lattice: a launch of few lattices of more than 256 columns spreads each lattice's columns over eight wavefronts of one column per
+// lane instead of eight columns per lane of one (NetFlow's / CMUsubject16's level diagonals, 50 / 23 lattices of 499 x 499: reverse pass 3.5 -> 3.2 / 2.9 ms;
+// at four and two columns per lane the barrier per step costs more than the shorter steps save: AUSLAN 0.74 -> 0.79).  Option wide_lat_waves: 0 never,
+// 1 wherever there are two or more columns per lane (the tests), -1 this rule
+int lat_waves(const gpsig_ctx* c, int C, int64_t lattices) {
+    if (C < 2 || c->wide_lat_waves == 0) return 1;
+    if (c->wide_lat_waves > 0) return C;
+    return (C == 8 && lattices <= 128) ? C : 1;
 }
 int lat_columns(int R2) { return R2 <= 64 ? 1 : (R2 <= 128 ? 2 : (R2 <= 256 ? 4 : 8)); }
 
@@ -344,7 +357,8 @@ int wide_lat_forward(gpsig_ctx* c, const gpsig_params* p, int d, const double* X
     const int M = p->num_levels;
     void* arg;
     CHK(ensure(c, B_WD2, sizeof(double) * size_t(pl.chunk_i) * L1 * L2 * size_t(diag ? 1 : N2) + 64, &arg));
-    WideLatKernel fn = lat_kernel(M, pl.C, false, p->base_kernel == GPSIG_BASE_RBF);
+    const int NW = lat_waves(c, pl.C, diag ? (N1 < pl.chunk_i ? N1 : pl.chunk_i) : (N1 < pl.chunk_i ? N1 : pl.chunk_i) * N2);
+    WideLatKernel fn = lat_kernel(M, pl.C, false, p->base_kernel == GPSIG_BASE_RBF, NW);
     hipEvent_t e0, e1;
     bool timed;
     CHK(wide_timing_begin(c, &e0, &e1, &timed));
@@ -357,7 +371,7 @@ int wide_lat_forward(gpsig_ctx* c, const gpsig_params* p, int d, const double* X
         A.P = diag ? ni : ni * N2; A.p0 = 0; A.Ptot = pl.Ptot;
         A.L1 = L1; A.L2 = L2; A.M = M; A.kind = p->base_kernel; A.difference = pl.dr;
         A.out = out + (diag ? i0 : i0 * N2);              // (the kernel's pair index starts at 0 in this chunk's lattices)
-        hipLaunchKernelGGL(fn, dim3(unsigned(A.P < 65535 ? A.P : 65535)), dim3(64), 0, c->stream, A);
+        hipLaunchKernelGGL(fn, dim3(unsigned(A.P < 65535 ? A.P : 65535)), dim3(64 * NW), 0, c->stream, A);
         HIPCHK(c, hipGetLastError());
     }
     if (timed) {
@@ -387,16 +401,17 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     CHK(ensure(c, B_WD3, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &lam));
     CHK(ensure(c, B_WD4, sizeof(double) * size_t(N1) * L1 * DA + 64, &gxl));
     CHK(ensure(c, B_WD5, sizeof(double) * size_t(N2) * L2 * DA + 64, &gxr));
-    const int TF = pl.R1 + 63;
-    const size_t per_group = sizeof(double) * size_t(M > 1 ? M - 1 : 1) * TF * 64 * pl.C;
     const int64_t Pmax = diag ? pl.chunk_i : pl.chunk_i * N2;
+    const int NW = ho ? 1 : lat_waves(c, pl.C, Pmax);
+    const int TF = pl.R1 + 64 * NW - 1;
+    const size_t per_group = sizeof(double) * size_t(M > 1 ? M - 1 : 1) * TF * 64 * (NW > 1 ? NW : pl.C);
     int64_t groups = int64_t(wide_chunk_bytes(c) / per_group);
     if (groups < 1) groups = 1;
     if (groups > Pmax) groups = Pmax;
     if (groups > 4096) groups = 4096;
     if (ho) groups = 1;                   // (the higher-order sweeps bring their own slots, if any)
     CHK(ensure(c, B_WD7, per_group * size_t(groups) + 64, &scr));
-    WideLatKernel fn = ho ? nullptr : lat_kernel(M, pl.C, true, p->base_kernel == GPSIG_BASE_RBF);
+    WideLatKernel fn = ho ? nullptr : lat_kernel(M, pl.C, true, p->base_kernel == GPSIG_BASE_RBF, NW);
     for (int64_t i0 = 0; i0 < N1; i0 += pl.chunk_i) {
         const int64_t ni = N1 - i0 < pl.chunk_i ? N1 - i0 : pl.chunk_i;
         CHK(lat_arguments(c, pl, i0, ni, N2, L1, L2, diag, static_cast<double*>(arg)));
@@ -418,7 +433,7 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
             CHK(ho_sweeps_launch(c, hs, M, pl.R1, pl.R2, static_cast<const double*>(dmat), static_cast<double*>(lam), G, pl.Ptot, diag ? 1 : N2, diag ? 0 : 1,
                                  diag ? 1 : N2, diag, diag ? i0 : i0 * N2, A.P));
         } else if (pl.R1 > 0 && pl.R2 > 0) {
-            hipLaunchKernelGGL(fn, dim3(unsigned(ng)), dim3(64), 0, c->stream, A);
+            hipLaunchKernelGGL(fn, dim3(unsigned(ng)), dim3(64 * NW), 0, c->stream, A);
             HIPCHK(c, hipGetLastError());
         }
         // the adjoint of the arguments, in place of the arguments

@@ -523,7 +523,8 @@ struct WideLatArgs {
     int32_t ngroups;
 };
 
-constexpr int WIDE_LAT_PF = 1;      // argument rows in flight ahead of a forward step
+// argument rows (and, in the backward sweep, stored prefix rows) in flight ahead of a step: a step of few columns is shorter than a memory access
+constexpr int wide_lat_pf(int C) { return C >= 8 ? 1 : (C == 4 ? 2 : 4); }
 
 template <int C, bool RBF>
 struct WideLatDm {
@@ -577,14 +578,27 @@ __device__ __forceinline__ double wide_from_right(double v) {      // lane l <- 
 
 // Level values of P lattices: one wavefront per lattice (grid-stride).  K_m (m < M) = Q_m at the last cell, K_M = the sum of the row totals of R_M:
 // both arrive at lane 63 (columns beyond the lattice pass the row prefixes on unchanged).
-template <int C, int LQ, bool RBF>
-__global__ void __launch_bounds__(64) wide_lattice_fwd_kernel(const WideLatArgs A) {
+// NW > 1: NW wavefronts per lattice (a workgroup), lane lam = threadIdx.x of 64 NW; the hand-over across a wavefront boundary goes through LDS (two buffers
+// alternating by the step's parity, one barrier per step).  For a FEW long lattices (the level diagonals of a minibatch: 50 lattices of 499 x 499 keep
+// 50 of 1,024 SIMDs busy with eight columns per lane) -- more steps (R1 + 64 NW - 1), an eighth of the work per step, NW times the wavefronts.
+template <int C, int LQ, bool RBF, int NW = 1>
+__global__ void __launch_bounds__(64 * NW) wide_lattice_fwd_kernel(const WideLatArgs A) {
     __shared__ double etab[EXP_TAB_N];
-    exp_tab_fill(etab, threadIdx.x, 64);
+    __shared__ double xw[2][NW][LQ + 2];
+    exp_tab_fill(etab, threadIdx.x, 64 * NW);
     __syncthreads();
-    const int lam = threadIdx.x, M = A.M;
-    const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr, TF = R1 + 63;
+    constexpr int GL = 64 * NW, PF = wide_lat_pf(C);
+    const int lam = threadIdx.x, M = A.M, wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr, TF = R1 + GL - 1;
     for (int64_t pp = blockIdx.x; pp < A.P; pp += gridDim.x) {
+        if constexpr (NW > 1) {
+            __syncthreads();
+            if (ln == 63) {
+#pragma unroll
+                for (int m = 0; m < LQ + 2; ++m) xw[0][wv][m] = xw[1][wv][m] = 0.0;
+            }
+            __syncthreads();
+        }
         const int64_t pg = A.p0 + pp;
         WideLatDm<C, RBF> dmg;
         dmg.lat = A.arg + (pg / A.N2) * A.si + (pg % A.N2) * A.sj;
@@ -592,26 +606,32 @@ __global__ void __launch_bounds__(64) wide_lattice_fwd_kernel(const WideLatArgs 
         { const int nv = R2 - C * lam; dmg.nvalid = nv < 0 ? 0 : (nv > C ? C : nv); }
         WaveFwd<C, LQ> fw;
         fw.reset();
-        // the argument rows of the coming WIDE_LAT_PF steps are in flight while a step computes (a launch of a few lattices is one wavefront per
+        // the argument rows of the coming PF steps are in flight while a step computes (a launch of a few lattices is one wavefront per
         // SIMD: nothing else hides the latency of these strided loads)
-        double raw[WIDE_LAT_PF][C + 1];
+        double raw[PF][C + 1];
         if (dr) { dmg.load(0, true, raw[0]); dmg.prime(raw[0]); }
 #pragma unroll
-        for (int u = 0; u < WIDE_LAT_PF; ++u) { const int r = u - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
+        for (int u = 0; u < PF; ++u) { const int r = u - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
         double kM = 0.0;
-        for (int t0 = 0; t0 < TF; t0 += WIDE_LAT_PF) {
+        for (int t0 = 0; t0 < TF; t0 += PF) {
 #pragma unroll
-            for (int u = 0; u < WIDE_LAT_PF; ++u) {
+            for (int u = 0; u < PF; ++u) {
                 const int t = t0 + u;
                 if (t >= TF) break;
                 double cin[LQ + 2], cur[C + 1];
                 cin[0] = 0.0;
 #pragma unroll
-                for (int m = 1; m < LQ + 2; ++m) cin[m] = wide_from_left(fw.sout[m]);
+                for (int m = 1; m < LQ + 2; ++m) {
+                    cin[m] = wide_from_left(fw.sout[m]);
+                    if constexpr (NW > 1) {
+                        const double x = xw[t & 1][wv > 0 ? wv - 1 : 0][m];
+                        cin[m] = (ln == 0 && wv > 0) ? x : cin[m];
+                    }
+                }
 #pragma unroll
                 for (int c = 0; c <= C; ++c) cur[c] = raw[u][c];
                 const int a = t - lam;
-                { const int r = a + WIDE_LAT_PF + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
+                { const int r = a + PF + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
                 if (a >= 0 && a < R1) {
                     double dm[C];
                     dmg.row(cur, true, dm);
@@ -620,9 +640,16 @@ __global__ void __launch_bounds__(64) wide_lattice_fwd_kernel(const WideLatArgs 
                     for (int m = 1; m <= LQ + 1; ++m)
                         if (m == M) kM += fw.sout[m];
                 }
+                if constexpr (NW > 1) {
+                    if (ln == 63) {
+#pragma unroll
+                        for (int m = 1; m < LQ + 2; ++m) xw[(t + 1) & 1][wv][m] = fw.sout[m];
+                    }
+                    __syncthreads();
+                }
             }
         }
-        if (lam == 63) {
+        if (lam == GL - 1) {
             A.out[pg] = 1.0;                                                       // signature_algs.py:20
 #pragma unroll
             for (int m = 1; m <= LQ; ++m)
@@ -634,16 +661,29 @@ __global__ void __launch_bounds__(64) wide_lattice_fwd_kernel(const WideLatArgs 
 
 // Both sweeps (grad_wave_kernel.hpp: seq_grad_wave_kernel with the argument lattice in place of the point rows): Lam[a][b] = dL/ddM[a][b] out.
 // grid: ngroups workgroups of one wavefront; a group's pairs one after the other through its scratch slot.
-template <int C, int LQ, bool RBF>
-__global__ void __launch_bounds__(64) wide_lattice_bwd_kernel(const WideLatArgs A) {
+template <int C, int LQ, bool RBF, int NW = 1>
+__global__ void __launch_bounds__(64 * NW) wide_lattice_bwd_kernel(const WideLatArgs A) {
     __shared__ double etab[EXP_TAB_N];
-    exp_tab_fill(etab, threadIdx.x, 64);
+    __shared__ double xw[2][NW][LQ + 2];
+    exp_tab_fill(etab, threadIdx.x, 64 * NW);
     __syncthreads();
-    const int lam = threadIdx.x, M = A.M;
-    const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr, TF = R1 + 63;
-    double* scr = A.scratch + size_t(blockIdx.x) * size_t(M - 1) * TF * 64 * C;
-    auto slot = [&](int m, int tf, int l, int c) -> double& { return scr[((size_t(m) * TF + tf) * 64 + l) * C + c]; };
+    constexpr int GL = 64 * NW, PF = wide_lat_pf(C);
+    const int lam = threadIdx.x, M = A.M, wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int dr = A.difference ? 1 : 0, R1 = A.L1 - dr, R2 = A.L2 - dr, TF = R1 + GL - 1;
+    double* scr = A.scratch + size_t(blockIdx.x) * size_t(M - 1) * TF * GL * C;
+    auto slot = [&](int m, int tf, int l, int c) -> double& { return scr[((size_t(m) * TF + tf) * GL + l) * C + c]; };
+    auto xw_clear = [&]() {
+        if constexpr (NW > 1) {
+            __syncthreads();
+            if (ln == 63) {
+#pragma unroll
+                for (int m = 0; m < LQ + 2; ++m) xw[0][wv][m] = xw[1][wv][m] = 0.0;
+            }
+            __syncthreads();
+        }
+    };
     for (int64_t pp = blockIdx.x; pp < A.P; pp += gridDim.x) {
+        xw_clear();
         const int64_t pg = A.p0 + pp;
         WideLatDm<C, RBF> dmg;
         dmg.lat = A.arg + (pg / A.N2) * A.si + (pg % A.N2) * A.sj;
@@ -656,23 +696,29 @@ __global__ void __launch_bounds__(64) wide_lattice_bwd_kernel(const WideLatArgs 
         {
             WaveFwd<C, LQ> fw;
             fw.reset();
-            double raw[WIDE_LAT_PF][C + 1];
+            double raw[PF][C + 1];
             if (dr) { dmg.load(0, true, raw[0]); dmg.prime(raw[0]); }
 #pragma unroll
-            for (int u = 0; u < WIDE_LAT_PF; ++u) { const int r = u - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
-            for (int t0 = 0; t0 < TF; t0 += WIDE_LAT_PF) {
+            for (int u = 0; u < PF; ++u) { const int r = u - lam + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
+            for (int t0 = 0; t0 < TF; t0 += PF) {
 #pragma unroll
-                for (int u = 0; u < WIDE_LAT_PF; ++u) {
+                for (int u = 0; u < PF; ++u) {
                     const int t = t0 + u;
                     if (t >= TF) break;
                     double cin[LQ + 2], cur[C + 1];
                     cin[0] = 0.0;
 #pragma unroll
-                    for (int m = 1; m < LQ + 2; ++m) cin[m] = wide_from_left(fw.sout[m]);
+                    for (int m = 1; m < LQ + 2; ++m) {
+                        cin[m] = wide_from_left(fw.sout[m]);
+                        if constexpr (NW > 1) {
+                            const double x = xw[t & 1][wv > 0 ? wv - 1 : 0][m];
+                            cin[m] = (ln == 0 && wv > 0) ? x : cin[m];
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c <= C; ++c) cur[c] = raw[u][c];
                     const int a = t - lam;
-                    { const int r = a + WIDE_LAT_PF + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
+                    { const int r = a + PF + dr; dmg.load(r, r >= 0 && r < A.L1, raw[u]); }
                     if (a >= 0 && a < R1) {
                         double dm[C];
                         dmg.row(cur, true, dm);
@@ -684,19 +730,25 @@ __global__ void __launch_bounds__(64) wide_lattice_bwd_kernel(const WideLatArgs 
                                 for (int c = 0; c < C; ++c) slot(m, t, lam, c) = fw.q[m][c];
                             }
                     }
+                    if constexpr (NW > 1) {
+                        if (ln == 63) {
+#pragma unroll
+                            for (int m = 1; m < LQ + 2; ++m) xw[(t + 1) & 1][wv][m] = fw.sout[m];
+                        }
+                        __syncthreads();
+                    }
                 }
             }
         }
-        __threadfence();        // the backward sweep reads what other lanes of this wavefront stored
+        __threadfence();        // the backward sweep reads what other lanes of this wavefront (workgroup) stored
+        xw_clear();
         // ---- backward sweep
         {
             WaveBwd<C, LQ> bw;
             bw.reset();
-            double raw[C + 1];
-            if (dr) { dmg.load(R1, true, raw); dmg.prime(raw); }
+            double rawr[PF][C + 1], qr[PF][LQ][C];
+            if (dr) { dmg.load(R1, true, rawr[0]); dmg.prime(rawr[0]); }
             double* lamrow = A.lam + size_t(pp) * R1 * R2;
-            double qcur[LQ][C];
-            { const int r = R1 - 1 + (63 - lam); dmg.load(r, r >= 0 && r < A.L1, raw); }      // the row of step 0 (beyond the sequence: zeros, not used)
             auto fetch_q = [&](int a, double (&q)[LQ][C]) {
                 const int tf = a - 1 + lam;
 #pragma unroll
@@ -711,28 +763,51 @@ __global__ void __launch_bounds__(64) wide_lattice_bwd_kernel(const WideLatArgs 
                         q[m][c] = v;
                     }
             };
-            fetch_q(R1 - 1 + (63 - lam), qcur);
-            for (int u = 0; u < TF; ++u) {
-                double sin[LQ], rnext[C + 1], qnext[LQ][C];
+            // the rows of the coming PF steps (arguments and stored prefixes) are in flight while a step computes
 #pragma unroll
-                for (int p = 0; p < LQ; ++p) sin[p] = wide_from_right(bw.svout[p]);
-                const int a = R1 - 1 - (u - (63 - lam));
-                { const int r = a - 1; dmg.load(r, r >= 0 && r < R1, rnext); }
-                fetch_q(a - 1, qnext);
-                if (a >= 0 && a < R1) {
-                    double dm[C], lv[C];
-                    dmg.row(raw, false, dm);
-                    bw.step(dm, clev, qcur, sin, M, lv);
+            for (int v = 0; v < PF; ++v) {
+                const int r = R1 - 1 - (v - (GL - 1 - lam));
+                dmg.load(r, r >= 0 && r < R1, rawr[v]);
+                fetch_q(r, qr[v]);
+            }
+            for (int u0 = 0; u0 < TF; u0 += PF) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        if (c < dmg.nvalid) lamrow[size_t(a) * R2 + C * lam + c] = lv[c];
+                for (int v = 0; v < PF; ++v) {
+                    const int u = u0 + v;
+                    if (u >= TF) break;
+                    double sin[LQ], raw[C + 1], qcur[LQ][C];
+#pragma unroll
+                    for (int p = 0; p < LQ; ++p) {
+                        sin[p] = wide_from_right(bw.svout[p]);
+                        if constexpr (NW > 1) {
+                            const double x = xw[u & 1][wv + 1 < NW ? wv + 1 : wv][p];
+                            sin[p] = (ln == 63 && wv + 1 < NW) ? x : sin[p];
+                        }
+                    }
+                    const int a = R1 - 1 - (u - (GL - 1 - lam));
+#pragma unroll
+                    for (int c = 0; c <= C; ++c) raw[c] = rawr[v][c];
+#pragma unroll
+                    for (int m = 0; m < LQ; ++m)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) qcur[m][c] = qr[v][m][c];
+                    { const int r = a - PF; dmg.load(r, r >= 0 && r < R1, rawr[v]); fetch_q(r, qr[v]); }
+                    if (a >= 0 && a < R1) {
+                        double dm[C], lv[C];
+                        dmg.row(raw, false, dm);
+                        bw.step(dm, clev, qcur, sin, M, lv);
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+                            if (c < dmg.nvalid) lamrow[size_t(a) * R2 + C * lam + c] = lv[c];
+                    }
+                    if constexpr (NW > 1) {
+                        if (ln == 0) {
+#pragma unroll
+                            for (int p = 0; p < LQ; ++p) xw[(u + 1) & 1][wv][p] = bw.svout[p];
+                        }
+                        __syncthreads();
+                    }
                 }
-#pragma unroll
-                for (int c = 0; c <= C; ++c) raw[c] = rnext[c];
-#pragma unroll
-                for (int m = 0; m < LQ; ++m)
-#pragma unroll
-                    for (int c = 0; c < C; ++c) qcur[m][c] = qnext[m][c];
             }
         }
         __threadfence();        // the slot is rewritten by the next pair

@@ -164,6 +164,8 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "wide_chunk_mb"  its argument chunk in HBM (0: "grad_scratch_mb", 4 GB by default: a latency-bound launch split in two takes twice as long)
  *   "wide_contract"  1 (default): the two contractions of a reverse pass with the adjoint array (rows of at most 32 augmented columns) as one
  *                 hand-written MFMA pass (wide_contract_kernel); 0: two rocBLAS dgemms (for A/B runs)
+ *   "wide_lat_waves"  wavefronts per sequence lattice on the wide route: -1 (default) eight for a launch of at most 128 lattices of more than 256
+ *                 columns, one otherwise; 0 always one; 1 two / four / eight wherever a lane would hold that many columns
  *   order > 1 and "grad_impl": the sequence recursion's reverse pass runs as two sweeps of a wavefront per pair (csrc/grad_wave_ho_kernel.hpp;
  *                 <= 5 levels, min(order, levels) <= 4, lattices of <= 512 columns): 0 scratch-free where the row totals fit LDS, 3 with
  *                 the prefixes in an HBM slot per pair group, any other value the lattice operations of rounds 2-5 (tests' A/B reference) */

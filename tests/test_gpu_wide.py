@@ -237,8 +237,11 @@ def test_wide_sequence_lattices_and_gradient(M, N1, N2, L1, L2, d, kind, base):
             (want * torch.tensor(G)).sum().backward()
             keep = []
             p = _params(base, d, M, difference, keep)
-            for mb in (0, 1):
+            # (waves: wavefronts per lattice -- -1 the planner's choice: the lattice's columns over several wavefronts of one column per lane where a
+            # launch holds few long lattices; 0: one wavefront per lattice with 1 / 2 / 4 / 8 columns per lane; 1: 2 / 4 / 8 wavefronts instead wherever possible)
+            for mb, waves in ((0, -1), (1, -1), (0, 0), (0, 1)):
                 ctx.set_option("wide_chunk_mb", mb)
+                ctx.set_option("wide_lat_waves", waves)
                 out = np.full(G.shape, np.nan)
                 gX, gY, gb = np.full_like(X, np.nan), (None if Y is None else np.full_like(Y, np.nan)), np.zeros(2)
                 if kind == "diag":
@@ -251,13 +254,14 @@ def test_wide_sequence_lattices_and_gradient(M, N1, N2, L1, L2, d, kind, base):
                 # (matern12: a sequence against itself has coinciding points -- the float64 oracle's kappa there is exp(-sqrt(rounding noise)), 1e-8 from
                 # one, its derivative whatever the noise makes of 1 / r; the product takes such distances as zero: DESIGN section 5)
                 tv, tg = (1e-6, 1e-5) if (base == "matern12" and kind != "cross") else (1e-9, 1e-8)
-                assert rel(out, want) < tv, (difference, mb, rel(out, want))
-                assert rel(gX, tX.grad) < tg, (difference, mb, rel(gX, tX.grad))
+                assert rel(out, want) < tv, (difference, mb, waves, rel(out, want))
+                assert rel(gX, tX.grad) < tg, (difference, mb, waves, rel(gX, tX.grad))
                 if Y is not None:
-                    assert rel(gY, tY.grad) < 1e-8, (difference, mb, rel(gY, tY.grad))
+                    assert rel(gY, tY.grad) < 1e-8, (difference, mb, waves, rel(gY, tY.grad))
     finally:
         ctx.set_option("wide", -1)
         ctx.set_option("wide_chunk_mb", 0)
+        ctx.set_option("wide_lat_waves", -1)
 
 
 def test_wide_route_is_what_the_reference_shapes_take():
