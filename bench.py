@@ -699,12 +699,15 @@ def run_workload(cfg, base, increments, steps, warmup, dev, rank=0, world=1, chu
 
 SECONDARY = [("c2", "linear", False, True, 1), ("c2", "linear", False, False, 5), ("c2", "rbf", False, False, 1), ("c3", "rbf", False, False, 1),
              ("c3", "rbf", True, False, 1), ("c3", "linear", False, False, 1), ("c5", "rbf", False, False, 1)]
+# round 6: the higher-order algorithms (signature_algs.py:37-74, 129-160) with SignatureRBF -- exact instances / higher-order chains in the tile kernel
+# (after the other records: the tests address those by position)
+SECONDARY_HO = [("c2", "rbf", False, False, 2), ("c3", "rbf", False, False, 2)]
 
 
 def secondary_lines(dev):
     """The other single-GPU configurations, 3 warm-up + 10 steps each, as short records beside the headline."""
     out = []
-    for cfg, base, inc, lattice, order in SECONDARY:
+    for cfg, base, inc, lattice, order in SECONDARY + SECONDARY_HO:
         name = cfg + "-" + base + ("-increments" if inc else "") + ("-lattice" if lattice else "") + ("-order%d" % order if order > 1 else "")
         try:
             r = run_workload(cfg, base, inc, 10, 3, dev, host_e2e=False, traffic="static", lattice=lattice, order=order)
@@ -719,9 +722,12 @@ def secondary_lines(dev):
                         "traffic": rf["traffic"], "traffic_source": (rf["traffic_source"] or {}).get("how")})
         except Exception as e:                      # a side record never costs the headline its line
             out.append({"name": name, "error": repr(e)})
+    ho = out[len(SECONDARY):]
+    del out[len(SECONDARY):]
     out.append(c4_single_gpu_line(dev))
     out.extend(gradient_lines(dev))
     out.extend(svgp_lines(dev))
+    out.extend(ho)
     return out
 
 
@@ -881,6 +887,56 @@ def gradient_lines(dev):
                     "dtype": "f64", "ms_per_step": ms, "value": float(N) * (N + 1) / 2 / (ms * 1e-3), "unit": "sequence-pairs/s"})
     except Exception as e:
         out.append({"name": "c2-matern32", "error": repr(e)})
+    # round 6: reverse passes at order 2 -- the sequence recursion's as two sweeps of a wavefront per pair (csrc/grad_wave_ho_kernel.hpp) inside the wide
+    # route's dgemms, the chains' in the tile kernel (tvs_grad_tile_inst_ho.hip)
+    try:
+        N, L, M = 512, 64, 4
+        D = 8
+        Xg = torch.tensor(np.cumsum(np.random.default_rng(0).standard_normal((N, L, D)) * 0.3, axis=1).reshape(N, -1), device=dev)
+        Wg = torch.tensor(np.random.default_rng(1).standard_normal((N, N)), device=dev)
+        mod = autodiff.SignatureKernelModule(kernels.SignatureRBF(L * D, D, M, order=2, lengthscales=math.sqrt(D)), device=dev)
+
+        def step2():
+            mod.zero_grad()
+            (mod.K(Xg) * Wg).sum().backward()
+        for _ in range(2):
+            step2()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step2()
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        out.append({"name": "grad-n512-rbf-order2", "workload": "K(X) forward + backward through gpsig_amd.autodiff.SignatureKernelModule, SignatureRBF order=2, N=%d, L=%d, d=%d, "
+                                                                "num_levels=%d, normalization=on, fp64" % (N, L, D, M),
+                    "dtype": "f64", "ms_per_step": ms, "value": float(N) * N / (ms * 1e-3), "unit": "sequence-pairs/s (forward + backward)"})
+    except Exception as e:
+        out.append({"name": "grad-n512-rbf-order2", "error": repr(e)})
+    try:
+        T, N, L, d3, M = 512, 16384, 50, 6, 4
+        rng = np.random.default_rng(0)
+        X3 = torch.tensor(rng.standard_normal((N, L * d3)) * 0.3, device=dev)
+        Z3 = torch.tensor(rng.standard_normal((M * (M + 1) // 2, T, d3)) * 0.3, device=dev).requires_grad_(True)
+        mod = autodiff.SignatureKernelModule(kernels.SignatureRBF(L * d3, d3, M, order=2), device=dev)
+
+        def step3():
+            Z3.grad = None
+            mod.zero_grad()
+            o = mod.K_tens_vs_seq(Z3, X3)
+            (o * o).sum().backward()
+        for _ in range(2):
+            step3()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step3()
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        out.append({"name": "grad-c3-rbf-order2", "workload": "Kzx forward + backward through gpsig_amd.autodiff.SignatureKernelModule at BASELINE configs[2]'s size, SignatureRBF order=2: "
+                                                              "T=%d inducing tensors, N=%d, L=%d, d=%d, num_levels=%d, normalization=on, fp64" % (T, N, L, d3, M),
+                    "dtype": "f64", "ms_per_step": ms, "value": float(T) * N / (ms * 1e-3), "unit": "tensor-sequence pairs/s (forward + backward)"})
+    except Exception as e:
+        out.append({"name": "grad-c3-rbf-order2", "error": repr(e)})
     return out
 
 

@@ -76,8 +76,9 @@ def test_default_line_carries_the_measurement():
     names = [s["name"] for s in line["secondary"]]
     assert names == ["c2-linear-lattice", "c2-linear-order5", "c2-rbf", "c3-rbf", "c3-rbf-increments", "c3-linear", "c5-rbf", "c4-single-gpu",
                      "grad-c2shape-n1024-linear", "grad-c2shape-n1024-linear-level-primitives", "grad-c2shape-n1024-linear-pair-kernels",
-                     "grad-c2shape-n1024-rbf", "grad-c2shape-n1024-matern32", "grad-n512-l128-rbf", "c2-matern32",
-                     "svgp-step-charactertrajectories", "svgp-step-netflow", "svgp-step-arabicdigits", "svgp-step-cmusubject16", "c3-svgp-predict"]
+                     "grad-c2shape-n1024-rbf", "grad-c2shape-n1024-matern32", "grad-n512-l128-rbf", "c2-matern32", "grad-n512-rbf-order2", "grad-c3-rbf-order2",
+                     "svgp-step-charactertrajectories", "svgp-step-netflow", "svgp-step-arabicdigits", "svgp-step-cmusubject16", "c3-svgp-predict",
+                     "c2-rbf-order2", "c3-rbf-order2"]
     ho = line["secondary"][1]                           # the higher-order algorithm at order = num_levels: the same contraction, the same time
     assert ho["bound"] == "mfma" and ho["ms_per_step"] < 1.3 * line["ms_per_step"]
     lat = line["secondary"][0]                          # the same Gram through the pair recursion: vector-issue bound, about twice the time
@@ -103,7 +104,7 @@ def test_default_line_carries_the_measurement():
     for name in ("svgp-step-netflow", "svgp-step-arabicdigits", "svgp-step-cmusubject16"):
         assert sv[name]["column_fma_per_s"] > base / 3.0, (name, sv[name]["column_fma_per_s"], base)
         assert sv[name]["ms_per_step"] < 40.0
-    pr = line["secondary"][-1]
+    pr = [s_ for s_ in line["secondary"] if s_["name"] == "c3-svgp-predict"][0]
     assert pr["name"] == "c3-svgp-predict" and pr["finite"] and 0 < pr["covariances_ms"] < pr["ms_per_step"] < 30.0
     g = {s["name"]: s["ms_per_step"] for s in line["secondary"] if s["name"].startswith("grad-")}
     # the linear kernel's reverse pass through the feature contraction: several times faster than through the pair kernels
@@ -113,3 +114,8 @@ def test_default_line_carries_the_measurement():
     assert g["grad-c2shape-n1024-rbf"] < 25 and g["grad-c2shape-n1024-matern32"] < 35 and g["grad-n512-l128-rbf"] < 32
     assert [s_ for s_ in line["secondary"] if s_["name"] == "c2-matern32"][0]["ms_per_step"] < 75       # (run-time-kind instances: 77-84 ms)
     assert line["secondary"][3]["stream_frac"] > 0     # printed as stream_frac, never as an HBM fraction above 1
+    # round 6: order 2 of SignatureRBF -- exact instances (K(X): 2.5 x order 1, was 9 x), higher-order chains in the tile kernel (Kzx: 1.15 x), fused reverse passes
+    by = {s_["name"]: s_ for s_ in line["secondary"]}
+    assert by["c2-rbf-order2"]["ms_per_step"] < 4.5 * by["c2-rbf"]["ms_per_step"] and by["c2-rbf-order2"]["rel_err"] <= 1e-6
+    assert by["c3-rbf-order2"]["ms_per_step"] < 2.0 * by["c3-rbf"]["ms_per_step"] and by["c3-rbf-order2"]["rel_err"] <= 1e-6
+    assert g["grad-n512-rbf-order2"] < 120 and g["grad-c3-rbf-order2"] < 6 * by["c3-rbf-order2"]["ms_per_step"] + 6
