@@ -35,7 +35,7 @@ enum BufId {
     B_SPEC,                                                    // spectral base-kernel table
     B_TQ,                                                      // item counters of the Kzx tile kernel's persistent launch
     B_STASH,                                                   // what the fused reverse kernel needs of the forward recursion (gpsig_seq_gram_levels_stash)
-    B_WD0, B_WD1, B_WD2, B_WD3, B_WD4, B_WD5, B_WD6, B_WD7, B_WD8, B_WD9,   // wide state spaces (wide_api.hip): augmented rows, kernel-argument chunks, their adjoints, lattice states
+    B_WD0, B_WD1, B_WD2, B_WD3, B_WD4, B_WD5, B_WD6, B_WD7, B_WD8, B_WD9, B_WD10,   // wide state spaces (wide_api.hip): augmented rows, kernel-argument chunks, their adjoints, lattice states
     B_COUNT
 };
 
@@ -96,7 +96,7 @@ struct gpsig_ctx {
     int tvs_tile = -1;            // Kzx tile kernel (tvs_tile_kernel.hpp): -1 where it is built, 0 never, 1 also below 32 tensors
     int wide = -1;                // wide state spaces (wide_api.hip: kernel arguments by dgemm, fused map / difference / recursion kernels): -1 where the exact-shape
                                   // kernels are not built (more than 8 columns for Kzx, more than 32 for the sequence lattices), 0 never, 1 wherever built
-    int wide_contract = 1, wide_lat_waves = -1;        // the reverse pass's two contractions for narrow rows: 1 = one hand-written pass over the adjoint array (wide_contract_kernel), 0 = rocBLAS dgemms
+    int wide_contract = 1, wide_lat_waves = -1, wide_sym_fold = 1;        // the reverse pass's two contractions for narrow rows: 1 = one hand-written pass over the adjoint array (wide_contract_kernel), 0 = rocBLAS dgemms
     int wide_chunk_mb = 0;        // its argument chunk in HBM (0: a quarter of the gradient scratch budget)
     int tvs_features = -1;        // Kzx of the linear / cosine kernel as one product of level features: -1 where a time model prefers it, 0 never, 1 wherever built
     int tvs_tile_nw = 0;          // its waves per workgroup: 0 = planner's choice

@@ -337,13 +337,14 @@ int lat_plan(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const
 }
 
 // the argument lattices of the left sequences i0 .. i0 + ni - 1 into `arg`
-int lat_arguments(gpsig_ctx* c, const LatPlan& pl, int64_t i0, int64_t ni, int64_t N2, int L1, int L2, bool diag, double* arg) {
+// (j0 > 0: the right sequences j0 .. N2 - 1 only -- the symmetric Gram's reverse pass, pairs i <= j)
+int lat_arguments(gpsig_ctx* c, const LatPlan& pl, int64_t i0, int64_t ni, int64_t N2, int L1, int L2, bool diag, double* arg, int64_t j0 = 0) {
     const int DA = pl.DA;
     if (diag)      // per sequence: row-major arg (L1, L2) = XL_n XR_n^T  ==  column-major (L2 x L1) = XR_n,cm^T (L2 x DA) XL_n,cm (DA x L1)
         return dgemm_batched(c, true, false, L2, L1, DA, pl.XR + i0 * L2 * DA, DA, int64_t(L2) * DA, pl.XL + i0 * L1 * DA, DA, int64_t(L1) * DA, arg, L2,
                              int64_t(L1) * L2, ni);
     // row-major arg (ni L1, N2 L2) = XL_chunk XR^T  ==  column-major (N2 L2 x ni L1) = XR_cm^T XL_chunk,cm
-    return dgemm(c, true, false, N2 * L2, ni * L1, DA, pl.XR, DA, pl.XL + i0 * L1 * DA, DA, 0.0, arg, N2 * L2);
+    return dgemm(c, true, false, (N2 - j0) * L2, ni * L1, DA, pl.XR + j0 * L2 * DA, DA, pl.XL + i0 * L1 * DA, DA, 0.0, arg, (N2 - j0) * L2);
 }
 
 }  // namespace
@@ -393,6 +394,16 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     if (ho && !ho_sweeps_plan(c, p, L1 - (p->difference ? 1 : 0), L2 - (p->difference ? 1 : 0), &hs))
         return fail(c, GPSIG_ERR_UNSUPPORTED, "no higher-order sweeps for this shape");
     CHK(lat_plan(c, p, d, Xs, Ys, N1, N2, L1, L2, diag, ho ? 3 : 2, &pl));
+    // the symmetric Gram (one array on both sides): the pairs i <= j with the upstream gradient folded onto them -- half the lattices
+    const bool fold = !diag && Ys == nullptr && N1 == N2 && L1 == L2 && c->wide_sym_fold != 0;
+    if (fold) {
+        void* gs;
+        CHK(ensure(c, B_WD10, sizeof(double) * size_t(p->num_levels + 1) * N1 * N1 + 64, &gs));
+        hipLaunchKernelGGL(wide_sym_upstream_kernel, dim3(grid_for(int64_t(p->num_levels + 1) * N1 * N1)), dim3(256), 0, c->stream, G, N1, p->num_levels + 1,
+                           static_cast<double*>(gs));
+        HIPCHK(c, hipGetLastError());
+        G = static_cast<const double*>(gs);
+    }
     const int M = p->num_levels, DA = pl.DA;
     const int64_t per_i = int64_t(L1) * L2 * (diag ? 1 : N2);
     void *arg, *lam, *gxl, *gxr, *scr, *dmat = nullptr;
@@ -414,13 +425,16 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     WideLatKernel fn = ho ? nullptr : lat_kernel(M, pl.C, true, p->base_kernel == GPSIG_BASE_RBF, NW);
     for (int64_t i0 = 0; i0 < N1; i0 += pl.chunk_i) {
         const int64_t ni = N1 - i0 < pl.chunk_i ? N1 - i0 : pl.chunk_i;
-        CHK(lat_arguments(c, pl, i0, ni, N2, L1, L2, diag, static_cast<double*>(arg)));
+        const int64_t j0 = fold ? i0 : 0, N2e = N2 - j0;              // right sequences of this chunk
+        CHK(lat_arguments(c, pl, i0, ni, N2, L1, L2, diag, static_cast<double*>(arg), j0));
         WideLatArgs A;
         memset(&A, 0, sizeof(A));
         A.arg = static_cast<const double*>(arg); A.ld = pl.ld; A.si = pl.si; A.sj = pl.sj; A.N2 = pl.N2;
-        A.P = diag ? ni : ni * N2; A.p0 = 0; A.Ptot = pl.Ptot;
+        if (!diag) { A.ld = N2e * int64_t(L2); A.si = int64_t(L1) * A.ld; A.N2 = N2e; }
+        A.P = diag ? ni : ni * N2e; A.p0 = 0; A.Ptot = pl.Ptot;
         A.L1 = L1; A.L2 = L2; A.M = M; A.kind = p->base_kernel; A.difference = pl.dr;
-        A.G = G + (diag ? i0 : i0 * N2);
+        A.G = G + (diag ? i0 : i0 * N2 + j0);
+        A.g_i = diag ? 1 : N2; A.g_j = diag ? 0 : 1;
         A.scratch = static_cast<double*>(scr); A.lam = static_cast<double*>(lam);
         const int64_t ng = A.P < groups ? A.P : groups;
         A.ngroups = int(ng);
@@ -430,8 +444,9 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
             else
                 hipLaunchKernelGGL(wide_lattice_dm_kernel<false>, dim3(grid_for(A.P * int64_t(pl.R1) * pl.R2)), dim3(256), 0, c->stream, A, static_cast<double*>(dmat));
             HIPCHK(c, hipGetLastError());
-            CHK(ho_sweeps_launch(c, hs, M, pl.R1, pl.R2, static_cast<const double*>(dmat), static_cast<double*>(lam), G, pl.Ptot, diag ? 1 : N2, diag ? 0 : 1,
-                                 diag ? 1 : N2, diag, diag ? i0 : i0 * N2, A.P));
+            // (the sweeps address G by (i, j') = divmod(pair0 + pair, N2e): i absolute with pair0 = i0 N2e, j' relative to the chunk's first right sequence)
+            CHK(ho_sweeps_launch(c, hs, M, pl.R1, pl.R2, static_cast<const double*>(dmat), static_cast<double*>(lam), G + j0, pl.Ptot, diag ? 1 : N2, diag ? 0 : 1,
+                                 diag ? 1 : N2e, diag, diag ? i0 : i0 * N2e, A.P));
         } else if (pl.R1 > 0 && pl.R2 > 0) {
             hipLaunchKernelGGL(fn, dim3(unsigned(ng)), dim3(64 * NW), 0, c->stream, A);
             HIPCHK(c, hipGetLastError());
@@ -450,7 +465,8 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
             CHK(dgemm_batched(c, false, true, DA, L2, L1, pl.XL + i0 * L1 * DA, DA, int64_t(L1) * DA, W, L2, int64_t(L1) * L2,
                               static_cast<double*>(gxr) + i0 * L2 * DA, DA, int64_t(L2) * DA, ni));
         } else {
-            CHK(contract_both(c, W, pl.XL + i0 * L1 * DA, pl.XR, ni * int64_t(L1), N2 * int64_t(L2), DA, i0 > 0, gl, static_cast<double*>(gxr)));
+            CHK(contract_both(c, W, pl.XL + i0 * L1 * DA, pl.XR + j0 * L2 * DA, ni * int64_t(L1), N2e * int64_t(L2), DA, i0 > 0, gl,
+                              static_cast<double*>(gxr) + j0 * L2 * DA));
         }
     }
     // through the augmentation: left form into gX; right form into gX as well (one array on both sides) or into gY

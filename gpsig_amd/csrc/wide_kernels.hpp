@@ -517,7 +517,8 @@ struct WideLatArgs {
     int64_t P, p0, Ptot;        // this launch: lattices p0 .. p0 + P - 1 of Ptot (the level arrays' pair axis)
     int32_t L1, L2, M, kind, difference;
     double* out;                // forward: (M+1, Ptot) level values
-    const double* G;            // reverse: (M+1, Ptot) upstream gradient
+    const double* G;            // reverse: (M+1, Ptot) upstream gradient, lattice pg of this launch at  (pg / N2) * g_i + (pg % N2) * g_j
+    int64_t g_i, g_j;
     double* scratch;            // reverse: per group (M-1) * TF * 64 * C doubles (forward Q's, as grad_wave_kernel.hpp)
     double* lam;                // reverse: Lam = dL/ddM, (P, R1, R2) row-major
     int32_t ngroups;
@@ -691,7 +692,7 @@ __global__ void __launch_bounds__(64 * NW) wide_lattice_bwd_kernel(const WideLat
         { const int nv = R2 - C * lam; dmg.nvalid = nv < 0 ? 0 : (nv > C ? C : nv); }
         double clev[LQ + 2];
 #pragma unroll
-        for (int p = 0; p < LQ + 2; ++p) clev[p] = (p >= 1 && p <= M) ? A.G[int64_t(p) * A.Ptot + pg] : 0.0;
+        for (int p = 0; p < LQ + 2; ++p) clev[p] = (p >= 1 && p <= M) ? A.G[int64_t(p) * A.Ptot + (pg / A.N2) * A.g_i + (pg % A.N2) * A.g_j] : 0.0;
         // ---- forward sweep, Q's of levels < M to the scratch slot
         {
             WaveFwd<C, LQ> fw;
@@ -835,6 +836,16 @@ __global__ void wide_lattice_adjoint_kernel(const WideLatArgs A, double* __restr
         double k, dk;
         wide_kappa_grad<RBF>(K, A.arg[off], k, dk);
         W[off] = gam * dk;
+    }
+}
+
+// The symmetric Gram's upstream gradient folded onto the pairs i <= j (the levels are symmetric functions of the two sequences):
+// Gs[m][i][j] = G[m][i][j] + G[m][j][i] (j > i),  G[m][i][i] (j == i),  0 (j < i).
+__global__ void wide_sym_upstream_kernel(const double* __restrict__ G, int64_t N, int M1, double* __restrict__ Gs) {
+    const int64_t total = int64_t(M1) * N * N;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t j = idx % N, i = (idx / N) % N, m = idx / (N * N);
+        Gs[idx] = j > i ? G[idx] + G[(m * N + j) * N + i] : (j == i ? G[idx] : 0.0);
     }
 }
 

@@ -212,7 +212,7 @@ def test_wide_module_gradients(base, d, num_lags):
 
 
 @pytest.mark.parametrize("M,N1,N2,L1,L2,d,kind", [(4, 7, 5, 9, 13, 12, "cross"), (3, 6, 6, 70, 70, 28, "sym"), (4, 9, 9, 33, 33, 46, "diag"), (4, 3, 4, 20, 131, 126, "cross"),
-                                                  (5, 2, 2, 300, 300, 3, "diag"), (2, 3, 2, 40, 260, 10, "cross"), (7, 3, 3, 12, 12, 14, "sym"), (1, 4, 3, 5, 6, 300, "cross"),
+                                                  (5, 2, 2, 300, 300, 3, "diag"), (2, 3, 2, 40, 260, 10, "cross"), (7, 3, 3, 12, 12, 14, "sym"), (1, 4, 3, 5, 6, 300, "cross"), (4, 37, 37, 21, 21, 10, "sym"),
                                                   (4, 70, 70, 8, 8, 16, "diag"), (4, 5, 5, 93, 93, 28, "diag")])
 @pytest.mark.parametrize("base", WIDE_BASES)
 def test_wide_sequence_lattices_and_gradient(M, N1, N2, L1, L2, d, kind, base):
@@ -239,9 +239,11 @@ def test_wide_sequence_lattices_and_gradient(M, N1, N2, L1, L2, d, kind, base):
             p = _params(base, d, M, difference, keep)
             # (waves: wavefronts per lattice -- -1 the planner's choice: the lattice's columns over several wavefronts of one column per lane where a
             # launch holds few long lattices; 0: one wavefront per lattice with 1 / 2 / 4 / 8 columns per lane; 1: 2 / 4 / 8 wavefronts instead wherever possible)
-            for mb, waves in ((0, -1), (1, -1), (0, 0), (0, 1)):
+            # fold: the symmetric Gram's reverse pass over the pairs i <= j with the upstream gradient folded onto them (1, the default) or over all ordered pairs
+            for mb, waves, fold in ((0, -1, 1), (1, -1, 1), (0, 0, 1), (0, 1, 1)) + (((0, -1, 0),) if kind == "sym" else ()):
                 ctx.set_option("wide_chunk_mb", mb)
                 ctx.set_option("wide_lat_waves", waves)
+                ctx.set_option("wide_sym_fold", fold)
                 out = np.full(G.shape, np.nan)
                 gX, gY, gb = np.full_like(X, np.nan), (None if Y is None else np.full_like(Y, np.nan)), np.zeros(2)
                 if kind == "diag":
@@ -262,6 +264,7 @@ def test_wide_sequence_lattices_and_gradient(M, N1, N2, L1, L2, d, kind, base):
         ctx.set_option("wide", -1)
         ctx.set_option("wide_chunk_mb", 0)
         ctx.set_option("wide_lat_waves", -1)
+        ctx.set_option("wide_sym_fold", 1)
 
 
 def test_wide_route_is_what_the_reference_shapes_take():
