@@ -1133,8 +1133,6 @@ class SignatureKernelModule(torch.nn.Module):
         return torch.stack(lev, dim=0)
 
     def _mx_tvs_levels(self, Zs, Xs, increments):
-        if self._spec.order > 1 and self._spec.num_levels > 1:
-            raise NotImplementedError("the matrix route (spectral kernel / more than 64 columns) has the tensor-vs-sequence chains at order 1")
         lt, T, d = Zs.shape[0], Zs.shape[1], Zs.shape[-1]                                           # kernels.py:313-340
         N, L = Xs.shape[:2]
         Xf = Xs.reshape(N * L, d)
@@ -1145,8 +1143,30 @@ class SignatureKernelModule(torch.nn.Module):
             Mk = self._kappa(Zs.reshape(lt * T, d), Xf).reshape(lt, T, N, L)
         if self.kern.difference:
             Mk = Mk[..., 1:] - Mk[..., :-1]                                                         # signature_algs.py:114
+        if self._spec.order > 1 and self._spec.num_levels > 1:
+            return self._mx_tvs_chains_higher_order(Mk)
         m = Mk.permute(0, 3, 1, 2).reshape(lt, Mk.shape[-1], T * N)                                 # (lt, R, P), pair index fastest
         return _ChainLevels.apply(m.contiguous(), self._spec).reshape(-1, T, N)
+
+    def _mx_tvs_chains_higher_order(self, Mk):
+        """signature_algs.py:144-158 on the differenced tensor Mk (lt, T, N, R), array operation by array operation with torch's autograd behind it: the
+        corner the library's kernels do not take -- order > 1 on the matrix route, i.e. more than 64 columns (or the spectral kernel) with a base kernel
+        outside the wide route's families (those run wide_tvs_fwd / _bwd_kernel at any width).  Built for coverage."""
+        def excumsum(A):                                                                            # tf.cumsum(exclusive=True, axis=2)
+            return torch.cumsum(A, dim=2) - A
+        order, lev, k = self._spec.order, [torch.ones_like(Mk[0, :, :, 0])], 0                      # :144
+        for i in range(1, self._spec.num_levels + 1):                                               # :147
+            R = [Mk[k]]                                                                             # :148
+            k += 1
+            for j in range(1, i):                                                                   # :150
+                dcur = min(j + 1, order)                                                            # :151
+                Rn = [Mk[k] * excumsum(sum(R))]                                                     # :153
+                for l in range(1, dcur):                                                            # :154
+                    Rn.append(Mk[k] * R[l - 1] / float(l + 1))                                      # :155
+                R = Rn
+                k += 1
+            lev.append(sum(R).sum(dim=2))                                                           # :158
+        return torch.stack(lev, dim=0)
 
     def _w(self):
         return self.sigma * self.variances                                                          # kernels.py:471

@@ -17,6 +17,7 @@ typedef hipError_t (*WaveHoLaunchFn)(const WaveHoArgs&, int, size_t, hipStream_t
 WaveHoLaunchFn wave_ho_lookup(int G, int C, int order, int M);      // grad_wave_ho_inst.hip: prefixes through an HBM slot
 WaveHoLaunchFn wave_ho_undo_lookup_g16(int C, int order, int M);    // grad_wave_ho_inst_u16.hip / _u64.hip: scratch-free
 WaveHoLaunchFn wave_ho_undo_lookup_g64(int C, int order, int M);
+WaveHoLaunchFn wave_ho_undo_lookup_g32(int C, int order, int M);
 struct HoSweeps { WaveHoLaunchFn fn; int G, C; size_t lds, slot; };
 WaveLaunchFn wave_lookup_inc(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptd(int G, int C, int DP, int LQ);
@@ -74,9 +75,14 @@ bool ho_sweeps_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, H
     for (auto& sh : shapes) {
         if (sh[0] * sh[1] < R2) continue;
         hs->G = sh[0]; hs->C = sh[1];
+        // 33 .. 64 columns at order >= 3: two columns per lane and two pairs per wavefront instead of four and four -- the four-column instances of
+        // orders 3 / 4 spill (312 B .. 1.6 KB of scratch at one wavefront per SIMD): K(X) N = 512 order 4 64.7 -> 39.3 ms; at order 2 they do not (25.8 against 27.0).
+        // Option ho_g32: -1 this rule, 0 never, 1 always
+        if (hs->G == 16 && hs->C == 4 && c->grad_impl == 0 && (c->ho_g32 > 0 || (c->ho_g32 < 0 && order >= 3))) { hs->G = 32; hs->C = 2; }
         hs->lds = wave_ho_undo_lds(hs->G, R1, order, M);
         if (c->grad_impl == 0 && hs->lds <= 64 * 1024)
-            hs->fn = hs->G == 16 ? wave_ho_undo_lookup_g16(hs->C, order, M) : wave_ho_undo_lookup_g64(hs->C, order, M);
+            hs->fn = hs->G == 16 ? wave_ho_undo_lookup_g16(hs->C, order, M) : (hs->G == 32 ? wave_ho_undo_lookup_g32(hs->C, order, M) : wave_ho_undo_lookup_g64(hs->C, order, M));
+        if (!hs->fn && hs->G == 32) { hs->G = 16; hs->C = 4; }
         if (!hs->fn) { hs->fn = wave_ho_lookup(hs->G, hs->C, order, M); hs->lds = 0; }
         break;
     }

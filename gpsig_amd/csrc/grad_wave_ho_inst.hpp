@@ -60,6 +60,8 @@ WaveHoLaunchFn HO_CAT(wave_ho_undo_lookup_g, GPSIG_HO_UNDO_G)(int C, int order, 
 #if GPSIG_HO_UNDO_G == 16
     if (C == 2) return pick_undo<16, 2>(order, M);
     if (C == 4) return pick_undo<16, 4>(order, M);
+#elif GPSIG_HO_UNDO_G == 32
+    if (C == 2) return pick_undo<32, 2>(order, M);
 #else
     if (C == 2) return pick_undo<64, 2>(order, M);
     if (C == 4) return pick_undo<64, 4>(order, M);

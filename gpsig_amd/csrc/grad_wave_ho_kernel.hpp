@@ -537,6 +537,9 @@ struct WaveHoUndo {
     }
 };
 
+#ifndef HO_UNDO_ATTR
+#define HO_UNDO_ATTR
+#endif
 inline size_t wave_ho_undo_lds(int G, int R1, int order, int M) {
     int w = 0;
     for (int j = 1; j < M; ++j) w += 1 + (((j + 1) < order ? (j + 1) : order) - 1);
@@ -545,7 +548,7 @@ inline size_t wave_ho_undo_lds(int G, int R1, int order, int M) {
 
 // grid: ngroups / (64 / G) workgroups of one wavefront; dynamic LDS: wave_ho_undo_lds
 template <int G, int C, int MM, int O>
-__global__ void __launch_bounds__(64) seq_grad_wave_ho_undo_kernel(const WaveHoArgs A) {
+__global__ void __launch_bounds__(64) HO_UNDO_ATTR seq_grad_wave_ho_undo_kernel(const WaveHoArgs A) {
     extern __shared__ double ho_rowtot[];
     constexpr int PW = 64 / G, LQ = MM - 1, RW = ho_rowtot_words<O, MM>();
     const int lane = threadIdx.x, lam = lane % G;
