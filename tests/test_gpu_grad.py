@@ -1233,22 +1233,24 @@ def test_spectral_kernel_gradients(family, normalization, difference, order):
     assert rel(got, want) < 1e-10
 
 
-@pytest.mark.parametrize("base,d,num_lags", [("rbf", 70, 0), ("linear", 40, 2), ("matern32", 200, 0), ("rbf", 100, 1)])
-def test_gradients_beyond_64_columns(base, d, num_lags):
+@pytest.mark.parametrize("base,d,num_lags,order", [("rbf", 70, 0, 1), ("linear", 40, 2, 1), ("matern32", 200, 0, 1), ("rbf", 100, 1, 1),
+                                                   ("linear", 40, 2, 2), ("matern32", 70, 0, 3), ("rbf", 33, 1, 2)])
+def test_gradients_beyond_64_columns(base, d, num_lags, order):
     """Training with state spaces the gradient kernels (64 columns after lags) do not reach: up to 256 columns and beyond through the
     matrix route, against autograd of the oracle (the reference's benchmarks run num_lags = 1 on state spaces of up to 963 features:
-    benchmarks/run_gpsig_benchmarks.py:32)."""
+    benchmarks/run_gpsig_benchmarks.py:32).  order > 1 (round 6): the wide route's higher-order chains for the distance kernels, the matrix route's
+    (array operations with torch's autograd) for the others; the sequence lattices through the matrix route's lattice op."""
     from gpsig_amd import kernels, autodiff
     M, L = 3, 6
     cls = {"linear": kernels.SignatureLinear, "rbf": kernels.SignatureRBF, "matern32": kernels.SignatureMatern32}[base]
     rng = np.random.default_rng(36)
-    kern = cls(L * d, d, M, num_lags=num_lags or None, lengthscales=rng.uniform(0.8, 1.6, d) * np.sqrt(d), variances=rng.uniform(0.5, 1.5, M + 1))
+    kern = cls(L * d, d, M, num_lags=num_lags or None, lengthscales=rng.uniform(0.8, 1.6, d) * np.sqrt(d), variances=rng.uniform(0.5, 1.5, M + 1), order=order)
     mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
     # (round 6: the library's wide route takes the primitives it is built for -- the distance kernels --, the matrix route the rest)
     assert mod._mx("seq") if base == "linear" else not mod._mx("tvs")
     leaf = lambda t: None if t is None else t.detach().cpu().clone().requires_grad_(True)
     orc = OT.SignatureKernelTorchOracle(d, M, base, variances=leaf(mod.variances), sigma=leaf(mod.sigma), lengthscales=leaf(mod.lengthscales),
-                                        num_lags=num_lags, lags=leaf(mod.lags) if num_lags else None, gamma=leaf(mod.gamma) if num_lags else None)
+                                        num_lags=num_lags, lags=leaf(mod.lags) if num_lags else None, gamma=leaf(mod.gamma) if num_lags else None, order=order)
     extra = [(mod.raw_lags, orc.lags, "logistic"), (mod.raw_gamma, orc.gamma, "pos")] if num_lags else []
     _compare_module_with_oracle(mod, orc, d * (num_lags + 1), M, L, extra)
 
