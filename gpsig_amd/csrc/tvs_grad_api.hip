@@ -76,7 +76,12 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
     int64_t runs = 4096 / TB < 1 ? 1 : 4096 / TB;
     if (runs > N) runs = N;
     int64_t run = (N + runs - 1) / runs;
-    if (run < 8 && N >= 8) run = 8;
+    // (runs of at least 8 amortise a lane's load of its components -- unless that leaves most of the chip idle: a minibatch of 50 sequences against
+    // 500 tensors with increments is 16 x 7 x 3 = 336 wavefronts of 8 x 2 sweeps over the sequence, 16 x 50 x 3 = 2,400 of one)
+    if (run < 8 && N >= 8) {
+        run = 8;
+        while (run > 1 && TB * NR * ((N + run - 1) / run) < 2048) run /= 2;
+    }
     if (run > 64) run = 64;
     runs = (N + run - 1) / run;
     // the d/dx partial sums of all tensor blocks are bounded by the scratch budget: sequences in chunks of whole runs
