@@ -10,5 +10,5 @@ cp gpurun_out/r02/pmc_c2.txt gpurun_out/r02/kernel_stats_c2.txt $O/ 2>/dev/null
 python tools/bench_order_rbf.py > $O/bench_order_rbf.txt 2>&1
 python tools/bench_order_kzx.py > $O/bench_order_kzx.txt 2>&1
 bash tools/gpu_r6_h.sh > $O/shapes.log 2>&1
-timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -5 > $O/pytest_gpu.txt
+timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" | tail -6 > $O/pytest_gpu.txt
 tail -2 $O/pytest_gpu.txt
