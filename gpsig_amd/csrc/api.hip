@@ -1674,10 +1674,12 @@ static int tens_vs_seq_device(gpsig_ctx* c, const gpsig_params* p, bool raw, con
         ScaleParams s;
         CHK(scale_params(c, p, !raw, &s));
         const int d_eff = s.d_eff();
-        // beyond the tile kernel's 8 columns -- and, at 5 / 6 columns with increments, launches of few sequences: the tile kernel's two level sets sweep a
+        // beyond the tile kernel's 8 columns -- and, at 5 .. 8 columns with increments, launches of few sequences: the tile kernel's two level sets sweep a
         // 16-sequence tile one after the other, 8 us per time step whatever the count, where the chains here take 2.4 (ECG's shape: 1.23 -> 0.36 ms,
-        // profiles/r06_ab_small_widths.txt); the reverse tile kernel continues from the same chain totals
-        const bool few = increments && d_eff > 4 && d_eff <= 6 && N <= 256 && p->base_kernel == GPSIG_BASE_RBF;
+        // profiles/r06_ab_small_widths.txt); the reverse tile kernel continues from the same chain totals (at 7 / 8 columns the forward pass is what the
+        // older mappings take -- 0.83 against 0.68 ms at UWave's shape --, the reverse pass saves its own forward sweep: 2.05 -> 1.59; option
+        // wide_few_cols: the widest state space of this rule, A/B runs)
+        const bool few = increments && d_eff > 4 && d_eff <= (c->wide_few_cols > 0 ? c->wide_few_cols : 8) && N <= 256 && p->base_kernel == GPSIG_BASE_RBF;
         if (!wide_tvs_available(c, p, d_eff, Tn, N, L) || !(c->wide == 1 || d_eff > 8 || (few && c->wide != 0 && c->tvs_tile != 1))) return GPSIG_OK;
         void* xs;
         CHK(ensure(c, B_XT, sizeof(double) * size_t(N) * L * d_eff + 8, &xs));
@@ -2218,6 +2220,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "wide_lat_waves")) c->wide_lat_waves = value;
     else if (!strcmp(name, "wide_sym_fold")) c->wide_sym_fold = value ? 1 : 0;
     else if (!strcmp(name, "ho_g32")) c->ho_g32 = value;
+    else if (!strcmp(name, "wide_few_cols")) c->wide_few_cols = value;
     else if (!strcmp(name, "tvs_features")) c->tvs_features = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else if (!strcmp(name, "diag_own")) c->diag_own = value;
