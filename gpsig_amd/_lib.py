@@ -310,8 +310,4 @@ def context(device=0, stream=0):
     ctx = _contexts.get(key)
     if ctx is None:
         ctx = _contexts[key] = Context(*key)
-        # A/B runs of the tools: GPSIG_OPTIONS="name=value,name=value" is applied to every context as it is created (include/gpsig_hip.h: gpsig_set_option)
-        for item in filter(None, os.environ.get("GPSIG_OPTIONS", "").split(",")):
-            name, _, value = item.partition("=")
-            ctx.set_option(name.strip(), int(value))
     return ctx
