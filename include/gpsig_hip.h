@@ -168,6 +168,9 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 columns, one otherwise; 0 always one; 1 two / four / eight wherever a lane would hold that many columns
  *   "wide_sym_fold"  1 (default): the reverse pass of a symmetric Gram on the wide route runs over the pairs i <= j with the upstream gradient
  *                 folded onto them (G + G^T above the diagonal); 0: over all ordered pairs (for A/B runs)
+ *   "wide_few_cols"  widest state space (default 8) at which the tensor-vs-sequence FORWARD pass of at most 256 sequences against tensors with increments
+ *                 takes the wide chains (SignatureRBF; the reverse tile kernel continues from their totals); "ho_g32": -1 (default) the higher-order
+ *                 sweeps of 33 .. 64 lattice columns with two columns per lane at order >= 3, four otherwise; 0 always four; 1 always two
  *   order > 1 and "grad_impl": the sequence recursion's reverse pass runs as two sweeps of a wavefront per pair (csrc/grad_wave_ho_kernel.hpp;
  *                 <= 5 levels, min(order, levels) <= 4, lattices of <= 512 columns): 0 scratch-free where the row totals fit LDS, 3 with
  *                 the prefixes in an HBM slot per pair group, any other value the lattice operations of rounds 2-5 (tests' A/B reference) */
