@@ -1004,13 +1004,15 @@ class SignatureKernelModule(torch.nn.Module):
     def _mx(self, prim, cols=0):
         """Does level primitive ``prim`` ('seq', 'diag', 'tens', 'tvs') take the matrix route?  Always when ``matrix_route`` is set (the spectral
         kernel; A/B runs).  Beyond 64 columns the library's exact-shape kernels are not built: the wide route takes what it is built for (the
-        distance kernels at order 1; sequence lattices of up to 512 columns -- ``cols``: the shorter side's length), the matrix route the rest."""
+        distance kernels; sequence lattices of up to 512 columns -- ``cols``: the shorter side's length; order > 1 within the limits below), the matrix route the rest."""
         if self.matrix_route:
             return True
         if self._d_cols <= 64 or self.kern.low_rank:
             return False
-        first = self._spec.order == 1 or self._spec.num_levels == 1 or prim == "tens"            # (Kzz has no order; the wide Kzx chains: order <= 4)
-        wide = (prim in WIDE_PRIMITIVES and self._spec.base in WIDE_BASES and (first or (prim == "tvs" and min(self._spec.order, self._spec.num_levels) <= 4))
+        first = self._spec.order == 1 or self._spec.num_levels == 1 or prim == "tens"            # (Kzz has no order)
+        # order > 1 on the wide route: the Kzx chains at orders <= 4; the sequence lattices' sweeps (csrc/grad_wave_ho_kernel.hpp) at <= 5 levels, orders <= 4
+        high = min(self._spec.order, self._spec.num_levels) <= 4 and (prim == "tvs" or self._spec.num_levels <= 5)
+        wide = (prim in WIDE_PRIMITIVES and self._spec.base in WIDE_BASES and (first or high)
                 and _WIDE["value"] != 0 and cols - int(self._spec.difference) <= WIDE_LAT_MAX_COLS)
         return not wide
 

@@ -18,6 +18,9 @@ WaveHoLaunchFn wave_ho_lookup(int G, int C, int order, int M);      // grad_wave
 WaveHoLaunchFn wave_ho_undo_lookup_g16(int C, int order, int M);    // grad_wave_ho_inst_u16.hip / _u64.hip: scratch-free
 WaveHoLaunchFn wave_ho_undo_lookup_g64(int C, int order, int M);
 WaveHoLaunchFn wave_ho_undo_lookup_g32(int C, int order, int M);
+WaveHoLaunchFn wave_ho_levels_lookup_g16(int C, int order, int M);   // the forward pass: seq_levels_wave_ho_kernel
+WaveHoLaunchFn wave_ho_levels_lookup_g32(int C, int order, int M);
+WaveHoLaunchFn wave_ho_levels_lookup_g64(int C, int order, int M);
 struct HoSweeps { WaveHoLaunchFn fn; int G, C; size_t lds, slot; };
 WaveLaunchFn wave_lookup_inc(int G, int C, int DP, int LQ);
 WaveLaunchFn wave_lookup_ptd(int G, int C, int DP, int LQ);
@@ -89,6 +92,39 @@ bool ho_sweeps_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, H
     if (!hs->fn) return false;
     hs->slot = hs->lds == 0 ? sizeof(double) * size_t(ho_stash_words(order, M)) * size_t(R1 + hs->G - 1) * hs->G * hs->C : 0;
     return true;
+}
+
+// the forward pass by one sweep per pair (seq_levels_wave_ho_kernel): the same lane shapes
+bool ho_levels_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, HoSweeps* hs) {
+    const int M = p->num_levels, order = p->order < M ? p->order : M;
+    if (c->grad_impl != 0 || order < 2 || R1 < 1 || R2 < 1) return false;
+    static const int shapes[][2] = {{16, 2}, {16, 4}, {64, 2}, {64, 4}, {64, 8}};
+    hs->fn = nullptr; hs->lds = 0; hs->slot = 0;
+    for (auto& sh : shapes) {
+        if (sh[0] * sh[1] < R2) continue;
+        hs->G = sh[0]; hs->C = sh[1];
+        if (hs->G == 16 && hs->C == 4 && (c->ho_g32 > 0 || (c->ho_g32 < 0 && order >= 3))) { hs->G = 32; hs->C = 2; }
+        hs->fn = hs->G == 16 ? wave_ho_levels_lookup_g16(hs->C, order, M) : (hs->G == 32 ? wave_ho_levels_lookup_g32(hs->C, order, M) : wave_ho_levels_lookup_g64(hs->C, order, M));
+        break;
+    }
+    return hs->fn != nullptr;
+}
+
+// dM (npairs, R1, R2) -> levels: level m of pair (i, j) at out[m * gm + i * gi + j * gj], (i, j) as in ho_sweeps_launch
+int ho_levels_launch(gpsig_ctx* c, const HoSweeps& hs, int M, int R1, int R2, const double* dM, double* out, int64_t gm, int64_t gi, int64_t gj, int64_t N2,
+                     bool diag, int64_t pair0, int64_t npairs) {
+    const int PW = 64 / hs.G;
+    int64_t ngroups = npairs < 16384 ? npairs : 16384;
+    if (ngroups < PW) ngroups = PW;
+    ngroups = (ngroups + PW - 1) / PW * PW;
+    WaveHoArgs A;
+    memset(&A, 0, sizeof(A));
+    A.gm = gm; A.gi = gi; A.gj = gj; A.N2 = int(N2); A.diag = diag ? 1 : 0;
+    A.R1 = R1; A.R2 = R2; A.M = M;
+    A.dM = dM; A.lam = out; A.pair0 = pair0; A.npairs = npairs; A.ngroups = int(ngroups);
+    const hipError_t e = hs.fn(A, int(ngroups / PW), 0, c->stream);
+    if (e != hipSuccess) return fail(c, GPSIG_ERR_HIP, "higher-order levels: launch failed: %s", hipGetErrorString(e));
+    return GPSIG_OK;
 }
 
 // dM (npairs, R1, R2) -> lam (npairs, R1, R2); G[level * gm + i * gi + j * gj] with (i, j) = divmod(pair0 + pair, N2) (diag: i = j = pair0 + pair)

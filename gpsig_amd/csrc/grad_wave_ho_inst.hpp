@@ -54,6 +54,24 @@ static WaveHoLaunchFn pick_undo(int order, int M) {
     if (M == 5 && order == 4) return &wave_ho_undo_launch<G, C, 5, 4>;
     return nullptr;
 }
+template <int G, int C, int MM, int O>
+static hipError_t wave_ho_levels_launch(const WaveHoArgs& a, int nblocks, size_t, hipStream_t s) {
+    hipLaunchKernelGGL((seq_levels_wave_ho_kernel<G, C, MM, O>), dim3(nblocks), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+template <int G, int C>
+static WaveHoLaunchFn pick_levels(int order, int M) {
+    if (M == 2 && order == 2) return &wave_ho_levels_launch<G, C, 2, 2>;
+    if (M == 3 && order == 2) return &wave_ho_levels_launch<G, C, 3, 2>;
+    if (M == 3 && order == 3) return &wave_ho_levels_launch<G, C, 3, 3>;
+    if (M == 4 && order == 2) return &wave_ho_levels_launch<G, C, 4, 2>;
+    if (M == 4 && order == 3) return &wave_ho_levels_launch<G, C, 4, 3>;
+    if (M == 4 && order == 4) return &wave_ho_levels_launch<G, C, 4, 4>;
+    if (M == 5 && order == 2) return &wave_ho_levels_launch<G, C, 5, 2>;
+    if (M == 5 && order == 3) return &wave_ho_levels_launch<G, C, 5, 3>;
+    if (M == 5 && order == 4) return &wave_ho_levels_launch<G, C, 5, 4>;
+    return nullptr;
+}
 #define HO_CAT2(a, b) a##b
 #define HO_CAT(a, b) HO_CAT2(a, b)
 WaveHoLaunchFn HO_CAT(wave_ho_undo_lookup_g, GPSIG_HO_UNDO_G)(int C, int order, int M) {
@@ -66,6 +84,19 @@ WaveHoLaunchFn HO_CAT(wave_ho_undo_lookup_g, GPSIG_HO_UNDO_G)(int C, int order, 
     if (C == 2) return pick_undo<64, 2>(order, M);
     if (C == 4) return pick_undo<64, 4>(order, M);
     if (C == 8) return pick_undo<64, 8>(order, M);
+#endif
+    return nullptr;
+}
+WaveHoLaunchFn HO_CAT(wave_ho_levels_lookup_g, GPSIG_HO_UNDO_G)(int C, int order, int M) {
+#if GPSIG_HO_UNDO_G == 16
+    if (C == 2) return pick_levels<16, 2>(order, M);
+    if (C == 4) return pick_levels<16, 4>(order, M);
+#elif GPSIG_HO_UNDO_G == 32
+    if (C == 2) return pick_levels<32, 2>(order, M);
+#else
+    if (C == 2) return pick_levels<64, 2>(order, M);
+    if (C == 4) return pick_levels<64, 4>(order, M);
+    if (C == 8) return pick_levels<64, 8>(order, M);
 #endif
     return nullptr;
 }

@@ -113,6 +113,12 @@ struct WaveHoFwd {
     // ct, cr: the left neighbour's st, sr of ITS previous step (zeros for the first lane of a pair).  store(word, column, value).
     template <class Store>
     __device__ __forceinline__ void step(const double (&dm)[C], const double (&ct)[LQ], const double (&cr)[LQ][O - 1], int M, Store&& store) {
+        double none = 0.0;
+        step_impl<false>(dm, ct, cr, M, store, none);
+    }
+    // TOP (M == LQ + 1): the cells' totals of level M's grid are added to ktop (the forward pass proper: K_M = their sum over the lattice)
+    template <bool TOP, class Store>
+    __device__ __forceinline__ void step_impl(const double (&dm)[C], const double (&ct)[LQ], const double (&cr)[LQ][O - 1], int M, Store&& store, double& ktop) {
         double pv[LQ][C], rt[LQ], rr[LQ][O - 1];
 #pragma unroll
         for (int j = 0; j < LQ; ++j) {
@@ -155,6 +161,14 @@ struct WaveHoFwd {
                         for (int r = 0; r < dn; ++r)
 #pragma unroll
                             for (int k = 0; k < dn; ++k) Rp[r][k] = Rn[r][k];
+                    } else if constexpr (TOP) {
+                        double Rn[O][O];
+                        ho_next_grid<O, J>(dm[c], pv[J - 1][c], CP, RP, Rp, Rn);
+                        constexpr int dn = ho_dim<O>(J + 1);
+#pragma unroll
+                        for (int r = 0; r < dn; ++r)
+#pragma unroll
+                            for (int k = 0; k < dn; ++k) ktop += Rn[r][k];
                     }
                     rt[J - 1] += tot;
                     q[J - 1][c] += rt[J - 1];
@@ -651,6 +665,69 @@ __global__ void __launch_bounds__(64) HO_UNDO_ATTR seq_grad_wave_ho_undo_kernel(
             }
         }
         __syncthreads();                                                 // the next pair rewrites the row totals
+    }
+}
+
+// ---- forward pass: the levels themselves (signature_algs.py:58-71), one sweep per pair.  K_m (m < M) = the 2-D prefix of tot_m at the last cell (the
+// group's last lane: columns beyond the lattice pass the row prefixes on unchanged), K_M = the sum over the cells of level M's grid (per-lane sums,
+// added up by the group's last lane).  A.lam: the level array, level m of pair (i, j) at [m * gm + i * gi + j * gj].
+template <int G, int C, int MM, int O>
+__global__ void __launch_bounds__(64) seq_levels_wave_ho_kernel(const WaveHoArgs A) {
+    __shared__ double red[64];
+    constexpr int PW = 64 / G, LQ = MM - 1;
+    const int lane = threadIdx.x, lam = lane % G;
+    const int grp = blockIdx.x * PW + lane / G;
+    const int R1 = A.R1, R2 = A.R2;
+    const int TF = R1 + G - 1;
+    const int64_t rounds = (A.npairs + A.ngroups - 1) / A.ngroups;
+    int nvalid = R2 - C * lam;
+    nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t pp = rd * A.ngroups + grp;
+        const bool have = pp < A.npairs;
+        const int64_t pg = A.pair0 + (have ? pp : 0);
+        const int64_t i = A.diag ? pg : pg / A.N2, j = A.diag ? pg : pg % A.N2;
+        const double* const dmp = A.dM + size_t(have ? pp : 0) * R1 * R2;
+        auto load_dm = [&](int a, double (&dm)[C]) {
+            const bool ok = a >= 0 && a < R1;
+            const size_t row = size_t(ok ? a : 0) * R2;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int b = C * lam + c;
+                const double v = dmp[row + (b < R2 ? b : R2 - 1)];
+                dm[c] = (ok && c < nvalid) ? v : 0.0;
+            }
+        };
+        WaveHoFwd<C, LQ, O> fw;
+        fw.reset();
+        double ktop = 0.0, dcur[C];
+        load_dm(0 - lam, dcur);
+        for (int t = 0; t < TF; ++t) {
+            double ct[LQ], cr[LQ][O - 1], dnext[C];
+#pragma unroll
+            for (int m = 0; m < LQ; ++m) {
+                ct[m] = wave_from_left<G>(fw.st[m]);
+#pragma unroll
+                for (int k = 0; k < O - 1; ++k) cr[m][k] = wave_from_left<G>(fw.sr[m][k]);
+            }
+            const int a = t - lam;
+            load_dm(a + 1, dnext);
+            if (a >= 0 && a < R1) fw.template step_impl<true>(dcur, ct, cr, MM, [](int, int, double) {}, ktop);
+#pragma unroll
+            for (int c = 0; c < C; ++c) dcur[c] = dnext[c];
+        }
+        __syncthreads();
+        red[lane] = ktop;
+        __syncthreads();
+        if (lam == G - 1 && have) {
+            double s = 0.0;
+            for (int l = 0; l < G; ++l) s += red[lane - (G - 1) + l];
+            double* const o = A.lam + i * A.gi + j * A.gj;
+            o[0] = 1.0;                                                  // signature_algs.py:49-53
+#pragma unroll
+            for (int m = 1; m <= LQ; ++m) o[int64_t(m) * A.gm] = fw.q[m - 1][C - 1];
+            o[int64_t(MM) * A.gm] = s;
+        }
     }
 }
 

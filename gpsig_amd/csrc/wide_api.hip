@@ -24,6 +24,9 @@ struct HoSweeps { WaveHoLaunchFn fn; int G, C; size_t lds, slot; };
 bool ho_sweeps_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, HoSweeps* hs);
 int ho_sweeps_launch(gpsig_ctx* c, const HoSweeps& hs, int M, int R1, int R2, const double* dM, double* lam, const double* G, int64_t gm, int64_t gi,
                      int64_t gj, int64_t N2, bool diag, int64_t pair0, int64_t npairs);
+bool ho_levels_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, HoSweeps* hs);
+int ho_levels_launch(gpsig_ctx* c, const HoSweeps& hs, int M, int R1, int R2, const double* dM, double* out, int64_t gm, int64_t gi, int64_t gj, int64_t N2,
+                     bool diag, int64_t pair0, int64_t npairs);
 
 namespace {
 
@@ -293,8 +296,12 @@ constexpr int WIDE_LAT_MAX_COLS = 512;            // 64 lanes x 8 columns
 
 bool wide_lat_available(const gpsig_ctx* c, const gpsig_params* p, int L1, int L2) {
     if (c->wide == 0 || c->capturing) return false;
-    if (!wide_kind(p->base_kernel) || (p->order > 1 && p->num_levels > 1) || p->num_levels > WIDE_MAX_LEVELS || p->num_levels < 1) return false;
+    if (!wide_kind(p->base_kernel) || p->num_levels > WIDE_MAX_LEVELS || p->num_levels < 1) return false;
     const int dr = p->difference ? 1 : 0;
+    if (p->order > 1 && p->num_levels > 1) {      // higher orders: the forward and the reverse sweeps of grad_wave_ho_kernel.hpp (<= 5 levels, orders <= 4)
+        HoSweeps hf, hb;
+        return L1 - dr >= 1 && L2 - dr >= 1 && ho_levels_plan(c, p, L1 - dr, L2 - dr, &hf) && ho_sweeps_plan(c, p, L1 - dr, L2 - dr, &hb);
+    }
     return L1 >= 1 && L2 >= 1 && L2 - dr <= WIDE_LAT_MAX_COLS;
 }
 
@@ -354,12 +361,17 @@ int lat_arguments(gpsig_ctx* c, const LatPlan& pl, int64_t i0, int64_t ni, int64
 int wide_lat_forward(gpsig_ctx* c, const gpsig_params* p, int d, const double* Xs, const double* Ys, int64_t N1, int64_t N2, int L1, int L2, bool diag,
                      double* out) {
     LatPlan pl;
-    CHK(lat_plan(c, p, d, Xs, Ys, N1, N2, L1, L2, diag, 1, &pl));
+    const bool ho = p->order > 1 && p->num_levels > 1;
+    HoSweeps hs;
+    if (ho && !ho_levels_plan(c, p, L1 - (p->difference ? 1 : 0), L2 - (p->difference ? 1 : 0), &hs))
+        return fail(c, GPSIG_ERR_UNSUPPORTED, "no higher-order forward sweep for this shape");
+    CHK(lat_plan(c, p, d, Xs, Ys, N1, N2, L1, L2, diag, ho ? 2 : 1, &pl));
     const int M = p->num_levels;
-    void* arg;
+    void *arg, *dmat = nullptr;
     CHK(ensure(c, B_WD2, sizeof(double) * size_t(pl.chunk_i) * L1 * L2 * size_t(diag ? 1 : N2) + 64, &arg));
-    const int NW = lat_waves(c, pl.C, diag ? (N1 < pl.chunk_i ? N1 : pl.chunk_i) : (N1 < pl.chunk_i ? N1 : pl.chunk_i) * N2);
-    WideLatKernel fn = lat_kernel(M, pl.C, false, p->base_kernel == GPSIG_BASE_RBF, NW);
+    if (ho) CHK(ensure(c, B_WD6, sizeof(double) * size_t(pl.chunk_i) * L1 * L2 * size_t(diag ? 1 : N2) + 64, &dmat));
+    const int NW = ho ? 1 : lat_waves(c, pl.C, diag ? (N1 < pl.chunk_i ? N1 : pl.chunk_i) : (N1 < pl.chunk_i ? N1 : pl.chunk_i) * N2);
+    WideLatKernel fn = ho ? nullptr : lat_kernel(M, pl.C, false, p->base_kernel == GPSIG_BASE_RBF, NW);
     hipEvent_t e0, e1;
     bool timed;
     CHK(wide_timing_begin(c, &e0, &e1, &timed));
@@ -372,6 +384,17 @@ int wide_lat_forward(gpsig_ctx* c, const gpsig_params* p, int d, const double* X
         A.P = diag ? ni : ni * N2; A.p0 = 0; A.Ptot = pl.Ptot;
         A.L1 = L1; A.L2 = L2; A.M = M; A.kind = p->base_kernel; A.difference = pl.dr;
         A.out = out + (diag ? i0 : i0 * N2);              // (the kernel's pair index starts at 0 in this chunk's lattices)
+        if (ho) {
+            if (pl.R1 < 1 || pl.R2 < 1) return fail(c, GPSIG_ERR_UNSUPPORTED, "empty lattices");
+            if (p->base_kernel == GPSIG_BASE_RBF)
+                hipLaunchKernelGGL(wide_lattice_dm_kernel<true>, dim3(grid_for(A.P * int64_t(pl.R1) * pl.R2)), dim3(256), 0, c->stream, A, static_cast<double*>(dmat));
+            else
+                hipLaunchKernelGGL(wide_lattice_dm_kernel<false>, dim3(grid_for(A.P * int64_t(pl.R1) * pl.R2)), dim3(256), 0, c->stream, A, static_cast<double*>(dmat));
+            HIPCHK(c, hipGetLastError());
+            CHK(ho_levels_launch(c, hs, M, pl.R1, pl.R2, static_cast<const double*>(dmat), out, pl.Ptot, diag ? 1 : N2, diag ? 0 : 1, diag ? 1 : N2, diag,
+                                 diag ? i0 : i0 * N2, A.P));
+            continue;
+        }
         hipLaunchKernelGGL(fn, dim3(unsigned(A.P < 65535 ? A.P : 65535)), dim3(64 * NW), 0, c->stream, A);
         HIPCHK(c, hipGetLastError());
     }

@@ -387,3 +387,51 @@ def test_wide_higher_order_chains_and_gradient(M, order, T, N, L, d, base):
                       ptr(dgZ), ptr(dgX), ptr(dgF), C.cast(dgb.data_ptr(), _P))
             side.synchronize()
             assert rel(dgZ, tZ.grad) < 1e-9 and rel(dgX, tX.grad) < 1e-9 and rel(dgF, tF.grad) < 1e-9, (use_aux, rel(dgZ, tZ.grad), rel(dgX, tX.grad), rel(dgF, tF.grad))
+
+
+@pytest.mark.parametrize("M,order,N1,N2,L1,L2,d,kind", [(4, 2, 7, 5, 9, 13, 12, "cross"), (3, 3, 6, 6, 40, 40, 28, "sym"), (4, 2, 9, 9, 33, 33, 70, "diag"), (5, 4, 3, 4, 20, 61, 126, "cross"),
+                                                       (4, 3, 5, 5, 100, 100, 5, "diag"), (2, 2, 3, 2, 40, 260, 10, "cross"), (5, 2, 20, 20, 8, 8, 16, "sym"), (4, 4, 4, 4, 12, 12, 300, "sym")])
+@pytest.mark.parametrize("base", ["rbf", "matern32", "matern12"])
+def test_wide_higher_order_lattices_and_gradient(M, order, N1, N2, L1, L2, d, kind, base):
+    """Round 6: the higher-order sequence recursion (signature_algs.py:37-74) on the wide route, both directions -- argument lattices by dgemm, dM by
+    wide_lattice_dm_kernel, one forward sweep per pair (seq_levels_wave_ho_kernel: K_m < M from the 2-D prefixes at the last cell, K_M from the cells'
+    level-M grids) or the two sweeps of the reverse pass, the adjoint contracted back -- at any number of columns: values and gradients against the
+    oracle's autograd, forced (option wide = 1) and as the planner routes it, in one chunk and in several."""
+    if base != "rbf" and (M, order) in ((2, 2), (5, 2), (4, 4), (5, 4)):
+        pytest.skip("a sample of the shapes is enough for the Matern families")
+    rng = np.random.default_rng(100 * M + L2 + d + order)
+    ctx = _host_ctx()
+    s = 1.0 / np.sqrt(d)
+    try:
+        for difference in (True, False):
+            X = np.cumsum(rng.standard_normal((N1, L1, d)) * 0.5 * s, axis=1)
+            Y = np.cumsum(rng.standard_normal((N2, L2, d)) * 0.5 * s, axis=1) if kind == "cross" else None
+            G = rng.standard_normal((M + 1, N1) if kind == "diag" else (M + 1, N1, N2 if kind == "cross" else N1)) * (1.0 if difference else 1e-2)
+            kt = OT.SignatureKernelTorchOracle(d, M, base, difference=difference, order=order)
+            tX = torch.tensor(X, requires_grad=True)
+            tY = None if Y is None else torch.tensor(Y, requires_grad=True)
+            want = kt.K_seq_diag_levels(tX) if kind == "diag" else kt.K_seq_levels(tX, tY)
+            (want * torch.tensor(G)).sum().backward()
+            keep = []
+            from gpsig_amd.autodiff import _Spec
+            p = _Spec(base, M, difference, 0.0, order=order).params(d, 0.0, keep)
+            for wide, mb in ((1, 0), (1, 1), (-1, 0)):
+                ctx.set_option("wide", wide)
+                ctx.set_option("wide_chunk_mb", mb)
+                out = np.full(G.shape, np.nan)
+                gX, gY, gb = np.full_like(X, np.nan), (None if Y is None else np.full_like(Y, np.nan)), np.zeros(2)
+                if kind == "diag":
+                    ctx.call("gpsig_seq_diag_levels", p, _vp(X), N1, L1, _vp(out))
+                    ctx.call("gpsig_seq_diag_levels_grad", p, _vp(X), N1, L1, _vp(G), _vp(gX), gb.ctypes.data_as(_P))
+                else:
+                    n2, l2 = (N2, L2) if Y is not None else (N1, L1)
+                    ctx.call("gpsig_seq_gram_levels", p, _vp(X), _vp(Y), N1, n2, L1, l2, _vp(out))
+                    ctx.call("gpsig_seq_gram_levels_grad", p, _vp(X), _vp(Y), N1, n2, L1, l2, _vp(G), _vp(gX), _vp(gY), gb.ctypes.data_as(_P))
+                tv, tg = (1e-6, 1e-5) if (base == "matern12" and kind != "cross") else (1e-9, 1e-8)
+                assert rel(out, want) < tv, (difference, wide, mb, rel(out, want))
+                assert rel(gX, tX.grad) < tg, (difference, wide, mb, rel(gX, tX.grad))
+                if Y is not None:
+                    assert rel(gY, tY.grad) < 1e-8, (difference, wide, mb, rel(gY, tY.grad))
+    finally:
+        ctx.set_option("wide", -1)
+        ctx.set_option("wide_chunk_mb", 0)
