@@ -435,3 +435,27 @@ def test_wide_higher_order_lattices_and_gradient(M, order, N1, N2, L1, L2, d, ki
     finally:
         ctx.set_option("wide", -1)
         ctx.set_option("wide_chunk_mb", 0)
+
+
+@pytest.mark.parametrize("d,num_lags,order", [(6, 1, 1), (13, 1, 1), (5, 1, 2)])
+def test_wide_training_step_recorded_as_one_hip_graph(d, num_lags, order):
+    """SVGPModule.fit(graph=True) at the reference's kind of shape (time-augmented columns doubled by one lag: 12 / 26 / 10 columns, inducing tensors with
+    increments): the wide route's dgemms and kernels record into the step's HIP graph like the exact-shape kernels -- the replayed steps give the eager
+    loop's ELBO trace and parameters."""
+    from gpsig_amd import kernels, models, likelihoods as LK, inducing_variables as iv
+    rng = np.random.default_rng(48)
+    N, L, M, T = 30, 15, 4, 9
+    X = np.cumsum(rng.standard_normal((N, L, d)) * 0.3 / np.sqrt(d), axis=1).reshape(N, -1)
+    Y = rng.integers(0, 2, (N, 1)).astype(np.float64)
+    Xg, Yg = torch.tensor(X, device="cuda:0"), torch.tensor(Y, device="cuda:0")
+    Z = rng.standard_normal((M * (M + 1) // 2, T, 2, d * (num_lags + 1))) * 0.4 / np.sqrt(d)
+    out = {}
+    for graph in (False, True):
+        kern = kernels.SignatureRBF(L * d, d, M, lengthscales=np.sqrt(d), num_lags=num_lags, order=order)
+        model = models.SVGPModule(kern, iv.InducingTensors(Z.copy(), M, increments=True), LK.Bernoulli(), num_data=N, device="cuda:0")
+        trace = model.fit(Xg, Yg, iterations=10, lr=0.02, minibatch_size=12, seed=5, graph=graph)
+        out[graph] = (np.asarray(trace), [p.detach().cpu().numpy().copy() for p in model.parameters()])
+    assert len(out[True][0]) == 10 and np.isfinite(out[True][0]).all()
+    assert np.abs(out[True][0] - out[False][0]).max() <= 1e-5 * np.abs(out[False][0]).max()
+    for a, b in zip(out[True][1], out[False][1]):
+        assert np.abs(a - b).max() <= 1e-4 * (np.abs(b).max() + 1e-12)
