@@ -661,21 +661,31 @@ int seq_grad_ho_wave(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, cons
     if (ni_max > 65535) ni_max = 65535;
     void* lat;
     CHK(ensure(c, B_GR5, per_pair * size_t(nj) * size_t(ni_max) + 64, &lat));
+    // the symmetric Gram (one array on both sides): the pairs i <= j with the upstream gradient folded onto them, as the wide route's reverse pass
+    const bool fold = sym && !diag && N1 == N2 && L1 == L2 && c->wide_sym_fold != 0;
+    if (fold) {
+        void* gs;
+        CHK(ensure(c, B_WD10, sizeof(double) * size_t(M + 1) * N1 * N1 + 64, &gs));
+        hipLaunchKernelGGL(ho_sym_upstream_kernel, dim3(grid_for(int64_t(M + 1) * N1 * N1)), dim3(256), 0, c->stream, Gup, N1, M + 1, static_cast<double*>(gs));
+        HIPCHK(c, hipGetLastError());
+        Gup = static_cast<const double*>(gs);
+    }
     LamContractArgs K;
     memset(&K, 0, sizeof(K));
     K.X = X; K.Y = Y; K.L1 = L1; K.L2 = L2; K.d = d; K.kind = p->base_kernel; K.mode = mode == MODE_INC ? MODE_PT_DIFF : mode;
     K.p0 = p->base_params[0]; K.p1 = p->base_params[1]; K.diag = diag ? 1 : 0;
     for (int64_t i0 = 0; i0 < N1; i0 += ni_max) {
         const int64_t ni = (N1 - i0 < ni_max) ? N1 - i0 : ni_max;
-        const int64_t npairs = ni * nj, P = npairs * int64_t(cells);
+        const int64_t j0 = fold ? i0 : 0, nje = nj - j0;             // the chunk's right sequences
+        const int64_t npairs = ni * nje, P = npairs * int64_t(cells);
         double* const dmat = static_cast<double*>(lat);
         double* const lam = dmat + P;
-        const HoBlock B{i0, ni, diag ? i0 : 0, nj, diag ? 1 : 0};
+        const HoBlock B{i0, ni, diag ? i0 : j0, nje, diag ? 1 : 0};
         hipLaunchKernelGGL(ho_dm_kernel, dim3(grid_for(P)), dim3(256), 0, c->stream, X, Y, L1, L2, d, int(p->base_kernel), mode == MODE_PT_NODIFF ? 1 : 0,
                            K.p0, K.p1, B, R1, R2, dmat);
         HIPCHK(c, hipGetLastError());
-        CHK(ho_sweeps_launch(c, hs, M, R1, R2, dmat, lam, Gup, gm, gi, gj, N2, diag, i0 * nj, npairs));
-        K.lam = lam; K.i0 = i0; K.ni = ni; K.j0 = B.j0; K.nj = nj;
+        CHK(ho_sweeps_launch(c, hs, M, R1, R2, dmat, lam, Gup + j0, gm, gi, gj, diag ? N2 : nje, diag, i0 * nje, npairs));
+        K.lam = lam; K.i0 = i0; K.ni = ni; K.j0 = B.j0; K.nj = nje;
         auto slices = [](int64_t targets, int64_t partners) {
             int64_t s = (CONTRACT_BLOCKS + targets - 1) / targets;
             if (s > partners) s = partners;
@@ -683,13 +693,13 @@ int seq_grad_ho_wave(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, cons
             return s < 1 ? int64_t(1) : s;
         };
         K.gT = gX; K.gbase = gbase;
-        K.nslices = int(diag ? 1 : slices(ni, nj));
+        K.nslices = int(diag ? 1 : slices(ni, nje));
         int blk = L1 >= 256 ? 256 : int((L1 + 63) / 64 * 64);
         CHK(launch_contract<0>(c, DP, dim3(unsigned(ni), unsigned(K.nslices)), blk, sizeof(double) * size_t(L2) * (DP + 1), K));
         K.gT = (diag || sym) ? gX : gY; K.gbase = nullptr;
-        K.nslices = int(diag ? 1 : slices(nj, ni));
+        K.nslices = int(diag ? 1 : slices(nje, ni));
         blk = L2 >= 256 ? 256 : int((L2 + 63) / 64 * 64);
-        CHK(launch_contract<1>(c, DP, dim3(unsigned(diag ? ni : nj), unsigned(K.nslices)), blk, sizeof(double) * size_t(L1) * (DP + 1), K));
+        CHK(launch_contract<1>(c, DP, dim3(unsigned(diag ? ni : nje), unsigned(K.nslices)), blk, sizeof(double) * size_t(L1) * (DP + 1), K));
     }
     *done = true;
     return GPSIG_OK;

@@ -50,6 +50,16 @@ __global__ void ho_dm_kernel(const double* __restrict__ X, const double* __restr
     }
 }
 
+// The symmetric Gram's upstream gradient folded onto the pairs i <= j (the levels are symmetric functions of the two sequences):
+// Gs[m][i][j] = G[m][i][j] + G[m][j][i] (j > i),  G[m][i][i] (j == i),  0 (j < i).
+__global__ void ho_sym_upstream_kernel(const double* __restrict__ G, int64_t N, int M1, double* __restrict__ Gs) {
+    const int64_t total = int64_t(M1) * N * N;
+    for (int64_t idx = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; idx < total; idx += int64_t(gridDim.x) * blockDim.x) {
+        const int64_t j = idx % N, i = (idx / N) % N, m = idx / (N * N);
+        Gs[idx] = j > i ? G[idx] + G[(m * N + j) * N + i] : (j == i ? G[idx] : 0.0);
+    }
+}
+
 // dst = (acc ? dst : 0) + scale * E(src), E the EXCLUSIVE cumulative sum along axis 0 (a) or 1 (b), from the front or, with
 // reverse, from the back (the transpose of the forward one).  One thread per lattice line; dst may alias src.
 __global__ void ho_cumsum_kernel(const double* src, double* dst, int64_t npairs, int R1, int R2, int axis, int reverse, double scale, int acc) {
