@@ -664,6 +664,8 @@ int seq_grad_ho_wave(gpsig_ctx* c, const gpsig_params* p, int DP, int mode, cons
     // the symmetric Gram (one array on both sides): the pairs i <= j with the upstream gradient folded onto them, as the wide route's reverse pass
     const bool fold = sym && !diag && N1 == N2 && L1 == L2 && c->wide_sym_fold != 0;
     if (fold) {
+        const int64_t cap = N1 / 16 > 8 ? N1 / 16 : 8;          // (the chunk's square below the diagonal is swept with zero upstream gradients: keep it small)
+        if (ni_max > cap) ni_max = cap;
         void* gs;
         CHK(ensure(c, B_WD10, sizeof(double) * size_t(M + 1) * N1 * N1 + 64, &gs));
         hipLaunchKernelGGL(ho_sym_upstream_kernel, dim3(grid_for(int64_t(M + 1) * N1 * N1)), dim3(256), 0, c->stream, Gup, N1, M + 1, static_cast<double*>(gs));

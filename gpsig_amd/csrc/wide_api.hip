@@ -420,6 +420,9 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     // the symmetric Gram (one array on both sides): the pairs i <= j with the upstream gradient folded onto them -- half the lattices
     const bool fold = !diag && Ys == nullptr && N1 == N2 && L1 == L2 && c->wide_sym_fold != 0;
     if (fold) {
+        // (a chunk of ni left sequences still sweeps its ni x ni square whole -- zeros below the diagonal: chunks of at most N / 16 keep that under 4 %)
+        const int64_t cap = N1 / 16 > 8 ? N1 / 16 : 8;
+        if (pl.chunk_i > cap) pl.chunk_i = cap;
         void* gs;
         CHK(ensure(c, B_WD10, sizeof(double) * size_t(p->num_levels + 1) * N1 * N1 + 64, &gs));
         hipLaunchKernelGGL(wide_sym_upstream_kernel, dim3(grid_for(int64_t(p->num_levels + 1) * N1 * N1)), dim3(256), 0, c->stream, G, N1, p->num_levels + 1,
