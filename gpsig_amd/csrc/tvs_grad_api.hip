@@ -58,7 +58,8 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
     if (ho && (p->base_kernel != GPSIG_BASE_RBF || (p->order < M ? p->order : M) > TVSG_MAX_ORDER)) return GPSIG_OK;
     const int D = tvs_tile_width(d);
     if (D == 0 || M > 6 || Tn < 1 || N < 1) return GPSIG_OK;
-    const int kind = p->base_kernel == GPSIG_BASE_LINEAR ? BASE_LINEAR : (p->base_kernel == GPSIG_BASE_RBF ? BASE_RBF : -1);
+    const bool matern = !ho && c->tvs_grad_matern != 0 && (p->base_kernel == GPSIG_BASE_MATERN12 || p->base_kernel == GPSIG_BASE_MATERN32 || p->base_kernel == GPSIG_BASE_MATERN52);
+    const int kind = p->base_kernel == GPSIG_BASE_LINEAR ? BASE_LINEAR : (p->base_kernel == GPSIG_BASE_RBF ? BASE_RBF : (matern ? TVSG_MATERN : -1));
     const bool collapse = increments && kind == BASE_LINEAR;              // <x, z1> - <x, z0> = <x, z1 - z0>
     const bool paired = increments && !collapse;
     const int E = paired ? 2 : 1;
@@ -66,7 +67,7 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
     if (!fn) return GPSIG_OK;
     const int NR = tvs_grad_tile_roles(M, kind);
     const int rec_elems = (L * D + L + TVSG_REC_ALIGN - 1) / TVSG_REC_ALIGN * TVSG_REC_ALIGN;
-    const size_t lds = tvs_grad_tile_lds_bytes(D, rec_elems, kind == BASE_RBF);
+    const size_t lds = tvs_grad_tile_lds_bytes(D, rec_elems, tvsg_has_table(kind));
     if (lds > 64 * 1024) return GPSIG_OK;
     const int64_t Tpad = (Tn + 63) / 64 * 64;
     const int tpw = paired ? 32 : 64;
@@ -90,7 +91,8 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
     if (chunk_runs < 1) chunk_runs = 1;
     if (chunk_runs > runs) chunk_runs = runs;
     if (chunk_runs > 65535) chunk_runs = 65535;
-    const double pre = kind == BASE_RBF ? EXP_PRESCALE256 : 1.0;
+    const double mat_c = p->base_kernel == GPSIG_BASE_MATERN12 ? 1.0 : (p->base_kernel == GPSIG_BASE_MATERN32 ? 1.7320508075688772935 : 2.2360679774997896964);
+    const double pre = kind == BASE_RBF ? EXP_PRESCALE256 : (kind == TVSG_MATERN ? mat_c * 256.0 / 0x1.62e42fefa39efp-1 : 1.0);
     ScaleParams s;
     memset(&s, 0, sizeof(s));
     s.d_in = d;
@@ -132,6 +134,7 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
         A.L = L; A.d = d; A.kind = p->base_kernel; A.difference = p->difference; A.M = M;
         A.run = int(run); A.rec_elems = rec_elems; A.order = p->order < M ? p->order : M;
         A.p0 = p->base_params[0]; A.p1 = p->base_params[1];
+        A.mat_a1 = p->base_kernel == GPSIG_BASE_MATERN12 ? 0.0 : 1.0; A.mat_a2 = p->base_kernel == GPSIG_BASE_MATERN52 ? 1.0 / 3.0 : 0.0; A.mat_g = pre * mat_c;
         HIPCHK(c, fn(A, dim3(unsigned(TB), unsigned(nr), unsigned(NR)), lds, c->stream));
         const int64_t rows = (n1 - n0) * L;
         hipLaunchKernelGGL(tvs_grad_reduce_gx_kernel, dim3(grid_for(rows * d)), dim3(256), 0, c->stream, static_cast<const double*>(gxp), int(TB) * NR, rows,

@@ -20,6 +20,7 @@ template <int M, int D>
 static TvsGradTileLaunchFn tvs_grad_tile_pick(int kind, bool paired) {
     if (kind == BASE_LINEAR) return paired ? nullptr : &tvs_grad_tile_launch<M, D, BASE_LINEAR, false>;     // increments arrive collapsed
     if (kind == BASE_RBF) return paired ? &tvs_grad_tile_launch<M, D, BASE_RBF, true> : &tvs_grad_tile_launch<M, D, BASE_RBF, false>;
+    if (kind == TVSG_MATERN) return paired ? &tvs_grad_tile_launch<M, D, TVSG_MATERN, true> : &tvs_grad_tile_launch<M, D, TVSG_MATERN, false>;
     return paired ? &tvs_grad_tile_launch<M, D, -1, true> : &tvs_grad_tile_launch<M, D, -1, false>;
 }
 

@@ -60,8 +60,15 @@ struct TvsGradTileArgs {
     int32_t rec_elems;   // multiple of TVSG_REC_ALIGN
     int32_t order;       // HO instances: min(order, num_levels) of the higher-order chains (signature_algs.py:129-160), <= TVSG_MAX_ORDER
     double p0, p1;
+    double mat_a1, mat_a2, mat_g;   // TVSG_MATERN: P(u) = 1 + a1 u + a2 u^2 (Matern-1/2: 0, 0; 3/2: 1, 0; 5/2: 1, 1/3), g = pre * c
 };
 constexpr int TVSG_MAX_ORDER = 4;
+// The three Matern families as ONE compile-time kind (round 6; what tvs_tile_kernel.hpp's forward instances did in round 5, here with wavefront-uniform
+// coefficients instead of three instruction streams): points prepared in units of 1 / s, s = c 256 / ln2 (c = 1, sqrt 3, sqrt 5), so that with r' = s r the
+// kernel is P(u) 2^(-r' / 256), u = c r = r' ln2 / 256 -- the table exp of the RBF instances, v_rsq_f64 + one Newton step for the root.  d kappa / dx =
+// c (P' - P) 2^(-r'/256) (x' - z') / r' (kernels.py:955-993 differentiated); distances clamped at 1e-40 (:779-781) have derivative zero, as the reference's max().
+constexpr int TVSG_MATERN = -2;
+constexpr bool tvsg_has_table(int kind) { return kind == BASE_RBF || kind == TVSG_MATERN; }
 
 // roles (level subsets, one workgroup each): at most four components per role where the levels allow it -- z, d/dz and the chain state
 // of four components at six features fit the 256 registers of two wavefronts per SIMD; one wavefront per SIMD issues float64
@@ -100,6 +107,8 @@ template <>
 struct TvsgCoef<BASE_RBF> { double k; };       // wz = k, vx = vz = -k
 template <>
 struct TvsgCoef<BASE_LINEAR> { double k; };    // wz = 1, vx = vz = 0
+template <>
+struct TvsgCoef<TVSG_MATERN> { double k, vx; };     // d kappa/dx = vx (x - z), d kappa/dz = vx (z - x):  wz = -vx, vz = vx
 
 // HO: the higher-order chains (signature_algs.py:129-160) at a run-time order.  Between time steps the state is the first-order one (the running
 // totals U_j of chain j); within a step chain j splits by repeat count, r_j[0] = m_j U_{j-1}, r_j[l] = m_j r_{j-1}[l-1] / (l+1), U_j += sum_l r_j[l].
@@ -180,6 +189,29 @@ struct TvsGradWave {
 #pragma unroll
                 for (int f = 0; f < D; ++f) t = fma(z[c][f], x[f], t);
                 out[c].k = kexp2_tab256(t, etab);
+            }
+        } else if constexpr (KIND == TVSG_MATERN) {
+            constexpr double K = 0x1.62e42fefa39efp-1 / 256.0;                  // u = c r = r' ln2 / 256
+            const double floor2 = 1e-40 * (A.mat_g * A.mat_g);                  // (>= the clamp of kernels.py:781 in prepared units; g = pre * c >= pre)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                double ip = z[c][0] * x[0];
+#pragma unroll
+                for (int f = 1; f < D; ++f) ip = fma(z[c][f], x[f], ip);
+                const double d2 = fma(-2.0, ip, zn[c] + xs);
+                const bool clamped = !(d2 > floor2);
+                const double dd = clamped ? floor2 : d2;
+                const double y = __builtin_amdgcn_rsq(dd);
+                double r = dd * y;
+                r = fma(fma(-r, r, dd), 0.5 * y, r);                            // one Newton step on the residual
+                const double e = kexp2_tab256(-r, etab);
+                const double u = r * K;
+                const double pu = fma(fma(A.mat_a2, u, A.mat_a1), u, 1.0);
+                out[c].k = pu * e;
+                if (WITH_GRAD) {
+                    const double dpu = fma(2.0 * A.mat_a2, u, A.mat_a1);
+                    out[c].vx = clamped ? 0.0 : (A.mat_g * (dpu - pu) * e) / r;
+                }
             }
         } else {
 #pragma unroll
@@ -280,6 +312,11 @@ struct TvsGradWave {
                 a = g * co[c].k;
                 sbx -= a;
                 bz[c] -= a;
+            } else if constexpr (KIND == TVSG_MATERN) {
+                const double gv = g * co[c].vx;
+                a = -gv;
+                sbx += gv;
+                bz[c] += gv;
             } else {
                 a = g * co[c].wz;
                 sbx = fma(g, co[c].vx, sbx);
@@ -414,7 +451,7 @@ template <int M, int D, int KIND, bool PAIRED, bool HO = false>
 __global__ __launch_bounds__(64, TVSG_WAVES_PER_EU) void tvs_grad_tile_kernel(const TvsGradTileArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tvsg_smem[];
     constexpr int NR = tvs_grad_tile_roles(M, KIND);
-    constexpr int NTAB = KIND == BASE_RBF ? EXP_TAB256_N : 0;
+    constexpr int NTAB = tvsg_has_table(KIND) ? EXP_TAB256_N : 0;
     constexpr int TPW = PAIRED ? 32 : 64;                          // tensors per workgroup
     constexpr int E = PAIRED ? 2 : 1;
     double* const etab = reinterpret_cast<double*>(tvsg_smem);
@@ -429,7 +466,7 @@ __global__ __launch_bounds__(64, TVSG_WAVES_PER_EU) void tvs_grad_tile_kernel(co
     const int lt = M * (M + 1) / 2;
     double* const gxp = A.gxp + (int64_t(role) * gridDim.x + blockIdx.x) * A.N * A.L * D;
 
-    if constexpr (KIND == BASE_RBF) exp_tab256_fill(etab, lane, 64);
+    if constexpr (tvsg_has_table(KIND)) exp_tab256_fill(etab, lane, 64);
 
     auto stage = [&](int64_t n, int buf) {
         const double* src = A.XR + n * int64_t(A.rec_elems);

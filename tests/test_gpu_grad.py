@@ -599,14 +599,16 @@ def test_tensor_level_gradients(base, difference, increments):
 
 @pytest.mark.parametrize("M,T,N,L,d", [(1, 3, 5, 4, 2), (2, 70, 9, 1, 4), (3, 33, 130, 2, 5), (4, 65, 37, 13, 6), (4, 130, 20, 5, 3), (5, 40, 17, 6, 7),
                                        (6, 9, 11, 7, 8), (4, 64, 64, 8, 1), (4, 130, 200, 50, 6)])
-@pytest.mark.parametrize("base", ["linear", "rbf", "matern32", "poly"])
+@pytest.mark.parametrize("base", ["linear", "rbf", "matern32", "poly", "matern12", "matern52"])
 def test_tensor_vs_sequence_tile_gradient_kernel(M, T, N, L, d, base):
     """tvs_grad_tile_kernel (round 3: every level of a wave in ONE reverse sweep per sequence, d/dx summed in LDS, no atomics) against
     autograd of the oracle and against the round-1 kernels: 1 .. 6 levels (one to four waves per workgroup), widths 1 .. 8 (padded to
     4 / 6 / 8), ragged tensor and sequence counts across lane, run and flush boundaries, a single time step, differences on / off,
     increments on / off (lane pairs for the non-linear families, collapsed for the linear one), several sequence chunks."""
-    if N * T > 10000 and base in ("matern32", "poly"):
-        pytest.skip("the large case (two sequence chunks at a scratch budget of 1 MiB) runs for the two compile-time families")
+    if N * T > 10000 and base in ("poly", "matern12"):
+        pytest.skip("the large case (two sequence chunks at a scratch budget of 1 MiB) runs for the compile-time families")
+    if base in ("matern12", "matern52") and (M, d) in ((1, 2), (2, 4), (6, 8)):
+        pytest.skip("a sample of the shapes is enough for the other two Matern families (one instruction stream, round 6)")
     rng = np.random.default_rng(1000 * M + T + d)
     ctx = _host_ctx()
     lt = M * (M + 1) // 2
@@ -634,7 +636,10 @@ def test_tensor_vs_sequence_tile_gradient_kernel(M, T, N, L, d, base):
                 finally:
                     ctx.set_option("tvs_grad_tile", 1)
                     ctx.set_option("grad_scratch_mb", 4096)
-                assert rel(gZ, tZ.grad) < 1e-9 and rel(gX, tX.grad) < 1e-9, (tile, mb, difference, increments, rel(gZ, tZ.grad), rel(gX, tX.grad))
+                # (Matern-1/2 in ONE column: d kappa / dx = -+ exp(-r), the sign taken as (x - z) / sqrt(x^2 + z^2 - 2 x z) -- for the closest of
+                # 64 x 512 points the squared distance cancels to 1e-9 of its terms: oracle and kernel round it differently, 3e-8 apart)
+                tol = 1e-6 if (base == "matern12" and d == 1) else 1e-9
+                assert rel(gZ, tZ.grad) < tol and rel(gX, tX.grad) < tol, (tile, mb, difference, increments, rel(gZ, tZ.grad), rel(gX, tX.grad))
                 if base == "poly":
                     assert abs(gb[0] - kt.p0.grad.item()) < 1e-9 * max(1.0, abs(gb[0])), (tile, mb, difference, increments)
                 res[(tile, mb)] = (gZ, gX)
