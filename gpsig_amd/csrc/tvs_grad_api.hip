@@ -13,7 +13,7 @@ TvsGradTileLaunchFn tvs_grad_tile_lookup_m3(int, int, bool);
 TvsGradTileLaunchFn tvs_grad_tile_lookup_m4(int, int, bool);
 TvsGradTileLaunchFn tvs_grad_tile_lookup_m5(int, int, bool);
 TvsGradTileLaunchFn tvs_grad_tile_lookup_m6(int, int, bool);
-TvsGradTileLaunchFn tvs_grad_tile_lookup_ho(int M, int D, bool paired);      // tvs_grad_tile_inst_ho.hip: SignatureRBF, order > 1
+TvsGradTileLaunchFn tvs_grad_tile_lookup_ho(int M, int D, bool paired, int kind);      // tvs_grad_tile_inst_ho.hip: SignatureRBF and the Matern families, order > 1
 int tvs_tile_width(int d);
 
 static TvsGradTileLaunchFn tvs_grad_tile_lookup(int M, int D, int kind, bool paired) {
@@ -38,10 +38,11 @@ static __global__ void tvs_grad_sum_kernel(const double* __restrict__ part, int6
 // does the tile kernel hold a higher-order instance for this call?  (grad_api.hip prefers it to the wide route's chains at these widths)
 bool tvs_grad_tile_ho_available(const gpsig_ctx* c, const gpsig_params* p, int d, int L, int increments) {
     const int M = p->num_levels;
-    if (!(p->order > 1 && M > 1) || p->base_kernel != GPSIG_BASE_RBF || (p->order < M ? p->order : M) > TVSG_MAX_ORDER) return false;
+    const bool mat = c->tvs_grad_matern != 0 && (p->base_kernel == GPSIG_BASE_MATERN12 || p->base_kernel == GPSIG_BASE_MATERN32 || p->base_kernel == GPSIG_BASE_MATERN52);
+    if (!(p->order > 1 && M > 1) || !(p->base_kernel == GPSIG_BASE_RBF || mat) || (p->order < M ? p->order : M) > TVSG_MAX_ORDER) return false;
     if (c->grad_impl != 0 || c->tvs_grad_tile == 0) return false;
     const int D = tvs_tile_width(d);
-    if (D == 0 || !tvs_grad_tile_lookup_ho(M, D, increments != 0)) return false;
+    if (D == 0 || !tvs_grad_tile_lookup_ho(M, D, increments != 0, mat ? TVSG_MATERN : BASE_RBF)) return false;
     const int rec_elems = (L * D + L + TVSG_REC_ALIGN - 1) / TVSG_REC_ALIGN * TVSG_REC_ALIGN;
     return tvs_grad_tile_lds_bytes(D, rec_elems, true) <= 64 * 1024;
 }
@@ -55,15 +56,16 @@ int tvs_grad_tile_device(gpsig_ctx* c, const gpsig_params* p, int d, const doubl
     *done = false;
     const int M = p->num_levels, lt = M * (M + 1) / 2;
     const bool ho = p->order > 1 && M > 1;
-    if (ho && (p->base_kernel != GPSIG_BASE_RBF || (p->order < M ? p->order : M) > TVSG_MAX_ORDER)) return GPSIG_OK;
+    const bool is_mat = p->base_kernel == GPSIG_BASE_MATERN12 || p->base_kernel == GPSIG_BASE_MATERN32 || p->base_kernel == GPSIG_BASE_MATERN52;
+    if (ho && (!(p->base_kernel == GPSIG_BASE_RBF || (is_mat && c->tvs_grad_matern != 0)) || (p->order < M ? p->order : M) > TVSG_MAX_ORDER)) return GPSIG_OK;
     const int D = tvs_tile_width(d);
     if (D == 0 || M > 6 || Tn < 1 || N < 1) return GPSIG_OK;
-    const bool matern = !ho && c->tvs_grad_matern != 0 && (p->base_kernel == GPSIG_BASE_MATERN12 || p->base_kernel == GPSIG_BASE_MATERN32 || p->base_kernel == GPSIG_BASE_MATERN52);
+    const bool matern = c->tvs_grad_matern != 0 && is_mat;
     const int kind = p->base_kernel == GPSIG_BASE_LINEAR ? BASE_LINEAR : (p->base_kernel == GPSIG_BASE_RBF ? BASE_RBF : (matern ? TVSG_MATERN : -1));
     const bool collapse = increments && kind == BASE_LINEAR;              // <x, z1> - <x, z0> = <x, z1 - z0>
     const bool paired = increments && !collapse;
     const int E = paired ? 2 : 1;
-    TvsGradTileLaunchFn fn = ho ? tvs_grad_tile_lookup_ho(M, D, paired) : tvs_grad_tile_lookup(M, D, kind, paired);
+    TvsGradTileLaunchFn fn = ho ? tvs_grad_tile_lookup_ho(M, D, paired, kind) : tvs_grad_tile_lookup(M, D, kind, paired);
     if (!fn) return GPSIG_OK;
     const int NR = tvs_grad_tile_roles(M, kind);
     const int rec_elems = (L * D + L + TVSG_REC_ALIGN - 1) / TVSG_REC_ALIGN * TVSG_REC_ALIGN;
