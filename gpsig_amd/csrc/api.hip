@@ -2216,7 +2216,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "tvs_tile")) c->tvs_tile = value;
     else if (!strcmp(name, "wide")) c->wide = value;
     else if (!strcmp(name, "wide_chunk_mb")) c->wide_chunk_mb = value > 0 ? value : 0;
-    else if (!strcmp(name, "wide_contract")) c->wide_contract = value ? 1 : 0;
+    else if (!strcmp(name, "wide_contract")) c->wide_contract = value;
     else if (!strcmp(name, "wide_lat_waves")) c->wide_lat_waves = value;
     else if (!strcmp(name, "wide_sym_fold")) c->wide_sym_fold = value ? 1 : 0;
     else if (!strcmp(name, "ho_g32")) c->ho_g32 = value;

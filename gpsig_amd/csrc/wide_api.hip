@@ -133,7 +133,7 @@ int contract_both(gpsig_ctx* c, const double* W, const double* XA, const double*
         // narrow rows: both contractions in one hand-written pass over W (wide_contract_kernel); rocBLAS spreads such skinny products over too few tiles
         const int64_t strips = (R + 63) / 64, ntiles = (CW + 63) / 64;
         const int DAP = DA <= 16 ? 16 : 32;
-        int64_t groups = (4096 + strips - 1) / strips;            // about four wavefronts per SIMD
+        int64_t groups = ((DAP == 16 && c->wide_contract != 2 ? 8192 : 4096) + strips - 1) / strips;            // several wavefronts per SIMD
         if (groups > ntiles) groups = ntiles;
         if (groups < 1) groups = 1;
         void *part, *gxp;
@@ -144,7 +144,10 @@ int contract_both(gpsig_ctx* c, const double* W, const double* XA, const double*
         K.W = W; K.XA = XA; K.ZA = ZA; K.R = R; K.CW = CW; K.DA = DA; K.groups = int(groups);
         K.gXA_part = static_cast<double*>(gxp); K.part = static_cast<double*>(part);
         const dim3 gridc(unsigned(strips < 65535 ? strips : 65535), unsigned(groups));
-        if (DAP == 16) hipLaunchKernelGGL(wide_contract_kernel<16>, gridc, dim3(64), 0, c->stream, K);
+        // 1 (default): part tiles of 16 rows (8.3 KB of LDS per wavefront; 1.18 ms per 4 GB of W at 12 columns where the first form takes 3.14), 3: of 32 rows (1.53), 2: the first form
+        if (DAP == 16 && c->wide_contract == 3) hipLaunchKernelGGL(wide_contract16_kernel<32>, gridc, dim3(64), 0, c->stream, K);
+        else if (DAP == 16 && c->wide_contract != 2) hipLaunchKernelGGL(wide_contract16_kernel<16>, gridc, dim3(64), 0, c->stream, K);
+        else if (DAP == 16) hipLaunchKernelGGL(wide_contract_kernel<16>, gridc, dim3(64), 0, c->stream, K);
         else hipLaunchKernelGGL(wide_contract_kernel<32>, gridc, dim3(64), 0, c->stream, K);
         HIPCHK(c, hipGetLastError());
         hipLaunchKernelGGL(wide_contract_reduce_kernel, dim3(grid_for(CW * DA)), dim3(256), 0, c->stream, static_cast<const double*>(part), strips, CW, DA, DAP,

@@ -1105,6 +1105,97 @@ __global__ void __launch_bounds__(64) wide_contract_kernel(const WideContractArg
     }
 }
 
+// Second form (round 6, DAP = 16): the same tile walk with PART tiles of HR = 32 / 16 rows in LDS (16.6 / 8.3 KB per wavefront instead of 49.6: two wavefronts per SIMD where the
+// first form fits three per CU -- its matrix cores idle while its only wavefront loads and stages), and the MFMAs' second operands in REGISTERS: a lane's 16
+// entries of the strip's XA rows are loaded once per strip, its 16 entries of the tile's ZA rows once per tile.  MFMA count and partial-sum layout unchanged.
+template <int HR>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) wide_contract16_kernel(const WideContractArgs A) {
+    constexpr int TS = 65, NH = 64 / HR, Q1 = HR / 4, MB = HR / 16;     // part tiles of HR rows: NH per tile, Q1 reduction steps of phase 1, MB row blocks of phase 2
+    __shared__ double tile[HR * TS];
+    const int lane = threadIdx.x, DA = A.DA, li = lane & 15, lk = lane >> 4;
+    const int64_t ntiles = (A.CW + 63) / 64;
+    const bool fok = li < DA;
+    for (int64_t strip = blockIdx.x; strip * 64 < A.R; strip += gridDim.x) {
+        const int64_t r0 = strip * 64;
+        const int nr = int(A.R - r0 < 64 ? A.R - r0 : 64);
+        // this lane's entries of the strip's rows of XA as MFMA B operands: step s of half h covers rows 32 h + 4 s + lk
+        double bx[NH][Q1];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int q = 0; q < Q1; ++q) {
+                const int row = HR * h + 4 * q + lk;
+                bx[h][q] = (row < nr && fok) ? A.XA[(r0 + row) * DA + li] : 0.0;
+            }
+        wide_f64x4 acc2[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc2[m] = wide_f64x4{0.0, 0.0, 0.0, 0.0};
+        double wn[HR];
+        auto request = [&](int64_t ti, int h) {
+            const int64_t c = ti * 64 + lane;
+            const int hb = HR * h < nr ? HR * h : 0;             // (a part tile wholly beyond the strip's rows: any rows inside it, masked at the LDS write)
+            const double* __restrict__ src = A.W + (r0 + hb) * A.CW + (c < A.CW ? c : 0);
+#pragma unroll
+            for (int r = 0; r < HR; ++r) wn[r] = src[int64_t(hb + r < nr ? r : 0) * A.CW];
+        };
+        if (int64_t(blockIdx.y) < ntiles) request(blockIdx.y, 0);
+        for (int64_t ti = blockIdx.y; ti < ntiles; ti += A.groups) {
+            const int64_t c0 = ti * 64;
+            const bool cok = c0 + lane < A.CW;
+            double bz[16];                                   // this lane's entries of the tile's rows of ZA: step s covers columns 4 s + lk
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t col = c0 + 4 * q + lk;
+                bz[q] = (col < A.CW && fok) ? A.ZA[col * DA + li] : 0.0;
+            }
+            wide_f64x4 acc1[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc1[m] = wide_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < HR; ++r) tile[r * TS + lane] = (HR * h + r < nr && cok) ? wn[r] : 0.0;
+                if (h + 1 < NH) request(ti, h + 1);
+                else if (ti + A.groups < ntiles) request(ti + A.groups, 0);
+                __syncthreads();
+                // phase 1: D1[column][f] += sum over the half's rows of W[row][column] XA[row][f]
+#pragma unroll
+                for (int q = 0; q < Q1; ++q) {
+                    double av[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) av[m] = tile[(4 * q + lk) * TS + m * 16 + li];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc1[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bx[h][q], acc1[m], 0, 0, 0);
+                }
+                // phase 2: D2[row][f] += sum over the tile's columns of W[row][column] ZA[column][f], the half's 32 rows
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    double av[MB];
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) av[m] = tile[(m * 16 + li) * TS + 4 * q + lk];
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) acc2[MB * h + m] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bz[q], acc2[MB * h + m], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t col = c0 + m * 16 + lk + 4 * r;
+                    if (col < A.CW) A.part[(strip * A.CW + col) * 16 + li] = acc1[m][r];
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m * 16 + lk + 4 * r;
+                if (row < nr) A.gXA_part[(int64_t(blockIdx.y) * A.R + r0 + row) * 16 + li] = acc2[m][r];
+            }
+    }
+}
+
 // dst[e][f] = (acc ? dst : 0) + sum over k of part[k][e][f], f < DA of DAP (a fixed order: deterministic)
 __global__ void wide_contract_reduce_kernel(const double* __restrict__ part, int64_t nparts, int64_t rows, int DA, int DAP, int acc, double* __restrict__ dst) {
     const int64_t n = rows * DA;

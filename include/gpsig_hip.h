@@ -162,8 +162,9 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *                 tensor-vs-sequence chains (orders <= 4) and the sequence lattices' reverse pass (<= 5 levels)).  Not taken inside
  *                 a graph capture.
  *   "wide_chunk_mb"  its argument chunk in HBM (0: "grad_scratch_mb", 4 GB by default: a latency-bound launch split in two takes twice as long)
- *   "wide_contract"  1 (default): the two contractions of a reverse pass with the adjoint array (rows of at most 32 augmented columns) as one
- *                 hand-written MFMA pass (wide_contract_kernel); 0: two rocBLAS dgemms (for A/B runs)
+ *   "wide_contract"  the two contractions of a reverse pass with the adjoint array (rows of at most 32 augmented columns) as one hand-written MFMA pass:
+ *                 1 (default) part tiles of 16 rows in LDS with the second operands in registers (rows of at most 16 columns; wider: the first form),
+ *                 3 part tiles of 32 rows, 2 the first form (whole 64 x 64 tiles and both operand blocks in LDS), 0 two rocBLAS dgemms (for A/B runs)
  *   "wide_lat_waves"  wavefronts per sequence lattice on the wide route: -1 (default) eight for a launch of at most 128 lattices of more than 256
  *                 columns, one otherwise; 0 always one; 1 two / four / eight wherever a lane would hold that many columns
  *   "wide_sym_fold"  1 (default): the reverse pass of a symmetric Gram on the wide route runs over the pairs i <= j with the upstream gradient
