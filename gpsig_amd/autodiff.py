@@ -916,7 +916,10 @@ class SignatureKernelModule(torch.nn.Module):
         # where the recursion kernels' work (tensors x sequences x steps x components x columns) exceeds feature_route_min_work -- a minibatch of 50
         # against 200 tensors is a dozen small launches slower this way (1.2 -> 1.9 ms), BASELINE configs[2] 2.6 times faster; "always"; False
         self.feature_route = True
-        self.feature_route_min_work = 1.0e10
+        self.feature_route_min_work = 3.0e9          # (linear: covariances forward + backward at T = 512, L = 50, d = 6 cross over near 2,000 sequences; round 6)
+        # SignatureCosine's recursion kernels are the run-time family (no compile-time instance of the reverse tile kernel): the feature route wins at every size
+        # measured (minibatch of 50: 2.3 against 2.7 ms; 4,096 sequences: 2.1 against 51.6)
+        self.feature_route_min_work_cosine = 0.0
         self.sum_route = True          # K(X [, X2]) of the linear / cosine kernel: level sum and gradient as one op where the library offers it
         d_cols = kern.num_features * (kern.num_lags + 1)
         # beyond 64 columns and for the spectral kernel: base-kernel tensors here (GEMMs, autograd), recursions in the library
@@ -1033,7 +1036,8 @@ class SignatureKernelModule(torch.nn.Module):
         for held, Phi in (self._phi_memo or ()):
             if held is Xs:
                 return Phi
-        if self.feature_route != "always" and self._spec.order == 1 and (work is None or work < self.feature_route_min_work):
+        min_work = self.feature_route_min_work_cosine if self._spec.base == "cosine" else self.feature_route_min_work
+        if self.feature_route != "always" and self._spec.order == 1 and (work is None or work < min_work):
             return None                                # (order > 1: the higher-order recursion kernels lose at every size -- 3.5 -> 2.0 ms at a minibatch of 50)
         n, l, d = Xs.shape
         ld = _SigFeatures.ld(self._spec, d, l)

@@ -446,7 +446,8 @@ def test_inducing_tensor_covariances_through_the_level_features(base, normalizat
     # the default (True) takes the route by the recursion kernels' work: not at this size, yes with the threshold lowered
     mod.feature_route = True
     mod.K_tens_vs_seq(torch.tensor(Z, device=dev), torch.tensor(X, device=dev), increments=increments)
-    assert (mod._phi(torch.tensor(X, device=dev).reshape(N, L, d), 1.0) is None) == (order == 1)      # (order > 1: at every size)
+    # (order > 1: at every size; SignatureCosine at every size too since round 6 -- its recursion kernels are the run-time family: 2.1 against 51.6 ms at 4,096 sequences)
+    assert (mod._phi(torch.tensor(X, device=dev).reshape(N, L, d), 1.0) is None) == (order == 1 and base == "linear")
     mod._phi_memo = None
     saved, mod.feature_route_min_work = mod.feature_route_min_work, 0.0
     try:

@@ -19,7 +19,7 @@ for name, cls in FAM:
     for lags, incr in ((0, False), (0, True), (1, True)):
         try:
             de = d * (lags + 1)
-            kern = cls(L * d, d, M, num_lags=lags or None, lengthscales=np.sqrt(d))
+            kern = cls(L * d, d, M, num_lags=lags or None, lengthscales=np.sqrt(d), order=int(os.environ.get("PROBE_ORDER", "1")))
             mod = autodiff.SignatureKernelModule(kern, device="cuda:0")
             Z = torch.as_tensor(rng.standard_normal((M * (M + 1) // 2, T, 2, de) if incr else (M * (M + 1) // 2, T, de)) * 0.4, device="cuda:0").requires_grad_(True)
             def covs_f():
