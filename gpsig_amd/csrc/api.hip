@@ -131,6 +131,9 @@ SeqLaunchFn seq_lookup_ho_f32_ptd_d32(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_f32_ptn_d32(int, int, int, int, int);
 SeqLaunchFn seq_lookup_ho_ptdrbf_exact(int G, int C, int D, int M, int order);
 SeqLaunchFn seq_lookup_ho_ptdrbf_exact_o4(int G, int C, int D, int M, int order);
+SeqLaunchFn seq_lookup_ho_ptdm12_exact(int kind, int G, int C, int D, int M, int order);     // the Matern families' exact higher-order instances
+SeqLaunchFn seq_lookup_ho_ptdm32_exact(int kind, int G, int C, int D, int M, int order);
+SeqLaunchFn seq_lookup_ho_ptdm52_exact(int kind, int G, int C, int D, int M, int order);
 typedef hipError_t (*TvsLaneTLaunchFn)(const TvsLaneTArgs&, hipStream_t);
 bool tvs_lanet_plan(int M, int d, bool incr, TvsLaneTLaunchFn* fns, int* ngroups);
 // wide_api.hip: state spaces beyond the exact-shape kernels' columns (kernel arguments by dgemm, fused map / difference / recursion kernels)
@@ -952,6 +955,17 @@ static int plan_seq(gpsig_ctx* c, const gpsig_params* p, int d_eff, int Ly, SeqP
                 out->cfg = SeqConfig{h.G, h.C, h.D, p->num_levels, true};
                 out->rbf_prescaled = true;               // (fast_kind stays -1: the stash instances are first-order)
                 out->prescale = SEQ_RBF_PRESCALE;
+            }
+        }
+        if (sizeof(TT) == 8 && c->allow_exact && g0.mode == MODE_PT_DIFF && seq_is_matern(p->base_kernel) && c->matern_fast != 0) {
+            SeqLaunchFn ex = p->base_kernel == GPSIG_BASE_MATERN12 ? seq_lookup_ho_ptdm12_exact(BASE_MATERN12, h.G, h.C, h.D, p->num_levels, p->order)
+                             : (p->base_kernel == GPSIG_BASE_MATERN32 ? seq_lookup_ho_ptdm32_exact(BASE_MATERN32, h.G, h.C, h.D, p->num_levels, p->order)
+                                                                      : seq_lookup_ho_ptdm52_exact(BASE_MATERN52, h.G, h.C, h.D, p->num_levels, p->order));
+            if (ex) {
+                out->fn = ex;
+                out->cfg = SeqConfig{h.G, h.C, h.D, p->num_levels, true};
+                out->rbf_prescaled = true;               // (prescaled records; the spare column is written and ignored)
+                out->prescale = seq_matern_prescale(p->base_kernel);
             }
         }
         if (!out->fn) return fail(c, GPSIG_ERR_UNSUPPORTED, "higher-order kernel shape missing from this build");

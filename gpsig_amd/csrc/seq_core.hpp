@@ -617,6 +617,36 @@ GPSIG_HD void seq_step_matern_prescaled(SeqLane<double, C, D, MMAX, MODE>& L, co
     seq_recursion(L, nbr, dm, M);
 }
 
+// The same for the HIGHER-ORDER algorithm (round 6: exact instances for the Matern families as for the RBF kernel -- seq_step_rbf_prescaled_ho)
+template <int KIND, int C, int D, int MMAX, int OMAX, int MODE, class Nbr>
+GPSIG_HD void seq_step_matern_prescaled_ho(SeqLaneHO<double, C, D, MMAX, OMAX, MODE>& L, const Nbr& nbr, const double (&xr)[D], const double* etab, int M,
+                                           int order, bool dummy, int rlo, int rhi) {
+    static_assert(MODE != MODE_INC && seq_is_matern(KIND), "point modes, Matern families");
+    constexpr double S = seq_matern_prescale(KIND), K = 0x1.62e42fefa39efp-1 / 256.0, FLOOR = 1e-40 * S * S;
+    double knew[C], dm[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+        double t = 0.0;
+#pragma unroll
+        for (int f = 0; f < D; ++f) { const double df = xr[f] - L.y[r][f]; t = fma(df, df, t); }
+        const double d = t > FLOOR ? t : FLOOR;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double r0 = __builtin_amdgcn_rsq(d);
+        double q = d * r0;
+        q = fma(fma(-q, q, d), 0.5 * r0, q);
+#else
+        const double q = std::sqrt(d);
+#endif
+        const double e = kexp2_tab256(-q, etab);
+        if constexpr (KIND == BASE_MATERN12) knew[r] = e;
+        else if constexpr (KIND == BASE_MATERN32) knew[r] = fma(q, K, 1.0) * e;
+        else { const double u = q * K; knew[r] = fma(fma(u, 1.0 / 3.0, 1.0), u, 1.0) * e; }
+    }
+    seq_point_increments<double, C, MODE>(L, nbr, knew, dummy, rlo, rhi, dm);
+    double R0[OMAX][OMAX][C];
+    detail::seq_ho_level<1>(L, nbr, dm, M, order, R0);
+}
+
 // First-order step for SignatureSpectral's state-space kernel (spectral_eval above; gpsig/kernels.py:921-942), point modes: the kernel
 // takes the two points themselves, which a lane has -- its C columns of y in registers, the x row of the step -- so the wavefront
 // kernel carries it as a compile-time family of its own (KIND == BASE_SPECTRAL instances: no branch in anyone else's step).

@@ -46,7 +46,7 @@ __device__ __forceinline__ float shr1(float v) {
 // of a step interleave instead of queueing behind a switch -- 5 % at the headline shape, 18 % at one wavefront per SIMD.
 #define SEQ_FAST_RBF(T, MODE, OMAX, KIND) (sizeof(T) == 8 && (KIND) == BASE_RBF && (MODE) == MODE_PT_DIFF)      // (OMAX > 0: round 6's exact higher-order instances)
 // ... and the Matern families (round 5): prescaled records too, seq_step_matern_prescaled in seq_core.hpp
-#define SEQ_FAST_MATERN(T, MODE, OMAX, KIND) (sizeof(T) == 8 && seq_is_matern(KIND) && (MODE) == MODE_PT_DIFF && (OMAX) == 0)
+#define SEQ_FAST_MATERN(T, MODE, OMAX, KIND) (sizeof(T) == 8 && seq_is_matern(KIND) && (MODE) == MODE_PT_DIFF)      // (OMAX > 0: round 6's exact higher-order instances)
 // The float64 RBF instances (round 5): two steps per loop trip -- the hand-over words alternate registers instead of being copied back, 12
 // v_mov_b64 of the 170 vector instructions of a step's body at the headline shape (tools/isa_loops.py --blocks: 170 -> 157) -- compiled for TWO
 // wavefronts per SIMD: the doubled live ranges need 197 registers, and held to the 168 of three wavefronts the body spills (69 ms).  Same box,
@@ -63,7 +63,7 @@ __device__ __forceinline__ float shr1(float v) {
 // this recursion -- every lattice row's totals of levels 1 .. M-1 (the last lane's hand-over words) and every lane's Q's when its pair ends
 // (SeqGramArgs::stash) -- so that the backward call starts at the turn of the sweeps instead of repeating the forward one.
 template <typename T, int G, int C, int D, int MMAX, int MODE, bool EXACT, int OMAX = 0, int KIND = -1, bool STASH = false>
-__global__ __launch_bounds__(64, ((SEQ_FAST_RBF(T, MODE, OMAX, KIND) && OMAX == 0) || SEQ_FAST_MATERN(T, MODE, OMAX, KIND)) && C * D <= 32 ? SEQ_RBF_WAVES : ((MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1)) void seq_gram_kernel(const SeqGramArgs A) {
+__global__ __launch_bounds__(64, ((SEQ_FAST_RBF(T, MODE, OMAX, KIND) || SEQ_FAST_MATERN(T, MODE, OMAX, KIND)) && OMAX == 0) && C * D <= 32 ? SEQ_RBF_WAVES : ((MODE != MODE_INC && OMAX == 0 && C * D <= 32) ? 2 : 1)) void seq_gram_kernel(const SeqGramArgs A) {
     static_assert(!STASH || (sizeof(T) == 8 && MODE == MODE_PT_DIFF && OMAX == 0 && EXACT && MMAX >= 2),
                   "the stash is written by exact float64 instances of the first-order algorithm on points with differences");
     static_assert(G == 16 || G == 64, "pair group is a DPP row or the whole wave");
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64, ((SEQ_FAST_RBF(T, MODE, OMAX, KIND) && OMAX == 
 
         if constexpr (FAST_RBF && OMAX > 0) seq_step_rbf_prescaled_ho(L, DevNbr{L}, xr, hx, etab, M, EXACT ? OMAX : A.order, dummy, rlo, rhi);
         else if constexpr (FAST_RBF) seq_step_rbf_prescaled(L, DevNbr{L}, xr, hx, etab, M, dummy, rlo, rhi);
+        else if constexpr (FAST_MATERN && OMAX > 0) seq_step_matern_prescaled_ho<KIND>(L, DevNbr{L}, xr, etab, M, EXACT ? OMAX : A.order, dummy, rlo, rhi);
         else if constexpr (FAST_MATERN) seq_step_matern_prescaled<KIND>(L, DevNbr{L}, xr, etab, M, dummy, rlo, rhi);
         else if constexpr (KIND == BASE_SPECTRAL && OMAX == 0 && MODE != MODE_INC) seq_step_spectral(L, DevNbr{L}, xr, A.spec, int(A.p0), int(A.p1), M, dummy, rlo, rhi);
         else seq_step(L, DevNbr{L}, xr, M, A.order, dummy, rlo, rhi, KIND >= 0 ? KIND : A.kind, p0, p1);

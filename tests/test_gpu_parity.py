@@ -2017,10 +2017,14 @@ def test_hip_path_against_independent_witness_values(K):
 
 
 @pytest.mark.parametrize("M,order,d,L", [(5, 2, 8, 64), (4, 2, 8, 50), (3, 2, 6, 33), (5, 2, 4, 64), (4, 2, 3, 20), (5, 4, 8, 64), (5, 3, 7, 100), (4, 3, 8, 64), (4, 4, 8, 70)])
-def test_exact_higher_order_rbf_instances(K, M, order, d, L):
+@pytest.mark.parametrize("base", ["rbf", "matern12", "matern32", "matern52"])
+def test_exact_higher_order_rbf_instances(K, M, order, d, L, base):
     """Round 6: the higher-order algorithm (signature_algs.py:37-74) with num_levels AND order at compile time for SignatureRBF -- the exact instances
     of seq_inst_ho_ptdrbf_exact*.hip (prescaled records, table exp): symmetric and cross Grams, normalised and not, against the oracle and against the
-    run-time instances (option exact = 0)."""
+    run-time instances (option exact = 0).  The Matern families: the order-2 instances of seq_inst_ho_ptdm*_exact.hip (prescaled records, table exp, rsq).
+    (Self-paired sequences have coinciding points: Matern-1/2 at 1e-6)"""
+    if base != "rbf" and order != 2:
+        pytest.skip("the Matern families have exact instances at order 2")
     import torch
     from gpsig_amd import _lib
     rng = np.random.default_rng(100 * M + 10 * order + d)
@@ -2029,7 +2033,7 @@ def test_exact_higher_order_rbf_instances(K, M, order, d, L):
     X2 = np.cumsum(rng.standard_normal((N2, L, d)) * 0.3, axis=1).reshape(N2, -1)
     ctx = _lib.context(0, 0)
     for normalization in (True, False):
-        kw = dict(base="rbf", input_dim=L * d, num_features=d, num_levels=M, order=order, lengthscales=np.sqrt(d) * np.ones(d), normalization=normalization)
+        kw = dict(base=base, input_dim=L * d, num_features=d, num_levels=M, order=order, lengthscales=np.sqrt(d) * np.ones(d), normalization=normalization)
         k, ko = make_kernel(K, kw), make_oracle(kw)
         got = {}
         for exact in (1, 0):
@@ -2039,9 +2043,9 @@ def test_exact_higher_order_rbf_instances(K, M, order, d, L):
             finally:
                 ctx.set_option("exact", 1)
         for a, b in zip(got[1], (ko.K(X), ko.K(X, X2), ko.K(X[:5], return_levels=True))):
-            assert relerr(a, b) <= 1e-9, (normalization, relerr(a, b))
+            assert relerr(a, b) <= (1e-6 if base == "matern12" else 1e-9), (normalization, relerr(a, b))
         for a, b in zip(got[1], got[0]):
-            assert relerr(a, b) <= 1e-10
+            assert relerr(a, b) <= (1e-6 if base == "matern12" else 1e-10)
 
 
 @pytest.mark.parametrize("M,order,d,T,N,L", [(4, 2, 6, 70, 45, 50), (4, 4, 6, 512, 40, 9), (3, 2, 3, 33, 130, 7), (5, 3, 8, 65, 20, 13), (5, 5, 4, 40, 17, 6), (3, 3, 8, 64, 64, 2)])
