@@ -1375,6 +1375,11 @@ static int seq_K_device(gpsig_ctx* c, const gpsig_params* p, bool raw, const voi
         rc = plan_seq(c, p, d_eff, swap ? L1 : L2, &pl, pairs_hint);
     }
     if (rc == GPSIG_OK && c->wide == 1 && generic_ok(p) && row_end == 0 && wide_lat_available(c, p, L1, L2)) rc = GPSIG_ERR_UNSUPPORTED;   // (option wide = 1)
+    // 17 .. 32 columns, first order: the exact-shape kernels' 32-column instances hold four lattice columns x 32 features per lane at one wavefront per
+    // SIMD -- a Gram of 384 sequences of 50 x 17 takes 10.8 ms there, 4.5 through the wide route's dgemm + lattice sweeps (tools/probe_shapes_rbf.py)
+    if (rc == GPSIG_OK && c->wide < 0 && sizeof(TT) == 8 && d_eff > 16 && pairs_hint >= 4096 && generic_ok(p) && row_end == 0 && !(p->order > 1 && p->num_levels > 1) &&
+        wide_lat_available(c, p, L1, L2))
+        rc = GPSIG_ERR_UNSUPPORTED;
     if (rc == GPSIG_ERR_UNSUPPORTED && generic_ok(p) && row_end == 0) {     // any-shape fallback (wide route where built; else orders of magnitude slower per pair)
         if (timed) { c->t_launches += 0; }
         return seq_K_generic(c, p, raw, X, X2, N1, N2, L1, L2, return_levels, out, x_squared);
