@@ -1114,7 +1114,8 @@ int gpsig_tens_vs_seq_levels_grad(gpsig_ctx* c, const gpsig_params* p, const voi
     CHK(grad_check(c, p, &d, &DP, 4096));
     // wide state spaces (wide_api.hip): beyond the tile kernel's 8 columns, or wherever built when the option says so
     // (higher orders: at any width -- the tile kernel's reverse pass is first-order, the older kernels go through scratch memory operation by operation)
-    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8 || (p->order > 1 && p->num_levels > 1 && c->wide != 0 && !tvs_grad_tile_ho_available(c, p, d, L, increments)));
+    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8 || (p->num_levels > 6 && c->wide != 0) ||      /* (7 / 8 levels: no reverse tile instance -- 100 ms at T = 512, N = 2,048 on the older kernels) */
+                                                                (p->order > 1 && p->num_levels > 1 && c->wide != 0 && !tvs_grad_tile_ho_available(c, p, d, L, increments)));
     if (DP == 0 && !wide) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns here (got %d)", d);
     if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
     if (N > 0x7fffffff || T > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 items");
@@ -1459,7 +1460,8 @@ int gpsig_tens_vs_seq_weighted_grad(gpsig_ctx* c, const gpsig_params* p, const v
     int d, DP;
     CHK(grad_check(c, p, &d, &DP, 4096));
     // (higher orders: at any width -- the tile kernel's reverse pass is first-order, the older kernels go through scratch memory operation by operation)
-    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8 || (p->order > 1 && p->num_levels > 1 && c->wide != 0 && !tvs_grad_tile_ho_available(c, p, d, L, increments)));
+    const bool wide = wide_tvs_available(c, p, d, T, N, L) && (c->wide == 1 || d > 8 || (p->num_levels > 6 && c->wide != 0) ||      /* (7 / 8 levels: no reverse tile instance -- 100 ms at T = 512, N = 2,048 on the older kernels) */
+                                                                (p->order > 1 && p->num_levels > 1 && c->wide != 0 && !tvs_grad_tile_ho_available(c, p, d, L, increments)));
     if (DP == 0 && !wide) return fail(c, GPSIG_ERR_UNSUPPORTED, "gradients are built for at most 64 feature columns here (got %d)", d);
     if (T < 0 || N < 0 || L < 1) return fail(c, GPSIG_ERR_INVALID, "bad sizes");
     if (N > 0x7fffffff || T > 0x7fffffff) return fail(c, GPSIG_ERR_UNSUPPORTED, "more than 2^31 items");
