@@ -2241,6 +2241,7 @@ int gpsig_set_option(gpsig_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "ho_g32")) c->ho_g32 = value;
     else if (!strcmp(name, "wide_few_cols")) c->wide_few_cols = value;
     else if (!strcmp(name, "tvs_grad_matern")) c->tvs_grad_matern = value ? 1 : 0;
+    else if (!strcmp(name, "wide_o1_sweeps")) c->wide_o1_sweeps = value;
     else if (!strcmp(name, "tvs_features")) c->tvs_features = value;
     else if (!strcmp(name, "tvs_tile_nw")) c->tvs_tile_nw = value;
     else if (!strcmp(name, "diag_own")) c->diag_own = value;

@@ -96,7 +96,7 @@ struct gpsig_ctx {
     int tvs_tile = -1;            // Kzx tile kernel (tvs_tile_kernel.hpp): -1 where it is built, 0 never, 1 also below 32 tensors
     int wide = -1;                // wide state spaces (wide_api.hip: kernel arguments by dgemm, fused map / difference / recursion kernels): -1 where the exact-shape
                                   // kernels are not built (more than 8 columns for Kzx, more than 32 for the sequence lattices), 0 never, 1 wherever built
-    int wide_contract = 1, wide_lat_waves = -1, wide_sym_fold = 1, ho_g32 = -1, wide_few_cols = 0, tvs_grad_matern = 1;        // the reverse pass's two contractions for narrow rows: 1 = one hand-written pass over the adjoint array (wide_contract_kernel), 0 = rocBLAS dgemms
+    int wide_contract = 1, wide_lat_waves = -1, wide_sym_fold = 1, ho_g32 = -1, wide_few_cols = 0, tvs_grad_matern = 1, wide_o1_sweeps = 1;        // the reverse pass's two contractions for narrow rows: 1 = one hand-written pass over the adjoint array (wide_contract_kernel), 0 = rocBLAS dgemms
     int wide_chunk_mb = 0;        // its argument chunk in HBM (0: a quarter of the gradient scratch budget)
     int tvs_features = -1;        // Kzx of the linear / cosine kernel as one product of level features: -1 where a time model prefers it, 0 never, 1 wherever built
     int tvs_tile_nw = 0;          // its waves per workgroup: 0 = planner's choice

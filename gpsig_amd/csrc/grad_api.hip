@@ -18,6 +18,7 @@ WaveHoLaunchFn wave_ho_lookup(int G, int C, int order, int M);      // grad_wave
 WaveHoLaunchFn wave_ho_undo_lookup_g16(int C, int order, int M);    // grad_wave_ho_inst_u16.hip / _u64.hip: scratch-free
 WaveHoLaunchFn wave_ho_undo_lookup_g64(int C, int order, int M);
 WaveHoLaunchFn wave_ho_undo_lookup_g32(int C, int order, int M);
+WaveHoLaunchFn wave_o1_lookup(int G, int C, int M);                    // first order from a dM lattice: seq_grad_wave_o1_kernel
 WaveHoLaunchFn wave_ho_levels_lookup_g16(int C, int order, int M);   // the forward pass: seq_levels_wave_ho_kernel
 WaveHoLaunchFn wave_ho_levels_lookup_g32(int C, int order, int M);
 WaveHoLaunchFn wave_ho_levels_lookup_g64(int C, int order, int M);
@@ -92,6 +93,17 @@ bool ho_sweeps_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, H
     if (!hs->fn) return false;
     hs->slot = hs->lds == 0 ? sizeof(double) * size_t(ho_stash_words(order, M)) * size_t(R1 + hs->G - 1) * hs->G * hs->C : 0;
     return true;
+}
+
+// first order, short lattices (<= 64 columns) from a dM lattice in memory: seq_grad_wave_o1_kernel, launched through ho_sweeps_launch
+bool o1_sweeps_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, HoSweeps* hs) {
+    const int M = p->num_levels;
+    if (c->grad_impl != 0 || (p->order > 1 && M > 1) || R1 < 1 || R2 < 1 || R2 > 64 || M > 8) return false;
+    hs->G = 16; hs->C = R2 <= 32 ? 2 : 4;
+    hs->fn = wave_o1_lookup(hs->G, hs->C, M);
+    hs->lds = sizeof(double) * size_t(64 / hs->G) * size_t(R1) * size_t(M <= 4 ? 3 : 7);
+    hs->slot = 0;
+    return hs->fn != nullptr && hs->lds <= 64 * 1024;
 }
 
 // the forward pass by one sweep per pair (seq_levels_wave_ho_kernel): the same lane shapes

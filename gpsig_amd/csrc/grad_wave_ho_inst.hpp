@@ -30,6 +30,21 @@ WaveHoLaunchFn wave_ho_lookup(int G, int C, int order, int M) {
 }
 #endif
 
+#ifndef GPSIG_HO_UNDO_ONLY
+// first order from a dM lattice (seq_grad_wave_o1_kernel): 16 lanes per lattice, 2 / 4 columns per lane (lattices of at most 64 columns), 3 or 7 levels kept
+template <int G, int C, int LQ>
+static hipError_t wave_o1_launch(const WaveHoArgs& a, int nblocks, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((seq_grad_wave_o1_kernel<G, C, LQ>), dim3(nblocks), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+WaveHoLaunchFn wave_o1_lookup(int G, int C, int M) {
+    if (M < 1 || M > 8 || G != 16) return nullptr;
+    if (C == 2) return M <= 4 ? &wave_o1_launch<16, 2, 3> : &wave_o1_launch<16, 2, 7>;
+    if (C == 4) return M <= 4 ? &wave_o1_launch<16, 4, 3> : &wave_o1_launch<16, 4, 7>;
+    return nullptr;
+}
+#endif
+
 #ifdef GPSIG_HO_UNDO_G
 template <int G, int C, int MM, int O>
 static hipError_t wave_ho_undo_launch(const WaveHoArgs& a, int nblocks, size_t lds, hipStream_t s) {

@@ -731,4 +731,92 @@ __global__ void __launch_bounds__(64) seq_levels_wave_ho_kernel(const WaveHoArgs
     }
 }
 
+// ---- first order from a dM lattice in memory (round 6): the scratch-free sweeps of seq_lam_undo_kernel (grad_wave_kernel.hpp: WaveFwd + WaveUndo) with the lane shapes
+// above and dM read instead of evaluated -- for the wide route's MANY SHORT lattices (a Gram of sequences of <= 64 observations at 17+ columns), which its own lattice
+// kernels sweep one per 64-lane wavefront however short they are.  Dynamic LDS: (64 / G) * R1 * LQ doubles (the row totals).
+template <int G, int C, int LQ>
+__global__ void __launch_bounds__(64) seq_grad_wave_o1_kernel(const WaveHoArgs A) {
+    extern __shared__ double o1_rowtot[];
+    constexpr int PW = 64 / G;
+    const int lane = threadIdx.x, lam = lane % G;
+    const int grp = blockIdx.x * PW + lane / G;
+    const int R1 = A.R1, R2 = A.R2, M = A.M;
+    const int TF = R1 + G - 1;
+    double* const rt = o1_rowtot + size_t(lane / G) * R1 * LQ;
+    const int64_t rounds = (A.npairs + A.ngroups - 1) / A.ngroups;
+    int nvalid = R2 - C * lam;
+    nvalid = nvalid < 0 ? 0 : (nvalid > C ? C : nvalid);
+    const int last_lane = R2 > 0 ? (R2 - 1) / C : 0;
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t pp = rd * A.ngroups + grp;
+        const bool have = pp < A.npairs;
+        const int64_t pg = A.pair0 + (have ? pp : 0);
+        const int64_t i = A.diag ? pg : pg / A.N2, j = A.diag ? pg : pg % A.N2;
+        const double* const dmp = A.dM + size_t(have ? pp : 0) * R1 * R2;
+        auto load_dm = [&](int a, double (&dm)[C]) {
+            const bool ok = a >= 0 && a < R1;
+            const size_t row = size_t(ok ? a : 0) * R2;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int b = C * lam + c;
+                const double v = dmp[row + (b < R2 ? b : R2 - 1)];
+                dm[c] = (ok && c < nvalid) ? v : 0.0;
+            }
+        };
+        double clev[LQ + 2];
+#pragma unroll
+        for (int p = 0; p < LQ + 2; ++p) clev[p] = (have && p >= 1 && p <= M) ? A.G[p * A.gm + i * A.gi + j * A.gj] : 0.0;
+        WaveFwd<C, LQ> fw;
+        fw.reset();
+        double dcur[C];
+        load_dm(0 - lam, dcur);
+        for (int t = 0; t < TF; ++t) {
+            double cin[LQ + 2], dnext[C];
+            cin[0] = 0.0;
+#pragma unroll
+            for (int m = 1; m < LQ + 2; ++m) cin[m] = wave_from_left<G>(fw.sout[m]);
+            const int a = t - lam;
+            load_dm(a + 1, dnext);
+            if (a >= 0 && a < R1) {
+                fw.step(dcur, cin, M);
+                if (lam == last_lane) {
+#pragma unroll
+                    for (int m = 1; m <= LQ; ++m) rt[a * LQ + m - 1] = m < M ? fw.sout[m] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) dcur[c] = dnext[c];
+        }
+        __syncthreads();
+        WaveUndo<C, LQ> bw;
+        bw.init(fw);
+        double* const lamrow = A.lam + size_t(have ? pp : 0) * R1 * R2 + C * lam;
+        load_dm(R1 - 1 + (G - 1 - lam), dcur);
+        for (int u = 0; u < TF; ++u) {
+            double sufin[LQ], svin[LQ], dnext[C];
+#pragma unroll
+            for (int p = 0; p < LQ; ++p) {
+                sufin[p] = wave_from_right<G>(bw.sufout[p]);
+                svin[p] = wave_from_right<G>(bw.svout[p]);
+            }
+            const int a = R1 - 1 - (u - (G - 1 - lam));
+            load_dm(a - 1, dnext);
+            if (a >= 0 && a < R1) {
+                double rtv[LQ], lv[C];
+#pragma unroll
+                for (int p = 0; p < LQ; ++p) rtv[p] = rt[a * LQ + p];
+                bw.step(dcur, clev, rtv, sufin, svin, M, a == 0, lam == 0, lv);
+                if (have) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (c < nvalid) lamrow[size_t(a) * R2 + c] = lv[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) dcur[c] = dnext[c];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace gpsig

@@ -25,6 +25,7 @@ bool ho_sweeps_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, H
 int ho_sweeps_launch(gpsig_ctx* c, const HoSweeps& hs, int M, int R1, int R2, const double* dM, double* lam, const double* G, int64_t gm, int64_t gi,
                      int64_t gj, int64_t N2, bool diag, int64_t pair0, int64_t npairs);
 bool ho_levels_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, HoSweeps* hs);
+bool o1_sweeps_plan(const gpsig_ctx* c, const gpsig_params* p, int R1, int R2, HoSweeps* hs);
 int ho_levels_launch(gpsig_ctx* c, const HoSweeps& hs, int M, int R1, int R2, const double* dM, double* out, int64_t gm, int64_t gi, int64_t gj, int64_t N2,
                      bool diag, int64_t pair0, int64_t npairs);
 
@@ -419,7 +420,12 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     HoSweeps hs;
     if (ho && !ho_sweeps_plan(c, p, L1 - (p->difference ? 1 : 0), L2 - (p->difference ? 1 : 0), &hs))
         return fail(c, GPSIG_ERR_UNSUPPORTED, "no higher-order sweeps for this shape");
-    CHK(lat_plan(c, p, d, Xs, Ys, N1, N2, L1, L2, diag, ho ? 3 : 2, &pl));
+    // first order, MANY SHORT lattices (a Gram of sequences of at most 65 observations): four lattices per wavefront from a dM lattice (seq_grad_wave_o1_kernel) instead of
+    // one per 64-lane wavefront; few lattices (a minibatch's level diagonals) stay with the lattice kernels below.  Option wide_o1_sweeps: 0 never, 1 (default) from 1,024 lattices, 2 wherever the shape fits (tests)
+    bool short_lat = false;
+    if (!ho && c->wide_o1_sweeps != 0 && ((diag ? N1 : N1 * N2) >= 1024 || c->wide_o1_sweeps == 2))
+        short_lat = o1_sweeps_plan(c, p, L1 - (p->difference ? 1 : 0), L2 - (p->difference ? 1 : 0), &hs);
+    CHK(lat_plan(c, p, d, Xs, Ys, N1, N2, L1, L2, diag, (ho || short_lat) ? 3 : 2, &pl));
     // the symmetric Gram (one array on both sides): the pairs i <= j with the upstream gradient folded onto them -- half the lattices
     const bool fold = !diag && Ys == nullptr && N1 == N2 && L1 == L2 && c->wide_sym_fold != 0;
     if (fold) {
@@ -436,22 +442,22 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
     const int M = p->num_levels, DA = pl.DA;
     const int64_t per_i = int64_t(L1) * L2 * (diag ? 1 : N2);
     void *arg, *lam, *gxl, *gxr, *scr, *dmat = nullptr;
-    if (ho) CHK(ensure(c, B_WD6, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &dmat));
+    if (ho || short_lat) CHK(ensure(c, B_WD6, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &dmat));
     CHK(ensure(c, B_WD2, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &arg));
     CHK(ensure(c, B_WD3, sizeof(double) * size_t(pl.chunk_i) * per_i + 64, &lam));
     CHK(ensure(c, B_WD4, sizeof(double) * size_t(N1) * L1 * DA + 64, &gxl));
     CHK(ensure(c, B_WD5, sizeof(double) * size_t(N2) * L2 * DA + 64, &gxr));
     const int64_t Pmax = diag ? pl.chunk_i : pl.chunk_i * N2;
-    const int NW = ho ? 1 : lat_waves(c, pl.C, Pmax);
+    const int NW = (ho || short_lat) ? 1 : lat_waves(c, pl.C, Pmax);
     const int TF = pl.R1 + 64 * NW - 1;
     const size_t per_group = sizeof(double) * size_t(M > 1 ? M - 1 : 1) * TF * 64 * (NW > 1 ? NW : pl.C);
     int64_t groups = int64_t(wide_chunk_bytes(c) / per_group);
     if (groups < 1) groups = 1;
     if (groups > Pmax) groups = Pmax;
     if (groups > 4096) groups = 4096;
-    if (ho) groups = 1;                   // (the higher-order sweeps bring their own slots, if any)
+    if (ho || short_lat) groups = 1;      // (these sweeps bring their own slots, if any)
     CHK(ensure(c, B_WD7, per_group * size_t(groups) + 64, &scr));
-    WideLatKernel fn = ho ? nullptr : lat_kernel(M, pl.C, true, p->base_kernel == GPSIG_BASE_RBF, NW);
+    WideLatKernel fn = (ho || short_lat) ? nullptr : lat_kernel(M, pl.C, true, p->base_kernel == GPSIG_BASE_RBF, NW);
     for (int64_t i0 = 0; i0 < N1; i0 += pl.chunk_i) {
         const int64_t ni = N1 - i0 < pl.chunk_i ? N1 - i0 : pl.chunk_i;
         const int64_t j0 = fold ? i0 : 0, N2e = N2 - j0;              // right sequences of this chunk
@@ -467,7 +473,7 @@ int wide_lat_backward(gpsig_ctx* c, const gpsig_params* p, int d, const double* 
         A.scratch = static_cast<double*>(scr); A.lam = static_cast<double*>(lam);
         const int64_t ng = A.P < groups ? A.P : groups;
         A.ngroups = int(ng);
-        if (ho && pl.R1 > 0 && pl.R2 > 0) {
+        if ((ho || short_lat) && pl.R1 > 0 && pl.R2 > 0) {
             if (p->base_kernel == GPSIG_BASE_RBF)
                 hipLaunchKernelGGL(wide_lattice_dm_kernel<true>, dim3(grid_for(A.P * int64_t(pl.R1) * pl.R2)), dim3(256), 0, c->stream, A, static_cast<double*>(dmat));
             else

@@ -240,10 +240,13 @@ def test_wide_sequence_lattices_and_gradient(M, N1, N2, L1, L2, d, kind, base):
             # (waves: wavefronts per lattice -- -1 the planner's choice: the lattice's columns over several wavefronts of one column per lane where a
             # launch holds few long lattices; 0: one wavefront per lattice with 1 / 2 / 4 / 8 columns per lane; 1: 2 / 4 / 8 wavefronts instead wherever possible)
             # fold: the symmetric Gram's reverse pass over the pairs i <= j with the upstream gradient folded onto them (1, the default) or over all ordered pairs
-            for mb, waves, fold in ((0, -1, 1), (1, -1, 1), (0, 0, 1), (0, 1, 1)) + (((0, -1, 0),) if kind == "sym" else ()):
+            # o1: lattices of at most 64 columns four to a wavefront from a dM lattice (seq_grad_wave_o1_kernel: 2 = wherever the shape fits; the planner takes it from
+            # 1,024 lattices), 0 = the lattice kernels
+            for mb, waves, fold, o1 in ((0, -1, 1, 1), (1, -1, 1, 2), (0, 0, 1, 0), (0, 1, 1, 1), (0, -1, 1, 2)) + (((0, -1, 0, 2), (0, -1, 0, 0)) if kind == "sym" else ()):
                 ctx.set_option("wide_chunk_mb", mb)
                 ctx.set_option("wide_lat_waves", waves)
                 ctx.set_option("wide_sym_fold", fold)
+                ctx.set_option("wide_o1_sweeps", o1)
                 out = np.full(G.shape, np.nan)
                 gX, gY, gb = np.full_like(X, np.nan), (None if Y is None else np.full_like(Y, np.nan)), np.zeros(2)
                 if kind == "diag":
@@ -256,15 +259,16 @@ def test_wide_sequence_lattices_and_gradient(M, N1, N2, L1, L2, d, kind, base):
                 # (matern12: a sequence against itself has coinciding points -- the float64 oracle's kappa there is exp(-sqrt(rounding noise)), 1e-8 from
                 # one, its derivative whatever the noise makes of 1 / r; the product takes such distances as zero: DESIGN section 5)
                 tv, tg = (1e-6, 1e-5) if (base == "matern12" and kind != "cross") else (1e-9, 1e-8)
-                assert rel(out, want) < tv, (difference, mb, waves, rel(out, want))
-                assert rel(gX, tX.grad) < tg, (difference, mb, waves, rel(gX, tX.grad))
+                assert rel(out, want) < tv, (difference, mb, waves, o1, rel(out, want))
+                assert rel(gX, tX.grad) < tg, (difference, mb, waves, o1, rel(gX, tX.grad))
                 if Y is not None:
-                    assert rel(gY, tY.grad) < 1e-8, (difference, mb, waves, rel(gY, tY.grad))
+                    assert rel(gY, tY.grad) < 1e-8, (difference, mb, waves, o1, rel(gY, tY.grad))
     finally:
         ctx.set_option("wide", -1)
         ctx.set_option("wide_chunk_mb", 0)
         ctx.set_option("wide_lat_waves", -1)
         ctx.set_option("wide_sym_fold", 1)
+        ctx.set_option("wide_o1_sweeps", 1)
 
 
 def test_wide_route_is_what_the_reference_shapes_take():
