@@ -172,6 +172,9 @@ int gpsig_set_shard(gpsig_ctx* ctx, int index, int count);
  *   "wide_few_cols"  widest state space (default 8) at which the tensor-vs-sequence FORWARD pass of at most 256 sequences against tensors with increments
  *                 takes the wide chains (SignatureRBF; the reverse tile kernel continues from their totals); "ho_g32": -1 (default) the higher-order
  *                 sweeps of 33 .. 64 lattice columns with two columns per lane at order >= 3, four otherwise; 0 always four; 1 always two
+ *   "wide_o1_sweeps"  first-order reverse pass of sequence lattices of at most 64 columns on the wide route: 1 (default) four lattices per wavefront from a dM
+ *                 lattice (seq_grad_wave_o1_kernel) for launches of 1,024 lattices or more, 2 wherever the shape fits, 0 the lattice kernels (one per wavefront)
+ *   "tvs_grad_matern" 1 (default): the Matern families in the tensor-vs-sequence reverse tile kernel as a compile-time kind; 0: the run-time family (A/B runs)
  *   order > 1 and "grad_impl": the sequence recursion's reverse pass runs as two sweeps of a wavefront per pair (csrc/grad_wave_ho_kernel.hpp;
  *                 <= 5 levels, min(order, levels) <= 4, lattices of <= 512 columns): 0 scratch-free where the row totals fit LDS, 3 with
  *                 the prefixes in an HBM slot per pair group, any other value the lattice operations of rounds 2-5 (tests' A/B reference) */
